@@ -1,0 +1,212 @@
+/* tbk.h — C ABI of the MI355X (gfx950) tiebrush/tiecov hot path.
+ *
+ * This is the drop-in boundary: a host program that has decoded
+ * BAM records into a structure-of-arrays tile calls these entry points in place
+ * of the reference's per-record loops.  Plain C structs of pointers + counts, no
+ * C++/torch types.  Every buffer is owned by the caller; pointers are either
+ * host pointers (TBK_MEM_HOST: staged through the context's pinned buffers) or
+ * device pointers (TBK_MEM_DEVICE: used in place, resident in HBM).
+ *
+ * Reference interfaces each entry point replaces (all under /root/reference/src):
+ *   tbk_collapse_tile  <-  the main loop of tiebrush:  TInputFiles::next()
+ *                          (tmerge.cpp:331-344, order tmerge.h:28-50),
+ *                          passes_options (tiebrush.cpp:532-541), addPData
+ *                          (:477-499), SPData::settle/dupAdd (:378-436),
+ *                          flushPData incl. the GSegList YD machine (:501-530,
+ *                          :111-250), GSamRecord::setupCoordinates
+ *                          (GSam.cpp:351-417).
+ *   tbk_coverage_tile  <-  the main loop of tiecov: bundle logic
+ *                          (tiecov.cpp:443-481), addCov (:194-223),
+ *                          flushCoverage (:226-241), addJunction/flushJuncs
+ *                          (:100-120).
+ *   tbk_sample_tile    <-  tiecov -s: addMean (:155-185), discretize/normalize/
+ *                          flushCoverage(pair) (:277-323).
+ *
+ * Return value: 0 on success, negative tbk_status otherwise.  Never throws,
+ * never exits.  A context is not thread-safe; use one per host thread.
+ */
+#ifndef TBK_H_
+#define TBK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TBK_ABI_VERSION 1
+
+typedef struct tbk_ctx tbk_ctx;
+
+typedef enum tbk_status {
+  TBK_OK = 0,
+  TBK_EINVAL = -1,       /* bad argument / inconsistent sizes                        */
+  TBK_ENOMEM = -2,       /* device or pinned allocation failed                       */
+  TBK_EHIP = -3,         /* a HIP runtime call or kernel failed (see tbk_last_error) */
+  TBK_E2BIG = -4,        /* output capacity too small; required sizes are reported   */
+  TBK_EUNSUPPORTED = -5, /* option outside the pinned semantics (-F, -M)             */
+  TBK_EUNSORTED = -6,    /* an input file is not (tid,pos)-sorted                    */
+  TBK_EFATALOP = -7,     /* tiecov: CIGAR op other than M/I/D/N/S (tiecov.cpp:219)   */
+  TBK_ECOLLISION = -8,   /* internal: key-hash collision survived all reseeds        */
+  TBK_ENODEVICE = -9     /* no gfx950 device / device ordinal out of range           */
+} tbk_status;
+
+/* tiebrush.cpp:82-87 (values differ from the reference enum on purpose: ABI-stable) */
+typedef enum tbk_strategy {
+  TBK_STRAT_CIGAR = 0, /* default: same CIGAR                       (cmpCigar     :304-310) */
+  TBK_STRAT_FULL = 1,  /* -L: same CIGAR and MD                     (cmpFull      :285-302) */
+  TBK_STRAT_CLIP = 2,  /* -P: same CIGAR after soft-clip stripping  (cmpCigarClip :312-332) */
+  TBK_STRAT_EXON = 3   /* -E: same exon coordinates                 (cmpExons     :334-345) */
+} tbk_strategy;
+
+typedef enum tbk_mem { TBK_MEM_HOST = 0, TBK_MEM_DEVICE = 1 } tbk_mem;
+
+#define TBK_NH_ABSENT INT32_MIN /* record has no NH tag */
+
+/* Options of the collapse path = struct Options (tiebrush.cpp:89-98) + mrgStrategy. */
+typedef struct tbk_collapse_opts {
+  int32_t strategy;           /* tbk_strategy                                         */
+  int32_t max_nh;             /* -N, default INT32_MAX                                */
+  int32_t min_qual;           /* -Q, default -1                                       */
+  uint32_t flags_mask;        /* -F, must be 0 (semantics unpinned)   */
+  uint8_t keep_supplementary; /* -S                                                   */
+  uint8_t keep_secondary;     /* --keep-secondary                                     */
+  uint8_t keep_unmapped;      /* -M, must be 0                     */
+  uint8_t collapse_same;      /* -A: needs qname_hash                                 */
+  uint8_t store_frac;         /* --store-frac: YC += 1/NH                             */
+  uint8_t reserved[3];
+} tbk_collapse_opts;
+
+/* One tile of decoded records, file-major: records of input file f occupy
+ * [file_off[f], file_off[f+1]) in file order.  file_off and tbmerged are always
+ * HOST arrays (tiny); every other pointer lives in `mem`. */
+typedef struct tbk_soa_in {
+  int32_t mem;              /* tbk_mem                                               */
+  uint32_t n_files;
+  uint32_t n_records;
+  uint32_t n_cigar_ops;     /* == cig_off[n_records]                                 */
+  const uint32_t* file_off; /* HOST [n_files+1]                                      */
+  const uint8_t* tbmerged;  /* HOST [n_files] 1 = written by TieBrush (tmerge.cpp:70-77) */
+  const int32_t* tid;       /* refID                                                 */
+  const int32_t* pos;       /* 0-based leftmost position (bam core.pos)              */
+  const uint16_t* flag;
+  const uint8_t* mapq;
+  const uint8_t* strand;    /* '+','-','.' = GSamRecord::spliceStrand (GSam.cpp:464-475) */
+  const int32_t* nh;        /* NH value or TBK_NH_ABSENT                             */
+  const uint32_t* cig_off;  /* [n_records+1] CSR offsets into cig                    */
+  const uint32_t* cig;      /* [n_cigar_ops] BAM encoding len<<4|op                  */
+  /* only read for records of tbmerged files; may be NULL when no file is tbmerged */
+  const double* yc_in;      /* tag_float("YC"), 0.0 if absent                        */
+  const int64_t* yx_in;     /* tag_int("YX",1)                                       */
+  const int64_t* yd_in;     /* tag_int("YD",0)                                       */
+  /* only for TBK_STRAT_FULL: MD:Z payload without NUL; md_off[i]==md_off[i+1] and md_has[i]==0 when absent */
+  const uint32_t* md_off;   /* [n_records+1]                                         */
+  const uint8_t* md;
+  const uint8_t* md_has;    /* [n_records]                                           */
+  /* only for collapse_same (-A): 64-bit hash of (qname bytes, pairOrder) */
+  const uint64_t* qname_hash;
+} tbk_soa_in;
+
+/* Collapsed groups in the order the reference writes them (flushPData order). */
+typedef struct tbk_groups_out {
+  int32_t mem;           /* tbk_mem of the arrays below                               */
+  uint32_t cap_groups;   /* capacity of each array                                    */
+  uint32_t* rep;         /* index (into the tile) of the representative record        */
+  double* yc;            /* accYC (double); the YC tag is (float)yc                   */
+  int64_t* yx;           /* accYX + popcount(samples)                                 */
+  int32_t* yd;           /* final YD (0 = tag removed)                                */
+  int32_t* g_start;      /* optional (may be NULL): 1-based start of the group        */
+  int32_t* g_end;        /* optional: 1-based end                                     */
+  int32_t* rec_group;    /* optional [n_records]: output index of each record's group, -1 = filtered */
+  uint32_t n_groups;     /* written by the callee = outCounter (tiebrush.cpp:528)     */
+  uint32_t n_passed;     /* written by the callee = inCounter  (tiebrush.cpp:573)     */
+} tbk_groups_out;
+
+/* Input of the coverage path: records of ONE collapsed (or plain) BAM in file order. */
+typedef struct tbk_cov_in {
+  int32_t mem;
+  uint32_t n_records;
+  uint32_t n_cigar_ops;
+  const int32_t* tid;
+  const int32_t* pos;
+  const uint16_t* flag;
+  const uint32_t* cig_off;
+  const uint32_t* cig;
+  const double* yc;        /* YC tag as double, 1.0 when absent (tiecov.cpp:482-485)  */
+  const uint8_t* strand;   /* spliceStrand; only read when junctions are requested    */
+  const int64_t* yx;       /* tag_int("YX",1); only read by tbk_sample_tile           */
+} tbk_cov_in;
+
+typedef struct tbk_cov_out {
+  int32_t mem;
+  uint32_t cap_intervals;  /* 0 = coverage not requested                              */
+  int32_t* iv_tid;         /* bedgraph rows: tid, 0-based start, end (exclusive), value */
+  int32_t* iv_start;
+  int32_t* iv_end;
+  double* iv_val;
+  uint32_t cap_junctions;  /* 0 = junctions not requested                             */
+  int32_t* j_tid;          /* junction rows in flushJuncs order; row i is JUNC%08d i+1 */
+  int32_t* j_start;        /* already start-1 (BED)                                   */
+  int32_t* j_end;
+  uint8_t* j_strand;
+  double* j_val;
+  uint32_t n_intervals;    /* written by the callee                                   */
+  uint32_t n_junctions;    /* written by the callee                                   */
+  uint64_t n_bases;        /* written by the callee: sum of M-op lengths of mapped records */
+  uint64_t span_bases;     /* written by the callee: sum of bundle spans              */
+} tbk_cov_out;
+
+typedef struct tbk_sample_out {
+  int32_t mem;
+  uint32_t cap_intervals;
+  int32_t* iv_tid;
+  int32_t* iv_start;
+  int32_t* iv_end;
+  int64_t* iv_count;       /* ceil(running mean of YX)                                */
+  float* iv_heat;          /* normalised to [0.1,1.5] by num_samples (tiecov.cpp:316-323) */
+  uint32_t n_intervals;
+} tbk_sample_out;
+
+/* Per-kernel timing of the most recent call (HIP events on the context's stream;
+ * only recorded when profiling was enabled with tbk_set_profiling). */
+typedef struct tbk_kernel_time {
+  const char* name; /* static string */
+  float ms;         /* summed over launches of that kernel in the call */
+  uint32_t launches;
+} tbk_kernel_time;
+
+/* ---- lifetime ---------------------------------------------------------------- */
+int tbk_abi_version(void);
+int tbk_create(int device_ordinal, tbk_ctx** out);
+void tbk_destroy(tbk_ctx* ctx);
+const char* tbk_strerror(int status);
+const char* tbk_last_error(const tbk_ctx* ctx); /* detail of the last TBK_EHIP etc. */
+
+/* Use an external HIP stream (e.g. torch's current stream) instead of the
+ * context's own; NULL restores the internal one. */
+int tbk_set_stream(tbk_ctx* ctx, void* hip_stream);
+void* tbk_get_stream(tbk_ctx* ctx);
+int tbk_set_profiling(tbk_ctx* ctx, int enabled);
+int tbk_kernel_times(tbk_ctx* ctx, tbk_kernel_time* out, int cap); /* returns count */
+
+/* Pinned host memory helpers for TBK_MEM_HOST callers. */
+int tbk_host_alloc(size_t bytes, void** out);
+void tbk_host_free(void* p);
+
+/* ---- hot path ---------------------------------------------------------------- */
+void tbk_collapse_opts_default(tbk_collapse_opts* o);
+int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa_in* in, tbk_groups_out* out);
+int tbk_coverage_tile(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out);
+int tbk_sample_tile(tbk_ctx* ctx, const tbk_cov_in* in, int32_t num_samples, tbk_sample_out* out);
+
+/* Device-side chaining tiebrush -> tiecov without a host round trip: builds the
+ * tbk_cov_in view of the collapsed records (representatives in output order, yc =
+ * (double)(float)accYC exactly as the YC:f tag round-trips) in context-owned
+ * device memory.  The returned view is valid until the next call on `ctx`. */
+int tbk_groups_to_cov_in(tbk_ctx* ctx, const tbk_soa_in* in, const tbk_groups_out* groups, tbk_cov_in* view);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TBK_H_ */

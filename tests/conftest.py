@@ -1,0 +1,35 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+_CACHE = {}
+
+
+def load_bam_cached(path, **kw):
+    from tiebrush_amd import bamio
+    key = (path, tuple(sorted(kw.items())))
+    if key not in _CACHE:
+        _CACHE[key] = bamio.read_bam(path, **kw)
+    return _CACHE[key]
+
+
+@pytest.fixture(scope="session")
+def bam_loader():
+    return load_bam_cached

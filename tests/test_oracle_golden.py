@@ -1,0 +1,78 @@
+"""Pins the CPU oracle (oracle/tb_oracle.c) against every golden fixture the reference's own
+test script holds (run_tests.sh:29-46), through the normaliser of SURVEY.md §4.4:
+goldens were written by tiebrush 0.0.6 (integer YC/YX omitted when 1, same-name
+duplicates always skipped == HEAD with -A, integer bedgraph values)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle_ffi as orc
+from tiebrush_amd import soa
+from helpers import GOLDEN, sample_paths, compare_groups_to_golden_bam, bedgraph_lines, junction_lines, read_lines
+
+# the exact records where HEAD's default (-A off) differs from the goldens by YC+1
+HEAD_DELTAS = {"t1": [1930, 2210], "t2": [2233, 4901, 5655, 8154]}
+
+
+@pytest.mark.parametrize("name,n_in,n_out", [("t1", 416922, 3479), ("t2", 242910, 8179)])
+def test_collapse_samples_to_tissue(name, n_in, n_out, bam_loader):
+    bams = [bam_loader(p) for p in sample_paths(name)]
+    tile = soa.tile_from_bams(bams, with_names=True)
+    gold = bam_loader(os.path.join(GOLDEN, name, name + ".bam"))
+    res = orc.collapse(tile, collapse_same=True)
+    assert res["n_passed"] == n_in and res["n_groups"] == n_out
+    assert compare_groups_to_golden_bam(res, tile, bams, gold) == []
+    head = orc.collapse(tile, collapse_same=False)
+    d = np.nonzero(head["yc"] != res["yc"])[0].tolist()
+    assert d == HEAD_DELTAS[name]
+    assert np.all((head["yc"] - res["yc"])[d] == 1.0)
+    assert np.array_equal(head["rep"], res["rep"]) and np.array_equal(head["yd"], res["yd"])
+
+
+def test_recollapse_tbmerged_t12(bam_loader):
+    bams = [bam_loader(os.path.join(GOLDEN, "t1", "t1.bam")), bam_loader(os.path.join(GOLDEN, "t2", "t2.bam"))]
+    tile = soa.tile_from_bams(bams, with_names=True)
+    assert tile.tbmerged.tolist() == [1, 1]
+    gold = bam_loader(os.path.join(GOLDEN, "t12.bam"))
+    res = orc.collapse(tile, collapse_same=True)
+    assert res["n_passed"] == 11658 and res["n_groups"] == 9491
+    assert compare_groups_to_golden_bam(res, tile, bams, gold) == []
+
+
+@pytest.mark.parametrize("name,n_iv,n_j,n_s", [("t1", 3671, 12, 82), ("t2", 8332, 18, 54)])
+def test_tiecov_outputs(name, n_iv, n_j, n_s, bam_loader):
+    b = bam_loader(os.path.join(GOLDEN, name, name + ".bam"))
+    ci = soa.cov_input_from_bam(b)
+    ns = len(b.header.co_samples())
+    assert ns == 10
+    c = orc.coverage(ci, num_samples=ns)
+    assert (c["n_intervals"], c["n_junctions"], c["n_sample"]) == (n_iv, n_j, n_s)
+    names = b.header.ref_names
+    assert np.all(c["iv_val"] == np.floor(c["iv_val"]))
+    assert bedgraph_lines(c, names) == read_lines(os.path.join(GOLDEN, name, name + ".coverage.bedgraph"))
+    assert junction_lines(c, names) == read_lines(os.path.join(GOLDEN, name, name + ".junctions.bed"))
+    g = read_lines(os.path.join(GOLDEN, name, name + ".sample.bedgraph"))[1:]
+    ours = ["%s\t%d\t%d\t%d" % (names[c["s_tid"][i]], c["s_start"][i], c["s_end"][i], c["s_count"][i])
+            for i in range(c["n_sample"])]
+    assert ours == ["\t".join(x.split("\t")[:4]) for x in g]
+    # column 5 of the goldens is "inf" (0.0.6 found no samples); HEAD value is pinned by restatement only
+    assert abs(float(c["s_heat"][0]) - (1.0 / 10 * 1.4 + 0.1)) < 1e-6
+
+
+def test_setup_coordinates_cases():
+    M, I, D, N, S = 0, 1, 2, 3, 4
+
+    def cg(*ops):
+        return [(l << 4) | o for l, o in ops]
+
+    assert orc.setup_coordinates(0, 99, cg((100, M)))[:2] == (100, 199)
+    s, e, ex = orc.setup_coordinates(0, 99, cg((5, S), (40, M), (100, N), (60, M), (3, S)))
+    assert (s, e) == (100, 299) and ex.tolist() == [[100, 139], [240, 299]]
+    # N I N: the insertion-only pseudo exon is skipped and the introns fuse (GSam.cpp:378)
+    s, e, ex = orc.setup_coordinates(0, 0, cg((10, M), (20, N), (2, I), (30, N), (10, M)))
+    assert (s, e) == (1, 70) and ex.tolist() == [[1, 10], [61, 70]]
+    # D counts as exonic
+    s, e, ex = orc.setup_coordinates(0, 0, cg((10, M), (2, D), (10, M)))
+    assert (s, e) == (1, 22) and ex.tolist() == [[1, 22]]
+    assert orc.setup_coordinates(4, 50, cg((10, M)))[:2] == (0, 0)
