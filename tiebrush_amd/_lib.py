@@ -1,0 +1,109 @@
+"""ctypes binding of the C ABI in include/tbk.h (libtbk.so, hand-written HIP for gfx950).
+
+There is deliberately no fallback: if the shared library is missing or fails to load the
+import raises, so a GPU box can never silently run something else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "libtbk.so")
+
+_P = C.c_void_p
+
+TBK_MEM_HOST, TBK_MEM_DEVICE = 0, 1
+STRAT = {"cigar": 0, "full": 1, "clip": 2, "exon": 3}
+STATUS = {0: "TBK_OK", -1: "TBK_EINVAL", -2: "TBK_ENOMEM", -3: "TBK_EHIP", -4: "TBK_E2BIG", -5: "TBK_EUNSUPPORTED",
+          -6: "TBK_EUNSORTED", -7: "TBK_EFATALOP", -8: "TBK_ECOLLISION", -9: "TBK_ENODEVICE"}
+
+# every symbol include/tbk.h declares
+SYMBOLS = ["tbk_abi_version", "tbk_create", "tbk_destroy", "tbk_strerror", "tbk_last_error", "tbk_set_stream",
+           "tbk_get_stream", "tbk_set_profiling", "tbk_kernel_times", "tbk_host_alloc", "tbk_host_free",
+           "tbk_collapse_opts_default", "tbk_collapse_tile", "tbk_coverage_tile", "tbk_sample_tile",
+           "tbk_groups_to_cov_in"]
+
+
+class CollapseOpts(C.Structure):
+    _fields_ = [("strategy", C.c_int32), ("max_nh", C.c_int32), ("min_qual", C.c_int32), ("flags_mask", C.c_uint32),
+                ("keep_supplementary", C.c_uint8), ("keep_secondary", C.c_uint8), ("keep_unmapped", C.c_uint8),
+                ("collapse_same", C.c_uint8), ("store_frac", C.c_uint8), ("reserved", C.c_uint8 * 3)]
+
+
+class SoaIn(C.Structure):
+    _fields_ = [("mem", C.c_int32), ("n_files", C.c_uint32), ("n_records", C.c_uint32), ("n_cigar_ops", C.c_uint32),
+                ("file_off", _P), ("tbmerged", _P), ("tid", _P), ("pos", _P), ("flag", _P), ("mapq", _P),
+                ("strand", _P), ("nh", _P), ("cig_off", _P), ("cig", _P), ("yc_in", _P), ("yx_in", _P), ("yd_in", _P),
+                ("md_off", _P), ("md", _P), ("md_has", _P), ("qname_hash", _P)]
+
+
+class GroupsOut(C.Structure):
+    _fields_ = [("mem", C.c_int32), ("cap_groups", C.c_uint32), ("rep", _P), ("yc", _P), ("yx", _P), ("yd", _P),
+                ("g_start", _P), ("g_end", _P), ("rec_group", _P), ("n_groups", C.c_uint32), ("n_passed", C.c_uint32)]
+
+
+class CovIn(C.Structure):
+    _fields_ = [("mem", C.c_int32), ("n_records", C.c_uint32), ("n_cigar_ops", C.c_uint32), ("tid", _P), ("pos", _P),
+                ("flag", _P), ("cig_off", _P), ("cig", _P), ("yc", _P), ("strand", _P), ("yx", _P)]
+
+
+class CovOut(C.Structure):
+    _fields_ = [("mem", C.c_int32), ("cap_intervals", C.c_uint32), ("iv_tid", _P), ("iv_start", _P), ("iv_end", _P),
+                ("iv_val", _P), ("cap_junctions", C.c_uint32), ("j_tid", _P), ("j_start", _P), ("j_end", _P),
+                ("j_strand", _P), ("j_val", _P), ("n_intervals", C.c_uint32), ("n_junctions", C.c_uint32),
+                ("n_bases", C.c_uint64), ("span_bases", C.c_uint64)]
+
+
+class SampleOut(C.Structure):
+    _fields_ = [("mem", C.c_int32), ("cap_intervals", C.c_uint32), ("iv_tid", _P), ("iv_start", _P), ("iv_end", _P),
+                ("iv_count", _P), ("iv_heat", _P), ("n_intervals", C.c_uint32)]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("ms", C.c_float), ("launches", C.c_uint32)]
+
+
+_lib = None
+
+
+def load():
+    """Load libtbk.so; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.tbk_abi_version.restype = C.c_int
+    L.tbk_create.argtypes = [C.c_int, C.POINTER(_P)]
+    L.tbk_create.restype = C.c_int
+    L.tbk_destroy.argtypes = [_P]
+    L.tbk_destroy.restype = None
+    L.tbk_strerror.argtypes = [C.c_int]
+    L.tbk_strerror.restype = C.c_char_p
+    L.tbk_last_error.argtypes = [_P]
+    L.tbk_last_error.restype = C.c_char_p
+    L.tbk_set_stream.argtypes = [_P, _P]
+    L.tbk_get_stream.argtypes = [_P]
+    L.tbk_get_stream.restype = _P
+    L.tbk_set_profiling.argtypes = [_P, C.c_int]
+    L.tbk_kernel_times.argtypes = [_P, C.POINTER(KernelTime), C.c_int]
+    L.tbk_host_alloc.argtypes = [C.c_size_t, C.POINTER(_P)]
+    L.tbk_host_free.argtypes = [_P]
+    L.tbk_host_free.restype = None
+    L.tbk_collapse_opts_default.argtypes = [C.POINTER(CollapseOpts)]
+    L.tbk_collapse_opts_default.restype = None
+    L.tbk_collapse_tile.argtypes = [_P, C.POINTER(CollapseOpts), C.POINTER(SoaIn), C.POINTER(GroupsOut)]
+    L.tbk_coverage_tile.argtypes = [_P, C.POINTER(CovIn), C.POINTER(CovOut)]
+    L.tbk_sample_tile.argtypes = [_P, C.POINTER(CovIn), C.c_int32, C.POINTER(SampleOut)]
+    L.tbk_groups_to_cov_in.argtypes = [_P, C.POINTER(SoaIn), C.POINTER(GroupsOut), C.POINTER(CovIn)]
+    _lib = L
+    return L
+
+
+class TbkError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        super().__init__("%s (%d) %s" % (STATUS.get(status, "?"), status, detail))

@@ -1,0 +1,305 @@
+"""Host-side Python mirror of the hot-path boundary (`include/tbk.h`).
+
+`Context.collapse` stands where the reference's tiebrush main loop stands
+(/root/reference/src/tiebrush.cpp:570-592: TInputFiles::next + passes_options + addPData +
+flushPData), `Context.coverage` where tiecov's loop stands (tiecov.cpp:435-513).  Arrays may be
+numpy (TBK_MEM_HOST: staged by the library) or torch CUDA tensors (TBK_MEM_DEVICE: used in
+place, resident in HBM).  torch is plumbing only: device memory + streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import replace
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import TbkError
+from .soa import CovInput, SoATile
+
+_NP2T = None
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _is_torch(a):
+    return a is not None and type(a).__module__.startswith("torch")
+
+
+def _addr(a, dtype, keep, n=None):
+    """Pointer of a numpy array / torch tensor after a dtype + contiguity check."""
+    if a is None:
+        return None
+    if _is_torch(a):
+        torch = _torch()
+        want = {np.int32: torch.int32, np.uint32: torch.int32, np.uint16: torch.int16, np.uint8: torch.uint8,
+                np.float64: torch.float64, np.int64: torch.int64, np.uint64: torch.int64, np.float32: torch.float32}[dtype]
+        # unsigned types travel as their signed twins of the same width (torch has no uint32 storage maths we need)
+        if a.dtype != want and a.element_size() != np.dtype(dtype).itemsize:
+            raise TypeError("tensor dtype %s does not match %s" % (a.dtype, dtype))
+        if not a.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+        if n is not None and a.numel() < n:
+            raise ValueError("tensor too small: %d < %d" % (a.numel(), n))
+        keep.append(a)
+        return a.data_ptr()
+    b = np.ascontiguousarray(a, dtype=dtype)
+    if n is not None and b.size < n:
+        raise ValueError("array too small: %d < %d" % (b.size, n))
+    keep.append(b)
+    return b.ctypes.data
+
+
+def to_device(obj, device="cuda:0"):
+    """Copy the per-record arrays of a SoATile / CovInput into HBM (torch tensors)."""
+    torch = _torch()
+
+    def mv(a, dt):
+        if a is None:
+            return None
+        b = np.ascontiguousarray(a, dtype=dt)
+        sd = {np.uint32: np.int32, np.uint16: np.int16, np.uint64: np.int64}.get(dt, dt)
+        return torch.from_numpy(b.view(sd)).to(device)
+
+    if isinstance(obj, SoATile):
+        r = replace(obj, tid=mv(obj.tid, np.int32), pos=mv(obj.pos, np.int32), flag=mv(obj.flag, np.uint16),
+                       mapq=mv(obj.mapq, np.uint8), strand=mv(obj.strand, np.uint8), nh=mv(obj.nh, np.int32),
+                       cig_off=mv(obj.cig_off, np.uint32), cig=mv(obj.cig, np.uint32), yc_in=mv(obj.yc_in, np.float64),
+                       yx_in=mv(obj.yx_in, np.int64), yd_in=mv(obj.yd_in, np.int64), md_off=mv(obj.md_off, np.uint32),
+                       md=mv(obj.md, np.uint8), md_has=mv(obj.md_has, np.uint8),
+                       qname_hash=mv(obj.qname_hash, np.uint64), qn_off=None, qn=None)
+        torch.cuda.synchronize()
+        return r
+    if isinstance(obj, CovInput):
+        r = replace(obj, tid=mv(obj.tid, np.int32), pos=mv(obj.pos, np.int32), flag=mv(obj.flag, np.uint16),
+                       cig_off=mv(obj.cig_off, np.uint32), cig=mv(obj.cig, np.uint32), yc=mv(obj.yc, np.float64),
+                       strand=mv(obj.strand, np.uint8), yx=mv(obj.yx, np.int64))
+        torch.cuda.synchronize()
+        return r
+    raise TypeError(type(obj))
+
+
+def _numel(a):
+    return int(a.numel()) if _is_torch(a) else int(np.asarray(a).size)
+
+
+class DeviceCovView:
+    """tbk_cov_in view living in context-owned device memory (valid until the next call)."""
+
+    def __init__(self, struct, n_records, n_cigar_ops):
+        self.struct = struct
+        self.n_records = n_records
+        self.n_cigar_ops = n_cigar_ops
+
+
+class Context:
+    def __init__(self, device: int = 0):
+        self.L = _lib.load()
+        h = C.c_void_p()
+        rc = self.L.tbk_create(int(device), C.byref(h))
+        if rc != 0:
+            raise TbkError(rc, "tbk_create(device=%d)" % device)
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.tbk_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- plumbing ---------------------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc != 0:
+            raise TbkError(rc, "%s: %s" % (what, (self.L.tbk_last_error(self.h) or b"").decode()))
+
+    def use_torch_stream(self):
+        """Launch on torch's current stream so that torch ops and our kernels order correctly."""
+        s = _torch().cuda.current_stream().cuda_stream
+        self._check(self.L.tbk_set_stream(self.h, C.c_void_p(s)), "tbk_set_stream")
+
+    def stream_ptr(self):
+        return self.L.tbk_get_stream(self.h)
+
+    def set_profiling(self, on: bool):
+        self._check(self.L.tbk_set_profiling(self.h, 1 if on else 0), "tbk_set_profiling")
+
+    def kernel_times(self):
+        arr = (_lib.KernelTime * 128)()
+        n = self.L.tbk_kernel_times(self.h, arr, 128)
+        return {arr[i].name.decode(): (float(arr[i].ms), int(arr[i].launches)) for i in range(min(n, 128))}
+
+    def _alloc(self, device_mode, n, dtype):
+        n = max(int(n), 1)
+        if device_mode:
+            torch = _torch()
+            td = {np.int32: torch.int32, np.uint32: torch.int32, np.uint8: torch.uint8, np.float64: torch.float64,
+                  np.int64: torch.int64, np.float32: torch.float32}[dtype]
+            return torch.empty(n, dtype=td, device="cuda:%d" % self.device)
+        return np.empty(n, dtype=dtype)
+
+    @staticmethod
+    def _trim(a, n, dtype):
+        if _is_torch(a):
+            return a[:n]
+        return a[:n].view(dtype) if a.dtype != dtype else a[:n]
+
+    # ---- collapse -----------------------------------------------------------------------------
+    def make_opts(self, strategy="cigar", max_nh=2**31 - 1, min_qual=-1, keep_supplementary=False,
+                  keep_secondary=False, keep_unmapped=False, collapse_same=False, store_frac=False, flags_mask=0):
+        o = _lib.CollapseOpts()
+        self.L.tbk_collapse_opts_default(C.byref(o))
+        o.strategy = _lib.STRAT[strategy] if isinstance(strategy, str) else int(strategy)
+        o.max_nh, o.min_qual, o.flags_mask = int(max_nh), int(min_qual), int(flags_mask)
+        o.keep_supplementary, o.keep_secondary = int(keep_supplementary), int(keep_secondary)
+        o.keep_unmapped, o.collapse_same, o.store_frac = int(keep_unmapped), int(collapse_same), int(store_frac)
+        return o
+
+    def _soa_struct(self, tile: SoATile, keep):
+        dev = _is_torch(tile.tid)
+        n = _numel(tile.tid)
+        nc = _numel(tile.cig)
+        fo = np.ascontiguousarray(tile.file_off, dtype=np.uint32)
+        tb = np.ascontiguousarray(tile.tbmerged, dtype=np.uint8)
+        keep += [fo, tb]
+        s = _lib.SoaIn(
+            _lib.TBK_MEM_DEVICE if dev else _lib.TBK_MEM_HOST, tile.n_files, n, nc, fo.ctypes.data, tb.ctypes.data,
+            _addr(tile.tid, np.int32, keep, n), _addr(tile.pos, np.int32, keep, n), _addr(tile.flag, np.uint16, keep, n),
+            _addr(tile.mapq, np.uint8, keep, n), _addr(tile.strand, np.uint8, keep, n), _addr(tile.nh, np.int32, keep, n),
+            _addr(tile.cig_off, np.uint32, keep, n + 1), _addr(tile.cig, np.uint32, keep, nc),
+            _addr(tile.yc_in, np.float64, keep, n), _addr(tile.yx_in, np.int64, keep, n),
+            _addr(tile.yd_in, np.int64, keep, n), _addr(tile.md_off, np.uint32, keep, n + 1),
+            _addr(tile.md, np.uint8, keep), _addr(tile.md_has, np.uint8, keep, n),
+            _addr(tile.qname_hash, np.uint64, keep, n))
+        return s, dev, n
+
+    def collapse(self, tile: SoATile, opts=None, want_coords=True, want_rec_group=False, out=None, raw=False, **kw):
+        """Collapse one tile.  Returns a dict (rep, yc, yx, yd[, g_start, g_end, rec_group], n_groups,
+        n_passed) in the reference's output order.  `out` may carry preallocated buffers to reuse."""
+        o = opts if opts is not None else self.make_opts(**kw)
+        keep = []
+        s, dev, n = self._soa_struct(tile, keep)
+        cap = max(n, 1)
+        bufs = out if out is not None else {}
+
+        def buf(name, count, dt, wanted=True):
+            if not wanted:
+                return None
+            if name not in bufs or _numel(bufs[name]) < count:
+                bufs[name] = self._alloc(dev, count, dt)
+            return bufs[name]
+
+        rep, yc = buf("rep", cap, np.uint32), buf("yc", cap, np.float64)
+        yx, yd = buf("yx", cap, np.int64), buf("yd", cap, np.int32)
+        gs, ge = buf("g_start", cap, np.int32, want_coords), buf("g_end", cap, np.int32, want_coords)
+        rg = buf("rec_group", cap, np.int32, want_rec_group)
+        g = _lib.GroupsOut(s.mem, cap, _addr(rep, np.uint32, keep), _addr(yc, np.float64, keep),
+                           _addr(yx, np.int64, keep), _addr(yd, np.int32, keep), _addr(gs, np.int32, keep),
+                           _addr(ge, np.int32, keep), _addr(rg, np.int32, keep), 0, 0)
+        self._check(self.L.tbk_collapse_tile(self.h, C.byref(o), C.byref(s), C.byref(g)), "tbk_collapse_tile")
+        m = int(g.n_groups)
+        res = dict(n_groups=m, n_passed=int(g.n_passed), _bufs=bufs, _struct=g, _soa=s, _keep=keep)
+        if raw:
+            return res
+        res.update(rep=self._trim(rep, m, np.uint32), yc=yc[:m], yx=yx[:m], yd=yd[:m])
+        if want_coords:
+            res.update(g_start=gs[:m], g_end=ge[:m])
+        if want_rec_group:
+            res["rec_group"] = rg[:n]
+        return res
+
+    def groups_to_cov_in(self, collapse_result) -> DeviceCovView:
+        """Device-side chain tiebrush -> tiecov (tbk_groups_to_cov_in)."""
+        v = _lib.CovIn()
+        self._check(self.L.tbk_groups_to_cov_in(self.h, C.byref(collapse_result["_soa"]),
+                                                C.byref(collapse_result["_struct"]), C.byref(v)),
+                    "tbk_groups_to_cov_in")
+        return DeviceCovView(v, int(v.n_records), int(v.n_cigar_ops))
+
+    # ---- coverage -----------------------------------------------------------------------------
+    def coverage(self, cin, want_cov=True, want_junc=True, cap_intervals=None, cap_junctions=None, out=None, raw=False):
+        keep = []
+        if isinstance(cin, DeviceCovView):
+            s = cin.struct
+            dev, n, nc = True, cin.n_records, cin.n_cigar_ops
+        else:
+            dev = _is_torch(cin.tid)
+            n = _numel(cin.tid)
+            nc = _numel(cin.cig)
+            s = _lib.CovIn(_lib.TBK_MEM_DEVICE if dev else _lib.TBK_MEM_HOST, n, nc, _addr(cin.tid, np.int32, keep, n),
+                           _addr(cin.pos, np.int32, keep, n), _addr(cin.flag, np.uint16, keep, n),
+                           _addr(cin.cig_off, np.uint32, keep, n + 1), _addr(cin.cig, np.uint32, keep, nc),
+                           _addr(cin.yc, np.float64, keep, n), _addr(cin.strand, np.uint8, keep, n), None)
+        ci = (cap_intervals if cap_intervals is not None else 2 * nc + 2 * n + 16) if want_cov else 0
+        cj = (cap_junctions if cap_junctions is not None else nc + 16) if want_junc else 0
+        bufs = out if out is not None else {}
+
+        def buf(name, count, dt):
+            if count == 0:
+                return None
+            if name not in bufs or _numel(bufs[name]) < count:
+                bufs[name] = self._alloc(dev, count, dt)
+            return bufs[name]
+
+        iv = [buf("iv_tid", ci, np.int32), buf("iv_start", ci, np.int32), buf("iv_end", ci, np.int32),
+              buf("iv_val", ci, np.float64)]
+        jv = [buf("j_tid", cj, np.int32), buf("j_start", cj, np.int32), buf("j_end", cj, np.int32),
+              buf("j_strand", cj, np.uint8), buf("j_val", cj, np.float64)]
+        o = _lib.CovOut(s.mem, ci, _addr(iv[0], np.int32, keep), _addr(iv[1], np.int32, keep),
+                        _addr(iv[2], np.int32, keep), _addr(iv[3], np.float64, keep), cj, _addr(jv[0], np.int32, keep),
+                        _addr(jv[1], np.int32, keep), _addr(jv[2], np.int32, keep), _addr(jv[3], np.uint8, keep),
+                        _addr(jv[4], np.float64, keep), 0, 0, 0, 0)
+        self._check(self.L.tbk_coverage_tile(self.h, C.byref(s), C.byref(o)), "tbk_coverage_tile")
+        a, b = int(o.n_intervals), int(o.n_junctions)
+        res = dict(n_intervals=a, n_junctions=b, n_bases=int(o.n_bases), span_bases=int(o.span_bases), _bufs=bufs)
+        if raw:
+            return res
+        if want_cov:
+            res.update(iv_tid=iv[0][:a], iv_start=iv[1][:a], iv_end=iv[2][:a], iv_val=iv[3][:a])
+        if want_junc:
+            res.update(j_tid=jv[0][:b], j_start=jv[1][:b], j_end=jv[2][:b], j_strand=jv[3][:b], j_val=jv[4][:b])
+        return res
+
+    def sample(self, cin: CovInput, num_samples: int, cap_intervals=None):
+        keep = []
+        dev = _is_torch(cin.tid)
+        n = _numel(cin.tid)
+        nc = _numel(cin.cig)
+        s = _lib.CovIn(_lib.TBK_MEM_DEVICE if dev else _lib.TBK_MEM_HOST, n, nc, _addr(cin.tid, np.int32, keep, n),
+                       _addr(cin.pos, np.int32, keep, n), _addr(cin.flag, np.uint16, keep, n),
+                       _addr(cin.cig_off, np.uint32, keep, n + 1), _addr(cin.cig, np.uint32, keep, nc), None, None,
+                       _addr(cin.yx, np.int64, keep, n))
+        if cap_intervals is None:
+            if dev:
+                raise ValueError("cap_intervals is required for device inputs")
+            c = np.asarray(cin.cig)
+            cap_intervals = int((c >> 4)[(c & 0xF) == 0].sum()) + 16
+        ci = cap_intervals
+        iv = [self._alloc(dev, ci, np.int32) for _ in range(3)] + [self._alloc(dev, ci, np.int64),
+                                                                    self._alloc(dev, ci, np.float32)]
+        o = _lib.SampleOut(s.mem, ci, _addr(iv[0], np.int32, keep), _addr(iv[1], np.int32, keep),
+                           _addr(iv[2], np.int32, keep), _addr(iv[3], np.int64, keep), _addr(iv[4], np.float32, keep), 0)
+        self._check(self.L.tbk_sample_tile(self.h, C.byref(s), int(num_samples), C.byref(o)), "tbk_sample_tile")
+        a = int(o.n_intervals)
+        return dict(n_sample=a, s_tid=iv[0][:a], s_start=iv[1][:a], s_end=iv[2][:a], s_count=iv[3][:a], s_heat=iv[4][:a])
+
+
+def to_numpy(d):
+    """Bring every tensor value of a result dict back to numpy (tests / writers)."""
+    out = {}
+    for k, v in d.items():
+        if k.startswith("_"):
+            continue
+        out[k] = v.cpu().numpy() if _is_torch(v) else v
+    if "rep" in out and out["rep"].dtype == np.int32:
+        out["rep"] = out["rep"].view(np.uint32)
+    return out

@@ -1,0 +1,748 @@
+// cov.hip — tiecov hot path on gfx950: bundle segmentation, CIGAR-walk per-base coverage with
+// LDS-binned atomics, run-length writeback, and splice-junction reduction.
+//
+// Reference semantics (paths relative to /root/reference/src):
+//   bundles         tiecov.cpp:443-481   new bundle iff tid changes or start > running max(end)
+//   addCov          tiecov.cpp:194-223   cov[base] += YC for every M base; D/N advance; I/S ignored;
+//                                        any other op is fatal (:219)
+//   flushCoverage   tiecov.cpp:226-241   RLE on exact equality, zero runs skipped, runs never
+//                                        cross a bundle
+//   addJunction     tiecov.cpp:100-112   per bundle sum of YC per (start,end,strand)
+//   flushJuncs      tiecov.cpp:114-120   sorted (start,end,strand char), numbered globally
+//
+// Data layout in HBM: bundles are laid end to end in a "compacted coordinate" space (cpos);
+// the space is cut into tiles of COV_W bases.  One workgroup owns one tile: it adds +yc/-yc
+// difference marks for every M segment into an LDS array (ds atomics), prefix-sums it in LDS
+// and emits only the change points — the per-base depth array never exists in HBM.
+// Segments that reach past the tile where their record starts are pre-binned ("spills") by a
+// counting sort over tiles.  Integer accumulation is exact in any order; non-integral YC
+// values are routed to the ordered double path (cov_tile_k<double>) which adds per base in
+// record order exactly as the reference does.
+#include "dev_common.cuh"
+#include "scan_op.cuh"
+#include "tbk_internal.h"
+
+namespace {
+
+constexpr int COV_W = 8192;  // bases per tile
+constexpr int COV_NT = 256;
+constexpr int COV_PER = COV_W / COV_NT;  // 32 bases per thread in the scan phase
+
+struct SegMax {
+  int32_t mx;
+  uint32_t flag;
+};
+struct SegMaxOp {
+  __device__ __forceinline__ SegMax operator()(const SegMax& a, const SegMax& b) const {
+    SegMax r;
+    r.mx = b.flag ? b.mx : (a.mx > b.mx ? a.mx : b.mx);
+    r.flag = a.flag | b.flag;
+    return r;
+  }
+};
+
+struct CovArrays {
+  // per compacted (mapped) record j
+  uint32_t* ridx;    // original record index
+  int32_t* start;    // 1-based
+  int32_t* end;      // 1-based inclusive
+  int32_t* tid;
+  uint32_t* bhead;   // bundle head flag
+  int32_t* inclmax;  // inclusive running max of end inside the tid run
+  uint32_t* bid;     // bundle id
+  uint64_t* cs;      // compacted start (0-based cpos)
+  // per bundle
+  int32_t* b_tid;
+  int32_t* b_start;
+  int32_t* b_end;
+  uint32_t* b_span;
+  uint64_t* b_off;
+};
+
+// ---- C0/C1 -------------------------------------------------------------------------------
+__global__ void cov_valid_k(const uint16_t* __restrict__ flag, uint32_t n, uint32_t* __restrict__ valid) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) valid[i] = (flag[i] & 0x4) ? 0u : 1u;
+}
+
+// scalars: [0]=n_bases [1]=sum|yc| [2]=n_introns
+__global__ void cov_prep_k(uint32_t n, const uint32_t* __restrict__ valid, const uint32_t* __restrict__ vpos,
+                           const int32_t* __restrict__ tid, const int32_t* __restrict__ pos,
+                           const uint32_t* __restrict__ cig_off, const uint32_t* __restrict__ cig,
+                           const double* __restrict__ yc, int check_ops, CovArrays A, uint32_t* __restrict__ jcnt,
+                           uint64_t* __restrict__ scalars, uint32_t* __restrict__ err) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t mb = 0, ay = 0;
+  uint32_t e = 0;
+  if (i < n && valid[i]) {
+    uint32_t j = vpos[i];
+    uint32_t c0 = cig_off[i], c1 = cig_off[i + 1];
+    int nex = 0;
+    int l = walk_exons(pos[i], cig + c0, c1 - c0, [](int, int) {}, &nex);
+    for (uint32_t k = c0; k < c1; ++k) {
+      uint32_t op = cig_op(cig[k]);
+      if (op == C_M)
+        mb += cig_len(cig[k]);
+      else if (op != C_I && op != C_D && op != C_N && op != C_S)
+        e |= check_ops ? TBK_DERR_FATALOP : 0u;
+    }
+    if (check_ops && (c1 - c0) >= 256) e |= TBK_DERR_NCIGAR;
+    double y = yc ? yc[i] : 1.0;
+    if (!(y == rint(y)) || !(fabs(y) < 1073741824.0)) e |= TBK_DERR_FRACTIONAL;
+    else ay = (uint64_t)fabs(y);
+    A.ridx[j] = i;
+    A.start[j] = pos[i] + 1;
+    A.end[j] = pos[i] + l;
+    A.tid[j] = tid[i];
+    if (jcnt) jcnt[j] = (uint32_t)(nex - 1);
+  }
+  mb = wave_sum(mb);
+  ay = wave_sum(ay);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) e |= __shfl_xor(e, d, 64);
+  if (lane_id() == 0) {
+    if (mb) atomicAdd((unsigned long long*)&scalars[0], (unsigned long long)mb);
+    if (ay) atomicAdd((unsigned long long*)&scalars[1], (unsigned long long)ay);
+    if (e) atomicOr(err, e);
+  }
+}
+
+// ---- C2: bundle heads via segmented (per tid run) running max of end -----------------------
+struct BundleLoad {
+  const int32_t* tid;
+  const int32_t* end;
+  __device__ __forceinline__ SegMax operator()(uint32_t j) const {
+    SegMax s;
+    s.mx = end[j];
+    s.flag = (j == 0 || tid[j] != tid[j - 1]) ? 1u : 0u;
+    return s;
+  }
+};
+struct BundleStore {
+  const int32_t* tid;
+  const int32_t* start;
+  uint32_t* bhead;
+  int32_t* inclmax;
+  uint32_t* err;
+  __device__ __forceinline__ void operator()(uint32_t j, const SegMax& inc, const SegMax& ex) const {
+    bool run_head = (j == 0 || tid[j] != tid[j - 1]);
+    bool head = run_head || start[j] > ex.mx;  // tiecov.cpp:443
+    if (!run_head && start[j] < start[j - 1]) atomicOr(err, TBK_DERR_UNSORTED);
+    bhead[j] = head ? 1u : 0u;
+    inclmax[j] = inc.mx;
+  }
+};
+
+__global__ void cov_bundle_fill_k(uint32_t m, CovArrays A) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  // bid arrives as the EXCLUSIVE scan of the head flags: turn it into the bundle index
+  uint32_t b = A.bid[j] + A.bhead[j] - 1u;
+  A.bid[j] = b;
+  if (A.bhead[j]) {
+    A.b_tid[b] = A.tid[j];
+    A.b_start[b] = A.start[j];
+  }
+  if (j + 1 == m || A.bhead[j + 1]) A.b_end[b] = A.inclmax[j];
+}
+__global__ void cov_bundle_span_k(uint32_t nb, CovArrays A) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < nb) A.b_span[b] = (uint32_t)(A.b_end[b] - A.b_start[b] + 1);
+}
+
+// ---- C5: compacted start + spill counting / filling ----------------------------------------
+// pieces of the M segments of record j that do not lie in its home tile
+template <class F>
+__device__ __forceinline__ void for_each_spill_piece(uint64_t cs, const uint32_t* __restrict__ cig, uint32_t nc, F f) {
+  uint64_t home = cs / COV_W;
+  uint64_t p = cs;
+  for (uint32_t k = 0; k < nc; ++k) {
+    uint32_t c = cig[k];
+    uint32_t op = cig_op(c), len = cig_len(c);
+    if (op == C_M) {
+      uint64_t a = p, b = p + len;
+      while (a < b) {
+        uint64_t t = a / COV_W;
+        uint64_t te = (t + 1) * COV_W;
+        uint64_t pe = b < te ? b : te;
+        if (t != home) f((uint32_t)t, (uint32_t)(a - t * COV_W), (uint32_t)(pe - a));
+        a = pe;
+      }
+      p = b;
+    } else if (op == C_D || op == C_N) {
+      p += len;
+    }
+  }
+}
+
+__global__ void cov_cs_count_k(uint32_t m, CovArrays A, const uint32_t* __restrict__ cig_off, const uint32_t* __restrict__ cig,
+                               uint32_t* __restrict__ tile_cnt) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  uint32_t b = A.bid[j];
+  uint64_t cs = A.b_off[b] + (uint64_t)(A.start[j] - A.b_start[b]);
+  A.cs[j] = cs;
+  uint32_t i = A.ridx[j];
+  for_each_spill_piece(cs, cig + cig_off[i], cig_off[i + 1] - cig_off[i],
+                       [&](uint32_t t, uint32_t, uint32_t) { atomicAdd(&tile_cnt[t], 1u); });
+}
+
+__global__ void cov_spill_fill_k(uint32_t m, CovArrays A, const uint32_t* __restrict__ cig_off, const uint32_t* __restrict__ cig,
+                                 const uint32_t* __restrict__ tile_off, uint32_t* __restrict__ tile_fill,
+                                 uint32_t* __restrict__ sp_seg, uint32_t* __restrict__ sp_rec) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  uint32_t i = A.ridx[j];
+  for_each_spill_piece(A.cs[j], cig + cig_off[i], cig_off[i + 1] - cig_off[i], [&](uint32_t t, uint32_t off, uint32_t len) {
+    uint32_t slot = tile_off[t] + atomicAdd(&tile_fill[t], 1u);
+    sp_seg[slot] = off | ((len - 1) << 16);  // off < 8192, len-1 < 8192
+    sp_rec[slot] = j;
+  });
+}
+
+// ---- C8: the tile kernel --------------------------------------------------------------------
+__device__ __forceinline__ uint32_t padidx(uint32_t p) { return p + (p >> 5); }
+
+template <class AccT>
+__device__ __forceinline__ AccT to_acc(double y);
+template <>
+__device__ __forceinline__ int32_t to_acc<int32_t>(double y) { return (int32_t)y; }
+template <>
+__device__ __forceinline__ long long to_acc<long long>(double y) { return (long long)y; }
+
+__device__ __forceinline__ void lds_add(int32_t* p, int32_t v) { atomicAdd(p, v); }
+__device__ __forceinline__ void lds_add(long long* p, long long v) { atomicAdd((unsigned long long*)p, (unsigned long long)v); }
+
+// change point: pos = cpos | tentative<<63 ; val = depth (as double: exact for |v| < 2^53)
+template <class AccT>
+__global__ __launch_bounds__(COV_NT) void cov_tile_k(uint32_t m, uint64_t S, CovArrays A, const uint32_t* __restrict__ cig_off,
+                                                     const uint32_t* __restrict__ cig, const double* __restrict__ yc,
+                                                     const uint32_t* __restrict__ sp_off, const uint32_t* __restrict__ sp_seg,
+                                                     const uint32_t* __restrict__ sp_rec, uint64_t* __restrict__ cp_pos,
+                                                     double* __restrict__ cp_val, uint32_t* __restrict__ tile_cp_base,
+                                                     uint32_t* __restrict__ tile_cp_cnt, uint32_t* __restrict__ cp_alloc,
+                                                     uint32_t cp_cap, uint32_t* __restrict__ err) {
+  __shared__ AccT diff[COV_W + COV_W / 32 + 1];
+  __shared__ uint32_t brk[COV_W / 32];
+  __shared__ uint32_t s_range[2];
+  __shared__ uint32_t sm_u[8];
+  __shared__ AccT sm_a[8];
+  __shared__ uint32_t s_base;
+
+  const uint32_t t = threadIdx.x;
+  const uint64_t tile = blockIdx.x;
+  const uint64_t t0 = tile * COV_W;
+  const uint32_t wlen = (uint32_t)((S - t0) < (uint64_t)COV_W ? (S - t0) : (uint64_t)COV_W);
+
+  for (uint32_t p = t; p < COV_W + COV_W / 32 + 1; p += COV_NT) diff[p] = 0;
+  if (t < COV_W / 32) brk[t] = 0;
+  if (t < 2) {  // home records: first j with cs >= t0 (t==0) / cs >= t0+W (t==1)
+    uint64_t key = t0 + (uint64_t)t * COV_W;
+    uint32_t lo = 0, hi = m;
+    while (lo < hi) {
+      uint32_t mid = lo + ((hi - lo) >> 1);
+      if (A.cs[mid] < key)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    s_range[t] = lo;
+  }
+  __syncthreads();
+  const uint32_t r0 = s_range[0], r1 = s_range[1];
+  for (uint32_t j = r0 + t; j < r1; j += COV_NT) {
+    uint32_t i = A.ridx[j];
+    AccT y = to_acc<AccT>(yc ? yc[i] : 1.0);
+    uint64_t p = A.cs[j];
+    if (A.bhead[j]) atomicOr(&brk[(uint32_t)(p - t0) >> 5], 1u << ((uint32_t)(p - t0) & 31));
+    uint32_t c0 = cig_off[i], c1 = cig_off[i + 1];
+    for (uint32_t k = c0; k < c1; ++k) {
+      uint32_t c = cig[k];
+      uint32_t op = cig_op(c), len = cig_len(c);
+      if (op == C_M) {
+        uint64_t a = p, b = p + len;
+        if (a < t0 + COV_W) {  // the part inside the home tile
+          uint32_t la = (uint32_t)(a - t0);
+          lds_add(&diff[padidx(la)], y);
+          if (b < t0 + COV_W) lds_add(&diff[padidx((uint32_t)(b - t0))], (AccT)(-y));
+        }
+        p = b;
+      } else if (op == C_D || op == C_N) {
+        p += len;
+      }
+    }
+  }
+  const uint32_t s0 = sp_off[tile], s1 = sp_off[tile + 1];
+  for (uint32_t s = s0 + t; s < s1; s += COV_NT) {
+    uint32_t seg = sp_seg[s];
+    uint32_t off = seg & 0xFFFFu, len = (seg >> 16) + 1;
+    uint32_t i = A.ridx[sp_rec[s]];
+    AccT y = to_acc<AccT>(yc ? yc[i] : 1.0);
+    lds_add(&diff[padidx(off)], y);
+    if (off + len < COV_W) lds_add(&diff[padidx(off + len)], (AccT)(-y));
+  }
+  __syncthreads();
+  // per-thread serial prefix over its 32 bases, then a block scan of the thread totals
+  AccT run = 0;
+  const uint32_t pb = t * COV_PER;
+#pragma unroll 8
+  for (int q = 0; q < COV_PER; ++q) {
+    run += diff[padidx(pb + q)];
+    diff[padidx(pb + q)] = run;
+  }
+  AccT tot;
+  AccT texcl = block_excl_sum<AccT, COV_NT>(run, sm_a, &tot);
+  // change points
+  uint32_t cnt = 0;
+  uint32_t bw = brk[t];
+  AccT prev = texcl;
+  uint32_t mask = 0;
+#pragma unroll 8
+  for (int q = 0; q < COV_PER; ++q) {
+    uint32_t p = pb + q;
+    AccT d = diff[padidx(p)] + texcl;
+    bool cp = (p < wlen) && (p == 0 || d != prev || ((bw >> q) & 1u));
+    mask |= cp ? (1u << q) : 0u;
+    cnt += cp ? 1u : 0u;
+    prev = d;
+  }
+  uint32_t btot;
+  uint32_t cex = block_excl_sum<uint32_t, COV_NT>(cnt, sm_u, &btot);
+  if (t == 0) {
+    uint32_t base = atomicAdd(cp_alloc, btot);
+    s_base = base;
+    tile_cp_base[tile] = base;
+    tile_cp_cnt[tile] = btot;
+    if ((uint64_t)base + btot > cp_cap) atomicOr(err, TBK_DERR_INTERNAL);
+  }
+  __syncthreads();
+  uint32_t o = s_base + cex;
+  if ((uint64_t)s_base + btot <= cp_cap) {
+    for (int q = 0; q < COV_PER; ++q) {
+      if ((mask >> q) & 1u) {
+        uint32_t p = pb + q;
+        AccT d = diff[padidx(p)] + texcl;
+        bool tent = (p == 0) && !((bw >> q) & 1u);
+        cp_pos[o] = (t0 + p) | (tent ? (1ull << 63) : 0ull);
+        cp_val[o] = (double)d;
+        ++o;
+      }
+    }
+  }
+}
+
+// ---- C10..C12: order the change points, turn them into intervals ------------------------------
+__global__ void cov_cp_gather_k(uint32_t ntiles, const uint32_t* __restrict__ tile_cp_base, const uint32_t* __restrict__ tile_cp_cnt,
+                                const uint32_t* __restrict__ tile_cp_off, const uint64_t* __restrict__ cp_pos,
+                                const double* __restrict__ cp_val, uint64_t* __restrict__ sp, double* __restrict__ sv) {
+  uint32_t tile = blockIdx.x;
+  uint32_t base = tile_cp_base[tile], cnt = tile_cp_cnt[tile], off = tile_cp_off[tile];
+  for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) {
+    sp[off + k] = cp_pos[base + k];
+    sv[off + k] = cp_val[base + k];
+  }
+}
+
+__device__ __forceinline__ bool cp_kept(const uint64_t* sp, const double* sv, uint32_t q) {
+  if (!(sp[q] >> 63)) return true;
+  return q > 0 && sv[q] != sv[q - 1];
+}
+
+__global__ void cov_iv_flag_k(uint32_t ncp, uint64_t S, const uint64_t* __restrict__ sp, const double* __restrict__ sv,
+                              uint32_t* __restrict__ emit, uint64_t* __restrict__ endpos) {
+  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= ncp) return;
+  bool e = cp_kept(sp, sv, q) && sv[q] != 0.0;
+  emit[q] = e ? 1u : 0u;
+  if (e) {
+    uint32_t r = q + 1;
+    while (r < ncp && !cp_kept(sp, sv, r)) ++r;
+    endpos[q] = (r < ncp) ? (sp[r] & ~(1ull << 63)) : S;
+  }
+}
+
+__global__ void cov_iv_write_k(uint32_t ncp, uint32_t nb, CovArrays A, const uint64_t* __restrict__ sp, const double* __restrict__ sv,
+                               const uint32_t* __restrict__ emit, const uint32_t* __restrict__ eoff,
+                               const uint64_t* __restrict__ endpos, uint32_t cap, int32_t* __restrict__ iv_tid,
+                               int32_t* __restrict__ iv_start, int32_t* __restrict__ iv_end, double* __restrict__ iv_val) {
+  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= ncp || !emit[q]) return;
+  uint32_t o = eoff[q];
+  if (o >= cap) return;
+  uint64_t p = sp[q] & ~(1ull << 63);
+  uint32_t lo = 0, hi = nb;  // last bundle with b_off <= p
+  while (hi - lo > 1) {
+    uint32_t mid = lo + ((hi - lo) >> 1);
+    if (A.b_off[mid] <= p)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  int32_t s0 = A.b_start[lo] - 1 + (int32_t)(p - A.b_off[lo]);
+  iv_tid[o] = A.b_tid[lo];
+  iv_start[o] = s0;
+  iv_end[o] = s0 + (int32_t)(endpos[q] - p);
+  iv_val[o] = sv[q];
+}
+
+// ---- ordered double path (non-integral YC): per base, add in record order -------------------
+// One thread per base of the tile; candidate segments = spills (sorted by record) then home
+// records in file order — the same order in which the reference's addCov touches the base.
+__global__ __launch_bounds__(COV_NT) void cov_tile_ordered_k(uint32_t m, uint64_t S, CovArrays A, const uint32_t* __restrict__ cig_off,
+                                                             const uint32_t* __restrict__ cig, const double* __restrict__ yc,
+                                                             const uint32_t* __restrict__ sp_off, const uint32_t* __restrict__ sp_seg,
+                                                             const uint32_t* __restrict__ sp_rec, uint64_t* __restrict__ cp_pos,
+                                                             double* __restrict__ cp_val, uint32_t* __restrict__ tile_cp_base,
+                                                             uint32_t* __restrict__ tile_cp_cnt, uint32_t* __restrict__ cp_alloc,
+                                                             uint32_t cp_cap, uint32_t* __restrict__ err) {
+  __shared__ double depth[COV_W + COV_W / 32 + 1];
+  __shared__ uint32_t brk[COV_W / 32];
+  __shared__ uint32_t s_range[2];
+  __shared__ uint32_t sm_u[8];
+  __shared__ uint32_t s_base;
+  const uint32_t t = threadIdx.x;
+  const uint64_t tile = blockIdx.x;
+  const uint64_t t0 = tile * COV_W;
+  const uint32_t wlen = (uint32_t)((S - t0) < (uint64_t)COV_W ? (S - t0) : (uint64_t)COV_W);
+  for (uint32_t p = t; p < COV_W + COV_W / 32 + 1; p += COV_NT) depth[p] = 0.0;
+  if (t < COV_W / 32) brk[t] = 0;
+  if (t < 2) {
+    uint64_t key = t0 + (uint64_t)t * COV_W;
+    uint32_t lo = 0, hi = m;
+    while (lo < hi) {
+      uint32_t mid = lo + ((hi - lo) >> 1);
+      if (A.cs[mid] < key)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    s_range[t] = lo;
+  }
+  __syncthreads();
+  const uint32_t r0 = s_range[0], r1 = s_range[1];
+  const uint32_t s0 = sp_off[tile], s1 = sp_off[tile + 1];
+  // Spills: the bin order is arbitrary (atomic slot assignment).  Serialise by record index:
+  // repeatedly take the smallest record id greater than the last one processed (selection by
+  // the whole block; spill counts per tile are small).  Each step adds one record's pieces.
+  // Every base is owned by exactly one thread (p % COV_NT == t), so no atomics are needed and
+  // each base sees its additions in increasing record order.
+  {
+    long long last = -1;
+    __shared__ uint32_t s_next;
+    for (;;) {
+      if (t == 0) s_next = 0xFFFFFFFFu;
+      __syncthreads();
+      uint32_t best = 0xFFFFFFFFu;
+      for (uint32_t s = s0 + t; s < s1; s += COV_NT) {
+        uint32_t r = sp_rec[s];
+        if ((long long)r > last && r < best) best = r;
+      }
+      if (best != 0xFFFFFFFFu) atomicMin(&s_next, best);
+      __syncthreads();
+      uint32_t nx = s_next;
+      __syncthreads();
+      if (nx == 0xFFFFFFFFu) break;
+      double y = yc ? yc[A.ridx[nx]] : 1.0;
+      for (uint32_t s = s0; s < s1; ++s) {
+        if (sp_rec[s] != nx) continue;
+        uint32_t seg = sp_seg[s];
+        uint32_t off = seg & 0xFFFFu, len = (seg >> 16) + 1;
+        // thread t owns bases p with p % COV_NT == t
+        uint32_t first = off + ((t + COV_NT - (off % COV_NT)) % COV_NT);
+        for (uint32_t p = first; p < off + len; p += COV_NT) depth[padidx(p)] += y;
+      }
+      last = nx;
+    }
+  }
+  __syncthreads();
+  for (uint32_t j = r0; j < r1; ++j) {  // home records, file order; all threads walk the same record
+    uint32_t i = A.ridx[j];
+    double y = yc ? yc[i] : 1.0;
+    uint64_t p = A.cs[j];
+    if (t == 0 && A.bhead[j]) brk[(uint32_t)(p - t0) >> 5] |= 1u << ((uint32_t)(p - t0) & 31);
+    uint32_t c0 = cig_off[i], c1 = cig_off[i + 1];
+    for (uint32_t k = c0; k < c1; ++k) {
+      uint32_t c = cig[k];
+      uint32_t op = cig_op(c), len = cig_len(c);
+      if (op == C_M) {
+        uint64_t a = p, b = p + len;
+        if (a < t0 + COV_W) {
+          uint32_t la = (uint32_t)(a - t0);
+          uint32_t lb = (uint32_t)((b < t0 + COV_W ? b : t0 + COV_W) - t0);
+          uint32_t first = la + ((t + COV_NT - (la % COV_NT)) % COV_NT);
+          for (uint32_t q = first; q < lb; q += COV_NT) depth[padidx(q)] += y;
+        }
+        p = b;
+      } else if (op == C_D || op == C_N) {
+        p += len;
+      }
+    }
+  }
+  __syncthreads();
+  uint32_t cnt = 0;
+  const uint32_t pb = t * COV_PER;
+  uint32_t bw = brk[t];
+  uint32_t mask = 0;
+  for (int q = 0; q < COV_PER; ++q) {
+    uint32_t p = pb + q;
+    double d = depth[padidx(p)];
+    double pv = p ? depth[padidx(p - 1)] : 0.0;
+    bool cp = (p < wlen) && (p == 0 || d != pv || ((bw >> q) & 1u));
+    mask |= cp ? (1u << q) : 0u;
+    cnt += cp ? 1u : 0u;
+  }
+  uint32_t btot;
+  uint32_t cex = block_excl_sum<uint32_t, COV_NT>(cnt, sm_u, &btot);
+  if (t == 0) {
+    uint32_t base = atomicAdd(cp_alloc, btot);
+    s_base = base;
+    tile_cp_base[tile] = base;
+    tile_cp_cnt[tile] = btot;
+    if ((uint64_t)base + btot > cp_cap) atomicOr(err, TBK_DERR_INTERNAL);
+  }
+  __syncthreads();
+  uint32_t o = s_base + cex;
+  if ((uint64_t)s_base + btot <= cp_cap) {
+    for (int q = 0; q < COV_PER; ++q) {
+      if ((mask >> q) & 1u) {
+        uint32_t p = pb + q;
+        bool tent = (p == 0) && !((bw >> q) & 1u);
+        cp_pos[o] = (t0 + p) | (tent ? (1ull << 63) : 0ull);
+        cp_val[o] = depth[padidx(p)];
+        ++o;
+      }
+    }
+  }
+}
+
+// ---- junctions ---------------------------------------------------------------------------------
+__global__ void junc_fill_k(uint32_t m, CovArrays A, const int32_t* __restrict__ pos, const uint32_t* __restrict__ cig_off,
+                            const uint32_t* __restrict__ cig, const uint8_t* __restrict__ strand, const uint32_t* __restrict__ joff,
+                            uint64_t* __restrict__ hi, uint64_t* __restrict__ lo, uint32_t* __restrict__ val) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  uint32_t i = A.ridx[j];
+  uint32_t o = joff[j];
+  uint32_t b = A.bid[j];
+  uint32_t st = strand ? strand[i] : (uint32_t)'.';
+  int prev_end = 0;
+  int k = 0, nex = 0;
+  walk_exons(pos[i], cig + cig_off[i], cig_off[i + 1] - cig_off[i],
+             [&](int es, int ee) {
+               if (k > 0) {  // CJunc(exons[i-1].end+1, exons[i].start-1, strand) tiecov.cpp:104
+                 hi[o] = ((uint64_t)b << 32) | (uint32_t)(prev_end + 1);
+                 lo[o] = ((uint64_t)(uint32_t)(es - 1) << 8) | st;
+                 val[o] = j;
+                 ++o;
+               }
+               prev_end = ee;
+               ++k;
+             },
+             &nex);
+}
+
+__global__ void junc_head_k(uint32_t nj, const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo, uint32_t* __restrict__ head) {
+  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nj) return;
+  head[q] = (q == 0 || hi[q] != hi[q - 1] || lo[q] != lo[q - 1]) ? 1u : 0u;
+}
+
+// one thread per unique junction: sums its members in sorted order = record order (the sort is
+// stable and the fill order is record order), exactly the order of CJunc::add (tiecov.cpp:88-90)
+__global__ void junc_write_k(uint32_t nj, CovArrays A, const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo,
+                             const uint32_t* __restrict__ val, const uint32_t* __restrict__ head, const uint32_t* __restrict__ hoff,
+                             const double* __restrict__ yc, uint32_t cap, int32_t* __restrict__ j_tid, int32_t* __restrict__ j_start,
+                             int32_t* __restrict__ j_end, uint8_t* __restrict__ j_strand, double* __restrict__ j_val) {
+  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nj || !head[q]) return;
+  uint32_t o = hoff[q];
+  if (o >= cap) return;
+  double s = 0.0;
+  uint32_t r = q;
+  do {
+    s += yc ? yc[A.ridx[val[r]]] : 1.0;
+    ++r;
+  } while (r < nj && !head[r]);
+  uint32_t b = (uint32_t)(hi[q] >> 32);
+  j_tid[o] = A.b_tid[b];
+  j_start[o] = (int32_t)(uint32_t)(hi[q] & 0xFFFFFFFFu) - 1;
+  j_end[o] = (int32_t)(uint32_t)(lo[q] >> 8);
+  j_strand[o] = (uint8_t)(lo[q] & 0xFFu);
+  j_val[o] = s;
+}
+
+}  // namespace
+
+// =============================================================================================
+int tbk_coverage_device(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out) {
+  const uint32_t n = in->n_records;
+  const bool want_cov = out->cap_intervals > 0, want_j = out->cap_junctions > 0;
+  out->n_intervals = out->n_junctions = 0;
+  out->n_bases = 0;
+  out->span_bases = 0;
+  if (n == 0) return 0;
+  const uint32_t B = 256;
+  uint64_t* sc = ctx->d_scalars;  // [0]=n_bases [1]=sum|yc| [2]=m [3]=nb [4]=S [5]=nspill [6]=ncp [7]=nj [8]=niv [9]=nju
+  TBK_HIP(hipMemsetAsync(sc, 0, 16 * sizeof(uint64_t), ctx->stream));
+  TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
+
+  uint32_t* valid = ws_alloc<uint32_t>(ctx, n);
+  uint32_t* vpos = ws_alloc<uint32_t>(ctx, n);
+  CovArrays A;
+  A.ridx = ws_alloc<uint32_t>(ctx, n);
+  A.start = ws_alloc<int32_t>(ctx, n);
+  A.end = ws_alloc<int32_t>(ctx, n);
+  A.tid = ws_alloc<int32_t>(ctx, n);
+  A.bhead = ws_alloc<uint32_t>(ctx, n);
+  A.inclmax = ws_alloc<int32_t>(ctx, n);
+  A.bid = ws_alloc<uint32_t>(ctx, n);
+  A.cs = ws_alloc<uint64_t>(ctx, n);
+  A.b_tid = ws_alloc<int32_t>(ctx, n);
+  A.b_start = ws_alloc<int32_t>(ctx, n);
+  A.b_end = ws_alloc<int32_t>(ctx, n);
+  A.b_span = ws_alloc<uint32_t>(ctx, n);
+  A.b_off = ws_alloc<uint64_t>(ctx, n + 1);
+  uint32_t* jcnt = want_j ? ws_alloc<uint32_t>(ctx, n) : nullptr;
+  uint32_t* joff = want_j ? ws_alloc<uint32_t>(ctx, n) : nullptr;
+  if (!A.b_off || (want_j && !joff)) return TBK_ENOMEM;
+
+  TBK_LAUNCH(ctx, "cov_valid", cov_valid_k, cdiv(n, B), B, 0, in->flag, n, valid);
+  TBK_TRY(tbk_exscan_u32(ctx, valid, vpos, n, sc + 2));
+  TBK_LAUNCH(ctx, "cov_prep", cov_prep_k, cdiv(n, B), B, 0, n, valid, vpos, in->tid, in->pos, in->cig_off, in->cig, in->yc,
+             want_cov ? 1 : 0, A, jcnt, sc, ctx->d_err);
+  TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  uint32_t eb = 0;
+  TBK_TRY(tbk_sync_err(ctx, &eb));
+  const bool fractional = (eb & TBK_DERR_FRACTIONAL) != 0;
+  eb &= ~TBK_DERR_FRACTIONAL;
+  if (eb) return tbk_derr_to_status(ctx, eb);
+  if (fractional) TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
+  const uint32_t m = (uint32_t)ctx->h_scalars[2];
+  out->n_bases = ctx->h_scalars[0];
+  const uint64_t sum_abs = ctx->h_scalars[1];
+  if (m == 0) return 0;
+
+  // bundles
+  {
+    BundleLoad ld{A.tid, A.end};
+    BundleStore st{A.tid, A.start, A.bhead, A.inclmax, ctx->d_err};
+    SegMax ident{INT32_MIN, 0u};
+    TBK_TRY((scan_op_run<SegMax, SegMaxOp, BundleLoad, BundleStore>(ctx, "cov_bundle_scan", m, ld, st, SegMaxOp{}, ident)));
+  }
+  TBK_TRY(tbk_exscan_u32(ctx, A.bhead, A.bid, m, sc + 3));
+  TBK_LAUNCH(ctx, "cov_bundle_fill", cov_bundle_fill_k, cdiv(m, B), B, 0, m, A);
+  TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  TBK_TRY(tbk_sync_err(ctx, &eb));
+  if (eb) return tbk_derr_to_status(ctx, eb);
+  const uint32_t nb = (uint32_t)ctx->h_scalars[3];
+  TBK_LAUNCH(ctx, "cov_bundle_span", cov_bundle_span_k, cdiv(nb, B), B, 0, nb, A);
+  TBK_TRY(tbk_exscan_u32_u64(ctx, A.b_span, A.b_off, nb, sc + 4));
+  // b_off[nb] = S (device-to-device copy of the total)
+  TBK_HIP(hipMemcpyAsync(A.b_off + nb, sc + 4, sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+  TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  TBK_HIP(hipStreamSynchronize(ctx->stream));
+  const uint64_t S = ctx->h_scalars[4];
+  out->span_bases = S;
+  const uint64_t ntiles64 = (S + COV_W - 1) / COV_W;
+  if (ntiles64 >= (1ull << 31)) return TBK_E2BIG;
+  const uint32_t ntiles = (uint32_t)ntiles64;
+
+  if (want_cov) {
+    uint32_t* tile_cnt = ws_alloc<uint32_t>(ctx, ntiles + 1);
+    uint32_t* tile_off = ws_alloc<uint32_t>(ctx, ntiles + 1);
+    uint32_t* tile_fill = ws_alloc<uint32_t>(ctx, ntiles + 1);
+    if (!tile_fill) return TBK_ENOMEM;
+    TBK_HIP(hipMemsetAsync(tile_cnt, 0, (size_t)(ntiles + 1) * 4, ctx->stream));
+    TBK_HIP(hipMemsetAsync(tile_fill, 0, (size_t)(ntiles + 1) * 4, ctx->stream));
+    TBK_LAUNCH(ctx, "cov_cs_count", cov_cs_count_k, cdiv(m, B), B, 0, m, A, in->cig_off, in->cig, tile_cnt);
+    TBK_TRY(tbk_exscan_u32(ctx, tile_cnt, tile_off, ntiles + 1, sc + 5));
+    TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    TBK_HIP(hipStreamSynchronize(ctx->stream));
+    const uint64_t nspill = ctx->h_scalars[5];
+    if (nspill >= (1ull << 32)) return TBK_E2BIG;
+    uint32_t* sp_seg = ws_alloc<uint32_t>(ctx, nspill + 1);
+    uint32_t* sp_rec = ws_alloc<uint32_t>(ctx, nspill + 1);
+    // change points: <= 2 per M segment piece + 1 per bundle + 1 per tile
+    const uint64_t cp_cap64 = 2ull * ((uint64_t)in->n_cigar_ops + nspill) + nb + ntiles + 16;
+    if (cp_cap64 >= (1ull << 32)) return TBK_E2BIG;
+    const uint32_t cp_cap = (uint32_t)cp_cap64;
+    uint64_t* cp_pos = ws_alloc<uint64_t>(ctx, cp_cap);
+    double* cp_val = ws_alloc<double>(ctx, cp_cap);
+    uint64_t* sp = ws_alloc<uint64_t>(ctx, cp_cap);
+    double* sv = ws_alloc<double>(ctx, cp_cap);
+    uint32_t* tile_cp_base = ws_alloc<uint32_t>(ctx, ntiles);
+    uint32_t* tile_cp_cnt = ws_alloc<uint32_t>(ctx, ntiles);
+    uint32_t* tile_cp_off = ws_alloc<uint32_t>(ctx, ntiles);
+    uint32_t* emit = ws_alloc<uint32_t>(ctx, cp_cap);
+    uint32_t* eoff = ws_alloc<uint32_t>(ctx, cp_cap);
+    uint64_t* endpos = ws_alloc<uint64_t>(ctx, cp_cap);
+    uint32_t* cp_alloc = (uint32_t*)(sc + 10);
+    if (!endpos) return TBK_ENOMEM;
+    if (nspill)
+      TBK_LAUNCH(ctx, "cov_spill_fill", cov_spill_fill_k, cdiv(m, B), B, 0, m, A, in->cig_off, in->cig, tile_off, tile_fill,
+                 sp_seg, sp_rec);
+    if (fractional) {
+      TBK_LAUNCH(ctx, "cov_tile_ordered", cov_tile_ordered_k, ntiles, COV_NT, 0, m, S, A, in->cig_off, in->cig, in->yc, tile_off,
+                 sp_seg, sp_rec, cp_pos, cp_val, tile_cp_base, tile_cp_cnt, cp_alloc, cp_cap, ctx->d_err);
+    } else if (sum_abs < (1ull << 31)) {
+      TBK_LAUNCH(ctx, "cov_tile", (cov_tile_k<int32_t>), ntiles, COV_NT, 0, m, S, A, in->cig_off, in->cig, in->yc, tile_off,
+                 sp_seg, sp_rec, cp_pos, cp_val, tile_cp_base, tile_cp_cnt, cp_alloc, cp_cap, ctx->d_err);
+    } else {
+      TBK_LAUNCH(ctx, "cov_tile", (cov_tile_k<long long>), ntiles, COV_NT, 0, m, S, A, in->cig_off, in->cig, in->yc, tile_off,
+                 sp_seg, sp_rec, cp_pos, cp_val, tile_cp_base, tile_cp_cnt, cp_alloc, cp_cap, ctx->d_err);
+    }
+    TBK_TRY(tbk_exscan_u32(ctx, tile_cp_cnt, tile_cp_off, ntiles, sc + 6));
+    TBK_LAUNCH(ctx, "cov_cp_gather", cov_cp_gather_k, ntiles, 64, 0, ntiles, tile_cp_base, tile_cp_cnt, tile_cp_off, cp_pos, cp_val,
+               sp, sv);
+    TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    TBK_TRY(tbk_sync_err(ctx, &eb));
+    if (eb) return tbk_derr_to_status(ctx, eb);
+    const uint32_t ncp = (uint32_t)ctx->h_scalars[6];
+    if (ncp) {
+      TBK_LAUNCH(ctx, "cov_iv_flag", cov_iv_flag_k, cdiv(ncp, B), B, 0, ncp, S, sp, sv, emit, endpos);
+      TBK_TRY(tbk_exscan_u32(ctx, emit, eoff, ncp, sc + 8));
+      TBK_LAUNCH(ctx, "cov_iv_write", cov_iv_write_k, cdiv(ncp, B), B, 0, ncp, nb, A, sp, sv, emit, eoff, endpos,
+                 out->cap_intervals, out->iv_tid, out->iv_start, out->iv_end, out->iv_val);
+    }
+  }
+
+  uint32_t nj = 0;
+  if (want_j) {
+    TBK_TRY(tbk_exscan_u32(ctx, jcnt, joff, m, sc + 7));
+    TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    TBK_HIP(hipStreamSynchronize(ctx->stream));
+    nj = (uint32_t)ctx->h_scalars[7];
+    if (nj) {
+      SortBufs sb;
+      sb.hi = ws_alloc<uint64_t>(ctx, nj);
+      sb.lo = ws_alloc<uint64_t>(ctx, nj);
+      sb.val = ws_alloc<uint32_t>(ctx, nj);
+      sb.hi2 = ws_alloc<uint64_t>(ctx, nj);
+      sb.lo2 = ws_alloc<uint64_t>(ctx, nj);
+      sb.val2 = ws_alloc<uint32_t>(ctx, nj);
+      uint32_t* head = ws_alloc<uint32_t>(ctx, nj);
+      uint32_t* hoff = ws_alloc<uint32_t>(ctx, nj);
+      if (!hoff) return TBK_ENOMEM;
+      TBK_LAUNCH(ctx, "junc_fill", junc_fill_k, cdiv(m, B), B, 0, m, A, in->pos, in->cig_off, in->cig, in->strand, joff, sb.hi,
+                 sb.lo, sb.val);
+      TBK_TRY(tbk_radix_sort128(ctx, &sb, nj));
+      TBK_LAUNCH(ctx, "junc_head", junc_head_k, cdiv(nj, B), B, 0, nj, sb.hi, sb.lo, head);
+      TBK_TRY(tbk_exscan_u32(ctx, head, hoff, nj, sc + 9));
+      TBK_LAUNCH(ctx, "junc_write", junc_write_k, cdiv(nj, B), B, 0, nj, A, sb.hi, sb.lo, sb.val, head, hoff, in->yc,
+                 out->cap_junctions, out->j_tid, out->j_start, out->j_end, out->j_strand, out->j_val);
+    }
+  }
+  TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  TBK_TRY(tbk_sync_err(ctx, &eb));
+  if (eb) return tbk_derr_to_status(ctx, eb);
+  TBK_TRY(tbk_check_launch(ctx, "coverage"));
+  if (want_cov) {
+    out->n_intervals = (uint32_t)ctx->h_scalars[8];
+    if (out->n_intervals > out->cap_intervals) return TBK_E2BIG;
+  }
+  if (want_j && nj) {
+    out->n_junctions = (uint32_t)ctx->h_scalars[9];
+    if (out->n_junctions > out->cap_junctions) return TBK_E2BIG;
+  }
+  return 0;
+}

@@ -1,0 +1,320 @@
+// prims.hip — device-wide primitives for gfx950: exclusive scans and a 128-bit-key LSD
+// radix sort ("wavefront radix over LDS-staged tiles": per-wave ballot matching for the
+// stable rank, the sorted sub-tile staged in LDS so that global writes are digit-contiguous).
+// All integer work, HBM-bound; no MFMA.
+#include "dev_common.cuh"
+#include "tbk_internal.h"
+
+// =====================================================================================
+// exclusive scan (u32 in, u32 or u64 out) — reduce / spine / down-sweep
+// =====================================================================================
+namespace {
+constexpr int SC_NT = 256;
+constexpr int SC_E = 8;
+constexpr int SC_TILE = SC_NT * SC_E;
+
+__global__ __launch_bounds__(SC_NT) void scan_reduce_k(const uint32_t* __restrict__ in, uint64_t* __restrict__ part, uint32_t n) {
+  __shared__ uint64_t sm[8];
+  uint64_t base = (uint64_t)blockIdx.x * SC_TILE;
+  uint64_t s = 0;
+#pragma unroll
+  for (int e = 0; e < SC_E; ++e) {
+    uint64_t i = base + (uint64_t)e * SC_NT + threadIdx.x;
+    if (i < n) s += in[i];
+  }
+  s = wave_sum(s);
+  if (lane_id() == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// single block: exclusive scan of part[0..nb) in place, total -> *total (may be null)
+__global__ __launch_bounds__(1024) void scan_spine_k(uint64_t* __restrict__ part, uint32_t nb, uint64_t* __restrict__ total) {
+  __shared__ uint64_t sm[16];
+  __shared__ uint64_t carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < nb; base += 1024) {
+    uint32_t i = base + threadIdx.x;
+    uint64_t v = (i < nb) ? part[i] : 0;
+    uint64_t inc = wave_incl_sum(v);
+    uint32_t w = threadIdx.x >> 6;
+    if (lane_id() == 63) sm[w] = inc;
+    __syncthreads();
+    uint64_t wb = 0, tot = 0;
+    for (int k = 0; k < 16; ++k) {
+      uint64_t x = sm[k];
+      if ((uint32_t)k < w) wb += x;
+      tot += x;
+    }
+    uint64_t carry = carry_s;
+    if (i < nb) part[i] = carry + wb + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = carry + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && total) *total = carry_s;
+}
+
+template <class OutT>
+__global__ __launch_bounds__(SC_NT) void scan_down_k(const uint32_t* __restrict__ in, OutT* __restrict__ out,
+                                                     const uint64_t* __restrict__ part, uint32_t n) {
+  __shared__ uint64_t sm[8];
+  uint64_t base = (uint64_t)blockIdx.x * SC_TILE + (uint64_t)threadIdx.x * SC_E;
+  uint32_t v[SC_E];
+  uint64_t s = 0;
+#pragma unroll
+  for (int e = 0; e < SC_E; ++e) {
+    uint64_t i = base + e;
+    v[e] = (i < n) ? in[i] : 0;
+    s += v[e];
+  }
+  uint64_t tot;
+  uint64_t ex = block_excl_sum<uint64_t, SC_NT>(s, sm, &tot) + part[blockIdx.x];
+#pragma unroll
+  for (int e = 0; e < SC_E; ++e) {
+    uint64_t i = base + e;
+    if (i < n) out[i] = (OutT)ex;
+    ex += v[e];
+  }
+}
+
+template <class OutT>
+int exscan_impl(tbk_ctx* ctx, const uint32_t* in, OutT* out, uint32_t n, uint64_t* d_total) {
+  if (n == 0) {
+    if (d_total) {
+      hipError_t e = hipMemsetAsync(d_total, 0, sizeof(uint64_t), ctx->stream);
+      if (e != hipSuccess) return TBK_EHIP;
+    }
+    return 0;
+  }
+  uint32_t nb = cdiv(n, SC_TILE);
+  uint64_t* part = ws_alloc<uint64_t>(ctx, nb);
+  if (!part) return TBK_ENOMEM;
+  TBK_LAUNCH(ctx, "scan_reduce", scan_reduce_k, nb, SC_NT, 0, in, part, n);
+  TBK_LAUNCH(ctx, "scan_spine", scan_spine_k, 1, 1024, 0, part, nb, d_total);
+  TBK_LAUNCH(ctx, "scan_down", (scan_down_k<OutT>), nb, SC_NT, 0, in, out, part, n);
+  return tbk_check_launch(ctx, "exscan");
+}
+}  // namespace
+
+int tbk_exscan_u32(tbk_ctx* ctx, const uint32_t* in, uint32_t* out, uint32_t n, uint64_t* d_total) {
+  return exscan_impl<uint32_t>(ctx, in, out, n, d_total);
+}
+int tbk_exscan_u32_u64(tbk_ctx* ctx, const uint32_t* in, uint64_t* out, uint32_t n, uint64_t* d_total) {
+  return exscan_impl<uint64_t>(ctx, in, out, n, d_total);
+}
+
+// =====================================================================================
+// 128-bit LSD radix sort, 8-bit digits, stable
+// =====================================================================================
+namespace {
+constexpr int RX_NT = 256;
+constexpr int RX_E = 8;                    // elements per lane per sub-tile
+constexpr int RX_SUB = RX_NT * RX_E;       // 2048
+constexpr int RX_ITER = 4;                 // sub-tiles per tile
+constexpr int RX_TILE = RX_SUB * RX_ITER;  // 8192: granularity of the (digit x tile) count table
+
+// AND / OR of all keys: bits where and == or are constant => whole digits of them are skipped
+__global__ __launch_bounds__(256) void rx_bits_k(const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo, uint32_t n,
+                                                 uint64_t* __restrict__ andor /*[4]: and_hi, or_hi, and_lo, or_lo*/) {
+  uint64_t ah = ~0ull, oh = 0, al = ~0ull, ol = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    uint64_t h = hi[i], l = lo[i];
+    ah &= h;
+    oh |= h;
+    al &= l;
+    ol |= l;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    ah &= __shfl_xor(ah, d, 64);
+    oh |= __shfl_xor(oh, d, 64);
+    al &= __shfl_xor(al, d, 64);
+    ol |= __shfl_xor(ol, d, 64);
+  }
+  if (lane_id() == 0) {
+    atomicAnd((unsigned long long*)&andor[0], (unsigned long long)ah);
+    atomicOr((unsigned long long*)&andor[1], (unsigned long long)oh);
+    atomicAnd((unsigned long long*)&andor[2], (unsigned long long)al);
+    atomicOr((unsigned long long*)&andor[3], (unsigned long long)ol);
+  }
+}
+
+__device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid) {
+  uint64_t peers = __ballot(valid);
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    bool bit = (d >> b) & 1u;
+    uint64_t bal = __ballot(valid && bit);
+    peers &= bit ? bal : ~bal;
+  }
+  return peers;
+}
+
+// per-tile digit counts -> table[digit * ntiles + tile]
+__global__ __launch_bounds__(RX_NT) void rx_hist_k(const uint64_t* __restrict__ word, uint32_t shift, uint32_t n, uint32_t ntiles,
+                                                   uint32_t* __restrict__ table) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  uint64_t base = (uint64_t)blockIdx.x * RX_TILE;
+  for (int it = 0; it < RX_TILE / RX_NT; ++it) {
+    uint64_t i = base + (uint64_t)it * RX_NT + threadIdx.x;
+    bool valid = i < n;
+    uint32_t d = valid ? (uint32_t)((word[i] >> shift) & 0xFFu) : 0u;
+    uint64_t peers = match_digit(d, valid);
+    if (valid && (peers & lanemask_lt()) == 0) atomicAdd(&h[d], (uint32_t)__popcll(peers));
+  }
+  __syncthreads();
+  table[(uint64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+
+// block d: exclusive scan of row d of the table in place; row total -> totals[d]
+__global__ __launch_bounds__(256) void rx_rowscan_k(uint32_t* __restrict__ table, uint32_t ntiles, uint32_t* __restrict__ totals) {
+  __shared__ uint32_t sm[8];
+  __shared__ uint32_t carry_s;
+  uint32_t* row = table + (uint64_t)blockIdx.x * ntiles;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < ntiles; base += 256) {
+    uint32_t i = base + threadIdx.x;
+    uint32_t v = (i < ntiles) ? row[i] : 0;
+    uint32_t tot;
+    uint32_t ex = block_excl_sum<uint32_t, 256>(v, sm, &tot);
+    uint32_t carry = carry_s;
+    if (i < ntiles) row[i] = carry + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = carry + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
+}
+
+__global__ __launch_bounds__(RX_NT) void rx_scatter_k(const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo,
+                                                      const uint32_t* __restrict__ val, uint64_t* __restrict__ hi2,
+                                                      uint64_t* __restrict__ lo2, uint32_t* __restrict__ val2, int use_hi,
+                                                      uint32_t shift, uint32_t n, uint32_t ntiles,
+                                                      const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals) {
+  __shared__ uint32_t digit_base[256];  // global offset of the next element of each digit for this tile
+  __shared__ uint32_t wave_cnt[4][256];
+  __shared__ uint32_t lpos[256];        // start of each digit inside the staged sub-tile
+  __shared__ uint32_t sm[8];
+  __shared__ uint64_t s_hi[RX_SUB];
+  __shared__ uint64_t s_lo[RX_SUB];
+  __shared__ uint32_t s_val[RX_SUB];
+
+  const uint32_t t = threadIdx.x;
+  const uint32_t w = t >> 6;
+  {
+    uint32_t tot_d = totals[t], dummy;
+    uint32_t dbase = block_excl_sum<uint32_t, RX_NT>(tot_d, sm, &dummy);
+    digit_base[t] = dbase + table[(uint64_t)t * ntiles + blockIdx.x];
+  }
+  const uint64_t tile_base = (uint64_t)blockIdx.x * RX_TILE;
+  for (int it = 0; it < RX_ITER; ++it) {
+    const uint64_t sub_base = tile_base + (uint64_t)it * RX_SUB;
+    if (sub_base >= n) break;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wave_cnt[k][t] = 0;
+    __syncthreads();
+    uint64_t khi[RX_E], klo[RX_E];
+    uint32_t kv[RX_E], kr[RX_E];
+#pragma unroll
+    for (int e = 0; e < RX_E; ++e) {
+      uint64_t i = sub_base + (uint64_t)w * (64 * RX_E) + (uint64_t)e * 64 + lane_id();
+      bool valid = i < n;
+      khi[e] = valid ? hi[i] : ~0ull;
+      klo[e] = valid ? lo[i] : ~0ull;
+      kv[e] = valid ? val[i] : 0u;
+    }
+#pragma unroll
+    for (int e = 0; e < RX_E; ++e) {
+      uint64_t i = sub_base + (uint64_t)w * (64 * RX_E) + (uint64_t)e * 64 + lane_id();
+      bool valid = i < n;
+      uint32_t d = (uint32_t)(((use_hi ? khi[e] : klo[e]) >> shift) & 0xFFu);
+      uint64_t peers = match_digit(d, valid);
+      uint32_t before = (uint32_t)__popcll(peers & lanemask_lt());
+      uint32_t base = valid ? wave_cnt[w][d] : 0u;
+      __builtin_amdgcn_wave_barrier();
+      if (valid && before == 0) wave_cnt[w][d] = base + (uint32_t)__popcll(peers);
+      __builtin_amdgcn_wave_barrier();
+      kr[e] = (base + before) | (d << 16) | (valid ? 0u : 0x80000000u);  // rank < 2048 fits 16 bits
+    }
+    __syncthreads();
+    {
+      uint32_t c0 = wave_cnt[0][t], c1 = wave_cnt[1][t], c2 = wave_cnt[2][t], c3 = wave_cnt[3][t];
+      uint32_t tot = c0 + c1 + c2 + c3, dummy;
+      uint32_t lp = block_excl_sum<uint32_t, RX_NT>(tot, sm, &dummy);
+      wave_cnt[0][t] = lp;
+      wave_cnt[1][t] = lp + c0;
+      wave_cnt[2][t] = lp + c0 + c1;
+      wave_cnt[3][t] = lp + c0 + c1 + c2;
+      lpos[t] = lp;
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < RX_E; ++e) {
+        if (!(kr[e] & 0x80000000u)) {
+          uint32_t d = (kr[e] >> 16) & 0xFFu;
+          uint32_t slot = wave_cnt[w][d] + (kr[e] & 0xFFFFu);
+          s_hi[slot] = khi[e];
+          s_lo[slot] = klo[e];
+          s_val[slot] = kv[e];
+        }
+      }
+      __syncthreads();
+      uint32_t cnt_sub = (uint32_t)((n - sub_base) < (uint64_t)RX_SUB ? (n - sub_base) : (uint64_t)RX_SUB);
+      for (uint32_t s = t; s < cnt_sub; s += RX_NT) {
+        uint64_t h = s_hi[s], l = s_lo[s];
+        uint32_t d = (uint32_t)(((use_hi ? h : l) >> shift) & 0xFFu);
+        uint32_t g = digit_base[d] + (s - lpos[d]);
+        hi2[g] = h;
+        lo2[g] = l;
+        val2[g] = s_val[s];
+      }
+      __syncthreads();
+      digit_base[t] += tot;
+      __syncthreads();
+    }
+  }
+}
+}  // namespace
+
+size_t tbk_radix_ws_bytes(uint32_t n) {
+  uint32_t ntiles = cdiv(n ? n : 1, RX_TILE);
+  return (size_t)256 * ntiles * 4 + 256 * 4 + 4096;
+}
+
+int tbk_radix_sort128(tbk_ctx* ctx, SortBufs* b, uint32_t n) {
+  if (n < 2) return 0;
+  uint64_t* d_andor = ctx->d_scalars + 32;
+  uint64_t init[4] = {~0ull, 0ull, ~0ull, 0ull};
+  memcpy(ctx->h_scalars + 32, init, sizeof(init));
+  TBK_HIP(hipMemcpyAsync(d_andor, ctx->h_scalars + 32, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+  uint32_t g = cdiv(n, 256 * 8);
+  if (g > 2048) g = 2048;
+  TBK_LAUNCH(ctx, "rx_bits", rx_bits_k, g, 256, 0, b->hi, b->lo, n, d_andor);
+  TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 32, d_andor, sizeof(init), hipMemcpyDeviceToHost, ctx->stream));
+  TBK_HIP(hipStreamSynchronize(ctx->stream));
+  uint64_t vary_hi = ctx->h_scalars[32] ^ ctx->h_scalars[33];
+  uint64_t vary_lo = ctx->h_scalars[34] ^ ctx->h_scalars[35];
+  uint32_t ntiles = cdiv(n, RX_TILE);
+  uint32_t* table = ws_alloc<uint32_t>(ctx, (size_t)256 * ntiles);
+  uint32_t* totals = ws_alloc<uint32_t>(ctx, 256);
+  if (!table || !totals) return TBK_ENOMEM;
+  for (int word = 0; word < 2; ++word) {  // LSD: lo word first
+    uint64_t vary = word == 0 ? vary_lo : vary_hi;
+    for (uint32_t shift = 0; shift < 64; shift += 8) {
+      if (((vary >> shift) & 0xFFull) == 0) continue;
+      const uint64_t* src = word == 0 ? b->lo : b->hi;
+      TBK_LAUNCH(ctx, "rx_hist", rx_hist_k, ntiles, RX_NT, 0, src, shift, n, ntiles, table);
+      TBK_LAUNCH(ctx, "rx_rowscan", rx_rowscan_k, 256, 256, 0, table, ntiles, totals);
+      TBK_LAUNCH(ctx, "rx_scatter", rx_scatter_k, ntiles, RX_NT, 0, b->hi, b->lo, b->val, b->hi2, b->lo2, b->val2, word,
+                 shift, n, ntiles, table, totals);
+      std::swap(b->hi, b->hi2);
+      std::swap(b->lo, b->lo2);
+      std::swap(b->val, b->val2);
+    }
+  }
+  return tbk_check_launch(ctx, "radix_sort128");
+}

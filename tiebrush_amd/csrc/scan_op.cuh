@@ -1,0 +1,152 @@
+// scan_op.cuh — device-wide inclusive scan with an arbitrary associative (not necessarily
+// commutative) operator over a trivially-copyable T made of 32-bit words.
+// Three launches: per-tile reduce, single-block spine, per-tile down-sweep.  Load/Store are
+// functors so the per-element work of the caller fuses into the first / last pass.
+#pragma once
+#include "dev_common.cuh"
+#include "tbk_internal.h"
+
+template <class T>
+__device__ __forceinline__ T shfl_up_t(const T& v, int d) {
+  static_assert(sizeof(T) % 4 == 0, "T must be made of 32-bit words");
+  T r;
+  const uint32_t* s = reinterpret_cast<const uint32_t*>(&v);
+  uint32_t* o = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+  for (unsigned k = 0; k < sizeof(T) / 4; ++k) o[k] = __shfl_up(s[k], d, 64);
+  return r;
+}
+template <class T>
+__device__ __forceinline__ T shfl_idx_t(const T& v, int l) {
+  T r;
+  const uint32_t* s = reinterpret_cast<const uint32_t*>(&v);
+  uint32_t* o = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+  for (unsigned k = 0; k < sizeof(T) / 4; ++k) o[k] = __shfl(s[k], l, 64);
+  return r;
+}
+
+constexpr int SO_NT = 256;
+constexpr int SO_E = 8;
+constexpr int SO_TILE = SO_NT * SO_E;
+
+// block-wide inclusive scan of one value per thread (thread order), 256 threads.
+// returns inclusive result; *excl_valid=false for thread 0 (no predecessor); block total in *total.
+template <class T, class Op>
+__device__ __forceinline__ T block_incl_scan_op(T v, Op op, T* sm /*>=4*/, T* total) {
+  T inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    T o = shfl_up_t(inc, d);
+    if ((int)lane_id() >= d) inc = op(o, inc);
+  }
+  uint32_t w = threadIdx.x >> 6;
+  if (lane_id() == 63) sm[w] = inc;
+  __syncthreads();
+  T tot = sm[0];
+  if (w >= 1) {
+    T pre = sm[0];
+    for (uint32_t k = 1; k < w; ++k) pre = op(pre, sm[k]);
+    inc = op(pre, inc);
+  }
+#pragma unroll
+  for (int k = 1; k < SO_NT / 64; ++k) tot = op(tot, sm[k]);
+  __syncthreads();
+  *total = tot;
+  return inc;
+}
+
+template <class T, class Op, class Load>
+__global__ __launch_bounds__(SO_NT) void so_reduce_k(uint32_t n, Load load, Op op, T ident, T* __restrict__ part) {
+  __shared__ T sm[SO_NT / 64];
+  uint64_t base = (uint64_t)blockIdx.x * SO_TILE + (uint64_t)threadIdx.x * SO_E;
+  T acc = ident;
+#pragma unroll
+  for (int e = 0; e < SO_E; ++e) {
+    uint64_t i = base + e;
+    if (i < n) acc = op(acc, load((uint32_t)i));
+  }
+  T tot;
+  (void)block_incl_scan_op(acc, op, sm, &tot);
+  if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+// single block: part[b] := exclusive prefix (ident for b == 0)
+template <class T, class Op>
+__global__ __launch_bounds__(SO_NT) void so_spine_k(T* __restrict__ part, uint32_t nb, Op op, T ident) {
+  __shared__ T sm[SO_NT / 64];
+  __shared__ T carry_s;
+  if (threadIdx.x == 0) carry_s = ident;
+  __syncthreads();
+  for (uint32_t base = 0; base < nb; base += SO_NT) {
+    uint32_t i = base + threadIdx.x;
+    T v = (i < nb) ? part[i] : ident;
+    T tot;
+    T inc = block_incl_scan_op(v, op, sm, &tot);
+    // exclusive = carry (+) inclusive of the previous thread
+    T prev = shfl_up_t(inc, 1);
+    __shared__ T wl[SO_NT / 64];
+    if (lane_id() == 63) wl[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    T carry = carry_s;
+    T ex;
+    if (threadIdx.x == 0)
+      ex = carry;
+    else if (lane_id() == 0)
+      ex = op(carry, wl[(threadIdx.x >> 6) - 1]);
+    else
+      ex = op(carry, prev);
+    if (i < nb) part[i] = ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = op(carry, tot);
+    __syncthreads();
+  }
+}
+
+// store(i, inclusive, exclusive) with exclusive == op-prefix of everything before i (ident for i == 0)
+template <class T, class Op, class Load, class Store>
+__global__ __launch_bounds__(SO_NT) void so_down_k(uint32_t n, Load load, Store store, Op op, T ident, const T* __restrict__ part) {
+  __shared__ T sm[SO_NT / 64];
+  __shared__ T wl[SO_NT / 64];
+  uint64_t base = (uint64_t)blockIdx.x * SO_TILE + (uint64_t)threadIdx.x * SO_E;
+  T v[SO_E];
+  T acc = ident;
+#pragma unroll
+  for (int e = 0; e < SO_E; ++e) {
+    uint64_t i = base + e;
+    v[e] = (i < n) ? load((uint32_t)i) : ident;
+    acc = op(acc, v[e]);
+  }
+  T tot;
+  T inc = block_incl_scan_op(acc, op, sm, &tot);
+  T prev = shfl_up_t(inc, 1);
+  if (lane_id() == 63) wl[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  T carry = part[blockIdx.x];
+  T ex;
+  if (threadIdx.x == 0)
+    ex = carry;
+  else if (lane_id() == 0)
+    ex = op(carry, wl[(threadIdx.x >> 6) - 1]);
+  else
+    ex = op(carry, prev);
+#pragma unroll
+  for (int e = 0; e < SO_E; ++e) {
+    uint64_t i = base + e;
+    T in = op(ex, v[e]);
+    if (i < n) store((uint32_t)i, in, ex);
+    ex = in;
+  }
+}
+
+template <class T, class Op, class Load, class Store>
+int scan_op_run(tbk_ctx* ctx, const char* name, uint32_t n, Load load, Store store, Op op, T ident) {
+  if (n == 0) return 0;
+  uint32_t nb = cdiv(n, SO_TILE);
+  T* part = ws_alloc<T>(ctx, nb);
+  if (!part) return TBK_ENOMEM;
+  TBK_LAUNCH(ctx, name, (so_reduce_k<T, Op, Load>), nb, SO_NT, 0, n, load, op, ident, part);
+  TBK_LAUNCH(ctx, name, (so_spine_k<T, Op>), 1, SO_NT, 0, part, nb, op, ident);
+  TBK_LAUNCH(ctx, name, (so_down_k<T, Op, Load, Store>), nb, SO_NT, 0, n, load, store, op, ident, part);
+  return tbk_check_launch(ctx, name);
+}

@@ -1,0 +1,424 @@
+// tbk_api.hip — the extern "C" boundary declared in include/tbk.h: context lifetime, workspace
+// arena, host<->device staging for TBK_MEM_HOST callers, error mapping.  The pipelines live in
+// collapse.hip / cov.hip; primitives in prims.hip.
+#include <algorithm>
+#include <new>
+
+#include "tbk_internal.h"
+
+// ---- workspace arena ------------------------------------------------------------------------------
+// One big hipMalloc'd block, bump-allocated per API call.  If a call outgrows it, overflow chunks are
+// chained for that call and the arena is re-created at the combined size at the start of the next
+// call, so a steady-state loop performs no allocation at all.
+static int ws_begin_call(tbk_ctx* ctx, size_t hint) {
+  size_t want = std::max(ctx->ws_cap, hint);
+  if (!ctx->ws_overflow.empty()) {
+    size_t tot = ctx->ws_cap;
+    for (auto& c : ctx->ws_overflow) {
+      tot += c.second;
+      (void)hipFree(c.first);
+    }
+    ctx->ws_overflow.clear();
+    want = std::max(want, tot + tot / 8);
+  }
+  if (want > ctx->ws_cap) {
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    ctx->ws = nullptr;
+    ctx->ws_cap = 0;
+    TBK_HIP(hipMalloc((void**)&ctx->ws, want));
+    ctx->ws_cap = want;
+  }
+  ctx->ws_off = 0;
+  ctx->ws_over_used = 0;
+  return 0;
+}
+
+int tbk_ws_reserve(tbk_ctx* ctx, size_t bytes) { return ws_begin_call(ctx, bytes); }
+
+void* tbk_ws_alloc_raw(tbk_ctx* ctx, size_t bytes) {
+  bytes = (bytes + 255) & ~(size_t)255;
+  if (bytes == 0) bytes = 256;
+  if (ctx->ws_overflow.empty() && ctx->ws_off + bytes <= ctx->ws_cap) {
+    void* p = ctx->ws + ctx->ws_off;
+    ctx->ws_off += bytes;
+    return p;
+  }
+  // overflow chunk (only while the arena is still learning its steady-state size)
+  if (!ctx->ws_overflow.empty()) {
+    auto& c = ctx->ws_overflow.back();
+    if (ctx->ws_over_used + bytes <= c.second) {
+      void* p = c.first + ctx->ws_over_used;
+      ctx->ws_over_used += bytes;
+      return p;
+    }
+  }
+  size_t cap = std::max(bytes, (size_t)64 << 20);
+  char* p = nullptr;
+  if (hipMalloc((void**)&p, cap) != hipSuccess) {
+    ctx->last_error = "workspace hipMalloc failed";
+    return nullptr;
+  }
+  ctx->ws_overflow.push_back({p, cap});
+  ctx->ws_over_used = bytes;
+  return p;
+}
+
+hipEvent_t tbk_event(tbk_ctx* ctx) {
+  if (ctx->ev_used == ctx->ev_pool.size()) {
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    ctx->ev_pool.push_back(e);
+  }
+  return ctx->ev_pool[ctx->ev_used++];
+}
+
+int tbk_check_launch(tbk_ctx* ctx, const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    ctx->last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return TBK_EHIP;
+  }
+  return 0;
+}
+
+int tbk_sync_err(tbk_ctx* ctx, uint32_t* err_bits) {
+  uint32_t* h = (uint32_t*)(ctx->h_scalars + 60);
+  TBK_HIP(hipMemcpyAsync(h, ctx->d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  TBK_HIP(hipStreamSynchronize(ctx->stream));
+  *err_bits = *h;
+  return 0;
+}
+
+int tbk_derr_to_status(tbk_ctx* ctx, uint32_t bits) {
+  char b[128];
+  snprintf(b, sizeof(b), "device error bits 0x%x", bits);
+  ctx->last_error = b;
+  if (bits & TBK_DERR_UNSORTED) return TBK_EUNSORTED;
+  if (bits & TBK_DERR_FATALOP) return TBK_EFATALOP;
+  if (bits & TBK_DERR_NCIGAR) return TBK_EUNSUPPORTED;
+  if (bits & TBK_DERR_SPAN) return TBK_EINVAL;
+  if (bits & TBK_DERR_COLLISION) return TBK_ECOLLISION;
+  if (bits & TBK_DERR_OVERFLOW) return TBK_E2BIG;
+  return TBK_EHIP;
+}
+
+static void prof_begin_call(tbk_ctx* ctx) {
+  ctx->ktimes.clear();
+  ctx->ev_used = 0;
+}
+static void prof_end_call(tbk_ctx* ctx) {
+  ctx->last_times.clear();
+  if (!ctx->profiling) return;
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& k : ctx->ktimes) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, k.a, k.b) != hipSuccess) continue;
+    bool found = false;
+    for (auto& t : ctx->last_times)
+      if (strcmp(t.name, k.name) == 0) {
+        t.ms += ms;
+        t.launches++;
+        found = true;
+        break;
+      }
+    if (!found) ctx->last_times.push_back({k.name, ms, 1});
+  }
+}
+
+// ---- staging helpers for TBK_MEM_HOST ---------------------------------------------------------------
+template <class T>
+static int h2d(tbk_ctx* ctx, const T* src, size_t n, const T** dst) {
+  *dst = nullptr;
+  if (!src) return 0;
+  T* d = ws_alloc<T>(ctx, n ? n : 1);
+  if (!d) return TBK_ENOMEM;
+  if (n) TBK_HIP(hipMemcpyAsync(d, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  *dst = d;
+  return 0;
+}
+template <class T>
+static int dalloc(tbk_ctx* ctx, T* host, size_t n, T** dst) {
+  *dst = nullptr;
+  if (!host) return 0;
+  T* d = ws_alloc<T>(ctx, n ? n : 1);
+  if (!d) return TBK_ENOMEM;
+  *dst = d;
+  return 0;
+}
+template <class T>
+static int d2h(tbk_ctx* ctx, T* host, const T* dev, size_t n) {
+  if (!host || !dev || !n) return 0;
+  TBK_HIP(hipMemcpyAsync(host, dev, n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+  return 0;
+}
+
+// ---- C ABI -----------------------------------------------------------------------------------------
+extern "C" {
+
+int tbk_abi_version(void) { return TBK_ABI_VERSION; }
+
+const char* tbk_strerror(int s) {
+  switch (s) {
+    case TBK_OK: return "ok";
+    case TBK_EINVAL: return "invalid argument";
+    case TBK_ENOMEM: return "out of memory";
+    case TBK_EHIP: return "HIP runtime error";
+    case TBK_E2BIG: return "output capacity too small";
+    case TBK_EUNSUPPORTED: return "option or input outside the supported/pinned semantics";
+    case TBK_EUNSORTED: return "input not coordinate-sorted";
+    case TBK_EFATALOP: return "unknown opcode (tiecov accepts only M/I/D/N/S)";
+    case TBK_ECOLLISION: return "key hash collision survived all reseeds";
+    case TBK_ENODEVICE: return "no usable gfx950 device";
+  }
+  return "unknown status";
+}
+
+int tbk_create(int device_ordinal, tbk_ctx** out) {
+  if (!out) return TBK_EINVAL;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_ordinal < 0 || device_ordinal >= ndev) return TBK_ENODEVICE;
+  tbk_ctx* ctx = new (std::nothrow) tbk_ctx();
+  if (!ctx) return TBK_ENOMEM;
+  ctx->device = device_ordinal;
+  bool ok = hipSetDevice(device_ordinal) == hipSuccess;
+  hipDeviceProp_t prop;
+  if (ok && hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
+  ok = ok && hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) == hipSuccess;
+  ctx->stream = ctx->own_stream;
+  ok = ok && hipMalloc((void**)&ctx->d_err, 256) == hipSuccess;
+  ok = ok && hipMalloc((void**)&ctx->d_scalars, 64 * sizeof(uint64_t)) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&ctx->h_scalars, (64 + 4096) * sizeof(uint64_t), hipHostMallocDefault) == hipSuccess;
+  if (!ok) {
+    tbk_destroy(ctx);
+    return TBK_EHIP;
+  }
+  *out = ctx;
+  return 0;
+}
+
+void tbk_destroy(tbk_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (auto& c : ctx->ws_overflow) (void)hipFree(c.first);
+  for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+  if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->d_view) (void)hipFree(ctx->d_view);
+  if (ctx->d_err) (void)hipFree(ctx->d_err);
+  if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
+  if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+const char* tbk_last_error(const tbk_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int tbk_set_stream(tbk_ctx* ctx, void* s) {
+  if (!ctx) return TBK_EINVAL;
+  ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+  return 0;
+}
+void* tbk_get_stream(tbk_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int tbk_set_profiling(tbk_ctx* ctx, int enabled) {
+  if (!ctx) return TBK_EINVAL;
+  ctx->profiling = enabled != 0;
+  return 0;
+}
+
+int tbk_kernel_times(tbk_ctx* ctx, tbk_kernel_time* out, int cap) {
+  if (!ctx) return TBK_EINVAL;
+  int n = (int)ctx->last_times.size();
+  for (int i = 0; i < n && i < cap; ++i) out[i] = ctx->last_times[i];
+  return n;
+}
+
+int tbk_host_alloc(size_t bytes, void** out) {
+  if (!out) return TBK_EINVAL;
+  return hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? 0 : TBK_ENOMEM;
+}
+void tbk_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
+void tbk_collapse_opts_default(tbk_collapse_opts* o) {
+  if (!o) return;
+  memset(o, 0, sizeof(*o));
+  o->strategy = TBK_STRAT_CIGAR;
+  o->max_nh = INT32_MAX;
+  o->min_qual = -1;
+}
+
+int tbk_coverage_tile(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out) {
+  if (!ctx || !in || !out) return TBK_EINVAL;
+  if (in->n_records && (!in->tid || !in->pos || !in->flag || !in->cig_off || (in->n_cigar_ops && !in->cig))) return TBK_EINVAL;
+  if (out->cap_intervals && (!out->iv_tid || !out->iv_start || !out->iv_end || !out->iv_val)) return TBK_EINVAL;
+  if (out->cap_junctions && (!out->j_tid || !out->j_start || !out->j_end || !out->j_strand || !out->j_val)) return TBK_EINVAL;
+  if (in->mem != out->mem) return TBK_EINVAL;
+  TBK_HIP(hipSetDevice(ctx->device));
+  prof_begin_call(ctx);
+  size_t hint = (size_t)in->n_records * 96 + (size_t)in->n_cigar_ops * 64 + ((size_t)8 << 20);
+  TBK_TRY(ws_begin_call(ctx, hint));
+  int rc;
+  if (in->mem == TBK_MEM_DEVICE) {
+    rc = tbk_coverage_device(ctx, in, out);
+  } else {
+    tbk_cov_in din = *in;
+    tbk_cov_out dout = *out;
+    din.mem = dout.mem = TBK_MEM_DEVICE;
+    size_t n = in->n_records;
+    TBK_TRY(h2d(ctx, in->tid, n, &din.tid));
+    TBK_TRY(h2d(ctx, in->pos, n, &din.pos));
+    TBK_TRY(h2d(ctx, in->flag, n, &din.flag));
+    TBK_TRY(h2d(ctx, in->cig_off, n + 1, &din.cig_off));
+    TBK_TRY(h2d(ctx, in->cig, (size_t)in->n_cigar_ops, &din.cig));
+    TBK_TRY(h2d(ctx, in->yc, n, &din.yc));
+    TBK_TRY(h2d(ctx, in->strand, n, &din.strand));
+    din.yx = nullptr;
+    TBK_TRY(dalloc(ctx, out->iv_tid, out->cap_intervals, &dout.iv_tid));
+    TBK_TRY(dalloc(ctx, out->iv_start, out->cap_intervals, &dout.iv_start));
+    TBK_TRY(dalloc(ctx, out->iv_end, out->cap_intervals, &dout.iv_end));
+    TBK_TRY(dalloc(ctx, out->iv_val, out->cap_intervals, &dout.iv_val));
+    TBK_TRY(dalloc(ctx, out->j_tid, out->cap_junctions, &dout.j_tid));
+    TBK_TRY(dalloc(ctx, out->j_start, out->cap_junctions, &dout.j_start));
+    TBK_TRY(dalloc(ctx, out->j_end, out->cap_junctions, &dout.j_end));
+    TBK_TRY(dalloc(ctx, out->j_strand, out->cap_junctions, &dout.j_strand));
+    TBK_TRY(dalloc(ctx, out->j_val, out->cap_junctions, &dout.j_val));
+    rc = tbk_coverage_device(ctx, &din, &dout);
+    out->n_intervals = dout.n_intervals;
+    out->n_junctions = dout.n_junctions;
+    out->n_bases = dout.n_bases;
+    out->span_bases = dout.span_bases;
+    if (rc == 0) {
+      TBK_TRY(d2h(ctx, out->iv_tid, dout.iv_tid, dout.n_intervals));
+      TBK_TRY(d2h(ctx, out->iv_start, dout.iv_start, dout.n_intervals));
+      TBK_TRY(d2h(ctx, out->iv_end, dout.iv_end, dout.n_intervals));
+      TBK_TRY(d2h(ctx, out->iv_val, dout.iv_val, dout.n_intervals));
+      TBK_TRY(d2h(ctx, out->j_tid, dout.j_tid, dout.n_junctions));
+      TBK_TRY(d2h(ctx, out->j_start, dout.j_start, dout.n_junctions));
+      TBK_TRY(d2h(ctx, out->j_end, dout.j_end, dout.n_junctions));
+      TBK_TRY(d2h(ctx, out->j_strand, dout.j_strand, dout.n_junctions));
+      TBK_TRY(d2h(ctx, out->j_val, dout.j_val, dout.n_junctions));
+      TBK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+  }
+  prof_end_call(ctx);
+  return rc;
+}
+
+int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa_in* in, tbk_groups_out* out) {
+  if (!ctx || !opts || !in || !out) return TBK_EINVAL;
+  if (opts->flags_mask != 0 || opts->keep_unmapped) return TBK_EUNSUPPORTED;
+  if (opts->strategy < 0 || opts->strategy > 3) return TBK_EINVAL;
+  if (in->n_files == 0 || in->n_files > 65535 || !in->file_off) return TBK_EINVAL;
+  if (in->file_off[0] != 0 || in->file_off[in->n_files] != in->n_records) return TBK_EINVAL;
+  if (in->n_records &&
+      (!in->tid || !in->pos || !in->flag || !in->mapq || !in->strand || !in->nh || !in->cig_off || (in->n_cigar_ops && !in->cig)))
+    return TBK_EINVAL;
+  if (!out->rep || !out->yc || !out->yx || !out->yd) return TBK_EINVAL;
+  if (opts->strategy == TBK_STRAT_FULL && (!in->md_off || !in->md_has)) return TBK_EINVAL;
+  if (opts->collapse_same && !in->qname_hash) return TBK_EINVAL;
+  bool any_tb = false;
+  if (in->tbmerged)
+    for (uint32_t f = 0; f < in->n_files; ++f) any_tb |= in->tbmerged[f] != 0;
+  if (any_tb && (!in->yc_in || !in->yx_in || !in->yd_in)) return TBK_EINVAL;
+  if (in->mem != out->mem) return TBK_EINVAL;
+  TBK_HIP(hipSetDevice(ctx->device));
+  prof_begin_call(ctx);
+  size_t hint = (size_t)in->n_records * 160 + (size_t)in->n_cigar_ops * 8 + ((size_t)8 << 20);
+  TBK_TRY(ws_begin_call(ctx, hint));
+  int rc;
+  if (in->mem == TBK_MEM_DEVICE) {
+    rc = tbk_collapse_device(ctx, opts, in, out);
+  } else {
+    tbk_soa_in din = *in;
+    tbk_groups_out dout = *out;
+    din.mem = dout.mem = TBK_MEM_DEVICE;
+    size_t n = in->n_records;
+    TBK_TRY(h2d(ctx, in->tid, n, &din.tid));
+    TBK_TRY(h2d(ctx, in->pos, n, &din.pos));
+    TBK_TRY(h2d(ctx, in->flag, n, &din.flag));
+    TBK_TRY(h2d(ctx, in->mapq, n, &din.mapq));
+    TBK_TRY(h2d(ctx, in->strand, n, &din.strand));
+    TBK_TRY(h2d(ctx, in->nh, n, &din.nh));
+    TBK_TRY(h2d(ctx, in->cig_off, n + 1, &din.cig_off));
+    TBK_TRY(h2d(ctx, in->cig, (size_t)in->n_cigar_ops, &din.cig));
+    TBK_TRY(h2d(ctx, in->yc_in, n, &din.yc_in));
+    TBK_TRY(h2d(ctx, in->yx_in, n, &din.yx_in));
+    TBK_TRY(h2d(ctx, in->yd_in, n, &din.yd_in));
+    TBK_TRY(h2d(ctx, in->md_off, in->md_off ? n + 1 : 0, &din.md_off));
+    TBK_TRY(h2d(ctx, in->md, in->md_off ? (size_t)in->md_off[n] : 0, &din.md));
+    TBK_TRY(h2d(ctx, in->md_has, n, &din.md_has));
+    TBK_TRY(h2d(ctx, in->qname_hash, n, &din.qname_hash));
+    size_t cap = out->cap_groups;
+    TBK_TRY(dalloc(ctx, out->rep, cap, &dout.rep));
+    TBK_TRY(dalloc(ctx, out->yc, cap, &dout.yc));
+    TBK_TRY(dalloc(ctx, out->yx, cap, &dout.yx));
+    TBK_TRY(dalloc(ctx, out->yd, cap, &dout.yd));
+    TBK_TRY(dalloc(ctx, out->g_start, cap, &dout.g_start));
+    TBK_TRY(dalloc(ctx, out->g_end, cap, &dout.g_end));
+    TBK_TRY(dalloc(ctx, out->rec_group, n, &dout.rec_group));
+    rc = tbk_collapse_device(ctx, opts, &din, &dout);
+    out->n_groups = dout.n_groups;
+    out->n_passed = dout.n_passed;
+    if (rc == 0) {
+      size_t g = dout.n_groups;
+      TBK_TRY(d2h(ctx, out->rep, dout.rep, g));
+      TBK_TRY(d2h(ctx, out->yc, dout.yc, g));
+      TBK_TRY(d2h(ctx, out->yx, dout.yx, g));
+      TBK_TRY(d2h(ctx, out->yd, dout.yd, g));
+      TBK_TRY(d2h(ctx, out->g_start, dout.g_start, g));
+      TBK_TRY(d2h(ctx, out->g_end, dout.g_end, g));
+      TBK_TRY(d2h(ctx, out->rec_group, dout.rec_group, n));
+      TBK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+  }
+  prof_end_call(ctx);
+  return rc;
+}
+
+int tbk_sample_tile(tbk_ctx* ctx, const tbk_cov_in* in, int32_t num_samples, tbk_sample_out* out) {
+  if (!ctx || !in || !out || num_samples <= 0) return TBK_EINVAL;
+  if (in->mem != out->mem) return TBK_EINVAL;
+  TBK_HIP(hipSetDevice(ctx->device));
+  prof_begin_call(ctx);
+  TBK_TRY(ws_begin_call(ctx, (size_t)in->n_records * 96 + ((size_t)8 << 20)));
+  int rc;
+  if (in->mem == TBK_MEM_DEVICE) {
+    rc = tbk_sample_device(ctx, in, num_samples, out);
+  } else {
+    tbk_cov_in din = *in;
+    tbk_sample_out dout = *out;
+    din.mem = dout.mem = TBK_MEM_DEVICE;
+    size_t n = in->n_records;
+    TBK_TRY(h2d(ctx, in->tid, n, &din.tid));
+    TBK_TRY(h2d(ctx, in->pos, n, &din.pos));
+    TBK_TRY(h2d(ctx, in->flag, n, &din.flag));
+    TBK_TRY(h2d(ctx, in->cig_off, n + 1, &din.cig_off));
+    TBK_TRY(h2d(ctx, in->cig, (size_t)in->n_cigar_ops, &din.cig));
+    TBK_TRY(h2d(ctx, in->yx, n, &din.yx));
+    din.yc = nullptr;
+    din.strand = nullptr;
+    TBK_TRY(dalloc(ctx, out->iv_tid, out->cap_intervals, &dout.iv_tid));
+    TBK_TRY(dalloc(ctx, out->iv_start, out->cap_intervals, &dout.iv_start));
+    TBK_TRY(dalloc(ctx, out->iv_end, out->cap_intervals, &dout.iv_end));
+    TBK_TRY(dalloc(ctx, out->iv_count, out->cap_intervals, &dout.iv_count));
+    TBK_TRY(dalloc(ctx, out->iv_heat, out->cap_intervals, &dout.iv_heat));
+    rc = tbk_sample_device(ctx, &din, num_samples, &dout);
+    out->n_intervals = dout.n_intervals;
+    if (rc == 0) {
+      size_t g = dout.n_intervals;
+      TBK_TRY(d2h(ctx, out->iv_tid, dout.iv_tid, g));
+      TBK_TRY(d2h(ctx, out->iv_start, dout.iv_start, g));
+      TBK_TRY(d2h(ctx, out->iv_end, dout.iv_end, g));
+      TBK_TRY(d2h(ctx, out->iv_count, dout.iv_count, g));
+      TBK_TRY(d2h(ctx, out->iv_heat, dout.iv_heat, g));
+      TBK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+  }
+  prof_end_call(ctx);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,133 @@
+// tbk_internal.h — context, workspace arena, launch/profiling helpers shared by the
+// HIP translation units behind include/tbk.h.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/tbk.h"
+
+// error bits raised by kernels (device word tbk_ctx::d_err)
+enum : uint32_t {
+  TBK_DERR_UNSORTED = 1u << 0,
+  TBK_DERR_COLLISION = 1u << 1,
+  TBK_DERR_FATALOP = 1u << 2,
+  TBK_DERR_SPAN = 1u << 3,      // read span >= 2^30
+  TBK_DERR_NCIGAR = 1u << 4,    // tiecov: n_cigar >= 256 never terminates in the reference
+  TBK_DERR_FRACTIONAL = 1u << 5, // non-integral YC met by an integer-only kernel
+  TBK_DERR_OVERFLOW = 1u << 6,
+  TBK_DERR_INTERNAL = 1u << 7
+};
+
+struct KTime {
+  const char* name;
+  hipEvent_t a, b;
+};
+
+struct tbk_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  // device workspace (bump allocator, reset at the start of each API call)
+  char* ws = nullptr;
+  size_t ws_cap = 0, ws_off = 0;
+  std::vector<std::pair<char*, size_t>> ws_overflow;
+  size_t ws_over_used = 0;
+  // small persistent device words + pinned mirror
+  uint32_t* d_err = nullptr;    // [1]
+  uint64_t* d_scalars = nullptr; // [64] misc device scalars (counts)
+  uint64_t* h_scalars = nullptr; // pinned [64+4096]
+  // pinned staging for TBK_MEM_HOST callers
+  char* h_stage = nullptr;
+  size_t h_stage_cap = 0;
+  char* d_stage = nullptr;  // device copies of host inputs / outputs
+  size_t d_stage_cap = 0, d_stage_off = 0;
+  // view storage for tbk_groups_to_cov_in
+  char* d_view = nullptr;
+  size_t d_view_cap = 0;
+  bool profiling = false;
+  std::vector<KTime> ktimes;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  std::vector<tbk_kernel_time> last_times;
+  std::string last_error;
+  int num_cu = 256;
+};
+
+#define TBK_HIP(call)                                                                            \
+  do {                                                                                           \
+    hipError_t _e = (call);                                                                      \
+    if (_e != hipSuccess) {                                                                      \
+      char _b[512];                                                                              \
+      snprintf(_b, sizeof(_b), "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(_e)); \
+      ctx->last_error = _b;                                                                      \
+      return TBK_EHIP;                                                                           \
+    }                                                                                            \
+  } while (0)
+
+#define TBK_TRY(expr)        \
+  do {                       \
+    int _rc = (expr);        \
+    if (_rc != 0) return _rc; \
+  } while (0)
+
+// ---- workspace ------------------------------------------------------------------
+int tbk_ws_reserve(tbk_ctx* ctx, size_t bytes);  // grow (frees + reallocates) if needed; resets the bump pointer
+void* tbk_ws_alloc_raw(tbk_ctx* ctx, size_t bytes);
+template <class T>
+static inline T* ws_alloc(tbk_ctx* ctx, size_t n) {
+  return (T*)tbk_ws_alloc_raw(ctx, n * sizeof(T));
+}
+
+// ---- launches --------------------------------------------------------------------
+hipEvent_t tbk_event(tbk_ctx* ctx);
+static inline void tbk_prof_begin(tbk_ctx* ctx, const char* name) {
+  if (!ctx->profiling) return;
+  KTime k{name, tbk_event(ctx), tbk_event(ctx)};
+  (void)hipEventRecord(k.a, ctx->stream);
+  ctx->ktimes.push_back(k);
+}
+static inline void tbk_prof_end(tbk_ctx* ctx) {
+  if (!ctx->profiling) return;
+  (void)hipEventRecord(ctx->ktimes.back().b, ctx->stream);
+}
+
+#define TBK_LAUNCH(ctx, name, kern, grid, block, shmem, ...)                          \
+  do {                                                                                \
+    tbk_prof_begin(ctx, name);                                                        \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), shmem, (ctx)->stream, __VA_ARGS__); \
+    tbk_prof_end(ctx);                                                                \
+  } while (0)
+
+int tbk_check_launch(tbk_ctx* ctx, const char* what);  // hipGetLastError -> TBK_EHIP
+int tbk_sync_err(tbk_ctx* ctx, uint32_t* err_bits);    // stream sync + read d_err
+int tbk_derr_to_status(tbk_ctx* ctx, uint32_t bits);
+
+static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// ---- primitives implemented in prims.hip -------------------------------------------
+// exclusive prefix sum of u32 -> u32 (n may be 0); total (u64) written to d_total if non-null
+int tbk_exscan_u32(tbk_ctx* ctx, const uint32_t* in, uint32_t* out, uint32_t n, uint64_t* d_total);
+// exclusive prefix sum of u32 -> u64
+int tbk_exscan_u32_u64(tbk_ctx* ctx, const uint32_t* in, uint64_t* out, uint32_t n, uint64_t* d_total);
+
+// LSD radix sort of (hi,lo) 128-bit keys with a u32 payload; result left in *hi/*lo/*val
+// (the routine ping-pongs between the given buffers and swaps the pointers for the caller).
+struct SortBufs {
+  uint64_t *hi, *lo;
+  uint32_t* val;
+  uint64_t *hi2, *lo2;
+  uint32_t* val2;
+};
+int tbk_radix_sort128(tbk_ctx* ctx, SortBufs* b, uint32_t n);
+size_t tbk_radix_ws_bytes(uint32_t n);
+
+// ---- pipelines --------------------------------------------------------------------
+int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_in* in, tbk_groups_out* out);
+int tbk_coverage_device(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out);
+int tbk_sample_device(tbk_ctx* ctx, const tbk_cov_in* in, int32_t num_samples, tbk_sample_out* out);
