@@ -75,6 +75,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    # One HIP runtime per process: torch bundles its own libamdhip64.so.7 / libhsa-runtime64; load it
+    # FIRST so that libtbk.so's NEEDED libamdhip64.so.7 binds to that already-loaded copy instead of
+    # pulling in /opt/rocm's second runtime (two runtimes in one process cannot both own the GPU).
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # standalone use without torch: the system ROCm runtime is the only one
+        pass
     L = C.CDLL(LIB_PATH)
     L.tbk_abi_version.restype = C.c_int
     L.tbk_create.argtypes = [C.c_int, C.POINTER(_P)]
