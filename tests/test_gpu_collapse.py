@@ -1,0 +1,206 @@
+"""GPU parity: tbk_collapse_tile (HIP) vs the CPU oracle, bit-exact on every output array, plus the
+reference's golden BAMs through the SURVEY.md §4.4 normaliser."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, sample_paths, compare_groups_to_golden_bam
+
+pytestmark = pytest.mark.gpu
+KEYS = ("rep", "yc", "yx", "yd", "g_start", "g_end", "rec_group")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from tiebrush_amd import api
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def _check(ctx, tile, device=True, **kw):
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import api
+    okw = dict(kw)
+    if "strategy" in okw and isinstance(okw["strategy"], str):
+        okw["strategy"] = {"cigar": 0, "full": 1, "clip": 2, "exon": 3}[okw["strategy"]]
+    want = orc.collapse(tile, want_rec_group=True, **okw)
+    got = api.to_numpy(ctx.collapse(api.to_device(tile, "cuda:0") if device else tile, want_rec_group=True, **kw))
+    assert got["n_passed"] == want["n_passed"]
+    assert got["n_groups"] == want["n_groups"]
+    for k in KEYS:
+        assert np.array_equal(np.asarray(got[k]), np.asarray(want[k])), k
+    return got, want
+
+
+@pytest.mark.parametrize("name", ["t1", "t2"])
+def test_golden_samples(ctx, name, bam_loader):
+    from tiebrush_amd import soa
+    bams = [bam_loader(p) for p in sample_paths(name)]
+    tile = soa.tile_from_bams(bams, with_names=True)
+    gold = bam_loader(os.path.join(GOLDEN, name, name + ".bam"))
+    got, _ = _check(ctx, tile, collapse_same=True)          # 0.0.6 semantics of the goldens == HEAD with -A
+    assert compare_groups_to_golden_bam(got, tile, bams, gold) == []
+    _check(ctx, tile)                                       # HEAD default
+    _check(ctx, tile, device=False)                         # host-pointer mode
+
+
+def test_golden_t12_tbmerged(ctx, bam_loader):
+    from tiebrush_amd import soa
+    bams = [bam_loader(os.path.join(GOLDEN, "t1", "t1.bam")), bam_loader(os.path.join(GOLDEN, "t2", "t2.bam"))]
+    tile = soa.tile_from_bams(bams, with_names=True)
+    gold = bam_loader(os.path.join(GOLDEN, "t12.bam"))
+    got, _ = _check(ctx, tile, collapse_same=True)
+    assert compare_groups_to_golden_bam(got, tile, bams, gold) == []
+
+
+def test_golden_full_strategy_with_md(ctx, bam_loader):
+    from tiebrush_amd import soa
+    bams = [bam_loader(p, keep_md=True) for p in sample_paths("t2")[:4]]
+    tile = soa.tile_from_bams(bams, with_md=True)
+    _check(ctx, tile, strategy="full")
+
+
+@pytest.mark.parametrize("profile,kw", [
+    ("c2", {}),
+    ("c3", dict(strategy="clip")),
+    ("c5", dict(strategy="exon", max_nh=5, min_qual=1)),
+    ("c5", dict(strategy="cigar", keep_secondary=True, keep_supplementary=True)),
+    ("c3", dict(strategy="exon")),
+])
+def test_synthetic(ctx, profile, kw):
+    from tiebrush_amd import synth
+    tile = synth.make_tile(4, 60000, profile, n_loci=2000)
+    _check(ctx, tile, **kw)
+
+
+def test_many_files(ctx):
+    from tiebrush_amd import synth
+    tile = synth.make_tile(64, 4000, "c2", n_loci=300)
+    _check(ctx, tile)
+
+
+def _mk(files, tb=None):
+    """files: list of lists of (tid,pos,flag,mapq,strand,nh,cigar[(len,op)..][,yc,yx,yd])"""
+    from tiebrush_amd import soa
+    recs = [r for f in files for r in f]
+    n = len(recs)
+    fo = np.zeros(len(files) + 1, np.uint32)
+    fo[1:] = np.cumsum([len(f) for f in files])
+    cigs = [[(l << 4) | o for l, o in r[6]] for r in recs]
+    off = np.zeros(n + 1, np.uint32)
+    off[1:] = np.cumsum([len(c) for c in cigs])
+    t = soa.SoATile(
+        n_files=len(files), file_off=fo, tbmerged=np.array(tb if tb else [0] * len(files), np.uint8),
+        tid=np.array([r[0] for r in recs], np.int32), pos=np.array([r[1] for r in recs], np.int32),
+        flag=np.array([r[2] for r in recs], np.uint16), mapq=np.array([r[3] for r in recs], np.uint8),
+        strand=np.array([ord(r[4]) for r in recs], np.uint8), nh=np.array([r[5] for r in recs], np.int32),
+        cig_off=off, cig=np.array([x for c in cigs for x in c], np.uint32))
+    if tb and any(tb):
+        t.yc_in = np.array([r[7] if len(r) > 7 else 0.0 for r in recs], np.float64)
+        t.yx_in = np.array([r[8] if len(r) > 8 else 1 for r in recs], np.int64)
+        t.yd_in = np.array([r[9] if len(r) > 9 else 0 for r in recs], np.int64)
+    return t
+
+
+M, I, D, N, S, H = 0, 1, 2, 3, 4, 5
+
+
+def test_tie_break_and_order(ctx):
+    """same (start,end,strand) with different CIGARs: n_cigar first, then memcmp of the little-endian words;
+    strand order '+' < '-' < '.'; representative decided by the merge order (prefix-max of end per file)."""
+    f0 = [
+        (0, 100, 0, 60, "+", 1, [(50, M), (100, N), (50, M)]),     # end 300
+        (0, 100, 0, 60, "+", 1, [(100, M)]),                       # end 200: its effective key is (100,300) in file 0
+        (0, 100, 0, 60, ".", 1, [(100, M)]),
+        (0, 100, 0, 60, "-", 1, [(100, M)]),
+        (0, 100, 0, 60, "+", 1, [(40, M), (120, N), (40, M)]),     # end 300, 3 ops
+        (0, 100, 0, 60, "+", 1, [(256, M)]),                       # memcmp is byte-wise on little-endian words
+        (0, 100, 0, 60, "+", 1, [(17, M), (222, D), (17, M)]),
+        (0, 100, 0, 60, "+", 1, [(3, S), (100, M)]),               # soft clip: differs under cigar, equal under clip
+        (0, 300, 0, 60, "+", 1, [(16, M), (1, I), (16, M)]),
+        (0, 300, 0, 60, "+", 1, [(32, M)]),
+        (0, 300, 0, 60, "+", 1, [(16, M), (2, D), (14, M)]),       # same exon as 32M
+    ]
+    f1 = [
+        (0, 100, 0, 60, "+", 1, [(100, M)]),                       # pops before file 0's 100M (end 200 < 300)
+        (0, 100, 16, 60, "+", 1, [(50, M), (100, N), (50, M)]),
+        (0, 100, 0, 60, "+", 1, [(200, M), (1, I)]),               # end 300
+        (0, 300, 0, 60, "+", 1, [(32, M)]),
+        (1, 5, 0, 60, ".", 1, [(10, M)]),
+        (2, 5, 0, 60, ".", 1, [(10, M)]),
+    ]
+    tile = _mk([f0, f1])
+    for strat in ("cigar", "clip", "exon"):
+        got, want = _check(ctx, tile, strategy=strat)
+    got, want = _check(ctx, tile)
+    # the 100M '+' group: file 1's record pops first (its key end is 200, file 0's is held back by the 300)
+    k = [i for i in range(got["n_groups"]) if got["g_end"][i] == 200 and got["yc"][i] == 2.0]
+    assert len(k) == 1 and got["rep"][k[0]] == len(f0)
+
+
+def test_filters_and_unmapped(ctx):
+    f0 = [
+        (0, 10, 4, 0, ".", -(2**31), []),                # unmapped, placed first
+        (0, 10, 0, 60, ".", 1, [(50, M)]),
+        (0, 10, 0x100, 60, ".", 1, [(50, M)]),           # secondary
+        (0, 10, 0x800, 60, ".", 1, [(50, M)]),           # supplementary
+        (0, 10, 0, 3, ".", 1, [(50, M)]),                # low mapq
+        (0, 10, 0, 60, ".", 7, [(50, M)]),               # NH 7
+        (0, 10, 0, 60, ".", -(2**31), [(50, M)]),        # NH absent -> 0 for the filter
+        (0, 20, 4, 0, ".", 1, [(50, M)]),                # unmapped in the middle (start=end=0)
+        (0, 30, 0, 60, ".", 1, [(50, M)]),
+        (-1, -1, 4, 0, ".", 1, []),                      # unmapped tail
+    ]
+    f1 = [(0, 10, 0, 60, ".", 1, [(50, M)]), (0, 30, 0, 60, ".", 2, [(50, M)])]
+    tile = _mk([f0, f1, []])
+    _check(ctx, tile)
+    _check(ctx, tile, max_nh=5, min_qual=10)
+    _check(ctx, tile, keep_secondary=True, keep_supplementary=True)
+    _check(ctx, tile, max_nh=0)
+    got, _ = _check(ctx, tile, min_qual=61)              # everything filtered
+    assert got["n_groups"] == 0
+
+
+def test_tbmerged_mixed_with_plain(ctx):
+    f0 = [(0, 10, 0, 60, "+", 1, [(50, M)], 3.0, 2, 7), (0, 10, 0, 60, "+", 1, [(50, M)], 0.0, 1, 0),
+          (0, 40, 0, 60, "-", 1, [(20, M), (100, N), (30, M)], 300.0, 254, 255)]
+    f1 = [(0, 10, 0, 60, "+", 1, [(50, M)]), (0, 10, 0, 60, "+", 1, [(50, M)]),
+          (0, 40, 0, 60, "-", 1, [(20, M), (100, N), (30, M)])]
+    f2 = [(0, 5, 0, 60, "+", 1, [(50, M)]), (0, 10, 0, 60, "+", 1, [(50, M)])]
+    _check(ctx, _mk([f0, f1, f2], tb=[1, 0, 0]))
+    _check(ctx, _mk([f1, f0, f2], tb=[0, 1, 0]))
+
+
+def test_empty_and_tiny(ctx):
+    tile = _mk([[], []])
+    got = ctx.collapse(tile)
+    assert got["n_groups"] == 0 and got["n_passed"] == 0
+    _check(ctx, _mk([[(0, 0, 0, 60, ".", 1, [(1, M)])]]))
+
+
+def test_unsorted_input_is_rejected(ctx):
+    from tiebrush_amd import api
+    tile = _mk([[(0, 100, 0, 60, ".", 1, [(10, M)]), (0, 50, 0, 60, ".", 1, [(10, M)])]])
+    with pytest.raises(api.TbkError) as ei:
+        ctx.collapse(tile)
+    assert ei.value.status == -6
+
+
+def test_unsupported_options_fail_loudly(ctx):
+    from tiebrush_amd import api
+    tile = _mk([[(0, 100, 0, 60, ".", 1, [(10, M)])]])
+    for kw in (dict(flags_mask=4), dict(keep_unmapped=True)):
+        with pytest.raises(api.TbkError) as ei:
+            ctx.collapse(tile, **kw)
+        assert ei.value.status == -5
+
+
+def test_yd_stress_spliced(ctx):
+    """few loci, many samples: long YD chains with splice variants exercise the list machine incl. the
+    mergeRead tail drop"""
+    from tiebrush_amd import synth
+    tile = synth.make_tile(12, 20000, "c2", n_loci=40)
+    got, want = _check(ctx, tile)
+    assert want["yd"].max() > 100

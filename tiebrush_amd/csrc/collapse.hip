@@ -1,9 +1,929 @@
-// collapse.hip — placeholder until the collapse pipeline lands
+// collapse.hip — tiebrush hot path on gfx950: k-way coordinate merge order, duplicate-group
+// detection, YC/YX reduction, representative selection, bucket ordering and the YD machine.
+//
+// Reference semantics (paths relative to /root/reference/src):
+//   merge order      tmerge.h:28-50, tmerge.cpp:331-344: greedy k-way merge on (tid,start,end,fidx)
+//                    == sort by (per-file prefix-max of (tid,start,end), fidx, idx)   [SURVEY.md §3.1]
+//   filter           tiebrush.cpp:532-541 (passes_options) — applied AFTER the order is fixed
+//   bucket / group   tiebrush.cpp:477-499, :438-457: same (tid,start) bucket; group key
+//                    (tstrand,end,strategy key); list order = (strand char, end, strategy compare)
+//   accumulate       tiebrush.cpp:378-436 (settle/dupAdd), flush :501-530
+//   YD               tiebrush.cpp:111-250 (GSegList) called per sample & strand list at flush
+//
+// GPU formulation.  Every record gets a 128-bit sort key
+//      hi = (tid+1 : 32 | start : 32)            -> bucket order
+//      lo = (strand code : 2 | span : 30 | h32)  -> (strand, end) order inside the bucket, then a
+//                                                   32-bit slice of a seeded 64-bit hash of the strategy key
+// and the passing records are LSD-radix sorted (stable, so equal keys stay in file-major order).
+// Groups are runs of equal keys; adjacent members are verified against the full strategy key, a
+// hash collision raises TBK_DERR_COLLISION and the host retries with another seed.  Per group a
+// wave-segmented reduction + one atomic per (wave, group) gives YC, |samples|, sum YX, max YD and
+// the representative = argmin (effend, record index), where effend is the per-file running max of
+// `end` (the merge-order key).  Groups that tie on (bucket,strand,end) are re-ordered by the
+// reference comparator (n_cigar, memcmp, ...).  The YD list machine is sequential per
+// (sample,strand) list; it is cut at provable renewal points (read start beyond every earlier end
+// of that list, or a chromosome change) into independent chains, one GPU thread each.
+#include "dev_common.cuh"
+#include "scan_op.cuh"
 #include "tbk_internal.h"
-int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts*, const tbk_soa_in*, tbk_groups_out*) {
-  ctx->last_error = "collapse pipeline not built";
-  return TBK_EUNSUPPORTED;
+
+namespace {
+
+struct ColIn {
+  uint32_t n, k;
+  const uint32_t* file_off;  // device copy [k+1]
+  const uint8_t* tbm;        // device copy [k]
+  const int32_t *tid, *pos;
+  const uint16_t* flag;
+  const uint8_t *mapq, *strand;
+  const int32_t* nh;
+  const uint32_t *cig_off, *cig;
+  const double* yc_in;
+  const int64_t *yx_in, *yd_in;
+  const uint32_t* md_off;
+  const uint8_t *md, *md_has;
+  const uint64_t* qh;
+};
+
+struct ColOpt {
+  int strategy;
+  int max_nh, min_qual;
+  int keep_supp, keep_sec, collapse_same, store_frac;
+  uint64_t seed;
+};
+
+__device__ __forceinline__ uint32_t strand_code(uint8_t s) { return s == '+' ? 0u : (s == '-' ? 1u : 2u); }
+
+// clipped CIGAR view (cmpCigarClip tiebrush.cpp:312-332)
+__device__ __forceinline__ void clip_view(const uint32_t* __restrict__ c, uint32_t n, uint32_t* b, uint32_t* e) {
+  uint32_t s = 0, t = n;
+  while (s < t && cig_op(c[s]) == C_S) ++s;
+  while (t > s && cig_op(c[t - 1]) == C_S) --t;
+  *b = s;
+  *e = t;
 }
+
+__device__ uint64_t strategy_hash(const ColIn& I, const ColOpt& O, uint32_t i) {
+  const uint32_t* c = I.cig + I.cig_off[i];
+  uint32_t n = I.cig_off[i + 1] - I.cig_off[i];
+  uint64_t h = O.seed;
+  switch (O.strategy) {
+    case TBK_STRAT_CIGAR:
+    case TBK_STRAT_FULL: {
+      h = hash_step(h, n);
+      for (uint32_t k = 0; k < n; ++k) h = hash_step(h, c[k]);
+      if (O.strategy == TBK_STRAT_FULL) {
+        uint32_t has = I.md_has[i];
+        h = hash_step(h, has);
+        if (has) {
+          uint32_t m0 = I.md_off[i], m1 = I.md_off[i + 1];
+          h = hash_step(h, m1 - m0);
+          for (uint32_t k = m0; k < m1; ++k) h = hash_step(h, I.md[k]);
+        }
+      }
+      break;
+    }
+    case TBK_STRAT_CLIP: {
+      uint32_t b, e;
+      clip_view(c, n, &b, &e);
+      h = hash_step(h, e - b);
+      for (uint32_t k = b; k < e; ++k) h = hash_step(h, c[k]);
+      break;
+    }
+    case TBK_STRAT_EXON: {
+      int nex = 0;
+      walk_exons(I.pos[i], c, n, [&](int s, int e) { h = hash_step(h, ((uint64_t)(uint32_t)s << 32) | (uint32_t)e); }, &nex);
+      h = hash_step(h, (uint64_t)nex);
+      break;
+    }
+  }
+  return h;
+}
+
+// exact equality of the strategy keys of two records (start/end/strand are already equal)
+__device__ bool strategy_equal(const ColIn& I, int strategy, uint32_t a, uint32_t b) {
+  const uint32_t* ca = I.cig + I.cig_off[a];
+  const uint32_t* cb = I.cig + I.cig_off[b];
+  uint32_t na = I.cig_off[a + 1] - I.cig_off[a], nb = I.cig_off[b + 1] - I.cig_off[b];
+  switch (strategy) {
+    case TBK_STRAT_CIGAR:
+    case TBK_STRAT_FULL: {
+      if (na != nb) return false;
+      for (uint32_t k = 0; k < na; ++k)
+        if (ca[k] != cb[k]) return false;
+      if (strategy == TBK_STRAT_FULL) {
+        uint32_t ha = I.md_has[a], hb = I.md_has[b];
+        if (ha != hb) return false;
+        if (ha) {
+          uint32_t la = I.md_off[a + 1] - I.md_off[a], lb = I.md_off[b + 1] - I.md_off[b];
+          if (la != lb) return false;
+          for (uint32_t k = 0; k < la; ++k)
+            if (I.md[I.md_off[a] + k] != I.md[I.md_off[b] + k]) return false;
+        }
+      }
+      return true;
+    }
+    case TBK_STRAT_CLIP: {
+      uint32_t ba, ea, bb, eb;
+      clip_view(ca, na, &ba, &ea);
+      clip_view(cb, nb, &bb, &eb);
+      if (ea - ba != eb - bb) return false;
+      for (uint32_t k = 0; k < ea - ba; ++k)
+        if (ca[ba + k] != cb[bb + k]) return false;
+      return true;
+    }
+    case TBK_STRAT_EXON: {
+      // same exon list: hash both walks with two independent seeds and compare element-wise through
+      // a lock-step re-walk: exon lists are short, so walk b for every exon index of a
+      int nxa = 0, nxb = 0;
+      bool eq = true;
+      int ia = 0;
+      walk_exons(I.pos[a], ca, na,
+                 [&](int s, int e) {
+                   int ib = 0, cnt = 0;
+                   bool found = false;
+                   walk_exons(I.pos[b], cb, nb,
+                              [&](int s2, int e2) {
+                                if (ib == ia) found = (s2 == s && e2 == e);
+                                ++ib;
+                              },
+                              &cnt);
+                   if (!found) eq = false;
+                   ++ia;
+                 },
+                 &nxa);
+      walk_exons(I.pos[b], cb, nb, [](int, int) {}, &nxb);
+      return eq && nxa == nxb;
+    }
+  }
+  return false;
+}
+
+// three-way compare of the strategy keys in the reference's order (cmpCigar & co, tiebrush.cpp:285-345)
+__device__ int strategy_cmp(const ColIn& I, int strategy, uint32_t a, uint32_t b) {
+  const uint32_t* ca = I.cig + I.cig_off[a];
+  const uint32_t* cb = I.cig + I.cig_off[b];
+  uint32_t na = I.cig_off[a + 1] - I.cig_off[a], nb = I.cig_off[b + 1] - I.cig_off[b];
+  auto memcmp_u32 = [](const uint32_t* x, const uint32_t* y, uint32_t n) -> int {
+    for (uint32_t k = 0; k < n; ++k) {
+      if (x[k] != y[k]) {  // memcmp over little-endian words: lowest byte first
+        uint32_t xs = __builtin_bswap32(x[k]), ys = __builtin_bswap32(y[k]);
+        return xs < ys ? -1 : 1;
+      }
+    }
+    return 0;
+  };
+  switch (strategy) {
+    case TBK_STRAT_CIGAR:
+    case TBK_STRAT_FULL: {
+      if (na != nb) return (int)na - (int)nb;
+      int c = memcmp_u32(ca, cb, na);
+      if (c != 0 || strategy == TBK_STRAT_CIGAR) return c;
+      uint32_t ha = I.md_has[a], hb = I.md_has[b];
+      if (!ha || !hb) {
+        if (ha == hb) return 0;
+        return ha ? 1 : -1;
+      }
+      uint32_t la = I.md_off[a + 1] - I.md_off[a], lb = I.md_off[b + 1] - I.md_off[b];
+      uint32_t m = la < lb ? la : lb;
+      for (uint32_t k = 0; k < m; ++k) {
+        uint8_t x = I.md[I.md_off[a] + k], y = I.md[I.md_off[b] + k];
+        if (x != y) return x < y ? -1 : 1;
+      }
+      if (la == lb) return 0;
+      return la < lb ? -1 : 1;
+    }
+    case TBK_STRAT_CLIP: {
+      uint32_t ba, ea, bb, eb;
+      clip_view(ca, na, &ba, &ea);
+      clip_view(cb, nb, &bb, &eb);
+      if (ea - ba != eb - bb) return (int)(ea - ba) - (int)(eb - bb);
+      return memcmp_u32(ca + ba, cb + bb, ea - ba);
+    }
+    case TBK_STRAT_EXON: {
+      int nxa = 0, nxb = 0;
+      walk_exons(I.pos[a], ca, na, [](int, int) {}, &nxa);
+      walk_exons(I.pos[b], cb, nb, [](int, int) {}, &nxb);
+      if (nxa != nxb) return nxa - nxb;
+      int res = 0, ia = 0;
+      walk_exons(I.pos[a], ca, na,
+                 [&](int s, int e) {
+                   if (res == 0) {
+                     int ib = 0, cnt = 0;
+                     walk_exons(I.pos[b], cb, nb,
+                                [&](int s2, int e2) {
+                                  if (ib == ia && res == 0) {
+                                    if (s != s2)
+                                      res = s - s2;
+                                    else if (e != e2)
+                                      res = e - e2;
+                                  }
+                                  ++ib;
+                                },
+                                &cnt);
+                   }
+                   ++ia;
+                 },
+                 &nxa);
+      return res;
+    }
+  }
+  return 0;
+}
+
+// ---- K1: keys --------------------------------------------------------------------------------------
+struct EffKey {  // scan element: lexicographic running max of (hi, end) per file + count of passing records
+  uint64_t khi;
+  int32_t kend;
+  uint32_t flag;
+  uint32_t cnt;
+  uint32_t pad;
+};
+struct EffOp {
+  __device__ __forceinline__ EffKey operator()(const EffKey& a, const EffKey& b) const {
+    EffKey r;
+    bool take_b = b.flag || b.khi > a.khi || (b.khi == a.khi && b.kend > a.kend);
+    r.khi = take_b ? b.khi : a.khi;
+    r.kend = take_b ? b.kend : a.kend;
+    r.flag = a.flag | b.flag;
+    r.cnt = a.cnt + b.cnt;
+    r.pad = 0;
+    return r;
+  }
+};
+
+__global__ void col_keys_k(ColIn I, ColOpt O, uint64_t* __restrict__ khi, uint64_t* __restrict__ klo, int32_t* __restrict__ kend,
+                           uint8_t* __restrict__ kflags /*bit0 pass, bit1 file head*/, uint16_t* __restrict__ fidx,
+                           uint32_t* __restrict__ err) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= I.n) return;
+  uint32_t lo = 0, hi = I.k;  // last f with file_off[f] <= i
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (I.file_off[mid] <= i)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  uint32_t f = lo;
+  uint16_t fl = I.flag[i];
+  int start = 0, end = 0;
+  if (!(fl & 0x4)) {
+    int l = cigar_reflen(I.cig + I.cig_off[i], I.cig_off[i + 1] - I.cig_off[i]);
+    start = I.pos[i] + 1;
+    end = I.pos[i] + l;
+  }
+  bool pass = true;  // passes_options, tiebrush.cpp:532-541
+  if (!O.keep_supp && (fl & 0x800)) pass = false;
+  if (!O.keep_sec && (fl & 0x100)) pass = false;
+  if (fl & 0x4) pass = false;  // keep_unmapped is rejected at the ABI
+  if ((int)I.mapq[i] < O.min_qual) pass = false;
+  int nh = I.nh[i] == TBK_NH_ABSENT ? 0 : I.nh[i];
+  if (nh > O.max_nh) pass = false;
+  uint64_t h = pass ? strategy_hash(I, O, i) : 0ull;
+  int64_t span = (int64_t)end - (int64_t)start + 1;
+  if (pass && (span < 0 || span >= (1ll << 30))) {
+    atomicOr(err, TBK_DERR_SPAN);
+    span = 0;
+  }
+  khi[i] = ((uint64_t)(uint32_t)(I.tid[i] + 1) << 32) | (uint32_t)start;
+  klo[i] = ((uint64_t)strand_code(I.strand[i]) << 62) | ((uint64_t)span << 32) | (h >> 32);
+  kend[i] = end;
+  kflags[i] = (pass ? 1u : 0u) | (i == I.file_off[f] ? 2u : 0u);
+  fidx[i] = (uint16_t)f;
+}
+
+struct EffLoad {
+  const uint64_t* khi;
+  const int32_t* kend;
+  const uint8_t* kflags;
+  __device__ __forceinline__ EffKey operator()(uint32_t i) const {
+    EffKey e;
+    e.khi = khi[i];
+    e.kend = kend[i];
+    uint8_t f = kflags[i];
+    e.flag = (f >> 1) & 1u;
+    e.cnt = f & 1u;
+    e.pad = 0;
+    return e;
+  }
+};
+struct EffStore {
+  const uint64_t* khi;
+  const uint64_t* klo;
+  const uint8_t* kflags;
+  int32_t* effend;
+  uint64_t* chi;
+  uint64_t* clo;
+  uint32_t* cval;
+  uint64_t* n_pass;
+  uint32_t n;
+  uint32_t* err;
+  __device__ __forceinline__ void operator()(uint32_t i, const EffKey& inc, const EffKey& ex) const {
+    if (kflags[i] & 1u) {
+      if (inc.khi != khi[i]) atomicOr(err, TBK_DERR_UNSORTED);  // an earlier record of the file has a larger (tid,start)
+      effend[i] = inc.kend;
+      uint32_t d = ex.cnt;
+      chi[d] = khi[i];
+      clo[d] = klo[i];
+      cval[d] = i;
+    }
+    if (i + 1 == n) *n_pass = inc.cnt;
+  }
+};
+
+// ---- K4: heads -------------------------------------------------------------------------------------
+// flags: bit0 group head, bit1 tie-set head, bit2 file head (first record of its file in the group)
+__global__ void col_heads_k(ColIn I, int strategy, uint32_t m, const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo,
+                            const uint32_t* __restrict__ val, const uint16_t* __restrict__ fidx, uint8_t* __restrict__ flags,
+                            uint32_t* __restrict__ ghead, uint32_t* __restrict__ err) {
+  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= m) return;
+  uint32_t gi = val[q];
+  bool bucket_head = true, group_head = true, tie_head = true, file_head = true;
+  if (q > 0) {
+    uint32_t pv = val[q - 1];
+    bucket_head = hi[q] != hi[q - 1];
+    group_head = bucket_head || lo[q] != lo[q - 1];
+    tie_head = bucket_head || (lo[q] >> 32) != (lo[q - 1] >> 32);
+    if (!group_head && !strategy_equal(I, strategy, gi, pv)) atomicOr(err, TBK_DERR_COLLISION);
+    file_head = group_head || fidx[gi] != fidx[pv];
+  }
+  flags[q] = (group_head ? 1u : 0u) | (tie_head ? 2u : 0u) | (file_head ? 4u : 0u);
+  ghead[q] = group_head ? 1u : 0u;
+}
+
+struct GroupAcc {
+  double* yc;
+  uint32_t* ns;
+  long long* yxin;
+  long long* ydin;
+  unsigned long long* rep;
+  uint32_t* first;  // sorted position of the group head
+  uint8_t* tie;
+};
+
+// wave-segmented reductions over lanes holding equal (sorted) keys
+template <class T, class Op>
+__device__ __forceinline__ T seg_reduce(T v, uint32_t key, Op op) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    T o = __shfl_up(v, d, 64);
+    uint32_t ok = __shfl_up(key, d, 64);
+    if ((int)lane_id() >= d && ok == key) v = op(v, o);
+  }
+  return v;
+}
+
+__global__ void col_reduce_k(ColIn I, ColOpt O, uint32_t m, const uint32_t* __restrict__ val, const uint8_t* __restrict__ flags,
+                             const uint32_t* __restrict__ gex, const uint16_t* __restrict__ fidx,
+                             const int32_t* __restrict__ effend, GroupAcc G, uint32_t* __restrict__ sgid, uint32_t* __restrict__ err) {
+  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  bool act = q < m;
+  uint32_t sg = 0xFFFFFFFFu;
+  double yc = 0.0;
+  uint32_t ns = 0;
+  long long yxin = 0, ydin = 0;
+  unsigned long long rep = ~0ull;
+  if (act) {
+    uint8_t fl = flags[q];
+    sg = gex[q] + (fl & 1u) - 1u;
+    sgid[q] = sg;
+    uint32_t gi = val[q];
+    uint32_t f = fidx[gi];
+    if (I.tbm[f]) {  // settle/dupAdd, TieBrush input (tiebrush.cpp:389-395, :412-419)
+      yc = I.yc_in[gi];
+      if (yc == 0.0) yc = 1.0;
+      if (yc != rint(yc) || fabs(yc) > 9.0e15) atomicOr(err, TBK_DERR_FRACTIONAL);
+      yxin = I.yx_in[gi];
+      ydin = I.yd_in[gi];
+    } else {
+      if (O.store_frac) {
+        int nh = I.nh[gi] == TBK_NH_ABSENT ? 1 : I.nh[gi];
+        yc = 1.0 / nh;
+      } else {
+        yc = 1.0;
+      }
+      ns = (fl & 4u) ? 1u : 0u;
+    }
+    rep = ((unsigned long long)(uint32_t)effend[gi] << 32) | gi;
+    if (fl & 1u) {
+      G.first[sg] = q;
+      G.tie[sg] = (fl >> 1) & 1u;
+    }
+  }
+  yc = seg_reduce(yc, sg, [](double a, double b) { return a + b; });
+  ns = seg_reduce(ns, sg, [](uint32_t a, uint32_t b) { return a + b; });
+  yxin = seg_reduce(yxin, sg, [](long long a, long long b) { return a + b; });
+  ydin = seg_reduce(ydin, sg, [](long long a, long long b) { return a > b ? a : b; });
+  rep = seg_reduce(rep, sg, [](unsigned long long a, unsigned long long b) { return a < b ? a : b; });
+  uint32_t nxt = __shfl_down(sg, 1, 64);
+  bool last = act && (lane_id() == 63 || nxt != sg);
+  if (last) {
+    atomicAdd(&G.yc[sg], yc);
+    if (ns) atomicAdd(&G.ns[sg], ns);
+    if (yxin) atomicAdd((unsigned long long*)&G.yxin[sg], (unsigned long long)yxin);
+    if (ydin > 0) __hip_atomic_fetch_max(&G.ydin[sg], ydin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    atomicMin(&G.rep[sg], rep);
+  }
+}
+
+// -A (collapse_same): a non-first record of its file whose (qname,pairOrder) equals the representative's
+// is not counted (tiebrush.cpp:422-424)
+__global__ void col_same_k(ColIn I, ColOpt O, uint32_t m, const uint32_t* __restrict__ val, const uint8_t* __restrict__ flags,
+                           const uint32_t* __restrict__ sgid, const uint16_t* __restrict__ fidx, GroupAcc G) {
+  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= m) return;
+  uint32_t gi = val[q];
+  if (I.tbm[fidx[gi]] || (flags[q] & 4u)) return;
+  uint32_t sg = sgid[q];
+  uint32_t r = (uint32_t)(G.rep[sg] & 0xFFFFFFFFull);
+  if (I.qh[gi] == I.qh[r]) atomicAdd(&G.yc[sg], -1.0);
+}
+
+// ---- tie sets: order groups that share (bucket,strand,end) by the reference comparator -----------------
+__global__ void col_tie_k(ColIn I, int strategy, uint32_t ng, const uint32_t* __restrict__ val, GroupAcc G, uint32_t* __restrict__ gperm) {
+  uint32_t sg = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sg >= ng) return;
+  gperm[sg] = sg;
+}
+__global__ void col_tie_sort_k(ColIn I, int strategy, uint32_t ng, const uint32_t* __restrict__ val, GroupAcc G,
+                               uint32_t* __restrict__ gperm) {
+  uint32_t sg = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sg >= ng || !G.tie[sg]) return;
+  uint32_t e = 1;
+  while (sg + e < ng && !G.tie[sg + e]) ++e;
+  if (e < 2) return;
+  // insertion sort of gperm[sg .. sg+e) by the comparator on any member (the head) of each group
+  for (uint32_t a = 1; a < e; ++a) {
+    uint32_t x = gperm[sg + a];
+    uint32_t rx = val[G.first[x]];
+    uint32_t b = a;
+    while (b > 0) {
+      uint32_t y = gperm[sg + b - 1];
+      if (strategy_cmp(I, strategy, rx, val[G.first[y]]) < 0) {
+        gperm[sg + b] = y;
+        --b;
+      } else {
+        break;
+      }
+    }
+    gperm[sg + b] = x;
+  }
+}
+__global__ void col_ginv_k(uint32_t ng, const uint32_t* __restrict__ gperm, uint32_t* __restrict__ ginv) {
+  uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o < ng) ginv[gperm[o]] = o;
+}
+
+// ---- YD ----------------------------------------------------------------------------------------------------
+// incidence items: one per (group, sample list) the flush touches (tiebrush.cpp:511-521)
+__global__ void yd_count_k(ColIn I, uint32_t m, const uint32_t* __restrict__ val, const uint8_t* __restrict__ flags,
+                           const uint16_t* __restrict__ fidx, uint32_t* __restrict__ cnt) {
+  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= m) return;
+  uint32_t gi = val[q];
+  uint32_t c = 0;
+  if ((flags[q] & 4u) && !I.tbm[fidx[gi]]) c = (I.strand[gi] == '+' || I.strand[gi] == '-') ? 1u : 2u;
+  cnt[q] = c;
+}
+__global__ void yd_fill_k(ColIn I, uint32_t m, const uint32_t* __restrict__ val, const uint8_t* __restrict__ flags,
+                          const uint16_t* __restrict__ fidx, const uint32_t* __restrict__ sgid, const uint32_t* __restrict__ ginv,
+                          const uint32_t* __restrict__ off, uint64_t* __restrict__ hi, uint64_t* __restrict__ lo,
+                          uint32_t* __restrict__ v) {
+  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= m) return;
+  uint32_t gi = val[q];
+  uint32_t f = fidx[gi];
+  if (!(flags[q] & 4u) || I.tbm[f]) return;
+  uint32_t o = ginv[sgid[q]];
+  uint32_t p = off[q];
+  uint8_t s = I.strand[gi];
+  if (s != '-') {  // '+' or '.': fsegs[f]
+    hi[p] = (uint64_t)f * 2;
+    lo[p] = o;
+    v[p] = o;
+    ++p;
+  }
+  if (s != '+') {  // '-' or '.': rsegs[f]
+    hi[p] = (uint64_t)f * 2 + 1;
+    lo[p] = o;
+    v[p] = o;
+  }
+}
+
+struct YdItems {
+  uint32_t* tidp1;
+  int32_t* start;
+  int32_t* end;
+  uint32_t* rep;
+  uint32_t* nex;
+  uint32_t* chead;
+};
+
+__global__ void yd_coords_k(ColIn I, uint32_t nit, const uint32_t* __restrict__ v, const uint32_t* __restrict__ gperm, GroupAcc G,
+                            const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo, YdItems Y) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nit) return;
+  uint32_t sg = gperm[v[t]];
+  uint32_t q = G.first[sg];
+  uint64_t h = shi[q], l = slo[q];
+  int32_t st = (int32_t)(uint32_t)(h & 0xFFFFFFFFull);
+  Y.tidp1[t] = (uint32_t)(h >> 32);
+  Y.start[t] = st;
+  Y.end[t] = st + (int32_t)((l >> 32) & 0x3FFFFFFFull) - 1;
+  uint32_t r = (uint32_t)(G.rep[sg] & 0xFFFFFFFFull);
+  Y.rep[t] = r;
+  int nex = 0;
+  walk_exons(I.pos[r], I.cig + I.cig_off[r], I.cig_off[r + 1] - I.cig_off[r], [](int, int) {}, &nex);
+  Y.nex[t] = (uint32_t)nex;
+}
+
+struct SegMaxY {
+  int32_t mx;
+  uint32_t flag;
+};
+struct SegMaxYOp {
+  __device__ __forceinline__ SegMaxY operator()(const SegMaxY& a, const SegMaxY& b) const {
+    SegMaxY r;
+    r.mx = b.flag ? b.mx : (a.mx > b.mx ? a.mx : b.mx);
+    r.flag = a.flag | b.flag;
+    return r;
+  }
+};
+struct YdLoad {
+  const uint64_t* list;
+  YdItems Y;
+  __device__ __forceinline__ bool list_head(uint32_t t) const {
+    return t == 0 || list[t] != list[t - 1] || Y.tidp1[t] != Y.tidp1[t - 1];  // new list, or rspacing.reset() (:586-589)
+  }
+  __device__ __forceinline__ SegMaxY operator()(uint32_t t) const {
+    SegMaxY s;
+    s.mx = Y.end[t];
+    s.flag = list_head(t) ? 1u : 0u;
+    return s;
+  }
+};
+struct YdStore {
+  YdLoad L;
+  __device__ __forceinline__ void operator()(uint32_t t, const SegMaxY&, const SegMaxY& ex) const {
+    // renewal: the read starts beyond every earlier end of this list => every node is cleared (processRead :230-241)
+    L.Y.chead[t] = (L.list_head(t) || L.Y.start[t] > ex.mx) ? 1u : 0u;
+  }
+};
+
+__global__ void yd_chain_first_k(uint32_t nit, const uint32_t* __restrict__ chead, const uint32_t* __restrict__ cex,
+                                 uint32_t* __restrict__ chain_first) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < nit && chead[t]) chain_first[cex[t]] = t;
+}
+
+// GSegList (tiebrush.cpp:111-250) with node indices into a per-chain arena; literal, including the
+// mergeRead tail drop.  One thread runs one chain.
+struct SegNodes {
+  uint32_t* s;
+  uint32_t* e;
+  int32_t* nx;
+};
+
+__device__ void yd_merge_read(const ColIn& I, uint32_t r, SegNodes N, int32_t& head, uint32_t& alloc) {
+  const uint32_t* c = I.cig + I.cig_off[r];
+  uint32_t n = I.cig_off[r + 1] - I.cig_off[r];
+  int nex = 0;
+  if (head < 0) {  // :168-177
+    int32_t cn = -1;
+    walk_exons(I.pos[r], c, n,
+               [&](int es, int ee) {
+                 uint32_t nw = alloc++;
+                 N.s[nw] = (uint32_t)es;
+                 N.e[nw] = (uint32_t)ee;
+                 N.nx[nw] = -1;
+                 if (cn < 0)
+                   head = (int32_t)nw;
+                 else
+                   N.nx[cn] = (int32_t)nw;
+                 cn = (int32_t)nw;
+               },
+               &nex);
+    return;
+  }
+  int32_t cur = head, prev = -1;
+  walk_exons(I.pos[r], c, n,
+             [&](int es_, int ee_) {
+               uint32_t es = (uint32_t)es_, ee = (uint32_t)ee_;
+               while (cur >= 0) {
+                 if (ee < N.s[cur]) {  // insert before cur :182-191
+                   uint32_t nw = alloc++;
+                   N.s[nw] = es;
+                   N.e[nw] = ee;
+                   N.nx[nw] = cur;
+                   if (cur == head)
+                     head = (int32_t)nw;
+                   else
+                     N.nx[prev] = (int32_t)nw;
+                   prev = (int32_t)nw;
+                   break;
+                 }
+                 if (es <= N.e[cur]) {  // overlap :194-212
+                   if (es < N.s[cur]) N.s[cur] = es;
+                   if (ee > N.e[cur]) N.e[cur] = ee;
+                   int32_t nx = N.nx[cur];
+                   while (nx >= 0 && N.s[nx] <= N.e[cur]) {
+                     uint32_t nend = N.e[nx];
+                     N.nx[cur] = N.nx[nx];
+                     nx = N.nx[cur];
+                     if (nend > N.e[cur]) {
+                       N.e[cur] = nend;
+                       break;
+                     }
+                   }
+                   break;
+                 }
+                 prev = cur;  // :214-216
+                 cur = N.nx[cur];
+               }
+               // cur < 0: this exon and all later ones are dropped (reference behaviour)
+             },
+             &nex);
+}
+
+__global__ void yd_run_k(ColIn I, uint32_t nchains, uint32_t nit, const uint32_t* __restrict__ chain_first, YdItems Y,
+                         const uint32_t* __restrict__ v, const uint32_t* __restrict__ noff, SegNodes N, int32_t* __restrict__ g_yd) {
+  uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nchains) return;
+  uint32_t t0 = chain_first[c];
+  uint32_t t1 = (c + 1 < nchains) ? chain_first[c + 1] : nit;
+  int32_t head = -1;
+  uint32_t last_pos = 0;
+  int last_dist = -1;
+  uint32_t alloc = noff[t0];
+  for (uint32_t t = t0; t < t1; ++t) {
+    uint32_t rstart = (uint32_t)Y.start[t];
+    uint32_t r = Y.rep[t];
+    int d;
+    if (last_pos == rstart) {  // :225-228
+      yd_merge_read(I, r, N, head, alloc);
+      d = last_dist;
+    } else {
+      d = 0;
+      int32_t node = head, prev = -1;
+      while (node >= 0 && N.s[node] < rstart) {
+        prev = node;
+        node = N.nx[node];
+      }
+      if (prev >= 0) {
+        if (N.e[prev] >= rstart) d = (int)(rstart - N.s[prev]);
+        if (d == 0) head = N.nx[prev];  // clearTo(prev)
+      }
+      last_pos = rstart;
+      last_dist = d;
+      yd_merge_read(I, r, N, head, alloc);
+    }
+    if (d > 0) atomicMax(&g_yd[v[t]], d);
+  }
+}
+
+// ---- outputs ---------------------------------------------------------------------------------------------
+__global__ void col_write_k(uint32_t ng, const uint32_t* __restrict__ gperm, GroupAcc G, const int32_t* __restrict__ g_yd,
+                            const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo, uint32_t cap,
+                            uint32_t* __restrict__ rep, double* __restrict__ yc, int64_t* __restrict__ yx, int32_t* __restrict__ yd,
+                            int32_t* __restrict__ g_start, int32_t* __restrict__ g_end) {
+  uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= ng || o >= cap) return;
+  uint32_t sg = gperm[o];
+  rep[o] = (uint32_t)(G.rep[sg] & 0xFFFFFFFFull);
+  yc[o] = G.yc[sg];
+  yx[o] = (int64_t)G.yxin[sg] + (int64_t)G.ns[sg];
+  int dmax = (int)G.ydin[sg];  // int dmax=spd.maxYD (tiebrush.cpp:511)
+  int d2 = g_yd ? g_yd[o] : 0;
+  if (d2 > dmax) dmax = d2;
+  yd[o] = dmax > 0 ? dmax : 0;
+  uint32_t q = G.first[sg];
+  int32_t st = (int32_t)(uint32_t)(shi[q] & 0xFFFFFFFFull);
+  if (g_start) g_start[o] = st;
+  if (g_end) g_end[o] = st + (int32_t)((slo[q] >> 32) & 0x3FFFFFFFull) - 1;
+}
+__global__ void col_recgroup_k(uint32_t m, const uint32_t* __restrict__ val, const uint32_t* __restrict__ sgid,
+                               const uint32_t* __restrict__ ginv, int32_t* __restrict__ rec_group) {
+  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < m) rec_group[val[q]] = (int32_t)ginv[sgid[q]];
+}
+
+__global__ void col_init_groups_k(uint32_t ng, GroupAcc G, int32_t* __restrict__ g_yd) {
+  uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= ng) return;
+  G.yc[g] = 0.0;
+  G.ns[g] = 0;
+  G.yxin[g] = 0;
+  G.ydin[g] = 0;
+  G.rep[g] = ~0ull;
+  g_yd[g] = 0;
+}
+
+}  // namespace
+
+// =============================================================================================================
+int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_in* in, tbk_groups_out* out) {
+  const uint32_t n = in->n_records;
+  const uint32_t B = 256;
+  out->n_groups = 0;
+  out->n_passed = 0;
+  if (o->store_frac && o->collapse_same) return TBK_EUNSUPPORTED;
+  if (out->rec_group) TBK_HIP(hipMemsetAsync(out->rec_group, 0xFF, (size_t)n * 4, ctx->stream));
+  if (n == 0) return 0;
+  uint64_t* sc = ctx->d_scalars;  // [0]=n_pass [1]=n_groups [2]=n_items [3]=n_chains [4]=n_nodes
+  ColIn I;
+  I.n = n;
+  I.k = in->n_files;
+  {
+    uint32_t* d_fo = ws_alloc<uint32_t>(ctx, in->n_files + 1);
+    uint8_t* d_tb = ws_alloc<uint8_t>(ctx, in->n_files);
+    if (!d_fo || !d_tb) return TBK_ENOMEM;
+    // stage through the pinned scalar block when small, else straight from the caller's memory
+    TBK_HIP(hipMemcpyAsync(d_fo, in->file_off, (size_t)(in->n_files + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (in->tbmerged) {
+      TBK_HIP(hipMemcpyAsync(d_tb, in->tbmerged, in->n_files, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+      TBK_HIP(hipMemsetAsync(d_tb, 0, in->n_files, ctx->stream));
+    }
+    TBK_HIP(hipStreamSynchronize(ctx->stream));  // the caller's host arrays may be transient
+    I.file_off = d_fo;
+    I.tbm = d_tb;
+  }
+  I.tid = in->tid;
+  I.pos = in->pos;
+  I.flag = in->flag;
+  I.mapq = in->mapq;
+  I.strand = in->strand;
+  I.nh = in->nh;
+  I.cig_off = in->cig_off;
+  I.cig = in->cig;
+  I.yc_in = in->yc_in;
+  I.yx_in = in->yx_in;
+  I.yd_in = in->yd_in;
+  I.md_off = in->md_off;
+  I.md = in->md;
+  I.md_has = in->md_has;
+  I.qh = in->qname_hash;
+  ColOpt O;
+  O.strategy = o->strategy;
+  O.max_nh = o->max_nh;
+  O.min_qual = o->min_qual;
+  O.keep_supp = o->keep_supplementary;
+  O.keep_sec = o->keep_secondary;
+  O.collapse_same = o->collapse_same;
+  O.store_frac = o->store_frac;
+
+  uint64_t* khi = ws_alloc<uint64_t>(ctx, n);
+  uint64_t* klo = ws_alloc<uint64_t>(ctx, n);
+  int32_t* kend = ws_alloc<int32_t>(ctx, n);
+  uint8_t* kflags = ws_alloc<uint8_t>(ctx, n);
+  uint16_t* fidx = ws_alloc<uint16_t>(ctx, n);
+  int32_t* effend = ws_alloc<int32_t>(ctx, n);
+  SortBufs sb;
+  sb.hi = ws_alloc<uint64_t>(ctx, n);
+  sb.lo = ws_alloc<uint64_t>(ctx, n);
+  sb.val = ws_alloc<uint32_t>(ctx, n);
+  sb.hi2 = khi;  // the unsorted key arrays are dead after compaction: reuse them as the ping-pong side
+  sb.lo2 = klo;
+  sb.val2 = ws_alloc<uint32_t>(ctx, n);
+  uint8_t* flags = ws_alloc<uint8_t>(ctx, n);
+  uint32_t* ghead = ws_alloc<uint32_t>(ctx, n);
+  uint32_t* gex = ws_alloc<uint32_t>(ctx, n);
+  uint32_t* sgid = ws_alloc<uint32_t>(ctx, n);
+  if (!sgid) return TBK_ENOMEM;
+
+  uint32_t m = 0, ng = 0;
+  GroupAcc G{};
+  int32_t* g_yd = nullptr;
+  uint32_t* gperm = nullptr;
+  uint32_t* ginv = nullptr;
+  const uint64_t seeds[4] = {0x71EB5EEDull, 0xA5A5F00DCAFE1234ull, 0x0123456789ABCDEFull, 0xDEADBEEF0BADF00Dull};
+  int attempt = 0;
+  for (;; ++attempt) {
+    if (attempt == 4) return TBK_ECOLLISION;
+    O.seed = seeds[attempt];
+    SortBufs s2 = sb;
+    TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
+    TBK_HIP(hipMemsetAsync(sc, 0, 16 * sizeof(uint64_t), ctx->stream));
+    TBK_LAUNCH(ctx, "col_keys", col_keys_k, cdiv(n, B), B, 0, I, O, khi, klo, kend, kflags, fidx, ctx->d_err);
+    {
+      EffLoad ld{khi, klo ? kend : kend, kflags};
+      EffStore st{khi, klo, kflags, effend, s2.hi, s2.lo, s2.val, sc + 0, n, ctx->d_err};
+      EffKey ident{0ull, INT32_MIN, 0u, 0u, 0u};
+      TBK_TRY((scan_op_run<EffKey, EffOp, EffLoad, EffStore>(ctx, "col_effkey_scan", n, ld, st, EffOp{}, ident)));
+    }
+    TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t eb = 0;
+    TBK_TRY(tbk_sync_err(ctx, &eb));
+    if (eb) return tbk_derr_to_status(ctx, eb);
+    m = (uint32_t)ctx->h_scalars[0];
+    out->n_passed = m;
+    if (m == 0) return 0;
+    TBK_TRY(tbk_radix_sort128(ctx, &s2, m));
+    TBK_LAUNCH(ctx, "col_heads", col_heads_k, cdiv(m, B), B, 0, I, O.strategy, m, s2.hi, s2.lo, s2.val, fidx, flags, ghead,
+               ctx->d_err);
+    TBK_TRY(tbk_exscan_u32(ctx, ghead, gex, m, sc + 1));
+    TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    TBK_TRY(tbk_sync_err(ctx, &eb));
+    if (eb & TBK_DERR_COLLISION) continue;  // reseed
+    if (eb) return tbk_derr_to_status(ctx, eb);
+    ng = (uint32_t)ctx->h_scalars[1];
+    sb = s2;
+    break;
+  }
+  out->n_groups = ng;
+  if (ng > out->cap_groups) return TBK_E2BIG;
+
+  G.yc = ws_alloc<double>(ctx, ng);
+  G.ns = ws_alloc<uint32_t>(ctx, ng);
+  G.yxin = ws_alloc<long long>(ctx, ng);
+  G.ydin = ws_alloc<long long>(ctx, ng);
+  G.rep = ws_alloc<unsigned long long>(ctx, ng);
+  G.first = ws_alloc<uint32_t>(ctx, ng);
+  G.tie = ws_alloc<uint8_t>(ctx, ng);
+  g_yd = ws_alloc<int32_t>(ctx, ng);
+  gperm = ws_alloc<uint32_t>(ctx, ng);
+  ginv = ws_alloc<uint32_t>(ctx, ng);
+  if (!ginv) return TBK_ENOMEM;
+  TBK_LAUNCH(ctx, "col_init_groups", col_init_groups_k, cdiv(ng, B), B, 0, ng, G, g_yd);
+  TBK_LAUNCH(ctx, "col_reduce", col_reduce_k, cdiv(m, B), B, 0, I, O, m, sb.val, flags, gex, fidx, effend, G, sgid, ctx->d_err);
+  if (O.collapse_same) TBK_LAUNCH(ctx, "col_same", col_same_k, cdiv(m, B), B, 0, I, O, m, sb.val, flags, sgid, fidx, G);
+  TBK_LAUNCH(ctx, "col_tie_init", col_tie_k, cdiv(ng, B), B, 0, I, O.strategy, ng, sb.val, G, gperm);
+  TBK_LAUNCH(ctx, "col_tie_sort", col_tie_sort_k, cdiv(ng, B), B, 0, I, O.strategy, ng, sb.val, G, gperm);
+  TBK_LAUNCH(ctx, "col_ginv", col_ginv_k, cdiv(ng, B), B, 0, ng, gperm, ginv);
+
+  // ---- YD ----
+  {
+    uint32_t* icnt = ws_alloc<uint32_t>(ctx, m);
+    uint32_t* ioff = ws_alloc<uint32_t>(ctx, m);
+    if (!ioff) return TBK_ENOMEM;
+    TBK_LAUNCH(ctx, "yd_count", yd_count_k, cdiv(m, B), B, 0, I, m, sb.val, flags, fidx, icnt);
+    TBK_TRY(tbk_exscan_u32(ctx, icnt, ioff, m, sc + 2));
+    TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t eb = 0;
+    TBK_TRY(tbk_sync_err(ctx, &eb));
+    if (eb & TBK_DERR_FRACTIONAL) {
+      ctx->last_error = "fractional YC in TieBrush-merged input: ordered accumulation path not built yet";
+      return TBK_EUNSUPPORTED;
+    }
+    if (eb) return tbk_derr_to_status(ctx, eb);
+    const uint64_t nit64 = ctx->h_scalars[2];
+    if (nit64 >= (1ull << 32)) return TBK_E2BIG;
+    const uint32_t nit = (uint32_t)nit64;
+    if (nit) {
+      SortBufs ib;
+      ib.hi = ws_alloc<uint64_t>(ctx, nit);
+      ib.lo = ws_alloc<uint64_t>(ctx, nit);
+      ib.val = ws_alloc<uint32_t>(ctx, nit);
+      ib.hi2 = ws_alloc<uint64_t>(ctx, nit);
+      ib.lo2 = ws_alloc<uint64_t>(ctx, nit);
+      ib.val2 = ws_alloc<uint32_t>(ctx, nit);
+      YdItems Y;
+      Y.tidp1 = ws_alloc<uint32_t>(ctx, nit);
+      Y.start = ws_alloc<int32_t>(ctx, nit);
+      Y.end = ws_alloc<int32_t>(ctx, nit);
+      Y.rep = ws_alloc<uint32_t>(ctx, nit);
+      Y.nex = ws_alloc<uint32_t>(ctx, nit);
+      Y.chead = ws_alloc<uint32_t>(ctx, nit);
+      uint32_t* cex = ws_alloc<uint32_t>(ctx, nit);
+      uint32_t* noff = ws_alloc<uint32_t>(ctx, nit);
+      uint32_t* chain_first = ws_alloc<uint32_t>(ctx, nit);
+      if (!chain_first) return TBK_ENOMEM;
+      TBK_LAUNCH(ctx, "yd_fill", yd_fill_k, cdiv(m, B), B, 0, I, m, sb.val, flags, fidx, sgid, ginv, ioff, ib.hi, ib.lo, ib.val);
+      TBK_TRY(tbk_radix_sort128(ctx, &ib, nit));
+      TBK_LAUNCH(ctx, "yd_coords", yd_coords_k, cdiv(nit, B), B, 0, I, nit, ib.val, gperm, G, sb.hi, sb.lo, Y);
+      {
+        YdLoad ld{ib.hi, Y};
+        YdStore st{ld};
+        SegMaxY ident{INT32_MIN, 0u};
+        TBK_TRY((scan_op_run<SegMaxY, SegMaxYOp, YdLoad, YdStore>(ctx, "yd_chain_scan", nit, ld, st, SegMaxYOp{}, ident)));
+      }
+      TBK_TRY(tbk_exscan_u32(ctx, Y.chead, cex, nit, sc + 3));
+      TBK_TRY(tbk_exscan_u32(ctx, Y.nex, noff, nit, sc + 4));
+      TBK_LAUNCH(ctx, "yd_chain_first", yd_chain_first_k, cdiv(nit, B), B, 0, nit, Y.chead, cex, chain_first);
+      TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+      TBK_HIP(hipStreamSynchronize(ctx->stream));
+      const uint32_t nchains = (uint32_t)ctx->h_scalars[3];
+      const uint64_t nnodes = ctx->h_scalars[4];
+      if (nnodes >= (1ull << 31)) return TBK_E2BIG;
+      SegNodes N;
+      N.s = ws_alloc<uint32_t>(ctx, nnodes + 1);
+      N.e = ws_alloc<uint32_t>(ctx, nnodes + 1);
+      N.nx = ws_alloc<int32_t>(ctx, nnodes + 1);
+      if (!N.nx) return TBK_ENOMEM;
+      TBK_LAUNCH(ctx, "yd_run", yd_run_k, cdiv(nchains, 64), 64, 0, I, nchains, nit, chain_first, Y, ib.val, noff, N, g_yd);
+    }
+  }
+  TBK_LAUNCH(ctx, "col_write", col_write_k, cdiv(ng, B), B, 0, ng, gperm, G, g_yd, sb.hi, sb.lo, out->cap_groups, out->rep, out->yc,
+             out->yx, out->yd, out->g_start, out->g_end);
+  if (out->rec_group) TBK_LAUNCH(ctx, "col_recgroup", col_recgroup_k, cdiv(m, B), B, 0, m, sb.val, sgid, ginv, out->rec_group);
+  uint32_t eb = 0;
+  TBK_TRY(tbk_sync_err(ctx, &eb));
+  if (eb & ~TBK_DERR_FRACTIONAL) return tbk_derr_to_status(ctx, eb);
+  return tbk_check_launch(ctx, "collapse");
+}
+
 int tbk_sample_device(tbk_ctx* ctx, const tbk_cov_in*, int32_t, tbk_sample_out*) {
   ctx->last_error = "sample pipeline not built";
   return TBK_EUNSUPPORTED;
