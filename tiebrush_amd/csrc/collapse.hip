@@ -11,9 +11,9 @@
 //   YD               tiebrush.cpp:111-250 (GSegList) called per sample & strand list at flush
 //
 // GPU formulation.  Every record gets a 128-bit sort key
-//      hi = (tid+1 : 32 | start : 32)            -> bucket order
-//      lo = (strand code : 2 | span : 30 | h32)  -> (strand, end) order inside the bucket, then a
-//                                                   32-bit slice of a seeded 64-bit hash of the strategy key
+//      hi = (tid+1 : 31 | start : 31 | strand code : 2) -> bucket order, then strand ('+' < '-' < '.')
+//      lo = (span : 32 | h32)                            -> end order, then a 32-bit slice of a seeded
+//                                                           64-bit hash of the strategy key
 // and the passing records are LSD-radix sorted (stable, so equal keys stay in file-major order).
 // Groups are runs of equal keys; adjacent members are verified against the full strategy key, a
 // hash collision raises TBK_DERR_COLLISION and the host retries with another seed.  Per group a
@@ -286,8 +286,9 @@ __global__ void col_keys_k(ColIn I, ColOpt O, uint64_t* __restrict__ khi, uint64
     atomicOr(err, TBK_DERR_SPAN);
     span = 0;
   }
-  khi[i] = ((uint64_t)(uint32_t)(I.tid[i] + 1) << 32) | (uint32_t)start;
-  klo[i] = ((uint64_t)strand_code(I.strand[i]) << 62) | ((uint64_t)span << 32) | (h >> 32);
+  // hi = tid+1 : 31 | start : 31 | strand code : 2   lo = span : 32 | h32   (tid+1 and start are < 2^31 in BAM)
+  khi[i] = ((uint64_t)(uint32_t)(I.tid[i] + 1) << 33) | ((uint64_t)(uint32_t)start << 2) | strand_code(I.strand[i]);
+  klo[i] = ((uint64_t)span << 32) | (h >> 32);
   kend[i] = end;
   kflags[i] = (pass ? 1u : 0u) | (i == I.file_off[f] ? 2u : 0u);
   fidx[i] = (uint16_t)f;
@@ -299,7 +300,7 @@ struct EffLoad {
   const uint8_t* kflags;
   __device__ __forceinline__ EffKey operator()(uint32_t i) const {
     EffKey e;
-    e.khi = khi[i];
+    e.khi = khi[i] >> 2;  // (tid,start) only: the strand bits are not part of the merge key
     e.kend = kend[i];
     uint8_t f = kflags[i];
     e.flag = (f >> 1) & 1u;
@@ -321,7 +322,7 @@ struct EffStore {
   uint32_t* err;
   __device__ __forceinline__ void operator()(uint32_t i, const EffKey& inc, const EffKey& ex) const {
     if (kflags[i] & 1u) {
-      if (inc.khi != khi[i]) atomicOr(err, TBK_DERR_UNSORTED);  // an earlier record of the file has a larger (tid,start)
+      if (inc.khi != (khi[i] >> 2)) atomicOr(err, TBK_DERR_UNSORTED);  // an earlier record of the file has a larger (tid,start)
       effend[i] = inc.kend;
       uint32_t d = ex.cnt;
       chi[d] = khi[i];
@@ -343,9 +344,10 @@ __global__ void col_heads_k(ColIn I, int strategy, uint32_t m, const uint64_t* _
   bool bucket_head = true, group_head = true, tie_head = true, file_head = true;
   if (q > 0) {
     uint32_t pv = val[q - 1];
-    bucket_head = hi[q] != hi[q - 1];
-    group_head = bucket_head || lo[q] != lo[q - 1];
-    tie_head = bucket_head || (lo[q] >> 32) != (lo[q - 1] >> 32);
+    bucket_head = (hi[q] >> 2) != (hi[q - 1] >> 2);
+    group_head = hi[q] != hi[q - 1] || lo[q] != lo[q - 1];
+    tie_head = hi[q] != hi[q - 1] || (lo[q] >> 32) != (lo[q - 1] >> 32);
+    (void)bucket_head;
     if (!group_head && !strategy_equal(I, strategy, gi, pv)) atomicOr(err, TBK_DERR_COLLISION);
     file_head = group_head || fidx[gi] != fidx[pv];
   }
@@ -528,10 +530,10 @@ __global__ void yd_coords_k(ColIn I, uint32_t nit, const uint32_t* __restrict__ 
   uint32_t sg = gperm[v[t]];
   uint32_t q = G.first[sg];
   uint64_t h = shi[q], l = slo[q];
-  int32_t st = (int32_t)(uint32_t)(h & 0xFFFFFFFFull);
-  Y.tidp1[t] = (uint32_t)(h >> 32);
+  int32_t st = (int32_t)(uint32_t)((h >> 2) & 0x7FFFFFFFull);
+  Y.tidp1[t] = (uint32_t)(h >> 33);
   Y.start[t] = st;
-  Y.end[t] = st + (int32_t)((l >> 32) & 0x3FFFFFFFull) - 1;
+  Y.end[t] = st + (int32_t)(uint32_t)(l >> 32) - 1;
   uint32_t r = (uint32_t)(G.rep[sg] & 0xFFFFFFFFull);
   Y.rep[t] = r;
   int nex = 0;
@@ -578,6 +580,49 @@ __global__ void yd_chain_first_k(uint32_t nit, const uint32_t* __restrict__ chea
   if (t < nit && chead[t]) chain_first[cex[t]] = t;
 }
 
+// exon list of every item, laid out at noff[t] (so a chain's exons are contiguous)
+__global__ void yd_exons_k(ColIn I, uint32_t nit, YdItems Y, const uint32_t* __restrict__ noff, uint32_t* __restrict__ ex_s,
+                           uint32_t* __restrict__ ex_e) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nit) return;
+  uint32_t r = Y.rep[t];
+  uint32_t o = noff[t];
+  int nex = 0;
+  walk_exons(I.pos[r], I.cig + I.cig_off[r], I.cig_off[r + 1] - I.cig_off[r],
+             [&](int es, int ee) {
+               ex_s[o] = (uint32_t)es;
+               ex_e[o] = (uint32_t)ee;
+               ++o;
+             },
+             &nex);
+}
+
+constexpr uint32_t YD_LONG = 24;  // chains at least this long get a whole wave
+
+// ids[0..] = short chains (thread each), ids2 = long chains (wave each); counts in cnt[0], cnt[1]
+__global__ void yd_classify_k(uint32_t nchains, uint32_t nit, const uint32_t* __restrict__ chain_first, uint32_t* __restrict__ ids_short,
+                              uint32_t* __restrict__ ids_long, uint32_t* __restrict__ cnt) {
+  uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nchains) return;  // (trailing lanes of the last wave simply do not vote)
+  uint32_t t0 = chain_first[c];
+  uint32_t t1 = (c + 1 < nchains) ? chain_first[c + 1] : nit;
+  bool is_long = (t1 - t0) >= YD_LONG;
+  // wave-aggregated append: one atomic per wave and class instead of one per chain
+  uint64_t ml = __ballot(is_long), ms = __ballot(!is_long);
+  uint32_t bl = 0, bs = 0;
+  int leader = __builtin_ctzll(ml | ms);
+  if ((int)lane_id() == leader) {
+    if (ml) bl = atomicAdd(&cnt[1], (uint32_t)__popcll(ml));
+    if (ms) bs = atomicAdd(&cnt[0], (uint32_t)__popcll(ms));
+  }
+  bl = __shfl(bl, leader, 64);
+  bs = __shfl(bs, leader, 64);
+  if (is_long)
+    ids_long[bl + (uint32_t)__popcll(ml & lanemask_lt())] = c;
+  else
+    ids_short[bs + (uint32_t)__popcll(ms & lanemask_lt())] = c;
+}
+
 // GSegList (tiebrush.cpp:111-250) with node indices into a per-chain arena; literal, including the
 // mergeRead tail drop.  One thread runs one chain.
 struct SegNodes {
@@ -586,71 +631,69 @@ struct SegNodes {
   int32_t* nx;
 };
 
-__device__ void yd_merge_read(const ColIn& I, uint32_t r, SegNodes N, int32_t& head, uint32_t& alloc) {
-  const uint32_t* c = I.cig + I.cig_off[r];
-  uint32_t n = I.cig_off[r + 1] - I.cig_off[r];
-  int nex = 0;
+__device__ void yd_merge_read(const uint32_t* __restrict__ xs, const uint32_t* __restrict__ xe, uint32_t nex, SegNodes N, int32_t& head,
+                              uint32_t& alloc) {
   if (head < 0) {  // :168-177
     int32_t cn = -1;
-    walk_exons(I.pos[r], c, n,
-               [&](int es, int ee) {
-                 uint32_t nw = alloc++;
-                 N.s[nw] = (uint32_t)es;
-                 N.e[nw] = (uint32_t)ee;
-                 N.nx[nw] = -1;
-                 if (cn < 0)
-                   head = (int32_t)nw;
-                 else
-                   N.nx[cn] = (int32_t)nw;
-                 cn = (int32_t)nw;
-               },
-               &nex);
+    for (uint32_t k = 0; k < nex; ++k) {
+      uint32_t nw = alloc++;
+      N.s[nw] = xs[k];
+      N.e[nw] = xe[k];
+      N.nx[nw] = -1;
+      if (cn < 0)
+        head = (int32_t)nw;
+      else
+        N.nx[cn] = (int32_t)nw;
+      cn = (int32_t)nw;
+    }
     return;
   }
   int32_t cur = head, prev = -1;
-  walk_exons(I.pos[r], c, n,
-             [&](int es_, int ee_) {
-               uint32_t es = (uint32_t)es_, ee = (uint32_t)ee_;
-               while (cur >= 0) {
-                 if (ee < N.s[cur]) {  // insert before cur :182-191
-                   uint32_t nw = alloc++;
-                   N.s[nw] = es;
-                   N.e[nw] = ee;
-                   N.nx[nw] = cur;
-                   if (cur == head)
-                     head = (int32_t)nw;
-                   else
-                     N.nx[prev] = (int32_t)nw;
-                   prev = (int32_t)nw;
-                   break;
-                 }
-                 if (es <= N.e[cur]) {  // overlap :194-212
-                   if (es < N.s[cur]) N.s[cur] = es;
-                   if (ee > N.e[cur]) N.e[cur] = ee;
-                   int32_t nx = N.nx[cur];
-                   while (nx >= 0 && N.s[nx] <= N.e[cur]) {
-                     uint32_t nend = N.e[nx];
-                     N.nx[cur] = N.nx[nx];
-                     nx = N.nx[cur];
-                     if (nend > N.e[cur]) {
-                       N.e[cur] = nend;
-                       break;
-                     }
-                   }
-                   break;
-                 }
-                 prev = cur;  // :214-216
-                 cur = N.nx[cur];
-               }
-               // cur < 0: this exon and all later ones are dropped (reference behaviour)
-             },
-             &nex);
+  for (uint32_t k = 0; k < nex; ++k) {
+    uint32_t es = xs[k], ee = xe[k];
+    while (cur >= 0) {
+      if (ee < N.s[cur]) {  // insert before cur :182-191
+        uint32_t nw = alloc++;
+        N.s[nw] = es;
+        N.e[nw] = ee;
+        N.nx[nw] = cur;
+        if (cur == head)
+          head = (int32_t)nw;
+        else
+          N.nx[prev] = (int32_t)nw;
+        prev = (int32_t)nw;
+        break;
+      }
+      if (es <= N.e[cur]) {  // overlap :194-212
+        if (es < N.s[cur]) N.s[cur] = es;
+        if (ee > N.e[cur]) N.e[cur] = ee;
+        int32_t nx = N.nx[cur];
+        while (nx >= 0 && N.s[nx] <= N.e[cur]) {
+          uint32_t nend = N.e[nx];
+          N.nx[cur] = N.nx[nx];
+          nx = N.nx[cur];
+          if (nend > N.e[cur]) {
+            N.e[cur] = nend;
+            break;
+          }
+        }
+        break;
+      }
+      prev = cur;  // :214-216
+      cur = N.nx[cur];
+    }
+    if (cur < 0) break;  // this exon and all later ones are dropped (reference behaviour)
+  }
 }
 
-__global__ void yd_run_k(ColIn I, uint32_t nchains, uint32_t nit, const uint32_t* __restrict__ chain_first, YdItems Y,
-                         const uint32_t* __restrict__ v, const uint32_t* __restrict__ noff, SegNodes N, int32_t* __restrict__ g_yd) {
-  uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= nchains) return;
+// thread per chain (short chains, and long chains whose list outgrew the 64 lanes of yd_wave_k)
+__global__ void yd_run_k(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ nids, uint32_t nchains, uint32_t nit,
+                         const uint32_t* __restrict__ chain_first, YdItems Y, const uint32_t* __restrict__ v,
+                         const uint32_t* __restrict__ noff, const uint32_t* __restrict__ ex_s, const uint32_t* __restrict__ ex_e,
+                         SegNodes N, int32_t* __restrict__ g_yd) {
+  uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= *nids) return;
+  uint32_t c = ids[x];
   uint32_t t0 = chain_first[c];
   uint32_t t1 = (c + 1 < nchains) ? chain_first[c + 1] : nit;
   int32_t head = -1;
@@ -659,10 +702,10 @@ __global__ void yd_run_k(ColIn I, uint32_t nchains, uint32_t nit, const uint32_t
   uint32_t alloc = noff[t0];
   for (uint32_t t = t0; t < t1; ++t) {
     uint32_t rstart = (uint32_t)Y.start[t];
-    uint32_t r = Y.rep[t];
+    uint32_t xo = noff[t], nex = Y.nex[t];
     int d;
     if (last_pos == rstart) {  // :225-228
-      yd_merge_read(I, r, N, head, alloc);
+      yd_merge_read(ex_s + xo, ex_e + xo, nex, N, head, alloc);
       d = last_dist;
     } else {
       d = 0;
@@ -677,10 +720,136 @@ __global__ void yd_run_k(ColIn I, uint32_t nchains, uint32_t nit, const uint32_t
       }
       last_pos = rstart;
       last_dist = d;
-      yd_merge_read(I, r, N, head, alloc);
+      yd_merge_read(ex_s + xo, ex_e + xo, nex, N, head, alloc);
     }
     if (d > 0) atomicMax(&g_yd[v[t]], d);
   }
+}
+
+// Wave-native GSegList: the sorted node list lives one node per lane (ns, ne in registers of lane i = node i),
+// control flow is wave-uniform, list surgery is ballots + shuffles.  One 64-thread block per long chain.
+// A list that would need more than 64 nodes hands the chain over to yd_run_k (ids_over).
+__device__ __forceinline__ uint32_t rl(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+
+__global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ nids, uint32_t nchains,
+                                                uint32_t nit, const uint32_t* __restrict__ chain_first, YdItems Y,
+                                                const uint32_t* __restrict__ v, const uint32_t* __restrict__ noff,
+                                                const uint32_t* __restrict__ ex_s, const uint32_t* __restrict__ ex_e,
+                                                int32_t* __restrict__ g_yd, uint32_t* __restrict__ ids_over, uint32_t* __restrict__ n_over) {
+  if (blockIdx.x >= *nids) return;
+  const uint32_t c = ids[blockIdx.x];
+  const uint32_t t0 = chain_first[c];
+  const uint32_t t1 = (c + 1 < nchains) ? chain_first[c + 1] : nit;
+  const int lane = (int)threadIdx.x;
+  uint32_t ns = 0, ne = 0;  // node `lane`
+  int cnt = 0;              // uniform
+  uint32_t last_pos = 0;
+  int last_dist = -1;
+  bool overflow = false;
+  for (uint32_t tb = t0; tb < t1 && !overflow; tb += 64) {
+    const uint32_t t = tb + (uint32_t)lane;
+    const bool have = t < t1;
+    // batch load: lane l holds item tb+l
+    uint32_t it_start = have ? (uint32_t)Y.start[t] : 0u;
+    uint32_t it_nex = have ? Y.nex[t] : 0u;
+    uint32_t it_xo = have ? noff[t] : 0u;
+    uint32_t it_o = have ? v[t] : 0u;
+    uint32_t it_e0 = have ? ex_e[it_xo] : 0u;  // first exon end (its start is the read start)
+    uint32_t it_s1 = (have && it_nex > 1) ? ex_s[it_xo + 1] : 0u, it_e1 = (have && it_nex > 1) ? ex_e[it_xo + 1] : 0u;
+    uint32_t it_s2 = (have && it_nex > 2) ? ex_s[it_xo + 2] : 0u, it_e2 = (have && it_nex > 2) ? ex_e[it_xo + 2] : 0u;
+    int it_d = 0;
+    const int nb = (int)((t1 - tb) < 64u ? (t1 - tb) : 64u);
+    for (int j = 0; j < nb && !overflow; ++j) {
+      const uint32_t rstart = rl(it_start, j);
+      const uint32_t nex = rl(it_nex, j);
+      const uint32_t xo = rl(it_xo, j);
+      const uint32_t e0 = rl(it_e0, j);
+      const uint32_t s1 = rl(it_s1, j), e1 = rl(it_e1, j), s2 = rl(it_s2, j), e2 = rl(it_e2, j);
+      int d;
+      if (last_pos == rstart) {  // processRead :225-228
+        d = last_dist;
+      } else {
+        d = 0;
+        uint64_t lt = __ballot(lane < cnt && ns < rstart);
+        int np = lt == ~0ull ? 64 : __builtin_ctzll(~lt);  // leading run of nodes starting before the read
+        if (np > 0) {
+          uint32_t ps = rl(ns, np - 1), pe = rl(ne, np - 1);
+          if (pe >= rstart) d = (int)(rstart - ps);
+          if (d == 0) {  // clearTo(prev): drop the first np nodes
+            ns = __shfl(ns, lane + np, 64);
+            ne = __shfl(ne, lane + np, 64);
+            cnt -= np;
+          }
+        }
+        last_pos = rstart;
+        last_dist = d;
+      }
+      // mergeRead :167-219
+      if (cnt == 0) {
+        if (nex > 64) {
+          overflow = true;
+        } else {
+          if ((uint32_t)lane < nex) {
+            ns = ex_s[xo + lane];
+            ne = ex_e[xo + lane];
+          }
+          cnt = (int)nex;
+        }
+      } else {
+        int cur = 0;
+        for (uint32_t k = 0; k < nex; ++k) {
+          uint32_t es = k == 0 ? rstart : (k == 1 ? s1 : (k == 2 ? s2 : ex_s[xo + k]));
+          uint32_t ee = k == 0 ? e0 : (k == 1 ? e1 : (k == 2 ? e2 : ex_e[xo + k]));
+          uint64_t stop = __ballot(lane >= cur && lane < cnt && (ee < ns || es <= ne));
+          if (stop == 0) break;  // ran off the list: this exon and the rest are dropped
+          int n = __builtin_ctzll(stop);
+          uint32_t nS = rl(ns, n), nE = rl(ne, n);
+          if (ee < nS) {  // insert before n
+            if (cnt == 64) {
+              overflow = true;
+              break;
+            }
+            uint32_t us = __shfl_up(ns, 1, 64), ue = __shfl_up(ne, 1, 64);
+            if (lane > n) {
+              ns = us;
+              ne = ue;
+            } else if (lane == n) {
+              ns = es;
+              ne = ee;
+            }
+            cnt++;
+            cur = n + 1;
+          } else {  // overlap: union, then swallow followers (stops after the first one that extends the node)
+            uint32_t newS = es < nS ? es : nS;
+            uint32_t newE = ee > nE ? ee : nE;
+            while (n + 1 < cnt) {
+              uint32_t xS = rl(ns, n + 1);
+              if (xS > newE) break;
+              uint32_t xE = rl(ne, n + 1);
+              uint32_t ds = __shfl_down(ns, 1, 64), de = __shfl_down(ne, 1, 64);
+              if (lane > n) {
+                ns = ds;
+                ne = de;
+              }
+              cnt--;
+              if (xE > newE) {
+                newE = xE;
+                break;
+              }
+            }
+            if (lane == n) {
+              ns = newS;
+              ne = newE;
+            }
+            cur = n;
+          }
+        }
+      }
+      if (lane == j) it_d = d;
+    }
+    if (!overflow && have && it_d > 0) atomicMax(&g_yd[it_o], it_d);
+  }
+  if (overflow && lane == 0) ids_over[atomicAdd(n_over, 1u)] = c;
 }
 
 // ---- outputs ---------------------------------------------------------------------------------------------
@@ -699,9 +868,9 @@ __global__ void col_write_k(uint32_t ng, const uint32_t* __restrict__ gperm, Gro
   if (d2 > dmax) dmax = d2;
   yd[o] = dmax > 0 ? dmax : 0;
   uint32_t q = G.first[sg];
-  int32_t st = (int32_t)(uint32_t)(shi[q] & 0xFFFFFFFFull);
+  int32_t st = (int32_t)(uint32_t)((shi[q] >> 2) & 0x7FFFFFFFull);
   if (g_start) g_start[o] = st;
-  if (g_end) g_end[o] = st + (int32_t)((slo[q] >> 32) & 0x3FFFFFFFull) - 1;
+  if (g_end) g_end[o] = st + (int32_t)(uint32_t)(slo[q] >> 32) - 1;
 }
 __global__ void col_recgroup_k(uint32_t m, const uint32_t* __restrict__ val, const uint32_t* __restrict__ sgid,
                                const uint32_t* __restrict__ ginv, int32_t* __restrict__ rec_group) {
@@ -911,8 +1080,30 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
       N.s = ws_alloc<uint32_t>(ctx, nnodes + 1);
       N.e = ws_alloc<uint32_t>(ctx, nnodes + 1);
       N.nx = ws_alloc<int32_t>(ctx, nnodes + 1);
-      if (!N.nx) return TBK_ENOMEM;
-      TBK_LAUNCH(ctx, "yd_run", yd_run_k, cdiv(nchains, 64), 64, 0, I, nchains, nit, chain_first, Y, ib.val, noff, N, g_yd);
+      uint32_t* ex_s = ws_alloc<uint32_t>(ctx, nnodes + 1);
+      uint32_t* ex_e = ws_alloc<uint32_t>(ctx, nnodes + 1);
+      uint32_t* ids_short = ws_alloc<uint32_t>(ctx, nchains);
+      uint32_t* ids_long = ws_alloc<uint32_t>(ctx, nchains);
+      uint32_t* ids_over = ws_alloc<uint32_t>(ctx, nchains);
+      uint32_t* ccnt = (uint32_t*)(sc + 24);  // [0] short, [1] long, [2] overflow
+      if (!ids_over) return TBK_ENOMEM;
+      TBK_HIP(hipMemsetAsync(ccnt, 0, 4 * sizeof(uint32_t), ctx->stream));
+      TBK_LAUNCH(ctx, "yd_exons", yd_exons_k, cdiv(nit, B), B, 0, I, nit, Y, noff, ex_s, ex_e);
+      TBK_LAUNCH(ctx, "yd_classify", yd_classify_k, cdiv(nchains, B), B, 0, nchains, nit, chain_first, ids_short, ids_long, ccnt);
+      TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 24, ccnt, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+      TBK_HIP(hipStreamSynchronize(ctx->stream));
+      const uint32_t* hc = (const uint32_t*)(ctx->h_scalars + 24);
+      const uint32_t n_short = hc[0], n_long = hc[1];
+      if (n_long) {
+        TBK_LAUNCH(ctx, "yd_wave", yd_wave_k, n_long, 64, 0, ids_long, ccnt + 1, nchains, nit, chain_first, Y, ib.val, noff, ex_s,
+                   ex_e, g_yd, ids_over, ccnt + 2);
+        // chains whose list outgrew a wave (count only known on the device: launch for the upper bound)
+        TBK_LAUNCH(ctx, "yd_run_overflow", yd_run_k, cdiv(n_long, 64), 64, 0, ids_over, ccnt + 2, nchains, nit, chain_first, Y, ib.val,
+                   noff, ex_s, ex_e, N, g_yd);
+      }
+      if (n_short)
+        TBK_LAUNCH(ctx, "yd_run", yd_run_k, cdiv(n_short, 64), 64, 0, ids_short, ccnt, nchains, nit, chain_first, Y, ib.val, noff, ex_s,
+                   ex_e, N, g_yd);
     }
   }
   TBK_LAUNCH(ctx, "col_write", col_write_k, cdiv(ng, B), B, 0, ng, gperm, G, g_yd, sb.hi, sb.lo, out->cap_groups, out->rep, out->yc,
@@ -928,7 +1119,91 @@ int tbk_sample_device(tbk_ctx* ctx, const tbk_cov_in*, int32_t, tbk_sample_out*)
   ctx->last_error = "sample pipeline not built";
   return TBK_EUNSUPPORTED;
 }
-extern "C" int tbk_groups_to_cov_in(tbk_ctx* ctx, const tbk_soa_in*, const tbk_groups_out*, tbk_cov_in*) {
-  ctx->last_error = "not built";
-  return TBK_EUNSUPPORTED;
+// ---- tiebrush -> tiecov device chain -----------------------------------------------------------------------
+namespace {
+__global__ void g2c_count_k(uint32_t ng, const uint32_t* __restrict__ rep, const uint32_t* __restrict__ cig_off, uint32_t* __restrict__ cnt) {
+  uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o < ng) cnt[o] = cig_off[rep[o] + 1] - cig_off[rep[o]];
+}
+__global__ void g2c_gather_k(uint32_t ng, const uint32_t* __restrict__ rep, const double* __restrict__ yc, const int64_t* __restrict__ yx,
+                             const int32_t* __restrict__ tid, const int32_t* __restrict__ pos, const uint16_t* __restrict__ flag,
+                             const uint8_t* __restrict__ strand, const uint32_t* __restrict__ cig_off, const uint32_t* __restrict__ cig,
+                             const uint32_t* __restrict__ ooff, uint32_t total, int32_t* __restrict__ o_tid, int32_t* __restrict__ o_pos,
+                             uint16_t* __restrict__ o_flag, uint8_t* __restrict__ o_strand, double* __restrict__ o_yc,
+                             int64_t* __restrict__ o_yx, uint32_t* __restrict__ o_cig_off, uint32_t* __restrict__ o_cig) {
+  uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= ng) return;
+  uint32_t r = rep[o];
+  o_tid[o] = tid[r];
+  o_pos[o] = pos[r];
+  o_flag[o] = flag[r];
+  o_strand[o] = strand[r];
+  o_yc[o] = (double)(float)yc[o];  // the YC:f tag round trip (bam_aux_update_float, tiebrush.cpp:509)
+  o_yx[o] = yx[o];
+  uint32_t d = ooff[o];
+  o_cig_off[o] = d;
+  if (o + 1 == ng) o_cig_off[ng] = total;
+  uint32_t c0 = cig_off[r], c1 = cig_off[r + 1];
+  for (uint32_t k = c0; k < c1; ++k) o_cig[d + (k - c0)] = cig[k];
+}
+}  // namespace
+
+extern "C" int tbk_groups_to_cov_in(tbk_ctx* ctx, const tbk_soa_in* in, const tbk_groups_out* g, tbk_cov_in* view) {
+  if (!ctx || !in || !g || !view) return TBK_EINVAL;
+  if (in->mem != TBK_MEM_DEVICE || g->mem != TBK_MEM_DEVICE) return TBK_EINVAL;
+  TBK_HIP(hipSetDevice(ctx->device));
+  const uint32_t ng = g->n_groups;
+  memset(view, 0, sizeof(*view));
+  view->mem = TBK_MEM_DEVICE;
+  if (ng == 0) return 0;
+  TBK_TRY(tbk_ws_reserve(ctx, (size_t)ng * 16 + ((size_t)1 << 20)));
+  uint32_t* cnt = ws_alloc<uint32_t>(ctx, ng);
+  uint32_t* ooff = ws_alloc<uint32_t>(ctx, ng);
+  if (!ooff) return TBK_ENOMEM;
+  const uint32_t B = 256;
+  TBK_LAUNCH(ctx, "g2c_count", g2c_count_k, cdiv(ng, B), B, 0, ng, g->rep, in->cig_off, cnt);
+  TBK_TRY(tbk_exscan_u32(ctx, cnt, ooff, ng, ctx->d_scalars + 20));
+  TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 20, ctx->d_scalars + 20, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  TBK_HIP(hipStreamSynchronize(ctx->stream));
+  const uint64_t total = ctx->h_scalars[20];
+  if (total >= (1ull << 32)) return TBK_E2BIG;
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  size_t need = al((size_t)ng * 4) * 2 + al((size_t)ng * 2) + al(ng) + al((size_t)ng * 8) * 2 + al((size_t)(ng + 1) * 4) + al((size_t)total * 4 + 4);
+  if (need > ctx->d_view_cap) {
+    if (ctx->d_view) (void)hipFree(ctx->d_view);
+    ctx->d_view = nullptr;
+    ctx->d_view_cap = 0;
+    size_t cap = need + need / 4;
+    TBK_HIP(hipMalloc((void**)&ctx->d_view, cap));
+    ctx->d_view_cap = cap;
+  }
+  char* p = ctx->d_view;
+  auto take = [&](size_t bytes) {
+    char* r = p;
+    p += al(bytes);
+    return r;
+  };
+  int32_t* o_tid = (int32_t*)take((size_t)ng * 4);
+  int32_t* o_pos = (int32_t*)take((size_t)ng * 4);
+  uint16_t* o_flag = (uint16_t*)take((size_t)ng * 2);
+  uint8_t* o_strand = (uint8_t*)take(ng);
+  double* o_yc = (double*)take((size_t)ng * 8);
+  int64_t* o_yx = (int64_t*)take((size_t)ng * 8);
+  uint32_t* o_cig_off = (uint32_t*)take((size_t)(ng + 1) * 4);
+  uint32_t* o_cig = (uint32_t*)take((size_t)total * 4 + 4);
+  TBK_LAUNCH(ctx, "g2c_gather", g2c_gather_k, cdiv(ng, B), B, 0, ng, g->rep, g->yc, g->yx, in->tid, in->pos, in->flag, in->strand,
+             in->cig_off, in->cig, ooff, (uint32_t)total, o_tid, o_pos, o_flag, o_strand, o_yc, o_yx, o_cig_off, o_cig);
+  TBK_HIP(hipStreamSynchronize(ctx->stream));
+  TBK_TRY(tbk_check_launch(ctx, "groups_to_cov_in"));
+  view->n_records = ng;
+  view->n_cigar_ops = (uint32_t)total;
+  view->tid = o_tid;
+  view->pos = o_pos;
+  view->flag = o_flag;
+  view->cig_off = o_cig_off;
+  view->cig = o_cig;
+  view->yc = o_yc;
+  view->strand = o_strand;
+  view->yx = o_yx;
+  return 0;
 }

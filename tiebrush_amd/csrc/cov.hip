@@ -71,10 +71,10 @@ __global__ void cov_prep_k(uint32_t n, const uint32_t* __restrict__ valid, const
                            const uint32_t* __restrict__ cig_off, const uint32_t* __restrict__ cig,
                            const double* __restrict__ yc, int check_ops, CovArrays A, uint32_t* __restrict__ jcnt,
                            uint64_t* __restrict__ scalars, uint32_t* __restrict__ err) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   uint64_t mb = 0, ay = 0;
   uint32_t e = 0;
-  if (i < n && valid[i]) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (!valid[i]) continue;
     uint32_t j = vpos[i];
     uint32_t c0 = cig_off[i], c1 = cig_off[i + 1];
     int nex = 0;
@@ -96,11 +96,27 @@ __global__ void cov_prep_k(uint32_t n, const uint32_t* __restrict__ valid, const
     A.tid[j] = tid[i];
     if (jcnt) jcnt[j] = (uint32_t)(nex - 1);
   }
+  // block-level reduction: the three scalars share one cache line, keep the atomics to one set per block
+  __shared__ unsigned long long red_mb[4], red_ay[4];
+  __shared__ uint32_t red_e[4];
   mb = wave_sum(mb);
   ay = wave_sum(ay);
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) e |= __shfl_xor(e, d, 64);
+  uint32_t w = threadIdx.x >> 6;
   if (lane_id() == 0) {
+    red_mb[w] = mb;
+    red_ay[w] = ay;
+    red_e[w] = e;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t nw = blockDim.x >> 6;
+    for (uint32_t k = 1; k < nw; ++k) {
+      mb += red_mb[k];
+      ay += red_ay[k];
+      e |= red_e[k];
+    }
     if (mb) atomicAdd((unsigned long long*)&scalars[0], (unsigned long long)mb);
     if (ay) atomicAdd((unsigned long long*)&scalars[1], (unsigned long long)ay);
     if (e) atomicOr(err, e);
@@ -608,7 +624,7 @@ int tbk_coverage_device(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out) {
 
   TBK_LAUNCH(ctx, "cov_valid", cov_valid_k, cdiv(n, B), B, 0, in->flag, n, valid);
   TBK_TRY(tbk_exscan_u32(ctx, valid, vpos, n, sc + 2));
-  TBK_LAUNCH(ctx, "cov_prep", cov_prep_k, cdiv(n, B), B, 0, n, valid, vpos, in->tid, in->pos, in->cig_off, in->cig, in->yc,
+  TBK_LAUNCH(ctx, "cov_prep", cov_prep_k, (cdiv(n, B) < 1024u ? cdiv(n, B) : 1024u), B, 0, n, valid, vpos, in->tid, in->pos, in->cig_off, in->cig, in->yc,
              want_cov ? 1 : 0, A, jcnt, sc, ctx->d_err);
   TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   uint32_t eb = 0;

@@ -112,8 +112,7 @@ namespace {
 constexpr int RX_NT = 256;
 constexpr int RX_E = 8;                    // elements per lane per sub-tile
 constexpr int RX_SUB = RX_NT * RX_E;       // 2048
-constexpr int RX_ITER = 4;                 // sub-tiles per tile
-constexpr int RX_TILE = RX_SUB * RX_ITER;  // 8192: granularity of the (digit x tile) count table
+constexpr int RX_MAX_ITER = 16;            // sub-tiles per tile (runtime choice: tile = RX_SUB * iter)
 
 // AND / OR of all keys: bits where and == or are constant => whole digits of them are skipped
 __global__ __launch_bounds__(256) void rx_bits_k(const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo, uint32_t n,
@@ -133,7 +132,22 @@ __global__ __launch_bounds__(256) void rx_bits_k(const uint64_t* __restrict__ hi
     al &= __shfl_xor(al, d, 64);
     ol |= __shfl_xor(ol, d, 64);
   }
+  __shared__ uint64_t red[4][4];
+  uint32_t w = threadIdx.x >> 6;
   if (lane_id() == 0) {
+    red[w][0] = ah;
+    red[w][1] = oh;
+    red[w][2] = al;
+    red[w][3] = ol;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {  // one set of atomics per block: the four words are a single hot cache line
+    for (int k = 1; k < 4; ++k) {
+      ah &= red[k][0];
+      oh |= red[k][1];
+      al &= red[k][2];
+      ol |= red[k][3];
+    }
     atomicAnd((unsigned long long*)&andor[0], (unsigned long long)ah);
     atomicOr((unsigned long long*)&andor[1], (unsigned long long)oh);
     atomicAnd((unsigned long long*)&andor[2], (unsigned long long)al);
@@ -154,17 +168,26 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid) {
 
 // per-tile digit counts -> table[digit * ntiles + tile]
 __global__ __launch_bounds__(RX_NT) void rx_hist_k(const uint64_t* __restrict__ word, uint32_t shift, uint32_t n, uint32_t ntiles,
-                                                   uint32_t* __restrict__ table) {
+                                                   uint32_t iter, uint32_t* __restrict__ table) {
   __shared__ uint32_t h[256];
   h[threadIdx.x] = 0;
   __syncthreads();
-  uint64_t base = (uint64_t)blockIdx.x * RX_TILE;
-  for (int it = 0; it < RX_TILE / RX_NT; ++it) {
-    uint64_t i = base + (uint64_t)it * RX_NT + threadIdx.x;
-    bool valid = i < n;
-    uint32_t d = valid ? (uint32_t)((word[i] >> shift) & 0xFFu) : 0u;
-    uint64_t peers = match_digit(d, valid);
-    if (valid && (peers & lanemask_lt()) == 0) atomicAdd(&h[d], (uint32_t)__popcll(peers));
+  uint64_t base = (uint64_t)blockIdx.x * RX_SUB * iter;
+  for (uint32_t it = 0; it < iter; ++it) {
+    uint64_t w[RX_E];
+#pragma unroll
+    for (int e = 0; e < RX_E; ++e) {  // all loads of the sub-tile in flight before the matching starts
+      uint64_t i = base + (uint64_t)it * RX_SUB + (uint64_t)e * RX_NT + threadIdx.x;
+      w[e] = i < n ? word[i] : 0ull;
+    }
+#pragma unroll
+    for (int e = 0; e < RX_E; ++e) {
+      uint64_t i = base + (uint64_t)it * RX_SUB + (uint64_t)e * RX_NT + threadIdx.x;
+      bool valid = i < n;
+      uint32_t d = (uint32_t)((w[e] >> shift) & 0xFFu);
+      uint64_t peers = match_digit(d, valid);
+      if (valid && (peers & lanemask_lt()) == 0) atomicAdd(&h[d], (uint32_t)__popcll(peers));
+    }
   }
   __syncthreads();
   table[(uint64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
@@ -194,7 +217,7 @@ __global__ __launch_bounds__(256) void rx_rowscan_k(uint32_t* __restrict__ table
 __global__ __launch_bounds__(RX_NT) void rx_scatter_k(const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo,
                                                       const uint32_t* __restrict__ val, uint64_t* __restrict__ hi2,
                                                       uint64_t* __restrict__ lo2, uint32_t* __restrict__ val2, int use_hi,
-                                                      uint32_t shift, uint32_t n, uint32_t ntiles,
+                                                      uint32_t shift, uint32_t n, uint32_t ntiles, uint32_t iter,
                                                       const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals) {
   __shared__ uint32_t digit_base[256];  // global offset of the next element of each digit for this tile
   __shared__ uint32_t wave_cnt[4][256];
@@ -211,8 +234,8 @@ __global__ __launch_bounds__(RX_NT) void rx_scatter_k(const uint64_t* __restrict
     uint32_t dbase = block_excl_sum<uint32_t, RX_NT>(tot_d, sm, &dummy);
     digit_base[t] = dbase + table[(uint64_t)t * ntiles + blockIdx.x];
   }
-  const uint64_t tile_base = (uint64_t)blockIdx.x * RX_TILE;
-  for (int it = 0; it < RX_ITER; ++it) {
+  const uint64_t tile_base = (uint64_t)blockIdx.x * RX_SUB * iter;
+  for (uint32_t it = 0; it < iter; ++it) {
     const uint64_t sub_base = tile_base + (uint64_t)it * RX_SUB;
     if (sub_base >= n) break;
 #pragma unroll
@@ -280,8 +303,16 @@ __global__ __launch_bounds__(RX_NT) void rx_scatter_k(const uint64_t* __restrict
 }
 }  // namespace
 
+// tile = RX_SUB * iter elements: small inputs get many small tiles (occupancy), big inputs bigger tiles
+// (the digit x tile table stays a few MB)
+static uint32_t rx_iter_for(uint32_t n) {
+  uint32_t it = (uint32_t)(((uint64_t)n + (uint64_t)RX_SUB * 4096 - 1) / ((uint64_t)RX_SUB * 4096));
+  if (it < 1) it = 1;
+  if (it > RX_MAX_ITER) it = RX_MAX_ITER;
+  return it;
+}
 size_t tbk_radix_ws_bytes(uint32_t n) {
-  uint32_t ntiles = cdiv(n ? n : 1, RX_TILE);
+  uint32_t ntiles = cdiv(n ? n : 1, RX_SUB * rx_iter_for(n));
   return (size_t)256 * ntiles * 4 + 256 * 4 + 4096;
 }
 
@@ -291,14 +322,15 @@ int tbk_radix_sort128(tbk_ctx* ctx, SortBufs* b, uint32_t n) {
   uint64_t init[4] = {~0ull, 0ull, ~0ull, 0ull};
   memcpy(ctx->h_scalars + 32, init, sizeof(init));
   TBK_HIP(hipMemcpyAsync(d_andor, ctx->h_scalars + 32, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-  uint32_t g = cdiv(n, 256 * 8);
-  if (g > 2048) g = 2048;
+  uint32_t g = cdiv(n, 256 * 16);
+  if (g > 512) g = 512;
   TBK_LAUNCH(ctx, "rx_bits", rx_bits_k, g, 256, 0, b->hi, b->lo, n, d_andor);
   TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 32, d_andor, sizeof(init), hipMemcpyDeviceToHost, ctx->stream));
   TBK_HIP(hipStreamSynchronize(ctx->stream));
   uint64_t vary_hi = ctx->h_scalars[32] ^ ctx->h_scalars[33];
   uint64_t vary_lo = ctx->h_scalars[34] ^ ctx->h_scalars[35];
-  uint32_t ntiles = cdiv(n, RX_TILE);
+  const uint32_t iter = rx_iter_for(n);
+  uint32_t ntiles = cdiv(n, RX_SUB * iter);
   uint32_t* table = ws_alloc<uint32_t>(ctx, (size_t)256 * ntiles);
   uint32_t* totals = ws_alloc<uint32_t>(ctx, 256);
   if (!table || !totals) return TBK_ENOMEM;
@@ -307,10 +339,10 @@ int tbk_radix_sort128(tbk_ctx* ctx, SortBufs* b, uint32_t n) {
     for (uint32_t shift = 0; shift < 64; shift += 8) {
       if (((vary >> shift) & 0xFFull) == 0) continue;
       const uint64_t* src = word == 0 ? b->lo : b->hi;
-      TBK_LAUNCH(ctx, "rx_hist", rx_hist_k, ntiles, RX_NT, 0, src, shift, n, ntiles, table);
+      TBK_LAUNCH(ctx, "rx_hist", rx_hist_k, ntiles, RX_NT, 0, src, shift, n, ntiles, iter, table);
       TBK_LAUNCH(ctx, "rx_rowscan", rx_rowscan_k, 256, 256, 0, table, ntiles, totals);
       TBK_LAUNCH(ctx, "rx_scatter", rx_scatter_k, ntiles, RX_NT, 0, b->hi, b->lo, b->val, b->hi2, b->lo2, b->val2, word,
-                 shift, n, ntiles, table, totals);
+                 shift, n, ntiles, iter, table, totals);
       std::swap(b->hi, b->hi2);
       std::swap(b->lo, b->lo2);
       std::swap(b->val, b->val2);
