@@ -120,3 +120,32 @@ def test_fatal_op_is_reported(ctx):
     with pytest.raises(api.TbkError) as ei:
         ctx.coverage(cin)
     assert ei.value.status == -7
+
+
+@pytest.mark.parametrize("name", ["t1", "t2"])
+def test_sample_track_golden(ctx, name, bam_loader):
+    """tiecov -s: float32 running mean of YX per base in record order (ordered tile kernel)"""
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import api, soa
+    b = bam_loader(os.path.join(GOLDEN, name, name + ".bam"))
+    cin = soa.cov_input_from_bam(b)
+    want = orc.coverage(cin, want_cov=False, want_junc=False, num_samples=10)
+    for dev in (False, True):
+        got = api.to_numpy(ctx.sample(api.to_device(cin, "cuda:0") if dev else cin, 10,
+                                      cap_intervals=want["n_sample"] + 1000))
+        assert got["n_sample"] == want["n_sample"]
+        for k in ("s_tid", "s_start", "s_end", "s_count", "s_heat"):
+            assert np.array_equal(got[k], want[k]), k
+
+
+def test_sample_track_synthetic_deep(ctx):
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import api, synth
+    tile = synth.make_tile(6, 30000, "c2", n_loci=200)
+    groups = orc.collapse(tile)
+    cin = synth.collapsed_to_cov_input(tile, groups)
+    want = orc.coverage(cin, want_cov=False, want_junc=False, num_samples=6)
+    got = api.to_numpy(ctx.sample(cin, 6))
+    assert got["n_sample"] == want["n_sample"]
+    for k in ("s_tid", "s_start", "s_end", "s_count", "s_heat"):
+        assert np.array_equal(got[k], want[k]), k

@@ -1,0 +1,114 @@
+"""CPU tests of the host-side C++ (BGZF/BAM codec, TInputFiles mirror, SoA tile loader, htslib tag rules)
+against the independent Python codec and the oracle.  No GPU involved."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, sample_paths
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, "tiebrush_amd", "_build", "tbh_tool")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    if not os.path.exists(TOOL):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tiebrush_amd", "csrc", "host"), "-s",
+                        os.path.join("..", "..", "_build", "tbh_tool")], check=True)
+
+
+def test_bam_roundtrip_is_byte_identical_after_inflate(tmp_path):
+    from tiebrush_amd import bamio
+    for src in (os.path.join(GOLDEN, "t1", "t1.bam"), os.path.join(GOLDEN, "t2", "t2s2.bam")):
+        out = str(tmp_path / "o.bam")
+        subprocess.run([TOOL, "cat", src, out], check=True)
+        a = bamio.bgzf_decompress(open(src, "rb").read())
+        b = bamio.bgzf_decompress(open(out, "rb").read())
+        ha, pa = bamio.parse_header(a)
+        hb, pb = bamio.parse_header(b)
+        assert ha.text.rstrip("\n") == hb.text.rstrip("\n") and ha.ref_names == hb.ref_names and ha.ref_lens == hb.ref_lens
+        assert a[pa:] == b[pb:]
+        assert open(out, "rb").read().endswith(bamio._BGZF_EOF)
+
+
+def test_merge_order_matches_oracle(bam_loader):
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import soa
+    paths = sample_paths("t2")[:5]
+    bams = [bam_loader(p) for p in paths]
+    tile = soa.tile_from_bams(bams)
+    want = orc.collapse(tile, want_merge_order=True)["merge_order"]
+    fo = tile.file_of()
+    want_pairs = np.stack([fo[want], want - tile.file_off[fo[want]]], axis=1)
+    out = subprocess.run([TOOL, "mergeorder"] + paths, check=True, capture_output=True, text=True).stdout
+    got = np.array([[int(x) for x in l.split()] for l in out.splitlines()], dtype=np.int64)
+    assert np.array_equal(got, want_pairs)
+
+
+def test_soa_tile_matches_python_decoder(tmp_path, bam_loader):
+    from tiebrush_amd import soa
+    paths = [os.path.join(GOLDEN, "t1", "t1.bam")] + sample_paths("t2")[:2]
+    bams = [bam_loader(p, keep_md=True) for p in paths]
+    tile = soa.tile_from_bams(bams, with_names=True, with_md=True)
+    d = str(tmp_path)
+    subprocess.run([TOOL, "soa", d] + paths, check=True)
+
+    def rd(name, dt):
+        return np.fromfile(os.path.join(d, name), dtype=dt)
+
+    assert np.array_equal(rd("file_off", np.uint32), tile.file_off)
+    assert rd("tbmerged", np.uint8).tolist() == [1, 0, 0]
+    for name, dt in (("tid", np.int32), ("pos", np.int32), ("flag", np.uint16), ("mapq", np.uint8), ("strand", np.uint8),
+                     ("nh", np.int32), ("cig_off", np.uint32), ("cig", np.uint32), ("md_off", np.uint32), ("md", np.uint8),
+                     ("md_has", np.uint8), ("qname_hash", np.uint64)):
+        assert np.array_equal(rd(name, dt), getattr(tile, name)), name
+    # carried tags are only meaningful for TieBrush-merged files
+    n0 = int(tile.file_off[1])
+    assert np.array_equal(rd("yc_in", np.float64)[:n0], tile.yc_in[:n0])
+    assert np.array_equal(rd("yx_in", np.int64)[:n0], tile.yx_in[:n0])
+    assert np.array_equal(rd("yd_in", np.int64)[:n0], tile.yd_in[:n0])
+    hdr = open(os.path.join(d, "header.txt")).read()
+    co = [l for l in hdr.split("\n") if l.startswith("@CO\tSAMPLE:")]
+    assert len(co) == 12 and co[-1].endswith("t2s1.bam") and co[0].endswith("t1s0.bam")
+    pg = [l for l in hdr.split("\n") if l.startswith("@PG")]
+    assert pg[-1].startswith("@PG\tID:TieBrush.1\tPN:TieBrush\tPP:TieBrush\tVN:test")
+
+
+@pytest.mark.parametrize("val,typ", [(0, "C"), (254, "C"), (255, "S"), (65534, "S"), (65535, "I"), (-1, "c"), (-129, "s"),
+                                     (-40000, "i"), (70000, "I")])
+def test_int_tag_width_rules_on_append(tmp_path, val, typ):
+    """htslib bam_aux_update_int: strict '<' against UINT8_MAX / UINT16_MAX (goldens: YD 255 -> S, 254 -> C)"""
+    from tiebrush_amd import bamio
+    src = os.path.join(GOLDEN, "t2", "t2s2.bam")
+    out = str(tmp_path / "o.bam")
+    subprocess.run([TOOL, "tags", src, out, "ZZ=i:%d" % val], check=True)
+    b = bamio.read_bam(out)
+    aux = bamio.record_aux(b, 0)
+    assert aux[-1] == ("ZZ", typ, val)
+
+
+def test_tag_update_in_place_rules(tmp_path):
+    from tiebrush_amd import bamio
+    src = os.path.join(GOLDEN, "t1", "t1.bam")   # records carry YC:C (0.0.6 format), some YD:C
+    out = str(tmp_path / "o.bam")
+    # float update of an integer-typed YC fails (EINVAL) and the stale value survives; YX appended;
+    # YD widened in place when needed, deleted with "del"
+    subprocess.run([TOOL, "tags", src, out, "YC=f:7.5", "YX=i:3", "YD=i:300"], check=True)
+    a, b = bamio.read_bam(src), bamio.read_bam(out)
+    for i in (0, 1, 2, 50):
+        aa, bb = dict((t, (ty, v)) for t, ty, v in bamio.record_aux(a, i)), dict((t, (ty, v)) for t, ty, v in bamio.record_aux(b, i))
+        if "YC" in aa:
+            assert bb["YC"] == aa["YC"]
+        else:
+            assert bb["YC"] == ("f", 7.5)
+        assert bb["YX"][1] == 3 and bb["YD"] == ("S", 300)
+        order_a = [t for t, _, _ in bamio.record_aux(a, i)]
+        order_b = [t for t, _, _ in bamio.record_aux(b, i)]
+        assert order_b[:len(order_a)] == order_a     # existing tags keep their positions
+    out2 = str(tmp_path / "o2.bam")
+    subprocess.run([TOOL, "tags", out, out2, "YD=i:5", "YX=del"], check=True)
+    c = bamio.read_bam(out2)
+    cc = dict((t, (ty, v)) for t, ty, v in bamio.record_aux(c, 1))
+    assert cc["YD"] == ("S", 5) and "YX" not in cc   # old width kept when it is wide enough

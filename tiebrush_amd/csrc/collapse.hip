@@ -1115,10 +1115,6 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
   return tbk_check_launch(ctx, "collapse");
 }
 
-int tbk_sample_device(tbk_ctx* ctx, const tbk_cov_in*, int32_t, tbk_sample_out*) {
-  ctx->last_error = "sample pipeline not built";
-  return TBK_EUNSUPPORTED;
-}
 // ---- tiebrush -> tiecov device chain -----------------------------------------------------------------------
 namespace {
 __global__ void g2c_count_k(uint32_t ng, const uint32_t* __restrict__ rep, const uint32_t* __restrict__ cig_off, uint32_t* __restrict__ cnt) {

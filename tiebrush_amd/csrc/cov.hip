@@ -404,8 +404,12 @@ __global__ void cov_iv_write_k(uint32_t ncp, uint32_t nb, CovArrays A, const uin
 // ---- ordered double path (non-integral YC): per base, add in record order -------------------
 // One thread per base of the tile; candidate segments = spills (sorted by record) then home
 // records in file order — the same order in which the reference's addCov touches the base.
+// SAMPLE = true computes tiecov -s instead (addMean, tiecov.cpp:155-185): per base a float32 running mean of YX
+// in record order, mean += (val - mean) / cnt; cnt++ starting from (0, 1); the emitted value is ceil(mean).
+template <bool SAMPLE>
 __global__ __launch_bounds__(COV_NT) void cov_tile_ordered_k(uint32_t m, uint64_t S, CovArrays A, const uint32_t* __restrict__ cig_off,
                                                              const uint32_t* __restrict__ cig, const double* __restrict__ yc,
+                                                             const int64_t* __restrict__ yx,
                                                              const uint32_t* __restrict__ sp_off, const uint32_t* __restrict__ sp_seg,
                                                              const uint32_t* __restrict__ sp_rec, uint64_t* __restrict__ cp_pos,
                                                              double* __restrict__ cp_val, uint32_t* __restrict__ tile_cp_base,
@@ -420,7 +424,33 @@ __global__ __launch_bounds__(COV_NT) void cov_tile_ordered_k(uint32_t m, uint64_
   const uint64_t tile = blockIdx.x;
   const uint64_t t0 = tile * COV_W;
   const uint32_t wlen = (uint32_t)((S - t0) < (uint64_t)COV_W ? (S - t0) : (uint64_t)COV_W);
-  for (uint32_t p = t; p < COV_W + COV_W / 32 + 1; p += COV_NT) depth[p] = 0.0;
+  float* s_mean = reinterpret_cast<float*>(depth);        // SAMPLE: slot q -> mean at [2q], cnt at [2q+1]
+  uint32_t* s_cnt = reinterpret_cast<uint32_t*>(depth);
+  auto add_base = [&](uint32_t q, double y, float val) {
+    if constexpr (SAMPLE) {
+      float mean = s_mean[2 * q];
+      uint32_t c = s_cnt[2 * q + 1];
+      mean += (val - mean) / (float)c;
+      s_mean[2 * q] = mean;
+      s_cnt[2 * q + 1] = c + 1;
+    } else {
+      depth[q] += y;
+    }
+  };
+  auto base_value = [&](uint32_t q) -> double {
+    if constexpr (SAMPLE)
+      return (double)(unsigned long long)ceilf(s_mean[2 * q]);
+    else
+      return depth[q];
+  };
+  for (uint32_t p = t; p < COV_W + COV_W / 32 + 1; p += COV_NT) {
+    if constexpr (SAMPLE) {
+      s_mean[2 * p] = 0.0f;
+      s_cnt[2 * p + 1] = 1u;
+    } else {
+      depth[p] = 0.0;
+    }
+  }
   if (t < COV_W / 32) brk[t] = 0;
   if (t < 2) {
     uint64_t key = t0 + (uint64_t)t * COV_W;
@@ -459,13 +489,14 @@ __global__ __launch_bounds__(COV_NT) void cov_tile_ordered_k(uint32_t m, uint64_
       __syncthreads();
       if (nx == 0xFFFFFFFFu) break;
       double y = yc ? yc[A.ridx[nx]] : 1.0;
+      float val = SAMPLE ? (float)(int)(float)(yx ? yx[A.ridx[nx]] : 1) : 0.0f;
       for (uint32_t s = s0; s < s1; ++s) {
         if (sp_rec[s] != nx) continue;
         uint32_t seg = sp_seg[s];
         uint32_t off = seg & 0xFFFFu, len = (seg >> 16) + 1;
         // thread t owns bases p with p % COV_NT == t
         uint32_t first = off + ((t + COV_NT - (off % COV_NT)) % COV_NT);
-        for (uint32_t p = first; p < off + len; p += COV_NT) depth[padidx(p)] += y;
+        for (uint32_t p = first; p < off + len; p += COV_NT) add_base(padidx(p), y, val);
       }
       last = nx;
     }
@@ -474,6 +505,7 @@ __global__ __launch_bounds__(COV_NT) void cov_tile_ordered_k(uint32_t m, uint64_
   for (uint32_t j = r0; j < r1; ++j) {  // home records, file order; all threads walk the same record
     uint32_t i = A.ridx[j];
     double y = yc ? yc[i] : 1.0;
+    float val = SAMPLE ? (float)(int)(float)(yx ? yx[i] : 1) : 0.0f;
     uint64_t p = A.cs[j];
     if (t == 0 && A.bhead[j]) brk[(uint32_t)(p - t0) >> 5] |= 1u << ((uint32_t)(p - t0) & 31);
     uint32_t c0 = cig_off[i], c1 = cig_off[i + 1];
@@ -486,7 +518,7 @@ __global__ __launch_bounds__(COV_NT) void cov_tile_ordered_k(uint32_t m, uint64_
           uint32_t la = (uint32_t)(a - t0);
           uint32_t lb = (uint32_t)((b < t0 + COV_W ? b : t0 + COV_W) - t0);
           uint32_t first = la + ((t + COV_NT - (la % COV_NT)) % COV_NT);
-          for (uint32_t q = first; q < lb; q += COV_NT) depth[padidx(q)] += y;
+          for (uint32_t q = first; q < lb; q += COV_NT) add_base(padidx(q), y, val);
         }
         p = b;
       } else if (op == C_D || op == C_N) {
@@ -501,8 +533,8 @@ __global__ __launch_bounds__(COV_NT) void cov_tile_ordered_k(uint32_t m, uint64_
   uint32_t mask = 0;
   for (int q = 0; q < COV_PER; ++q) {
     uint32_t p = pb + q;
-    double d = depth[padidx(p)];
-    double pv = p ? depth[padidx(p - 1)] : 0.0;
+    double d = base_value(padidx(p));
+    double pv = p ? base_value(padidx(p - 1)) : 0.0;
     bool cp = (p < wlen) && (p == 0 || d != pv || ((bw >> q) & 1u));
     mask |= cp ? (1u << q) : 0u;
     cnt += cp ? 1u : 0u;
@@ -524,7 +556,7 @@ __global__ __launch_bounds__(COV_NT) void cov_tile_ordered_k(uint32_t m, uint64_
         uint32_t p = pb + q;
         bool tent = (p == 0) && !((bw >> q) & 1u);
         cp_pos[o] = (t0 + p) | (tent ? (1ull << 63) : 0ull);
-        cp_val[o] = depth[padidx(p)];
+        cp_val[o] = base_value(padidx(p));
         ++o;
       }
     }
@@ -590,7 +622,19 @@ __global__ void junc_write_k(uint32_t nj, CovArrays A, const uint64_t* __restric
 }  // namespace
 
 // =============================================================================================
-int tbk_coverage_device(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out) {
+namespace {
+__global__ void sample_convert_k(uint32_t n, const double* __restrict__ v, float denom, int64_t* __restrict__ cnt, float* __restrict__ heat) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long c = (unsigned long long)v[i];
+  cnt[i] = (int64_t)c;
+  const float mint = 0.1f, maxt = 1.5f;  // normalize(bsam,0.1,1.5,n) tiecov.cpp:316-323, float32 arithmetic
+  const float mult = (maxt - mint);
+  heat[i] = ((float)c / denom) * mult + mint;
+}
+}  // namespace
+
+static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sample_mode) {
   const uint32_t n = in->n_records;
   const bool want_cov = out->cap_intervals > 0, want_j = out->cap_junctions > 0;
   out->n_intervals = out->n_junctions = 0;
@@ -624,8 +668,8 @@ int tbk_coverage_device(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out) {
 
   TBK_LAUNCH(ctx, "cov_valid", cov_valid_k, cdiv(n, B), B, 0, in->flag, n, valid);
   TBK_TRY(tbk_exscan_u32(ctx, valid, vpos, n, sc + 2));
-  TBK_LAUNCH(ctx, "cov_prep", cov_prep_k, (cdiv(n, B) < 1024u ? cdiv(n, B) : 1024u), B, 0, n, valid, vpos, in->tid, in->pos, in->cig_off, in->cig, in->yc,
-             want_cov ? 1 : 0, A, jcnt, sc, ctx->d_err);
+  TBK_LAUNCH(ctx, "cov_prep", cov_prep_k, (cdiv(n, B) < 1024u ? cdiv(n, B) : 1024u), B, 0, n, valid, vpos, in->tid, in->pos, in->cig_off, in->cig,
+             sample_mode ? (const double*)nullptr : in->yc, want_cov ? 1 : 0, A, jcnt, sc, ctx->d_err);
   TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   uint32_t eb = 0;
   TBK_TRY(tbk_sync_err(ctx, &eb));
@@ -697,9 +741,12 @@ int tbk_coverage_device(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out) {
     if (nspill)
       TBK_LAUNCH(ctx, "cov_spill_fill", cov_spill_fill_k, cdiv(m, B), B, 0, m, A, in->cig_off, in->cig, tile_off, tile_fill,
                  sp_seg, sp_rec);
-    if (fractional) {
-      TBK_LAUNCH(ctx, "cov_tile_ordered", cov_tile_ordered_k, ntiles, COV_NT, 0, m, S, A, in->cig_off, in->cig, in->yc, tile_off,
-                 sp_seg, sp_rec, cp_pos, cp_val, tile_cp_base, tile_cp_cnt, cp_alloc, cp_cap, ctx->d_err);
+    if (sample_mode) {
+      TBK_LAUNCH(ctx, "sample_tile", (cov_tile_ordered_k<true>), ntiles, COV_NT, 0, m, S, A, in->cig_off, in->cig, in->yc, in->yx,
+                 tile_off, sp_seg, sp_rec, cp_pos, cp_val, tile_cp_base, tile_cp_cnt, cp_alloc, cp_cap, ctx->d_err);
+    } else if (fractional) {
+      TBK_LAUNCH(ctx, "cov_tile_ordered", (cov_tile_ordered_k<false>), ntiles, COV_NT, 0, m, S, A, in->cig_off, in->cig, in->yc,
+                 in->yx, tile_off, sp_seg, sp_rec, cp_pos, cp_val, tile_cp_base, tile_cp_cnt, cp_alloc, cp_cap, ctx->d_err);
     } else if (sum_abs < (1ull << 31)) {
       TBK_LAUNCH(ctx, "cov_tile", (cov_tile_k<int32_t>), ntiles, COV_NT, 0, m, S, A, in->cig_off, in->cig, in->yc, tile_off,
                  sp_seg, sp_rec, cp_pos, cp_val, tile_cp_base, tile_cp_cnt, cp_alloc, cp_cap, ctx->d_err);
@@ -761,4 +808,29 @@ int tbk_coverage_device(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out) {
     if (out->n_junctions > out->cap_junctions) return TBK_E2BIG;
   }
   return 0;
+}
+
+int tbk_coverage_device(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out) { return cov_run(ctx, in, out, false); }
+
+// tiecov -s (addMean / discretize / normalize / flushCoverage(pair), tiecov.cpp:155-185, :277-323)
+int tbk_sample_device(tbk_ctx* ctx, const tbk_cov_in* in, int32_t num_samples, tbk_sample_out* out) {
+  out->n_intervals = 0;
+  if (out->cap_intervals == 0 || !out->iv_tid || !out->iv_start || !out->iv_end || !out->iv_count || !out->iv_heat) return TBK_EINVAL;
+  tbk_cov_out co;
+  memset(&co, 0, sizeof(co));
+  co.mem = TBK_MEM_DEVICE;
+  co.cap_intervals = out->cap_intervals;
+  co.iv_tid = out->iv_tid;
+  co.iv_start = out->iv_start;
+  co.iv_end = out->iv_end;
+  co.iv_val = ws_alloc<double>(ctx, out->cap_intervals);
+  if (!co.iv_val) return TBK_ENOMEM;
+  TBK_TRY(cov_run(ctx, in, &co, true));
+  out->n_intervals = co.n_intervals;
+  if (co.n_intervals) {
+    TBK_LAUNCH(ctx, "sample_convert", sample_convert_k, cdiv(co.n_intervals, 256), 256, 0, co.n_intervals, co.iv_val, (float)num_samples,
+               out->iv_count, out->iv_heat);
+    TBK_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return tbk_check_launch(ctx, "sample");
 }

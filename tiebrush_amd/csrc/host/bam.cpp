@@ -1,0 +1,368 @@
+#include "bam.h"
+
+#include <string.h>
+
+#include <sstream>
+
+#include "bgzf.h"
+
+namespace tbh {
+
+static inline uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+static inline uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+static inline void wr32(std::vector<uint8_t>& o, uint32_t v) {
+  for (int k = 0; k < 4; ++k) o.push_back((uint8_t)(v >> (8 * k)));
+}
+
+// ---- header ---------------------------------------------------------------------------------------
+bool BamHeader::parse(const std::vector<uint8_t>& data, size_t* rec_begin, std::string& err) {
+  if (data.size() < 12 || memcmp(data.data(), "BAM\1", 4) != 0) {
+    err = "not a BAM stream";
+    return false;
+  }
+  uint32_t l_text = rd32(&data[4]);
+  if (8 + (size_t)l_text + 4 > data.size()) {
+    err = "truncated BAM header";
+    return false;
+  }
+  text.assign((const char*)&data[8], l_text);
+  size_t z = text.find('\0');
+  if (z != std::string::npos) text.resize(z);
+  if (!text.empty() && text.back() != '\n') text.push_back('\n');
+  size_t p = 8 + l_text;
+  n_targets = (int32_t)rd32(&data[p]);
+  p += 4;
+  target_name.clear();
+  target_len.clear();
+  for (int32_t i = 0; i < n_targets; ++i) {
+    if (p + 4 > data.size()) {
+      err = "truncated reference list";
+      return false;
+    }
+    uint32_t l_name = rd32(&data[p]);
+    if (p + 8 + l_name > data.size()) {
+      err = "truncated reference list";
+      return false;
+    }
+    target_name.emplace_back((const char*)&data[p + 4], l_name ? l_name - 1 : 0);
+    target_len.push_back(rd32(&data[p + 4 + l_name]));
+    p += 8 + l_name;
+  }
+  *rec_begin = p;
+  return true;
+}
+
+void BamHeader::serialize(std::vector<uint8_t>& out) const {
+  out.insert(out.end(), {'B', 'A', 'M', 1});
+  wr32(out, (uint32_t)text.size());
+  out.insert(out.end(), text.begin(), text.end());
+  wr32(out, (uint32_t)n_targets);
+  for (int32_t i = 0; i < n_targets; ++i) {
+    wr32(out, (uint32_t)target_name[i].size() + 1);
+    out.insert(out.end(), target_name[i].begin(), target_name[i].end());
+    out.push_back(0);
+    wr32(out, target_len[i]);
+  }
+}
+
+std::vector<std::string> BamHeader::lines() const {
+  std::vector<std::string> r;
+  size_t s = 0;
+  while (s < text.size()) {
+    size_t e = text.find('\n', s);
+    if (e == std::string::npos) e = text.size();
+    if (e > s) r.push_back(text.substr(s, e - s));
+    s = e + 1;
+  }
+  return r;
+}
+
+static std::vector<std::string> split_tabs(const std::string& l) {
+  std::vector<std::string> f;
+  size_t s = 0;
+  for (;;) {
+    size_t e = l.find('\t', s);
+    f.push_back(l.substr(s, e == std::string::npos ? std::string::npos : e - s));
+    if (e == std::string::npos) break;
+    s = e + 1;
+  }
+  return f;
+}
+
+bool BamHeader::sorted_by_coordinate() const {
+  for (auto& l : lines())
+    if (l.compare(0, 3, "@HD") == 0)
+      for (auto& f : split_tabs(l))
+        if (f == "SO:coordinate") return true;
+  return false;
+}
+
+bool BamHeader::is_tiebrush() const {
+  for (auto& l : lines()) {
+    if (l.compare(0, 3, "@PG") != 0) continue;
+    bool pn = false, vn = false;
+    for (auto& f : split_tabs(l)) {
+      if (f == "PN:TieBrush") pn = true;
+      if (f.compare(0, 3, "VN:") == 0) vn = true;
+    }
+    if (pn && vn) return true;
+  }
+  return false;
+}
+
+std::vector<std::string> BamHeader::co_samples() const {
+  std::vector<std::string> r;
+  for (auto& l : lines())
+    if (l.compare(0, 11, "@CO\tSAMPLE:") == 0) {
+      std::string v = l.substr(11);
+      size_t t = v.find('\t');  // tmerge.cpp:211 reads up to the next tab
+      if (t != std::string::npos) v.resize(t);
+      r.push_back(v);
+    }
+  return r;
+}
+
+int BamHeader::name2tid(const std::string& name) const {
+  for (int32_t i = 0; i < n_targets; ++i)
+    if (target_name[i] == name) return i;
+  return -1;
+}
+
+static void insert_after_last(std::string& text, const char* type3, const std::string& line) {
+  // position just after the last line starting with type3 ("@CO"/"@PG"); end of text when none
+  size_t best = std::string::npos, s = 0;
+  while (s < text.size()) {
+    size_t e = text.find('\n', s);
+    if (e == std::string::npos) e = text.size() - 1;
+    if (text.compare(s, 3, type3) == 0) best = e + 1;
+    s = e + 1;
+  }
+  if (best == std::string::npos) best = text.size();
+  text.insert(best, line + "\n");
+}
+
+void BamHeader::add_co(const std::string& payload) { insert_after_last(text, "@CO", "@CO\t" + payload); }
+
+void BamHeader::add_pg(const std::string& name, const std::string& ver, const std::string& cl) {
+  std::vector<std::string> ids;
+  std::string last_id;
+  for (auto& l : lines())
+    if (l.compare(0, 3, "@PG") == 0)
+      for (auto& f : split_tabs(l))
+        if (f.compare(0, 3, "ID:") == 0) {
+          ids.push_back(f.substr(3));
+          last_id = f.substr(3);
+        }
+  std::string id = name;
+  for (int k = 1;; ++k) {
+    bool clash = false;
+    for (auto& x : ids) clash |= (x == id);
+    if (!clash) break;
+    id = name + "." + std::to_string(k);
+  }
+  std::string line = "@PG\tID:" + id + "\tPN:" + name;
+  if (!last_id.empty()) line += "\tPP:" + last_id;
+  line += "\tVN:" + ver + "\tCL:" + cl;
+  // after the last @PG; when there is none, before any @CO block (htslib keeps @CO last)
+  bool has_pg = !ids.empty();
+  if (has_pg) {
+    insert_after_last(text, "@PG", line);
+  } else {
+    size_t co = std::string::npos, s = 0;
+    while (s < text.size()) {
+      size_t e = text.find('\n', s);
+      if (e == std::string::npos) e = text.size() - 1;
+      if (text.compare(s, 3, "@CO") == 0) {
+        co = s;
+        break;
+      }
+      s = e + 1;
+    }
+    if (co == std::string::npos) co = text.size();
+    text.insert(co, line + "\n");
+  }
+}
+
+// ---- records -----------------------------------------------------------------------------------------
+int32_t RecView::tid() const { return (int32_t)rd32(p); }
+int32_t RecView::pos() const { return (int32_t)rd32(p + 4); }
+uint16_t RecView::n_cigar() const { return rd16(p + 12); }
+uint16_t RecView::flag() const { return rd16(p + 14); }
+int32_t RecView::l_seq() const { return (int32_t)rd32(p + 16); }
+uint32_t RecView::cigar(uint32_t i) const { return rd32(cigar_bytes() + 4 * i); }
+const uint8_t* RecView::aux_begin() const {
+  int32_t ls = l_seq();
+  return cigar_bytes() + 4 * (size_t)n_cigar() + (size_t)((ls + 1) / 2) + (size_t)ls;
+}
+
+static size_t type_size(uint8_t t) {
+  switch (t) {
+    case 'A': case 'c': case 'C': return 1;
+    case 's': case 'S': return 2;
+    case 'i': case 'I': case 'f': return 4;
+    case 'd': return 8;
+  }
+  return 0;
+}
+
+size_t aux_field_size(const uint8_t* f, const uint8_t* end) {
+  if (f + 3 > end) return 0;
+  uint8_t t = f[2];
+  size_t fs = type_size(t);
+  if (fs) return f + 3 + fs <= end ? 3 + fs : 0;
+  if (t == 'Z' || t == 'H') {
+    const uint8_t* z = (const uint8_t*)memchr(f + 3, 0, (size_t)(end - (f + 3)));
+    return z ? (size_t)(z - f) + 1 : 0;
+  }
+  if (t == 'B') {
+    if (f + 8 > end) return 0;
+    size_t es = type_size(f[3]);
+    if (!es || f[3] == 'A' || f[3] == 'd') return 0;
+    size_t n = rd32(f + 4);
+    return f + 8 + n * es <= end ? 8 + n * es : 0;
+  }
+  return 0;
+}
+
+const uint8_t* aux_get(const uint8_t* aux, const uint8_t* end, const char tag[2]) {
+  const uint8_t* f = aux;
+  while (f + 3 <= end) {
+    size_t sz = aux_field_size(f, end);
+    if (!sz) return nullptr;
+    if (f[0] == (uint8_t)tag[0] && f[1] == (uint8_t)tag[1]) return f + 2;
+    f += sz;
+  }
+  return nullptr;
+}
+
+int64_t aux2i(const uint8_t* s) {
+  switch (*s) {
+    case 'c': return (int8_t)s[1];
+    case 'C': return s[1];
+    case 's': return (int16_t)rd16(s + 1);
+    case 'S': return rd16(s + 1);
+    case 'i': return (int32_t)rd32(s + 1);
+    case 'I': return rd32(s + 1);
+  }
+  return 0;
+}
+double aux2f(const uint8_t* s) {
+  if (*s == 'd') {
+    double v;
+    memcpy(&v, s + 1, 8);
+    return v;
+  }
+  if (*s == 'f') {
+    float v;
+    memcpy(&v, s + 1, 4);
+    return v;
+  }
+  return (double)aux2i(s);
+}
+char aux2A(const uint8_t* s) { return *s == 'A' ? (char)s[1] : 0; }
+const char* aux2Z(const uint8_t* s) { return (*s == 'Z' || *s == 'H') ? (const char*)(s + 1) : nullptr; }
+
+int BamRec::update_int(const char tag[2], int64_t val) {
+  if (val < INT32_MIN || val > (int64_t)UINT32_MAX) return -1;
+  uint8_t type;
+  uint32_t sz;
+  if (val < INT16_MIN) { type = 'i'; sz = 4; }
+  else if (val < INT8_MIN) { type = 's'; sz = 2; }
+  else if (val < 0) { type = 'c'; sz = 1; }
+  else if (val < UINT8_MAX) { type = 'C'; sz = 1; }      // 255 does NOT fit 'C' (strict <)
+  else if (val < UINT16_MAX) { type = 'S'; sz = 2; }
+  else { type = 'I'; sz = 4; }
+  RecView v = view();
+  const uint8_t* s = aux_get(v.aux_begin(), v.aux_end(), tag);
+  uint8_t le[4];
+  uint32_t uv = (uint32_t)val;
+  for (int k = 0; k < 4; ++k) le[k] = (uint8_t)(uv >> (8 * k));
+  if (!s) {  // append tag,type,value
+    d.push_back((uint8_t)tag[0]);
+    d.push_back((uint8_t)tag[1]);
+    d.push_back(type);
+    d.insert(d.end(), le, le + sz);
+    return 0;
+  }
+  uint32_t old_sz;
+  switch (*s) {
+    case 'c': case 'C': old_sz = 1; break;
+    case 's': case 'S': old_sz = 2; break;
+    case 'i': case 'I': old_sz = 4; break;
+    default: return -1;  // EINVAL: not an integer tag, stale value survives
+  }
+  size_t off = (size_t)(s - d.data());
+  if (old_sz < sz) {
+    d.insert(d.begin() + off + 1 + old_sz, sz - old_sz, 0);
+  } else {  // reuse the old width; only the sign class of the type letter follows the value
+    sz = old_sz;
+    type = (uint8_t)((val < 0 ? "\0cs\0i" : "\0CS\0I")[old_sz]);
+  }
+  d[off] = type;
+  memcpy(&d[off + 1], le, sz);
+  return 0;
+}
+
+int BamRec::update_float(const char tag[2], float val) {
+  RecView v = view();
+  const uint8_t* s = aux_get(v.aux_begin(), v.aux_end(), tag);
+  uint8_t le[4];
+  memcpy(le, &val, 4);
+  if (!s) {
+    d.push_back((uint8_t)tag[0]);
+    d.push_back((uint8_t)tag[1]);
+    d.push_back('f');
+    d.insert(d.end(), le, le + 4);
+    return 0;
+  }
+  size_t off = (size_t)(s - d.data());
+  if (*s == 'd') {
+    d.erase(d.begin() + off + 5, d.begin() + off + 9);
+  } else if (*s != 'f') {
+    return -1;  // EINVAL: the reference ignores the return value (GSam.h:303-305)
+  }
+  d[off] = 'f';
+  memcpy(&d[off + 1], le, 4);
+  return 0;
+}
+
+int BamRec::del(const char tag[2]) {
+  RecView v = view();
+  const uint8_t* s = aux_get(v.aux_begin(), v.aux_end(), tag);
+  if (!s) return 0;
+  size_t off = (size_t)(s - 2 - d.data());
+  size_t sz = aux_field_size(d.data() + off, d.data() + d.size());
+  if (!sz) return -1;
+  d.erase(d.begin() + off, d.begin() + off + sz);
+  return 0;
+}
+
+bool BamFile::load(const std::string& p, std::string& err, int threads) {
+  path = p;
+  if (!bgzf_read_file(p, data, err, threads)) return false;
+  size_t off = 0;
+  if (!hdr.parse(data, &off, err)) {
+    err += " (" + p + ")";
+    return false;
+  }
+  rec_off.clear();
+  while (off + 4 <= data.size()) {
+    uint32_t bs = rd32(&data[off]);
+    if (bs < 32 || off + 4 + bs > data.size()) {
+      err = "corrupt record in " + p;
+      return false;
+    }
+    rec_off.push_back(off);
+    off += 4 + (size_t)bs;
+  }
+  return true;
+}
+
+RecView BamFile::rec(size_t i) const {
+  RecView v;
+  v.p = data.data() + rec_off[i] + 4;
+  v.len = rd32(data.data() + rec_off[i]);
+  return v;
+}
+
+}  // namespace tbh

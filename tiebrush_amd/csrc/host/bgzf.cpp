@@ -1,0 +1,202 @@
+#include "bgzf.h"
+
+#include <stdio.h>
+#include <string.h>
+#include <zlib.h>
+
+#include <atomic>
+#include <thread>
+
+namespace tbh {
+
+static const uint8_t kEof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43,
+                                 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+static constexpr size_t kBlock = 0xff00;
+
+static inline uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+static inline uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+bool bgzf_probe(const std::string& path) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  uint8_t h[18];
+  size_t n = fread(h, 1, sizeof(h), f);
+  fclose(f);
+  return n == sizeof(h) && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) && h[12] == 'B' && h[13] == 'C';
+}
+
+struct Member {
+  size_t off;    // start of the member in the file
+  size_t cdata;  // start of the deflate stream
+  size_t clen;
+  uint32_t isize;
+  size_t out_off;
+};
+
+bool bgzf_read_file(const std::string& path, std::vector<uint8_t>& out, std::string& err, int threads) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) {
+    err = "cannot open " + path;
+    return false;
+  }
+  std::vector<uint8_t> raw;
+  fseek(f, 0, SEEK_END);
+  long sz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  raw.resize(sz > 0 ? (size_t)sz : 0);
+  if (sz > 0 && fread(raw.data(), 1, raw.size(), f) != raw.size()) {
+    fclose(f);
+    err = "short read on " + path;
+    return false;
+  }
+  fclose(f);
+  std::vector<Member> mem;
+  size_t off = 0, total = 0;
+  while (off < raw.size()) {
+    if (off + 18 > raw.size() || raw[off] != 0x1f || raw[off + 1] != 0x8b || raw[off + 2] != 8 || !(raw[off + 3] & 4)) {
+      err = "not a BGZF member at offset " + std::to_string(off) + " of " + path;
+      return false;
+    }
+    uint16_t xlen = rd16(&raw[off + 10]);
+    size_t p = off + 12, end = p + xlen;
+    int bsize = -1;
+    while (p + 4 <= end && end <= raw.size()) {
+      uint16_t slen = rd16(&raw[p + 2]);
+      if (raw[p] == 'B' && raw[p + 1] == 'C' && slen == 2) bsize = rd16(&raw[p + 4]);
+      p += 4 + slen;
+    }
+    if (bsize < 0 || off + (size_t)bsize + 1 > raw.size()) {
+      err = "corrupt BGZF member in " + path;
+      return false;
+    }
+    Member m;
+    m.off = off;
+    m.cdata = off + 12 + xlen;
+    m.clen = (size_t)bsize + 1 - 8 - (12 + xlen);
+    m.isize = rd32(&raw[off + bsize + 1 - 4]);
+    m.out_off = total;
+    total += m.isize;
+    mem.push_back(m);
+    off += (size_t)bsize + 1;
+  }
+  out.resize(total);
+  std::atomic<size_t> next{0};
+  std::atomic<bool> ok{true};
+  auto work = [&]() {
+    z_stream zs;
+    for (;;) {
+      size_t i = next.fetch_add(1);
+      if (i >= mem.size() || !ok.load()) break;
+      const Member& m = mem[i];
+      if (m.isize == 0) continue;
+      memset(&zs, 0, sizeof(zs));
+      if (inflateInit2(&zs, -15) != Z_OK) {
+        ok = false;
+        break;
+      }
+      zs.next_in = raw.data() + m.cdata;
+      zs.avail_in = (uInt)m.clen;
+      zs.next_out = out.data() + m.out_off;
+      zs.avail_out = m.isize;
+      int rc = inflate(&zs, Z_FINISH);
+      inflateEnd(&zs);
+      if (rc != Z_STREAM_END || zs.avail_out != 0) ok = false;
+    }
+  };
+  if (threads <= 1 || mem.size() < 8) {
+    work();
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; ++t) th.emplace_back(work);
+    for (auto& t : th) t.join();
+  }
+  if (!ok) {
+    err = "inflate failed in " + path;
+    return false;
+  }
+  return true;
+}
+
+BgzfWriter::~BgzfWriter() {
+  if (f_) close();
+}
+
+bool BgzfWriter::open(const std::string& path, int level) {
+  level_ = level;
+  if (path == "-") {
+    f_ = stdout;
+    own_ = false;
+  } else {
+    f_ = fopen(path.c_str(), "wb");
+    own_ = true;
+  }
+  if (!f_) {
+    err_ = "cannot create " + path;
+    return false;
+  }
+  buf_.reserve(kBlock);
+  return true;
+}
+
+bool BgzfWriter::flush_block() {
+  if (buf_.empty()) return true;
+  uint8_t outb[0x10000 + 64];
+  z_stream zs;
+  memset(&zs, 0, sizeof(zs));
+  if (deflateInit2(&zs, level_, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
+    err_ = "deflateInit2 failed";
+    return false;
+  }
+  zs.next_in = buf_.data();
+  zs.avail_in = (uInt)buf_.size();
+  zs.next_out = outb + 18;
+  zs.avail_out = sizeof(outb) - 18 - 8;
+  int rc = deflate(&zs, Z_FINISH);
+  size_t clen = zs.total_out;
+  deflateEnd(&zs);
+  if (rc != Z_STREAM_END) {
+    err_ = "deflate failed";
+    return false;
+  }
+  size_t bsize = clen + 25;  // total member length - 1
+  const uint8_t hdr[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, (uint8_t)(bsize & 0xff), (uint8_t)(bsize >> 8)};
+  memcpy(outb, hdr, 18);
+  uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), buf_.data(), (uInt)buf_.size());
+  uint32_t isz = (uint32_t)buf_.size();
+  uint8_t* t = outb + 18 + clen;
+  for (int k = 0; k < 4; ++k) t[k] = (uint8_t)(crc >> (8 * k));
+  for (int k = 0; k < 4; ++k) t[4 + k] = (uint8_t)(isz >> (8 * k));
+  if (fwrite(outb, 1, 18 + clen + 8, f_) != 18 + clen + 8) {
+    err_ = "write failed";
+    return false;
+  }
+  buf_.clear();
+  return true;
+}
+
+bool BgzfWriter::write(const void* p, size_t n) {
+  const uint8_t* s = (const uint8_t*)p;
+  while (n) {
+    size_t room = kBlock - buf_.size();
+    size_t k = n < room ? n : room;
+    buf_.insert(buf_.end(), s, s + k);
+    s += k;
+    n -= k;
+    if (buf_.size() == kBlock && !flush_block()) return false;
+  }
+  return true;
+}
+
+bool BgzfWriter::close() {
+  if (!f_) return true;
+  bool ok = flush_block();
+  ok = ok && fwrite(kEof, 1, sizeof(kEof), f_) == sizeof(kEof);
+  if (own_)
+    ok = (fclose(f_) == 0) && ok;
+  else
+    fflush(f_);
+  f_ = nullptr;
+  return ok;
+}
+
+}  // namespace tbh

@@ -1,0 +1,36 @@
+// bgzf.h — minimal BGZF codec over zlib (htslib is not available in this image).
+// Host side only: BGZF inflate/deflate stays on the CPU by design (north_star).
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+namespace tbh {
+
+// Inflate a whole BGZF file into `out`.  Blocks are independent, so they are inflated by
+// `threads` workers.  Returns false and fills `err` on malformed input.
+bool bgzf_read_file(const std::string& path, std::vector<uint8_t>& out, std::string& err, int threads = 1);
+
+// True when the file starts with a BGZF member (gzip magic + BC extra field).
+bool bgzf_probe(const std::string& path);
+
+class BgzfWriter {
+ public:
+  BgzfWriter() = default;
+  ~BgzfWriter();
+  bool open(const std::string& path, int level = 6);  // "-" = stdout
+  bool write(const void* p, size_t n);
+  bool close();  // flushes and appends the 28-byte EOF block
+  const std::string& error() const { return err_; }
+
+ private:
+  bool flush_block();
+  FILE* f_ = nullptr;
+  bool own_ = false;
+  int level_ = 6;
+  std::vector<uint8_t> buf_;
+  std::string err_;
+};
+
+}  // namespace tbh

@@ -1,0 +1,149 @@
+// tiebrush — drop-in command line of the reference's collapse tool (/root/reference/src/tiebrush.cpp:557-676),
+// with the per-record main loop (:570-592) replaced by one call into the MI355X hot path:
+//   decode every input into a SoA tile (host, zlib)  ->  tbk_collapse_tile (HIP)  ->  tag + write (host).
+// There is no CPU implementation of the collapse in this binary: without a usable GPU it exits with an error.
+#include <limits.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../../include/tbk.h"
+#include "GSam.h"
+#include "args.h"
+#include "tmerge.h"
+
+#define VERSION "0.0.7"
+
+static const char* USAGE =
+    "TieBrush v" VERSION " (MI355X build)\n"
+    "Collapses identical alignments from several coordinate-sorted BAM files into one BAM.\n"
+    "Every output alignment carries: YC (how many alignments it stands for), YX (in how many\n"
+    "samples it was seen) and YD (upstream extent of its coverage island, omitted when 0).\n"
+    "\n"
+    " usage: tiebrush [options] -o OUT.bam IN1.bam [IN2.bam ...]   (or one text file listing the inputs)\n"
+    "\n"
+    "  -h,--help            print this text and exit\n"
+    "  --version            print the version and exit\n"
+    "  -o FILE              output BAM (required)\n"
+    "  -L,--full            group by CIGAR and MD\n"
+    "  -P,--clip            group by CIGAR after removing soft clips\n"
+    "  -E,--exon            group by exon coordinates\n"
+    "                       (default: group by CIGAR; the three are mutually exclusive)\n"
+    "  -S,--keep-supp       keep supplementary alignments\n"
+    "  --keep-secondary     keep secondary alignments\n"
+    "  -M,--keep-unmap      keep unmapped reads (not available in the GPU build)\n"
+    "  -N INT               drop alignments with NH above INT\n"
+    "  -Q INT               drop alignments with mapping quality below INT\n"
+    "  -F INT               flag bits that must agree (not available in the GPU build)\n"
+    "  -A,--collapse-same   do not count the same read of the same sample twice\n"
+    "  --store-frac         YC adds 1/NH per alignment (needs --keep-secondary)\n"
+    "  -V,--verbose         echo the command line\n";
+
+int main(int argc, char* argv[]) {
+  TInputFiles inRecords;
+  inRecords.setup(VERSION, argc, argv);
+  Args args(argc, argv, "help;debug;verbose;version;full;clip;exon;keep-supp;keep-secondary;keep-unmap;collapse-same;store-frac;SMLPEDVho:N:Q:F:A");
+  if (!args.error().empty()) {
+    GMessage("%s\n%s\n", USAGE, args.error().c_str());
+    return 1;
+  }
+  if (args.getOpt('h') || args.getOpt("help")) {
+    fprintf(stdout, "%s", USAGE);
+    return 0;
+  }
+  if (args.getOpt("version")) {
+    fprintf(stdout, "%s\n", VERSION);
+    return 0;
+  }
+  if (args.startNonOpt() == 0) {
+    GMessage("%s", USAGE);
+    GMessage("\nError: no input provided!\n");
+    return 1;
+  }
+  const char* outfname = args.getOpt('o');
+  if (!outfname || !*outfname) {
+    GMessage("%s", USAGE);
+    GMessage("\nError: output filename must be provided (-o)!\n");
+    return 1;
+  }
+  tbk_collapse_opts opt;
+  tbk_collapse_opts_default(&opt);
+  if (const char* s = args.getOpt('N')) opt.max_nh = atoi(s);
+  if (const char* s = args.getOpt('Q')) opt.min_qual = atoi(s);
+  if (const char* s = args.getOpt('F')) opt.flags_mask = (uint32_t)atoi(s);
+  opt.keep_supplementary = (args.getOpt("keep-supp") || args.getOpt('S')) ? 1 : 0;
+  opt.keep_secondary = args.getOpt("keep-secondary") ? 1 : 0;
+  opt.keep_unmapped = (args.getOpt("keep-unmap") || args.getOpt('M')) ? 1 : 0;
+  opt.collapse_same = (args.getOpt("collapse-same") || args.getOpt('A')) ? 1 : 0;
+  opt.store_frac = args.getOpt("store-frac") ? 1 : 0;
+  if (opt.store_frac && !opt.keep_secondary) GError("Error: --store-frac requires --keep-secondary to be enabled.\n");
+  bool stratF = args.getOpt("full") || args.getOpt('L');
+  bool stratP = args.getOpt("clip") || args.getOpt('P');
+  bool stratE = args.getOpt("exon") || args.getOpt('E');
+  if (stratF | stratP | stratE) {
+    if (!(stratF ^ stratP ^ stratE)) GError("Error: only one merging strategy can be requested.\n");
+    opt.strategy = stratF ? TBK_STRAT_FULL : (stratP ? TBK_STRAT_CLIP : TBK_STRAT_EXON);
+  }
+  if (args.getOpt("verbose") || args.getOpt('V')) {
+    fprintf(stderr, "Running TieBrush " VERSION ". Command line:\n");
+    args.printCmdLine(stderr);
+  }
+  if (opt.flags_mask != 0) GError("Error: -F is not supported by the GPU build (its reference semantics are unpinned)\n");
+  if (opt.keep_unmapped) GError("Error: -M/--keep-unmap is not supported by the GPU build\n");
+  while (const char* ifn = args.nextNonOpt()) inRecords.addFile(tbh_realpath(ifn).c_str());
+
+  inRecords.start();
+  tbk_ctx* ctx = nullptr;
+  int dev = getenv("TBK_DEVICE") ? atoi(getenv("TBK_DEVICE")) : 0;
+  int rc = tbk_create(dev, &ctx);
+  if (rc != 0) GError("Error: cannot use GPU %d (%s); this build has no CPU collapse path\n", dev, tbk_strerror(rc));
+
+  int nthreads = (int)std::thread::hardware_concurrency();
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > 32) nthreads = 32;
+  TbkTile tile;
+  inRecords.load_tile(tile, opt.strategy == TBK_STRAT_FULL, opt.collapse_same != 0, nthreads);
+  tbk_soa_in in = tile.view();
+  size_t n = tile.n();
+  std::vector<uint32_t> rep(n ? n : 1);
+  std::vector<double> yc(n ? n : 1);
+  std::vector<int64_t> yx(n ? n : 1);
+  std::vector<int32_t> yd(n ? n : 1);
+  tbk_groups_out out;
+  memset(&out, 0, sizeof(out));
+  out.mem = TBK_MEM_HOST;
+  out.cap_groups = (uint32_t)(n ? n : 1);
+  out.rep = rep.data();
+  out.yc = yc.data();
+  out.yx = yx.data();
+  out.yd = yd.data();
+  rc = tbk_collapse_tile(ctx, &opt, &in, &out);
+  if (rc == TBK_EUNSORTED) GError("Error: an input file is not coordinate-sorted!\n");
+  if (rc != 0) GError("Error: GPU collapse failed: %s (%s)\n", tbk_strerror(rc), tbk_last_error(ctx));
+
+  {
+    GSamWriter outfile(outfname, inRecords.header(), GSamFile_BAM);
+    tbh::BamRec r;
+    for (uint32_t g = 0; g < out.n_groups; ++g) {  // flushPData tagging, tiebrush.cpp:506-525
+      tbh::RecView v = inRecords.record(rep[g]);
+      r.d.assign(v.p, v.p + v.len);
+      r.update_float("YC", (float)yc[g]);
+      r.update_int("YX", yx[g]);
+      if (yd[g] > 0)
+        r.update_int("YD", yd[g]);
+      else
+        r.del("YD");
+      outfile.write_raw(r);
+    }
+  }
+  inRecords.stop();
+  tbk_destroy(ctx);
+  uint64_t inCounter = out.n_passed, outCounter = out.n_groups;
+  double p = 100.00 - (double)(outCounter * 100.00) / (double)inCounter;
+  GMessage("%ld input records written as %ld (%.2f%% reduction)\n", (long)inCounter, (long)outCounter, p);
+  return 0;
+}

@@ -1,0 +1,78 @@
+// tmerge.h — host-side mirror of the reference's TInputFiles / TInputRecord surface
+// (/root/reference/src/tmerge.h:13-117, tmerge.cpp:48-350): same method names and meaning.
+// `next()` still hands out one record at a time in the reference's merge order for callers that
+// iterate; the accelerated tools do not iterate — they call `load_tile()` and hand the whole tile
+// to tbk_collapse_tile (include/tbk.h).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../../include/tbk.h"
+#include "GSam.h"
+
+struct TSamReader {
+  std::string fname;
+  GSamReader* samreader = nullptr;
+  bool tbMerged = false;
+  explicit TSamReader(const char* fn = nullptr) : fname(fn ? fn : "") {}
+  ~TSamReader() { delete samreader; }
+};
+
+struct TInputRecord {
+  GSamRecord* brec;
+  int fidx;
+  bool tbMerged;
+  // "decreasing location sort" of the reference (tmerge.h:28-50): a < b means a pops later
+  bool operator<(TInputRecord& o);
+  void disown() { brec = nullptr; }
+  TInputRecord(GSamRecord* b = nullptr, int i = 0, bool tb = false) : brec(b), fidx(i), tbMerged(tb) {}
+  ~TInputRecord() { delete brec; }
+};
+
+// Structure-of-arrays tile of every input file (file-major), the layout of tbk_soa_in.
+struct TbkTile {
+  std::vector<uint32_t> file_off;
+  std::vector<uint8_t> tbmerged;
+  std::vector<int32_t> tid, pos, nh;
+  std::vector<uint16_t> flag;
+  std::vector<uint8_t> mapq, strand;
+  std::vector<uint32_t> cig_off, cig;
+  std::vector<double> yc_in;
+  std::vector<int64_t> yx_in, yd_in;
+  std::vector<uint32_t> md_off;
+  std::vector<uint8_t> md, md_has;
+  std::vector<uint64_t> qname_hash;
+  tbk_soa_in view() const;
+  size_t n() const { return tid.size(); }
+};
+
+struct TInputFiles {
+ protected:
+  TInputRecord* crec = nullptr;
+  sam_hdr_t* mHdr = nullptr;
+  std::string pg_ver, pg_args;
+  std::vector<size_t> cursor_;  // next record of each file for next()
+
+ public:
+  std::vector<TSamReader*> freaders;
+  std::vector<TInputRecord*> recs;  // one head record per file, kept sorted like the reference's GList
+  std::string headerfilename;
+  bool headerfiletbMerged = false;
+
+  ~TInputFiles();
+  sam_hdr_t* header() { return mHdr; }
+  void setup(const char* ver, int argc, char** argv);
+  void addFile(const char* fn);
+  bool addSam(GSamReader* r, int fidx);
+  int count() { return (int)freaders.size(); }
+  int start();            // opens every input, merges headers, primes next()
+  TInputRecord* next();   // valid until the following next() (tmerge.cpp:331-344)
+  void stop();
+  // accelerated path: decode every file into one SoA tile (multi-threaded aux scan)
+  void load_tile(TbkTile& t, bool want_md, bool want_qname_hash, int threads);
+  tbh::RecView record(uint32_t global_index) const;  // raw record behind tile index i
+  std::vector<uint32_t> tile_off_;                   // file_off of the last load_tile()
+};
+
+uint64_t tbh_qname_hash(const char* name, int pair_order);
+std::string tbh_realpath(const std::string& p);
