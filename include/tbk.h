@@ -106,6 +106,11 @@ typedef struct tbk_soa_in {
   const uint8_t* md_has;    /* [n_records]                                           */
   /* only for collapse_same (-A): 64-bit hash of (qname bytes, pairOrder) */
   const uint64_t* qname_hash;
+  /* only when stitching partial groups of several ranks: explicit merge-order priority of
+   * each record; the representative of a group is then argmin (prio_hi, prio_lo) over its members.
+   * prio_hi = effective end of the partial's representative, prio_lo = (global file index << 32) | index in file */
+  const uint64_t* prio_hi;
+  const uint64_t* prio_lo;
 } tbk_soa_in;
 
 /* Collapsed groups in the order the reference writes them (flushPData order). */
@@ -119,6 +124,8 @@ typedef struct tbk_groups_out {
   int32_t* g_start;      /* optional (may be NULL): 1-based start of the group        */
   int32_t* g_end;        /* optional: 1-based end                                     */
   int32_t* rec_group;    /* optional [n_records]: output index of each record's group, -1 = filtered */
+  int32_t* rep_effend;   /* optional: merge-order key of the representative = running max of `end` in its file
+                            (tmerge.h:28-50); what a cross-rank stitch needs to pick the global representative */
   uint32_t n_groups;     /* written by the callee = outCounter (tiebrush.cpp:528)     */
   uint32_t n_passed;     /* written by the callee = inCounter  (tiebrush.cpp:573)     */
 } tbk_groups_out;

@@ -1,0 +1,85 @@
+"""Multi-rank path on CPU: loopback of R virtual ranks and a real world_size-2 gloo run, both checked against the
+flat single-tile result (per-tile compute served by the oracle; sharding/exchange/stitch is the product code)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from dist_helpers import OracleCompute, split_tile, check_against_flat, STRAT
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("world,profile,strategy,kw", [
+    (2, "c2", "cigar", {}),
+    (3, "c3", "clip", {}),
+    (4, "c5", "exon", dict(max_nh=5, min_qual=1)),
+    (8, "c2", "cigar", {}),
+])
+def test_loopback_equals_flat(world, profile, strategy, kw):
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import dist, synth
+    tile = synth.make_tile(max(world, 4) * 2, 6000, profile, n_loci=300)
+    flat = orc.collapse(tile, strategy=STRAT[strategy], **kw)
+    flat_cov = orc.coverage(synth.collapsed_to_cov_input(tile, flat))
+    tiles, first = split_tile(tile, world)
+    res = dist.run_loopback(OracleCompute(), tiles, first, strategy=strategy, want_coverage=True, **kw)
+    check_against_flat(res, tile, flat, flat_cov)
+    assert sum(1 for r in res if r.n_groups > 0) >= min(world, 2)   # the work really is spread
+
+
+def test_loopback_golden_t2(bam_loader):
+    from helpers import sample_paths
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import dist, soa
+    bams = [bam_loader(p) for p in sample_paths("t2")]
+    tile = soa.tile_from_bams(bams)
+    flat = orc.collapse(tile)
+    tiles, first = split_tile(tile, 5)
+    res = dist.run_loopback(OracleCompute(), tiles, first)
+    check_against_flat(res, tile, flat)
+
+
+def test_refuses_order_dependent_flags():
+    from tiebrush_amd import dist, synth
+    tile = synth.make_tile(2, 100, "c2", n_loci=10)
+    tiles, first = split_tile(tile, 2)
+    with pytest.raises(ValueError):
+        dist.run_loopback(OracleCompute(), tiles, first, store_frac=True)
+
+
+def _gloo_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as td
+    from dist_helpers import OracleCompute, split_tile
+    from tiebrush_amd import dist, synth
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    tile = synth.make_tile(4, 5000, "c2", n_loci=200)
+    tiles, first = split_tile(tile, world)
+    r = dist.run_distributed(OracleCompute(), tiles[rank], first[rank], device="cpu", want_coverage=True)
+    q.put((rank, r))
+    td.barrier()
+    td.destroy_process_group()
+
+
+def test_gloo_world2_equals_flat():
+    import torch.multiprocessing as mp
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import synth
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    tile = synth.make_tile(4, 5000, "c2", n_loci=200)
+    flat = orc.collapse(tile)
+    flat_cov = orc.coverage(synth.collapsed_to_cov_input(tile, flat))
+    check_against_flat([got[0], got[1]], tile, flat, flat_cov)

@@ -1,0 +1,49 @@
+"""Multi-rank path with the real HIP compute: R virtual ranks on the one GPU of the box (loopback driver), checked
+against the flat oracle result.  Exercises rep_effend, the explicit stitch priority and the carried YC/YX/YD."""
+import numpy as np
+import pytest
+
+from dist_helpers import split_tile, check_against_flat, STRAT
+
+pytestmark = pytest.mark.gpu
+
+
+class GpuCompute:
+    def __init__(self):
+        from tiebrush_amd import api
+        self.ctx = api.Context(0)
+        self.api = api
+
+    def collapse(self, tile, **kw):
+        return self.api.to_numpy(self.ctx.collapse(tile, **kw))
+
+    def coverage(self, cin):
+        return self.api.to_numpy(self.ctx.coverage(cin))
+
+
+@pytest.mark.parametrize("world,profile,strategy,kw", [
+    (2, "c2", "cigar", {}),
+    (4, "c3", "clip", {}),
+    (8, "c5", "exon", dict(max_nh=5, min_qual=1)),
+])
+def test_loopback_gpu_equals_flat_oracle(world, profile, strategy, kw):
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import dist, synth
+    tile = synth.make_tile(world * 2, 20000, profile, n_loci=800)
+    flat = orc.collapse(tile, strategy=STRAT[strategy], **kw)
+    flat_cov = orc.coverage(synth.collapsed_to_cov_input(tile, flat))
+    tiles, first = split_tile(tile, world)
+    res = dist.run_loopback(GpuCompute(), tiles, first, strategy=strategy, want_coverage=True, **kw)
+    check_against_flat(res, tile, flat, flat_cov)
+
+
+def test_loopback_gpu_golden(bam_loader):
+    from helpers import sample_paths
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import dist, soa
+    bams = [bam_loader(p) for p in sample_paths("t1")]
+    tile = soa.tile_from_bams(bams)
+    flat = orc.collapse(tile)
+    tiles, first = split_tile(tile, 4)
+    res = dist.run_loopback(GpuCompute(), tiles, first)
+    check_against_flat(res, tile, flat)

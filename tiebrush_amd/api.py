@@ -71,7 +71,8 @@ def to_device(obj, device="cuda:0"):
                        cig_off=mv(obj.cig_off, np.uint32), cig=mv(obj.cig, np.uint32), yc_in=mv(obj.yc_in, np.float64),
                        yx_in=mv(obj.yx_in, np.int64), yd_in=mv(obj.yd_in, np.int64), md_off=mv(obj.md_off, np.uint32),
                        md=mv(obj.md, np.uint8), md_has=mv(obj.md_has, np.uint8),
-                       qname_hash=mv(obj.qname_hash, np.uint64), qn_off=None, qn=None)
+                       qname_hash=mv(obj.qname_hash, np.uint64), qn_off=None, qn=None,
+                       prio_hi=mv(obj.prio_hi, np.uint64), prio_lo=mv(obj.prio_lo, np.uint64))
         torch.cuda.synchronize()
         return r
     if isinstance(obj, CovInput):
@@ -179,10 +180,12 @@ class Context:
             _addr(tile.yc_in, np.float64, keep, n), _addr(tile.yx_in, np.int64, keep, n),
             _addr(tile.yd_in, np.int64, keep, n), _addr(tile.md_off, np.uint32, keep, n + 1),
             _addr(tile.md, np.uint8, keep), _addr(tile.md_has, np.uint8, keep, n),
-            _addr(tile.qname_hash, np.uint64, keep, n))
+            _addr(tile.qname_hash, np.uint64, keep, n), _addr(tile.prio_hi, np.uint64, keep, n),
+            _addr(tile.prio_lo, np.uint64, keep, n))
         return s, dev, n
 
-    def collapse(self, tile: SoATile, opts=None, want_coords=True, want_rec_group=False, out=None, raw=False, **kw):
+    def collapse(self, tile: SoATile, opts=None, want_coords=True, want_rec_group=False, want_effend=False, out=None,
+                 raw=False, **kw):
         """Collapse one tile.  Returns a dict (rep, yc, yx, yd[, g_start, g_end, rec_group], n_groups,
         n_passed) in the reference's output order.  `out` may carry preallocated buffers to reuse."""
         o = opts if opts is not None else self.make_opts(**kw)
@@ -202,9 +205,10 @@ class Context:
         yx, yd = buf("yx", cap, np.int64), buf("yd", cap, np.int32)
         gs, ge = buf("g_start", cap, np.int32, want_coords), buf("g_end", cap, np.int32, want_coords)
         rg = buf("rec_group", cap, np.int32, want_rec_group)
+        re_ = buf("rep_effend", cap, np.int32, want_effend)
         g = _lib.GroupsOut(s.mem, cap, _addr(rep, np.uint32, keep), _addr(yc, np.float64, keep),
                            _addr(yx, np.int64, keep), _addr(yd, np.int32, keep), _addr(gs, np.int32, keep),
-                           _addr(ge, np.int32, keep), _addr(rg, np.int32, keep), 0, 0)
+                           _addr(ge, np.int32, keep), _addr(rg, np.int32, keep), _addr(re_, np.int32, keep), 0, 0)
         self._check(self.L.tbk_collapse_tile(self.h, C.byref(o), C.byref(s), C.byref(g)), "tbk_collapse_tile")
         m = int(g.n_groups)
         res = dict(n_groups=m, n_passed=int(g.n_passed), _bufs=bufs, _struct=g, _soa=s, _keep=keep)
@@ -215,6 +219,8 @@ class Context:
             res.update(g_start=gs[:m], g_end=ge[:m])
         if want_rec_group:
             res["rec_group"] = rg[:n]
+        if want_effend:
+            res["rep_effend"] = re_[:m]
         return res
 
     def groups_to_cov_in(self, collapse_result) -> DeviceCovView:

@@ -43,6 +43,7 @@ struct ColIn {
   const uint32_t* md_off;
   const uint8_t *md, *md_has;
   const uint64_t* qh;
+  const uint64_t *prio_hi, *prio_lo;
 };
 
 struct ColOpt {
@@ -441,6 +442,20 @@ __global__ void col_same_k(ColIn I, ColOpt O, uint32_t m, const uint32_t* __rest
   uint32_t sg = sgid[q];
   uint32_t r = (uint32_t)(G.rep[sg] & 0xFFFFFFFFull);
   if (I.qh[gi] == I.qh[r]) atomicAdd(&G.yc[sg], -1.0);
+}
+
+// cross-rank stitch: the representative is the member with the smallest explicit priority (groups have at most one
+// member per rank, so a serial scan of the group's contiguous members is cheap)
+__global__ void col_rep_prio_k(ColIn I, uint32_t ng, uint32_t m, const uint32_t* __restrict__ val, GroupAcc G) {
+  uint32_t sg = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sg >= ng) return;
+  uint32_t q0 = G.first[sg], q1 = (sg + 1 < ng) ? G.first[sg + 1] : m;
+  uint32_t best = val[q0];
+  for (uint32_t q = q0 + 1; q < q1; ++q) {
+    uint32_t gi = val[q];
+    if (I.prio_hi[gi] < I.prio_hi[best] || (I.prio_hi[gi] == I.prio_hi[best] && I.prio_lo[gi] < I.prio_lo[best])) best = gi;
+  }
+  G.rep[sg] = (G.rep[sg] & 0xFFFFFFFF00000000ull) | best;
 }
 
 // ---- tie sets: order groups that share (bucket,strand,end) by the reference comparator -----------------
@@ -856,11 +871,13 @@ __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids
 __global__ void col_write_k(uint32_t ng, const uint32_t* __restrict__ gperm, GroupAcc G, const int32_t* __restrict__ g_yd,
                             const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo, uint32_t cap,
                             uint32_t* __restrict__ rep, double* __restrict__ yc, int64_t* __restrict__ yx, int32_t* __restrict__ yd,
-                            int32_t* __restrict__ g_start, int32_t* __restrict__ g_end) {
+                            int32_t* __restrict__ g_start, int32_t* __restrict__ g_end, const int32_t* __restrict__ effend,
+                            int32_t* __restrict__ rep_effend) {
   uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= ng || o >= cap) return;
   uint32_t sg = gperm[o];
   rep[o] = (uint32_t)(G.rep[sg] & 0xFFFFFFFFull);
+  if (rep_effend) rep_effend[o] = effend[rep[o]];
   yc[o] = G.yc[sg];
   yx[o] = (int64_t)G.yxin[sg] + (int64_t)G.ns[sg];
   int dmax = (int)G.ydin[sg];  // int dmax=spd.maxYD (tiebrush.cpp:511)
@@ -934,6 +951,8 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
   I.md = in->md;
   I.md_has = in->md_has;
   I.qh = in->qname_hash;
+  I.prio_hi = in->prio_hi;
+  I.prio_lo = in->prio_lo;
   ColOpt O;
   O.strategy = o->strategy;
   O.max_nh = o->max_nh;
@@ -1017,6 +1036,7 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
   if (!ginv) return TBK_ENOMEM;
   TBK_LAUNCH(ctx, "col_init_groups", col_init_groups_k, cdiv(ng, B), B, 0, ng, G, g_yd);
   TBK_LAUNCH(ctx, "col_reduce", col_reduce_k, cdiv(m, B), B, 0, I, O, m, sb.val, flags, gex, fidx, effend, G, sgid, ctx->d_err);
+  if (I.prio_hi && I.prio_lo) TBK_LAUNCH(ctx, "col_rep_prio", col_rep_prio_k, cdiv(ng, B), B, 0, I, ng, m, sb.val, G);
   if (O.collapse_same) TBK_LAUNCH(ctx, "col_same", col_same_k, cdiv(m, B), B, 0, I, O, m, sb.val, flags, sgid, fidx, G);
   TBK_LAUNCH(ctx, "col_tie_init", col_tie_k, cdiv(ng, B), B, 0, I, O.strategy, ng, sb.val, G, gperm);
   TBK_LAUNCH(ctx, "col_tie_sort", col_tie_sort_k, cdiv(ng, B), B, 0, I, O.strategy, ng, sb.val, G, gperm);
@@ -1107,7 +1127,7 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
     }
   }
   TBK_LAUNCH(ctx, "col_write", col_write_k, cdiv(ng, B), B, 0, ng, gperm, G, g_yd, sb.hi, sb.lo, out->cap_groups, out->rep, out->yc,
-             out->yx, out->yd, out->g_start, out->g_end);
+             out->yx, out->yd, out->g_start, out->g_end, effend, out->rep_effend);
   if (out->rec_group) TBK_LAUNCH(ctx, "col_recgroup", col_recgroup_k, cdiv(m, B), B, 0, m, sb.val, sgid, ginv, out->rec_group);
   uint32_t eb = 0;
   TBK_TRY(tbk_sync_err(ctx, &eb));

@@ -319,6 +319,7 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
   if (!out->rep || !out->yc || !out->yx || !out->yd) return TBK_EINVAL;
   if (opts->strategy == TBK_STRAT_FULL && (!in->md_off || !in->md_has)) return TBK_EINVAL;
   if (opts->collapse_same && !in->qname_hash) return TBK_EINVAL;
+  if ((in->prio_hi == nullptr) != (in->prio_lo == nullptr)) return TBK_EINVAL;
   bool any_tb = false;
   if (in->tbmerged)
     for (uint32_t f = 0; f < in->n_files; ++f) any_tb |= in->tbmerged[f] != 0;
@@ -351,6 +352,8 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
     TBK_TRY(h2d(ctx, in->md, in->md_off ? (size_t)in->md_off[n] : 0, &din.md));
     TBK_TRY(h2d(ctx, in->md_has, n, &din.md_has));
     TBK_TRY(h2d(ctx, in->qname_hash, n, &din.qname_hash));
+    TBK_TRY(h2d(ctx, in->prio_hi, n, &din.prio_hi));
+    TBK_TRY(h2d(ctx, in->prio_lo, n, &din.prio_lo));
     size_t cap = out->cap_groups;
     TBK_TRY(dalloc(ctx, out->rep, cap, &dout.rep));
     TBK_TRY(dalloc(ctx, out->yc, cap, &dout.yc));
@@ -359,6 +362,7 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
     TBK_TRY(dalloc(ctx, out->g_start, cap, &dout.g_start));
     TBK_TRY(dalloc(ctx, out->g_end, cap, &dout.g_end));
     TBK_TRY(dalloc(ctx, out->rec_group, n, &dout.rec_group));
+    TBK_TRY(dalloc(ctx, out->rep_effend, cap, &dout.rep_effend));
     rc = tbk_collapse_device(ctx, opts, &din, &dout);
     out->n_groups = dout.n_groups;
     out->n_passed = dout.n_passed;
@@ -371,6 +375,7 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
       TBK_TRY(d2h(ctx, out->g_start, dout.g_start, g));
       TBK_TRY(d2h(ctx, out->g_end, dout.g_end, g));
       TBK_TRY(d2h(ctx, out->rec_group, dout.rec_group, n));
+      TBK_TRY(d2h(ctx, out->rep_effend, dout.rep_effend, g));
       TBK_HIP(hipStreamSynchronize(ctx->stream));
     }
   }

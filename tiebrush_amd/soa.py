@@ -52,6 +52,8 @@ class SoATile:
     qname_hash: Optional[np.ndarray] = None  # uint64
     qn_off: Optional[np.ndarray] = None  # uint32 [n+1]   (oracle only: -A compares real names)
     qn: Optional[np.ndarray] = None      # uint8
+    prio_hi: Optional[np.ndarray] = None  # uint64: explicit merge-order priority (cross-rank stitch only)
+    prio_lo: Optional[np.ndarray] = None  # uint64
 
     @property
     def n_records(self) -> int:
