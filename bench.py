@@ -6,7 +6,9 @@ resident in HBM: tbk_collapse_tile (k-way merge order, grouping, YC/YX/YD) -> de
 (tbk_groups_to_cov_in) -> tbk_coverage_tile (bedgraph intervals + junctions) of the collapsed
 records.  Workload at N=1 = BASELINE.json configs[1]: 2 synthetic sorted BAMs x 1M 100-bp reads,
 default CIGAR-only collapse.  With N>1 every rank owns its own 2 input files (weak scaling: the
-N input streams shard per rank) and the ranks all-gather their boundary group keys.
+N input streams shard per rank); groups that span ranks are stitched inside the
+timed step (tiebrush_amd/dist.py: all-gather of splitter keys, all-to-all of partial groups over
+RCCL, second collapse, tiecov of the owned bundle range).
 
 Prints ONE JSON line (rank 0).  value = input alignment records collapsed per second, whole job.
 """
@@ -33,6 +35,7 @@ def main():
     ap.add_argument("--profile", default="c2", choices=["c2", "c3", "c5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-steps", type=int, default=5)
+    ap.add_argument("--force-dist", action="store_true", help="run the multi-rank stitch path even with one rank")
     args = ap.parse_args()
 
     import numpy as np
@@ -42,10 +45,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = "cuda:%d" % local_rank
 
     from tiebrush_amd import api, synth
@@ -56,42 +62,58 @@ def main():
     dtile = api.to_device(tile, dev)
     opts = ctx.make_opts(**strat)
     cbufs, vbufs = {}, {}
-    gather_buf = None
+
+    class StitchCompute:
+        """compute object of tiebrush_amd.dist: the same context, output buffers reused per call site"""
+
+        def __init__(self):
+            self.bufs = {}
+
+        def collapse(self, tile, **kw):
+            return ctx.collapse(tile, out=self.bufs.setdefault(("c", tile.n_files, "prio" if tile.prio_hi is not None else ""), {}), **kw)
+
+        def groups_to_cov_in(self, fin):
+            return ctx.groups_to_cov_in(fin)
+
+        def pack_partials(self, loc, first_fidx, cig_cap):
+            return ctx.pack_partials(loc, first_fidx, cig_cap, out=self.bufs.setdefault("p", {}))
+
+        def coverage(self, view):
+            return ctx.coverage(view, out=self.bufs.setdefault("v", {}), raw=True)
+
+    from tiebrush_amd import dist as tdist
+    stitch = StitchCompute()
 
     def step():
+        if use_dist:
+            # local collapse -> bundle-aligned cuts (all-gather + all-reduce) -> all-to-all of the partial groups over
+            # RCCL/xGMI -> stitch collapse -> tiecov of the owned slice, everything resident in HBM
+            r = tdist.run_distributed(stitch, dtile, rank * args.files_per_gpu, device=dev, want_coverage=True,
+                                      device_chain=True, **strat)
+            return ({"n_passed": r.n_passed_local, "n_groups": r.n_groups}, r.coverage)
         g = ctx.collapse(dtile, opts=opts, want_coords=True, out=cbufs, raw=True)
         view = ctx.groups_to_cov_in(g)
         c = ctx.coverage(view, out=vbufs, raw=True)
-        if world > 1:
-            # boundary stitch: every rank publishes its first/last group key (tid,start,end,count) so that the
-            # owner of a coordinate range can merge groups that span ranks (tiny all-gather over xGMI)
-            nonlocal gather_buf
-            ng = g["n_groups"]
-            gs, ge = cbufs["g_start"], cbufs["g_end"]
-            b = torch.stack([gs[0], ge[0], gs[max(ng - 1, 0)], ge[max(ng - 1, 0)]]).to(torch.int64)
-            if gather_buf is None:
-                gather_buf = torch.empty(world * 4, dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(gather_buf, b)
         return g, c
 
     for _ in range(args.warmup):
         g, c = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         g, c = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     n_passed, n_groups = g["n_passed"], g["n_groups"]
     n_bases, span, n_iv, n_j = c["n_bases"], c["span_bases"], c["n_intervals"], c["n_junctions"]
     stats = torch.tensor([dt, float(n_passed), float(n_bases)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = stats.clone()
@@ -113,7 +135,7 @@ def main():
                 a[0] += ms
                 a[1] += ln
             view = ctx.groups_to_cov_in(gg)
-            ctx.coverage(view, out=vbufs, raw=True)
+            cc = ctx.coverage(view, out=vbufs, raw=True)
             for k, (ms, ln) in ctx.kernel_times().items():
                 a = acc.setdefault(("coverage", k), [0.0, 0])
                 a[0] += ms
@@ -121,9 +143,10 @@ def main():
         ctx.set_profiling(False)
         ncig_in = int(tile.cig.shape[0])
         # algorithmic bytes
-        b_collapse = n_passed * 16 + 4 * ncig_in
+        # (the profiled steps are rank 0's local collapse + coverage; their own counts price the bytes)
+        b_collapse = gg["n_passed"] * 16 + 4 * ncig_in
         ncig_cov = int(view.n_cigar_ops)
-        b_cov = n_groups * 12 + 4 * ncig_cov + 16 * span + 16 * n_iv
+        b_cov = gg["n_groups"] * 12 + 4 * ncig_cov + 16 * cc["span_bases"] + 16 * cc["n_intervals"]
 
         def roofline(stage, name, alg_bytes):
             ms, ln = acc[(stage, name)]
@@ -158,8 +181,8 @@ def main():
             if time.perf_counter() - t1 > 10.0 or reps >= 20:
                 break
         cdt = time.perf_counter() - t1
-        assert og["n_groups"] == n_groups and og["n_passed"] == n_passed, "GPU/oracle disagree on the bench workload"
-        assert oc["n_intervals"] == n_iv and oc["n_junctions"] == n_j
+        assert og["n_passed"] == n_passed and (use_dist or og["n_groups"] == n_groups), "GPU/oracle disagree on the bench workload"
+        assert use_dist or (oc["n_intervals"] == n_iv and oc["n_junctions"] == n_j)
         cpu = {"value": round(og["n_passed"] * reps / cdt, 1), "unit": "records/s", "cores": 1, "kind": "port",
                "sample": "rank-0 shard (%d files x %d reads) collapse+coverage on SoA, %d repetitions, gcc -O2" %
                          (args.files_per_gpu, args.reads_per_file, reps),
@@ -191,7 +214,7 @@ def main():
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

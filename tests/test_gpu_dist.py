@@ -47,3 +47,43 @@ def test_loopback_gpu_golden(bam_loader):
     tiles, first = split_tile(tile, 4)
     res = dist.run_loopback(GpuCompute(), tiles, first)
     check_against_flat(res, tile, flat)
+
+
+class DeviceCompute:
+    """tiles resident in HBM, results stay torch tensors; tiecov through the device chain"""
+
+    def __init__(self):
+        from tiebrush_amd import api
+        self.ctx = api.Context(0)
+
+    def collapse(self, tile, **kw):
+        return self.ctx.collapse(tile, **kw)
+
+    def groups_to_cov_in(self, fin):
+        return self.ctx.groups_to_cov_in(fin)
+
+    def pack_partials(self, loc, first_fidx, cig_cap):
+        return self.ctx.pack_partials(loc, first_fidx, cig_cap)
+
+    def coverage(self, view):
+        from tiebrush_amd import api
+        return api.to_numpy(self.ctx.coverage(view))
+
+
+def test_loopback_device_resident_equals_flat_oracle():
+    import torch
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import api, dist, synth
+    tile = synth.make_tile(8, 20000, "c2", n_loci=800)
+    flat = orc.collapse(tile)
+    flat_cov = orc.coverage(synth.collapsed_to_cov_input(tile, flat))
+    tiles, first = split_tile(tile, 4)
+    dtiles = [api.to_device(t, "cuda:0") for t in tiles]
+    comp = DeviceCompute()
+    # the device chain view lives in context memory until the next call: run coverage inside each rank's turn
+    res = dist.run_loopback(comp, dtiles, first, want_coverage=True, device_chain=True)
+    for r in res:
+        for f in ("tid", "start", "end", "rep_fidx", "rep_idx", "yc", "yx", "yd"):
+            v = getattr(r, f)
+            setattr(r, f, v.cpu().numpy() if isinstance(v, torch.Tensor) else v)
+    check_against_flat(res, tile, flat, flat_cov)

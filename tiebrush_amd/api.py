@@ -106,6 +106,7 @@ class Context:
             raise TbkError(rc, "tbk_create(device=%d)" % device)
         self.h = h
         self.device = device
+        self._on_torch_stream = False
 
     def close(self):
         if getattr(self, "h", None):
@@ -127,6 +128,13 @@ class Context:
         """Launch on torch's current stream so that torch ops and our kernels order correctly."""
         s = _torch().cuda.current_stream().cuda_stream
         self._check(self.L.tbk_set_stream(self.h, C.c_void_p(s)), "tbk_set_stream")
+        self._on_torch_stream = True
+
+    def _order_after_torch(self, dev):
+        """Device inputs were produced on torch's stream; the context launches on its own stream unless
+        use_torch_stream() was called: make the producer visible first."""
+        if dev and not self._on_torch_stream:
+            _torch().cuda.current_stream().synchronize()
 
     def stream_ptr(self):
         return self.L.tbk_get_stream(self.h)
@@ -191,6 +199,7 @@ class Context:
         o = opts if opts is not None else self.make_opts(**kw)
         keep = []
         s, dev, n = self._soa_struct(tile, keep)
+        self._order_after_torch(dev)
         cap = max(n, 1)
         bufs = out if out is not None else {}
 
@@ -226,10 +235,30 @@ class Context:
     def groups_to_cov_in(self, collapse_result) -> DeviceCovView:
         """Device-side chain tiebrush -> tiecov (tbk_groups_to_cov_in)."""
         v = _lib.CovIn()
+        self._order_after_torch(True)
         self._check(self.L.tbk_groups_to_cov_in(self.h, C.byref(collapse_result["_soa"]),
                                                 C.byref(collapse_result["_struct"]), C.byref(v)),
                     "tbk_groups_to_cov_in")
         return DeviceCovView(v, int(v.n_records), int(v.n_cigar_ops))
+
+    def pack_partials(self, collapse_result, first_fidx: int, cig_cap: int, out=None):
+        """tbk_pack_partials: (P [n_groups, 9] int64, cig [n_cig] int32-typed uint32 words) on the device."""
+        torch = _torch()
+        ng = int(collapse_result["n_groups"])
+        bufs = out if out is not None else {}
+        if "P" not in bufs or bufs["P"].shape[0] < max(ng, 1):
+            bufs["P"] = torch.empty((max(ng, 1), 9), dtype=torch.int64, device="cuda:%d" % self.device)
+        if "cig" not in bufs or bufs["cig"].numel() < max(cig_cap, 1):
+            bufs["cig"] = torch.empty(max(cig_cap, 1), dtype=torch.int32, device="cuda:%d" % self.device)
+        if "emax" not in bufs or bufs["emax"].numel() < max(ng, 1):
+            bufs["emax"] = torch.empty(max(ng, 1), dtype=torch.int64, device="cuda:%d" % self.device)
+        n = C.c_uint32(0)
+        self._order_after_torch(True)
+        self._check(self.L.tbk_pack_partials(self.h, C.byref(collapse_result["_soa"]), C.byref(collapse_result["_struct"]),
+                                             int(first_fidx), C.c_void_p(bufs["P"].data_ptr()), C.c_void_p(bufs["cig"].data_ptr()),
+                                             int(bufs["cig"].numel()), C.byref(n), C.c_void_p(bufs["emax"].data_ptr())),
+                    "tbk_pack_partials")
+        return bufs["P"][:ng], bufs["cig"][:int(n.value)], bufs["emax"][:ng]
 
     # ---- coverage -----------------------------------------------------------------------------
     def coverage(self, cin, want_cov=True, want_junc=True, cap_intervals=None, cap_junctions=None, out=None, raw=False):
@@ -245,6 +274,7 @@ class Context:
                            _addr(cin.pos, np.int32, keep, n), _addr(cin.flag, np.uint16, keep, n),
                            _addr(cin.cig_off, np.uint32, keep, n + 1), _addr(cin.cig, np.uint32, keep, nc),
                            _addr(cin.yc, np.float64, keep, n), _addr(cin.strand, np.uint8, keep, n), None)
+        self._order_after_torch(dev)
         ci = (cap_intervals if cap_intervals is not None else 2 * nc + 2 * n + 16) if want_cov else 0
         cj = (cap_junctions if cap_junctions is not None else nc + 16) if want_junc else 0
         bufs = out if out is not None else {}

@@ -14,19 +14,22 @@ Protocol per tile (one process per GPU, torch.distributed; backend "nccl" = RCCL
   1. local collapse (tbk_collapse_tile) -> local groups in output order, with rep_effend
   2. all-gather of 64 sampled group keys per rank  -> R-1 target splitters
   3. each target is moved forward to a GLOBAL bundle boundary (no group of any rank spans it) with a
-     few all-reduce(max/min) rounds of two scalars — so every rank ends up owning whole tiecov bundles
+     few all-reduce(max/min) rounds of one scalar — so every rank ends up owning whole tiecov bundles
   4. all-to-all(v) of the partial groups {tid,pos,strand,yx,yd,prio,ncig | yc | CIGAR words}
   5. stitch = tbk_collapse_tile again over the received partials ("files" = source ranks, all marked
      TieBrush-merged so YC/YX/YD are carried; representative by explicit priority)
   6. tiecov on the owned slice; junction numbers are offset by an all-gather of the per-rank counts.
+
 The rank algorithm is a generator that yields collective requests, so the same code runs over
 torch.distributed (`run_distributed`) and over an in-process loopback of R virtual ranks (`run_loopback`,
-used to exercise R>1 on a single GPU and in CPU tests).
+used to exercise R>1 on a single GPU and in CPU tests).  Arrays are numpy (host tiles) or torch CUDA
+tensors (tiles resident in HBM: nothing but a few scalars ever visits the host); the index bookkeeping
+between the two HIP collapses (searchsorted / cummax / bincount over group keys) is plumbing.
 """
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Optional
+from typing import Any, Optional
 
 import numpy as np
 
@@ -36,132 +39,244 @@ N_SAMPLES = 64
 KEY_INF = np.iinfo(np.int64).max
 
 
+# ---- numpy / torch shim (only the handful of index ops the protocol needs) -----------------------------------
+def _is_t(a):
+    return type(a).__module__.startswith("torch")
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class _NP:
+    i64, f64 = np.int64, np.float64
+
+    @staticmethod
+    def to_i64(a):
+        a = np.asarray(a)
+        if a.dtype == np.uint32:
+            return a.astype(np.int64)
+        return a.astype(np.int64)
+
+    u32_to_i64 = to_i64
+    zeros = staticmethod(lambda n, dt=np.int64, like=None: np.zeros(n, dt))
+    full = staticmethod(lambda n, v, like=None: np.full(n, v, np.int64))
+    arange = staticmethod(lambda n, like=None: np.arange(n, dtype=np.int64))
+    cummax = staticmethod(lambda a: np.maximum.accumulate(a) if len(a) else a)
+    cumsum = staticmethod(lambda a: np.cumsum(a))
+    searchsorted = staticmethod(lambda a, v, right=False: np.searchsorted(a, v, side="right" if right else "left"))
+    repeat = staticmethod(lambda a, r: np.repeat(a, r))
+    stack = staticmethod(lambda xs, axis=0: np.stack(xs, axis=axis))
+    cat = staticmethod(lambda xs: np.concatenate(xs))
+    sort = staticmethod(lambda a: np.sort(a))
+    item = staticmethod(lambda a: int(a))
+    host = staticmethod(lambda a: np.asarray(a))
+    where = staticmethod(lambda c, a, b: np.where(c, a, b))
+
+    @staticmethod
+    def bincount(x, minlength, weights=None):
+        return np.bincount(x, weights=weights, minlength=minlength).astype(np.int64)
+
+    @staticmethod
+    def scalar(v, like=None):
+        return np.array([v], np.int64)
+
+    @staticmethod
+    def as_dtype(a, name):
+        return np.asarray(a).astype({"i32": np.int32, "u16": np.uint16, "u8": np.uint8, "u32": np.uint32, "i64": np.int64,
+                                     "f64": np.float64, "u64": np.uint64}[name])
+
+
+class _TT:
+    @staticmethod
+    def to_i64(a):
+        return a.to(_torch().int64)
+
+    @staticmethod
+    def u32_to_i64(a):  # uint32 payloads travel as int32 tensors
+        return a.to(_torch().int64) & 0xFFFFFFFF
+
+    @staticmethod
+    def zeros(n, dt=None, like=None):
+        return _torch().zeros(n, dtype=_torch().int64, device=like.device)
+
+    @staticmethod
+    def full(n, v, like=None):
+        return _torch().full((n,), v, dtype=_torch().int64, device=like.device)
+
+    @staticmethod
+    def arange(n, like=None):
+        return _torch().arange(n, dtype=_torch().int64, device=like.device)
+
+    cummax = staticmethod(lambda a: _torch().cummax(a, 0).values if a.numel() else a)
+    cumsum = staticmethod(lambda a: _torch().cumsum(a, 0))
+    searchsorted = staticmethod(lambda a, v, right=False: _torch().searchsorted(a, v, right=right))
+    repeat = staticmethod(lambda a, r: _torch().repeat_interleave(a, r))
+    stack = staticmethod(lambda xs, axis=0: _torch().stack(xs, dim=axis))
+    cat = staticmethod(lambda xs: _torch().cat(xs))
+    sort = staticmethod(lambda a: _torch().sort(a).values)
+    item = staticmethod(lambda a: int(a.item()))
+    host = staticmethod(lambda a: a.cpu().numpy())
+    where = staticmethod(lambda c, a, b: _torch().where(c, a, b))
+
+    @staticmethod
+    def bincount(x, minlength, weights=None):
+        return _torch().bincount(x, weights=weights, minlength=minlength).to(_torch().int64)
+
+    @staticmethod
+    def scalar(v, like=None):
+        return _torch().tensor([v], dtype=_torch().int64, device=like.device)
+
+    @staticmethod
+    def as_dtype(a, name):
+        t = _torch()
+        return a.to({"i32": t.int32, "u16": t.int16, "u8": t.uint8, "u32": t.int32, "i64": t.int64, "f64": t.float64,
+                     "u64": t.int64}[name])
+
+
+def _xp(a):
+    return _TT if _is_t(a) else _NP
+
+
 @dataclass
 class ShardResult:
-    """This rank's slice of the global result, in the reference's output order."""
+    """This rank's slice of the global result, in the reference's output order (arrays: numpy or torch)."""
     n_groups: int
     n_passed_local: int          # passing input records of THIS rank's files (sum over ranks = inCounter)
-    tid: np.ndarray
-    start: np.ndarray            # 1-based
-    end: np.ndarray
-    rep_fidx: np.ndarray         # global file index of the representative record
-    rep_idx: np.ndarray          # its index inside that file
-    yc: np.ndarray
-    yx: np.ndarray
-    yd: np.ndarray
-    cov_input: CovInput          # what tiecov reads back for this slice
+    tid: Any
+    start: Any                   # 1-based
+    end: Any
+    rep_fidx: Any                # global file index of the representative record
+    rep_idx: Any                 # its index inside that file
+    yc: Any
+    yx: Any
+    yd: Any
+    cov_input: Any = None        # CovInput (host) or DeviceCovView (device): what tiecov reads back for this slice
     coverage: Optional[dict] = None
     junction_offset: int = 0
+    n_partials_received: int = 0
 
 
-def _key64(tid, pos1):
-    return ((np.asarray(tid, np.int64) + 1) << 32) | np.asarray(pos1, np.int64)
-
-
-def _gather_cigars(tile: SoATile, rep):
-    rep = np.asarray(rep, np.int64)
-    co = np.asarray(tile.cig_off, np.int64)
+def _gather_cigars(X, cig_off, cig, rep):
+    co = X.u32_to_i64(cig_off)
     ncig = co[rep + 1] - co[rep]
-    off = np.zeros(len(rep) + 1, np.int64)
-    np.cumsum(ncig, out=off[1:])
-    tot = int(off[-1])
-    rec_of = np.repeat(np.arange(len(rep)), ncig)
-    within = np.arange(tot) - off[:-1][rec_of]
-    cig = np.asarray(tile.cig)[co[rep][rec_of] + within] if tot else np.zeros(0, np.uint32)
-    return ncig, off, cig.astype(np.uint32)
+    n = int(rep.shape[0])
+    off = X.cat([X.zeros(1, like=ncig), X.cumsum(ncig)]) if n else X.zeros(1, like=co)
+    rec_of = X.repeat(X.arange(n, like=co), ncig)
+    within = X.arange(int(X.item(off[-1])) if n else 0, like=co) - off[:-1][rec_of]
+    idx = co[rep][rec_of] + within
+    return ncig, off, cig[idx]
+
+
+def _pack_generic(X, local_tile, loc, first_fidx):
+    """Exchange layout of the local groups (the layout tbk_pack_partials produces on the device)."""
+    like = local_tile.tid
+    rep = X.u32_to_i64(loc["rep"])
+    fo = X.to_i64(local_tile.file_off) if not _is_t(like) else \
+        _torch().from_numpy(np.asarray(local_tile.file_off).astype(np.int64)).to(like.device)
+    lf = X.searchsorted(fo, rep, right=True) - 1
+    ncig, _, cig = _gather_cigars(X, local_tile.cig_off, local_tile.cig, rep)
+    ycb = loc["yc"].view(_torch().int64) if _is_t(like) else np.ascontiguousarray(loc["yc"], np.float64).view(np.int64)
+    P = X.stack([X.to_i64(local_tile.tid[rep]), X.to_i64(local_tile.pos[rep]), X.to_i64(local_tile.strand[rep]),
+                 X.to_i64(loc["yx"]), X.to_i64(loc["yd"]), X.to_i64(loc["rep_effend"]),
+                 ((lf + first_fidx) << 32) | (rep - fo[lf]), ncig, ycb], axis=1)
+    return P, cig
 
 
 def shard_collapse(compute, local_tile: SoATile, first_fidx: int, rank: int, world: int, strategy="cigar",
-                   want_coverage=False, **filters):
-    """Generator: yields ("all_gather"|"all_reduce_max"|"all_reduce_min"|"all_to_all", payload) requests and is
-    sent the result; finally returns a ShardResult.  `compute` provides collapse(tile, **kw) / coverage(cin)
-    returning host (numpy) dicts — tiebrush_amd.api.Context on a GPU."""
+                   want_coverage=False, device_chain=False, **filters):
+    """Generator: yields ("all_gather"|"all_reduce_max"|"all_reduce_min"|"exchange", payload) requests and is sent
+    the result; finally returns a ShardResult.  `compute` provides collapse(tile, **kw) / coverage(cin)
+    [/ pack_partials / groups_to_cov_in] — tiebrush_amd.api.Context or a wrapper of it."""
     if filters.get("store_frac") or filters.get("collapse_same"):
         raise ValueError("--store-frac and -A need a global second pass: single-GPU only (DESIGN.md §7)")
+    X = _xp(local_tile.tid)
     loc = compute.collapse(local_tile, strategy=strategy, want_coords=True, want_effend=True, **filters)
     ng = int(loc["n_groups"])
-    rep = np.asarray(loc["rep"]).astype(np.int64)
-    fo = np.asarray(local_tile.file_off, np.int64)
-    lf = np.searchsorted(fo, rep, side="right") - 1 if ng else np.zeros(0, np.int64)
-    tid = np.asarray(local_tile.tid)[rep].astype(np.int64) if ng else np.zeros(0, np.int64)
-    gstart = np.asarray(loc["g_start"]).astype(np.int64)
-    gend = np.asarray(loc["g_end"]).astype(np.int64)
-    key = _key64(tid, gstart)                       # nondecreasing: local output order is bucket order
-    ekey = _key64(tid, gend)
-    emax = np.maximum.accumulate(ekey) if ng else ekey
+    tidp1 = None
+    if _is_t(local_tile.tid) and hasattr(compute, "pack_partials"):
+        P, cig, emax = compute.pack_partials(loc, first_fidx, int(local_tile.cig.numel()))     # HIP: pack + running max
+    else:
+        P, cig = _pack_generic(X, local_tile, loc, first_fidx)
+        emax = X.cummax(((P[:, 0] + 1) << 32) | X.to_i64(loc["g_end"]))
+    key = ((P[:, 0] + 1) << 32) | X.to_i64(loc["g_start"])          # nondecreasing: local output order is bucket order
 
     # ---- 2. splitter targets from sampled keys -------------------------------------------------------------
-    samp = np.full(N_SAMPLES, KEY_INF, np.int64)
     if ng:
-        samp[:] = key[np.minimum((np.arange(N_SAMPLES) * ng) // N_SAMPLES, ng - 1)]
+        samp = key[(X.arange(N_SAMPLES, like=key) * ng) // N_SAMPLES]
+    else:
+        samp = X.full(N_SAMPLES, KEY_INF, like=key)
     allsamp = yield ("all_gather", samp)            # [world, N_SAMPLES]
-    flat = np.sort(np.asarray(allsamp).reshape(-1))
-    flat = flat[flat != KEY_INF]
-    cuts = []
-    for j in range(1, world):
-        target = int(flat[(j * len(flat)) // world]) if len(flat) else KEY_INF
-        # ---- 3. move the cut forward to a global bundle boundary ------------------------------------------
-        p = target
-        for _ in range(10000):
-            if p == KEY_INF:
+    if world > 1:
+        flat = np.sort(X.host(allsamp).reshape(-1))
+        flat = flat[flat != KEY_INF]
+        tgt = np.array([int(flat[(j * len(flat)) // world]) if len(flat) else KEY_INF for j in range(1, world)], np.int64)
+        p = _torch().from_numpy(tgt).to(key.device) if _is_t(key) else tgt
+        # ---- 3. move every cut forward to a global bundle boundary (all R-1 cuts refined together) ----------
+        for _ in range(100000):
+            i = X.searchsorted(key, p)
+            m_local = X.full(world - 1, -1, like=key)
+            if ng:
+                ii = (i - 1).clamp(min=0) if _is_t(i) else np.maximum(i - 1, 0)
+                m_local = X.where(i > 0, emax[ii], m_local)
+            m = yield ("all_reduce_max", m_local)
+            ok = (m < p) | (p == KEY_INF)           # every earlier group of every rank ends before the cut
+            if bool(ok.all()):
                 break
-            i = int(np.searchsorted(key, p, side="left"))
-            m_local = int(emax[i - 1]) if i > 0 else -1
-            m = int((yield ("all_reduce_max", np.array([m_local], np.int64)))[0])
-            if m < p:                               # every earlier group of every rank ends before p
-                break
-            i2 = int(np.searchsorted(key, m, side="right"))   # first local group starting after m
-            nxt = int(key[i2]) if i2 < ng else KEY_INF
-            p = int((yield ("all_reduce_min", np.array([nxt], np.int64)))[0])
-        cuts.append(p)
-    cuts = np.array(cuts, np.int64)
-    dest = np.searchsorted(cuts, key, side="right") if world > 1 else np.zeros(ng, np.int64)
+            nxt = X.full(world - 1, KEY_INF, like=key)
+            if ng:
+                i2 = X.searchsorted(key, m, right=True)      # first local group starting after m
+                jj = i2.clamp(max=ng - 1) if _is_t(i2) else np.minimum(i2, ng - 1)
+                nxt = X.where(i2 < ng, key[jj], nxt)
+            nxt = X.where(ok, p, nxt)
+            p = yield ("all_reduce_min", nxt)
+        dest = X.searchsorted(p, key, right=True)
+    else:
+        dest = X.zeros(ng, like=key)
 
     # ---- 4. exchange the partial groups ---------------------------------------------------------------------
-    ncig, coff, cig = _gather_cigars(local_tile, rep) if ng else (np.zeros(0, np.int64), np.zeros(1, np.int64), np.zeros(0, np.uint32))
-    prio_hi = np.asarray(loc["rep_effend"]).astype(np.int64)
-    prio_lo = ((first_fidx + lf) << 32) | (rep - fo[lf]) if ng else np.zeros(0, np.int64)
-    P = np.stack([tid, np.asarray(local_tile.pos)[rep].astype(np.int64) if ng else tid, np.asarray(local_tile.strand)[rep].astype(np.int64) if ng else tid,
-                  np.asarray(loc["yx"]).astype(np.int64), np.asarray(loc["yd"]).astype(np.int64), prio_hi, prio_lo, ncig], axis=1) \
-        if ng else np.zeros((0, 8), np.int64)
-    yc = np.asarray(loc["yc"]).astype(np.float64)
-    cnt = np.bincount(dest, minlength=world).astype(np.int64)
-    ccnt = np.bincount(dest, weights=ncig, minlength=world).astype(np.int64) if ng else np.zeros(world, np.int64)
-    rP, rcnt = yield ("all_to_all", (P, cnt))
-    ryc, _ = yield ("all_to_all", (yc, cnt))
-    rcig, rccnt = yield ("all_to_all", (cig.astype(np.int64), ccnt))
+    # dest is nondecreasing: per-destination row / CIGAR-word counts are differences of prefix positions
+    edges = X.searchsorted(dest, X.arange(world + 1, like=key))
+    cnt = edges[1:] - edges[:-1]
+    csum = X.cat([X.zeros(1, like=key), X.cumsum(P[:, 7])])
+    ccnt = csum[edges[1:]] - csum[edges[:-1]]
+    rP, rcnt, rcig = yield ("exchange", (P, cnt, cig, ccnt))
 
     # ---- 5. stitch: second-level collapse over the received partials ---------------------------------------
     n2 = int(rP.shape[0])
+    rcnt_h = np.asarray(rcnt, np.int64)
     file_off = np.zeros(world + 1, np.uint32)
-    file_off[1:] = np.cumsum(rcnt)
-    cig_off2 = np.zeros(n2 + 1, np.uint32)
-    cig_off2[1:] = np.cumsum(rP[:, 7]) if n2 else 0
+    file_off[1:] = np.cumsum(rcnt_h)
+    cig_off2 = X.cat([X.zeros(1, like=rP), X.cumsum(rP[:, 7])]) if n2 else X.zeros(1, like=rP)
+    col = (lambda c: rP[:, c].contiguous()) if _is_t(rP) else (lambda c: np.ascontiguousarray(rP[:, c]))
     tile2 = SoATile(
-        n_files=world, file_off=file_off, tbmerged=np.ones(world, np.uint8), tid=rP[:, 0].astype(np.int32),
-        pos=rP[:, 1].astype(np.int32), flag=np.zeros(n2, np.uint16), mapq=np.full(n2, 255, np.uint8),
-        strand=rP[:, 2].astype(np.uint8), nh=np.full(n2, -(2**31), np.int32), cig_off=cig_off2,
-        cig=np.asarray(rcig).astype(np.uint32), yc_in=np.asarray(ryc, np.float64), yx_in=rP[:, 3].copy(), yd_in=rP[:, 4].copy(),
-        prio_hi=rP[:, 5].astype(np.uint64), prio_lo=rP[:, 6].astype(np.uint64))
+        n_files=world, file_off=file_off, tbmerged=np.ones(world, np.uint8), tid=X.as_dtype(col(0), "i32"),
+        pos=X.as_dtype(col(1), "i32"), flag=X.as_dtype(X.zeros(n2, like=rP), "u16"),
+        mapq=X.as_dtype(X.full(n2, 255, like=rP), "u8"), strand=X.as_dtype(col(2), "u8"),
+        nh=X.as_dtype(X.full(n2, -(2**31), like=rP), "i32"), cig_off=X.as_dtype(cig_off2, "u32"), cig=rcig,
+        yc_in=col(8).view(_torch().float64) if _is_t(rP) else col(8).view(np.float64), yx_in=col(3), yd_in=col(4),
+        prio_hi=col(5) if _is_t(rP) else col(5).view(np.uint64), prio_lo=col(6) if _is_t(rP) else col(6).view(np.uint64))
     fin = compute.collapse(tile2, strategy=strategy, want_coords=True, keep_supplementary=True, keep_secondary=True)
     g2 = int(fin["n_groups"])
-    rep2 = np.asarray(fin["rep"]).astype(np.int64)
-    plo = rP[rep2, 6] if g2 else np.zeros(0, np.int64)
-    cov_in = None
-    ncg, cof, cg = _gather_cigars(tile2, rep2) if g2 else (np.zeros(0, np.int64), np.zeros(1, np.int64), np.zeros(0, np.uint32))
-    cov_in = CovInput(tid=tile2.tid[rep2] if g2 else np.zeros(0, np.int32), pos=tile2.pos[rep2] if g2 else np.zeros(0, np.int32),
-                      flag=np.zeros(g2, np.uint16), cig_off=cof.astype(np.uint32), cig=cg,
-                      yc=np.asarray(fin["yc"]).astype(np.float32).astype(np.float64),
-                      strand=tile2.strand[rep2] if g2 else np.zeros(0, np.uint8), yx=np.asarray(fin["yx"]).astype(np.int64))
-    res = ShardResult(n_groups=g2, n_passed_local=int(loc["n_passed"]), tid=cov_in.tid, start=np.asarray(fin["g_start"]),
-                      end=np.asarray(fin["g_end"]), rep_fidx=(plo >> 32).astype(np.int64), rep_idx=(plo & 0xFFFFFFFF).astype(np.int64),
-                      yc=np.asarray(fin["yc"]), yx=np.asarray(fin["yx"]), yd=np.asarray(fin["yd"]), cov_input=cov_in)
+    rep2 = X.u32_to_i64(fin["rep"])
+    plo = rP[:, 6][rep2]
+    res = ShardResult(n_groups=g2, n_passed_local=int(loc["n_passed"]), tid=tile2.tid[rep2], start=fin["g_start"],
+                      end=fin["g_end"], rep_fidx=plo >> 32, rep_idx=plo & 0xFFFFFFFF, yc=fin["yc"], yx=fin["yx"], yd=fin["yd"],
+                      n_partials_received=n2)
     # ---- 6. tiecov on the owned slice (whole bundles by construction of the cuts) ---------------------------
+    if device_chain:
+        res.cov_input = compute.groups_to_cov_in(fin)        # stays in HBM
+    else:
+        ncg, cof, cg = _gather_cigars(X, tile2.cig_off, tile2.cig, rep2)
+        ycf = fin["yc"].to(_torch().float32).to(_torch().float64) if _is_t(rP) else np.asarray(fin["yc"]).astype(np.float32).astype(np.float64)
+        res.cov_input = CovInput(tid=tile2.tid[rep2], pos=tile2.pos[rep2], flag=X.as_dtype(X.zeros(g2, like=rP), "u16"),
+                                 cig_off=X.as_dtype(cof, "u32"), cig=cg, yc=ycf, strand=tile2.strand[rep2], yx=X.to_i64(fin["yx"]))
     if want_coverage:
-        cov = compute.coverage(cov_in)
-        nj = yield ("all_gather", np.array([int(cov["n_junctions"])], np.int64))
+        cov = compute.coverage(res.cov_input)
+        nj = yield ("all_gather", X.scalar(int(cov["n_junctions"]), like=key))
         res.coverage = cov
-        res.junction_offset = int(np.asarray(nj).reshape(-1)[:rank].sum())
+        res.junction_offset = int(X.host(nj).reshape(-1)[:rank].sum())
     return res
 
 
@@ -173,26 +288,28 @@ def run_loopback(compute, tiles, first_fidx, **kw):
     reqs = [next(g) for g in gens]
     results = [None] * world
     while any(r is None for r in results):
-        kinds = {q[0] for q, res in zip(reqs, results) if res is None}
-        assert len(kinds) == 1 and all(res is None for res in results), "ranks diverged"
-        kind = kinds.pop()
+        assert all(res is None for res in results) and len({q[0] for q in reqs}) == 1, "ranks diverged"
+        kind = reqs[0][0]
         pay = [q[1] for q in reqs]
+        X = _xp(pay[0][0] if kind == "exchange" else pay[0])
         if kind == "all_gather":
-            out = [np.stack(pay)] * world
+            out = [X.stack(pay)] * world
         elif kind == "all_reduce_max":
-            out = [np.max(np.stack(pay), axis=0)] * world
+            out = [X.stack(pay).max(0) if X is _NP else X.stack(pay).max(0).values] * world
         elif kind == "all_reduce_min":
-            out = [np.min(np.stack(pay), axis=0)] * world
-        elif kind == "all_to_all":
+            out = [X.stack(pay).min(0) if X is _NP else X.stack(pay).min(0).values] * world
+        elif kind == "exchange":
             out = []
             for d in range(world):
-                parts, cnts = [], []
+                rows, words, cnts = [], [], []
                 for s in range(world):
-                    data, cnt = pay[s]
-                    o = int(cnt[:d].sum())
-                    parts.append(data[o:o + int(cnt[d])])
-                    cnts.append(int(cnt[d]))
-                out.append((np.concatenate(parts), np.array(cnts, np.int64)))
+                    P, cnt, cig, ccnt = pay[s]
+                    ch, cc = np.asarray(X.host(cnt), np.int64), np.asarray(X.host(ccnt), np.int64)
+                    o, oc = int(ch[:d].sum()), int(cc[:d].sum())
+                    rows.append(P[o:o + int(ch[d])])
+                    words.append(cig[oc:oc + int(cc[d])])
+                    cnts.append(int(ch[d]))
+                out.append((X.cat(rows), np.array(cnts, np.int64), X.cat(words)))
         else:
             raise AssertionError(kind)
         new = []
@@ -207,14 +324,28 @@ def run_loopback(compute, tiles, first_fidx, **kw):
 
 
 def run_distributed(compute, tile, first_fidx, device=None, group=None, **kw):
-    """One process per GPU: serve the generator's collectives with torch.distributed (RCCL on ROCm)."""
+    """One process per GPU: serve the generator's collectives with torch.distributed (RCCL on ROCm).  Payloads that
+    are already torch tensors on the collective's device go out as they are (no host staging)."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     dev = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
 
+    _signed = {np.dtype(np.uint32): np.int32, np.dtype(np.uint64): np.int64, np.dtype(np.uint16): np.int16}
+
     def t(a):
-        return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        if _is_t(a):
+            return a
+        a = np.ascontiguousarray(a)
+        if a.dtype in _signed:          # collectives have no unsigned types: ship the same bits as signed
+            a = a.view(_signed[a.dtype])
+        return torch.from_numpy(a).to(dev)
+
+    def back(x, like):
+        if _is_t(like):
+            return x
+        r = x.cpu().numpy()
+        return r.view(like.dtype) if np.asarray(like).dtype in _signed else r
 
     gen = shard_collapse(compute, tile, first_fidx, rank, world, **kw)
     try:
@@ -222,25 +353,27 @@ def run_distributed(compute, tile, first_fidx, device=None, group=None, **kw):
         while True:
             kind, pay = req
             if kind == "all_gather":
-                x = t(pay)
-                outs = [torch.empty_like(x) for _ in range(world)]
-                dist.all_gather(outs, x, group=group)
-                res = torch.stack(outs).cpu().numpy()
+                x = t(pay).contiguous()
+                out = torch.empty((world,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+                dist.all_gather_into_tensor(out.view(-1), x.view(-1), group=group)
+                res = back(out, pay)
             elif kind in ("all_reduce_max", "all_reduce_min"):
-                x = t(pay)
+                x = t(pay).clone()
                 dist.all_reduce(x, op=dist.ReduceOp.MAX if kind.endswith("max") else dist.ReduceOp.MIN, group=group)
-                res = x.cpu().numpy()
-            elif kind == "all_to_all":
-                data, cnt = pay
-                c = t(cnt)
+                res = back(x, pay)
+            elif kind == "exchange":
+                P, cnt, cig, ccnt = pay
+                c = torch.stack([t(cnt), t(ccnt)], dim=1).contiguous()     # [world, 2]: rows and CIGAR words per destination
                 rc = torch.empty_like(c)
-                dist.all_to_all_single(rc, c, group=group)          # who sends me how many rows
-                rcnt = rc.cpu().numpy().astype(np.int64)
-                x = t(data)
-                out = torch.empty((int(rcnt.sum()),) + tuple(x.shape[1:]), dtype=x.dtype, device=dev)
-                dist.all_to_all_single(out, x, output_split_sizes=rcnt.tolist(), input_split_sizes=np.asarray(cnt).tolist(),
-                                       group=group)
-                res = (out.cpu().numpy(), rcnt)
+                dist.all_to_all_single(rc, c, group=group)                  # who sends me how much
+                sc_h, rc_h = c.cpu().numpy().astype(np.int64), rc.cpu().numpy().astype(np.int64)
+                x = t(P).contiguous()
+                outP = torch.empty((int(rc_h[:, 0].sum()),) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+                dist.all_to_all_single(outP, x, output_split_sizes=rc_h[:, 0].tolist(), input_split_sizes=sc_h[:, 0].tolist(), group=group)
+                y = t(cig).contiguous()
+                outC = torch.empty(int(rc_h[:, 1].sum()), dtype=y.dtype, device=y.device)
+                dist.all_to_all_single(outC, y, output_split_sizes=rc_h[:, 1].tolist(), input_split_sizes=sc_h[:, 1].tolist(), group=group)
+                res = (back(outP, P), rc_h[:, 0].copy(), back(outC, cig))
             else:
                 raise AssertionError(kind)
             req = gen.send(res)
