@@ -213,9 +213,16 @@ def main():
         line.update(roof)
         if cpu is not None:
             line["cpu_baseline"] = cpu
-        print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio: flush that first so the JSON line is the LAST line on stdout
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
