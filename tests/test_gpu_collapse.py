@@ -204,3 +204,35 @@ def test_yd_stress_spliced(ctx):
     tile = synth.make_tile(12, 20000, "c2", n_loci=40)
     got, want = _check(ctx, tile)
     assert want["yd"].max() > 100
+
+
+def test_store_frac_ordered_accumulation(ctx):
+    """--store-frac: YC is a double accumulated in merge order; sums of 1/NH are order-sensitive in the last ulp"""
+    from tiebrush_amd import synth
+    tile = synth.make_tile(6, 40000, "c5", n_loci=150)
+    got, want = _check(ctx, tile, keep_secondary=True, store_frac=True)
+    assert np.any(want["yc"] != np.floor(want["yc"]))
+    _check(ctx, tile, keep_secondary=True, store_frac=True, strategy="exon", max_nh=20)
+
+
+def test_fractional_tbmerged_and_collapse_same(ctx, bam_loader):
+    """re-collapse of a --store-frac output (fractional carried YC) mixed with plain files, with and without -A"""
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import soa, synth
+    rng = np.random.default_rng(7)
+    base = synth.make_tile(3, 20000, "c5", n_loci=100)
+    # file 0 plays a TieBrush output: unique keys per position are not required for the arithmetic
+    base.tbmerged = np.array([1, 0, 0], np.uint8)
+    n = base.n_records
+    base.yc_in = np.where(rng.random(n) < 0.5, rng.integers(1, 9, n) / 5.0, rng.integers(1, 300, n).astype(np.float64))
+    base.yx_in = rng.integers(1, 12, n).astype(np.int64)
+    base.yd_in = rng.integers(0, 400, n).astype(np.int64)
+    _check(ctx, base, keep_secondary=True)
+    # -A needs names: synthetic names with deliberate repeats inside a file
+    names = [b"r%d" % (i // 2) for i in range(n)]
+    lens = np.array([len(x) for x in names])
+    base.qn_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+    base.qn = np.frombuffer(b"".join(names), np.uint8).copy()
+    base.qname_hash = np.array([soa.qname_hash64(x, soa.pair_order(int(f))) for x, f in zip(names, base.flag)], np.uint64)
+    _check(ctx, base, keep_secondary=True, collapse_same=True)
+    _check(ctx, base, keep_secondary=True, collapse_same=True, store_frac=True)

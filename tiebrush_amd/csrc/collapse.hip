@@ -444,6 +444,47 @@ __global__ void col_same_k(ColIn I, ColOpt O, uint32_t m, const uint32_t* __rest
   if (I.qh[gi] == I.qh[r]) atomicAdd(&G.yc[sg], -1.0);
 }
 
+// ---- ordered YC accumulation (--store-frac, fractional carried YC) ------------------------------------------------
+// accYC is a double accumulated in MERGE order (settle, then dupAdd in pop order: tiebrush.cpp:378-436).  Integer
+// counts are exact in any order; fractional terms are not, so the members of every group are re-sorted by
+// (group, effend) — stable, hence (effend, record index) = merge order — and summed by one thread per group.
+__global__ void ord_fill_k(uint32_t m, const uint32_t* __restrict__ val, const uint32_t* __restrict__ sgid,
+                           const int32_t* __restrict__ effend, const uint8_t* __restrict__ flags, uint64_t* __restrict__ hi,
+                           uint64_t* __restrict__ lo, uint32_t* __restrict__ v, uint8_t* __restrict__ fh_by_rec) {
+  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= m) return;
+  uint32_t gi = val[q];
+  hi[q] = sgid[q];
+  lo[q] = (uint32_t)effend[gi];
+  v[q] = gi;
+  fh_by_rec[gi] = (flags[q] >> 2) & 1u;  // first record of its file inside the group
+}
+__global__ void ord_sum_k(ColIn I, ColOpt O, uint32_t ng, uint32_t m, const uint32_t* __restrict__ v, const uint16_t* __restrict__ fidx,
+                          const uint8_t* __restrict__ fh_by_rec, GroupAcc G) {
+  uint32_t sg = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sg >= ng) return;
+  uint32_t q0 = G.first[sg], q1 = (sg + 1 < ng) ? G.first[sg + 1] : m;
+  uint32_t rep = (uint32_t)(G.rep[sg] & 0xFFFFFFFFull);
+  double acc = 0.0;
+  for (uint32_t q = q0; q < q1; ++q) {
+    uint32_t gi = v[q];
+    double y;
+    if (I.tbm[fidx[gi]]) {
+      y = I.yc_in[gi];
+      if (y == 0.0) y = 1.0;
+    } else if (O.collapse_same && !fh_by_rec[gi] && I.qh[gi] == I.qh[rep]) {
+      continue;  // -A: same read of the same sample is not counted again (tiebrush.cpp:422-424)
+    } else if (O.store_frac) {
+      int nh = I.nh[gi] == TBK_NH_ABSENT ? 1 : I.nh[gi];
+      y = 1.0 / nh;
+    } else {
+      y = 1.0;
+    }
+    acc = (q == q0) ? y : acc + y;
+  }
+  G.yc[sg] = acc;
+}
+
 // cross-rank stitch: the representative is the member with the smallest explicit priority (groups have at most one
 // member per rank, so a serial scan of the group's contiguous members is cheap)
 __global__ void col_rep_prio_k(ColIn I, uint32_t ng, uint32_t m, const uint32_t* __restrict__ val, GroupAcc G) {
@@ -914,7 +955,6 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
   const uint32_t B = 256;
   out->n_groups = 0;
   out->n_passed = 0;
-  if (o->store_frac && o->collapse_same) return TBK_EUNSUPPORTED;
   if (out->rec_group) TBK_HIP(hipMemsetAsync(out->rec_group, 0xFF, (size_t)n * 4, ctx->stream));
   if (n == 0) return 0;
   uint64_t* sc = ctx->d_scalars;  // [0]=n_pass [1]=n_groups [2]=n_items [3]=n_chains [4]=n_nodes
@@ -1052,11 +1092,24 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
     TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     uint32_t eb = 0;
     TBK_TRY(tbk_sync_err(ctx, &eb));
-    if (eb & TBK_DERR_FRACTIONAL) {
-      ctx->last_error = "fractional YC in TieBrush-merged input: ordered accumulation path not built yet";
-      return TBK_EUNSUPPORTED;
-    }
+    const bool need_ordered = O.store_frac || (eb & TBK_DERR_FRACTIONAL);
+    eb &= ~TBK_DERR_FRACTIONAL;
     if (eb) return tbk_derr_to_status(ctx, eb);
+    if (need_ordered) {
+      TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
+      SortBufs ob;
+      ob.hi = ws_alloc<uint64_t>(ctx, m);
+      ob.lo = ws_alloc<uint64_t>(ctx, m);
+      ob.val = ws_alloc<uint32_t>(ctx, m);
+      ob.hi2 = ws_alloc<uint64_t>(ctx, m);
+      ob.lo2 = ws_alloc<uint64_t>(ctx, m);
+      ob.val2 = ws_alloc<uint32_t>(ctx, m);
+      uint8_t* fh_by_rec = ws_alloc<uint8_t>(ctx, n);
+      if (!ob.val2 || !fh_by_rec) return TBK_ENOMEM;
+      TBK_LAUNCH(ctx, "ord_fill", ord_fill_k, cdiv(m, B), B, 0, m, sb.val, sgid, effend, flags, ob.hi, ob.lo, ob.val, fh_by_rec);
+      TBK_TRY(tbk_radix_sort128(ctx, &ob, m));
+      TBK_LAUNCH(ctx, "ord_sum", ord_sum_k, cdiv(ng, 64), 64, 0, I, O, ng, m, ob.val, fidx, fh_by_rec, G);
+    }
     const uint64_t nit64 = ctx->h_scalars[2];
     if (nit64 >= (1ull << 32)) return TBK_E2BIG;
     const uint32_t nit = (uint32_t)nit64;
