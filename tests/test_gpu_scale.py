@@ -1,0 +1,124 @@
+"""GPU parity at BASELINE.json sizes.
+  * config 2 at full size (2 x 1M reads) and a config-3 shaped tile (64 files, --clip): bit-exact vs the oracle;
+  * a 32 x 1M tile (and, with TBK_FULL_SCALE=1, config 3 at its full 64 x 5M) through size-independent properties:
+    count conservation, output order, rec_group consistency, idempotence of re-collapsing the output, and for
+    tiecov the checksum  sum((end-start)*value) == sum(YC * M bases)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from tiebrush_amd import api
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def _exact(ctx, tile, **kw):
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import api, synth
+    okw = dict(kw)
+    if "strategy" in okw:
+        okw["strategy"] = {"cigar": 0, "full": 1, "clip": 2, "exon": 3}[okw["strategy"]]
+    want = orc.collapse(tile, want_rec_group=True, **okw)
+    dt = api.to_device(tile, "cuda:0")
+    res = ctx.collapse(dt, want_rec_group=True, **kw)
+    got = api.to_numpy(res)
+    assert got["n_groups"] == want["n_groups"] and got["n_passed"] == want["n_passed"]
+    for k in ("rep", "yc", "yx", "yd", "g_start", "g_end", "rec_group"):
+        assert np.array_equal(got[k], want[k]), k
+    cw = orc.coverage(synth.collapsed_to_cov_input(tile, want))
+    cg = api.to_numpy(ctx.coverage(ctx.groups_to_cov_in(res)))
+    for k in ("iv_tid", "iv_start", "iv_end", "iv_val", "j_tid", "j_start", "j_end", "j_strand", "j_val"):
+        assert np.array_equal(cg[k], cw[k]), k
+    assert cg["n_bases"] == cw["n_bases"] and cg["span_bases"] == cw["span_bases"]
+
+
+def test_config2_full_size_exact(ctx):
+    from tiebrush_amd import synth
+    _exact(ctx, synth.make_tile(2, 1_000_000, "c2"))
+
+
+def test_config3_shape_exact(ctx):
+    from tiebrush_amd import synth
+    _exact(ctx, synth.make_tile(64, 150_000, "c3"), strategy="clip")
+
+
+def test_config5_shape_exact(ctx):
+    from tiebrush_amd import synth
+    _exact(ctx, synth.make_tile(128, 40_000, "c5"), strategy="exon", max_nh=5, min_qual=1)
+
+
+def _properties(ctx, tile, **kw):
+    import torch
+    from tiebrush_amd import api, soa
+    n = tile.n_records
+    dt = api.to_device(tile, "cuda:0")
+    res = ctx.collapse(dt, want_rec_group=True, **kw)
+    g = res["n_groups"]
+    assert res["n_passed"] == n                                   # config 2/3 inputs pass every filter
+    yc, yx, yd, rep = res["yc"], res["yx"], res["yd"], res["rep"].to(torch.int64) & 0xFFFFFFFF
+    assert float(yc.sum()) == float(n)                            # every passing record is counted exactly once
+    assert int(yx.min()) >= 1 and int(yx.max()) <= tile.n_files and int(yd.min()) >= 0
+    # output order: buckets by (tid,start); inside a bucket strand code then end
+    tid = dt.tid[rep].to(torch.int64)
+    code = torch.where(dt.strand[rep] == 43, 0, torch.where(dt.strand[rep] == 45, 1, 2)).to(torch.int64)
+    key = ((tid + 1) << 33) | (res["g_start"].to(torch.int64) << 2) | code
+    assert bool((key[1:] >= key[:-1]).all())
+    same = key[1:] == key[:-1]
+    assert bool((res["g_end"][1:][same] >= res["g_end"][:-1][same]).all())
+    # rec_group: every record belongs to one group, group sizes add up to YC, the representative is a member
+    rg = res["rec_group"].to(torch.int64)
+    assert int(rg.min()) >= 0 and int(rg.max()) == g - 1
+    assert torch.equal(torch.bincount(rg, minlength=g).to(torch.float64), yc)
+    assert torch.equal(rg[rep], torch.arange(g, device=rg.device))
+    # tiecov checksum on the collapsed records
+    view = ctx.groups_to_cov_in(res)
+    cov = ctx.coverage(view)
+    ni = cov["n_intervals"]
+    area = ((cov["iv_end"] - cov["iv_start"]).to(torch.float64) * cov["iv_val"]).sum()
+    co = dt.cig_off.to(torch.int64) & 0xFFFFFFFF
+    ops = dt.cig.to(torch.int64) & 0xFFFFFFFF
+    mlen = torch.where((ops & 0xF) == 0, ops >> 4, torch.zeros_like(ops))
+    csum = torch.cat([torch.zeros(1, dtype=torch.int64, device=ops.device), torch.cumsum(mlen, 0)])
+    mb = csum[co[rep + 1]] - csum[co[rep]]
+    assert float(area) == float((mb.to(torch.float64) * yc.to(torch.float32).to(torch.float64)).sum())
+    assert cov["n_bases"] == int(mb.sum())
+    iv = (cov["iv_tid"].to(torch.int64) << 32) | cov["iv_start"].to(torch.int64)
+    assert bool((iv[1:] > iv[:-1]).all()) and bool((cov["iv_val"] != 0).all())
+    # idempotence: the collapsed output, fed back as one TieBrush-merged file, collapses to itself
+    gnp = api.to_numpy({k: v for k, v in res.items() if not k.startswith("_")})
+    r = gnp["rep"].astype(np.int64)
+    co_h = tile.cig_off.astype(np.int64)
+    nc = co_h[r + 1] - co_h[r]
+    off = np.zeros(g + 1, np.int64)
+    np.cumsum(nc, out=off[1:])
+    idx = np.repeat(co_h[r] - off[:-1], nc) + np.arange(int(off[-1]))
+    t2 = soa.SoATile(n_files=1, file_off=np.array([0, g], np.uint32), tbmerged=np.ones(1, np.uint8), tid=tile.tid[r], pos=tile.pos[r],
+                     flag=tile.flag[r], mapq=tile.mapq[r], strand=tile.strand[r], nh=tile.nh[r], cig_off=off.astype(np.uint32),
+                     cig=tile.cig[idx], yc_in=gnp["yc"].astype(np.float32).astype(np.float64), yx_in=gnp["yx"].astype(np.int64),
+                     yd_in=gnp["yd"].astype(np.int64))
+    again = api.to_numpy(ctx.collapse(api.to_device(t2, "cuda:0"), **kw))
+    assert again["n_groups"] == g and np.array_equal(again["rep"], np.arange(g, dtype=np.uint32))
+    for k in ("yc", "yx", "yd", "g_start", "g_end"):
+        assert np.array_equal(again[k], gnp[k]), k
+    return g, ni
+
+
+def test_properties_32x1M(ctx):
+    from tiebrush_amd import synth
+    tile = synth.make_tile(32, 1_000_000, "c3")
+    g, ni = _properties(ctx, tile, strategy="clip")
+    assert 0 < g < tile.n_records
+
+
+@pytest.mark.skipif(os.environ.get("TBK_FULL_SCALE") != "1", reason="config 3 at 64 x 5M takes minutes of host-side generation; set TBK_FULL_SCALE=1")
+def test_properties_config3_full_64x5M(ctx):
+    from tiebrush_amd import synth
+    tile = synth.make_tile(64, 5_000_000, "c3")
+    _properties(ctx, tile, strategy="clip")
