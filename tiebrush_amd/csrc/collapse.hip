@@ -816,6 +816,40 @@ __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids
     int it_d = 0;
     const int nb = (int)((t1 - tb) < 64u ? (t1 - tb) : 64u);
     for (int j = 0; j < nb && !overflow; ++j) {
+      // ---- fast path: a maximal run of single-exon items that fall inside the first island [S0,E0] and stay clear
+      // of the next node (start D1).  For such an item processRead finds prev = node 0 with prev.end >= start, so
+      // d = start - S0, and mergeRead only stretches node 0's end — no clearTo, no insertion, no swallow.  The run is
+      // found for all remaining lanes of the batch at once with a wave prefix-max of the exon ends.
+      if (cnt >= 1) {
+        const uint32_t S0 = rl(ns, 0), E0 = rl(ne, 0);
+        const uint32_t D1 = cnt > 1 ? rl(ns, 1) : 0xFFFFFFFFu;
+        if (E0 < D1) {
+          uint32_t ev = (lane >= j && lane < nb) ? it_e0 : 0u;
+          uint32_t pm = ev;  // inclusive prefix max over lanes (DPP row shifts + row broadcasts, identity 0)
+          pm = max(pm, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x111, 0xf, 0xf, false));
+          pm = max(pm, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x112, 0xf, 0xf, false));
+          pm = max(pm, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x114, 0xf, 0xf, false));
+          pm = max(pm, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x118, 0xf, 0xf, false));
+          pm = max(pm, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x142, 0xa, 0xf, false));
+          pm = max(pm, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x143, 0xc, 0xf, false));
+          uint32_t ex = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x138, 0xf, 0xf, false);  // wave_shr:1 -> exclusive
+          uint32_t ebefore = ex > E0 ? ex : E0;
+          bool okl = lane >= j && lane < nb && it_nex == 1u && S0 < it_start && it_e0 < D1 && it_start <= ebefore;
+          uint64_t mk = __ballot(okl) >> j;
+          int r = mk == ~0ull ? 64 : __builtin_ctzll(~mk);
+          if (r > nb - j) r = nb - j;
+          if (r > 0) {
+            if (lane >= j && lane < j + r) it_d = (int)(it_start - S0);
+            uint32_t newE = rl(pm, j + r - 1);
+            if (newE < E0) newE = E0;
+            if (lane == 0) ne = newE;
+            last_pos = rl(it_start, j + r - 1);
+            last_dist = (int)(last_pos - S0);
+            j += r - 1;
+            continue;
+          }
+        }
+      }
       const uint32_t rstart = rl(it_start, j);
       const uint32_t nex = rl(it_nex, j);
       const uint32_t xo = rl(it_xo, j);
