@@ -233,22 +233,20 @@ __device__ int strategy_cmp(const ColIn& I, int strategy, uint32_t a, uint32_t b
 }
 
 // ---- K1: keys --------------------------------------------------------------------------------------
-struct EffKey {  // scan element: lexicographic running max of (hi, end) per file + count of passing records
-  uint64_t khi;
+struct EffKey {  // scan element: lexicographic running max of (hi, end) per file + count of passing records (all 32-bit words)
+  uint32_t khi_h, khi_l;
   int32_t kend;
-  uint32_t flag;
-  uint32_t cnt;
-  uint32_t pad;
+  uint32_t flag_cnt;  // bit 31 = a file head lies in the covered span, bits 0..30 = passing records
 };
 struct EffOp {
   __device__ __forceinline__ EffKey operator()(const EffKey& a, const EffKey& b) const {
+    uint64_t ak = ((uint64_t)a.khi_h << 32) | a.khi_l, bk = ((uint64_t)b.khi_h << 32) | b.khi_l;
+    bool take_b = (b.flag_cnt >> 31) || bk > ak || (bk == ak && b.kend > a.kend);
     EffKey r;
-    bool take_b = b.flag || b.khi > a.khi || (b.khi == a.khi && b.kend > a.kend);
-    r.khi = take_b ? b.khi : a.khi;
+    r.khi_h = take_b ? b.khi_h : a.khi_h;
+    r.khi_l = take_b ? b.khi_l : a.khi_l;
     r.kend = take_b ? b.kend : a.kend;
-    r.flag = a.flag | b.flag;
-    r.cnt = a.cnt + b.cnt;
-    r.pad = 0;
+    r.flag_cnt = ((a.flag_cnt | b.flag_cnt) & 0x80000000u) | ((a.flag_cnt + b.flag_cnt) & 0x7FFFFFFFu);
     return r;
   }
 };
@@ -301,12 +299,12 @@ struct EffLoad {
   const uint8_t* kflags;
   __device__ __forceinline__ EffKey operator()(uint32_t i) const {
     EffKey e;
-    e.khi = khi[i] >> 2;  // (tid,start) only: the strand bits are not part of the merge key
+    uint64_t k = khi[i] >> 2;  // (tid,start) only: the strand bits are not part of the merge key
+    e.khi_h = (uint32_t)(k >> 32);
+    e.khi_l = (uint32_t)k;
     e.kend = kend[i];
     uint8_t f = kflags[i];
-    e.flag = (f >> 1) & 1u;
-    e.cnt = f & 1u;
-    e.pad = 0;
+    e.flag_cnt = ((uint32_t)((f >> 1) & 1u) << 31) | (f & 1u);
     return e;
   }
 };
@@ -323,14 +321,15 @@ struct EffStore {
   uint32_t* err;
   __device__ __forceinline__ void operator()(uint32_t i, const EffKey& inc, const EffKey& ex) const {
     if (kflags[i] & 1u) {
-      if (inc.khi != (khi[i] >> 2)) atomicOr(err, TBK_DERR_UNSORTED);  // an earlier record of the file has a larger (tid,start)
+      uint64_t ik = ((uint64_t)inc.khi_h << 32) | inc.khi_l;
+      if (ik != (khi[i] >> 2)) atomicOr(err, TBK_DERR_UNSORTED);  // an earlier record of the file has a larger (tid,start)
       effend[i] = inc.kend;
-      uint32_t d = ex.cnt;
+      uint32_t d = ex.flag_cnt & 0x7FFFFFFFu;
       chi[d] = khi[i];
       clo[d] = klo[i];
       cval[d] = i;
     }
-    if (i + 1 == n) *n_pass = inc.cnt;
+    if (i + 1 == n) *n_pass = inc.flag_cnt & 0x7FFFFFFFu;
   }
 };
 
@@ -1072,7 +1071,7 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
     {
       EffLoad ld{khi, klo ? kend : kend, kflags};
       EffStore st{khi, klo, kflags, effend, s2.hi, s2.lo, s2.val, sc + 0, n, ctx->d_err};
-      EffKey ident{0ull, INT32_MIN, 0u, 0u, 0u};
+      EffKey ident{0u, 0u, INT32_MIN, 0u};
       TBK_TRY((scan_op_run<EffKey, EffOp, EffLoad, EffStore>(ctx, "col_effkey_scan", n, ld, st, EffOp{}, ident)));
     }
     TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));

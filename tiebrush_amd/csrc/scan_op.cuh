@@ -6,24 +6,26 @@
 #include "dev_common.cuh"
 #include "tbk_internal.h"
 
+// Word-wise shuffle of a small POD.  The words go through a by-value array copy (bit_cast), never through a pointer
+// to the live object, so the struct stays in registers (an address-taken struct ends up in scratch memory).
+template <class T>
+struct Words {
+  uint32_t w[sizeof(T) / 4];
+};
 template <class T>
 __device__ __forceinline__ T shfl_up_t(const T& v, int d) {
   static_assert(sizeof(T) % 4 == 0, "T must be made of 32-bit words");
-  T r;
-  const uint32_t* s = reinterpret_cast<const uint32_t*>(&v);
-  uint32_t* o = reinterpret_cast<uint32_t*>(&r);
+  Words<T> a = __builtin_bit_cast(Words<T>, v);
 #pragma unroll
-  for (unsigned k = 0; k < sizeof(T) / 4; ++k) o[k] = __shfl_up(s[k], d, 64);
-  return r;
+  for (unsigned k = 0; k < sizeof(T) / 4; ++k) a.w[k] = __shfl_up(a.w[k], d, 64);
+  return __builtin_bit_cast(T, a);
 }
 template <class T>
 __device__ __forceinline__ T shfl_idx_t(const T& v, int l) {
-  T r;
-  const uint32_t* s = reinterpret_cast<const uint32_t*>(&v);
-  uint32_t* o = reinterpret_cast<uint32_t*>(&r);
+  Words<T> a = __builtin_bit_cast(Words<T>, v);
 #pragma unroll
-  for (unsigned k = 0; k < sizeof(T) / 4; ++k) o[k] = __shfl(s[k], l, 64);
-  return r;
+  for (unsigned k = 0; k < sizeof(T) / 4; ++k) a.w[k] = __shfl(a.w[k], l, 64);
+  return __builtin_bit_cast(T, a);
 }
 
 constexpr int SO_NT = 256;
