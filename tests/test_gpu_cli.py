@@ -100,3 +100,41 @@ def test_cli_usage_errors():
     r = subprocess.run([os.path.join(BIN, "tiebrush"), "-L", "-P", "-o", "/tmp/x.bam", os.path.join(GOLDEN, "t12.bam")],
                        capture_output=True, text=True)
     assert r.returncode == 1 and "only one merging strategy" in r.stderr
+
+
+@pytest.mark.parametrize("profile,flags,okw", [
+    ("c5", ["-E", "-N", "5", "-Q", "1"], dict(strategy=3, max_nh=5, min_qual=1)),
+    ("c3", ["--clip"], dict(strategy=2)),
+    ("c5", ["--keep-secondary", "-S", "--store-frac"], dict(keep_secondary=True, keep_supplementary=True, store_frac=True)),
+])
+def test_cli_on_synthetic_bams_matches_oracle(tmp_path, profile, flags, okw):
+    """options no reference fixture exercises (-E/-P/-N/-Q/-S/--store-frac), end to end through real BAM files:
+    tiebrush CLI output == oracle on the same records; tiecov CLI text == oracle coverage of that output"""
+    import struct
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import bamio, synth, soa
+    tile = synth.make_tile(3, 4000, profile, n_loci=60)
+    paths = synth.write_bams(tile, str(tmp_path / "in"))
+    out = str(tmp_path / "out.bam")
+    r = _run([os.path.join(BIN, "tiebrush"), "-o", out] + flags + paths)
+    want = orc.collapse(tile, **okw)
+    o = bamio.read_bam(out)
+    assert o.n == want["n_groups"]
+    assert "%d input records written as %d" % (want["n_passed"], want["n_groups"]) in r.stderr
+    fo = tile.file_of()
+    for g in range(o.n):
+        gi = int(want["rep"][g])
+        f = int(fo[gi])
+        assert o.qname[g] == b"r%d_%d" % (f, gi - int(tile.file_off[f]))
+        assert np.float32(o.yc[g]) == np.float32(want["yc"][g]) and o.yx[g] == want["yx"][g] and o.yd[g] == want["yd"][g]
+    pre = str(tmp_path / "cov")
+    _run([os.path.join(BIN, "tiecov"), "-c", pre, "-j", pre, out])
+    cw = orc.coverage(soa.cov_input_from_bam(o))
+    names = o.header.ref_names
+    want_cov = ["track type=bedGraph"] + ["%s\t%d\t%d\t%.3f" % (names[cw["iv_tid"][i]], cw["iv_start"][i], cw["iv_end"][i], cw["iv_val"][i])
+                                          for i in range(cw["n_intervals"])]
+    want_j = ["track name=junctions"] + ["%s\t%d\t%d\tJUNC%08d\t%.3f\t%s" % (names[cw["j_tid"][i]], cw["j_start"][i], cw["j_end"][i], i + 1,
+                                                                            cw["j_val"][i], chr(cw["j_strand"][i]))
+                                         for i in range(cw["n_junctions"])]
+    assert read_lines(pre + ".bedgraph") == want_cov
+    assert read_lines(pre + ".bed") == want_j
