@@ -33,3 +33,13 @@ def load_bam_cached(path, **kw):
 @pytest.fixture(scope="session")
 def bam_loader():
     return load_bam_cached
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_built():
+    """Everything native is built in-tree (and travels with the snapshot); build it when a fresh checkout lacks it."""
+    need = [os.path.join(ROOT, "tiebrush_amd", "_build", n) for n in ("libtbk.so", "tiebrush", "tiecov", "tbh_tool")]
+    need.append(os.path.join(ROOT, "oracle", "_build", "libtb_oracle.so"))
+    if not all(os.path.exists(p) for p in need):
+        import __graft_entry__ as g
+        g.build()
