@@ -801,17 +801,33 @@ __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids
   uint32_t last_pos = 0;
   int last_dist = -1;
   bool overflow = false;
-  for (uint32_t tb = t0; tb < t1 && !overflow; tb += 64) {
+  // batch loader: lane l holds item tb+l.  The next batch is requested before the current one is processed so that
+  // its global-load latency hides behind the (long, scalar-ish) item loop.
+  struct Batch {
+    uint32_t start, nex, xo, o, e0, s1, e1, s2, e2;
+  };
+  auto load_batch = [&](uint32_t tb) {
+    Batch b;
     const uint32_t t = tb + (uint32_t)lane;
     const bool have = t < t1;
-    // batch load: lane l holds item tb+l
-    uint32_t it_start = have ? (uint32_t)Y.start[t] : 0u;
-    uint32_t it_nex = have ? Y.nex[t] : 0u;
-    uint32_t it_xo = have ? noff[t] : 0u;
-    uint32_t it_o = have ? v[t] : 0u;
-    uint32_t it_e0 = have ? ex_e[it_xo] : 0u;  // first exon end (its start is the read start)
-    uint32_t it_s1 = (have && it_nex > 1) ? ex_s[it_xo + 1] : 0u, it_e1 = (have && it_nex > 1) ? ex_e[it_xo + 1] : 0u;
-    uint32_t it_s2 = (have && it_nex > 2) ? ex_s[it_xo + 2] : 0u, it_e2 = (have && it_nex > 2) ? ex_e[it_xo + 2] : 0u;
+    b.start = have ? (uint32_t)Y.start[t] : 0u;
+    b.nex = have ? Y.nex[t] : 0u;
+    b.xo = have ? noff[t] : 0u;
+    b.o = have ? v[t] : 0u;
+    b.e0 = have ? ex_e[b.xo] : 0u;  // first exon end (its start is the read start)
+    b.s1 = (have && b.nex > 1) ? ex_s[b.xo + 1] : 0u;
+    b.e1 = (have && b.nex > 1) ? ex_e[b.xo + 1] : 0u;
+    b.s2 = (have && b.nex > 2) ? ex_s[b.xo + 2] : 0u;
+    b.e2 = (have && b.nex > 2) ? ex_e[b.xo + 2] : 0u;
+    return b;
+  };
+  Batch nxt = load_batch(t0);
+  for (uint32_t tb = t0; tb < t1 && !overflow; tb += 64) {
+    const Batch cur = nxt;
+    if (tb + 64 < t1) nxt = load_batch(tb + 64);
+    const bool have = tb + (uint32_t)lane < t1;
+    const uint32_t it_start = cur.start, it_nex = cur.nex, it_xo = cur.xo, it_o = cur.o, it_e0 = cur.e0;
+    const uint32_t it_s1 = cur.s1, it_e1 = cur.e1, it_s2 = cur.s2, it_e2 = cur.e2;
     int it_d = 0;
     const int nb = (int)((t1 - tb) < 64u ? (t1 - tb) : 64u);
     for (int j = 0; j < nb && !overflow; ++j) {
@@ -898,7 +914,9 @@ __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids
               overflow = true;
               break;
             }
-            uint32_t us = __shfl_up(ns, 1, 64), ue = __shfl_up(ne, 1, 64);
+            // one-lane shifts are DPP wave shifts (single VALU op) instead of ds_bpermute round trips
+            uint32_t us = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ns, 0x138, 0xf, 0xf, false);
+            uint32_t ue = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ne, 0x138, 0xf, 0xf, false);
             if (lane > n) {
               ns = us;
               ne = ue;
@@ -915,7 +933,8 @@ __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids
               uint32_t xS = rl(ns, n + 1);
               if (xS > newE) break;
               uint32_t xE = rl(ne, n + 1);
-              uint32_t ds = __shfl_down(ns, 1, 64), de = __shfl_down(ne, 1, 64);
+              uint32_t ds = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ns, 0x130, 0xf, 0xf, false);
+              uint32_t de = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ne, 0x130, 0xf, 0xf, false);
               if (lane > n) {
                 ns = ds;
                 ne = de;

@@ -102,12 +102,12 @@ std::string GSamRecord::cigar() {
   return s;
 }
 
-void GSamReader::bopen(const char* filename, int32_t, const char*) {
+void GSamReader::bopen(const char* filename, int32_t, const char*, int inflate_threads) {
   fname_ = filename;
   f_ = std::make_shared<tbh::BamFile>();
   std::string err;
   if (!tbh::bgzf_probe(fname_)) GError("Error: could not open alignment file %s (only BAM input is supported)\n", filename);
-  if (!f_->load(fname_, err, 4)) GError("Error: could not open alignment file %s (%s)\n", filename, err.c_str());
+  if (!f_->load(fname_, err, inflate_threads < 1 ? 1 : inflate_threads)) GError("Error: could not open alignment file %s (%s)\n", filename, err.c_str());
   next_ = 0;
 }
 

@@ -129,8 +129,10 @@ class GSamReader {
   std::string fname_;
 
  public:
-  GSamReader(const char* fn, int32_t required_fields = 0, const char* cram_ref = nullptr) { bopen(fn, required_fields, cram_ref); }
-  void bopen(const char* filename, int32_t = 0, const char* = nullptr);
+  GSamReader(const char* fn, int32_t required_fields = 0, const char* cram_ref = nullptr, int inflate_threads = 4) {
+    bopen(fn, required_fields, cram_ref, inflate_threads);
+  }
+  void bopen(const char* filename, int32_t = 0, const char* = nullptr, int inflate_threads = 4);
   void bclose() { f_.reset(); }
   sam_hdr_t* header() { return f_ ? &f_->hdr : nullptr; }
   const char* fileName() { return fname_.c_str(); }

@@ -121,8 +121,10 @@ BgzfWriter::~BgzfWriter() {
   if (f_) close();
 }
 
-bool BgzfWriter::open(const std::string& path, int level) {
+bool BgzfWriter::open(const std::string& path, int level, int threads) {
   level_ = level;
+  if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+  threads_ = threads < 1 ? 1 : (threads > 32 ? 32 : threads);
   if (path == "-") {
     f_ = stdout;
     own_ = false;
@@ -134,62 +136,88 @@ bool BgzfWriter::open(const std::string& path, int level) {
     err_ = "cannot create " + path;
     return false;
   }
-  buf_.reserve(kBlock);
   return true;
 }
 
-bool BgzfWriter::flush_block() {
-  if (buf_.empty()) return true;
-  uint8_t outb[0x10000 + 64];
+// deflate one <=0xff00-byte block into a complete BGZF member
+static bool deflate_member(const uint8_t* src, size_t n, int level, std::vector<uint8_t>& out) {
+  out.resize(0x10000 + 64);
   z_stream zs;
   memset(&zs, 0, sizeof(zs));
-  if (deflateInit2(&zs, level_, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
-    err_ = "deflateInit2 failed";
-    return false;
-  }
-  zs.next_in = buf_.data();
-  zs.avail_in = (uInt)buf_.size();
-  zs.next_out = outb + 18;
-  zs.avail_out = sizeof(outb) - 18 - 8;
+  if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+  zs.next_in = const_cast<uint8_t*>(src);
+  zs.avail_in = (uInt)n;
+  zs.next_out = out.data() + 18;
+  zs.avail_out = (uInt)(out.size() - 18 - 8);
   int rc = deflate(&zs, Z_FINISH);
   size_t clen = zs.total_out;
   deflateEnd(&zs);
-  if (rc != Z_STREAM_END) {
+  if (rc != Z_STREAM_END) return false;
+  size_t bsize = clen + 25;  // total member length - 1
+  const uint8_t hdr[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, (uint8_t)(bsize & 0xff), (uint8_t)(bsize >> 8)};
+  memcpy(out.data(), hdr, 18);
+  uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), src, (uInt)n);
+  uint32_t isz = (uint32_t)n;
+  uint8_t* t = out.data() + 18 + clen;
+  for (int k = 0; k < 4; ++k) t[k] = (uint8_t)(crc >> (8 * k));
+  for (int k = 0; k < 4; ++k) t[4 + k] = (uint8_t)(isz >> (8 * k));
+  out.resize(18 + clen + 8);
+  return true;
+}
+
+bool BgzfWriter::flush_chunk() {
+  if (buf_.empty()) return true;
+  size_t nblk = (buf_.size() + kBlock - 1) / kBlock;
+  std::vector<std::vector<uint8_t>> outs(nblk);
+  std::atomic<size_t> next{0};
+  std::atomic<bool> ok{true};
+  auto work = [&]() {
+    for (;;) {
+      size_t i = next.fetch_add(1);
+      if (i >= nblk) break;
+      size_t off = i * kBlock;
+      size_t n = buf_.size() - off < kBlock ? buf_.size() - off : kBlock;
+      if (!deflate_member(buf_.data() + off, n, level_, outs[i])) ok = false;
+    }
+  };
+  int nt = (int)(nblk < (size_t)threads_ ? nblk : (size_t)threads_);
+  if (nt <= 1) {
+    work();
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) th.emplace_back(work);
+    for (auto& t : th) t.join();
+  }
+  if (!ok) {
     err_ = "deflate failed";
     return false;
   }
-  size_t bsize = clen + 25;  // total member length - 1
-  const uint8_t hdr[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, (uint8_t)(bsize & 0xff), (uint8_t)(bsize >> 8)};
-  memcpy(outb, hdr, 18);
-  uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), buf_.data(), (uInt)buf_.size());
-  uint32_t isz = (uint32_t)buf_.size();
-  uint8_t* t = outb + 18 + clen;
-  for (int k = 0; k < 4; ++k) t[k] = (uint8_t)(crc >> (8 * k));
-  for (int k = 0; k < 4; ++k) t[4 + k] = (uint8_t)(isz >> (8 * k));
-  if (fwrite(outb, 1, 18 + clen + 8, f_) != 18 + clen + 8) {
-    err_ = "write failed";
-    return false;
-  }
+  for (auto& o : outs)
+    if (fwrite(o.data(), 1, o.size(), f_) != o.size()) {
+      err_ = "write failed";
+      return false;
+    }
   buf_.clear();
   return true;
 }
 
 bool BgzfWriter::write(const void* p, size_t n) {
   const uint8_t* s = (const uint8_t*)p;
-  while (n) {
-    size_t room = kBlock - buf_.size();
-    size_t k = n < room ? n : room;
-    buf_.insert(buf_.end(), s, s + k);
-    s += k;
-    n -= k;
-    if (buf_.size() == kBlock && !flush_block()) return false;
+  buf_.insert(buf_.end(), s, s + n);
+  // cut on a block boundary so that the member sequence does not depend on the chunking
+  if (buf_.size() >= chunk_) {
+    size_t whole = (buf_.size() / kBlock) * kBlock;
+    std::vector<uint8_t> tail(buf_.begin() + whole, buf_.end());
+    buf_.resize(whole);
+    if (!flush_chunk()) return false;
+    buf_.swap(tail);
   }
   return true;
 }
 
 bool BgzfWriter::close() {
   if (!f_) return true;
-  bool ok = flush_block();
+  bool ok = flush_chunk();
   ok = ok && fwrite(kEof, 1, sizeof(kEof), f_) == sizeof(kEof);
   if (own_)
     ok = (fclose(f_) == 0) && ok;

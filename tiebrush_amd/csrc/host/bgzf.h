@@ -15,20 +15,24 @@ bool bgzf_read_file(const std::string& path, std::vector<uint8_t>& out, std::str
 // True when the file starts with a BGZF member (gzip magic + BC extra field).
 bool bgzf_probe(const std::string& path);
 
+// BGZF members are independent deflate streams: the writer buffers up to `chunk` bytes of payload, then deflates the
+// 0xff00-byte blocks of that chunk on `threads` workers and writes them out in order.
 class BgzfWriter {
  public:
   BgzfWriter() = default;
   ~BgzfWriter();
-  bool open(const std::string& path, int level = 6);  // "-" = stdout
+  bool open(const std::string& path, int level = 6, int threads = 0 /*0 = hardware concurrency, capped at 32*/);
   bool write(const void* p, size_t n);
   bool close();  // flushes and appends the 28-byte EOF block
   const std::string& error() const { return err_; }
 
  private:
-  bool flush_block();
+  bool flush_chunk();
   FILE* f_ = nullptr;
   bool own_ = false;
   int level_ = 6;
+  int threads_ = 1;
+  size_t chunk_ = (size_t)64 << 20;
   std::vector<uint8_t> buf_;
   std::string err_;
 };

@@ -198,8 +198,27 @@ int TInputFiles::start() {  // tmerge.cpp:287-329
     fclose(f);
   }
   cursor_.assign(freaders.size(), 0);
+  // inflate + index every input concurrently (host BGZF stays on the CPU by design; files are independent)
+  {
+    std::vector<GSamReader*> rds(freaders.size(), nullptr);
+    std::atomic<size_t> nf{0};
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nt = std::min<size_t>(freaders.size(), hw ? std::min<unsigned>(hw, 64) : 4);
+    int per_file = (int)std::max<size_t>(1, (hw ? std::min<unsigned>(hw, 64) : 4) / std::max<size_t>(1, nt));
+    auto w = [&]() {
+      for (;;) {
+        size_t i = nf.fetch_add(1);
+        if (i >= freaders.size()) break;
+        rds[i] = new GSamReader(freaders[i]->fname.c_str(), SAM_QNAME | SAM_FLAG | SAM_RNAME | SAM_POS | SAM_CIGAR | SAM_AUX, nullptr, per_file);
+      }
+    };
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nt; ++t) th.emplace_back(w);
+    for (auto& x : th) x.join();
+    for (size_t i = 0; i < freaders.size(); ++i) freaders[i]->samreader = rds[i];
+  }
   for (size_t i = 0; i < freaders.size(); ++i) {
-    GSamReader* rd = new GSamReader(freaders[i]->fname.c_str(), SAM_QNAME | SAM_FLAG | SAM_RNAME | SAM_POS | SAM_CIGAR | SAM_AUX);
+    GSamReader* rd = freaders[i]->samreader;
     bool tb = addSam(rd, (int)i);
     GSamRecord* b = rd->next();
     if (b) sorted_insert(recs, new TInputRecord(b, (int)i, tb));
