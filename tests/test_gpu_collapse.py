@@ -236,3 +236,34 @@ def test_fractional_tbmerged_and_collapse_same(ctx, bam_loader):
     base.qname_hash = np.array([soa.qname_hash64(x, soa.pair_order(int(f))) for x, f in zip(names, base.flag)], np.uint64)
     _check(ctx, base, keep_secondary=True, collapse_same=True)
     _check(ctx, base, keep_secondary=True, collapse_same=True, store_frac=True)
+
+
+def test_hash_collision_reseed_path(ctx, monkeypatch):
+    """the grouping hash is only a sort accelerator: every non-head is verified against the full key, a collision makes
+    the host retry with another seed, and four colliding seeds fail loudly — never a wrong group"""
+    from tiebrush_amd import api, synth
+    # soft-clipped reads give distinct CIGARs with equal (start, end): xS..yS vs yS..xS
+    tile = synth.make_tile(3, 60000, "c3", n_loci=20)
+    monkeypatch.setenv("TBK_DEBUG_HASH_MASK", "0xFFF")      # 12 hash bits: a few colliding pairs, seed dependent
+    seen_reseed = False
+    for k in range(6):
+        t = synth.make_tile(3, 6000, "c3", n_loci=8 + k)
+        try:
+            _check(ctx, t)
+        except api.TbkError as e:
+            assert e.status == -8                          # TBK_ECOLLISION after four seeds: loud, not wrong
+            continue
+        seen_reseed |= "reseeded" in ctx.last_message()
+    monkeypatch.setenv("TBK_DEBUG_HASH_MASK", "0x3")        # 2 bits: every seed collides
+    with pytest.raises(api.TbkError) as ei:
+        ctx.collapse(tile)
+    assert ei.value.status == -8
+    monkeypatch.delenv("TBK_DEBUG_HASH_MASK")
+    _check(ctx, tile)
+
+
+def test_1024_files(ctx):
+    """config-5 shape: 1024 input files (16-bit file index, 2048 YD lists)"""
+    from tiebrush_amd import synth
+    tile = synth.make_tile(1024, 600, "c5", n_loci=150)
+    _check(ctx, tile, strategy="exon", max_nh=5, min_qual=1)

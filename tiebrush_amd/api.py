@@ -136,6 +136,9 @@ class Context:
         if dev and not self._on_torch_stream:
             _torch().cuda.current_stream().synchronize()
 
+    def last_message(self) -> str:
+        return (self.L.tbk_last_error(self.h) or b"").decode()
+
     def stream_ptr(self):
         return self.L.tbk_get_stream(self.h)
 

@@ -23,6 +23,8 @@
 // reference comparator (n_cigar, memcmp, ...).  The YD list machine is sequential per
 // (sample,strand) list; it is cut at provable renewal points (read start beyond every earlier end
 // of that list, or a chromosome change) into independent chains, one GPU thread each.
+#include <stdlib.h>
+
 #include "dev_common.cuh"
 #include "scan_op.cuh"
 #include "tbk_internal.h"
@@ -51,6 +53,7 @@ struct ColOpt {
   int max_nh, min_qual;
   int keep_supp, keep_sec, collapse_same, store_frac;
   uint64_t seed;
+  uint32_t hash_mask;  // 0xFFFFFFFF in production; TBK_DEBUG_HASH_MASK narrows it to provoke collisions in tests
 };
 
 __device__ __forceinline__ uint32_t strand_code(uint8_t s) { return s == '+' ? 0u : (s == '-' ? 1u : 2u); }
@@ -287,7 +290,7 @@ __global__ void col_keys_k(ColIn I, ColOpt O, uint64_t* __restrict__ khi, uint64
   }
   // hi = tid+1 : 31 | start : 31 | strand code : 2   lo = span : 32 | h32   (tid+1 and start are < 2^31 in BAM)
   khi[i] = ((uint64_t)(uint32_t)(I.tid[i] + 1) << 33) | ((uint64_t)(uint32_t)start << 2) | strand_code(I.strand[i]);
-  klo[i] = ((uint64_t)span << 32) | (h >> 32);
+  klo[i] = ((uint64_t)span << 32) | ((h >> 32) & O.hash_mask);
   kend[i] = end;
   kflags[i] = (pass ? 1u : 0u) | (i == I.file_off[f] ? 2u : 0u);
   fidx[i] = (uint16_t)f;
@@ -1053,6 +1056,8 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
   O.keep_sec = o->keep_secondary;
   O.collapse_same = o->collapse_same;
   O.store_frac = o->store_frac;
+  O.hash_mask = 0xFFFFFFFFu;
+  if (const char* e = getenv("TBK_DEBUG_HASH_MASK")) O.hash_mask = (uint32_t)strtoul(e, nullptr, 0);
 
   uint64_t* khi = ws_alloc<uint64_t>(ctx, n);
   uint64_t* klo = ws_alloc<uint64_t>(ctx, n);
@@ -1110,6 +1115,11 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
     if (eb) return tbk_derr_to_status(ctx, eb);
     ng = (uint32_t)ctx->h_scalars[1];
     sb = s2;
+    if (attempt > 0) {
+      char b[96];
+      snprintf(b, sizeof(b), "info: key-hash collision, reseeded %d time(s)", attempt);
+      ctx->last_error = b;
+    }
     break;
   }
   out->n_groups = ng;
