@@ -267,3 +267,25 @@ def test_1024_files(ctx):
     from tiebrush_amd import synth
     tile = synth.make_tile(1024, 600, "c5", n_loci=150)
     _check(ctx, tile, strategy="exon", max_nh=5, min_qual=1)
+
+
+def test_yd_list_longer_than_a_wave(ctx):
+    """reads with 70+ tiny exons: the per-lane node list of yd_wave_k overflows (64 lanes) and the chain is handed to
+    the thread-per-chain kernel; both must reproduce the reference list machine"""
+    rng = np.random.default_rng(3)
+    files = []
+    for f in range(2):
+        recs = []
+        for i in range(40):
+            pos = 100 + 3 * i + int(rng.integers(0, 3))
+            cig = []
+            for e in range(int(rng.integers(66, 90))):
+                cig += [(int(rng.integers(2, 5)), M), (int(rng.integers(3, 9)), N)]
+            cig.append((4, M))
+            recs.append((0, pos, 0, 60, str(rng.choice(["+", "-", "."])), 1, cig))
+            if i % 3 == 0:
+                recs.append((0, pos, 0, 60, ".", 1, [(50, M)]))
+        recs.sort(key=lambda r: (r[0], r[1]))
+        files.append(recs)
+    got, want = _check(ctx, _mk(files))
+    assert want["yd"].max() > 0
