@@ -804,6 +804,8 @@ __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids
   uint32_t last_pos = 0;
   int last_dist = -1;
   bool overflow = false;
+  uint32_t S0 = 0, E0 = 0, D1 = 0xFFFFFFFFu;
+  bool mirror_ok = false;
   // batch loader: lane l holds item tb+l.  The next batch is requested before the current one is processed so that
   // its global-load latency hides behind the (long, scalar-ish) item loop.
   struct Batch {
@@ -834,65 +836,86 @@ __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids
     int it_d = 0;
     const int nb = (int)((t1 - tb) < 64u ? (t1 - tb) : 64u);
     for (int j = 0; j < nb && !overflow; ++j) {
+      // scalar mirror of the first two nodes: node 0 = [S0,E0], node 1 starts at D1 (refreshed only after list surgery)
+      if (!mirror_ok) {
+        S0 = cnt > 0 ? rl(ns, 0) : 0u;
+        E0 = cnt > 0 ? rl(ne, 0) : 0u;
+        D1 = cnt > 1 ? rl(ns, 1) : 0xFFFFFFFFu;
+        mirror_ok = true;
+      }
+      const uint32_t nex = rl(it_nex, j);
       // ---- fast path: a maximal run of single-exon items that fall inside the first island [S0,E0] and stay clear
       // of the next node (start D1).  For such an item processRead finds prev = node 0 with prev.end >= start, so
       // d = start - S0, and mergeRead only stretches node 0's end — no clearTo, no insertion, no swallow.  The run is
       // found for all remaining lanes of the batch at once with a wave prefix-max of the exon ends.
-      if (cnt >= 1) {
-        const uint32_t S0 = rl(ns, 0), E0 = rl(ne, 0);
-        const uint32_t D1 = cnt > 1 ? rl(ns, 1) : 0xFFFFFFFFu;
-        if (E0 < D1) {
-          uint32_t ev = (lane >= j && lane < nb) ? it_e0 : 0u;
-          uint32_t pm = ev;  // inclusive prefix max over lanes (DPP row shifts + row broadcasts, identity 0)
-          pm = max(pm, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x111, 0xf, 0xf, false));
-          pm = max(pm, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x112, 0xf, 0xf, false));
-          pm = max(pm, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x114, 0xf, 0xf, false));
-          pm = max(pm, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x118, 0xf, 0xf, false));
-          pm = max(pm, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x142, 0xa, 0xf, false));
-          pm = max(pm, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x143, 0xc, 0xf, false));
-          uint32_t ex = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x138, 0xf, 0xf, false);  // wave_shr:1 -> exclusive
-          uint32_t ebefore = ex > E0 ? ex : E0;
-          bool okl = lane >= j && lane < nb && it_nex == 1u && S0 < it_start && it_e0 < D1 && it_start <= ebefore;
-          uint64_t mk = __ballot(okl) >> j;
-          int r = mk == ~0ull ? 64 : __builtin_ctzll(~mk);
-          if (r > nb - j) r = nb - j;
-          if (r > 0) {
-            if (lane >= j && lane < j + r) it_d = (int)(it_start - S0);
-            uint32_t newE = rl(pm, j + r - 1);
-            if (newE < E0) newE = E0;
-            if (lane == 0) ne = newE;
-            last_pos = rl(it_start, j + r - 1);
-            last_dist = (int)(last_pos - S0);
-            j += r - 1;
-            continue;
-          }
+      if (nex == 1u && cnt >= 1 && E0 < D1) {
+        uint32_t ev = (lane >= j && lane < nb) ? it_e0 : 0u;
+        uint32_t pm = ev;  // inclusive prefix max over lanes (DPP row shifts + row broadcasts, identity 0)
+        pm = max(pm, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x111, 0xf, 0xf, false));
+        pm = max(pm, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x112, 0xf, 0xf, false));
+        pm = max(pm, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x114, 0xf, 0xf, false));
+        pm = max(pm, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x118, 0xf, 0xf, false));
+        pm = max(pm, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x142, 0xa, 0xf, false));
+        pm = max(pm, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x143, 0xc, 0xf, false));
+        uint32_t ex = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x138, 0xf, 0xf, false);  // wave_shr:1 -> exclusive
+        uint32_t ebefore = ex > E0 ? ex : E0;
+        bool okl = lane >= j && lane < nb && it_nex == 1u && S0 < it_start && it_e0 < D1 && it_start <= ebefore;
+        uint64_t mk = __ballot(okl) >> j;
+        int r = mk == ~0ull ? 64 : __builtin_ctzll(~mk);
+        if (r > nb - j) r = nb - j;
+        if (r > 0) {
+          if (lane >= j && lane < j + r) it_d = (int)(it_start - S0);
+          uint32_t newE = rl(pm, j + r - 1);
+          if (newE > E0) E0 = newE;
+          if (lane == 0) ne = E0;
+          last_pos = rl(it_start, j + r - 1);
+          last_dist = (int)(last_pos - S0);
+          j += r - 1;
+          continue;
         }
       }
       const uint32_t rstart = rl(it_start, j);
-      const uint32_t nex = rl(it_nex, j);
       const uint32_t xo = rl(it_xo, j);
       const uint32_t e0 = rl(it_e0, j);
-      const uint32_t s1 = rl(it_s1, j), e1 = rl(it_e1, j), s2 = rl(it_s2, j), e2 = rl(it_e2, j);
       int d;
-      if (last_pos == rstart) {  // processRead :225-228
+      // ---- processRead :221-250
+      if (last_pos == rstart) {
         d = last_dist;
       } else {
         d = 0;
-        uint64_t lt = __ballot(lane < cnt && ns < rstart);
-        int np = lt == ~0ull ? 64 : __builtin_ctzll(~lt);  // leading run of nodes starting before the read
-        if (np > 0) {
-          uint32_t ps = rl(ns, np - 1), pe = rl(ne, np - 1);
-          if (pe >= rstart) d = (int)(rstart - ps);
-          if (d == 0) {  // clearTo(prev): drop the first np nodes
-            ns = __shfl(ns, lane + np, 64);
-            ne = __shfl(ne, lane + np, 64);
-            cnt -= np;
+        if (cnt >= 1 && D1 >= rstart) {  // at most node 0 starts before the read: all scalar
+          if (S0 < rstart) {
+            if (E0 >= rstart) {
+              d = (int)(rstart - S0);
+            } else {  // clearTo(node 0)
+              ns = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ns, 0x130, 0xf, 0xf, false);
+              ne = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ne, 0x130, 0xf, 0xf, false);
+              cnt -= 1;
+              S0 = cnt > 0 ? rl(ns, 0) : 0u;
+              E0 = cnt > 0 ? rl(ne, 0) : 0u;
+              D1 = cnt > 1 ? rl(ns, 1) : 0xFFFFFFFFu;
+            }
+          }
+        } else if (cnt >= 1) {
+          uint64_t lt = __ballot(lane < cnt && ns < rstart);
+          int np = lt == ~0ull ? 64 : __builtin_ctzll(~lt);  // leading run of nodes starting before the read
+          if (np > 0) {
+            uint32_t ps = rl(ns, np - 1), pe = rl(ne, np - 1);
+            if (pe >= rstart) d = (int)(rstart - ps);
+            if (d == 0) {  // clearTo(prev): drop the first np nodes
+              ns = __shfl(ns, lane + np, 64);
+              ne = __shfl(ne, lane + np, 64);
+              cnt -= np;
+              S0 = cnt > 0 ? rl(ns, 0) : 0u;
+              E0 = cnt > 0 ? rl(ne, 0) : 0u;
+              D1 = cnt > 1 ? rl(ns, 1) : 0xFFFFFFFFu;
+            }
           }
         }
         last_pos = rstart;
         last_dist = d;
       }
-      // mergeRead :167-219
+      // ---- mergeRead :167-219
       if (cnt == 0) {
         if (nex > 64) {
           overflow = true;
@@ -902,57 +925,77 @@ __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids
             ne = ex_e[xo + lane];
           }
           cnt = (int)nex;
+          mirror_ok = false;
         }
       } else {
         int cur = 0;
-        for (uint32_t k = 0; k < nex; ++k) {
-          uint32_t es = k == 0 ? rstart : (k == 1 ? s1 : (k == 2 ? s2 : ex_s[xo + k]));
-          uint32_t ee = k == 0 ? e0 : (k == 1 ? e1 : (k == 2 ? e2 : ex_e[xo + k]));
-          uint64_t stop = __ballot(lane >= cur && lane < cnt && (ee < ns || es <= ne));
-          if (stop == 0) break;  // ran off the list: this exon and the rest are dropped
-          int n = __builtin_ctzll(stop);
-          uint32_t nS = rl(ns, n), nE = rl(ne, n);
-          if (ee < nS) {  // insert before n
-            if (cnt == 64) {
-              overflow = true;
-              break;
+        uint32_t k = 0;
+        // exon 0 against node 0, all scalar, when it overlaps node 0 and swallows nothing
+        if (e0 >= S0 && rstart <= E0) {
+          uint32_t newE = e0 > E0 ? e0 : E0;
+          if (newE < D1) {
+            if (rstart < S0) S0 = rstart;
+            E0 = newE;
+            if (lane == 0) {
+              ns = S0;
+              ne = E0;
             }
-            // one-lane shifts are DPP wave shifts (single VALU op) instead of ds_bpermute round trips
-            uint32_t us = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ns, 0x138, 0xf, 0xf, false);
-            uint32_t ue = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ne, 0x138, 0xf, 0xf, false);
-            if (lane > n) {
-              ns = us;
-              ne = ue;
-            } else if (lane == n) {
-              ns = es;
-              ne = ee;
-            }
-            cnt++;
-            cur = n + 1;
-          } else {  // overlap: union, then swallow followers (stops after the first one that extends the node)
-            uint32_t newS = es < nS ? es : nS;
-            uint32_t newE = ee > nE ? ee : nE;
-            while (n + 1 < cnt) {
-              uint32_t xS = rl(ns, n + 1);
-              if (xS > newE) break;
-              uint32_t xE = rl(ne, n + 1);
-              uint32_t ds = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ns, 0x130, 0xf, 0xf, false);
-              uint32_t de = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ne, 0x130, 0xf, 0xf, false);
-              if (lane > n) {
-                ns = ds;
-                ne = de;
-              }
-              cnt--;
-              if (xE > newE) {
-                newE = xE;
+            k = 1;
+          }
+        }
+        if (k < nex) {
+          const uint32_t s1 = rl(it_s1, j), e1 = rl(it_e1, j), s2 = rl(it_s2, j), e2 = rl(it_e2, j);
+          for (; k < nex; ++k) {
+            uint32_t es = k == 0 ? rstart : (k == 1 ? s1 : (k == 2 ? s2 : ex_s[xo + k]));
+            uint32_t ee = k == 0 ? e0 : (k == 1 ? e1 : (k == 2 ? e2 : ex_e[xo + k]));
+            uint64_t stop = __ballot(lane >= cur && lane < cnt && (ee < ns || es <= ne));
+            if (stop == 0) break;  // ran off the list: this exon and the rest are dropped
+            int n = __builtin_ctzll(stop);
+            if (n < 2) mirror_ok = false;
+            uint32_t nS = rl(ns, n), nE = rl(ne, n);
+            if (ee < nS) {  // insert before n
+              if (cnt == 64) {
+                overflow = true;
                 break;
               }
+              // one-lane shifts are DPP wave shifts (single VALU op) instead of ds_bpermute round trips
+              uint32_t us = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ns, 0x138, 0xf, 0xf, false);
+              uint32_t ue = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ne, 0x138, 0xf, 0xf, false);
+              if (lane > n) {
+                ns = us;
+                ne = ue;
+              } else if (lane == n) {
+                ns = es;
+                ne = ee;
+              }
+              cnt++;
+              cur = n + 1;
+            } else {  // overlap: union, then swallow followers (stops after the first one that extends the node)
+              uint32_t newS = es < nS ? es : nS;
+              uint32_t newE = ee > nE ? ee : nE;
+              while (n + 1 < cnt) {
+                uint32_t xS = rl(ns, n + 1);
+                if (xS > newE) break;
+                uint32_t xE = rl(ne, n + 1);
+                uint32_t ds = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ns, 0x130, 0xf, 0xf, false);
+                uint32_t de = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ne, 0x130, 0xf, 0xf, false);
+                if (lane > n) {
+                  ns = ds;
+                  ne = de;
+                }
+                cnt--;
+                if (n + 1 < 2) mirror_ok = false;
+                if (xE > newE) {
+                  newE = xE;
+                  break;
+                }
+              }
+              if (lane == n) {
+                ns = newS;
+                ne = newE;
+              }
+              cur = n;
             }
-            if (lane == n) {
-              ns = newS;
-              ne = newE;
-            }
-            cur = n;
           }
         }
       }
