@@ -61,6 +61,7 @@ def main():
     ctx = api.Context(local_rank)
     dtile = api.to_device(tile, dev)
     opts = ctx.make_opts(**strat)
+    opts_defer = ctx.make_opts(defer_yd=True, **strat)   # YD list machine overlaps the (YD-independent) tiecov chain
     cbufs, vbufs = {}, {}
 
     class StitchCompute:
@@ -91,9 +92,10 @@ def main():
             r = tdist.run_distributed(stitch, dtile, rank * args.files_per_gpu, device=dev, want_coverage=True,
                                       device_chain=True, **strat)
             return ({"n_passed": r.n_passed_local, "n_groups": r.n_groups}, r.coverage)
-        g = ctx.collapse(dtile, opts=opts, want_coords=True, out=cbufs, raw=True)
+        g = ctx.collapse(dtile, opts=opts_defer, want_coords=True, out=cbufs, raw=True)
         view = ctx.groups_to_cov_in(g)
         c = ctx.coverage(view, out=vbufs, raw=True)
+        ctx.finish_yd()                                   # every output of the step, YD included, is final here
         return g, c
 
     for _ in range(args.warmup):

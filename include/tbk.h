@@ -75,7 +75,10 @@ typedef struct tbk_collapse_opts {
   uint8_t keep_unmapped;      /* -M, must be 0                     */
   uint8_t collapse_same;      /* -A: needs qname_hash                                 */
   uint8_t store_frac;         /* --store-frac: YC += 1/NH                             */
-  uint8_t reserved[3];
+  uint8_t defer_yd;           /* TBK_MEM_DEVICE only: return as soon as rep/yc/yx/coordinates are final and compute
+                                 the YD column on a side stream; tbk_collapse_finish_yd() completes out->yd.  Lets
+                                 the caller overlap the (YD-independent) tiecov chain with the YD list machine.   */
+  uint8_t reserved[2];
 } tbk_collapse_opts;
 
 /* One tile of decoded records, file-major: records of input file f occupy
@@ -204,6 +207,9 @@ void tbk_host_free(void* p);
 /* ---- hot path ---------------------------------------------------------------- */
 void tbk_collapse_opts_default(tbk_collapse_opts* o);
 int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa_in* in, tbk_groups_out* out);
+/* Waits for a deferred YD stage (no-op when none is pending); returns its status.  The arrays of the deferred call's
+ * tbk_soa_in / tbk_groups_out must stay alive until then.  Implied by the next tbk_collapse_tile and by tbk_destroy. */
+int tbk_collapse_finish_yd(tbk_ctx* ctx);
 int tbk_coverage_tile(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out);
 int tbk_sample_tile(tbk_ctx* ctx, const tbk_cov_in* in, int32_t num_samples, tbk_sample_out* out);
 

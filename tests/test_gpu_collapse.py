@@ -289,3 +289,29 @@ def test_yd_list_longer_than_a_wave(ctx):
         files.append(recs)
     got, want = _check(ctx, _mk(files))
     assert want["yd"].max() > 0
+
+
+def test_deferred_yd_overlaps_tiecov_chain(ctx):
+    """defer_yd: rep/yc/yx are final at return, the YD column is completed by finish_yd() while the caller already runs
+    the tiecov chain; results identical to the inline path and to the oracle"""
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import api, synth
+    tile = synth.make_tile(4, 50000, "c2", n_loci=400)
+    want = orc.collapse(tile)
+    cw = orc.coverage(synth.collapsed_to_cov_input(tile, want))
+    dt = api.to_device(tile, "cuda:0")
+    for rep in range(3):                                   # first call learns the arena size (inline), later ones defer
+        res = ctx.collapse(dt, defer_yd=True)
+        cov = api.to_numpy(ctx.coverage(ctx.groups_to_cov_in(res)))
+        ctx.finish_yd()
+        got = api.to_numpy(res)
+        for k in ("rep", "yc", "yx", "yd", "g_start", "g_end"):
+            assert np.array_equal(got[k], want[k]), (k, rep)
+        for k in ("iv_tid", "iv_start", "iv_end", "iv_val", "j_start", "j_end", "j_val"):
+            assert np.array_equal(cov[k], cw[k]), (k, rep)
+    # a new collapse implies finish_yd of the previous one
+    r1 = ctx.collapse(dt, defer_yd=True)
+    r2 = api.to_numpy(ctx.collapse(dt))
+    assert np.array_equal(r2["yd"], want["yd"])
+    with pytest.raises(api.TbkError):
+        ctx.collapse(tile, defer_yd=True)                  # host-pointer mode cannot defer

@@ -21,14 +21,14 @@ STATUS = {0: "TBK_OK", -1: "TBK_EINVAL", -2: "TBK_ENOMEM", -3: "TBK_EHIP", -4: "
 # every symbol include/tbk.h declares
 SYMBOLS = ["tbk_abi_version", "tbk_create", "tbk_destroy", "tbk_strerror", "tbk_last_error", "tbk_set_stream",
            "tbk_get_stream", "tbk_set_profiling", "tbk_kernel_times", "tbk_host_alloc", "tbk_host_free",
-           "tbk_collapse_opts_default", "tbk_collapse_tile", "tbk_coverage_tile", "tbk_sample_tile",
+           "tbk_collapse_opts_default", "tbk_collapse_tile", "tbk_collapse_finish_yd", "tbk_coverage_tile", "tbk_sample_tile",
            "tbk_groups_to_cov_in", "tbk_pack_partials"]
 
 
 class CollapseOpts(C.Structure):
     _fields_ = [("strategy", C.c_int32), ("max_nh", C.c_int32), ("min_qual", C.c_int32), ("flags_mask", C.c_uint32),
                 ("keep_supplementary", C.c_uint8), ("keep_secondary", C.c_uint8), ("keep_unmapped", C.c_uint8),
-                ("collapse_same", C.c_uint8), ("store_frac", C.c_uint8), ("reserved", C.c_uint8 * 3)]
+                ("collapse_same", C.c_uint8), ("store_frac", C.c_uint8), ("defer_yd", C.c_uint8), ("reserved", C.c_uint8 * 2)]
 
 
 class SoaIn(C.Structure):
@@ -104,6 +104,7 @@ def load():
     L.tbk_collapse_opts_default.argtypes = [C.POINTER(CollapseOpts)]
     L.tbk_collapse_opts_default.restype = None
     L.tbk_collapse_tile.argtypes = [_P, C.POINTER(CollapseOpts), C.POINTER(SoaIn), C.POINTER(GroupsOut)]
+    L.tbk_collapse_finish_yd.argtypes = [_P]
     L.tbk_coverage_tile.argtypes = [_P, C.POINTER(CovIn), C.POINTER(CovOut)]
     L.tbk_sample_tile.argtypes = [_P, C.POINTER(CovIn), C.c_int32, C.POINTER(SampleOut)]
     L.tbk_groups_to_cov_in.argtypes = [_P, C.POINTER(SoaIn), C.POINTER(GroupsOut), C.POINTER(CovIn)]

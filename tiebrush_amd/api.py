@@ -167,14 +167,20 @@ class Context:
 
     # ---- collapse -----------------------------------------------------------------------------
     def make_opts(self, strategy="cigar", max_nh=2**31 - 1, min_qual=-1, keep_supplementary=False,
-                  keep_secondary=False, keep_unmapped=False, collapse_same=False, store_frac=False, flags_mask=0):
+                  keep_secondary=False, keep_unmapped=False, collapse_same=False, store_frac=False, flags_mask=0,
+                  defer_yd=False):
         o = _lib.CollapseOpts()
         self.L.tbk_collapse_opts_default(C.byref(o))
         o.strategy = _lib.STRAT[strategy] if isinstance(strategy, str) else int(strategy)
         o.max_nh, o.min_qual, o.flags_mask = int(max_nh), int(min_qual), int(flags_mask)
         o.keep_supplementary, o.keep_secondary = int(keep_supplementary), int(keep_secondary)
         o.keep_unmapped, o.collapse_same, o.store_frac = int(keep_unmapped), int(collapse_same), int(store_frac)
+        o.defer_yd = int(defer_yd)
         return o
+
+    def finish_yd(self):
+        """Wait for a deferred YD stage (collapse(..., defer_yd=True)); the `yd` array is complete afterwards."""
+        self._check(self.L.tbk_collapse_finish_yd(self.h), "tbk_collapse_finish_yd")
 
     def _soa_struct(self, tile: SoATile, keep):
         dev = _is_torch(tile.tid)

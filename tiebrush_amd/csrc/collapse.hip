@@ -1007,9 +1007,19 @@ __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids
 }
 
 // ---- outputs ---------------------------------------------------------------------------------------------
-__global__ void col_write_k(uint32_t ng, const uint32_t* __restrict__ gperm, GroupAcc G, const int32_t* __restrict__ g_yd,
+__global__ void col_write_yd_k(uint32_t ng, const uint32_t* __restrict__ gperm, GroupAcc G, const int32_t* __restrict__ g_yd,
+                               uint32_t cap, int32_t* __restrict__ yd) {
+  uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= ng || o >= cap) return;
+  int dmax = (int)G.ydin[gperm[o]];  // int dmax=spd.maxYD (tiebrush.cpp:511)
+  int d2 = g_yd[o];
+  if (d2 > dmax) dmax = d2;
+  yd[o] = dmax > 0 ? dmax : 0;
+}
+
+__global__ void col_write_k(uint32_t ng, const uint32_t* __restrict__ gperm, GroupAcc G,
                             const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo, uint32_t cap,
-                            uint32_t* __restrict__ rep, double* __restrict__ yc, int64_t* __restrict__ yx, int32_t* __restrict__ yd,
+                            uint32_t* __restrict__ rep, double* __restrict__ yc, int64_t* __restrict__ yx,
                             int32_t* __restrict__ g_start, int32_t* __restrict__ g_end, const int32_t* __restrict__ effend,
                             int32_t* __restrict__ rep_effend) {
   uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1019,10 +1029,6 @@ __global__ void col_write_k(uint32_t ng, const uint32_t* __restrict__ gperm, Gro
   if (rep_effend) rep_effend[o] = effend[rep[o]];
   yc[o] = G.yc[sg];
   yx[o] = (int64_t)G.yxin[sg] + (int64_t)G.ns[sg];
-  int dmax = (int)G.ydin[sg];  // int dmax=spd.maxYD (tiebrush.cpp:511)
-  int d2 = g_yd ? g_yd[o] : 0;
-  if (d2 > dmax) dmax = d2;
-  yd[o] = dmax > 0 ? dmax : 0;
   uint32_t q = G.first[sg];
   int32_t st = (int32_t)(uint32_t)((shi[q] >> 2) & 0x7FFFFFFFull);
   if (g_start) g_start[o] = st;
@@ -1045,7 +1051,114 @@ __global__ void col_init_groups_k(uint32_t ng, GroupAcc G, int32_t* __restrict__
   g_yd[g] = 0;
 }
 
+struct YdJob {  // everything the YD stage needs from the main stage (device pointers stay valid until it has run)
+  ColIn I;
+  uint32_t m, ng, cap;
+  const uint32_t* val;
+  const uint8_t* flags;
+  const uint16_t* fidx;
+  const uint32_t *sgid, *ginv, *gperm;
+  GroupAcc G;
+  const uint64_t *shi, *slo;
+  int32_t* g_yd;
+  int32_t* out_yd;
+};
+
 }  // namespace
+
+// The YD stage (tiebrush.cpp:511-524 for every flushed group) — runs on `ctx`'s stream / arena / scalars, which may be
+// the calling context (inline) or the context's private side context on a helper thread (deferred, overlapping the
+// caller's next calls such as the tiecov chain, which does not depend on YD).
+int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
+  const YdJob J = *(const YdJob*)jobp;
+  delete (YdJob*)jobp;
+  const uint32_t B = 256;
+  const uint32_t m = J.m, ng = J.ng;
+  const ColIn& I = J.I;
+  uint64_t* sc = ctx->d_scalars;
+  TBK_HIP(hipSetDevice(ctx->device));
+  TBK_HIP(hipMemsetAsync(sc, 0, 32 * sizeof(uint64_t), ctx->stream));
+  TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
+  {
+    uint32_t* icnt = ws_alloc<uint32_t>(ctx, m);
+    uint32_t* ioff = ws_alloc<uint32_t>(ctx, m);
+    if (!ioff) return TBK_ENOMEM;
+    TBK_LAUNCH(ctx, "yd_count", yd_count_k, cdiv(m, B), B, 0, I, m, J.val, J.flags, J.fidx, icnt);
+    TBK_TRY(tbk_exscan_u32(ctx, icnt, ioff, m, sc + 2));
+    TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    TBK_HIP(hipStreamSynchronize(ctx->stream));
+    const uint64_t nit64 = ctx->h_scalars[2];
+    if (nit64 >= (1ull << 32)) return TBK_E2BIG;
+    const uint32_t nit = (uint32_t)nit64;
+    if (nit) {
+      SortBufs ib;
+      ib.hi = ws_alloc<uint64_t>(ctx, nit);
+      ib.lo = ws_alloc<uint64_t>(ctx, nit);
+      ib.val = ws_alloc<uint32_t>(ctx, nit);
+      ib.hi2 = ws_alloc<uint64_t>(ctx, nit);
+      ib.lo2 = ws_alloc<uint64_t>(ctx, nit);
+      ib.val2 = ws_alloc<uint32_t>(ctx, nit);
+      YdItems Y;
+      Y.tidp1 = ws_alloc<uint32_t>(ctx, nit);
+      Y.start = ws_alloc<int32_t>(ctx, nit);
+      Y.end = ws_alloc<int32_t>(ctx, nit);
+      Y.rep = ws_alloc<uint32_t>(ctx, nit);
+      Y.nex = ws_alloc<uint32_t>(ctx, nit);
+      Y.chead = ws_alloc<uint32_t>(ctx, nit);
+      uint32_t* cex = ws_alloc<uint32_t>(ctx, nit);
+      uint32_t* noff = ws_alloc<uint32_t>(ctx, nit);
+      uint32_t* chain_first = ws_alloc<uint32_t>(ctx, nit);
+      if (!chain_first) return TBK_ENOMEM;
+      TBK_LAUNCH(ctx, "yd_fill", yd_fill_k, cdiv(m, B), B, 0, I, m, J.val, J.flags, J.fidx, J.sgid, J.ginv, ioff, ib.hi, ib.lo, ib.val);
+      TBK_TRY(tbk_radix_sort128(ctx, &ib, nit));
+      TBK_LAUNCH(ctx, "yd_coords", yd_coords_k, cdiv(nit, B), B, 0, I, nit, ib.val, J.gperm, J.G, J.shi, J.slo, Y);
+      {
+        YdLoad ld{ib.hi, Y};
+        YdStore st{ld};
+        SegMaxY ident{INT32_MIN, 0u};
+        TBK_TRY((scan_op_run<SegMaxY, SegMaxYOp, YdLoad, YdStore>(ctx, "yd_chain_scan", nit, ld, st, SegMaxYOp{}, ident)));
+      }
+      TBK_TRY(tbk_exscan_u32(ctx, Y.chead, cex, nit, sc + 3));
+      TBK_TRY(tbk_exscan_u32(ctx, Y.nex, noff, nit, sc + 4));
+      TBK_LAUNCH(ctx, "yd_chain_first", yd_chain_first_k, cdiv(nit, B), B, 0, nit, Y.chead, cex, chain_first);
+      TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+      TBK_HIP(hipStreamSynchronize(ctx->stream));
+      const uint32_t nchains = (uint32_t)ctx->h_scalars[3];
+      const uint64_t nnodes = ctx->h_scalars[4];
+      if (nnodes >= (1ull << 31)) return TBK_E2BIG;
+      SegNodes N;
+      N.s = ws_alloc<uint32_t>(ctx, nnodes + 1);
+      N.e = ws_alloc<uint32_t>(ctx, nnodes + 1);
+      N.nx = ws_alloc<int32_t>(ctx, nnodes + 1);
+      uint32_t* ex_s = ws_alloc<uint32_t>(ctx, nnodes + 1);
+      uint32_t* ex_e = ws_alloc<uint32_t>(ctx, nnodes + 1);
+      uint32_t* ids_short = ws_alloc<uint32_t>(ctx, nchains);
+      uint32_t* ids_long = ws_alloc<uint32_t>(ctx, nchains);
+      uint32_t* ids_over = ws_alloc<uint32_t>(ctx, nchains);
+      uint32_t* ccnt = (uint32_t*)(sc + 24);  // [0] short, [1] long, [2] overflow
+      if (!ids_over) return TBK_ENOMEM;
+      TBK_LAUNCH(ctx, "yd_exons", yd_exons_k, cdiv(nit, B), B, 0, I, nit, Y, noff, ex_s, ex_e);
+      TBK_LAUNCH(ctx, "yd_classify", yd_classify_k, cdiv(nchains, B), B, 0, nchains, nit, chain_first, ids_short, ids_long, ccnt);
+      TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 24, ccnt, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+      TBK_HIP(hipStreamSynchronize(ctx->stream));
+      const uint32_t* hc = (const uint32_t*)(ctx->h_scalars + 24);
+      const uint32_t n_short = hc[0], n_long = hc[1];
+      if (n_long) {
+        TBK_LAUNCH(ctx, "yd_wave", yd_wave_k, n_long, 64, 0, ids_long, ccnt + 1, nchains, nit, chain_first, Y, ib.val, noff, ex_s,
+                   ex_e, J.g_yd, ids_over, ccnt + 2);
+        // chains whose list outgrew a wave (count only known on the device: launch for the upper bound)
+        TBK_LAUNCH(ctx, "yd_run_overflow", yd_run_k, cdiv(n_long, 64), 64, 0, ids_over, ccnt + 2, nchains, nit, chain_first, Y, ib.val,
+                   noff, ex_s, ex_e, N, J.g_yd);
+      }
+      if (n_short)
+        TBK_LAUNCH(ctx, "yd_run", yd_run_k, cdiv(n_short, 64), 64, 0, ids_short, ccnt, nchains, nit, chain_first, Y, ib.val, noff, ex_s,
+                   ex_e, N, J.g_yd);
+    }
+  }
+  TBK_LAUNCH(ctx, "col_write_yd", col_write_yd_k, cdiv(ng, B), B, 0, ng, J.gperm, J.G, J.g_yd, J.cap, J.out_yd);
+  TBK_HIP(hipStreamSynchronize(ctx->stream));
+  return tbk_check_launch(ctx, "collapse_yd");
+}
 
 // =============================================================================================================
 int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_in* in, tbk_groups_out* out) {
@@ -1187,14 +1300,8 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
   TBK_LAUNCH(ctx, "col_tie_sort", col_tie_sort_k, cdiv(ng, B), B, 0, I, O.strategy, ng, sb.val, G, gperm);
   TBK_LAUNCH(ctx, "col_ginv", col_ginv_k, cdiv(ng, B), B, 0, ng, gperm, ginv);
 
-  // ---- YD ----
+  // ---- ordered YC when a fractional term can occur ----
   {
-    uint32_t* icnt = ws_alloc<uint32_t>(ctx, m);
-    uint32_t* ioff = ws_alloc<uint32_t>(ctx, m);
-    if (!ioff) return TBK_ENOMEM;
-    TBK_LAUNCH(ctx, "yd_count", yd_count_k, cdiv(m, B), B, 0, I, m, sb.val, flags, fidx, icnt);
-    TBK_TRY(tbk_exscan_u32(ctx, icnt, ioff, m, sc + 2));
-    TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     uint32_t eb = 0;
     TBK_TRY(tbk_sync_err(ctx, &eb));
     const bool need_ordered = O.store_frac || (eb & TBK_DERR_FRACTIONAL);
@@ -1215,82 +1322,35 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
       TBK_TRY(tbk_radix_sort128(ctx, &ob, m));
       TBK_LAUNCH(ctx, "ord_sum", ord_sum_k, cdiv(ng, 64), 64, 0, I, O, ng, m, ob.val, fidx, fh_by_rec, G);
     }
-    const uint64_t nit64 = ctx->h_scalars[2];
-    if (nit64 >= (1ull << 32)) return TBK_E2BIG;
-    const uint32_t nit = (uint32_t)nit64;
-    if (nit) {
-      SortBufs ib;
-      ib.hi = ws_alloc<uint64_t>(ctx, nit);
-      ib.lo = ws_alloc<uint64_t>(ctx, nit);
-      ib.val = ws_alloc<uint32_t>(ctx, nit);
-      ib.hi2 = ws_alloc<uint64_t>(ctx, nit);
-      ib.lo2 = ws_alloc<uint64_t>(ctx, nit);
-      ib.val2 = ws_alloc<uint32_t>(ctx, nit);
-      YdItems Y;
-      Y.tidp1 = ws_alloc<uint32_t>(ctx, nit);
-      Y.start = ws_alloc<int32_t>(ctx, nit);
-      Y.end = ws_alloc<int32_t>(ctx, nit);
-      Y.rep = ws_alloc<uint32_t>(ctx, nit);
-      Y.nex = ws_alloc<uint32_t>(ctx, nit);
-      Y.chead = ws_alloc<uint32_t>(ctx, nit);
-      uint32_t* cex = ws_alloc<uint32_t>(ctx, nit);
-      uint32_t* noff = ws_alloc<uint32_t>(ctx, nit);
-      uint32_t* chain_first = ws_alloc<uint32_t>(ctx, nit);
-      if (!chain_first) return TBK_ENOMEM;
-      TBK_LAUNCH(ctx, "yd_fill", yd_fill_k, cdiv(m, B), B, 0, I, m, sb.val, flags, fidx, sgid, ginv, ioff, ib.hi, ib.lo, ib.val);
-      TBK_TRY(tbk_radix_sort128(ctx, &ib, nit));
-      TBK_LAUNCH(ctx, "yd_coords", yd_coords_k, cdiv(nit, B), B, 0, I, nit, ib.val, gperm, G, sb.hi, sb.lo, Y);
-      {
-        YdLoad ld{ib.hi, Y};
-        YdStore st{ld};
-        SegMaxY ident{INT32_MIN, 0u};
-        TBK_TRY((scan_op_run<SegMaxY, SegMaxYOp, YdLoad, YdStore>(ctx, "yd_chain_scan", nit, ld, st, SegMaxYOp{}, ident)));
-      }
-      TBK_TRY(tbk_exscan_u32(ctx, Y.chead, cex, nit, sc + 3));
-      TBK_TRY(tbk_exscan_u32(ctx, Y.nex, noff, nit, sc + 4));
-      TBK_LAUNCH(ctx, "yd_chain_first", yd_chain_first_k, cdiv(nit, B), B, 0, nit, Y.chead, cex, chain_first);
-      TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-      TBK_HIP(hipStreamSynchronize(ctx->stream));
-      const uint32_t nchains = (uint32_t)ctx->h_scalars[3];
-      const uint64_t nnodes = ctx->h_scalars[4];
-      if (nnodes >= (1ull << 31)) return TBK_E2BIG;
-      SegNodes N;
-      N.s = ws_alloc<uint32_t>(ctx, nnodes + 1);
-      N.e = ws_alloc<uint32_t>(ctx, nnodes + 1);
-      N.nx = ws_alloc<int32_t>(ctx, nnodes + 1);
-      uint32_t* ex_s = ws_alloc<uint32_t>(ctx, nnodes + 1);
-      uint32_t* ex_e = ws_alloc<uint32_t>(ctx, nnodes + 1);
-      uint32_t* ids_short = ws_alloc<uint32_t>(ctx, nchains);
-      uint32_t* ids_long = ws_alloc<uint32_t>(ctx, nchains);
-      uint32_t* ids_over = ws_alloc<uint32_t>(ctx, nchains);
-      uint32_t* ccnt = (uint32_t*)(sc + 24);  // [0] short, [1] long, [2] overflow
-      if (!ids_over) return TBK_ENOMEM;
-      TBK_HIP(hipMemsetAsync(ccnt, 0, 4 * sizeof(uint32_t), ctx->stream));
-      TBK_LAUNCH(ctx, "yd_exons", yd_exons_k, cdiv(nit, B), B, 0, I, nit, Y, noff, ex_s, ex_e);
-      TBK_LAUNCH(ctx, "yd_classify", yd_classify_k, cdiv(nchains, B), B, 0, nchains, nit, chain_first, ids_short, ids_long, ccnt);
-      TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 24, ccnt, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-      TBK_HIP(hipStreamSynchronize(ctx->stream));
-      const uint32_t* hc = (const uint32_t*)(ctx->h_scalars + 24);
-      const uint32_t n_short = hc[0], n_long = hc[1];
-      if (n_long) {
-        TBK_LAUNCH(ctx, "yd_wave", yd_wave_k, n_long, 64, 0, ids_long, ccnt + 1, nchains, nit, chain_first, Y, ib.val, noff, ex_s,
-                   ex_e, g_yd, ids_over, ccnt + 2);
-        // chains whose list outgrew a wave (count only known on the device: launch for the upper bound)
-        TBK_LAUNCH(ctx, "yd_run_overflow", yd_run_k, cdiv(n_long, 64), 64, 0, ids_over, ccnt + 2, nchains, nit, chain_first, Y, ib.val,
-                   noff, ex_s, ex_e, N, g_yd);
-      }
-      if (n_short)
-        TBK_LAUNCH(ctx, "yd_run", yd_run_k, cdiv(n_short, 64), 64, 0, ids_short, ccnt, nchains, nit, chain_first, Y, ib.val, noff, ex_s,
-                   ex_e, N, g_yd);
-    }
   }
-  TBK_LAUNCH(ctx, "col_write", col_write_k, cdiv(ng, B), B, 0, ng, gperm, G, g_yd, sb.hi, sb.lo, out->cap_groups, out->rep, out->yc,
-             out->yx, out->yd, out->g_start, out->g_end, effend, out->rep_effend);
+  TBK_LAUNCH(ctx, "col_write", col_write_k, cdiv(ng, B), B, 0, ng, gperm, G, sb.hi, sb.lo, out->cap_groups, out->rep, out->yc, out->yx,
+             out->g_start, out->g_end, effend, out->rep_effend);
   if (out->rec_group) TBK_LAUNCH(ctx, "col_recgroup", col_recgroup_k, cdiv(m, B), B, 0, m, sb.val, sgid, ginv, out->rec_group);
-  uint32_t eb = 0;
-  TBK_TRY(tbk_sync_err(ctx, &eb));
-  if (eb & ~TBK_DERR_FRACTIONAL) return tbk_derr_to_status(ctx, eb);
-  return tbk_check_launch(ctx, "collapse");
+  {
+    uint32_t eb = 0;
+    TBK_TRY(tbk_sync_err(ctx, &eb));
+    if (eb & ~TBK_DERR_FRACTIONAL) return tbk_derr_to_status(ctx, eb);
+  }
+  TBK_TRY(tbk_check_launch(ctx, "collapse"));
+  // ---- YD stage: handed to the caller (tbk_api) as a job — run inline or deferred on the side context ----
+  YdJob* job = new YdJob();
+  job->I = I;
+  job->m = m;
+  job->ng = ng;
+  job->cap = out->cap_groups;
+  job->val = sb.val;
+  job->flags = flags;
+  job->fidx = fidx;
+  job->sgid = sgid;
+  job->ginv = ginv;
+  job->gperm = gperm;
+  job->G = G;
+  job->shi = sb.hi;
+  job->slo = sb.lo;
+  job->g_yd = g_yd;
+  job->out_yd = out->yd;
+  ctx->yd_job = job;
+  return 0;
 }
 
 // ---- tiebrush -> tiecov device chain -----------------------------------------------------------------------

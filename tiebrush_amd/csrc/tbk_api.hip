@@ -12,6 +12,15 @@
 // call, so a steady-state loop performs no allocation at all.
 static int ws_begin_call(tbk_ctx* ctx, size_t hint) {
   size_t want = std::max(ctx->ws_cap, hint);
+  if (ctx->yd_thread) {
+    // a deferred YD stage still reads arrays in [0, ws_base_off): never move the arena now; this call bump-allocates
+    // behind the pinned prefix and spills into overflow chunks if it must
+    for (auto& c : ctx->ws_overflow) (void)hipFree(c.first);
+    ctx->ws_overflow.clear();
+    ctx->ws_off = ctx->ws_base_off;
+    ctx->ws_over_used = 0;
+    return 0;
+  }
   if (!ctx->ws_overflow.empty()) {
     size_t tot = ctx->ws_cap;
     for (auto& c : ctx->ws_overflow) {
@@ -28,7 +37,7 @@ static int ws_begin_call(tbk_ctx* ctx, size_t hint) {
     TBK_HIP(hipMalloc((void**)&ctx->ws, want));
     ctx->ws_cap = want;
   }
-  ctx->ws_off = 0;
+  ctx->ws_off = ctx->ws_base_off;
   ctx->ws_over_used = 0;
   return 0;
 }
@@ -152,6 +161,29 @@ static int d2h(tbk_ctx* ctx, T* host, const T* dev, size_t n) {
   return 0;
 }
 
+// ---- deferred YD stage -------------------------------------------------------------------------------
+static int yd_stage_on(tbk_ctx* run_on, void* job, size_t hint) {
+  if (hipSetDevice(run_on->device) != hipSuccess) return TBK_EHIP;
+  prof_begin_call(run_on);
+  int rc = ws_begin_call(run_on, hint);
+  if (rc == 0) rc = tbk_collapse_yd_run(run_on, job);
+  prof_end_call(run_on);
+  return rc;
+}
+
+static int finish_yd(tbk_ctx* ctx) {
+  if (!ctx->yd_thread) return 0;
+  ctx->yd_thread->join();
+  delete ctx->yd_thread;
+  ctx->yd_thread = nullptr;
+  ctx->ws_base_off = 0;
+  if (ctx->yd_ctx) {
+    for (auto& t : ctx->yd_ctx->last_times) ctx->last_times.push_back(t);
+    if (ctx->yd_rc != 0) ctx->last_error = ctx->yd_ctx->last_error;
+  }
+  return ctx->yd_rc;
+}
+
 // ---- C ABI -----------------------------------------------------------------------------------------
 extern "C" {
 
@@ -197,8 +229,18 @@ int tbk_create(int device_ordinal, tbk_ctx** out) {
   return 0;
 }
 
+int tbk_collapse_finish_yd(tbk_ctx* ctx) {
+  if (!ctx) return TBK_EINVAL;
+  return finish_yd(ctx);
+}
+
 void tbk_destroy(tbk_ctx* ctx) {
   if (!ctx) return;
+  (void)finish_yd(ctx);
+  if (ctx->yd_ctx) {
+    tbk_destroy(ctx->yd_ctx);
+    ctx->yd_ctx = nullptr;
+  }
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto& c : ctx->ws_overflow) (void)hipFree(c.first);
@@ -325,13 +367,32 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
     for (uint32_t f = 0; f < in->n_files; ++f) any_tb |= in->tbmerged[f] != 0;
   if (any_tb && (!in->yc_in || !in->yx_in || !in->yd_in)) return TBK_EINVAL;
   if (in->mem != out->mem) return TBK_EINVAL;
+  if (opts->defer_yd && in->mem != TBK_MEM_DEVICE) return TBK_EINVAL;
+  TBK_TRY(finish_yd(ctx));  // a still-pending YD stage of the previous tile owns part of the arena
   TBK_HIP(hipSetDevice(ctx->device));
   prof_begin_call(ctx);
   size_t hint = (size_t)in->n_records * 160 + (size_t)in->n_cigar_ops * 8 + ((size_t)8 << 20);
   TBK_TRY(ws_begin_call(ctx, hint));
   int rc;
+  ctx->yd_job = nullptr;
+  const size_t yd_hint = (size_t)in->n_records * 96 + ((size_t)8 << 20);
   if (in->mem == TBK_MEM_DEVICE) {
     rc = tbk_collapse_device(ctx, opts, in, out);
+    if (rc == 0 && ctx->yd_job) {
+      void* job = ctx->yd_job;
+      ctx->yd_job = nullptr;
+      bool defer = opts->defer_yd && ctx->ws_overflow.empty();  // arena must be in steady state to pin a prefix of it
+      if (defer && !ctx->yd_ctx && tbk_create(ctx->device, &ctx->yd_ctx) != 0) defer = false;
+      if (defer) {
+        ctx->yd_ctx->profiling = ctx->profiling;
+        ctx->ws_base_off = (ctx->ws_off + 255) & ~(size_t)255;
+        ctx->yd_rc = 0;
+        tbk_ctx* side = ctx->yd_ctx;
+        ctx->yd_thread = new std::thread([ctx, side, job, yd_hint]() { ctx->yd_rc = yd_stage_on(side, job, yd_hint); });
+      } else {
+        rc = tbk_collapse_yd_run(ctx, job);
+      }
+    }
   } else {
     tbk_soa_in din = *in;
     tbk_groups_out dout = *out;
@@ -364,6 +425,11 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
     TBK_TRY(dalloc(ctx, out->rec_group, n, &dout.rec_group));
     TBK_TRY(dalloc(ctx, out->rep_effend, cap, &dout.rep_effend));
     rc = tbk_collapse_device(ctx, opts, &din, &dout);
+    if (rc == 0 && ctx->yd_job) {
+      void* job = ctx->yd_job;
+      ctx->yd_job = nullptr;
+      rc = tbk_collapse_yd_run(ctx, job);
+    }
     out->n_groups = dout.n_groups;
     out->n_passed = dout.n_passed;
     if (rc == 0) {

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -57,6 +58,12 @@ struct tbk_ctx {
   std::vector<tbk_kernel_time> last_times;
   std::string last_error;
   int num_cu = 256;
+  // deferred YD stage (tbk_collapse_opts.defer_yd): a private side context + helper thread
+  void* yd_job = nullptr;        // prepared by tbk_collapse_device, consumed by tbk_collapse_yd_run
+  tbk_ctx* yd_ctx = nullptr;
+  std::thread* yd_thread = nullptr;
+  int yd_rc = 0;
+  size_t ws_base_off = 0;        // arena bytes pinned while a deferred YD stage still reads the main stage's arrays
 };
 
 #define TBK_HIP(call)                                                                            \
@@ -129,5 +136,6 @@ size_t tbk_radix_ws_bytes(uint32_t n);
 
 // ---- pipelines --------------------------------------------------------------------
 int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_in* in, tbk_groups_out* out);
+int tbk_collapse_yd_run(tbk_ctx* run_on, void* job);  // consumes ctx->yd_job (prepared by tbk_collapse_device)
 int tbk_coverage_device(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out);
 int tbk_sample_device(tbk_ctx* ctx, const tbk_cov_in* in, int32_t num_samples, tbk_sample_out* out);
