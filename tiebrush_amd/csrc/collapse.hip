@@ -549,15 +549,16 @@ __global__ void yd_count_k(ColIn I, uint32_t m, const uint32_t* __restrict__ val
 }
 __global__ void yd_fill_k(ColIn I, uint32_t m, const uint32_t* __restrict__ val, const uint8_t* __restrict__ flags,
                           const uint16_t* __restrict__ fidx, const uint32_t* __restrict__ sgid, const uint32_t* __restrict__ ginv,
-                          const uint32_t* __restrict__ off, uint64_t* __restrict__ hi, uint64_t* __restrict__ lo,
-                          uint32_t* __restrict__ v) {
+                          const uint32_t* __restrict__ off, const uint32_t* __restrict__ ooff, GroupAcc G, uint64_t* __restrict__ hi,
+                          uint64_t* __restrict__ lo, uint32_t* __restrict__ v) {
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= m) return;
   uint32_t gi = val[q];
   uint32_t f = fidx[gi];
   if (!(flags[q] & 4u) || I.tbm[f]) return;
-  uint32_t o = ginv[sgid[q]];
-  uint32_t p = off[q];
+  uint32_t sg = sgid[q];
+  uint32_t o = ginv[sg];
+  uint32_t p = ooff[o] + (off[q] - off[G.first[sg]]);  // position in output order
   uint8_t s = I.strand[gi];
   if (s != '-') {  // '+' or '.': fsegs[f]
     hi[p] = (uint64_t)f * 2;
@@ -570,6 +571,18 @@ __global__ void yd_fill_k(ColIn I, uint32_t m, const uint32_t* __restrict__ val,
     lo[p] = o;
     v[p] = o;
   }
+}
+
+// items are generated directly in OUTPUT order (group o, then file order inside the group): the later sort then only
+// has to split them by list id (stable), not order them by group
+__global__ void yd_gcount_k(uint32_t ng, uint32_t m, const uint32_t* __restrict__ gperm, GroupAcc G, const uint32_t* __restrict__ ioff,
+                            const uint32_t* __restrict__ icnt, uint32_t* __restrict__ ocnt) {
+  uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= ng) return;
+  uint32_t sg = gperm[o];
+  uint32_t q0 = G.first[sg];
+  uint32_t end = (sg + 1 < ng) ? ioff[G.first[sg + 1]] : (ioff[m - 1] + icnt[m - 1]);
+  ocnt[o] = end - ioff[q0];
 }
 
 struct YdItems {
@@ -1109,8 +1122,14 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       uint32_t* noff = ws_alloc<uint32_t>(ctx, nit);
       uint32_t* chain_first = ws_alloc<uint32_t>(ctx, nit);
       if (!chain_first) return TBK_ENOMEM;
-      TBK_LAUNCH(ctx, "yd_fill", yd_fill_k, cdiv(m, B), B, 0, I, m, J.val, J.flags, J.fidx, J.sgid, J.ginv, ioff, ib.hi, ib.lo, ib.val);
-      TBK_TRY(tbk_radix_sort128(ctx, &ib, nit));
+      uint32_t* ocnt = ws_alloc<uint32_t>(ctx, ng);
+      uint32_t* ooff = ws_alloc<uint32_t>(ctx, ng);
+      if (!ooff) return TBK_ENOMEM;
+      TBK_LAUNCH(ctx, "yd_gcount", yd_gcount_k, cdiv(ng, B), B, 0, ng, m, J.gperm, J.G, ioff, icnt, ocnt);
+      TBK_TRY(tbk_exscan_u32(ctx, ocnt, ooff, ng, nullptr));
+      TBK_LAUNCH(ctx, "yd_fill", yd_fill_k, cdiv(m, B), B, 0, I, m, J.val, J.flags, J.fidx, J.sgid, J.ginv, ioff, ooff, J.G, ib.hi, ib.lo,
+                 ib.val);
+      TBK_TRY(tbk_radix_sort128(ctx, &ib, nit, ~0ull, 0ull));  // stable split by list id; group order is already in place
       TBK_LAUNCH(ctx, "yd_coords", yd_coords_k, cdiv(nit, B), B, 0, I, nit, ib.val, J.gperm, J.G, J.shi, J.slo, Y);
       {
         YdLoad ld{ib.hi, Y};

@@ -316,7 +316,7 @@ size_t tbk_radix_ws_bytes(uint32_t n) {
   return (size_t)256 * ntiles * 4 + 256 * 4 + 4096;
 }
 
-int tbk_radix_sort128(tbk_ctx* ctx, SortBufs* b, uint32_t n) {
+int tbk_radix_sort128(tbk_ctx* ctx, SortBufs* b, uint32_t n, uint64_t only_hi, uint64_t only_lo) {
   if (n < 2) return 0;
   uint64_t* d_andor = ctx->d_scalars + 32;
   uint64_t init[4] = {~0ull, 0ull, ~0ull, 0ull};
@@ -327,8 +327,8 @@ int tbk_radix_sort128(tbk_ctx* ctx, SortBufs* b, uint32_t n) {
   TBK_LAUNCH(ctx, "rx_bits", rx_bits_k, g, 256, 0, b->hi, b->lo, n, d_andor);
   TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 32, d_andor, sizeof(init), hipMemcpyDeviceToHost, ctx->stream));
   TBK_HIP(hipStreamSynchronize(ctx->stream));
-  uint64_t vary_hi = ctx->h_scalars[32] ^ ctx->h_scalars[33];
-  uint64_t vary_lo = ctx->h_scalars[34] ^ ctx->h_scalars[35];
+  uint64_t vary_hi = (ctx->h_scalars[32] ^ ctx->h_scalars[33]) & only_hi;
+  uint64_t vary_lo = (ctx->h_scalars[34] ^ ctx->h_scalars[35]) & only_lo;
   const uint32_t iter = rx_iter_for(n);
   uint32_t ntiles = cdiv(n, RX_SUB * iter);
   uint32_t* table = ws_alloc<uint32_t>(ctx, (size_t)256 * ntiles);

@@ -131,7 +131,8 @@ struct SortBufs {
   uint64_t *hi2, *lo2;
   uint32_t* val2;
 };
-int tbk_radix_sort128(tbk_ctx* ctx, SortBufs* b, uint32_t n);
+// only_hi / only_lo: bits that take part in the ordering (the rest are payload that must not reorder equal keys)
+int tbk_radix_sort128(tbk_ctx* ctx, SortBufs* b, uint32_t n, uint64_t only_hi = ~0ull, uint64_t only_lo = ~0ull);
 size_t tbk_radix_ws_bytes(uint32_t n);
 
 // ---- pipelines --------------------------------------------------------------------
