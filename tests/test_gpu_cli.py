@@ -138,3 +138,26 @@ def test_cli_on_synthetic_bams_matches_oracle(tmp_path, profile, flags, okw):
                                          for i in range(cw["n_junctions"])]
     assert read_lines(pre + ".bedgraph") == want_cov
     assert read_lines(pre + ".bed") == want_j
+
+
+def test_cli_tiling_by_reference_is_exact(tmp_path):
+    """TBK_TILE_RECORDS forces one tile per reference sequence: byte-identical output BAM to the single-tile run"""
+    from tiebrush_amd import bamio
+    a, b = str(tmp_path / "one.bam"), str(tmp_path / "tiled.bam")
+    _run([os.path.join(BIN, "tiebrush"), "-o", a] + sample_paths("t2"))
+    env = dict(os.environ, TBK_TILE_RECORDS="1000")
+    r = subprocess.run([os.path.join(BIN, "tiebrush"), "-o", b] + sample_paths("t2"), check=True, capture_output=True, text=True, env=env)
+    assert "242910 input records written as 8179" in r.stderr
+    ra, rb = bamio.bgzf_decompress(open(a, "rb").read()), bamio.bgzf_decompress(open(b, "rb").read())
+    ha, pa = bamio.parse_header(ra)
+    hb, pb = bamio.parse_header(rb)
+    assert ra[pa:] == rb[pb:]
+    # several references with reads: synthetic 3-contig input, tiny tiles
+    from tiebrush_amd import synth
+    tile = synth.make_tile(3, 3000, "c2", n_loci=40)
+    paths = synth.write_bams(tile, str(tmp_path / "syn"))
+    c, d = str(tmp_path / "c.bam"), str(tmp_path / "d.bam")
+    _run([os.path.join(BIN, "tiebrush"), "-o", c] + paths)
+    subprocess.run([os.path.join(BIN, "tiebrush"), "-o", d] + paths, check=True, capture_output=True, env=dict(os.environ, TBK_TILE_RECORDS="1"))
+    rc_, rd_ = bamio.bgzf_decompress(open(c, "rb").read()), bamio.bgzf_decompress(open(d, "rb").read())
+    assert rc_[bamio.parse_header(rc_)[1]:] == rd_[bamio.parse_header(rd_)[1]:]

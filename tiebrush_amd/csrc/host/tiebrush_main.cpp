@@ -105,44 +105,54 @@ int main(int argc, char* argv[]) {
   int nthreads = (int)std::thread::hardware_concurrency();
   if (nthreads < 1) nthreads = 1;
   if (nthreads > 32) nthreads = 32;
-  TbkTile tile;
-  inRecords.load_tile(tile, opt.strategy == TBK_STRAT_FULL, opt.collapse_same != 0, nthreads);
-  tbk_soa_in in = tile.view();
-  size_t n = tile.n();
-  std::vector<uint32_t> rep(n ? n : 1);
-  std::vector<double> yc(n ? n : 1);
-  std::vector<int64_t> yx(n ? n : 1);
-  std::vector<int32_t> yd(n ? n : 1);
-  tbk_groups_out out;
-  memset(&out, 0, sizeof(out));
-  out.mem = TBK_MEM_HOST;
-  out.cap_groups = (uint32_t)(n ? n : 1);
-  out.rep = rep.data();
-  out.yc = yc.data();
-  out.yx = yx.data();
-  out.yd = yd.data();
-  rc = tbk_collapse_tile(ctx, &opt, &in, &out);
-  if (rc == TBK_EUNSORTED) GError("Error: an input file is not coordinate-sorted!\n");
-  if (rc != 0) GError("Error: GPU collapse failed: %s (%s)\n", tbk_strerror(rc), tbk_last_error(ctx));
-
+  // one tile per run of whole reference sequences (exact: nothing the collapse computes crosses a refID, see tmerge.h)
+  size_t tile_records = getenv("TBK_TILE_RECORDS") ? (size_t)atoll(getenv("TBK_TILE_RECORDS")) : ((size_t)256 << 20);
+  std::vector<TInputFiles::TilePlan> plans = inRecords.plan_tiles(tile_records);
+  uint64_t inCounter = 0, outCounter = 0;
   {
     GSamWriter outfile(outfname, inRecords.header(), GSamFile_BAM);
+    TbkTile tile;
+    std::vector<uint32_t> rep;
+    std::vector<double> yc;
+    std::vector<int64_t> yx;
+    std::vector<int32_t> yd;
     tbh::BamRec r;
-    for (uint32_t g = 0; g < out.n_groups; ++g) {  // flushPData tagging, tiebrush.cpp:506-525
-      tbh::RecView v = inRecords.record(rep[g]);
-      r.d.assign(v.p, v.p + v.len);
-      r.update_float("YC", (float)yc[g]);
-      r.update_int("YX", yx[g]);
-      if (yd[g] > 0)
-        r.update_int("YD", yd[g]);
-      else
-        r.del("YD");
-      outfile.write_raw(r);
+    for (const auto& plan : plans) {
+      inRecords.load_tile(tile, opt.strategy == TBK_STRAT_FULL, opt.collapse_same != 0, nthreads, &plan);
+      tbk_soa_in in = tile.view();
+      size_t n = tile.n();
+      rep.resize(n ? n : 1);
+      yc.resize(n ? n : 1);
+      yx.resize(n ? n : 1);
+      yd.resize(n ? n : 1);
+      tbk_groups_out out;
+      memset(&out, 0, sizeof(out));
+      out.mem = TBK_MEM_HOST;
+      out.cap_groups = (uint32_t)(n ? n : 1);
+      out.rep = rep.data();
+      out.yc = yc.data();
+      out.yx = yx.data();
+      out.yd = yd.data();
+      rc = tbk_collapse_tile(ctx, &opt, &in, &out);
+      if (rc == TBK_EUNSORTED) GError("Error: an input file is not coordinate-sorted!\n");
+      if (rc != 0) GError("Error: GPU collapse failed: %s (%s)\n", tbk_strerror(rc), tbk_last_error(ctx));
+      for (uint32_t g = 0; g < out.n_groups; ++g) {  // flushPData tagging, tiebrush.cpp:506-525
+        tbh::RecView v = inRecords.record(rep[g]);
+        r.d.assign(v.p, v.p + v.len);
+        r.update_float("YC", (float)yc[g]);
+        r.update_int("YX", yx[g]);
+        if (yd[g] > 0)
+          r.update_int("YD", yd[g]);
+        else
+          r.del("YD");
+        outfile.write_raw(r);
+      }
+      inCounter += out.n_passed;
+      outCounter += out.n_groups;
     }
   }
   inRecords.stop();
   tbk_destroy(ctx);
-  uint64_t inCounter = out.n_passed, outCounter = out.n_groups;
   double p = 100.00 - (double)(outCounter * 100.00) / (double)inCounter;
   GMessage("%ld input records written as %ld (%.2f%% reduction)\n", (long)inCounter, (long)outCounter, p);
   return 0;

@@ -244,23 +244,83 @@ void TInputFiles::stop() {
 
 tbh::RecView TInputFiles::record(uint32_t gi) const {
   size_t f = (size_t)(std::upper_bound(tile_off_.begin(), tile_off_.end(), gi) - tile_off_.begin()) - 1;
-  return freaders[f]->samreader->file()->rec(gi - tile_off_[f]);
+  return freaders[f]->samreader->file()->rec(tile_lo_[f] + (gi - tile_off_[f]));
 }
 
-void TInputFiles::load_tile(TbkTile& t, bool want_md, bool want_qh, int threads) {
+std::vector<TInputFiles::TilePlan> TInputFiles::plan_tiles(size_t max_records) {
   size_t k = freaders.size();
+  int32_t nt = mHdr ? mHdr->n_targets : 0;
+  // first[f][t] = index of the first record of file f whose refID is >= t (unmapped-without-position records, refID -1,
+  // sort last in a coordinate-sorted BAM and belong to no tile: the GPU build always drops them, tiebrush.cpp:535)
+  std::vector<std::vector<size_t>> first(k, std::vector<size_t>((size_t)nt + 1, 0));
+  for (size_t f = 0; f < k; ++f) {
+    tbh::BamFile* bf = freaders[f]->samreader->file();
+    int32_t cur = 0;
+    int64_t prev = -1;
+    size_t n = bf->n();
+    for (size_t i = 0; i < n; ++i) {
+      int32_t tid = bf->rec(i).tid();
+      int64_t eff = tid < 0 ? (int64_t)nt : (int64_t)tid;
+      if (eff < prev) GError("Error: %s file not coordinate-sorted!\n", freaders[f]->fname.c_str());
+      prev = eff;
+      while (cur < nt && (int64_t)cur < eff) first[f][(size_t)++cur] = i;
+      if (eff >= nt) {
+        while (cur < nt) first[f][(size_t)++cur] = i;
+        // everything from here on is refID -1
+        for (size_t j = i; j < n; ++j)
+          if (bf->rec(j).tid() >= 0) GError("Error: %s file not coordinate-sorted!\n", freaders[f]->fname.c_str());
+        break;
+      }
+    }
+    while (cur < nt) first[f][(size_t)++cur] = n;
+  }
+  std::vector<TilePlan> plans;
+  int32_t t0 = 0;
+  while (t0 < nt) {
+    size_t tot = 0;
+    int32_t t1 = t0;
+    while (t1 < nt) {
+      size_t add = 0;
+      for (size_t f = 0; f < k; ++f) add += first[f][(size_t)t1 + 1] - first[f][(size_t)t1];
+      if (t1 > t0 && tot + add > max_records) break;
+      tot += add;
+      ++t1;
+    }
+    if (tot > 0) {
+      TilePlan p;
+      p.tid_lo = t0;
+      p.tid_hi = t1;
+      p.n = tot;
+      for (size_t f = 0; f < k; ++f) {
+        p.lo.push_back(first[f][(size_t)t0]);
+        p.hi.push_back(first[f][(size_t)t1]);
+      }
+      plans.push_back(p);
+    }
+    t0 = t1;
+  }
+  return plans;
+}
+
+void TInputFiles::load_tile(TbkTile& t, bool want_md, bool want_qh, int threads, const TilePlan* plan) {
+  size_t k = freaders.size();
+  t = TbkTile();
   t.file_off.assign(k + 1, 0);
   t.tbmerged.assign(k, 0);
   std::vector<uint64_t> cig_base(k + 1, 0), md_base(k + 1, 0);
+  std::vector<size_t> lo(k, 0), hi(k, 0);
   bool any_tb = false;
   for (size_t f = 0; f < k; ++f) {
     tbh::BamFile* bf = freaders[f]->samreader->file();
-    if ((uint64_t)t.file_off[f] + bf->n() >= (1ull << 32)) GError("Error: more than 2^32 records in one tile\n");
-    t.file_off[f + 1] = t.file_off[f] + (uint32_t)bf->n();
+    lo[f] = plan ? plan->lo[f] : 0;
+    hi[f] = plan ? plan->hi[f] : bf->n();
+    if ((uint64_t)t.file_off[f] + (hi[f] - lo[f]) >= (1ull << 32)) GError("Error: more than 2^32 records in one tile\n");
+    t.file_off[f + 1] = t.file_off[f] + (uint32_t)(hi[f] - lo[f]);
     t.tbmerged[f] = freaders[f]->tbMerged ? 1 : 0;
     any_tb |= freaders[f]->tbMerged;
   }
   tile_off_ = t.file_off;
+  tile_lo_ = lo;
   size_t n = t.file_off[k];
   // pass 1: CIGAR / MD sizes per file
   std::vector<uint64_t> ncig(k, 0), nmd(k, 0);
@@ -272,7 +332,7 @@ void TInputFiles::load_tile(TbkTile& t, bool want_md, bool want_qh, int threads)
         if (f >= k) break;
         tbh::BamFile* bf = freaders[f]->samreader->file();
         uint64_t c = 0, m = 0;
-        for (size_t i = 0; i < bf->n(); ++i) {
+        for (size_t i = lo[f]; i < hi[f]; ++i) {
           tbh::RecView v = bf->rec(i);
           c += v.n_cigar();
           if (want_md) {
@@ -324,7 +384,7 @@ void TInputFiles::load_tile(TbkTile& t, bool want_md, bool want_qh, int threads)
       uint64_t co = cig_base[f], mo = md_base[f];
       size_t g = t.file_off[f];
       bool tb = t.tbmerged[f] != 0;
-      for (size_t i = 0; i < bf->n(); ++i, ++g) {
+      for (size_t i = lo[f]; i < hi[f]; ++i, ++g) {
         tbh::RecView v = bf->rec(i);
         t.tid[g] = v.tid();
         t.pos[g] = v.pos();

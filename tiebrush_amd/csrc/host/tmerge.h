@@ -68,10 +68,20 @@ struct TInputFiles {
   int start();            // opens every input, merges headers, primes next()
   TInputRecord* next();   // valid until the following next() (tmerge.cpp:331-344)
   void stop();
-  // accelerated path: decode every file into one SoA tile (multi-threaded aux scan)
-  void load_tile(TbkTile& t, bool want_md, bool want_qname_hash, int threads);
+  // accelerated path.  Everything the collapse does is confined to one reference sequence (buckets, groups and tiecov
+  // bundles never span a tid; the YD lists are reset at every tid change, tiebrush.cpp:586-589), so the input can be cut
+  // into tiles of whole reference sequences without changing a single output byte.  plan_tiles() groups consecutive tids
+  // up to `max_records` per tile; load_tile() decodes one tile into SoA form (multi-threaded aux scan).
+  struct TilePlan {
+    int32_t tid_lo = 0, tid_hi = 0;  // [tid_lo, tid_hi)
+    std::vector<size_t> lo, hi;      // per input file: record range
+    size_t n = 0;
+  };
+  std::vector<TilePlan> plan_tiles(size_t max_records);
+  void load_tile(TbkTile& t, bool want_md, bool want_qname_hash, int threads, const TilePlan* plan = nullptr);
   tbh::RecView record(uint32_t global_index) const;  // raw record behind tile index i
   std::vector<uint32_t> tile_off_;                   // file_off of the last load_tile()
+  std::vector<size_t> tile_lo_;                      // first record of each file inside the last tile
 };
 
 uint64_t tbh_qname_hash(const char* name, int pair_order);
