@@ -79,6 +79,9 @@ def main():
         def pack_partials(self, loc, first_fidx, cig_cap):
             return ctx.pack_partials(loc, first_fidx, cig_cap, out=self.bufs.setdefault("p", {}))
 
+        def finish_yd(self):
+            ctx.finish_yd()
+
         def coverage(self, view):
             return ctx.coverage(view, out=self.bufs.setdefault("v", {}), raw=True)
 

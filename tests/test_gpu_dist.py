@@ -65,6 +65,9 @@ class DeviceCompute:
     def pack_partials(self, loc, first_fidx, cig_cap):
         return self.ctx.pack_partials(loc, first_fidx, cig_cap)
 
+    def finish_yd(self):
+        self.ctx.finish_yd()
+
     def coverage(self, view):
         from tiebrush_amd import api
         return api.to_numpy(self.ctx.coverage(view))

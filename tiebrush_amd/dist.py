@@ -192,11 +192,16 @@ def shard_collapse(compute, local_tile: SoATile, first_fidx: int, rank: int, wor
     if filters.get("store_frac") or filters.get("collapse_same"):
         raise ValueError("--store-frac and -A need a global second pass: single-GPU only (DESIGN.md §7)")
     X = _xp(local_tile.tid)
-    loc = compute.collapse(local_tile, strategy=strategy, want_coords=True, want_effend=True, **filters)
+    # on the device the local YD list machine is deferred: it overlaps the exchange, the stitch and tiecov, and its column
+    # follows the partial rows in a second, small all-to-all (YD of a final group = max over its partials)
+    defer = _is_t(local_tile.tid) and hasattr(compute, "finish_yd") and hasattr(compute, "pack_partials")
+    loc = compute.collapse(local_tile, strategy=strategy, want_coords=True, want_effend=True,
+                           **(dict(defer_yd=True) if defer else {}), **filters)
     ng = int(loc["n_groups"])
-    tidp1 = None
     if _is_t(local_tile.tid) and hasattr(compute, "pack_partials"):
         P, cig, emax = compute.pack_partials(loc, first_fidx, int(local_tile.cig.numel()))     # HIP: pack + running max
+        if defer:
+            P[:, 4] = 0                             # the YD column is not final yet
     else:
         P, cig = _pack_generic(X, local_tile, loc, first_fidx)
         emax = X.cummax(((P[:, 0] + 1) << 32) | X.to_i64(loc["g_end"]))
@@ -257,7 +262,8 @@ def shard_collapse(compute, local_tile: SoATile, first_fidx: int, rank: int, wor
         nh=X.as_dtype(X.full(n2, -(2**31), like=rP), "i32"), cig_off=X.as_dtype(cig_off2, "u32"), cig=rcig,
         yc_in=col(8).view(_torch().float64) if _is_t(rP) else col(8).view(np.float64), yx_in=col(3), yd_in=col(4),
         prio_hi=col(5) if _is_t(rP) else col(5).view(np.uint64), prio_lo=col(6) if _is_t(rP) else col(6).view(np.uint64))
-    fin = compute.collapse(tile2, strategy=strategy, want_coords=True, keep_supplementary=True, keep_secondary=True)
+    fin = compute.collapse(tile2, strategy=strategy, want_coords=True, keep_supplementary=True, keep_secondary=True,
+                           want_rec_group=defer)
     g2 = int(fin["n_groups"])
     rep2 = X.u32_to_i64(fin["rep"])
     plo = rP[:, 6][rep2]
@@ -277,6 +283,13 @@ def shard_collapse(compute, local_tile: SoATile, first_fidx: int, rank: int, wor
         nj = yield ("all_gather", X.scalar(int(cov["n_junctions"]), like=key))
         res.coverage = cov
         res.junction_offset = int(X.host(nj).reshape(-1)[:rank].sum())
+    if defer:
+        compute.finish_yd()                                     # local YD column is final now
+        ryd, _ = yield ("all_to_all", (X.to_i64(loc["yd"]).contiguous(), cnt))
+        yd = _torch().zeros(max(g2, 1), dtype=_torch().int64, device=ryd.device)
+        if n2:
+            yd.scatter_reduce_(0, fin["rec_group"].to(_torch().int64), ryd, reduce="amax", include_self=True)
+        res.yd = yd[:g2].to(_torch().int32)
     return res
 
 
@@ -291,13 +304,24 @@ def run_loopback(compute, tiles, first_fidx, **kw):
         assert all(res is None for res in results) and len({q[0] for q in reqs}) == 1, "ranks diverged"
         kind = reqs[0][0]
         pay = [q[1] for q in reqs]
-        X = _xp(pay[0][0] if kind == "exchange" else pay[0])
+        X = _xp(pay[0][0] if kind in ("exchange", "all_to_all") else pay[0])
         if kind == "all_gather":
             out = [X.stack(pay)] * world
         elif kind == "all_reduce_max":
             out = [X.stack(pay).max(0) if X is _NP else X.stack(pay).max(0).values] * world
         elif kind == "all_reduce_min":
             out = [X.stack(pay).min(0) if X is _NP else X.stack(pay).min(0).values] * world
+        elif kind == "all_to_all":
+            out = []
+            for d in range(world):
+                parts, cnts = [], []
+                for s_ in range(world):
+                    data, cnt = pay[s_]
+                    ch = np.asarray(X.host(cnt), np.int64)
+                    o = int(ch[:d].sum())
+                    parts.append(data[o:o + int(ch[d])])
+                    cnts.append(int(ch[d]))
+                out.append((X.cat(parts), np.array(cnts, np.int64)))
         elif kind == "exchange":
             out = []
             for d in range(world):
@@ -361,6 +385,16 @@ def run_distributed(compute, tile, first_fidx, device=None, group=None, **kw):
                 x = t(pay).clone()
                 dist.all_reduce(x, op=dist.ReduceOp.MAX if kind.endswith("max") else dist.ReduceOp.MIN, group=group)
                 res = back(x, pay)
+            elif kind == "all_to_all":
+                data, cnt = pay
+                c = t(cnt).contiguous()
+                rc = torch.empty_like(c)
+                dist.all_to_all_single(rc, c, group=group)
+                sc_h, rc_h = c.cpu().numpy().astype(np.int64), rc.cpu().numpy().astype(np.int64)
+                x = t(data).contiguous()
+                out = torch.empty((int(rc_h.sum()),) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+                dist.all_to_all_single(out, x, output_split_sizes=rc_h.tolist(), input_split_sizes=sc_h.tolist(), group=group)
+                res = (back(out, data), rc_h)
             elif kind == "exchange":
                 P, cnt, cig, ccnt = pay
                 c = torch.stack([t(cnt), t(ccnt)], dim=1).contiguous()     # [world, 2]: rows and CIGAR words per destination

@@ -18,6 +18,8 @@ class C:
     def pack_partials(s, loc, ff, cap):
         torch.cuda.synchronize(); t0=time.perf_counter()
         r = ctx.pack_partials(loc, ff, cap, out=s.b.setdefault("p",{})); torch.cuda.synchronize(); print("  pack %.3f ms"%((time.perf_counter()-t0)*1e3)); return r
+    def finish_yd(s):
+        ctx.finish_yd()
     def coverage(s, v):
         torch.cuda.synchronize(); t0=time.perf_counter()
         r= ctx.coverage(v, out=s.b.setdefault("v",{}), raw=True); torch.cuda.synchronize(); print("  cov %.3f ms"%((time.perf_counter()-t0)*1e3)); return r
