@@ -5,7 +5,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/tbk.h"
@@ -107,29 +109,43 @@ int main(int argc, char* argv[]) {
   std::vector<double> yc(n, 1.0);
   std::vector<int64_t> yx(n, 1);
   std::vector<uint8_t> strand(n, '.');
+  // pass 1 (serial, cheap): CIGAR offsets; pass 2 (threads): fields + one aux scan per record
   uint64_t ops = 0;
-  for (size_t i = 0; i < n; ++i) ops += bf->rec(i).n_cigar();
+  for (size_t i = 0; i < n; ++i) {
+    if (ops >= (1ull << 32)) break;
+    cig_off[i] = (uint32_t)ops;
+    ops += bf->rec(i).n_cigar();
+  }
   if (ops >= (1ull << 32) || n >= (1ull << 32)) GError("Error: input too large for one tile\n");
   cig.resize(ops);
-  uint64_t co = 0;
-  for (size_t i = 0; i < n; ++i) {
-    tbh::RecView v = bf->rec(i);
-    tid[i] = v.tid();
-    pos[i] = v.pos();
-    flag[i] = v.flag();
-    cig_off[i] = (uint32_t)co;
-    for (uint32_t c = 0; c < v.n_cigar(); ++c) cig[co + c] = v.cigar(c);
-    co += v.n_cigar();
-    const uint8_t *a = v.aux_begin(), *e = v.aux_end();
-    if (const uint8_t* s = tbh::aux_get(a, e, "YC")) yc[i] = tbh::aux2f(s);
-    if (const uint8_t* s = tbh::aux_get(a, e, "YX")) yx[i] = tbh::aux2i(s);
-    char xs = 0, ts = 0;
-    if (const uint8_t* s = tbh::aux_get(a, e, "XS")) xs = (*s == 'A' || *s == 'Z') ? (char)s[1] : 0;
-    if (!xs)
-      if (const uint8_t* s = tbh::aux_get(a, e, "ts")) ts = (*s == 'A' || *s == 'Z') ? (char)s[1] : 0;
-    char c = xs;
-    if (c == 0 && (ts == '+' || ts == '-')) c = (flag[i] & 0x10) ? (ts == '+' ? '-' : '+') : ts;
-    strand[i] = (uint8_t)((c == '+' || c == '-') ? c : '.');
+  uint64_t co = ops;
+  {
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nt = std::max<size_t>(1, std::min<size_t>(hw ? hw : 4, 32));
+    if (n < 100000) nt = 1;
+    auto work = [&](size_t lo, size_t hi) {
+      for (size_t i = lo; i < hi; ++i) {
+        tbh::RecView v = bf->rec(i);
+        tid[i] = v.tid();
+        pos[i] = v.pos();
+        flag[i] = v.flag();
+        uint32_t o = cig_off[i];
+        for (uint32_t c = 0; c < v.n_cigar(); ++c) cig[o + c] = v.cigar(c);
+        const uint8_t *a = v.aux_begin(), *e = v.aux_end();
+        if (const uint8_t* s = tbh::aux_get(a, e, "YC")) yc[i] = tbh::aux2f(s);
+        if (const uint8_t* s = tbh::aux_get(a, e, "YX")) yx[i] = tbh::aux2i(s);
+        char xs = 0, ts = 0;
+        if (const uint8_t* s = tbh::aux_get(a, e, "XS")) xs = (*s == 'A' || *s == 'Z') ? (char)s[1] : 0;
+        if (!xs)
+          if (const uint8_t* s = tbh::aux_get(a, e, "ts")) ts = (*s == 'A' || *s == 'Z') ? (char)s[1] : 0;
+        char c = xs;
+        if (c == 0 && (ts == '+' || ts == '-')) c = (flag[i] & 0x10) ? (ts == '+' ? '-' : '+') : ts;
+        strand[i] = (uint8_t)((c == '+' || c == '-') ? c : '.');
+      }
+    };
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nt; ++t) th.emplace_back(work, n * t / nt, n * (t + 1) / nt);
+    for (auto& x : th) x.join();
   }
   cig_off[n] = (uint32_t)co;
 
