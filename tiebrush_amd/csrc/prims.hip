@@ -59,23 +59,40 @@ __global__ __launch_bounds__(1024) void scan_spine_k(uint64_t* __restrict__ part
 template <class OutT>
 __global__ __launch_bounds__(SC_NT) void scan_down_k(const uint32_t* __restrict__ in, OutT* __restrict__ out,
                                                      const uint64_t* __restrict__ part, uint32_t n) {
+  // striped global access (coalesced), blocked ownership for the scan: the tile is transposed through padded LDS
   __shared__ uint64_t sm[8];
-  uint64_t base = (uint64_t)blockIdx.x * SC_TILE + (uint64_t)threadIdx.x * SC_E;
+  __shared__ uint32_t tin[SC_TILE + SC_TILE / 8];
+  __shared__ uint64_t tex[SC_TILE + SC_TILE / 8];
+  const uint64_t base = (uint64_t)blockIdx.x * SC_TILE;
+#pragma unroll
+  for (int e = 0; e < SC_E; ++e) {
+    uint32_t j = (uint32_t)e * SC_NT + threadIdx.x;
+    uint64_t i = base + j;
+    tin[j + (j >> 3)] = (i < n) ? in[i] : 0u;
+  }
+  __syncthreads();
   uint32_t v[SC_E];
   uint64_t s = 0;
 #pragma unroll
   for (int e = 0; e < SC_E; ++e) {
-    uint64_t i = base + e;
-    v[e] = (i < n) ? in[i] : 0;
+    uint32_t j = threadIdx.x * SC_E + e;
+    v[e] = tin[j + (j >> 3)];
     s += v[e];
   }
   uint64_t tot;
   uint64_t ex = block_excl_sum<uint64_t, SC_NT>(s, sm, &tot) + part[blockIdx.x];
 #pragma unroll
   for (int e = 0; e < SC_E; ++e) {
-    uint64_t i = base + e;
-    if (i < n) out[i] = (OutT)ex;
+    uint32_t j = threadIdx.x * SC_E + e;
+    tex[j + (j >> 3)] = ex;
     ex += v[e];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < SC_E; ++e) {
+    uint32_t j = (uint32_t)e * SC_NT + threadIdx.x;
+    uint64_t i = base + j;
+    if (i < n) out[i] = (OutT)tex[j + (j >> 3)];
   }
 }
 

@@ -58,16 +58,27 @@ __device__ __forceinline__ T block_incl_scan_op(T v, Op op, T* sm /*>=4*/, T* to
   return inc;
 }
 
+// Tile staging: global loads/stores are striped (lane-consecutive addresses, coalesced); the scan needs each thread to
+// own SO_E consecutive elements, so the tile goes through LDS.  One pad element per SO_E keeps the blocked accesses
+// off a single bank group (lane stride 9 elements instead of 8).
+__device__ __forceinline__ uint32_t so_pad(uint32_t j) { return j + (j >> 3); }
+constexpr int SO_LDS = SO_TILE + SO_TILE / 8;
+
 template <class T, class Op, class Load>
 __global__ __launch_bounds__(SO_NT) void so_reduce_k(uint32_t n, Load load, Op op, T ident, T* __restrict__ part) {
+  __shared__ T tile[SO_LDS];
   __shared__ T sm[SO_NT / 64];
-  uint64_t base = (uint64_t)blockIdx.x * SO_TILE + (uint64_t)threadIdx.x * SO_E;
-  T acc = ident;
+  const uint64_t base = (uint64_t)blockIdx.x * SO_TILE;
 #pragma unroll
   for (int e = 0; e < SO_E; ++e) {
-    uint64_t i = base + e;
-    if (i < n) acc = op(acc, load((uint32_t)i));
+    uint32_t j = (uint32_t)e * SO_NT + threadIdx.x;
+    uint64_t i = base + j;
+    tile[so_pad(j)] = (i < n) ? load((uint32_t)i) : ident;
   }
+  __syncthreads();
+  T acc = ident;
+#pragma unroll
+  for (int e = 0; e < SO_E; ++e) acc = op(acc, tile[so_pad(threadIdx.x * SO_E + e)]);
   T tot;
   (void)block_incl_scan_op(acc, op, sm, &tot);
   if (threadIdx.x == 0) part[blockIdx.x] = tot;
@@ -108,19 +119,26 @@ __global__ __launch_bounds__(SO_NT) void so_spine_k(T* __restrict__ part, uint32
 // store(i, inclusive, exclusive) with exclusive == op-prefix of everything before i (ident for i == 0)
 template <class T, class Op, class Load, class Store>
 __global__ __launch_bounds__(SO_NT) void so_down_k(uint32_t n, Load load, Store store, Op op, T ident, const T* __restrict__ part) {
+  __shared__ T tile[SO_LDS];
   __shared__ T sm[SO_NT / 64];
   __shared__ T wl[SO_NT / 64];
-  uint64_t base = (uint64_t)blockIdx.x * SO_TILE + (uint64_t)threadIdx.x * SO_E;
+  const uint64_t base = (uint64_t)blockIdx.x * SO_TILE;
+#pragma unroll
+  for (int e = 0; e < SO_E; ++e) {
+    uint32_t j = (uint32_t)e * SO_NT + threadIdx.x;
+    uint64_t i = base + j;
+    tile[so_pad(j)] = (i < n) ? load((uint32_t)i) : ident;
+  }
+  __syncthreads();
   T v[SO_E];
   T acc = ident;
 #pragma unroll
   for (int e = 0; e < SO_E; ++e) {
-    uint64_t i = base + e;
-    v[e] = (i < n) ? load((uint32_t)i) : ident;
+    v[e] = tile[so_pad(threadIdx.x * SO_E + e)];
     acc = op(acc, v[e]);
   }
   T tot;
-  T inc = block_incl_scan_op(acc, op, sm, &tot);
+  T inc = block_incl_scan_op(acc, op, sm, &tot);  // (contains the barriers that order the reads above before the writes below)
   T prev = shfl_up_t(inc, 1);
   if (lane_id() == 63) wl[threadIdx.x >> 6] = inc;
   __syncthreads();
@@ -133,11 +151,20 @@ __global__ __launch_bounds__(SO_NT) void so_down_k(uint32_t n, Load load, Store 
   else
     ex = op(carry, prev);
 #pragma unroll
-  for (int e = 0; e < SO_E; ++e) {
-    uint64_t i = base + e;
-    T in = op(ex, v[e]);
-    if (i < n) store((uint32_t)i, in, ex);
-    ex = in;
+  for (int e = 0; e < SO_E; ++e) {  // exclusive prefix of every element back into the tile
+    tile[so_pad(threadIdx.x * SO_E + e)] = ex;
+    ex = op(ex, v[e]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < SO_E; ++e) {  // striped again: the functor's global stores are lane-consecutive
+    uint32_t j = (uint32_t)e * SO_NT + threadIdx.x;
+    uint64_t i = base + j;
+    if (i < n) {
+      T exj = tile[so_pad(j)];
+      T vj = load((uint32_t)i);
+      store((uint32_t)i, op(exj, vj), exj);
+    }
   }
 }
 
