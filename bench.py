@@ -133,18 +133,21 @@ def main():
     if rank == 0:
         ctx.set_profiling(True)
         acc = {}
-        for _ in range(args.prof_steps):
-            gg = ctx.collapse(dtile, opts=opts, want_coords=True, out=cbufs, raw=True)
+
+        def take(stage):
             for k, (ms, ln) in ctx.kernel_times().items():
-                a = acc.setdefault(("collapse", k), [0.0, 0])
+                a = acc.setdefault((stage, k), [0.0, 0])
                 a[0] += ms
                 a[1] += ln
+
+        for _ in range(args.prof_steps):   # the same step as the timed loop (YD stage overlapping the tiecov chain)
+            gg = ctx.collapse(dtile, opts=opts_defer, want_coords=True, out=cbufs, raw=True)
+            take("collapse")
             view = ctx.groups_to_cov_in(gg)
             cc = ctx.coverage(view, out=vbufs, raw=True)
-            for k, (ms, ln) in ctx.kernel_times().items():
-                a = acc.setdefault(("coverage", k), [0.0, 0])
-                a[0] += ms
-                a[1] += ln
+            take("coverage")
+            ctx.finish_yd()
+            take("collapse")               # the deferred YD stage belongs to tbk_collapse_tile
         ctx.set_profiling(False)
         ncig_in = int(tile.cig.shape[0])
         # algorithmic bytes

@@ -178,7 +178,7 @@ static int finish_yd(tbk_ctx* ctx) {
   ctx->yd_thread = nullptr;
   ctx->ws_base_off = 0;
   if (ctx->yd_ctx) {
-    for (auto& t : ctx->yd_ctx->last_times) ctx->last_times.push_back(t);
+    ctx->last_times = ctx->yd_ctx->last_times;  // tbk_kernel_times() right after the wait = the YD stage
     if (ctx->yd_rc != 0) ctx->last_error = ctx->yd_ctx->last_error;
   }
   return ctx->yd_rc;
