@@ -10,15 +10,12 @@ from __future__ import annotations
 
 import ctypes as C
 from dataclasses import replace
-from typing import Optional
 
 import numpy as np
 
 from . import _lib
 from ._lib import TbkError
 from .soa import CovInput, SoATile
-
-_NP2T = None
 
 
 def _torch():

@@ -284,7 +284,7 @@ __global__ void col_keys_k(ColIn I, ColOpt O, uint64_t* __restrict__ khi, uint64
   if (nh > O.max_nh) pass = false;
   uint64_t h = pass ? strategy_hash(I, O, i) : 0ull;
   int64_t span = (int64_t)end - (int64_t)start + 1;
-  if (pass && (span < 0 || span >= (1ll << 30))) {
+  if (pass && (span < 0 || span >= (1ll << 30) || start < 0 || I.tid[i] < -1)) {  // key fields: tid+1 and start need 31 bits
     atomicOr(err, TBK_DERR_SPAN);
     span = 0;
   }
@@ -502,7 +502,7 @@ __global__ void col_rep_prio_k(ColIn I, uint32_t ng, uint32_t m, const uint32_t*
 }
 
 // ---- tie sets: order groups that share (bucket,strand,end) by the reference comparator -----------------
-__global__ void col_tie_k(ColIn I, int strategy, uint32_t ng, const uint32_t* __restrict__ val, GroupAcc G, uint32_t* __restrict__ gperm) {
+__global__ void col_tie_init_k(ColIn I, int strategy, uint32_t ng, const uint32_t* __restrict__ val, GroupAcc G, uint32_t* __restrict__ gperm) {
   uint32_t sg = blockIdx.x * blockDim.x + threadIdx.x;
   if (sg >= ng) return;
   gperm[sg] = sg;
@@ -1268,7 +1268,7 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
     TBK_HIP(hipMemsetAsync(sc, 0, 16 * sizeof(uint64_t), ctx->stream));
     TBK_LAUNCH(ctx, "col_keys", col_keys_k, cdiv(n, B), B, 0, I, O, khi, klo, kend, kflags, fidx, ctx->d_err);
     {
-      EffLoad ld{khi, klo ? kend : kend, kflags};
+      EffLoad ld{khi, kend, kflags};
       EffStore st{khi, klo, kflags, effend, s2.hi, s2.lo, s2.val, sc + 0, n, ctx->d_err};
       EffKey ident{0u, 0u, INT32_MIN, 0u};
       TBK_TRY((scan_op_run<EffKey, EffOp, EffLoad, EffStore>(ctx, "col_effkey_scan", n, ld, st, EffOp{}, ident)));
@@ -1315,7 +1315,7 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
   TBK_LAUNCH(ctx, "col_reduce", col_reduce_k, cdiv(m, B), B, 0, I, O, m, sb.val, flags, gex, fidx, effend, G, sgid, ctx->d_err);
   if (I.prio_hi && I.prio_lo) TBK_LAUNCH(ctx, "col_rep_prio", col_rep_prio_k, cdiv(ng, B), B, 0, I, ng, m, sb.val, G);
   if (O.collapse_same) TBK_LAUNCH(ctx, "col_same", col_same_k, cdiv(m, B), B, 0, I, O, m, sb.val, flags, sgid, fidx, G);
-  TBK_LAUNCH(ctx, "col_tie_init", col_tie_k, cdiv(ng, B), B, 0, I, O.strategy, ng, sb.val, G, gperm);
+  TBK_LAUNCH(ctx, "col_tie_init", col_tie_init_k, cdiv(ng, B), B, 0, I, O.strategy, ng, sb.val, G, gperm);
   TBK_LAUNCH(ctx, "col_tie_sort", col_tie_sort_k, cdiv(ng, B), B, 0, I, O.strategy, ng, sb.val, G, gperm);
   TBK_LAUNCH(ctx, "col_ginv", col_ginv_k, cdiv(ng, B), B, 0, ng, gperm, ginv);
 

@@ -43,11 +43,6 @@ struct tbk_ctx {
   uint32_t* d_err = nullptr;    // [1]
   uint64_t* d_scalars = nullptr; // [64] misc device scalars (counts)
   uint64_t* h_scalars = nullptr; // pinned [64+4096]
-  // pinned staging for TBK_MEM_HOST callers
-  char* h_stage = nullptr;
-  size_t h_stage_cap = 0;
-  char* d_stage = nullptr;  // device copies of host inputs / outputs
-  size_t d_stage_cap = 0, d_stage_off = 0;
   // view storage for tbk_groups_to_cov_in
   char* d_view = nullptr;
   size_t d_view_cap = 0;
