@@ -142,3 +142,143 @@ def test_fuzz_coverage(ctx, seed):
             gs = api.to_numpy(ctx.sample(cin, 7))
             for k in ("s_tid", "s_start", "s_end", "s_count", "s_heat"):
                 assert np.array_equal(gs[k], want[k]), k
+
+
+def _dense_tile(rng, n_files, per_file, span, introns):
+    """Long YD chains: dense starts on one contig, reads spliced over a small set of shared introns (so later exons land
+    inside, before, beyond or across nodes that earlier reads left), plus unspliced reads that bridge them."""
+    from tiebrush_amd import soa
+    files = []
+    for f in range(n_files):
+        recs = []
+        for _ in range(per_file):
+            pos = int(rng.integers(0, span))
+            kind = rng.random()
+            ops = []
+            if kind < 0.45:
+                ops = [(int(rng.choice([30, 50, 75, 100])), M)]
+            else:
+                cur = pos
+                nj = 0
+                left = int(rng.choice([50, 76, 100]))
+                for (a, b) in introns:
+                    if a > cur and a - cur < left and nj < int(rng.integers(1, 4)):
+                        ops.append((a - cur, M))
+                        ops.append((b - a, N))
+                        left -= a - cur
+                        cur = b
+                        nj += 1
+                ops.append((max(left, 1), M))
+            strand = "." if len(ops) == 1 and rng.random() < 0.8 else str(rng.choice(["+", "-"]))
+            recs.append((0, pos, 0, 60, strand, 1, ops))
+        recs.sort(key=lambda r: r[1])
+        files.append(recs)
+    allr = [r for f in files for r in f]
+    n = len(allr)
+    fo = np.zeros(n_files + 1, np.uint32)
+    fo[1:] = np.cumsum([len(f) for f in files])
+    cigs = [[(l << 4) | o for l, o in r[6]] for r in allr]
+    off = np.zeros(n + 1, np.uint32)
+    off[1:] = np.cumsum([len(c) for c in cigs])
+    return soa.SoATile(
+        n_files=n_files, file_off=fo, tbmerged=np.zeros(n_files, np.uint8), tid=np.zeros(n, np.int32),
+        pos=np.array([r[1] for r in allr], np.int32), flag=np.zeros(n, np.uint16), mapq=np.full(n, 60, np.uint8),
+        strand=np.array([ord(r[4]) for r in allr], np.uint8), nh=np.ones(n, np.int32), cig_off=off,
+        cig=np.array([x for c in cigs for x in c], np.uint32))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_yd_long_chains(ctx, seed):
+    """yd_wave_k (one wave per long chain): runs of list-preserving items, spliced reads landing in / beyond existing
+    nodes, insertions, swallows and island restarts, against the literal GSegList of the oracle."""
+    rng = np.random.default_rng(9000 + seed)
+    span = int(rng.choice([600, 2000, 6000]))
+    introns = []
+    a = 40
+    while a < span + 300:
+        ln = int(rng.choice([12, 25, 60, 150]))
+        introns.append((a, a + ln))
+        if rng.random() < 0.3:                      # alternative acceptor sharing the donor
+            introns.append((a, a + ln + int(rng.integers(5, 40))))
+        a += ln + int(rng.choice([20, 45, 90, 160]))
+    introns.sort()
+    tile = _dense_tile(rng, int(rng.integers(1, 4)), 4000, span, introns)
+    want = _cmp(ctx, tile, strategy="cigar")
+    assert int(np.asarray(want["yd"]).max()) > 0
+    _cmp(ctx, tile, strategy="exon")
+
+
+def _spliced_region_tile(rng, n_files, n_regions):
+    """Each region is one long chain seeded by a three-exon read (nodes A, B, C), followed by reads whose later exons
+    land inside B / C (raising their ends), start beyond C (dropped with the rest of the read), cross from B into C
+    (swallow) or open new nodes in the gaps, and then by reads that start inside the raised parts of B and C."""
+    from tiebrush_amd import soa
+    files = []
+    for f in range(n_files):
+        recs = []
+        for r in range(n_regions):
+            b = 1000 + 2000 * r
+            if r % 3 == 2:      # single-island region: spliced reads whose exon 1 starts inside what earlier reads of the
+                recs.append((b, [(31, M)]))                     # same run added to the island, or beyond it (dropped)
+                for _ in range(int(rng.integers(25, 50))):
+                    s0 = b + int(rng.integers(1, 26))
+                    if rng.random() < 0.5:
+                        ops = [(int(rng.integers(5, 90)), M)]
+                    else:
+                        d1 = b + int(rng.choice([28, 33]))
+                        a1 = b + int(rng.choice([50, 60, 75]))
+                        ops = [(d1 - s0 + 1, M), (a1 - d1 - 1, N), (int(rng.integers(3, 80)), M)]
+                    recs.append((s0, ops))
+                for _ in range(int(rng.integers(8, 20))):
+                    recs.append((b + int(rng.integers(40, 160)), [(int(rng.integers(5, 50)), M)]))
+                continue
+            recs.append((b, [(21, M), (79, N), (21, M), (79, N), (21, M)]))
+            for _ in range(int(rng.integers(25, 60))):
+                s0 = b + int(rng.integers(1, 21))
+                kind = int(rng.integers(0, 6))
+                d1 = b + int(rng.choice([20, 20, 26]))           # donor of intron 1 (exon 0 end, inclusive)
+                a1 = b + int(rng.choice([100, 100, 104, 92]))    # acceptor
+                if kind == 0 or s0 > d1:
+                    ops = [(int(rng.integers(5, 70)), M)]
+                elif kind in (1, 2):
+                    ops = [(d1 - s0 + 1, M), (a1 - d1 - 1, N), (int(rng.integers(3, 70 if kind == 1 else 130)), M)]
+                elif kind in (3, 4):
+                    d2 = b + int(rng.choice([120, 120, 127]))
+                    a2 = b + int(rng.choice([200, 200, 206, 190]))
+                    ops = [(d1 - s0 + 1, M), (a1 - d1 - 1, N), (d2 - a1 + 1, M), (a2 - d2 - 1, N), (int(rng.integers(3, 60)), M)]
+                else:
+                    ops = [(d1 - s0 + 1, M), (b + int(rng.choice([300, 240, 160])) - d1 - 1, N), (int(rng.integers(3, 40)), M)]
+                recs.append((s0, ops))
+            for _ in range(int(rng.integers(10, 30))):
+                s0 = b + int(rng.integers(95, 175))
+                if rng.random() < 0.6:
+                    ops = [(int(rng.integers(5, 60)), M)]
+                else:
+                    d2 = s0 + int(rng.integers(3, 30))
+                    a2 = max(b + int(rng.choice([200, 206, 190])), d2 + 2)
+                    ops = [(d2 - s0 + 1, M), (a2 - d2 - 1, N), (int(rng.integers(3, 60)), M)]
+                recs.append((s0, ops))
+            for _ in range(int(rng.integers(5, 20))):
+                recs.append((b + int(rng.integers(195, 290)), [(int(rng.integers(5, 60)), M)]))
+        recs.sort(key=lambda x: x[0])
+        files.append(recs)
+    allr = [r for f in files for r in f]
+    n = len(allr)
+    fo = np.zeros(n_files + 1, np.uint32)
+    fo[1:] = np.cumsum([len(f) for f in files])
+    cigs = [[(l << 4) | o for l, o in r[1]] for r in allr]
+    off = np.zeros(n + 1, np.uint32)
+    off[1:] = np.cumsum([len(c) for c in cigs])
+    return soa.SoATile(
+        n_files=n_files, file_off=fo, tbmerged=np.zeros(n_files, np.uint8), tid=np.zeros(n, np.int32),
+        pos=np.array([r[0] for r in allr], np.int32), flag=np.zeros(n, np.uint16), mapq=np.full(n, 60, np.uint8),
+        strand=np.full(n, ord("+"), np.uint8), nh=np.ones(n, np.int32), cig_off=off,
+        cig=np.array([x for c in cigs for x in c], np.uint32))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_yd_spliced_regions(ctx, seed):
+    rng = np.random.default_rng(9500 + seed)
+    tile = _spliced_region_tile(rng, int(rng.integers(1, 3)), 60)
+    want = _cmp(ctx, tile, strategy="cigar")
+    assert int(np.asarray(want["yd"]).max()) > 100          # distances measured from B / C starts far into raised ends

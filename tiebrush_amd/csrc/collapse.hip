@@ -589,27 +589,62 @@ struct YdItems {
   uint32_t* tidp1;
   int32_t* start;
   int32_t* end;
-  uint32_t* rep;
+  uint32_t* xo;   // offset of the item's exon list in the per-group exon arrays
   uint32_t* nex;
   uint32_t* chead;
 };
 
-__global__ void yd_coords_k(ColIn I, uint32_t nit, const uint32_t* __restrict__ v, const uint32_t* __restrict__ gperm, GroupAcc G,
-                            const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo, YdItems Y) {
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nit) return;
-  uint32_t sg = gperm[v[t]];
+// per output group (computed once, every item of the group reuses it): coordinates, exon count, exon list
+struct YdGroups {
+  uint32_t* tidp1;
+  int32_t* start;
+  int32_t* end;
+  uint32_t* nex;
+  uint32_t* xoff;
+};
+
+__global__ void yd_groups_k(ColIn I, uint32_t ng, const uint32_t* __restrict__ gperm, GroupAcc G, const uint64_t* __restrict__ shi,
+                            const uint64_t* __restrict__ slo, YdGroups Q) {
+  uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= ng) return;
+  uint32_t sg = gperm[o];
   uint32_t q = G.first[sg];
   uint64_t h = shi[q], l = slo[q];
   int32_t st = (int32_t)(uint32_t)((h >> 2) & 0x7FFFFFFFull);
-  Y.tidp1[t] = (uint32_t)(h >> 33);
-  Y.start[t] = st;
-  Y.end[t] = st + (int32_t)(uint32_t)(l >> 32) - 1;
+  Q.tidp1[o] = (uint32_t)(h >> 33);
+  Q.start[o] = st;
+  Q.end[o] = st + (int32_t)(uint32_t)(l >> 32) - 1;
   uint32_t r = (uint32_t)(G.rep[sg] & 0xFFFFFFFFull);
-  Y.rep[t] = r;
   int nex = 0;
   walk_exons(I.pos[r], I.cig + I.cig_off[r], I.cig_off[r + 1] - I.cig_off[r], [](int, int) {}, &nex);
-  Y.nex[t] = (uint32_t)nex;
+  Q.nex[o] = (uint32_t)nex;
+}
+
+__global__ void yd_gexons_k(ColIn I, uint32_t ng, const uint32_t* __restrict__ gperm, GroupAcc G, YdGroups Q, uint32_t* __restrict__ ex_s,
+                            uint32_t* __restrict__ ex_e) {
+  uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= ng) return;
+  uint32_t r = (uint32_t)(G.rep[gperm[o]] & 0xFFFFFFFFull);
+  uint32_t w = Q.xoff[o];
+  int nex = 0;
+  walk_exons(I.pos[r], I.cig + I.cig_off[r], I.cig_off[r + 1] - I.cig_off[r],
+             [&](int es, int ee) {
+               ex_s[w] = (uint32_t)es;
+               ex_e[w] = (uint32_t)ee;
+               ++w;
+             },
+             &nex);
+}
+
+__global__ void yd_coords_k(uint32_t nit, const uint32_t* __restrict__ v, YdGroups Q, YdItems Y) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nit) return;
+  uint32_t o = v[t];
+  Y.tidp1[t] = Q.tidp1[o];
+  Y.start[t] = Q.start[o];
+  Y.end[t] = Q.end[o];
+  Y.nex[t] = Q.nex[o];
+  Y.xo[t] = Q.xoff[o];
 }
 
 struct SegMaxY {
@@ -651,47 +686,35 @@ __global__ void yd_chain_first_k(uint32_t nit, const uint32_t* __restrict__ chea
   if (t < nit && chead[t]) chain_first[cex[t]] = t;
 }
 
-// exon list of every item, laid out at noff[t] (so a chain's exons are contiguous)
-__global__ void yd_exons_k(ColIn I, uint32_t nit, YdItems Y, const uint32_t* __restrict__ noff, uint32_t* __restrict__ ex_s,
-                           uint32_t* __restrict__ ex_e) {
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nit) return;
-  uint32_t r = Y.rep[t];
-  uint32_t o = noff[t];
-  int nex = 0;
-  walk_exons(I.pos[r], I.cig + I.cig_off[r], I.cig_off[r + 1] - I.cig_off[r],
-             [&](int es, int ee) {
-               ex_s[o] = (uint32_t)es;
-               ex_e[o] = (uint32_t)ee;
-               ++o;
-             },
-             &nex);
-}
-
 constexpr uint32_t YD_LONG = 24;  // chains at least this long get a whole wave
+constexpr int YD_FAST_NODES = 12;   // the spliced-read fast path of yd_wave_k searches at most this many nodes per lane
 
 // ids[0..] = short chains (thread each), ids2 = long chains (wave each); counts in cnt[0], cnt[1]
 __global__ void yd_classify_k(uint32_t nchains, uint32_t nit, const uint32_t* __restrict__ chain_first, uint32_t* __restrict__ ids_short,
                               uint32_t* __restrict__ ids_long, uint32_t* __restrict__ cnt) {
+  // block-aggregated append: two global atomics per 256 chains
+  __shared__ uint32_t s_cnt[2], s_base[2];
+  if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
   uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= nchains) return;  // (trailing lanes of the last wave simply do not vote)
-  uint32_t t0 = chain_first[c];
-  uint32_t t1 = (c + 1 < nchains) ? chain_first[c + 1] : nit;
-  bool is_long = (t1 - t0) >= YD_LONG;
-  // wave-aggregated append: one atomic per wave and class instead of one per chain
-  uint64_t ml = __ballot(is_long), ms = __ballot(!is_long);
-  uint32_t bl = 0, bs = 0;
-  int leader = __builtin_ctzll(ml | ms);
-  if ((int)lane_id() == leader) {
-    if (ml) bl = atomicAdd(&cnt[1], (uint32_t)__popcll(ml));
-    if (ms) bs = atomicAdd(&cnt[0], (uint32_t)__popcll(ms));
+  bool act = c < nchains;
+  bool is_long = false;
+  uint32_t slot = 0;
+  if (act) {
+    uint32_t t0 = chain_first[c];
+    uint32_t t1 = (c + 1 < nchains) ? chain_first[c + 1] : nit;
+    is_long = (t1 - t0) >= YD_LONG;
+    slot = atomicAdd(&s_cnt[is_long ? 1 : 0], 1u);
   }
-  bl = __shfl(bl, leader, 64);
-  bs = __shfl(bs, leader, 64);
-  if (is_long)
-    ids_long[bl + (uint32_t)__popcll(ml & lanemask_lt())] = c;
-  else
-    ids_short[bs + (uint32_t)__popcll(ms & lanemask_lt())] = c;
+  __syncthreads();
+  if (threadIdx.x < 2) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&cnt[threadIdx.x], s_cnt[threadIdx.x]) : 0u;
+  __syncthreads();
+  if (act) {
+    if (is_long)
+      ids_long[s_base[1] + slot] = c;
+    else
+      ids_short[s_base[0] + slot] = c;
+  }
 }
 
 // GSegList (tiebrush.cpp:111-250) with node indices into a per-chain arena; literal, including the
@@ -773,7 +796,7 @@ __global__ void yd_run_k(const uint32_t* __restrict__ ids, const uint32_t* __res
   uint32_t alloc = noff[t0];
   for (uint32_t t = t0; t < t1; ++t) {
     uint32_t rstart = (uint32_t)Y.start[t];
-    uint32_t xo = noff[t], nex = Y.nex[t];
+    uint32_t xo = Y.xo[t], nex = Y.nex[t];
     int d;
     if (last_pos == rstart) {  // :225-228
       yd_merge_read(ex_s + xo, ex_e + xo, nex, N, head, alloc);
@@ -800,6 +823,16 @@ __global__ void yd_run_k(const uint32_t* __restrict__ ids, const uint32_t* __res
 // Wave-native GSegList: the sorted node list lives one node per lane (ns, ne in registers of lane i = node i),
 // control flow is wave-uniform, list surgery is ballots + shuffles.  One 64-thread block per long chain.
 // A list that would need more than 64 nodes hands the chain over to yd_run_k (ids_over).
+// inclusive prefix max over the 64 lanes (DPP row shifts + row broadcasts, identity 0)
+__device__ __forceinline__ uint32_t wave_prefix_max(uint32_t pm) {
+  pm = max(pm, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x111, 0xf, 0xf, false));
+  pm = max(pm, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x112, 0xf, 0xf, false));
+  pm = max(pm, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x114, 0xf, 0xf, false));
+  pm = max(pm, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x118, 0xf, 0xf, false));
+  pm = max(pm, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x142, 0xa, 0xf, false));
+  pm = max(pm, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x143, 0xc, 0xf, false));
+  return pm;
+}
 __device__ __forceinline__ uint32_t rl(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
 
 __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ nids, uint32_t nchains,
@@ -830,7 +863,7 @@ __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids
     const bool have = t < t1;
     b.start = have ? (uint32_t)Y.start[t] : 0u;
     b.nex = have ? Y.nex[t] : 0u;
-    b.xo = have ? noff[t] : 0u;
+    b.xo = have ? Y.xo[t] : 0u;
     b.o = have ? v[t] : 0u;
     b.e0 = have ? ex_e[b.xo] : 0u;  // first exon end (its start is the read start)
     b.s1 = (have && b.nex > 1) ? ex_s[b.xo + 1] : 0u;
@@ -857,39 +890,95 @@ __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids
         mirror_ok = true;
       }
       const uint32_t nex = rl(it_nex, j);
-      // ---- fast path: a maximal run of single-exon items that fall inside the first island [S0,E0] and stay clear
-      // of the next node (start D1).  For such an item processRead finds prev = node 0 with prev.end >= start, so
-      // d = start - S0, and mergeRead only stretches node 0's end — no clearTo, no insertion, no swallow.  The run is
-      // found for all remaining lanes of the batch at once with a wave prefix-max of the exon ends.
-      if (nex == 1u && cnt >= 1 && E0 < D1) {
-        uint32_t ev = (lane >= j && lane < nb) ? it_e0 : 0u;
-        uint32_t pm = ev;  // inclusive prefix max over lanes (DPP row shifts + row broadcasts, identity 0)
-        pm = max(pm, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x111, 0xf, 0xf, false));
-        pm = max(pm, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x112, 0xf, 0xf, false));
-        pm = max(pm, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x114, 0xf, 0xf, false));
-        pm = max(pm, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x118, 0xf, 0xf, false));
-        pm = max(pm, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x142, 0xa, 0xf, false));
-        pm = max(pm, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x143, 0xc, 0xf, false));
+      // ---- fast path: a maximal run of items that leave the list structure alone.  Exon 0 of such an item falls inside
+      // the first island [S0,E0] and stays clear of the next node (start D1): processRead finds prev = node 0 with
+      // prev.end >= start, so d = start - S0, and mergeRead only stretches node 0's end — no clearTo, no insertion, no
+      // swallow.  Exons 1 and 2 (spliced reads) must each start inside an existing later node and end before that
+      // node's successor starts: mergeRead then only raises that node's end (max), again without surgery.  Node starts
+      // never move inside a run and every raised end stays below the following start, so testing against the list as
+      // it was when the run began is exact.  The run is found for all remaining lanes of the batch at once: a wave
+      // prefix-max of the exon-0 ends gives node 0's end before each item; the later nodes' ends are max-reduced
+      // through LDS afterwards.
+      // (the head item's exon 0 is tested on the scalar side first, so an item that cannot start a run costs three
+      // compares rather than the whole window analysis)
+      const uint32_t hd_start = rl(it_start, j), hd_e0 = rl(it_e0, j);
+      if (nex <= 3u && cnt >= 1 && E0 < D1 && S0 < hd_start && hd_e0 < D1 && hd_start <= E0) {
+        const bool inwin = lane >= j && lane < nb;
+        const uint32_t pm = wave_prefix_max(inwin ? it_e0 : 0u);
         uint32_t ex = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x138, 0xf, 0xf, false);  // wave_shr:1 -> exclusive
         uint32_t ebefore = ex > E0 ? ex : E0;
-        bool okl = lane >= j && lane < nb && it_nex == 1u && S0 < it_start && it_e0 < D1 && it_start <= ebefore;
+        bool xok = it_nex == 1u;
+        bool u1 = false, u2 = false;  // exon 1 / exon 2 raises the end of node n1 / n2
+        uint32_t n1 = 0, n2 = 0;
+        const uint64_t multi = __ballot(inwin && it_nex >= 2u && it_nex <= 3u);
+        if (multi != 0 && cnt <= YD_FAST_NODES) {
+          bool h1 = false, h2 = false;
+          uint32_t UL;  // upper bound, over this window, of the end of the last node
+          if (cnt == 1) {
+            UL = ebefore;  // node 0 is the last node; its end just before this item (own exon 0 ends before exon 1 starts)
+          } else {
+            uint32_t Sm = D1, Em = 0;  // D1 == start of node 1
+            for (int m = 1; m < cnt; ++m) {
+              Em = rl(ne, m);
+              const uint32_t NS = (m + 1 < cnt) ? rl(ns, m + 1) : 0xFFFFFFFFu;
+              if (Sm <= it_s1 && it_s1 <= Em && it_e1 < NS) {
+                h1 = true;
+                n1 = (uint32_t)m;
+              }
+              if (Sm <= it_s2 && it_s2 <= Em && it_e2 < NS) {
+                h2 = true;
+                n2 = (uint32_t)m;
+              }
+              Sm = NS;
+            }
+            const uint32_t L = (uint32_t)cnt - 1u;
+            uint32_t cand = 0;
+            if (inwin && it_nex >= 2u && h1 && n1 == L) cand = it_e1;
+            if (inwin && it_nex == 3u && h1 && h2 && n2 == L && it_e2 > cand) cand = it_e2;
+            const uint32_t wm = rl(wave_prefix_max(cand), 63);
+            UL = wm > Em ? wm : Em;
+          }
+          // an exon that starts beyond the end of the last node runs off the list: it and the rest of the read are dropped
+          const bool off1 = it_s1 > UL, off2 = it_s2 > UL;
+          if (it_nex == 2u) {
+            xok = h1 || off1;
+            u1 = h1;
+          } else if (it_nex == 3u) {
+            xok = off1 || (h1 && (h2 || off2));
+            u1 = h1;
+            u2 = h1 && h2;
+          }
+        }
+        bool okl = inwin && xok && S0 < it_start && it_e0 < D1 && it_start <= ebefore;
         uint64_t mk = __ballot(okl) >> j;
         int r = mk == ~0ull ? 64 : __builtin_ctzll(~mk);
         if (r > nb - j) r = nb - j;
         if (r > 0) {
-          if (lane >= j && lane < j + r) it_d = (int)(it_start - S0);
+          const bool inrun = lane >= j && lane < j + r;
+          if (inrun) it_d = (int)(it_start - S0);
           uint32_t newE = rl(pm, j + r - 1);
           if (newE > E0) E0 = newE;
           if (lane == 0) ne = E0;
+          if (__ballot(inrun && u1) != 0) {  // raise the ends of the nodes the later exons landed in
+            __shared__ uint32_t upd[64];
+            upd[lane] = 0u;
+            __syncthreads();
+            if (inrun && u1) atomicMax(&upd[n1], it_e1);
+            if (inrun && u2) atomicMax(&upd[n2], it_e2);
+            __syncthreads();
+            const uint32_t u = upd[lane];
+            if (lane >= 1 && lane < cnt && u > ne) ne = u;
+            __syncthreads();
+          }
           last_pos = rl(it_start, j + r - 1);
           last_dist = (int)(last_pos - S0);
           j += r - 1;
           continue;
         }
       }
-      const uint32_t rstart = rl(it_start, j);
+      const uint32_t rstart = hd_start;
       const uint32_t xo = rl(it_xo, j);
-      const uint32_t e0 = rl(it_e0, j);
+      const uint32_t e0 = hd_e0;
       int d;
       // ---- processRead :221-250
       if (last_pos == rstart) {
@@ -933,7 +1022,19 @@ __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids
         if (nex > 64) {
           overflow = true;
         } else {
-          if ((uint32_t)lane < nex) {
+          if (nex <= 3u) {  // the first three exons travel with the batch: no global load on the critical path
+            const uint32_t s1 = rl(it_s1, j), e1 = rl(it_e1, j), s2 = rl(it_s2, j), e2 = rl(it_e2, j);
+            if (lane == 0) {
+              ns = rstart;
+              ne = e0;
+            } else if (lane == 1) {
+              ns = s1;
+              ne = e1;
+            } else if (lane == 2) {
+              ns = s2;
+              ne = e2;
+            }
+          } else if ((uint32_t)lane < nex) {
             ns = ex_s[xo + lane];
             ne = ex_e[xo + lane];
           }
@@ -1115,7 +1216,7 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       Y.tidp1 = ws_alloc<uint32_t>(ctx, nit);
       Y.start = ws_alloc<int32_t>(ctx, nit);
       Y.end = ws_alloc<int32_t>(ctx, nit);
-      Y.rep = ws_alloc<uint32_t>(ctx, nit);
+      Y.xo = ws_alloc<uint32_t>(ctx, nit);
       Y.nex = ws_alloc<uint32_t>(ctx, nit);
       Y.chead = ws_alloc<uint32_t>(ctx, nit);
       uint32_t* cex = ws_alloc<uint32_t>(ctx, nit);
@@ -1130,7 +1231,16 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       TBK_LAUNCH(ctx, "yd_fill", yd_fill_k, cdiv(m, B), B, 0, I, m, J.val, J.flags, J.fidx, J.sgid, J.ginv, ioff, ooff, J.G, ib.hi, ib.lo,
                  ib.val);
       TBK_TRY(tbk_radix_sort128(ctx, &ib, nit, ~0ull, 0ull));  // stable split by list id; group order is already in place
-      TBK_LAUNCH(ctx, "yd_coords", yd_coords_k, cdiv(nit, B), B, 0, I, nit, ib.val, J.gperm, J.G, J.shi, J.slo, Y);
+      YdGroups Q;
+      Q.tidp1 = ws_alloc<uint32_t>(ctx, ng);
+      Q.start = ws_alloc<int32_t>(ctx, ng);
+      Q.end = ws_alloc<int32_t>(ctx, ng);
+      Q.nex = ws_alloc<uint32_t>(ctx, ng);
+      Q.xoff = ws_alloc<uint32_t>(ctx, ng);
+      if (!Q.xoff) return TBK_ENOMEM;
+      TBK_LAUNCH(ctx, "yd_groups", yd_groups_k, cdiv(ng, B), B, 0, I, ng, J.gperm, J.G, J.shi, J.slo, Q);
+      TBK_TRY(tbk_exscan_u32(ctx, Q.nex, Q.xoff, ng, sc + 5));
+      TBK_LAUNCH(ctx, "yd_coords", yd_coords_k, cdiv(nit, B), B, 0, nit, ib.val, Q, Y);
       {
         YdLoad ld{ib.hi, Y};
         YdStore st{ld};
@@ -1143,20 +1253,20 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
       TBK_HIP(hipStreamSynchronize(ctx->stream));
       const uint32_t nchains = (uint32_t)ctx->h_scalars[3];
-      const uint64_t nnodes = ctx->h_scalars[4];
+      const uint64_t nnodes = ctx->h_scalars[4], ngex = ctx->h_scalars[5];
       if (nnodes >= (1ull << 31)) return TBK_E2BIG;
       SegNodes N;
       N.s = ws_alloc<uint32_t>(ctx, nnodes + 1);
       N.e = ws_alloc<uint32_t>(ctx, nnodes + 1);
       N.nx = ws_alloc<int32_t>(ctx, nnodes + 1);
-      uint32_t* ex_s = ws_alloc<uint32_t>(ctx, nnodes + 1);
-      uint32_t* ex_e = ws_alloc<uint32_t>(ctx, nnodes + 1);
+      uint32_t* ex_s = ws_alloc<uint32_t>(ctx, ngex + 1);
+      uint32_t* ex_e = ws_alloc<uint32_t>(ctx, ngex + 1);
       uint32_t* ids_short = ws_alloc<uint32_t>(ctx, nchains);
       uint32_t* ids_long = ws_alloc<uint32_t>(ctx, nchains);
       uint32_t* ids_over = ws_alloc<uint32_t>(ctx, nchains);
       uint32_t* ccnt = (uint32_t*)(sc + 24);  // [0] short, [1] long, [2] overflow
       if (!ids_over) return TBK_ENOMEM;
-      TBK_LAUNCH(ctx, "yd_exons", yd_exons_k, cdiv(nit, B), B, 0, I, nit, Y, noff, ex_s, ex_e);
+      TBK_LAUNCH(ctx, "yd_gexons", yd_gexons_k, cdiv(ng, B), B, 0, I, ng, J.gperm, J.G, Q, ex_s, ex_e);
       TBK_LAUNCH(ctx, "yd_classify", yd_classify_k, cdiv(nchains, B), B, 0, nchains, nit, chain_first, ids_short, ids_long, ccnt);
       TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 24, ccnt, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
       TBK_HIP(hipStreamSynchronize(ctx->stream));
