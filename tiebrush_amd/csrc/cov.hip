@@ -18,6 +18,8 @@
 // counting sort over tiles.  Integer accumulation is exact in any order; non-integral YC
 // values are routed to the ordered double path (cov_tile_k<double>) which adds per base in
 // record order exactly as the reference does.
+#include <thread>
+
 #include "dev_common.cuh"
 #include "scan_op.cuh"
 #include "tbk_internal.h"
@@ -634,6 +636,61 @@ __global__ void sample_convert_k(uint32_t n, const double* __restrict__ v, float
 }
 }  // namespace
 
+// ---- junction branch ---------------------------------------------------------------------------------------
+// items (one per N op of a valid record) -> sort by (bundle,start | end,strand) -> heads -> ordered sums.  Independent
+// of the interval branch once the bundles exist, so tbk_coverage_device runs it on a side context (own stream, own
+// arena, own host thread) while the main stream builds the intervals; `ctx` is whichever context it runs on.
+constexpr uint32_t COV_SIDE_MIN = 1u << 16;  // below this many records the fork costs more than it hides
+static int junc_branch(tbk_ctx* ctx, uint32_t m, const CovArrays& A, const tbk_cov_in* in, const uint32_t* jcnt, tbk_cov_out* out,
+                       uint32_t* nj_out, uint32_t* nju_out) {
+  const uint32_t B = 256;
+  uint64_t* sc = ctx->d_scalars;
+  *nj_out = *nju_out = 0;
+  uint32_t* joff = ws_alloc<uint32_t>(ctx, m);
+  if (!joff) return TBK_ENOMEM;
+  TBK_TRY(tbk_exscan_u32(ctx, jcnt, joff, m, sc + 7));
+  TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 7, sc + 7, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  TBK_HIP(hipStreamSynchronize(ctx->stream));
+  const uint32_t nj = (uint32_t)ctx->h_scalars[7];
+  *nj_out = nj;
+  if (!nj) return 0;
+  SortBufs sb;
+  sb.hi = ws_alloc<uint64_t>(ctx, nj);
+  sb.lo = ws_alloc<uint64_t>(ctx, nj);
+  sb.val = ws_alloc<uint32_t>(ctx, nj);
+  sb.hi2 = ws_alloc<uint64_t>(ctx, nj);
+  sb.lo2 = ws_alloc<uint64_t>(ctx, nj);
+  sb.val2 = ws_alloc<uint32_t>(ctx, nj);
+  uint32_t* head = ws_alloc<uint32_t>(ctx, nj);
+  uint32_t* hoff = ws_alloc<uint32_t>(ctx, nj);
+  if (!hoff) return TBK_ENOMEM;
+  TBK_LAUNCH(ctx, "junc_fill", junc_fill_k, cdiv(m, B), B, 0, m, A, in->pos, in->cig_off, in->cig, in->strand, joff, sb.hi, sb.lo,
+             sb.val);
+  TBK_TRY(tbk_radix_sort128(ctx, &sb, nj));
+  TBK_LAUNCH(ctx, "junc_head", junc_head_k, cdiv(nj, B), B, 0, nj, sb.hi, sb.lo, head);
+  TBK_TRY(tbk_exscan_u32(ctx, head, hoff, nj, sc + 9));
+  TBK_LAUNCH(ctx, "junc_write", junc_write_k, cdiv(nj, B), B, 0, nj, A, sb.hi, sb.lo, sb.val, head, hoff, in->yc, out->cap_junctions,
+             out->j_tid, out->j_start, out->j_end, out->j_strand, out->j_val);
+  TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 9, sc + 9, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  TBK_HIP(hipStreamSynchronize(ctx->stream));
+  *nju_out = (uint32_t)ctx->h_scalars[9];
+  return tbk_check_launch(ctx, "junctions");
+}
+
+struct JuncSide {  // the junction branch on the side context; joined before tbk_coverage_device returns, whatever the path
+  std::thread* th = nullptr;
+  int rc = 0;
+  int join() {
+    if (th) {
+      th->join();
+      delete th;
+      th = nullptr;
+    }
+    return rc;
+  }
+  ~JuncSide() { (void)join(); }
+};
+
 static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sample_mode) {
   const uint32_t n = in->n_records;
   const bool want_cov = out->cap_intervals > 0, want_j = out->cap_junctions > 0;
@@ -663,8 +720,9 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
   A.b_span = ws_alloc<uint32_t>(ctx, n);
   A.b_off = ws_alloc<uint64_t>(ctx, n + 1);
   uint32_t* jcnt = want_j ? ws_alloc<uint32_t>(ctx, n) : nullptr;
-  uint32_t* joff = want_j ? ws_alloc<uint32_t>(ctx, n) : nullptr;
-  if (!A.b_off || (want_j && !joff)) return TBK_ENOMEM;
+  if (!A.b_off || (want_j && !jcnt)) return TBK_ENOMEM;
+  uint32_t nj = 0, nju = 0;
+  JuncSide side;
 
   TBK_LAUNCH(ctx, "cov_valid", cov_valid_k, cdiv(n, B), B, 0, in->flag, n, valid);
   TBK_TRY(tbk_exscan_u32(ctx, valid, vpos, n, sc + 2));
@@ -695,6 +753,17 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
   TBK_TRY(tbk_sync_err(ctx, &eb));
   if (eb) return tbk_derr_to_status(ctx, eb);
   const uint32_t nb = (uint32_t)ctx->h_scalars[3];
+  if (want_j && want_cov && m >= COV_SIDE_MIN) {  // bundles exist (the stream was just synchronised): fork the junction branch
+    tbk_ctx* jc = tbk_side_ctx(ctx);
+    if (jc) {
+      const size_t hint = (size_t)m * 8 + (size_t)in->n_cigar_ops * 56 + ((size_t)4 << 20);
+      side.th = new std::thread([&side, jc, hint, m, &A, in, jcnt, out, &nj, &nju]() {
+        side.rc = tbk_side_begin(jc, hint);
+        if (side.rc == 0) side.rc = junc_branch(jc, m, A, in, jcnt, out, &nj, &nju);
+        tbk_side_end(jc);
+      });
+    }
+  }
   TBK_LAUNCH(ctx, "cov_bundle_span", cov_bundle_span_k, cdiv(nb, B), B, 0, nb, A);
   TBK_TRY(tbk_exscan_u32_u64(ctx, A.b_span, A.b_off, nb, sc + 4));
   // b_off[nb] = S (device-to-device copy of the total)
@@ -769,42 +838,25 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
     }
   }
 
-  uint32_t nj = 0;
-  if (want_j) {
-    TBK_TRY(tbk_exscan_u32(ctx, jcnt, joff, m, sc + 7));
-    TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    TBK_HIP(hipStreamSynchronize(ctx->stream));
-    nj = (uint32_t)ctx->h_scalars[7];
-    if (nj) {
-      SortBufs sb;
-      sb.hi = ws_alloc<uint64_t>(ctx, nj);
-      sb.lo = ws_alloc<uint64_t>(ctx, nj);
-      sb.val = ws_alloc<uint32_t>(ctx, nj);
-      sb.hi2 = ws_alloc<uint64_t>(ctx, nj);
-      sb.lo2 = ws_alloc<uint64_t>(ctx, nj);
-      sb.val2 = ws_alloc<uint32_t>(ctx, nj);
-      uint32_t* head = ws_alloc<uint32_t>(ctx, nj);
-      uint32_t* hoff = ws_alloc<uint32_t>(ctx, nj);
-      if (!hoff) return TBK_ENOMEM;
-      TBK_LAUNCH(ctx, "junc_fill", junc_fill_k, cdiv(m, B), B, 0, m, A, in->pos, in->cig_off, in->cig, in->strand, joff, sb.hi,
-                 sb.lo, sb.val);
-      TBK_TRY(tbk_radix_sort128(ctx, &sb, nj));
-      TBK_LAUNCH(ctx, "junc_head", junc_head_k, cdiv(nj, B), B, 0, nj, sb.hi, sb.lo, head);
-      TBK_TRY(tbk_exscan_u32(ctx, head, hoff, nj, sc + 9));
-      TBK_LAUNCH(ctx, "junc_write", junc_write_k, cdiv(nj, B), B, 0, nj, A, sb.hi, sb.lo, sb.val, head, hoff, in->yc,
-                 out->cap_junctions, out->j_tid, out->j_start, out->j_end, out->j_strand, out->j_val);
-    }
-  }
+  if (want_j && !side.th) TBK_TRY(junc_branch(ctx, m, A, in, jcnt, out, &nj, &nju));
   TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   TBK_TRY(tbk_sync_err(ctx, &eb));
   if (eb) return tbk_derr_to_status(ctx, eb);
   TBK_TRY(tbk_check_launch(ctx, "coverage"));
+  if (side.th) {
+    const int jrc = side.join();
+    ctx->side_times_pending = true;
+    if (jrc != 0) {
+      ctx->last_error = ctx->side_ctx->last_error;
+      return jrc;
+    }
+  }
   if (want_cov) {
     out->n_intervals = (uint32_t)ctx->h_scalars[8];
     if (out->n_intervals > out->cap_intervals) return TBK_E2BIG;
   }
   if (want_j && nj) {
-    out->n_junctions = (uint32_t)ctx->h_scalars[9];
+    out->n_junctions = nju;
     if (out->n_junctions > out->cap_junctions) return TBK_E2BIG;
   }
   return 0;

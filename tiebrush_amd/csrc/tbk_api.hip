@@ -111,6 +111,7 @@ int tbk_derr_to_status(tbk_ctx* ctx, uint32_t bits) {
   return TBK_EHIP;
 }
 
+static void merge_side_times(tbk_ctx* ctx);
 static void prof_begin_call(tbk_ctx* ctx) {
   ctx->ktimes.clear();
   ctx->ev_used = 0;
@@ -132,6 +133,7 @@ static void prof_end_call(tbk_ctx* ctx) {
       }
     if (!found) ctx->last_times.push_back({k.name, ms, 1});
   }
+  merge_side_times(ctx);
 }
 
 // ---- staging helpers for TBK_MEM_HOST ---------------------------------------------------------------
@@ -159,6 +161,36 @@ static int d2h(tbk_ctx* ctx, T* host, const T* dev, size_t n) {
   if (!host || !dev || !n) return 0;
   TBK_HIP(hipMemcpyAsync(host, dev, n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
   return 0;
+}
+
+// ---- side context ----------------------------------------------------------------------------------------
+tbk_ctx* tbk_side_ctx(tbk_ctx* ctx) {
+  if (!ctx->side_ctx && tbk_create(ctx->device, &ctx->side_ctx) != 0) ctx->side_ctx = nullptr;
+  if (ctx->side_ctx) ctx->side_ctx->profiling = ctx->profiling;
+  return ctx->side_ctx;
+}
+int tbk_side_begin(tbk_ctx* side, size_t arena_hint) {
+  if (hipSetDevice(side->device) != hipSuccess) return TBK_EHIP;
+  prof_begin_call(side);
+  return ws_begin_call(side, arena_hint);
+}
+void tbk_side_end(tbk_ctx* side) { prof_end_call(side); }
+
+// kernel times of a side branch are reported with the call that ran it
+static void merge_side_times(tbk_ctx* ctx) {
+  if (!ctx->side_times_pending || !ctx->side_ctx) return;
+  ctx->side_times_pending = false;
+  for (auto& t : ctx->side_ctx->last_times) {
+    bool found = false;
+    for (auto& u : ctx->last_times)
+      if (strcmp(u.name, t.name) == 0) {
+        u.ms += t.ms;
+        u.launches += t.launches;
+        found = true;
+        break;
+      }
+    if (!found) ctx->last_times.push_back(t);
+  }
 }
 
 // ---- deferred YD stage -------------------------------------------------------------------------------
@@ -240,6 +272,10 @@ void tbk_destroy(tbk_ctx* ctx) {
   if (ctx->yd_ctx) {
     tbk_destroy(ctx->yd_ctx);
     ctx->yd_ctx = nullptr;
+  }
+  if (ctx->side_ctx) {
+    tbk_destroy(ctx->side_ctx);
+    ctx->side_ctx = nullptr;
   }
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);

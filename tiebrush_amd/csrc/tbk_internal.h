@@ -59,7 +59,16 @@ struct tbk_ctx {
   std::thread* yd_thread = nullptr;
   int yd_rc = 0;
   size_t ws_base_off = 0;        // arena bytes pinned while a deferred YD stage still reads the main stage's arrays
+  // side context for a branch that runs beside the main stream inside one call (tiecov junctions)
+  tbk_ctx* side_ctx = nullptr;
+  bool side_times_pending = false;
 };
+
+// side context (created on first use; nullptr if that fails -> the caller runs the branch inline), and the call
+// bracket a branch thread puts around its work on it
+tbk_ctx* tbk_side_ctx(tbk_ctx* ctx);
+int tbk_side_begin(tbk_ctx* side, size_t arena_hint);
+void tbk_side_end(tbk_ctx* side);
 
 #define TBK_HIP(call)                                                                            \
   do {                                                                                           \
