@@ -322,7 +322,10 @@ struct EffStore {
   uint64_t* n_pass;
   uint32_t n;
   uint32_t* err;
+  const uint16_t* fidx;
+  uint32_t* head_off;  // [file] compacted offset of the file's first record (files without records: untouched)
   __device__ __forceinline__ void operator()(uint32_t i, const EffKey& inc, const EffKey& ex) const {
+    if (kflags[i] & 2u) head_off[fidx[i]] = ex.flag_cnt & 0x7FFFFFFFu;
     if (kflags[i] & 1u) {
       uint64_t ik = ((uint64_t)inc.khi_h << 32) | inc.khi_l;
       if (ik != (khi[i] >> 2)) atomicOr(err, TBK_DERR_UNSORTED);  // an earlier record of the file has a larger (tid,start)
@@ -335,6 +338,17 @@ struct EffStore {
     if (i + 1 == n) *n_pass = inc.flag_cnt & 0x7FFFFFFFu;
   }
 };
+
+// run_off[f] = compacted offset where file f's passing records begin (f == k: their total); empty files take the
+// offset of the next file that has records
+__global__ void col_runs_k(uint32_t k, const uint32_t* __restrict__ file_off, const uint32_t* __restrict__ head_off,
+                           const uint64_t* __restrict__ n_pass, uint32_t* __restrict__ run_off) {
+  uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f > k) return;
+  uint32_t g = f;
+  while (g < k && file_off[g] == file_off[g + 1]) ++g;
+  run_off[f] = g < k ? head_off[g] : (uint32_t)*n_pass;
+}
 
 // ---- K4: heads -------------------------------------------------------------------------------------
 // flags: bit0 group head, bit1 tie-set head, bit2 file head (first record of its file in the group)
@@ -1361,7 +1375,15 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
   uint32_t* ghead = ws_alloc<uint32_t>(ctx, n);
   uint32_t* gex = ws_alloc<uint32_t>(ctx, n);
   uint32_t* sgid = ws_alloc<uint32_t>(ctx, n);
-  if (!sgid) return TBK_ENOMEM;
+  uint32_t* head_off = ws_alloc<uint32_t>(ctx, (size_t)in->n_files + 1);
+  uint32_t* run_off = ws_alloc<uint32_t>(ctx, (size_t)in->n_files + 1);
+  if (!sgid || !head_off || !run_off) return TBK_ENOMEM;
+  bool use_runs = in->n_files <= 64;  // ceil(log2(files)) merge rounds against ~12 radix passes
+  uint32_t runs_min = 32768;          // below this the tile is launch-bound either way; keep the one code path
+  if (const char* e = getenv("TBK_SORT")) {  // test hook: "radix" / "runs" force one path whatever the shape
+    use_runs = strcmp(e, "radix") != 0 && (use_runs || strcmp(e, "runs") == 0);
+    if (strcmp(e, "runs") == 0) runs_min = 0;
+  }
 
   uint32_t m = 0, ng = 0;
   GroupAcc G{};
@@ -1379,10 +1401,11 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
     TBK_LAUNCH(ctx, "col_keys", col_keys_k, cdiv(n, B), B, 0, I, O, khi, klo, kend, kflags, fidx, ctx->d_err);
     {
       EffLoad ld{khi, kend, kflags};
-      EffStore st{khi, klo, kflags, effend, s2.hi, s2.lo, s2.val, sc + 0, n, ctx->d_err};
+      EffStore st{khi, klo, kflags, effend, s2.hi, s2.lo, s2.val, sc + 0, n, ctx->d_err, fidx, head_off};
       EffKey ident{0u, 0u, INT32_MIN, 0u};
       TBK_TRY((scan_op_run<EffKey, EffOp, EffLoad, EffStore>(ctx, "col_effkey_scan", n, ld, st, EffOp{}, ident)));
     }
+    if (use_runs) TBK_LAUNCH(ctx, "col_runs", col_runs_k, cdiv(I.k + 1, B), B, 0, I.k, I.file_off, head_off, sc + 0, run_off);
     TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     uint32_t eb = 0;
     TBK_TRY(tbk_sync_err(ctx, &eb));
@@ -1390,12 +1413,29 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
     m = (uint32_t)ctx->h_scalars[0];
     out->n_passed = m;
     if (m == 0) return 0;
-    TBK_TRY(tbk_radix_sort128(ctx, &s2, m));
-    TBK_LAUNCH(ctx, "col_heads", col_heads_k, cdiv(m, B), B, 0, I, O.strategy, m, s2.hi, s2.lo, s2.val, fidx, flags, ghead,
-               ctx->d_err);
-    TBK_TRY(tbk_exscan_u32(ctx, ghead, gex, m, sc + 1));
-    TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    TBK_TRY(tbk_sync_err(ctx, &eb));
+    // The files are position-sorted runs (verified by the scan above): merge them and order each (tid,start) bucket
+    // locally (msort.hip).  Many files, a small tile, or a bucket longer than the local window take the radix sort.
+    bool runs_now = use_runs && m >= runs_min;
+    for (;;) {
+      if (runs_now)
+        TBK_TRY(tbk_sort_runs(ctx, &s2, m, run_off, I.k, ctx->d_err));
+      else
+        TBK_TRY(tbk_radix_sort128(ctx, &s2, m));
+      TBK_LAUNCH(ctx, "col_heads", col_heads_k, cdiv(m, B), B, 0, I, O.strategy, m, s2.hi, s2.lo, s2.val, fidx, flags, ghead,
+                 ctx->d_err);
+      TBK_TRY(tbk_exscan_u32(ctx, ghead, gex, m, sc + 1));
+      TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+      TBK_TRY(tbk_sync_err(ctx, &eb));
+      if (runs_now && (eb & TBK_DERR_BIGBUCKET)) {  // redo on the merged (phase-A) order, which the *2 side still holds
+        std::swap(s2.hi, s2.hi2);
+        std::swap(s2.lo, s2.lo2);
+        std::swap(s2.val, s2.val2);
+        TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
+        runs_now = false;
+        continue;
+      }
+      break;
+    }
     if (eb & TBK_DERR_COLLISION) continue;  // reseed
     if (eb) return tbk_derr_to_status(ctx, eb);
     ng = (uint32_t)ctx->h_scalars[1];

@@ -1,0 +1,241 @@
+// msort.hip — the record sort of the collapse stage for inputs that arrive as a few position-sorted runs (one per
+// input file, which is what `tiebrush` requires of its BAMs: tmerge.cpp keeps one cursor per file and always takes the
+// smallest head).  Instead of twelve LSD radix passes over the 128-bit key, the order is built from the structure:
+//
+//   phase A  merge the runs by position P = hi >> 2 (tid,start) — ceil(log2(runs)) rounds of pairwise merge-path
+//            merges, stable (left run first on ties), so equal P stay in input (file, index) order;
+//   phase B  inside every bucket of equal P order by (strand, span, hash) — buckets are short (a few reads share a
+//            start), so a block takes a window of consecutive buckets into LDS and ranks each record by counting.
+//
+// The result is the same permutation the stable 128-bit radix sort produces.  Buckets longer than a window raise
+// TBK_DERR_BIGBUCKET and the caller falls back to the radix sort (on the phase-A output, which is still a valid
+// stable input for it).  All integer work, HBM/LDS-bound; no MFMA.
+#include "dev_common.cuh"
+#include "tbk_internal.h"
+
+namespace {
+constexpr int MG_NT = 256;
+constexpr int MG_E = 8;
+constexpr int MG_T = MG_NT * MG_E;  // outputs per tile
+
+// run boundaries of round r: run q of the round is input runs [q << r, (q + 1) << r)
+__device__ __forceinline__ uint32_t run_start(const uint32_t* __restrict__ run_off, uint32_t k, uint32_t r, uint32_t q) {
+  uint64_t f = (uint64_t)q << r;
+  return run_off[f < k ? (uint32_t)f : k];
+}
+
+// Merge path, left run first on ties: the number of elements the first d outputs of merge(A, B) take from A.
+// All 64 lanes of a wave call it; every round probes 64 split points at once, so a run of a million elements takes
+// four rounds of (two parallel) global loads instead of twenty dependent ones.
+__device__ __forceinline__ uint32_t mpath_wave(const uint64_t* __restrict__ A, uint32_t nA, const uint64_t* __restrict__ B, uint32_t nB,
+                                               uint32_t d) {
+  uint32_t lo = d > nB ? d - nB : 0u;  // g(lo) holds by construction
+  uint32_t hi = d < nA ? d : nA;
+  const uint32_t lane = lane_id();
+  while (lo < hi) {  // invariant: g(lo) true, answer in [lo, hi];  g(i) = A[i-1] <= B[d-i]  (monotone: true ... true false ... false)
+    const uint32_t span = hi - lo;
+    const uint32_t step = (span + 63u) / 64u;
+    uint64_t p64 = (uint64_t)lo + (uint64_t)(lane + 1u) * step;
+    const uint32_t p = p64 < hi ? (uint32_t)p64 : hi;
+    const bool g = (A[p - 1] >> 2) <= (B[d - p] >> 2);
+    const uint64_t t = __ballot(g);
+    const int c = t == ~0ull ? 64 : __builtin_ctzll(~t);  // leading run of true probes
+    uint32_t nlo = lo, nhi = hi;
+    if (c > 0) nlo = (uint32_t)__shfl((int)p, c - 1, 64);
+    if (c < 64) nhi = (uint32_t)__shfl((int)p, c, 64) - 1u;
+    lo = nlo;
+    hi = nhi < nlo ? nlo : nhi;
+  }
+  return lo;
+}
+
+// one round: every pair of adjacent runs of round r becomes one run of round r + 1
+__global__ __launch_bounds__(MG_NT) void msort_merge_k(const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo,
+                                                       const uint32_t* __restrict__ val, uint64_t* __restrict__ ohi,
+                                                       uint64_t* __restrict__ olo, uint32_t* __restrict__ oval, uint32_t n,
+                                                       const uint32_t* __restrict__ run_off, uint32_t k, uint32_t r) {
+  __shared__ uint64_t keys[MG_T];
+  __shared__ uint32_t src[MG_T];
+  __shared__ uint32_t s_i[2];
+  const uint32_t o0 = blockIdx.x * MG_T;
+  const uint32_t o1 = (n - o0) < (uint32_t)MG_T ? n : o0 + MG_T;
+  const uint32_t npairs = (uint32_t)((((uint64_t)k + (1ull << (r + 1)) - 1) >> (r + 1)));
+  // first pair that reaches beyond o0
+  uint32_t j;
+  {
+    uint32_t a = 0, b = npairs;  // smallest j with run_start(2(j+1)) > o0
+    while (a < b) {
+      uint32_t mid = (a + b) >> 1;
+      if (run_start(run_off, k, r, 2 * (mid + 1)) > o0)
+        b = mid;
+      else
+        a = mid + 1;
+    }
+    j = a;
+  }
+  uint32_t o = o0;
+  while (o < o1 && j < npairs) {
+    const uint32_t ps = run_start(run_off, k, r, 2 * j), pm = run_start(run_off, k, r, 2 * j + 1), pe = run_start(run_off, k, r, 2 * j + 2);
+    if (pe <= o) {
+      ++j;
+      continue;
+    }
+    const uint32_t seg_end = pe < o1 ? pe : o1;
+    const uint64_t* A = hi + ps;
+    const uint64_t* Bp = hi + pm;
+    const uint32_t nA = pm - ps, nB = pe - pm;
+    const uint32_t d0 = o - ps, d1 = seg_end - ps;
+    if (threadIdx.x < 128) {  // wave 0: lower diagonal, wave 1: upper diagonal
+      const uint32_t w = threadIdx.x >> 6;
+      const uint32_t i = mpath_wave(A, nA, Bp, nB, w == 0 ? d0 : d1);
+      if (lane_id() == 0) s_i[w] = i;
+    }
+    __syncthreads();
+    const uint32_t i0 = s_i[0], i1 = s_i[1];
+    const uint32_t b0 = d0 - i0, b1 = d1 - i1;
+    const uint32_t na = i1 - i0, nb = b1 - b0, L = na + nb;  // L == d1 - d0 <= MG_T
+    for (uint32_t x = threadIdx.x; x < L; x += MG_NT) keys[x] = (x < na ? A[i0 + x] : Bp[b0 + (x - na)]) >> 2;
+    __syncthreads();
+    // every thread merges MG_E consecutive outputs of the segment
+    {
+      const uint32_t dl = threadIdx.x * MG_E < L ? threadIdx.x * MG_E : L;
+      uint32_t a = dl > nb ? dl - nb : 0u, b = dl < na ? dl : na;
+      while (a < b) {  // largest i with keys[i-1] <= keysB[dl-i]
+        uint32_t mid = (a + b + 1) >> 1;
+        if (keys[mid - 1] <= keys[na + dl - mid])
+          a = mid;
+        else
+          b = mid - 1;
+      }
+      uint32_t ia = a, ib = dl - a;
+#pragma unroll
+      for (int e = 0; e < MG_E; ++e) {
+        const uint32_t x = dl + e;
+        if (x < L) {
+          const bool takeA = ib >= nb || (ia < na && keys[ia] <= keys[na + ib]);
+          src[x] = takeA ? ps + i0 + ia : pm + b0 + ib;
+          if (takeA)
+            ++ia;
+          else
+            ++ib;
+        }
+      }
+    }
+    __syncthreads();
+    for (uint32_t x = threadIdx.x; x < L; x += MG_NT) {  // striped: coalesced stores, two nearly contiguous gather streams
+      const uint32_t s = src[x];
+      ohi[o + x] = hi[s];
+      olo[o + x] = lo[s];
+      oval[o + x] = val[s];
+    }
+    __syncthreads();
+    o = seg_end;
+    ++j;
+  }
+}
+
+constexpr int RF_NT = 256;
+constexpr int RF_W = 1024;    // positions a block owns (it sorts the buckets whose first record lies among them)
+constexpr int RF_CAP = 2048;  // window: the owned positions plus the rest of the last owned bucket
+constexpr int RF_E = RF_CAP / RF_NT;
+
+// phase B.  Input sorted by P (stable); output: inside each bucket ordered by (strand, lo), equal keys in input order.
+__global__ __launch_bounds__(RF_NT) void msort_refine_k(const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo,
+                                                        const uint32_t* __restrict__ val, uint64_t* __restrict__ ohi,
+                                                        uint64_t* __restrict__ olo, uint32_t* __restrict__ oval, uint32_t m,
+                                                        uint32_t* __restrict__ err) {
+  __shared__ uint64_t K[RF_CAP];
+  __shared__ uint8_t head[RF_CAP];
+  __shared__ uint32_t s_first, s_end;
+  const uint32_t r0 = blockIdx.x * RF_W;
+  const uint32_t r1 = (m - r0) < (uint32_t)RF_W ? m : r0 + RF_W;
+  const uint32_t lim = (m - r1) < (uint32_t)(RF_CAP - RF_W) ? m : r1 + (RF_CAP - RF_W);
+  if (threadIdx.x == 0) {
+    s_first = 0xFFFFFFFFu;
+    s_end = 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  {
+    uint32_t fmin = 0xFFFFFFFFu, emin = 0xFFFFFFFFu;
+    for (uint32_t i = r0 + threadIdx.x; i < lim; i += RF_NT) {
+      const bool h = i == 0 || (hi[i] >> 2) != (hi[i - 1] >> 2);
+      if (h) {
+        if (i < r1) {
+          if (i < fmin) fmin = i;
+        } else if (i < emin) {
+          emin = i;
+        }
+      }
+    }
+    if (fmin != 0xFFFFFFFFu) atomicMin(&s_first, fmin);
+    if (emin != 0xFFFFFFFFu) atomicMin(&s_end, emin);
+  }
+  __syncthreads();
+  const uint32_t ws = s_first;
+  if (ws == 0xFFFFFFFFu) return;  // the whole range lies inside a bucket that started earlier: its owner handles (or reports) it
+  uint32_t we = s_end;
+  if (we == 0xFFFFFFFFu) {
+    if (lim == m) {
+      we = m;
+    } else {  // the last owned bucket does not end inside the window
+      if (threadIdx.x == 0) atomicOr(err, TBK_DERR_BIGBUCKET);
+      return;
+    }
+  }
+  const uint32_t nw = we - ws;  // <= RF_CAP
+  uint64_t rh[RF_E], rl[RF_E];
+  uint32_t rv[RF_E];
+#pragma unroll
+  for (int e = 0; e < RF_E; ++e) {
+    const uint32_t x = (uint32_t)e * RF_NT + threadIdx.x;
+    if (x < nw) {
+      rh[e] = hi[ws + x];
+      rl[e] = lo[ws + x];
+      rv[e] = val[ws + x];
+      K[x] = ((rh[e] & 3ull) << 62) | rl[e];  // span < 2^30 (checked when the keys are built): strand fits above it
+      head[x] = (x == 0 || (rh[e] >> 2) != (hi[ws + x - 1] >> 2)) ? 1 : 0;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < RF_E; ++e) {
+    const uint32_t x = (uint32_t)e * RF_NT + threadIdx.x;
+    if (x < nw) {
+      const uint64_t kx = K[x];
+      uint32_t cnt = 0, back = 0;
+      for (uint32_t j = x; !head[j];) {  // earlier records of the bucket: ties go before x
+        --j;
+        ++back;
+        cnt += K[j] <= kx ? 1u : 0u;
+      }
+      for (uint32_t j = x + 1; j < nw && !head[j]; ++j) cnt += K[j] < kx ? 1u : 0u;
+      const uint32_t dst = ws + x - back + cnt;
+      ohi[dst] = rh[e];
+      olo[dst] = rl[e];
+      oval[dst] = rv[e];
+    }
+  }
+}
+
+}  // namespace
+
+// Sort b (n records: nruns runs, run f = [run_off[f], run_off[f+1]), each non-decreasing in hi >> 2 and in input
+// order) exactly as tbk_radix_sort128 would.  A bucket too long for phase B sets TBK_DERR_BIGBUCKET in *err; the caller
+// then swaps b's two sides back (the phase-A output, still a valid stable input) and runs the radix sort on it.
+int tbk_sort_runs(tbk_ctx* ctx, SortBufs* b, uint32_t n, const uint32_t* d_run_off, uint32_t nruns, uint32_t* err) {
+  if (n < 2) return 0;
+  uint32_t rounds = 0;
+  while ((1u << rounds) < nruns) ++rounds;
+  const uint32_t tiles = cdiv(n, MG_T);
+  for (uint32_t r = 0; r < rounds; ++r) {
+    TBK_LAUNCH(ctx, "msort_merge", msort_merge_k, tiles, MG_NT, 0, b->hi, b->lo, b->val, b->hi2, b->lo2, b->val2, n, d_run_off, nruns, r);
+    std::swap(b->hi, b->hi2);
+    std::swap(b->lo, b->lo2);
+    std::swap(b->val, b->val2);
+  }
+  TBK_LAUNCH(ctx, "msort_refine", msort_refine_k, cdiv(n, RF_W), RF_NT, 0, b->hi, b->lo, b->val, b->hi2, b->lo2, b->val2, n, err);
+  std::swap(b->hi, b->hi2);  // (on TBK_DERR_BIGBUCKET the caller swaps back: the *2 side then holds the phase-A output)
+  std::swap(b->lo, b->lo2);
+  std::swap(b->val, b->val2);
+  return tbk_check_launch(ctx, "sort_runs");
+}

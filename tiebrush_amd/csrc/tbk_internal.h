@@ -22,7 +22,8 @@ enum : uint32_t {
   TBK_DERR_NCIGAR = 1u << 4,    // tiecov: n_cigar >= 256 never terminates in the reference
   TBK_DERR_FRACTIONAL = 1u << 5, // non-integral YC met by an integer-only kernel
   TBK_DERR_OVERFLOW = 1u << 6,
-  TBK_DERR_INTERNAL = 1u << 7
+  TBK_DERR_INTERNAL = 1u << 7,
+  TBK_DERR_BIGBUCKET = 1u << 8  // not an error: the run sort met a (tid,start) bucket longer than its window -> radix fallback
 };
 
 struct KTime {
@@ -138,6 +139,8 @@ struct SortBufs {
 // only_hi / only_lo: bits that take part in the ordering (the rest are payload that must not reorder equal keys)
 int tbk_radix_sort128(tbk_ctx* ctx, SortBufs* b, uint32_t n, uint64_t only_hi = ~0ull, uint64_t only_lo = ~0ull);
 size_t tbk_radix_ws_bytes(uint32_t n);
+// same result for an input made of `nruns` position-sorted runs (msort.hip)
+int tbk_sort_runs(tbk_ctx* ctx, SortBufs* b, uint32_t n, const uint32_t* d_run_off, uint32_t nruns, uint32_t* err);
 
 // ---- pipelines --------------------------------------------------------------------
 int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_in* in, tbk_groups_out* out);
