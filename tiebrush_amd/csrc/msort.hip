@@ -146,6 +146,8 @@ __global__ __launch_bounds__(RF_NT) void msort_refine_k(const uint64_t* __restri
                                                         uint32_t* __restrict__ err) {
   __shared__ uint64_t K[RF_CAP];
   __shared__ uint8_t head[RF_CAP];
+  __shared__ uint16_t bs[RF_CAP], bend[RF_CAP];
+  __shared__ int s_wmax[RF_NT / 64];
   __shared__ uint32_t s_first, s_end;
   const uint32_t r0 = blockIdx.x * RF_W;
   const uint32_t r1 = (m - r0) < (uint32_t)RF_W ? m : r0 + RF_W;
@@ -197,19 +199,57 @@ __global__ __launch_bounds__(RF_NT) void msort_refine_k(const uint64_t* __restri
     }
   }
   __syncthreads();
+  // bucket bounds of every window position: bs[x] = first position of x's bucket (running max of the head positions,
+  // blocked ownership for the scan), bend[first position] = one past the bucket's last position
+  {
+    const uint32_t p0 = threadIdx.x * RF_E;
+    int loc[RF_E];
+    int cur = -1;
+#pragma unroll
+    for (int e = 0; e < RF_E; ++e) {
+      const uint32_t p = p0 + e;
+      if (p < nw && head[p]) cur = (int)p;
+      loc[e] = cur;
+    }
+    int inc = cur;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      int o = __shfl_up(inc, d, 64);
+      if ((int)lane_id() >= d && o > inc) inc = o;
+    }
+    if (lane_id() == 63) s_wmax[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    int pre = __shfl_up(inc, 1, 64);
+    if (lane_id() == 0) pre = -1;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w)
+      if (s_wmax[w] > pre) pre = s_wmax[w];
+#pragma unroll
+    for (int e = 0; e < RF_E; ++e) {
+      const uint32_t p = p0 + e;
+      if (p < nw) bs[p] = (uint16_t)(loc[e] >= 0 ? loc[e] : pre);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < RF_E; ++e) {
+    const uint32_t x = (uint32_t)e * RF_NT + threadIdx.x;
+    if (x < nw) {
+      if (x > 0 && head[x]) bend[bs[x - 1]] = (uint16_t)x;
+      if (x == nw - 1) bend[bs[x]] = (uint16_t)nw;
+    }
+  }
+  __syncthreads();
+  // rank by counting inside the bucket; the bounds are known, so the LDS reads of a loop are independent and pipeline
 #pragma unroll
   for (int e = 0; e < RF_E; ++e) {
     const uint32_t x = (uint32_t)e * RF_NT + threadIdx.x;
     if (x < nw) {
       const uint64_t kx = K[x];
-      uint32_t cnt = 0, back = 0;
-      for (uint32_t j = x; !head[j];) {  // earlier records of the bucket: ties go before x
-        --j;
-        ++back;
-        cnt += K[j] <= kx ? 1u : 0u;
-      }
-      for (uint32_t j = x + 1; j < nw && !head[j]; ++j) cnt += K[j] < kx ? 1u : 0u;
-      const uint32_t dst = ws + x - back + cnt;
+      const uint32_t b0 = bs[x], b1 = bend[b0];
+      uint32_t c0 = 0, c1 = 0;
+      for (uint32_t j = b0; j < x; ++j) c0 += K[j] <= kx ? 1u : 0u;  // earlier records of the bucket: ties go before x
+      for (uint32_t j = x + 1; j < b1; ++j) c1 += K[j] < kx ? 1u : 0u;
+      const uint32_t dst = ws + b0 + c0 + c1;
       ohi[dst] = rh[e];
       olo[dst] = rl[e];
       oval[dst] = rv[e];
