@@ -1206,7 +1206,6 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
   uint64_t* sc = ctx->d_scalars;
   TBK_HIP(hipSetDevice(ctx->device));
   TBK_HIP(hipMemsetAsync(sc, 0, 32 * sizeof(uint64_t), ctx->stream));
-  TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
   {
     uint32_t* icnt = ws_alloc<uint32_t>(ctx, m);
     uint32_t* ioff = ws_alloc<uint32_t>(ctx, m);
@@ -1319,14 +1318,29 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
     uint32_t* d_fo = ws_alloc<uint32_t>(ctx, in->n_files + 1);
     uint8_t* d_tb = ws_alloc<uint8_t>(ctx, in->n_files);
     if (!d_fo || !d_tb) return TBK_ENOMEM;
-    // stage through the pinned scalar block when small, else straight from the caller's memory
-    TBK_HIP(hipMemcpyAsync(d_fo, in->file_off, (size_t)(in->n_files + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-    if (in->tbmerged) {
-      TBK_HIP(hipMemcpyAsync(d_tb, in->tbmerged, in->n_files, hipMemcpyHostToDevice, ctx->stream));
+    // The caller's host arrays may be transient.  Small tables are staged through the context's pinned block, so the
+    // upload is a true asynchronous copy and needs no wait; large ones go straight from the caller's memory and are
+    // waited for.
+    const size_t fo_bytes = (size_t)(in->n_files + 1) * 4, tb_bytes = in->n_files;
+    if (fo_bytes + tb_bytes <= 4096 * sizeof(uint64_t)) {
+      char* stage = (char*)(ctx->h_scalars + 64);
+      memcpy(stage, in->file_off, fo_bytes);
+      TBK_HIP(hipMemcpyAsync(d_fo, stage, fo_bytes, hipMemcpyHostToDevice, ctx->stream));
+      if (in->tbmerged) {
+        memcpy(stage + fo_bytes, in->tbmerged, tb_bytes);
+        TBK_HIP(hipMemcpyAsync(d_tb, stage + fo_bytes, tb_bytes, hipMemcpyHostToDevice, ctx->stream));
+      } else {
+        TBK_HIP(hipMemsetAsync(d_tb, 0, tb_bytes, ctx->stream));
+      }
     } else {
-      TBK_HIP(hipMemsetAsync(d_tb, 0, in->n_files, ctx->stream));
+      TBK_HIP(hipMemcpyAsync(d_fo, in->file_off, fo_bytes, hipMemcpyHostToDevice, ctx->stream));
+      if (in->tbmerged) {
+        TBK_HIP(hipMemcpyAsync(d_tb, in->tbmerged, tb_bytes, hipMemcpyHostToDevice, ctx->stream));
+      } else {
+        TBK_HIP(hipMemsetAsync(d_tb, 0, tb_bytes, ctx->stream));
+      }
+      TBK_HIP(hipStreamSynchronize(ctx->stream));
     }
-    TBK_HIP(hipStreamSynchronize(ctx->stream));  // the caller's host arrays may be transient
     I.file_off = d_fo;
     I.tbm = d_tb;
   }
@@ -1396,7 +1410,6 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
     if (attempt == 4) return TBK_ECOLLISION;
     O.seed = seeds[attempt];
     SortBufs s2 = sb;
-    TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
     TBK_HIP(hipMemsetAsync(sc, 0, 16 * sizeof(uint64_t), ctx->stream));
     TBK_LAUNCH(ctx, "col_keys", col_keys_k, cdiv(n, B), B, 0, I, O, khi, klo, kend, kflags, fidx, ctx->d_err);
     {
@@ -1406,7 +1419,6 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
       TBK_TRY((scan_op_run<EffKey, EffOp, EffLoad, EffStore>(ctx, "col_effkey_scan", n, ld, st, EffOp{}, ident)));
     }
     if (use_runs) TBK_LAUNCH(ctx, "col_runs", col_runs_k, cdiv(I.k + 1, B), B, 0, I.k, I.file_off, head_off, sc + 0, run_off);
-    TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     uint32_t eb = 0;
     TBK_TRY(tbk_sync_err(ctx, &eb));
     if (eb) return tbk_derr_to_status(ctx, eb);
@@ -1424,7 +1436,6 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
       TBK_LAUNCH(ctx, "col_heads", col_heads_k, cdiv(m, B), B, 0, I, O.strategy, m, s2.hi, s2.lo, s2.val, fidx, flags, ghead,
                  ctx->d_err);
       TBK_TRY(tbk_exscan_u32(ctx, ghead, gex, m, sc + 1));
-      TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
       TBK_TRY(tbk_sync_err(ctx, &eb));
       if (runs_now && (eb & TBK_DERR_BIGBUCKET)) {  // redo on the merged (phase-A) order, which the *2 side still holds
         std::swap(s2.hi, s2.hi2);
@@ -1470,12 +1481,19 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
   TBK_LAUNCH(ctx, "col_ginv", col_ginv_k, cdiv(ng, B), B, 0, ng, gperm, ginv);
 
   // ---- ordered YC when a fractional term can occur ----
+  // (only --store-frac and TieBrush-merged inputs can bring one: plain BAM inputs skip the read-back)
+  bool any_tbm = false;
+  if (in->tbmerged)
+    for (uint32_t f = 0; f < in->n_files; ++f) any_tbm |= in->tbmerged[f] != 0;
   {
-    uint32_t eb = 0;
-    TBK_TRY(tbk_sync_err(ctx, &eb));
-    const bool need_ordered = O.store_frac || (eb & TBK_DERR_FRACTIONAL);
-    eb &= ~TBK_DERR_FRACTIONAL;
-    if (eb) return tbk_derr_to_status(ctx, eb);
+    bool need_ordered = false;
+    if (O.store_frac || any_tbm) {
+      uint32_t eb = 0;
+      TBK_TRY(tbk_sync_err(ctx, &eb));
+      need_ordered = O.store_frac || (eb & TBK_DERR_FRACTIONAL);
+      eb &= ~TBK_DERR_FRACTIONAL;
+      if (eb) return tbk_derr_to_status(ctx, eb);
+    }
     if (need_ordered) {
       TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
       SortBufs ob;

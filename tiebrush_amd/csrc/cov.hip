@@ -701,7 +701,6 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
   const uint32_t B = 256;
   uint64_t* sc = ctx->d_scalars;  // [0]=n_bases [1]=sum|yc| [2]=m [3]=nb [4]=S [5]=nspill [6]=ncp [7]=nj [8]=niv [9]=nju
   TBK_HIP(hipMemsetAsync(sc, 0, 16 * sizeof(uint64_t), ctx->stream));
-  TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
 
   uint32_t* valid = ws_alloc<uint32_t>(ctx, n);
   uint32_t* vpos = ws_alloc<uint32_t>(ctx, n);
@@ -728,7 +727,6 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
   TBK_TRY(tbk_exscan_u32(ctx, valid, vpos, n, sc + 2));
   TBK_LAUNCH(ctx, "cov_prep", cov_prep_k, (cdiv(n, B) < 1024u ? cdiv(n, B) : 1024u), B, 0, n, valid, vpos, in->tid, in->pos, in->cig_off, in->cig,
              sample_mode ? (const double*)nullptr : in->yc, want_cov ? 1 : 0, A, jcnt, sc, ctx->d_err);
-  TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   uint32_t eb = 0;
   TBK_TRY(tbk_sync_err(ctx, &eb));
   const bool fractional = (eb & TBK_DERR_FRACTIONAL) != 0;
@@ -749,7 +747,6 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
   }
   TBK_TRY(tbk_exscan_u32(ctx, A.bhead, A.bid, m, sc + 3));
   TBK_LAUNCH(ctx, "cov_bundle_fill", cov_bundle_fill_k, cdiv(m, B), B, 0, m, A);
-  TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   TBK_TRY(tbk_sync_err(ctx, &eb));
   if (eb) return tbk_derr_to_status(ctx, eb);
   const uint32_t nb = (uint32_t)ctx->h_scalars[3];
@@ -826,7 +823,6 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
     TBK_TRY(tbk_exscan_u32(ctx, tile_cp_cnt, tile_cp_off, ntiles, sc + 6));
     TBK_LAUNCH(ctx, "cov_cp_gather", cov_cp_gather_k, ntiles, 64, 0, ntiles, tile_cp_base, tile_cp_cnt, tile_cp_off, cp_pos, cp_val,
                sp, sv);
-    TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     TBK_TRY(tbk_sync_err(ctx, &eb));
     if (eb) return tbk_derr_to_status(ctx, eb);
     const uint32_t ncp = (uint32_t)ctx->h_scalars[6];
@@ -839,7 +835,6 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
   }
 
   if (want_j && !side.th) TBK_TRY(junc_branch(ctx, m, A, in, jcnt, out, &nj, &nju));
-  TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   TBK_TRY(tbk_sync_err(ctx, &eb));
   if (eb) return tbk_derr_to_status(ctx, eb);
   TBK_TRY(tbk_check_launch(ctx, "coverage"));

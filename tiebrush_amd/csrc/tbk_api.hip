@@ -91,10 +91,10 @@ int tbk_check_launch(tbk_ctx* ctx, const char* what) {
 }
 
 int tbk_sync_err(tbk_ctx* ctx, uint32_t* err_bits) {
-  uint32_t* h = (uint32_t*)(ctx->h_scalars + 60);
-  TBK_HIP(hipMemcpyAsync(h, ctx->d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  // the error word is scalar 15: one copy brings the counters of the stage and the error bits
+  TBK_HIP(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   TBK_HIP(hipStreamSynchronize(ctx->stream));
-  *err_bits = *h;
+  *err_bits = (uint32_t)ctx->h_scalars[15];
   return 0;
 }
 
@@ -250,8 +250,8 @@ int tbk_create(int device_ordinal, tbk_ctx** out) {
   if (ok && hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
   ok = ok && hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) == hipSuccess;
   ctx->stream = ctx->own_stream;
-  ok = ok && hipMalloc((void**)&ctx->d_err, 256) == hipSuccess;
   ok = ok && hipMalloc((void**)&ctx->d_scalars, 64 * sizeof(uint64_t)) == hipSuccess;
+  if (ok) ctx->d_err = (uint32_t*)(ctx->d_scalars + 15);
   ok = ok && hipHostMalloc((void**)&ctx->h_scalars, (64 + 4096) * sizeof(uint64_t), hipHostMallocDefault) == hipSuccess;
   if (!ok) {
     tbk_destroy(ctx);
@@ -283,7 +283,6 @@ void tbk_destroy(tbk_ctx* ctx) {
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->d_view) (void)hipFree(ctx->d_view);
-  if (ctx->d_err) (void)hipFree(ctx->d_err);
   if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
   if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

@@ -41,7 +41,7 @@ struct tbk_ctx {
   std::vector<std::pair<char*, size_t>> ws_overflow;
   size_t ws_over_used = 0;
   // small persistent device words + pinned mirror
-  uint32_t* d_err = nullptr;    // [1]
+  uint32_t* d_err = nullptr;    // error bits: the low word of d_scalars[15] (cleared and read back with the counters)
   uint64_t* d_scalars = nullptr; // [64] misc device scalars (counts)
   uint64_t* h_scalars = nullptr; // pinned [64+4096]
   // view storage for tbk_groups_to_cov_in
@@ -117,7 +117,7 @@ static inline void tbk_prof_end(tbk_ctx* ctx) {
   } while (0)
 
 int tbk_check_launch(tbk_ctx* ctx, const char* what);  // hipGetLastError -> TBK_EHIP
-int tbk_sync_err(tbk_ctx* ctx, uint32_t* err_bits);    // stream sync + read d_err
+int tbk_sync_err(tbk_ctx* ctx, uint32_t* err_bits);    // d_scalars[0..15] -> h_scalars, stream sync, error bits
 int tbk_derr_to_status(tbk_ctx* ctx, uint32_t bits);
 
 static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
