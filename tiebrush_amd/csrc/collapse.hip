@@ -1285,6 +1285,18 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       TBK_HIP(hipStreamSynchronize(ctx->stream));
       const uint32_t* hc = (const uint32_t*)(ctx->h_scalars + 24);
       const uint32_t n_short = hc[0], n_long = hc[1];
+      // short chains (a thread each) and long chains (a wave each) are independent: the short ones go to the auxiliary
+      // stream and fill the CUs the few long, latency-bound waves leave idle.  (The stream was synchronised just above,
+      // so the fork needs no event; the join does.)
+      hipStream_t aux = n_short && n_long ? tbk_aux_stream(ctx) : nullptr;
+      if (n_short && aux) {
+        hipStream_t keep = ctx->stream;
+        ctx->stream = aux;
+        TBK_LAUNCH(ctx, "yd_run", yd_run_k, cdiv(n_short, 64), 64, 0, ids_short, ccnt, nchains, nit, chain_first, Y, ib.val, noff, ex_s,
+                   ex_e, N, J.g_yd);
+        ctx->stream = keep;
+        TBK_HIP(hipEventRecord(ctx->aux_done, aux));
+      }
       if (n_long) {
         TBK_LAUNCH(ctx, "yd_wave", yd_wave_k, n_long, 64, 0, ids_long, ccnt + 1, nchains, nit, chain_first, Y, ib.val, noff, ex_s,
                    ex_e, J.g_yd, ids_over, ccnt + 2);
@@ -1292,9 +1304,10 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
         TBK_LAUNCH(ctx, "yd_run_overflow", yd_run_k, cdiv(n_long, 64), 64, 0, ids_over, ccnt + 2, nchains, nit, chain_first, Y, ib.val,
                    noff, ex_s, ex_e, N, J.g_yd);
       }
-      if (n_short)
+      if (n_short && !aux)
         TBK_LAUNCH(ctx, "yd_run", yd_run_k, cdiv(n_short, 64), 64, 0, ids_short, ccnt, nchains, nit, chain_first, Y, ib.val, noff, ex_s,
                    ex_e, N, J.g_yd);
+      if (n_short && aux) TBK_HIP(hipStreamWaitEvent(ctx->stream, ctx->aux_done, 0));
     }
   }
   TBK_LAUNCH(ctx, "col_write_yd", col_write_yd_k, cdiv(ng, B), B, 0, ng, J.gperm, J.G, J.g_yd, J.cap, J.out_yd);

@@ -163,6 +163,17 @@ static int d2h(tbk_ctx* ctx, T* host, const T* dev, size_t n) {
   return 0;
 }
 
+hipStream_t tbk_aux_stream(tbk_ctx* ctx) {
+  if (!ctx->aux) {
+    if (hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) != hipSuccess) ctx->aux = nullptr;
+    if (ctx->aux && hipEventCreateWithFlags(&ctx->aux_done, hipEventDisableTiming) != hipSuccess) {
+      (void)hipStreamDestroy(ctx->aux);
+      ctx->aux = nullptr;
+    }
+  }
+  return ctx->aux;
+}
+
 // ---- side context ----------------------------------------------------------------------------------------
 tbk_ctx* tbk_side_ctx(tbk_ctx* ctx) {
   if (!ctx->side_ctx && tbk_create(ctx->device, &ctx->side_ctx) != 0) ctx->side_ctx = nullptr;
@@ -285,6 +296,8 @@ void tbk_destroy(tbk_ctx* ctx) {
   if (ctx->d_view) (void)hipFree(ctx->d_view);
   if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
   if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
+  if (ctx->aux_done) (void)hipEventDestroy(ctx->aux_done);
+  if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }

@@ -35,6 +35,8 @@ struct tbk_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
+  hipStream_t aux = nullptr;     // second stream for independent kernels inside one stage (created on first use)
+  hipEvent_t aux_done = nullptr;
   // device workspace (bump allocator, reset at the start of each API call)
   char* ws = nullptr;
   size_t ws_cap = 0, ws_off = 0;
@@ -67,6 +69,7 @@ struct tbk_ctx {
 
 // side context (created on first use; nullptr if that fails -> the caller runs the branch inline), and the call
 // bracket a branch thread puts around its work on it
+hipStream_t tbk_aux_stream(tbk_ctx* ctx);  // nullptr if it cannot be created -> the caller stays on one stream
 tbk_ctx* tbk_side_ctx(tbk_ctx* ctx);
 int tbk_side_begin(tbk_ctx* side, size_t arena_hint);
 void tbk_side_end(tbk_ctx* side);
