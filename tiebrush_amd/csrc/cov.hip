@@ -566,22 +566,27 @@ __global__ __launch_bounds__(COV_NT) void cov_tile_ordered_k(uint32_t m, uint64_
 }
 
 // ---- junctions ---------------------------------------------------------------------------------
-__global__ void junc_fill_k(uint32_t m, CovArrays A, const int32_t* __restrict__ pos, const uint32_t* __restrict__ cig_off,
-                            const uint32_t* __restrict__ cig, const uint8_t* __restrict__ strand, const uint32_t* __restrict__ joff,
-                            uint64_t* __restrict__ hi, uint64_t* __restrict__ lo, uint32_t* __restrict__ val) {
+// sort key of a junction item: hi = tid : 32 | start : 32, lo = (end - start + 1) : 32 | strand char : 8.  Bundles are
+// disjoint coordinate ranges in (tid, start) order, so this is the per-bundle (start, end, strand) order of the
+// reference (tiecov.cpp:104, junction flush per bundle) without needing the bundle ids — the branch can start as
+// soon as the valid records are known.  The length form keeps the high bytes of `lo` constant (fewer radix passes).
+__global__ void junc_fill_k(uint32_t m, CovArrays A, const int32_t* __restrict__ tid, const int32_t* __restrict__ pos,
+                            const uint32_t* __restrict__ cig_off, const uint32_t* __restrict__ cig,
+                            const uint8_t* __restrict__ strand, const uint32_t* __restrict__ joff, uint64_t* __restrict__ hi,
+                            uint64_t* __restrict__ lo, uint32_t* __restrict__ val) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= m) return;
   uint32_t i = A.ridx[j];
   uint32_t o = joff[j];
-  uint32_t b = A.bid[j];
+  uint64_t t = (uint64_t)(uint32_t)tid[i] << 32;
   uint32_t st = strand ? strand[i] : (uint32_t)'.';
   int prev_end = 0;
   int k = 0, nex = 0;
   walk_exons(pos[i], cig + cig_off[i], cig_off[i + 1] - cig_off[i],
              [&](int es, int ee) {
                if (k > 0) {  // CJunc(exons[i-1].end+1, exons[i].start-1, strand) tiecov.cpp:104
-                 hi[o] = ((uint64_t)b << 32) | (uint32_t)(prev_end + 1);
-                 lo[o] = ((uint64_t)(uint32_t)(es - 1) << 8) | st;
+                 hi[o] = t | (uint32_t)(prev_end + 1);
+                 lo[o] = ((uint64_t)(uint32_t)(es - 1 - prev_end) << 8) | st;  // end - start + 1 (0 for an empty N)
                  val[o] = j;
                  ++o;
                }
@@ -613,10 +618,10 @@ __global__ void junc_write_k(uint32_t nj, CovArrays A, const uint64_t* __restric
     s += yc ? yc[A.ridx[val[r]]] : 1.0;
     ++r;
   } while (r < nj && !head[r]);
-  uint32_t b = (uint32_t)(hi[q] >> 32);
-  j_tid[o] = A.b_tid[b];
-  j_start[o] = (int32_t)(uint32_t)(hi[q] & 0xFFFFFFFFu) - 1;
-  j_end[o] = (int32_t)(uint32_t)(lo[q] >> 8);
+  const int32_t start = (int32_t)(uint32_t)(hi[q] & 0xFFFFFFFFu);
+  j_tid[o] = (int32_t)(uint32_t)(hi[q] >> 32);
+  j_start[o] = start - 1;
+  j_end[o] = start + (int32_t)(uint32_t)(lo[q] >> 8) - 1;
   j_strand[o] = (uint8_t)(lo[q] & 0xFFu);
   j_val[o] = s;
 }
@@ -637,8 +642,8 @@ __global__ void sample_convert_k(uint32_t n, const double* __restrict__ v, float
 }  // namespace
 
 // ---- junction branch ---------------------------------------------------------------------------------------
-// items (one per N op of a valid record) -> sort by (bundle,start | end,strand) -> heads -> ordered sums.  Independent
-// of the interval branch once the bundles exist, so tbk_coverage_device runs it on a side context (own stream, own
+// items (one per N op of a valid record) -> sort by (tid,start | length,strand) -> heads -> ordered sums.  Independent
+// of the interval branch once the valid records are compacted, so tbk_coverage_device runs it on a side context (own stream, own
 // arena, own host thread) while the main stream builds the intervals; `ctx` is whichever context it runs on.
 constexpr uint32_t COV_SIDE_MIN = 1u << 16;  // below this many records the fork costs more than it hides
 static int junc_branch(tbk_ctx* ctx, uint32_t m, const CovArrays& A, const tbk_cov_in* in, const uint32_t* jcnt, tbk_cov_out* out,
@@ -664,8 +669,8 @@ static int junc_branch(tbk_ctx* ctx, uint32_t m, const CovArrays& A, const tbk_c
   uint32_t* head = ws_alloc<uint32_t>(ctx, nj);
   uint32_t* hoff = ws_alloc<uint32_t>(ctx, nj);
   if (!hoff) return TBK_ENOMEM;
-  TBK_LAUNCH(ctx, "junc_fill", junc_fill_k, cdiv(m, B), B, 0, m, A, in->pos, in->cig_off, in->cig, in->strand, joff, sb.hi, sb.lo,
-             sb.val);
+  TBK_LAUNCH(ctx, "junc_fill", junc_fill_k, cdiv(m, B), B, 0, m, A, in->tid, in->pos, in->cig_off, in->cig, in->strand, joff, sb.hi,
+             sb.lo, sb.val);
   TBK_TRY(tbk_radix_sort128(ctx, &sb, nj));
   TBK_LAUNCH(ctx, "junc_head", junc_head_k, cdiv(nj, B), B, 0, nj, sb.hi, sb.lo, head);
   TBK_TRY(tbk_exscan_u32(ctx, head, hoff, nj, sc + 9));
@@ -737,6 +742,17 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
   out->n_bases = ctx->h_scalars[0];
   const uint64_t sum_abs = ctx->h_scalars[1];
   if (m == 0) return 0;
+  if (want_j && want_cov && m >= COV_SIDE_MIN) {  // the valid records are compacted (the stream was just synchronised): fork the junction branch
+    tbk_ctx* jc = tbk_side_ctx(ctx);
+    if (jc) {
+      const size_t hint = (size_t)m * 8 + (size_t)in->n_cigar_ops * 56 + ((size_t)4 << 20);
+      side.th = new std::thread([&side, jc, hint, m, &A, in, jcnt, out, &nj, &nju]() {
+        side.rc = tbk_side_begin(jc, hint);
+        if (side.rc == 0) side.rc = junc_branch(jc, m, A, in, jcnt, out, &nj, &nju);
+        tbk_side_end(jc);
+      });
+    }
+  }
 
   // bundles
   {
@@ -750,17 +766,6 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
   TBK_TRY(tbk_sync_err(ctx, &eb));
   if (eb) return tbk_derr_to_status(ctx, eb);
   const uint32_t nb = (uint32_t)ctx->h_scalars[3];
-  if (want_j && want_cov && m >= COV_SIDE_MIN) {  // bundles exist (the stream was just synchronised): fork the junction branch
-    tbk_ctx* jc = tbk_side_ctx(ctx);
-    if (jc) {
-      const size_t hint = (size_t)m * 8 + (size_t)in->n_cigar_ops * 56 + ((size_t)4 << 20);
-      side.th = new std::thread([&side, jc, hint, m, &A, in, jcnt, out, &nj, &nju]() {
-        side.rc = tbk_side_begin(jc, hint);
-        if (side.rc == 0) side.rc = junc_branch(jc, m, A, in, jcnt, out, &nj, &nju);
-        tbk_side_end(jc);
-      });
-    }
-  }
   TBK_LAUNCH(ctx, "cov_bundle_span", cov_bundle_span_k, cdiv(nb, B), B, 0, nb, A);
   TBK_TRY(tbk_exscan_u32_u64(ctx, A.b_span, A.b_off, nb, sc + 4));
   // b_off[nb] = S (device-to-device copy of the total)
