@@ -6,7 +6,9 @@
 #include "tbk_internal.h"
 
 // =====================================================================================
-// exclusive scan (u32 in, u32 or u64 out) — reduce / spine / down-sweep
+// exclusive scan (u32 in, u32 or u64 out) — reduce / spine / down-sweep (one block when the input is small).
+// Fusing the passes through in-kernel hand-offs (look-back chains, last-block-done tickets) was measured SLOWER on
+// gfx950: every agent-scope release writes the XCD's L2 back, which costs more than a kernel boundary.
 // =====================================================================================
 namespace {
 constexpr int SC_NT = 256;
@@ -54,6 +56,32 @@ __global__ __launch_bounds__(1024) void scan_spine_k(uint64_t* __restrict__ part
     __syncthreads();
   }
   if (threadIdx.x == 0 && total) *total = carry_s;
+}
+
+// n <= SC_SMALL: the whole scan in one block
+constexpr uint32_t SC_SMALL = 8192;
+template <class OutT>
+__global__ __launch_bounds__(1024) void scan_small_k(const uint32_t* __restrict__ in, OutT* __restrict__ out, uint32_t n,
+                                                     uint64_t* __restrict__ total) {
+  __shared__ uint64_t sm[16];
+  constexpr uint32_t E = SC_SMALL / 1024;  // consecutive elements per thread
+  uint32_t v[E];
+  uint64_t s = 0;
+#pragma unroll
+  for (uint32_t e = 0; e < E; ++e) {
+    const uint32_t i = threadIdx.x * E + e;
+    v[e] = i < n ? in[i] : 0u;
+    s += v[e];
+  }
+  uint64_t tot;
+  uint64_t ex = block_excl_sum<uint64_t, 1024>(s, sm, &tot);
+#pragma unroll
+  for (uint32_t e = 0; e < E; ++e) {
+    const uint32_t i = threadIdx.x * E + e;
+    if (i < n) out[i] = (OutT)ex;
+    ex += v[e];
+  }
+  if (threadIdx.x == 0 && total) *total = tot;
 }
 
 template <class OutT>
@@ -104,6 +132,10 @@ int exscan_impl(tbk_ctx* ctx, const uint32_t* in, OutT* out, uint32_t n, uint64_
       if (e != hipSuccess) return TBK_EHIP;
     }
     return 0;
+  }
+  if (n <= SC_SMALL) {
+    TBK_LAUNCH(ctx, "scan_small", (scan_small_k<OutT>), 1, 1024, 0, in, out, n, d_total);
+    return tbk_check_launch(ctx, "exscan");
   }
   uint32_t nb = cdiv(n, SC_TILE);
   uint64_t* part = ws_alloc<uint64_t>(ctx, nb);

@@ -44,31 +44,19 @@ int main() {
   t("kernel + memcpyAsync D2H + sync", [&] { bump<<<1, 64, 0, s>>>(d, nullptr); hipMemcpyAsync(hp, d, 64, hipMemcpyDeviceToHost, s); hipStreamSynchronize(s); });
   t("kernel + 2 memcpyAsync D2H + sync", [&] { bump<<<1, 64, 0, s>>>(d, nullptr); hipMemcpyAsync(hp, d, 32, hipMemcpyDeviceToHost, s); hipMemcpyAsync(hp + 4, d + 4, 4, hipMemcpyDeviceToHost, s); hipStreamSynchronize(s); });
   t("kernel writing mapped host word + sync", [&] { bump<<<1, 64, 0, s>>>(d, hm_dev); hipStreamSynchronize(s); });
+  t("kernel + spin on hipStreamQuery", [&] { bump<<<1, 64, 0, s>>>(d, nullptr); while (hipStreamQuery(s) == hipErrorNotReady) {} });
+  t("kernel + memcpyAsync D2H + spin hipStreamQuery", [&] { bump<<<1, 64, 0, s>>>(d, nullptr); hipMemcpyAsync(hp, d, 64, hipMemcpyDeviceToHost, s); while (hipStreamQuery(s) == hipErrorNotReady) {} });
+  t("kernel + mapped word + spin hipStreamQuery", [&] { bump<<<1, 64, 0, s>>>(d, hm_dev); while (hipStreamQuery(s) == hipErrorNotReady) {} });
+  {
+    hipEvent_t ev;
+    hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    t("kernel + eventRecord + spin hipEventQuery", [&] { bump<<<1, 64, 0, s>>>(d, nullptr); hipEventRecord(ev, s); while (hipEventQuery(ev) == hipErrorNotReady) {} });
+    t("kernel + eventRecord + hipEventSynchronize", [&] { bump<<<1, 64, 0, s>>>(d, nullptr); hipEventRecord(ev, s); hipEventSynchronize(ev); });
+  }
   t("work(2M) kernel + sync", [&] { work<<<n / 256, 256, 0, s>>>(x, n); hipStreamSynchronize(s); });
   t("work(2M) x2 async", [&] { work<<<n / 256, 256, 0, s>>>(x, n); work<<<n / 256, 256, 0, s>>>(x, n); });
   t("memsetAsync 128B", [&] { hipMemsetAsync(d, 0, 64, s); });
   volatile unsigned long long sink = *hm + *hp;
   (void)sink;
-  // polling a mapped word instead of hipStreamSynchronize
-  {
-    *hm = 0;
-    hipMemset(d, 0, 64);
-    unsigned long long expect = 0;
-    auto t0 = std::chrono::steady_clock::now();
-    for (int i = 0; i < R; ++i) {
-      ++expect;
-      bump<<<1, 64, 0, s>>>(d, hm_dev);
-      long spins = 0;
-      while (*(volatile unsigned long long*)hm != expect && ++spins < 200000000L) {
-      }
-      if (spins >= 200000000L) {
-        printf("spin never saw the value (iteration %d)\n", i);
-        hipStreamSynchronize(s);
-        return 0;
-      }
-    }
-    double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / R;
-    printf("%-46s %8.2f us/iter\n", "kernel writing mapped word + host spin on it", us);
-  }
   return 0;
 }
