@@ -352,11 +352,15 @@ __global__ void col_runs_k(uint32_t k, const uint32_t* __restrict__ file_off, co
 
 // ---- K4: heads -------------------------------------------------------------------------------------
 // flags: bit0 group head, bit1 tie-set head, bit2 file head (first record of its file in the group)
-__global__ void col_heads_k(ColIn I, int strategy, uint32_t m, const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo,
+__global__ void col_heads_k(ColIn I, int strategy, const uint64_t* __restrict__ pm, uint32_t m_hi, const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo,
                             const uint32_t* __restrict__ val, const uint16_t* __restrict__ fidx, uint8_t* __restrict__ flags,
                             uint32_t* __restrict__ ghead, uint32_t* __restrict__ err) {
+  const uint32_t m = (uint32_t)*pm;
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= m) return;
+  if (q >= m) {  // (the grid covers the host's upper bound m_hi: the scan behind this kernel reads zeros there)
+    if (q < m_hi) ghead[q] = 0u;
+    return;
+  }
   uint32_t gi = val[q];
   bool bucket_head = true, group_head = true, tie_head = true, file_head = true;
   if (q > 0) {
@@ -394,9 +398,10 @@ __device__ __forceinline__ T seg_reduce(T v, uint32_t key, Op op) {
   return v;
 }
 
-__global__ void col_reduce_k(ColIn I, ColOpt O, uint32_t m, const uint32_t* __restrict__ val, const uint8_t* __restrict__ flags,
+__global__ void col_reduce_k(ColIn I, ColOpt O, const uint64_t* __restrict__ pm, const uint32_t* __restrict__ val, const uint8_t* __restrict__ flags,
                              const uint32_t* __restrict__ gex, const uint16_t* __restrict__ fidx,
                              const int32_t* __restrict__ effend, GroupAcc G, uint32_t* __restrict__ sgid, uint32_t* __restrict__ err) {
+  const uint32_t m = (uint32_t)*pm;
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   bool act = q < m;
   uint32_t sg = 0xFFFFFFFFu;
@@ -449,8 +454,9 @@ __global__ void col_reduce_k(ColIn I, ColOpt O, uint32_t m, const uint32_t* __re
 
 // -A (collapse_same): a non-first record of its file whose (qname,pairOrder) equals the representative's
 // is not counted (tiebrush.cpp:422-424)
-__global__ void col_same_k(ColIn I, ColOpt O, uint32_t m, const uint32_t* __restrict__ val, const uint8_t* __restrict__ flags,
+__global__ void col_same_k(ColIn I, ColOpt O, const uint64_t* __restrict__ pm, const uint32_t* __restrict__ val, const uint8_t* __restrict__ flags,
                            const uint32_t* __restrict__ sgid, const uint16_t* __restrict__ fidx, GroupAcc G) {
+  const uint32_t m = (uint32_t)*pm;
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= m) return;
   uint32_t gi = val[q];
@@ -503,7 +509,8 @@ __global__ void ord_sum_k(ColIn I, ColOpt O, uint32_t ng, uint32_t m, const uint
 
 // cross-rank stitch: the representative is the member with the smallest explicit priority (groups have at most one
 // member per rank, so a serial scan of the group's contiguous members is cheap)
-__global__ void col_rep_prio_k(ColIn I, uint32_t ng, uint32_t m, const uint32_t* __restrict__ val, GroupAcc G) {
+__global__ void col_rep_prio_k(ColIn I, const uint64_t* __restrict__ png, const uint64_t* __restrict__ pm, const uint32_t* __restrict__ val, GroupAcc G) {
+  const uint32_t ng = (uint32_t)*png, m = (uint32_t)*pm;
   uint32_t sg = blockIdx.x * blockDim.x + threadIdx.x;
   if (sg >= ng) return;
   uint32_t q0 = G.first[sg], q1 = (sg + 1 < ng) ? G.first[sg + 1] : m;
@@ -516,13 +523,15 @@ __global__ void col_rep_prio_k(ColIn I, uint32_t ng, uint32_t m, const uint32_t*
 }
 
 // ---- tie sets: order groups that share (bucket,strand,end) by the reference comparator -----------------
-__global__ void col_tie_init_k(ColIn I, int strategy, uint32_t ng, const uint32_t* __restrict__ val, GroupAcc G, uint32_t* __restrict__ gperm) {
+__global__ void col_tie_init_k(ColIn I, int strategy, const uint64_t* __restrict__ png, const uint32_t* __restrict__ val, GroupAcc G, uint32_t* __restrict__ gperm) {
+  const uint32_t ng = (uint32_t)*png;
   uint32_t sg = blockIdx.x * blockDim.x + threadIdx.x;
   if (sg >= ng) return;
   gperm[sg] = sg;
 }
-__global__ void col_tie_sort_k(ColIn I, int strategy, uint32_t ng, const uint32_t* __restrict__ val, GroupAcc G,
+__global__ void col_tie_sort_k(ColIn I, int strategy, const uint64_t* __restrict__ png, const uint32_t* __restrict__ val, GroupAcc G,
                                uint32_t* __restrict__ gperm) {
+  const uint32_t ng = (uint32_t)*png;
   uint32_t sg = blockIdx.x * blockDim.x + threadIdx.x;
   if (sg >= ng || !G.tie[sg]) return;
   uint32_t e = 1;
@@ -545,7 +554,8 @@ __global__ void col_tie_sort_k(ColIn I, int strategy, uint32_t ng, const uint32_
     gperm[sg + b] = x;
   }
 }
-__global__ void col_ginv_k(uint32_t ng, const uint32_t* __restrict__ gperm, uint32_t* __restrict__ ginv) {
+__global__ void col_ginv_k(const uint64_t* __restrict__ png, const uint32_t* __restrict__ gperm, uint32_t* __restrict__ ginv) {
+  const uint32_t ng = (uint32_t)*png;
   uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o < ng) ginv[gperm[o]] = o;
 }
@@ -1145,11 +1155,12 @@ __global__ void col_write_yd_k(uint32_t ng, const uint32_t* __restrict__ gperm, 
   yd[o] = dmax > 0 ? dmax : 0;
 }
 
-__global__ void col_write_k(uint32_t ng, const uint32_t* __restrict__ gperm, GroupAcc G,
+__global__ void col_write_k(const uint64_t* __restrict__ png, const uint32_t* __restrict__ gperm, GroupAcc G,
                             const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo, uint32_t cap,
                             uint32_t* __restrict__ rep, double* __restrict__ yc, int64_t* __restrict__ yx,
                             int32_t* __restrict__ g_start, int32_t* __restrict__ g_end, const int32_t* __restrict__ effend,
                             int32_t* __restrict__ rep_effend) {
+  const uint32_t ng = (uint32_t)*png;
   uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= ng || o >= cap) return;
   uint32_t sg = gperm[o];
@@ -1162,13 +1173,15 @@ __global__ void col_write_k(uint32_t ng, const uint32_t* __restrict__ gperm, Gro
   if (g_start) g_start[o] = st;
   if (g_end) g_end[o] = st + (int32_t)(uint32_t)(slo[q] >> 32) - 1;
 }
-__global__ void col_recgroup_k(uint32_t m, const uint32_t* __restrict__ val, const uint32_t* __restrict__ sgid,
+__global__ void col_recgroup_k(const uint64_t* __restrict__ pm, const uint32_t* __restrict__ val, const uint32_t* __restrict__ sgid,
                                const uint32_t* __restrict__ ginv, int32_t* __restrict__ rec_group) {
+  const uint32_t m = (uint32_t)*pm;
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q < m) rec_group[val[q]] = (int32_t)ginv[sgid[q]];
 }
 
-__global__ void col_init_groups_k(uint32_t ng, GroupAcc G, int32_t* __restrict__ g_yd) {
+__global__ void col_init_groups_k(const uint64_t* __restrict__ png, GroupAcc G, int32_t* __restrict__ g_yd) {
+  const uint32_t ng = (uint32_t)*png;
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= ng) return;
   G.yc[g] = 0.0;
@@ -1420,9 +1433,18 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
   int32_t* g_yd = nullptr;
   uint32_t* gperm = nullptr;
   uint32_t* ginv = nullptr;
+  bool any_tbm = false;
+  if (in->tbmerged)
+    for (uint32_t f = 0; f < in->n_files; ++f) any_tbm |= in->tbmerged[f] != 0;
+  // Every kernel reads the record / group counts from the device scalars (sc[0] = passing records, sc[1] = groups), so
+  // the host only needs them where it must size something by them.  "Lean" tiles — plain BAM inputs on the run-sort
+  // path, integral YC — need that nowhere: grids and arrays take the upper bound n, nothing is read back until the
+  // single synchronisation at the end, and the rare events that want a different path (a bucket too long for the
+  // local sort, a key-hash collision) simply restart the tile.
+  bool lean = use_runs && !O.store_frac && !any_tbm && n >= runs_min;
   const uint64_t seeds[4] = {0x71EB5EEDull, 0xA5A5F00DCAFE1234ull, 0x0123456789ABCDEFull, 0xDEADBEEF0BADF00Dull};
   int attempt = 0;
-  for (;; ++attempt) {
+  for (;;) {
     if (attempt == 4) return TBK_ECOLLISION;
     O.seed = seeds[attempt];
     SortBufs s2 = sb;
@@ -1436,22 +1458,27 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
     }
     if (use_runs) TBK_LAUNCH(ctx, "col_runs", col_runs_k, cdiv(I.k + 1, B), B, 0, I.k, I.file_off, head_off, sc + 0, run_off);
     uint32_t eb = 0;
-    TBK_TRY(tbk_sync_err(ctx, &eb));
-    if (eb) return tbk_derr_to_status(ctx, eb);
-    m = (uint32_t)ctx->h_scalars[0];
-    out->n_passed = m;
-    if (m == 0) return 0;
+    uint32_t m_hi = n, ng_hi = n;  // what sizes grids and arrays: the counts themselves, or their upper bound
+    if (!lean) {
+      TBK_TRY(tbk_sync_err(ctx, &eb));
+      if (eb) return tbk_derr_to_status(ctx, eb);
+      m = (uint32_t)ctx->h_scalars[0];
+      out->n_passed = m;
+      if (m == 0) return 0;
+      m_hi = m;
+    }
     // The files are position-sorted runs (verified by the scan above): merge them and order each (tid,start) bucket
     // locally (msort.hip).  Many files, a small tile, or a bucket longer than the local window take the radix sort.
-    bool runs_now = use_runs && m >= runs_min;
+    bool runs_now = use_runs && (lean || m >= runs_min);
     for (;;) {
       if (runs_now)
-        TBK_TRY(tbk_sort_runs(ctx, &s2, m, run_off, I.k, ctx->d_err));
+        TBK_TRY(tbk_sort_runs(ctx, &s2, m_hi, run_off, I.k, ctx->d_err));
       else
         TBK_TRY(tbk_radix_sort128(ctx, &s2, m));
-      TBK_LAUNCH(ctx, "col_heads", col_heads_k, cdiv(m, B), B, 0, I, O.strategy, m, s2.hi, s2.lo, s2.val, fidx, flags, ghead,
-                 ctx->d_err);
-      TBK_TRY(tbk_exscan_u32(ctx, ghead, gex, m, sc + 1));
+      TBK_LAUNCH(ctx, "col_heads", col_heads_k, cdiv(m_hi, B), B, 0, I, O.strategy, sc + 0, m_hi, s2.hi, s2.lo, s2.val, fidx, flags,
+                 ghead, ctx->d_err);
+      TBK_TRY(tbk_exscan_u32(ctx, ghead, gex, m_hi, sc + 1));
+      if (lean) break;
       TBK_TRY(tbk_sync_err(ctx, &eb));
       if (runs_now && (eb & TBK_DERR_BIGBUCKET)) {  // redo on the merged (phase-A) order, which the *2 side still holds
         std::swap(s2.hi, s2.hi2);
@@ -1463,9 +1490,81 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
       }
       break;
     }
-    if (eb & TBK_DERR_COLLISION) continue;  // reseed
-    if (eb) return tbk_derr_to_status(ctx, eb);
-    ng = (uint32_t)ctx->h_scalars[1];
+    if (!lean) {
+      if (eb & TBK_DERR_COLLISION) {  // reseed
+        ++attempt;
+        continue;
+      }
+      if (eb) return tbk_derr_to_status(ctx, eb);
+      ng = (uint32_t)ctx->h_scalars[1];
+      if (ng > out->cap_groups) {
+        out->n_groups = ng;
+        return TBK_E2BIG;
+      }
+      ng_hi = ng;
+    }
+    const uint64_t *pm = sc + 0, *png = sc + 1;
+    G.yc = ws_alloc<double>(ctx, ng_hi);
+    G.ns = ws_alloc<uint32_t>(ctx, ng_hi);
+    G.yxin = ws_alloc<long long>(ctx, ng_hi);
+    G.ydin = ws_alloc<long long>(ctx, ng_hi);
+    G.rep = ws_alloc<unsigned long long>(ctx, ng_hi);
+    G.first = ws_alloc<uint32_t>(ctx, ng_hi);
+    G.tie = ws_alloc<uint8_t>(ctx, ng_hi);
+    g_yd = ws_alloc<int32_t>(ctx, ng_hi);
+    gperm = ws_alloc<uint32_t>(ctx, ng_hi);
+    ginv = ws_alloc<uint32_t>(ctx, ng_hi);
+    if (!ginv) return TBK_ENOMEM;
+    TBK_LAUNCH(ctx, "col_init_groups", col_init_groups_k, cdiv(ng_hi, B), B, 0, png, G, g_yd);
+    TBK_LAUNCH(ctx, "col_reduce", col_reduce_k, cdiv(m_hi, B), B, 0, I, O, pm, s2.val, flags, gex, fidx, effend, G, sgid, ctx->d_err);
+    if (I.prio_hi && I.prio_lo) TBK_LAUNCH(ctx, "col_rep_prio", col_rep_prio_k, cdiv(ng_hi, B), B, 0, I, png, pm, s2.val, G);
+    if (O.collapse_same) TBK_LAUNCH(ctx, "col_same", col_same_k, cdiv(m_hi, B), B, 0, I, O, pm, s2.val, flags, sgid, fidx, G);
+    TBK_LAUNCH(ctx, "col_tie_init", col_tie_init_k, cdiv(ng_hi, B), B, 0, I, O.strategy, png, s2.val, G, gperm);
+    TBK_LAUNCH(ctx, "col_tie_sort", col_tie_sort_k, cdiv(ng_hi, B), B, 0, I, O.strategy, png, s2.val, G, gperm);
+    TBK_LAUNCH(ctx, "col_ginv", col_ginv_k, cdiv(ng_hi, B), B, 0, png, gperm, ginv);
+
+    // ---- ordered YC when a fractional term can occur (only --store-frac and TieBrush-merged inputs can bring one;
+    // such tiles are never lean, so m and ng are known here) ----
+    if (O.store_frac || any_tbm) {
+      TBK_TRY(tbk_sync_err(ctx, &eb));
+      const bool need_ordered = O.store_frac || (eb & TBK_DERR_FRACTIONAL);
+      eb &= ~TBK_DERR_FRACTIONAL;
+      if (eb) return tbk_derr_to_status(ctx, eb);
+      if (need_ordered) {
+        TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
+        SortBufs ob;
+        ob.hi = ws_alloc<uint64_t>(ctx, m);
+        ob.lo = ws_alloc<uint64_t>(ctx, m);
+        ob.val = ws_alloc<uint32_t>(ctx, m);
+        ob.hi2 = ws_alloc<uint64_t>(ctx, m);
+        ob.lo2 = ws_alloc<uint64_t>(ctx, m);
+        ob.val2 = ws_alloc<uint32_t>(ctx, m);
+        uint8_t* fh_by_rec = ws_alloc<uint8_t>(ctx, n);
+        if (!ob.val2 || !fh_by_rec) return TBK_ENOMEM;
+        TBK_LAUNCH(ctx, "ord_fill", ord_fill_k, cdiv(m, B), B, 0, m, s2.val, sgid, effend, flags, ob.hi, ob.lo, ob.val, fh_by_rec);
+        TBK_TRY(tbk_radix_sort128(ctx, &ob, m));
+        TBK_LAUNCH(ctx, "ord_sum", ord_sum_k, cdiv(ng, 64), 64, 0, I, O, ng, m, ob.val, fidx, fh_by_rec, G);
+      }
+    }
+    TBK_LAUNCH(ctx, "col_write", col_write_k, cdiv(ng_hi, B), B, 0, png, gperm, G, s2.hi, s2.lo, out->cap_groups, out->rep, out->yc,
+               out->yx, out->g_start, out->g_end, effend, out->rep_effend);
+    if (out->rec_group) TBK_LAUNCH(ctx, "col_recgroup", col_recgroup_k, cdiv(m_hi, B), B, 0, pm, s2.val, sgid, ginv, out->rec_group);
+    TBK_TRY(tbk_sync_err(ctx, &eb));
+    if (lean) {
+      if (eb & TBK_DERR_BIGBUCKET) {  // same keys again, on the radix path (the counts are read back there)
+        use_runs = false;
+        lean = false;
+        continue;
+      }
+      if (eb & TBK_DERR_COLLISION) {  // reseed
+        ++attempt;
+        continue;
+      }
+      m = (uint32_t)ctx->h_scalars[0];
+      ng = (uint32_t)ctx->h_scalars[1];
+      out->n_passed = m;
+    }
+    if (eb & ~TBK_DERR_FRACTIONAL) return tbk_derr_to_status(ctx, eb);
     sb = s2;
     if (attempt > 0) {
       char b[96];
@@ -1475,65 +1574,8 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
     break;
   }
   out->n_groups = ng;
+  if (m == 0) return 0;
   if (ng > out->cap_groups) return TBK_E2BIG;
-
-  G.yc = ws_alloc<double>(ctx, ng);
-  G.ns = ws_alloc<uint32_t>(ctx, ng);
-  G.yxin = ws_alloc<long long>(ctx, ng);
-  G.ydin = ws_alloc<long long>(ctx, ng);
-  G.rep = ws_alloc<unsigned long long>(ctx, ng);
-  G.first = ws_alloc<uint32_t>(ctx, ng);
-  G.tie = ws_alloc<uint8_t>(ctx, ng);
-  g_yd = ws_alloc<int32_t>(ctx, ng);
-  gperm = ws_alloc<uint32_t>(ctx, ng);
-  ginv = ws_alloc<uint32_t>(ctx, ng);
-  if (!ginv) return TBK_ENOMEM;
-  TBK_LAUNCH(ctx, "col_init_groups", col_init_groups_k, cdiv(ng, B), B, 0, ng, G, g_yd);
-  TBK_LAUNCH(ctx, "col_reduce", col_reduce_k, cdiv(m, B), B, 0, I, O, m, sb.val, flags, gex, fidx, effend, G, sgid, ctx->d_err);
-  if (I.prio_hi && I.prio_lo) TBK_LAUNCH(ctx, "col_rep_prio", col_rep_prio_k, cdiv(ng, B), B, 0, I, ng, m, sb.val, G);
-  if (O.collapse_same) TBK_LAUNCH(ctx, "col_same", col_same_k, cdiv(m, B), B, 0, I, O, m, sb.val, flags, sgid, fidx, G);
-  TBK_LAUNCH(ctx, "col_tie_init", col_tie_init_k, cdiv(ng, B), B, 0, I, O.strategy, ng, sb.val, G, gperm);
-  TBK_LAUNCH(ctx, "col_tie_sort", col_tie_sort_k, cdiv(ng, B), B, 0, I, O.strategy, ng, sb.val, G, gperm);
-  TBK_LAUNCH(ctx, "col_ginv", col_ginv_k, cdiv(ng, B), B, 0, ng, gperm, ginv);
-
-  // ---- ordered YC when a fractional term can occur ----
-  // (only --store-frac and TieBrush-merged inputs can bring one: plain BAM inputs skip the read-back)
-  bool any_tbm = false;
-  if (in->tbmerged)
-    for (uint32_t f = 0; f < in->n_files; ++f) any_tbm |= in->tbmerged[f] != 0;
-  {
-    bool need_ordered = false;
-    if (O.store_frac || any_tbm) {
-      uint32_t eb = 0;
-      TBK_TRY(tbk_sync_err(ctx, &eb));
-      need_ordered = O.store_frac || (eb & TBK_DERR_FRACTIONAL);
-      eb &= ~TBK_DERR_FRACTIONAL;
-      if (eb) return tbk_derr_to_status(ctx, eb);
-    }
-    if (need_ordered) {
-      TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
-      SortBufs ob;
-      ob.hi = ws_alloc<uint64_t>(ctx, m);
-      ob.lo = ws_alloc<uint64_t>(ctx, m);
-      ob.val = ws_alloc<uint32_t>(ctx, m);
-      ob.hi2 = ws_alloc<uint64_t>(ctx, m);
-      ob.lo2 = ws_alloc<uint64_t>(ctx, m);
-      ob.val2 = ws_alloc<uint32_t>(ctx, m);
-      uint8_t* fh_by_rec = ws_alloc<uint8_t>(ctx, n);
-      if (!ob.val2 || !fh_by_rec) return TBK_ENOMEM;
-      TBK_LAUNCH(ctx, "ord_fill", ord_fill_k, cdiv(m, B), B, 0, m, sb.val, sgid, effend, flags, ob.hi, ob.lo, ob.val, fh_by_rec);
-      TBK_TRY(tbk_radix_sort128(ctx, &ob, m));
-      TBK_LAUNCH(ctx, "ord_sum", ord_sum_k, cdiv(ng, 64), 64, 0, I, O, ng, m, ob.val, fidx, fh_by_rec, G);
-    }
-  }
-  TBK_LAUNCH(ctx, "col_write", col_write_k, cdiv(ng, B), B, 0, ng, gperm, G, sb.hi, sb.lo, out->cap_groups, out->rep, out->yc, out->yx,
-             out->g_start, out->g_end, effend, out->rep_effend);
-  if (out->rec_group) TBK_LAUNCH(ctx, "col_recgroup", col_recgroup_k, cdiv(m, B), B, 0, m, sb.val, sgid, ginv, out->rec_group);
-  {
-    uint32_t eb = 0;
-    TBK_TRY(tbk_sync_err(ctx, &eb));
-    if (eb & ~TBK_DERR_FRACTIONAL) return tbk_derr_to_status(ctx, eb);
-  }
   TBK_TRY(tbk_check_launch(ctx, "collapse"));
   // ---- YD stage: handed to the caller (tbk_api) as a job — run inline or deferred on the side context ----
   YdJob* job = new YdJob();

@@ -52,8 +52,11 @@ __device__ __forceinline__ uint32_t mpath_wave(const uint64_t* __restrict__ A, u
 // one round: every pair of adjacent runs of round r becomes one run of round r + 1
 __global__ __launch_bounds__(MG_NT) void msort_merge_k(const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo,
                                                        const uint32_t* __restrict__ val, uint64_t* __restrict__ ohi,
-                                                       uint64_t* __restrict__ olo, uint32_t* __restrict__ oval, uint32_t n,
+                                                       uint64_t* __restrict__ olo, uint32_t* __restrict__ oval,
                                                        const uint32_t* __restrict__ run_off, uint32_t k, uint32_t r) {
+  // (the grid covers the host's upper bound of the record count; the count itself is the end of the last run)
+  const uint32_t n = run_off[k];
+  if ((uint64_t)blockIdx.x * MG_T >= n) return;
   __shared__ uint64_t keys[MG_T];
   __shared__ uint32_t src[MG_T];
   __shared__ uint32_t s_i[2];
@@ -142,8 +145,10 @@ constexpr int RF_E = RF_CAP / RF_NT;
 // phase B.  Input sorted by P (stable); output: inside each bucket ordered by (strand, lo), equal keys in input order.
 __global__ __launch_bounds__(RF_NT) void msort_refine_k(const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo,
                                                         const uint32_t* __restrict__ val, uint64_t* __restrict__ ohi,
-                                                        uint64_t* __restrict__ olo, uint32_t* __restrict__ oval, uint32_t m,
-                                                        uint32_t* __restrict__ err) {
+                                                        uint64_t* __restrict__ olo, uint32_t* __restrict__ oval,
+                                                        const uint32_t* __restrict__ pm, uint32_t* __restrict__ err) {
+  const uint32_t m = *pm;
+  if ((uint64_t)blockIdx.x * RF_W >= m) return;
   __shared__ uint64_t K[RF_CAP];
   __shared__ uint8_t head[RF_CAP];
   __shared__ uint16_t bs[RF_CAP], bend[RF_CAP];
@@ -259,21 +264,23 @@ __global__ __launch_bounds__(RF_NT) void msort_refine_k(const uint64_t* __restri
 
 }  // namespace
 
-// Sort b (n records: nruns runs, run f = [run_off[f], run_off[f+1]), each non-decreasing in hi >> 2 and in input
-// order) exactly as tbk_radix_sort128 would.  A bucket too long for phase B sets TBK_DERR_BIGBUCKET in *err; the caller
+// Sort b (nruns runs, run f = [run_off[f], run_off[f+1]), each non-decreasing in hi >> 2 and in input order; the record
+// count run_off[nruns] is read on the device, n_hi is the host's upper bound of it and only sizes the grids) exactly
+// as tbk_radix_sort128 would.  A bucket too long for phase B sets TBK_DERR_BIGBUCKET in *err; the caller
 // then swaps b's two sides back (the phase-A output, still a valid stable input) and runs the radix sort on it.
-int tbk_sort_runs(tbk_ctx* ctx, SortBufs* b, uint32_t n, const uint32_t* d_run_off, uint32_t nruns, uint32_t* err) {
-  if (n < 2) return 0;
+int tbk_sort_runs(tbk_ctx* ctx, SortBufs* b, uint32_t n_hi, const uint32_t* d_run_off, uint32_t nruns, uint32_t* err) {
+  const uint32_t n = n_hi;
+  if (n == 0) return 0;
   uint32_t rounds = 0;
   while ((1u << rounds) < nruns) ++rounds;
   const uint32_t tiles = cdiv(n, MG_T);
   for (uint32_t r = 0; r < rounds; ++r) {
-    TBK_LAUNCH(ctx, "msort_merge", msort_merge_k, tiles, MG_NT, 0, b->hi, b->lo, b->val, b->hi2, b->lo2, b->val2, n, d_run_off, nruns, r);
+    TBK_LAUNCH(ctx, "msort_merge", msort_merge_k, tiles, MG_NT, 0, b->hi, b->lo, b->val, b->hi2, b->lo2, b->val2, d_run_off, nruns, r);
     std::swap(b->hi, b->hi2);
     std::swap(b->lo, b->lo2);
     std::swap(b->val, b->val2);
   }
-  TBK_LAUNCH(ctx, "msort_refine", msort_refine_k, cdiv(n, RF_W), RF_NT, 0, b->hi, b->lo, b->val, b->hi2, b->lo2, b->val2, n, err);
+  TBK_LAUNCH(ctx, "msort_refine", msort_refine_k, cdiv(n, RF_W), RF_NT, 0, b->hi, b->lo, b->val, b->hi2, b->lo2, b->val2, d_run_off + nruns, err);
   std::swap(b->hi, b->hi2);  // (on TBK_DERR_BIGBUCKET the caller swaps back: the *2 side then holds the phase-A output)
   std::swap(b->lo, b->lo2);
   std::swap(b->val, b->val2);
