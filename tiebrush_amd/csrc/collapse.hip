@@ -620,10 +620,8 @@ struct YdItems {
 
 // per output group (computed once, every item of the group reuses it): coordinates, exon count, exon list
 struct YdGroups {
-  uint32_t* tidp1;
-  int32_t* start;
-  int32_t* end;
-  uint32_t* nex;
+  uint4* pk;       // (tid + 1, start, end, exon count): one 16-byte gather per item instead of four
+  uint32_t* nex;   // the exon counts again, contiguous, as the input of the offset scan
   uint32_t* xoff;
 };
 
@@ -635,13 +633,13 @@ __global__ void yd_groups_k(ColIn I, uint32_t ng, const uint32_t* __restrict__ g
   uint32_t q = G.first[sg];
   uint64_t h = shi[q], l = slo[q];
   int32_t st = (int32_t)(uint32_t)((h >> 2) & 0x7FFFFFFFull);
-  Q.tidp1[o] = (uint32_t)(h >> 33);
-  Q.start[o] = st;
-  Q.end[o] = st + (int32_t)(uint32_t)(l >> 32) - 1;
+  const uint32_t tidp1 = (uint32_t)(h >> 33);
+  const uint32_t en = (uint32_t)(st + (int32_t)(uint32_t)(l >> 32) - 1);
   uint32_t r = (uint32_t)(G.rep[sg] & 0xFFFFFFFFull);
   int nex = 0;
   walk_exons(I.pos[r], I.cig + I.cig_off[r], I.cig_off[r + 1] - I.cig_off[r], [](int, int) {}, &nex);
   Q.nex[o] = (uint32_t)nex;
+  Q.pk[o] = make_uint4(tidp1, (uint32_t)st, en, (uint32_t)nex);
 }
 
 __global__ void yd_gexons_k(ColIn I, uint32_t ng, const uint32_t* __restrict__ gperm, GroupAcc G, YdGroups Q, uint32_t* __restrict__ ex_s,
@@ -664,10 +662,11 @@ __global__ void yd_coords_k(uint32_t nit, const uint32_t* __restrict__ v, YdGrou
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nit) return;
   uint32_t o = v[t];
-  Y.tidp1[t] = Q.tidp1[o];
-  Y.start[t] = Q.start[o];
-  Y.end[t] = Q.end[o];
-  Y.nex[t] = Q.nex[o];
+  const uint4 g = Q.pk[o];
+  Y.tidp1[t] = g.x;
+  Y.start[t] = (int32_t)g.y;
+  Y.end[t] = (int32_t)g.z;
+  Y.nex[t] = g.w;
   Y.xo[t] = Q.xoff[o];
 }
 
@@ -1258,9 +1257,7 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
                  ib.val);
       TBK_TRY(tbk_radix_sort128(ctx, &ib, nit, ~0ull, 0ull));  // stable split by list id; group order is already in place
       YdGroups Q;
-      Q.tidp1 = ws_alloc<uint32_t>(ctx, ng);
-      Q.start = ws_alloc<int32_t>(ctx, ng);
-      Q.end = ws_alloc<int32_t>(ctx, ng);
+      Q.pk = ws_alloc<uint4>(ctx, ng);
       Q.nex = ws_alloc<uint32_t>(ctx, ng);
       Q.xoff = ws_alloc<uint32_t>(ctx, ng);
       if (!Q.xoff) return TBK_ENOMEM;

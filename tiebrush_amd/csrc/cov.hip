@@ -91,7 +91,7 @@ __global__ void cov_prep_k(uint32_t n, const uint32_t* __restrict__ valid, const
     if (check_ops && (c1 - c0) >= 256) e |= TBK_DERR_NCIGAR;
     double y = yc ? yc[i] : 1.0;
     if (!(y == rint(y)) || !(fabs(y) < 1073741824.0)) e |= TBK_DERR_FRACTIONAL;
-    else ay = (uint64_t)fabs(y);
+    else ay += (uint64_t)fabs(y);
     A.ridx[j] = i;
     A.start[j] = pos[i] + 1;
     A.end[j] = pos[i] + l;
@@ -626,6 +626,46 @@ __global__ void junc_write_k(uint32_t nj, CovArrays A, const uint64_t* __restric
   j_val[o] = s;
 }
 
+
+// Integral YC (the common case): the order of the additions cannot matter, so the members of a junction are summed in
+// parallel — wave-segmented partial sums, one double atomic per (wave, junction) — instead of one thread walking all
+// the members of a junction (a junction of a highly expressed gene has tens of thousands).
+__global__ void junc_head_write_k(uint32_t nj, const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo,
+                                  const uint32_t* __restrict__ head, const uint32_t* __restrict__ hoff, uint32_t cap,
+                                  int32_t* __restrict__ j_tid, int32_t* __restrict__ j_start, int32_t* __restrict__ j_end,
+                                  uint8_t* __restrict__ j_strand, double* __restrict__ j_val) {
+  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nj || !head[q]) return;
+  uint32_t o = hoff[q];
+  if (o >= cap) return;
+  const int32_t start = (int32_t)(uint32_t)(hi[q] & 0xFFFFFFFFu);
+  j_tid[o] = (int32_t)(uint32_t)(hi[q] >> 32);
+  j_start[o] = start - 1;
+  j_end[o] = start + (int32_t)(uint32_t)(lo[q] >> 8) - 1;
+  j_strand[o] = (uint8_t)(lo[q] & 0xFFu);
+  j_val[o] = 0.0;
+}
+__global__ void junc_sum_k(uint32_t nj, CovArrays A, const uint32_t* __restrict__ val, const uint32_t* __restrict__ head,
+                           const uint32_t* __restrict__ hoff, const double* __restrict__ yc, uint32_t cap, double* __restrict__ j_val) {
+  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool act = q < nj;
+  uint32_t o = 0xFFFFFFFFu;
+  double v = 0.0;
+  if (act) {
+    o = hoff[q] + head[q] - 1u;
+    v = yc ? yc[A.ridx[val[q]]] : 1.0;
+  }
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {  // inclusive segmented sum over lanes holding the same junction
+    double pv = __shfl_up(v, d, 64);
+    uint32_t po = __shfl_up(o, d, 64);
+    if ((int)lane_id() >= d && po == o) v += pv;
+  }
+  uint32_t no = __shfl_down(o, 1, 64);
+  const bool last = lane_id() == 63 || no != o;
+  if (act && last && o < cap) atomicAdd(&j_val[o], v);
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -647,7 +687,7 @@ __global__ void sample_convert_k(uint32_t n, const double* __restrict__ v, float
 // arena, own host thread) while the main stream builds the intervals; `ctx` is whichever context it runs on.
 constexpr uint32_t COV_SIDE_MIN = 1u << 16;  // below this many records the fork costs more than it hides
 static int junc_branch(tbk_ctx* ctx, uint32_t m, const CovArrays& A, const tbk_cov_in* in, const uint32_t* jcnt, tbk_cov_out* out,
-                       uint32_t* nj_out, uint32_t* nju_out) {
+                       bool integral, uint32_t* nj_out, uint32_t* nju_out) {
   const uint32_t B = 256;
   uint64_t* sc = ctx->d_scalars;
   *nj_out = *nju_out = 0;
@@ -674,8 +714,14 @@ static int junc_branch(tbk_ctx* ctx, uint32_t m, const CovArrays& A, const tbk_c
   TBK_TRY(tbk_radix_sort128(ctx, &sb, nj));
   TBK_LAUNCH(ctx, "junc_head", junc_head_k, cdiv(nj, B), B, 0, nj, sb.hi, sb.lo, head);
   TBK_TRY(tbk_exscan_u32(ctx, head, hoff, nj, sc + 9));
-  TBK_LAUNCH(ctx, "junc_write", junc_write_k, cdiv(nj, B), B, 0, nj, A, sb.hi, sb.lo, sb.val, head, hoff, in->yc, out->cap_junctions,
-             out->j_tid, out->j_start, out->j_end, out->j_strand, out->j_val);
+  if (integral) {
+    TBK_LAUNCH(ctx, "junc_head_write", junc_head_write_k, cdiv(nj, B), B, 0, nj, sb.hi, sb.lo, head, hoff, out->cap_junctions, out->j_tid,
+               out->j_start, out->j_end, out->j_strand, out->j_val);
+    TBK_LAUNCH(ctx, "junc_sum", junc_sum_k, cdiv(nj, B), B, 0, nj, A, sb.val, head, hoff, in->yc, out->cap_junctions, out->j_val);
+  } else {
+    TBK_LAUNCH(ctx, "junc_write", junc_write_k, cdiv(nj, B), B, 0, nj, A, sb.hi, sb.lo, sb.val, head, hoff, in->yc, out->cap_junctions,
+               out->j_tid, out->j_start, out->j_end, out->j_strand, out->j_val);
+  }
   TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 9, sc + 9, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   TBK_HIP(hipStreamSynchronize(ctx->stream));
   *nju_out = (uint32_t)ctx->h_scalars[9];
@@ -741,14 +787,15 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
   const uint32_t m = (uint32_t)ctx->h_scalars[2];
   out->n_bases = ctx->h_scalars[0];
   const uint64_t sum_abs = ctx->h_scalars[1];
+  const bool integral = !fractional && !sample_mode && sum_abs < (1ull << 52);  // junction sums may then be formed in any order
   if (m == 0) return 0;
   if (want_j && want_cov && m >= COV_SIDE_MIN) {  // the valid records are compacted (the stream was just synchronised): fork the junction branch
     tbk_ctx* jc = tbk_side_ctx(ctx);
     if (jc) {
       const size_t hint = (size_t)m * 8 + (size_t)in->n_cigar_ops * 56 + ((size_t)4 << 20);
-      side.th = new std::thread([&side, jc, hint, m, &A, in, jcnt, out, &nj, &nju]() {
+      side.th = new std::thread([&side, jc, hint, m, &A, in, jcnt, out, integral, &nj, &nju]() {
         side.rc = tbk_side_begin(jc, hint);
-        if (side.rc == 0) side.rc = junc_branch(jc, m, A, in, jcnt, out, &nj, &nju);
+        if (side.rc == 0) side.rc = junc_branch(jc, m, A, in, jcnt, out, integral, &nj, &nju);
         tbk_side_end(jc);
       });
     }
@@ -839,7 +886,7 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
     }
   }
 
-  if (want_j && !side.th) TBK_TRY(junc_branch(ctx, m, A, in, jcnt, out, &nj, &nju));
+  if (want_j && !side.th) TBK_TRY(junc_branch(ctx, m, A, in, jcnt, out, integral, &nj, &nju));
   TBK_TRY(tbk_sync_err(ctx, &eb));
   if (eb) return tbk_derr_to_status(ctx, eb);
   TBK_TRY(tbk_check_launch(ctx, "coverage"));
