@@ -149,3 +149,18 @@ def test_sample_track_synthetic_deep(ctx):
     assert got["n_sample"] == want["n_sample"]
     for k in ("s_tid", "s_start", "s_end", "s_count", "s_heat"):
         assert np.array_equal(got[k], want[k]), k
+
+
+def test_deep_pileup_needs_64bit_accumulators(ctx):
+    """2.4M records of YC 1000 on one spot: the depth (2.4e9) is beyond int32, and every thread of the prep kernel sees
+    about nine records — the |YC| total that picks the accumulator width must count all of them."""
+    from tiebrush_amd import soa
+    n = 2_400_000
+    M = 0
+    pos = np.full(n, 1000, np.int32)
+    pos[n // 2:] = 1010
+    cin = soa.CovInput(tid=np.zeros(n, np.int32), pos=pos, flag=np.zeros(n, np.uint16),
+                       cig_off=np.arange(n + 1, dtype=np.uint32), cig=np.full(n, (40 << 4) | M, np.uint32),
+                       yc=np.full(n, 1000.0), strand=np.full(n, ord("."), np.uint8), yx=np.ones(n, np.int64))
+    got = _check(ctx, cin, True)
+    assert float(got["iv_val"].max()) == 1000.0 * n
