@@ -54,6 +54,17 @@ def test_config5_shape_exact(ctx):
     _exact(ctx, synth.make_tile(128, 40_000, "c5"), strategy="exon", max_nh=5, min_qual=1)
 
 
+@pytest.mark.parametrize("profile,kw", [("c2", {}), ("c3", {"strategy": "clip"})])
+def test_long_buckets_exact(ctx, profile, kw):
+    """A handful of loci: thousands of reads start on the same base (rRNA / mitochondrial style pile-ups), so the run
+    sort meets (tid,start) buckets far longer than its local window and hands them to the block-level bucket sort."""
+    from tiebrush_amd import synth
+    tile = synth.make_tile(4, 150_000, profile, n_loci=3)
+    key = (tile.tid.astype(np.int64) << 32) | tile.pos.astype(np.int64)
+    assert np.unique(key, return_counts=True)[1].max() > 2048
+    _exact(ctx, tile, **kw)
+
+
 def _properties(ctx, tile, **kw):
     import torch
     from tiebrush_amd import api, soa

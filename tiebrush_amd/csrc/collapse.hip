@@ -1469,7 +1469,7 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
     bool runs_now = use_runs && (lean || m >= runs_min);
     for (;;) {
       if (runs_now)
-        TBK_TRY(tbk_sort_runs(ctx, &s2, m_hi, run_off, I.k, ctx->d_err));
+        TBK_TRY(tbk_sort_runs(ctx, &s2, m_hi, run_off, I.k, ctx->d_err, (uint32_t*)(sc + 12)));  // sc[12]: zeroed with the counters above
       else
         TBK_TRY(tbk_radix_sort128(ctx, &s2, m));
       TBK_LAUNCH(ctx, "col_heads", col_heads_k, cdiv(m_hi, B), B, 0, I, O.strategy, sc + 0, m_hi, s2.hi, s2.lo, s2.val, fidx, flags,

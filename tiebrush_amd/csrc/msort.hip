@@ -7,9 +7,10 @@
 //   phase B  inside every bucket of equal P order by (strand, span, hash) — buckets are short (a few reads share a
 //            start), so a block takes a window of consecutive buckets into LDS and ranks each record by counting.
 //
-// The result is the same permutation the stable 128-bit radix sort produces.  Buckets longer than a window raise
-// TBK_DERR_BIGBUCKET and the caller falls back to the radix sort (on the phase-A output, which is still a valid
-// stable input for it).  All integer work, HBM/LDS-bound; no MFMA.
+//            A bucket longer than a window (thousands of reads starting on one base) is sorted by one block with a
+//            stable LSD radix sort over its varying key bytes (msort_big_k).
+//
+// The result is the same permutation the stable 128-bit radix sort produces.  All integer work, HBM/LDS-bound; no MFMA.
 #include "dev_common.cuh"
 #include "tbk_internal.h"
 
@@ -146,47 +147,54 @@ constexpr int RF_E = RF_CAP / RF_NT;
 __global__ __launch_bounds__(RF_NT) void msort_refine_k(const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo,
                                                         const uint32_t* __restrict__ val, uint64_t* __restrict__ ohi,
                                                         uint64_t* __restrict__ olo, uint32_t* __restrict__ oval,
-                                                        const uint32_t* __restrict__ pm, uint32_t* __restrict__ err) {
+                                                        const uint32_t* __restrict__ pm, uint32_t* __restrict__ big,
+                                                        uint32_t* __restrict__ nbig) {
   const uint32_t m = *pm;
   if ((uint64_t)blockIdx.x * RF_W >= m) return;
   __shared__ uint64_t K[RF_CAP];
   __shared__ uint8_t head[RF_CAP];
   __shared__ uint16_t bs[RF_CAP], bend[RF_CAP];
   __shared__ int s_wmax[RF_NT / 64];
-  __shared__ uint32_t s_first, s_end;
+  __shared__ uint32_t s_first, s_end, s_lasthead;
   const uint32_t r0 = blockIdx.x * RF_W;
   const uint32_t r1 = (m - r0) < (uint32_t)RF_W ? m : r0 + RF_W;
   const uint32_t lim = (m - r1) < (uint32_t)(RF_CAP - RF_W) ? m : r1 + (RF_CAP - RF_W);
   if (threadIdx.x == 0) {
     s_first = 0xFFFFFFFFu;
     s_end = 0xFFFFFFFFu;
+    s_lasthead = 0u;
   }
   __syncthreads();
   {
-    uint32_t fmin = 0xFFFFFFFFu, emin = 0xFFFFFFFFu;
+    uint32_t fmin = 0xFFFFFFFFu, emin = 0xFFFFFFFFu, lmax = 0u;
     for (uint32_t i = r0 + threadIdx.x; i < lim; i += RF_NT) {
       const bool h = i == 0 || (hi[i] >> 2) != (hi[i - 1] >> 2);
       if (h) {
         if (i < r1) {
           if (i < fmin) fmin = i;
+          if (i > lmax) lmax = i;
         } else if (i < emin) {
           emin = i;
         }
       }
     }
-    if (fmin != 0xFFFFFFFFu) atomicMin(&s_first, fmin);
+    if (fmin != 0xFFFFFFFFu) {
+      atomicMin(&s_first, fmin);
+      atomicMax(&s_lasthead, lmax);
+    }
     if (emin != 0xFFFFFFFFu) atomicMin(&s_end, emin);
   }
   __syncthreads();
   const uint32_t ws = s_first;
-  if (ws == 0xFFFFFFFFu) return;  // the whole range lies inside a bucket that started earlier: its owner handles (or reports) it
+  if (ws == 0xFFFFFFFFu) return;  // the whole range lies inside a bucket that started earlier: its owner handles it (or hands it on)
   uint32_t we = s_end;
   if (we == 0xFFFFFFFFu) {
     if (lim == m) {
       we = m;
-    } else {  // the last owned bucket does not end inside the window
-      if (threadIdx.x == 0) atomicOr(err, TBK_DERR_BIGBUCKET);
-      return;
+    } else {  // the last owned bucket does not end inside the window: msort_big_k takes it, the earlier ones stay here
+      we = s_lasthead;
+      if (threadIdx.x == 0) big[atomicAdd(nbig, 1u)] = we;
+      if (we == ws) return;
     }
   }
   const uint32_t nw = we - ws;  // <= RF_CAP
@@ -262,13 +270,141 @@ __global__ __launch_bounds__(RF_NT) void msort_refine_k(const uint64_t* __restri
   }
 }
 
+
+// ---- buckets too long for a refine window ---------------------------------------------------------------------
+__device__ __forceinline__ uint64_t match_digit8(uint32_t d, bool valid) {
+  uint64_t peers = __ballot(valid);
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    bool bit = (d >> b) & 1u;
+    uint64_t bal = __ballot(valid && bit);
+    peers &= bit ? bal : ~bal;
+  }
+  return peers;
+}
+
+// One block per long bucket (thousands of reads starting on one base: rRNA, mitochondrial genes, deep amplicons): a
+// stable block-level LSD radix sort of the bucket by K = (strand, span, hash), 8-bit digits, only over digits that
+// vary inside the bucket, ping-ponging between the refine input and output ranges of the bucket.
+__global__ __launch_bounds__(256) void msort_big_k(uint64_t* __restrict__ hi, uint64_t* __restrict__ lo, uint32_t* __restrict__ val,
+                                                   uint64_t* __restrict__ ohi, uint64_t* __restrict__ olo, uint32_t* __restrict__ oval,
+                                                   const uint32_t* __restrict__ pm, const uint32_t* __restrict__ big,
+                                                   const uint32_t* __restrict__ nbig, uint32_t grid_cap, uint32_t* __restrict__ err) {
+  const uint32_t nb_ = *nbig;
+  if (nb_ > grid_cap && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(err, TBK_DERR_BIGBUCKET);
+  if (blockIdx.x >= nb_) return;
+  __shared__ uint32_t s_be;
+  __shared__ unsigned long long s_and, s_or;
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t wcnt[4][256];
+  __shared__ uint32_t sm[8];
+  const uint32_t m = *pm;
+  const uint32_t b0 = big[blockIdx.x];
+  const uint64_t P0 = hi[b0] >> 2;
+  if (threadIdx.x == 0) {
+    s_be = m;
+    s_and = ~0ull;
+    s_or = 0ull;
+  }
+  __syncthreads();
+  for (uint32_t base = b0 + 1; base < m; base += 256) {  // end of the bucket
+    const uint32_t i = base + threadIdx.x;
+    const bool diff = i < m && (hi[i] >> 2) != P0;
+    if (diff) atomicMin(&s_be, i);
+    if (__syncthreads_or(diff ? 1 : 0)) break;
+  }
+  __syncthreads();
+  const uint32_t n = s_be - b0;
+  {
+    uint64_t a = ~0ull, o = 0ull;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+      const uint64_t k = ((hi[b0 + i] & 3ull) << 62) | lo[b0 + i];
+      a &= k;
+      o |= k;
+    }
+    atomicAnd(&s_and, (unsigned long long)a);
+    atomicOr(&s_or, (unsigned long long)o);
+  }
+  __syncthreads();
+  const uint64_t vary = s_and ^ s_or;
+  uint64_t *sh = hi + b0, *sl = lo + b0, *dh = ohi + b0, *dl = olo + b0;
+  uint32_t *sv = val + b0, *dv = oval + b0;
+  bool in_src_side = true;  // where the current order lives: the refine-input side (true) or the output side
+  const uint32_t w = threadIdx.x >> 6;
+  for (uint32_t shift = 0; shift < 64; shift += 8) {
+    if (((vary >> shift) & 0xFFull) == 0) continue;
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+      const uint64_t k = ((sh[i] & 3ull) << 62) | sl[i];
+      atomicAdd(&hist[(uint32_t)(k >> shift) & 0xFFu], 1u);
+    }
+    __syncthreads();
+    {
+      uint32_t tot;
+      const uint32_t c = hist[threadIdx.x];
+      const uint32_t ex = block_excl_sum<uint32_t, 256>(c, sm, &tot);
+      hist[threadIdx.x] = ex;  // running output base of digit threadIdx.x
+    }
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < n; c0 += 256) {  // chunks in order: stable
+      const uint32_t i = c0 + threadIdx.x;
+      const bool valid = i < n;
+      uint64_t h = 0, l = 0;
+      uint32_t v = 0, d = 0;
+      if (valid) {
+        h = sh[i];
+        l = sl[i];
+        v = sv[i];
+        d = (uint32_t)((((h & 3ull) << 62) | l) >> shift) & 0xFFu;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wcnt[q][threadIdx.x] = 0;
+      __syncthreads();
+      const uint64_t peers = match_digit8(d, valid);
+      const uint32_t rank = (uint32_t)__builtin_popcountll(peers & lanemask_lt());
+      if (valid && rank == 0) wcnt[w][d] = (uint32_t)__builtin_popcountll(peers);
+      __syncthreads();
+      if (valid) {
+        uint32_t off = hist[d] + rank;
+        for (uint32_t q = 0; q < w; ++q) off += wcnt[q][d];
+        dh[off] = h;
+        dl[off] = l;
+        dv[off] = v;
+      }
+      __syncthreads();
+      hist[threadIdx.x] += wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
+      __syncthreads();
+    }
+    uint64_t* th = sh;
+    sh = dh;
+    dh = th;
+    uint64_t* tl = sl;
+    sl = dl;
+    dl = tl;
+    uint32_t* tv = sv;
+    sv = dv;
+    dv = tv;
+    in_src_side = !in_src_side;
+  }
+  if (in_src_side) {  // an even number of passes (or none): the order lives on the input side, the result belongs on the other
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+      dh[i] = sh[i];
+      dl[i] = sl[i];
+      dv[i] = sv[i];
+    }
+  }
+}
 }  // namespace
 
 // Sort b (nruns runs, run f = [run_off[f], run_off[f+1]), each non-decreasing in hi >> 2 and in input order; the record
 // count run_off[nruns] is read on the device, n_hi is the host's upper bound of it and only sizes the grids) exactly
-// as tbk_radix_sort128 would.  A bucket too long for phase B sets TBK_DERR_BIGBUCKET in *err; the caller
-// then swaps b's two sides back (the phase-A output, still a valid stable input) and runs the radix sort on it.
-int tbk_sort_runs(tbk_ctx* ctx, SortBufs* b, uint32_t n_hi, const uint32_t* d_run_off, uint32_t nruns, uint32_t* err) {
+// as tbk_radix_sort128 would.  `nbig` is a device word the caller has zeroed (it counts the buckets too long for a
+// phase-B window; those are sorted by msort_big_k).  More than 4096 of them — a pathological tile — set
+// TBK_DERR_BIGBUCKET in *err; the caller then swaps b's two sides back (still a valid stable input) and runs the radix
+// sort on it.
+int tbk_sort_runs(tbk_ctx* ctx, SortBufs* b, uint32_t n_hi, const uint32_t* d_run_off, uint32_t nruns, uint32_t* err,
+                  uint32_t* nbig) {
   const uint32_t n = n_hi;
   if (n == 0) return 0;
   uint32_t rounds = 0;
@@ -280,7 +416,16 @@ int tbk_sort_runs(tbk_ctx* ctx, SortBufs* b, uint32_t n_hi, const uint32_t* d_ru
     std::swap(b->lo, b->lo2);
     std::swap(b->val, b->val2);
   }
-  TBK_LAUNCH(ctx, "msort_refine", msort_refine_k, cdiv(n, RF_W), RF_NT, 0, b->hi, b->lo, b->val, b->hi2, b->lo2, b->val2, d_run_off + nruns, err);
+  const uint32_t big_cap = n / (RF_CAP - RF_W) + 1;  // a long bucket holds more than a window's overhang
+  uint32_t* big = ws_alloc<uint32_t>(ctx, big_cap);
+  if (!big) return TBK_ENOMEM;
+  TBK_LAUNCH(ctx, "msort_refine", msort_refine_k, cdiv(n, RF_W), RF_NT, 0, b->hi, b->lo, b->val, b->hi2, b->lo2, b->val2, d_run_off + nruns,
+             big, nbig);
+  // (their number is only known on the device: launch for a generous bound, surplus blocks leave at once; more long
+  // buckets than that — a pathological tile — raise TBK_DERR_BIGBUCKET and the caller falls back to the radix sort)
+  const uint32_t big_grid = big_cap < 4096u ? big_cap : 4096u;
+  TBK_LAUNCH(ctx, "msort_big", msort_big_k, big_grid, 256, 0, b->hi, b->lo, b->val, b->hi2, b->lo2, b->val2, d_run_off + nruns, big, nbig,
+             big_grid, err);
   std::swap(b->hi, b->hi2);  // (on TBK_DERR_BIGBUCKET the caller swaps back: the *2 side then holds the phase-A output)
   std::swap(b->lo, b->lo2);
   std::swap(b->val, b->val2);

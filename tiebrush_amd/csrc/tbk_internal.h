@@ -143,7 +143,8 @@ struct SortBufs {
 int tbk_radix_sort128(tbk_ctx* ctx, SortBufs* b, uint32_t n, uint64_t only_hi = ~0ull, uint64_t only_lo = ~0ull);
 size_t tbk_radix_ws_bytes(uint32_t n);
 // same result for an input made of `nruns` position-sorted runs (msort.hip)
-int tbk_sort_runs(tbk_ctx* ctx, SortBufs* b, uint32_t n_hi, const uint32_t* d_run_off, uint32_t nruns, uint32_t* err);
+int tbk_sort_runs(tbk_ctx* ctx, SortBufs* b, uint32_t n_hi, const uint32_t* d_run_off, uint32_t nruns, uint32_t* err,
+                  uint32_t* nbig_zeroed);
 
 // ---- pipelines --------------------------------------------------------------------
 int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_in* in, tbk_groups_out* out);
