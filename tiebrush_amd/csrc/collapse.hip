@@ -1415,10 +1415,10 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
   uint32_t* head_off = ws_alloc<uint32_t>(ctx, (size_t)in->n_files + 1);
   uint32_t* run_off = ws_alloc<uint32_t>(ctx, (size_t)in->n_files + 1);
   if (!sgid || !head_off || !run_off) return TBK_ENOMEM;
-  // ceil(log2(files)) merge rounds + one local pass against ~12 radix passes.  Measured on MI355X: 2 files 0.17 ms vs
-  // 0.47 ms; at 64 files (6 rounds) the two are level, and many files at one coordinate make buckets that outgrow
-  // the local window (radix fallback on top of the merge) — so only a few files take this path.
-  bool use_runs = in->n_files <= 8;
+  // ceil(log2(files)) merge rounds + one local pass against ~12 radix passes.  Measured on MI355X: 2 files x 1 M
+  // 0.17 ms vs 0.47 ms; 16 files x 0.5 M: whole step 3.90 vs 4.13 ms; 64 files x 0.25 M (6 rounds): 8.58 vs 8.67 ms —
+  // level there, so more files than that take the radix sort.
+  bool use_runs = in->n_files <= 64;
   uint32_t runs_min = 32768;          // below this the tile is launch-bound either way; keep the one code path
   if (const char* e = getenv("TBK_SORT")) {  // test hook: "radix" / "runs" force one path whatever the shape
     use_runs = strcmp(e, "radix") != 0 && (use_runs || strcmp(e, "runs") == 0);
