@@ -6,9 +6,10 @@ resident in HBM: tbk_collapse_tile (k-way merge order, grouping, YC/YX/YD) -> de
 (tbk_groups_to_cov_in) -> tbk_coverage_tile (bedgraph intervals + junctions) of the collapsed
 records.  Workload at N=1 = BASELINE.json configs[1]: 2 synthetic sorted BAMs x 1M 100-bp reads,
 default CIGAR-only collapse.  With N>1 every rank owns its own 2 input files (weak scaling: the
-N input streams shard per rank); groups that span ranks are stitched inside the
-timed step (tiebrush_amd/dist.py: all-gather of splitter keys, all-to-all of partial groups over
-RCCL, second collapse, tiecov of the owned bundle range).
+N input streams shard per rank); inside the timed step the ranks agree on
+bundle-aligned coordinate cuts (all-gather of sampled keys, all-reduce rounds), shuffle the passing
+records by coordinate (all-to-all over RCCL) and each collapses + covers its own range over ALL files
+(tiebrush_amd/dist.py).
 
 Prints ONE JSON line (rank 0).  value = input alignment records collapsed per second, whole job.
 """
@@ -35,7 +36,7 @@ def main():
     ap.add_argument("--profile", default="c2", choices=["c2", "c3", "c5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-steps", type=int, default=5)
-    ap.add_argument("--force-dist", action="store_true", help="run the multi-rank stitch path even with one rank")
+    ap.add_argument("--force-dist", action="store_true", help="run the multi-rank (shuffle-then-collapse) path even with one rank")
     args = ap.parse_args()
 
     import numpy as np
@@ -76,8 +77,20 @@ def main():
         def groups_to_cov_in(self, fin):
             return ctx.groups_to_cov_in(fin)
 
-        def pack_partials(self, loc, first_fidx, cig_cap):
-            return ctx.pack_partials(loc, first_fidx, cig_cap, out=self.bufs.setdefault("p", {}))
+        def shard_prepare(self, tile, **kw):
+            return ctx.shard_prepare(tile, out=self.bufs.setdefault("sp", {}), **kw)
+
+        def shard_probe_max(self, *a):
+            return ctx.shard_probe_max(*a)
+
+        def shard_probe_next(self, *a):
+            return ctx.shard_probe_next(*a)
+
+        def shard_pack(self, *a):
+            return ctx.shard_pack(*a, out=self.bufs.setdefault("pk", {}))
+
+        def shard_unpack(self, rows, file_off2):
+            return ctx.shard_unpack(rows, file_off2, out=self.bufs.setdefault("up", {}))
 
         def finish_yd(self):
             ctx.finish_yd()
@@ -90,8 +103,8 @@ def main():
 
     def step():
         if use_dist:
-            # local collapse -> bundle-aligned cuts (all-gather + all-reduce) -> all-to-all of the partial groups over
-            # RCCL/xGMI -> stitch collapse -> tiecov of the owned slice, everything resident in HBM
+            # bundle-aligned cuts (all-gather + all-reduce) -> all-to-all of the passing records over RCCL/xGMI -> one
+            # collapse of the owned coordinate range over all files -> tiecov of it, everything resident in HBM
             r = tdist.run_distributed(stitch, dtile, rank * args.files_per_gpu, device=dev, want_coverage=True,
                                       device_chain=True, **strat)
             return ({"n_passed": r.n_passed_local, "n_groups": r.n_groups}, r.coverage)

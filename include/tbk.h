@@ -229,6 +229,37 @@ int tbk_pack_partials(tbk_ctx* ctx, const tbk_soa_in* in, const tbk_groups_out* 
                       uint32_t* cig_out, uint32_t cig_cap, uint32_t* n_cig,
                       int64_t* emax_out /* optional [n_groups]: running max of (tid+1)<<32 | g_end, needs groups->g_end */);
 
+/* ---- Multi-GPU: shuffle, then collapse (the reference has no counterpart — its only parallelism is
+ * tiewrap.py:96-126, batches of files re-collapsed hierarchically).  Every rank holds some input files; the ranks agree
+ * on coordinate cuts no read spans, every passing record moves to the rank owning its range, and that rank runs the
+ * ordinary tbk_collapse_tile / tbk_coverage_tile on complete data.  These entry points are the device side; the
+ * exchange itself is the caller's (torch.distributed over RCCL in tiebrush_amd/dist.py).  All arrays are device memory
+ * unless stated; file_off arrays are host memory as in tbk_soa_in. */
+
+/* Per record of `in` (n_records): key = (tid+1)<<31 | start (nondecreasing inside a file, else TBK_EUNSORTED),
+ * emax = per-file running max of (tid+1)<<31 | end over ALL records, effend = the effective end of the reference's
+ * k-way merge (tmerge.h:28-50; it depends on filtered records too, so it is computed here and travels as the record's
+ * explicit priority), pass bit 0 = passes_options (tiebrush.cpp:532-541) under `opts`. */
+int tbk_shard_prepare(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa_in* in, int64_t* key, int64_t* emax, int32_t* effend,
+                      uint8_t* pass);
+/* m_out[c] = max(m_out[c], farthest keyed read end among the local records that start before cuts[c]) */
+int tbk_shard_probe_max(tbk_ctx* ctx, const uint32_t* file_off, uint32_t n_files, const int64_t* key, const int64_t* emax,
+                        const int64_t* cuts, uint32_t n_cuts, int64_t* m_out);
+/* nxt_out[c] = min(nxt_out[c], first local record start beyond the keyed end m[c]) */
+int tbk_shard_probe_next(tbk_ctx* ctx, const uint32_t* file_off, uint32_t n_files, const int64_t* key, const int64_t* m, uint32_t n_cuts,
+                         int64_t* nxt_out);
+/* Passing records -> rows[<= n_records][TBK_SHARD_ROW] = {tid, pos, strand, n_cigar, effend, index inside its file} and their
+ * CIGAR words, grouped by (destination rank = number of cuts <= key, file), file order inside; src_idx[row] = local
+ * record.  tab[world][n_files][5] (int64, device) = {first record, rows, words, row base, word base} per block. */
+#define TBK_SHARD_ROW 6
+int tbk_shard_pack(tbk_ctx* ctx, const tbk_soa_in* in, const int64_t* key, const uint8_t* pass, const int32_t* effend, const int64_t* cuts,
+                   uint32_t world, int32_t* rows, uint32_t* cig_out, int64_t* src_idx, int64_t* tab);
+/* Received rows (all sources, in (source rank, file) order; file_off2[K+1] host = run boundaries over all K input files)
+ * -> the SoA arrays of a tile for tbk_collapse_tile: flag 0, mapq 255, NH absent, cig_off (n2+1 entries) from the
+ * n_cigar column, prio_hi = effend, prio_lo = file << 32 | index in file. */
+int tbk_shard_unpack(tbk_ctx* ctx, const int32_t* rows, uint32_t n2, const uint32_t* file_off2, uint32_t K, int32_t* tid, int32_t* pos,
+                     uint16_t* flag, uint8_t* mapq, uint8_t* strand, int32_t* nh, uint32_t* cig_off, int64_t* prio_hi, int64_t* prio_lo);
+
 #ifdef __cplusplus
 }
 #endif

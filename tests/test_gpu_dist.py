@@ -1,5 +1,6 @@
 """Multi-rank path with the real HIP compute: R virtual ranks on the one GPU of the box (loopback driver), checked
-against the flat oracle result.  Exercises rep_effend, the explicit stitch priority and the carried YC/YX/YD."""
+against the flat oracle result.  Host tiles take the numpy restatement of the shuffle around the HIP collapse (explicit
+priorities); device-resident tiles take the tbk_shard_* kernels end to end."""
 import numpy as np
 import pytest
 
@@ -62,8 +63,10 @@ class DeviceCompute:
     def groups_to_cov_in(self, fin):
         return self.ctx.groups_to_cov_in(fin)
 
-    def pack_partials(self, loc, first_fidx, cig_cap):
-        return self.ctx.pack_partials(loc, first_fidx, cig_cap)
+    def __getattr__(self, name):          # tbk_shard_prepare / _probe_* / _pack / _unpack
+        if name.startswith("shard_"):
+            return getattr(self.ctx, name)
+        raise AttributeError(name)
 
     def finish_yd(self):
         self.ctx.finish_yd()
@@ -73,18 +76,25 @@ class DeviceCompute:
         return api.to_numpy(self.ctx.coverage(view))
 
 
-def test_loopback_device_resident_equals_flat_oracle():
+@pytest.mark.parametrize("world,nfiles,profile,strategy,kw", [
+    (4, 8, "c2", "cigar", {}),
+    (3, 7, "c3", "clip", {}),
+    (8, 16, "c5", "exon", dict(max_nh=5, min_qual=1)),
+    (2, 2, "c2", "cigar", dict(keep_secondary=True)),
+    (1, 3, "c2", "cigar", {}),
+])
+def test_loopback_device_resident_equals_flat_oracle(world, nfiles, profile, strategy, kw):
     import torch
     from oracle import oracle_ffi as orc
     from tiebrush_amd import api, dist, synth
-    tile = synth.make_tile(8, 20000, "c2", n_loci=800)
-    flat = orc.collapse(tile)
+    tile = synth.make_tile(nfiles, 20000, profile, n_loci=800)
+    flat = orc.collapse(tile, strategy=STRAT[strategy], **kw)
     flat_cov = orc.coverage(synth.collapsed_to_cov_input(tile, flat))
-    tiles, first = split_tile(tile, 4)
+    tiles, first = split_tile(tile, world)
     dtiles = [api.to_device(t, "cuda:0") for t in tiles]
     comp = DeviceCompute()
     # the device chain view lives in context memory until the next call: run coverage inside each rank's turn
-    res = dist.run_loopback(comp, dtiles, first, want_coverage=True, device_chain=True)
+    res = dist.run_loopback(comp, dtiles, first, strategy=strategy, want_coverage=True, device_chain=True, **kw)
     for r in res:
         for f in ("tid", "start", "end", "rep_fidx", "rep_idx", "yc", "yx", "yd"):
             v = getattr(r, f)

@@ -266,6 +266,83 @@ class Context:
                     "tbk_pack_partials")
         return bufs["P"][:ng], bufs["cig"][:int(n.value)], bufs["emax"][:ng]
 
+    # ---- multi-GPU: shuffle, then collapse (device side of tiebrush_amd.dist) -------------------
+    def _dev(self):
+        return "cuda:%d" % self.device
+
+    def shard_prepare(self, tile: SoATile, out=None, **filters):
+        """tbk_shard_prepare: (key, emax, effend, pass) for the device-resident tile."""
+        torch = _torch()
+        keep = []
+        s, dev, n = self._soa_struct(tile, keep)
+        assert dev, "shard_prepare needs a device-resident tile"
+        bufs = out if out is not None else {}
+        for name, dt in (("key", torch.int64), ("emax", torch.int64), ("effend", torch.int32), ("pass", torch.uint8)):
+            if name not in bufs or bufs[name].numel() < max(n, 1):
+                bufs[name] = torch.empty(max(n, 1), dtype=dt, device=self._dev())
+        o = self.make_opts(**filters)
+        self._order_after_torch(True)
+        self._check(self.L.tbk_shard_prepare(self.h, C.byref(o), C.byref(s), C.c_void_p(bufs["key"].data_ptr()),
+                                             C.c_void_p(bufs["emax"].data_ptr()), C.c_void_p(bufs["effend"].data_ptr()),
+                                             C.c_void_p(bufs["pass"].data_ptr())), "tbk_shard_prepare")
+        return bufs["key"][:n], bufs["emax"][:n], bufs["effend"][:n], bufs["pass"][:n]
+
+    def shard_probe_max(self, file_off, key, emax, cuts, m_out):
+        fo = np.ascontiguousarray(file_off, dtype=np.uint32)
+        self._order_after_torch(True)
+        self._check(self.L.tbk_shard_probe_max(self.h, fo.ctypes.data, len(fo) - 1, C.c_void_p(key.data_ptr()), C.c_void_p(emax.data_ptr()),
+                                               C.c_void_p(cuts.data_ptr()), int(cuts.numel()), C.c_void_p(m_out.data_ptr())),
+                    "tbk_shard_probe_max")
+        return m_out
+
+    def shard_probe_next(self, file_off, key, m, nxt_out):
+        fo = np.ascontiguousarray(file_off, dtype=np.uint32)
+        self._order_after_torch(True)
+        self._check(self.L.tbk_shard_probe_next(self.h, fo.ctypes.data, len(fo) - 1, C.c_void_p(key.data_ptr()), C.c_void_p(m.data_ptr()),
+                                                int(m.numel()), C.c_void_p(nxt_out.data_ptr())), "tbk_shard_probe_next")
+        return nxt_out
+
+    def shard_pack(self, tile: SoATile, key, passm, effend, cuts, world, out=None):
+        """tbk_shard_pack: (rows [n, 6] int32 — the first sum(tab[..., 1]) are filled —, cig words, src_idx [n] int64,
+        tab [world, n_files, 5] int64)."""
+        torch = _torch()
+        keep = []
+        s, dev, n = self._soa_struct(tile, keep)
+        bufs = out if out is not None else {}
+        nc = _numel(tile.cig)
+        n_pass = n                                   # upper bound; the table tells how many rows were written
+        if "rows" not in bufs or bufs["rows"].shape[0] < max(n_pass, 1):
+            bufs["rows"] = torch.empty((max(n_pass, 1), 6), dtype=torch.int32, device=self._dev())
+        if "cig" not in bufs or bufs["cig"].numel() < max(nc, 1):
+            bufs["cig"] = torch.empty(max(nc, 1), dtype=torch.int32, device=self._dev())
+        if "src" not in bufs or bufs["src"].numel() < max(n_pass, 1):
+            bufs["src"] = torch.empty(max(n_pass, 1), dtype=torch.int64, device=self._dev())
+        tab = torch.empty((world, tile.n_files, 5), dtype=torch.int64, device=self._dev())
+        self._order_after_torch(True)
+        self._check(self.L.tbk_shard_pack(self.h, C.byref(s), C.c_void_p(key.data_ptr()), C.c_void_p(passm.data_ptr()),
+                                          C.c_void_p(effend.data_ptr()), C.c_void_p(cuts.data_ptr()) if world > 1 else None, int(world),
+                                          C.c_void_p(bufs["rows"].data_ptr()), C.c_void_p(bufs["cig"].data_ptr()),
+                                          C.c_void_p(bufs["src"].data_ptr()), C.c_void_p(tab.data_ptr())), "tbk_shard_pack")
+        return bufs["rows"][:n_pass], bufs["cig"], bufs["src"][:n_pass], tab
+
+    def shard_unpack(self, rows, file_off2, out=None):
+        """tbk_shard_unpack: the SoA arrays (torch tensors) of the received rows; file_off2 = run boundaries (host)."""
+        torch = _torch()
+        n2 = int(rows.shape[0])
+        fo = np.ascontiguousarray(file_off2, dtype=np.uint32)
+        bufs = out if out is not None else {}
+        spec = (("tid", torch.int32, n2), ("pos", torch.int32, n2), ("flag", torch.int16, n2), ("mapq", torch.uint8, n2),
+                ("strand", torch.uint8, n2), ("nh", torch.int32, n2), ("cig_off", torch.int32, n2 + 1), ("prio_hi", torch.int64, n2),
+                ("prio_lo", torch.int64, n2))
+        for name, dt, cnt in spec:
+            if name not in bufs or bufs[name].numel() < max(cnt, 1):
+                bufs[name] = torch.empty(max(cnt, 1), dtype=dt, device=self._dev())
+        self._order_after_torch(True)
+        rows = rows.contiguous()
+        self._check(self.L.tbk_shard_unpack(self.h, C.c_void_p(rows.data_ptr()) if n2 else None, n2, fo.ctypes.data, len(fo) - 1,
+                                            *[C.c_void_p(bufs[name].data_ptr()) for name, _, _ in spec]), "tbk_shard_unpack")
+        return {name: bufs[name][:cnt] for name, _, cnt in spec}
+
     # ---- coverage -----------------------------------------------------------------------------
     def coverage(self, cin, want_cov=True, want_junc=True, cap_intervals=None, cap_junctions=None, out=None, raw=False):
         keep = []

@@ -1,0 +1,426 @@
+// shard.hip — device side of the multi-GPU path (tiebrush_amd/dist.py): shuffle, then collapse.
+//
+// Every rank holds some of the input files.  Instead of collapsing locally and stitching partial groups afterwards,
+// the ranks agree on coordinate cuts that no read of any file spans (global bundle boundaries), send every passing
+// record to the rank that owns its coordinate range, and each rank then runs the ordinary tbk_collapse_tile /
+// tbk_coverage_tile on complete data: one collapse per record, YD computed once on whole groups, no second exchange.
+//
+//   tbk_shard_prepare   per record: merge key, filter verdict (passes_options, tiebrush.cpp:532-541), the effective
+//                       end of the k-way merge (per-file running max, tmerge.h:28-50 — computed BEFORE filtering, so it
+//                       travels with the record as its explicit priority), and the per-file running max of the read
+//                       ends that the cut search needs
+//   tbk_shard_probe_*   for candidate cuts: the farthest read end before each cut / the next record start after a key
+//   tbk_shard_pack      passing records -> 24-byte rows + CIGAR words grouped by (destination rank, file), in file order
+//   tbk_shard_unpack    received rows -> the SoA arrays of a tile whose "files" are all the input files
+//
+// All integer / byte work, HBM-bound, no MFMA.  No data-path collective lives here: the exchange itself is
+// torch.distributed (RCCL over xGMI) in dist.py.
+#include "dev_common.cuh"
+#include "scan_op.cuh"
+#include "tbk_internal.h"
+
+namespace {
+constexpr int SH_B = 256;
+
+struct ShOpt {
+  int max_nh, min_qual;
+  uint8_t keep_supp, keep_sec;
+};
+
+// key = (tid + 1) : 32 | start : 31 (start = pos + 1, the GSamRecord 1-based start) — per file nondecreasing
+__global__ void shard_keys_k(uint32_t n, uint32_t k, const uint32_t* __restrict__ file_off, const int32_t* __restrict__ tid,
+                             const int32_t* __restrict__ pos, const uint16_t* __restrict__ flag, const uint8_t* __restrict__ mapq,
+                             const int32_t* __restrict__ nh, const uint32_t* __restrict__ cig_off, const uint32_t* __restrict__ cig,
+                             ShOpt O, int64_t* __restrict__ key, int32_t* __restrict__ kend, uint8_t* __restrict__ kfl,
+                             uint16_t* __restrict__ fidx, uint32_t* __restrict__ err) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    bool pass;
+    uint32_t lo = 0, hi = k;  // last f with file_off[f] <= i
+    while (hi - lo > 1) {
+      uint32_t mid = (lo + hi) >> 1;
+      if (file_off[mid] <= i)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    const uint16_t fl = flag[i];
+    int start = 0, end = 0;
+    if (!(fl & 0x4)) {
+      int l = cigar_reflen(cig + cig_off[i], cig_off[i + 1] - cig_off[i]);
+      start = pos[i] + 1;
+      end = pos[i] + l;
+    }
+    pass = true;  // passes_options, tiebrush.cpp:532-541
+    if (!O.keep_supp && (fl & 0x800)) pass = false;
+    if (!O.keep_sec && (fl & 0x100)) pass = false;
+    if (fl & 0x4) pass = false;
+    if ((int)mapq[i] < O.min_qual) pass = false;
+    int h = nh[i] == TBK_NH_ABSENT ? 0 : nh[i];
+    if (h > O.max_nh) pass = false;
+    if (pass && (start < 0 || tid[i] < -1 || (int64_t)end - start + 1 >= (1ll << 30))) atomicOr(err, TBK_DERR_SPAN);
+    key[i] = ((int64_t)(uint32_t)(tid[i] + 1) << 31) | (uint32_t)start;
+    kend[i] = end;
+    kfl[i] = (pass ? 1u : 0u) | (i == file_off[lo] ? 2u : 0u);
+    fidx[i] = (uint16_t)lo;
+  }
+}
+
+struct ShKey {  // scan element (32-bit words): running (key, end) maximum and running keyed-end maximum, both per file
+  uint32_t kh, kl;
+  int32_t kend;
+  uint32_t mh, ml;
+  uint32_t head;
+};
+struct ShOp {
+  __device__ __forceinline__ ShKey operator()(const ShKey& a, const ShKey& b) const {
+    const uint64_t ak = ((uint64_t)a.kh << 32) | a.kl, bk = ((uint64_t)b.kh << 32) | b.kl;
+    const uint64_t am = ((uint64_t)a.mh << 32) | a.ml, bm = ((uint64_t)b.mh << 32) | b.ml;
+    const bool take_b = b.head || bk > ak || (bk == ak && b.kend > a.kend);
+    const bool m_b = b.head || bm > am;
+    ShKey r;
+    r.kh = take_b ? b.kh : a.kh;
+    r.kl = take_b ? b.kl : a.kl;
+    r.kend = take_b ? b.kend : a.kend;
+    r.mh = m_b ? b.mh : a.mh;
+    r.ml = m_b ? b.ml : a.ml;
+    r.head = a.head | b.head;
+    return r;
+  }
+};
+struct ShLoad {
+  const int64_t* key;
+  const int32_t* kend;
+  const uint8_t* kfl;
+  __device__ __forceinline__ ShKey operator()(uint32_t i) const {
+    const uint64_t k = (uint64_t)key[i];
+    const uint64_t m = (k & ~0x7FFFFFFFull) | (uint32_t)kend[i];  // (tid + 1) : 32 | end : 31
+    ShKey e;
+    e.kh = (uint32_t)(k >> 32);
+    e.kl = (uint32_t)k;
+    e.kend = kend[i];
+    e.mh = (uint32_t)(m >> 32);
+    e.ml = (uint32_t)m;
+    e.head = (kfl[i] >> 1) & 1u;
+    return e;
+  }
+};
+struct ShStore {
+  const int64_t* key;
+  int32_t* effend;
+  int64_t* emax;
+  uint32_t* err;
+  __device__ __forceinline__ void operator()(uint32_t i, const ShKey& inc, const ShKey&) const {
+    const uint64_t ik = ((uint64_t)inc.kh << 32) | inc.kl;
+    if (ik != (uint64_t)key[i]) atomicOr(err, TBK_DERR_UNSORTED);  // an earlier record of the file has a larger (tid,start)
+    effend[i] = inc.kend;
+    emax[i] = (int64_t)(((uint64_t)inc.mh << 32) | inc.ml);
+  }
+};
+
+// one thread per (cut, file): the farthest keyed read end among the file's records that start before the cut
+__global__ void shard_probe_max_k(uint32_t nc, uint32_t k, const uint32_t* __restrict__ file_off, const int64_t* __restrict__ key,
+                                  const int64_t* __restrict__ emax, const int64_t* __restrict__ cuts, long long* __restrict__ m_out) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nc * k) return;
+  const uint32_t c = t / k, f = t % k;
+  const int64_t p = cuts[c];
+  uint32_t lo = file_off[f], hi = file_off[f + 1];
+  const uint32_t f0 = lo;
+  while (lo < hi) {  // first record with key >= p
+    uint32_t mid = (lo + hi) >> 1;
+    if (key[mid] < p)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  if (lo > f0) atomicMax(&m_out[c], (long long)emax[lo - 1]);
+}
+// one thread per (cut, file): the first record start of the file that lies beyond the keyed end m[c]
+__global__ void shard_probe_next_k(uint32_t nc, uint32_t k, const uint32_t* __restrict__ file_off, const int64_t* __restrict__ key,
+                                   const int64_t* __restrict__ m, long long* __restrict__ nxt_out) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nc * k) return;
+  const uint32_t c = t / k, f = t % k;
+  const int64_t v = m[c];
+  uint32_t lo = file_off[f], hi = file_off[f + 1];
+  const uint32_t f1 = hi;
+  while (lo < hi) {  // first record with key > v
+    uint32_t mid = (lo + hi) >> 1;
+    if (key[mid] <= v)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  if (lo < f1) atomicMin(&nxt_out[c], (long long)key[lo]);
+}
+
+__global__ void shard_passcig_k(uint32_t n, const uint8_t* __restrict__ pass, const uint32_t* __restrict__ cig_off, uint32_t* __restrict__ p32,
+                                uint32_t* __restrict__ c32) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t p = pass[i] & 1u;
+  p32[i] = p;
+  c32[i] = p ? cig_off[i + 1] - cig_off[i] : 0u;
+}
+
+// (destination, file) blocks: a file is sorted, so the records of file f that go to rank d are the contiguous range
+// between the lower bounds of cut d-1 and cut d.  One thread per block computes the range and its passing-row /
+// CIGAR-word counts; thread 0 then lays the blocks out destination-major, file-minor.
+// tab layout (int64): [world][k] x {first record, rows, words, row base, word base}
+__global__ void shard_table_k(uint32_t n, uint32_t world, uint32_t k, const uint32_t* __restrict__ file_off, const int64_t* __restrict__ key,
+                              const int64_t* __restrict__ cuts, const uint32_t* __restrict__ pr, const uint32_t* __restrict__ cg,
+                              const uint64_t* __restrict__ tot_rows, const uint64_t* __restrict__ tot_words, long long* __restrict__ tab) {
+  const uint32_t nblk = world * k;
+  for (uint32_t t = threadIdx.x; t < nblk; t += blockDim.x) {
+    const uint32_t d = t / k, f = t % k;
+    auto lower = [&](uint32_t which) -> uint32_t {  // first record of file f with key >= cut[which - 1]; which == 0: file start, == world: file end
+      if (which == 0) return file_off[f];
+      if (which == world) return file_off[f + 1];
+      const int64_t p = cuts[which - 1];
+      uint32_t lo = file_off[f], hi = file_off[f + 1];
+      while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (key[mid] < p)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      return lo;
+    };
+    const uint32_t a = lower(d), b = lower(d + 1);
+    const uint64_t pa = a < n ? pr[a] : *tot_rows, pb = b < n ? pr[b] : *tot_rows;
+    const uint64_t ca = a < n ? cg[a] : *tot_words, cb = b < n ? cg[b] : *tot_words;
+    tab[(size_t)t * 5 + 0] = a;
+    tab[(size_t)t * 5 + 1] = (long long)(pb - pa);
+    tab[(size_t)t * 5 + 2] = (long long)(cb - ca);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long long rb = 0, wb = 0;
+    for (uint32_t t = 0; t < nblk; ++t) {
+      tab[(size_t)t * 5 + 3] = rb;
+      tab[(size_t)t * 5 + 4] = wb;
+      rb += tab[(size_t)t * 5 + 1];
+      wb += tab[(size_t)t * 5 + 2];
+    }
+  }
+}
+
+// rows: 6 x int32 per passing record = {tid, pos, strand, n_cigar, effective end, index inside its file}
+__global__ void shard_scatter_k(uint32_t n, uint32_t world, uint32_t k, const uint32_t* __restrict__ file_off, const int64_t* __restrict__ key,
+                                const int64_t* __restrict__ cuts, const uint8_t* __restrict__ pass, const uint16_t* __restrict__ fidx,
+                                const uint32_t* __restrict__ pr, const uint32_t* __restrict__ cg, const long long* __restrict__ tab,
+                                const int32_t* __restrict__ tid, const int32_t* __restrict__ pos, const uint8_t* __restrict__ strand,
+                                const uint32_t* __restrict__ cig_off, const uint32_t* __restrict__ cig, const int32_t* __restrict__ effend,
+                                int32_t* __restrict__ rows, uint32_t* __restrict__ cig_out, int64_t* __restrict__ src_idx) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !(pass[i] & 1u)) return;
+  const int64_t kx = key[i];
+  uint32_t d = 0;  // number of cuts <= key
+  {
+    uint32_t lo = 0, hi = world - 1;
+    while (lo < hi) {
+      uint32_t mid = (lo + hi) >> 1;
+      if (cuts[mid] <= kx)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    d = lo;
+  }
+  const uint32_t f = fidx[i];
+  const long long* T = tab + ((size_t)d * k + f) * 5;
+  const uint32_t a = (uint32_t)T[0];
+  const uint64_t o = (uint64_t)T[3] + (pr[i] - pr[a]);
+  const uint64_t w = (uint64_t)T[4] + (cg[i] - cg[a]);
+  const uint32_t c0 = cig_off[i], nc = cig_off[i + 1] - c0;
+  int32_t* R = rows + o * 6;
+  R[0] = tid[i];
+  R[1] = pos[i];
+  R[2] = strand[i];
+  R[3] = (int32_t)nc;
+  R[4] = effend[i];
+  R[5] = (int32_t)(i - file_off[f]);
+  src_idx[o] = i;
+  for (uint32_t q = 0; q < nc; ++q) cig_out[w + q] = cig[c0 + q];
+}
+
+__global__ void shard_fidx_k(uint32_t n, uint32_t k, const uint32_t* __restrict__ fo, uint16_t* __restrict__ fidx) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t lo = 0, hi = k;
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (fo[mid] <= i)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  fidx[i] = (uint16_t)lo;
+}
+__global__ void shard_ncig_k(uint32_t n2, const int32_t* __restrict__ rows, uint32_t* __restrict__ nc) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n2) nc[j] = (uint32_t)rows[(size_t)j * 6 + 3];
+}
+// received rows -> SoA; the record's file is the run it lies in (file_off2 over ALL input files), its explicit priority
+// (effective end, then file and index: the merge order of the reference) rides in prio_hi / prio_lo
+__global__ void shard_unpack_k(uint32_t n2, uint32_t K, const int32_t* __restrict__ rows, const uint32_t* __restrict__ file_off2,
+                               const uint64_t* __restrict__ total_words, int32_t* __restrict__ tid, int32_t* __restrict__ pos,
+                               uint16_t* __restrict__ flag, uint8_t* __restrict__ mapq, uint8_t* __restrict__ strand, int32_t* __restrict__ nh,
+                               uint32_t* __restrict__ cig_off, int64_t* __restrict__ prio_hi, int64_t* __restrict__ prio_lo) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n2) return;
+  const int32_t* R = rows + (size_t)j * 6;
+  uint32_t lo = 0, hi = K;  // last f with file_off2[f] <= j
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (file_off2[mid] <= j)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  tid[j] = R[0];
+  pos[j] = R[1];
+  flag[j] = 0;
+  mapq[j] = 255;
+  strand[j] = (uint8_t)R[2];
+  nh[j] = TBK_NH_ABSENT;
+  prio_hi[j] = (int64_t)R[4];
+  prio_lo[j] = ((int64_t)lo << 32) | (uint32_t)R[5];
+  if (j + 1 == n2) cig_off[n2] = (uint32_t)*total_words;
+}
+}  // namespace
+
+static int shard_upload_file_off(tbk_ctx* ctx, const uint32_t* host_fo, uint32_t k, uint32_t** d_fo) {
+  *d_fo = ws_alloc<uint32_t>(ctx, (size_t)k + 1);
+  if (!*d_fo) return TBK_ENOMEM;
+  const size_t bytes = (size_t)(k + 1) * 4;
+  if (bytes <= 4096 * sizeof(uint64_t)) {  // staged through the pinned block: asynchronous, the caller's array may be transient
+    memcpy(ctx->h_scalars + 64, host_fo, bytes);
+    TBK_HIP(hipMemcpyAsync(*d_fo, ctx->h_scalars + 64, bytes, hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    TBK_HIP(hipMemcpyAsync(*d_fo, host_fo, bytes, hipMemcpyHostToDevice, ctx->stream));
+    TBK_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return 0;
+}
+
+extern "C" int tbk_shard_prepare(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_in* in, int64_t* key, int64_t* emax,
+                                 int32_t* effend, uint8_t* pass) {
+  if (!ctx || !o || !in || !key || !emax || !effend || !pass) return TBK_EINVAL;
+  if (in->mem != TBK_MEM_DEVICE || in->n_files == 0 || in->n_files > 65535 || !in->file_off) return TBK_EINVAL;
+  if (o->flags_mask != 0 || o->keep_unmapped) return TBK_EUNSUPPORTED;
+  TBK_HIP(hipSetDevice(ctx->device));
+  const uint32_t n = in->n_records;
+  if (n == 0) return 0;
+  TBK_TRY(tbk_ws_reserve(ctx, (size_t)n * 16 + ((size_t)1 << 20)));
+  uint64_t* sc = ctx->d_scalars;
+  TBK_HIP(hipMemsetAsync(sc, 0, 16 * sizeof(uint64_t), ctx->stream));
+  uint32_t* d_fo = nullptr;
+  TBK_TRY(shard_upload_file_off(ctx, in->file_off, in->n_files, &d_fo));
+  int32_t* kend = ws_alloc<int32_t>(ctx, n);
+  uint16_t* fidx = ws_alloc<uint16_t>(ctx, n);
+  if (!kend || !fidx) return TBK_ENOMEM;
+  ShOpt O{o->max_nh, o->min_qual, o->keep_supplementary, o->keep_secondary};
+  TBK_LAUNCH(ctx, "shard_keys", shard_keys_k, cdiv(n, SH_B), SH_B, 0, n, in->n_files, d_fo, in->tid, in->pos, in->flag, in->mapq, in->nh,
+             in->cig_off, in->cig, O, key, kend, pass, fidx, ctx->d_err);
+  {
+    ShLoad ld{key, kend, pass};
+    ShStore st{key, effend, emax, ctx->d_err};
+    ShKey ident{0u, 0u, INT32_MIN, 0u, 0u, 0u};
+    TBK_TRY((scan_op_run<ShKey, ShOp, ShLoad, ShStore>(ctx, "shard_eff_scan", n, ld, st, ShOp{}, ident)));
+  }
+  uint32_t eb = 0;
+  TBK_TRY(tbk_sync_err(ctx, &eb));
+  if (eb) return tbk_derr_to_status(ctx, eb);
+  return tbk_check_launch(ctx, "shard_prepare");
+}
+
+// m_out[c] (caller-initialised to -1) := max(m_out[c], farthest keyed end before cuts[c]); everything device-resident
+extern "C" int tbk_shard_probe_max(tbk_ctx* ctx, const uint32_t* file_off, uint32_t n_files, const int64_t* key, const int64_t* emax,
+                                   const int64_t* cuts, uint32_t n_cuts, int64_t* m_out) {
+  if (!ctx || !file_off || !key || !emax || !cuts || !m_out || n_files == 0) return TBK_EINVAL;
+  TBK_HIP(hipSetDevice(ctx->device));
+  if (n_cuts == 0) return 0;
+  TBK_TRY(tbk_ws_reserve(ctx, (size_t)1 << 20));
+  uint32_t* d_fo = nullptr;
+  TBK_TRY(shard_upload_file_off(ctx, file_off, n_files, &d_fo));
+  TBK_LAUNCH(ctx, "shard_probe_max", shard_probe_max_k, cdiv((size_t)n_cuts * n_files, SH_B), SH_B, 0, n_cuts, n_files, d_fo, key, emax, cuts,
+             (long long*)m_out);
+  return tbk_check_launch(ctx, "shard_probe_max");
+}
+// nxt_out[c] (caller-initialised to +inf) := min(nxt_out[c], first record start beyond m[c])
+extern "C" int tbk_shard_probe_next(tbk_ctx* ctx, const uint32_t* file_off, uint32_t n_files, const int64_t* key, const int64_t* m,
+                                    uint32_t n_cuts, int64_t* nxt_out) {
+  if (!ctx || !file_off || !key || !m || !nxt_out || n_files == 0) return TBK_EINVAL;
+  TBK_HIP(hipSetDevice(ctx->device));
+  if (n_cuts == 0) return 0;
+  TBK_TRY(tbk_ws_reserve(ctx, (size_t)1 << 20));
+  uint32_t* d_fo = nullptr;
+  TBK_TRY(shard_upload_file_off(ctx, file_off, n_files, &d_fo));
+  TBK_LAUNCH(ctx, "shard_probe_next", shard_probe_next_k, cdiv((size_t)n_cuts * n_files, SH_B), SH_B, 0, n_cuts, n_files, d_fo, key, m,
+             (long long*)nxt_out);
+  return tbk_check_launch(ctx, "shard_probe_next");
+}
+
+// rows [<= n_records][6] int32, cig_out [<= n_cigar_ops] uint32, src_idx [<= n_records] int64 (row -> local record), tab
+// [world][n_files][5] int64 on the DEVICE (first record, rows, words, row base, word base per (destination, file))
+extern "C" int tbk_shard_pack(tbk_ctx* ctx, const tbk_soa_in* in, const int64_t* key, const uint8_t* pass, const int32_t* effend,
+                              const int64_t* cuts, uint32_t world, int32_t* rows, uint32_t* cig_out, int64_t* src_idx, int64_t* tab) {
+  if (!ctx || !in || !key || !pass || !effend || !rows || !cig_out || !src_idx || !tab || world == 0) return TBK_EINVAL;
+  if (world > 1 && !cuts) return TBK_EINVAL;
+  if (in->mem != TBK_MEM_DEVICE || in->n_files == 0 || in->n_files > 65535 || !in->file_off) return TBK_EINVAL;
+  TBK_HIP(hipSetDevice(ctx->device));
+  const uint32_t n = in->n_records, k = in->n_files;
+  TBK_TRY(tbk_ws_reserve(ctx, (size_t)n * 24 + ((size_t)1 << 20)));
+  uint64_t* sc = ctx->d_scalars;
+  uint32_t* d_fo = nullptr;
+  TBK_TRY(shard_upload_file_off(ctx, in->file_off, k, &d_fo));
+  uint32_t* p32 = ws_alloc<uint32_t>(ctx, (size_t)n + 1);
+  uint32_t* c32 = ws_alloc<uint32_t>(ctx, (size_t)n + 1);
+  uint32_t* pr = ws_alloc<uint32_t>(ctx, (size_t)n + 1);
+  uint32_t* cg = ws_alloc<uint32_t>(ctx, (size_t)n + 1);
+  uint16_t* fidx = ws_alloc<uint16_t>(ctx, (size_t)n + 1);
+  if (!fidx) return TBK_ENOMEM;
+  if (n) {
+    TBK_LAUNCH(ctx, "shard_passcig", shard_passcig_k, cdiv(n, SH_B), SH_B, 0, n, pass, in->cig_off, p32, c32);
+  }
+  TBK_TRY(tbk_exscan_u32(ctx, p32, pr, n, sc + 21));
+  TBK_TRY(tbk_exscan_u32(ctx, c32, cg, n, sc + 22));
+  TBK_LAUNCH(ctx, "shard_table", shard_table_k, 1, 256, 0, n, world, k, d_fo, key, cuts, pr, cg, sc + 21, sc + 22, (long long*)tab);
+  if (n) {
+    // (the file index of a record: recomputed here, prepare's scratch is gone)
+    TBK_LAUNCH(ctx, "shard_fidx", shard_fidx_k, cdiv(n, SH_B), SH_B, 0, n, k, d_fo, fidx);
+    TBK_LAUNCH(ctx, "shard_scatter", shard_scatter_k, cdiv(n, SH_B), SH_B, 0, n, world, k, d_fo, key, cuts, pass, fidx, pr, cg,
+               (const long long*)tab, in->tid, in->pos, in->strand, in->cig_off, in->cig, effend, rows, cig_out, src_idx);
+  }
+  TBK_HIP(hipStreamSynchronize(ctx->stream));
+  return tbk_check_launch(ctx, "shard_pack");
+}
+
+// rows of all source ranks, concatenated in (source rank, file) order; file_off2[K + 1] (host) = run boundaries over all K
+// input files.  Fills the SoA arrays of the tile (cig_off gets n2 + 1 entries); the CIGAR words are used as received.
+extern "C" int tbk_shard_unpack(tbk_ctx* ctx, const int32_t* rows, uint32_t n2, const uint32_t* file_off2, uint32_t K, int32_t* tid,
+                                int32_t* pos, uint16_t* flag, uint8_t* mapq, uint8_t* strand, int32_t* nh, uint32_t* cig_off, int64_t* prio_hi,
+                                int64_t* prio_lo) {
+  if (!ctx || !file_off2 || K == 0 || !cig_off) return TBK_EINVAL;
+  TBK_HIP(hipSetDevice(ctx->device));
+  TBK_TRY(tbk_ws_reserve(ctx, (size_t)n2 * 8 + ((size_t)1 << 20)));
+  if (n2 == 0) {
+    TBK_HIP(hipMemsetAsync(cig_off, 0, 4, ctx->stream));
+    TBK_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+  }
+  if (!rows || !tid || !pos || !flag || !mapq || !strand || !nh || !prio_hi || !prio_lo) return TBK_EINVAL;
+  uint32_t* d_fo = nullptr;
+  TBK_TRY(shard_upload_file_off(ctx, file_off2, K, &d_fo));
+  uint32_t* nc = ws_alloc<uint32_t>(ctx, n2);
+  if (!nc) return TBK_ENOMEM;
+  TBK_LAUNCH(ctx, "shard_ncig", shard_ncig_k, cdiv(n2, SH_B), SH_B, 0, n2, rows, nc);
+  TBK_TRY(tbk_exscan_u32(ctx, nc, cig_off, n2, ctx->d_scalars + 23));
+  TBK_LAUNCH(ctx, "shard_unpack", shard_unpack_k, cdiv(n2, SH_B), SH_B, 0, n2, K, rows, d_fo, ctx->d_scalars + 23, tid, pos, flag, mapq, strand, nh,
+             cig_off, prio_hi, prio_lo);
+  TBK_HIP(hipStreamSynchronize(ctx->stream));
+  return tbk_check_launch(ctx, "shard_unpack");
+}

@@ -1,30 +1,32 @@
-"""Multi-GPU collapse: input files shard per rank, groups that span ranks are stitched by key.
+"""Multi-GPU collapse: input files shard per rank; the records are shuffled by coordinate, then collapsed once.
 
-Why this is exact: everything order-dependent is per file — a sample lives on one rank —
-or an associative reduction over a group's members:
-  YC  = sum of the per-rank partial YC (integer counts: exact in any order)
-  YX  = sum of the per-rank YX (each rank's samples are disjoint files)
-  YD  = max of the per-rank YD (the list machine of a sample only sees that sample's groups, and their
-        order is a function of the group keys, so the owner rank computes its d values alone)
-  rep = argmin over the per-rank representatives of (effective end, global file index, index in file)
-        — the greedy k-way merge key of tmerge.h:28-50.
-`--store-frac` (FP order) and `-A` (needs the global representative's name) are refused here.
+Every rank holds some of the input files (a sample lives on one rank).  The ranks agree on R-1 coordinate cuts that no
+read of any file spans — global tiecov bundle boundaries — and every record that passes the filters moves to the rank
+that owns its coordinate range.  That rank then holds, for its range, the sorted records of ALL input files, i.e. a
+tile for the ordinary single-GPU path: one `tbk_collapse_tile` (run-merge sort over the K files as runs, YC / YX / YD
+on complete groups) and one `tbk_coverage_tile`, nothing to stitch afterwards.
+
+Why this is exact: groups never span a cut (a group shares (tid,start)), YD chains renew at every cut
+(no read of the list reaches across it), tiecov bundles are whole.  The one quantity that depends on records the
+filters drop is the effective end of the k-way merge (tmerge.h:28-50: per-file running max, taken BEFORE
+passes_options), which decides the representative; the owner of a file computes it and it travels with the record as
+its explicit priority (prio_hi = effective end, prio_lo = file << 32 | index in file), which `tbk_collapse_tile`
+honours.  `--store-frac` and `-A` are refused here (they need the single-tile path's ordered passes).
 
 Protocol per tile (one process per GPU, torch.distributed; backend "nccl" = RCCL over xGMI, "gloo" on CPU):
-  1. local collapse (tbk_collapse_tile) -> local groups in output order, with rep_effend
-  2. all-gather of 64 sampled group keys per rank  -> R-1 target splitters
-  3. each target is moved forward to a GLOBAL bundle boundary (no group of any rank spans it) with a
-     few all-reduce(max/min) rounds of one scalar — so every rank ends up owning whole tiecov bundles
-  4. all-to-all(v) of the partial groups {tid,pos,strand,yx,yd,prio,ncig | yc | CIGAR words}
-  5. stitch = tbk_collapse_tile again over the received partials ("files" = source ranks, all marked
-     TieBrush-merged so YC/YX/YD are carried; representative by explicit priority)
-  6. tiecov on the owned slice; junction numbers are offset by an all-gather of the per-rank counts.
+  1. tbk_shard_prepare: per record merge key, filter verdict, effective end, per-file running max of the read ends
+  2. all-gather of 64 sampled keys (+ file counts) per rank -> R-1 target cuts
+  3. each target moves forward to a global bundle boundary: all-reduce(max) of "farthest read end before the cut",
+     all-reduce(min) of "next read start after it", until every cut is clean (tbk_shard_probe_max / _next)
+  4. tbk_shard_pack + all-to-all(v): 24-byte rows {tid,pos,strand,n_cigar,effective end,index} and the CIGAR words,
+     grouped by (destination, file) so that the receiver sees one sorted run per input file
+  5. tbk_shard_unpack -> tbk_collapse_tile over the K runs -> tiecov on the owned slice; junction numbers are offset
+     by an all-gather of the per-rank counts.
 
-The rank algorithm is a generator that yields collective requests, so the same code runs over
-torch.distributed (`run_distributed`) and over an in-process loopback of R virtual ranks (`run_loopback`,
-used to exercise R>1 on a single GPU and in CPU tests).  Arrays are numpy (host tiles) or torch CUDA
-tensors (tiles resident in HBM: nothing but a few scalars ever visits the host); the index bookkeeping
-between the two HIP collapses (searchsorted / cummax / bincount over group keys) is plumbing.
+The rank algorithm is a generator that yields collective requests, so the same code runs over torch.distributed
+(`run_distributed`) and over an in-process loopback of R virtual ranks (`run_loopback`, used to exercise R>1 on a single
+GPU and in CPU tests).  Arrays are numpy (host tiles, numpy restatement of the four device steps below) or torch CUDA
+tensors (tiles resident in HBM: only counts and cut keys ever visit the host).
 """
 from __future__ import annotations
 
@@ -36,7 +38,7 @@ import numpy as np
 from .soa import SoATile, CovInput
 
 N_SAMPLES = 64
-KEY_INF = np.iinfo(np.int64).max
+KEY_INF = 1 << 62        # above every key: keys are (tid+1) << 31 | start
 
 
 # ---- numpy / torch shim (only the handful of index ops the protocol needs) -----------------------------------
@@ -169,128 +171,276 @@ def _gather_cigars(X, cig_off, cig, rep):
     return ncig, off, cig[idx]
 
 
-def _pack_generic(X, local_tile, loc, first_fidx):
-    """Exchange layout of the local groups (the layout tbk_pack_partials produces on the device)."""
-    like = local_tile.tid
-    rep = X.u32_to_i64(loc["rep"])
-    fo = X.to_i64(local_tile.file_off) if not _is_t(like) else \
-        _torch().from_numpy(np.asarray(local_tile.file_off).astype(np.int64)).to(like.device)
-    lf = X.searchsorted(fo, rep, right=True) - 1
-    ncig, _, cig = _gather_cigars(X, local_tile.cig_off, local_tile.cig, rep)
-    ycb = loc["yc"].view(_torch().int64) if _is_t(like) else np.ascontiguousarray(loc["yc"], np.float64).view(np.int64)
-    P = X.stack([X.to_i64(local_tile.tid[rep]), X.to_i64(local_tile.pos[rep]), X.to_i64(local_tile.strand[rep]),
-                 X.to_i64(loc["yx"]), X.to_i64(loc["yd"]), X.to_i64(loc["rep_effend"]),
-                 ((lf + first_fidx) << 32) | (rep - fo[lf]), ncig, ycb], axis=1)
-    return P, cig
+# ---- numpy restatement of the device steps (host tiles: CPU tests, gloo) --------------------------------------------
+def _reflen_np(tile):
+    ops = np.asarray(tile.cig) & 0xF
+    ln = (np.asarray(tile.cig) >> 4).astype(np.int64)
+    w = np.where(np.isin(ops, [0, 2, 3, 7, 8]), ln, 0)
+    c = np.concatenate([[0], np.cumsum(w)])
+    co = np.asarray(tile.cig_off).astype(np.int64)
+    return c[co[1:]] - c[co[:-1]]
+
+
+def _prepare_np(tile, max_nh=2**31 - 1, min_qual=-1, keep_supplementary=False, keep_secondary=False, **_):
+    """tbk_shard_prepare on the host: (key, emax, effend, pass)."""
+    n = tile.n_records
+    flag = np.asarray(tile.flag).astype(np.int64)
+    mapped = (flag & 0x4) == 0
+    pos = np.asarray(tile.pos).astype(np.int64)
+    start = np.where(mapped, pos + 1, 0)
+    end = np.where(mapped, pos + _reflen_np(tile), 0)
+    tid = np.asarray(tile.tid).astype(np.int64)
+    key = ((tid + 1) << 31) | start
+    nh = np.asarray(tile.nh).astype(np.int64)
+    nh = np.where(nh == -(2**31), 0, nh)
+    ok = mapped & (np.asarray(tile.mapq).astype(np.int64) >= min_qual) & (nh <= max_nh)
+    if not keep_supplementary:
+        ok &= (flag & 0x800) == 0
+    if not keep_secondary:
+        ok &= (flag & 0x100) == 0
+    emax = np.zeros(n, np.int64)
+    effend = np.zeros(n, np.int64)
+    fo = np.asarray(tile.file_off).astype(np.int64)
+    for f in range(tile.n_files):
+        lo, hi = int(fo[f]), int(fo[f + 1])
+        if hi == lo:
+            continue
+        k = key[lo:hi]
+        if np.any(k[1:] < k[:-1]):
+            raise ValueError("input not coordinate-sorted")
+        emax[lo:hi] = np.maximum.accumulate(((tid[lo:hi] + 1) << 31) | end[lo:hi])
+        head = np.ones(hi - lo, bool)
+        head[1:] = k[1:] != k[:-1]
+        run = np.cumsum(head) - 1
+        big = np.int64(1) << 33
+        effend[lo:hi] = np.maximum.accumulate(run * big + end[lo:hi]) - run * big
+    return key, emax, effend.astype(np.int32), ok.astype(np.uint8)
+
+
+def _probe_max_np(file_off, key, emax, cuts):
+    m = np.full(len(cuts), -1, np.int64)
+    for f in range(len(file_off) - 1):
+        lo, hi = int(file_off[f]), int(file_off[f + 1])
+        i = np.searchsorted(key[lo:hi], cuts, side="left")
+        m = np.where(i > 0, np.maximum(m, emax[lo + np.maximum(i - 1, 0)]), m)
+    return m
+
+
+def _probe_next_np(file_off, key, m):
+    nxt = np.full(len(m), KEY_INF, np.int64)
+    for f in range(len(file_off) - 1):
+        lo, hi = int(file_off[f]), int(file_off[f + 1])
+        i = np.searchsorted(key[lo:hi], m, side="right")
+        nxt = np.where(i < hi - lo, np.minimum(nxt, key[lo + np.minimum(i, max(hi - lo - 1, 0))] if hi > lo else nxt), nxt)
+    return nxt
+
+
+def _pack_np(tile, key, passm, effend, cuts, world):
+    """tbk_shard_pack on the host: (rows, cig words, src_idx, tab[world][k][5])."""
+    k = tile.n_files
+    fo = np.asarray(tile.file_off).astype(np.int64)
+    co = np.asarray(tile.cig_off).astype(np.int64)
+    tab = np.zeros((world, k, 5), np.int64)
+    order = []
+    for d in range(world):
+        for f in range(k):
+            lo, hi = int(fo[f]), int(fo[f + 1])
+            a = lo if d == 0 else lo + int(np.searchsorted(key[lo:hi], cuts[d - 1], side="left"))
+            b = hi if d == world - 1 else lo + int(np.searchsorted(key[lo:hi], cuts[d], side="left"))
+            idx = np.arange(a, b)[passm[a:b].astype(bool)]
+            tab[d, f, 0], tab[d, f, 1] = a, len(idx)
+            tab[d, f, 2] = int((co[idx + 1] - co[idx]).sum())
+            order.append(idx)
+    src = np.concatenate(order) if order else np.zeros(0, np.int64)
+    flat = tab.reshape(-1, 5)
+    flat[:, 3] = np.concatenate([[0], np.cumsum(flat[:, 1])])[:-1]
+    flat[:, 4] = np.concatenate([[0], np.cumsum(flat[:, 2])])[:-1]
+    f_of = np.searchsorted(fo, src, side="right") - 1
+    ncig = co[src + 1] - co[src]
+    rows = np.stack([np.asarray(tile.tid)[src].astype(np.int64), np.asarray(tile.pos)[src].astype(np.int64),
+                     np.asarray(tile.strand)[src].astype(np.int64), ncig, effend[src].astype(np.int64), src - fo[f_of]],
+                    axis=1).astype(np.int32) if len(src) else np.zeros((0, 6), np.int32)
+    _, _, cigw = _gather_cigars(_NP, tile.cig_off, np.asarray(tile.cig), src)
+    return rows, cigw, src, tab
+
+
+def _unpack_np(rows, file_off2):
+    n2 = rows.shape[0]
+    gf = np.searchsorted(np.asarray(file_off2).astype(np.int64), np.arange(n2), side="right") - 1
+    cig_off = np.concatenate([[0], np.cumsum(rows[:, 3].astype(np.int64))]).astype(np.uint32)
+    return dict(tid=rows[:, 0].astype(np.int32), pos=rows[:, 1].astype(np.int32), flag=np.zeros(n2, np.uint16),
+                mapq=np.full(n2, 255, np.uint8), strand=rows[:, 2].astype(np.uint8), nh=np.full(n2, -(2**31), np.int32),
+                cig_off=cig_off, prio_hi=rows[:, 4].astype(np.int64).astype(np.uint64),
+                prio_lo=((gf.astype(np.int64) << 32) | rows[:, 5].astype(np.int64)).astype(np.uint64))
 
 
 def shard_collapse(compute, local_tile: SoATile, first_fidx: int, rank: int, world: int, strategy="cigar",
                    want_coverage=False, device_chain=False, **filters):
-    """Generator: yields ("all_gather"|"all_reduce_max"|"all_reduce_min"|"exchange", payload) requests and is sent
-    the result; finally returns a ShardResult.  `compute` provides collapse(tile, **kw) / coverage(cin)
-    [/ pack_partials / groups_to_cov_in] — tiebrush_amd.api.Context or a wrapper of it."""
+    """Generator: yields ("all_gather"|"all_reduce_max"|"all_reduce_min"|"exchange_rows"|"all_to_all", payload) requests
+    and is sent the result; finally returns a ShardResult.  `compute` provides collapse(tile, **kw) / coverage(cin)
+    [/ shard_prepare / shard_probe_* / shard_pack / shard_unpack / groups_to_cov_in / finish_yd] —
+    tiebrush_amd.api.Context or a wrapper of it."""
     if filters.get("store_frac") or filters.get("collapse_same"):
-        raise ValueError("--store-frac and -A need a global second pass: single-GPU only (DESIGN.md §7)")
+        raise ValueError("--store-frac and -A need the single-tile path's ordered passes: single-GPU only (DESIGN.md §7)")
     X = _xp(local_tile.tid)
-    # on the device the local YD list machine is deferred: it overlaps the exchange, the stitch and tiecov, and its column
-    # follows the partial rows in a second, small all-to-all (YD of a final group = max over its partials)
-    defer = _is_t(local_tile.tid) and hasattr(compute, "finish_yd") and hasattr(compute, "pack_partials")
-    loc = compute.collapse(local_tile, strategy=strategy, want_coords=True, want_effend=True,
-                           **(dict(defer_yd=True) if defer else {}), **filters)
-    ng = int(loc["n_groups"])
-    if _is_t(local_tile.tid) and hasattr(compute, "pack_partials"):
-        P, cig, emax = compute.pack_partials(loc, first_fidx, int(local_tile.cig.numel()))     # HIP: pack + running max
-        if defer:
-            P[:, 4] = 0                             # the YD column is not final yet
-    else:
-        P, cig = _pack_generic(X, local_tile, loc, first_fidx)
-        emax = X.cummax(((P[:, 0] + 1) << 32) | X.to_i64(loc["g_end"]))
-    key = ((P[:, 0] + 1) << 32) | X.to_i64(loc["g_start"])          # nondecreasing: local output order is bucket order
+    mark = getattr(compute, "mark", None) or (lambda _name: None)       # optional phase hook (tools/prof_dist.py)
+    on_dev = _is_t(local_tile.tid) and hasattr(compute, "shard_prepare")
+    k = local_tile.n_files
+    fo_h = np.asarray(local_tile.file_off).astype(np.int64)
+    n = int(fo_h[-1])
+    any_tbm = bool(np.asarray(local_tile.tbmerged).any())
 
-    # ---- 2. splitter targets from sampled keys -------------------------------------------------------------
-    if ng:
-        samp = key[(X.arange(N_SAMPLES, like=key) * ng) // N_SAMPLES]
+    # ---- 1. per-record keys, filter verdict, effective end ---------------------------------------------------
+    if on_dev:
+        key, emax, effend, passm = compute.shard_prepare(local_tile, **filters)
     else:
-        samp = X.full(N_SAMPLES, KEY_INF, like=key)
-    allsamp = yield ("all_gather", samp)            # [world, N_SAMPLES]
+        key, emax, effend, passm = _prepare_np(local_tile, **filters)
+
+    mark("prepare")
+    # ---- 2. splitter targets from sampled keys (the file table of every rank rides along) --------------------
+    if n:
+        samp = key[(X.arange(N_SAMPLES, like=key) * n) // N_SAMPLES]
+    else:
+        samp = X.full(N_SAMPLES, KEY_INF, like=key) if _is_t(key) else np.full(N_SAMPLES, KEY_INF, np.int64)
+    meta = X.scalar(0, like=samp)
+    meta = X.cat([samp, X.cat([X.scalar(k, like=samp), X.scalar(first_fidx, like=samp), X.scalar(int(any_tbm), like=samp)])])
+    allmeta = X.host((yield ("all_gather", meta))).reshape(world, N_SAMPLES + 3)
+    ks = allmeta[:, N_SAMPLES].astype(np.int64)
+    firsts = allmeta[:, N_SAMPLES + 1].astype(np.int64)
+    if not np.array_equal(firsts, np.concatenate([[firsts[0]], firsts[0] + np.cumsum(ks)[:-1]])):
+        raise ValueError("ranks must hold consecutive blocks of the input files, in rank order")
+    K, kmax = int(ks.sum()), int(ks.max())
+    tbm_anywhere = bool(allmeta[:, N_SAMPLES + 2].any())
+    p = None
     if world > 1:
-        flat = np.sort(X.host(allsamp).reshape(-1))
+        flat = np.sort(allmeta[:, :N_SAMPLES].reshape(-1))
         flat = flat[flat != KEY_INF]
         tgt = np.array([int(flat[(j * len(flat)) // world]) if len(flat) else KEY_INF for j in range(1, world)], np.int64)
         p = _torch().from_numpy(tgt).to(key.device) if _is_t(key) else tgt
         # ---- 3. move every cut forward to a global bundle boundary (all R-1 cuts refined together) ----------
         for _ in range(100000):
-            i = X.searchsorted(key, p)
-            m_local = X.full(world - 1, -1, like=key)
-            if ng:
-                ii = (i - 1).clamp(min=0) if _is_t(i) else np.maximum(i - 1, 0)
-                m_local = X.where(i > 0, emax[ii], m_local)
+            if on_dev:
+                m_local = compute.shard_probe_max(fo_h, key, emax, p, X.full(world - 1, -1, like=key))
+            else:
+                m_local = _probe_max_np(fo_h, X.host(key), X.host(emax), X.host(p))
+                m_local = _torch().from_numpy(m_local).to(key.device) if _is_t(key) else m_local
             m = yield ("all_reduce_max", m_local)
-            ok = (m < p) | (p == KEY_INF)           # every earlier group of every rank ends before the cut
+            ok = (m < p) | (p == KEY_INF)           # every earlier read of every rank ends before the cut
             if bool(ok.all()):
                 break
-            nxt = X.full(world - 1, KEY_INF, like=key)
-            if ng:
-                i2 = X.searchsorted(key, m, right=True)      # first local group starting after m
-                jj = i2.clamp(max=ng - 1) if _is_t(i2) else np.minimum(i2, ng - 1)
-                nxt = X.where(i2 < ng, key[jj], nxt)
+            if on_dev:
+                nxt = compute.shard_probe_next(fo_h, key, m, X.full(world - 1, KEY_INF, like=key))
+            else:
+                nxt = _probe_next_np(fo_h, X.host(key), X.host(m))
+                nxt = _torch().from_numpy(nxt).to(key.device) if _is_t(key) else nxt
             nxt = X.where(ok, p, nxt)
             p = yield ("all_reduce_min", nxt)
-        dest = X.searchsorted(p, key, right=True)
+
+    mark("cuts")
+    # ---- 4. rows grouped by (destination, file); exchange ----------------------------------------------------
+    if on_dev:
+        rows, cigw, src, tab = compute.shard_pack(local_tile, key, passm, effend, p, world)
+        tab_h = tab.cpu().numpy()
     else:
-        dest = X.zeros(ng, like=key)
+        hostify = (lambda a: X.host(a)) if _is_t(key) else (lambda a: a)
+        rows, cigw, src, tab_h = _pack_np(_host_tile(local_tile), hostify(key), hostify(passm), hostify(effend),
+                                          None if p is None else hostify(p), world)
+        if _is_t(key):
+            T = _torch()
+            rows, cigw, src = (T.from_numpy(np.ascontiguousarray(a)).to(key.device) for a in (rows, cigw.view(np.int32), src))
+    cnt_rows = tab_h[:, :, 1].sum(1).astype(np.int64)
+    cnt_words = tab_h[:, :, 2].sum(1).astype(np.int64)
+    n_pass = int(cnt_rows.sum())
+    rows, src = rows[:n_pass], src[:n_pass]
+    per_file = np.zeros((world, kmax), np.int64)
+    per_file[:, :k] = tab_h[:, :, 1]
+    mark("pack")
+    rrows, rcnt, rcig, rper = yield ("exchange_rows", (rows, cnt_rows, cigw[:int(cnt_words.sum())], cnt_words, per_file))
+    ext = None
+    if tbm_anywhere:                                # carried YC / YX / YD of TieBrush-merged inputs follow the rows
+        if any_tbm and local_tile.yc_in is not None:
+            ycb = local_tile.yc_in.view(_torch().int64) if _is_t(local_tile.yc_in) else \
+                np.ascontiguousarray(local_tile.yc_in, np.float64).view(np.int64)
+            e3 = X.stack([ycb, X.to_i64(local_tile.yx_in), X.to_i64(local_tile.yd_in)], axis=1)[src]
+        else:
+            e3 = X.stack([X.zeros(n_pass, like=key)] * 3, axis=1) if n_pass else \
+                (X.zeros(0, like=key).reshape(0, 3))
+        ext, _ = yield ("all_to_all", (e3.contiguous() if _is_t(e3) else np.ascontiguousarray(e3), cnt_rows))
+        tflags = np.zeros(kmax, np.int64)
+        tflags[:k] = np.asarray(local_tile.tbmerged)
+        alltb = X.host((yield ("all_gather", _to_like(tflags, key)))).reshape(world, kmax)
 
-    # ---- 4. exchange the partial groups ---------------------------------------------------------------------
-    # dest is nondecreasing: per-destination row / CIGAR-word counts are differences of prefix positions
-    edges = X.searchsorted(dest, X.arange(world + 1, like=key))
-    cnt = edges[1:] - edges[:-1]
-    csum = X.cat([X.zeros(1, like=key), X.cumsum(P[:, 7])])
-    ccnt = csum[edges[1:]] - csum[edges[:-1]]
-    rP, rcnt, rcig = yield ("exchange", (P, cnt, cig, ccnt))
-
-    # ---- 5. stitch: second-level collapse over the received partials ---------------------------------------
-    n2 = int(rP.shape[0])
-    rcnt_h = np.asarray(rcnt, np.int64)
-    file_off = np.zeros(world + 1, np.uint32)
-    file_off[1:] = np.cumsum(rcnt_h)
-    cig_off2 = X.cat([X.zeros(1, like=rP), X.cumsum(rP[:, 7])]) if n2 else X.zeros(1, like=rP)
-    col = (lambda c: rP[:, c].contiguous()) if _is_t(rP) else (lambda c: np.ascontiguousarray(rP[:, c]))
-    tile2 = SoATile(
-        n_files=world, file_off=file_off, tbmerged=np.ones(world, np.uint8), tid=X.as_dtype(col(0), "i32"),
-        pos=X.as_dtype(col(1), "i32"), flag=X.as_dtype(X.zeros(n2, like=rP), "u16"),
-        mapq=X.as_dtype(X.full(n2, 255, like=rP), "u8"), strand=X.as_dtype(col(2), "u8"),
-        nh=X.as_dtype(X.full(n2, -(2**31), like=rP), "i32"), cig_off=X.as_dtype(cig_off2, "u32"), cig=rcig,
-        yc_in=col(8).view(_torch().float64) if _is_t(rP) else col(8).view(np.float64), yx_in=col(3), yd_in=col(4),
-        prio_hi=col(5) if _is_t(rP) else col(5).view(np.uint64), prio_lo=col(6) if _is_t(rP) else col(6).view(np.uint64))
+    mark("exchange")
+    # ---- 5. the tile of this rank's coordinate range: one sorted run per input file -------------------------
+    n2 = int(rrows.shape[0])
+    rper_h = np.asarray(rper, np.int64).reshape(world, kmax)
+    runs = np.concatenate([rper_h[s, :int(ks[s])] for s in range(world)]) if K else np.zeros(0, np.int64)
+    file_off2 = np.zeros(K + 1, np.uint32)
+    file_off2[1:] = np.cumsum(runs)
+    assert int(file_off2[-1]) == n2
+    tbm2 = np.zeros(K, np.uint8)
+    if tbm_anywhere:
+        tbm2 = np.concatenate([alltb[s, :int(ks[s])] for s in range(world)]).astype(np.uint8)
+    if on_dev:
+        A = compute.shard_unpack(rrows, file_off2)
+    else:
+        A = _unpack_np(X.host(rrows) if _is_t(rrows) else np.asarray(rrows), file_off2)
+        if _is_t(rrows):
+            T = _torch()
+            A = {kk: T.from_numpy(np.ascontiguousarray(v.view(np.int64) if v.dtype == np.uint64 else
+                                                       v.view(np.int16) if v.dtype == np.uint16 else
+                                                       v.view(np.int32) if v.dtype == np.uint32 else v)).to(rrows.device)
+                 for kk, v in A.items()}
+    tile2 = SoATile(n_files=K, file_off=file_off2, tbmerged=tbm2, tid=A["tid"], pos=A["pos"], flag=A["flag"], mapq=A["mapq"],
+                    strand=A["strand"], nh=A["nh"], cig_off=A["cig_off"], cig=rcig, prio_hi=A["prio_hi"], prio_lo=A["prio_lo"])
+    if ext is not None:
+        tile2.yc_in = ext[:, 0].contiguous().view(_torch().float64) if _is_t(ext) else np.ascontiguousarray(ext[:, 0]).view(np.float64)
+        tile2.yx_in = ext[:, 1].contiguous() if _is_t(ext) else np.ascontiguousarray(ext[:, 1])
+        tile2.yd_in = ext[:, 2].contiguous() if _is_t(ext) else np.ascontiguousarray(ext[:, 2])
+    mark("unpack")
+    defer = on_dev and hasattr(compute, "finish_yd")
     fin = compute.collapse(tile2, strategy=strategy, want_coords=True, keep_supplementary=True, keep_secondary=True,
-                           want_rec_group=defer)
+                           **(dict(defer_yd=True) if defer else {}))
     g2 = int(fin["n_groups"])
-    rep2 = X.u32_to_i64(fin["rep"])
-    plo = rP[:, 6][rep2]
-    res = ShardResult(n_groups=g2, n_passed_local=int(loc["n_passed"]), tid=tile2.tid[rep2], start=fin["g_start"],
-                      end=fin["g_end"], rep_fidx=plo >> 32, rep_idx=plo & 0xFFFFFFFF, yc=fin["yc"], yx=fin["yx"], yd=fin["yd"],
+    rep2 = X.u32_to_i64(fin["rep"]) if _is_t(fin["rep"]) else np.asarray(fin["rep"]).astype(np.int64)
+    plo = X.to_i64(A["prio_lo"])[rep2] if _is_t(A["prio_lo"]) else np.asarray(A["prio_lo"]).astype(np.int64)[rep2]
+    res = ShardResult(n_groups=g2, n_passed_local=n_pass, tid=tile2.tid[rep2], start=fin["g_start"], end=fin["g_end"],
+                      rep_fidx=plo >> 32, rep_idx=plo & 0xFFFFFFFF, yc=fin["yc"], yx=fin["yx"], yd=fin["yd"],
                       n_partials_received=n2)
+    mark("collapse")
     # ---- 6. tiecov on the owned slice (whole bundles by construction of the cuts) ---------------------------
     if device_chain:
         res.cov_input = compute.groups_to_cov_in(fin)        # stays in HBM
     else:
         ncg, cof, cg = _gather_cigars(X, tile2.cig_off, tile2.cig, rep2)
-        ycf = fin["yc"].to(_torch().float32).to(_torch().float64) if _is_t(rP) else np.asarray(fin["yc"]).astype(np.float32).astype(np.float64)
-        res.cov_input = CovInput(tid=tile2.tid[rep2], pos=tile2.pos[rep2], flag=X.as_dtype(X.zeros(g2, like=rP), "u16"),
+        ycf = fin["yc"].to(_torch().float32).to(_torch().float64) if _is_t(fin["yc"]) else \
+            np.asarray(fin["yc"]).astype(np.float32).astype(np.float64)
+        res.cov_input = CovInput(tid=tile2.tid[rep2], pos=tile2.pos[rep2], flag=X.as_dtype(X.zeros(g2, like=rep2), "u16"),
                                  cig_off=X.as_dtype(cof, "u32"), cig=cg, yc=ycf, strand=tile2.strand[rep2], yx=X.to_i64(fin["yx"]))
     if want_coverage:
         cov = compute.coverage(res.cov_input)
-        nj = yield ("all_gather", X.scalar(int(cov["n_junctions"]), like=key))
+        nj = yield ("all_gather", X.scalar(int(cov["n_junctions"]), like=rep2))
         res.coverage = cov
         res.junction_offset = int(X.host(nj).reshape(-1)[:rank].sum())
+    mark("coverage")
     if defer:
-        compute.finish_yd()                                     # local YD column is final now
-        ryd, _ = yield ("all_to_all", (X.to_i64(loc["yd"]).contiguous(), cnt))
-        yd = _torch().zeros(max(g2, 1), dtype=_torch().int64, device=ryd.device)
-        if n2:
-            yd.scatter_reduce_(0, fin["rec_group"].to(_torch().int64), ryd, reduce="amax", include_self=True)
-        res.yd = yd[:g2].to(_torch().int32)
+        compute.finish_yd()                                     # the YD column is final now
+    mark("finish_yd")
     return res
+
+
+def _to_like(a, like):
+    return _torch().from_numpy(np.ascontiguousarray(a)).to(like.device) if _is_t(like) else a
+
+
+def _host_tile(tile):
+    """numpy view of a tile whose arrays may be torch tensors (host restatement path only)."""
+    if not _is_t(tile.tid):
+        return tile
+    h = lambda a: None if a is None else a.cpu().numpy()
+    return SoATile(n_files=tile.n_files, file_off=tile.file_off, tbmerged=tile.tbmerged, tid=h(tile.tid), pos=h(tile.pos),
+                   flag=h(tile.flag).view(np.uint16), mapq=h(tile.mapq), strand=h(tile.strand), nh=h(tile.nh),
+                   cig_off=h(tile.cig_off).view(np.uint32), cig=h(tile.cig).view(np.uint32))
 
 
 # ---- drivers ---------------------------------------------------------------------------------------------------
@@ -304,7 +454,7 @@ def run_loopback(compute, tiles, first_fidx, **kw):
         assert all(res is None for res in results) and len({q[0] for q in reqs}) == 1, "ranks diverged"
         kind = reqs[0][0]
         pay = [q[1] for q in reqs]
-        X = _xp(pay[0][0] if kind in ("exchange", "all_to_all") else pay[0])
+        X = _xp(pay[0][0] if kind in ("exchange_rows", "all_to_all") else pay[0])
         if kind == "all_gather":
             out = [X.stack(pay)] * world
         elif kind == "all_reduce_max":
@@ -322,18 +472,19 @@ def run_loopback(compute, tiles, first_fidx, **kw):
                     parts.append(data[o:o + int(ch[d])])
                     cnts.append(int(ch[d]))
                 out.append((X.cat(parts), np.array(cnts, np.int64)))
-        elif kind == "exchange":
+        elif kind == "exchange_rows":
             out = []
             for d in range(world):
-                rows, words, cnts = [], [], []
+                rows, words, cnts, metas = [], [], [], []
                 for s in range(world):
-                    P, cnt, cig, ccnt = pay[s]
-                    ch, cc = np.asarray(X.host(cnt), np.int64), np.asarray(X.host(ccnt), np.int64)
+                    R, cnt, cig, ccnt, per = pay[s]
+                    ch, cc = np.asarray(cnt, np.int64), np.asarray(ccnt, np.int64)
                     o, oc = int(ch[:d].sum()), int(cc[:d].sum())
-                    rows.append(P[o:o + int(ch[d])])
+                    rows.append(R[o:o + int(ch[d])])
                     words.append(cig[oc:oc + int(cc[d])])
                     cnts.append(int(ch[d]))
-                out.append((X.cat(rows), np.array(cnts, np.int64), X.cat(words)))
+                    metas.append(np.asarray(per)[d])
+                out.append((X.cat(rows), np.array(cnts, np.int64), X.cat(words), np.stack(metas)))
         else:
             raise AssertionError(kind)
         new = []
@@ -395,19 +546,21 @@ def run_distributed(compute, tile, first_fidx, device=None, group=None, **kw):
                 out = torch.empty((int(rc_h.sum()),) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
                 dist.all_to_all_single(out, x, output_split_sizes=rc_h.tolist(), input_split_sizes=sc_h.tolist(), group=group)
                 res = (back(out, data), rc_h)
-            elif kind == "exchange":
-                P, cnt, cig, ccnt = pay
-                c = torch.stack([t(cnt), t(ccnt)], dim=1).contiguous()     # [world, 2]: rows and CIGAR words per destination
+            elif kind == "exchange_rows":
+                R, cnt, cig, ccnt, per = pay
+                # one small all-to-all tells every rank what it will receive: [rows, CIGAR words, rows per file of the sender]
+                c = torch.cat([t(np.asarray(cnt, np.int64)).view(world, 1), t(np.asarray(ccnt, np.int64)).view(world, 1),
+                               t(np.asarray(per, np.int64)).view(world, -1)], dim=1).contiguous()
                 rc = torch.empty_like(c)
-                dist.all_to_all_single(rc, c, group=group)                  # who sends me how much
+                dist.all_to_all_single(rc, c, group=group)
                 sc_h, rc_h = c.cpu().numpy().astype(np.int64), rc.cpu().numpy().astype(np.int64)
-                x = t(P).contiguous()
-                outP = torch.empty((int(rc_h[:, 0].sum()),) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-                dist.all_to_all_single(outP, x, output_split_sizes=rc_h[:, 0].tolist(), input_split_sizes=sc_h[:, 0].tolist(), group=group)
+                x = t(R).contiguous()
+                outR = torch.empty((int(rc_h[:, 0].sum()),) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+                dist.all_to_all_single(outR, x, output_split_sizes=rc_h[:, 0].tolist(), input_split_sizes=sc_h[:, 0].tolist(), group=group)
                 y = t(cig).contiguous()
                 outC = torch.empty(int(rc_h[:, 1].sum()), dtype=y.dtype, device=y.device)
                 dist.all_to_all_single(outC, y, output_split_sizes=rc_h[:, 1].tolist(), input_split_sizes=sc_h[:, 1].tolist(), group=group)
-                res = (back(outP, P), rc_h[:, 0].copy(), back(outC, cig))
+                res = (back(outR, R), rc_h[:, 0].copy(), back(outC, cig), rc_h[:, 2:].copy())
             else:
                 raise AssertionError(kind)
             req = gen.send(res)

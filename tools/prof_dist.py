@@ -15,9 +15,14 @@ class C:
     def groups_to_cov_in(s, f):
         torch.cuda.synchronize(); t0=time.perf_counter()
         r= ctx.groups_to_cov_in(f); torch.cuda.synchronize(); print("  g2c %.3f ms"%((time.perf_counter()-t0)*1e3)); return r
-    def pack_partials(s, loc, ff, cap):
+    def _timed(s, name, fn, *a, **k):
         torch.cuda.synchronize(); t0=time.perf_counter()
-        r = ctx.pack_partials(loc, ff, cap, out=s.b.setdefault("p",{})); torch.cuda.synchronize(); print("  pack %.3f ms"%((time.perf_counter()-t0)*1e3)); return r
+        r = fn(*a, **k); torch.cuda.synchronize(); print("  %s %.3f ms"%(name, (time.perf_counter()-t0)*1e3)); return r
+    def shard_prepare(s, tile, **kw): return s._timed("prepare", ctx.shard_prepare, tile, out=s.b.setdefault("sp",{}), **kw)
+    def shard_probe_max(s, *a): return s._timed("probe_max", ctx.shard_probe_max, *a)
+    def shard_probe_next(s, *a): return s._timed("probe_next", ctx.shard_probe_next, *a)
+    def shard_pack(s, *a): return s._timed("pack", ctx.shard_pack, *a, out=s.b.setdefault("pk",{}))
+    def shard_unpack(s, rows, fo): return s._timed("unpack", ctx.shard_unpack, rows, fo, out=s.b.setdefault("up",{}))
     def finish_yd(s):
         ctx.finish_yd()
     def coverage(s, v):
@@ -29,20 +34,24 @@ for it in range(4):
     r = dist.run_loopback(c, [dt], [0], want_coverage=True, device_chain=True)
     torch.cuda.synchronize(); print("step %.3f ms"%((time.perf_counter()-t0)*1e3))
 
-# ---- per-op timing of the torch glue -----------------------------------------------------------------------
-import collections
-acc = collections.defaultdict(float)
-def wrap(name, fn):
-    def w(*a, **k):
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        r = fn(*a, **k)
-        torch.cuda.synchronize(); acc[name] += (time.perf_counter() - t0) * 1e3
-        return r
-    return staticmethod(w)
-for name in ("to_i64", "u32_to_i64", "zeros", "full", "arange", "cummax", "cumsum", "searchsorted", "repeat", "stack", "cat", "host", "where", "bincount", "as_dtype"):
-    setattr(D._TT, name, wrap(name, getattr(D._TT, name)))
-import builtins
-torch.cuda.synchronize(); t0 = time.perf_counter()
-r = dist.run_loopback(c, [dt], [0], want_coverage=True, device_chain=True)
-torch.cuda.synchronize(); print("instrumented step %.3f ms" % ((time.perf_counter() - t0) * 1e3))
-for k, v in sorted(acc.items(), key=lambda kv: -kv[1]): print("   %-14s %.3f ms" % (k, v))
+# ---- phase timing (host clock, synchronised at every mark) ------------------------------------------------------
+class M:
+    def __init__(s): s.b = {}; s.t = None; s.acc = {}
+    def __getattr__(s, name):
+        return getattr(ctx, name)
+    def collapse(s, t, **kw): return ctx.collapse(t, out=s.b.setdefault(("c", t.n_files), {}), **kw)
+    def coverage(s, v): return ctx.coverage(v, out=s.b.setdefault("v", {}), raw=True)
+    def shard_prepare(s, tile, **kw): return ctx.shard_prepare(tile, out=s.b.setdefault("sp", {}), **kw)
+    def shard_pack(s, *a): return ctx.shard_pack(*a, out=s.b.setdefault("pk", {}))
+    def shard_unpack(s, rows, fo): return ctx.shard_unpack(rows, fo, out=s.b.setdefault("up", {}))
+    def mark(s, name):
+        torch.cuda.synchronize(); now = time.perf_counter()
+        if s.t is not None: s.acc[name] = s.acc.get(name, 0.0) + (now - s.t) * 1e3
+        s.t = now
+m = M()
+R = 10
+for it in range(R + 2):
+    if it == 2: m.acc = {}
+    torch.cuda.synchronize(); m.t = time.perf_counter()
+    dist.run_loopback(m, [dt], [0], want_coverage=True, device_chain=True)
+print("phases (ms, synchronised):", {k: round(v / R, 3) for k, v in m.acc.items()}, "sum %.3f" % (sum(m.acc.values()) / R))
