@@ -58,30 +58,34 @@ __global__ __launch_bounds__(1024) void scan_spine_k(uint64_t* __restrict__ part
   if (threadIdx.x == 0 && total) *total = carry_s;
 }
 
-// n <= SC_SMALL: the whole scan in one block
-constexpr uint32_t SC_SMALL = 8192;
+// n <= SC_SMALL: the whole scan in one block (chunks of 8192 with a running carry)
+constexpr uint32_t SC_SMALL = 16384;
 template <class OutT>
 __global__ __launch_bounds__(1024) void scan_small_k(const uint32_t* __restrict__ in, OutT* __restrict__ out, uint32_t n,
                                                      uint64_t* __restrict__ total) {
   __shared__ uint64_t sm[16];
-  constexpr uint32_t E = SC_SMALL / 1024;  // consecutive elements per thread
-  uint32_t v[E];
-  uint64_t s = 0;
+  constexpr uint32_t E = 8;  // consecutive elements per thread and chunk
+  uint64_t carry = 0;
+  for (uint32_t c0 = 0; c0 < n; c0 += 1024 * E) {
+    uint32_t v[E];
+    uint64_t s = 0;
 #pragma unroll
-  for (uint32_t e = 0; e < E; ++e) {
-    const uint32_t i = threadIdx.x * E + e;
-    v[e] = i < n ? in[i] : 0u;
-    s += v[e];
-  }
-  uint64_t tot;
-  uint64_t ex = block_excl_sum<uint64_t, 1024>(s, sm, &tot);
+    for (uint32_t e = 0; e < E; ++e) {
+      const uint32_t i = c0 + threadIdx.x * E + e;
+      v[e] = i < n ? in[i] : 0u;
+      s += v[e];
+    }
+    uint64_t tot;
+    uint64_t ex = carry + block_excl_sum<uint64_t, 1024>(s, sm, &tot);
 #pragma unroll
-  for (uint32_t e = 0; e < E; ++e) {
-    const uint32_t i = threadIdx.x * E + e;
-    if (i < n) out[i] = (OutT)ex;
-    ex += v[e];
+    for (uint32_t e = 0; e < E; ++e) {
+      const uint32_t i = c0 + threadIdx.x * E + e;
+      if (i < n) out[i] = (OutT)ex;
+      ex += v[e];
+    }
+    carry += tot;
   }
-  if (threadIdx.x == 0 && total) *total = tot;
+  if (threadIdx.x == 0 && total) *total = carry;
 }
 
 template <class OutT>
