@@ -41,6 +41,23 @@ def test_loopback_golden_t2(bam_loader):
     check_against_flat(res, tile, flat)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_loopback_tbmerged_inputs(world, bam_loader):
+    """TieBrush-merged inputs (t1.bam, t2.bam: carried YC / YX / YD) mixed with plain sample files: the carried tags
+    follow the shuffled rows, the file flags are gathered, and the result is the flat re-collapse (SURVEY §8e chain)."""
+    from helpers import GOLDEN, sample_paths
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import dist, soa
+    bams = [bam_loader(os.path.join(GOLDEN, "t1", "t1.bam"))] + [bam_loader(p) for p in sample_paths("t2")[:3]] + \
+           [bam_loader(os.path.join(GOLDEN, "t2", "t2.bam"))]
+    tile = soa.tile_from_bams(bams)
+    assert tile.tbmerged.tolist() == [1, 0, 0, 0, 1]
+    flat = orc.collapse(tile)
+    tiles, first = split_tile(tile, world)
+    res = dist.run_loopback(OracleCompute(), tiles, first)
+    check_against_flat(res, tile, flat)
+
+
 def test_refuses_order_dependent_flags():
     from tiebrush_amd import dist, synth
     tile = synth.make_tile(2, 100, "c2", n_loci=10)

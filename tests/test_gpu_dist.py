@@ -100,3 +100,26 @@ def test_loopback_device_resident_equals_flat_oracle(world, nfiles, profile, str
             v = getattr(r, f)
             setattr(r, f, v.cpu().numpy() if isinstance(v, torch.Tensor) else v)
     check_against_flat(res, tile, flat, flat_cov)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_loopback_device_resident_tbmerged_inputs(world, bam_loader):
+    """carried YC / YX / YD of TieBrush-merged inputs through the device shuffle (third all-to-all + gathered file flags)"""
+    import os
+    import torch
+    from helpers import GOLDEN, sample_paths
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import api, dist, soa
+    bams = [bam_loader(os.path.join(GOLDEN, "t1", "t1.bam"))] + [bam_loader(p) for p in sample_paths("t2")[:5]] + \
+           [bam_loader(os.path.join(GOLDEN, "t2", "t2.bam"))]
+    tile = soa.tile_from_bams(bams)
+    flat = orc.collapse(tile)
+    flat_cov = orc.coverage(__import__("tiebrush_amd.synth", fromlist=["x"]).collapsed_to_cov_input(tile, flat))
+    tiles, first = split_tile(tile, world)
+    dtiles = [api.to_device(t, "cuda:0") for t in tiles]
+    res = dist.run_loopback(DeviceCompute(), dtiles, first, want_coverage=True, device_chain=True)
+    for r in res:
+        for f in ("tid", "start", "end", "rep_fidx", "rep_idx", "yc", "yx", "yd"):
+            v = getattr(r, f)
+            setattr(r, f, v.cpu().numpy() if isinstance(v, torch.Tensor) else v)
+    check_against_flat(res, tile, flat, flat_cov)

@@ -413,7 +413,7 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
   bool any_tb = false;
   if (in->tbmerged)
     for (uint32_t f = 0; f < in->n_files; ++f) any_tb |= in->tbmerged[f] != 0;
-  if (any_tb && (!in->yc_in || !in->yx_in || !in->yd_in)) return TBK_EINVAL;
+  if (in->n_records && any_tb && (!in->yc_in || !in->yx_in || !in->yd_in)) return TBK_EINVAL;
   if (in->mem != out->mem) return TBK_EINVAL;
   if (opts->defer_yd && in->mem != TBK_MEM_DEVICE) return TBK_EINVAL;
   TBK_TRY(finish_yd(ctx));  // a still-pending YD stage of the previous tile owns part of the arena

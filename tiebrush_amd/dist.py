@@ -467,7 +467,7 @@ def run_loopback(compute, tiles, first_fidx, **kw):
                 parts, cnts = [], []
                 for s_ in range(world):
                     data, cnt = pay[s_]
-                    ch = np.asarray(X.host(cnt), np.int64)
+                    ch = np.asarray(X.host(cnt) if _is_t(cnt) else cnt, np.int64)
                     o = int(ch[:d].sum())
                     parts.append(data[o:o + int(ch[d])])
                     cnts.append(int(ch[d]))
