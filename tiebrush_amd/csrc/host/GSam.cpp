@@ -140,6 +140,10 @@ void GSamWriter::write_raw(const tbh::BamRec& r) {
   if (!w_.write(le, 4) || !w_.write(r.d.data(), r.d.size())) GError("Error: failed to write an alignment record\n");
 }
 
+void GSamWriter::write_framed(const uint8_t* p, size_t n) {
+  if (n && !w_.write(p, n)) GError("Error: failed to write alignment records\n");
+}
+
 void GSamWriter::write(GSamRecord* brec) {
   if (brec) write_raw(*brec->get_b());
 }

@@ -157,4 +157,6 @@ class GSamWriter {
   sam_hdr_t* header() { return &hdr_; }
   void write(GSamRecord* brec);
   void write_raw(const tbh::BamRec& r);
+  // a run of already framed records (each: little-endian block_size, then the record)
+  void write_framed(const uint8_t* p, size_t n);
 };

@@ -165,39 +165,52 @@ static bool deflate_member(const uint8_t* src, size_t n, int level, std::vector<
   return true;
 }
 
+bool BgzfWriter::wait_bg() {
+  if (bg_) {
+    bg_->join();
+    delete bg_;
+    bg_ = nullptr;
+  }
+  if (!bg_ok_ && err_.empty()) err_ = "deflate or write failed";
+  return bg_ok_;
+}
+
+// The chunk is deflated block-parallel and written by a background thread while the caller keeps producing: one chunk
+// in flight (the member sequence is the same as with synchronous flushing).
 bool BgzfWriter::flush_chunk() {
+  if (!wait_bg()) return false;
   if (buf_.empty()) return true;
-  size_t nblk = (buf_.size() + kBlock - 1) / kBlock;
-  std::vector<std::vector<uint8_t>> outs(nblk);
-  std::atomic<size_t> next{0};
-  std::atomic<bool> ok{true};
-  auto work = [&]() {
-    for (;;) {
-      size_t i = next.fetch_add(1);
-      if (i >= nblk) break;
-      size_t off = i * kBlock;
-      size_t n = buf_.size() - off < kBlock ? buf_.size() - off : kBlock;
-      if (!deflate_member(buf_.data() + off, n, level_, outs[i])) ok = false;
-    }
-  };
-  int nt = (int)(nblk < (size_t)threads_ ? nblk : (size_t)threads_);
-  if (nt <= 1) {
-    work();
-  } else {
-    std::vector<std::thread> th;
-    for (int t = 0; t < nt; ++t) th.emplace_back(work);
-    for (auto& t : th) t.join();
-  }
-  if (!ok) {
-    err_ = "deflate failed";
-    return false;
-  }
-  for (auto& o : outs)
-    if (fwrite(o.data(), 1, o.size(), f_) != o.size()) {
-      err_ = "write failed";
-      return false;
-    }
+  bg_buf_.swap(buf_);
   buf_.clear();
+  bg_ = new std::thread([this]() {
+    const std::vector<uint8_t>& src = bg_buf_;
+    size_t nblk = (src.size() + kBlock - 1) / kBlock;
+    std::vector<std::vector<uint8_t>> outs(nblk);
+    std::atomic<size_t> next{0};
+    std::atomic<bool> ok{true};
+    auto work = [&]() {
+      for (;;) {
+        size_t i = next.fetch_add(1);
+        if (i >= nblk) break;
+        size_t off = i * kBlock;
+        size_t n = src.size() - off < kBlock ? src.size() - off : kBlock;
+        if (!deflate_member(src.data() + off, n, level_, outs[i])) ok = false;
+      }
+    };
+    int nt = (int)(nblk < (size_t)threads_ ? nblk : (size_t)threads_);
+    if (nt <= 1) {
+      work();
+    } else {
+      std::vector<std::thread> th;
+      for (int t = 0; t < nt; ++t) th.emplace_back(work);
+      for (auto& t : th) t.join();
+    }
+    bool good = ok;
+    for (auto& o : outs)
+      if (good && fwrite(o.data(), 1, o.size(), f_) != o.size()) good = false;
+    if (!good) bg_ok_ = false;
+    bg_buf_.clear();
+  });
   return true;
 }
 
@@ -218,6 +231,7 @@ bool BgzfWriter::write(const void* p, size_t n) {
 bool BgzfWriter::close() {
   if (!f_) return true;
   bool ok = flush_chunk();
+  ok = wait_bg() && ok;
   ok = ok && fwrite(kEof, 1, sizeof(kEof), f_) == sizeof(kEof);
   if (own_)
     ok = (fclose(f_) == 0) && ok;

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace tbh {
@@ -27,13 +28,17 @@ class BgzfWriter {
   const std::string& error() const { return err_; }
 
  private:
-  bool flush_chunk();
+  bool flush_chunk();   // hands buf_ to the background compressor (after waiting for the previous hand-off)
+  bool wait_bg();       // joins the background compressor; false if it failed
   FILE* f_ = nullptr;
   bool own_ = false;
   int level_ = 6;
   int threads_ = 1;
-  size_t chunk_ = (size_t)64 << 20;
+  size_t chunk_ = (size_t)16 << 20;
   std::vector<uint8_t> buf_;
+  std::vector<uint8_t> bg_buf_;   // chunk being deflated + written while the caller fills buf_ again
+  std::thread* bg_ = nullptr;
+  bool bg_ok_ = true;
   std::string err_;
 };
 

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <string>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -96,11 +97,28 @@ int main(int argc, char* argv[]) {
   if (opt.keep_unmapped) GError("Error: -M/--keep-unmap is not supported by the GPU build\n");
   while (const char* ifn = args.nextNonOpt()) inRecords.addFile(tbh_realpath(ifn).c_str());
 
-  inRecords.start();
+  const bool timing = getenv("TBK_TIMING") != nullptr;
+  auto tnow = [] { return std::chrono::steady_clock::now(); };
+  auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double, std::milli>(b - a).count();
+  };
+  auto t_start = tnow();
+  // the HIP runtime takes ~0.2 s to come up: bring the context up on a helper thread while the inputs are opened and
+  // the first tile is inflated and parsed
   tbk_ctx* ctx = nullptr;
   int dev = getenv("TBK_DEVICE") ? atoi(getenv("TBK_DEVICE")) : 0;
-  int rc = tbk_create(dev, &ctx);
-  if (rc != 0) GError("Error: cannot use GPU %d (%s); this build has no CPU collapse path\n", dev, tbk_strerror(rc));
+  int rc = 0;
+  std::thread ctx_thread([&]() { rc = tbk_create(dev, &ctx); });
+  bool ctx_ready = false;
+  auto need_ctx = [&]() {
+    if (ctx_ready) return;
+    ctx_thread.join();
+    ctx_ready = true;
+    if (rc != 0) GError("Error: cannot use GPU %d (%s); this build has no CPU collapse path\n", dev, tbk_strerror(rc));
+  };
+  inRecords.start();
+  auto t_ctx = tnow();
+  double ms_load = 0, ms_gpu = 0, ms_tag = 0;
 
   int nthreads = (int)std::thread::hardware_concurrency();
   if (nthreads < 1) nthreads = 1;
@@ -116,15 +134,17 @@ int main(int argc, char* argv[]) {
     std::vector<double> yc;
     std::vector<int64_t> yx;
     std::vector<int32_t> yd;
-    tbh::BamRec r;
     for (const auto& plan : plans) {
+      auto t0 = tnow();
       inRecords.load_tile(tile, opt.strategy == TBK_STRAT_FULL, opt.collapse_same != 0, nthreads, &plan);
+      auto t1 = tnow();
       tbk_soa_in in = tile.view();
       size_t n = tile.n();
       rep.resize(n ? n : 1);
       yc.resize(n ? n : 1);
       yx.resize(n ? n : 1);
       yd.resize(n ? n : 1);
+      need_ctx();
       tbk_groups_out out;
       memset(&out, 0, sizeof(out));
       out.mem = TBK_MEM_HOST;
@@ -134,25 +154,58 @@ int main(int argc, char* argv[]) {
       out.yx = yx.data();
       out.yd = yd.data();
       rc = tbk_collapse_tile(ctx, &opt, &in, &out);
+      auto t2 = tnow();
       if (rc == TBK_EUNSORTED) GError("Error: an input file is not coordinate-sorted!\n");
       if (rc != 0) GError("Error: GPU collapse failed: %s (%s)\n", tbk_strerror(rc), tbk_last_error(ctx));
-      for (uint32_t g = 0; g < out.n_groups; ++g) {  // flushPData tagging, tiebrush.cpp:506-525
-        tbh::RecView v = inRecords.record(rep[g]);
-        r.d.assign(v.p, v.p + v.len);
-        r.update_float("YC", (float)yc[g]);
-        r.update_int("YX", yx[g]);
-        if (yd[g] > 0)
-          r.update_int("YD", yd[g]);
-        else
-          r.del("YD");
-        outfile.write_raw(r);
+      // flushPData tagging (tiebrush.cpp:506-525): the groups are independent, so slices of them are tagged and framed
+      // by worker threads into per-slice byte runs, which then go to the writer in order
+      {
+        const uint32_t ng = out.n_groups;
+        const int nt = ng < 4096 ? 1 : nthreads;
+        std::vector<std::vector<uint8_t>> runs((size_t)nt);
+        auto tag_slice = [&](int t) {
+          const uint32_t g0 = (uint32_t)((uint64_t)ng * t / nt), g1 = (uint32_t)((uint64_t)ng * (t + 1) / nt);
+          std::vector<uint8_t>& o = runs[(size_t)t];
+          tbh::BamRec rr;
+          for (uint32_t g = g0; g < g1; ++g) {
+            tbh::RecView v = inRecords.record(rep[g]);
+            rr.d.assign(v.p, v.p + v.len);
+            rr.update_float("YC", (float)yc[g]);
+            rr.update_int("YX", yx[g]);
+            if (yd[g] > 0)
+              rr.update_int("YD", yd[g]);
+            else
+              rr.del("YD");
+            const uint32_t bs = (uint32_t)rr.d.size();
+            const uint8_t le[4] = {(uint8_t)bs, (uint8_t)(bs >> 8), (uint8_t)(bs >> 16), (uint8_t)(bs >> 24)};
+            o.insert(o.end(), le, le + 4);
+            o.insert(o.end(), rr.d.begin(), rr.d.end());
+          }
+        };
+        if (nt == 1) {
+          tag_slice(0);
+        } else {
+          std::vector<std::thread> th;
+          for (int t = 0; t < nt; ++t) th.emplace_back(tag_slice, t);
+          for (auto& x : th) x.join();
+        }
+        for (auto& o : runs) outfile.write_framed(o.data(), o.size());
       }
+      auto t3 = tnow();
+      ms_load += tms(t0, t1);
+      ms_gpu += tms(t1, t2);
+      ms_tag += tms(t2, t3);
       inCounter += out.n_passed;
       outCounter += out.n_groups;
     }
   }
+  auto t_closed = tnow();
+  need_ctx();
   inRecords.stop();
   tbk_destroy(ctx);
+  if (timing)
+    fprintf(stderr, "timing ms: open+context %.1f | decode+SoA %.1f | collapse (PCIe incl.) %.1f | tag+queue %.1f | total to writer close %.1f\n",
+            tms(t_start, t_ctx), ms_load, ms_gpu, ms_tag, tms(t_start, t_closed));
   double p = 100.00 - (double)(outCounter * 100.00) / (double)inCounter;
   GMessage("%ld input records written as %ld (%.2f%% reduction)\n", (long)inCounter, (long)outCounter, p);
   return 0;
