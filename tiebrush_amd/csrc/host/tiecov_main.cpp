@@ -35,6 +35,41 @@ static bool ends_with(const std::string& s, const char* suf) {
   return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
 }
 
+// Text output: the lines are independent, so slices of them are formatted by worker threads (same printf formats as the
+// reference) and written in order.
+template <class F>
+static void emit_lines(FILE* f, uint32_t n, F fmt) {
+  unsigned hw = std::thread::hardware_concurrency();
+  size_t nt = n < 50000 ? 1 : std::max<size_t>(1, std::min<size_t>(hw ? hw : 4, 32));
+  std::vector<std::string> parts(nt);
+  auto work = [&](size_t t) {
+    const uint32_t lo = (uint32_t)((uint64_t)n * t / nt), hi = (uint32_t)((uint64_t)n * (t + 1) / nt);
+    std::string& o = parts[t];
+    o.reserve((size_t)(hi - lo) * 40);
+    char b[1024];
+    for (uint32_t i = lo; i < hi; ++i) {
+      int len = fmt(i, b, sizeof(b));
+      if (len < 0) len = 0;
+      if ((size_t)len >= sizeof(b)) {  // a very long reference name: format again into a buffer that fits
+        std::vector<char> big((size_t)len + 1);
+        len = fmt(i, big.data(), big.size());
+        o.append(big.data(), (size_t)len);
+      } else {
+        o.append(b, (size_t)len);
+      }
+    }
+  };
+  if (nt == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nt; ++t) th.emplace_back(work, t);
+    for (auto& x : th) x.join();
+  }
+  for (auto& o : parts)
+    if (!o.empty() && fwrite(o.data(), 1, o.size(), f) != o.size()) GError("Error: failed to write an output line\n");
+}
+
 int main(int argc, char* argv[]) {
   Args args(argc, argv, "help;verbose;version;DVWhc:s:j:");
   if (!args.error().empty()) {
@@ -100,6 +135,11 @@ int main(int argc, char* argv[]) {
     num_samples = (int)hdr->co_samples().size();
     if (num_samples == 0) GError("Error: no sample lines found in header");
   }
+  // the HIP runtime takes ~0.2 s to come up: do that on a helper thread while the input is decoded
+  tbk_ctx* ctx = nullptr;
+  int dev = getenv("TBK_DEVICE") ? atoi(getenv("TBK_DEVICE")) : 0;
+  int rc = 0;
+  std::thread ctx_thread([&]() { rc = tbk_create(dev, &ctx); });
   // ---- decode to SoA (tiecov.cpp:482-485 defaults: YC absent -> 1.0, YX absent -> 1)
   tbh::BamFile* bf = samreader.file();
   size_t n = bf->n();
@@ -149,9 +189,7 @@ int main(int argc, char* argv[]) {
   }
   cig_off[n] = (uint32_t)co;
 
-  tbk_ctx* ctx = nullptr;
-  int dev = getenv("TBK_DEVICE") ? atoi(getenv("TBK_DEVICE")) : 0;
-  int rc = tbk_create(dev, &ctx);
+  ctx_thread.join();
   if (rc != 0) GError("Error: cannot use GPU %d (%s); this build has no CPU coverage path\n", dev, tbk_strerror(rc));
   tbk_cov_in in;
   memset(&in, 0, sizeof(in));
@@ -188,12 +226,15 @@ int main(int argc, char* argv[]) {
     rc = tbk_coverage_tile(ctx, &in, &o);
     if (rc == TBK_EFATALOP) GError("ERROR: unknown opcode in a CIGAR string (tiecov accepts M, I, D, N, S only)\n");
     if (rc != 0) GError("Error: GPU coverage failed: %s (%s)\n", tbk_strerror(rc), tbk_last_error(ctx));
-    if (coutf)
-      for (uint32_t i = 0; i < o.n_intervals; ++i)  // flushCoverage, tiecov.cpp:237
-        fprintf(coutf, "%s\t%d\t%d\t%.3f\n", hdr->target_name[it[i]].c_str(), is[i], ie[i], iv[i]);
-    if (joutf)
-      for (uint32_t i = 0; i < o.n_junctions; ++i)  // CJunc::write, tiecov.cpp:91-95
-        fprintf(joutf, "%s\t%d\t%d\tJUNC%08d\t%.3f\t%c\n", hdr->target_name[jt[i]].c_str(), js[i], je[i], (int)i + 1, jv[i], (char)jstr[i]);
+    if (coutf)  // flushCoverage, tiecov.cpp:237
+      emit_lines(coutf, o.n_intervals, [&](uint32_t i, char* b, size_t cap) {
+        return snprintf(b, cap, "%s\t%d\t%d\t%.3f\n", hdr->target_name[it[i]].c_str(), is[i], ie[i], iv[i]);
+      });
+    if (joutf)  // CJunc::write, tiecov.cpp:91-95
+      emit_lines(joutf, o.n_junctions, [&](uint32_t i, char* b, size_t cap) {
+        return snprintf(b, cap, "%s\t%d\t%d\tJUNC%08d\t%.3f\t%c\n", hdr->target_name[jt[i]].c_str(), js[i], je[i], (int)i + 1, jv[i],
+                        (char)jstr[i]);
+      });
   }
   if (soutf) {
     uint64_t mb = 0;
@@ -215,8 +256,9 @@ int main(int argc, char* argv[]) {
     rc = tbk_sample_tile(ctx, &in, num_samples, &so);
     if (rc == TBK_EFATALOP) GError("ERROR: unknown opcode in a CIGAR string (tiecov accepts M, I, D, N, S only)\n");
     if (rc != 0) GError("Error: GPU sample track failed: %s (%s)\n", tbk_strerror(rc), tbk_last_error(ctx));
-    for (uint32_t i = 0; i < so.n_intervals; ++i)  // flushCoverage(pair), tiecov.cpp:289
-      fprintf(soutf, "%s\t%d\t%d\t%ld\t%f\n", hdr->target_name[st[i]].c_str(), ss[i], se[i], (long)sc[i], sh[i]);
+    emit_lines(soutf, so.n_intervals, [&](uint32_t i, char* b, size_t cap) {  // flushCoverage(pair), tiecov.cpp:289
+      return snprintf(b, cap, "%s\t%d\t%d\t%ld\t%f\n", hdr->target_name[st[i]].c_str(), ss[i], se[i], (long)sc[i], sh[i]);
+    });
   }
   if (coutf && coutf != stdout) fclose(coutf);
   if (joutf) fclose(joutf);
