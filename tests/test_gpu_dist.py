@@ -123,3 +123,28 @@ def test_loopback_device_resident_tbmerged_inputs(world, bam_loader):
             v = getattr(r, f)
             setattr(r, f, v.cpu().numpy() if isinstance(v, torch.Tensor) else v)
     check_against_flat(res, tile, flat, flat_cov)
+
+
+def test_shard_prepare_matches_host_restatement_and_rejects_unsorted():
+    """tbk_shard_prepare against the numpy restatement dist.py uses for host tiles: keys, running maxima of the read
+    ends, effective ends (computed before filtering) and filter verdicts; an unsorted file is refused."""
+    import torch
+    from tiebrush_amd import api, dist, synth
+    from tiebrush_amd._lib import TbkError
+    tile = synth.make_tile(3, 30000, "c5", n_loci=500)
+    ctx = api.Context(0)
+    kw = dict(max_nh=5, min_qual=1, keep_secondary=True)
+    key, emax, effend, passm = ctx.shard_prepare(api.to_device(tile, "cuda:0"), **kw)
+    hk, hm, he, hp = dist._prepare_np(tile, **kw)
+    assert np.array_equal(key.cpu().numpy(), hk) and np.array_equal(emax.cpu().numpy(), hm)
+    assert np.array_equal(effend.cpu().numpy(), he) and np.array_equal(passm.cpu().numpy() & 1, hp)
+    assert 0 < int(hp.sum()) < tile.n_records
+    bad = synth.make_tile(2, 1000, "c2", n_loci=50)
+    bad.pos = bad.pos.copy()
+    bad.pos[10], bad.pos[500] = bad.pos[500], bad.pos[10]
+    with pytest.raises(TbkError) as e:
+        ctx.shard_prepare(api.to_device(bad, "cuda:0"))
+    assert e.value.status == -6                      # TBK_EUNSORTED
+    with pytest.raises(ValueError):
+        dist._prepare_np(bad)
+    ctx.close()
