@@ -298,12 +298,19 @@ def shard_collapse(compute, local_tile: SoATile, first_fidx: int, rank: int, wor
 
     mark("prepare")
     # ---- 2. splitter targets from sampled keys (the file table of every rank rides along) --------------------
-    if n:
-        samp = key[(X.arange(N_SAMPLES, like=key) * n) // N_SAMPLES]
+    idx_h = (np.arange(N_SAMPLES, dtype=np.int64) * n) // N_SAMPLES
+    if _is_t(key):                                  # one gather + one small upload; the rest of the payload is host data
+        T = _torch()
+        meta = T.empty(N_SAMPLES + 3, dtype=T.int64, device=key.device)
+        tail = T.tensor([k, first_fidx, int(any_tbm)], dtype=T.int64)
+        if n:
+            meta[:N_SAMPLES] = key[T.from_numpy(idx_h).to(key.device, non_blocking=True)]
+        else:
+            meta[:N_SAMPLES] = KEY_INF
+        meta[N_SAMPLES:] = tail.to(key.device, non_blocking=True)
     else:
-        samp = X.full(N_SAMPLES, KEY_INF, like=key) if _is_t(key) else np.full(N_SAMPLES, KEY_INF, np.int64)
-    meta = X.scalar(0, like=samp)
-    meta = X.cat([samp, X.cat([X.scalar(k, like=samp), X.scalar(first_fidx, like=samp), X.scalar(int(any_tbm), like=samp)])])
+        samp = key[idx_h] if n else np.full(N_SAMPLES, KEY_INF, np.int64)
+        meta = np.concatenate([samp, np.array([k, first_fidx, int(any_tbm)], np.int64)])
     allmeta = X.host((yield ("all_gather", meta))).reshape(world, N_SAMPLES + 3)
     ks = allmeta[:, N_SAMPLES].astype(np.int64)
     firsts = allmeta[:, N_SAMPLES + 1].astype(np.int64)
@@ -541,7 +548,8 @@ def run_distributed(compute, tile, first_fidx, device=None, group=None, **kw):
                 c = t(cnt).contiguous()
                 rc = torch.empty_like(c)
                 dist.all_to_all_single(rc, c, group=group)
-                sc_h, rc_h = c.cpu().numpy().astype(np.int64), rc.cpu().numpy().astype(np.int64)
+                sc_h = (c.cpu().numpy() if _is_t(cnt) else np.asarray(cnt)).astype(np.int64)
+                rc_h = rc.cpu().numpy().astype(np.int64)
                 x = t(data).contiguous()
                 out = torch.empty((int(rc_h.sum()),) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
                 dist.all_to_all_single(out, x, output_split_sizes=rc_h.tolist(), input_split_sizes=sc_h.tolist(), group=group)
@@ -549,11 +557,12 @@ def run_distributed(compute, tile, first_fidx, device=None, group=None, **kw):
             elif kind == "exchange_rows":
                 R, cnt, cig, ccnt, per = pay
                 # one small all-to-all tells every rank what it will receive: [rows, CIGAR words, rows per file of the sender]
-                c = torch.cat([t(np.asarray(cnt, np.int64)).view(world, 1), t(np.asarray(ccnt, np.int64)).view(world, 1),
-                               t(np.asarray(per, np.int64)).view(world, -1)], dim=1).contiguous()
+                sc_h = np.concatenate([np.asarray(cnt, np.int64).reshape(world, 1), np.asarray(ccnt, np.int64).reshape(world, 1),
+                                       np.asarray(per, np.int64).reshape(world, -1)], axis=1)
+                c = t(sc_h).contiguous()
                 rc = torch.empty_like(c)
                 dist.all_to_all_single(rc, c, group=group)
-                sc_h, rc_h = c.cpu().numpy().astype(np.int64), rc.cpu().numpy().astype(np.int64)
+                rc_h = rc.cpu().numpy().astype(np.int64)
                 x = t(R).contiguous()
                 outR = torch.empty((int(rc_h[:, 0].sum()),) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
                 dist.all_to_all_single(outR, x, output_split_sizes=rc_h[:, 0].tolist(), input_split_sizes=sc_h[:, 0].tolist(), group=group)
