@@ -259,9 +259,18 @@ __global__ __launch_bounds__(RF_NT) void msort_refine_k(const uint64_t* __restri
     if (x < nw) {
       const uint64_t kx = K[x];
       const uint32_t b0 = bs[x], b1 = bend[b0];
+      // rank = records of the bucket with a smaller key, plus equal ones that come earlier.  With kx1 = kx + 1 for the
+      // earlier part both halves are one "K[j] < bound" test: K[j] <= kx  <=>  K[j] < kx + 1 (kx + 1 cannot wrap: the
+      // top two bits of a key are a strand code <= 2).
       uint32_t c0 = 0, c1 = 0;
-      for (uint32_t j = b0; j < x; ++j) c0 += K[j] <= kx ? 1u : 0u;  // earlier records of the bucket: ties go before x
-      for (uint32_t j = x + 1; j < b1; ++j) c1 += K[j] < kx ? 1u : 0u;
+      const uint64_t kx1 = kx + 1;
+      uint32_t j = b0;
+      for (; j + 1 < b1; j += 2) {
+        const uint64_t ka = K[j], kb = K[j + 1];
+        c0 += ka < (j < x ? kx1 : kx) ? 1u : 0u;
+        c1 += kb < (j + 1 < x ? kx1 : kx) ? 1u : 0u;
+      }
+      if (j < b1) c0 += K[j] < (j < x ? kx1 : kx) ? 1u : 0u;
       const uint32_t dst = ws + b0 + c0 + c1;
       ohi[dst] = rh[e];
       olo[dst] = rl[e];
