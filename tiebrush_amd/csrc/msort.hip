@@ -265,12 +265,22 @@ __global__ __launch_bounds__(RF_NT) void msort_refine_k(const uint64_t* __restri
       uint32_t c0 = 0, c1 = 0;
       const uint64_t kx1 = kx + 1;
       uint32_t j = b0;
+      for (; j + 7 < b1; j += 8) {
+        uint64_t kk[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) kk[u] = K[j + u];
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+          c0 += kk[u] < (j + u < x ? kx1 : kx) ? 1u : 0u;
+          c1 += kk[u + 1] < (j + u + 1 < x ? kx1 : kx) ? 1u : 0u;
+        }
+      }
       for (; j + 1 < b1; j += 2) {
         const uint64_t ka = K[j], kb = K[j + 1];
         c0 += ka < (j < x ? kx1 : kx) ? 1u : 0u;
         c1 += kb < (j + 1 < x ? kx1 : kx) ? 1u : 0u;
       }
-      if (j < b1) c0 += K[j] < (j < x ? kx1 : kx) ? 1u : 0u;
+      for (; j < b1; ++j) c0 += K[j] < (j < x ? kx1 : kx) ? 1u : 0u;
       const uint32_t dst = ws + b0 + c0 + c1;
       ohi[dst] = rh[e];
       olo[dst] = rl[e];
