@@ -140,7 +140,7 @@ typedef struct tbk_cov_in {
   uint32_t n_cigar_ops;
   const int32_t* tid;
   const int32_t* pos;
-  const uint16_t* flag;
+  const uint16_t* flag;    /* only bit 0x4 (unmapped: record skipped) is read; NULL = every record counts */
   const uint32_t* cig_off;
   const uint32_t* cig;
   const double* yc;        /* YC tag as double, 1.0 when absent (tiecov.cpp:482-485)  */

@@ -523,21 +523,16 @@ __global__ void col_rep_prio_k(ColIn I, const uint64_t* __restrict__ png, const 
 }
 
 // ---- tie sets: order groups that share (bucket,strand,end) by the reference comparator -----------------
-__global__ void col_tie_init_k(ColIn I, int strategy, const uint64_t* __restrict__ png, const uint32_t* __restrict__ val, GroupAcc G, uint32_t* __restrict__ gperm) {
-  const uint32_t ng = (uint32_t)*png;
-  uint32_t sg = blockIdx.x * blockDim.x + threadIdx.x;
-  if (sg >= ng) return;
-  gperm[sg] = sg;
-}
+// One thread per tie set (its head): identity order for the set, insertion sort by the reference comparator on any
+// member (the group head) when the set has more than one group, then the inverse permutation of the set's range.
 __global__ void col_tie_sort_k(ColIn I, int strategy, const uint64_t* __restrict__ png, const uint32_t* __restrict__ val, GroupAcc G,
-                               uint32_t* __restrict__ gperm) {
+                               uint32_t* __restrict__ gperm, uint32_t* __restrict__ ginv) {
   const uint32_t ng = (uint32_t)*png;
   uint32_t sg = blockIdx.x * blockDim.x + threadIdx.x;
   if (sg >= ng || !G.tie[sg]) return;
   uint32_t e = 1;
   while (sg + e < ng && !G.tie[sg + e]) ++e;
-  if (e < 2) return;
-  // insertion sort of gperm[sg .. sg+e) by the comparator on any member (the head) of each group
+  for (uint32_t a = 0; a < e; ++a) gperm[sg + a] = sg + a;
   for (uint32_t a = 1; a < e; ++a) {
     uint32_t x = gperm[sg + a];
     uint32_t rx = val[G.first[x]];
@@ -553,11 +548,7 @@ __global__ void col_tie_sort_k(ColIn I, int strategy, const uint64_t* __restrict
     }
     gperm[sg + b] = x;
   }
-}
-__global__ void col_ginv_k(const uint64_t* __restrict__ png, const uint32_t* __restrict__ gperm, uint32_t* __restrict__ ginv) {
-  const uint32_t ng = (uint32_t)*png;
-  uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o < ng) ginv[gperm[o]] = o;
+  for (uint32_t a = 0; a < e; ++a) ginv[gperm[sg + a]] = sg + a;
 }
 
 // ---- YD ----------------------------------------------------------------------------------------------------
@@ -1516,9 +1507,7 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
     TBK_LAUNCH(ctx, "col_reduce", col_reduce_k, cdiv(m_hi, B), B, 0, I, O, pm, s2.val, flags, gex, fidx, effend, G, sgid, ctx->d_err);
     if (I.prio_hi && I.prio_lo) TBK_LAUNCH(ctx, "col_rep_prio", col_rep_prio_k, cdiv(ng_hi, B), B, 0, I, png, pm, s2.val, G);
     if (O.collapse_same) TBK_LAUNCH(ctx, "col_same", col_same_k, cdiv(m_hi, B), B, 0, I, O, pm, s2.val, flags, sgid, fidx, G);
-    TBK_LAUNCH(ctx, "col_tie_init", col_tie_init_k, cdiv(ng_hi, B), B, 0, I, O.strategy, png, s2.val, G, gperm);
-    TBK_LAUNCH(ctx, "col_tie_sort", col_tie_sort_k, cdiv(ng_hi, B), B, 0, I, O.strategy, png, s2.val, G, gperm);
-    TBK_LAUNCH(ctx, "col_ginv", col_ginv_k, cdiv(ng_hi, B), B, 0, png, gperm, ginv);
+    TBK_LAUNCH(ctx, "col_tie_sort", col_tie_sort_k, cdiv(ng_hi, B), B, 0, I, O.strategy, png, s2.val, G, gperm, ginv);
 
     // ---- ordered YC when a fractional term can occur (only --store-frac and TieBrush-merged inputs can bring one;
     // such tiles are never lean, so m and ng are known here) ----
@@ -1675,7 +1664,7 @@ extern "C" int tbk_groups_to_cov_in(tbk_ctx* ctx, const tbk_soa_in* in, const tb
   view->n_cigar_ops = (uint32_t)total;
   view->tid = o_tid;
   view->pos = o_pos;
-  view->flag = o_flag;
+  view->flag = nullptr;  // every representative counts: tbk_coverage_tile skips its validity pass (o_flag stays available below)
   view->cig_off = o_cig_off;
   view->cig = o_cig;
   view->yc = o_yc;

@@ -76,8 +76,8 @@ __global__ void cov_prep_k(uint32_t n, const uint32_t* __restrict__ valid, const
   uint64_t mb = 0, ay = 0;
   uint32_t e = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    if (!valid[i]) continue;
-    uint32_t j = vpos[i];
+    if (valid && !valid[i]) continue;
+    uint32_t j = valid ? vpos[i] : i;
     uint32_t c0 = cig_off[i], c1 = cig_off[i + 1];
     int nex = 0;
     int l = walk_exons(pos[i], cig + c0, c1 - c0, [](int, int) {}, &nex);
@@ -774,9 +774,14 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
   uint32_t nj = 0, nju = 0;
   JuncSide side;
 
-  TBK_LAUNCH(ctx, "cov_valid", cov_valid_k, cdiv(n, B), B, 0, in->flag, n, valid);
-  TBK_TRY(tbk_exscan_u32(ctx, valid, vpos, n, sc + 2));
-  TBK_LAUNCH(ctx, "cov_prep", cov_prep_k, (cdiv(n, B) < 1024u ? cdiv(n, B) : 1024u), B, 0, n, valid, vpos, in->tid, in->pos, in->cig_off, in->cig,
+  // flag == NULL: every record counts (the device chain hands over representatives, which all passed the collapse
+  // filters) — no validity flags, no compaction
+  const bool all_valid = in->flag == nullptr;
+  if (!all_valid) {
+    TBK_LAUNCH(ctx, "cov_valid", cov_valid_k, cdiv(n, B), B, 0, in->flag, n, valid);
+    TBK_TRY(tbk_exscan_u32(ctx, valid, vpos, n, sc + 2));
+  }
+  TBK_LAUNCH(ctx, "cov_prep", cov_prep_k, (cdiv(n, B) < 1024u ? cdiv(n, B) : 1024u), B, 0, n, all_valid ? (const uint32_t*)nullptr : valid, vpos, in->tid, in->pos, in->cig_off, in->cig,
              sample_mode ? (const double*)nullptr : in->yc, want_cov ? 1 : 0, A, jcnt, sc, ctx->d_err);
   uint32_t eb = 0;
   TBK_TRY(tbk_sync_err(ctx, &eb));
@@ -784,7 +789,7 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
   eb &= ~TBK_DERR_FRACTIONAL;
   if (eb) return tbk_derr_to_status(ctx, eb);
   if (fractional) TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
-  const uint32_t m = (uint32_t)ctx->h_scalars[2];
+  const uint32_t m = all_valid ? n : (uint32_t)ctx->h_scalars[2];
   out->n_bases = ctx->h_scalars[0];
   const uint64_t sum_abs = ctx->h_scalars[1];
   const bool integral = !fractional && !sample_mode && sum_abs < (1ull << 52);  // junction sums may then be formed in any order

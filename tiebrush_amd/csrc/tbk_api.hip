@@ -342,7 +342,7 @@ void tbk_collapse_opts_default(tbk_collapse_opts* o) {
 
 int tbk_coverage_tile(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out) {
   if (!ctx || !in || !out) return TBK_EINVAL;
-  if (in->n_records && (!in->tid || !in->pos || !in->flag || !in->cig_off || (in->n_cigar_ops && !in->cig))) return TBK_EINVAL;
+  if (in->n_records && (!in->tid || !in->pos || !in->cig_off || (in->n_cigar_ops && !in->cig))) return TBK_EINVAL;  // flag may be NULL
   if (out->cap_intervals && (!out->iv_tid || !out->iv_start || !out->iv_end || !out->iv_val)) return TBK_EINVAL;
   if (out->cap_junctions && (!out->j_tid || !out->j_start || !out->j_end || !out->j_strand || !out->j_val)) return TBK_EINVAL;
   if (in->mem != out->mem) return TBK_EINVAL;
