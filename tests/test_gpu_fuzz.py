@@ -282,3 +282,19 @@ def test_fuzz_yd_spliced_regions(ctx, seed):
     tile = _spliced_region_tile(rng, int(rng.integers(1, 3)), 60)
     want = _cmp(ctx, tile, strategy="cigar")
     assert int(np.asarray(want["yd"]).max()) > 100          # distances measured from B / C starts far into raised ends
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_collapse_forced_run_sort(ctx, seed, monkeypatch):
+    """The run-merge sort (and the sync-free 'lean' flow that goes with it) normally serves large tiles only; force it on
+    the small adversarial tiles too: odd file counts, empty files, every strategy, buckets that tie on everything."""
+    monkeypatch.setenv("TBK_SORT", "runs")
+    rng = np.random.default_rng(7000 + seed)
+    for _ in range(10):
+        tile = _rand_tile(rng, with_tb=bool(seed % 2))
+        for strat in STRATS:
+            _cmp(ctx, tile, strategy=strat)
+        _cmp(ctx, tile, strategy=str(rng.choice(STRATS)), keep_secondary=True, keep_supplementary=True,
+             max_nh=int(rng.choice([1, 5, 2**31 - 1])), min_qual=int(rng.choice([-1, 1, 31])))
+    monkeypatch.setenv("TBK_SORT", "radix")
+    _cmp(ctx, _rand_tile(rng), strategy="cigar")
