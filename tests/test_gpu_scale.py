@@ -65,6 +65,43 @@ def test_long_buckets_exact(ctx, profile, kw):
     _exact(ctx, tile, **kw)
 
 
+def test_amplicon_pileup_exact(ctx):
+    """300k reads starting on ONE base (deep amplicon): a single (tid,start) bucket far beyond what one block should sort —
+    the run sort hands the tile back to the radix sort; plus a second, ordinary locus so that both kinds of bucket meet."""
+    from tiebrush_amd import soa
+    rng = np.random.default_rng(5)
+    M, S, I = 0, 4, 1
+    files = []
+    for f in range(3):
+        n_hot, n_bg = 100_000, 20_000
+        pos = np.concatenate([np.full(n_hot, 5000), np.sort(rng.integers(9000, 12000, n_bg))]).astype(np.int32)
+        kind = rng.integers(0, 6, n_hot + n_bg)
+        ln = rng.choice([70, 90, 100, 120], n_hot + n_bg)
+        cigs = []
+        for k, l in zip(kind, ln):
+            if k == 0:
+                cigs.append([(l << 4) | M])
+            elif k == 1:
+                cigs.append([(3 << 4) | S, ((l - 3) << 4) | M])
+            elif k == 2:
+                cigs.append([(40 << 4) | M, (2 << 4) | I, ((l - 42) << 4) | M])
+            else:
+                cigs.append([((l - 10 * int(k)) << 4) | M, (5 << 4) | S])
+        files.append((pos, cigs))
+    n = sum(len(p) for p, _ in files)
+    fo = np.zeros(4, np.uint32)
+    fo[1:] = np.cumsum([len(p) for p, _ in files])
+    allc = [c for _, cs in files for c in cs]
+    off = np.zeros(n + 1, np.uint32)
+    off[1:] = np.cumsum([len(c) for c in allc])
+    tile = soa.SoATile(n_files=3, file_off=fo, tbmerged=np.zeros(3, np.uint8), tid=np.zeros(n, np.int32),
+                       pos=np.concatenate([p for p, _ in files]), flag=np.zeros(n, np.uint16), mapq=np.full(n, 60, np.uint8),
+                       strand=np.full(n, ord("."), np.uint8), nh=np.ones(n, np.int32), cig_off=off,
+                       cig=np.array([x for c in allc for x in c], np.uint32))
+    _exact(ctx, tile)
+    _exact(ctx, tile, strategy="clip")
+
+
 def _properties(ctx, tile, **kw):
     import torch
     from tiebrush_amd import api, soa

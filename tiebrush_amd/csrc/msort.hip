@@ -302,6 +302,8 @@ __device__ __forceinline__ uint64_t match_digit8(uint32_t d, bool valid) {
   return peers;
 }
 
+constexpr uint32_t MS_BIG_MAX = 1u << 17;  // records one block still sorts; beyond that the tile goes to the radix sort
+
 // One block per long bucket (thousands of reads starting on one base: rRNA, mitochondrial genes, deep amplicons): a
 // stable block-level LSD radix sort of the bucket by K = (strand, span, hash), 8-bit digits, only over digits that
 // vary inside the bucket, ping-ponging between the refine input and output ranges of the bucket.
@@ -334,6 +336,10 @@ __global__ __launch_bounds__(256) void msort_big_k(uint64_t* __restrict__ hi, ui
   }
   __syncthreads();
   const uint32_t n = s_be - b0;
+  if (n > MS_BIG_MAX) {  // one block would take milliseconds: let the caller's whole-tile radix sort (all CUs) have the tile
+    if (threadIdx.x == 0) atomicOr(err, TBK_DERR_BIGBUCKET);
+    return;
+  }
   {
     uint64_t a = ~0ull, o = 0ull;
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
@@ -419,7 +425,7 @@ __global__ __launch_bounds__(256) void msort_big_k(uint64_t* __restrict__ hi, ui
 // Sort b (nruns runs, run f = [run_off[f], run_off[f+1]), each non-decreasing in hi >> 2 and in input order; the record
 // count run_off[nruns] is read on the device, n_hi is the host's upper bound of it and only sizes the grids) exactly
 // as tbk_radix_sort128 would.  `nbig` is a device word the caller has zeroed (it counts the buckets too long for a
-// phase-B window; those are sorted by msort_big_k).  More than 4096 of them — a pathological tile — set
+// phase-B window; those are sorted by msort_big_k).  More than 4096 of them, or one of more than 2^17 records, set
 // TBK_DERR_BIGBUCKET in *err; the caller then swaps b's two sides back (still a valid stable input) and runs the radix
 // sort on it.
 int tbk_sort_runs(tbk_ctx* ctx, SortBufs* b, uint32_t n_hi, const uint32_t* d_run_off, uint32_t nruns, uint32_t* err,
