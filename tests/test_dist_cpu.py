@@ -66,15 +66,30 @@ def test_refuses_order_dependent_flags():
         dist.run_loopback(OracleCompute(), tiles, first, store_frac=True)
 
 
+def _gloo_tile():
+    """4 files; file 1 poses as a TieBrush-merged input (carried YC / YX / YD), so the third all-to-all and the file-flag
+    gather of the protocol run over the real process group too"""
+    from tiebrush_amd import synth
+    tile = synth.make_tile(4, 5000, "c2", n_loci=200)
+    rng = np.random.default_rng(11)
+    n = tile.n_records
+    tile.tbmerged = np.array([0, 1, 0, 0], np.uint8)
+    tile.yc_in = rng.integers(1, 40, n).astype(np.float64)
+    tile.yx_in = rng.integers(1, 6, n).astype(np.int64)
+    tile.yd_in = rng.integers(0, 90, n).astype(np.int64)
+    return tile
+
+
 def _gloo_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as td
     from dist_helpers import OracleCompute, split_tile
-    from tiebrush_amd import dist, synth
+    from tiebrush_amd import dist
+    from test_dist_cpu import _gloo_tile
     td.init_process_group("gloo", rank=rank, world_size=world)
-    tile = synth.make_tile(4, 5000, "c2", n_loci=200)
+    tile = _gloo_tile()
     tiles, first = split_tile(tile, world)
     r = dist.run_distributed(OracleCompute(), tiles[rank], first[rank], device="cpu", want_coverage=True)
     q.put((rank, r))
@@ -96,7 +111,7 @@ def test_gloo_world2_equals_flat():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    tile = synth.make_tile(4, 5000, "c2", n_loci=200)
+    tile = _gloo_tile()
     flat = orc.collapse(tile)
     flat_cov = orc.coverage(synth.collapsed_to_cov_input(tile, flat))
     check_against_flat([got[0], got[1]], tile, flat, flat_cov)
