@@ -728,14 +728,14 @@ static int junc_branch(tbk_ctx* ctx, uint32_t m, const CovArrays& A, const tbk_c
   return tbk_check_launch(ctx, "junctions");
 }
 
-struct JuncSide {  // the junction branch on the side context; joined before tbk_coverage_device returns, whatever the path
-  std::thread* th = nullptr;
+struct JuncSide {  // the junction branch on the side context's worker; collected before tbk_coverage_device returns, whatever the path
+  TbkWorker* w = nullptr;
+  bool th = false;  // posted and not yet collected
   int rc = 0;
   int join() {
     if (th) {
-      th->join();
-      delete th;
-      th = nullptr;
+      w->wait();
+      th = false;
     }
     return rc;
   }
@@ -798,7 +798,10 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
     tbk_ctx* jc = tbk_side_ctx(ctx);
     if (jc) {
       const size_t hint = (size_t)m * 8 + (size_t)in->n_cigar_ops * 56 + ((size_t)4 << 20);
-      side.th = new std::thread([&side, jc, hint, m, &A, in, jcnt, out, integral, &nj, &nju]() {
+      if (!ctx->side_worker) ctx->side_worker = new TbkWorker();
+      side.w = ctx->side_worker;
+      side.th = true;
+      side.w->post([&side, jc, hint, m, &A, in, jcnt, out, integral, &nj, &nju]() {
         side.rc = tbk_side_begin(jc, hint);
         if (side.rc == 0) side.rc = junc_branch(jc, m, A, in, jcnt, out, integral, &nj, &nju);
         tbk_side_end(jc);

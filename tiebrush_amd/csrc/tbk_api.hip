@@ -12,7 +12,7 @@
 // call, so a steady-state loop performs no allocation at all.
 static int ws_begin_call(tbk_ctx* ctx, size_t hint) {
   size_t want = std::max(ctx->ws_cap, hint);
-  if (ctx->yd_thread) {
+  if (ctx->yd_pending) {
     // a deferred YD stage still reads arrays in [0, ws_base_off): never move the arena now; this call bump-allocates
     // behind the pinned prefix and spills into overflow chunks if it must
     for (auto& c : ctx->ws_overflow) (void)hipFree(c.first);
@@ -215,10 +215,9 @@ static int yd_stage_on(tbk_ctx* run_on, void* job, size_t hint) {
 }
 
 static int finish_yd(tbk_ctx* ctx) {
-  if (!ctx->yd_thread) return 0;
-  ctx->yd_thread->join();
-  delete ctx->yd_thread;
-  ctx->yd_thread = nullptr;
+  if (!ctx->yd_pending) return 0;
+  ctx->yd_worker->wait();
+  ctx->yd_pending = false;
   ctx->ws_base_off = 0;
   if (ctx->yd_ctx) {
     ctx->last_times = ctx->yd_ctx->last_times;  // tbk_kernel_times() right after the wait = the YD stage
@@ -280,6 +279,10 @@ int tbk_collapse_finish_yd(tbk_ctx* ctx) {
 void tbk_destroy(tbk_ctx* ctx) {
   if (!ctx) return;
   (void)finish_yd(ctx);
+  delete ctx->yd_worker;
+  ctx->yd_worker = nullptr;
+  delete ctx->side_worker;
+  ctx->side_worker = nullptr;
   if (ctx->yd_ctx) {
     tbk_destroy(ctx->yd_ctx);
     ctx->yd_ctx = nullptr;
@@ -436,7 +439,9 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
         ctx->ws_base_off = (ctx->ws_off + 255) & ~(size_t)255;
         ctx->yd_rc = 0;
         tbk_ctx* side = ctx->yd_ctx;
-        ctx->yd_thread = new std::thread([ctx, side, job, yd_hint]() { ctx->yd_rc = yd_stage_on(side, job, yd_hint); });
+        if (!ctx->yd_worker) ctx->yd_worker = new TbkWorker();
+        ctx->yd_pending = true;
+        ctx->yd_worker->post([ctx, side, job, yd_hint]() { ctx->yd_rc = yd_stage_on(side, job, yd_hint); });
       } else {
         rc = tbk_collapse_yd_run(ctx, job);
       }

@@ -7,6 +7,9 @@
 #include <string.h>
 
 #include <string>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -29,6 +32,53 @@ enum : uint32_t {
 struct KTime {
   const char* name;
   hipEvent_t a, b;
+};
+
+// A helper thread that lives as long as its context: side stages (deferred YD, the junction branch) are posted to it
+// instead of paying a thread creation per call.
+struct TbkWorker {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::function<void()> job;
+  bool busy = false, quit = false, started = false;
+  void post(std::function<void()> j) {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      if (!started) {
+        started = true;
+        th = std::thread([this]() {
+          std::unique_lock<std::mutex> lk2(m);
+          for (;;) {
+            cv.wait(lk2, [&] { return quit || (bool)job; });
+            if (quit) return;
+            std::function<void()> run = std::move(job);
+            job = nullptr;
+            lk2.unlock();
+            run();
+            lk2.lock();
+            busy = false;
+            cv.notify_all();
+          }
+        });
+      }
+      job = std::move(j);
+      busy = true;
+    }
+    cv.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait(lk, [&] { return !busy; });
+  }
+  ~TbkWorker() {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      quit = true;
+    }
+    cv.notify_all();
+    if (th.joinable()) th.join();
+  }
 };
 
 struct tbk_ctx {
@@ -59,11 +109,13 @@ struct tbk_ctx {
   // deferred YD stage (tbk_collapse_opts.defer_yd): a private side context + helper thread
   void* yd_job = nullptr;        // prepared by tbk_collapse_device, consumed by tbk_collapse_yd_run
   tbk_ctx* yd_ctx = nullptr;
-  std::thread* yd_thread = nullptr;
+  TbkWorker* yd_worker = nullptr;  // created with the side context
+  bool yd_pending = false;        // a deferred YD stage is running (or finished and not yet collected)
   int yd_rc = 0;
   size_t ws_base_off = 0;        // arena bytes pinned while a deferred YD stage still reads the main stage's arrays
   // side context for a branch that runs beside the main stream inside one call (tiecov junctions)
   tbk_ctx* side_ctx = nullptr;
+  TbkWorker* side_worker = nullptr;
   bool side_times_pending = false;
 };
 
