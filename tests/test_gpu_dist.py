@@ -148,3 +148,53 @@ def test_shard_prepare_matches_host_restatement_and_rejects_unsorted():
     with pytest.raises(ValueError):
         dist._prepare_np(bad)
     ctx.close()
+
+
+def _two_proc_worker(rank, world, port, q):
+    import os
+    import sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import torch
+    import torch.distributed as td
+    from dist_helpers import split_tile
+    from test_gpu_dist import DeviceCompute
+    from tiebrush_amd import api, dist, synth
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    tile = synth.make_tile(6, 20000, "c3", n_loci=600)
+    tiles, first = split_tile(tile, world)
+    dt = api.to_device(tiles[rank], "cuda:0")
+    r = dist.run_distributed(DeviceCompute(), dt, first[rank], want_coverage=True, device_chain=True, strategy="clip")
+    for f in ("tid", "start", "end", "rep_fidx", "rep_idx", "yc", "yx", "yd"):
+        v = getattr(r, f)
+        setattr(r, f, v.cpu().numpy() if isinstance(v, torch.Tensor) else v)
+    r.cov_input = None
+    q.put((rank, r))
+    td.barrier()
+    td.destroy_process_group()
+
+
+def test_two_processes_device_path():
+    """Two real processes (torch.distributed, gloo staging the device tensors through the host) sharing the one GPU of
+    the box, each with its own context and the HIP shuffle kernels: the multi-process protocol end to end.  (RCCL itself
+    needs one GPU per rank and runs in the driver's scaling bench.)"""
+    import os
+    import torch.multiprocessing as mp
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import synth
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_two_proc_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    tile = synth.make_tile(6, 20000, "c3", n_loci=600)
+    flat = orc.collapse(tile, strategy=STRAT["clip"])
+    flat_cov = orc.coverage(synth.collapsed_to_cov_input(tile, flat))
+    check_against_flat([got[0], got[1]], tile, flat, flat_cov)

@@ -512,12 +512,16 @@ def run_distributed(compute, tile, first_fidx, device=None, group=None, **kw):
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     dev = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
+    if dist.get_backend(group) == "gloo":
+        dev = "cpu"
 
     _signed = {np.dtype(np.uint32): np.int32, np.dtype(np.uint64): np.int64, np.dtype(np.uint16): np.int16}
 
+    stage = dist.get_backend(group) == "gloo"       # gloo moves host memory: device tensors are staged through the host
+
     def t(a):
         if _is_t(a):
-            return a
+            return a.cpu() if (stage and a.is_cuda) else a
         a = np.ascontiguousarray(a)
         if a.dtype in _signed:          # collectives have no unsigned types: ship the same bits as signed
             a = a.view(_signed[a.dtype])
@@ -525,7 +529,7 @@ def run_distributed(compute, tile, first_fidx, device=None, group=None, **kw):
 
     def back(x, like):
         if _is_t(like):
-            return x
+            return x.to(like.device) if x.device != like.device else x
         r = x.cpu().numpy()
         return r.view(like.dtype) if np.asarray(like).dtype in _signed else r
 
