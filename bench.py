@@ -51,8 +51,16 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        # TBK_BENCH_BACKEND=gloo is a test hook: several ranks may then share one GPU (collectives staged through the
+        # host), so this script's multi-rank path can be exercised on a 1-GPU box; measured runs use RCCL, one GPU per rank
+        backend = os.environ.get("TBK_BENCH_BACKEND", "nccl")
+        if backend != "nccl":
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     dev = "cuda:%d" % local_rank
 
     from tiebrush_amd import api, synth
@@ -130,7 +138,8 @@ def main():
     dt = time.perf_counter() - t0
     n_passed, n_groups = g["n_passed"], g["n_groups"]
     n_bases, span, n_iv, n_j = c["n_bases"], c["span_bases"], c["n_intervals"], c["n_junctions"]
-    stats = torch.tensor([dt, float(n_passed), float(n_bases)], dtype=torch.float64, device=dev)
+    stats = torch.tensor([dt, float(n_passed), float(n_bases)], dtype=torch.float64,
+                         device=dev if os.environ.get("TBK_BENCH_BACKEND", "nccl") == "nccl" else "cpu")
     if use_dist:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
