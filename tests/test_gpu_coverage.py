@@ -164,3 +164,24 @@ def test_deep_pileup_needs_64bit_accumulators(ctx):
                        yc=np.full(n, 1000.0), strand=np.full(n, ord("."), np.uint8), yx=np.ones(n, np.int64))
     got = _check(ctx, cin, True)
     assert float(got["iv_val"].max()) == 1000.0 * n
+
+
+@pytest.mark.parametrize("frac", [False, True])
+def test_junctions_only_and_intervals_only(ctx, frac):
+    """tiecov -j without -c and -c without -j: each branch alone (the junction branch then runs inline, not on the side
+    context), integral and fractional YC."""
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import api, synth
+    tile = synth.make_tile(2, 60000, "c2", n_loci=300)
+    g = orc.collapse(tile)
+    cin = synth.collapsed_to_cov_input(tile, g)
+    if frac:
+        cin.yc = cin.yc + 0.25
+    want = orc.coverage(cin)
+    dc = api.to_device(cin, "cuda:0")
+    j = api.to_numpy(ctx.coverage(dc, want_cov=False))
+    for k in ("j_tid", "j_start", "j_end", "j_strand", "j_val"):
+        assert np.array_equal(j[k], want[k]), k
+    c = api.to_numpy(ctx.coverage(dc, want_junc=False))
+    for k in ("iv_tid", "iv_start", "iv_end", "iv_val"):
+        assert np.array_equal(c[k], want[k]), k
