@@ -296,5 +296,8 @@ def test_fuzz_collapse_forced_run_sort(ctx, seed, monkeypatch):
             _cmp(ctx, tile, strategy=strat)
         _cmp(ctx, tile, strategy=str(rng.choice(STRATS)), keep_secondary=True, keep_supplementary=True,
              max_nh=int(rng.choice([1, 5, 2**31 - 1])), min_qual=int(rng.choice([-1, 1, 31])))
+        _cmp(ctx, tile, strategy=str(rng.choice(STRATS)), collapse_same=True, keep_secondary=True)
+        _cmp(ctx, tile, strategy=str(rng.choice(STRATS)), store_frac=True, keep_secondary=True,
+             collapse_same=bool(rng.random() < 0.5))
     monkeypatch.setenv("TBK_SORT", "radix")
     _cmp(ctx, _rand_tile(rng), strategy="cigar")
