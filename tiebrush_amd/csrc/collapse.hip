@@ -1246,7 +1246,11 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       TBK_TRY(tbk_exscan_u32(ctx, ocnt, ooff, ng, nullptr));
       TBK_LAUNCH(ctx, "yd_fill", yd_fill_k, cdiv(m, B), B, 0, I, m, J.val, J.flags, J.fidx, J.sgid, J.ginv, ioff, ooff, J.G, ib.hi, ib.lo,
                  ib.val);
-      TBK_TRY(tbk_radix_sort128(ctx, &ib, nit, ~0ull, 0ull));  // stable split by list id; group order is already in place
+      {  // stable split by list id (file * 2 + strand list); group order is already in place.  The id range is known:
+        uint32_t bits = 1;  // no scan for the varying bits
+        while ((1ull << bits) < 2ull * I.k) ++bits;
+        TBK_TRY(tbk_radix_sort128(ctx, &ib, nit, (1ull << bits) - 1ull, 0ull, true));
+      }
       YdGroups Q;
       Q.pk = ws_alloc<uint4>(ctx, ng);
       Q.nex = ws_alloc<uint32_t>(ctx, ng);

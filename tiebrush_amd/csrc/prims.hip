@@ -369,19 +369,22 @@ size_t tbk_radix_ws_bytes(uint32_t n) {
   return (size_t)256 * ntiles * 4 + 256 * 4 + 4096;
 }
 
-int tbk_radix_sort128(tbk_ctx* ctx, SortBufs* b, uint32_t n, uint64_t only_hi, uint64_t only_lo) {
+int tbk_radix_sort128(tbk_ctx* ctx, SortBufs* b, uint32_t n, uint64_t only_hi, uint64_t only_lo, bool masks_are_exact) {
   if (n < 2) return 0;
-  uint64_t* d_andor = ctx->d_scalars + 32;
-  uint64_t init[4] = {~0ull, 0ull, ~0ull, 0ull};
-  memcpy(ctx->h_scalars + 32, init, sizeof(init));
-  TBK_HIP(hipMemcpyAsync(d_andor, ctx->h_scalars + 32, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-  uint32_t g = cdiv(n, 256 * 16);
-  if (g > 512) g = 512;
-  TBK_LAUNCH(ctx, "rx_bits", rx_bits_k, g, 256, 0, b->hi, b->lo, n, d_andor);
-  TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 32, d_andor, sizeof(init), hipMemcpyDeviceToHost, ctx->stream));
-  TBK_HIP(hipStreamSynchronize(ctx->stream));
-  uint64_t vary_hi = (ctx->h_scalars[32] ^ ctx->h_scalars[33]) & only_hi;
-  uint64_t vary_lo = (ctx->h_scalars[34] ^ ctx->h_scalars[35]) & only_lo;
+  uint64_t vary_hi = only_hi, vary_lo = only_lo;
+  if (!masks_are_exact) {  // find the bits that actually vary (one reduction kernel + one read-back)
+    uint64_t* d_andor = ctx->d_scalars + 32;
+    uint64_t init[4] = {~0ull, 0ull, ~0ull, 0ull};
+    memcpy(ctx->h_scalars + 32, init, sizeof(init));
+    TBK_HIP(hipMemcpyAsync(d_andor, ctx->h_scalars + 32, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+    uint32_t g = cdiv(n, 256 * 16);
+    if (g > 512) g = 512;
+    TBK_LAUNCH(ctx, "rx_bits", rx_bits_k, g, 256, 0, b->hi, b->lo, n, d_andor);
+    TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 32, d_andor, sizeof(init), hipMemcpyDeviceToHost, ctx->stream));
+    TBK_HIP(hipStreamSynchronize(ctx->stream));
+    vary_hi = (ctx->h_scalars[32] ^ ctx->h_scalars[33]) & only_hi;
+    vary_lo = (ctx->h_scalars[34] ^ ctx->h_scalars[35]) & only_lo;
+  }
   const uint32_t iter = rx_iter_for(n);
   uint32_t ntiles = cdiv(n, RX_SUB * iter);
   uint32_t* table = ws_alloc<uint32_t>(ctx, (size_t)256 * ntiles);

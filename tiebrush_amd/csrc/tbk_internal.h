@@ -191,8 +191,10 @@ struct SortBufs {
   uint64_t *hi2, *lo2;
   uint32_t* val2;
 };
-// only_hi / only_lo: bits that take part in the ordering (the rest are payload that must not reorder equal keys)
-int tbk_radix_sort128(tbk_ctx* ctx, SortBufs* b, uint32_t n, uint64_t only_hi = ~0ull, uint64_t only_lo = ~0ull);
+// only_hi / only_lo: bits that take part in the ordering (the rest are payload that must not reorder equal keys).
+// masks_are_exact: the caller knows which bits can differ (e.g. a small id range) — no scan of the keys, no read-back
+int tbk_radix_sort128(tbk_ctx* ctx, SortBufs* b, uint32_t n, uint64_t only_hi = ~0ull, uint64_t only_lo = ~0ull,
+                      bool masks_are_exact = false);
 size_t tbk_radix_ws_bytes(uint32_t n);
 // same result for an input made of `nruns` position-sorted runs (msort.hip)
 int tbk_sort_runs(tbk_ctx* ctx, SortBufs* b, uint32_t n_hi, const uint32_t* d_run_off, uint32_t nruns, uint32_t* err,
