@@ -1,17 +1,24 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the tiebrush/tiecov hot path on MI355X.
 
-One "step" = one pass of the hot path over one batch of synthetic input that is already
-resident in HBM: tbk_collapse_tile (k-way merge order, grouping, YC/YX/YD) -> device chain
-(tbk_groups_to_cov_in) -> tbk_coverage_tile (bedgraph intervals + junctions) of the collapsed
-records.  Workload at N=1 = BASELINE.json configs[1]: 2 synthetic sorted BAMs x 1M 100-bp reads,
-default CIGAR-only collapse.  With N>1 every rank owns its own 2 input files (weak scaling: the
-N input streams shard per rank); inside the timed step the ranks agree on
-bundle-aligned coordinate cuts (all-gather of sampled keys, all-reduce rounds), shuffle the passing
-records by coordinate (all-to-all over RCCL) and each collapses + covers its own range over ALL files
-(tiebrush_amd/dist.py).
+One "step" = one pass of the hot path over one batch of synthetic input that is already resident in HBM:
+tbk_collapse_tile (k-way merge order, grouping, YC/YX/YD) -> device chain (tbk_groups_to_cov_in) -> tbk_coverage_tile
+(bedgraph intervals + junctions) of the collapsed records.
 
-Prints ONE JSON line (rank 0).  value = input alignment records collapsed per second, whole job.
+Workload (BASELINE.json `configs`):
+  N = 1   configs[2] = the largest single-GPU configuration: 64 synthetic sorted BAMs x 5M 100-bp reads, --clip collapse,
+          then tiecov -c -j of the result                                                       (--profile c3 defaults)
+  N > 1   configs[3]'s shape: 32 files x 2M reads PER RANK (256 files over 8 GPUs), default CIGAR-only collapse; inside the
+          timed step the ranks agree on bundle-aligned coordinate cuts (all-gather of sampled keys, all-reduce rounds),
+          shuffle the passing records by coordinate (all-to-all over RCCL/xGMI) and each collapses + covers its own range
+          over ALL files (tiebrush_amd/dist.py).  Weak scaling: per-rank input is fixed.
+The tile is generated on the GPU (tiebrush_amd/synth_dev.py) before the timed region.
+
+Prints ONE JSON line (rank 0).  value = input alignment records collapsed per second, whole job, inputs resident in HBM.
+Extra objects: `roofline` (dominant kernel, HIP events on the launch stream), `roofline_coverage` (cov_tile),
+`kernel_path_host_to_host` (the same step with the SoA starting in pinned host memory and every result ending there:
+H2D + D2H inside the clock, SURVEY.md §8d — reported, never `value`), `cpu_baseline` (the CPU oracle, 1 thread, gcc -O2
+and the reference's shipped -O0, on a bounded coordinate window of the same tile).
 """
 import argparse
 import json
@@ -23,19 +30,30 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured stream copy)
+
+WORKLOADS = {   # profile -> (files per GPU, reads per file, collapse options, description)
+    "c2": (2, 1_000_000, {}, "default CIGAR-only"),
+    "c3": (64, 5_000_000, dict(strategy="clip"), "--clip"),
+    "c4": (32, 2_000_000, {}, "default CIGAR-only"),
+    "c5": (128, 1_000_000, dict(strategy="exon", max_nh=5, min_qual=1), "--exon -N 5 -Q 1"),
+}
+ORACLE_KW = {"c2": {}, "c3": dict(strategy=2), "c4": {}, "c5": dict(strategy=3, max_nh=5, min_qual=1)}
+SYNTH_PROFILE = {"c2": "c2", "c3": "c3", "c4": "c2", "c5": "c5"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--files-per-gpu", type=int, default=2)
-    ap.add_argument("--reads-per-file", type=int, default=1_000_000)
-    ap.add_argument("--profile", default="c2", choices=["c2", "c3", "c5"])
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--profile", default=None, choices=sorted(WORKLOADS), help="default: c3 at N=1, c4 at N>1")
+    ap.add_argument("--files-per-gpu", type=int, default=None)
+    ap.add_argument("--reads-per-file", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--prof-steps", type=int, default=5)
+    ap.add_argument("--no-host-path", action="store_true")
+    ap.add_argument("--prof-steps", type=int, default=2)
+    ap.add_argument("--cpu-sample-records", type=int, default=12_000_000, help="target size of the CPU-baseline window")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank (shuffle-then-collapse) path even with one rank")
     args = ap.parse_args()
 
@@ -62,14 +80,22 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     dev = "cuda:%d" % local_rank
+    torch.cuda.set_device(local_rank)
 
-    from tiebrush_amd import api, synth
-    strat = {"c2": {}, "c3": dict(strategy="clip"), "c5": dict(strategy="exon", max_nh=5, min_qual=1)}[args.profile]
+    profile = args.profile or ("c3" if world == 1 else "c4")
+    files, reads, strat, strat_name = WORKLOADS[profile]
+    files = args.files_per_gpu or files
+    reads = args.reads_per_file or reads
+
+    from tiebrush_amd import api, synth, synth_dev
     tx = synth.make_transcriptome()
-    tile = synth.make_tile(args.files_per_gpu, args.reads_per_file, args.profile, first_file=rank * args.files_per_gpu, tx=tx)
+    t_gen = time.perf_counter()
+    dtile = synth_dev.make_tile_device(files, reads, SYNTH_PROFILE[profile], device=dev, first_file=rank * files, tx=tx)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
+    n_records = dtile.n_records
+    n_cig_in = int(dtile.cig.numel())
     ctx = api.Context(local_rank)
-    dtile = api.to_device(tile, dev)
-    opts = ctx.make_opts(**strat)
     opts_defer = ctx.make_opts(defer_yd=True, **strat)   # YD list machine overlaps the (YD-independent) tiecov chain
     cbufs, vbufs = {}, {}
 
@@ -109,14 +135,13 @@ def main():
     from tiebrush_amd import dist as tdist
     stitch = StitchCompute()
 
-    def step():
+    def step(tile=dtile):
         if use_dist:
             # bundle-aligned cuts (all-gather + all-reduce) -> all-to-all of the passing records over RCCL/xGMI -> one
             # collapse of the owned coordinate range over all files -> tiecov of it, everything resident in HBM
-            r = tdist.run_distributed(stitch, dtile, rank * args.files_per_gpu, device=dev, want_coverage=True,
-                                      device_chain=True, **strat)
+            r = tdist.run_distributed(stitch, tile, rank * files, device=dev, want_coverage=True, device_chain=True, **strat)
             return ({"n_passed": r.n_passed_local, "n_groups": r.n_groups}, r.coverage)
-        g = ctx.collapse(dtile, opts=opts_defer, want_coords=True, out=cbufs, raw=True)
+        g = ctx.collapse(tile, opts=opts_defer, want_coords=True, out=cbufs, raw=True)
         view = ctx.groups_to_cov_in(g)
         c = ctx.coverage(view, out=vbufs, raw=True)
         ctx.finish_yd()                                   # every output of the step, YD included, is final here
@@ -171,12 +196,14 @@ def main():
             ctx.finish_yd()
             take("collapse")               # the deferred YD stage belongs to tbk_collapse_tile
         ctx.set_profiling(False)
-        ncig_in = int(tile.cig.shape[0])
-        # algorithmic bytes
-        # (the profiled steps are rank 0's local collapse + coverage; their own counts price the bytes)
-        b_collapse = gg["n_passed"] * 16 + 4 * ncig_in
+        # algorithmic bytes; the profiled steps are rank 0's local collapse + coverage
+        b_collapse = gg["n_passed"] * 16 + 4 * n_cig_in
         ncig_cov = int(view.n_cigar_ops)
         b_cov = gg["n_groups"] * 12 + 4 * ncig_cov + 16 * cc["span_bases"] + 16 * cc["n_intervals"]
+        traffic = {}
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s_%dx%d.json" % (profile, files, reads))
+        if os.path.exists(tpath):          # PMC passes (FETCH_SIZE / WRITE_SIZE, corrected) of this same workload, per launch
+            traffic = json.load(open(tpath)).get("bytes_per_launch", {})
 
         def roofline(stage, name, alg_bytes):
             ms, ln = acc[(stage, name)]
@@ -184,38 +211,99 @@ def main():
             launches_per_step = ln / args.prof_steps
             achieved = (alg_bytes / launches_per_step) / (per_launch_ms * 1e-3) / 1e9
             return {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic.get(name),
                     "avg_launch_us": round(per_launch_ms * 1e3, 2), "launches_per_step": launches_per_step,
                     "algorithmic_bytes_per_step": int(alg_bytes)}
 
         tot = {k: v[0] / args.prof_steps for k, v in acc.items()}
         dom = max(tot, key=tot.get)
         roof["roofline"] = roofline(dom[0], dom[1], b_collapse if dom[0] == "collapse" else b_cov)
-        roof["roofline_coverage"] = roofline("coverage", "cov_tile", b_cov)
+        if ("coverage", "cov_tile") in acc:
+            roof["roofline_coverage"] = roofline("coverage", "cov_tile", b_cov)
         cdom = max((k for k in tot if k[0] == "collapse"), key=tot.get)
         roof["roofline_collapse"] = roofline("collapse", cdom[1], b_collapse)
         roof["kernel_ms_per_step"] = {"%s/%s" % k: round(v, 4) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}
+        roof["launches_per_step"] = int(sum(v[1] for v in acc.values()) / args.prof_steps)
         roof["gpu_kernel_ms_per_step_total"] = round(sum(tot.values()), 4)
 
-    # ---- CPU baseline: the oracle (literal single-threaded port of the reference) on rank 0's shard ----
-    cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
-        from oracle import oracle_ffi as orc
-        okw = {"c2": {}, "c3": dict(strategy=2), "c5": dict(strategy=3, max_nh=5, min_qual=1)}[args.profile]
-        reps = 0
+    # ---- kernel path, pinned host -> pinned host: H2D of the SoA and D2H of every result inside the clock ----
+    host_path = None
+    if rank == 0 and not use_dist and not args.no_host_path:
+        names = ("tid", "pos", "flag", "mapq", "strand", "nh", "cig_off", "cig")
+        hin = {k: torch.empty(getattr(dtile, k).shape, dtype=getattr(dtile, k).dtype, pin_memory=True) for k in names}
+        for k in names:
+            hin[k].copy_(getattr(dtile, k))
+        torch.cuda.synchronize()
+        from dataclasses import replace
+        stage = replace(dtile, **{k: torch.empty_like(getattr(dtile, k)) for k in names})
+        hout = {}
+
+        def host_step():
+            for k in names:
+                getattr(stage, k).copy_(hin[k], non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            gq, cq = step(stage)
+            ng, ni, nj = gq["n_groups"], cq["n_intervals"], cq["n_junctions"]
+            outs = [(cbufs[k], ng) for k in ("rep", "yc", "yx", "yd", "g_start", "g_end")]
+            outs += [(vbufs[k], ni) for k in ("iv_tid", "iv_start", "iv_end", "iv_val")]
+            outs += [(vbufs[k], nj) for k in ("j_tid", "j_start", "j_end", "j_strand", "j_val")]
+            nbytes = 0
+            for i, (t, cnt) in enumerate(outs):
+                if i not in hout or hout[i].numel() < cnt:
+                    hout[i] = torch.empty(max(int(cnt * 1.1), 1), dtype=t.dtype, pin_memory=True)
+                hout[i][:cnt].copy_(t[:cnt], non_blocking=True)
+                nbytes += cnt * t.element_size()
+            torch.cuda.synchronize()
+            return gq["n_passed"], nbytes
+
+        host_step()
+        reps = 3
         t1 = time.perf_counter()
-        while True:
-            og = orc.collapse(tile, **okw)
-            oc = orc.coverage(synth.collapsed_to_cov_input(tile, og))
-            reps += 1
-            if time.perf_counter() - t1 > 10.0 or reps >= 20:
-                break
-        cdt = time.perf_counter() - t1
-        assert og["n_passed"] == n_passed and (use_dist or og["n_groups"] == n_groups), "GPU/oracle disagree on the bench workload"
-        assert use_dist or (oc["n_intervals"] == n_iv and oc["n_junctions"] == n_j)
-        cpu = {"value": round(og["n_passed"] * reps / cdt, 1), "unit": "records/s", "cores": 1, "kind": "port",
-               "sample": "rank-0 shard (%d files x %d reads) collapse+coverage on SoA, %d repetitions, gcc -O2" %
-                         (args.files_per_gpu, args.reads_per_file, reps),
+        for _ in range(reps):
+            npass, out_bytes = host_step()
+        hdt = (time.perf_counter() - t1) / reps
+        in_bytes = sum(hin[k].numel() * hin[k].element_size() for k in names)
+        host_path = {"value": round(npass / hdt, 1), "unit": "records/s", "ms_per_step": round(hdt * 1e3, 3),
+                     "h2d_bytes": int(in_bytes), "d2h_bytes": int(out_bytes), "reps": reps,
+                     "note": "SoA in pinned host memory -> groups, intervals and junctions in pinned host memory; PCIe inside the clock"}
+        del hin, stage, hout
+
+    # ---- CPU baseline: the oracle (literal single-threaded restatement of the reference) on a bounded coordinate window ----
+    cpu = None
+    if rank == 0 and not use_dist and not args.no_cpu_baseline:
+        from oracle import oracle_ffi as orc
+        okw = ORACLE_KW[profile]
+        # window: the first w bases of chr3 in every file, w sized so that about --cpu-sample-records records fall inside
+        frac = min(1.0, args.cpu_sample_records / max(n_records, 1))
+        if frac >= 1.0:
+            sample = synth_dev.tile_to_host(dtile)
+            wdesc = "the whole tile"
+        else:
+            n_t2 = int((dtile.tid == 2).sum())
+            w = int(synth.REF_LENS[2] * min(1.0, args.cpu_sample_records / max(n_t2, 1)))
+            sample = synth_dev.tile_to_host(dtile, window=(2, 0, w))
+            wdesc = "all %d files restricted to chr3:0-%d" % (files, w)
+
+        def cpu_leg(opt, budget_s):
+            reps = 0
+            t1 = time.perf_counter()
+            while True:
+                og = orc.collapse(sample, opt=opt, **okw)
+                oc = orc.coverage(synth.collapsed_to_cov_input(sample, og), opt=opt)
+                reps += 1
+                if time.perf_counter() - t1 > budget_s or reps >= 20:
+                    break
+            return og, oc, og["n_passed"] * reps / (time.perf_counter() - t1), reps
+
+        og, oc, v2, r2 = cpu_leg("O2", 10.0)
+        _, _, v0, r0 = cpu_leg("O0", 10.0)
+        # the GPU path on the same sample must agree with the oracle (counts here; tests/ compare every array)
+        sg = ctx.collapse(api.to_device(sample, dev), **strat)
+        assert sg["n_passed"] == og["n_passed"] and sg["n_groups"] == og["n_groups"], "GPU/oracle disagree on the bench sample"
+        cpu = {"value": round(v2, 1), "unit": "records/s", "cores": 1, "kind": "port",
+               "sample": "%s: %d records -> %d groups, collapse+coverage on SoA, gcc -O2, %d repetition(s)" %
+                         (wdesc, sample.n_records, og["n_groups"], r2),
+               "value_O0": round(v0, 1), "note_O0": "same code at -O0 -g, how the reference ships (CMakeLists.txt:49), %d repetition(s)" % r0,
                "host_cores_available": os.cpu_count()}
 
     if rank == 0:
@@ -233,14 +321,15 @@ def main():
             "dtype": "int64",
             "data": "synthetic",
             "config": {"workload": "%s: %d synthetic sorted BAMs x %d 100bp reads per GPU, %s collapse + tiecov -c -j of the result"
-                                   % (args.profile, args.files_per_gpu, args.reads_per_file,
-                                      {"c2": "default CIGAR-only", "c3": "--clip", "c5": "--exon -N 5 -Q 1"}[args.profile]),
-                       "records_per_gpu": int(tile.n_records), "groups_out": int(n_groups), "parallelism": "files-per-rank x%d" % world,
-                       "resident": "SoA in HBM before the timed region"},
+                                   % (profile, files, reads, strat_name),
+                       "records_per_gpu": int(n_records), "groups_out": int(n_groups), "parallelism": "files-per-rank x%d" % world,
+                       "resident": "SoA in HBM before the timed region", "generated_on_device_s": round(t_gen, 2)},
             "bases_per_s": round(tot_bases * args.steps / dt, 1),
             "tiecov": {"bases_covered_per_step": int(n_bases), "bundle_span_bases": int(span), "intervals": int(n_iv), "junctions": int(n_j)},
         }
         line.update(roof)
+        if host_path is not None:
+            line["kernel_path_host_to_host"] = host_path
         if cpu is not None:
             line["cpu_baseline"] = cpu
     if use_dist:

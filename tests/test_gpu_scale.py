@@ -103,10 +103,11 @@ def test_amplicon_pileup_exact(ctx):
 
 
 def _properties(ctx, tile, **kw):
+    """`tile`: a numpy SoATile or one whose arrays already live on the GPU (synth_dev)."""
     import torch
     from tiebrush_amd import api, soa
     n = tile.n_records
-    dt = api.to_device(tile, "cuda:0")
+    dt = tile if api._is_torch(tile.tid) else api.to_device(tile, "cuda:0")
     res = ctx.collapse(dt, want_rec_group=True, **kw)
     g = res["n_groups"]
     assert res["n_passed"] == n                                   # config 2/3 inputs pass every filter
@@ -120,11 +121,13 @@ def _properties(ctx, tile, **kw):
     assert bool((key[1:] >= key[:-1]).all())
     same = key[1:] == key[:-1]
     assert bool((res["g_end"][1:][same] >= res["g_end"][:-1][same]).all())
+    del key, same, code, tid
     # rec_group: every record belongs to one group, group sizes add up to YC, the representative is a member
     rg = res["rec_group"].to(torch.int64)
     assert int(rg.min()) >= 0 and int(rg.max()) == g - 1
     assert torch.equal(torch.bincount(rg, minlength=g).to(torch.float64), yc)
     assert torch.equal(rg[rep], torch.arange(g, device=rg.device))
+    del rg
     # tiecov checksum on the collapsed records
     view = ctx.groups_to_cov_in(res)
     cov = ctx.coverage(view)
@@ -134,27 +137,30 @@ def _properties(ctx, tile, **kw):
     ops = dt.cig.to(torch.int64) & 0xFFFFFFFF
     mlen = torch.where((ops & 0xF) == 0, ops >> 4, torch.zeros_like(ops))
     csum = torch.cat([torch.zeros(1, dtype=torch.int64, device=ops.device), torch.cumsum(mlen, 0)])
+    del mlen
     mb = csum[co[rep + 1]] - csum[co[rep]]
+    del csum
     assert float(area) == float((mb.to(torch.float64) * yc.to(torch.float32).to(torch.float64)).sum())
     assert cov["n_bases"] == int(mb.sum())
     iv = (cov["iv_tid"].to(torch.int64) << 32) | cov["iv_start"].to(torch.int64)
     assert bool((iv[1:] > iv[:-1]).all()) and bool((cov["iv_val"] != 0).all())
-    # idempotence: the collapsed output, fed back as one TieBrush-merged file, collapses to itself
-    gnp = api.to_numpy({k: v for k, v in res.items() if not k.startswith("_")})
-    r = gnp["rep"].astype(np.int64)
-    co_h = tile.cig_off.astype(np.int64)
-    nc = co_h[r + 1] - co_h[r]
-    off = np.zeros(g + 1, np.int64)
-    np.cumsum(nc, out=off[1:])
-    idx = np.repeat(co_h[r] - off[:-1], nc) + np.arange(int(off[-1]))
-    t2 = soa.SoATile(n_files=1, file_off=np.array([0, g], np.uint32), tbmerged=np.ones(1, np.uint8), tid=tile.tid[r], pos=tile.pos[r],
-                     flag=tile.flag[r], mapq=tile.mapq[r], strand=tile.strand[r], nh=tile.nh[r], cig_off=off.astype(np.uint32),
-                     cig=tile.cig[idx], yc_in=gnp["yc"].astype(np.float32).astype(np.float64), yx_in=gnp["yx"].astype(np.int64),
-                     yd_in=gnp["yd"].astype(np.int64))
-    again = api.to_numpy(ctx.collapse(api.to_device(t2, "cuda:0"), **kw))
-    assert again["n_groups"] == g and np.array_equal(again["rep"], np.arange(g, dtype=np.uint32))
+    del iv, cov, view, mb
+    # idempotence: the collapsed output, fed back as one TieBrush-merged file, collapses to itself (built on the device)
+    nc = co[rep + 1] - co[rep]
+    off = torch.zeros(g + 1, dtype=torch.int64, device=nc.device)
+    torch.cumsum(nc, 0, out=off[1:])
+    idx = torch.repeat_interleave(co[rep] - off[:-1], nc) + torch.arange(int(off[-1]), device=nc.device)
+    t2 = soa.SoATile(n_files=1, file_off=np.array([0, g], np.uint32), tbmerged=np.ones(1, np.uint8), tid=dt.tid[rep].contiguous(),
+                     pos=dt.pos[rep].contiguous(), flag=dt.flag[rep].contiguous(), mapq=dt.mapq[rep].contiguous(),
+                     strand=dt.strand[rep].contiguous(), nh=dt.nh[rep].contiguous(), cig_off=off.to(torch.int32), cig=dt.cig[idx].contiguous(),
+                     yc_in=yc.to(torch.float32).to(torch.float64), yx_in=yx.clone(), yd_in=yd.to(torch.int64))
+    del idx, ops, co
+    want = {k: res[k].clone() for k in ("yc", "yx", "yd", "g_start", "g_end")}
+    again = ctx.collapse(t2, **kw)
+    assert again["n_groups"] == g
+    assert torch.equal(again["rep"].to(torch.int64) & 0xFFFFFFFF, torch.arange(g, device=nc.device))
     for k in ("yc", "yx", "yd", "g_start", "g_end"):
-        assert np.array_equal(again[k], gnp[k]), k
+        assert torch.equal(again[k], want[k]), k
     return g, ni
 
 
@@ -165,8 +171,22 @@ def test_properties_32x1M(ctx):
     assert 0 < g < tile.n_records
 
 
-@pytest.mark.skipif(os.environ.get("TBK_FULL_SCALE") != "1", reason="config 3 at 64 x 5M takes minutes of host-side generation; set TBK_FULL_SCALE=1")
 def test_properties_config3_full_64x5M(ctx):
-    from tiebrush_amd import synth
-    tile = synth.make_tile(64, 5_000_000, "c3")
-    _properties(ctx, tile, strategy="clip")
+    """BASELINE.json configs[2] at its full size (320 M records, one tile), generated on the GPU (synth_dev)."""
+    import torch
+    from tiebrush_amd import synth_dev
+    tile = synth_dev.make_tile_device(64, 5_000_000, "c3", device="cuda:0")
+    g, ni = _properties(ctx, tile, strategy="clip")
+    assert 0 < g < tile.n_records
+    del tile
+    torch.cuda.empty_cache()
+
+
+def test_device_generator_matches_host_model(ctx):
+    """synth_dev on the GPU == synth_dev on the CPU (counter-based integer stream), and the tile is oracle-exact."""
+    from tiebrush_amd import synth_dev
+    a = synth_dev.tile_to_host(synth_dev.make_tile_device(5, 60_000, "c3", device="cuda:0"))
+    b = synth_dev.tile_to_host(synth_dev.make_tile_device(5, 60_000, "c3", device="cpu"))
+    for k in ("tid", "pos", "flag", "mapq", "strand", "nh", "cig_off", "cig"):
+        assert np.array_equal(getattr(a, k), getattr(b, k)), k
+    _exact(ctx, a, strategy="clip")
