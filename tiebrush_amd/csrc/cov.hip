@@ -53,6 +53,8 @@ struct CovArrays {
   int32_t* inclmax;  // inclusive running max of end inside the tid run
   uint32_t* bid;     // bundle id
   uint64_t* cs;      // compacted start (0-based cpos)
+  uint16_t* pk;      // tile kernel input: compacted start inside its home tile (13 bits) | bundle head << 15
+  int32_t* yi;       // tile kernel input: YC as int32 (valid when every YC is integral and sum |YC| < 2^31)
   // per bundle
   int32_t* b_tid;
   int32_t* b_start;
@@ -90,9 +92,14 @@ __global__ void cov_prep_k(uint32_t n, const uint32_t* __restrict__ valid, const
     }
     if (check_ops && (c1 - c0) >= 256) e |= TBK_DERR_NCIGAR;
     double y = yc ? yc[i] : 1.0;
-    if (!(y == rint(y)) || !(fabs(y) < 1073741824.0)) e |= TBK_DERR_FRACTIONAL;
-    else ay += (uint64_t)fabs(y);
+    if (!(y == rint(y)) || !(fabs(y) < 1073741824.0)) {
+      e |= TBK_DERR_FRACTIONAL;
+      y = 0.0;
+    } else {
+      ay += (uint64_t)fabs(y);
+    }
     A.ridx[j] = i;
+    A.yi[j] = (int32_t)y;  // (only read when every value turned out integral and small)
     A.start[j] = pos[i] + 1;
     A.end[j] = pos[i] + l;
     A.tid[j] = tid[i];
@@ -193,29 +200,98 @@ __device__ __forceinline__ void for_each_spill_piece(uint64_t cs, const uint32_t
   }
 }
 
-__global__ void cov_cs_count_k(uint32_t m, CovArrays A, const uint32_t* __restrict__ cig_off, const uint32_t* __restrict__ cig,
-                               uint32_t* __restrict__ tile_cnt) {
-  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= m) return;
-  uint32_t b = A.bid[j];
-  uint64_t cs = A.b_off[b] + (uint64_t)(A.start[j] - A.b_start[b]);
-  A.cs[j] = cs;
-  uint32_t i = A.ridx[j];
-  for_each_spill_piece(cs, cig + cig_off[i], cig_off[i + 1] - cig_off[i],
-                       [&](uint32_t t, uint32_t, uint32_t) { atomicAdd(&tile_cnt[t], 1u); });
+// Also fills tile_first[t] = first record whose compacted start lies in tile t or later (records are start-sorted, so the
+// home records of tile t are [tile_first[t], tile_first[t+1]) — no per-tile binary search in the tile kernel).
+//
+// Spill pieces are binned by a counting sort over tiles.  The records of a block are consecutive in start order, so their
+// pieces land in a handful of tiles just behind the block's first home tile: counts (and, in the fill pass, ranks) are
+// taken in an LDS window of COV_SW tiles and reach the global per-tile counters once per block and tile, not once per
+// piece — deep pile-ups made the per-piece global atomics on one counter the cost of both passes.
+constexpr uint32_t COV_SW = 64;
+__device__ __forceinline__ uint64_t cov_cs_of(const CovArrays& A, uint32_t j) {
+  const uint32_t b = A.bid[j];
+  return A.b_off[b] + (uint64_t)(A.start[j] - A.b_start[b]);
+}
+__global__ __launch_bounds__(256) void cov_cs_count_k(uint32_t m, CovArrays A, const uint32_t* __restrict__ cig_off,
+                                                      const uint32_t* __restrict__ cig, uint32_t* __restrict__ tile_cnt,
+                                                      uint32_t* __restrict__ tile_first, uint32_t ntiles) {
+  __shared__ uint32_t lcnt[COV_SW];
+  __shared__ uint32_t s_tbase;
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (threadIdx.x < COV_SW) lcnt[threadIdx.x] = 0;
+  uint64_t cs = 0;
+  bool spills = false;
+  if (j < m) {
+    cs = cov_cs_of(A, j);
+    A.cs[j] = cs;
+    A.pk[j] = (uint16_t)((uint32_t)(cs % COV_W) | (A.bhead[j] ? 0x8000u : 0u));
+    const uint32_t t = (uint32_t)(cs / COV_W);
+    if (threadIdx.x == 0) s_tbase = t;
+    uint32_t tp = j ? (uint32_t)(cov_cs_of(A, j - 1) / COV_W) + 1u : 0u;  // tiles after the previous record's home tile
+    for (; tp <= t; ++tp) tile_first[tp] = j;
+    if (j + 1 == m)
+      for (uint32_t u = t + 1; u <= ntiles; ++u) tile_first[u] = m;
+    // a read whose reference span ends inside its home tile has no piece elsewhere: no CIGAR walk (96 % of the reads)
+    spills = (uint32_t)(cs % COV_W) + (uint32_t)(A.end[j] - A.start[j] + 1) > (uint32_t)COV_W;
+  }
+  __syncthreads();
+  const uint32_t tbase = s_tbase;
+  if (spills) {
+    const uint32_t i = A.ridx[j];
+    for_each_spill_piece(cs, cig + cig_off[i], cig_off[i + 1] - cig_off[i], [&](uint32_t t, uint32_t, uint32_t) {
+      if (t - tbase < COV_SW)
+        atomicAdd(&lcnt[t - tbase], 1u);
+      else
+        atomicAdd(&tile_cnt[t], 1u);
+    });
+  }
+  __syncthreads();
+  if (threadIdx.x < COV_SW && lcnt[threadIdx.x]) atomicAdd(&tile_cnt[tbase + threadIdx.x], lcnt[threadIdx.x]);
 }
 
-__global__ void cov_spill_fill_k(uint32_t m, CovArrays A, const uint32_t* __restrict__ cig_off, const uint32_t* __restrict__ cig,
-                                 const uint32_t* __restrict__ tile_off, uint32_t* __restrict__ tile_fill,
-                                 uint32_t* __restrict__ sp_seg, uint32_t* __restrict__ sp_rec) {
-  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= m) return;
-  uint32_t i = A.ridx[j];
-  for_each_spill_piece(A.cs[j], cig + cig_off[i], cig_off[i + 1] - cig_off[i], [&](uint32_t t, uint32_t off, uint32_t len) {
-    uint32_t slot = tile_off[t] + atomicAdd(&tile_fill[t], 1u);
-    sp_seg[slot] = off | ((len - 1) << 16);  // off < 8192, len-1 < 8192
-    sp_rec[slot] = j;
-  });
+__global__ __launch_bounds__(256) void cov_spill_fill_k(uint32_t m, CovArrays A, const uint32_t* __restrict__ cig_off,
+                                                        const uint32_t* __restrict__ cig, const uint32_t* __restrict__ tile_off,
+                                                        uint32_t* __restrict__ tile_fill, uint32_t* __restrict__ sp_seg,
+                                                        uint32_t* __restrict__ sp_rec) {
+  __shared__ uint32_t lcnt[COV_SW], lbase[COV_SW];
+  __shared__ uint32_t s_tbase;
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (threadIdx.x < COV_SW) lcnt[threadIdx.x] = 0;
+  uint64_t cs = 0;
+  bool spills = false;
+  uint32_t i = 0, nc = 0;
+  if (j < m) {
+    cs = A.cs[j];
+    if (threadIdx.x == 0) s_tbase = (uint32_t)(cs / COV_W);
+    spills = (uint32_t)(cs % COV_W) + (uint32_t)(A.end[j] - A.start[j] + 1) > (uint32_t)COV_W;
+    if (spills) {
+      i = A.ridx[j];
+      nc = cig_off[i + 1] - cig_off[i];
+    }
+  }
+  __syncthreads();
+  const uint32_t tbase = s_tbase;
+  if (spills)  // pass 1: how many pieces the block sends to each tile of its window
+    for_each_spill_piece(cs, cig + cig_off[i], nc, [&](uint32_t t, uint32_t, uint32_t) {
+      if (t - tbase < COV_SW) atomicAdd(&lcnt[t - tbase], 1u);
+    });
+  __syncthreads();
+  if (threadIdx.x < COV_SW) {  // one reservation per (block, tile)
+    const uint32_t c = lcnt[threadIdx.x];
+    lbase[threadIdx.x] = c ? atomicAdd(&tile_fill[tbase + threadIdx.x], c) : 0u;
+    lcnt[threadIdx.x] = 0;
+  }
+  __syncthreads();
+  if (spills)  // pass 2: ranks inside the reservation from the LDS counters
+    for_each_spill_piece(cs, cig + cig_off[i], nc, [&](uint32_t t, uint32_t off, uint32_t len) {
+      uint32_t slot;
+      if (t - tbase < COV_SW)
+        slot = tile_off[t] + lbase[t - tbase] + atomicAdd(&lcnt[t - tbase], 1u);
+      else
+        slot = tile_off[t] + atomicAdd(&tile_fill[t], 1u);
+      sp_seg[slot] = off | ((len - 1) << 16);  // off < 8192, len-1 < 8192
+      sp_rec[slot] = j;
+    });
 }
 
 // ---- C8: the tile kernel --------------------------------------------------------------------
@@ -232,9 +308,16 @@ __device__ __forceinline__ void lds_add(int32_t* p, int32_t v) { atomicAdd(p, v)
 __device__ __forceinline__ void lds_add(long long* p, long long v) { atomicAdd((unsigned long long*)p, (unsigned long long)v); }
 
 // change point: pos = cpos | tentative<<63 ; val = depth (as double: exact for |v| < 2^53)
-template <class AccT>
-__global__ __launch_bounds__(COV_NT) void cov_tile_k(uint32_t m, uint64_t S, CovArrays A, const uint32_t* __restrict__ cig_off,
+// IDENT: the records are their own compaction (device chain: no validity pass), ridx[j] == j.
+// 512 threads per 8192-base tile (16 bases each in the scan phase) at <= 64 VGPRs: four blocks = 32 waves per CU, the
+// occupancy this latency-bound kernel needs (PMC: 70 % of its wave cycles are spent parked on memory at 16 waves per CU).
+constexpr int COV_R = 2;  // home records a thread has in flight: their independent loads are issued together
+constexpr int COVT_NT = 512;
+constexpr int COVT_PER = COV_W / COVT_NT;
+template <class AccT, bool IDENT>
+__global__ __launch_bounds__(COVT_NT, 8) void cov_tile_k(uint32_t m, uint64_t S, CovArrays A, const uint32_t* __restrict__ cig_off,
                                                      const uint32_t* __restrict__ cig, const double* __restrict__ yc,
+                                                     const uint32_t* __restrict__ tile_first,
                                                      const uint32_t* __restrict__ sp_off, const uint32_t* __restrict__ sp_seg,
                                                      const uint32_t* __restrict__ sp_rec, uint64_t* __restrict__ cp_pos,
                                                      double* __restrict__ cp_val, uint32_t* __restrict__ tile_cp_base,
@@ -242,90 +325,103 @@ __global__ __launch_bounds__(COV_NT) void cov_tile_k(uint32_t m, uint64_t S, Cov
                                                      uint32_t cp_cap, uint32_t* __restrict__ err) {
   __shared__ AccT diff[COV_W + COV_W / 32 + 1];
   __shared__ uint32_t brk[COV_W / 32];
-  __shared__ uint32_t s_range[2];
-  __shared__ uint32_t sm_u[8];
-  __shared__ AccT sm_a[8];
+  __shared__ uint32_t sm_u[COVT_NT / 64];
+  __shared__ AccT sm_a[COVT_NT / 64];
   __shared__ uint32_t s_base;
 
   const uint32_t t = threadIdx.x;
   const uint64_t tile = blockIdx.x;
   const uint64_t t0 = tile * COV_W;
   const uint32_t wlen = (uint32_t)((S - t0) < (uint64_t)COV_W ? (S - t0) : (uint64_t)COV_W);
+  const uint32_t r0 = tile_first[tile], r1 = tile_first[tile + 1];
+  const uint32_t s0 = sp_off[tile], s1 = sp_off[tile + 1];
 
-  for (uint32_t p = t; p < COV_W + COV_W / 32 + 1; p += COV_NT) diff[p] = 0;
+  for (uint32_t p = t; p < COV_W + COV_W / 32 + 1; p += COVT_NT) diff[p] = 0;
   if (t < COV_W / 32) brk[t] = 0;
-  if (t < 2) {  // home records: first j with cs >= t0 (t==0) / cs >= t0+W (t==1)
-    uint64_t key = t0 + (uint64_t)t * COV_W;
-    uint32_t lo = 0, hi = m;
-    while (lo < hi) {
-      uint32_t mid = lo + ((hi - lo) >> 1);
-      if (A.cs[mid] < key)
-        lo = mid + 1;
-      else
-        hi = mid;
-    }
-    s_range[t] = lo;
-  }
   __syncthreads();
-  const uint32_t r0 = s_range[0], r1 = s_range[1];
-  for (uint32_t j = r0 + t; j < r1; j += COV_NT) {
-    uint32_t i = A.ridx[j];
-    AccT y = to_acc<AccT>(yc ? yc[i] : 1.0);
-    uint64_t p = A.cs[j];
-    if (A.bhead[j]) atomicOr(&brk[(uint32_t)(p - t0) >> 5], 1u << ((uint32_t)(p - t0) & 31));
-    uint32_t c0 = cig_off[i], c1 = cig_off[i + 1];
-    for (uint32_t k = c0; k < c1; ++k) {
-      uint32_t c = cig[k];
-      uint32_t op = cig_op(c), len = cig_len(c);
-      if (op == C_M) {
-        uint64_t a = p, b = p + len;
-        if (a < t0 + COV_W) {  // the part inside the home tile
-          uint32_t la = (uint32_t)(a - t0);
-          lds_add(&diff[padidx(la)], y);
-          if (b < t0 + COV_W) lds_add(&diff[padidx((uint32_t)(b - t0))], (AccT)(-y));
+  // home records: COV_R per thread and round, so that the (independent) loads of a round are in flight together and only
+  // the CIGAR words wait for their offsets
+  for (uint32_t jb = r0; jb < r1; jb += COVT_NT * COV_R) {
+    uint32_t c0[COV_R], c1[COV_R], w0[COV_R], lp[COV_R];
+    AccT y[COV_R];
+    bool bh[COV_R];
+#pragma unroll
+    for (int u = 0; u < COV_R; ++u) {
+      const uint32_t j = jb + (uint32_t)u * COVT_NT + t;
+      c0[u] = c1[u] = 0;
+      if (j < r1) {
+        const uint32_t i = IDENT ? j : A.ridx[j];
+        c0[u] = cig_off[i];
+        c1[u] = cig_off[i + 1];
+        if constexpr (sizeof(AccT) == 4)
+          y[u] = A.yi[j];
+        else
+          y[u] = to_acc<AccT>(yc ? yc[i] : 1.0);
+        const uint32_t pk = A.pk[j];
+        lp[u] = pk & 0x1FFFu;
+        bh[u] = (pk & 0x8000u) != 0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < COV_R; ++u) w0[u] = c0[u] < c1[u] ? cig[c0[u]] : 0u;
+#pragma unroll
+    for (int u = 0; u < COV_R; ++u) {
+      if (jb + (uint32_t)u * COVT_NT + t >= r1) continue;
+      uint32_t p = lp[u];  // position relative to the tile start; pieces beyond the tile were pre-binned as spills
+      if (bh[u]) atomicOr(&brk[p >> 5], 1u << (p & 31));
+      for (uint32_t k = c0[u]; k < c1[u]; ++k) {
+        const uint32_t c = k == c0[u] ? w0[u] : cig[k];
+        const uint32_t op = cig_op(c), len = cig_len(c);
+        if (op == C_M) {
+          if (p < (uint32_t)COV_W) {  // the part inside the home tile
+            lds_add(&diff[padidx(p)], y[u]);
+            if (p + len < (uint32_t)COV_W) lds_add(&diff[padidx(p + len)], (AccT)(-y[u]));
+          }
+          p += len;
+          if (p >= (uint32_t)COV_W) break;  // everything further lies in later tiles
+        } else if (op == C_D || op == C_N) {
+          p += len;
+          if (p >= (uint32_t)COV_W) break;
         }
-        p = b;
-      } else if (op == C_D || op == C_N) {
-        p += len;
       }
     }
   }
-  const uint32_t s0 = sp_off[tile], s1 = sp_off[tile + 1];
-  for (uint32_t s = s0 + t; s < s1; s += COV_NT) {
+  for (uint32_t s = s0 + t; s < s1; s += COVT_NT) {
     uint32_t seg = sp_seg[s];
     uint32_t off = seg & 0xFFFFu, len = (seg >> 16) + 1;
-    uint32_t i = A.ridx[sp_rec[s]];
+    uint32_t i = IDENT ? sp_rec[s] : A.ridx[sp_rec[s]];
     AccT y = to_acc<AccT>(yc ? yc[i] : 1.0);
     lds_add(&diff[padidx(off)], y);
     if (off + len < COV_W) lds_add(&diff[padidx(off + len)], (AccT)(-y));
   }
   __syncthreads();
-  // per-thread serial prefix over its 32 bases, then a block scan of the thread totals
+  // per-thread serial prefix over its 32 bases (kept in registers), then a block scan of the thread totals
+  AccT v[COVT_PER];
   AccT run = 0;
-  const uint32_t pb = t * COV_PER;
-#pragma unroll 8
-  for (int q = 0; q < COV_PER; ++q) {
+  const uint32_t pb = t * COVT_PER;
+#pragma unroll
+  for (int q = 0; q < COVT_PER; ++q) {
     run += diff[padidx(pb + q)];
-    diff[padidx(pb + q)] = run;
+    v[q] = run;
   }
   AccT tot;
-  AccT texcl = block_excl_sum<AccT, COV_NT>(run, sm_a, &tot);
+  const AccT texcl = block_excl_sum<AccT, COVT_NT>(run, sm_a, &tot);
   // change points
   uint32_t cnt = 0;
-  uint32_t bw = brk[t];
+  const uint32_t bw = (brk[pb >> 5] >> (pb & 31u)) & ((1u << COVT_PER) - 1u);
   AccT prev = texcl;
   uint32_t mask = 0;
-#pragma unroll 8
-  for (int q = 0; q < COV_PER; ++q) {
-    uint32_t p = pb + q;
-    AccT d = diff[padidx(p)] + texcl;
-    bool cp = (p < wlen) && (p == 0 || d != prev || ((bw >> q) & 1u));
+#pragma unroll
+  for (int q = 0; q < COVT_PER; ++q) {
+    const uint32_t p = pb + q;
+    v[q] += texcl;
+    const bool cp = (p < wlen) && (p == 0 || v[q] != prev || ((bw >> q) & 1u));
     mask |= cp ? (1u << q) : 0u;
-    cnt += cp ? 1u : 0u;
-    prev = d;
+    prev = v[q];
   }
+  cnt = (uint32_t)__builtin_popcount(mask);
   uint32_t btot;
-  uint32_t cex = block_excl_sum<uint32_t, COV_NT>(cnt, sm_u, &btot);
+  uint32_t cex = block_excl_sum<uint32_t, COVT_NT>(cnt, sm_u, &btot);
   if (t == 0) {
     uint32_t base = atomicAdd(cp_alloc, btot);
     s_base = base;
@@ -336,13 +432,13 @@ __global__ __launch_bounds__(COV_NT) void cov_tile_k(uint32_t m, uint64_t S, Cov
   __syncthreads();
   uint32_t o = s_base + cex;
   if ((uint64_t)s_base + btot <= cp_cap) {
-    for (int q = 0; q < COV_PER; ++q) {
+#pragma unroll
+    for (int q = 0; q < COVT_PER; ++q) {
       if ((mask >> q) & 1u) {
-        uint32_t p = pb + q;
-        AccT d = diff[padidx(p)] + texcl;
-        bool tent = (p == 0) && !((bw >> q) & 1u);
+        const uint32_t p = pb + q;
+        const bool tent = (p == 0) && !((bw >> q) & 1u);
         cp_pos[o] = (t0 + p) | (tent ? (1ull << 63) : 0ull);
-        cp_val[o] = (double)d;
+        cp_val[o] = (double)v[q];
         ++o;
       }
     }
@@ -411,7 +507,7 @@ __global__ void cov_iv_write_k(uint32_t ncp, uint32_t nb, CovArrays A, const uin
 template <bool SAMPLE>
 __global__ __launch_bounds__(COV_NT) void cov_tile_ordered_k(uint32_t m, uint64_t S, CovArrays A, const uint32_t* __restrict__ cig_off,
                                                              const uint32_t* __restrict__ cig, const double* __restrict__ yc,
-                                                             const int64_t* __restrict__ yx,
+                                                             const int64_t* __restrict__ yx, const uint32_t* __restrict__ tile_first,
                                                              const uint32_t* __restrict__ sp_off, const uint32_t* __restrict__ sp_seg,
                                                              const uint32_t* __restrict__ sp_rec, uint64_t* __restrict__ cp_pos,
                                                              double* __restrict__ cp_val, uint32_t* __restrict__ tile_cp_base,
@@ -419,7 +515,6 @@ __global__ __launch_bounds__(COV_NT) void cov_tile_ordered_k(uint32_t m, uint64_
                                                              uint32_t cp_cap, uint32_t* __restrict__ err) {
   __shared__ double depth[COV_W + COV_W / 32 + 1];
   __shared__ uint32_t brk[COV_W / 32];
-  __shared__ uint32_t s_range[2];
   __shared__ uint32_t sm_u[8];
   __shared__ uint32_t s_base;
   const uint32_t t = threadIdx.x;
@@ -454,20 +549,8 @@ __global__ __launch_bounds__(COV_NT) void cov_tile_ordered_k(uint32_t m, uint64_
     }
   }
   if (t < COV_W / 32) brk[t] = 0;
-  if (t < 2) {
-    uint64_t key = t0 + (uint64_t)t * COV_W;
-    uint32_t lo = 0, hi = m;
-    while (lo < hi) {
-      uint32_t mid = lo + ((hi - lo) >> 1);
-      if (A.cs[mid] < key)
-        lo = mid + 1;
-      else
-        hi = mid;
-    }
-    s_range[t] = lo;
-  }
   __syncthreads();
-  const uint32_t r0 = s_range[0], r1 = s_range[1];
+  const uint32_t r0 = tile_first[tile], r1 = tile_first[tile + 1];
   const uint32_t s0 = sp_off[tile], s1 = sp_off[tile + 1];
   // Spills: the bin order is arbitrary (atomic slot assignment).  Serialise by record index:
   // repeatedly take the smallest record id greater than the last one processed (selection by
@@ -764,6 +847,8 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
   A.inclmax = ws_alloc<int32_t>(ctx, n);
   A.bid = ws_alloc<uint32_t>(ctx, n);
   A.cs = ws_alloc<uint64_t>(ctx, n);
+  A.pk = ws_alloc<uint16_t>(ctx, n);
+  A.yi = ws_alloc<int32_t>(ctx, n);
   A.b_tid = ws_alloc<int32_t>(ctx, n);
   A.b_start = ws_alloc<int32_t>(ctx, n);
   A.b_end = ws_alloc<int32_t>(ctx, n);
@@ -837,10 +922,11 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
     uint32_t* tile_cnt = ws_alloc<uint32_t>(ctx, ntiles + 1);
     uint32_t* tile_off = ws_alloc<uint32_t>(ctx, ntiles + 1);
     uint32_t* tile_fill = ws_alloc<uint32_t>(ctx, ntiles + 1);
-    if (!tile_fill) return TBK_ENOMEM;
+    uint32_t* tile_first = ws_alloc<uint32_t>(ctx, ntiles + 1);
+    if (!tile_fill || !tile_first) return TBK_ENOMEM;
     TBK_HIP(hipMemsetAsync(tile_cnt, 0, (size_t)(ntiles + 1) * 4, ctx->stream));
     TBK_HIP(hipMemsetAsync(tile_fill, 0, (size_t)(ntiles + 1) * 4, ctx->stream));
-    TBK_LAUNCH(ctx, "cov_cs_count", cov_cs_count_k, cdiv(m, B), B, 0, m, A, in->cig_off, in->cig, tile_cnt);
+    TBK_LAUNCH(ctx, "cov_cs_count", cov_cs_count_k, cdiv(m, B), B, 0, m, A, in->cig_off, in->cig, tile_cnt, tile_first, ntiles);
     TBK_TRY(tbk_exscan_u32(ctx, tile_cnt, tile_off, ntiles + 1, sc + 5));
     TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     TBK_HIP(hipStreamSynchronize(ctx->stream));
@@ -869,16 +955,24 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
                  sp_seg, sp_rec);
     if (sample_mode) {
       TBK_LAUNCH(ctx, "sample_tile", (cov_tile_ordered_k<true>), ntiles, COV_NT, 0, m, S, A, in->cig_off, in->cig, in->yc, in->yx,
-                 tile_off, sp_seg, sp_rec, cp_pos, cp_val, tile_cp_base, tile_cp_cnt, cp_alloc, cp_cap, ctx->d_err);
+                 tile_first, tile_off, sp_seg, sp_rec, cp_pos, cp_val, tile_cp_base, tile_cp_cnt, cp_alloc, cp_cap, ctx->d_err);
     } else if (fractional) {
       TBK_LAUNCH(ctx, "cov_tile_ordered", (cov_tile_ordered_k<false>), ntiles, COV_NT, 0, m, S, A, in->cig_off, in->cig, in->yc,
-                 in->yx, tile_off, sp_seg, sp_rec, cp_pos, cp_val, tile_cp_base, tile_cp_cnt, cp_alloc, cp_cap, ctx->d_err);
-    } else if (sum_abs < (1ull << 31)) {
-      TBK_LAUNCH(ctx, "cov_tile", (cov_tile_k<int32_t>), ntiles, COV_NT, 0, m, S, A, in->cig_off, in->cig, in->yc, tile_off,
-                 sp_seg, sp_rec, cp_pos, cp_val, tile_cp_base, tile_cp_cnt, cp_alloc, cp_cap, ctx->d_err);
+                 in->yx, tile_first, tile_off, sp_seg, sp_rec, cp_pos, cp_val, tile_cp_base, tile_cp_cnt, cp_alloc, cp_cap, ctx->d_err);
     } else {
-      TBK_LAUNCH(ctx, "cov_tile", (cov_tile_k<long long>), ntiles, COV_NT, 0, m, S, A, in->cig_off, in->cig, in->yc, tile_off,
-                 sp_seg, sp_rec, cp_pos, cp_val, tile_cp_base, tile_cp_cnt, cp_alloc, cp_cap, ctx->d_err);
+#define COV_TILE_LAUNCH(ACC, ID)                                                                                                   \
+  TBK_LAUNCH(ctx, "cov_tile", (cov_tile_k<ACC, ID>), ntiles, COVT_NT, 0, m, S, A, in->cig_off, in->cig, in->yc, tile_first, tile_off, \
+             sp_seg, sp_rec, cp_pos, cp_val, tile_cp_base, tile_cp_cnt, cp_alloc, cp_cap, ctx->d_err)
+      const bool small = sum_abs < (1ull << 31);  // int32 accumulators when the depth cannot overflow them
+      if (small && all_valid)
+        COV_TILE_LAUNCH(int32_t, true);
+      else if (small)
+        COV_TILE_LAUNCH(int32_t, false);
+      else if (all_valid)
+        COV_TILE_LAUNCH(long long, true);
+      else
+        COV_TILE_LAUNCH(long long, false);
+#undef COV_TILE_LAUNCH
     }
     TBK_TRY(tbk_exscan_u32(ctx, tile_cp_cnt, tile_cp_off, ntiles, sc + 6));
     TBK_LAUNCH(ctx, "cov_cp_gather", cov_cp_gather_k, ntiles, 64, 0, ntiles, tile_cp_base, tile_cp_cnt, tile_cp_off, cp_pos, cp_val,

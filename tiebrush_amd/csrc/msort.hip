@@ -336,7 +336,9 @@ __global__ __launch_bounds__(256) void msort_big_k(uint64_t* __restrict__ hi, ui
   }
   __syncthreads();
   const uint32_t n = s_be - b0;
-  if (n > MS_BIG_MAX) {  // one block would take milliseconds: let the caller's whole-tile radix sort (all CUs) have the tile
+  if (n > MS_BIG_MAX && n > m / 64) {  // one block would hold up the whole (small) tile: let the caller's whole-tile radix sort (all CUs) have it.
+    // In a large tile a deep pile-up is one of many (config 3 at full size: ~10^5 buckets beyond a window, the deepest 5 x 10^5
+    // records of 3 x 10^8) and the blocks of this kernel run side by side, so it stays here.
     if (threadIdx.x == 0) atomicOr(err, TBK_DERR_BIGBUCKET);
     return;
   }
@@ -425,7 +427,7 @@ __global__ __launch_bounds__(256) void msort_big_k(uint64_t* __restrict__ hi, ui
 // Sort b (nruns runs, run f = [run_off[f], run_off[f+1]), each non-decreasing in hi >> 2 and in input order; the record
 // count run_off[nruns] is read on the device, n_hi is the host's upper bound of it and only sizes the grids) exactly
 // as tbk_radix_sort128 would.  `nbig` is a device word the caller has zeroed (it counts the buckets too long for a
-// phase-B window; those are sorted by msort_big_k).  More than 4096 of them, or one of more than 2^17 records, set
+// phase-B window; those are sorted by msort_big_k).  More than 262144 of them, or one of more than 2^17 records that is also more than 1/64 of the tile, set
 // TBK_DERR_BIGBUCKET in *err; the caller then swaps b's two sides back (still a valid stable input) and runs the radix
 // sort on it.
 int tbk_sort_runs(tbk_ctx* ctx, SortBufs* b, uint32_t n_hi, const uint32_t* d_run_off, uint32_t nruns, uint32_t* err,
@@ -448,7 +450,7 @@ int tbk_sort_runs(tbk_ctx* ctx, SortBufs* b, uint32_t n_hi, const uint32_t* d_ru
              big, nbig);
   // (their number is only known on the device: launch for a generous bound, surplus blocks leave at once; more long
   // buckets than that — a pathological tile — raise TBK_DERR_BIGBUCKET and the caller falls back to the radix sort)
-  const uint32_t big_grid = big_cap < 4096u ? big_cap : 4096u;
+  const uint32_t big_grid = big_cap < 262144u ? big_cap : 262144u;
   TBK_LAUNCH(ctx, "msort_big", msort_big_k, big_grid, 256, 0, b->hi, b->lo, b->val, b->hi2, b->lo2, b->val2, d_run_off + nruns, big, nbig,
              big_grid, err);
   std::swap(b->hi, b->hi2);  // (on TBK_DERR_BIGBUCKET the caller swaps back: the *2 side then holds the phase-A output)
