@@ -27,213 +27,11 @@
 
 #include "dev_common.cuh"
 #include "scan_op.cuh"
+#include "strategy.cuh"
 #include "tbk_internal.h"
+#include "wgroup.h"
 
 namespace {
-
-struct ColIn {
-  uint32_t n, k;
-  const uint32_t* file_off;  // device copy [k+1]
-  const uint8_t* tbm;        // device copy [k]
-  const int32_t *tid, *pos;
-  const uint16_t* flag;
-  const uint8_t *mapq, *strand;
-  const int32_t* nh;
-  const uint32_t *cig_off, *cig;
-  const double* yc_in;
-  const int64_t *yx_in, *yd_in;
-  const uint32_t* md_off;
-  const uint8_t *md, *md_has;
-  const uint64_t* qh;
-  const uint64_t *prio_hi, *prio_lo;
-};
-
-struct ColOpt {
-  int strategy;
-  int max_nh, min_qual;
-  int keep_supp, keep_sec, collapse_same, store_frac;
-  uint64_t seed;
-  uint32_t hash_mask;  // 0xFFFFFFFF in production; TBK_DEBUG_HASH_MASK narrows it to provoke collisions in tests
-};
-
-__device__ __forceinline__ uint32_t strand_code(uint8_t s) { return s == '+' ? 0u : (s == '-' ? 1u : 2u); }
-
-// clipped CIGAR view (cmpCigarClip tiebrush.cpp:312-332)
-__device__ __forceinline__ void clip_view(const uint32_t* __restrict__ c, uint32_t n, uint32_t* b, uint32_t* e) {
-  uint32_t s = 0, t = n;
-  while (s < t && cig_op(c[s]) == C_S) ++s;
-  while (t > s && cig_op(c[t - 1]) == C_S) --t;
-  *b = s;
-  *e = t;
-}
-
-__device__ uint64_t strategy_hash(const ColIn& I, const ColOpt& O, uint32_t i) {
-  const uint32_t* c = I.cig + I.cig_off[i];
-  uint32_t n = I.cig_off[i + 1] - I.cig_off[i];
-  uint64_t h = O.seed;
-  switch (O.strategy) {
-    case TBK_STRAT_CIGAR:
-    case TBK_STRAT_FULL: {
-      h = hash_step(h, n);
-      for (uint32_t k = 0; k < n; ++k) h = hash_step(h, c[k]);
-      if (O.strategy == TBK_STRAT_FULL) {
-        uint32_t has = I.md_has[i];
-        h = hash_step(h, has);
-        if (has) {
-          uint32_t m0 = I.md_off[i], m1 = I.md_off[i + 1];
-          h = hash_step(h, m1 - m0);
-          for (uint32_t k = m0; k < m1; ++k) h = hash_step(h, I.md[k]);
-        }
-      }
-      break;
-    }
-    case TBK_STRAT_CLIP: {
-      uint32_t b, e;
-      clip_view(c, n, &b, &e);
-      h = hash_step(h, e - b);
-      for (uint32_t k = b; k < e; ++k) h = hash_step(h, c[k]);
-      break;
-    }
-    case TBK_STRAT_EXON: {
-      int nex = 0;
-      walk_exons(I.pos[i], c, n, [&](int s, int e) { h = hash_step(h, ((uint64_t)(uint32_t)s << 32) | (uint32_t)e); }, &nex);
-      h = hash_step(h, (uint64_t)nex);
-      break;
-    }
-  }
-  return h;
-}
-
-// exact equality of the strategy keys of two records (start/end/strand are already equal)
-__device__ bool strategy_equal(const ColIn& I, int strategy, uint32_t a, uint32_t b) {
-  const uint32_t* ca = I.cig + I.cig_off[a];
-  const uint32_t* cb = I.cig + I.cig_off[b];
-  uint32_t na = I.cig_off[a + 1] - I.cig_off[a], nb = I.cig_off[b + 1] - I.cig_off[b];
-  switch (strategy) {
-    case TBK_STRAT_CIGAR:
-    case TBK_STRAT_FULL: {
-      if (na != nb) return false;
-      for (uint32_t k = 0; k < na; ++k)
-        if (ca[k] != cb[k]) return false;
-      if (strategy == TBK_STRAT_FULL) {
-        uint32_t ha = I.md_has[a], hb = I.md_has[b];
-        if (ha != hb) return false;
-        if (ha) {
-          uint32_t la = I.md_off[a + 1] - I.md_off[a], lb = I.md_off[b + 1] - I.md_off[b];
-          if (la != lb) return false;
-          for (uint32_t k = 0; k < la; ++k)
-            if (I.md[I.md_off[a] + k] != I.md[I.md_off[b] + k]) return false;
-        }
-      }
-      return true;
-    }
-    case TBK_STRAT_CLIP: {
-      uint32_t ba, ea, bb, eb;
-      clip_view(ca, na, &ba, &ea);
-      clip_view(cb, nb, &bb, &eb);
-      if (ea - ba != eb - bb) return false;
-      for (uint32_t k = 0; k < ea - ba; ++k)
-        if (ca[ba + k] != cb[bb + k]) return false;
-      return true;
-    }
-    case TBK_STRAT_EXON: {
-      // same exon list: hash both walks with two independent seeds and compare element-wise through
-      // a lock-step re-walk: exon lists are short, so walk b for every exon index of a
-      int nxa = 0, nxb = 0;
-      bool eq = true;
-      int ia = 0;
-      walk_exons(I.pos[a], ca, na,
-                 [&](int s, int e) {
-                   int ib = 0, cnt = 0;
-                   bool found = false;
-                   walk_exons(I.pos[b], cb, nb,
-                              [&](int s2, int e2) {
-                                if (ib == ia) found = (s2 == s && e2 == e);
-                                ++ib;
-                              },
-                              &cnt);
-                   if (!found) eq = false;
-                   ++ia;
-                 },
-                 &nxa);
-      walk_exons(I.pos[b], cb, nb, [](int, int) {}, &nxb);
-      return eq && nxa == nxb;
-    }
-  }
-  return false;
-}
-
-// three-way compare of the strategy keys in the reference's order (cmpCigar & co, tiebrush.cpp:285-345)
-__device__ int strategy_cmp(const ColIn& I, int strategy, uint32_t a, uint32_t b) {
-  const uint32_t* ca = I.cig + I.cig_off[a];
-  const uint32_t* cb = I.cig + I.cig_off[b];
-  uint32_t na = I.cig_off[a + 1] - I.cig_off[a], nb = I.cig_off[b + 1] - I.cig_off[b];
-  auto memcmp_u32 = [](const uint32_t* x, const uint32_t* y, uint32_t n) -> int {
-    for (uint32_t k = 0; k < n; ++k) {
-      if (x[k] != y[k]) {  // memcmp over little-endian words: lowest byte first
-        uint32_t xs = __builtin_bswap32(x[k]), ys = __builtin_bswap32(y[k]);
-        return xs < ys ? -1 : 1;
-      }
-    }
-    return 0;
-  };
-  switch (strategy) {
-    case TBK_STRAT_CIGAR:
-    case TBK_STRAT_FULL: {
-      if (na != nb) return (int)na - (int)nb;
-      int c = memcmp_u32(ca, cb, na);
-      if (c != 0 || strategy == TBK_STRAT_CIGAR) return c;
-      uint32_t ha = I.md_has[a], hb = I.md_has[b];
-      if (!ha || !hb) {
-        if (ha == hb) return 0;
-        return ha ? 1 : -1;
-      }
-      uint32_t la = I.md_off[a + 1] - I.md_off[a], lb = I.md_off[b + 1] - I.md_off[b];
-      uint32_t m = la < lb ? la : lb;
-      for (uint32_t k = 0; k < m; ++k) {
-        uint8_t x = I.md[I.md_off[a] + k], y = I.md[I.md_off[b] + k];
-        if (x != y) return x < y ? -1 : 1;
-      }
-      if (la == lb) return 0;
-      return la < lb ? -1 : 1;
-    }
-    case TBK_STRAT_CLIP: {
-      uint32_t ba, ea, bb, eb;
-      clip_view(ca, na, &ba, &ea);
-      clip_view(cb, nb, &bb, &eb);
-      if (ea - ba != eb - bb) return (int)(ea - ba) - (int)(eb - bb);
-      return memcmp_u32(ca + ba, cb + bb, ea - ba);
-    }
-    case TBK_STRAT_EXON: {
-      int nxa = 0, nxb = 0;
-      walk_exons(I.pos[a], ca, na, [](int, int) {}, &nxa);
-      walk_exons(I.pos[b], cb, nb, [](int, int) {}, &nxb);
-      if (nxa != nxb) return nxa - nxb;
-      int res = 0, ia = 0;
-      walk_exons(I.pos[a], ca, na,
-                 [&](int s, int e) {
-                   if (res == 0) {
-                     int ib = 0, cnt = 0;
-                     walk_exons(I.pos[b], cb, nb,
-                                [&](int s2, int e2) {
-                                  if (ib == ia && res == 0) {
-                                    if (s != s2)
-                                      res = s - s2;
-                                    else if (e != e2)
-                                      res = e - e2;
-                                  }
-                                  ++ib;
-                                },
-                                &cnt);
-                   }
-                   ++ia;
-                 },
-                 &nxa);
-      return res;
-    }
-  }
-  return 0;
-}
 
 // ---- K1: keys --------------------------------------------------------------------------------------
 struct EffKey {  // scan element: lexicographic running max of (hi, end) per file + count of passing records (all 32-bit words)
@@ -283,6 +81,24 @@ __global__ void col_keys_k(ColIn I, ColOpt O, uint64_t* __restrict__ khi, uint64
   int nh = I.nh[i] == TBK_NH_ABSENT ? 0 : I.nh[i];
   if (nh > O.max_nh) pass = false;
   uint64_t h = pass ? strategy_hash(I, O, i) : 0ull;
+  // Hash word of the key: 31 hashed bits, or — bit 31 set — an EXACT code when the strategy key is a single reference-consuming
+  // CIGAR operation (after clip stripping under -P) or a single exon under -E: with (tid,start,strand,span) in the key the
+  // operation's length is the span, so the op code alone identifies the alignment and equal keys need no comparison of the
+  // CIGARs (three reads in four of an RNA-seq sample).  Order inside a (strand, end) tie set never depends on this word.
+  uint32_t h32 = (uint32_t)(h >> 32) & O.hash_mask & 0x7FFFFFFFu;
+  if (pass && O.strategy != TBK_STRAT_FULL) {
+    const uint32_t* c = I.cig + I.cig_off[i];
+    uint32_t nc = I.cig_off[i + 1] - I.cig_off[i];
+    if (O.strategy == TBK_STRAT_EXON) {
+      int nex = 0;
+      walk_exons(I.pos[i], c, nc, [](int, int) {}, &nex);
+      if (nex == 1) h32 = 0x8000000Fu;
+    } else {
+      uint32_t b = 0, e = nc;
+      if (O.strategy == TBK_STRAT_CLIP) clip_view(c, nc, &b, &e);
+      if (e - b == 1 && ((0x18Du >> cig_op(c[b])) & 1u)) h32 = 0x80000000u | cig_op(c[b]);
+    }
+  }
   int64_t span = (int64_t)end - (int64_t)start + 1;
   if (pass && (span < 0 || span >= (1ll << 30) || start < 0 || I.tid[i] < -1)) {  // key fields: tid+1 and start need 31 bits
     atomicOr(err, TBK_DERR_SPAN);
@@ -290,7 +106,7 @@ __global__ void col_keys_k(ColIn I, ColOpt O, uint64_t* __restrict__ khi, uint64
   }
   // hi = tid+1 : 31 | start : 31 | strand code : 2   lo = span : 32 | h32   (tid+1 and start are < 2^31 in BAM)
   khi[i] = ((uint64_t)(uint32_t)(I.tid[i] + 1) << 33) | ((uint64_t)(uint32_t)start << 2) | strand_code(I.strand[i]);
-  klo[i] = ((uint64_t)span << 32) | ((h >> 32) & O.hash_mask);
+  klo[i] = ((uint64_t)span << 32) | h32;
   kend[i] = end;
   kflags[i] = (pass ? 1u : 0u) | (i == I.file_off[f] ? 2u : 0u);
   fidx[i] = (uint16_t)f;
@@ -598,6 +414,43 @@ __global__ void yd_gcount_k(uint32_t ng, uint32_t m, const uint32_t* __restrict_
   uint32_t q0 = G.first[sg];
   uint32_t end = (sg + 1 < ng) ? ioff[G.first[sg + 1]] : (ioff[m - 1] + icnt[m - 1]);
   ocnt[o] = end - ioff[q0];
+}
+
+// window path: the (group, sample) incidences exist already (WgOut::pfile / pgrp, a group's incidences in file order)
+__global__ void yd_gcount_w_k(uint32_t ng, const uint32_t* __restrict__ gperm, GroupAcc G, const uint64_t* __restrict__ ghi,
+                              uint32_t* __restrict__ ocnt) {
+  uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= ng) return;
+  const uint32_t sg = gperm[o];
+  ocnt[o] = G.ns[sg] * (((uint32_t)ghi[sg] & 3u) == 2u ? 2u : 1u);  // '.' feeds both lists (tiebrush.cpp:515-520)
+}
+__global__ void yd_fill_w_k(uint32_t np, const uint16_t* __restrict__ pfile, const uint32_t* __restrict__ pgrp,
+                            const uint32_t* __restrict__ gpoff, const uint32_t* __restrict__ ginv, const uint32_t* __restrict__ ooff,
+                            const uint64_t* __restrict__ ghi, uint64_t* __restrict__ hi, uint64_t* __restrict__ lo, uint32_t* __restrict__ v) {
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= np) return;
+  const uint32_t sg = pgrp[p];
+  const uint32_t o = ginv[sg];
+  const uint32_t c = (uint32_t)ghi[sg] & 3u;  // strand code: 0 '+', 1 '-', 2 '.'
+  uint32_t pos = ooff[o] + (p - gpoff[sg]) * (c == 2u ? 2u : 1u);
+  const uint64_t f = pfile[p];
+  if (c != 1u) {  // '+' or '.': fsegs[f]
+    hi[pos] = f * 2;
+    lo[pos] = o;
+    v[pos] = o;
+    ++pos;
+  }
+  if (c != 0u) {  // '-' or '.': rsegs[f]
+    hi[pos] = f * 2 + 1;
+    lo[pos] = o;
+    v[pos] = o;
+  }
+}
+__global__ void col_recgroup_w_k(uint32_t n, const uint32_t* __restrict__ rec_sg, const uint32_t* __restrict__ ginv, int32_t* __restrict__ rec_group) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t sg = rec_sg[i];
+  rec_group[i] = sg == 0xFFFFFFFFu ? -1 : (int32_t)ginv[sg];
 }
 
 struct YdItems {
@@ -1193,6 +1046,11 @@ struct YdJob {  // everything the YD stage needs from the main stage (device poi
   const uint64_t *shi, *slo;
   int32_t* g_yd;
   int32_t* out_yd;
+  // window path: incidences instead of sorted records (val / flags / fidx / sgid are unused then)
+  bool win = false;
+  uint32_t np = 0;
+  const uint16_t* pfile = nullptr;
+  const uint32_t *pgrp = nullptr, *gpoff = nullptr;
 };
 
 }  // namespace
@@ -1210,14 +1068,24 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
   TBK_HIP(hipSetDevice(ctx->device));
   TBK_HIP(hipMemsetAsync(sc, 0, 32 * sizeof(uint64_t), ctx->stream));
   {
-    uint32_t* icnt = ws_alloc<uint32_t>(ctx, m);
-    uint32_t* ioff = ws_alloc<uint32_t>(ctx, m);
-    if (!ioff) return TBK_ENOMEM;
-    TBK_LAUNCH(ctx, "yd_count", yd_count_k, cdiv(m, B), B, 0, I, m, J.val, J.flags, J.fidx, icnt);
-    TBK_TRY(tbk_exscan_u32(ctx, icnt, ioff, m, sc + 2));
+    uint32_t *icnt = nullptr, *ioff = nullptr, *ocnt = nullptr, *ooff = nullptr;
+    uint64_t nit64;
+    if (J.win) {  // items per output group straight from the per-group sample counts
+      ocnt = ws_alloc<uint32_t>(ctx, ng);
+      ooff = ws_alloc<uint32_t>(ctx, ng);
+      if (!ooff) return TBK_ENOMEM;
+      TBK_LAUNCH(ctx, "yd_gcount", yd_gcount_w_k, cdiv(ng, B), B, 0, ng, J.gperm, J.G, J.shi, ocnt);
+      TBK_TRY(tbk_exscan_u32(ctx, ocnt, ooff, ng, sc + 2));
+    } else {
+      icnt = ws_alloc<uint32_t>(ctx, m);
+      ioff = ws_alloc<uint32_t>(ctx, m);
+      if (!ioff) return TBK_ENOMEM;
+      TBK_LAUNCH(ctx, "yd_count", yd_count_k, cdiv(m, B), B, 0, I, m, J.val, J.flags, J.fidx, icnt);
+      TBK_TRY(tbk_exscan_u32(ctx, icnt, ioff, m, sc + 2));
+    }
     TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     TBK_HIP(hipStreamSynchronize(ctx->stream));
-    const uint64_t nit64 = ctx->h_scalars[2];
+    nit64 = ctx->h_scalars[2];
     if (nit64 >= (1ull << 32)) return TBK_E2BIG;
     const uint32_t nit = (uint32_t)nit64;
     if (nit) {
@@ -1239,13 +1107,17 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       uint32_t* noff = ws_alloc<uint32_t>(ctx, nit);
       uint32_t* chain_first = ws_alloc<uint32_t>(ctx, nit);
       if (!chain_first) return TBK_ENOMEM;
-      uint32_t* ocnt = ws_alloc<uint32_t>(ctx, ng);
-      uint32_t* ooff = ws_alloc<uint32_t>(ctx, ng);
-      if (!ooff) return TBK_ENOMEM;
-      TBK_LAUNCH(ctx, "yd_gcount", yd_gcount_k, cdiv(ng, B), B, 0, ng, m, J.gperm, J.G, ioff, icnt, ocnt);
-      TBK_TRY(tbk_exscan_u32(ctx, ocnt, ooff, ng, nullptr));
-      TBK_LAUNCH(ctx, "yd_fill", yd_fill_k, cdiv(m, B), B, 0, I, m, J.val, J.flags, J.fidx, J.sgid, J.ginv, ioff, ooff, J.G, ib.hi, ib.lo,
-                 ib.val);
+      if (J.win) {
+        TBK_LAUNCH(ctx, "yd_fill", yd_fill_w_k, cdiv(J.np, B), B, 0, J.np, J.pfile, J.pgrp, J.gpoff, J.ginv, ooff, J.shi, ib.hi, ib.lo, ib.val);
+      } else {
+        ocnt = ws_alloc<uint32_t>(ctx, ng);
+        ooff = ws_alloc<uint32_t>(ctx, ng);
+        if (!ooff) return TBK_ENOMEM;
+        TBK_LAUNCH(ctx, "yd_gcount", yd_gcount_k, cdiv(ng, B), B, 0, ng, m, J.gperm, J.G, ioff, icnt, ocnt);
+        TBK_TRY(tbk_exscan_u32(ctx, ocnt, ooff, ng, nullptr));
+        TBK_LAUNCH(ctx, "yd_fill", yd_fill_k, cdiv(m, B), B, 0, I, m, J.val, J.flags, J.fidx, J.sgid, J.ginv, ioff, ooff, J.G, ib.hi, ib.lo,
+                   ib.val);
+      }
       {  // stable split by list id (file * 2 + strand list); group order is already in place.  The id range is known:
         uint32_t bits = 1;  // no scan for the varying bits
         while ((1ull << bits) < 2ull * I.k) ++bits;
@@ -1420,6 +1292,23 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
     if (strcmp(e, "runs") == 0) runs_min = 0;
   }
 
+  // The window path (wgroup.hip) goes from the runs to the groups without sorting the records; it covers plain BAM inputs
+  // with integral YC (the ordered / carried-tag cases keep the sort path, which has the per-record order they need).
+  bool use_win = tbk_window_supported(in->n_files) && !O.store_frac && !O.collapse_same && !I.prio_hi && n >= 4096;
+  if (in->tbmerged)
+    for (uint32_t f = 0; f < in->n_files; ++f) use_win = use_win && in->tbmerged[f] == 0;
+  if (const char* e = getenv("TBK_PATH")) {  // test hook: "sort" keeps the sort path, "window" takes the window path whatever the size
+    if (strcmp(e, "sort") == 0) use_win = false;
+    if (strcmp(e, "window") == 0)
+      use_win = tbk_window_supported(in->n_files) && !O.store_frac && !O.collapse_same && !I.prio_hi && [&] {
+        bool ok = true;
+        if (in->tbmerged)
+          for (uint32_t f = 0; f < in->n_files; ++f) ok = ok && in->tbmerged[f] == 0;
+        return ok;
+      }();
+  }
+  WgOut win_out;
+  bool win_done = false;
   uint32_t m = 0, ng = 0;
   GroupAcc G{};
   int32_t* g_yd = nullptr;
@@ -1448,8 +1337,60 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
       EffKey ident{0u, 0u, INT32_MIN, 0u};
       TBK_TRY((scan_op_run<EffKey, EffOp, EffLoad, EffStore>(ctx, "col_effkey_scan", n, ld, st, EffOp{}, ident)));
     }
-    if (use_runs) TBK_LAUNCH(ctx, "col_runs", col_runs_k, cdiv(I.k + 1, B), B, 0, I.k, I.file_off, head_off, sc + 0, run_off);
+    if (use_runs || use_win) TBK_LAUNCH(ctx, "col_runs", col_runs_k, cdiv(I.k + 1, B), B, 0, I.k, I.file_off, head_off, sc + 0, run_off);
     uint32_t eb = 0;
+    if (use_win) {
+      // ---- window path (wgroup.hip): groups straight from the position-sorted runs, no record sort ----
+      TBK_TRY(tbk_sync_err(ctx, &eb));
+      if (eb) return tbk_derr_to_status(ctx, eb);
+      m = (uint32_t)ctx->h_scalars[0];
+      out->n_passed = m;
+      if (m == 0) return 0;
+      WgOut wo;
+      TBK_TRY(tbk_window_groups(ctx, I, O.strategy, s2.hi, s2.lo, s2.val, m, run_off, effend, khi, klo, out->rec_group != nullptr, O.seed, &wo, &eb));
+      if (eb & TBK_DERR_BIGBUCKET) {  // a pile-up with more distinct alignments than the LDS table holds: sort path
+        TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
+        use_win = false;
+        continue;
+      }
+      if (eb & TBK_DERR_COLLISION) {  // reseed
+        ++attempt;
+        continue;
+      }
+      if (eb) return tbk_derr_to_status(ctx, eb);
+      ng = wo.ng;
+      if (ng > out->cap_groups) {
+        out->n_groups = ng;
+        return TBK_E2BIG;
+      }
+      G.yc = wo.yc;
+      G.ns = wo.ns;
+      G.yxin = wo.yxin;
+      G.ydin = wo.ydin;
+      G.rep = wo.rep;
+      G.first = wo.first;
+      G.tie = wo.tie;
+      g_yd = ws_alloc<int32_t>(ctx, ng);
+      gperm = ws_alloc<uint32_t>(ctx, ng);
+      ginv = ws_alloc<uint32_t>(ctx, ng);
+      if (!ginv) return TBK_ENOMEM;
+      TBK_HIP(hipMemsetAsync(g_yd, 0, (size_t)ng * 4, ctx->stream));
+      const uint64_t* png = sc + 1;  // (tbk_window_groups left the group count there)
+      TBK_LAUNCH(ctx, "col_tie_sort", col_tie_sort_k, cdiv(ng, B), B, 0, I, O.strategy, png, wo.gmem, G, gperm, ginv);
+      TBK_LAUNCH(ctx, "col_write", col_write_k, cdiv(ng, B), B, 0, png, gperm, G, wo.ghi, wo.glo, out->cap_groups, out->rep, out->yc,
+                 out->yx, out->g_start, out->g_end, effend, out->rep_effend);
+      if (out->rec_group) TBK_LAUNCH(ctx, "col_recgroup", col_recgroup_w_k, cdiv(n, B), B, 0, n, wo.rec_sg, ginv, out->rec_group);
+      TBK_TRY(tbk_sync_err(ctx, &eb));
+      if (eb) return tbk_derr_to_status(ctx, eb);
+      win_out = wo;
+      win_done = true;
+      if (attempt > 0) {
+        char b[96];
+        snprintf(b, sizeof(b), "info: key-hash collision, reseeded %d time(s)", attempt);
+        ctx->last_error = b;
+      }
+      break;
+    }
     uint32_t m_hi = n, ng_hi = n;  // what sizes grids and arrays: the counts themselves, or their upper bound
     if (!lean) {
       TBK_TRY(tbk_sync_err(ctx, &eb));
@@ -1573,6 +1514,13 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
   job->m = m;
   job->ng = ng;
   job->cap = out->cap_groups;
+  if (win_done) {
+    job->win = true;
+    job->np = win_out.np;
+    job->pfile = win_out.pfile;
+    job->pgrp = win_out.pgrp;
+    job->gpoff = win_out.gpoff;
+  }
   job->val = sb.val;
   job->flags = flags;
   job->fidx = fidx;
@@ -1580,8 +1528,8 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
   job->ginv = ginv;
   job->gperm = gperm;
   job->G = G;
-  job->shi = sb.hi;
-  job->slo = sb.lo;
+  job->shi = win_done ? win_out.ghi : sb.hi;
+  job->slo = win_done ? win_out.glo : sb.lo;
   job->g_yd = g_yd;
   job->out_yd = out->yd;
   ctx->yd_job = job;

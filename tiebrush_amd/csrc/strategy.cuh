@@ -1,0 +1,216 @@
+// strategy.cuh — the record view of the collapse stage and the strategy key of a record (what "the same alignment" means
+// under the four merge strategies): seeded hash, exact equality, and the reference's three-way compare.
+// Reference: cmpCigar / cmpCigarClip / cmpExons / cmpFull, /root/reference/src/tiebrush.cpp:285-345.
+// Shared by collapse.hip (sort path) and wgroup.hip (window path).
+#pragma once
+#include "dev_common.cuh"
+#include "tbk_internal.h"
+
+namespace tbkd {
+
+struct ColIn {
+  uint32_t n, k;
+  const uint32_t* file_off;  // device copy [k+1]
+  const uint8_t* tbm;        // device copy [k]
+  const int32_t *tid, *pos;
+  const uint16_t* flag;
+  const uint8_t *mapq, *strand;
+  const int32_t* nh;
+  const uint32_t *cig_off, *cig;
+  const double* yc_in;
+  const int64_t *yx_in, *yd_in;
+  const uint32_t* md_off;
+  const uint8_t *md, *md_has;
+  const uint64_t* qh;
+  const uint64_t *prio_hi, *prio_lo;
+};
+
+struct ColOpt {
+  int strategy;
+  int max_nh, min_qual;
+  int keep_supp, keep_sec, collapse_same, store_frac;
+  uint64_t seed;
+  uint32_t hash_mask;  // 0xFFFFFFFF in production; TBK_DEBUG_HASH_MASK narrows it to provoke collisions in tests
+};
+
+__device__ __forceinline__ uint32_t strand_code(uint8_t s) { return s == '+' ? 0u : (s == '-' ? 1u : 2u); }
+
+// clipped CIGAR view (cmpCigarClip tiebrush.cpp:312-332)
+__device__ __forceinline__ void clip_view(const uint32_t* __restrict__ c, uint32_t n, uint32_t* b, uint32_t* e) {
+  uint32_t s = 0, t = n;
+  while (s < t && cig_op(c[s]) == C_S) ++s;
+  while (t > s && cig_op(c[t - 1]) == C_S) --t;
+  *b = s;
+  *e = t;
+}
+
+__device__ inline uint64_t strategy_hash(const ColIn& I, const ColOpt& O, uint32_t i) {
+  const uint32_t* c = I.cig + I.cig_off[i];
+  uint32_t n = I.cig_off[i + 1] - I.cig_off[i];
+  uint64_t h = O.seed;
+  switch (O.strategy) {
+    case TBK_STRAT_CIGAR:
+    case TBK_STRAT_FULL: {
+      h = hash_step(h, n);
+      for (uint32_t k = 0; k < n; ++k) h = hash_step(h, c[k]);
+      if (O.strategy == TBK_STRAT_FULL) {
+        uint32_t has = I.md_has[i];
+        h = hash_step(h, has);
+        if (has) {
+          uint32_t m0 = I.md_off[i], m1 = I.md_off[i + 1];
+          h = hash_step(h, m1 - m0);
+          for (uint32_t k = m0; k < m1; ++k) h = hash_step(h, I.md[k]);
+        }
+      }
+      break;
+    }
+    case TBK_STRAT_CLIP: {
+      uint32_t b, e;
+      clip_view(c, n, &b, &e);
+      h = hash_step(h, e - b);
+      for (uint32_t k = b; k < e; ++k) h = hash_step(h, c[k]);
+      break;
+    }
+    case TBK_STRAT_EXON: {
+      int nex = 0;
+      walk_exons(I.pos[i], c, n, [&](int s, int e) { h = hash_step(h, ((uint64_t)(uint32_t)s << 32) | (uint32_t)e); }, &nex);
+      h = hash_step(h, (uint64_t)nex);
+      break;
+    }
+  }
+  return h;
+}
+
+// exact equality of the strategy keys of two records (start/end/strand are already equal)
+__device__ inline bool strategy_equal(const ColIn& I, int strategy, uint32_t a, uint32_t b) {
+  const uint32_t* ca = I.cig + I.cig_off[a];
+  const uint32_t* cb = I.cig + I.cig_off[b];
+  uint32_t na = I.cig_off[a + 1] - I.cig_off[a], nb = I.cig_off[b + 1] - I.cig_off[b];
+  switch (strategy) {
+    case TBK_STRAT_CIGAR:
+    case TBK_STRAT_FULL: {
+      if (na != nb) return false;
+      for (uint32_t k = 0; k < na; ++k)
+        if (ca[k] != cb[k]) return false;
+      if (strategy == TBK_STRAT_FULL) {
+        uint32_t ha = I.md_has[a], hb = I.md_has[b];
+        if (ha != hb) return false;
+        if (ha) {
+          uint32_t la = I.md_off[a + 1] - I.md_off[a], lb = I.md_off[b + 1] - I.md_off[b];
+          if (la != lb) return false;
+          for (uint32_t k = 0; k < la; ++k)
+            if (I.md[I.md_off[a] + k] != I.md[I.md_off[b] + k]) return false;
+        }
+      }
+      return true;
+    }
+    case TBK_STRAT_CLIP: {
+      uint32_t ba, ea, bb, eb;
+      clip_view(ca, na, &ba, &ea);
+      clip_view(cb, nb, &bb, &eb);
+      if (ea - ba != eb - bb) return false;
+      for (uint32_t k = 0; k < ea - ba; ++k)
+        if (ca[ba + k] != cb[bb + k]) return false;
+      return true;
+    }
+    case TBK_STRAT_EXON: {
+      // same exon list: hash both walks with two independent seeds and compare element-wise through
+      // a lock-step re-walk: exon lists are short, so walk b for every exon index of a
+      int nxa = 0, nxb = 0;
+      bool eq = true;
+      int ia = 0;
+      walk_exons(I.pos[a], ca, na,
+                 [&](int s, int e) {
+                   int ib = 0, cnt = 0;
+                   bool found = false;
+                   walk_exons(I.pos[b], cb, nb,
+                              [&](int s2, int e2) {
+                                if (ib == ia) found = (s2 == s && e2 == e);
+                                ++ib;
+                              },
+                              &cnt);
+                   if (!found) eq = false;
+                   ++ia;
+                 },
+                 &nxa);
+      walk_exons(I.pos[b], cb, nb, [](int, int) {}, &nxb);
+      return eq && nxa == nxb;
+    }
+  }
+  return false;
+}
+
+// three-way compare of the strategy keys in the reference's order (cmpCigar & co, tiebrush.cpp:285-345)
+__device__ inline int strategy_cmp(const ColIn& I, int strategy, uint32_t a, uint32_t b) {
+  const uint32_t* ca = I.cig + I.cig_off[a];
+  const uint32_t* cb = I.cig + I.cig_off[b];
+  uint32_t na = I.cig_off[a + 1] - I.cig_off[a], nb = I.cig_off[b + 1] - I.cig_off[b];
+  auto memcmp_u32 = [](const uint32_t* x, const uint32_t* y, uint32_t n) -> int {
+    for (uint32_t k = 0; k < n; ++k) {
+      if (x[k] != y[k]) {  // memcmp over little-endian words: lowest byte first
+        uint32_t xs = __builtin_bswap32(x[k]), ys = __builtin_bswap32(y[k]);
+        return xs < ys ? -1 : 1;
+      }
+    }
+    return 0;
+  };
+  switch (strategy) {
+    case TBK_STRAT_CIGAR:
+    case TBK_STRAT_FULL: {
+      if (na != nb) return (int)na - (int)nb;
+      int c = memcmp_u32(ca, cb, na);
+      if (c != 0 || strategy == TBK_STRAT_CIGAR) return c;
+      uint32_t ha = I.md_has[a], hb = I.md_has[b];
+      if (!ha || !hb) {
+        if (ha == hb) return 0;
+        return ha ? 1 : -1;
+      }
+      uint32_t la = I.md_off[a + 1] - I.md_off[a], lb = I.md_off[b + 1] - I.md_off[b];
+      uint32_t m = la < lb ? la : lb;
+      for (uint32_t k = 0; k < m; ++k) {
+        uint8_t x = I.md[I.md_off[a] + k], y = I.md[I.md_off[b] + k];
+        if (x != y) return x < y ? -1 : 1;
+      }
+      if (la == lb) return 0;
+      return la < lb ? -1 : 1;
+    }
+    case TBK_STRAT_CLIP: {
+      uint32_t ba, ea, bb, eb;
+      clip_view(ca, na, &ba, &ea);
+      clip_view(cb, nb, &bb, &eb);
+      if (ea - ba != eb - bb) return (int)(ea - ba) - (int)(eb - bb);
+      return memcmp_u32(ca + ba, cb + bb, ea - ba);
+    }
+    case TBK_STRAT_EXON: {
+      int nxa = 0, nxb = 0;
+      walk_exons(I.pos[a], ca, na, [](int, int) {}, &nxa);
+      walk_exons(I.pos[b], cb, nb, [](int, int) {}, &nxb);
+      if (nxa != nxb) return nxa - nxb;
+      int res = 0, ia = 0;
+      walk_exons(I.pos[a], ca, na,
+                 [&](int s, int e) {
+                   if (res == 0) {
+                     int ib = 0, cnt = 0;
+                     walk_exons(I.pos[b], cb, nb,
+                                [&](int s2, int e2) {
+                                  if (ib == ia && res == 0) {
+                                    if (s != s2)
+                                      res = s - s2;
+                                    else if (e != e2)
+                                      res = e - e2;
+                                  }
+                                  ++ib;
+                                },
+                                &cnt);
+                   }
+                   ++ia;
+                 },
+                 &nxa);
+      return res;
+    }
+  }
+  return 0;
+}
+
+}  // namespace tbkd
+using namespace tbkd;

@@ -1,0 +1,30 @@
+// wgroup.h — host interface of the window path (wgroup.hip) used by the collapse pipeline (collapse.hip).
+#pragma once
+#include "strategy.cuh"
+#include "tbk_internal.h"
+
+struct WgOut {
+  uint32_t ng = 0, np = 0;          // groups; (group, sample) incidences
+  uint64_t *ghi = nullptr, *glo = nullptr;  // [ng] group keys, in key order (the order of the sort path's groups)
+  uint32_t* gmem = nullptr;         // [ng] the representative record of the group (any member serves the comparators)
+  uint32_t* gpoff = nullptr;        // [ng] first incidence of the group
+  uint16_t* pfile = nullptr;        // [np] sample (input file) of the incidence; a group's incidences are in file order
+  uint32_t* pgrp = nullptr;         // [np] group of the incidence
+  uint32_t* rec_sg = nullptr;       // optional [n]: group (key order) of every passing record, 0xFFFFFFFF otherwise
+  // per-group accumulators, as the sort path's reduction leaves them
+  double* yc = nullptr;
+  uint32_t* ns = nullptr;
+  long long *yxin = nullptr, *ydin = nullptr;
+  unsigned long long* rep = nullptr;
+  uint32_t* first = nullptr;        // == identity: the "sorted arrays" of the later stages are the group arrays
+  uint8_t* tie = nullptr;
+};
+
+// chi / clo / cval: the compacted passing records (k runs, run f = [run_off[f], run_off[f+1]), device offsets), m of them (host
+// value); effend by original record index; scratch_hi / scratch_lo: two dead 8-byte-per-record arrays (>= m) to work in.
+// Returns 0 and fills *out (arrays from ctx's workspace), or a TBK status; TBK_DERR_BIGBUCKET / _COLLISION are left in
+// ctx->d_err for the caller's usual read-back to act on (the counts in *out are then meaningless).
+int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const uint64_t* chi, const uint64_t* clo, const uint32_t* cval,
+                      uint32_t m, const uint32_t* d_run_off, const int32_t* effend, uint64_t* scratch_hi, uint64_t* scratch_lo,
+                      bool want_rec_sg, uint64_t seed, WgOut* out, uint32_t* err_bits);
+bool tbk_window_supported(uint32_t k);

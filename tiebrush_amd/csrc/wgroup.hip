@@ -1,0 +1,903 @@
+// wgroup.hip — the "window path" of the collapse stage on gfx950: from the k position-sorted runs of passing records
+// straight to the collapsed groups, without ever sorting the records themselves.
+//
+// What it replaces (reference: /root/reference/src/tiebrush.cpp:477-499 addPData — find-or-insert of a read into the
+// sorted group list of its (tid,start) bucket — and tmerge.cpp:331-344, the k-way merge that feeds it): on the GPU the
+// sort path (collapse.hip + msort.hip) orders all m records by the 128-bit key and derives the groups from adjacent
+// records.  Deep data makes that wasteful: config 3 collapses 320 M records into 25 M groups, and a pile-up of 10^5 reads
+// on one base is sorted only to find its few dozen distinct alignments.
+//
+// Here the coordinate axis is cut into windows by splitters chosen from a sample of the runs (every s-th record; every
+// g-th sorted sample is a splitter; a splitter value that repeats — a pile-up — gets a window of its own).  Each run
+// contributes one contiguous piece to a window, found by a galloping search, so a window's records are k coalesced
+// reads.  One workgroup per window:
+//   * at most WG_CAP records (every window except pile-ups, by construction < 2T + k s): the records are staged in LDS,
+//     an index permutation is merge-sorted by (key, load order = file-major record order) with branch-free bisections,
+//     and groups, per-group counts, sample counts and the representative (arg-min of (effective end, record index)) come
+//     from wave-segmented reductions over the sorted order;
+//   * a pile-up (one (tid,start), any number of records): the records stream through once, file by file, into an LDS
+//     hash table keyed by (strand, span, key hash) — 64 bits, exact inside one bucket — with wave-aggregated counts, a
+//     per-group bitset of the samples seen and an atomic min for the representative; the few distinct groups are ranked
+//     at the end.
+// Every record is compared with the first record of its group under the exact strategy key (a hash collision raises
+// TBK_DERR_COLLISION and the host reseeds), so grouping is exact.  Windows write their groups and (group, sample)
+// incidences at their own record offset; a scan over the per-window counts and a compaction pass put them in key order.
+// What cannot be handled (more distinct groups in a pile-up than the table holds, k > 1024) raises TBK_DERR_BIGBUCKET
+// and the tile takes the sort path.
+//
+// All integer work; bound by HBM (every record is read once, 20 B + its CIGAR words for the verification) and by LDS
+// latency in the window sort.  No MFMA.
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "dev_common.cuh"
+#include "strategy.cuh"
+#include "tbk_internal.h"
+#include "wgroup.h"
+
+namespace {
+
+constexpr int WG_NT = 384;               // threads per window block
+constexpr int WG_E = 8;                  // records per thread in the LDS path
+constexpr int WG_CAP = WG_NT * WG_E;     // 3072 records sorted in LDS
+constexpr uint32_t WG_T = 1024;          // records between splitters: a window holds < 2 T + k s <= WG_CAP records
+constexpr uint32_t WG_KS = 1024;         // k * s budget
+constexpr int WG_NW = WG_NT / 64;
+constexpr int WG_R = 4;                  // records per thread and chunk in the pile-up path
+
+// ---- partition ------------------------------------------------------------------------------------------------
+__global__ void wg_sample_k(const uint64_t* __restrict__ chi, uint32_t m, uint32_t s, uint32_t ns, uint64_t* __restrict__ shi,
+                            uint64_t* __restrict__ slo, uint32_t* __restrict__ sval) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ns) return;
+  uint64_t d = (uint64_t)j * s;
+  shi[j] = chi[d < m ? d : m - 1] >> 2;
+  slo[j] = 0;
+  sval[j] = j;
+}
+
+// Y sorted samples; splitter i = Y[(i + 1) * g].  Two bounds per splitter: first of a run of equal splitters -> (v, v + 1 if
+// the run is longer than one else v); the others -> (v + 1, v + 1).  Equal consecutive bounds make empty windows.
+__global__ void wg_split_k(const uint64_t* __restrict__ Y, uint32_t g, uint32_t nsp, uint64_t* __restrict__ W) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nsp) return;
+  const uint64_t v = Y[(uint64_t)(i + 1) * g];
+  const bool has_prev = i > 0, has_next = i + 1 < nsp;
+  const uint64_t pv = has_prev ? Y[(uint64_t)i * g] : 0, nv = has_next ? Y[(uint64_t)(i + 2) * g] : 0;
+  const bool first = !has_prev || pv != v;
+  const bool heavy = (has_prev && pv == v) || (has_next && nv == v);
+  W[2 * i] = first ? v : v + 1;
+  W[2 * i + 1] = (first && !heavy) ? v : v + 1;
+}
+
+// off[r * k + f], r = 0 .. nrows - 1: r = 0 -> start of run f, r = nrows - 1 -> end of run f, else the first record of run
+// f with P >= W[r - 1].  A thread owns WG_OR consecutive rows of one run: one bisection, then galloping from the last answer
+// (consecutive splitters are ~T / k records apart inside a run).  Lanes run over f: a row is written coalesced.
+constexpr uint32_t WG_OR = 16;
+__global__ void wg_offsets_k(const uint64_t* __restrict__ chi, const uint32_t* __restrict__ run_off, uint32_t k, const uint64_t* __restrict__ W,
+                             uint32_t nrows, uint32_t* __restrict__ off) {
+  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t f = (uint32_t)(tid % k);
+  const uint64_t c = tid / k;
+  const uint64_t r0 = c * WG_OR;
+  if (r0 >= nrows) return;
+  const uint32_t a = run_off[f], b = run_off[f + 1];
+  uint32_t p = a;
+  bool have = false;
+  for (uint32_t u = 0; u < WG_OR; ++u) {
+    const uint64_t r = r0 + u;
+    if (r >= nrows) break;
+    uint32_t ans;
+    if (r == 0) {
+      ans = a;
+    } else if (r == nrows - 1) {
+      ans = b;
+    } else {
+      const uint64_t v = W[r - 1];
+      uint32_t lo, hi;  // answer in [lo, hi]
+      if (!have) {
+        lo = a;
+        hi = b;
+      } else {  // gallop from p (answers are non-decreasing in r)
+        lo = p;
+        uint32_t step = 1;
+        hi = p;
+        while (hi < b && (chi[hi] >> 2) < v) {
+          lo = hi + 1;
+          hi = (b - hi > step) ? hi + step : b;
+          step <<= 1;
+        }
+      }
+      while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if ((chi[mid] >> 2) < v)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      ans = lo;
+      p = ans;
+      have = true;
+    }
+    off[r * k + f] = ans;
+  }
+}
+
+// ---- window kernel -----------------------------------------------------------------------------------------------
+struct WgIn {
+  const uint64_t *chi, *clo;   // compacted passing records: k runs, each non-decreasing in chi >> 2
+  const uint32_t* cval;        // original record index
+  const int32_t* effend;       // [original index] effective end of the k-way merge
+  const uint32_t* off;         // [(nw + 1) * k]
+  const uint64_t* W;           // [nw - 1] bounds (window w = [W[w-1], W[w]))
+  uint32_t k, nw;
+};
+struct WgTemp {                // per window, at the window's record base
+  uint64_t *hi, *lo;           // group key
+  uint32_t *cnt, *ns, *poff;   // members, samples, first incidence (window-local)
+  unsigned long long* rep;     // min (effend << 32 | record)
+  uint16_t *pfile, *pgl;       // incidence: sample, window-local group
+  uint32_t *wg_cnt, *wp_cnt;   // per window: groups, incidences
+  uint32_t* wbase;             // per window: record base
+  uint32_t* rec_slot;          // optional [original index]: temp slot (record base + local group) of the record's group
+  unsigned long long* dbg;     // optional [32]: cycles / blocks / records per block kind (TBK_WG_DEBUG)
+};
+
+__device__ __forceinline__ bool key_less(const uint64_t* hi, const uint64_t* lo, uint32_t a, uint64_t bh, uint64_t bl, uint32_t b) {
+  const uint64_t ah = hi[a];
+  if (ah != bh) return ah < bh;
+  const uint64_t al = lo[a];
+  if (al != bl) return al < bl;
+  return a < b;
+}
+
+template <class T>
+__device__ __forceinline__ T wg_block_excl(T v, T* sm /*WG_NW*/, T* total) {
+  T inc = wave_incl_sum(v);
+  const uint32_t w = threadIdx.x >> 6;
+  if (lane_id() == 63) sm[w] = inc;
+  __syncthreads();
+  T base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < WG_NW; ++i) {
+    T x = sm[i];
+    if ((uint32_t)i < w) base += x;
+    tot += x;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+// file of item e: last f with pre[f] <= e  (pre has k + 1 entries, pre[k] = n_w; empty pieces repeat a value)
+__device__ __forceinline__ uint32_t piece_of(const uint32_t* pre, uint32_t k, uint32_t e) {
+  uint32_t lo = 0, hi = k;  // answer in [lo, hi)
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (pre[mid] <= e)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+constexpr uint32_t WG_LDS_MAIN = WG_CAP * (8 + 8 + 4 + 2 + 2);  // sort kernel: hi, lo, val, two index permutations = 72 KiB
+constexpr uint32_t WG_LDS_HASH = 34 * 1024;                    // hash kernel: the group table (four blocks per CU)
+
+// Stable merge sort of the index permutation `src` (n entries, ping-pong with `dst`; returns where the result lives) by
+// (hi[idx], lo[idx], idx).  In round `len` every element finds its rank in the sibling run by a bisection without branches:
+// each thread keeps up to WG_E bisections in flight, every probe is issued (clamped when it falls outside the sibling run),
+// so the dependent LDS reads (index, then its key words) of the chains overlap.
+template <int E>
+__device__ __forceinline__ uint16_t* wg_merge_sort(uint16_t* src, uint16_t* dst, uint32_t n, const uint64_t* hi, const uint64_t* lo,
+                                                   uint32_t lim /* indices are < lim */) {
+  const uint32_t t = threadIdx.x;
+  const int eu = (int)((n + WG_NT - 1) / WG_NT);  // item slots in use (uniform)
+  for (uint32_t len = 1; len < n; len <<= 1) {
+    uint32_t idx[E], oa[E], osz[E], cntv[E], dbase[E];
+    uint64_t kh[E], kl[E];
+#pragma unroll
+    for (int u = 0; u < E; ++u) {
+      const uint32_t e = t + (uint32_t)u * WG_NT;
+      cntv[u] = osz[u] = oa[u] = idx[u] = dbase[u] = 0;
+      kh[u] = kl[u] = 0;
+      if (u < eu && e < n) {
+        const uint32_t base = e & ~(2 * len - 1);
+        const uint32_t mid = base + len < n ? base + len : n;
+        const uint32_t end = base + 2 * len < n ? base + 2 * len : n;
+        idx[u] = src[e];
+        kh[u] = hi[idx[u]];
+        kl[u] = lo[idx[u]];
+        if (e < mid) {  // left run: + elements of the right run below me
+          oa[u] = mid;
+          osz[u] = end - mid;
+          dbase[u] = e;
+        } else {  // right run: + elements of the left run below me
+          oa[u] = base;
+          osz[u] = mid - base;
+          dbase[u] = base + (e - mid);
+        }
+      }
+    }
+    for (uint32_t st = len; st > 0; st >>= 1) {
+      uint32_t o[E];
+      uint64_t oh[E], ol[E];
+#pragma unroll
+      for (int u = 0; u < E; ++u) {
+        if (u < eu) {
+          const uint32_t c = cntv[u] + st;
+          const uint32_t pos = oa[u] + (c <= osz[u] ? c : 1u) - 1u;
+          o[u] = src[pos < n ? pos : 0u];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < E; ++u) {
+        if (u < eu) {
+          const uint32_t oo = o[u] < lim ? o[u] : 0u;
+          oh[u] = hi[oo];
+          ol[u] = lo[oo];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < E; ++u) {
+        if (u < eu) {
+          const uint32_t c = cntv[u] + st;
+          const bool less = (oh[u] < kh[u]) | ((oh[u] == kh[u]) & ((ol[u] < kl[u]) | ((ol[u] == kl[u]) & (o[u] < idx[u]))));
+          cntv[u] = (c <= osz[u] && less) ? c : cntv[u];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < E; ++u) {
+      const uint32_t e = t + (uint32_t)u * WG_NT;
+      if (u < eu && e < n) dst[dbase[u] + cntv[u]] = (uint16_t)idx[u];
+    }
+    __syncthreads();
+    uint16_t* tmp = src;
+    src = dst;
+    dst = tmp;
+  }
+  return src;
+}
+
+__device__ __forceinline__ unsigned long long wg_fingerprint(uint64_t hi, uint64_t lo, uint64_t seed) {
+  unsigned long long f = mix64(hi ^ seed) ^ mix64(lo + 0x9E3779B97F4A7C15ull + (seed << 1));
+  f = mix64(f);
+  return f == ~0ull ? 0ull : f;  // ~0 marks an empty slot
+}
+
+// pieces of window w: lengths, prefix (LDS pre[k + 1]), record count, the window's record base.  Returns false for a window that
+// is empty by construction (equal bounds).
+__device__ __forceinline__ bool wg_prologue(const WgIn& In, uint32_t w, uint32_t* pre, uint32_t* sm_u, uint32_t* n_w, uint32_t* wbase) {
+  const uint32_t t = threadIdx.x, k = In.k;
+  if (w > 0 && w + 1 < In.nw && In.W[w] == In.W[w - 1]) return false;  // (every splitter owns two bounds)
+  const uint32_t* row0 = In.off + (size_t)w * k;
+  const uint32_t* row1 = row0 + k;
+  uint32_t len[3], basep = 0;  // k <= 1024 < 3 * WG_NT; thread t owns files 3t .. 3t+2 (blocked: prefix order = file order)
+  uint32_t sum = 0;
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const uint32_t f = t * 3 + u;
+    len[u] = 0;
+    if (f < k) {
+      const uint32_t a = row0[f], b = row1[f];
+      len[u] = b > a ? b - a : 0u;
+      basep += a - In.off[f];  // row 0 = run starts
+    }
+    sum += len[u];
+  }
+  uint32_t tot;
+  uint32_t ex = wg_block_excl<uint32_t>(sum, sm_u, &tot);
+  *n_w = tot;
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const uint32_t f = t * 3 + u;
+    if (f < k) pre[f] = ex;
+    ex += len[u];
+  }
+  if (t == 0) pre[k] = tot;
+  uint32_t btot;
+  (void)wg_block_excl<uint32_t>(basep, sm_u, &btot);
+  *wbase = btot;
+  __syncthreads();
+  return true;
+}
+
+// One workgroup per window.  Hash path first (any number of records): the records stream through once into an LDS table
+// of groups — claim word = a 64-bit fingerprint of the key, the key itself stored beside it and compared by every record
+// that lands on the slot (a fingerprint collision raises TBK_DERR_COLLISION: the host reseeds) — with per-group count,
+// representative (atomic min of effective end << 32 | record), first record (exact verification of the strategy key)
+// and a bitset of the samples seen; the distinct groups are then merge-sorted by key and written out.  A window with
+// more distinct groups than the table holds falls back to sorting its records in LDS (at most WG_CAP of them: every
+// window except a pile-up on a single base); a pile-up that overflows sends the tile to the sort path.
+__global__ __launch_bounds__(WG_NT, 6) void wg_hash_k(WgIn In, WgTemp T, ColIn I, int strategy, uint32_t gcap, uint32_t nwords,
+                                                      uint64_t seed, uint32_t* __restrict__ ovf /* [0] count, [1..] windows */, uint32_t ovf_cap,
+                                                      uint32_t* __restrict__ err) {
+  __shared__ __align__(16) unsigned char lds[WG_LDS_HASH];
+  __shared__ uint32_t pre[1024 + 1];
+  __shared__ uint32_t sm_u[WG_NW];
+  __shared__ uint32_t s_misc[4];
+  const uint32_t t = threadIdx.x;
+  const uint32_t w = blockIdx.x;
+  const uint32_t k = In.k;
+  const unsigned long long t_start = T.dbg ? __builtin_readcyclecounter() : 0ull;
+  auto dbg_done = [&](int kind, uint32_t nrec) {
+    if (T.dbg && threadIdx.x == 0) {
+      atomicAdd(&T.dbg[kind * 4 + 0], __builtin_readcyclecounter() - t_start);
+      atomicAdd(&T.dbg[kind * 4 + 1], 1ull);
+      atomicAdd(&T.dbg[kind * 4 + 2], (unsigned long long)nrec);
+      atomicMax(&T.dbg[kind * 4 + 3], __builtin_readcyclecounter() - t_start);
+    }
+  };
+  uint32_t n_w, wbase;
+  if (!wg_prologue(In, w, pre, sm_u, &n_w, &wbase)) {
+    if (t == 0) {
+      T.wg_cnt[w] = T.wp_cnt[w] = 0;
+      T.wbase[w] = 0;
+    }
+    return;
+  }
+  const uint32_t* row0 = In.off + (size_t)w * k;
+  if (t == 0) T.wbase[w] = wbase;
+  if (n_w == 0) {
+    if (t == 0) T.wg_cnt[w] = T.wp_cnt[w] = 0;
+    dbg_done(0, 0);
+    return;
+  }
+
+  // =========================== hash path ===========================
+  // LDS: gcap slots of 44 + 4 nwords bytes (host: gcap = WG_LDS_MAIN / that)
+  unsigned long long* tc = reinterpret_cast<unsigned long long*>(lds);            // [gcap] claim word (fingerprint), ~0 = empty
+  uint64_t* thi = reinterpret_cast<uint64_t*>(tc + gcap);                           // [gcap] key
+  uint64_t* tlo = thi + gcap;                                                       // [gcap]
+  unsigned long long* trep = reinterpret_cast<unsigned long long*>(tlo + gcap);     // [gcap]
+  uint32_t* tcnt = reinterpret_cast<uint32_t*>(trep + gcap);                        // [gcap]
+  uint32_t* tfirst = tcnt + gcap;                                                   // [gcap] first record (verification)
+  uint32_t* tbits = tfirst + gcap;                                                  // [gcap * nwords] samples seen
+  uint16_t* pa = reinterpret_cast<uint16_t*>(tbits + (size_t)gcap * nwords);        // [gcap] slot permutations of the ranking
+  uint16_t* pb = pa + gcap;                                                         // [gcap]
+  for (uint32_t i = t; i < gcap; i += WG_NT) {
+    tc[i] = ~0ull;
+    trep[i] = ~0ull;
+    tcnt[i] = 0;
+  }
+  for (uint32_t i = t; i < gcap * nwords; i += WG_NT) tbits[i] = 0;
+  if (t == 0) {
+    s_misc[0] = 0;  // distinct groups
+    s_misc[1] = 0;  // overflow
+  }
+  __syncthreads();
+  // the window streams through in chunks of WG_NT * WG_R records (all pieces laid end to end): WG_R records per thread so that
+  // their loads, probes and gathers overlap; two barriers per chunk
+  for (uint32_t c0 = 0; c0 < n_w; c0 += WG_NT * WG_R) {
+    uint32_t slot[WG_R], rec[WG_R], fil[WG_R];
+    uint64_t kh[WG_R], kl[WG_R];
+    uint32_t won = 0, actm = 0;
+#pragma unroll
+    for (int u = 0; u < WG_R; ++u) {
+      const uint32_t e = c0 + (uint32_t)u * WG_NT + t;
+      slot[u] = 0xFFFFFFFFu;
+      rec[u] = fil[u] = 0;
+      kh[u] = kl[u] = 0;
+      if (e < n_w) {
+        actm |= 1u << u;
+        fil[u] = piece_of(pre, k, e);
+        const uint32_t src = row0[fil[u]] + (e - pre[fil[u]]);
+        kh[u] = In.chi[src];
+        kl[u] = In.clo[src];
+        rec[u] = In.cval[src];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < WG_R; ++u) {
+      if ((actm >> u) & 1u) {
+        const unsigned long long F = wg_fingerprint(kh[u], kl[u], seed);
+        uint32_t hs = (uint32_t)(((F >> 32) * gcap) >> 32);
+        for (uint32_t probe = 0; probe < gcap; ++probe) {
+          const unsigned long long cur = tc[hs];
+          if (cur == F) {
+            slot[u] = hs;
+            break;
+          }
+          if (cur == ~0ull) {
+            const unsigned long long old = atomicCAS(&tc[hs], ~0ull, F);
+            if (old == ~0ull) {
+              slot[u] = hs;
+              won |= 1u << u;
+              break;
+            }
+            if (old == F) {
+              slot[u] = hs;
+              break;
+            }
+          }
+          hs = hs + 1 == gcap ? 0u : hs + 1;
+        }
+        if ((won >> u) & 1u) {
+          thi[slot[u]] = kh[u];
+          tlo[slot[u]] = kl[u];
+          tfirst[slot[u]] = rec[u];
+          if (atomicAdd(&s_misc[0], 1u) + 1u > (gcap >> 2) * 3u) s_misc[1] = 1;
+        }
+        if (slot[u] == 0xFFFFFFFFu) s_misc[1] = 1;
+      }
+    }
+    __syncthreads();  // key and first record of every slot claimed in this chunk are visible
+    if (s_misc[1]) break;
+    unsigned long long rr[WG_R];
+#pragma unroll
+    for (int u = 0; u < WG_R; ++u)
+      rr[u] = ((actm >> u) & 1u) ? (((unsigned long long)(uint32_t)In.effend[rec[u]] << 32) | rec[u]) : ~0ull;
+#pragma unroll
+    for (int u = 0; u < WG_R; ++u) {
+      const bool act = (actm >> u) & 1u;
+      if (act) {
+        const uint32_t s = slot[u];
+        if (thi[s] != kh[u] || tlo[s] != kl[u]) {
+          atomicOr(err, TBK_DERR_COLLISION);  // two keys, one fingerprint
+        } else if (!((won >> u) & 1u) && !((kl[u] >> 31) & 1ull) && !strategy_equal(I, strategy, rec[u], tfirst[s])) {
+          atomicOr(err, TBK_DERR_COLLISION);  // (an exact key — bit 31 of the hash word, col_keys_k — needs no comparison)
+        }
+        if (rr[u] < trep[s]) atomicMin(&trep[s], rr[u]);
+        const uint32_t bi = s * nwords + (fil[u] >> 5), bm = 1u << (fil[u] & 31);
+        if (!(tbits[bi] & bm)) atomicOr(&tbits[bi], bm);
+      }
+      // counts: the leader's group by one ballot (a pile-up is mostly one group), the other lanes add for themselves
+      const uint64_t am = __ballot(act);
+      if (am) {
+        const int leader = __builtin_ctzll(am);
+        const uint32_t s0 = __shfl(slot[u], leader, 64);
+        const uint64_t same = __ballot(act && slot[u] == s0);
+        if ((int)lane_id() == leader) atomicAdd(&tcnt[s0], (uint32_t)__builtin_popcountll(same));
+        if (act && slot[u] != s0) atomicAdd(&tcnt[slot[u]], 1u);
+      }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  const bool overflow = s_misc[1] != 0;
+  const uint32_t d = s_misc[0];
+  if (!overflow) {
+    // ---- rank the occupied slots by key, emit groups and incidences in order ----
+    {
+      uint32_t carry = 0;
+      for (uint32_t i0 = 0; i0 < gcap; i0 += WG_NT) {
+        const uint32_t i = i0 + t;
+        const uint32_t occ = (i < gcap && tc[i] != ~0ull) ? 1u : 0u;
+        uint32_t tot;
+        const uint32_t ex = wg_block_excl<uint32_t>(occ, sm_u, &tot);
+        if (occ) pa[carry + ex] = (uint16_t)i;
+        carry += tot;
+      }
+    }
+    __syncthreads();
+    uint16_t* byrank = wg_merge_sort<2>(pa, pb, d, thi, tlo, gcap);  // d <= 3/4 gcap < 2 * WG_NT
+    uint16_t* other = byrank == pa ? pb : pa;
+    uint32_t* nsr = tfirst;  // (dead after the streaming) [d] samples per group in rank order -> offsets
+    __syncthreads();
+    for (uint32_t g = t; g < d; g += WG_NT) {
+      const uint32_t s = byrank[g];
+      uint32_t c = 0;
+      for (uint32_t x = 0; x < nwords; ++x) c += (uint32_t)__builtin_popcount(tbits[s * nwords + x]);
+      nsr[g] = c;
+      other[s] = (uint16_t)g;  // slot -> rank
+    }
+    __syncthreads();
+    {
+      uint32_t carry = 0;
+      for (uint32_t i0 = 0; i0 < d; i0 += WG_NT) {
+        const uint32_t i = i0 + t;
+        const uint32_t v = i < d ? nsr[i] : 0u;
+        uint32_t tot;
+        const uint32_t ex = wg_block_excl<uint32_t>(v, sm_u, &tot);
+        if (i < d) nsr[i] = carry + ex;
+        carry += tot;
+      }
+      if (t == 0) {
+        T.wg_cnt[w] = d;
+        T.wp_cnt[w] = carry;
+      }
+    }
+    __syncthreads();
+    for (uint32_t g = t; g < d; g += WG_NT) {
+      const uint32_t s = byrank[g];
+      T.hi[wbase + g] = thi[s];
+      T.lo[wbase + g] = tlo[s];
+      T.cnt[wbase + g] = tcnt[s];
+      T.rep[wbase + g] = trep[s];
+      uint32_t pl = nsr[g];
+      T.poff[wbase + g] = pl;
+      uint32_t c = 0;
+      for (uint32_t x = 0; x < nwords; ++x) {
+        uint32_t bits = tbits[s * nwords + x];
+        while (bits) {
+          const uint32_t bpos = (uint32_t)__builtin_ctz(bits);
+          bits &= bits - 1;
+          T.pfile[wbase + pl] = (uint16_t)(x * 32 + bpos);
+          T.pgl[wbase + pl] = (uint16_t)g;
+          ++pl;
+          ++c;
+        }
+      }
+      T.ns[wbase + g] = c;
+    }
+    if (T.rec_slot) {  // second pass over the window: record -> its group's rank
+      for (uint32_t e = t; e < n_w; e += WG_NT) {
+        const uint32_t f = piece_of(pre, k, e);
+        const uint32_t src = row0[f] + (e - pre[f]);
+        const unsigned long long F = wg_fingerprint(In.chi[src], In.clo[src], seed);
+        uint32_t hs = (uint32_t)(((F >> 32) * gcap) >> 32);
+        for (uint32_t probe = 0; probe < gcap && tc[hs] != F; ++probe) hs = hs + 1 == gcap ? 0u : hs + 1;  // (every record was inserted)
+        T.rec_slot[In.cval[src]] = wbase + other[hs];
+      }
+    }
+    dbg_done(2, n_w);
+    return;
+  }
+  // more distinct groups than the table holds: a window of at most WG_CAP records goes to the sort kernel's worklist, a
+  // pile-up sends the tile to the sort path
+  if (t == 0) {
+    T.wg_cnt[w] = T.wp_cnt[w] = 0;
+    if (n_w > (uint32_t)WG_CAP) {
+      atomicOr(err, TBK_DERR_BIGBUCKET);
+    } else {
+      const uint32_t i = atomicAdd(&ovf[0], 1u);
+      if (i < ovf_cap)
+        ovf[1 + i] = w;
+      else
+        atomicOr(err, TBK_DERR_BIGBUCKET);
+    }
+  }
+}
+
+// The windows the hash kernel could not hold (more distinct groups than table slots — shallow data): at most WG_CAP records
+// each, sorted in LDS.  A fixed grid walks the worklist.
+__global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgTemp T, ColIn I, int strategy, const uint32_t* __restrict__ ovf, uint32_t ovf_cap,
+                                                      uint32_t* __restrict__ err) {
+  __shared__ __align__(16) unsigned char lds[WG_LDS_MAIN];
+  __shared__ uint32_t pre[1024 + 1];
+  __shared__ uint32_t sm_u[WG_NW];
+  const uint32_t t = threadIdx.x;
+  const uint32_t k = In.k;
+  const uint32_t cnt = ovf[0] < ovf_cap ? ovf[0] : ovf_cap;
+  for (uint32_t wi = blockIdx.x; wi < cnt; wi += gridDim.x) {
+    const uint32_t w = ovf[1 + wi];
+    const unsigned long long t_start = T.dbg ? __builtin_readcyclecounter() : 0ull;
+    auto dbg_done = [&](int kind, uint32_t nrec) {
+      if (T.dbg && threadIdx.x == 0) {
+        atomicAdd(&T.dbg[kind * 4 + 0], __builtin_readcyclecounter() - t_start);
+        atomicAdd(&T.dbg[kind * 4 + 1], 1ull);
+        atomicAdd(&T.dbg[kind * 4 + 2], (unsigned long long)nrec);
+        atomicMax(&T.dbg[kind * 4 + 3], __builtin_readcyclecounter() - t_start);
+      }
+    };
+    __syncthreads();  // (LDS of the previous window is free)
+    uint32_t n_w, wbase;
+    (void)wg_prologue(In, w, pre, sm_u, &n_w, &wbase);
+    const uint32_t* row0 = In.off + (size_t)w * k;
+    // =========================== LDS sort path (shallow window: more groups than table slots) ===========================
+    uint64_t* hi = reinterpret_cast<uint64_t*>(lds);
+    uint64_t* lo = hi + WG_CAP;
+    uint32_t* val = reinterpret_cast<uint32_t*>(lo + WG_CAP);
+    uint16_t* qa = reinterpret_cast<uint16_t*>(val + WG_CAP);
+    uint16_t* qb = qa + WG_CAP;
+    for (uint32_t e = t; e < n_w; e += WG_NT) {
+      const uint32_t f = piece_of(pre, k, e);
+      const uint32_t src = row0[f] + (e - pre[f]);
+      hi[e] = In.chi[src];
+      lo[e] = In.clo[src];
+      val[e] = In.cval[src];
+      qa[e] = (uint16_t)e;
+    }
+    __syncthreads();
+    uint16_t* src = wg_merge_sort<WG_E>(qa, qb, n_w, hi, lo, WG_CAP);
+    const unsigned long long t_load = t_start, t_sort = T.dbg ? __builtin_readcyclecounter() : 0ull;
+    // ---- heads, group ids, incidences: thread t owns the WG_E consecutive sorted positions from t * WG_E ----
+    const uint32_t q0 = t * WG_E;
+    uint32_t ix[WG_E], fl[WG_E], recs[WG_E];
+    uint32_t hf = 0;  // bit u: group head, bit 8 + u: first record of its sample inside the group
+    {
+      uint32_t pxv = 0, pf = 0;
+      uint64_t ph = 0, pl = 0;
+      uint32_t prec = 0;
+      if (q0 > 0 && q0 <= n_w) {
+        pxv = src[q0 - 1];
+        ph = hi[pxv];
+        pl = lo[pxv];
+        pf = piece_of(pre, k, pxv);
+        prec = val[pxv];
+      }
+      uint32_t vb[WG_E];  // predecessor of every position that continues a group: the pair is verified below
+      uint32_t need = 0;
+#pragma unroll
+      for (int u = 0; u < WG_E; ++u) {
+        const uint32_t q = q0 + u;
+        ix[u] = 0;
+        fl[u] = 0;
+        recs[u] = 0;
+        vb[u] = 0;
+        if (q < n_w) {
+          ix[u] = src[q];
+          const uint64_t h = hi[ix[u]], l = lo[ix[u]];
+          fl[u] = piece_of(pre, k, ix[u]);
+          recs[u] = val[ix[u]];
+          const bool head = q == 0 || h != ph || l != pl;
+          const bool fh = head || fl[u] != pf;
+          hf |= (head ? 1u : 0u) << u;
+          hf |= (fh ? 1u : 0u) << (8 + u);
+          vb[u] = prec;
+          // (an exact key — bit 31 of the hash word, col_keys_k — needs no comparison: equal keys are equal alignments)
+          if (!head && !((l >> 31) & 1ull)) need |= 1u << u;
+          ph = h;
+          pl = l;
+          pf = fl[u];
+          prec = recs[u];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < WG_E; ++u)
+        if (((need >> u) & 1u) && !strategy_equal(I, strategy, recs[u], vb[u])) atomicOr(err, TBK_DERR_COLLISION);
+    }
+    const uint32_t nh = (uint32_t)__builtin_popcount(hf & 0xFFu), nf = (uint32_t)__builtin_popcount(hf >> 8);
+    uint32_t tot;
+    const uint32_t ex = wg_block_excl<uint32_t>(nh | (nf << 16), sm_u, &tot);
+    const uint32_t ng_w = tot & 0xFFFFu, np_w = tot >> 16;
+    uint32_t gl[WG_E];
+    {
+      uint32_t g = (ex & 0xFFFFu), pl = ex >> 16;  // groups / incidences before this thread's first position
+#pragma unroll
+      for (int u = 0; u < WG_E; ++u) {
+        const uint32_t q = q0 + u;
+        gl[u] = 0;
+        if (q < n_w) {
+          const bool head = (hf >> u) & 1u, fh = (hf >> (8 + u)) & 1u;
+          g += head ? 1u : 0u;
+          gl[u] = g - 1u;
+          if (head) {
+            T.hi[wbase + gl[u]] = hi[ix[u]];
+            T.lo[wbase + gl[u]] = lo[ix[u]];
+            T.poff[wbase + gl[u]] = pl;
+          }
+          if (fh) {
+            T.pfile[wbase + pl] = (uint16_t)fl[u];
+            T.pgl[wbase + pl] = (uint16_t)gl[u];
+            ++pl;
+          }
+          if (T.rec_slot) T.rec_slot[recs[u]] = wbase + gl[u];
+        }
+      }
+    }
+    const unsigned long long t_heads = T.dbg ? __builtin_readcyclecounter() : 0ull;
+    __syncthreads();  // hi / lo are dead from here: their space holds the per-group accumulators
+    uint32_t* gcnt = reinterpret_cast<uint32_t*>(lds);
+    uint32_t* gns = gcnt + WG_CAP;
+    unsigned long long* grep = reinterpret_cast<unsigned long long*>(gns + WG_CAP);
+    for (uint32_t g = t; g < ng_w; g += WG_NT) {
+      gcnt[g] = 0;
+      gns[g] = 0;
+      grep[g] = ~0ull;
+    }
+    unsigned long long rr[WG_E];
+#pragma unroll
+    for (int u = 0; u < WG_E; ++u)  // eight independent gathers in flight
+      rr[u] = q0 + u < n_w ? (((unsigned long long)(uint32_t)In.effend[recs[u]] << 32) | recs[u]) : ~0ull;
+    __syncthreads();
+    {  // runs of one group inside the thread's positions are folded in registers; one set of LDS atomics per run
+      uint32_t cg = 0xFFFFFFFFu, c = 0, nsv = 0;
+      unsigned long long r = ~0ull;
+#pragma unroll
+      for (int u = 0; u < WG_E; ++u) {
+        if (q0 + u < n_w) {
+          if (gl[u] != cg) {
+            if (cg != 0xFFFFFFFFu) {
+              atomicAdd(&gcnt[cg], c);
+              if (nsv) atomicAdd(&gns[cg], nsv);
+              atomicMin(&grep[cg], r);
+            }
+            cg = gl[u];
+            c = 0;
+            nsv = 0;
+            r = ~0ull;
+          }
+          ++c;
+          nsv += (hf >> (8 + u)) & 1u;
+          r = rr[u] < r ? rr[u] : r;
+        }
+      }
+      if (cg != 0xFFFFFFFFu) {
+        atomicAdd(&gcnt[cg], c);
+        if (nsv) atomicAdd(&gns[cg], nsv);
+        atomicMin(&grep[cg], r);
+      }
+    }
+    __syncthreads();
+    for (uint32_t g = t; g < ng_w; g += WG_NT) {
+      T.cnt[wbase + g] = gcnt[g];
+      T.ns[wbase + g] = gns[g];
+      T.rep[wbase + g] = grep[g];
+    }
+    if (t == 0) {
+      T.wg_cnt[w] = ng_w;
+      T.wp_cnt[w] = np_w;
+    }
+    dbg_done(1, n_w);
+    if (T.dbg && t == 0) {
+      atomicAdd(&T.dbg[12], t_load - t_start);
+      atomicAdd(&T.dbg[13], t_sort - t_load);
+      atomicAdd(&T.dbg[14], t_heads - t_sort);
+      atomicAdd(&T.dbg[15], __builtin_readcyclecounter() - t_heads);
+    }
+  }
+}
+
+
+// ---- compaction: windows -> key order --------------------------------------------------------------------------------
+struct WgFinal {
+  uint64_t *ghi, *glo;
+  uint32_t *gmem, *gpoff, *pgrp, *first, *ns, *slot2sg;
+  uint16_t* pfile;
+  double* yc;
+  long long *yxin, *ydin;
+  unsigned long long* rep;
+};
+__global__ __launch_bounds__(64) void wg_compact_k(uint32_t nw, WgTemp T, const uint32_t* __restrict__ gbase, const uint32_t* __restrict__ pbase,
+                                                   WgFinal F) {
+  const uint32_t w = blockIdx.x;
+  if (w >= nw) return;
+  const uint32_t ng = T.wg_cnt[w], np = T.wp_cnt[w];
+  if (!ng) return;
+  const uint32_t wb = T.wbase[w], gb = gbase[w], pb = pbase[w];
+  for (uint32_t g = threadIdx.x; g < ng; g += 64) {
+    const uint32_t sg = gb + g;
+    F.ghi[sg] = T.hi[wb + g];
+    F.glo[sg] = T.lo[wb + g];
+    const unsigned long long r = T.rep[wb + g];
+    F.rep[sg] = r;
+    F.gmem[sg] = (uint32_t)(r & 0xFFFFFFFFull);
+    F.yc[sg] = (double)T.cnt[wb + g];
+    F.ns[sg] = T.ns[wb + g];
+    F.yxin[sg] = 0;
+    F.ydin[sg] = 0;
+    F.first[sg] = sg;
+    F.gpoff[sg] = pb + T.poff[wb + g];
+    if (F.slot2sg) F.slot2sg[wb + g] = sg;
+  }
+  for (uint32_t p = threadIdx.x; p < np; p += 64) {
+    F.pfile[pb + p] = T.pfile[wb + p];
+    F.pgrp[pb + p] = gb + T.pgl[wb + p];
+  }
+}
+__global__ void wg_tie_k(uint32_t ng, const uint64_t* __restrict__ ghi, const uint64_t* __restrict__ glo, uint8_t* __restrict__ tie) {
+  uint32_t sg = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sg >= ng) return;
+  tie[sg] = (sg == 0 || ghi[sg] != ghi[sg - 1] || (glo[sg] >> 32) != (glo[sg - 1] >> 32)) ? 1 : 0;
+}
+__global__ void wg_recsg_k(uint32_t n, const uint32_t* __restrict__ rec_slot, const uint32_t* __restrict__ slot2sg, uint32_t* __restrict__ rec_sg) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t s = rec_slot[i];
+  rec_sg[i] = s == 0xFFFFFFFFu ? 0xFFFFFFFFu : slot2sg[s];
+}
+
+}  // namespace
+
+bool tbk_window_supported(uint32_t k) { return k >= 1 && k <= 1024; }
+
+int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const uint64_t* chi, const uint64_t* clo, const uint32_t* cval,
+                      uint32_t m, const uint32_t* d_run_off, const int32_t* effend, uint64_t* scratch_hi, uint64_t* scratch_lo,
+                      bool want_rec_sg, uint64_t seed, WgOut* out, uint32_t* err_bits) {
+  const uint32_t k = I.k;
+  const uint32_t B = 256;
+  *err_bits = 0;
+  if (!tbk_window_supported(k) || m == 0) return TBK_EINVAL;
+  // sample stride s (power of two, k s <= WG_KS) and samples per splitter g = T / s
+  uint32_t s = 1;
+  while (s * 2 * k <= WG_KS && s * 2 <= WG_T) s *= 2;
+  const uint32_t g = WG_T / s;
+  const uint32_t ns = cdiv(m, s);
+  const uint32_t nsp = ns > 1 ? (ns - 1) / g : 0;  // splitters Y[g], Y[2g], ... < ns
+  const uint32_t nW = 2 * nsp;                       // bounds
+  const uint32_t nw = nW + 1;                        // windows
+  const uint32_t nrows = nw + 1;
+  uint64_t* W = ws_alloc<uint64_t>(ctx, nW + 1);
+  uint32_t* off = ws_alloc<uint32_t>(ctx, (size_t)nrows * k);
+  if (!W || !off) return TBK_ENOMEM;
+  if (nsp) {
+    SortBufs sb;
+    sb.hi = ws_alloc<uint64_t>(ctx, ns);
+    sb.lo = ws_alloc<uint64_t>(ctx, ns);
+    sb.val = ws_alloc<uint32_t>(ctx, ns);
+    sb.hi2 = ws_alloc<uint64_t>(ctx, ns);
+    sb.lo2 = ws_alloc<uint64_t>(ctx, ns);
+    sb.val2 = ws_alloc<uint32_t>(ctx, ns);
+    if (!sb.val2) return TBK_ENOMEM;
+    TBK_LAUNCH(ctx, "wg_sample", wg_sample_k, cdiv(ns, B), B, 0, chi, m, s, ns, sb.hi, sb.lo, sb.val);
+    TBK_TRY(tbk_radix_sort128(ctx, &sb, ns, ~0ull, 0ull));
+    TBK_LAUNCH(ctx, "wg_split", wg_split_k, cdiv(nsp, B), B, 0, sb.hi, g, nsp, W);
+  }
+  {
+    const uint64_t nthreads = (uint64_t)cdiv(nrows, WG_OR) * k;
+    TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_k, cdiv(nthreads, B), B, 0, chi, d_run_off, k, W, nrows, off);
+  }
+  WgTemp T;
+  T.hi = scratch_hi;
+  T.lo = scratch_lo;
+  T.cnt = ws_alloc<uint32_t>(ctx, m);
+  T.ns = ws_alloc<uint32_t>(ctx, m);
+  T.poff = ws_alloc<uint32_t>(ctx, m);
+  T.rep = ws_alloc<unsigned long long>(ctx, m);
+  T.pfile = ws_alloc<uint16_t>(ctx, m);
+  T.pgl = ws_alloc<uint16_t>(ctx, m);
+  T.wg_cnt = ws_alloc<uint32_t>(ctx, nw);
+  T.wp_cnt = ws_alloc<uint32_t>(ctx, nw);
+  T.wbase = ws_alloc<uint32_t>(ctx, nw);
+  uint32_t* gbase = ws_alloc<uint32_t>(ctx, nw);
+  uint32_t* pbase = ws_alloc<uint32_t>(ctx, nw);
+  T.rec_slot = nullptr;
+  T.dbg = nullptr;
+  if (getenv("TBK_WG_DEBUG")) {
+    T.dbg = ws_alloc<unsigned long long>(ctx, 16);
+    if (T.dbg) TBK_HIP(hipMemsetAsync(T.dbg, 0, 16 * 8, ctx->stream));
+  }
+  if (want_rec_sg) {
+    T.rec_slot = ws_alloc<uint32_t>(ctx, I.n);
+    if (!T.rec_slot) return TBK_ENOMEM;
+    TBK_HIP(hipMemsetAsync(T.rec_slot, 0xFF, (size_t)I.n * 4, ctx->stream));
+  }
+  if (!T.pgl || !pbase) return TBK_ENOMEM;
+  WgIn In{chi, clo, cval, effend, off, W, k, nw};
+  const uint32_t nwords = cdiv(k, 32);
+  const uint32_t gcap = WG_LDS_HASH / (44u + 4u * nwords);
+  const uint32_t ovf_cap = nw;
+  uint32_t* ovf = ws_alloc<uint32_t>(ctx, (size_t)ovf_cap + 1);
+  if (!ovf) return TBK_ENOMEM;
+  TBK_HIP(hipMemsetAsync(ovf, 0, sizeof(uint32_t), ctx->stream));
+  TBK_LAUNCH(ctx, "wg_hash", wg_hash_k, nw, WG_NT, 0, In, T, I, strategy, gcap, nwords, seed, ovf, ovf_cap, ctx->d_err);
+  TBK_LAUNCH(ctx, "wg_sort", wg_sort_k, std::min<uint32_t>(nw, 1024u), WG_NT, 0, In, T, I, strategy, ovf, ovf_cap, ctx->d_err);
+  uint64_t* sc = ctx->d_scalars;
+  TBK_TRY(tbk_exscan_u32(ctx, T.wg_cnt, gbase, nw, sc + 1));
+  TBK_TRY(tbk_exscan_u32(ctx, T.wp_cnt, pbase, nw, sc + 2));
+  uint32_t eb = 0;
+  TBK_TRY(tbk_sync_err(ctx, &eb));
+  *err_bits = eb;
+  if (T.dbg) {
+    unsigned long long h[16];
+    TBK_HIP(hipMemcpy(h, T.dbg, sizeof(h), hipMemcpyDeviceToHost));
+    const char* nm[3] = {"empty", "sort", "hash"};
+    fprintf(stderr, "wg_window lds phases (Mcyc): load %.1f  sort %.1f  heads+verify %.1f  reduce+write %.1f\n", h[12] / 1e6, h[13] / 1e6,
+            h[14] / 1e6, h[15] / 1e6);
+    for (int i = 0; i < 3; ++i)
+      fprintf(stderr, "wg_window %-6s blocks %8llu records %10llu  cycles/block avg %9.0f max %9llu  (total %.1f Mcyc)\n", nm[i], h[i * 4 + 1],
+              h[i * 4 + 2], h[i * 4 + 1] ? (double)h[i * 4] / (double)h[i * 4 + 1] : 0.0, h[i * 4 + 3], (double)h[i * 4] / 1e6);
+  }
+  if (eb) return 0;  // the caller decides (reseed / sort path / error)
+  const uint32_t ng = (uint32_t)ctx->h_scalars[1], np = (uint32_t)ctx->h_scalars[2];
+  out->ng = ng;
+  out->np = np;
+  out->ghi = ws_alloc<uint64_t>(ctx, ng);
+  out->glo = ws_alloc<uint64_t>(ctx, ng);
+  out->gmem = ws_alloc<uint32_t>(ctx, ng);
+  out->gpoff = ws_alloc<uint32_t>(ctx, ng);
+  out->pfile = ws_alloc<uint16_t>(ctx, np);
+  out->pgrp = ws_alloc<uint32_t>(ctx, np);
+  out->yc = ws_alloc<double>(ctx, ng);
+  out->ns = ws_alloc<uint32_t>(ctx, ng);
+  out->yxin = ws_alloc<long long>(ctx, ng);
+  out->ydin = ws_alloc<long long>(ctx, ng);
+  out->rep = ws_alloc<unsigned long long>(ctx, ng);
+  out->first = ws_alloc<uint32_t>(ctx, ng);
+  out->tie = ws_alloc<uint8_t>(ctx, ng);
+  uint32_t* slot2sg = want_rec_sg ? ws_alloc<uint32_t>(ctx, m) : nullptr;
+  out->rec_sg = want_rec_sg ? ws_alloc<uint32_t>(ctx, I.n) : nullptr;
+  if (!out->tie || (want_rec_sg && !out->rec_sg)) return TBK_ENOMEM;
+  if (ng) {
+    WgFinal F{out->ghi, out->glo, out->gmem, out->gpoff, out->pgrp, out->first, out->ns, slot2sg, out->pfile, out->yc, out->yxin,
+              out->ydin, out->rep};
+    TBK_LAUNCH(ctx, "wg_compact", wg_compact_k, nw, 64, 0, nw, T, gbase, pbase, F);
+    TBK_LAUNCH(ctx, "wg_tie", wg_tie_k, cdiv(ng, B), B, 0, ng, out->ghi, out->glo, out->tie);
+    if (want_rec_sg) TBK_LAUNCH(ctx, "wg_recsg", wg_recsg_k, cdiv(I.n, B), B, 0, I.n, T.rec_slot, slot2sg, out->rec_sg);
+  }
+  return tbk_check_launch(ctx, "window_groups");
+}
