@@ -97,8 +97,12 @@ def _gloo_worker(rank, world, port, q):
     td.destroy_process_group()
 
 
-def test_gloo_world2_equals_flat():
+@pytest.mark.parametrize("a2a_bytes", [None, 4096])
+def test_gloo_world2_equals_flat(a2a_bytes, monkeypatch):
+    """a2a_bytes = 4096: every block of the exchange goes out in many bounded rounds (the path large tiles take)"""
     import torch.multiprocessing as mp
+    if a2a_bytes:
+        monkeypatch.setenv("TBK_A2A_MAX_BYTES", str(a2a_bytes))
     from oracle import oracle_ffi as orc
     from tiebrush_amd import synth
     ctx = mp.get_context("spawn")

@@ -17,7 +17,7 @@ def test_bench_two_ranks_contract():
     port = 29800 + (os.getpid() % 1000)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--reads-per-file", "30000", "--no-cpu-baseline"]
+           "--files-per-gpu", "2", "--reads-per-file", "30000", "--no-cpu-baseline"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.strip().split("\n") if l.startswith("{")]

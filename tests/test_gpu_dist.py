@@ -82,12 +82,14 @@ class DeviceCompute:
     (8, 16, "c5", "exon", dict(max_nh=5, min_qual=1)),
     (2, 2, "c2", "cigar", dict(keep_secondary=True)),
     (1, 3, "c2", "cigar", {}),
+    (8, 256, "c2", "cigar", {}),      # BASELINE.json configs[3]'s shape: 256 files, 32 per rank, 8 ranks (every rank's tile has 256 runs)
+    (8, 1024, "c5", "exon", dict(max_nh=5, min_qual=1)),   # configs[4]'s shape: 1024 files over 8 ranks
 ])
 def test_loopback_device_resident_equals_flat_oracle(world, nfiles, profile, strategy, kw):
     import torch
     from oracle import oracle_ffi as orc
     from tiebrush_amd import api, dist, synth
-    tile = synth.make_tile(nfiles, 20000, profile, n_loci=800)
+    tile = synth.make_tile(nfiles, 20000 if nfiles <= 16 else (4000 if nfiles <= 256 else 1000), profile, n_loci=800)
     flat = orc.collapse(tile, strategy=STRAT[strategy], **kw)
     flat_cov = orc.coverage(synth.collapsed_to_cov_input(tile, flat))
     tiles, first = split_tile(tile, world)

@@ -1213,7 +1213,7 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
     // waited for.
     const size_t fo_bytes = (size_t)(in->n_files + 1) * 4, tb_bytes = in->n_files;
     if (fo_bytes + tb_bytes <= 4096 * sizeof(uint64_t)) {
-      char* stage = (char*)(ctx->h_scalars + 64);
+      char* stage = (char*)tbk_stage_acquire(ctx);
       memcpy(stage, in->file_off, fo_bytes);
       TBK_HIP(hipMemcpyAsync(d_fo, stage, fo_bytes, hipMemcpyHostToDevice, ctx->stream));
       if (in->tbmerged) {
@@ -1222,6 +1222,7 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
       } else {
         TBK_HIP(hipMemsetAsync(d_tb, 0, tb_bytes, ctx->stream));
       }
+      tbk_stage_release(ctx);
     } else {
       TBK_HIP(hipMemcpyAsync(d_fo, in->file_off, fo_bytes, hipMemcpyHostToDevice, ctx->stream));
       if (in->tbmerged) {
@@ -1294,13 +1295,14 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
 
   // The window path (wgroup.hip) goes from the runs to the groups without sorting the records; it covers plain BAM inputs
   // with integral YC (the ordered / carried-tag cases keep the sort path, which has the per-record order they need).
-  bool use_win = tbk_window_supported(in->n_files) && !O.store_frac && !O.collapse_same && !I.prio_hi && n >= 4096;
+  // Small tiles of a few files are launch-bound either way and the lean run-sort path needs no read-back: it keeps them.
+  bool use_win = tbk_window_supported(in->n_files) && !O.store_frac && !O.collapse_same && (n >= (8u << 20) || (in->n_files > 64 && n >= 65536));
   if (in->tbmerged)
     for (uint32_t f = 0; f < in->n_files; ++f) use_win = use_win && in->tbmerged[f] == 0;
   if (const char* e = getenv("TBK_PATH")) {  // test hook: "sort" keeps the sort path, "window" takes the window path whatever the size
     if (strcmp(e, "sort") == 0) use_win = false;
     if (strcmp(e, "window") == 0)
-      use_win = tbk_window_supported(in->n_files) && !O.store_frac && !O.collapse_same && !I.prio_hi && [&] {
+      use_win = tbk_window_supported(in->n_files) && !O.store_frac && !O.collapse_same && [&] {
         bool ok = true;
         if (in->tbmerged)
           for (uint32_t f = 0; f < in->n_files; ++f) ok = ok && in->tbmerged[f] == 0;

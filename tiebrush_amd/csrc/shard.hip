@@ -297,8 +297,10 @@ static int shard_upload_file_off(tbk_ctx* ctx, const uint32_t* host_fo, uint32_t
   if (!*d_fo) return TBK_ENOMEM;
   const size_t bytes = (size_t)(k + 1) * 4;
   if (bytes <= 4096 * sizeof(uint64_t)) {  // staged through the pinned block: asynchronous, the caller's array may be transient
-    memcpy(ctx->h_scalars + 64, host_fo, bytes);
-    TBK_HIP(hipMemcpyAsync(*d_fo, ctx->h_scalars + 64, bytes, hipMemcpyHostToDevice, ctx->stream));
+    void* stage = tbk_stage_acquire(ctx);
+    memcpy(stage, host_fo, bytes);
+    TBK_HIP(hipMemcpyAsync(*d_fo, stage, bytes, hipMemcpyHostToDevice, ctx->stream));
+    tbk_stage_release(ctx);
   } else {
     TBK_HIP(hipMemcpyAsync(*d_fo, host_fo, bytes, hipMemcpyHostToDevice, ctx->stream));
     TBK_HIP(hipStreamSynchronize(ctx->stream));
@@ -348,6 +350,7 @@ extern "C" int tbk_shard_probe_max(tbk_ctx* ctx, const uint32_t* file_off, uint3
   TBK_TRY(shard_upload_file_off(ctx, file_off, n_files, &d_fo));
   TBK_LAUNCH(ctx, "shard_probe_max", shard_probe_max_k, cdiv((size_t)n_cuts * n_files, SH_B), SH_B, 0, n_cuts, n_files, d_fo, key, emax, cuts,
              (long long*)m_out);
+  TBK_HIP(hipStreamSynchronize(ctx->stream));  // the caller reads the result on its own stream / hands it to a collective
   return tbk_check_launch(ctx, "shard_probe_max");
 }
 // nxt_out[c] (caller-initialised to +inf) := min(nxt_out[c], first record start beyond m[c])
@@ -361,6 +364,7 @@ extern "C" int tbk_shard_probe_next(tbk_ctx* ctx, const uint32_t* file_off, uint
   TBK_TRY(shard_upload_file_off(ctx, file_off, n_files, &d_fo));
   TBK_LAUNCH(ctx, "shard_probe_next", shard_probe_next_k, cdiv((size_t)n_cuts * n_files, SH_B), SH_B, 0, n_cuts, n_files, d_fo, key, m,
              (long long*)nxt_out);
+  TBK_HIP(hipStreamSynchronize(ctx->stream));  // the caller reads the result on its own stream / hands it to a collective
   return tbk_check_launch(ctx, "shard_probe_next");
 }
 

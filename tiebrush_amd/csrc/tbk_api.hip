@@ -81,6 +81,19 @@ hipEvent_t tbk_event(tbk_ctx* ctx) {
   return ctx->ev_pool[ctx->ev_used++];
 }
 
+void* tbk_stage_acquire(tbk_ctx* ctx) {
+  if (ctx->stage_ev) (void)hipEventSynchronize(ctx->stage_ev);
+  return ctx->h_scalars + 64;
+}
+void tbk_stage_release(tbk_ctx* ctx) {
+  if (!ctx->stage_ev && hipEventCreateWithFlags(&ctx->stage_ev, hipEventDisableTiming) != hipSuccess) {
+    ctx->stage_ev = nullptr;
+    (void)hipStreamSynchronize(ctx->stream);  // no event: the upload has run before the block is touched again
+    return;
+  }
+  (void)hipEventRecord(ctx->stage_ev, ctx->stream);
+}
+
 int tbk_check_launch(tbk_ctx* ctx, const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -300,6 +313,7 @@ void tbk_destroy(tbk_ctx* ctx) {
   if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
   if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
   if (ctx->aux_done) (void)hipEventDestroy(ctx->aux_done);
+  if (ctx->stage_ev) (void)hipEventDestroy(ctx->stage_ev);
   if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;

@@ -96,6 +96,7 @@ struct tbk_ctx {
   uint32_t* d_err = nullptr;    // error bits: the low word of d_scalars[15] (cleared and read back with the counters)
   uint64_t* d_scalars = nullptr; // [64] misc device scalars (counts)
   uint64_t* h_scalars = nullptr; // pinned [64+4096]
+  hipEvent_t stage_ev = nullptr; // recorded behind the last asynchronous upload out of the pinned staging block (h_scalars + 64)
   // view storage for tbk_groups_to_cov_in
   char* d_view = nullptr;
   size_t d_view_cap = 0;
@@ -172,6 +173,10 @@ static inline void tbk_prof_end(tbk_ctx* ctx) {
   } while (0)
 
 int tbk_check_launch(tbk_ctx* ctx, const char* what);  // hipGetLastError -> TBK_EHIP
+// small host tables go to the device through the context's pinned staging block: tbk_stage_acquire waits until the previous
+// upload out of it has run (a no-op almost always) and returns the block, tbk_stage_release marks the upload just queued
+void* tbk_stage_acquire(tbk_ctx* ctx);
+void tbk_stage_release(tbk_ctx* ctx);
 int tbk_sync_err(tbk_ctx* ctx, uint32_t* err_bits);    // d_scalars[0..15] -> h_scalars, stream sync, error bits
 int tbk_derr_to_status(tbk_ctx* ctx, uint32_t bits);
 

@@ -129,6 +129,7 @@ struct WgIn {
   const uint64_t *chi, *clo;   // compacted passing records: k runs, each non-decreasing in chi >> 2
   const uint32_t* cval;        // original record index
   const int32_t* effend;       // [original index] effective end of the k-way merge
+  const uint64_t* prio;        // optional [original index]: explicit merge-order priority (cross-rank tiles) used instead of effend
   const uint32_t* off;         // [(nw + 1) * k]
   const uint64_t* W;           // [nw - 1] bounds (window w = [W[w-1], W[w]))
   uint32_t k, nw;
@@ -143,6 +144,10 @@ struct WgTemp {                // per window, at the window's record base
   uint32_t* rec_slot;          // optional [original index]: temp slot (record base + local group) of the record's group
   unsigned long long* dbg;     // optional [32]: cycles / blocks / records per block kind (TBK_WG_DEBUG)
 };
+
+__device__ __forceinline__ uint32_t wg_effend(const WgIn& In, uint32_t rec) {
+  return In.prio ? (uint32_t)In.prio[rec] : (uint32_t)In.effend[rec];
+}
 
 __device__ __forceinline__ bool key_less(const uint64_t* hi, const uint64_t* lo, uint32_t a, uint64_t bh, uint64_t bl, uint32_t b) {
   const uint64_t ah = hi[a];
@@ -429,7 +434,7 @@ __global__ __launch_bounds__(WG_NT, 6) void wg_hash_k(WgIn In, WgTemp T, ColIn I
     unsigned long long rr[WG_R];
 #pragma unroll
     for (int u = 0; u < WG_R; ++u)
-      rr[u] = ((actm >> u) & 1u) ? (((unsigned long long)(uint32_t)In.effend[rec[u]] << 32) | rec[u]) : ~0ull;
+      rr[u] = ((actm >> u) & 1u) ? (((unsigned long long)wg_effend(In, rec[u]) << 32) | rec[u]) : ~0ull;
 #pragma unroll
     for (int u = 0; u < WG_R; ++u) {
       const bool act = (actm >> u) & 1u;
@@ -682,7 +687,7 @@ __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgTemp T, ColIn I
     unsigned long long rr[WG_E];
 #pragma unroll
     for (int u = 0; u < WG_E; ++u)  // eight independent gathers in flight
-      rr[u] = q0 + u < n_w ? (((unsigned long long)(uint32_t)In.effend[recs[u]] << 32) | recs[u]) : ~0ull;
+      rr[u] = q0 + u < n_w ? (((unsigned long long)wg_effend(In, recs[u]) << 32) | recs[u]) : ~0ull;
     __syncthreads();
     {  // runs of one group inside the thread's positions are folded in registers; one set of LDS atomics per run
       uint32_t cg = 0xFFFFFFFFu, c = 0, nsv = 0;
@@ -847,7 +852,7 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
     TBK_HIP(hipMemsetAsync(T.rec_slot, 0xFF, (size_t)I.n * 4, ctx->stream));
   }
   if (!T.pgl || !pbase) return TBK_ENOMEM;
-  WgIn In{chi, clo, cval, effend, off, W, k, nw};
+  WgIn In{chi, clo, cval, effend, I.prio_hi, off, W, k, nw};
   const uint32_t nwords = cdiv(k, 32);
   const uint32_t gcap = WG_LDS_HASH / (44u + 4u * nwords);
   const uint32_t ovf_cap = nw;

@@ -30,6 +30,8 @@ tensors (tiles resident in HBM: only counts and cut keys ever visit the host).
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import Any, Optional
 
@@ -533,6 +535,41 @@ def run_distributed(compute, tile, first_fidx, device=None, group=None, **kw):
         r = x.cpu().numpy()
         return r.view(like.dtype) if np.asarray(like).dtype in _signed else r
 
+    A2A_MAX_BYTES = int(os.environ.get("TBK_A2A_MAX_BYTES", 256 << 20))   # per-peer piece of one all_to_all_single call
+
+    def a2a_rows(x, send_cnt, recv_cnt):
+        """all_to_all of the row blocks of x (dim 0 split by send_cnt), recv_cnt rows from each source.  One rank: a
+        copy.  Blocks beyond A2A_MAX_BYTES go out in several rounds: the RCCL of this image drops the tail of a
+        1.5 GB self-exchange (tools/scratch/a2a_test.py: 64 M rows x 24 B arrive as 32 M rows + zeros), and rounds of a
+        bounded size also bound the staging memory."""
+        out = torch.empty((int(sum(recv_cnt)),) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        if world == 1:
+            out.copy_(x[:out.shape[0]])
+            return out
+        row_bytes = max(1, x.element_size() * int(np.prod(x.shape[1:], dtype=np.int64)))
+        chunk = max(1, A2A_MAX_BYTES // row_bytes)
+        big = max(int(max(send_cnt)), int(max(recv_cnt)))
+        rounds = torch.tensor([(big + chunk - 1) // chunk], dtype=torch.int64, device=x.device if not stage else "cpu")
+        dist.all_reduce(rounds, op=dist.ReduceOp.MAX, group=group)
+        rounds = max(1, int(rounds))
+        if rounds == 1:
+            dist.all_to_all_single(out, x, output_split_sizes=[int(c) for c in recv_cnt], input_split_sizes=[int(c) for c in send_cnt],
+                                   group=group)
+            return out
+        so = np.concatenate([[0], np.cumsum(send_cnt)]).astype(np.int64)
+        ro = np.concatenate([[0], np.cumsum(recv_cnt)]).astype(np.int64)
+        for r in range(rounds):
+            ss = [max(0, min(chunk, int(send_cnt[d]) - r * chunk)) for d in range(world)]
+            rs = [max(0, min(chunk, int(recv_cnt[s_]) - r * chunk)) for s_ in range(world)]
+            xin = torch.cat([x[int(so[d]) + r * chunk: int(so[d]) + r * chunk + ss[d]] for d in range(world)])
+            tmp = torch.empty((sum(rs),) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+            dist.all_to_all_single(tmp, xin, output_split_sizes=rs, input_split_sizes=ss, group=group)
+            o = 0
+            for s_ in range(world):
+                out[int(ro[s_]) + r * chunk: int(ro[s_]) + r * chunk + rs[s_]] = tmp[o:o + rs[s_]]
+                o += rs[s_]
+        return out
+
     gen = shard_collapse(compute, tile, first_fidx, rank, world, **kw)
     try:
         req = next(gen)
@@ -554,9 +591,7 @@ def run_distributed(compute, tile, first_fidx, device=None, group=None, **kw):
                 dist.all_to_all_single(rc, c, group=group)
                 sc_h = (c.cpu().numpy() if _is_t(cnt) else np.asarray(cnt)).astype(np.int64)
                 rc_h = rc.cpu().numpy().astype(np.int64)
-                x = t(data).contiguous()
-                out = torch.empty((int(rc_h.sum()),) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-                dist.all_to_all_single(out, x, output_split_sizes=rc_h.tolist(), input_split_sizes=sc_h.tolist(), group=group)
+                out = a2a_rows(t(data).contiguous(), sc_h.tolist(), rc_h.tolist())
                 res = (back(out, data), rc_h)
             elif kind == "exchange_rows":
                 R, cnt, cig, ccnt, per = pay
@@ -567,12 +602,8 @@ def run_distributed(compute, tile, first_fidx, device=None, group=None, **kw):
                 rc = torch.empty_like(c)
                 dist.all_to_all_single(rc, c, group=group)
                 rc_h = rc.cpu().numpy().astype(np.int64)
-                x = t(R).contiguous()
-                outR = torch.empty((int(rc_h[:, 0].sum()),) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-                dist.all_to_all_single(outR, x, output_split_sizes=rc_h[:, 0].tolist(), input_split_sizes=sc_h[:, 0].tolist(), group=group)
-                y = t(cig).contiguous()
-                outC = torch.empty(int(rc_h[:, 1].sum()), dtype=y.dtype, device=y.device)
-                dist.all_to_all_single(outC, y, output_split_sizes=rc_h[:, 1].tolist(), input_split_sizes=sc_h[:, 1].tolist(), group=group)
+                outR = a2a_rows(t(R).contiguous(), sc_h[:, 0].tolist(), rc_h[:, 0].tolist())
+                outC = a2a_rows(t(cig).contiguous(), sc_h[:, 1].tolist(), rc_h[:, 1].tolist())
                 res = (back(outR, R), rc_h[:, 0].copy(), back(outC, cig), rc_h[:, 2:].copy())
             else:
                 raise AssertionError(kind)
