@@ -95,9 +95,15 @@ def main():
     t_gen = time.perf_counter() - t_gen
     n_records = dtile.n_records
     n_cig_in = int(dtile.cig.numel())
-    ctx = api.Context(local_rank)
-    opts_defer = ctx.make_opts(defer_yd=True, **strat)   # YD list machine overlaps the (YD-independent) tiecov chain
-    cbufs, vbufs = {}, {}
+    # Two contexts take the steps in turn (software pipelining of independent tiles, as a streaming host would run them):
+    # the YD list machine of step i — deferred onto its context's side stream — overlaps the tiecov chain of step i and the
+    # collapse of step i + 1.  Every step's YD is complete before the timed region ends.
+    ctxs = [api.Context(local_rank), api.Context(local_rank)]
+    ctx = ctxs[0]
+    opts_defer = ctx.make_opts(defer_yd=True, **strat)
+    cbufs2, vbufs2 = [{}, {}], [{}, {}]
+    cbufs, vbufs = cbufs2[0], vbufs2[0]
+    step_no = [0]
 
     class StitchCompute:
         """compute object of tiebrush_amd.dist: the same context, output buffers reused per call site"""
@@ -141,14 +147,21 @@ def main():
             # collapse of the owned coordinate range over all files -> tiecov of it, everything resident in HBM
             r = tdist.run_distributed(stitch, tile, rank * files, device=dev, want_coverage=True, device_chain=True, **strat)
             return ({"n_passed": r.n_passed_local, "n_groups": r.n_groups}, r.coverage)
-        g = ctx.collapse(tile, opts=opts_defer, want_coords=True, out=cbufs, raw=True)
-        view = ctx.groups_to_cov_in(g)
-        c = ctx.coverage(view, out=vbufs, raw=True)
-        ctx.finish_yd()                                   # every output of the step, YD included, is final here
+        i = step_no[0] & 1
+        step_no[0] += 1
+        cx = ctxs[i]
+        g = cx.collapse(tile, opts=opts_defer, want_coords=True, out=cbufs2[i], raw=True)   # (waits for this context's previous YD stage)
+        view = cx.groups_to_cov_in(g)
+        c = cx.coverage(view, out=vbufs2[i], raw=True)
         return g, c
+
+    def drain():
+        for cx in ctxs:
+            cx.finish_yd()                                # every output of every step, YD included, is final here
 
     for _ in range(args.warmup):
         g, c = step()
+    drain()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -156,6 +169,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         g, c = step()
+    drain()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -187,14 +201,15 @@ def main():
                 a[0] += ms
                 a[1] += ln
 
-        for _ in range(args.prof_steps):   # the same step as the timed loop (YD stage overlapping the tiecov chain)
+        for _ in range(args.prof_steps):   # the same calls as a timed step, one after the other: every kernel is measured with
+            # the GPU to itself (in the timed loop the YD stage and the next tile's collapse run beside the tiecov chain)
             gg = ctx.collapse(dtile, opts=opts_defer, want_coords=True, out=cbufs, raw=True)
             take("collapse")
+            ctx.finish_yd()
+            take("collapse")               # the deferred YD stage belongs to tbk_collapse_tile
             view = ctx.groups_to_cov_in(gg)
             cc = ctx.coverage(view, out=vbufs, raw=True)
             take("coverage")
-            ctx.finish_yd()
-            take("collapse")               # the deferred YD stage belongs to tbk_collapse_tile
         ctx.set_profiling(False)
         # algorithmic bytes; the profiled steps are rank 0's local collapse + coverage
         b_collapse = gg["n_passed"] * 16 + 4 * n_cig_in
@@ -213,6 +228,7 @@ def main():
             return {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic.get(name),
                     "avg_launch_us": round(per_launch_ms * 1e3, 2), "launches_per_step": launches_per_step,
+                    "measured": "HIP events on the launch stream, profiling steps after the timed region, calls serialised (kernel alone on the GPU)",
                     "algorithmic_bytes_per_step": int(alg_bytes)}
 
         tot = {k: v[0] / args.prof_steps for k, v in acc.items()}
@@ -242,7 +258,9 @@ def main():
             for k in names:
                 getattr(stage, k).copy_(hin[k], non_blocking=True)
             torch.cuda.current_stream().synchronize()
+            step_no[0] = 0
             gq, cq = step(stage)
+            drain()
             ng, ni, nj = gq["n_groups"], cq["n_intervals"], cq["n_junctions"]
             outs = [(cbufs[k], ng) for k in ("rep", "yc", "yx", "yd", "g_start", "g_end")]
             outs += [(vbufs[k], ni) for k in ("iv_tid", "iv_start", "iv_end", "iv_val")]

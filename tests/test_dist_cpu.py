@@ -64,6 +64,8 @@ def test_refuses_order_dependent_flags():
     tiles, first = split_tile(tile, 2)
     with pytest.raises(ValueError):
         dist.run_loopback(OracleCompute(), tiles, first, store_frac=True)
+    with pytest.raises(ValueError):                       # refused up front, before any collective has run
+        dist.run_loopback(OracleCompute(), tiles, first, strategy="full")
 
 
 def _gloo_tile():

@@ -112,3 +112,88 @@ def test_tag_update_in_place_rules(tmp_path):
     c = bamio.read_bam(out2)
     cc = dict((t, (ty, v)) for t, ty, v in bamio.record_aux(c, 1))
     assert cc["YD"] == ("S", 5) and "YX" not in cc   # old width kept when it is wide enough
+
+
+def _mini_bam(path, recs, level=1):
+    """recs: list of (pos, flag, aux bytes)"""
+    from tiebrush_amd import bamio
+    body = b"".join(bamio.encode_record(0, pos, flag, 60, [(50 << 4) | 0, (200 << 4) | 3, (50 << 4) | 0], b"r%d" % i, aux)
+                    for i, (pos, flag, aux) in enumerate(recs))
+    bamio.write_bam(path, "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chr1\tLN:100000\n", ["chr1"], [100000], body, level)
+
+
+def test_splice_strand_branches_through_the_host_codec(tmp_path):
+    """GSamRecord::spliceStrand (GSam.cpp:464-475): XS of type A or Z wins (its first byte, even '.', which then blocks the
+    ts fallback); else ts:A:+/- counts, flipped on the reverse strand; anything else is '.'.  The C++ loader, the Python
+    decoder and the oracle's expectation must agree record by record."""
+    from tiebrush_amd import bamio
+    cases = [
+        (100, 0, b"XSA+", "+"), (110, 16, b"XSA-", "-"), (120, 0, b"XSZ-\0", "-"), (130, 0, b"XSZ+extra\0", "+"),
+        (140, 0, b"XSA.", "."), (150, 0, b"XSA." + b"tsA+", "."),          # XS:A:. blocks ts
+        (160, 0, b"tsA+", "+"), (170, 16, b"tsA+", "-"), (180, 16, b"tsA-", "+"), (190, 0, b"tsA-", "-"),
+        (200, 0, b"tsA?", "."), (210, 0, b"", "."), (220, 0, b"XSi\x05\0\0\0" + b"tsA+", "+"),   # XS of another type is not a strand
+        (230, 0, b"NHC\x01" + b"tsA-" + b"XSA+", "+"),                     # XS wins wherever it stands
+    ]
+    p = str(tmp_path / "s.bam")
+    _mini_bam(p, [(pos, fl, aux) for pos, fl, aux, _ in cases])
+    want = np.array([ord(c) for _, _, _, c in cases], np.uint8)
+    assert np.array_equal(bamio.read_bam(p).strand, want)                  # Python decoder
+    d = str(tmp_path / "soa")
+    os.makedirs(d)
+    subprocess.run([TOOL, "soa", d, p], check=True)                        # C++ loader (GSamRecord::spliceStrand mirror)
+    assert np.array_equal(np.fromfile(os.path.join(d, "strand"), np.uint8), want)
+
+
+def _corrupt(src_bytes, mutate):
+    """inflate a BAM, mutate the record stream in place, deflate again"""
+    from tiebrush_amd import bamio
+    raw = bytearray(bamio.bgzf_decompress(src_bytes))
+    _, p = bamio.parse_header(bytes(raw))
+    mutate(raw, p)
+    return bamio.bgzf_compress(bytes(raw), 1) + bamio._BGZF_EOF
+
+
+@pytest.mark.parametrize("what", ["l_read_name", "n_cigar", "l_seq_negative", "tid", "no_nul", "truncated", "crc", "bsize"])
+def test_malformed_input_is_refused_not_read_past(tmp_path, what):
+    """what htslib rejects, the host codec rejects: field lengths beyond the record, reference ids outside the header,
+    a read name without its NUL, a truncated record stream, a BGZF member with a wrong CRC32 or an impossible BSIZE"""
+    import struct
+    good = str(tmp_path / "g.bam")
+    _mini_bam(good, [(100 + 10 * i, 0, b"NHC\x01") for i in range(20)])
+    data = open(good, "rb").read()
+
+    def mut(raw, p):
+        r = p + 4 + 0  # first record: refID at r, l_read_name at r+8, n_cigar_op at r+12, l_seq at r+16
+        if what == "l_read_name":
+            raw[r + 8] = 250
+        elif what == "n_cigar":
+            raw[r + 12:r + 14] = struct.pack("<H", 60000)
+        elif what == "l_seq_negative":
+            raw[r + 16:r + 20] = struct.pack("<i", -5)
+        elif what == "tid":
+            raw[r:r + 4] = struct.pack("<i", 7)
+        elif what == "no_nul":
+            raw[r + 32 + raw[r + 8] - 1] = ord("x")
+        elif what == "truncated":
+            del raw[-9:]
+
+    if what == "crc":
+        b = bytearray(data)
+        bs = struct.unpack("<H", b[16:18])[0]
+        b[bs + 1 - 8] ^= 0xFF                                   # CRC32 of the first member
+        bad = bytes(b)
+    elif what == "bsize":
+        b = bytearray(data)
+        b[16:18] = struct.pack("<H", 10)                        # BSIZE smaller than header + trailer
+        bad = bytes(b)
+    else:
+        bad = _corrupt(data, mut)
+    p = str(tmp_path / "bad.bam")
+    open(p, "wb").write(bad)
+    d = str(tmp_path / "soa")
+    os.makedirs(d)
+    r = subprocess.run([TOOL, "soa", d, p], capture_output=True, text=True)
+    assert r.returncode != 0 and r.returncode > 0, (what, r.returncode, r.stderr)   # a clean error exit, not a signal
+    assert r.stderr.strip() != ""
+    ok = subprocess.run([TOOL, "soa", d, good], capture_output=True, text=True)
+    assert ok.returncode == 0

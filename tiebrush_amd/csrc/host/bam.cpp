@@ -352,8 +352,27 @@ bool BamFile::load(const std::string& p, std::string& err, int threads) {
       err = "corrupt record in " + p;
       return false;
     }
+    {  // the variable-length fields must lie inside the record and refID inside the header (htslib's bam_read1 rejects the same):
+       // RecView::qname / cigar / aux_begin index by these lengths without further checks
+      const uint8_t* r = &data[off + 4];
+      const int32_t tid = (int32_t)rd32(r);
+      const uint32_t l_read_name = r[8];
+      const uint32_t n_cigar = (uint32_t)r[12] | ((uint32_t)r[13] << 8);
+      const int32_t l_seq = (int32_t)rd32(r + 16);
+      const int32_t mtid = (int32_t)rd32(r + 20);
+      const uint64_t need = 32ull + l_read_name + 4ull * n_cigar + (l_seq < 0 ? 0ull : ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq);
+      const bool name_ok = l_read_name >= 1 && 32 + l_read_name <= bs && r[32 + l_read_name - 1] == 0;
+      if (l_seq < 0 || need > bs || !name_ok || tid < -1 || tid >= hdr.n_targets || mtid < -1 || mtid >= hdr.n_targets) {
+        err = "malformed record " + std::to_string(rec_off.size()) + " in " + p + " (field lengths / reference id outside the record / header)";
+        return false;
+      }
+    }
     rec_off.push_back(off);
     off += 4 + (size_t)bs;
+  }
+  if (off != data.size()) {  // trailing bytes that are not a whole record: a truncated file
+    err = "truncated record at the end of " + p;
+    return false;
   }
   return true;
 }

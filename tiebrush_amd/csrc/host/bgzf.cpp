@@ -30,6 +30,7 @@ struct Member {
   size_t cdata;  // start of the deflate stream
   size_t clen;
   uint32_t isize;
+  uint32_t crc;  // CRC32 of the uncompressed bytes (RFC 1952 trailer)
   size_t out_off;
 };
 
@@ -65,8 +66,9 @@ bool bgzf_read_file(const std::string& path, std::vector<uint8_t>& out, std::str
       if (raw[p] == 'B' && raw[p + 1] == 'C' && slen == 2) bsize = rd16(&raw[p + 4]);
       p += 4 + slen;
     }
-    if (bsize < 0 || off + (size_t)bsize + 1 > raw.size()) {
-      err = "corrupt BGZF member in " + path;
+    // member = 12 + xlen bytes of header, the deflate stream, CRC32 + ISIZE (8 bytes): a BSIZE too small for that is corrupt
+    if (bsize < 0 || off + (size_t)bsize + 1 > raw.size() || (size_t)bsize + 1 < (size_t)12 + xlen + 8 || end > raw.size()) {
+      err = "corrupt BGZF member at offset " + std::to_string(off) + " of " + path;
       return false;
     }
     Member m;
@@ -74,6 +76,11 @@ bool bgzf_read_file(const std::string& path, std::vector<uint8_t>& out, std::str
     m.cdata = off + 12 + xlen;
     m.clen = (size_t)bsize + 1 - 8 - (12 + xlen);
     m.isize = rd32(&raw[off + bsize + 1 - 4]);
+    m.crc = rd32(&raw[off + bsize + 1 - 8]);
+    if (m.isize > 65536) {  // a BGZF block holds at most 64 KiB (SAM spec 4.1)
+      err = "BGZF member with ISIZE > 64 KiB at offset " + std::to_string(off) + " of " + path;
+      return false;
+    }
     m.out_off = total;
     total += m.isize;
     mem.push_back(m);
@@ -101,6 +108,8 @@ bool bgzf_read_file(const std::string& path, std::vector<uint8_t>& out, std::str
       int rc = inflate(&zs, Z_FINISH);
       inflateEnd(&zs);
       if (rc != Z_STREAM_END || zs.avail_out != 0) ok = false;
+      // the member's CRC32 covers the uncompressed bytes (RFC 1952); htslib rejects a mismatch, so do we
+      else if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), out.data() + m.out_off, m.isize) != m.crc) ok = false;
     }
   };
   if (threads <= 1 || mem.size() < 8) {
@@ -111,7 +120,7 @@ bool bgzf_read_file(const std::string& path, std::vector<uint8_t>& out, std::str
     for (auto& t : th) t.join();
   }
   if (!ok) {
-    err = "inflate failed in " + path;
+    err = "inflate failed or CRC32 mismatch in " + path;
     return false;
   }
   return true;

@@ -237,23 +237,32 @@ int main(int argc, char* argv[]) {
       });
   }
   if (soutf) {
-    uint64_t mb = 0;
-    for (size_t i = 0; i < (size_t)co; ++i)
-      if ((cig[i] & 0xF) == 0) mb += cig[i] >> 4;
-    size_t cs = (size_t)(mb < (1ull << 31) ? mb : (1ull << 31) - 1) + 16;
-    std::vector<int32_t> st(cs), ss(cs), se(cs);
-    std::vector<int64_t> sc(cs);
-    std::vector<float> sh(cs);
+    // the value of the track changes only where an M segment starts or ends: at most 2 intervals per CIGAR operation + 2 per
+    // record, as for the coverage track (not one per covered base); if a call still reports TBK_E2BIG it also reports the
+    // count it needs, and the call is repeated with that
+    size_t cs = 2 * (size_t)co + 2 * (size_t)n + 16;
+    std::vector<int32_t> st, ss, se;
+    std::vector<int64_t> sc;
+    std::vector<float> sh;
     tbk_sample_out so;
-    memset(&so, 0, sizeof(so));
-    so.mem = TBK_MEM_HOST;
-    so.cap_intervals = (uint32_t)cs;
-    so.iv_tid = st.data();
-    so.iv_start = ss.data();
-    so.iv_end = se.data();
-    so.iv_count = sc.data();
-    so.iv_heat = sh.data();
-    rc = tbk_sample_tile(ctx, &in, num_samples, &so);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      st.resize(cs);
+      ss.resize(cs);
+      se.resize(cs);
+      sc.resize(cs);
+      sh.resize(cs);
+      memset(&so, 0, sizeof(so));
+      so.mem = TBK_MEM_HOST;
+      so.cap_intervals = (uint32_t)cs;
+      so.iv_tid = st.data();
+      so.iv_start = ss.data();
+      so.iv_end = se.data();
+      so.iv_count = sc.data();
+      so.iv_heat = sh.data();
+      rc = tbk_sample_tile(ctx, &in, num_samples, &so);
+      if (rc != TBK_E2BIG) break;
+      cs = (size_t)so.n_intervals + 16;
+    }
     if (rc == TBK_EFATALOP) GError("ERROR: unknown opcode in a CIGAR string (tiecov accepts M, I, D, N, S only)\n");
     if (rc != 0) GError("Error: GPU sample track failed: %s (%s)\n", tbk_strerror(rc), tbk_last_error(ctx));
     emit_lines(soutf, so.n_intervals, [&](uint32_t i, char* b, size_t cap) {  // flushCoverage(pair), tiecov.cpp:289

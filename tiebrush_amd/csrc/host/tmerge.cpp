@@ -353,6 +353,7 @@ void TInputFiles::load_tile(TbkTile& t, bool want_md, bool want_qh, int threads,
     md_base[f + 1] = md_base[f] + nmd[f];
   }
   if (cig_base[k] >= (1ull << 32)) GError("Error: more than 2^32 CIGAR operations in one tile\n");
+  if (md_base[k] >= (1ull << 32)) GError("Error: more than 2^32 bytes of MD tags in one tile\n");  // md_off is 32-bit too
   t.tid.resize(n);
   t.pos.resize(n);
   t.nh.resize(n);

@@ -284,6 +284,8 @@ def shard_collapse(compute, local_tile: SoATile, first_fidx: int, rank: int, wor
     tiebrush_amd.api.Context or a wrapper of it."""
     if filters.get("store_frac") or filters.get("collapse_same"):
         raise ValueError("--store-frac and -A need the single-tile path's ordered passes: single-GPU only (DESIGN.md §7)")
+    if strategy in ("full", 1):
+        raise ValueError("-L (CIGAR + MD) is single-GPU only: the shuffled rows carry no MD tags")
     X = _xp(local_tile.tid)
     mark = getattr(compute, "mark", None) or (lambda _name: None)       # optional phase hook (tools/prof_dist.py)
     on_dev = _is_t(local_tile.tid) and hasattr(compute, "shard_prepare")
