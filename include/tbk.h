@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TBK_ABI_VERSION 1
+#define TBK_ABI_VERSION 2
 
 typedef struct tbk_ctx tbk_ctx;
 
@@ -107,13 +107,17 @@ typedef struct tbk_soa_in {
   const uint32_t* md_off;   /* [n_records+1]                                         */
   const uint8_t* md;
   const uint8_t* md_has;    /* [n_records]                                           */
-  /* only for collapse_same (-A): 64-bit hash of (qname bytes, pairOrder) */
+  /* only for collapse_same (-A): 64-bit hash of (qname bytes, pairOrder) — a filter only: equal hashes are confirmed by a
+   * byte compare of the names below and of pairOrder (flag 0x40 / 0x80), as the reference's strcmp does (tiebrush.cpp:422-424) */
   const uint64_t* qname_hash;
   /* only when stitching partial groups of several ranks: explicit merge-order priority of
    * each record; the representative of a group is then argmin (prio_hi, prio_lo) over its members.
    * prio_hi = effective end of the partial's representative, prio_lo = (global file index << 32) | index in file */
   const uint64_t* prio_hi;
   const uint64_t* prio_lo;
+  /* only for collapse_same (-A), required with it: read names without NUL as CSR (ABI version 2: fields appended) */
+  const uint32_t* qname_off; /* [n_records+1]                                        */
+  const uint8_t* qname;
 } tbk_soa_in;
 
 /* Collapsed groups in the order the reference writes them (flushPData order). */

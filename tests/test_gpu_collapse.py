@@ -238,6 +238,36 @@ def test_fractional_tbmerged_and_collapse_same(ctx, bam_loader):
     _check(ctx, base, keep_secondary=True, collapse_same=True, store_frac=True)
 
 
+def test_collapse_same_is_decided_on_the_name_bytes(ctx, monkeypatch):
+    """-A: "same read" = same QNAME and pairOrder (tiebrush.cpp:422-424).  The 64-bit name hash is only a filter: with the
+    hash narrowed to 2 bits (TBK_DEBUG_QHASH_MASK) nearly every pair of reads collides, and the result is still the
+    oracle's (which compares the names), with and without paired flags and --store-frac."""
+    from tiebrush_amd import soa, synth
+    rng = np.random.default_rng(77)
+    base = synth.make_tile(3, 4000, "c2", n_loci=12)
+    n = base.n_records
+    base.flag = (base.flag | rng.choice([0, 0x40, 0x80], n).astype(np.uint16)).astype(np.uint16)
+    names = [b"q%d" % int(x) for x in rng.integers(0, 40, n)]                # few names: many true repeats inside a file
+    lens = np.array([len(x) for x in names])
+    base.qn_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+    base.qn = np.frombuffer(b"".join(names), np.uint8).copy()
+    base.qname_hash = np.array([soa.qname_hash64(x, soa.pair_order(int(f))) for x, f in zip(names, base.flag)], np.uint64)
+    _check(ctx, base, collapse_same=True)
+    monkeypatch.setenv("TBK_DEBUG_QHASH_MASK", "0x3")
+    _check(ctx, base, collapse_same=True)
+    _check(ctx, base, collapse_same=True, store_frac=True)
+    monkeypatch.setenv("TBK_DEBUG_QHASH_MASK", "0x0")                        # every hash equal: the bytes alone decide
+    _check(ctx, base, collapse_same=True)
+    monkeypatch.delenv("TBK_DEBUG_QHASH_MASK")
+    # names are required with -A (no silent hash-only mode)
+    from tiebrush_amd import api
+    nameless = synth.make_tile(2, 500, "c2", n_loci=5)
+    nameless.qname_hash = np.zeros(nameless.n_records, np.uint64)
+    with pytest.raises(api.TbkError) as e:
+        ctx.collapse(nameless, collapse_same=True)
+    assert e.value.status == -1
+
+
 def test_hash_collision_reseed_path(ctx, monkeypatch):
     """the grouping hash is only a sort accelerator: every non-head is verified against the full key, a collision makes
     the host retry with another seed, and four colliding seeds fail loudly — never a wrong group"""

@@ -64,6 +64,7 @@ def test_soa_tile_matches_python_decoder(tmp_path, bam_loader):
                      ("nh", np.int32), ("cig_off", np.uint32), ("cig", np.uint32), ("md_off", np.uint32), ("md", np.uint8),
                      ("md_has", np.uint8), ("qname_hash", np.uint64)):
         assert np.array_equal(rd(name, dt), getattr(tile, name)), name
+    assert np.array_equal(rd("qname_off", np.uint32), tile.qn_off) and np.array_equal(rd("qname", np.uint8), tile.qn)   # -A compares the names
     # carried tags are only meaningful for TieBrush-merged files
     n0 = int(tile.file_off[1])
     assert np.array_equal(rd("yc_in", np.float64)[:n0], tile.yc_in[:n0])

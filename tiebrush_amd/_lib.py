@@ -36,7 +36,8 @@ class SoaIn(C.Structure):
     _fields_ = [("mem", C.c_int32), ("n_files", C.c_uint32), ("n_records", C.c_uint32), ("n_cigar_ops", C.c_uint32),
                 ("file_off", _P), ("tbmerged", _P), ("tid", _P), ("pos", _P), ("flag", _P), ("mapq", _P),
                 ("strand", _P), ("nh", _P), ("cig_off", _P), ("cig", _P), ("yc_in", _P), ("yx_in", _P), ("yd_in", _P),
-                ("md_off", _P), ("md", _P), ("md_has", _P), ("qname_hash", _P), ("prio_hi", _P), ("prio_lo", _P)]
+                ("md_off", _P), ("md", _P), ("md_has", _P), ("qname_hash", _P), ("prio_hi", _P), ("prio_lo", _P),
+                ("qname_off", _P), ("qname", _P)]
 
 
 class GroupsOut(C.Structure):

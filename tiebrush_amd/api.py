@@ -68,7 +68,7 @@ def to_device(obj, device="cuda:0"):
                        cig_off=mv(obj.cig_off, np.uint32), cig=mv(obj.cig, np.uint32), yc_in=mv(obj.yc_in, np.float64),
                        yx_in=mv(obj.yx_in, np.int64), yd_in=mv(obj.yd_in, np.int64), md_off=mv(obj.md_off, np.uint32),
                        md=mv(obj.md, np.uint8), md_has=mv(obj.md_has, np.uint8),
-                       qname_hash=mv(obj.qname_hash, np.uint64), qn_off=None, qn=None,
+                       qname_hash=mv(obj.qname_hash, np.uint64), qn_off=mv(obj.qn_off, np.uint32), qn=mv(obj.qn, np.uint8),
                        prio_hi=mv(obj.prio_hi, np.uint64), prio_lo=mv(obj.prio_lo, np.uint64))
         torch.cuda.synchronize()
         return r
@@ -195,7 +195,7 @@ class Context:
             _addr(tile.yd_in, np.int64, keep, n), _addr(tile.md_off, np.uint32, keep, n + 1),
             _addr(tile.md, np.uint8, keep), _addr(tile.md_has, np.uint8, keep, n),
             _addr(tile.qname_hash, np.uint64, keep, n), _addr(tile.prio_hi, np.uint64, keep, n),
-            _addr(tile.prio_lo, np.uint64, keep, n))
+            _addr(tile.prio_lo, np.uint64, keep, n), _addr(tile.qn_off, np.uint32, keep, n + 1), _addr(tile.qn, np.uint8, keep))
         return s, dev, n
 
     def collapse(self, tile: SoATile, opts=None, want_coords=True, want_rec_group=False, want_effend=False, out=None,

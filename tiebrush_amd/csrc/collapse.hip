@@ -279,7 +279,7 @@ __global__ void col_same_k(ColIn I, ColOpt O, const uint64_t* __restrict__ pm, c
   if (I.tbm[fidx[gi]] || (flags[q] & 4u)) return;
   uint32_t sg = sgid[q];
   uint32_t r = (uint32_t)(G.rep[sg] & 0xFFFFFFFFull);
-  if (I.qh[gi] == I.qh[r]) atomicAdd(&G.yc[sg], -1.0);
+  if (same_read(I, gi, r)) atomicAdd(&G.yc[sg], -1.0);
 }
 
 // ---- ordered YC accumulation (--store-frac, fractional carried YC) ------------------------------------------------
@@ -310,7 +310,7 @@ __global__ void ord_sum_k(ColIn I, ColOpt O, uint32_t ng, uint32_t m, const uint
     if (I.tbm[fidx[gi]]) {
       y = I.yc_in[gi];
       if (y == 0.0) y = 1.0;
-    } else if (O.collapse_same && !fh_by_rec[gi] && I.qh[gi] == I.qh[rep]) {
+    } else if (O.collapse_same && !fh_by_rec[gi] && same_read(I, gi, rep)) {
       continue;  // -A: same read of the same sample is not counted again (tiebrush.cpp:422-424)
     } else if (O.store_frac) {
       int nh = I.nh[gi] == TBK_NH_ABSENT ? 1 : I.nh[gi];
@@ -1250,6 +1250,10 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
   I.md = in->md;
   I.md_has = in->md_has;
   I.qh = in->qname_hash;
+  I.qn_off = in->qname_off;
+  I.qn = in->qname;
+  I.qh_mask = ~0ull;
+  if (const char* e = getenv("TBK_DEBUG_QHASH_MASK")) I.qh_mask = strtoull(e, nullptr, 0);
   I.prio_hi = in->prio_hi;
   I.prio_lo = in->prio_lo;
   ColOpt O;

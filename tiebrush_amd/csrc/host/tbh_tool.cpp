@@ -64,6 +64,8 @@ int main(int argc, char** argv) {
     dump(d, "md", t.md);
     dump(d, "md_has", t.md_has);
     dump(d, "qname_hash", t.qname_hash);
+    dump(d, "qname_off", t.qname_off);
+    dump(d, "qname", t.qname);
     FILE* f = fopen((d + "/header.txt").c_str(), "w");
     fputs(in.header()->text.c_str(), f);
     fclose(f);

@@ -68,7 +68,11 @@ tbk_soa_in TbkTile::view() const {
     s.md = md.data();
     s.md_has = md_has.data();
   }
-  if (!qname_hash.empty()) s.qname_hash = qname_hash.data();
+  if (!qname_hash.empty()) {
+    s.qname_hash = qname_hash.data();
+    s.qname_off = qname_off.data();
+    s.qname = qname.data();
+  }
   return s;
 }
 
@@ -307,7 +311,7 @@ void TInputFiles::load_tile(TbkTile& t, bool want_md, bool want_qh, int threads,
   t = TbkTile();
   t.file_off.assign(k + 1, 0);
   t.tbmerged.assign(k, 0);
-  std::vector<uint64_t> cig_base(k + 1, 0), md_base(k + 1, 0);
+  std::vector<uint64_t> cig_base(k + 1, 0), md_base(k + 1, 0), qn_base(k + 1, 0);
   std::vector<size_t> lo(k, 0), hi(k, 0);
   bool any_tb = false;
   for (size_t f = 0; f < k; ++f) {
@@ -323,7 +327,7 @@ void TInputFiles::load_tile(TbkTile& t, bool want_md, bool want_qh, int threads,
   tile_lo_ = lo;
   size_t n = t.file_off[k];
   // pass 1: CIGAR / MD sizes per file
-  std::vector<uint64_t> ncig(k, 0), nmd(k, 0);
+  std::vector<uint64_t> ncig(k, 0), nmd(k, 0), nqn(k, 0);
   {
     std::atomic<size_t> nf{0};
     auto w = [&]() {
@@ -331,10 +335,11 @@ void TInputFiles::load_tile(TbkTile& t, bool want_md, bool want_qh, int threads,
         size_t f = nf.fetch_add(1);
         if (f >= k) break;
         tbh::BamFile* bf = freaders[f]->samreader->file();
-        uint64_t c = 0, m = 0;
+        uint64_t c = 0, m = 0, q = 0;
         for (size_t i = lo[f]; i < hi[f]; ++i) {
           tbh::RecView v = bf->rec(i);
           c += v.n_cigar();
+          if (want_qh) q += strlen(v.qname());
           if (want_md) {
             const uint8_t* s = tbh::aux_get(v.aux_begin(), v.aux_end(), "MD");
             if (s && *s == 'Z') m += strlen((const char*)s + 1);
@@ -342,6 +347,7 @@ void TInputFiles::load_tile(TbkTile& t, bool want_md, bool want_qh, int threads,
         }
         ncig[f] = c;
         nmd[f] = m;
+        nqn[f] = q;
       }
     };
     std::vector<std::thread> th;
@@ -351,6 +357,7 @@ void TInputFiles::load_tile(TbkTile& t, bool want_md, bool want_qh, int threads,
   for (size_t f = 0; f < k; ++f) {
     cig_base[f + 1] = cig_base[f] + ncig[f];
     md_base[f + 1] = md_base[f] + nmd[f];
+    qn_base[f + 1] = qn_base[f] + nqn[f];
   }
   if (cig_base[k] >= (1ull << 32)) GError("Error: more than 2^32 CIGAR operations in one tile\n");
   if (md_base[k] >= (1ull << 32)) GError("Error: more than 2^32 bytes of MD tags in one tile\n");  // md_off is 32-bit too
@@ -372,7 +379,13 @@ void TInputFiles::load_tile(TbkTile& t, bool want_md, bool want_qh, int threads,
     t.md.resize(md_base[k]);
     t.md_has.assign(n, 0);
   }
-  if (want_qh) t.qname_hash.resize(n);
+  if (want_qh) {
+    if (qn_base[k] >= (1ull << 32)) GError("Error: more than 2^32 bytes of read names in one tile\n");
+    t.qname_hash.resize(n);
+    t.qname_off.resize(n + 1);
+    t.qname.resize(qn_base[k]);
+    t.qname_off[n] = (uint32_t)qn_base[k];
+  }
   t.cig_off[n] = (uint32_t)cig_base[k];
   if (want_md) t.md_off[n] = (uint32_t)md_base[k];
   // pass 2: fill
@@ -382,7 +395,7 @@ void TInputFiles::load_tile(TbkTile& t, bool want_md, bool want_qh, int threads,
       size_t f = nf.fetch_add(1);
       if (f >= k) break;
       tbh::BamFile* bf = freaders[f]->samreader->file();
-      uint64_t co = cig_base[f], mo = md_base[f];
+      uint64_t co = cig_base[f], mo = md_base[f], qo = qn_base[f];
       size_t g = t.file_off[f];
       bool tb = t.tbmerged[f] != 0;
       for (size_t i = lo[f]; i < hi[f]; ++i, ++g) {
@@ -443,6 +456,10 @@ void TInputFiles::load_tile(TbkTile& t, bool want_md, bool want_qh, int threads,
         if (want_qh) {
           int po = (fl & 0x40) ? 1 : ((fl & 0x80) ? 2 : 0);
           t.qname_hash[g] = tbh_qname_hash(v.qname(), po);
+          const size_t ql = strlen(v.qname());
+          t.qname_off[g] = (uint32_t)qo;
+          memcpy(t.qname.data() + qo, v.qname(), ql);
+          qo += ql;
         }
       }
     }

@@ -42,6 +42,8 @@ struct TbkTile {
   std::vector<uint32_t> md_off;
   std::vector<uint8_t> md, md_has;
   std::vector<uint64_t> qname_hash;
+  std::vector<uint32_t> qname_off;  // -A: the names themselves (CSR, no NUL): the device confirms equal hashes on the bytes
+  std::vector<uint8_t> qname;
   tbk_soa_in view() const;
   size_t n() const { return tid.size(); }
 };

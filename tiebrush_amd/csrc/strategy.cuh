@@ -22,6 +22,9 @@ struct ColIn {
   const uint32_t* md_off;
   const uint8_t *md, *md_has;
   const uint64_t* qh;
+  const uint32_t* qn_off;  // read names (CSR), -A only
+  const uint8_t* qn;
+  uint64_t qh_mask;        // ~0 in production; TBK_DEBUG_QHASH_MASK narrows the name-hash filter to provoke collisions in tests
   const uint64_t *prio_hi, *prio_lo;
 };
 
@@ -32,6 +35,20 @@ struct ColOpt {
   uint64_t seed;
   uint32_t hash_mask;  // 0xFFFFFFFF in production; TBK_DEBUG_HASH_MASK narrows it to provoke collisions in tests
 };
+
+// -A: "the same read" = same QNAME and same pairOrder (GSamRecord::pairOrder: 1 first, 2 second, 0 neither; tiebrush.cpp:422-424).
+// The 64-bit hash of (name, pairOrder) is a filter; equality is decided on the bytes.
+__device__ inline bool same_read(const ColIn& I, uint32_t a, uint32_t b) {
+  if ((I.qh[a] & I.qh_mask) != (I.qh[b] & I.qh_mask)) return false;
+  const uint32_t fa = I.flag[a], fb = I.flag[b];
+  const uint32_t pa = (fa & 0x40) ? 1u : ((fa & 0x80) ? 2u : 0u), pb = (fb & 0x40) ? 1u : ((fb & 0x80) ? 2u : 0u);
+  if (pa != pb) return false;
+  const uint32_t a0 = I.qn_off[a], a1 = I.qn_off[a + 1], b0 = I.qn_off[b], b1 = I.qn_off[b + 1];
+  if (a1 - a0 != b1 - b0) return false;
+  for (uint32_t k = 0; k < a1 - a0; ++k)
+    if (I.qn[a0 + k] != I.qn[b0 + k]) return false;
+  return true;
+}
 
 __device__ __forceinline__ uint32_t strand_code(uint8_t s) { return s == '+' ? 0u : (s == '-' ? 1u : 2u); }
 

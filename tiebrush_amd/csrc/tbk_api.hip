@@ -425,7 +425,7 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
     return TBK_EINVAL;
   if (!out->rep || !out->yc || !out->yx || !out->yd) return TBK_EINVAL;
   if (opts->strategy == TBK_STRAT_FULL && (!in->md_off || !in->md_has)) return TBK_EINVAL;
-  if (opts->collapse_same && !in->qname_hash) return TBK_EINVAL;
+  if (opts->collapse_same && (!in->qname_hash || !in->qname_off || (in->n_records && !in->qname))) return TBK_EINVAL;  // -A compares names
   if ((in->prio_hi == nullptr) != (in->prio_lo == nullptr)) return TBK_EINVAL;
   bool any_tb = false;
   if (in->tbmerged)
@@ -480,6 +480,8 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
     TBK_TRY(h2d(ctx, in->md, in->md_off ? (size_t)in->md_off[n] : 0, &din.md));
     TBK_TRY(h2d(ctx, in->md_has, n, &din.md_has));
     TBK_TRY(h2d(ctx, in->qname_hash, n, &din.qname_hash));
+    TBK_TRY(h2d(ctx, in->qname_off, in->qname_off ? n + 1 : 0, &din.qname_off));
+    TBK_TRY(h2d(ctx, in->qname, in->qname_off ? (size_t)in->qname_off[n] : 0, &din.qname));
     TBK_TRY(h2d(ctx, in->prio_hi, n, &din.prio_hi));
     TBK_TRY(h2d(ctx, in->prio_lo, n, &din.prio_lo));
     size_t cap = out->cap_groups;
