@@ -223,16 +223,6 @@ int tbk_sample_tile(tbk_ctx* ctx, const tbk_cov_in* in, int32_t num_samples, tbk
  * device memory.  The returned view is valid until the next call on `ctx`. */
 int tbk_groups_to_cov_in(tbk_ctx* ctx, const tbk_soa_in* in, const tbk_groups_out* groups, tbk_cov_in* view);
 
-/* Multi-GPU stitch helper: pack the groups of a finished tbk_collapse_tile call (device
- * memory, rep_effend requested) into the exchange layout of one row per group,
- *   P[g] = { tid, pos, strand, yx, yd, prio_hi = rep_effend, prio_lo = (first_fidx+file)<<32 | index in file,
- *            n_cigar, bits of (double)yc }                                            (9 x int64)
- * and the representatives' CIGAR words back to back in cig_out (capacity cig_cap words, count -> *n_cig). */
-#define TBK_PARTIAL_COLS 9
-int tbk_pack_partials(tbk_ctx* ctx, const tbk_soa_in* in, const tbk_groups_out* groups, uint32_t first_fidx, int64_t* P,
-                      uint32_t* cig_out, uint32_t cig_cap, uint32_t* n_cig,
-                      int64_t* emax_out /* optional [n_groups]: running max of (tid+1)<<32 | g_end, needs groups->g_end */);
-
 /* ---- Multi-GPU: shuffle, then collapse (the reference has no counterpart — its only parallelism is
  * tiewrap.py:96-126, batches of files re-collapsed hierarchically).  Every rank holds some input files; the ranks agree
  * on coordinate cuts no read spans, every passing record moves to the rank owning its range, and that rank runs the

@@ -161,3 +161,37 @@ def test_cli_tiling_by_reference_is_exact(tmp_path):
     subprocess.run([os.path.join(BIN, "tiebrush"), "-o", d] + paths, check=True, capture_output=True, env=dict(os.environ, TBK_TILE_RECORDS="1"))
     rc_, rd_ = bamio.bgzf_decompress(open(c, "rb").read()), bamio.bgzf_decompress(open(d, "rb").read())
     assert rc_[bamio.parse_header(rc_)[1]:] == rd_[bamio.parse_header(rd_)[1]:]
+
+
+def test_cli_streams_many_inputs_with_few_descriptors_and_small_tiles(tmp_path):
+    """The streaming driver (TInputFiles::next_tile): 300 inputs under `ulimit -n 64` (an input's descriptor is only open
+    while its window is refilled), tiles of ~2000 records cut at global bundle boundaries — the output equals the oracle's
+    flat collapse of the same inputs record for record, YC / YX / YD included, and equals the one-tile run byte for byte."""
+    import resource
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import bamio, synth
+    tile = synth.make_tile(300, 120, "c5", n_loci=300)
+    paths = synth.write_bams(tile, str(tmp_path / "m"))
+    lst = str(tmp_path / "inputs.txt")
+    open(lst, "w").write("\n".join(paths) + "\n")
+    flat = orc.collapse(tile, strategy=3, max_nh=5, min_qual=1)
+    args = ["-E", "-N", "5", "-Q", "1"]
+
+    def limit():
+        resource.setrlimit(resource.RLIMIT_NOFILE, (64, 64))
+
+    one, tiled = str(tmp_path / "one.bam"), str(tmp_path / "tiled.bam")
+    _run([os.path.join(BIN, "tiebrush"), "-o", one] + args + [lst])
+    r = subprocess.run([os.path.join(BIN, "tiebrush"), "-o", tiled] + args + [lst], check=True, capture_output=True, text=True,
+                       env=dict(os.environ, TBK_TILE_RECORDS="2000", TBK_TIMING="1"), preexec_fn=limit)
+    assert "%d input records written as %d" % (flat["n_passed"], flat["n_groups"]) in r.stderr
+    ntiles = int([l for l in r.stderr.splitlines() if l.startswith("tiles:")][0].split()[1])
+    assert ntiles > 5
+    ra, rb = bamio.bgzf_decompress(open(one, "rb").read()), bamio.bgzf_decompress(open(tiled, "rb").read())
+    assert ra[bamio.parse_header(ra)[1]:] == rb[bamio.parse_header(rb)[1]:]
+    out = bamio.read_bam(tiled)
+    assert out.n == flat["n_groups"]
+    rep = flat["rep"].astype(np.int64)
+    assert np.array_equal(out.pos, tile.pos[rep]) and np.array_equal(out.tid, tile.tid[rep])
+    assert np.array_equal(out.yc.astype(np.float64), flat["yc"].astype(np.float32).astype(np.float64))
+    assert np.array_equal(out.yx, flat["yx"]) and np.array_equal(out.yd, flat["yd"])

@@ -198,3 +198,35 @@ def test_malformed_input_is_refused_not_read_past(tmp_path, what):
     assert r.stderr.strip() != ""
     ok = subprocess.run([TOOL, "soa", d, good], capture_output=True, text=True)
     assert ok.returncode == 0
+
+
+def test_streamed_tiles_cut_where_no_read_crosses(tmp_path, bam_loader):
+    """TInputFiles::next_tile: the tiles partition every input in order; at every cut no read of ANY input that starts
+    before it reaches it (a global bundle boundary or a reference change), so tiles collapse independently; and the
+    windows stay near the requested tile size instead of holding the files."""
+    from tiebrush_amd import synth
+    tile = synth.make_tile(6, 4000, "c3", n_loci=400)                 # many separate loci: plenty of places to cut
+    paths = synth.write_bams(tile, str(tmp_path / "s"))
+    bams = [bam_loader(p) for p in paths]
+    out = subprocess.run([TOOL, "tiles", "3000"] + paths, check=True, capture_output=True, text=True).stdout
+    rows = np.array([[int(x) for x in l.split()] for l in out.splitlines()], dtype=np.int64)
+    assert len(rows) > 2                                              # really streamed in several tiles
+    taken = rows[:, 1:]
+    placed = [int((b.tid >= 0).sum()) for b in bams]
+    assert taken.sum(0).tolist() == placed                            # every placed record, once
+    cum = np.cumsum(taken, axis=0)
+    for t in range(len(rows) - 1):
+        # cut key = the smallest start among the records right behind the cut
+        nxt = [((int(b.tid[c]) + 1) << 32) | (int(b.pos[c]) + 1) for b, c in zip(bams, cum[t]) if c < b.n and b.tid[c] >= 0]
+        cut = min(nxt)
+        for b, c in zip(bams, cum[t]):
+            if c == 0:
+                continue
+            ops, ln = b.cig & 0xF, (b.cig >> 4).astype(np.int64)
+            ref = np.where(np.isin(ops, [0, 2, 3, 7, 8]), ln, 0)
+            csum = np.concatenate([[0], np.cumsum(ref)])
+            co = b.cig_off.astype(np.int64)
+            end = b.pos[:c].astype(np.int64) + (csum[co[1:c + 1]] - csum[co[:c]])
+            key_end = ((b.tid[:c].astype(np.int64) + 1) << 32) | end
+            assert int(key_end.max()) < cut                           # nothing before the cut reaches it
+    assert int(rows[-1, 0]) < int(rows[0, 0])                         # consumed records leave the windows

@@ -247,25 +247,6 @@ class Context:
                     "tbk_groups_to_cov_in")
         return DeviceCovView(v, int(v.n_records), int(v.n_cigar_ops))
 
-    def pack_partials(self, collapse_result, first_fidx: int, cig_cap: int, out=None):
-        """tbk_pack_partials: (P [n_groups, 9] int64, cig [n_cig] int32-typed uint32 words) on the device."""
-        torch = _torch()
-        ng = int(collapse_result["n_groups"])
-        bufs = out if out is not None else {}
-        if "P" not in bufs or bufs["P"].shape[0] < max(ng, 1):
-            bufs["P"] = torch.empty((max(ng, 1), 9), dtype=torch.int64, device="cuda:%d" % self.device)
-        if "cig" not in bufs or bufs["cig"].numel() < max(cig_cap, 1):
-            bufs["cig"] = torch.empty(max(cig_cap, 1), dtype=torch.int32, device="cuda:%d" % self.device)
-        if "emax" not in bufs or bufs["emax"].numel() < max(ng, 1):
-            bufs["emax"] = torch.empty(max(ng, 1), dtype=torch.int64, device="cuda:%d" % self.device)
-        n = C.c_uint32(0)
-        self._order_after_torch(True)
-        self._check(self.L.tbk_pack_partials(self.h, C.byref(collapse_result["_soa"]), C.byref(collapse_result["_struct"]),
-                                             int(first_fidx), C.c_void_p(bufs["P"].data_ptr()), C.c_void_p(bufs["cig"].data_ptr()),
-                                             int(bufs["cig"].numel()), C.byref(n), C.c_void_p(bufs["emax"].data_ptr())),
-                    "tbk_pack_partials")
-        return bufs["P"][:ng], bufs["cig"][:int(n.value)], bufs["emax"][:ng]
-
     # ---- multi-GPU: shuffle, then collapse (device side of tiebrush_amd.dist) -------------------
     def _dev(self):
         return "cuda:%d" % self.device

@@ -1632,96 +1632,3 @@ extern "C" int tbk_groups_to_cov_in(tbk_ctx* ctx, const tbk_soa_in* in, const tb
 }
 
 // ---- multi-GPU stitch: pack the groups of one rank into the exchange layout ---------------------------------
-namespace {
-__global__ void pack_partials_k(uint32_t ng, const uint32_t* __restrict__ rep, const double* __restrict__ yc, const int64_t* __restrict__ yx,
-                                const int32_t* __restrict__ yd, const int32_t* __restrict__ effend, const int32_t* __restrict__ tid,
-                                const int32_t* __restrict__ pos, const uint8_t* __restrict__ strand, const uint32_t* __restrict__ cig_off,
-                                const uint32_t* __restrict__ cig, const uint32_t* __restrict__ file_off, uint32_t k, uint32_t first_fidx,
-                                const uint32_t* __restrict__ ooff, int64_t* __restrict__ P, uint32_t* __restrict__ cig_out, uint32_t cig_cap) {
-  uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= ng) return;
-  uint32_t r = rep[o];
-  uint32_t lo = 0, hi = k;
-  while (hi - lo > 1) {
-    uint32_t mid = (lo + hi) >> 1;
-    if (file_off[mid] <= r)
-      lo = mid;
-    else
-      hi = mid;
-  }
-  uint32_t c0 = cig_off[r], c1 = cig_off[r + 1];
-  int64_t* row = P + (size_t)o * TBK_PARTIAL_COLS;
-  row[0] = tid[r];
-  row[1] = pos[r];
-  row[2] = strand[r];
-  row[3] = yx[o];
-  row[4] = yd[o];
-  row[5] = effend[o];
-  row[6] = ((int64_t)(first_fidx + lo) << 32) | (int64_t)(r - file_off[lo]);
-  row[7] = c1 - c0;
-  row[8] = __double_as_longlong(yc[o]);
-  uint32_t d = ooff[o];
-  for (uint32_t q = c0; q < c1; ++q)
-    if (d + (q - c0) < cig_cap) cig_out[d + (q - c0)] = cig[q];
-}
-}  // namespace
-
-namespace {
-struct I64Max {
-  long long v;
-  uint32_t pad0, pad1;
-};
-struct I64MaxOp {
-  __device__ __forceinline__ I64Max operator()(const I64Max& a, const I64Max& b) const { return a.v > b.v ? a : b; }
-};
-struct EmaxLoad {
-  const uint32_t* rep;
-  const int32_t* tid;
-  const int32_t* g_end;
-  __device__ __forceinline__ I64Max operator()(uint32_t o) const {
-    I64Max r;
-    r.v = ((long long)(tid[rep[o]] + 1) << 32) | (long long)(uint32_t)g_end[o];
-    r.pad0 = r.pad1 = 0;
-    return r;
-  }
-};
-struct EmaxStore {
-  int64_t* out;
-  __device__ __forceinline__ void operator()(uint32_t o, const I64Max& inc, const I64Max&) const { out[o] = inc.v; }
-};
-}  // namespace
-
-extern "C" int tbk_pack_partials(tbk_ctx* ctx, const tbk_soa_in* in, const tbk_groups_out* g, uint32_t first_fidx, int64_t* P,
-                                 uint32_t* cig_out, uint32_t cig_cap, uint32_t* n_cig, int64_t* emax_out) {
-  if (emax_out && (!g || !g->g_end)) return TBK_EINVAL;
-  if (!ctx || !in || !g || !P || !n_cig) return TBK_EINVAL;
-  if (in->mem != TBK_MEM_DEVICE || g->mem != TBK_MEM_DEVICE || !g->rep_effend) return TBK_EINVAL;
-  TBK_HIP(hipSetDevice(ctx->device));
-  *n_cig = 0;
-  const uint32_t ng = g->n_groups;
-  if (ng == 0) return 0;
-  TBK_TRY(tbk_ws_reserve(ctx, (size_t)ng * 16 + (size_t)in->n_files * 8 + ((size_t)1 << 20)));
-  uint32_t* cnt = ws_alloc<uint32_t>(ctx, ng);
-  uint32_t* ooff = ws_alloc<uint32_t>(ctx, ng);
-  uint32_t* d_fo = ws_alloc<uint32_t>(ctx, in->n_files + 1);
-  if (!d_fo) return TBK_ENOMEM;
-  const uint32_t B = 256;
-  TBK_HIP(hipMemcpyAsync(d_fo, in->file_off, (size_t)(in->n_files + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-  TBK_LAUNCH(ctx, "g2c_count", g2c_count_k, cdiv(ng, B), B, 0, ng, g->rep, in->cig_off, cnt);
-  TBK_TRY(tbk_exscan_u32(ctx, cnt, ooff, ng, ctx->d_scalars + 20));
-  TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 20, ctx->d_scalars + 20, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-  TBK_HIP(hipStreamSynchronize(ctx->stream));
-  const uint64_t total = ctx->h_scalars[20];
-  if (total > cig_cap) return TBK_E2BIG;
-  *n_cig = (uint32_t)total;
-  TBK_LAUNCH(ctx, "pack_partials", pack_partials_k, cdiv(ng, B), B, 0, ng, g->rep, g->yc, g->yx, g->yd, g->rep_effend, in->tid, in->pos,
-             in->strand, in->cig_off, in->cig, d_fo, in->n_files, first_fidx, ooff, P, cig_out, cig_cap);
-  if (emax_out) {
-    EmaxLoad ld{g->rep, in->tid, g->g_end};
-    EmaxStore st{emax_out};
-    I64Max ident{INT64_MIN, 0u, 0u};
-    TBK_TRY((scan_op_run<I64Max, I64MaxOp, EmaxLoad, EmaxStore>(ctx, "pack_emax_scan", ng, ld, st, I64MaxOp{}, ident)));
-  }
-  TBK_HIP(hipStreamSynchronize(ctx->stream));
-  return tbk_check_launch(ctx, "pack_partials");
-}

@@ -107,19 +107,33 @@ void GSamReader::bopen(const char* filename, int32_t, const char*, int inflate_t
   f_ = std::make_shared<tbh::BamFile>();
   std::string err;
   if (!tbh::bgzf_probe(fname_)) GError("Error: could not open alignment file %s (only BAM input is supported)\n", filename);
-  if (!f_->load(fname_, err, inflate_threads < 1 ? 1 : inflate_threads)) GError("Error: could not open alignment file %s (%s)\n", filename, err.c_str());
+  threads_ = inflate_threads < 1 ? 1 : inflate_threads;
+  // header only: records are inflated on demand (GSamReader::next / TInputFiles::next_tile), the window slides
+  if (!f_->open(fname_, err)) GError("Error: could not open alignment file %s (%s)\n", filename, err.c_str());
   next_ = 0;
+}
+
+// is there a record at next_?  Slides the window: what was handed out is dropped once it is a large share of the window
+bool GSamReader::more() {
+  if (next_ < f_->n()) return true;
+  if (next_ > 0) {
+    f_->consume(next_);
+    next_ = 0;
+  }
+  std::string err;
+  if (!f_->at_eof() && !f_->fill(1, err, threads_)) GError("Error: reading %s failed (%s)\n", fname_.c_str(), err.c_str());
+  return next_ < f_->n();
 }
 
 GSamRecord* GSamReader::next() {
   if (!f_) GError("Warning: GSamReader::next() called with no open file.\n");
-  if (next_ >= f_->n()) return nullptr;
+  if (!more()) return nullptr;
   return new GSamRecord(f_->rec(next_++), &f_->hdr);
 }
 
 bool GSamReader::next(GSamRecord& rec) {
   if (!f_) GError("Warning: GSamReader::next() called with no open file.\n");
-  if (next_ >= f_->n()) return false;
+  if (!more()) return false;
   rec.init(f_->rec(next_++), &f_->hdr);
   return true;
 }

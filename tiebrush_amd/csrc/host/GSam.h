@@ -127,6 +127,8 @@ class GSamReader {
   std::shared_ptr<tbh::BamFile> f_;
   size_t next_ = 0;
   std::string fname_;
+  int threads_ = 1;
+  bool more();
 
  public:
   GSamReader(const char* fn, int32_t required_fields = 0, const char* cram_ref = nullptr, int inflate_threads = 4) {

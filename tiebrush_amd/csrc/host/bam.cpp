@@ -1,5 +1,6 @@
 #include "bam.h"
 
+#include <stdio.h>
 #include <string.h>
 
 #include <sstream>
@@ -337,44 +338,149 @@ int BamRec::del(const char tag[2]) {
   return 0;
 }
 
-bool BamFile::load(const std::string& p, std::string& err, int threads) {
+
+bool BamFile::open(const std::string& p, std::string& err) {
   path = p;
-  if (!bgzf_read_file(p, data, err, threads)) return false;
-  size_t off = 0;
-  if (!hdr.parse(data, &off, err)) {
-    err += " (" + p + ")";
-    return false;
-  }
+  data.clear();
   rec_off.clear();
-  while (off + 4 <= data.size()) {
-    uint32_t bs = rd32(&data[off]);
-    if (bs < 32 || off + 4 + bs > data.size()) {
-      err = "corrupt record in " + p;
+  key_start.clear();
+  pmax_end.clear();
+  file_pos_ = 0;
+  parsed_ = 0;
+  consumed_ = 0;
+  eof_ = false;
+  header_done_ = false;
+  // the header may span several members: inflate until it parses
+  for (;;) {
+    if (!fill(0, err, 1)) return false;
+    if (header_done_) return true;
+    if (eof_) {
+      err = "truncated BAM header (" + p + ")";
       return false;
     }
-    {  // the variable-length fields must lie inside the record and refID inside the header (htslib's bam_read1 rejects the same):
-       // RecView::qname / cigar / aux_begin index by these lengths without further checks
-      const uint8_t* r = &data[off + 4];
-      const int32_t tid = (int32_t)rd32(r);
-      const uint32_t l_read_name = r[8];
-      const uint32_t n_cigar = (uint32_t)r[12] | ((uint32_t)r[13] << 8);
-      const int32_t l_seq = (int32_t)rd32(r + 16);
-      const int32_t mtid = (int32_t)rd32(r + 20);
-      const uint64_t need = 32ull + l_read_name + 4ull * n_cigar + (l_seq < 0 ? 0ull : ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq);
-      const bool name_ok = l_read_name >= 1 && 32 + l_read_name <= bs && r[32 + l_read_name - 1] == 0;
-      if (l_seq < 0 || need > bs || !name_ok || tid < -1 || tid >= hdr.n_targets || mtid < -1 || mtid >= hdr.n_targets) {
-        err = "malformed record " + std::to_string(rec_off.size()) + " in " + p + " (field lengths / reference id outside the record / header)";
-        return false;
-      }
+  }
+}
+
+bool BamFile::load(const std::string& p, std::string& err, int threads) {
+  if (!open(p, err)) return false;
+  while (!at_eof())
+    if (!fill(rec_off.size() + ((size_t)1 << 20), err, threads)) return false;
+  return true;
+}
+
+// index the records that are complete in data[parsed_, ...)
+bool BamFile::index_records(std::string& err) {
+  if (!header_done_) {
+    size_t off = 0;
+    std::string herr;
+    if (!hdr.parse(data, &off, herr)) {
+      if (!eof_) return true;  // not all of it is here yet
+      err = herr + " (" + path + ")";
+      return false;
     }
+    header_done_ = true;
+    parsed_ = off;
+  }
+  size_t off = parsed_;
+  int64_t run = pmax_end.empty() ? INT64_MIN : pmax_end.back();
+  while (off + 4 <= data.size()) {
+    uint32_t bs = rd32(&data[off]);
+    if (bs < 32) {
+      err = "corrupt record in " + path;
+      return false;
+    }
+    if (off + 4 + (size_t)bs > data.size()) break;  // the record continues in the next member
+    // the variable-length fields must lie inside the record and refID inside the header (htslib's bam_read1 rejects the same):
+    // RecView::qname / cigar / aux_begin index by these lengths without further checks
+    const uint8_t* r = &data[off + 4];
+    const int32_t tid = (int32_t)rd32(r);
+    const int32_t pos = (int32_t)rd32(r + 4);
+    const uint32_t l_read_name = r[8];
+    const uint32_t n_cigar = (uint32_t)r[12] | ((uint32_t)r[13] << 8);
+    const uint32_t flag = (uint32_t)r[14] | ((uint32_t)r[15] << 8);
+    const int32_t l_seq = (int32_t)rd32(r + 16);
+    const int32_t mtid = (int32_t)rd32(r + 20);
+    const uint64_t need = 32ull + l_read_name + 4ull * n_cigar + (l_seq < 0 ? 0ull : ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq);
+    const bool name_ok = l_read_name >= 1 && 32 + l_read_name <= bs && r[32 + l_read_name - 1] == 0;
+    if (l_seq < 0 || need > bs || !name_ok || tid < -1 || tid >= hdr.n_targets || mtid < -1 || mtid >= hdr.n_targets) {
+      err = "malformed record " + std::to_string(consumed_ + rec_off.size()) + " in " + path +
+            " (field lengths / reference id outside the record / header)";
+      return false;
+    }
+    // sort key and read end (reference length of the CIGAR: M, D, N, =, X) for the tile cuts of the streaming driver
+    int64_t ks = tid < 0 ? INT64_MAX : (((int64_t)tid + 1) << 32) | (int64_t)(uint32_t)(pos + 1);
+    int64_t ke = ks;
+    if (tid >= 0 && !(flag & 0x4)) {
+      int64_t l = 0;
+      const uint8_t* c = r + 32 + l_read_name;
+      for (uint32_t i = 0; i < n_cigar; ++i) {
+        const uint32_t w = rd32(c + 4 * i);
+        if ((0x18Du >> (w & 0xF)) & 1u) l += w >> 4;
+      }
+      ke = (((int64_t)tid + 1) << 32) | (int64_t)(uint32_t)(pos + (l > 0 ? l : 1));
+    }
+    if (ke > run) run = ke;
     rec_off.push_back(off);
+    key_start.push_back(ks);
+    pmax_end.push_back(run);
     off += 4 + (size_t)bs;
   }
-  if (off != data.size()) {  // trailing bytes that are not a whole record: a truncated file
-    err = "truncated record at the end of " + p;
+  parsed_ = off;
+  if (eof_ && parsed_ != data.size()) {
+    err = "truncated record at the end of " + path;
     return false;
   }
   return true;
+}
+
+bool BamFile::fill(size_t min_records, std::string& err, int threads, size_t chunk_bytes) {
+  const size_t kFillBytes = chunk_bytes < ((size_t)128 << 10) ? ((size_t)128 << 10) : chunk_bytes;  // compressed bytes per read (>= 2 members)
+  std::vector<uint8_t> raw;
+  bool first = true;
+  while (first || (rec_off.size() < min_records && !eof_) || (!header_done_ && !eof_)) {
+    first = false;
+    if (eof_) break;
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) {
+      err = "cannot open " + path;
+      return false;
+    }
+    raw.resize(kFillBytes);
+    if (fseeko(f, (off_t)file_pos_, SEEK_SET) != 0) {
+      fclose(f);
+      err = "cannot seek in " + path;
+      return false;
+    }
+    const size_t got = fread(raw.data(), 1, raw.size(), f);
+    const bool hit_eof = got < raw.size();
+    fclose(f);
+    size_t used = 0;
+    if (!bgzf_inflate_chunk(raw.data(), got, hit_eof, data, &used, err, threads, path)) return false;
+    file_pos_ += used;
+    if (hit_eof) eof_ = true;
+    if (used == 0 && !hit_eof) {
+      err = "BGZF member larger than the read buffer in " + path;
+      return false;
+    }
+    if (!index_records(err)) return false;
+    if (min_records == 0 && header_done_) break;
+  }
+  if (eof_ && !index_records(err)) return false;
+  return true;
+}
+
+void BamFile::consume(size_t nrec) {
+  if (nrec == 0) return;
+  if (nrec > rec_off.size()) nrec = rec_off.size();
+  const size_t cut = nrec == rec_off.size() ? parsed_ : (size_t)rec_off[nrec];
+  consumed_ += nrec;
+  rec_off.erase(rec_off.begin(), rec_off.begin() + (long)nrec);
+  key_start.erase(key_start.begin(), key_start.begin() + (long)nrec);
+  pmax_end.erase(pmax_end.begin(), pmax_end.begin() + (long)nrec);
+  // (pmax_end keeps counting the dropped records: they end before every later cut, so they never decide one)
+  data.erase(data.begin(), data.begin() + (long)cut);
+  for (auto& o : rec_off) o -= cut;
+  parsed_ -= cut;
 }
 
 RecView BamFile::rec(size_t i) const {

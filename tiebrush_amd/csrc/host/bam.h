@@ -72,14 +72,34 @@ struct BamRec {
   int del(const char tag[2]);                       // bam_aux_del(bam_aux_get())
 };
 
+// A BAM file read as a sliding window: open() reads the header, fill() inflates further BGZF members and indexes the
+// records they complete, consume() drops records from the front.  Host memory holds the window, not the file; the file
+// descriptor is only open during a fill() (any number of inputs, whatever RLIMIT_NOFILE says).  Records handed out by
+// rec() are invalidated by the next fill() / consume().
 struct BamFile {
   BamHeader hdr;
-  std::vector<uint8_t> data;      // inflated stream
-  std::vector<uint64_t> rec_off;  // offset of every record's block_size field
+  std::vector<uint8_t> data;      // inflated window (the first record starts at rec_off[0])
+  std::vector<uint64_t> rec_off;  // offset (in data) of every indexed record's block_size field
+  std::vector<int64_t> key_start; // per indexed record: sort key (tid + 1) << 32 | (pos + 1); refID -1 -> INT64_MAX
+  std::vector<int64_t> pmax_end;  // per indexed record: running max over the window of (tid + 1) << 32 | end (1-based inclusive)
   std::string path;
-  bool load(const std::string& path, std::string& err, int threads = 1);
+  bool open(const std::string& path, std::string& err);
+  // inflate until the window holds at least min_records records (or the file ends); false on malformed input
+  bool fill(size_t min_records, std::string& err, int threads = 1, size_t chunk_bytes = (size_t)8 << 20);
+  void consume(size_t n_records);  // drop the first n records of the window
+  bool at_eof() const { return eof_ && parsed_ == data.size(); }
+  bool load(const std::string& path, std::string& err, int threads = 1);  // open + everything (small files, tests)
   size_t n() const { return rec_off.size(); }
   RecView rec(size_t i) const;
+  uint64_t first_index() const { return consumed_; }  // file-wide index of the window's first record
+
+ private:
+  bool index_records(std::string& err);
+  uint64_t file_pos_ = 0;   // next compressed byte to read
+  size_t parsed_ = 0;       // bytes of `data` covered by the header and the indexed records
+  uint64_t consumed_ = 0;   // records dropped so far
+  bool eof_ = false;
+  bool header_done_ = false;
 };
 
 }  // namespace tbh

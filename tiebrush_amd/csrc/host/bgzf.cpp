@@ -34,43 +34,34 @@ struct Member {
   size_t out_off;
 };
 
-bool bgzf_read_file(const std::string& path, std::vector<uint8_t>& out, std::string& err, int threads) {
-  FILE* f = fopen(path.c_str(), "rb");
-  if (!f) {
-    err = "cannot open " + path;
-    return false;
-  }
-  std::vector<uint8_t> raw;
-  fseek(f, 0, SEEK_END);
-  long sz = ftell(f);
-  fseek(f, 0, SEEK_SET);
-  raw.resize(sz > 0 ? (size_t)sz : 0);
-  if (sz > 0 && fread(raw.data(), 1, raw.size(), f) != raw.size()) {
-    fclose(f);
-    err = "short read on " + path;
-    return false;
-  }
-  fclose(f);
+// Inflate the whole BGZF members found in raw[0, n) and append their payload to `out`; *consumed = bytes of `raw` they
+// occupied (a member cut off by the end of the buffer is left for the next call; with at_eof it is an error).
+bool bgzf_inflate_chunk(const uint8_t* raw, size_t n, bool at_eof, std::vector<uint8_t>& out, size_t* consumed, std::string& err,
+                        int threads, const std::string& path) {
   std::vector<Member> mem;
-  size_t off = 0, total = 0;
-  while (off < raw.size()) {
-    if (off + 18 > raw.size() || raw[off] != 0x1f || raw[off + 1] != 0x8b || raw[off + 2] != 8 || !(raw[off + 3] & 4)) {
-      err = "not a BGZF member at offset " + std::to_string(off) + " of " + path;
+  size_t off = 0, total = out.size();
+  *consumed = 0;
+  while (off < n) {
+    if (off + 18 > n) break;  // not even a header: wait for more
+    if (raw[off] != 0x1f || raw[off + 1] != 0x8b || raw[off + 2] != 8 || !(raw[off + 3] & 4)) {
+      err = "not a BGZF member in " + path;
       return false;
     }
     uint16_t xlen = rd16(&raw[off + 10]);
     size_t p = off + 12, end = p + xlen;
+    if (end > n) break;
     int bsize = -1;
-    while (p + 4 <= end && end <= raw.size()) {
+    while (p + 4 <= end) {
       uint16_t slen = rd16(&raw[p + 2]);
       if (raw[p] == 'B' && raw[p + 1] == 'C' && slen == 2) bsize = rd16(&raw[p + 4]);
       p += 4 + slen;
     }
     // member = 12 + xlen bytes of header, the deflate stream, CRC32 + ISIZE (8 bytes): a BSIZE too small for that is corrupt
-    if (bsize < 0 || off + (size_t)bsize + 1 > raw.size() || (size_t)bsize + 1 < (size_t)12 + xlen + 8 || end > raw.size()) {
-      err = "corrupt BGZF member at offset " + std::to_string(off) + " of " + path;
+    if (bsize < 0 || (size_t)bsize + 1 < (size_t)12 + xlen + 8) {
+      err = "corrupt BGZF member in " + path;
       return false;
     }
+    if (off + (size_t)bsize + 1 > n) break;  // the member continues beyond the buffer
     Member m;
     m.off = off;
     m.cdata = off + 12 + xlen;
@@ -78,7 +69,7 @@ bool bgzf_read_file(const std::string& path, std::vector<uint8_t>& out, std::str
     m.isize = rd32(&raw[off + bsize + 1 - 4]);
     m.crc = rd32(&raw[off + bsize + 1 - 8]);
     if (m.isize > 65536) {  // a BGZF block holds at most 64 KiB (SAM spec 4.1)
-      err = "BGZF member with ISIZE > 64 KiB at offset " + std::to_string(off) + " of " + path;
+      err = "BGZF member with ISIZE > 64 KiB in " + path;
       return false;
     }
     m.out_off = total;
@@ -86,6 +77,11 @@ bool bgzf_read_file(const std::string& path, std::vector<uint8_t>& out, std::str
     mem.push_back(m);
     off += (size_t)bsize + 1;
   }
+  if (at_eof && off != n) {
+    err = "truncated BGZF member at the end of " + path;
+    return false;
+  }
+  *consumed = off;
   out.resize(total);
   std::atomic<size_t> next{0};
   std::atomic<bool> ok{true};
@@ -101,7 +97,7 @@ bool bgzf_read_file(const std::string& path, std::vector<uint8_t>& out, std::str
         ok = false;
         break;
       }
-      zs.next_in = raw.data() + m.cdata;
+      zs.next_in = const_cast<uint8_t*>(raw) + m.cdata;
       zs.avail_in = (uInt)m.clen;
       zs.next_out = out.data() + m.out_off;
       zs.avail_out = m.isize;
@@ -124,6 +120,28 @@ bool bgzf_read_file(const std::string& path, std::vector<uint8_t>& out, std::str
     return false;
   }
   return true;
+}
+
+bool bgzf_read_file(const std::string& path, std::vector<uint8_t>& out, std::string& err, int threads) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) {
+    err = "cannot open " + path;
+    return false;
+  }
+  std::vector<uint8_t> raw;
+  fseek(f, 0, SEEK_END);
+  long sz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  raw.resize(sz > 0 ? (size_t)sz : 0);
+  if (sz > 0 && fread(raw.data(), 1, raw.size(), f) != raw.size()) {
+    fclose(f);
+    err = "short read on " + path;
+    return false;
+  }
+  fclose(f);
+  out.clear();
+  size_t used = 0;
+  return bgzf_inflate_chunk(raw.data(), raw.size(), true, out, &used, err, threads, path);
 }
 
 BgzfWriter::~BgzfWriter() {

@@ -13,6 +13,11 @@ namespace tbh {
 // `threads` workers.  Returns false and fills `err` on malformed input.
 bool bgzf_read_file(const std::string& path, std::vector<uint8_t>& out, std::string& err, int threads = 1);
 
+// Streaming form: inflate the whole members inside raw[0, n), appending to `out`; *consumed = compressed bytes used (a member
+// cut off by the end of the buffer waits for the next call unless at_eof).
+bool bgzf_inflate_chunk(const uint8_t* raw, size_t n, bool at_eof, std::vector<uint8_t>& out, size_t* consumed, std::string& err,
+                        int threads, const std::string& path);
+
 // True when the file starts with a BGZF member (gzip magic + BC extra field).
 bool bgzf_probe(const std::string& path);
 

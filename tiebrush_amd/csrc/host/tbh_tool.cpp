@@ -71,6 +71,22 @@ int main(int argc, char** argv) {
     fclose(f);
     return 0;
   }
+  if (cmd == "tiles" && argc >= 4) {  // tiles <target records> files...: one line per streamed tile = records taken from every input
+    TInputFiles in;
+    in.setup("test", 0, nullptr);
+    for (int i = 3; i < argc; ++i) in.addFile(argv[i]);
+    in.start();
+    TInputFiles::TilePlan plan;
+    while (in.next_tile(plan, (size_t)atoll(argv[2]), 4)) {
+      size_t win = 0;
+      for (auto fr : in.freaders) win += fr->samreader->file()->n();
+      printf("%zu", win);  // records resident in the windows when the tile was cut
+      for (size_t f = 0; f < plan.hi.size(); ++f) printf(" %zu", plan.hi[f]);
+      printf("\n");
+      in.release_tile(plan);
+    }
+    return 0;
+  }
   if (cmd == "tags" && argc >= 5) {
     GSamReader rd(argv[2]);
     GSamWriter wr(argv[3], rd.header());
@@ -91,6 +107,6 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
-  fprintf(stderr, "usage: tbh_tool cat|mergeorder|soa|tags ...\n");
+  fprintf(stderr, "usage: tbh_tool cat|mergeorder|soa|tiles|tags ...\n");
   return 2;
 }

@@ -123,9 +123,10 @@ int main(int argc, char* argv[]) {
   int nthreads = (int)std::thread::hardware_concurrency();
   if (nthreads < 1) nthreads = 1;
   if (nthreads > 32) nthreads = 32;
-  // one tile per run of whole reference sequences (exact: nothing the collapse computes crosses a refID, see tmerge.h)
-  size_t tile_records = getenv("TBK_TILE_RECORDS") ? (size_t)atoll(getenv("TBK_TILE_RECORDS")) : ((size_t)256 << 20);
-  std::vector<TInputFiles::TilePlan> plans = inRecords.plan_tiles(tile_records);
+  // The inputs stream through in tiles of about TBK_TILE_RECORDS records, cut where no read of any input reaches across
+  // (TInputFiles::next_tile): exact — nothing the collapse computes crosses such a point — and host memory holds one tile's
+  // window of every input instead of the inflated files (the reference holds one record per input, tmerge.cpp:331-344).
+  size_t tile_records = getenv("TBK_TILE_RECORDS") ? (size_t)atoll(getenv("TBK_TILE_RECORDS")) : ((size_t)64 << 20);
   uint64_t inCounter = 0, outCounter = 0;
   {
     GSamWriter outfile(outfname, inRecords.header(), GSamFile_BAM);
@@ -134,7 +135,10 @@ int main(int argc, char* argv[]) {
     std::vector<double> yc;
     std::vector<int64_t> yx;
     std::vector<int32_t> yd;
-    for (const auto& plan : plans) {
+    TInputFiles::TilePlan plan;
+    size_t n_tiles = 0;
+    while (inRecords.next_tile(plan, tile_records, nthreads)) {
+      ++n_tiles;
       auto t0 = tnow();
       inRecords.load_tile(tile, opt.strategy == TBK_STRAT_FULL, opt.collapse_same != 0, nthreads, &plan);
       auto t1 = tnow();
@@ -197,7 +201,9 @@ int main(int argc, char* argv[]) {
       ms_tag += tms(t2, t3);
       inCounter += out.n_passed;
       outCounter += out.n_groups;
+      inRecords.release_tile(plan);
     }
+    if (timing) fprintf(stderr, "tiles: %zu\n", n_tiles);
   }
   auto t_closed = tnow();
   need_ctx();

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <atomic>
 #include <map>
+#include <mutex>
 #include <thread>
 
 uint64_t tbh_qname_hash(const char* name, int pair_order) {  // FNV-1a, same as tiebrush_amd/soa.py
@@ -251,8 +252,117 @@ tbh::RecView TInputFiles::record(uint32_t gi) const {
   return freaders[f]->samreader->file()->rec(tile_lo_[f] + (gi - tile_off_[f]));
 }
 
+// ---- streaming tiles ---------------------------------------------------------------------------------------------
+bool TInputFiles::next_tile(TilePlan& plan, size_t target_records, int threads) {
+  const size_t k = freaders.size();
+  std::vector<tbh::BamFile*> bf(k);
+  for (size_t f = 0; f < k; ++f) bf[f] = freaders[f]->samreader->file();
+  size_t want = std::max<size_t>(16, target_records / std::max<size_t>(1, k));
+  plan.lo.assign(k, 0);
+  plan.hi.assign(k, 0);
+  plan.n = 0;
+  for (;;) {
+    // 1. every input holds `want` records or has ended (files fill side by side)
+    {
+      std::atomic<size_t> nf{0};
+      std::atomic<bool> ok{true};
+      std::string first_err;
+      std::mutex em;
+      const int per_file = std::max(1, threads / (int)std::max<size_t>(1, std::min<size_t>(k, (size_t)threads)));
+      auto w = [&]() {
+        for (;;) {
+          size_t f = nf.fetch_add(1);
+          if (f >= k) break;
+          std::string err;
+          // (read size ~ what `want` records take compressed, so that many inputs do not each hold megabytes they do not need yet)
+          if (!bf[f]->at_eof() && bf[f]->n() < want && !bf[f]->fill(want, err, per_file, std::min<size_t>((size_t)8 << 20, want * 64))) {
+            std::lock_guard<std::mutex> lk(em);
+            if (ok.exchange(false)) first_err = err;
+          }
+        }
+      };
+      std::vector<std::thread> th;
+      for (size_t t = 0; t < std::min<size_t>(k, (size_t)std::max(1, threads)); ++t) th.emplace_back(w);
+      for (auto& x : th) x.join();
+      if (!ok) GError("Error: reading the input failed (%s)\n", first_err.c_str());
+    }
+    // 2. limit of the tile: the watermark (everything that starts before it has been read from every input) and, where an
+    // input holds more than its share already, the start of its `want`-th record
+    int64_t c0 = INT64_MAX;
+    bool all_eof = true, any = false;
+    for (size_t f = 0; f < k; ++f) {
+      const size_t nf = bf[f]->n();
+      if (nf) any = true;
+      if (nf > want) {
+        c0 = std::min(c0, bf[f]->key_start[want - 1]);
+        all_eof = false;  // (more of this input is waiting: not the final tile)
+      } else if (!bf[f]->at_eof()) {
+        all_eof = false;
+        c0 = nf ? std::min(c0, bf[f]->key_start.back()) : INT64_MIN;
+      }
+    }
+    if (!any && all_eof) return false;
+    // sortedness of what is in the windows (the device checks again per tile; a cut needs it here)
+    for (size_t f = 0; f < k; ++f) {
+      const auto& ks = bf[f]->key_start;
+      for (size_t i = 1; i < ks.size(); ++i)
+        if (ks[i] < ks[i - 1]) GError("Error: %s file not coordinate-sorted!\n", freaders[f]->fname.c_str());
+    }
+    auto below = [&](size_t f, int64_t key) {  // records of file f that start before key
+      const auto& ks = bf[f]->key_start;
+      return (size_t)(std::lower_bound(ks.begin(), ks.end(), key) - ks.begin());
+    };
+    // 3. the last cut at or before the watermark: b is a cut iff no read that starts before b reaches b.  Walk back from
+    // the watermark: if some read crosses b, no point behind the earliest such read's start and up to b can be a cut.
+    int64_t b = all_eof ? INT64_MAX : c0;
+    if (!all_eof) {
+      for (;;) {
+        int64_t first_cross = INT64_MAX;
+        for (size_t f = 0; f < k; ++f) {
+          const size_t nb = below(f, b);
+          if (!nb || bf[f]->pmax_end[nb - 1] < b) continue;  // nothing of this file reaches b
+          // first record whose running max end reaches b: it (or an earlier one with that end) crosses b
+          const auto& pm = bf[f]->pmax_end;
+          const size_t i = (size_t)(std::lower_bound(pm.begin(), pm.begin() + (long)nb, b) - pm.begin());
+          first_cross = std::min(first_cross, bf[f]->key_start[i]);
+        }
+        if (first_cross == INT64_MAX) break;  // b is a cut
+        b = first_cross;
+      }
+    }
+    size_t tot = 0;
+    for (size_t f = 0; f < k; ++f) {
+      plan.hi[f] = b == INT64_MAX ? bf[f]->n() : below(f, b);
+      // unplaced reads (refID -1) sort last and belong to no tile (the GPU build always drops them, tiebrush.cpp:535)
+      const auto& ks = bf[f]->key_start;
+      while (plan.hi[f] > 0 && ks[plan.hi[f] - 1] == INT64_MAX) --plan.hi[f];
+      tot += plan.hi[f];
+    }
+    if (tot > 0 || all_eof) {
+      if (tot == 0) {  // only unplaced reads are left: drop them, done
+        for (size_t f = 0; f < k; ++f) bf[f]->consume(bf[f]->n());
+        return false;
+      }
+      plan.n = tot;
+      plan.tid_lo = plan.tid_hi = 0;
+      return true;
+    }
+    want *= 2;  // no cut inside what is buffered (one bundle spans it): read further
+  }
+}
+
+void TInputFiles::release_tile(const TilePlan& plan) {
+  for (size_t f = 0; f < freaders.size(); ++f) freaders[f]->samreader->file()->consume(plan.hi[f]);
+}
+
 std::vector<TInputFiles::TilePlan> TInputFiles::plan_tiles(size_t max_records) {
   size_t k = freaders.size();
+  for (size_t f = 0; f < k; ++f) {  // (whole inputs in memory: the streaming driver uses next_tile instead)
+    std::string err;
+    tbh::BamFile* b = freaders[f]->samreader->file();
+    while (!b->at_eof())
+      if (!b->fill(b->n() + ((size_t)1 << 20), err, 4)) GError("Error: reading %s failed (%s)\n", freaders[f]->fname.c_str(), err.c_str());
+  }
   int32_t nt = mHdr ? mHdr->n_targets : 0;
   // first[f][t] = index of the first record of file f whose refID is >= t (unmapped-without-position records, refID -1,
   // sort last in a coordinate-sorted BAM and belong to no tile: the GPU build always drops them, tiebrush.cpp:535)
@@ -316,6 +426,11 @@ void TInputFiles::load_tile(TbkTile& t, bool want_md, bool want_qh, int threads,
   bool any_tb = false;
   for (size_t f = 0; f < k; ++f) {
     tbh::BamFile* bf = freaders[f]->samreader->file();
+    if (!plan) {  // no plan = the whole inputs as one tile (small inputs, tests): read them to their end
+      std::string err;
+      while (!bf->at_eof())
+        if (!bf->fill(bf->n() + ((size_t)1 << 20), err, 4)) GError("Error: reading %s failed (%s)\n", freaders[f]->fname.c_str(), err.c_str());
+    }
     lo[f] = plan ? plan->lo[f] : 0;
     hi[f] = plan ? plan->hi[f] : bf->n();
     if ((uint64_t)t.file_off[f] + (hi[f] - lo[f]) >= (1ull << 32)) GError("Error: more than 2^32 records in one tile\n");

@@ -79,7 +79,14 @@ struct TInputFiles {
     std::vector<size_t> lo, hi;      // per input file: record range
     size_t n = 0;
   };
-  std::vector<TilePlan> plan_tiles(size_t max_records);
+  std::vector<TilePlan> plan_tiles(size_t max_records);   // (reads every input to its end first: small inputs, tests)
+  // Streaming form: the next tile of about target_records records, cut at a GLOBAL bundle boundary — a coordinate no read
+  // of any input reaches across — or at a reference change: buckets and groups are whole, the per-sample YD lists provably
+  // clear at such a point (every node ends before the next read starts, tiebrush.cpp:230-241), so tiles collapse
+  // independently and the output is byte-identical to the one-tile run.  Only the windows of the inputs up to the cut are
+  // in memory; release_tile() drops them.  Returns false when every input is exhausted.
+  bool next_tile(TilePlan& plan, size_t target_records, int threads);
+  void release_tile(const TilePlan& plan);
   void load_tile(TbkTile& t, bool want_md, bool want_qname_hash, int threads, const TilePlan* plan = nullptr);
   tbh::RecView record(uint32_t global_index) const;  // raw record behind tile index i
   std::vector<uint32_t> tile_off_;                   // file_off of the last load_tile()
