@@ -109,7 +109,7 @@ void GSamReader::bopen(const char* filename, int32_t, const char*, int inflate_t
   if (!tbh::bgzf_probe(fname_)) GError("Error: could not open alignment file %s (only BAM input is supported)\n", filename);
   threads_ = inflate_threads < 1 ? 1 : inflate_threads;
   // header only: records are inflated on demand (GSamReader::next / TInputFiles::next_tile), the window slides
-  if (!f_->open(fname_, err)) GError("Error: could not open alignment file %s (%s)\n", filename, err.c_str());
+  if (!f_->open(fname_, err, threads_)) GError("Error: could not open alignment file %s (%s)\n", filename, err.c_str());
   next_ = 0;
 }
 
@@ -156,6 +156,10 @@ void GSamWriter::write_raw(const tbh::BamRec& r) {
 
 void GSamWriter::write_framed(const uint8_t* p, size_t n) {
   if (n && !w_.write(p, n)) GError("Error: failed to write alignment records\n");
+}
+
+void GSamWriter::write_members(const uint8_t* z, size_t n) {
+  if (!w_.write_members(z, n)) GError("Error: failed to write alignment records\n");
 }
 
 void GSamWriter::write(GSamRecord* brec) {

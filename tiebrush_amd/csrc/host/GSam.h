@@ -161,4 +161,7 @@ class GSamWriter {
   void write_raw(const tbh::BamRec& r);
   // a run of already framed records (each: little-endian block_size, then the record)
   void write_framed(const uint8_t* p, size_t n);
+  // the same run already deflated into BGZF members by the caller's worker threads (tbh::bgzf_deflate_members)
+  void write_members(const uint8_t* z, size_t n);
+  int level() const { return w_.level(); }
 };

@@ -339,7 +339,7 @@ int BamRec::del(const char tag[2]) {
 }
 
 
-bool BamFile::open(const std::string& p, std::string& err) {
+bool BamFile::open(const std::string& p, std::string& err, int threads) {
   path = p;
   data.clear();
   rec_off.clear();
@@ -352,7 +352,7 @@ bool BamFile::open(const std::string& p, std::string& err) {
   header_done_ = false;
   // the header may span several members: inflate until it parses
   for (;;) {
-    if (!fill(0, err, 1)) return false;
+    if (!fill(0, err, threads)) return false;
     if (header_done_) return true;
     if (eof_) {
       err = "truncated BAM header (" + p + ")";
@@ -362,7 +362,7 @@ bool BamFile::open(const std::string& p, std::string& err) {
 }
 
 bool BamFile::load(const std::string& p, std::string& err, int threads) {
-  if (!open(p, err)) return false;
+  if (!open(p, err, threads)) return false;
   while (!at_eof())
     if (!fill(rec_off.size() + ((size_t)1 << 20), err, threads)) return false;
   return true;

@@ -83,7 +83,7 @@ struct BamFile {
   std::vector<int64_t> key_start; // per indexed record: sort key (tid + 1) << 32 | (pos + 1); refID -1 -> INT64_MAX
   std::vector<int64_t> pmax_end;  // per indexed record: running max over the window of (tid + 1) << 32 | end (1-based inclusive)
   std::string path;
-  bool open(const std::string& path, std::string& err);
+  bool open(const std::string& path, std::string& err, int threads = 1);
   // inflate until the window holds at least min_records records (or the file ends); false on malformed input
   bool fill(size_t min_records, std::string& err, int threads = 1, size_t chunk_bytes = (size_t)8 << 20);
   void consume(size_t n_records);  // drop the first n records of the window

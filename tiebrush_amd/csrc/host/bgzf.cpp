@@ -1,6 +1,7 @@
 #include "bgzf.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
 
@@ -15,6 +16,22 @@ static constexpr size_t kBlock = 0xff00;
 
 static inline uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 static inline uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+int cpu_budget() {
+  int n = (int)std::thread::hardware_concurrency();
+  if (n < 1) n = 1;
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota> <period>" or "max <period>"
+    char q[64];
+    long period = 0;
+    if (fscanf(f, "%63s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+      long quota = atol(q);
+      int c = (int)((quota + period - 1) / period);
+      if (c >= 1 && c < n) n = c;
+    }
+    fclose(f);
+  }
+  return n;
+}
 
 bool bgzf_probe(const std::string& path) {
   FILE* f = fopen(path.c_str(), "rb");
@@ -150,8 +167,8 @@ BgzfWriter::~BgzfWriter() {
 
 bool BgzfWriter::open(const std::string& path, int level, int threads) {
   level_ = level;
-  if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
-  threads_ = threads < 1 ? 1 : (threads > 32 ? 32 : threads);
+  if (threads <= 0) threads = cpu_budget();
+  threads_ = threads < 1 ? 1 : (threads > 128 ? 128 : threads);
   if (path == "-") {
     f_ = stdout;
     own_ = false;
@@ -189,6 +206,26 @@ static bool deflate_member(const uint8_t* src, size_t n, int level, std::vector<
   for (int k = 0; k < 4; ++k) t[k] = (uint8_t)(crc >> (8 * k));
   for (int k = 0; k < 4; ++k) t[4 + k] = (uint8_t)(isz >> (8 * k));
   out.resize(18 + clen + 8);
+  return true;
+}
+
+// src -> whole BGZF members appended to `out` (any byte run may be cut into members anywhere: they are independent streams)
+bool bgzf_deflate_members(const uint8_t* src, size_t n, int level, std::vector<uint8_t>& out) {
+  std::vector<uint8_t> m;
+  for (size_t off = 0; off < n; off += kBlock) {
+    const size_t len = n - off < kBlock ? n - off : kBlock;
+    if (!deflate_member(src + off, len, level, m)) return false;
+    out.insert(out.end(), m.begin(), m.end());
+  }
+  return true;
+}
+
+bool BgzfWriter::write_members(const uint8_t* z, size_t n) {
+  if (!flush_chunk() || !wait_bg()) return false;  // what was written uncompressed so far goes out first, as its own members
+  if (n && fwrite(z, 1, n, f_) != n) {
+    err_ = "write failed";
+    return false;
+  }
   return true;
 }
 

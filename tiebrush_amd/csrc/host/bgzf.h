@@ -18,6 +18,13 @@ bool bgzf_read_file(const std::string& path, std::vector<uint8_t>& out, std::str
 bool bgzf_inflate_chunk(const uint8_t* raw, size_t n, bool at_eof, std::vector<uint8_t>& out, size_t* consumed, std::string& err,
                         int threads, const std::string& path);
 
+// Deflate a byte run into whole BGZF members (<= 0xff00 payload bytes each), appended to `out`.
+bool bgzf_deflate_members(const uint8_t* src, size_t n, int level, std::vector<uint8_t>& out);
+
+// Worker threads worth starting: the hardware concurrency, cut down to the cgroup CPU quota when there is one (a container
+// may show 256 cores and be allowed 16: more threads than that only add throttling).
+int cpu_budget();
+
 // True when the file starts with a BGZF member (gzip magic + BC extra field).
 bool bgzf_probe(const std::string& path);
 
@@ -29,6 +36,9 @@ class BgzfWriter {
   ~BgzfWriter();
   bool open(const std::string& path, int level = 6, int threads = 0 /*0 = hardware concurrency, capped at 32*/);
   bool write(const void* p, size_t n);
+  // already deflated members (bgzf_deflate_members), e.g. produced by worker threads: written as they are, in call order
+  bool write_members(const uint8_t* z, size_t n);
+  int level() const { return level_; }
   bool close();  // flushes and appends the 28-byte EOF block
   const std::string& error() const { return err_; }
 

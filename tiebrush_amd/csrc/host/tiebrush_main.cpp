@@ -8,6 +8,8 @@
 #include <string.h>
 
 #include <string>
+#include <unistd.h>
+
 #include <chrono>
 #include <thread>
 #include <vector>
@@ -15,6 +17,7 @@
 #include "../../../include/tbk.h"
 #include "GSam.h"
 #include "args.h"
+#include "bgzf.h"
 #include "tmerge.h"
 
 #define VERSION "0.0.7"
@@ -118,11 +121,12 @@ int main(int argc, char* argv[]) {
   };
   inRecords.start();
   auto t_ctx = tnow();
-  double ms_load = 0, ms_gpu = 0, ms_tag = 0;
+  double ms_load = 0, ms_gpu = 0, ms_tag = 0, ms_inflate = 0;
 
-  int nthreads = (int)std::thread::hardware_concurrency();
+  int nthreads = tbh::cpu_budget();
   if (nthreads < 1) nthreads = 1;
-  if (nthreads > 32) nthreads = 32;
+  if (nthreads > 128) nthreads = 128;
+  if (const char* e = getenv("TBK_THREADS")) nthreads = std::max(1, atoi(e));
   // The inputs stream through in tiles of about TBK_TILE_RECORDS records, cut where no read of any input reaches across
   // (TInputFiles::next_tile): exact — nothing the collapse computes crosses such a point — and host memory holds one tile's
   // window of every input instead of the inflated files (the reference holds one record per input, tmerge.cpp:331-344).
@@ -137,7 +141,11 @@ int main(int argc, char* argv[]) {
     std::vector<int32_t> yd;
     TInputFiles::TilePlan plan;
     size_t n_tiles = 0;
-    while (inRecords.next_tile(plan, tile_records, nthreads)) {
+    for (;;) {
+      auto ti = tnow();
+      const bool more = inRecords.next_tile(plan, tile_records, nthreads);
+      ms_inflate += tms(ti, tnow());
+      if (!more) break;
       ++n_tiles;
       auto t0 = tnow();
       inRecords.load_tile(tile, opt.strategy == TBK_STRAT_FULL, opt.collapse_same != 0, nthreads, &plan);
@@ -166,10 +174,11 @@ int main(int argc, char* argv[]) {
       {
         const uint32_t ng = out.n_groups;
         const int nt = ng < 4096 ? 1 : nthreads;
-        std::vector<std::vector<uint8_t>> runs((size_t)nt);
+        std::vector<std::vector<uint8_t>> runs((size_t)nt);   // per slice: its records, tagged, framed and deflated into BGZF members
+        const int level = outfile.level();
         auto tag_slice = [&](int t) {
           const uint32_t g0 = (uint32_t)((uint64_t)ng * t / nt), g1 = (uint32_t)((uint64_t)ng * (t + 1) / nt);
-          std::vector<uint8_t>& o = runs[(size_t)t];
+          std::vector<uint8_t> o;
           tbh::BamRec rr;
           for (uint32_t g = g0; g < g1; ++g) {
             tbh::RecView v = inRecords.record(rep[g]);
@@ -185,6 +194,8 @@ int main(int argc, char* argv[]) {
             o.insert(o.end(), le, le + 4);
             o.insert(o.end(), rr.d.begin(), rr.d.end());
           }
+          // BGZF members are independent deflate streams: the slice compresses itself, the writer only appends
+          if (!tbh::bgzf_deflate_members(o.data(), o.size(), level, runs[(size_t)t])) GError("Error: deflate failed\n");
         };
         if (nt == 1) {
           tag_slice(0);
@@ -193,7 +204,7 @@ int main(int argc, char* argv[]) {
           for (int t = 0; t < nt; ++t) th.emplace_back(tag_slice, t);
           for (auto& x : th) x.join();
         }
-        for (auto& o : runs) outfile.write_framed(o.data(), o.size());
+        for (auto& z : runs) outfile.write_members(z.data(), z.size());
       }
       auto t3 = tnow();
       ms_load += tms(t0, t1);
@@ -207,12 +218,13 @@ int main(int argc, char* argv[]) {
   }
   auto t_closed = tnow();
   need_ctx();
-  inRecords.stop();
-  tbk_destroy(ctx);
+  // (no tbk_destroy / stop: the process ends below, the OS reclaims device and host memory faster than piecewise frees)
   if (timing)
-    fprintf(stderr, "timing ms: open+context %.1f | decode+SoA %.1f | collapse (PCIe incl.) %.1f | tag+queue %.1f | total to writer close %.1f\n",
-            tms(t_start, t_ctx), ms_load, ms_gpu, ms_tag, tms(t_start, t_closed));
+    fprintf(stderr, "timing ms: open+context %.1f | inflate+index %.1f | SoA %.1f | collapse (PCIe incl.) %.1f | tag+queue %.1f | total to writer close %.1f\n",
+            tms(t_start, t_ctx), ms_inflate, ms_load, ms_gpu, ms_tag, tms(t_start, t_closed));
   double p = 100.00 - (double)(outCounter * 100.00) / (double)inCounter;
   GMessage("%ld input records written as %ld (%.2f%% reduction)\n", (long)inCounter, (long)outCounter, p);
-  return 0;
+  fflush(stdout);
+  fflush(stderr);
+  _exit(0);  // the output is closed and flushed: skip the runtime's teardown of a process that is done (tens of ms of hipFree / unload)
 }

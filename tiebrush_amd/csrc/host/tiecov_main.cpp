@@ -39,7 +39,7 @@ static bool ends_with(const std::string& s, const char* suf) {
 // reference) and written in order.
 template <class F>
 static void emit_lines(FILE* f, uint32_t n, F fmt) {
-  unsigned hw = std::thread::hardware_concurrency();
+  unsigned hw = (unsigned)tbh::cpu_budget();
   size_t nt = n < 50000 ? 1 : std::max<size_t>(1, std::min<size_t>(hw ? hw : 4, 32));
   std::vector<std::string> parts(nt);
   auto work = [&](size_t t) {
@@ -160,7 +160,7 @@ int main(int argc, char* argv[]) {
   cig.resize(ops);
   uint64_t co = ops;
   {
-    unsigned hw = std::thread::hardware_concurrency();
+    unsigned hw = (unsigned)tbh::cpu_budget();
     size_t nt = std::max<size_t>(1, std::min<size_t>(hw ? hw : 4, 32));
     if (n < 100000) nt = 1;
     auto work = [&](size_t lo, size_t hi) {

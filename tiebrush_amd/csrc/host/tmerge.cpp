@@ -207,9 +207,9 @@ int TInputFiles::start() {  // tmerge.cpp:287-329
   {
     std::vector<GSamReader*> rds(freaders.size(), nullptr);
     std::atomic<size_t> nf{0};
-    unsigned hw = std::thread::hardware_concurrency();
-    size_t nt = std::min<size_t>(freaders.size(), hw ? std::min<unsigned>(hw, 64) : 4);
-    int per_file = (int)std::max<size_t>(1, (hw ? std::min<unsigned>(hw, 64) : 4) / std::max<size_t>(1, nt));
+    unsigned hw = (unsigned)tbh::cpu_budget();
+    size_t nt = std::min<size_t>(freaders.size(), hw ? std::min<unsigned>(hw, 128) : 4);
+    int per_file = (int)std::max<size_t>(1, (hw ? std::min<unsigned>(hw, 128) : 4) / std::max<size_t>(1, nt));
     auto w = [&]() {
       for (;;) {
         size_t i = nf.fetch_add(1);
@@ -441,17 +441,27 @@ void TInputFiles::load_tile(TbkTile& t, bool want_md, bool want_qh, int threads,
   tile_off_ = t.file_off;
   tile_lo_ = lo;
   size_t n = t.file_off[k];
-  // pass 1: CIGAR / MD sizes per file
-  std::vector<uint64_t> ncig(k, 0), nmd(k, 0), nqn(k, 0);
+  // The work is cut into tasks of at most kTask consecutive records of one file, so that a few large inputs still occupy
+  // every worker.  pass 1: CIGAR / MD / name sizes per task -> where each task writes
+  constexpr size_t kTask = (size_t)1 << 16;
+  struct Task {
+    size_t f, a, b;          // file, record range inside the window
+    uint64_t co, mo, qo;     // bases of its CIGAR words / MD bytes / name bytes
+  };
+  std::vector<Task> tasks;
+  for (size_t f = 0; f < k; ++f)
+    for (size_t a = lo[f]; a < hi[f]; a += kTask) tasks.push_back(Task{f, a, std::min(hi[f], a + kTask), 0, 0, 0});
+  std::vector<uint64_t> ncig(tasks.size(), 0), nmd(tasks.size(), 0), nqn(tasks.size(), 0);
   {
     std::atomic<size_t> nf{0};
     auto w = [&]() {
       for (;;) {
-        size_t f = nf.fetch_add(1);
-        if (f >= k) break;
-        tbh::BamFile* bf = freaders[f]->samreader->file();
+        size_t ti = nf.fetch_add(1);
+        if (ti >= tasks.size()) break;
+        const Task& T = tasks[ti];
+        tbh::BamFile* bf = freaders[T.f]->samreader->file();
         uint64_t c = 0, m = 0, q = 0;
-        for (size_t i = lo[f]; i < hi[f]; ++i) {
+        for (size_t i = T.a; i < T.b; ++i) {
           tbh::RecView v = bf->rec(i);
           c += v.n_cigar();
           if (want_qh) q += strlen(v.qname());
@@ -460,19 +470,28 @@ void TInputFiles::load_tile(TbkTile& t, bool want_md, bool want_qh, int threads,
             if (s && *s == 'Z') m += strlen((const char*)s + 1);
           }
         }
-        ncig[f] = c;
-        nmd[f] = m;
-        nqn[f] = q;
+        ncig[ti] = c;
+        nmd[ti] = m;
+        nqn[ti] = q;
       }
     };
     std::vector<std::thread> th;
-    for (int i = 0; i < std::max(1, threads); ++i) th.emplace_back(w);
+    for (int i = 0; i < std::max(1, std::min<int>(threads, (int)tasks.size())); ++i) th.emplace_back(w);
     for (auto& x : th) x.join();
   }
-  for (size_t f = 0; f < k; ++f) {
-    cig_base[f + 1] = cig_base[f] + ncig[f];
-    md_base[f + 1] = md_base[f] + nmd[f];
-    qn_base[f + 1] = qn_base[f] + nqn[f];
+  {
+    uint64_t c = 0, m = 0, q = 0;
+    for (size_t ti = 0; ti < tasks.size(); ++ti) {
+      tasks[ti].co = c;
+      tasks[ti].mo = m;
+      tasks[ti].qo = q;
+      c += ncig[ti];
+      m += nmd[ti];
+      q += nqn[ti];
+    }
+    cig_base[k] = c;
+    md_base[k] = m;
+    qn_base[k] = q;
   }
   if (cig_base[k] >= (1ull << 32)) GError("Error: more than 2^32 CIGAR operations in one tile\n");
   if (md_base[k] >= (1ull << 32)) GError("Error: more than 2^32 bytes of MD tags in one tile\n");  // md_off is 32-bit too
@@ -507,13 +526,15 @@ void TInputFiles::load_tile(TbkTile& t, bool want_md, bool want_qh, int threads,
   std::atomic<size_t> nf{0};
   auto w = [&]() {
     for (;;) {
-      size_t f = nf.fetch_add(1);
-      if (f >= k) break;
+      size_t ti = nf.fetch_add(1);
+      if (ti >= tasks.size()) break;
+      const Task& T = tasks[ti];
+      const size_t f = T.f;
       tbh::BamFile* bf = freaders[f]->samreader->file();
-      uint64_t co = cig_base[f], mo = md_base[f], qo = qn_base[f];
-      size_t g = t.file_off[f];
+      uint64_t co = T.co, mo = T.mo, qo = T.qo;
+      size_t g = t.file_off[f] + (T.a - lo[f]);
       bool tb = t.tbmerged[f] != 0;
-      for (size_t i = lo[f]; i < hi[f]; ++i, ++g) {
+      for (size_t i = T.a; i < T.b; ++i, ++g) {
         tbh::RecView v = bf->rec(i);
         t.tid[g] = v.tid();
         t.pos[g] = v.pos();
@@ -580,6 +601,6 @@ void TInputFiles::load_tile(TbkTile& t, bool want_md, bool want_qh, int threads,
     }
   };
   std::vector<std::thread> th;
-  for (int i = 0; i < std::max(1, threads); ++i) th.emplace_back(w);
+  for (int i = 0; i < std::max(1, std::min<int>(threads, (int)tasks.size())); ++i) th.emplace_back(w);
   for (auto& x : th) x.join();
 }
