@@ -223,6 +223,29 @@ int tbk_sample_tile(tbk_ctx* ctx, const tbk_cov_in* in, int32_t num_samples, tbk
  * device memory.  The returned view is valid until the next call on `ctx`. */
 int tbk_groups_to_cov_in(tbk_ctx* ctx, const tbk_soa_in* in, const tbk_groups_out* groups, tbk_cov_in* view);
 
+/* ---- BGZF / BAM decode on the device ---------------------------------------------------------------
+ * What GSamReader::next() -> sam_read1() (GSam.h:506-516; htslib bgzf_read_block + inflate) does on the host. */
+
+/* Inflate a run of whole BGZF members (`comp`, host memory: gzip members with the BC extra field, raw deflate, <= 64 KiB
+ * payload each) into `out` (host, or device when mem == TBK_MEM_DEVICE).  One GPU lane per member; ISIZE and CRC32 of
+ * every member are verified.  *out_bytes = payload size; TBK_E2BIG (with *out_bytes set) when out_cap is too small,
+ * TBK_EINVAL for anything htslib would reject. */
+int tbk_bgzf_inflate(tbk_ctx* ctx, const uint8_t* comp, uint64_t comp_bytes, uint8_t* out, uint64_t out_cap, uint64_t* out_bytes, int mem);
+
+/* Decode whole BAM files on the device: comp[f] / comp_bytes[f] = the BGZF members of input file f (host memory, the 28-byte
+ * EOF member may be included).  Inflate, BAM header skip, record index, field validation (what htslib's bam_read1 rejects is
+ * TBK_EINVAL) and the aux scan of the host loader (NH; XS / ts -> spliceStrand, GSam.cpp:464-475; carried YC / YX / YD of
+ * the files flagged in tbmerged; MD with want_md; QNAME + its hash with want_names) run as kernels; *tile describes a
+ * DEVICE-resident tile in context-owned memory (valid until tbk_bam_release or the next tbk_bam_decode), ready for
+ * tbk_collapse_tile; file_off_out[n_files + 1] (host, caller's) receives the record ranges and is what tile->file_off
+ * points to.  The inflated records stay on the device for tbk_bam_records. */
+int tbk_bam_decode(tbk_ctx* ctx, uint32_t n_files, const uint8_t* const* comp, const uint64_t* comp_bytes, const uint8_t* tbmerged,
+                   int want_md, int want_names, tbk_soa_in* tile, uint32_t* file_off_out);
+/* The raw records (block_size field first, as in the BAM stream) behind n tile indices (idx in idx_mem), packed in that
+ * order into `out` (host); out_off[n + 1] (host) = their byte offsets.  TBK_E2BIG with out_off[n] = needed bytes. */
+int tbk_bam_records(tbk_ctx* ctx, const uint32_t* idx, uint32_t n, int idx_mem, uint8_t* out, uint64_t out_cap, uint64_t* out_off);
+void tbk_bam_release(tbk_ctx* ctx);
+
 /* ---- Multi-GPU: shuffle, then collapse (the reference has no counterpart — its only parallelism is
  * tiewrap.py:96-126, batches of files re-collapsed hierarchically).  Every rank holds some input files; the ranks agree
  * on coordinate cuts no read spans, every passing record moves to the rank owning its range, and that rank runs the

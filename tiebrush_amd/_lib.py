@@ -22,7 +22,7 @@ STATUS = {0: "TBK_OK", -1: "TBK_EINVAL", -2: "TBK_ENOMEM", -3: "TBK_EHIP", -4: "
 SYMBOLS = ["tbk_abi_version", "tbk_create", "tbk_destroy", "tbk_strerror", "tbk_last_error", "tbk_set_stream",
            "tbk_get_stream", "tbk_set_profiling", "tbk_kernel_times", "tbk_host_alloc", "tbk_host_free",
            "tbk_collapse_opts_default", "tbk_collapse_tile", "tbk_collapse_finish_yd", "tbk_coverage_tile", "tbk_sample_tile",
-           "tbk_groups_to_cov_in", "tbk_shard_prepare", "tbk_shard_probe_max", "tbk_shard_probe_next",
+           "tbk_groups_to_cov_in", "tbk_bgzf_inflate", "tbk_bam_decode", "tbk_bam_records", "tbk_bam_release", "tbk_shard_prepare", "tbk_shard_probe_max", "tbk_shard_probe_next",
            "tbk_shard_pack", "tbk_shard_unpack"]
 
 
@@ -110,6 +110,11 @@ def load():
     L.tbk_coverage_tile.argtypes = [_P, C.POINTER(CovIn), C.POINTER(CovOut)]
     L.tbk_sample_tile.argtypes = [_P, C.POINTER(CovIn), C.c_int32, C.POINTER(SampleOut)]
     L.tbk_groups_to_cov_in.argtypes = [_P, C.POINTER(SoaIn), C.POINTER(GroupsOut), C.POINTER(CovIn)]
+    L.tbk_bgzf_inflate.argtypes = [_P, _P, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64), C.c_int]
+    L.tbk_bam_decode.argtypes = [_P, C.c_uint32, _P, _P, _P, C.c_int, C.c_int, C.POINTER(SoaIn), _P]
+    L.tbk_bam_records.argtypes = [_P, _P, C.c_uint32, C.c_int, _P, C.c_uint64, _P]
+    L.tbk_bam_release.argtypes = [_P]
+    L.tbk_bam_release.restype = None
     L.tbk_shard_prepare.argtypes = [_P, C.POINTER(CollapseOpts), C.POINTER(SoaIn), _P, _P, _P, _P]
     L.tbk_shard_probe_max.argtypes = [_P, _P, C.c_uint32, _P, _P, _P, C.c_uint32, _P]
     L.tbk_shard_probe_next.argtypes = [_P, _P, C.c_uint32, _P, _P, C.c_uint32, _P]

@@ -247,6 +247,97 @@ class Context:
                     "tbk_groups_to_cov_in")
         return DeviceCovView(v, int(v.n_records), int(v.n_cigar_ops))
 
+    # ---- BGZF on the device -------------------------------------------------------------------------
+    def bgzf_inflate(self, comp: bytes) -> bytes:
+        """tbk_bgzf_inflate: whole BGZF members -> their payload (host bytes in, host bytes out)"""
+        src = np.frombuffer(comp, dtype=np.uint8)
+        need = C.c_uint64(0)
+        out = np.empty(max(1, 4 * len(src) + 65536), dtype=np.uint8)
+        rc = self.L.tbk_bgzf_inflate(self.h, src.ctypes.data, len(src), out.ctypes.data, out.size, C.byref(need), _lib.TBK_MEM_HOST)
+        if rc == -4:    # TBK_E2BIG: the call reported the size
+            out = np.empty(int(need.value), dtype=np.uint8)
+            rc = self.L.tbk_bgzf_inflate(self.h, src.ctypes.data, len(src), out.ctypes.data, out.size, C.byref(need), _lib.TBK_MEM_HOST)
+        self._check(rc, "tbk_bgzf_inflate")
+        return out[:int(need.value)].tobytes()
+
+    def bam_decode(self, files, tbmerged=None, want_md=False, want_names=False):
+        """tbk_bam_decode: list of whole BAM files (bytes) -> (SoaIn struct describing the device-resident tile, file_off).
+        The struct can go straight to collapse_struct(); its arrays live in the context until bam_release()."""
+        k = len(files)
+        bufs = [np.frombuffer(f, dtype=np.uint8) for f in files]
+        ptrs = (C.c_void_p * k)(*[b.ctypes.data for b in bufs])
+        sizes = np.array([len(b) for b in bufs], dtype=np.uint64)
+        tb = np.ascontiguousarray(tbmerged if tbmerged is not None else np.zeros(k, np.uint8), dtype=np.uint8)
+        fo = np.zeros(k + 1, dtype=np.uint32)
+        s = _lib.SoaIn()
+        self._check(self.L.tbk_bam_decode(self.h, k, ptrs, sizes.ctypes.data, tb.ctypes.data, int(want_md), int(want_names), C.byref(s),
+                                          fo.ctypes.data), "tbk_bam_decode")
+        self._bam_keep = (bufs, tb, fo)
+        return s, fo
+
+    def bam_records(self, idx):
+        """tbk_bam_records: (bytes of the packed records, offsets [n+1])"""
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        n = len(idx)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        out = np.empty(max(1, 512 * n), dtype=np.uint8)
+        rc = self.L.tbk_bam_records(self.h, idx.ctypes.data, n, _lib.TBK_MEM_HOST, out.ctypes.data, out.size, off.ctypes.data)
+        if rc == -4:
+            out = np.empty(int(off[n]), dtype=np.uint8)
+            rc = self.L.tbk_bam_records(self.h, idx.ctypes.data, n, _lib.TBK_MEM_HOST, out.ctypes.data, out.size, off.ctypes.data)
+        self._check(rc, "tbk_bam_records")
+        return out[:int(off[n])].tobytes(), off
+
+    def bam_release(self):
+        self.L.tbk_bam_release(self.h)
+
+    def soa_to_numpy(self, s, fields=("tid", "pos", "flag", "mapq", "strand", "nh", "cig_off", "cig")):
+        """copy arrays of a device-resident SoaIn (bam_decode) to numpy (tests)"""
+        import ctypes
+        torch = _torch()
+        n, nc = int(s.n_records), int(s.n_cigar_ops)
+        spec = {"tid": (np.int32, n), "pos": (np.int32, n), "flag": (np.uint16, n), "mapq": (np.uint8, n), "strand": (np.uint8, n),
+                "nh": (np.int32, n), "cig_off": (np.uint32, n + 1), "cig": (np.uint32, nc), "yc_in": (np.float64, n), "yx_in": (np.int64, n),
+                "yd_in": (np.int64, n), "md_off": (np.uint32, n + 1), "md_has": (np.uint8, n), "qname_hash": (np.uint64, n),
+                "qname_off": (np.uint32, n + 1)}
+        out = {}
+        hip = ctypes.CDLL("libamdhip64.so")
+        for name in fields:
+            dt, cnt = spec[name]
+            a = np.empty(cnt, dtype=dt)
+            ptr = getattr(s, name)
+            if cnt and ptr:
+                assert hip.hipMemcpy(C.c_void_p(a.ctypes.data), C.c_void_p(ptr), C.c_size_t(a.nbytes), 2) == 0
+            out[name] = a
+        for name, offname in (("md", "md_off"), ("qname", "qname_off")):
+            if offname in out and getattr(s, name):
+                cnt = int(out[offname][-1])
+                a = np.empty(cnt, dtype=np.uint8)
+                if cnt:
+                    assert hip.hipMemcpy(C.c_void_p(a.ctypes.data), C.c_void_p(getattr(s, name)), C.c_size_t(cnt), 2) == 0
+                out[name] = a
+        return out
+
+    def collapse_struct(self, s, n_files, **kw):
+        """collapse a tile given as a raw SoaIn struct on the device (bam_decode); returns the usual dict (torch tensors)"""
+        torch = _torch()
+        o = self.make_opts(**kw)
+        n = int(s.n_records)
+        cap = max(n, 1)
+        dev = "cuda:%d" % self.device
+        rep = torch.empty(cap, dtype=torch.int32, device=dev)
+        yc = torch.empty(cap, dtype=torch.float64, device=dev)
+        yx = torch.empty(cap, dtype=torch.int64, device=dev)
+        yd = torch.empty(cap, dtype=torch.int32, device=dev)
+        gs = torch.empty(cap, dtype=torch.int32, device=dev)
+        ge = torch.empty(cap, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        g = _lib.GroupsOut(_lib.TBK_MEM_DEVICE, cap, rep.data_ptr(), yc.data_ptr(), yx.data_ptr(), yd.data_ptr(), gs.data_ptr(), ge.data_ptr(),
+                           None, None, 0, 0)
+        self._check(self.L.tbk_collapse_tile(self.h, C.byref(o), C.byref(s), C.byref(g)), "tbk_collapse_tile")
+        m = int(g.n_groups)
+        return dict(n_groups=m, n_passed=int(g.n_passed), rep=rep[:m], yc=yc[:m], yx=yx[:m], yd=yd[:m], g_start=gs[:m], g_end=ge[:m])
+
     # ---- multi-GPU: shuffle, then collapse (device side of tiebrush_amd.dist) -------------------
     def _dev(self):
         return "cuda:%d" % self.device

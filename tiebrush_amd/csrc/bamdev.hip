@@ -1,0 +1,1038 @@
+// bamdev.hip — BGZF inflate and BAM record decode on gfx950: what GSamReader::next() -> sam_read1() does per record on the
+// host (/root/reference/src/GSam.h:506-516, htslib bgzf_read_block + bam_read1) done for whole files at once on the device.
+//
+//   tbk_bam_decode    compressed BGZF members of k files (host memory) -> device-resident SoA tile (tbk_soa_in, TBK_MEM_DEVICE)
+//     bgz_inflate_k     one lane per BGZF member (members are independent raw-deflate streams of <= 64 KiB): RFC 1951 decoder
+//                       with canonical-code tables in LDS (count per length + symbols in code order), byte-exact LZ77 window
+//                       in the member's own output; CRC32 and ISIZE of every member are verified like htslib does
+//     bam_index_k       one workgroup per file walks the record chain (block_size -> next record) through LDS-staged chunks
+//     bam_fields_k      one thread per record: core fields, the aux scan of the host loader (NH, XS / ts -> spliceStrand,
+//                       carried YC / YX / YD of TieBrush-merged inputs, MD and QNAME sizes), field-length validation
+//     bam_fill_k        CIGAR words, MD bytes, names + name hash at the offsets the scans produced
+//   tbk_bam_gather    the raw records behind tile indices (the representatives), packed, to host memory for tagging
+//
+// Integer / byte work; the inflate is bound by its dependent bit-serial decode (every member in flight at once hides it:
+// ~30 k members on 256 CUs), not by HBM.  No MFMA.
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "dev_common.cuh"
+#include "tbk_internal.h"
+
+namespace {
+
+// ---- RFC 1951 inflate, one lane per member ------------------------------------------------------------------------
+constexpr int INF_NT = 64;           // one wave per block: 64 members
+constexpr int INF_TAB = 16 + 288 + 16 + 32;  // u16 per lane: lencnt[16] lensym[288] distcnt[16] distsym[32]
+
+struct BitIn {
+  const uint8_t* p;
+  const uint8_t* end;
+  uint64_t buf;
+  int cnt;
+  bool bad;
+  __device__ __forceinline__ void fill() {
+    while (cnt <= 56) {
+      uint64_t b = 0;
+      if (p < end)
+        b = *p;
+      ++p;  // past the end: zeros flow in; `bad` is raised when more than 8 bytes beyond the end are consumed
+      buf |= b << cnt;
+      cnt += 8;
+    }
+  }
+  __device__ __forceinline__ uint32_t bits(int n) {  // n <= 32
+    if (cnt < n) fill();
+    const uint32_t v = (uint32_t)(buf & ((1ull << n) - 1ull));
+    buf >>= n;
+    cnt -= n;
+    return v;
+  }
+  __device__ __forceinline__ bool overrun() const { return p > end + 8; }
+};
+
+__constant__ uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__constant__ uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__constant__ uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__constant__ uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// canonical Huffman table from code lengths (puff.c's construct): cnt[len] = codes of that length, sym = symbols in code
+// order.  Returns < 0 for an over-subscribed set, > 0 for an incomplete one, 0 for a complete one.
+__device__ int huff_build(uint16_t* cnt, uint16_t* sym, const uint8_t* lens, int n) {
+  for (int l = 0; l <= 15; ++l) cnt[l] = 0;
+  for (int s = 0; s < n; ++s) cnt[lens[s]]++;
+  if (cnt[0] == n) return 0;  // no codes: complete, but decoding will fail
+  int left = 1;
+  for (int l = 1; l <= 15; ++l) {
+    left <<= 1;
+    left -= cnt[l];
+    if (left < 0) return left;
+  }
+  uint16_t offs[16];
+  offs[1] = 0;
+  for (int l = 1; l < 15; ++l) offs[l + 1] = offs[l] + cnt[l];
+  for (int s = 0; s < n; ++s)
+    if (lens[s] != 0) sym[offs[lens[s]]++] = (uint16_t)s;
+  return left;
+}
+
+__device__ __forceinline__ int huff_decode(BitIn& in, const uint16_t* cnt, const uint16_t* sym) {
+  int code = 0, first = 0, index = 0;
+  if (in.cnt < 15) in.fill();
+  uint32_t bitbuf = (uint32_t)in.buf;
+  for (int len = 1; len <= 15; ++len) {
+    code |= (int)(bitbuf & 1u);
+    bitbuf >>= 1;
+    const int count = cnt[len];
+    if (code - count < first) {
+      in.buf >>= len;
+      in.cnt -= len;
+      return sym[index + (code - first)];
+    }
+    index += count;
+    first += count;
+    first <<= 1;
+    code <<= 1;
+  }
+  return -1;
+}
+
+struct BgzMember {
+  uint64_t src;   // offset of the deflate stream in the compressed buffer
+  uint64_t dst;   // offset of the member's payload in the inflated buffer
+  uint32_t clen;  // deflate bytes
+  uint32_t isize; // payload bytes
+  uint32_t crc;   // CRC32 of the payload
+  uint32_t file;
+};
+
+__global__ __launch_bounds__(INF_NT) void bgz_inflate_k(uint32_t nmem, const BgzMember* __restrict__ mem, const uint8_t* __restrict__ src,
+                                                        uint8_t* __restrict__ dst, uint32_t flags, unsigned long long* __restrict__ dbg, uint32_t* __restrict__ err) {
+  __shared__ uint16_t tab[INF_NT * INF_TAB];
+  __shared__ uint32_t crct[4][256];
+  for (uint32_t i = threadIdx.x; i < 256; i += INF_NT) {  // CRC-32 (IEEE, reflected), slicing-by-4 tables
+    uint32_t c = i;
+    for (int k = 0; k < 8; ++k) c = (c & 1u) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
+    crct[0][i] = c;
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < 256; i += INF_NT) {
+    uint32_t c = crct[0][i];
+    for (int t = 1; t < 4; ++t) {
+      c = crct[0][c & 0xFFu] ^ (c >> 8);
+      crct[t][i] = c;
+    }
+  }
+  __syncthreads();
+  const uint32_t m = blockIdx.x * INF_NT + threadIdx.x;
+  if (m >= nmem) return;
+  const BgzMember M = mem[m];
+  uint16_t* lencnt = tab + threadIdx.x * INF_TAB;
+  uint16_t* lensym = lencnt + 16;
+  uint16_t* distcnt = lensym + 288;
+  uint16_t* distsym = distcnt + 16;
+  BitIn in;
+  in.p = src + M.src;
+  in.end = in.p + M.clen;
+  in.buf = 0;
+  in.cnt = 0;
+  in.bad = false;
+  uint8_t* out = dst + M.dst;
+  uint32_t o = 0;
+  const uint32_t cap = M.isize;
+  bool bad = false;
+  unsigned long long t_build = 0, t_dec = 0, t_copy = 0, t_lit = 0, n_sym = 0, n_copy = 0, t_all = __builtin_readcyclecounter();
+  for (;;) {
+    const uint32_t last = in.bits(1);
+    const uint32_t type = in.bits(2);
+    if (type == 0) {  // stored
+      in.buf >>= (in.cnt & 7);
+      in.cnt -= (in.cnt & 7);
+      const uint32_t len = in.bits(16), nlen = in.bits(16);
+      if ((len ^ 0xFFFFu) != nlen || o + len > cap) {
+        bad = true;
+        break;
+      }
+      for (uint32_t i = 0; i < len; ++i) out[o++] = (uint8_t)in.bits(8);
+    } else if (type == 3) {
+      bad = true;
+      break;
+    } else {
+      unsigned long long tb0 = __builtin_readcyclecounter();
+      if (type == 1) {  // fixed codes
+        uint8_t lens[288];
+        for (int s = 0; s < 144; ++s) lens[s] = 8;
+        for (int s = 144; s < 256; ++s) lens[s] = 9;
+        for (int s = 256; s < 280; ++s) lens[s] = 7;
+        for (int s = 280; s < 288; ++s) lens[s] = 8;
+        huff_build(lencnt, lensym, lens, 288);
+        for (int s = 0; s < 30; ++s) lens[s] = 5;
+        huff_build(distcnt, distsym, lens, 30);
+      } else {  // dynamic codes
+        const int nlen = (int)in.bits(5) + 257, ndist = (int)in.bits(5) + 1, ncode = (int)in.bits(4) + 4;
+        if (nlen > 286 || ndist > 30) {
+          bad = true;
+          break;
+        }
+        uint8_t lens[320];
+        for (int i = 0; i < 19; ++i) lens[i] = 0;
+        for (int i = 0; i < ncode; ++i) lens[kClOrder[i]] = (uint8_t)in.bits(3);
+        if (huff_build(lencnt, lensym, lens, 19) != 0) {  // the code-length code must be complete
+          bad = true;
+          break;
+        }
+        int idx = 0;
+        while (idx < nlen + ndist) {
+          int sym = huff_decode(in, lencnt, lensym);
+          if (sym < 0) {
+            bad = true;
+            break;
+          }
+          if (sym < 16) {
+            lens[idx++] = (uint8_t)sym;
+          } else {
+            int rep, val = 0;
+            if (sym == 16) {
+              if (idx == 0) {
+                bad = true;
+                break;
+              }
+              val = lens[idx - 1];
+              rep = 3 + (int)in.bits(2);
+            } else if (sym == 17) {
+              rep = 3 + (int)in.bits(3);
+            } else {
+              rep = 11 + (int)in.bits(7);
+            }
+            if (idx + rep > nlen + ndist) {
+              bad = true;
+              break;
+            }
+            while (rep--) lens[idx++] = (uint8_t)val;
+          }
+        }
+        if (bad) break;
+        if (lens[256] == 0) {  // no end-of-block code
+          bad = true;
+          break;
+        }
+        int e = huff_build(lencnt, lensym, lens, nlen);
+        if (e < 0 || (e > 0 && nlen - lencnt[0] != 1)) {  // over-subscribed, or incomplete with more than one code
+          bad = true;
+          break;
+        }
+        e = huff_build(distcnt, distsym, lens + nlen, ndist);
+        if (e < 0 || (e > 0 && ndist - distcnt[0] != 1)) {
+          bad = true;
+          break;
+        }
+      }
+      t_build += __builtin_readcyclecounter() - tb0;
+      // decode literals and length / distance pairs
+      for (;;) {
+        unsigned long long td0 = __builtin_readcyclecounter();
+        int sym = huff_decode(in, lencnt, lensym);
+        t_dec += __builtin_readcyclecounter() - td0;
+        ++n_sym;
+        if (sym < 0 || in.overrun()) {
+          bad = true;
+          break;
+        }
+        if (sym < 256) {
+          if (o >= cap) {
+            bad = true;
+            break;
+          }
+          out[o++] = (uint8_t)sym;
+        } else if (sym == 256) {
+          break;
+        } else {
+          sym -= 257;
+          if (sym >= 29) {
+            bad = true;
+            break;
+          }
+          const uint32_t len = kLenBase[sym] + in.bits(kLenExtra[sym]);
+          const int ds = huff_decode(in, distcnt, distsym);
+          if (ds < 0 || ds >= 30) {
+            bad = true;
+            break;
+          }
+          const uint32_t dist = kDistBase[ds] + in.bits(kDistExtra[ds]);
+          if (dist > o || o + len > cap) {
+            bad = true;
+            break;
+          }
+          unsigned long long tc0 = __builtin_readcyclecounter();
+          ++n_copy;
+          // LZ77 copy.  A byte-by-byte loop makes every load wait for the store before it (the ranges may overlap), ~1 us per
+          // byte; instead up to 16 source bytes are loaded together (independent loads) and then stored.  With dist < 16 the
+          // source repeats with period dist: the chunk is built from the first `dist` bytes.
+          if (dist >= 16) {
+            uint32_t i = 0;
+            while (i < len) {
+              const uint32_t nb = len - i < 16u ? len - i : 16u;
+              const uint32_t lim = dist < nb ? dist : nb;  // bytes that exist before this chunk is written (dist >= 16 >= nb here)
+              uint8_t b[16];
+#pragma unroll
+              for (int q = 0; q < 16; ++q) b[q] = (uint32_t)q < lim ? out[o - dist + q] : 0;
+#pragma unroll
+              for (int q = 0; q < 16; ++q)
+                if ((uint32_t)q < nb) out[o + q] = b[q];
+              o += nb;
+              i += nb;
+            }
+          } else {
+            uint8_t pat[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) pat[q] = (uint32_t)q < dist ? out[o - dist + q] : 0;
+            // expand the period to 16 bytes: b[q] = pat[q % dist]
+            uint8_t b[16];
+            uint32_t r = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              uint8_t v = 0;
+#pragma unroll
+              for (int z = 0; z < 16; ++z) v = (uint32_t)z == r ? pat[z] : v;
+              b[q] = v;
+              r = r + 1 == dist ? 0u : r + 1;
+            }
+            const uint32_t step = (16u / dist) * dist;  // whole periods per chunk: the pattern phase stays 0
+            uint32_t i = 0;
+            while (i < len) {
+              const uint32_t nb = len - i < step ? len - i : step;
+#pragma unroll
+              for (int q = 0; q < 16; ++q)
+                if ((uint32_t)q < nb) out[o + q] = b[q];
+              o += nb;
+              i += nb;
+            }
+          }
+          t_copy += __builtin_readcyclecounter() - tc0;
+        }
+      }
+      if (bad) break;
+    }
+    if (last) break;
+    if (in.overrun()) {
+      bad = true;
+      break;
+    }
+  }
+  if (dbg && m == 0) {
+    dbg[0] = __builtin_readcyclecounter() - t_all;
+    dbg[1] = t_build;
+    dbg[2] = t_dec;
+    dbg[3] = t_copy;
+    dbg[4] = n_sym;
+    dbg[5] = n_copy;
+  }
+  if (!bad && o != cap) bad = true;
+  if (!bad && !(flags & 1u)) {  // the member's CRC32 covers the payload (RFC 1952): htslib rejects a mismatch, so do we
+    uint32_t c = 0xFFFFFFFFu;
+    uint32_t i = 0;
+    for (; i < cap && ((uintptr_t)(out + i) & 3u); ++i) c = crct[0][(c ^ out[i]) & 0xFFu] ^ (c >> 8);
+    for (; i + 16 <= cap; i += 16) {  // four aligned words per round: the loads are issued together
+      const uint32_t* w = reinterpret_cast<const uint32_t*>(out + i);
+      const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+      uint32_t x = c ^ w0;
+      c = crct[3][x & 0xFFu] ^ crct[2][(x >> 8) & 0xFFu] ^ crct[1][(x >> 16) & 0xFFu] ^ crct[0][x >> 24];
+      x = c ^ w1;
+      c = crct[3][x & 0xFFu] ^ crct[2][(x >> 8) & 0xFFu] ^ crct[1][(x >> 16) & 0xFFu] ^ crct[0][x >> 24];
+      x = c ^ w2;
+      c = crct[3][x & 0xFFu] ^ crct[2][(x >> 8) & 0xFFu] ^ crct[1][(x >> 16) & 0xFFu] ^ crct[0][x >> 24];
+      x = c ^ w3;
+      c = crct[3][x & 0xFFu] ^ crct[2][(x >> 8) & 0xFFu] ^ crct[1][(x >> 16) & 0xFFu] ^ crct[0][x >> 24];
+    }
+    for (; i < cap; ++i) c = crct[0][(c ^ out[i]) & 0xFFu] ^ (c >> 8);
+    if ((c ^ 0xFFFFFFFFu) != M.crc) bad = true;
+  }
+  if (bad) atomicOr(err, 1u);
+}
+
+}  // namespace
+
+// ---- C ABI ------------------------------------------------------------------------------------------------------------
+extern "C" int tbk_bgzf_inflate(tbk_ctx* ctx, const uint8_t* comp, uint64_t comp_bytes, uint8_t* out, uint64_t out_cap, uint64_t* out_bytes,
+                                int mem) {
+  if (!ctx || !comp || !out || !out_bytes) return TBK_EINVAL;
+  TBK_HIP(hipSetDevice(ctx->device));
+  // member table from the gzip headers (host side: a few bytes per 64 KiB member)
+  std::vector<BgzMember> mt;
+  uint64_t off = 0, total = 0;
+  while (off < comp_bytes) {
+    if (off + 18 > comp_bytes || comp[off] != 0x1f || comp[off + 1] != 0x8b || comp[off + 2] != 8 || !(comp[off + 3] & 4)) return TBK_EINVAL;
+    const uint32_t xlen = comp[off + 10] | (comp[off + 11] << 8);
+    uint64_t p = off + 12, end = p + xlen;
+    if (end > comp_bytes) return TBK_EINVAL;
+    int bsize = -1;
+    while (p + 4 <= end) {
+      const uint32_t slen = comp[p + 2] | (comp[p + 3] << 8);
+      if (comp[p] == 'B' && comp[p + 1] == 'C' && slen == 2) bsize = comp[p + 4] | (comp[p + 5] << 8);
+      p += 4 + slen;
+    }
+    if (bsize < 0 || (uint64_t)bsize + 1 < 12ull + xlen + 8 || off + (uint64_t)bsize + 1 > comp_bytes) return TBK_EINVAL;
+    const uint8_t* t = comp + off + bsize + 1 - 8;
+    BgzMember m;
+    m.src = off + 12 + xlen;
+    m.clen = (uint32_t)((uint64_t)bsize + 1 - 8 - (12 + xlen));
+    m.crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+    m.isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+    if (m.isize > 65536) return TBK_EINVAL;
+    m.dst = total;
+    m.file = 0;
+    total += m.isize;
+    if (m.isize) mt.push_back(m);
+    off += (uint64_t)bsize + 1;
+  }
+  *out_bytes = total;
+  if (total > out_cap) return TBK_E2BIG;
+  if (mt.empty()) return 0;
+  tbk_prof_begin_call(ctx);
+  TBK_TRY(tbk_ws_reserve(ctx, comp_bytes + total + mt.size() * sizeof(BgzMember) + ((size_t)1 << 20)));
+  uint8_t* d_comp = ws_alloc<uint8_t>(ctx, comp_bytes);
+  BgzMember* d_mt = ws_alloc<BgzMember>(ctx, mt.size());
+  uint8_t* d_out = mem == TBK_MEM_DEVICE ? out : ws_alloc<uint8_t>(ctx, total);
+  if (!d_comp || !d_mt || !d_out) return TBK_ENOMEM;
+  TBK_HIP(hipMemcpyAsync(d_comp, comp, comp_bytes, hipMemcpyHostToDevice, ctx->stream));
+  TBK_HIP(hipMemcpyAsync(d_mt, mt.data(), mt.size() * sizeof(BgzMember), hipMemcpyHostToDevice, ctx->stream));
+  unsigned long long* d_dbg = getenv("TBK_INF_DEBUG") ? ws_alloc<unsigned long long>(ctx, 8) : nullptr;
+  TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
+  TBK_LAUNCH(ctx, "bgz_inflate", bgz_inflate_k, cdiv(mt.size(), INF_NT), INF_NT, 0, (uint32_t)mt.size(), d_mt, d_comp, d_out, (uint32_t)(getenv("TBK_INF_FLAGS") ? atoi(getenv("TBK_INF_FLAGS")) : 0), d_dbg, ctx->d_err);
+  if (mem != TBK_MEM_DEVICE) TBK_HIP(hipMemcpyAsync(out, d_out, total, hipMemcpyDeviceToHost, ctx->stream));
+  uint32_t eb = 0;
+  TBK_TRY(tbk_sync_err(ctx, &eb));  // (also waits for the member table upload: `mt` dies with this frame)
+  tbk_prof_end_call(ctx);
+  if (d_dbg) {
+    unsigned long long h[8];
+    (void)hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost);
+    fprintf(stderr, "inflate member 0: cycles %llu build %llu decode %llu copy %llu symbols %llu copies %llu\n", h[0], h[1], h[2], h[3], h[4], h[5]);
+  }
+  if (eb) {
+    ctx->last_error = "corrupt BGZF member (deflate stream, ISIZE or CRC32)";
+    return TBK_EINVAL;
+  }
+  return tbk_check_launch(ctx, "bgzf_inflate");
+}
+
+// =====================================================================================================================
+// BAM decode on the device: inflated streams -> record index -> SoA tile
+// =====================================================================================================================
+namespace {
+
+__device__ __forceinline__ uint32_t ld32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+__device__ __forceinline__ uint32_t ld16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+
+// one thread per file: "BAM\1", l_text, text, n_ref, references -> offset of the first alignment record
+__global__ void bam_header_k(uint32_t k, const uint8_t* __restrict__ inf, const uint64_t* __restrict__ fbase, const uint64_t* __restrict__ fbytes,
+                             uint64_t* __restrict__ first, int32_t* __restrict__ nref, uint32_t* __restrict__ err) {
+  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= k) return;
+  const uint8_t* p = inf + fbase[f];
+  const uint64_t n = fbytes[f];
+  bool bad = n < 12 || p[0] != 'B' || p[1] != 'A' || p[2] != 'M' || p[3] != 1;
+  uint64_t o = 0;
+  int32_t nr = 0;
+  if (!bad) {
+    const uint64_t l_text = ld32(p + 4);
+    o = 8 + l_text;
+    if (o + 4 > n) {
+      bad = true;
+    } else {
+      nr = (int32_t)ld32(p + o);
+      o += 4;
+      for (int32_t i = 0; i < nr && !bad; ++i) {
+        if (o + 4 > n) {
+          bad = true;
+          break;
+        }
+        const uint64_t l_name = ld32(p + o);
+        if (o + 8 + l_name > n) bad = true;
+        o += 8 + l_name;
+      }
+    }
+  }
+  first[f] = o;
+  nref[f] = nr;
+  if (bad) atomicOr(err, 2u);
+}
+
+// One workgroup per file walks the record chain (block_size -> next record): the stream is staged through LDS in chunks, one
+// lane follows the chain inside the chunk (an LDS read per record instead of a memory round trip), the offsets found are
+// written out by the whole group.  rec[cap_off[f] + i] = offset of record i of file f in the inflated buffer.
+constexpr int IDX_NT = 256;
+constexpr uint32_t IDX_CH = 48 * 1024;
+__global__ __launch_bounds__(IDX_NT) void bam_index_k(const uint8_t* __restrict__ inf, const uint64_t* __restrict__ fbase,
+                                                      const uint64_t* __restrict__ fbytes, const uint64_t* __restrict__ first,
+                                                      const uint64_t* __restrict__ cap_off, uint64_t* __restrict__ rec, uint32_t* __restrict__ cnt,
+                                                      uint32_t* __restrict__ err) {
+  __shared__ __align__(16) uint8_t buf[IDX_CH + 16];
+  __shared__ uint32_t list[IDX_CH / 36 + 2];
+  __shared__ uint32_t s_n;
+  __shared__ unsigned long long s_next;
+  __shared__ uint32_t s_bad;
+  const uint32_t f = blockIdx.x;
+  const uint8_t* base = inf + fbase[f];
+  const uint64_t n = fbytes[f];
+  uint64_t p = first[f];
+  uint64_t total = 0;
+  uint64_t* out = rec + cap_off[f];
+  if (threadIdx.x == 0) s_bad = 0;
+  __syncthreads();
+  while (p < n) {
+    const uint64_t c0 = p & ~(uint64_t)15;  // 16-byte aligned chunk start (the buffers are 256-byte aligned and files start 16-aligned)
+    const uint32_t cl = (uint32_t)((n - c0) < (uint64_t)IDX_CH ? (n - c0) : (uint64_t)IDX_CH);
+    for (uint32_t i = threadIdx.x * 16; i < cl; i += IDX_NT * 16) {
+      if (i + 16 <= cl) {
+        *reinterpret_cast<uint4*>(buf + i) = *reinterpret_cast<const uint4*>(base + c0 + i);
+      } else {
+        for (uint32_t b = i; b < cl; ++b) buf[b] = base[c0 + b];
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t q = (uint32_t)(p - c0), m = 0;
+      bool bad = false;
+      while (q + 4 <= cl) {
+        const uint32_t bs = (uint32_t)buf[q] | ((uint32_t)buf[q + 1] << 8) | ((uint32_t)buf[q + 2] << 16) | ((uint32_t)buf[q + 3] << 24);
+        if (bs < 32 || c0 + q + 4 + (uint64_t)bs > n) {
+          bad = true;
+          break;
+        }
+        list[m++] = q;
+        q += 4 + bs;
+      }
+      if (!bad && q < cl && c0 + cl == n) bad = true;  // fewer than 4 bytes left at the end of the file: a truncated record
+      s_n = m;
+      s_next = c0 + q;
+      if (bad) s_bad = 1;
+    }
+    __syncthreads();
+    const uint32_t m = s_n;
+    for (uint32_t i = threadIdx.x; i < m; i += IDX_NT) out[total + i] = fbase[f] + c0 + list[i];
+    total += m;
+    const uint64_t np = s_next;
+    const bool bad = s_bad != 0;
+    __syncthreads();
+    if (bad || np <= p) {  // (no progress cannot happen: a chunk is longer than a block_size field plus the alignment slack)
+      if (threadIdx.x == 0) atomicOr(err, 4u);
+      break;
+    }
+    p = np;
+  }
+  if (threadIdx.x == 0) cnt[f] = (uint32_t)(total < 0xFFFFFFFFull ? total : 0xFFFFFFFFull);
+}
+
+struct BamSoA {
+  int32_t *tid, *pos, *nh;
+  uint16_t* flag;
+  uint8_t *mapq, *strand;
+  uint32_t* ncig;      // per record CIGAR operation count -> cig_off by a scan
+  double* yc;
+  int64_t *yx, *yd;
+  uint32_t *nmd, *nqn; // MD / name byte counts (optional)
+  uint8_t* md_has;
+};
+
+// one thread per record: validation as the host loader's (bam.cpp index_records), core fields, one aux scan
+__global__ void bam_fields_k(uint32_t n, const uint8_t* __restrict__ inf, const uint64_t* __restrict__ rec, const uint32_t* __restrict__ file_off,
+                             uint32_t k, const uint8_t* __restrict__ tbm, const int32_t* __restrict__ nref, BamSoA S, int want_md, int want_qn,
+                             uint32_t* __restrict__ err) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t lo = 0, hi = k;  // file of record i
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (file_off[mid] <= i)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  const uint32_t f = lo;
+  const uint8_t* r = inf + rec[i];
+  const uint32_t bs = ld32(r);
+  r += 4;
+  const int32_t tid = (int32_t)ld32(r), pos = (int32_t)ld32(r + 4);
+  const uint32_t l_read_name = r[8], mapq = r[9], n_cigar = ld16(r + 12), flag = ld16(r + 14);
+  const int32_t l_seq = (int32_t)ld32(r + 16), mtid = (int32_t)ld32(r + 20);
+  const uint64_t need = 32ull + l_read_name + 4ull * n_cigar + (l_seq < 0 ? 0ull : ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq);
+  const bool name_ok = l_read_name >= 1 && 32 + l_read_name <= bs && r[32 + l_read_name - 1] == 0;
+  const int32_t nt = nref[f];
+  if (l_seq < 0 || need > bs || !name_ok || tid < -1 || tid >= nt || mtid < -1 || mtid >= nt) {
+    atomicOr(err, 8u);
+    S.ncig[i] = 0;
+    if (want_md) S.nmd[i] = 0;
+    if (want_qn) S.nqn[i] = 0;
+    return;
+  }
+  S.tid[i] = tid;
+  S.pos[i] = pos;
+  S.flag[i] = (uint16_t)flag;
+  S.mapq[i] = (uint8_t)mapq;
+  S.ncig[i] = n_cigar;
+  if (want_qn) S.nqn[i] = l_read_name - 1;
+  // aux scan; bam_aux_get semantics = first occurrence of each tag
+  const uint8_t* a = r + need;
+  const uint8_t* e = r + bs;
+  const bool tb = tbm[f] != 0;
+  char xs = 0, ts = 0;
+  int32_t nh = TBK_NH_ABSENT;
+  double yc = 0.0;
+  int64_t yx = 1, yd = 0;
+  uint32_t nmd = 0, seen = 0;
+  uint8_t md_has = 0;
+  auto aux_i = [](const uint8_t* s) -> int64_t {  // bam_aux2i
+    switch (*s) {
+      case 'c': return (int8_t)s[1];
+      case 'C': return s[1];
+      case 's': return (int16_t)ld16(s + 1);
+      case 'S': return ld16(s + 1);
+      case 'i': return (int32_t)ld32(s + 1);
+      case 'I': return ld32(s + 1);
+    }
+    return 0;
+  };
+  while (a + 3 <= e) {
+    const uint8_t* s = a + 2;
+    const uint8_t ty = *s;
+    uint64_t sz = 0;  // tag + type + value
+    switch (ty) {
+      case 'A': case 'c': case 'C': sz = 4; break;
+      case 's': case 'S': sz = 5; break;
+      case 'i': case 'I': case 'f': sz = 7; break;
+      case 'd': sz = 11; break;
+      case 'Z': case 'H': {
+        const uint8_t* z = s + 1;
+        while (z < e && *z) ++z;
+        sz = z < e ? (uint64_t)(z - a) + 1 : 0;
+        break;
+      }
+      case 'B': {
+        if (a + 8 <= e) {
+          const uint8_t st = s[1];
+          const uint32_t cntb = ld32(s + 2);
+          const uint32_t es = (st == 'c' || st == 'C') ? 1u : (st == 's' || st == 'S') ? 2u : (st == 'i' || st == 'I' || st == 'f') ? 4u : 0u;
+          sz = es ? 8ull + (uint64_t)cntb * es : 0;
+        }
+        break;
+      }
+    }
+    if (!sz || a + sz > e) break;
+    if (a[0] == 'N' && a[1] == 'H' && !(seen & 1)) {
+      seen |= 1;
+      nh = (int32_t)aux_i(s);
+    } else if (a[0] == 'X' && a[1] == 'S' && !(seen & 2)) {
+      seen |= 2;
+      xs = (ty == 'A' || ty == 'Z') ? (char)s[1] : 0;
+    } else if (a[0] == 't' && a[1] == 's' && !(seen & 4)) {
+      seen |= 4;
+      ts = (ty == 'A' || ty == 'Z') ? (char)s[1] : 0;
+    } else if (tb && a[0] == 'Y' && a[1] == 'C' && !(seen & 8)) {
+      seen |= 8;
+      if (ty == 'f') {
+        yc = (double)__uint_as_float(ld32(s + 1));
+      } else if (ty == 'd') {
+        yc = __longlong_as_double((long long)((uint64_t)ld32(s + 1) | ((uint64_t)ld32(s + 5) << 32)));
+      } else {
+        yc = (double)aux_i(s);
+      }
+    } else if (tb && a[0] == 'Y' && a[1] == 'X' && !(seen & 16)) {
+      seen |= 16;
+      yx = aux_i(s);
+    } else if (tb && a[0] == 'Y' && a[1] == 'D' && !(seen & 32)) {
+      seen |= 32;
+      yd = aux_i(s);
+    } else if (want_md && a[0] == 'M' && a[1] == 'D' && !(seen & 64)) {
+      seen |= 64;
+      if (ty == 'Z') {
+        nmd = (uint32_t)(sz - 4);
+        md_has = 1;
+      }
+    }
+    a += sz;
+  }
+  S.nh[i] = nh;
+  char c = xs;  // GSamRecord::spliceStrand (GSam.cpp:464-475)
+  if (c == 0 && (ts == '+' || ts == '-')) c = (flag & 0x10) ? (ts == '+' ? '-' : '+') : ts;
+  S.strand[i] = (uint8_t)((c == '+' || c == '-') ? c : '.');
+  if (S.yc) {
+    S.yc[i] = yc;
+    S.yx[i] = yx;
+    S.yd[i] = yd;
+  }
+  if (want_md) {
+    S.nmd[i] = nmd;
+    S.md_has[i] = md_has;
+  }
+}
+
+__global__ void bam_fill_k(uint32_t n, const uint8_t* __restrict__ inf, const uint64_t* __restrict__ rec, const uint32_t* __restrict__ cig_off,
+                           uint32_t* __restrict__ cig, const uint16_t* __restrict__ flag, const uint32_t* __restrict__ md_off, uint8_t* __restrict__ md,
+                           const uint32_t* __restrict__ qn_off, uint8_t* __restrict__ qn, uint64_t* __restrict__ qh) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* r = inf + rec[i] + 4;
+  const uint32_t l_read_name = r[8];
+  const uint32_t c0 = cig_off[i], nc = cig_off[i + 1] - c0;
+  const uint8_t* cp = r + 32 + l_read_name;
+  for (uint32_t q = 0; q < nc; ++q) cig[c0 + q] = ld32(cp + 4 * q);
+  if (qn_off) {
+    const uint32_t o = qn_off[i], l = qn_off[i + 1] - o;
+    uint64_t h = 0xCBF29CE484222325ull;  // FNV-1a over the name bytes and pairOrder + 1 (tmerge.cpp tbh_qname_hash)
+    for (uint32_t q = 0; q < l; ++q) {
+      const uint8_t b = r[32 + q];
+      qn[o + q] = b;
+      h = (h ^ b) * 0x100000001B3ull;
+    }
+    const uint32_t fl = flag[i];
+    const uint32_t po = (fl & 0x40) ? 1u : ((fl & 0x80) ? 2u : 0u);
+    h = (h ^ (po + 1)) * 0x100000001B3ull;
+    qh[i] = h;
+  }
+  if (md_off && md_off[i + 1] > md_off[i]) {  // copy the MD:Z payload (found again: first MD tag)
+    const uint32_t bs = ld32(r - 4);
+    const int32_t l_seq = (int32_t)ld32(r + 16);
+    const uint8_t* a = cp + 4ull * nc + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq;
+    const uint8_t* e = r + bs;
+    while (a + 3 <= e) {
+      const uint8_t ty = a[2];
+      uint64_t sz = 0;
+      switch (ty) {
+        case 'A': case 'c': case 'C': sz = 4; break;
+        case 's': case 'S': sz = 5; break;
+        case 'i': case 'I': case 'f': sz = 7; break;
+        case 'd': sz = 11; break;
+        case 'Z': case 'H': {
+          const uint8_t* z = a + 3;
+          while (z < e && *z) ++z;
+          sz = z < e ? (uint64_t)(z - a) + 1 : 0;
+          break;
+        }
+        case 'B': {
+          if (a + 8 <= e) {
+            const uint8_t st = a[3];
+            const uint32_t cntb = ld32(a + 4);
+            const uint32_t es = (st == 'c' || st == 'C') ? 1u : (st == 's' || st == 'S') ? 2u : (st == 'i' || st == 'I' || st == 'f') ? 4u : 0u;
+            sz = es ? 8ull + (uint64_t)cntb * es : 0;
+          }
+          break;
+        }
+      }
+      if (!sz || a + sz > e) break;
+      if (a[0] == 'M' && a[1] == 'D') {
+        if (ty == 'Z') {
+          const uint32_t o = md_off[i];
+          for (uint32_t q = 0; q + 4 < sz; ++q) md[o + q] = a[3 + q];
+        }
+        break;
+      }
+      a += sz;
+    }
+  }
+}
+
+__global__ void bam_compact_k(uint32_t k, const uint64_t* __restrict__ cap_off, const uint32_t* __restrict__ file_off, const uint64_t* __restrict__ rec_in,
+                              uint64_t* __restrict__ rec_out) {
+  const uint32_t f = blockIdx.y;
+  const uint32_t n = file_off[f + 1] - file_off[f];
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) rec_out[file_off[f] + i] = rec_in[cap_off[f] + i];
+}
+
+// gather: sizes, then bytes
+__global__ void bam_recsize_k(uint32_t n, const uint32_t* __restrict__ idx, const uint8_t* __restrict__ inf, const uint64_t* __restrict__ rec,
+                              uint32_t nrec, uint32_t* __restrict__ sz, uint32_t* __restrict__ err) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  const uint32_t i = idx[g];
+  if (i >= nrec) {
+    atomicOr(err, 16u);
+    sz[g] = 0;
+    return;
+  }
+  sz[g] = 4 + ld32(inf + rec[i]);
+}
+__global__ void bam_reccopy_k(uint32_t n, const uint32_t* __restrict__ idx, const uint8_t* __restrict__ inf, const uint64_t* __restrict__ rec,
+                              const uint64_t* __restrict__ off, uint8_t* __restrict__ out) {
+  // one wave per record: 64 consecutive bytes per step
+  const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (g >= n) return;
+  const uint8_t* s = inf + rec[idx[g]];
+  const uint64_t o = off[g];
+  const uint32_t len = (uint32_t)(off[g + 1] - o);
+  for (uint32_t b = lane_id(); b < len; b += 64) out[o + b] = s[b];
+}
+
+struct BamDev {
+  uint8_t* inf = nullptr;      // inflated streams of all files, each starting 256-byte aligned
+  uint64_t* rec = nullptr;     // [n] offset of every record (its block_size field) in `inf`
+  uint32_t n = 0;
+  std::vector<void*> owned;    // device allocations of the decoded tile
+};
+
+}  // namespace
+
+static void bamdev_free(tbk_ctx* ctx) {
+  BamDev* B = (BamDev*)ctx->bam_dev;
+  if (!B) return;
+  for (void* p : B->owned) (void)hipFree(p);
+  delete B;
+  ctx->bam_dev = nullptr;
+}
+
+extern "C" void tbk_bam_release(tbk_ctx* ctx) {
+  if (ctx) bamdev_free(ctx);
+}
+
+template <class T>
+static T* bd_alloc(BamDev* B, size_t n) {
+  void* p = nullptr;
+  if (hipMalloc(&p, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr;
+  B->owned.push_back(p);
+  return (T*)p;
+}
+
+extern "C" int tbk_bam_decode(tbk_ctx* ctx, uint32_t n_files, const uint8_t* const* comp, const uint64_t* comp_bytes, const uint8_t* tbmerged,
+                              int want_md, int want_names, tbk_soa_in* tile, uint32_t* file_off_out) {
+  if (!ctx || !comp || !comp_bytes || !tile || !file_off_out || n_files == 0 || n_files > 65535) return TBK_EINVAL;
+  TBK_HIP(hipSetDevice(ctx->device));
+  bamdev_free(ctx);
+  tbk_prof_begin_call(ctx);
+  const uint32_t k = n_files;
+  // ---- member table of every file; inflated streams laid out file after file, 256-byte aligned ----
+  std::vector<BgzMember> mt;
+  std::vector<uint64_t> cbase(k + 1, 0), fbase(k, 0), fbytes(k, 0);
+  uint64_t ctot = 0, itot = 0;
+  for (uint32_t f = 0; f < k; ++f) {
+    cbase[f] = ctot;
+    const uint8_t* c = comp[f];
+    const uint64_t cb = comp_bytes[f];
+    if (!c) return TBK_EINVAL;
+    itot = (itot + 255) & ~(uint64_t)255;
+    fbase[f] = itot;
+    uint64_t off = 0;
+    while (off < cb) {
+      if (off + 18 > cb || c[off] != 0x1f || c[off + 1] != 0x8b || c[off + 2] != 8 || !(c[off + 3] & 4)) return TBK_EINVAL;
+      const uint32_t xlen = c[off + 10] | (c[off + 11] << 8);
+      uint64_t p = off + 12, end = p + xlen;
+      if (end > cb) return TBK_EINVAL;
+      int bsize = -1;
+      while (p + 4 <= end) {
+        const uint32_t slen = c[p + 2] | (c[p + 3] << 8);
+        if (c[p] == 'B' && c[p + 1] == 'C' && slen == 2) bsize = c[p + 4] | (c[p + 5] << 8);
+        p += 4 + slen;
+      }
+      if (bsize < 0 || (uint64_t)bsize + 1 < 12ull + xlen + 8 || off + (uint64_t)bsize + 1 > cb) return TBK_EINVAL;
+      const uint8_t* t = c + off + bsize + 1 - 8;
+      BgzMember m;
+      m.src = ctot + off + 12 + xlen;
+      m.clen = (uint32_t)((uint64_t)bsize + 1 - 8 - (12 + xlen));
+      m.crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+      m.isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+      if (m.isize > 65536) return TBK_EINVAL;
+      m.dst = itot;
+      m.file = f;
+      itot += m.isize;
+      if (m.isize) mt.push_back(m);
+      off += (uint64_t)bsize + 1;
+    }
+    fbytes[f] = itot - fbase[f];
+    ctot += cb;
+  }
+  cbase[k] = ctot;
+  if (mt.empty()) {
+    memset(tile, 0, sizeof(*tile));
+    for (uint32_t f = 0; f <= k; ++f) file_off_out[f] = 0;
+    return TBK_EINVAL;  // no BAM header anywhere
+  }
+  BamDev* B = new BamDev();
+  ctx->bam_dev = B;
+  B->inf = bd_alloc<uint8_t>(B, itot + 64);
+  // work memory (arena): compressed bytes, member table, per-file tables, the over-sized record list
+  std::vector<uint64_t> cap_off(k + 1, 0);
+  for (uint32_t f = 0; f < k; ++f) cap_off[f + 1] = cap_off[f] + fbytes[f] / 36 + 1;
+  TBK_TRY(tbk_ws_reserve(ctx, ctot + mt.size() * sizeof(BgzMember) + cap_off[k] * 8 + (size_t)k * 64 + ((size_t)4 << 20)));
+  uint8_t* d_comp = ws_alloc<uint8_t>(ctx, ctot);
+  BgzMember* d_mt = ws_alloc<BgzMember>(ctx, mt.size());
+  uint64_t* d_tab = ws_alloc<uint64_t>(ctx, (size_t)4 * k + 4);  // fbase, fbytes, first, cap_off
+  int32_t* d_nref = ws_alloc<int32_t>(ctx, k);
+  uint32_t* d_cnt = ws_alloc<uint32_t>(ctx, k);
+  uint64_t* d_rec0 = ws_alloc<uint64_t>(ctx, cap_off[k]);
+  uint8_t* d_tbm = ws_alloc<uint8_t>(ctx, k);
+  if (!B->inf || !d_comp || !d_mt || !d_tab || !d_rec0 || !d_tbm) return TBK_ENOMEM;
+  for (uint32_t f = 0; f < k; ++f) TBK_HIP(hipMemcpyAsync(d_comp + cbase[f], comp[f], comp_bytes[f], hipMemcpyHostToDevice, ctx->stream));
+  TBK_HIP(hipMemcpyAsync(d_mt, mt.data(), mt.size() * sizeof(BgzMember), hipMemcpyHostToDevice, ctx->stream));
+  TBK_HIP(hipMemcpyAsync(d_tab, fbase.data(), k * 8, hipMemcpyHostToDevice, ctx->stream));
+  TBK_HIP(hipMemcpyAsync(d_tab + k, fbytes.data(), k * 8, hipMemcpyHostToDevice, ctx->stream));
+  TBK_HIP(hipMemcpyAsync(d_tab + 3 * k, cap_off.data(), k * 8, hipMemcpyHostToDevice, ctx->stream));
+  std::vector<uint8_t> tb(k, 0);
+  if (tbmerged) memcpy(tb.data(), tbmerged, k);
+  TBK_HIP(hipMemcpyAsync(d_tbm, tb.data(), k, hipMemcpyHostToDevice, ctx->stream));
+  TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
+  TBK_LAUNCH(ctx, "bgz_inflate", bgz_inflate_k, cdiv(mt.size(), INF_NT), INF_NT, 0, (uint32_t)mt.size(), d_mt, d_comp, B->inf, 0u,
+             (unsigned long long*)nullptr, ctx->d_err);
+  TBK_LAUNCH(ctx, "bam_header", bam_header_k, cdiv(k, 64), 64, 0, k, B->inf, d_tab, d_tab + k, d_tab + 2 * k, d_nref, ctx->d_err);
+  TBK_LAUNCH(ctx, "bam_index", bam_index_k, k, IDX_NT, 0, B->inf, d_tab, d_tab + k, d_tab + 2 * k, d_tab + 3 * k, d_rec0, d_cnt, ctx->d_err);
+  std::vector<uint32_t> cnt(k, 0);
+  TBK_HIP(hipMemcpyAsync(cnt.data(), d_cnt, k * 4, hipMemcpyDeviceToHost, ctx->stream));
+  uint32_t eb = 0;
+  TBK_TRY(tbk_sync_err(ctx, &eb));
+  if (eb) {
+    ctx->last_error = (eb & 1u) ? "corrupt BGZF member (deflate stream, ISIZE or CRC32)" : (eb & 2u) ? "not a BAM stream / truncated header" : "corrupt BAM record chain";
+    bamdev_free(ctx);
+    return TBK_EINVAL;
+  }
+  uint64_t ntot = 0;
+  file_off_out[0] = 0;
+  for (uint32_t f = 0; f < k; ++f) {
+    ntot += cnt[f];
+    if (ntot >= (1ull << 32)) {
+      bamdev_free(ctx);
+      return TBK_E2BIG;
+    }
+    file_off_out[f + 1] = (uint32_t)ntot;
+  }
+  const uint32_t n = (uint32_t)ntot;
+  B->n = n;
+  B->rec = bd_alloc<uint64_t>(B, n);
+  uint32_t* d_fo = ws_alloc<uint32_t>(ctx, k + 1);
+  if (!B->rec || !d_fo) return TBK_ENOMEM;
+  TBK_HIP(hipMemcpyAsync(d_fo, file_off_out, (k + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (n) TBK_LAUNCH(ctx, "bam_compact", bam_compact_k, dim3(64, k), 256, 0, k, d_tab + 3 * k, d_fo, d_rec0, B->rec);
+  // ---- SoA ----
+  bool any_tb = false;
+  for (uint32_t f = 0; f < k; ++f) any_tb |= tb[f] != 0;
+  BamSoA S{};
+  S.tid = bd_alloc<int32_t>(B, n);
+  S.pos = bd_alloc<int32_t>(B, n);
+  S.nh = bd_alloc<int32_t>(B, n);
+  S.flag = bd_alloc<uint16_t>(B, n);
+  S.mapq = bd_alloc<uint8_t>(B, n);
+  S.strand = bd_alloc<uint8_t>(B, n);
+  S.ncig = ws_alloc<uint32_t>(ctx, (size_t)n + 1);
+  uint32_t* cig_off = bd_alloc<uint32_t>(B, (size_t)n + 1);
+  if (any_tb) {
+    S.yc = bd_alloc<double>(B, n);
+    S.yx = bd_alloc<int64_t>(B, n);
+    S.yd = bd_alloc<int64_t>(B, n);
+  }
+  uint32_t *md_off = nullptr, *qn_off = nullptr;
+  if (want_md) {
+    S.nmd = ws_alloc<uint32_t>(ctx, (size_t)n + 1);
+    S.md_has = bd_alloc<uint8_t>(B, n);
+    md_off = bd_alloc<uint32_t>(B, (size_t)n + 1);
+  }
+  if (want_names) {
+    S.nqn = ws_alloc<uint32_t>(ctx, (size_t)n + 1);
+    qn_off = bd_alloc<uint32_t>(B, (size_t)n + 1);
+  }
+  if (!S.strand || !S.ncig || !cig_off || (any_tb && !S.yd) || (want_md && !md_off) || (want_names && !qn_off)) return TBK_ENOMEM;
+  uint64_t* sc = ctx->d_scalars;
+  uint64_t ncig = 0, nmd = 0, nqn = 0;
+  uint32_t* cig = nullptr;
+  uint8_t *md = nullptr, *qn = nullptr;
+  uint64_t* qh = nullptr;
+  if (n) {
+    TBK_LAUNCH(ctx, "bam_fields", bam_fields_k, cdiv(n, 256), 256, 0, n, B->inf, B->rec, d_fo, k, d_tbm, d_nref, S, want_md, want_names, ctx->d_err);
+    TBK_HIP(hipMemsetAsync(S.ncig + n, 0, 4, ctx->stream));
+    TBK_TRY(tbk_exscan_u32(ctx, S.ncig, cig_off, n + 1, sc + 1));
+    if (want_md) {
+      TBK_HIP(hipMemsetAsync(S.nmd + n, 0, 4, ctx->stream));
+      TBK_TRY(tbk_exscan_u32(ctx, S.nmd, md_off, n + 1, sc + 2));
+    }
+    if (want_names) {
+      TBK_HIP(hipMemsetAsync(S.nqn + n, 0, 4, ctx->stream));
+      TBK_TRY(tbk_exscan_u32(ctx, S.nqn, qn_off, n + 1, sc + 3));
+    }
+    TBK_TRY(tbk_sync_err(ctx, &eb));
+    if (eb) {
+      ctx->last_error = "malformed BAM record (field lengths / reference id outside the record / header)";
+      bamdev_free(ctx);
+      return TBK_EINVAL;
+    }
+    ncig = ctx->h_scalars[1];
+    nmd = want_md ? ctx->h_scalars[2] : 0;
+    nqn = want_names ? ctx->h_scalars[3] : 0;
+    if (ncig >= (1ull << 32) || nmd >= (1ull << 32) || nqn >= (1ull << 32)) {
+      bamdev_free(ctx);
+      return TBK_E2BIG;
+    }
+    cig = bd_alloc<uint32_t>(B, ncig);
+    if (want_md) md = bd_alloc<uint8_t>(B, nmd);
+    if (want_names) {
+      qn = bd_alloc<uint8_t>(B, nqn);
+      qh = bd_alloc<uint64_t>(B, n);
+    }
+    if (!cig || (want_md && !md) || (want_names && !qh)) return TBK_ENOMEM;
+    TBK_LAUNCH(ctx, "bam_fill", bam_fill_k, cdiv(n, 256), 256, 0, n, B->inf, B->rec, cig_off, cig, S.flag, md_off, md, qn_off, qn, qh);
+    TBK_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  memset(tile, 0, sizeof(*tile));
+  tile->mem = TBK_MEM_DEVICE;
+  tile->n_files = k;
+  tile->n_records = n;
+  tile->n_cigar_ops = (uint32_t)ncig;
+  tile->file_off = file_off_out;
+  tile->tbmerged = tbmerged;
+  tile->tid = S.tid;
+  tile->pos = S.pos;
+  tile->flag = S.flag;
+  tile->mapq = S.mapq;
+  tile->strand = S.strand;
+  tile->nh = S.nh;
+  tile->cig_off = cig_off;
+  tile->cig = cig;
+  tile->yc_in = S.yc;
+  tile->yx_in = S.yx;
+  tile->yd_in = S.yd;
+  tile->md_off = md_off;
+  tile->md = md;
+  tile->md_has = S.md_has;
+  tile->qname_hash = qh;
+  tile->qname_off = qn_off;
+  tile->qname = qn;
+  tbk_prof_end_call(ctx);
+  return tbk_check_launch(ctx, "bam_decode");
+}
+
+// the raw records (block_size field included, i.e. framed as in the BAM stream) behind tile indices, packed in the order given
+extern "C" int tbk_bam_records(tbk_ctx* ctx, const uint32_t* idx, uint32_t n, int idx_mem, uint8_t* out, uint64_t out_cap, uint64_t* out_off) {
+  if (!ctx || !ctx->bam_dev || !out_off || (n && (!idx || !out))) return TBK_EINVAL;
+  BamDev* B = (BamDev*)ctx->bam_dev;
+  TBK_HIP(hipSetDevice(ctx->device));
+  out_off[0] = 0;
+  if (n == 0) return 0;
+  TBK_TRY(tbk_ws_reserve(ctx, (size_t)n * 24 + ((size_t)4 << 20)));
+  const uint32_t* d_idx = idx;
+  if (idx_mem != TBK_MEM_DEVICE) {
+    uint32_t* t = ws_alloc<uint32_t>(ctx, n);
+    if (!t) return TBK_ENOMEM;
+    TBK_HIP(hipMemcpyAsync(t, idx, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    d_idx = t;
+  }
+  uint32_t* sz = ws_alloc<uint32_t>(ctx, (size_t)n + 1);
+  uint64_t* off = ws_alloc<uint64_t>(ctx, (size_t)n + 1);
+  if (!sz || !off) return TBK_ENOMEM;
+  TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
+  TBK_LAUNCH(ctx, "bam_recsize", bam_recsize_k, cdiv(n, 256), 256, 0, n, d_idx, B->inf, B->rec, B->n, sz, ctx->d_err);
+  TBK_HIP(hipMemsetAsync(sz + n, 0, 4, ctx->stream));
+  TBK_TRY(tbk_exscan_u32_u64(ctx, sz, off, n + 1, ctx->d_scalars + 1));
+  uint32_t eb = 0;
+  TBK_TRY(tbk_sync_err(ctx, &eb));
+  if (eb) return TBK_EINVAL;
+  const uint64_t total = ctx->h_scalars[1];
+  if (total > out_cap) {
+    out_off[n] = total;
+    return TBK_E2BIG;
+  }
+  uint8_t* d_out = ws_alloc<uint8_t>(ctx, total);
+  if (!d_out) return TBK_ENOMEM;
+  TBK_LAUNCH(ctx, "bam_reccopy", bam_reccopy_k, cdiv((uint64_t)n * 64, 256), 256, 0, n, d_idx, B->inf, B->rec, off, d_out);
+  TBK_HIP(hipMemcpyAsync(out, d_out, total, hipMemcpyDeviceToHost, ctx->stream));
+  TBK_HIP(hipMemcpyAsync(out_off, off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  TBK_HIP(hipStreamSynchronize(ctx->stream));
+  return tbk_check_launch(ctx, "bam_records");
+}

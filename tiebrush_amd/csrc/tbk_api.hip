@@ -125,11 +125,11 @@ int tbk_derr_to_status(tbk_ctx* ctx, uint32_t bits) {
 }
 
 static void merge_side_times(tbk_ctx* ctx);
-static void prof_begin_call(tbk_ctx* ctx) {
+void tbk_prof_begin_call(tbk_ctx* ctx) {
   ctx->ktimes.clear();
   ctx->ev_used = 0;
 }
-static void prof_end_call(tbk_ctx* ctx) {
+void tbk_prof_end_call(tbk_ctx* ctx) {
   ctx->last_times.clear();
   if (!ctx->profiling) return;
   (void)hipStreamSynchronize(ctx->stream);
@@ -195,10 +195,10 @@ tbk_ctx* tbk_side_ctx(tbk_ctx* ctx) {
 }
 int tbk_side_begin(tbk_ctx* side, size_t arena_hint) {
   if (hipSetDevice(side->device) != hipSuccess) return TBK_EHIP;
-  prof_begin_call(side);
+  tbk_prof_begin_call(side);
   return ws_begin_call(side, arena_hint);
 }
-void tbk_side_end(tbk_ctx* side) { prof_end_call(side); }
+void tbk_side_end(tbk_ctx* side) { tbk_prof_end_call(side); }
 
 // kernel times of a side branch are reported with the call that ran it
 static void merge_side_times(tbk_ctx* ctx) {
@@ -220,10 +220,10 @@ static void merge_side_times(tbk_ctx* ctx) {
 // ---- deferred YD stage -------------------------------------------------------------------------------
 static int yd_stage_on(tbk_ctx* run_on, void* job, size_t hint) {
   if (hipSetDevice(run_on->device) != hipSuccess) return TBK_EHIP;
-  prof_begin_call(run_on);
+  tbk_prof_begin_call(run_on);
   int rc = ws_begin_call(run_on, hint);
   if (rc == 0) rc = tbk_collapse_yd_run(run_on, job);
-  prof_end_call(run_on);
+  tbk_prof_end_call(run_on);
   return rc;
 }
 
@@ -292,6 +292,7 @@ int tbk_collapse_finish_yd(tbk_ctx* ctx) {
 void tbk_destroy(tbk_ctx* ctx) {
   if (!ctx) return;
   (void)finish_yd(ctx);
+  tbk_bam_release(ctx);
   delete ctx->yd_worker;
   ctx->yd_worker = nullptr;
   delete ctx->side_worker;
@@ -364,7 +365,7 @@ int tbk_coverage_tile(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out) {
   if (out->cap_junctions && (!out->j_tid || !out->j_start || !out->j_end || !out->j_strand || !out->j_val)) return TBK_EINVAL;
   if (in->mem != out->mem) return TBK_EINVAL;
   TBK_HIP(hipSetDevice(ctx->device));
-  prof_begin_call(ctx);
+  tbk_prof_begin_call(ctx);
   size_t hint = (size_t)in->n_records * 96 + (size_t)in->n_cigar_ops * 64 + ((size_t)8 << 20);
   TBK_TRY(ws_begin_call(ctx, hint));
   int rc;
@@ -410,7 +411,7 @@ int tbk_coverage_tile(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out) {
       TBK_HIP(hipStreamSynchronize(ctx->stream));
     }
   }
-  prof_end_call(ctx);
+  tbk_prof_end_call(ctx);
   return rc;
 }
 
@@ -435,7 +436,7 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
   if (opts->defer_yd && in->mem != TBK_MEM_DEVICE) return TBK_EINVAL;
   TBK_TRY(finish_yd(ctx));  // a still-pending YD stage of the previous tile owns part of the arena
   TBK_HIP(hipSetDevice(ctx->device));
-  prof_begin_call(ctx);
+  tbk_prof_begin_call(ctx);
   size_t hint = (size_t)in->n_records * 160 + (size_t)in->n_cigar_ops * 8 + ((size_t)8 << 20);
   TBK_TRY(ws_begin_call(ctx, hint));
   int rc;
@@ -514,7 +515,7 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
       TBK_HIP(hipStreamSynchronize(ctx->stream));
     }
   }
-  prof_end_call(ctx);
+  tbk_prof_end_call(ctx);
   return rc;
 }
 
@@ -522,7 +523,7 @@ int tbk_sample_tile(tbk_ctx* ctx, const tbk_cov_in* in, int32_t num_samples, tbk
   if (!ctx || !in || !out || num_samples <= 0) return TBK_EINVAL;
   if (in->mem != out->mem) return TBK_EINVAL;
   TBK_HIP(hipSetDevice(ctx->device));
-  prof_begin_call(ctx);
+  tbk_prof_begin_call(ctx);
   TBK_TRY(ws_begin_call(ctx, (size_t)in->n_records * 96 + ((size_t)8 << 20)));
   int rc;
   if (in->mem == TBK_MEM_DEVICE) {
@@ -557,7 +558,7 @@ int tbk_sample_tile(tbk_ctx* ctx, const tbk_cov_in* in, int32_t num_samples, tbk
       TBK_HIP(hipStreamSynchronize(ctx->stream));
     }
   }
-  prof_end_call(ctx);
+  tbk_prof_end_call(ctx);
   return rc;
 }
 

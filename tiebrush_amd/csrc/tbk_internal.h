@@ -118,6 +118,7 @@ struct tbk_ctx {
   tbk_ctx* side_ctx = nullptr;
   TbkWorker* side_worker = nullptr;
   bool side_times_pending = false;
+  void* bam_dev = nullptr;       // device-decoded BAM input (bamdev.hip): inflated streams + record index + the SoA tile's arrays
 };
 
 // side context (created on first use; nullptr if that fails -> the caller runs the branch inline), and the call
@@ -172,7 +173,10 @@ static inline void tbk_prof_end(tbk_ctx* ctx) {
     tbk_prof_end(ctx);                                                                \
   } while (0)
 
+void tbk_prof_begin_call(tbk_ctx* ctx);  // brackets of one API call for the per-kernel event timing (tbk_set_profiling)
+void tbk_prof_end_call(tbk_ctx* ctx);
 int tbk_check_launch(tbk_ctx* ctx, const char* what);  // hipGetLastError -> TBK_EHIP
+extern "C" void tbk_bam_release(tbk_ctx* ctx);
 // small host tables go to the device through the context's pinned staging block: tbk_stage_acquire waits until the previous
 // upload out of it has run (a no-op almost always) and returns the block, tbk_stage_release marks the upload just queued
 void* tbk_stage_acquire(tbk_ctx* ctx);
