@@ -145,7 +145,7 @@ def test_cli_tiling_by_reference_is_exact(tmp_path):
     from tiebrush_amd import bamio
     a, b = str(tmp_path / "one.bam"), str(tmp_path / "tiled.bam")
     _run([os.path.join(BIN, "tiebrush"), "-o", a] + sample_paths("t2"))
-    env = dict(os.environ, TBK_TILE_RECORDS="1000")
+    env = dict(os.environ, TBK_TILE_RECORDS="1000", TBK_DEVICE_DECODE="0")
     r = subprocess.run([os.path.join(BIN, "tiebrush"), "-o", b] + sample_paths("t2"), check=True, capture_output=True, text=True, env=env)
     assert "242910 input records written as 8179" in r.stderr
     ra, rb = bamio.bgzf_decompress(open(a, "rb").read()), bamio.bgzf_decompress(open(b, "rb").read())
@@ -158,7 +158,7 @@ def test_cli_tiling_by_reference_is_exact(tmp_path):
     paths = synth.write_bams(tile, str(tmp_path / "syn"))
     c, d = str(tmp_path / "c.bam"), str(tmp_path / "d.bam")
     _run([os.path.join(BIN, "tiebrush"), "-o", c] + paths)
-    subprocess.run([os.path.join(BIN, "tiebrush"), "-o", d] + paths, check=True, capture_output=True, env=dict(os.environ, TBK_TILE_RECORDS="1"))
+    subprocess.run([os.path.join(BIN, "tiebrush"), "-o", d] + paths, check=True, capture_output=True, env=dict(os.environ, TBK_TILE_RECORDS="1", TBK_DEVICE_DECODE="0"))
     rc_, rd_ = bamio.bgzf_decompress(open(c, "rb").read()), bamio.bgzf_decompress(open(d, "rb").read())
     assert rc_[bamio.parse_header(rc_)[1]:] == rd_[bamio.parse_header(rd_)[1]:]
 
@@ -183,7 +183,7 @@ def test_cli_streams_many_inputs_with_few_descriptors_and_small_tiles(tmp_path):
     one, tiled = str(tmp_path / "one.bam"), str(tmp_path / "tiled.bam")
     _run([os.path.join(BIN, "tiebrush"), "-o", one] + args + [lst])
     r = subprocess.run([os.path.join(BIN, "tiebrush"), "-o", tiled] + args + [lst], check=True, capture_output=True, text=True,
-                       env=dict(os.environ, TBK_TILE_RECORDS="2000", TBK_TIMING="1"), preexec_fn=limit)
+                       env=dict(os.environ, TBK_TILE_RECORDS="2000", TBK_TIMING="1", TBK_DEVICE_DECODE="0"), preexec_fn=limit)
     assert "%d input records written as %d" % (flat["n_passed"], flat["n_groups"]) in r.stderr
     ntiles = int([l for l in r.stderr.splitlines() if l.startswith("tiles:")][0].split()[1])
     assert ntiles > 5

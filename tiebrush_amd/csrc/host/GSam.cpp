@@ -1,5 +1,9 @@
 #include "GSam.h"
 
+#include <stdlib.h>
+
+#include <algorithm>
+
 #include <stdarg.h>
 #include <string.h>
 
@@ -142,7 +146,9 @@ GSamWriter::GSamWriter(const char* fname, sam_hdr_t* bh, GSamFileType ftype) {
   if (!bh) GError("Error: no header data provided for GSamWriter::create()!\n");
   if (ftype != GSamFile_BAM) GError("Error: only BAM output is supported\n");
   hdr_ = *bh;
-  if (!w_.open(fname)) GError("Error: could not create output file %s\n", fname);
+  // zlib level of the BGZF members: 6 as htslib's default; TBK_BAM_LEVEL overrides (the records are the same at any level)
+  const int level = getenv("TBK_BAM_LEVEL") ? std::max(0, std::min(9, atoi(getenv("TBK_BAM_LEVEL")))) : 6;
+  if (!w_.open(fname, level)) GError("Error: could not create output file %s\n", fname);
   std::vector<uint8_t> h;
   hdr_.serialize(h);
   if (!w_.write(h.data(), h.size())) GError("Error writing the header to %s\n", fname);

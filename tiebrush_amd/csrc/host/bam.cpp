@@ -352,7 +352,7 @@ bool BamFile::open(const std::string& p, std::string& err, int threads) {
   header_done_ = false;
   // the header may span several members: inflate until it parses
   for (;;) {
-    if (!fill(0, err, threads)) return false;
+    if (!fill(0, err, threads, (size_t)256 << 10)) return false;  // (a header-sized read: the records are read when a tile asks for them)
     if (header_done_) return true;
     if (eof_) {
       err = "truncated BAM header (" + p + ")";

@@ -10,6 +10,9 @@
 #include <string>
 #include <unistd.h>
 
+#include <functional>
+#include <atomic>
+#include <sys/stat.h>
 #include <chrono>
 #include <thread>
 #include <vector>
@@ -141,7 +144,151 @@ int main(int argc, char* argv[]) {
     std::vector<int32_t> yd;
     TInputFiles::TilePlan plan;
     size_t n_tiles = 0;
-    for (;;) {
+    std::function<tbh::RecView(uint32_t)> get_record = [&](uint32_t g) { return inRecords.record(rep[g]); };
+    // flushPData tagging (tiebrush.cpp:506-525): the groups are independent, so slices of them are tagged, framed and
+    // deflated by worker threads into per-slice runs of BGZF members, which then go to the writer in order
+    auto write_groups = [&](uint32_t ng) {
+      const int nt = ng < 4096 ? 1 : nthreads;
+      std::vector<std::vector<uint8_t>> runs((size_t)nt);
+      const int level = outfile.level();
+      auto tag_slice = [&](int t) {
+        const uint32_t g0 = (uint32_t)((uint64_t)ng * t / nt), g1 = (uint32_t)((uint64_t)ng * (t + 1) / nt);
+        std::vector<uint8_t> o;
+        tbh::BamRec rr;
+        for (uint32_t g = g0; g < g1; ++g) {
+          tbh::RecView v = get_record(g);
+          rr.d.assign(v.p, v.p + v.len);
+          rr.update_float("YC", (float)yc[g]);
+          rr.update_int("YX", yx[g]);
+          if (yd[g] > 0)
+            rr.update_int("YD", yd[g]);
+          else
+            rr.del("YD");
+          const uint32_t bs = (uint32_t)rr.d.size();
+          const uint8_t le[4] = {(uint8_t)bs, (uint8_t)(bs >> 8), (uint8_t)(bs >> 16), (uint8_t)(bs >> 24)};
+          o.insert(o.end(), le, le + 4);
+          o.insert(o.end(), rr.d.begin(), rr.d.end());
+        }
+        // BGZF members are independent deflate streams: the slice compresses itself, the writer only appends
+        if (!tbh::bgzf_deflate_members(o.data(), o.size(), level, runs[(size_t)t])) GError("Error: deflate failed\n");
+      };
+      if (nt == 1) {
+        tag_slice(0);
+      } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) th.emplace_back(tag_slice, t);
+        for (auto& x : th) x.join();
+      }
+      for (auto& z : runs) outfile.write_members(z.data(), z.size());
+    };
+    // ---- device decode: when the inputs fit, their BGZF members go to the GPU as they are — inflate,
+    // record index, aux scan and SoA happen there (tbk_bam_decode), the collapse reads the tile where it lies, and only the
+    // representatives' raw records come back (tbk_bam_records) to be tagged.  Anything it cannot take falls through to the
+    // streaming host path below.
+    bool done_on_device = false;
+    {
+      const char* e = getenv("TBK_DEVICE_DECODE");
+      const bool want = e ? atoi(e) != 0 : true;
+      uint64_t total = 0;
+      const size_t k = inRecords.freaders.size();
+      std::vector<uint64_t> fsz(k, 0);
+      for (size_t f = 0; f < k; ++f) {
+        struct stat st;
+        if (stat(inRecords.freaders[f]->fname.c_str(), &st) == 0) fsz[f] = (uint64_t)st.st_size;
+        total += fsz[f];
+      }
+      const uint64_t lim = getenv("TBK_DEVICE_DECODE_MAX") ? (uint64_t)atoll(getenv("TBK_DEVICE_DECODE_MAX")) : ((uint64_t)6 << 30);
+      if (want && total > 0 && total <= lim) {
+        auto t0 = tnow();
+        std::vector<std::vector<uint8_t>> comp(k);
+        {
+          std::atomic<size_t> nf{0};
+          std::atomic<bool> ok{true};
+          auto w = [&]() {
+            for (;;) {
+              size_t f = nf.fetch_add(1);
+              if (f >= k) break;
+              comp[f].resize(fsz[f]);
+              FILE* fp = fopen(inRecords.freaders[f]->fname.c_str(), "rb");
+              if (!fp || fread(comp[f].data(), 1, fsz[f], fp) != fsz[f]) ok = false;
+              if (fp) fclose(fp);
+            }
+          };
+          std::vector<std::thread> th;
+          for (int t = 0; t < std::min<int>(nthreads, (int)k); ++t) th.emplace_back(w);
+          for (auto& x : th) x.join();
+          if (!ok) GError("Error: reading the input failed\n");
+        }
+        std::vector<const uint8_t*> ptr(k);
+        std::vector<uint8_t> tb(k);
+        for (size_t f = 0; f < k; ++f) {
+          ptr[f] = comp[f].data();
+          tb[f] = inRecords.freaders[f]->tbMerged ? 1 : 0;
+        }
+        std::vector<uint32_t> fo(k + 1, 0);
+        auto t_read = tnow();
+        need_ctx();
+        auto t_ctxw = tnow();
+        tbk_soa_in in;
+        rc = tbk_bam_decode(ctx, (uint32_t)k, ptr.data(), fsz.data(), tb.data(), opt.strategy == TBK_STRAT_FULL, opt.collapse_same != 0, &in, fo.data());
+        auto t1 = tnow();
+        if (rc == 0) {
+          comp.clear();
+          comp.shrink_to_fit();
+          const size_t n = in.n_records;
+          rep.resize(n ? n : 1);
+          yc.resize(n ? n : 1);
+          yx.resize(n ? n : 1);
+          yd.resize(n ? n : 1);
+          tbk_groups_out out;
+          memset(&out, 0, sizeof(out));
+          out.mem = TBK_MEM_HOST;
+          out.cap_groups = (uint32_t)(n ? n : 1);
+          out.rep = rep.data();
+          out.yc = yc.data();
+          out.yx = yx.data();
+          out.yd = yd.data();
+          rc = tbk_collapse_tile(ctx, &opt, &in, &out);
+          auto t_col = tnow();
+          if (rc == TBK_EUNSORTED) GError("Error: an input file is not coordinate-sorted!\n");
+          if (rc != 0) GError("Error: GPU collapse failed: %s (%s)\n", tbk_strerror(rc), tbk_last_error(ctx));
+          std::vector<uint64_t> roff((size_t)out.n_groups + 1, 0);
+          std::vector<uint8_t> blob((size_t)out.n_groups * 96 + 4096);
+          rc = tbk_bam_records(ctx, rep.data(), out.n_groups, TBK_MEM_HOST, blob.data(), blob.size(), roff.data());
+          if (rc == TBK_E2BIG) {
+            blob.resize(roff[out.n_groups]);
+            rc = tbk_bam_records(ctx, rep.data(), out.n_groups, TBK_MEM_HOST, blob.data(), blob.size(), roff.data());
+          }
+          if (rc != 0) GError("Error: fetching the representative records failed: %s (%s)\n", tbk_strerror(rc), tbk_last_error(ctx));
+          auto t_rec = tnow();
+          tbk_bam_release(ctx);
+          auto t2 = tnow();
+          if (timing)
+            fprintf(stderr, "device path ms: read files %.1f | wait for the HIP context %.1f | decode %.1f | collapse %.1f | fetch representatives %.1f | release %.1f\n",
+                    tms(t0, t_read), tms(t_read, t_ctxw), tms(t_ctxw, t1), tms(t1, t_col), tms(t_col, t_rec), tms(t_rec, t2));
+          get_record = [&](uint32_t g) {
+            tbh::RecView v;
+            v.p = blob.data() + roff[g] + 4;
+            v.len = (uint32_t)(roff[g + 1] - roff[g] - 4);
+            return v;
+          };
+          write_groups(out.n_groups);
+          auto t3 = tnow();
+          ms_inflate += tms(t0, t1);
+          ms_gpu += tms(t1, t2);
+          ms_tag += tms(t2, t3);
+          inCounter += out.n_passed;
+          outCounter += out.n_groups;
+          n_tiles = 1;
+          done_on_device = true;
+          if (timing) fprintf(stderr, "device decode: %zu records from %llu compressed bytes\n", n, (unsigned long long)total);
+        } else if (timing) {
+          fprintf(stderr, "device decode not used (%s: %s): streaming host path\n", tbk_strerror(rc), tbk_last_error(ctx));
+        }
+      }
+    }
+    get_record = done_on_device ? get_record : std::function<tbh::RecView(uint32_t)>([&](uint32_t g) { return inRecords.record(rep[g]); });
+    for (; !done_on_device;) {
       auto ti = tnow();
       const bool more = inRecords.next_tile(plan, tile_records, nthreads);
       ms_inflate += tms(ti, tnow());
@@ -169,43 +316,7 @@ int main(int argc, char* argv[]) {
       auto t2 = tnow();
       if (rc == TBK_EUNSORTED) GError("Error: an input file is not coordinate-sorted!\n");
       if (rc != 0) GError("Error: GPU collapse failed: %s (%s)\n", tbk_strerror(rc), tbk_last_error(ctx));
-      // flushPData tagging (tiebrush.cpp:506-525): the groups are independent, so slices of them are tagged and framed
-      // by worker threads into per-slice byte runs, which then go to the writer in order
-      {
-        const uint32_t ng = out.n_groups;
-        const int nt = ng < 4096 ? 1 : nthreads;
-        std::vector<std::vector<uint8_t>> runs((size_t)nt);   // per slice: its records, tagged, framed and deflated into BGZF members
-        const int level = outfile.level();
-        auto tag_slice = [&](int t) {
-          const uint32_t g0 = (uint32_t)((uint64_t)ng * t / nt), g1 = (uint32_t)((uint64_t)ng * (t + 1) / nt);
-          std::vector<uint8_t> o;
-          tbh::BamRec rr;
-          for (uint32_t g = g0; g < g1; ++g) {
-            tbh::RecView v = inRecords.record(rep[g]);
-            rr.d.assign(v.p, v.p + v.len);
-            rr.update_float("YC", (float)yc[g]);
-            rr.update_int("YX", yx[g]);
-            if (yd[g] > 0)
-              rr.update_int("YD", yd[g]);
-            else
-              rr.del("YD");
-            const uint32_t bs = (uint32_t)rr.d.size();
-            const uint8_t le[4] = {(uint8_t)bs, (uint8_t)(bs >> 8), (uint8_t)(bs >> 16), (uint8_t)(bs >> 24)};
-            o.insert(o.end(), le, le + 4);
-            o.insert(o.end(), rr.d.begin(), rr.d.end());
-          }
-          // BGZF members are independent deflate streams: the slice compresses itself, the writer only appends
-          if (!tbh::bgzf_deflate_members(o.data(), o.size(), level, runs[(size_t)t])) GError("Error: deflate failed\n");
-        };
-        if (nt == 1) {
-          tag_slice(0);
-        } else {
-          std::vector<std::thread> th;
-          for (int t = 0; t < nt; ++t) th.emplace_back(tag_slice, t);
-          for (auto& x : th) x.join();
-        }
-        for (auto& z : runs) outfile.write_members(z.data(), z.size());
-      }
+      write_groups(out.n_groups);
       auto t3 = tnow();
       ms_load += tms(t0, t1);
       ms_gpu += tms(t1, t2);

@@ -432,8 +432,9 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
   if (in->tbmerged)
     for (uint32_t f = 0; f < in->n_files; ++f) any_tb |= in->tbmerged[f] != 0;
   if (in->n_records && any_tb && (!in->yc_in || !in->yx_in || !in->yd_in)) return TBK_EINVAL;
-  if (in->mem != out->mem) return TBK_EINVAL;
-  if (opts->defer_yd && in->mem != TBK_MEM_DEVICE) return TBK_EINVAL;
+  // a device-resident tile (e.g. tbk_bam_decode) may deliver its groups to host arrays; host input needs host output
+  if (in->mem != out->mem && !(in->mem == TBK_MEM_DEVICE && out->mem == TBK_MEM_HOST)) return TBK_EINVAL;
+  if (opts->defer_yd && (in->mem != TBK_MEM_DEVICE || out->mem != TBK_MEM_DEVICE)) return TBK_EINVAL;
   TBK_TRY(finish_yd(ctx));  // a still-pending YD stage of the previous tile owns part of the arena
   TBK_HIP(hipSetDevice(ctx->device));
   tbk_prof_begin_call(ctx);
@@ -442,7 +443,39 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
   int rc;
   ctx->yd_job = nullptr;
   const size_t yd_hint = (size_t)in->n_records * 96 + ((size_t)8 << 20);
-  if (in->mem == TBK_MEM_DEVICE) {
+  if (in->mem == TBK_MEM_DEVICE && out->mem == TBK_MEM_HOST) {
+    tbk_groups_out dout = *out;
+    dout.mem = TBK_MEM_DEVICE;
+    const size_t cap = out->cap_groups, n = in->n_records;
+    TBK_TRY(dalloc(ctx, out->rep, cap, &dout.rep));
+    TBK_TRY(dalloc(ctx, out->yc, cap, &dout.yc));
+    TBK_TRY(dalloc(ctx, out->yx, cap, &dout.yx));
+    TBK_TRY(dalloc(ctx, out->yd, cap, &dout.yd));
+    TBK_TRY(dalloc(ctx, out->g_start, cap, &dout.g_start));
+    TBK_TRY(dalloc(ctx, out->g_end, cap, &dout.g_end));
+    TBK_TRY(dalloc(ctx, out->rec_group, n, &dout.rec_group));
+    TBK_TRY(dalloc(ctx, out->rep_effend, cap, &dout.rep_effend));
+    rc = tbk_collapse_device(ctx, opts, in, &dout);
+    if (rc == 0 && ctx->yd_job) {
+      void* job = ctx->yd_job;
+      ctx->yd_job = nullptr;
+      rc = tbk_collapse_yd_run(ctx, job);
+    }
+    out->n_groups = dout.n_groups;
+    out->n_passed = dout.n_passed;
+    if (rc == 0) {
+      const size_t g = dout.n_groups;
+      TBK_TRY(d2h(ctx, out->rep, dout.rep, g));
+      TBK_TRY(d2h(ctx, out->yc, dout.yc, g));
+      TBK_TRY(d2h(ctx, out->yx, dout.yx, g));
+      TBK_TRY(d2h(ctx, out->yd, dout.yd, g));
+      TBK_TRY(d2h(ctx, out->g_start, dout.g_start, g));
+      TBK_TRY(d2h(ctx, out->g_end, dout.g_end, g));
+      TBK_TRY(d2h(ctx, out->rec_group, dout.rec_group, n));
+      TBK_TRY(d2h(ctx, out->rep_effend, dout.rep_effend, g));
+      TBK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+  } else if (in->mem == TBK_MEM_DEVICE) {
     rc = tbk_collapse_device(ctx, opts, in, out);
     if (rc == 0 && ctx->yd_job) {
       void* job = ctx->yd_job;
