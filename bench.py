@@ -348,6 +348,12 @@ def main():
         line.update(roof)
         if host_path is not None:
             line["kernel_path_host_to_host"] = host_path
+        e2e_path = os.path.join(ROOT, "profiles", "r2_e2e_32x1M.json")
+        if os.path.exists(e2e_path):   # the command lines end to end (BAM files -> BAM file): measured by tools/e2e_bench.py, not in this run
+            e = json.load(open(e2e_path))
+            line["end_to_end"] = {"value": e["records_per_s_end_to_end"], "unit": "records/s", "workload": e["workload"],
+                                  "wall_s": e["tiebrush_wall_s"], "host_decode_wall_s": e.get("host_decode_wall_s"),
+                                  "source": "profiles/r2_e2e_32x1M.json (tools/e2e_bench.py on the same kind of box; process start, BGZF both ways, PCIe inside the clock)"}
         if cpu is not None:
             line["cpu_baseline"] = cpu
     if use_dist:
