@@ -88,9 +88,12 @@ __global__ __launch_bounds__(1024) void scan_small_k(const uint32_t* __restrict_
   if (threadIdx.x == 0 && total) *total = carry;
 }
 
-template <class OutT>
+// INLINE: no spine launch — `part` holds the raw tile sums and every block adds up the ones before it (nb <= SC_INLINE_NB,
+// a few KB out of L2); the last block also writes the grand total.
+constexpr uint32_t SC_INLINE_NB = 4096;
+template <class OutT, bool INLINE>
 __global__ __launch_bounds__(SC_NT) void scan_down_k(const uint32_t* __restrict__ in, OutT* __restrict__ out,
-                                                     const uint64_t* __restrict__ part, uint32_t n) {
+                                                     const uint64_t* __restrict__ part, uint32_t n, uint64_t* __restrict__ total) {
   // striped global access (coalesced), blocked ownership for the scan: the tile is transposed through padded LDS
   __shared__ uint64_t sm[8];
   __shared__ uint32_t tin[SC_TILE + SC_TILE / 8];
@@ -111,8 +114,19 @@ __global__ __launch_bounds__(SC_NT) void scan_down_k(const uint32_t* __restrict_
     v[e] = tin[j + (j >> 3)];
     s += v[e];
   }
+  uint64_t carry;
+  if (INLINE) {
+    uint64_t c = 0;
+    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += SC_NT) c += part[b];
+    uint64_t dummy;
+    (void)block_excl_sum<uint64_t, SC_NT>(c, sm, &dummy);
+    carry = dummy;
+  } else {
+    carry = part[blockIdx.x];
+  }
   uint64_t tot;
-  uint64_t ex = block_excl_sum<uint64_t, SC_NT>(s, sm, &tot) + part[blockIdx.x];
+  uint64_t ex = block_excl_sum<uint64_t, SC_NT>(s, sm, &tot) + carry;
+  if (INLINE && total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = carry + tot;
 #pragma unroll
   for (int e = 0; e < SC_E; ++e) {
     uint32_t j = threadIdx.x * SC_E + e;
@@ -145,8 +159,12 @@ int exscan_impl(tbk_ctx* ctx, const uint32_t* in, OutT* out, uint32_t n, uint64_
   uint64_t* part = ws_alloc<uint64_t>(ctx, nb);
   if (!part) return TBK_ENOMEM;
   TBK_LAUNCH(ctx, "scan_reduce", scan_reduce_k, nb, SC_NT, 0, in, part, n);
-  TBK_LAUNCH(ctx, "scan_spine", scan_spine_k, 1, 1024, 0, part, nb, d_total);
-  TBK_LAUNCH(ctx, "scan_down", (scan_down_k<OutT>), nb, SC_NT, 0, in, out, part, n);
+  if (nb <= SC_INLINE_NB) {
+    TBK_LAUNCH(ctx, "scan_down", (scan_down_k<OutT, true>), nb, SC_NT, 0, in, out, part, n, d_total);
+  } else {
+    TBK_LAUNCH(ctx, "scan_spine", scan_spine_k, 1, 1024, 0, part, nb, d_total);
+    TBK_LAUNCH(ctx, "scan_down", (scan_down_k<OutT, false>), nb, SC_NT, 0, in, out, part, n, d_total);
+  }
   return tbk_check_launch(ctx, "exscan");
 }
 }  // namespace

@@ -117,7 +117,9 @@ __global__ __launch_bounds__(SO_NT) void so_spine_k(T* __restrict__ part, uint32
 }
 
 // store(i, inclusive, exclusive) with exclusive == op-prefix of everything before i (ident for i == 0)
-template <class T, class Op, class Load, class Store>
+// INLINE: `part` holds the raw tile totals (no spine launch) and the block folds the ones before it, in order
+constexpr uint32_t SO_INLINE_NB = 2048;
+template <class T, class Op, class Load, class Store, bool INLINE>
 __global__ __launch_bounds__(SO_NT) void so_down_k(uint32_t n, Load load, Store store, Op op, T ident, const T* __restrict__ part) {
   __shared__ T tile[SO_LDS];
   __shared__ T sm[SO_NT / 64];
@@ -142,7 +144,16 @@ __global__ __launch_bounds__(SO_NT) void so_down_k(uint32_t n, Load load, Store 
   T prev = shfl_up_t(inc, 1);
   if (lane_id() == 63) wl[threadIdx.x >> 6] = inc;
   __syncthreads();
-  T carry = part[blockIdx.x];
+  T carry;
+  if (INLINE) {  // thread t folds a contiguous slice of the earlier tiles' totals; the block scan keeps the slices in order
+    const uint32_t nbp = blockIdx.x, per = (nbp + SO_NT - 1) / SO_NT;
+    T c = ident;
+    for (uint32_t b = threadIdx.x * per, e = min(nbp, b + per); b < e; ++b) c = op(c, part[b]);
+    __syncthreads();  // sm / wl reuse
+    (void)block_incl_scan_op(c, op, sm, &carry);
+  } else {
+    carry = part[blockIdx.x];
+  }
   T ex;
   if (threadIdx.x == 0)
     ex = carry;
@@ -175,7 +186,11 @@ int scan_op_run(tbk_ctx* ctx, const char* name, uint32_t n, Load load, Store sto
   T* part = ws_alloc<T>(ctx, nb);
   if (!part) return TBK_ENOMEM;
   TBK_LAUNCH(ctx, name, (so_reduce_k<T, Op, Load>), nb, SO_NT, 0, n, load, op, ident, part);
-  TBK_LAUNCH(ctx, name, (so_spine_k<T, Op>), 1, SO_NT, 0, part, nb, op, ident);
-  TBK_LAUNCH(ctx, name, (so_down_k<T, Op, Load, Store>), nb, SO_NT, 0, n, load, store, op, ident, part);
+  if (nb <= SO_INLINE_NB) {
+    TBK_LAUNCH(ctx, name, (so_down_k<T, Op, Load, Store, true>), nb, SO_NT, 0, n, load, store, op, ident, part);
+  } else {
+    TBK_LAUNCH(ctx, name, (so_spine_k<T, Op>), 1, SO_NT, 0, part, nb, op, ident);
+    TBK_LAUNCH(ctx, name, (so_down_k<T, Op, Load, Store, false>), nb, SO_NT, 0, n, load, store, op, ident, part);
+  }
   return tbk_check_launch(ctx, name);
 }
