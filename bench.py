@@ -52,10 +52,12 @@ def main():
     ap.add_argument("--reads-per-file", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
-    ap.add_argument("--prof-steps", type=int, default=2)
+    ap.add_argument("--prof-steps", type=int, default=2, help="serialised per-kernel timing steps after the timed region (>= 1)")
+    ap.add_argument("--contexts", type=int, default=2, help="contexts (each with its own host thread) that take the steps in turn")
     ap.add_argument("--cpu-sample-records", type=int, default=12_000_000, help="target size of the CPU-baseline window")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank (shuffle-then-collapse) path even with one rank")
     args = ap.parse_args()
+    args.prof_steps = max(1, args.prof_steps)
 
     import numpy as np
     import torch
@@ -98,10 +100,11 @@ def main():
     # Two contexts take the steps in turn (software pipelining of independent tiles, as a streaming host would run them):
     # the YD list machine of step i — deferred onto its context's side stream — overlaps the tiecov chain of step i and the
     # collapse of step i + 1.  Every step's YD is complete before the timed region ends.
-    ctxs = [api.Context(local_rank), api.Context(local_rank)]
+    NCTX = max(1, args.contexts)
+    ctxs = [api.Context(local_rank) for _ in range(NCTX)]
     ctx = ctxs[0]
     opts_defer = ctx.make_opts(defer_yd=True, **strat)
-    cbufs2, vbufs2 = [{}, {}], [{}, {}]
+    cbufs2, vbufs2 = [{} for _ in range(NCTX)], [{} for _ in range(NCTX)]
     cbufs, vbufs = cbufs2[0], vbufs2[0]
     step_no = [0]
 
@@ -147,7 +150,7 @@ def main():
             # collapse of the owned coordinate range over all files -> tiecov of it, everything resident in HBM
             r = tdist.run_distributed(stitch, tile, rank * files, device=dev, want_coverage=True, device_chain=True, **strat)
             return ({"n_passed": r.n_passed_local, "n_groups": r.n_groups}, r.coverage)
-        i = step_no[0] & 1
+        i = step_no[0] % NCTX
         step_no[0] += 1
         cx = ctxs[i]
         g = cx.collapse(tile, opts=opts_defer, want_coords=True, out=cbufs2[i], raw=True)   # (waits for this context's previous YD stage)
@@ -164,7 +167,7 @@ def main():
     # YD stage — what a streaming host with two workers does.  Launch-bound workloads (config 2) gain most; config 3 keeps the GPU
     # busy either way.
     import threading
-    last = [None, None]
+    last = [None] * NCTX
 
     def run_steps(k):
         if use_dist:
@@ -185,7 +188,7 @@ def main():
             except BaseException as e:                    # a failed step fails the bench, never a silent short count
                 errs.append(e)
 
-        th = [threading.Thread(target=worker, args=(i, (k + 1 - i) // 2)) for i in range(2)]
+        th = [threading.Thread(target=worker, args=(i, (k + NCTX - 1 - i) // NCTX)) for i in range(NCTX)]
         for x in th:
             x.start()
         for x in th:
@@ -207,7 +210,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    g, c = last[0] if last[0] is not None else last[1]
+    g, c = next(x for x in last if x is not None)
     n_passed, n_groups = g["n_passed"], g["n_groups"]
     n_bases, span, n_iv, n_j = c["n_bases"], c["span_bases"], c["n_intervals"], c["n_junctions"]
     stats = torch.tensor([dt, float(n_passed), float(n_bases)], dtype=torch.float64,

@@ -52,46 +52,62 @@ struct EffOp {
   }
 };
 
-__global__ void col_keys_k(ColIn I, ColOpt O, uint64_t* __restrict__ khi, uint64_t* __restrict__ klo, int32_t* __restrict__ kend,
-                           uint8_t* __restrict__ kflags /*bit0 pass, bit1 file head*/, uint16_t* __restrict__ fidx,
-                           uint32_t* __restrict__ err) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= I.n) return;
-  uint32_t lo = 0, hi = I.k;  // last f with file_off[f] <= i
-  while (hi - lo > 1) {
-    uint32_t mid = (lo + hi) >> 1;
-    if (I.file_off[mid] <= i)
-      lo = mid;
-    else
-      hi = mid;
+__global__ __launch_bounds__(256) void col_keys_k(ColIn I, ColOpt O, uint64_t* __restrict__ khi, uint64_t* __restrict__ klo, int32_t* __restrict__ kend,
+                                                  uint8_t* __restrict__ kflags /*bit0 pass, bit1 file head*/, uint16_t* __restrict__ fidx,
+                                                  uint32_t* __restrict__ err) {
+  // the file of the block's first record by one bisection; every thread walks on from there (a block rarely spans two files)
+  __shared__ uint32_t s_f;
+  const uint32_t i0 = blockIdx.x * blockDim.x;
+  if (threadIdx.x == 0) {
+    uint32_t lo = 0, hi = I.k;  // last f with file_off[f] <= i0
+    while (hi - lo > 1) {
+      uint32_t mid = (lo + hi) >> 1;
+      if (I.file_off[mid] <= i0)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    s_f = lo;
   }
-  uint32_t f = lo;
-  uint16_t fl = I.flag[i];
+  const uint32_t i = i0 + threadIdx.x;
+  const bool in = i < I.n;
+  // the record's fields: independent loads, all in flight before the first use
+  const uint16_t fl = in ? I.flag[i] : (uint16_t)0x4;
+  const int pos = in ? I.pos[i] : 0;
+  const int tidv = in ? I.tid[i] : 0;
+  const int mq = in ? (int)I.mapq[i] : 0;
+  const auto nhv = in ? I.nh[i] : TBK_NH_ABSENT;
+  const uint32_t sc = in ? strand_code(I.strand[i]) : 0u;
+  const uint32_t c0 = in ? I.cig_off[i] : 0u, c1 = in ? I.cig_off[i + 1] : 0u;
+  __syncthreads();
+  if (!in) return;
+  uint32_t f = s_f;
+  while (f + 1 < I.k && I.file_off[f + 1] <= i) ++f;
+  const uint32_t* c = I.cig + c0;
+  const uint32_t nc = c1 - c0;
   int start = 0, end = 0;
   if (!(fl & 0x4)) {
-    int l = cigar_reflen(I.cig + I.cig_off[i], I.cig_off[i + 1] - I.cig_off[i]);
-    start = I.pos[i] + 1;
-    end = I.pos[i] + l;
+    int l = cigar_reflen(c, nc);
+    start = pos + 1;
+    end = pos + l;
   }
   bool pass = true;  // passes_options, tiebrush.cpp:532-541
   if (!O.keep_supp && (fl & 0x800)) pass = false;
   if (!O.keep_sec && (fl & 0x100)) pass = false;
   if (fl & 0x4) pass = false;  // keep_unmapped is rejected at the ABI
-  if ((int)I.mapq[i] < O.min_qual) pass = false;
-  int nh = I.nh[i] == TBK_NH_ABSENT ? 0 : I.nh[i];
+  if (mq < O.min_qual) pass = false;
+  int nh = nhv == TBK_NH_ABSENT ? 0 : nhv;
   if (nh > O.max_nh) pass = false;
-  uint64_t h = pass ? strategy_hash(I, O, i) : 0ull;
+  uint64_t h = pass ? strategy_hash(I, O, i, c, nc) : 0ull;
   // Hash word of the key: 31 hashed bits, or — bit 31 set — an EXACT code when the strategy key is a single reference-consuming
   // CIGAR operation (after clip stripping under -P) or a single exon under -E: with (tid,start,strand,span) in the key the
   // operation's length is the span, so the op code alone identifies the alignment and equal keys need no comparison of the
   // CIGARs (three reads in four of an RNA-seq sample).  Order inside a (strand, end) tie set never depends on this word.
   uint32_t h32 = (uint32_t)(h >> 32) & O.hash_mask & 0x7FFFFFFFu;
   if (pass && O.strategy != TBK_STRAT_FULL) {
-    const uint32_t* c = I.cig + I.cig_off[i];
-    uint32_t nc = I.cig_off[i + 1] - I.cig_off[i];
     if (O.strategy == TBK_STRAT_EXON) {
       int nex = 0;
-      walk_exons(I.pos[i], c, nc, [](int, int) {}, &nex);
+      walk_exons(pos, c, nc, [](int, int) {}, &nex);
       if (nex == 1) h32 = 0x8000000Fu;
     } else {
       uint32_t b = 0, e = nc;
@@ -100,12 +116,12 @@ __global__ void col_keys_k(ColIn I, ColOpt O, uint64_t* __restrict__ khi, uint64
     }
   }
   int64_t span = (int64_t)end - (int64_t)start + 1;
-  if (pass && (span < 0 || span >= (1ll << 30) || start < 0 || I.tid[i] < -1)) {  // key fields: tid+1 and start need 31 bits
+  if (pass && (span < 0 || span >= (1ll << 30) || start < 0 || tidv < -1)) {  // key fields: tid+1 and start need 31 bits
     atomicOr(err, TBK_DERR_SPAN);
     span = 0;
   }
   // hi = tid+1 : 31 | start : 31 | strand code : 2   lo = span : 32 | h32   (tid+1 and start are < 2^31 in BAM)
-  khi[i] = ((uint64_t)(uint32_t)(I.tid[i] + 1) << 33) | ((uint64_t)(uint32_t)start << 2) | strand_code(I.strand[i]);
+  khi[i] = ((uint64_t)(uint32_t)(tidv + 1) << 33) | ((uint64_t)(uint32_t)start << 2) | sc;
   klo[i] = ((uint64_t)span << 32) | h32;
   kend[i] = end;
   kflags[i] = (pass ? 1u : 0u) | (i == I.file_off[f] ? 2u : 0u);
@@ -140,6 +156,8 @@ struct EffStore {
   uint32_t* err;
   const uint16_t* fidx;
   uint32_t* head_off;  // [file] compacted offset of the file's first record (files without records: untouched)
+  uint32_t* ceff;      // optional (window path): effective end — or the explicit merge priority — in compacted order
+  const uint64_t* prio;
   __device__ __forceinline__ void operator()(uint32_t i, const EffKey& inc, const EffKey& ex) const {
     if (kflags[i] & 2u) head_off[fidx[i]] = ex.flag_cnt & 0x7FFFFFFFu;
     if (kflags[i] & 1u) {
@@ -150,6 +168,7 @@ struct EffStore {
       chi[d] = khi[i];
       clo[d] = klo[i];
       cval[d] = i;
+      if (ceff) ceff[d] = prio ? (uint32_t)prio[i] : (uint32_t)inc.kend;
     }
     if (i + 1 == n) *n_pass = inc.flag_cnt & 0x7FFFFFFFu;
   }
@@ -1273,6 +1292,7 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
   uint8_t* kflags = ws_alloc<uint8_t>(ctx, n);
   uint16_t* fidx = ws_alloc<uint16_t>(ctx, n);
   int32_t* effend = ws_alloc<int32_t>(ctx, n);
+  uint32_t* ceff = nullptr;  // (window path, allocated below)
   SortBufs sb;
   sb.hi = ws_alloc<uint64_t>(ctx, n);
   sb.lo = ws_alloc<uint64_t>(ctx, n);
@@ -1313,6 +1333,10 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
         return ok;
       }();
   }
+  if (use_win) {
+    ceff = ws_alloc<uint32_t>(ctx, n);
+    if (!ceff) return TBK_ENOMEM;
+  }
   WgOut win_out;
   bool win_done = false;
   uint32_t m = 0, ng = 0;
@@ -1339,7 +1363,7 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
     TBK_LAUNCH(ctx, "col_keys", col_keys_k, cdiv(n, B), B, 0, I, O, khi, klo, kend, kflags, fidx, ctx->d_err);
     {
       EffLoad ld{khi, kend, kflags};
-      EffStore st{khi, klo, kflags, effend, s2.hi, s2.lo, s2.val, sc + 0, n, ctx->d_err, fidx, head_off};
+      EffStore st{khi, klo, kflags, effend, s2.hi, s2.lo, s2.val, sc + 0, n, ctx->d_err, fidx, head_off, use_win ? ceff : nullptr, I.prio_hi};
       EffKey ident{0u, 0u, INT32_MIN, 0u};
       TBK_TRY((scan_op_run<EffKey, EffOp, EffLoad, EffStore>(ctx, "col_effkey_scan", n, ld, st, EffOp{}, ident)));
     }
@@ -1353,7 +1377,7 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
       out->n_passed = m;
       if (m == 0) return 0;
       WgOut wo;
-      TBK_TRY(tbk_window_groups(ctx, I, O.strategy, s2.hi, s2.lo, s2.val, m, run_off, effend, khi, klo, out->rec_group != nullptr, O.seed, &wo, &eb));
+      TBK_TRY(tbk_window_groups(ctx, I, O.strategy, s2.hi, s2.lo, s2.val, ceff, m, run_off, khi, klo, out->rec_group != nullptr, O.seed, &wo, &eb));
       if (eb & TBK_DERR_BIGBUCKET) {  // a pile-up with more distinct alignments than the LDS table holds: sort path
         TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
         use_win = false;
@@ -1387,6 +1411,10 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
                  out->yx, out->g_start, out->g_end, effend, out->rep_effend);
       if (out->rec_group) TBK_LAUNCH(ctx, "col_recgroup", col_recgroup_w_k, cdiv(n, B), B, 0, n, wo.rec_sg, ginv, out->rec_group);
       TBK_TRY(tbk_sync_err(ctx, &eb));
+      if (eb & TBK_DERR_COLLISION) {  // (the verification pass of the window path, wg_finish_k): reseed
+        ++attempt;
+        continue;
+      }
       if (eb) return tbk_derr_to_status(ctx, eb);
       win_out = wo;
       win_done = true;

@@ -61,9 +61,8 @@ __device__ __forceinline__ void clip_view(const uint32_t* __restrict__ c, uint32
   *e = t;
 }
 
-__device__ inline uint64_t strategy_hash(const ColIn& I, const ColOpt& O, uint32_t i) {
-  const uint32_t* c = I.cig + I.cig_off[i];
-  uint32_t n = I.cig_off[i + 1] - I.cig_off[i];
+// (c, n): the record's CIGAR words, I.cig + I.cig_off[i] and their count
+__device__ inline uint64_t strategy_hash(const ColIn& I, const ColOpt& O, uint32_t i, const uint32_t* c, uint32_t n) {
   uint64_t h = O.seed;
   switch (O.strategy) {
     case TBK_STRAT_CIGAR:
@@ -96,6 +95,10 @@ __device__ inline uint64_t strategy_hash(const ColIn& I, const ColOpt& O, uint32
     }
   }
   return h;
+}
+
+__device__ inline uint64_t strategy_hash(const ColIn& I, const ColOpt& O, uint32_t i) {
+  return strategy_hash(I, O, i, I.cig + I.cig_off[i], I.cig_off[i + 1] - I.cig_off[i]);
 }
 
 // exact equality of the strategy keys of two records (start/end/strand are already equal)

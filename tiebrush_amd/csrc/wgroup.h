@@ -21,10 +21,12 @@ struct WgOut {
 };
 
 // chi / clo / cval: the compacted passing records (k runs, run f = [run_off[f], run_off[f+1]), device offsets), m of them (host
-// value); effend by original record index; scratch_hi / scratch_lo: two dead 8-byte-per-record arrays (>= m) to work in.
-// Returns 0 and fills *out (arrays from ctx's workspace), or a TBK status; TBK_DERR_BIGBUCKET / _COLLISION are left in
-// ctx->d_err for the caller's usual read-back to act on (the counts in *out are then meaningless).
+// value); ceff: the effective end of the k-way merge of every compacted record (or, for cross-rank tiles, the low word of the
+// explicit merge priority); scratch_hi / scratch_lo: two dead 8-byte-per-record arrays (>= m) to work in.
+// Returns 0 and fills *out (arrays from ctx's workspace), or a TBK status; TBK_DERR_BIGBUCKET / _COLLISION come back in *err_bits
+// (the counts in *out are then meaningless).  The last kernel queued (wg_finish) may still raise TBK_DERR_COLLISION in ctx->d_err:
+// the caller's next read-back must treat it as a reseed request.
 int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const uint64_t* chi, const uint64_t* clo, const uint32_t* cval,
-                      uint32_t m, const uint32_t* d_run_off, const int32_t* effend, uint64_t* scratch_hi, uint64_t* scratch_lo,
+                      const uint32_t* ceff, uint32_t m, const uint32_t* d_run_off, uint64_t* scratch_hi, uint64_t* scratch_lo,
                       bool want_rec_sg, uint64_t seed, WgOut* out, uint32_t* err_bits);
 bool tbk_window_supported(uint32_t k);

@@ -128,8 +128,7 @@ __global__ void wg_offsets_k(const uint64_t* __restrict__ chi, const uint32_t* _
 struct WgIn {
   const uint64_t *chi, *clo;   // compacted passing records: k runs, each non-decreasing in chi >> 2
   const uint32_t* cval;        // original record index
-  const int32_t* effend;       // [original index] effective end of the k-way merge
-  const uint64_t* prio;        // optional [original index]: explicit merge-order priority (cross-rank tiles) used instead of effend
+  const uint32_t* ceff;        // effective end of the k-way merge (cross-rank tiles: the explicit merge-order priority instead)
   const uint32_t* off;         // [(nw + 1) * k]
   const uint64_t* W;           // [nw - 1] bounds (window w = [W[w-1], W[w]))
   uint32_t k, nw;
@@ -140,14 +139,11 @@ struct WgTemp {                // per window, at the window's record base
   unsigned long long* rep;     // min (effend << 32 | record)
   uint16_t *pfile, *pgl;       // incidence: sample, window-local group
   uint32_t *wg_cnt, *wp_cnt;   // per window: groups, incidences
-  uint32_t* wbase;             // per window: record base
-  uint32_t* rec_slot;          // optional [original index]: temp slot (record base + local group) of the record's group
+  uint32_t* wbase;             // [nw + 1] per window: record base (wg_rowsum_k)
+  uint32_t* cslot;             // [compacted record] window base + number of the record's group inside the window ...
+  uint32_t* c2r;               // ... and from that number to the group's temp slot (window base + rank by key)
   unsigned long long* dbg;     // optional [32]: cycles / blocks / records per block kind (TBK_WG_DEBUG)
 };
-
-__device__ __forceinline__ uint32_t wg_effend(const WgIn& In, uint32_t rec) {
-  return In.prio ? (uint32_t)In.prio[rec] : (uint32_t)In.effend[rec];
-}
 
 __device__ __forceinline__ bool key_less(const uint64_t* hi, const uint64_t* lo, uint32_t a, uint64_t bh, uint64_t bl, uint32_t b) {
   const uint64_t ah = hi[a];
@@ -310,22 +306,46 @@ __device__ __forceinline__ bool wg_prologue(const WgIn& In, uint32_t w, uint32_t
   return true;
 }
 
-// One workgroup per window.  Hash path first (any number of records): the records stream through once into an LDS table
+// wbase[r] = records of all runs before row r of the offsets matrix (r = w: the record base of window w); one wave per row
+__global__ __launch_bounds__(256) void wg_rowsum_k(const uint32_t* __restrict__ off, uint32_t k, uint32_t nrows, uint32_t* __restrict__ wbase) {
+  const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= nrows) return;
+  const uint32_t* row = off + (size_t)r * k;
+  uint32_t sum = 0;
+  for (uint32_t f = lane_id(); f < k; f += 64) sum += row[f] - off[f];  // row 0 = run starts
+  sum = wave_sum(sum);
+  if (lane_id() == 0) wbase[r] = sum;
+}
+
+// the windows that hold records, in window order inside a wave (the order is only a scheduling matter)
+__global__ void wg_list_k(uint32_t nw, const uint32_t* __restrict__ wbase, uint32_t* __restrict__ list, unsigned long long* __restrict__ cnt) {
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool have = w < nw && wbase[w + 1] != wbase[w];
+  const uint64_t bm = __ballot(have);
+  if (!bm) return;
+  unsigned long long base = 0;
+  if (lane_id() == (uint32_t)__builtin_ctzll(bm)) base = atomicAdd(cnt, (unsigned long long)__builtin_popcountll(bm));
+  base = __shfl(base, __builtin_ctzll(bm), 64);
+  if (have) list[base + __builtin_popcountll(bm & ((1ull << lane_id()) - 1ull))] = w;
+}
+
+// One workgroup per window, any number of records: they stream through once, all pieces laid end to end, into an LDS table
 // of groups — claim word = a 64-bit fingerprint of the key, the key itself stored beside it and compared by every record
 // that lands on the slot (a fingerprint collision raises TBK_DERR_COLLISION: the host reseeds) — with per-group count,
-// representative (atomic min of effective end << 32 | record), first record (exact verification of the strategy key)
-// and a bitset of the samples seen; the distinct groups are then merge-sorted by key and written out.  A window with
-// more distinct groups than the table holds falls back to sorting its records in LDS (at most WG_CAP of them: every
-// window except a pile-up on a single base); a pile-up that overflows sends the tile to the sort path.
-__global__ __launch_bounds__(WG_NT, 6) void wg_hash_k(WgIn In, WgTemp T, ColIn I, int strategy, uint32_t gcap, uint32_t nwords,
-                                                      uint64_t seed, uint32_t* __restrict__ ovf /* [0] count, [1..] windows */, uint32_t ovf_cap,
-                                                      uint32_t* __restrict__ err) {
-  __shared__ __align__(16) unsigned char lds[WG_LDS_HASH];
-  __shared__ uint32_t pre[1024 + 1];
+// representative (atomic min of effective end << 32 | record), claim number and a bitset of the samples seen.  Every
+// record leaves (window base + claim number of its group) in cslot; the distinct groups are then merge-sorted by key and
+// written out with the claim -> rank map, from which wg_finish_k verifies the strategy key of every record against its
+// group's representative and derives the record -> group map.  A window with more distinct groups than the table holds
+// goes to the sort kernel's worklist (at most WG_CAP records: every window except a pile-up on a single base); a pile-up
+// that overflows sends the tile to the sort path.
+__global__ __launch_bounds__(WG_NT, 6) void wg_hash_k(WgIn In, WgTemp T, uint32_t gcap, uint32_t nwords, uint64_t seed,
+                                                      const uint32_t* __restrict__ wlist, uint32_t* __restrict__ ovf /* [0] count, [1..] windows */,
+                                                      uint32_t ovf_cap, uint32_t* __restrict__ err) {
+  extern __shared__ __align__(16) unsigned char lds[];
   __shared__ uint32_t sm_u[WG_NW];
   __shared__ uint32_t s_misc[4];
   const uint32_t t = threadIdx.x;
-  const uint32_t w = blockIdx.x;
+  const uint32_t w = wlist[blockIdx.x];
   const uint32_t k = In.k;
   const unsigned long long t_start = T.dbg ? __builtin_readcyclecounter() : 0ull;
   auto dbg_done = [&](int kind, uint32_t nrec) {
@@ -336,64 +356,98 @@ __global__ __launch_bounds__(WG_NT, 6) void wg_hash_k(WgIn In, WgTemp T, ColIn I
       atomicMax(&T.dbg[kind * 4 + 3], __builtin_readcyclecounter() - t_start);
     }
   };
-  uint32_t n_w, wbase;
-  if (!wg_prologue(In, w, pre, sm_u, &n_w, &wbase)) {
-    if (t == 0) {
-      T.wg_cnt[w] = T.wp_cnt[w] = 0;
-      T.wbase[w] = 0;
+  unsigned long long t_last = t_start;
+  auto phase = [&](int i) {  // thread 0's clock between phase marks (TBK_WG_DEBUG)
+    if (T.dbg && threadIdx.x == 0) {
+      const unsigned long long now = __builtin_readcyclecounter();
+      atomicAdd(&T.dbg[16 + i], now - t_last);
+      t_last = now;
     }
-    return;
-  }
-  const uint32_t* row0 = In.off + (size_t)w * k;
-  if (t == 0) T.wbase[w] = wbase;
-  if (n_w == 0) {
+  };
+  const uint32_t wbase = T.wbase[w];
+  const uint32_t n_w = T.wbase[w + 1] - wbase;
+  if (n_w == 0) {  // (also every window that is empty by construction: equal bounds)
     if (t == 0) T.wg_cnt[w] = T.wp_cnt[w] = 0;
     dbg_done(0, 0);
     return;
   }
-
-  // =========================== hash path ===========================
-  // LDS: gcap slots of 44 + 4 nwords bytes (host: gcap = WG_LDS_MAIN / that)
+  // LDS: gcap slots of 44 + 4 nwords bytes, then the pieces' prefix and source bases (host: wg_hash_lds)
   unsigned long long* tc = reinterpret_cast<unsigned long long*>(lds);            // [gcap] claim word (fingerprint), ~0 = empty
   uint64_t* thi = reinterpret_cast<uint64_t*>(tc + gcap);                           // [gcap] key
   uint64_t* tlo = thi + gcap;                                                       // [gcap]
   unsigned long long* trep = reinterpret_cast<unsigned long long*>(tlo + gcap);     // [gcap]
   uint32_t* tcnt = reinterpret_cast<uint32_t*>(trep + gcap);                        // [gcap]
-  uint32_t* tfirst = tcnt + gcap;                                                   // [gcap] first record (verification)
-  uint32_t* tbits = tfirst + gcap;                                                  // [gcap * nwords] samples seen
-  uint16_t* pa = reinterpret_cast<uint16_t*>(tbits + (size_t)gcap * nwords);        // [gcap] slot permutations of the ranking
-  uint16_t* pb = pa + gcap;                                                         // [gcap]
-  for (uint32_t i = t; i < gcap; i += WG_NT) {
-    tc[i] = ~0ull;
-    trep[i] = ~0ull;
-    tcnt[i] = 0;
-  }
-  for (uint32_t i = t; i < gcap * nwords; i += WG_NT) tbits[i] = 0;
-  if (t == 0) {
-    s_misc[0] = 0;  // distinct groups
-    s_misc[1] = 0;  // overflow
+  uint32_t* tci = tcnt + gcap;                                                      // [gcap] claim number of the slot
+  uint32_t* tbits = tci + gcap;                                                     // [gcap * nwords] samples seen
+  uint32_t* pre = tbits + (size_t)gcap * nwords;                                    // [k + 1] first item of piece f
+  uint32_t* rb = pre + (k + 1);                                                     // [k] item e of piece f is compacted record rb[f] + e
+  uint16_t* pa = reinterpret_cast<uint16_t*>(rb + k);                               // [gcap] slots by claim number, then the ranking's ping
+  uint16_t* pb = pa + gcap;                                                         // [gcap] ... and pong
+  {
+    const uint32_t* row0 = In.off + (size_t)w * k;
+    const uint32_t* row1 = row0 + k;
+    uint32_t a[3], len[3], sum = 0;  // k <= 1024 < 3 * WG_NT; thread t owns files 3t .. 3t+2 (blocked: prefix order = file order)
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const uint32_t f = t * 3 + u;
+      a[u] = len[u] = 0;
+      if (f < k) {
+        a[u] = row0[f];
+        const uint32_t b = row1[f];
+        len[u] = b > a[u] ? b - a[u] : 0u;
+      }
+      sum += len[u];
+    }
+    for (uint32_t i = t; i < gcap; i += WG_NT) {
+      tc[i] = ~0ull;
+      trep[i] = ~0ull;
+      tcnt[i] = 0;
+    }
+    for (uint32_t i = t; i < gcap * nwords; i += WG_NT) tbits[i] = 0;
+    if (t == 0) {
+      s_misc[0] = 0;  // distinct groups
+      s_misc[1] = 0;  // overflow
+    }
+    uint32_t tot;
+    uint32_t ex = wg_block_excl<uint32_t>(sum, sm_u, &tot);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const uint32_t f = t * 3 + u;
+      if (f < k) {
+        pre[f] = ex;
+        rb[f] = a[u] - ex;  // (mod 2^32)
+      }
+      ex += len[u];
+    }
+    if (t == 0) pre[k] = n_w;
   }
   __syncthreads();
-  // the window streams through in chunks of WG_NT * WG_R records (all pieces laid end to end): WG_R records per thread so that
-  // their loads, probes and gathers overlap; two barriers per chunk
+  phase(0);
+  // the window streams through in chunks of WG_NT * WG_R records: WG_R records per thread so that their loads and probes
+  // overlap; two barriers per chunk
   for (uint32_t c0 = 0; c0 < n_w; c0 += WG_NT * WG_R) {
-    uint32_t slot[WG_R], rec[WG_R], fil[WG_R];
+    uint32_t slot[WG_R], rec[WG_R], fil[WG_R], src[WG_R], eff[WG_R];
     uint64_t kh[WG_R], kl[WG_R];
     uint32_t won = 0, actm = 0;
 #pragma unroll
     for (int u = 0; u < WG_R; ++u) {
       const uint32_t e = c0 + (uint32_t)u * WG_NT + t;
       slot[u] = 0xFFFFFFFFu;
-      rec[u] = fil[u] = 0;
+      rec[u] = fil[u] = src[u] = eff[u] = 0;
       kh[u] = kl[u] = 0;
       if (e < n_w) {
         actm |= 1u << u;
         fil[u] = piece_of(pre, k, e);
-        const uint32_t src = row0[fil[u]] + (e - pre[fil[u]]);
-        kh[u] = In.chi[src];
-        kl[u] = In.clo[src];
-        rec[u] = In.cval[src];
+        src[u] = rb[fil[u]] + e;
+        kh[u] = In.chi[src[u]];
+        kl[u] = In.clo[src[u]];
+        rec[u] = In.cval[src[u]];
+        eff[u] = In.ceff[src[u]];
       }
+    }
+    if (T.dbg) {
+      if (t == 0 && (kh[0] ^ kl[0] ^ rec[0] ^ eff[0] ^ kh[WG_R - 1] ^ rec[WG_R - 1]) == 0x123456789ull) T.dbg[31] = 1;  // (the loads have landed)
+      phase(2);
     }
 #pragma unroll
     for (int u = 0; u < WG_R; ++u) {
@@ -423,29 +477,27 @@ __global__ __launch_bounds__(WG_NT, 6) void wg_hash_k(WgIn In, WgTemp T, ColIn I
         if ((won >> u) & 1u) {
           thi[slot[u]] = kh[u];
           tlo[slot[u]] = kl[u];
-          tfirst[slot[u]] = rec[u];
-          if (atomicAdd(&s_misc[0], 1u) + 1u > (gcap >> 2) * 3u) s_misc[1] = 1;
+          const uint32_t ci = atomicAdd(&s_misc[0], 1u);
+          tci[slot[u]] = ci;
+          pa[ci] = (uint16_t)slot[u];  // (a claim takes a slot: ci < gcap)
+          if (ci + 1u > (gcap >> 2) * 3u) s_misc[1] = 1;
         }
         if (slot[u] == 0xFFFFFFFFu) s_misc[1] = 1;
       }
     }
-    __syncthreads();  // key and first record of every slot claimed in this chunk are visible
+    phase(3);
+    __syncthreads();  // key and claim number of every slot claimed in this chunk are visible
+    phase(4);
     if (s_misc[1]) break;
-    unsigned long long rr[WG_R];
-#pragma unroll
-    for (int u = 0; u < WG_R; ++u)
-      rr[u] = ((actm >> u) & 1u) ? (((unsigned long long)wg_effend(In, rec[u]) << 32) | rec[u]) : ~0ull;
 #pragma unroll
     for (int u = 0; u < WG_R; ++u) {
       const bool act = (actm >> u) & 1u;
       if (act) {
         const uint32_t s = slot[u];
-        if (thi[s] != kh[u] || tlo[s] != kl[u]) {
-          atomicOr(err, TBK_DERR_COLLISION);  // two keys, one fingerprint
-        } else if (!((won >> u) & 1u) && !((kl[u] >> 31) & 1ull) && !strategy_equal(I, strategy, rec[u], tfirst[s])) {
-          atomicOr(err, TBK_DERR_COLLISION);  // (an exact key — bit 31 of the hash word, col_keys_k — needs no comparison)
-        }
-        if (rr[u] < trep[s]) atomicMin(&trep[s], rr[u]);
+        if (thi[s] != kh[u] || tlo[s] != kl[u]) atomicOr(err, TBK_DERR_COLLISION);  // two keys, one fingerprint
+        T.cslot[src[u]] = wbase + tci[s];
+        const unsigned long long rr = ((unsigned long long)eff[u] << 32) | rec[u];
+        if (rr < trep[s]) atomicMin(&trep[s], rr);
         const uint32_t bi = s * nwords + (fil[u] >> 5), bm = 1u << (fil[u] & 31);
         if (!(tbits[bi] & bm)) atomicOr(&tbits[bi], bm);
       }
@@ -459,35 +511,25 @@ __global__ __launch_bounds__(WG_NT, 6) void wg_hash_k(WgIn In, WgTemp T, ColIn I
         if (act && slot[u] != s0) atomicAdd(&tcnt[slot[u]], 1u);
       }
     }
+    phase(5);
     __syncthreads();
+    phase(6);
   }
   __syncthreads();
   const bool overflow = s_misc[1] != 0;
   const uint32_t d = s_misc[0];
   if (!overflow) {
-    // ---- rank the occupied slots by key, emit groups and incidences in order ----
-    {
-      uint32_t carry = 0;
-      for (uint32_t i0 = 0; i0 < gcap; i0 += WG_NT) {
-        const uint32_t i = i0 + t;
-        const uint32_t occ = (i < gcap && tc[i] != ~0ull) ? 1u : 0u;
-        uint32_t tot;
-        const uint32_t ex = wg_block_excl<uint32_t>(occ, sm_u, &tot);
-        if (occ) pa[carry + ex] = (uint16_t)i;
-        carry += tot;
-      }
-    }
-    __syncthreads();
+    // ---- rank the groups by key (pa holds their slots in claim order), emit groups and incidences in rank order ----
     uint16_t* byrank = wg_merge_sort<2>(pa, pb, d, thi, tlo, gcap);  // d <= 3/4 gcap < 2 * WG_NT
-    uint16_t* other = byrank == pa ? pb : pa;
-    uint32_t* nsr = tfirst;  // (dead after the streaming) [d] samples per group in rank order -> offsets
+    phase(8);
+    for (uint32_t g = t; g < d; g += WG_NT) T.c2r[wbase + tci[byrank[g]]] = wbase + g;
     __syncthreads();
+    uint32_t* nsr = tci;  // (dead from here) [d] samples per group in rank order -> offsets
     for (uint32_t g = t; g < d; g += WG_NT) {
       const uint32_t s = byrank[g];
       uint32_t c = 0;
       for (uint32_t x = 0; x < nwords; ++x) c += (uint32_t)__builtin_popcount(tbits[s * nwords + x]);
       nsr[g] = c;
-      other[s] = (uint16_t)g;  // slot -> rank
     }
     __syncthreads();
     {
@@ -528,16 +570,7 @@ __global__ __launch_bounds__(WG_NT, 6) void wg_hash_k(WgIn In, WgTemp T, ColIn I
       }
       T.ns[wbase + g] = c;
     }
-    if (T.rec_slot) {  // second pass over the window: record -> its group's rank
-      for (uint32_t e = t; e < n_w; e += WG_NT) {
-        const uint32_t f = piece_of(pre, k, e);
-        const uint32_t src = row0[f] + (e - pre[f]);
-        const unsigned long long F = wg_fingerprint(In.chi[src], In.clo[src], seed);
-        uint32_t hs = (uint32_t)(((F >> 32) * gcap) >> 32);
-        for (uint32_t probe = 0; probe < gcap && tc[hs] != F; ++probe) hs = hs + 1 == gcap ? 0u : hs + 1;  // (every record was inserted)
-        T.rec_slot[In.cval[src]] = wbase + other[hs];
-      }
-    }
+    phase(9);
     dbg_done(2, n_w);
     return;
   }
@@ -601,7 +634,7 @@ __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgTemp T, ColIn I
     const unsigned long long t_load = t_start, t_sort = T.dbg ? __builtin_readcyclecounter() : 0ull;
     // ---- heads, group ids, incidences: thread t owns the WG_E consecutive sorted positions from t * WG_E ----
     const uint32_t q0 = t * WG_E;
-    uint32_t ix[WG_E], fl[WG_E], recs[WG_E];
+    uint32_t ix[WG_E], fl[WG_E], recs[WG_E], srci[WG_E];
     uint32_t hf = 0;  // bit u: group head, bit 8 + u: first record of its sample inside the group
     {
       uint32_t pxv = 0, pf = 0;
@@ -622,11 +655,13 @@ __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgTemp T, ColIn I
         ix[u] = 0;
         fl[u] = 0;
         recs[u] = 0;
+        srci[u] = 0;
         vb[u] = 0;
         if (q < n_w) {
           ix[u] = src[q];
           const uint64_t h = hi[ix[u]], l = lo[ix[u]];
           fl[u] = piece_of(pre, k, ix[u]);
+          srci[u] = row0[fl[u]] + (ix[u] - pre[fl[u]]);
           recs[u] = val[ix[u]];
           const bool head = q == 0 || h != ph || l != pl;
           const bool fh = head || fl[u] != pf;
@@ -664,13 +699,14 @@ __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgTemp T, ColIn I
             T.hi[wbase + gl[u]] = hi[ix[u]];
             T.lo[wbase + gl[u]] = lo[ix[u]];
             T.poff[wbase + gl[u]] = pl;
+            T.c2r[wbase + gl[u]] = wbase + gl[u];
           }
           if (fh) {
             T.pfile[wbase + pl] = (uint16_t)fl[u];
             T.pgl[wbase + pl] = (uint16_t)gl[u];
             ++pl;
           }
-          if (T.rec_slot) T.rec_slot[recs[u]] = wbase + gl[u];
+          T.cslot[srci[u]] = wbase + gl[u];
         }
       }
     }
@@ -687,7 +723,7 @@ __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgTemp T, ColIn I
     unsigned long long rr[WG_E];
 #pragma unroll
     for (int u = 0; u < WG_E; ++u)  // eight independent gathers in flight
-      rr[u] = q0 + u < n_w ? (((unsigned long long)wg_effend(In, recs[u]) << 32) | recs[u]) : ~0ull;
+      rr[u] = q0 + u < n_w ? (((unsigned long long)In.ceff[srci[u]] << 32) | recs[u]) : ~0ull;
     __syncthreads();
     {  // runs of one group inside the thread's positions are folded in registers; one set of LDS atomics per run
       uint32_t cg = 0xFFFFFFFFu, c = 0, nsv = 0;
@@ -779,11 +815,23 @@ __global__ void wg_tie_k(uint32_t ng, const uint64_t* __restrict__ ghi, const ui
   if (sg >= ng) return;
   tie[sg] = (sg == 0 || ghi[sg] != ghi[sg - 1] || (glo[sg] >> 32) != (glo[sg - 1] >> 32)) ? 1 : 0;
 }
-__global__ void wg_recsg_k(uint32_t n, const uint32_t* __restrict__ rec_slot, const uint32_t* __restrict__ slot2sg, uint32_t* __restrict__ rec_sg) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t s = rec_slot[i];
-  rec_sg[i] = s == 0xFFFFFFFFu ? 0xFFFFFFFFu : slot2sg[s];
+// One thread per compacted record: its group's temp slot from (cslot, c2r); the strategy key of every record whose key word is
+// not exact (bit 31 of the hash word, col_keys_k) is compared with its group's representative — a member of the group — so a
+// hash collision cannot merge two alignments (TBK_DERR_COLLISION: the host reseeds); optionally record -> group (key order).
+__global__ void wg_finish_k(uint32_t m, const uint64_t* __restrict__ clo, const uint32_t* __restrict__ cval, const uint32_t* __restrict__ cslot,
+                            const uint32_t* __restrict__ c2r, const unsigned long long* __restrict__ trep, const uint32_t* __restrict__ slot2sg,
+                            uint32_t* __restrict__ rec_sg, ColIn I, int strategy, uint32_t* __restrict__ err) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  const uint32_t slot = c2r[cslot[j]];
+  const bool exact = (clo[j] >> 31) & 1ull;
+  if (exact && !rec_sg) return;
+  const uint32_t rec = cval[j];
+  if (rec_sg) rec_sg[rec] = slot2sg[slot];
+  if (!exact) {
+    const uint32_t anchor = (uint32_t)(trep[slot] & 0xFFFFFFFFull);
+    if (anchor != rec && !strategy_equal(I, strategy, rec, anchor)) atomicOr(err, TBK_DERR_COLLISION);
+  }
 }
 
 }  // namespace
@@ -791,7 +839,7 @@ __global__ void wg_recsg_k(uint32_t n, const uint32_t* __restrict__ rec_slot, co
 bool tbk_window_supported(uint32_t k) { return k >= 1 && k <= 1024; }
 
 int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const uint64_t* chi, const uint64_t* clo, const uint32_t* cval,
-                      uint32_t m, const uint32_t* d_run_off, const int32_t* effend, uint64_t* scratch_hi, uint64_t* scratch_lo,
+                      const uint32_t* ceff, uint32_t m, const uint32_t* d_run_off, uint64_t* scratch_hi, uint64_t* scratch_lo,
                       bool want_rec_sg, uint64_t seed, WgOut* out, uint32_t* err_bits) {
   const uint32_t k = I.k;
   const uint32_t B = 256;
@@ -837,29 +885,40 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   T.pgl = ws_alloc<uint16_t>(ctx, m);
   T.wg_cnt = ws_alloc<uint32_t>(ctx, nw);
   T.wp_cnt = ws_alloc<uint32_t>(ctx, nw);
-  T.wbase = ws_alloc<uint32_t>(ctx, nw);
+  T.wbase = ws_alloc<uint32_t>(ctx, (size_t)nw + 1);
+  T.cslot = ws_alloc<uint32_t>(ctx, m);
+  T.c2r = ws_alloc<uint32_t>(ctx, m);
   uint32_t* gbase = ws_alloc<uint32_t>(ctx, nw);
   uint32_t* pbase = ws_alloc<uint32_t>(ctx, nw);
-  T.rec_slot = nullptr;
   T.dbg = nullptr;
   if (getenv("TBK_WG_DEBUG")) {
-    T.dbg = ws_alloc<unsigned long long>(ctx, 16);
-    if (T.dbg) TBK_HIP(hipMemsetAsync(T.dbg, 0, 16 * 8, ctx->stream));
+    T.dbg = ws_alloc<unsigned long long>(ctx, 32);
+    if (T.dbg) TBK_HIP(hipMemsetAsync(T.dbg, 0, 32 * 8, ctx->stream));
   }
-  if (want_rec_sg) {
-    T.rec_slot = ws_alloc<uint32_t>(ctx, I.n);
-    if (!T.rec_slot) return TBK_ENOMEM;
-    TBK_HIP(hipMemsetAsync(T.rec_slot, 0xFF, (size_t)I.n * 4, ctx->stream));
-  }
-  if (!T.pgl || !pbase) return TBK_ENOMEM;
-  WgIn In{chi, clo, cval, effend, I.prio_hi, off, W, k, nw};
+  if (!T.pgl || !pbase || !T.c2r) return TBK_ENOMEM;
+  WgIn In{chi, clo, cval, ceff, off, W, k, nw};
   const uint32_t nwords = cdiv(k, 32);
-  const uint32_t gcap = WG_LDS_HASH / (44u + 4u * nwords);
+  // LDS of the hash kernel: the pieces' tables (8 k + 4 bytes) and the group table share WG_LDS_HASH (four blocks per CU)
+  const uint32_t gcap = (WG_LDS_HASH - (8u * k + 8u)) / (44u + 4u * nwords);
+  const uint32_t lds_hash = gcap * (44u + 4u * nwords) + 8u * k + 8u;
+  TBK_LAUNCH(ctx, "wg_rowsum", wg_rowsum_k, cdiv(nrows, 4), 256, 0, off, k, nrows, T.wbase);
   const uint32_t ovf_cap = nw;
   uint32_t* ovf = ws_alloc<uint32_t>(ctx, (size_t)ovf_cap + 1);
   if (!ovf) return TBK_ENOMEM;
   TBK_HIP(hipMemsetAsync(ovf, 0, sizeof(uint32_t), ctx->stream));
-  TBK_LAUNCH(ctx, "wg_hash", wg_hash_k, nw, WG_NT, 0, In, T, I, strategy, gcap, nwords, seed, ovf, ovf_cap, ctx->d_err);
+  // the windows that hold records (every splitter owns two bounds, so about half of the windows are empty by construction):
+  // the hash kernel's grid is exactly those — an empty block would hold a table's worth of LDS while it finds out
+  uint32_t* wlist = ws_alloc<uint32_t>(ctx, nw);
+  if (!wlist) return TBK_ENOMEM;
+  uint64_t* scw = ctx->d_scalars;
+  TBK_HIP(hipMemsetAsync(scw + 3, 0, sizeof(uint64_t), ctx->stream));
+  TBK_HIP(hipMemsetAsync(T.wg_cnt, 0, (size_t)nw * 4, ctx->stream));
+  TBK_HIP(hipMemsetAsync(T.wp_cnt, 0, (size_t)nw * 4, ctx->stream));
+  TBK_LAUNCH(ctx, "wg_list", wg_list_k, cdiv(nw, B), B, 0, nw, T.wbase, wlist, (unsigned long long*)(scw + 3));
+  TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 3, scw + 3, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  TBK_HIP(hipStreamSynchronize(ctx->stream));
+  const uint32_t nw_live = (uint32_t)ctx->h_scalars[3];
+  if (nw_live) TBK_LAUNCH(ctx, "wg_hash", wg_hash_k, nw_live, WG_NT, lds_hash, In, T, gcap, nwords, seed, wlist, ovf, ovf_cap, ctx->d_err);
   TBK_LAUNCH(ctx, "wg_sort", wg_sort_k, std::min<uint32_t>(nw, 1024u), WG_NT, 0, In, T, I, strategy, ovf, ovf_cap, ctx->d_err);
   uint64_t* sc = ctx->d_scalars;
   TBK_TRY(tbk_exscan_u32(ctx, T.wg_cnt, gbase, nw, sc + 1));
@@ -868,8 +927,14 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   TBK_TRY(tbk_sync_err(ctx, &eb));
   *err_bits = eb;
   if (T.dbg) {
-    unsigned long long h[16];
+    unsigned long long h[32];
     TBK_HIP(hipMemcpy(h, T.dbg, sizeof(h), hipMemcpyDeviceToHost));
+    static const char* ph[11] = {"prologue+init", "-", "key loads", "probe", "barrier 1", "atomics", "barrier 2", "-",
+                                 "rank sort", "emit", "-"};
+    unsigned long long tot = 0;
+    for (int i = 0; i < 11; ++i) tot += h[16 + i];
+    for (int i = 0; i < 11; ++i)
+      fprintf(stderr, "wg_hash phase %-15s %8.1f Mcyc %5.1f %%\n", ph[i], h[16 + i] / 1e6, tot ? 100.0 * h[16 + i] / tot : 0.0);
     const char* nm[3] = {"empty", "sort", "hash"};
     fprintf(stderr, "wg_window lds phases (Mcyc): load %.1f  sort %.1f  heads+verify %.1f  reduce+write %.1f\n", h[12] / 1e6, h[13] / 1e6,
             h[14] / 1e6, h[15] / 1e6);
@@ -902,7 +967,9 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
               out->ydin, out->rep};
     TBK_LAUNCH(ctx, "wg_compact", wg_compact_k, nw, 64, 0, nw, T, gbase, pbase, F);
     TBK_LAUNCH(ctx, "wg_tie", wg_tie_k, cdiv(ng, B), B, 0, ng, out->ghi, out->glo, out->tie);
-    if (want_rec_sg) TBK_LAUNCH(ctx, "wg_recsg", wg_recsg_k, cdiv(I.n, B), B, 0, I.n, T.rec_slot, slot2sg, out->rec_sg);
+    if (want_rec_sg) TBK_HIP(hipMemsetAsync(out->rec_sg, 0xFF, (size_t)I.n * 4, ctx->stream));  // (records that did not pass)
+    TBK_LAUNCH(ctx, "wg_finish", wg_finish_k, cdiv(m, B), B, 0, m, clo, cval, T.cslot, T.c2r, T.rep, slot2sg, out->rec_sg, I, strategy,
+               ctx->d_err);
   }
   return tbk_check_launch(ctx, "window_groups");
 }

@@ -6,3 +6,7 @@ ctx = api.Context(0)
 g = ctx.collapse(dt, strategy="clip")
 os.environ["TBK_WG_DEBUG"] = "1"
 g = ctx.collapse(dt, strategy="clip")
+os.environ.pop("TBK_WG_DEBUG")
+gy = ctx.collapse(dt, strategy="clip")
+os.environ["TBK_WG_DEBUG"] = "1"
+print("no rec_slot (YC only path?)", file=sys.stderr)
