@@ -186,6 +186,7 @@ __device__ __forceinline__ uint32_t piece_of(const uint32_t* pre, uint32_t k, ui
 
 constexpr uint32_t WG_LDS_MAIN = WG_CAP * (8 + 8 + 4 + 2 + 2);  // sort kernel: hi, lo, val, two index permutations = 72 KiB
 constexpr uint32_t WG_LDS_HASH = 34 * 1024;                    // hash kernel: the group table (four blocks per CU)
+constexpr uint32_t WG_LDS_HASH2 = 64 * 1024;                   // second tier (two blocks per CU)
 
 // Stable merge sort of the index permutation `src` (n entries, ping-pong with `dst`; returns where the result lives) by
 // (hi[idx], lo[idx], idx).  In round `len` every element finds its rank in the sibling run by a bisection without branches:
@@ -338,14 +339,12 @@ __global__ void wg_list_k(uint32_t nw, const uint32_t* __restrict__ wbase, uint3
 // group's representative and derives the record -> group map.  A window with more distinct groups than the table holds
 // goes to the sort kernel's worklist (at most WG_CAP records: every window except a pile-up on a single base); a pile-up
 // that overflows sends the tile to the sort path.
-__global__ __launch_bounds__(WG_NT, 6) void wg_hash_k(WgIn In, WgTemp T, uint32_t gcap, uint32_t nwords, uint64_t seed,
-                                                      const uint32_t* __restrict__ wlist, uint32_t* __restrict__ ovf /* [0] count, [1..] windows */,
-                                                      uint32_t ovf_cap, uint32_t* __restrict__ err) {
-  extern __shared__ __align__(16) unsigned char lds[];
-  __shared__ uint32_t sm_u[WG_NW];
-  __shared__ uint32_t s_misc[4];
+// (`final_tier`: an overflowing window of more than WG_CAP records cannot go on to the sort kernel)
+template <int SORT_E /* the ranking sorts at most SORT_E * WG_NT groups */>
+__device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgTemp& T, uint32_t gcap, uint32_t nwords, uint64_t seed, uint32_t w,
+                                               unsigned char* lds, uint32_t* sm_u, uint32_t* s_misc, uint32_t* __restrict__ ovf,
+                                               uint32_t ovf_cap, bool final_tier, uint32_t* __restrict__ err) {
   const uint32_t t = threadIdx.x;
-  const uint32_t w = wlist[blockIdx.x];
   const uint32_t k = In.k;
   const unsigned long long t_start = T.dbg ? __builtin_readcyclecounter() : 0ull;
   auto dbg_done = [&](int kind, uint32_t nrec) {
@@ -386,12 +385,14 @@ __global__ __launch_bounds__(WG_NT, 6) void wg_hash_k(WgIn In, WgTemp T, uint32_
   {
     const uint32_t* row0 = In.off + (size_t)w * k;
     const uint32_t* row1 = row0 + k;
-    uint32_t a[3], len[3], sum = 0;  // k <= 1024 < 3 * WG_NT; thread t owns files 3t .. 3t+2 (blocked: prefix order = file order)
+    // k <= 1024 < 3 * WG_NT; thread t owns the fpt files from t * fpt (blocked: prefix order = file order)
+    const uint32_t fpt = (k + WG_NT - 1) / WG_NT;
+    uint32_t a[3], len[3], sum = 0;
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
-      const uint32_t f = t * 3 + u;
+      const uint32_t f = t * fpt + u;
       a[u] = len[u] = 0;
-      if (f < k) {
+      if ((uint32_t)u < fpt && f < k) {
         a[u] = row0[f];
         const uint32_t b = row1[f];
         len[u] = b > a[u] ? b - a[u] : 0u;
@@ -412,8 +413,8 @@ __global__ __launch_bounds__(WG_NT, 6) void wg_hash_k(WgIn In, WgTemp T, uint32_
     uint32_t ex = wg_block_excl<uint32_t>(sum, sm_u, &tot);
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
-      const uint32_t f = t * 3 + u;
-      if (f < k) {
+      const uint32_t f = t * fpt + u;
+      if ((uint32_t)u < fpt && f < k) {
         pre[f] = ex;
         rb[f] = a[u] - ex;  // (mod 2^32)
       }
@@ -520,7 +521,8 @@ __global__ __launch_bounds__(WG_NT, 6) void wg_hash_k(WgIn In, WgTemp T, uint32_
   const uint32_t d = s_misc[0];
   if (!overflow) {
     // ---- rank the groups by key (pa holds their slots in claim order), emit groups and incidences in rank order ----
-    uint16_t* byrank = wg_merge_sort<2>(pa, pb, d, thi, tlo, gcap);  // d <= 3/4 gcap < 2 * WG_NT
+    uint16_t* byrank = wg_merge_sort<SORT_E>(pa, pb, d, thi, tlo, gcap);  // d <= 3/4 gcap <= SORT_E * WG_NT
+    // (ranking by counting smaller keys — d broadcast reads per group — was measured slower than the merge rounds: 9.1 vs 8.1 ms)
     phase(8);
     for (uint32_t g = t; g < d; g += WG_NT) T.c2r[wbase + tci[byrank[g]]] = wbase + g;
     __syncthreads();
@@ -578,7 +580,7 @@ __global__ __launch_bounds__(WG_NT, 6) void wg_hash_k(WgIn In, WgTemp T, uint32_
   // pile-up sends the tile to the sort path
   if (t == 0) {
     T.wg_cnt[w] = T.wp_cnt[w] = 0;
-    if (n_w > (uint32_t)WG_CAP) {
+    if (final_tier && n_w > (uint32_t)WG_CAP) {
       atomicOr(err, TBK_DERR_BIGBUCKET);
     } else {
       const uint32_t i = atomicAdd(&ovf[0], 1u);
@@ -590,7 +592,31 @@ __global__ __launch_bounds__(WG_NT, 6) void wg_hash_k(WgIn In, WgTemp T, uint32_
   }
 }
 
-// The windows the hash kernel could not hold (more distinct groups than table slots — shallow data): at most WG_CAP records
+// first tier: one block per window that holds records, a table of WG_LDS_HASH bytes (four blocks per CU)
+__global__ __launch_bounds__(WG_NT, 6) void wg_hash_k(WgIn In, WgTemp T, uint32_t gcap, uint32_t nwords, uint64_t seed,
+                                                      const uint32_t* __restrict__ wlist, uint32_t* __restrict__ ovf /* [0] count, [1..] windows */,
+                                                      uint32_t ovf_cap, uint32_t* __restrict__ err) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  __shared__ uint32_t sm_u[WG_NW];
+  __shared__ uint32_t s_misc[4];
+  wg_hash_window<2>(In, T, gcap, nwords, seed, wlist[blockIdx.x], lds, sm_u, s_misc, ovf, ovf_cap, false, err);
+}
+// second tier: the windows with more distinct groups than the first table holds (shallow data) against a table of WG_LDS_HASH2 bytes
+// (two blocks per CU); a fixed grid walks the first tier's worklist.  What overflows again goes to the sort kernel.
+__global__ __launch_bounds__(WG_NT, 6) void wg_hash2_k(WgIn In, WgTemp T, uint32_t gcap, uint32_t nwords, uint64_t seed,
+                                                       const uint32_t* __restrict__ ovf_in, uint32_t* __restrict__ ovf, uint32_t ovf_cap,
+                                                       uint32_t* __restrict__ err) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  __shared__ uint32_t sm_u[WG_NW];
+  __shared__ uint32_t s_misc[4];
+  const uint32_t cnt = ovf_in[0] < ovf_cap ? ovf_in[0] : ovf_cap;
+  for (uint32_t wi = blockIdx.x; wi < cnt; wi += gridDim.x) {
+    __syncthreads();  // (LDS of the previous window is free)
+    wg_hash_window<3>(In, T, gcap, nwords, seed, ovf_in[1 + wi], lds, sm_u, s_misc, ovf, ovf_cap, true, err);
+  }
+}
+
+// The windows the hash kernels could not hold (more distinct groups than table slots — shallow data): at most WG_CAP records
 // each, sorted in LDS.  A fixed grid walks the worklist.
 __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgTemp T, ColIn I, int strategy, const uint32_t* __restrict__ ovf, uint32_t ovf_cap,
                                                       uint32_t* __restrict__ err) {
@@ -904,8 +930,10 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   TBK_LAUNCH(ctx, "wg_rowsum", wg_rowsum_k, cdiv(nrows, 4), 256, 0, off, k, nrows, T.wbase);
   const uint32_t ovf_cap = nw;
   uint32_t* ovf = ws_alloc<uint32_t>(ctx, (size_t)ovf_cap + 1);
-  if (!ovf) return TBK_ENOMEM;
+  uint32_t* ovf2 = ws_alloc<uint32_t>(ctx, (size_t)ovf_cap + 1);
+  if (!ovf || !ovf2) return TBK_ENOMEM;
   TBK_HIP(hipMemsetAsync(ovf, 0, sizeof(uint32_t), ctx->stream));
+  TBK_HIP(hipMemsetAsync(ovf2, 0, sizeof(uint32_t), ctx->stream));
   // the windows that hold records (every splitter owns two bounds, so about half of the windows are empty by construction):
   // the hash kernel's grid is exactly those — an empty block would hold a table's worth of LDS while it finds out
   uint32_t* wlist = ws_alloc<uint32_t>(ctx, nw);
@@ -918,7 +946,16 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 3, scw + 3, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   TBK_HIP(hipStreamSynchronize(ctx->stream));
   const uint32_t nw_live = (uint32_t)ctx->h_scalars[3];
-  if (nw_live) TBK_LAUNCH(ctx, "wg_hash", wg_hash_k, nw_live, WG_NT, lds_hash, In, T, gcap, nwords, seed, wlist, ovf, ovf_cap, ctx->d_err);
+  if (nw_live) {
+    TBK_LAUNCH(ctx, "wg_hash", wg_hash_k, nw_live, WG_NT, lds_hash, In, T, gcap, nwords, seed, wlist, ovf, ovf_cap, ctx->d_err);
+    const uint32_t gcap2 = (WG_LDS_HASH2 - (8u * k + 8u)) / (44u + 4u * nwords);
+    const uint32_t lds_hash2 = gcap2 * (44u + 4u * nwords) + 8u * k + 8u;
+    if (gcap2 < 65536u) {  // (slot numbers are 16-bit in the ranking)
+      TBK_LAUNCH(ctx, "wg_hash2", wg_hash2_k, std::min<uint32_t>(nw_live, 512u), WG_NT, lds_hash2, In, T, gcap2, nwords, seed, ovf, ovf2, ovf_cap,
+                 ctx->d_err);
+      ovf = ovf2;
+    }
+  }
   TBK_LAUNCH(ctx, "wg_sort", wg_sort_k, std::min<uint32_t>(nw, 1024u), WG_NT, 0, In, T, I, strategy, ovf, ovf_cap, ctx->d_err);
   uint64_t* sc = ctx->d_scalars;
   TBK_TRY(tbk_exscan_u32(ctx, T.wg_cnt, gbase, nw, sc + 1));
