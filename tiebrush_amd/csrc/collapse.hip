@@ -399,8 +399,7 @@ __global__ void yd_count_k(ColIn I, uint32_t m, const uint32_t* __restrict__ val
 }
 __global__ void yd_fill_k(ColIn I, uint32_t m, const uint32_t* __restrict__ val, const uint8_t* __restrict__ flags,
                           const uint16_t* __restrict__ fidx, const uint32_t* __restrict__ sgid, const uint32_t* __restrict__ ginv,
-                          const uint32_t* __restrict__ off, const uint32_t* __restrict__ ooff, GroupAcc G, uint64_t* __restrict__ hi,
-                          uint64_t* __restrict__ lo, uint32_t* __restrict__ v) {
+                          const uint32_t* __restrict__ off, const uint32_t* __restrict__ ooff, GroupAcc G, uint64_t* __restrict__ item) {
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= m) return;
   uint32_t gi = val[q];
@@ -411,15 +410,11 @@ __global__ void yd_fill_k(ColIn I, uint32_t m, const uint32_t* __restrict__ val,
   uint32_t p = ooff[o] + (off[q] - off[G.first[sg]]);  // position in output order
   uint8_t s = I.strand[gi];
   if (s != '-') {  // '+' or '.': fsegs[f]
-    hi[p] = (uint64_t)f * 2;
-    lo[p] = o;
-    v[p] = o;
+    item[p] = ((uint64_t)(f * 2) << 32) | o;
     ++p;
   }
   if (s != '+') {  // '-' or '.': rsegs[f]
-    hi[p] = (uint64_t)f * 2 + 1;
-    lo[p] = o;
-    v[p] = o;
+    item[p] = ((uint64_t)(f * 2 + 1) << 32) | o;
   }
 }
 
@@ -445,24 +440,20 @@ __global__ void yd_gcount_w_k(uint32_t ng, const uint32_t* __restrict__ gperm, G
 }
 __global__ void yd_fill_w_k(uint32_t np, const uint16_t* __restrict__ pfile, const uint32_t* __restrict__ pgrp,
                             const uint32_t* __restrict__ gpoff, const uint32_t* __restrict__ ginv, const uint32_t* __restrict__ ooff,
-                            const uint64_t* __restrict__ ghi, uint64_t* __restrict__ hi, uint64_t* __restrict__ lo, uint32_t* __restrict__ v) {
+                            const uint64_t* __restrict__ ghi, uint64_t* __restrict__ item) {
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= np) return;
   const uint32_t sg = pgrp[p];
   const uint32_t o = ginv[sg];
   const uint32_t c = (uint32_t)ghi[sg] & 3u;  // strand code: 0 '+', 1 '-', 2 '.'
   uint32_t pos = ooff[o] + (p - gpoff[sg]) * (c == 2u ? 2u : 1u);
-  const uint64_t f = pfile[p];
+  const uint32_t f = pfile[p];
   if (c != 1u) {  // '+' or '.': fsegs[f]
-    hi[pos] = f * 2;
-    lo[pos] = o;
-    v[pos] = o;
+    item[pos] = ((uint64_t)(f * 2) << 32) | o;
     ++pos;
   }
   if (c != 0u) {  // '-' or '.': rsegs[f]
-    hi[pos] = f * 2 + 1;
-    lo[pos] = o;
-    v[pos] = o;
+    item[pos] = ((uint64_t)(f * 2 + 1) << 32) | o;
   }
 }
 __global__ void col_recgroup_w_k(uint32_t n, const uint32_t* __restrict__ rec_sg, const uint32_t* __restrict__ ginv, int32_t* __restrict__ rec_group) {
@@ -521,10 +512,10 @@ __global__ void yd_gexons_k(ColIn I, uint32_t ng, const uint32_t* __restrict__ g
              &nex);
 }
 
-__global__ void yd_coords_k(uint32_t nit, const uint32_t* __restrict__ v, YdGroups Q, YdItems Y) {
+__global__ void yd_coords_k(uint32_t nit, const uint64_t* __restrict__ v /* item words: group in the low half */, YdGroups Q, YdItems Y) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nit) return;
-  uint32_t o = v[t];
+  uint32_t o = (uint32_t)v[t];
   const uint4 g = Q.pk[o];
   Y.tidp1[t] = g.x;
   Y.start[t] = (int32_t)g.y;
@@ -546,10 +537,10 @@ struct SegMaxYOp {
   }
 };
 struct YdLoad {
-  const uint64_t* list;
+  const uint64_t* list;  // item words: list id in the high half
   YdItems Y;
   __device__ __forceinline__ bool list_head(uint32_t t) const {
-    return t == 0 || list[t] != list[t - 1] || Y.tidp1[t] != Y.tidp1[t - 1];  // new list, or rspacing.reset() (:586-589)
+    return t == 0 || (list[t] >> 32) != (list[t - 1] >> 32) || Y.tidp1[t] != Y.tidp1[t - 1];  // new list, or rspacing.reset() (:586-589)
   }
   __device__ __forceinline__ SegMaxY operator()(uint32_t t) const {
     SegMaxY s;
@@ -668,7 +659,7 @@ __device__ void yd_merge_read(const uint32_t* __restrict__ xs, const uint32_t* _
 
 // thread per chain (short chains, and long chains whose list outgrew the 64 lanes of yd_wave_k)
 __global__ void yd_run_k(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ nids, uint32_t nchains, uint32_t nit,
-                         const uint32_t* __restrict__ chain_first, YdItems Y, const uint32_t* __restrict__ v,
+                         const uint32_t* __restrict__ chain_first, YdItems Y, const uint64_t* __restrict__ v,
                          const uint32_t* __restrict__ noff, const uint32_t* __restrict__ ex_s, const uint32_t* __restrict__ ex_e,
                          SegNodes N, int32_t* __restrict__ g_yd) {
   uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -702,7 +693,7 @@ __global__ void yd_run_k(const uint32_t* __restrict__ ids, const uint32_t* __res
       last_dist = d;
       yd_merge_read(ex_s + xo, ex_e + xo, nex, N, head, alloc);
     }
-    if (d > 0) atomicMax(&g_yd[v[t]], d);
+    if (d > 0) atomicMax(&g_yd[(uint32_t)v[t]], d);
   }
 }
 
@@ -723,7 +714,7 @@ __device__ __forceinline__ uint32_t rl(uint32_t v, int lane) { return (uint32_t)
 
 __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ nids, uint32_t nchains,
                                                 uint32_t nit, const uint32_t* __restrict__ chain_first, YdItems Y,
-                                                const uint32_t* __restrict__ v, const uint32_t* __restrict__ noff,
+                                                const uint64_t* __restrict__ v, const uint32_t* __restrict__ noff,
                                                 const uint32_t* __restrict__ ex_s, const uint32_t* __restrict__ ex_e,
                                                 int32_t* __restrict__ g_yd, uint32_t* __restrict__ ids_over, uint32_t* __restrict__ n_over) {
   if (blockIdx.x >= *nids) return;
@@ -750,7 +741,7 @@ __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids
     b.start = have ? (uint32_t)Y.start[t] : 0u;
     b.nex = have ? Y.nex[t] : 0u;
     b.xo = have ? Y.xo[t] : 0u;
-    b.o = have ? v[t] : 0u;
+    b.o = have ? (uint32_t)v[t] : 0u;
     b.e0 = have ? ex_e[b.xo] : 0u;  // first exon end (its start is the read start)
     b.s1 = (have && b.nex > 1) ? ex_s[b.xo + 1] : 0u;
     b.e1 = (have && b.nex > 1) ? ex_e[b.xo + 1] : 0u;
@@ -1108,13 +1099,9 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
     if (nit64 >= (1ull << 32)) return TBK_E2BIG;
     const uint32_t nit = (uint32_t)nit64;
     if (nit) {
-      SortBufs ib;
-      ib.hi = ws_alloc<uint64_t>(ctx, nit);
-      ib.lo = ws_alloc<uint64_t>(ctx, nit);
-      ib.val = ws_alloc<uint32_t>(ctx, nit);
-      ib.hi2 = ws_alloc<uint64_t>(ctx, nit);
-      ib.lo2 = ws_alloc<uint64_t>(ctx, nit);
-      ib.val2 = ws_alloc<uint32_t>(ctx, nit);
+      // items: one word each, list id (file * 2 + strand list) : 32 | group in output order : 32
+      uint64_t* iv = ws_alloc<uint64_t>(ctx, nit);
+      uint64_t* iv2 = ws_alloc<uint64_t>(ctx, nit);
       YdItems Y;
       Y.tidp1 = ws_alloc<uint32_t>(ctx, nit);
       Y.start = ws_alloc<int32_t>(ctx, nit);
@@ -1127,20 +1114,19 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       uint32_t* chain_first = ws_alloc<uint32_t>(ctx, nit);
       if (!chain_first) return TBK_ENOMEM;
       if (J.win) {
-        TBK_LAUNCH(ctx, "yd_fill", yd_fill_w_k, cdiv(J.np, B), B, 0, J.np, J.pfile, J.pgrp, J.gpoff, J.ginv, ooff, J.shi, ib.hi, ib.lo, ib.val);
+        TBK_LAUNCH(ctx, "yd_fill", yd_fill_w_k, cdiv(J.np, B), B, 0, J.np, J.pfile, J.pgrp, J.gpoff, J.ginv, ooff, J.shi, iv);
       } else {
         ocnt = ws_alloc<uint32_t>(ctx, ng);
         ooff = ws_alloc<uint32_t>(ctx, ng);
         if (!ooff) return TBK_ENOMEM;
         TBK_LAUNCH(ctx, "yd_gcount", yd_gcount_k, cdiv(ng, B), B, 0, ng, m, J.gperm, J.G, ioff, icnt, ocnt);
         TBK_TRY(tbk_exscan_u32(ctx, ocnt, ooff, ng, nullptr));
-        TBK_LAUNCH(ctx, "yd_fill", yd_fill_k, cdiv(m, B), B, 0, I, m, J.val, J.flags, J.fidx, J.sgid, J.ginv, ioff, ooff, J.G, ib.hi, ib.lo,
-                   ib.val);
+        TBK_LAUNCH(ctx, "yd_fill", yd_fill_k, cdiv(m, B), B, 0, I, m, J.val, J.flags, J.fidx, J.sgid, J.ginv, ioff, ooff, J.G, iv);
       }
       {  // stable split by list id (file * 2 + strand list); group order is already in place.  The id range is known:
         uint32_t bits = 1;  // no scan for the varying bits
         while ((1ull << bits) < 2ull * I.k) ++bits;
-        TBK_TRY(tbk_radix_sort128(ctx, &ib, nit, (1ull << bits) - 1ull, 0ull, true));
+        TBK_TRY(tbk_radix_sort_w64(ctx, &iv, &iv2, nit, 32, bits));
       }
       YdGroups Q;
       Q.pk = ws_alloc<uint4>(ctx, ng);
@@ -1149,9 +1135,9 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       if (!Q.xoff) return TBK_ENOMEM;
       TBK_LAUNCH(ctx, "yd_groups", yd_groups_k, cdiv(ng, B), B, 0, I, ng, J.gperm, J.G, J.shi, J.slo, Q);
       TBK_TRY(tbk_exscan_u32(ctx, Q.nex, Q.xoff, ng, sc + 5));
-      TBK_LAUNCH(ctx, "yd_coords", yd_coords_k, cdiv(nit, B), B, 0, nit, ib.val, Q, Y);
+      TBK_LAUNCH(ctx, "yd_coords", yd_coords_k, cdiv(nit, B), B, 0, nit, iv, Q, Y);
       {
-        YdLoad ld{ib.hi, Y};
+        YdLoad ld{iv, Y};
         YdStore st{ld};
         SegMaxY ident{INT32_MIN, 0u};
         TBK_TRY((scan_op_run<SegMaxY, SegMaxYOp, YdLoad, YdStore>(ctx, "yd_chain_scan", nit, ld, st, SegMaxYOp{}, ident)));
@@ -1188,20 +1174,20 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       if (n_short && aux) {
         hipStream_t keep = ctx->stream;
         ctx->stream = aux;
-        TBK_LAUNCH(ctx, "yd_run", yd_run_k, cdiv(n_short, 64), 64, 0, ids_short, ccnt, nchains, nit, chain_first, Y, ib.val, noff, ex_s,
+        TBK_LAUNCH(ctx, "yd_run", yd_run_k, cdiv(n_short, 64), 64, 0, ids_short, ccnt, nchains, nit, chain_first, Y, iv, noff, ex_s,
                    ex_e, N, J.g_yd);
         ctx->stream = keep;
         TBK_HIP(hipEventRecord(ctx->aux_done, aux));
       }
       if (n_long) {
-        TBK_LAUNCH(ctx, "yd_wave", yd_wave_k, n_long, 64, 0, ids_long, ccnt + 1, nchains, nit, chain_first, Y, ib.val, noff, ex_s,
+        TBK_LAUNCH(ctx, "yd_wave", yd_wave_k, n_long, 64, 0, ids_long, ccnt + 1, nchains, nit, chain_first, Y, iv, noff, ex_s,
                    ex_e, J.g_yd, ids_over, ccnt + 2);
         // chains whose list outgrew a wave (count only known on the device: launch for the upper bound)
-        TBK_LAUNCH(ctx, "yd_run_overflow", yd_run_k, cdiv(n_long, 64), 64, 0, ids_over, ccnt + 2, nchains, nit, chain_first, Y, ib.val,
+        TBK_LAUNCH(ctx, "yd_run_overflow", yd_run_k, cdiv(n_long, 64), 64, 0, ids_over, ccnt + 2, nchains, nit, chain_first, Y, iv,
                    noff, ex_s, ex_e, N, J.g_yd);
       }
       if (n_short && !aux)
-        TBK_LAUNCH(ctx, "yd_run", yd_run_k, cdiv(n_short, 64), 64, 0, ids_short, ccnt, nchains, nit, chain_first, Y, ib.val, noff, ex_s,
+        TBK_LAUNCH(ctx, "yd_run", yd_run_k, cdiv(n_short, 64), 64, 0, ids_short, ccnt, nchains, nit, chain_first, Y, iv, noff, ex_s,
                    ex_e, N, J.g_yd);
       if (n_short && aux) TBK_HIP(hipStreamWaitEvent(ctx->stream, ctx->aux_done, 0));
     }

@@ -374,6 +374,82 @@ __global__ __launch_bounds__(RX_NT) void rx_scatter_k(const uint64_t* __restrict
 }
 }  // namespace
 
+// ---- single 64-bit words ordered by a bit range (e.g. id : value packed into one word): the same tiled LSD pass on 8 bytes per
+// element instead of 20; the histogram pass is rx_hist_k ----------------
+namespace {
+__global__ __launch_bounds__(RX_NT) void w64_scatter_k(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint32_t shift, uint32_t n,
+                                                       uint32_t ntiles, uint32_t iter, const uint32_t* __restrict__ table,
+                                                       const uint32_t* __restrict__ totals) {
+  __shared__ uint32_t digit_base[256];
+  __shared__ uint32_t wave_cnt[4][256];
+  __shared__ uint32_t lpos[256];
+  __shared__ uint32_t sm[8];
+  __shared__ uint64_t s_w[RX_SUB];
+  const uint32_t t = threadIdx.x;
+  const uint32_t w = t >> 6;
+  {
+    uint32_t tot_d = totals[t], dummy;
+    uint32_t dbase = block_excl_sum<uint32_t, RX_NT>(tot_d, sm, &dummy);
+    digit_base[t] = dbase + table[(uint64_t)t * ntiles + blockIdx.x];
+  }
+  const uint64_t tile_base = (uint64_t)blockIdx.x * RX_SUB * iter;
+  for (uint32_t it = 0; it < iter; ++it) {
+    const uint64_t sub_base = tile_base + (uint64_t)it * RX_SUB;
+    if (sub_base >= n) break;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wave_cnt[k][t] = 0;
+    __syncthreads();
+    uint64_t kk[RX_E];
+    uint32_t kr[RX_E];
+#pragma unroll
+    for (int e = 0; e < RX_E; ++e) {
+      uint64_t i = sub_base + (uint64_t)w * (64 * RX_E) + (uint64_t)e * 64 + lane_id();
+      kk[e] = i < n ? in[i] : ~0ull;
+    }
+#pragma unroll
+    for (int e = 0; e < RX_E; ++e) {
+      uint64_t i = sub_base + (uint64_t)w * (64 * RX_E) + (uint64_t)e * 64 + lane_id();
+      bool valid = i < n;
+      uint32_t d = (uint32_t)((kk[e] >> shift) & 0xFFu);
+      uint64_t peers = match_digit(d, valid);
+      uint32_t before = (uint32_t)__popcll(peers & lanemask_lt());
+      uint32_t base = valid ? wave_cnt[w][d] : 0u;
+      __builtin_amdgcn_wave_barrier();
+      if (valid && before == 0) wave_cnt[w][d] = base + (uint32_t)__popcll(peers);
+      __builtin_amdgcn_wave_barrier();
+      kr[e] = (base + before) | (d << 16) | (valid ? 0u : 0x80000000u);
+    }
+    __syncthreads();
+    uint32_t c0 = wave_cnt[0][t], c1 = wave_cnt[1][t], c2 = wave_cnt[2][t], c3 = wave_cnt[3][t];
+    uint32_t tot = c0 + c1 + c2 + c3, dummy;
+    uint32_t lp = block_excl_sum<uint32_t, RX_NT>(tot, sm, &dummy);
+    wave_cnt[0][t] = lp;
+    wave_cnt[1][t] = lp + c0;
+    wave_cnt[2][t] = lp + c0 + c1;
+    wave_cnt[3][t] = lp + c0 + c1 + c2;
+    lpos[t] = lp;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < RX_E; ++e) {
+      if (!(kr[e] & 0x80000000u)) {
+        uint32_t d = (kr[e] >> 16) & 0xFFu;
+        s_w[wave_cnt[w][d] + (kr[e] & 0xFFFFu)] = kk[e];
+      }
+    }
+    __syncthreads();
+    uint32_t cnt_sub = (uint32_t)((n - sub_base) < (uint64_t)RX_SUB ? (n - sub_base) : (uint64_t)RX_SUB);
+    for (uint32_t q = t; q < cnt_sub; q += RX_NT) {
+      uint64_t kq = s_w[q];
+      uint32_t d = (uint32_t)((kq >> shift) & 0xFFu);
+      out[digit_base[d] + (q - lpos[d])] = kq;
+    }
+    __syncthreads();
+    digit_base[t] += tot;
+    __syncthreads();
+  }
+}
+}  // namespace
+
 // tile = RX_SUB * iter elements: small inputs get many small tiles (occupancy), big inputs bigger tiles
 // (the digit x tile table stays a few MB)
 static uint32_t rx_iter_for(uint32_t n) {
@@ -423,4 +499,21 @@ int tbk_radix_sort128(tbk_ctx* ctx, SortBufs* b, uint32_t n, uint64_t only_hi, u
     }
   }
   return tbk_check_launch(ctx, "radix_sort128");
+}
+
+// stable sort of 64-bit words by their bits [lo_bit, lo_bit + bits); the result is in *w (swapped with *w2 as the passes go)
+int tbk_radix_sort_w64(tbk_ctx* ctx, uint64_t** w, uint64_t** w2, uint32_t n, uint32_t lo_bit, uint32_t bits) {
+  if (n < 2) return 0;
+  const uint32_t iter = rx_iter_for(n);
+  uint32_t ntiles = cdiv(n, RX_SUB * iter);
+  uint32_t* table = ws_alloc<uint32_t>(ctx, (size_t)256 * ntiles);
+  uint32_t* totals = ws_alloc<uint32_t>(ctx, 256);
+  if (!table || !totals) return TBK_ENOMEM;
+  for (uint32_t shift = lo_bit; shift < lo_bit + bits && shift < 64; shift += 8) {
+    TBK_LAUNCH(ctx, "rx_hist", rx_hist_k, ntiles, RX_NT, 0, *w, shift, n, ntiles, iter, table);
+    TBK_LAUNCH(ctx, "rx_rowscan", rx_rowscan_k, 256, 256, 0, table, ntiles, totals);
+    TBK_LAUNCH(ctx, "rx_scatter", w64_scatter_k, ntiles, RX_NT, 0, *w, *w2, shift, n, ntiles, iter, table, totals);
+    std::swap(*w, *w2);
+  }
+  return tbk_check_launch(ctx, "radix_sort_w64");
 }
