@@ -1126,7 +1126,7 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       {  // stable split by list id (file * 2 + strand list); group order is already in place.  The id range is known:
         uint32_t bits = 1;  // no scan for the varying bits
         while ((1ull << bits) < 2ull * I.k) ++bits;
-        TBK_TRY(tbk_radix_sort_w64(ctx, &iv, &iv2, nit, 32, bits));
+        TBK_TRY(tbk_radix_sort_w64(ctx, &iv, &iv2, nit, ((1ull << bits) - 1ull) << 32, true));
       }
       YdGroups Q;
       Q.pk = ws_alloc<uint4>(ctx, ng);

@@ -501,15 +501,31 @@ int tbk_radix_sort128(tbk_ctx* ctx, SortBufs* b, uint32_t n, uint64_t only_hi, u
   return tbk_check_launch(ctx, "radix_sort128");
 }
 
-// stable sort of 64-bit words by their bits [lo_bit, lo_bit + bits); the result is in *w (swapped with *w2 as the passes go)
-int tbk_radix_sort_w64(tbk_ctx* ctx, uint64_t** w, uint64_t** w2, uint32_t n, uint32_t lo_bit, uint32_t bits) {
+// stable sort of 64-bit words by the bits of `mask`; mask_is_exact: the caller knows which bits can differ — otherwise one
+// reduction over the words (and one read-back) finds the bits that do, and whole constant digits are skipped.  The result is in
+// *w (swapped with *w2 as the passes go).
+int tbk_radix_sort_w64(tbk_ctx* ctx, uint64_t** w, uint64_t** w2, uint32_t n, uint64_t mask, bool mask_is_exact) {
   if (n < 2) return 0;
+  uint64_t vary = mask;
+  if (!mask_is_exact) {
+    uint64_t* d_andor = ctx->d_scalars + 32;
+    uint64_t init[4] = {~0ull, 0ull, ~0ull, 0ull};
+    memcpy(ctx->h_scalars + 32, init, sizeof(init));
+    TBK_HIP(hipMemcpyAsync(d_andor, ctx->h_scalars + 32, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+    uint32_t g = cdiv(n, 256 * 16);
+    if (g > 512) g = 512;
+    TBK_LAUNCH(ctx, "rx_bits", rx_bits_k, g, 256, 0, *w, *w, n, d_andor);
+    TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 32, d_andor, sizeof(init), hipMemcpyDeviceToHost, ctx->stream));
+    TBK_HIP(hipStreamSynchronize(ctx->stream));
+    vary = (ctx->h_scalars[32] ^ ctx->h_scalars[33]) & mask;
+  }
   const uint32_t iter = rx_iter_for(n);
   uint32_t ntiles = cdiv(n, RX_SUB * iter);
   uint32_t* table = ws_alloc<uint32_t>(ctx, (size_t)256 * ntiles);
   uint32_t* totals = ws_alloc<uint32_t>(ctx, 256);
   if (!table || !totals) return TBK_ENOMEM;
-  for (uint32_t shift = lo_bit; shift < lo_bit + bits && shift < 64; shift += 8) {
+  for (uint32_t shift = 0; shift < 64; shift += 8) {
+    if (((vary >> shift) & 0xFFull) == 0) continue;
     TBK_LAUNCH(ctx, "rx_hist", rx_hist_k, ntiles, RX_NT, 0, *w, shift, n, ntiles, iter, table);
     TBK_LAUNCH(ctx, "rx_rowscan", rx_rowscan_k, 256, 256, 0, table, ntiles, totals);
     TBK_LAUNCH(ctx, "rx_scatter", w64_scatter_k, ntiles, RX_NT, 0, *w, *w2, shift, n, ntiles, iter, table, totals);

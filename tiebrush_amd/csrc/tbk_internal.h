@@ -205,8 +205,9 @@ struct SortBufs {
 int tbk_radix_sort128(tbk_ctx* ctx, SortBufs* b, uint32_t n, uint64_t only_hi = ~0ull, uint64_t only_lo = ~0ull,
                       bool masks_are_exact = false);
 size_t tbk_radix_ws_bytes(uint32_t n);
-// stable sort of 64-bit words by their bits [lo_bit, lo_bit + bits); result in *w (swapped with *w2 as the passes go)
-int tbk_radix_sort_w64(tbk_ctx* ctx, uint64_t** w, uint64_t** w2, uint32_t n, uint32_t lo_bit, uint32_t bits);
+// stable sort of 64-bit words by the bits of `mask` (mask_is_exact: no scan for the bits that really vary, no read-back); result in
+// *w (swapped with *w2 as the passes go)
+int tbk_radix_sort_w64(tbk_ctx* ctx, uint64_t** w, uint64_t** w2, uint32_t n, uint64_t mask, bool mask_is_exact);
 // same result for an input made of `nruns` position-sorted runs (msort.hip)
 int tbk_sort_runs(tbk_ctx* ctx, SortBufs* b, uint32_t n_hi, const uint32_t* d_run_off, uint32_t nruns, uint32_t* err,
                   uint32_t* nbig_zeroed);

@@ -47,14 +47,11 @@ constexpr int WG_NW = WG_NT / 64;
 constexpr int WG_R = 4;                  // records per thread and chunk in the pile-up path
 
 // ---- partition ------------------------------------------------------------------------------------------------
-__global__ void wg_sample_k(const uint64_t* __restrict__ chi, uint32_t m, uint32_t s, uint32_t ns, uint64_t* __restrict__ shi,
-                            uint64_t* __restrict__ slo, uint32_t* __restrict__ sval) {
+__global__ void wg_sample_k(const uint64_t* __restrict__ chi, uint32_t m, uint32_t s, uint32_t ns, uint64_t* __restrict__ shi) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= ns) return;
   uint64_t d = (uint64_t)j * s;
   shi[j] = chi[d < m ? d : m - 1] >> 2;
-  slo[j] = 0;
-  sval[j] = j;
 }
 
 // Y sorted samples; splitter i = Y[(i + 1) * g].  Two bounds per splitter: first of a run of equal splitters -> (v, v + 1 if
@@ -884,17 +881,12 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   uint32_t* off = ws_alloc<uint32_t>(ctx, (size_t)nrows * k);
   if (!W || !off) return TBK_ENOMEM;
   if (nsp) {
-    SortBufs sb;
-    sb.hi = ws_alloc<uint64_t>(ctx, ns);
-    sb.lo = ws_alloc<uint64_t>(ctx, ns);
-    sb.val = ws_alloc<uint32_t>(ctx, ns);
-    sb.hi2 = ws_alloc<uint64_t>(ctx, ns);
-    sb.lo2 = ws_alloc<uint64_t>(ctx, ns);
-    sb.val2 = ws_alloc<uint32_t>(ctx, ns);
-    if (!sb.val2) return TBK_ENOMEM;
-    TBK_LAUNCH(ctx, "wg_sample", wg_sample_k, cdiv(ns, B), B, 0, chi, m, s, ns, sb.hi, sb.lo, sb.val);
-    TBK_TRY(tbk_radix_sort128(ctx, &sb, ns, ~0ull, 0ull));
-    TBK_LAUNCH(ctx, "wg_split", wg_split_k, cdiv(nsp, B), B, 0, sb.hi, g, nsp, W);
+    uint64_t* Y = ws_alloc<uint64_t>(ctx, ns);
+    uint64_t* Y2 = ws_alloc<uint64_t>(ctx, ns);
+    if (!Y2) return TBK_ENOMEM;
+    TBK_LAUNCH(ctx, "wg_sample", wg_sample_k, cdiv(ns, B), B, 0, chi, m, s, ns, Y);
+    TBK_TRY(tbk_radix_sort_w64(ctx, &Y, &Y2, ns, ~0ull, false));
+    TBK_LAUNCH(ctx, "wg_split", wg_split_k, cdiv(nsp, B), B, 0, Y, g, nsp, W);
   }
   {
     const uint64_t nthreads = (uint64_t)cdiv(nrows, WG_OR) * k;
