@@ -210,6 +210,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    hbm_used_gb = round((total_b - free_b) / 1e9, 1)      # tile + every context's arena and outputs, after the timed region
     g, c = next(x for x in last if x is not None)
     n_passed, n_groups = g["n_passed"], g["n_groups"]
     n_bases, span, n_iv, n_j = c["n_bases"], c["span_bases"], c["n_intervals"], c["n_junctions"]
@@ -377,7 +379,8 @@ def main():
             "config": {"workload": "%s: %d synthetic sorted BAMs x %d 100bp reads per GPU, %s collapse + tiecov -c -j of the result"
                                    % (profile, files, reads, strat_name),
                        "records_per_gpu": int(n_records), "groups_out": int(n_groups), "parallelism": "files-per-rank x%d" % world,
-                       "resident": "SoA in HBM before the timed region", "generated_on_device_s": round(t_gen, 2)},
+                       "resident": "SoA in HBM before the timed region", "generated_on_device_s": round(t_gen, 2),
+                       "contexts": NCTX, "hbm_in_use_gb": hbm_used_gb},
             "bases_per_s": round(tot_bases * args.steps / dt, 1),
             "tiecov": {"bases_covered_per_step": int(n_bases), "bundle_span_bases": int(span), "intervals": int(n_iv), "junctions": int(n_j)},
         }

@@ -1285,14 +1285,22 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
   sb.val = ws_alloc<uint32_t>(ctx, n);
   sb.hi2 = khi;  // the unsorted key arrays are dead after compaction: reuse them as the ping-pong side
   sb.lo2 = klo;
-  sb.val2 = ws_alloc<uint32_t>(ctx, n);
-  uint8_t* flags = ws_alloc<uint8_t>(ctx, n);
-  uint32_t* ghead = ws_alloc<uint32_t>(ctx, n);
-  uint32_t* gex = ws_alloc<uint32_t>(ctx, n);
-  uint32_t* sgid = ws_alloc<uint32_t>(ctx, n);
+  sb.val2 = nullptr;
+  // per-record arrays of the sort path only (the window path never touches them: allocated when the tile takes the sort path)
+  uint8_t* flags = nullptr;
+  uint32_t *ghead = nullptr, *gex = nullptr, *sgid = nullptr;
+  auto sort_path_arrays = [&]() -> bool {
+    if (sgid) return true;
+    sb.val2 = ws_alloc<uint32_t>(ctx, n);
+    flags = ws_alloc<uint8_t>(ctx, n);
+    ghead = ws_alloc<uint32_t>(ctx, n);
+    gex = ws_alloc<uint32_t>(ctx, n);
+    sgid = ws_alloc<uint32_t>(ctx, n);
+    return sgid != nullptr;
+  };
   uint32_t* head_off = ws_alloc<uint32_t>(ctx, (size_t)in->n_files + 1);
   uint32_t* run_off = ws_alloc<uint32_t>(ctx, (size_t)in->n_files + 1);
-  if (!sgid || !head_off || !run_off) return TBK_ENOMEM;
+  if (!sb.val || !effend || !head_off || !run_off) return TBK_ENOMEM;
   // ceil(log2(files)) merge rounds + one local pass against ~12 radix passes.  Measured on MI355X: 2 files x 1 M
   // 0.17 ms vs 0.47 ms; 16 files x 0.5 M: whole step 3.90 vs 4.13 ms; 64 files x 0.25 M (6 rounds): 8.58 vs 8.67 ms —
   // level there, so more files than that take the radix sort.
@@ -1411,6 +1419,8 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
       }
       break;
     }
+    if (!sort_path_arrays()) return TBK_ENOMEM;
+    s2.val2 = sb.val2;
     uint32_t m_hi = n, ng_hi = n;  // what sizes grids and arrays: the counts themselves, or their upper bound
     if (!lean) {
       TBK_TRY(tbk_sync_err(ctx, &eb));

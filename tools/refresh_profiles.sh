@@ -1,0 +1,19 @@
+#!/bin/bash
+# Regenerates the round's rocprofv3 evidence for the default bench (config 3) on the GPU box; outputs (small) under gpurun_out/prof/.
+# Run through gpurun from the repo root:  gpurun --timeout 1500 -- 'bash tools/refresh_profiles.sh'
+set -u
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/prof; rm -rf $O; mkdir -p $O
+COMMON="--no-cpu-baseline --no-host-path"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -o ks -- python3 bench.py --steps 5 --warmup 2 $COMMON > $O/bench_under_rocprof.json 2> $O/ks.err
+cp $(find $O/ks -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
+rm -rf $O/ks
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pf -o pf -- python3 bench.py --steps 2 --warmup 1 --prof-steps 1 $COMMON > /dev/null 2> $O/pf.err
+python3 tools/pmc_summary.py $(find $O/pf -name "*counter_collection.csv" | head -1) $O/pmc_fetch_size.csv
+rm -rf $O/pf
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pw -o pw -- python3 bench.py --steps 2 --warmup 1 --prof-steps 1 $COMMON > /dev/null 2> $O/pw.err
+python3 tools/pmc_summary.py $(find $O/pw -name "*counter_collection.csv" | head -1) $O/pmc_write_size.csv
+rm -rf $O/pw
+python3 tools/build_traffic.py $O/pmc_fetch_size.csv $O/pmc_write_size.csv $O/traffic.json "c3: 64 files x 5000000 reads, --clip + tiecov"
+python3 bench.py > $O/bench_default.json 2> $O/bench.err
+tail -c 600 $O/bench_under_rocprof.json; echo; ls -la $O
