@@ -1,0 +1,129 @@
+"""The window path of the collapse stage (wgroup.hip) against the oracle, forced onto small tiles (TBK_PATH=window) in both of
+its forms: RAW (keys, filter and effective ends computed inside the window kernels from the input records) and compacted
+(TBK_RAW=0: key pass + scan + compaction first).  Small adversarial tiles (one window), synthetic tiles of many windows with
+every tier (hash table, second table, LDS sort), pile-ups with unsorted ends (the effective-end scan across waves, rows and
+chunks), unmapped records inside and behind the files, inputs the raw form hands back to the general path."""
+import numpy as np
+import pytest
+
+from test_gpu_fuzz import STRATS, _cmp, _rand_tile
+
+pytestmark = pytest.mark.gpu
+
+M, I, D, N, S = 0, 1, 2, 3, 4
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from tiebrush_amd import api
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(params=["1", "0"], ids=["raw", "compacted"])
+def window_mode(request, monkeypatch):
+    monkeypatch.setenv("TBK_PATH", "window")
+    monkeypatch.setenv("TBK_RAW", request.param)
+    return request.param
+
+
+def _tile(files):
+    """files: list of lists of (tid, pos, flag, mapq, strand, nh, [(len, op) ...]) in file order"""
+    from tiebrush_amd import soa
+    allr = [r for f in files for r in f]
+    n, k = len(allr), len(files)
+    fo = np.zeros(k + 1, np.uint32)
+    fo[1:] = np.cumsum([len(f) for f in files])
+    cigs = [[(l << 4) | o for l, o in r[6]] for r in allr]
+    off = np.zeros(n + 1, np.uint32)
+    off[1:] = np.cumsum([len(c) for c in cigs])
+    return soa.SoATile(
+        n_files=k, file_off=fo, tbmerged=np.zeros(k, np.uint8), tid=np.array([r[0] for r in allr], np.int32),
+        pos=np.array([r[1] for r in allr], np.int32), flag=np.array([r[2] for r in allr], np.uint16),
+        mapq=np.array([r[3] for r in allr], np.uint8), strand=np.array([ord(r[4]) for r in allr], np.uint8),
+        nh=np.array([r[5] for r in allr], np.int32), cig_off=off, cig=np.array([x for c in cigs for x in c], np.uint32))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_small_tiles(ctx, window_mode, seed):
+    rng = np.random.default_rng(8100 + seed)
+    for _ in range(10):
+        tile = _rand_tile(rng, with_tb=False)
+        for strat in STRATS:
+            _cmp(ctx, tile, strategy=strat)
+        _cmp(ctx, tile, strategy=str(rng.choice(STRATS)), keep_secondary=True, keep_supplementary=True,
+             max_nh=int(rng.choice([1, 5, 2**31 - 1])), min_qual=int(rng.choice([-1, 1, 31])))
+
+
+@pytest.mark.parametrize("profile,files,reads,kw", [
+    ("c3", 8, 20000, dict(strategy="clip")),                      # deep: hash tier
+    ("c2", 2, 60000, dict()),                                     # shallow: second table / LDS sort tier
+    ("c5", 40, 3000, dict(strategy="exon", max_nh=5, min_qual=1)),  # filters + spliced reads + many files
+    ("c3", 70, 1500, dict(strategy="cigar")),
+])
+def test_many_windows(ctx, window_mode, profile, files, reads, kw):
+    from tiebrush_amd import synth
+    tile = synth.make_tile(files, reads, profile, n_loci=400)
+    _cmp(ctx, tile, **kw)
+
+
+def test_pileup_effective_ends(ctx, window_mode):
+    """One base, thousands of reads per file whose ends go up and down in file order: the representative is the member with the
+    smallest (running maximum of the ends before it in its file, record index) — the scan's carry crosses lanes, waves,
+    rows and chunks of the window kernel, and filtered / unmapped records take part in it exactly as the merge sees them."""
+    rng = np.random.default_rng(5)
+    files = []
+    for f in range(3):
+        recs = []
+        for i in range(int(rng.integers(2500, 5200))):
+            ln = int(rng.choice([30, 30, 40, 50, 50, 75, 90]))
+            flag = int(rng.choice([0, 0, 0, 16, 0x100, 4]))          # secondary: filtered, still raises the running end
+            mapq = int(rng.choice([60, 60, 0]))
+            recs.append((1, 1000, flag, mapq, str(rng.choice(["+", "-"])), 1, [(ln, M)]))
+        pre = [(0, int(p), 0, 60, "+", 1, [(25, M)]) for p in sorted(rng.integers(0, 500, 300))]
+        post = [(1, int(p), 0, 60, "-", 1, [(10, M), (100, N), (15, M)]) for p in sorted(rng.integers(1001, 1400, 700))]
+        tail = [(-1, -1, 4, 0, ".", -(2**31), [])] * 5              # unplaced reads close a sorted BAM
+        files.append(pre + recs + post + tail)
+    tile = _tile(files)
+    _cmp(ctx, tile)
+    _cmp(ctx, tile, min_qual=1)
+    _cmp(ctx, tile, strategy="clip", keep_secondary=True)
+
+
+def test_unmapped_mates_inside_a_run(ctx, window_mode):
+    """an unmapped read placed at its mate's position sits inside a run of equal starts: it neither splits the run nor
+    contributes an end"""
+    recs = [(0, 100, 0, 60, "+", 1, [(50, M)]), (0, 100, 4 | 8, 0, ".", 1, []), (0, 100, 0, 60, "+", 1, [(30, M)]),
+            (0, 100, 0, 60, "+", 1, [(50, M)]), (0, 120, 0, 60, "+", 1, [(30, M)])]
+    other = [(0, 100, 0, 60, "+", 1, [(30, M)]), (0, 100, 0, 60, "+", 1, [(50, M)])]
+    _cmp(ctx, _tile([recs, other]))
+    _cmp(ctx, _tile([other, recs]))
+
+
+def test_inputs_the_raw_form_hands_back(ctx, window_mode):
+    """an inversion among records that do not pass is not an error (the merge order is fixed on what passes and what came
+    before it), an inversion that reaches a passing record is TBK_EUNSORTED — the raw form must not decide either by itself"""
+    from tiebrush_amd import api
+    ok = [(0, 100, 0, 60, "+", 1, [(50, M)]), (0, 300, 0x100, 60, "+", 1, [(50, M)]), (0, 200, 0x100, 60, "+", 1, [(50, M)]),
+          (0, 400, 0, 60, "+", 1, [(50, M)])]
+    _cmp(ctx, _tile([ok, ok]))
+    bad = [(0, 100, 0, 60, "+", 1, [(50, M)]), (0, 300, 0, 60, "+", 1, [(50, M)]), (0, 200, 0, 60, "+", 1, [(50, M)])]
+    with pytest.raises(api.TbkError) as e:
+        ctx.collapse(_tile([ok, bad]))
+    assert e.value.status == -6                                     # TBK_EUNSORTED
+
+
+def test_exact_key_codes(ctx, window_mode):
+    """key words that carry an exact code instead of a hash (single operation, M N M, two exons): alignments that differ only
+    in the split of the first block / the gap, and shapes just beyond the code's field widths (hashed and verified)"""
+    recs = []
+    for a, g in [(10, 100), (11, 99), (10, 101), (1023, 50), (1024, 49), (10, (1 << 20) - 1), (10, 1 << 20), (9, (1 << 20) + 1)]:
+        total = 3_000_000
+        recs.append((0, 500, 0, 60, "+", 1, [(a, M), (g, N), (total - a - g, M)]))
+        recs.append((0, 500, 0, 60, "+", 1, [(a, M), (g, N), (total - a - g, M)]))
+    recs.append((0, 500, 0, 60, "+", 1, [(3_000_000, M)]))
+    recs.append((0, 500, 0, 60, "+", 1, [(1_000_000, M), (1_000_000, D), (1_000_000, M)]))
+    recs.append((0, 500, 0, 60, "+", 1, [(3, S), (10, M), (100, N), (2_999_890, M), (2, S)]))
+    for strat in STRATS[0:1] + STRATS[2:]:
+        _cmp(ctx, _tile([recs, list(reversed(recs))]), strategy=strat)

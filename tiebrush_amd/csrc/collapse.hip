@@ -83,47 +83,11 @@ __global__ __launch_bounds__(256) void col_keys_k(ColIn I, ColOpt O, uint64_t* _
   if (!in) return;
   uint32_t f = s_f;
   while (f + 1 < I.k && I.file_off[f + 1] <= i) ++f;
-  const uint32_t* c = I.cig + c0;
-  const uint32_t nc = c1 - c0;
-  int start = 0, end = 0;
-  if (!(fl & 0x4)) {
-    int l = cigar_reflen(c, nc);
-    start = pos + 1;
-    end = pos + l;
-  }
-  bool pass = true;  // passes_options, tiebrush.cpp:532-541
-  if (!O.keep_supp && (fl & 0x800)) pass = false;
-  if (!O.keep_sec && (fl & 0x100)) pass = false;
-  if (fl & 0x4) pass = false;  // keep_unmapped is rejected at the ABI
-  if (mq < O.min_qual) pass = false;
-  int nh = nhv == TBK_NH_ABSENT ? 0 : nhv;
-  if (nh > O.max_nh) pass = false;
-  uint64_t h = pass ? strategy_hash(I, O, i, c, nc) : 0ull;
-  // Hash word of the key: 31 hashed bits, or — bit 31 set — an EXACT code when the strategy key is a single reference-consuming
-  // CIGAR operation (after clip stripping under -P) or a single exon under -E: with (tid,start,strand,span) in the key the
-  // operation's length is the span, so the op code alone identifies the alignment and equal keys need no comparison of the
-  // CIGARs (three reads in four of an RNA-seq sample).  Order inside a (strand, end) tie set never depends on this word.
-  uint32_t h32 = (uint32_t)(h >> 32) & O.hash_mask & 0x7FFFFFFFu;
-  if (pass && O.strategy != TBK_STRAT_FULL) {
-    if (O.strategy == TBK_STRAT_EXON) {
-      int nex = 0;
-      walk_exons(pos, c, nc, [](int, int) {}, &nex);
-      if (nex == 1) h32 = 0x8000000Fu;
-    } else {
-      uint32_t b = 0, e = nc;
-      if (O.strategy == TBK_STRAT_CLIP) clip_view(c, nc, &b, &e);
-      if (e - b == 1 && ((0x18Du >> cig_op(c[b])) & 1u)) h32 = 0x80000000u | cig_op(c[b]);
-    }
-  }
-  int64_t span = (int64_t)end - (int64_t)start + 1;
-  if (pass && (span < 0 || span >= (1ll << 30) || start < 0 || tidv < -1)) {  // key fields: tid+1 and start need 31 bits
-    atomicOr(err, TBK_DERR_SPAN);
-    span = 0;
-  }
-  // hi = tid+1 : 31 | start : 31 | strand code : 2   lo = span : 32 | h32   (tid+1 and start are < 2^31 in BAM)
-  khi[i] = ((uint64_t)(uint32_t)(tidv + 1) << 33) | ((uint64_t)(uint32_t)start << 2) | sc;
-  klo[i] = ((uint64_t)span << 32) | h32;
-  kend[i] = end;
+  const RecKey K = record_key(I, O, i, fl, pos, tidv, mq, nhv, sc, I.cig + c0, c1 - c0, err);
+  const bool pass = K.pass;
+  khi[i] = K.hi;
+  klo[i] = K.lo;
+  kend[i] = K.end;
   kflags[i] = (pass ? 1u : 0u) | (i == I.file_off[f] ? 2u : 0u);
   fidx[i] = (uint16_t)f;
 }
@@ -1018,7 +982,7 @@ __global__ void col_write_k(const uint64_t* __restrict__ png, const uint32_t* __
   if (o >= ng || o >= cap) return;
   uint32_t sg = gperm[o];
   rep[o] = (uint32_t)(G.rep[sg] & 0xFFFFFFFFull);
-  if (rep_effend) rep_effend[o] = effend[rep[o]];
+  if (rep_effend) rep_effend[o] = effend ? effend[rep[o]] : (int32_t)(uint32_t)(G.rep[sg] >> 32);
   yc[o] = G.yc[sg];
   yx[o] = (int64_t)G.yxin[sg] + (int64_t)G.ns[sg];
   uint32_t q = G.first[sg];
@@ -1272,20 +1236,31 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
   O.hash_mask = 0xFFFFFFFFu;
   if (const char* e = getenv("TBK_DEBUG_HASH_MASK")) O.hash_mask = (uint32_t)strtoul(e, nullptr, 0);
 
-  uint64_t* khi = ws_alloc<uint64_t>(ctx, n);
-  uint64_t* klo = ws_alloc<uint64_t>(ctx, n);
-  int32_t* kend = ws_alloc<int32_t>(ctx, n);
-  uint8_t* kflags = ws_alloc<uint8_t>(ctx, n);
-  uint16_t* fidx = ws_alloc<uint16_t>(ctx, n);
-  int32_t* effend = ws_alloc<int32_t>(ctx, n);
-  uint32_t* ceff = nullptr;  // (window path, allocated below)
-  SortBufs sb;
-  sb.hi = ws_alloc<uint64_t>(ctx, n);
-  sb.lo = ws_alloc<uint64_t>(ctx, n);
-  sb.val = ws_alloc<uint32_t>(ctx, n);
-  sb.hi2 = khi;  // the unsorted key arrays are dead after compaction: reuse them as the ping-pong side
-  sb.lo2 = klo;
-  sb.val2 = nullptr;
+  // per-record arrays of the key pass / scan / compaction (the raw window path never touches them: allocated when the tile takes
+  // the general front end)
+  uint64_t *khi = nullptr, *klo = nullptr;
+  int32_t* kend = nullptr;
+  uint8_t* kflags = nullptr;
+  uint16_t* fidx = nullptr;
+  int32_t* effend = nullptr;
+  uint32_t* ceff = nullptr;  // (window path on compacted records, allocated below)
+  SortBufs sb{};
+  auto front_arrays = [&]() -> bool {
+    if (sb.val) return true;
+    khi = ws_alloc<uint64_t>(ctx, n);
+    klo = ws_alloc<uint64_t>(ctx, n);
+    kend = ws_alloc<int32_t>(ctx, n);
+    kflags = ws_alloc<uint8_t>(ctx, n);
+    fidx = ws_alloc<uint16_t>(ctx, n);
+    effend = ws_alloc<int32_t>(ctx, n);
+    sb.hi = ws_alloc<uint64_t>(ctx, n);
+    sb.lo = ws_alloc<uint64_t>(ctx, n);
+    sb.val = ws_alloc<uint32_t>(ctx, n);
+    sb.hi2 = khi;  // the unsorted key arrays are dead after compaction: reuse them as the ping-pong side
+    sb.lo2 = klo;
+    sb.val2 = nullptr;
+    return sb.val && effend;
+  };
   // per-record arrays of the sort path only (the window path never touches them: allocated when the tile takes the sort path)
   uint8_t* flags = nullptr;
   uint32_t *ghead = nullptr, *gex = nullptr, *sgid = nullptr;
@@ -1300,7 +1275,7 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
   };
   uint32_t* head_off = ws_alloc<uint32_t>(ctx, (size_t)in->n_files + 1);
   uint32_t* run_off = ws_alloc<uint32_t>(ctx, (size_t)in->n_files + 1);
-  if (!sb.val || !effend || !head_off || !run_off) return TBK_ENOMEM;
+  if (!head_off || !run_off) return TBK_ENOMEM;
   // ceil(log2(files)) merge rounds + one local pass against ~12 radix passes.  Measured on MI355X: 2 files x 1 M
   // 0.17 ms vs 0.47 ms; 16 files x 0.5 M: whole step 3.90 vs 4.13 ms; 64 files x 0.25 M (6 rounds): 8.58 vs 8.67 ms —
   // level there, so more files than that take the radix sort.
@@ -1327,10 +1302,10 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
         return ok;
       }();
   }
-  if (use_win) {
-    ceff = ws_alloc<uint32_t>(ctx, n);
-    if (!ceff) return TBK_ENOMEM;
-  }
+  // Raw window path: plain tiles without an explicit merge priority go from the input records straight to the groups — the key
+  // pass, the effective-end scan and the compaction are folded into the window kernels (TBK_RAW=0: test hook, keeps them apart)
+  bool use_raw = use_win && !I.prio_hi;
+  if (const char* e = getenv("TBK_RAW")) use_raw = use_raw && strcmp(e, "0") != 0;
   WgOut win_out;
   bool win_done = false;
   uint32_t m = 0, ng = 0;
@@ -1352,8 +1327,70 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
   for (;;) {
     if (attempt == 4) return TBK_ECOLLISION;
     O.seed = seeds[attempt];
-    SortBufs s2 = sb;
     TBK_HIP(hipMemsetAsync(sc, 0, 16 * sizeof(uint64_t), ctx->stream));
+    if (use_raw && use_win) {
+      uint32_t eb = 0;
+      WgOut wo;
+      TBK_TRY(tbk_window_groups(ctx, I, O.strategy, nullptr, nullptr, nullptr, nullptr, n, I.file_off, nullptr, nullptr, out->rec_group != nullptr,
+                                O.seed, &wo, &eb, &O));
+      if (eb & (TBK_DERR_RAWORDER | TBK_DERR_BIGBUCKET)) {  // not this path's kind of input (the general front end decides what is an
+        TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));  // error), or a pile-up beyond the group table
+        use_raw = false;
+        if (eb & TBK_DERR_BIGBUCKET) use_win = false;
+        continue;
+      }
+      if (eb & TBK_DERR_COLLISION) {  // reseed
+        ++attempt;
+        continue;
+      }
+      if (eb) return tbk_derr_to_status(ctx, eb);
+      m = (uint32_t)ctx->h_scalars[0];
+      out->n_passed = m;
+      if (m == 0) return 0;
+      ng = wo.ng;
+      if (ng > out->cap_groups) {
+        out->n_groups = ng;
+        return TBK_E2BIG;
+      }
+      G.yc = wo.yc;
+      G.ns = wo.ns;
+      G.yxin = wo.yxin;
+      G.ydin = wo.ydin;
+      G.rep = wo.rep;
+      G.first = wo.first;
+      G.tie = wo.tie;
+      g_yd = ws_alloc<int32_t>(ctx, ng);
+      gperm = ws_alloc<uint32_t>(ctx, ng);
+      ginv = ws_alloc<uint32_t>(ctx, ng);
+      if (!ginv) return TBK_ENOMEM;
+      TBK_HIP(hipMemsetAsync(g_yd, 0, (size_t)ng * 4, ctx->stream));
+      const uint64_t* png = sc + 1;  // (tbk_window_groups left the group count there)
+      TBK_LAUNCH(ctx, "col_tie_sort", col_tie_sort_k, cdiv(ng, B), B, 0, I, O.strategy, png, wo.gmem, G, gperm, ginv);
+      // (effend == nullptr: the effective end of the representative rides in the high word of G.rep)
+      TBK_LAUNCH(ctx, "col_write", col_write_k, cdiv(ng, B), B, 0, png, gperm, G, wo.ghi, wo.glo, out->cap_groups, out->rep, out->yc,
+                 out->yx, out->g_start, out->g_end, (const int32_t*)nullptr, out->rep_effend);
+      if (out->rec_group) TBK_LAUNCH(ctx, "col_recgroup", col_recgroup_w_k, cdiv(n, B), B, 0, n, wo.rec_sg, ginv, out->rec_group);
+      TBK_TRY(tbk_sync_err(ctx, &eb));
+      if (eb & TBK_DERR_COLLISION) {  // (the verification pass, wg_finish_raw_k): reseed
+        ++attempt;
+        continue;
+      }
+      if (eb) return tbk_derr_to_status(ctx, eb);
+      win_out = wo;
+      win_done = true;
+      if (attempt > 0) {
+        char b[96];
+        snprintf(b, sizeof(b), "info: key-hash collision, reseeded %d time(s)", attempt);
+        ctx->last_error = b;
+      }
+      break;
+    }
+    if (!front_arrays()) return TBK_ENOMEM;
+    if (use_win && !ceff) {
+      ceff = ws_alloc<uint32_t>(ctx, n);
+      if (!ceff) return TBK_ENOMEM;
+    }
+    SortBufs s2 = sb;
     TBK_LAUNCH(ctx, "col_keys", col_keys_k, cdiv(n, B), B, 0, I, O, khi, klo, kend, kflags, fidx, ctx->d_err);
     {
       EffLoad ld{khi, kend, kflags};

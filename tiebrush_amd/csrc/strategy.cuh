@@ -101,6 +101,73 @@ __device__ inline uint64_t strategy_hash(const ColIn& I, const ColOpt& O, uint32
   return strategy_hash(I, O, i, I.cig + I.cig_off[i], I.cig_off[i + 1] - I.cig_off[i]);
 }
 
+// The 128-bit group key of one record from its raw fields (shared by col_keys_k and the raw window path, wgroup.hip):
+//   hi = tid+1 : 31 | start : 31 | strand code : 2        lo = span : 32 | h32
+// start / end as GSamRecord::setupCoordinates leaves them (GSam.cpp:351-417; unmapped: 0 / 0), `pass` = passes_options
+// (tiebrush.cpp:532-541).  h32 = 31 bits of the seeded strategy hash, or — bit 31 set — an EXACT code: with (tid, start,
+// strand, span) in the key, a strategy key that is a single reference-consuming operation (after clip stripping under -P),
+// a single exon under -E, or the spliced shape M N M / two exons with a first block < 2^10 and a gap < 2^20 is identified
+// by the code alone, so equal keys are equal alignments and need no comparison of the CIGARs (nearly every read of an
+// RNA-seq sample).  The order inside a (strand, end) tie set never depends on this word (col_tie_sort_k).
+struct RecKey {
+  uint64_t hi, lo;
+  int32_t end;
+  bool pass;
+};
+__device__ __forceinline__ RecKey record_key(const ColIn& I, const ColOpt& O, uint32_t i, uint32_t fl, int pos, int tidv, int mq, int32_t nhv,
+                                             uint32_t sc, const uint32_t* __restrict__ c, uint32_t nc, uint32_t* __restrict__ err) {
+  int start = 0, end = 0;
+  if (!(fl & 0x4)) {
+    const int l = cigar_reflen(c, nc);
+    start = pos + 1;
+    end = pos + l;
+  }
+  bool pass = true;  // passes_options, tiebrush.cpp:532-541
+  if (!O.keep_supp && (fl & 0x800)) pass = false;
+  if (!O.keep_sec && (fl & 0x100)) pass = false;
+  if (fl & 0x4) pass = false;  // keep_unmapped is rejected at the ABI
+  if (mq < O.min_qual) pass = false;
+  const int nh = nhv == TBK_NH_ABSENT ? 0 : nhv;
+  if (nh > O.max_nh) pass = false;
+  const uint64_t h = pass ? strategy_hash(I, O, i, c, nc) : 0ull;
+  uint32_t h32 = (uint32_t)(h >> 32) & O.hash_mask & 0x7FFFFFFFu;
+  if (pass && O.strategy != TBK_STRAT_FULL) {
+    if (O.strategy == TBK_STRAT_EXON) {
+      int nex = 0, e1 = 0, s2 = 0, ix = 0;
+      walk_exons(pos, c, nc,
+                 [&](int s, int e) {
+                   if (ix == 0) e1 = e;
+                   if (ix == 1) s2 = s;
+                   ++ix;
+                 },
+                 &nex);
+      if (nex == 1) h32 = 0x8000000Fu;
+      if (nex == 2) {
+        const uint32_t a = (uint32_t)(e1 - start + 1), g = (uint32_t)(s2 - e1 - 1);
+        if (a < (1u << 10) && g < (1u << 20)) h32 = 0xC0000000u | (a << 20) | g;
+      }
+    } else {
+      uint32_t b = 0, e = nc;
+      if (O.strategy == TBK_STRAT_CLIP) clip_view(c, nc, &b, &e);
+      if (e - b == 1 && ((0x18Du >> cig_op(c[b])) & 1u)) h32 = 0x80000000u | cig_op(c[b]);
+      if (e - b == 3 && cig_op(c[b]) == C_M && cig_op(c[b + 1]) == C_N && cig_op(c[b + 2]) == C_M && cig_len(c[b]) < (1u << 10) &&
+          cig_len(c[b + 1]) < (1u << 20))
+        h32 = 0xC0000000u | (cig_len(c[b]) << 20) | cig_len(c[b + 1]);
+    }
+  }
+  int64_t span = (int64_t)end - (int64_t)start + 1;
+  if (pass && (span < 0 || span >= (1ll << 30) || start < 0 || tidv < -1)) {  // key fields: tid+1 and start need 31 bits
+    atomicOr(err, TBK_DERR_SPAN);
+    span = 0;
+  }
+  RecKey K;
+  K.hi = ((uint64_t)(uint32_t)(tidv + 1) << 33) | ((uint64_t)(uint32_t)start << 2) | sc;
+  K.lo = ((uint64_t)span << 32) | h32;
+  K.end = end;
+  K.pass = pass;
+  return K;
+}
+
 // exact equality of the strategy keys of two records (start/end/strand are already equal)
 __device__ inline bool strategy_equal(const ColIn& I, int strategy, uint32_t a, uint32_t b) {
   const uint32_t* ca = I.cig + I.cig_off[a];

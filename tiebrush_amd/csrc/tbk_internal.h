@@ -26,7 +26,8 @@ enum : uint32_t {
   TBK_DERR_FRACTIONAL = 1u << 5, // non-integral YC met by an integer-only kernel
   TBK_DERR_OVERFLOW = 1u << 6,
   TBK_DERR_INTERNAL = 1u << 7,
-  TBK_DERR_BIGBUCKET = 1u << 8  // not an error: the run sort met a (tid,start) bucket longer than its window -> radix fallback
+  TBK_DERR_BIGBUCKET = 1u << 8, // not an error: the run sort met a (tid,start) bucket longer than its window -> radix fallback
+  TBK_DERR_RAWORDER = 1u << 9   // not an error: the raw window path met an input it does not take (wgroup.hip) -> general path
 };
 
 struct KTime {

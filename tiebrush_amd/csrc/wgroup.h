@@ -28,5 +28,9 @@ struct WgOut {
 // the caller's next read-back must treat it as a reseed request.
 int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const uint64_t* chi, const uint64_t* clo, const uint32_t* cval,
                       const uint32_t* ceff, uint32_t m, const uint32_t* d_run_off, uint64_t* scratch_hi, uint64_t* scratch_lo,
-                      bool want_rec_sg, uint64_t seed, WgOut* out, uint32_t* err_bits);
+                      bool want_rec_sg, uint64_t seed, WgOut* out, uint32_t* err_bits, const tbkd::ColOpt* raw_opt = nullptr);
+// raw_opt != nullptr — RAW mode: the windows are cut on the input records themselves (chi .. ceff and the scratch arrays are
+// unused and may be null, m = I.n, d_run_off = I.file_off on the device); keys, the filter and the effective ends are computed
+// inside the window kernels, the number of passing records is added to ctx->d_scalars[0] (zeroed by the caller).
+// TBK_DERR_RAWORDER in *err_bits: the input is not of the shape this mode takes — run the general path.
 bool tbk_window_supported(uint32_t k);

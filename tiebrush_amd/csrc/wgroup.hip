@@ -121,6 +121,127 @@ __global__ void wg_offsets_k(const uint64_t* __restrict__ chi, const uint32_t* _
   }
 }
 
+// ---- raw mode: the windows are cut on the records as they come (no key pass, no compaction) -----------------------------------
+// Partition key of a raw record: (tid, pos) with every tid < 0 (unplaced reads, the tail of a sorted BAM) folded onto one value
+// beyond all references.  A file whose raw keys never decrease is coordinate-sorted in the sense of col_effkey_scan (mapped
+// records: key = (tid + 1, pos + 1); unmapped ones carry start 0 and can neither raise a running maximum nor split a run of
+// equal starts), its effective ends are prefix maxima of `end` inside runs of equal raw key, and a window bounded by raw keys
+// holds every record of its (tid, start) buckets.  Anything else (an inversion, tid >= 0 with pos < 0) raises TBK_DERR_RAWORDER
+// and the tile takes the general path, which decides what is an error.
+__device__ __forceinline__ uint64_t raw_key(int tid, int pos) {
+  return tid < 0 ? (1ull << 62) : (((uint64_t)(uint32_t)tid << 31) | ((uint32_t)pos & 0x7FFFFFFFu));
+}
+__global__ void wg_sample_raw_k(const int32_t* __restrict__ tid, const int32_t* __restrict__ pos, uint32_t n, uint32_t s, uint32_t ns,
+                                uint64_t* __restrict__ shi) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ns) return;
+  uint64_t d = (uint64_t)j * s;
+  if (d >= n) d = n - 1;
+  shi[j] = raw_key(tid[d], pos[d]);
+}
+__global__ void wg_offsets_raw_k(const int32_t* __restrict__ rtid, const int32_t* __restrict__ rpos, const uint32_t* __restrict__ run_off, uint32_t k,
+                                 const uint64_t* __restrict__ W, uint32_t nrows, uint32_t* __restrict__ off) {
+  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t f = (uint32_t)(tid % k);
+  const uint64_t c = tid / k;
+  const uint64_t r0 = c * WG_OR;
+  if (r0 >= nrows) return;
+  const uint32_t a = run_off[f], b = run_off[f + 1];
+  uint32_t p = a;
+  bool have = false;
+  for (uint32_t u = 0; u < WG_OR; ++u) {
+    const uint64_t r = r0 + u;
+    if (r >= nrows) break;
+    uint32_t ans;
+    if (r == 0) {
+      ans = a;
+    } else if (r == nrows - 1) {
+      ans = b;
+    } else {
+      const uint64_t v = W[r - 1];
+      uint32_t lo, hi;  // answer in [lo, hi]
+      if (!have) {
+        lo = a;
+        hi = b;
+      } else {  // gallop from p (answers are non-decreasing in r)
+        lo = p;
+        uint32_t step = 1;
+        hi = p;
+        while (hi < b && raw_key(rtid[hi], rpos[hi]) < v) {
+          lo = hi + 1;
+          hi = (b - hi > step) ? hi + step : b;
+          step <<= 1;
+        }
+      }
+      while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (raw_key(rtid[mid], rpos[mid]) < v)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      ans = lo;
+      p = ans;
+      have = true;
+    }
+    off[r * k + f] = ans;
+  }
+}
+struct WgRaw {                 // raw mode: the window kernels read the records themselves (WgIn::chi / clo / cval / ceff are null)
+  ColIn I;
+  ColOpt O;
+  unsigned long long* n_pass;  // passing records (one atomic per block)
+  uint32_t all_slots;          // 1: every passing record leaves its group slot in cslot (record -> group map wanted); 0: only the
+                               // records whose key word is not exact (they are verified by wg_finish_raw_k)
+};
+// Inclusive prefix maximum of x inside segments (f = 1: a segment starts at this lane), wave wide, DPP only.  Returns the scanned
+// value; *fo = 1 when a segment start lies at or before this lane (the carry from earlier waves does not reach it).
+__device__ __forceinline__ uint32_t wave_seg_max(uint32_t x, uint32_t f, uint32_t* fo) {
+#define WG_SEG_STEP(ctrl, rm)                                                                  \
+  {                                                                                            \
+    const uint32_t xo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rm, 0xf, false); \
+    const uint32_t fq = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, ctrl, rm, 0xf, false); \
+    x = f ? x : (xo > x ? xo : x);                                                             \
+    f |= fq;                                                                                   \
+  }
+  WG_SEG_STEP(0x111, 0xf)
+  WG_SEG_STEP(0x112, 0xf)
+  WG_SEG_STEP(0x114, 0xf)
+  WG_SEG_STEP(0x118, 0xf)
+  WG_SEG_STEP(0x142, 0xa)
+  WG_SEG_STEP(0x143, 0xc)
+#undef WG_SEG_STEP
+  *fo = f;
+  return x;
+}
+// One raw record of a window piece: fields -> key, pass, raw partition key, the value it feeds into the effective-end scan
+// (its end if it is mapped), and whether a segment of that scan starts here.  `first_of_piece`: the record opens the piece of
+// its file inside this window; `prev_rk`: the raw key of the lane to the left (valid for lanes > 0 that do not open a piece).
+struct RawRec {
+  uint64_t hi, lo, rk;
+  uint32_t x;     // end of a mapped record, 0 otherwise
+  bool pass;
+};
+__device__ __forceinline__ RawRec wg_raw_load(const WgRaw& R, uint32_t i, uint32_t* __restrict__ err) {
+  const ColIn& I = R.I;
+  const uint32_t fl = I.flag[i];
+  const int pos = I.pos[i], tidv = I.tid[i];
+  const int mq = (int)I.mapq[i];
+  const int32_t nhv = I.nh[i];
+  const uint32_t sc = strand_code(I.strand[i]);
+  const uint32_t c0 = I.cig_off[i], c1 = I.cig_off[i + 1];
+  const RecKey K = record_key(I, R.O, i, fl, pos, tidv, mq, nhv, sc, I.cig + c0, c1 - c0, err);
+  RawRec r;
+  r.hi = K.hi;
+  r.lo = K.lo;
+  r.pass = K.pass;
+  r.rk = raw_key(tidv, pos);
+  const bool mapped = !(fl & 0x4u);
+  r.x = mapped && K.end > 0 ? (uint32_t)K.end : 0u;
+  if ((tidv >= 0 && pos < 0) || (mapped && tidv < 0)) atomicOr(err, TBK_DERR_RAWORDER);
+  return r;
+}
+
 // ---- window kernel -----------------------------------------------------------------------------------------------
 struct WgIn {
   const uint64_t *chi, *clo;   // compacted passing records: k runs, each non-decreasing in chi >> 2
@@ -337,10 +458,13 @@ __global__ void wg_list_k(uint32_t nw, const uint32_t* __restrict__ wbase, uint3
 // goes to the sort kernel's worklist (at most WG_CAP records: every window except a pile-up on a single base); a pile-up
 // that overflows sends the tile to the sort path.
 // (`final_tier`: an overflowing window of more than WG_CAP records cannot go on to the sort kernel)
-template <int SORT_E /* the ranking sorts at most SORT_E * WG_NT groups */>
-__device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgTemp& T, uint32_t gcap, uint32_t nwords, uint64_t seed, uint32_t w,
-                                               unsigned char* lds, uint32_t* sm_u, uint32_t* s_misc, uint32_t* __restrict__ ovf,
-                                               uint32_t ovf_cap, bool final_tier, uint32_t* __restrict__ err) {
+// RAW: the pieces are pieces of the input files themselves; every record's key, filter verdict and effective end (a segmented
+// prefix maximum along the piece, carried across waves, rows and chunks) are computed here, records that do not pass take no
+// part in the grouping.
+template <int SORT_E /* the ranking sorts at most SORT_E * WG_NT groups */, bool RAW>
+__device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, const WgTemp& T, uint32_t gcap, uint32_t nwords, uint64_t seed,
+                                               uint32_t w, unsigned char* lds, uint32_t* sm_u, uint32_t* s_misc, uint2* s_agg /* [WG_R * WG_NW] */,
+                                               uint32_t* __restrict__ ovf, uint32_t ovf_cap, bool final_tier, uint32_t* __restrict__ err) {
   const uint32_t t = threadIdx.x;
   const uint32_t k = In.k;
   const unsigned long long t_start = T.dbg ? __builtin_readcyclecounter() : 0ull;
@@ -405,6 +529,9 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgTemp& T, 
     if (t == 0) {
       s_misc[0] = 0;  // distinct groups
       s_misc[1] = 0;  // overflow
+      s_misc[2] = 0;  // RAW: passing records
+      s_misc[4] = 0;  // RAW: carry of the effective-end scan into chunk 0 ...
+      s_misc[5] = 0;  // ... and into chunk 1 (alternating)
     }
     uint32_t tot;
     uint32_t ex = wg_block_excl<uint32_t>(sum, sm_u, &tot);
@@ -421,26 +548,61 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgTemp& T, 
   }
   __syncthreads();
   phase(0);
+  uint32_t npass_t = 0, par = 0;
   // the window streams through in chunks of WG_NT * WG_R records: WG_R records per thread so that their loads and probes
   // overlap; two barriers per chunk
   for (uint32_t c0 = 0; c0 < n_w; c0 += WG_NT * WG_R) {
     uint32_t slot[WG_R], rec[WG_R], fil[WG_R], src[WG_R], eff[WG_R];
     uint64_t kh[WG_R], kl[WG_R];
     uint32_t won = 0, actm = 0;
+    uint32_t xs[WG_R], fs[WG_R];  // RAW: scanned end inside the wave row, and whether a segment start shields it from the carry
 #pragma unroll
     for (int u = 0; u < WG_R; ++u) {
       const uint32_t e = c0 + (uint32_t)u * WG_NT + t;
       slot[u] = 0xFFFFFFFFu;
       rec[u] = fil[u] = src[u] = eff[u] = 0;
       kh[u] = kl[u] = 0;
-      if (e < n_w) {
-        actm |= 1u << u;
-        fil[u] = piece_of(pre, k, e);
-        src[u] = rb[fil[u]] + e;
-        kh[u] = In.chi[src[u]];
-        kl[u] = In.clo[src[u]];
-        rec[u] = In.cval[src[u]];
-        eff[u] = In.ceff[src[u]];
+      xs[u] = fs[u] = 0;
+      if constexpr (!RAW) {
+        if (e < n_w) {
+          actm |= 1u << u;
+          fil[u] = piece_of(pre, k, e);
+          src[u] = rb[fil[u]] + e;
+          kh[u] = In.chi[src[u]];
+          kl[u] = In.clo[src[u]];
+          rec[u] = In.cval[src[u]];
+          eff[u] = In.ceff[src[u]];
+        }
+      } else {
+        const bool act = e < n_w;
+        uint64_t rk = ~0ull;
+        uint32_t x = 0;
+        bool first = true;
+        if (act) {
+          fil[u] = piece_of(pre, k, e);
+          src[u] = rb[fil[u]] + e;
+          rec[u] = src[u];
+          const RawRec r = wg_raw_load(R, src[u], err);
+          kh[u] = r.hi;
+          kl[u] = r.lo;
+          rk = r.rk;
+          x = r.x;
+          if (r.pass) {
+            actm |= 1u << u;
+            ++npass_t;
+          }
+          first = e == pre[fil[u]];
+        }
+        // the record before this one in its file: the lane to the left, or — lane 0, or the first record of a piece — from memory
+        uint64_t prk = ((uint64_t)(uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(rk >> 32), 0x138, 0xf, 0xf, false) << 32) |
+                       (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)rk, 0x138, 0xf, 0xf, false);
+        if (act && (first || lane_id() == 0)) {
+          prk = src[u] > R.I.file_off[fil[u]] ? raw_key(R.I.tid[src[u] - 1], R.I.pos[src[u] - 1]) : 0ull;
+        }
+        if (act && prk > rk) atomicOr(err, TBK_DERR_RAWORDER);  // not coordinate-sorted as this path needs it
+        const uint32_t head = (!act || first || prk != rk) ? 1u : 0u;
+        xs[u] = wave_seg_max(x, head, &fs[u]);
+        if (lane_id() == 63) s_agg[u * WG_NW + (t >> 6)] = make_uint2(xs[u], fs[u]);
       }
     }
     if (T.dbg) {
@@ -487,13 +649,28 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgTemp& T, 
     __syncthreads();  // key and claim number of every slot claimed in this chunk are visible
     phase(4);
     if (s_misc[1]) break;
+    if constexpr (RAW) {  // effective ends: the carry that enters every (row, wave) of this chunk, folded in element order
+      uint32_t c = s_misc[4 + par];
+      uint32_t snap[WG_R];
+      const uint32_t wv = t >> 6;
+#pragma unroll
+      for (int q = 0; q < WG_R * WG_NW; ++q) {
+        if ((uint32_t)(q % WG_NW) == wv) snap[q / WG_NW] = c;
+        const uint2 a = s_agg[q];
+        c = a.y ? a.x : (a.x > c ? a.x : c);
+      }
+      if (t == 0) s_misc[4 + (par ^ 1u)] = c;
+      par ^= 1u;
+#pragma unroll
+      for (int u = 0; u < WG_R; ++u) eff[u] = fs[u] ? xs[u] : (xs[u] > snap[u] ? xs[u] : snap[u]);
+    }
 #pragma unroll
     for (int u = 0; u < WG_R; ++u) {
       const bool act = (actm >> u) & 1u;
       if (act) {
         const uint32_t s = slot[u];
         if (thi[s] != kh[u] || tlo[s] != kl[u]) atomicOr(err, TBK_DERR_COLLISION);  // two keys, one fingerprint
-        T.cslot[src[u]] = wbase + tci[s];
+        if (!RAW || R.all_slots || !((kl[u] >> 31) & 1ull)) T.cslot[src[u]] = wbase + tci[s];
         const unsigned long long rr = ((unsigned long long)eff[u] << 32) | rec[u];
         if (rr < trep[s]) atomicMin(&trep[s], rr);
         const uint32_t bi = s * nwords + (fil[u] >> 5), bm = 1u << (fil[u] & 31);
@@ -546,7 +723,12 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgTemp& T, 
         T.wp_cnt[w] = carry;
       }
     }
+    if constexpr (RAW) {
+      const uint32_t ws = wave_sum(npass_t);
+      if (lane_id() == 0 && ws) atomicAdd(&s_misc[2], ws);
+    }
     __syncthreads();
+    if (RAW && t == 0 && s_misc[2]) atomicAdd(R.n_pass, (unsigned long long)s_misc[2]);
     for (uint32_t g = t; g < d; g += WG_NT) {
       const uint32_t s = byrank[g];
       T.hi[wbase + g] = thi[s];
@@ -590,36 +772,45 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgTemp& T, 
 }
 
 // first tier: one block per window that holds records, a table of WG_LDS_HASH bytes (four blocks per CU)
-__global__ __launch_bounds__(WG_NT, 6) void wg_hash_k(WgIn In, WgTemp T, uint32_t gcap, uint32_t nwords, uint64_t seed,
+template <bool RAW>
+__global__ __launch_bounds__(WG_NT, 6) void wg_hash_k(WgIn In, WgRaw R, WgTemp T, uint32_t gcap, uint32_t nwords, uint64_t seed,
                                                       const uint32_t* __restrict__ wlist, uint32_t* __restrict__ ovf /* [0] count, [1..] windows */,
                                                       uint32_t ovf_cap, uint32_t* __restrict__ err) {
   extern __shared__ __align__(16) unsigned char lds[];
   __shared__ uint32_t sm_u[WG_NW];
-  __shared__ uint32_t s_misc[4];
-  wg_hash_window<2>(In, T, gcap, nwords, seed, wlist[blockIdx.x], lds, sm_u, s_misc, ovf, ovf_cap, false, err);
+  __shared__ uint32_t s_misc[8];
+  __shared__ uint2 s_agg[WG_R * WG_NW];
+  wg_hash_window<2, RAW>(In, R, T, gcap, nwords, seed, wlist[blockIdx.x], lds, sm_u, s_misc, s_agg, ovf, ovf_cap, false, err);
 }
 // second tier: the windows with more distinct groups than the first table holds (shallow data) against a table of WG_LDS_HASH2 bytes
 // (two blocks per CU); a fixed grid walks the first tier's worklist.  What overflows again goes to the sort kernel.
-__global__ __launch_bounds__(WG_NT, 6) void wg_hash2_k(WgIn In, WgTemp T, uint32_t gcap, uint32_t nwords, uint64_t seed,
+template <bool RAW>
+__global__ __launch_bounds__(WG_NT, 6) void wg_hash2_k(WgIn In, WgRaw R, WgTemp T, uint32_t gcap, uint32_t nwords, uint64_t seed,
                                                        const uint32_t* __restrict__ ovf_in, uint32_t* __restrict__ ovf, uint32_t ovf_cap,
                                                        uint32_t* __restrict__ err) {
   extern __shared__ __align__(16) unsigned char lds[];
   __shared__ uint32_t sm_u[WG_NW];
-  __shared__ uint32_t s_misc[4];
+  __shared__ uint32_t s_misc[8];
+  __shared__ uint2 s_agg[WG_R * WG_NW];
   const uint32_t cnt = ovf_in[0] < ovf_cap ? ovf_in[0] : ovf_cap;
   for (uint32_t wi = blockIdx.x; wi < cnt; wi += gridDim.x) {
     __syncthreads();  // (LDS of the previous window is free)
-    wg_hash_window<3>(In, T, gcap, nwords, seed, ovf_in[1 + wi], lds, sm_u, s_misc, ovf, ovf_cap, true, err);
+    wg_hash_window<3, RAW>(In, R, T, gcap, nwords, seed, ovf_in[1 + wi], lds, sm_u, s_misc, s_agg, ovf, ovf_cap, true, err);
   }
 }
 
 // The windows the hash kernels could not hold (more distinct groups than table slots — shallow data): at most WG_CAP records
 // each, sorted in LDS.  A fixed grid walks the worklist.
-__global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgTemp T, ColIn I, int strategy, const uint32_t* __restrict__ ovf, uint32_t ovf_cap,
-                                                      uint32_t* __restrict__ err) {
+// RAW: keys, filter verdicts and effective ends are computed while the window is loaded (see wg_hash_window); records that do not
+// pass sort behind every key and are left out.
+template <bool RAW>
+__global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgRaw R, WgTemp T, ColIn I, int strategy, const uint32_t* __restrict__ ovf,
+                                                      uint32_t ovf_cap, uint32_t* __restrict__ err) {
   __shared__ __align__(16) unsigned char lds[WG_LDS_MAIN];
   __shared__ uint32_t pre[1024 + 1];
   __shared__ uint32_t sm_u[WG_NW];
+  __shared__ uint2 s_agg[WG_NW];
+  __shared__ uint32_t s_carry, s_np;
   const uint32_t t = threadIdx.x;
   const uint32_t k = In.k;
   const uint32_t cnt = ovf[0] < ovf_cap ? ovf[0] : ovf_cap;
@@ -641,19 +832,79 @@ __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgTemp T, ColIn I
     // =========================== LDS sort path (shallow window: more groups than table slots) ===========================
     uint64_t* hi = reinterpret_cast<uint64_t*>(lds);
     uint64_t* lo = hi + WG_CAP;
-    uint32_t* val = reinterpret_cast<uint32_t*>(lo + WG_CAP);
+    uint32_t* val = reinterpret_cast<uint32_t*>(lo + WG_CAP);  // the record (RAW: its effective end; the record is its source index)
     uint16_t* qa = reinterpret_cast<uint16_t*>(val + WG_CAP);
     uint16_t* qb = qa + WG_CAP;
-    for (uint32_t e = t; e < n_w; e += WG_NT) {
-      const uint32_t f = piece_of(pre, k, e);
-      const uint32_t src = row0[f] + (e - pre[f]);
-      hi[e] = In.chi[src];
-      lo[e] = In.clo[src];
-      val[e] = In.cval[src];
-      qa[e] = (uint16_t)e;
+    if constexpr (!RAW) {
+      for (uint32_t e = t; e < n_w; e += WG_NT) {
+        const uint32_t f = piece_of(pre, k, e);
+        const uint32_t src = row0[f] + (e - pre[f]);
+        hi[e] = In.chi[src];
+        lo[e] = In.clo[src];
+        val[e] = In.cval[src];
+        qa[e] = (uint16_t)e;
+      }
+      __syncthreads();
+    } else {
+      if (t == 0) {
+        s_carry = 0;
+        s_np = 0;
+      }
+      __syncthreads();
+      uint32_t npass_t = 0;
+      for (uint32_t e0 = 0; e0 < n_w; e0 += WG_NT) {  // rows of WG_NT consecutive records; the scan carry runs along them
+        const uint32_t e = e0 + t;
+        const bool act = e < n_w;
+        uint64_t rk = ~0ull, h = ~0ull, l = ~0ull;
+        uint32_t x = 0, f = 0, srcv = 0;
+        bool first = true;
+        if (act) {
+          f = piece_of(pre, k, e);
+          srcv = row0[f] + (e - pre[f]);
+          const RawRec r = wg_raw_load(R, srcv, err);
+          if (r.pass) {
+            h = r.hi;
+            l = r.lo;
+            ++npass_t;
+          }
+          rk = r.rk;
+          x = r.x;
+          first = e == pre[f];
+        }
+        uint64_t prk = ((uint64_t)(uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(rk >> 32), 0x138, 0xf, 0xf, false) << 32) |
+                       (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)rk, 0x138, 0xf, 0xf, false);
+        if (act && (first || lane_id() == 0)) prk = srcv > R.I.file_off[f] ? raw_key(R.I.tid[srcv - 1], R.I.pos[srcv - 1]) : 0ull;
+        if (act && prk > rk) atomicOr(err, TBK_DERR_RAWORDER);
+        const uint32_t head = (!act || first || prk != rk) ? 1u : 0u;
+        uint32_t fo;
+        x = wave_seg_max(x, head, &fo);
+        if (lane_id() == 63) s_agg[t >> 6] = make_uint2(x, fo);
+        __syncthreads();
+        uint32_t c = s_carry, snap = 0;
+#pragma unroll
+        for (int q = 0; q < WG_NW; ++q) {
+          if ((uint32_t)q == (t >> 6)) snap = c;
+          const uint2 a = s_agg[q];
+          c = a.y ? a.x : (a.x > c ? a.x : c);
+        }
+        if (act) {
+          hi[e] = h;  // (a record that does not pass: ~0, ~0 — behind every key)
+          lo[e] = l;
+          val[e] = fo ? x : (x > snap ? x : snap);
+          qa[e] = (uint16_t)e;
+        }
+        __syncthreads();
+        if (t == 0) s_carry = c;
+      }
+      {
+        const uint32_t ws = wave_sum(npass_t);
+        if (lane_id() == 0 && ws) atomicAdd(&s_np, ws);
+      }
+      __syncthreads();
+      if (t == 0 && s_np) atomicAdd(R.n_pass, (unsigned long long)s_np);
     }
-    __syncthreads();
     uint16_t* src = wg_merge_sort<WG_E>(qa, qb, n_w, hi, lo, WG_CAP);
+    if constexpr (RAW) n_w = s_np;  // the passing records are the first s_np sorted positions
     const unsigned long long t_load = t_start, t_sort = T.dbg ? __builtin_readcyclecounter() : 0ull;
     // ---- heads, group ids, incidences: thread t owns the WG_E consecutive sorted positions from t * WG_E ----
     const uint32_t q0 = t * WG_E;
@@ -668,7 +919,7 @@ __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgTemp T, ColIn I
         ph = hi[pxv];
         pl = lo[pxv];
         pf = piece_of(pre, k, pxv);
-        prec = val[pxv];
+        prec = RAW ? row0[pf] + (pxv - pre[pf]) : val[pxv];
       }
       uint32_t vb[WG_E];  // predecessor of every position that continues a group: the pair is verified below
       uint32_t need = 0;
@@ -685,7 +936,7 @@ __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgTemp T, ColIn I
           const uint64_t h = hi[ix[u]], l = lo[ix[u]];
           fl[u] = piece_of(pre, k, ix[u]);
           srci[u] = row0[fl[u]] + (ix[u] - pre[fl[u]]);
-          recs[u] = val[ix[u]];
+          recs[u] = RAW ? srci[u] : val[ix[u]];
           const bool head = q == 0 || h != ph || l != pl;
           const bool fh = head || fl[u] != pf;
           hf |= (head ? 1u : 0u) << u;
@@ -729,7 +980,7 @@ __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgTemp T, ColIn I
             T.pgl[wbase + pl] = (uint16_t)gl[u];
             ++pl;
           }
-          T.cslot[srci[u]] = wbase + gl[u];
+          if (!RAW || R.all_slots || !((lo[ix[u]] >> 31) & 1ull)) T.cslot[srci[u]] = wbase + gl[u];
         }
       }
     }
@@ -746,7 +997,7 @@ __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgTemp T, ColIn I
     unsigned long long rr[WG_E];
 #pragma unroll
     for (int u = 0; u < WG_E; ++u)  // eight independent gathers in flight
-      rr[u] = q0 + u < n_w ? (((unsigned long long)In.ceff[srci[u]] << 32) | recs[u]) : ~0ull;
+      rr[u] = q0 + u < n_w ? (((unsigned long long)(RAW ? val[ix[u]] : In.ceff[srci[u]]) << 32) | recs[u]) : ~0ull;
     __syncthreads();
     {  // runs of one group inside the thread's positions are folded in registers; one set of LDS atomics per run
       uint32_t cg = 0xFFFFFFFFu, c = 0, nsv = 0;
@@ -857,17 +1108,44 @@ __global__ void wg_finish_k(uint32_t m, const uint64_t* __restrict__ clo, const 
   }
 }
 
+// RAW: one thread per input record; cslot holds a slot only for the records that need this pass (every passing record when the
+// record -> group map is wanted, else those whose key word is not exact)
+__global__ void wg_finish_raw_k(uint32_t n, const uint32_t* __restrict__ cslot, const uint32_t* __restrict__ c2r,
+                                const unsigned long long* __restrict__ trep, const uint32_t* __restrict__ slot2sg, uint32_t* __restrict__ rec_sg,
+                                ColIn I, int strategy, uint32_t* __restrict__ err) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t cs = cslot[j];
+  if (cs == 0xFFFFFFFFu) return;
+  const uint32_t slot = c2r[cs];
+  if (rec_sg) rec_sg[j] = slot2sg[slot];
+  const uint32_t anchor = (uint32_t)(trep[slot] & 0xFFFFFFFFull);
+  if (anchor != j && !strategy_equal(I, strategy, j, anchor)) atomicOr(err, TBK_DERR_COLLISION);
+}
+
 }  // namespace
 
 bool tbk_window_supported(uint32_t k) { return k >= 1 && k <= 1024; }
 
 int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const uint64_t* chi, const uint64_t* clo, const uint32_t* cval,
                       const uint32_t* ceff, uint32_t m, const uint32_t* d_run_off, uint64_t* scratch_hi, uint64_t* scratch_lo,
-                      bool want_rec_sg, uint64_t seed, WgOut* out, uint32_t* err_bits) {
+                      bool want_rec_sg, uint64_t seed, WgOut* out, uint32_t* err_bits, const tbkd::ColOpt* raw_opt) {
   const uint32_t k = I.k;
   const uint32_t B = 256;
   *err_bits = 0;
+  const bool raw = raw_opt != nullptr;  // the records themselves are the runs: m = I.n, d_run_off = I.file_off, chi .. ceff unused
   if (!tbk_window_supported(k) || m == 0) return TBK_EINVAL;
+  WgRaw R{};
+  if (raw) {
+    R.I = I;
+    R.O = *raw_opt;
+    R.O.seed = seed;
+    R.n_pass = (unsigned long long*)(ctx->d_scalars + 0);
+    R.all_slots = want_rec_sg ? 1u : 0u;
+    scratch_hi = ws_alloc<uint64_t>(ctx, m);
+    scratch_lo = ws_alloc<uint64_t>(ctx, m);
+    if (!scratch_lo) return TBK_ENOMEM;
+  }
   // sample stride s (power of two, k s <= WG_KS) and samples per splitter g = T / s
   uint32_t s = 1;
   while (s * 2 * k <= WG_KS && s * 2 <= WG_T) s *= 2;
@@ -884,13 +1162,19 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
     uint64_t* Y = ws_alloc<uint64_t>(ctx, ns);
     uint64_t* Y2 = ws_alloc<uint64_t>(ctx, ns);
     if (!Y2) return TBK_ENOMEM;
-    TBK_LAUNCH(ctx, "wg_sample", wg_sample_k, cdiv(ns, B), B, 0, chi, m, s, ns, Y);
+    if (raw)
+      TBK_LAUNCH(ctx, "wg_sample", wg_sample_raw_k, cdiv(ns, B), B, 0, I.tid, I.pos, m, s, ns, Y);
+    else
+      TBK_LAUNCH(ctx, "wg_sample", wg_sample_k, cdiv(ns, B), B, 0, chi, m, s, ns, Y);
     TBK_TRY(tbk_radix_sort_w64(ctx, &Y, &Y2, ns, ~0ull, false));
     TBK_LAUNCH(ctx, "wg_split", wg_split_k, cdiv(nsp, B), B, 0, Y, g, nsp, W);
   }
   {
     const uint64_t nthreads = (uint64_t)cdiv(nrows, WG_OR) * k;
-    TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_k, cdiv(nthreads, B), B, 0, chi, d_run_off, k, W, nrows, off);
+    if (raw)
+      TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_raw_k, cdiv(nthreads, B), B, 0, I.tid, I.pos, d_run_off, k, W, nrows, off);
+    else
+      TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_k, cdiv(nthreads, B), B, 0, chi, d_run_off, k, W, nrows, off);
   }
   WgTemp T;
   T.hi = scratch_hi;
@@ -914,6 +1198,7 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
     if (T.dbg) TBK_HIP(hipMemsetAsync(T.dbg, 0, 32 * 8, ctx->stream));
   }
   if (!T.pgl || !pbase || !T.c2r) return TBK_ENOMEM;
+  if (raw) TBK_HIP(hipMemsetAsync(T.cslot, 0xFF, (size_t)m * 4, ctx->stream));  // (only the records wg_finish_raw_k must visit get a slot)
   WgIn In{chi, clo, cval, ceff, off, W, k, nw};
   const uint32_t nwords = cdiv(k, 32);
   // LDS of the hash kernel: the pieces' tables (8 k + 4 bytes) and the group table share WG_LDS_HASH (four blocks per CU)
@@ -939,16 +1224,26 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   TBK_HIP(hipStreamSynchronize(ctx->stream));
   const uint32_t nw_live = (uint32_t)ctx->h_scalars[3];
   if (nw_live) {
-    TBK_LAUNCH(ctx, "wg_hash", wg_hash_k, nw_live, WG_NT, lds_hash, In, T, gcap, nwords, seed, wlist, ovf, ovf_cap, ctx->d_err);
+    if (raw)
+      TBK_LAUNCH(ctx, "wg_hash", wg_hash_k<true>, nw_live, WG_NT, lds_hash, In, R, T, gcap, nwords, seed, wlist, ovf, ovf_cap, ctx->d_err);
+    else
+      TBK_LAUNCH(ctx, "wg_hash", wg_hash_k<false>, nw_live, WG_NT, lds_hash, In, R, T, gcap, nwords, seed, wlist, ovf, ovf_cap, ctx->d_err);
     const uint32_t gcap2 = (WG_LDS_HASH2 - (8u * k + 8u)) / (44u + 4u * nwords);
     const uint32_t lds_hash2 = gcap2 * (44u + 4u * nwords) + 8u * k + 8u;
     if (gcap2 < 65536u) {  // (slot numbers are 16-bit in the ranking)
-      TBK_LAUNCH(ctx, "wg_hash2", wg_hash2_k, std::min<uint32_t>(nw_live, 512u), WG_NT, lds_hash2, In, T, gcap2, nwords, seed, ovf, ovf2, ovf_cap,
-                 ctx->d_err);
+      if (raw)
+        TBK_LAUNCH(ctx, "wg_hash2", wg_hash2_k<true>, std::min<uint32_t>(nw_live, 512u), WG_NT, lds_hash2, In, R, T, gcap2, nwords, seed, ovf, ovf2,
+                   ovf_cap, ctx->d_err);
+      else
+        TBK_LAUNCH(ctx, "wg_hash2", wg_hash2_k<false>, std::min<uint32_t>(nw_live, 512u), WG_NT, lds_hash2, In, R, T, gcap2, nwords, seed, ovf, ovf2,
+                   ovf_cap, ctx->d_err);
       ovf = ovf2;
     }
   }
-  TBK_LAUNCH(ctx, "wg_sort", wg_sort_k, std::min<uint32_t>(nw, 1024u), WG_NT, 0, In, T, I, strategy, ovf, ovf_cap, ctx->d_err);
+  if (raw)
+    TBK_LAUNCH(ctx, "wg_sort", wg_sort_k<true>, std::min<uint32_t>(nw, 1024u), WG_NT, 0, In, R, T, I, strategy, ovf, ovf_cap, ctx->d_err);
+  else
+    TBK_LAUNCH(ctx, "wg_sort", wg_sort_k<false>, std::min<uint32_t>(nw, 1024u), WG_NT, 0, In, R, T, I, strategy, ovf, ovf_cap, ctx->d_err);
   uint64_t* sc = ctx->d_scalars;
   TBK_TRY(tbk_exscan_u32(ctx, T.wg_cnt, gbase, nw, sc + 1));
   TBK_TRY(tbk_exscan_u32(ctx, T.wp_cnt, pbase, nw, sc + 2));
@@ -997,8 +1292,11 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
     TBK_LAUNCH(ctx, "wg_compact", wg_compact_k, nw, 64, 0, nw, T, gbase, pbase, F);
     TBK_LAUNCH(ctx, "wg_tie", wg_tie_k, cdiv(ng, B), B, 0, ng, out->ghi, out->glo, out->tie);
     if (want_rec_sg) TBK_HIP(hipMemsetAsync(out->rec_sg, 0xFF, (size_t)I.n * 4, ctx->stream));  // (records that did not pass)
-    TBK_LAUNCH(ctx, "wg_finish", wg_finish_k, cdiv(m, B), B, 0, m, clo, cval, T.cslot, T.c2r, T.rep, slot2sg, out->rec_sg, I, strategy,
-               ctx->d_err);
+    if (raw)
+      TBK_LAUNCH(ctx, "wg_finish", wg_finish_raw_k, cdiv(m, B), B, 0, m, T.cslot, T.c2r, T.rep, slot2sg, out->rec_sg, I, strategy, ctx->d_err);
+    else
+      TBK_LAUNCH(ctx, "wg_finish", wg_finish_k, cdiv(m, B), B, 0, m, clo, cval, T.cslot, T.c2r, T.rep, slot2sg, out->rec_sg, I, strategy,
+                 ctx->d_err);
   }
   return tbk_check_launch(ctx, "window_groups");
 }
