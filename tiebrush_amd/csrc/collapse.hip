@@ -83,7 +83,8 @@ __global__ __launch_bounds__(256) void col_keys_k(ColIn I, ColOpt O, uint64_t* _
   if (!in) return;
   uint32_t f = s_f;
   while (f + 1 < I.k && I.file_off[f + 1] <= i) ++f;
-  const RecKey K = record_key(I, O, i, fl, pos, tidv, mq, nhv, sc, I.cig + c0, c1 - c0, err);
+  const RecKey K = record_key(I, O, i, fl, pos, tidv, mq, nhv, sc, I.cig + c0, c1 - c0);
+  if (K.err) atomicOr(err, K.err);
   const bool pass = K.pass;
   khi[i] = K.hi;
   klo[i] = K.lo;

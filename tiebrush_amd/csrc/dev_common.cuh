@@ -26,8 +26,9 @@ __device__ __forceinline__ uint64_t hash_step(uint64_t h, uint64_t v) { return m
 // Reference GSamRecord::setupCoordinates (/root/reference/src/GSam.cpp:351-417), literal:
 // calls on_exon(start1,end1) for every exon in order, returns l (reference length so that
 // end = pos + l) and the exon count through *nex.  Unmapped records are the caller's business.
-template <class F>
-__device__ __forceinline__ int walk_exons(int32_t pos, const uint32_t* __restrict__ cig, uint32_t n, F on_exon, int* nex) {
+// (C: anything indexable that yields the CIGAR words — a pointer, or a view with the first words in registers)
+template <class C, class F>
+__device__ __forceinline__ int walk_exons(int32_t pos, C cig, uint32_t n, F on_exon, int* nex) {
   int l = 0, cnt = 0;
   int exstart = pos;
   bool intron = false, ins = false;
@@ -71,7 +72,8 @@ __device__ __forceinline__ int walk_exons(int32_t pos, const uint32_t* __restric
 }
 
 // reference length only (end = pos + l)
-__device__ __forceinline__ int cigar_reflen(const uint32_t* __restrict__ cig, uint32_t n) {
+template <class C>
+__device__ __forceinline__ int cigar_reflen(C cig, uint32_t n) {
   int l = 0;
   for (uint32_t i = 0; i < n; ++i) {
     uint32_t c = cig[i];
@@ -81,6 +83,14 @@ __device__ __forceinline__ int cigar_reflen(const uint32_t* __restrict__ cig, ui
   }
   return l;
 }
+
+// CIGAR words of one record with the first three already in registers (loaded together with the record's other fields, ahead
+// of their use); longer CIGARs read on from memory
+struct CigView {
+  uint32_t w0, w1, w2;
+  const uint32_t* p;
+  __device__ __forceinline__ uint32_t operator[](uint32_t k) const { return k == 0 ? w0 : (k == 1 ? w1 : (k == 2 ? w2 : p[k])); }
+};
 
 // ---- wave64 scans ---------------------------------------------------------------------
 template <class T>

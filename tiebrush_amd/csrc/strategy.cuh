@@ -53,7 +53,8 @@ __device__ inline bool same_read(const ColIn& I, uint32_t a, uint32_t b) {
 __device__ __forceinline__ uint32_t strand_code(uint8_t s) { return s == '+' ? 0u : (s == '-' ? 1u : 2u); }
 
 // clipped CIGAR view (cmpCigarClip tiebrush.cpp:312-332)
-__device__ __forceinline__ void clip_view(const uint32_t* __restrict__ c, uint32_t n, uint32_t* b, uint32_t* e) {
+template <class C>
+__device__ __forceinline__ void clip_view(C c, uint32_t n, uint32_t* b, uint32_t* e) {
   uint32_t s = 0, t = n;
   while (s < t && cig_op(c[s]) == C_S) ++s;
   while (t > s && cig_op(c[t - 1]) == C_S) --t;
@@ -62,7 +63,8 @@ __device__ __forceinline__ void clip_view(const uint32_t* __restrict__ c, uint32
 }
 
 // (c, n): the record's CIGAR words, I.cig + I.cig_off[i] and their count
-__device__ inline uint64_t strategy_hash(const ColIn& I, const ColOpt& O, uint32_t i, const uint32_t* c, uint32_t n) {
+template <class C>
+__device__ inline uint64_t strategy_hash(const ColIn& I, const ColOpt& O, uint32_t i, C c, uint32_t n) {
   uint64_t h = O.seed;
   switch (O.strategy) {
     case TBK_STRAT_CIGAR:
@@ -113,9 +115,11 @@ struct RecKey {
   uint64_t hi, lo;
   int32_t end;
   bool pass;
+  uint32_t err;  // TBK_DERR_* bits met (the caller raises them)
 };
+template <class C>
 __device__ __forceinline__ RecKey record_key(const ColIn& I, const ColOpt& O, uint32_t i, uint32_t fl, int pos, int tidv, int mq, int32_t nhv,
-                                             uint32_t sc, const uint32_t* __restrict__ c, uint32_t nc, uint32_t* __restrict__ err) {
+                                             uint32_t sc, C c, uint32_t nc) {
   int start = 0, end = 0;
   if (!(fl & 0x4)) {
     const int l = cigar_reflen(c, nc);
@@ -129,8 +133,8 @@ __device__ __forceinline__ RecKey record_key(const ColIn& I, const ColOpt& O, ui
   if (mq < O.min_qual) pass = false;
   const int nh = nhv == TBK_NH_ABSENT ? 0 : nhv;
   if (nh > O.max_nh) pass = false;
-  const uint64_t h = pass ? strategy_hash(I, O, i, c, nc) : 0ull;
-  uint32_t h32 = (uint32_t)(h >> 32) & O.hash_mask & 0x7FFFFFFFu;
+  uint32_t h32 = 0;
+  bool exact = false;
   if (pass && O.strategy != TBK_STRAT_FULL) {
     if (O.strategy == TBK_STRAT_EXON) {
       int nex = 0, e1 = 0, s2 = 0, ix = 0;
@@ -141,26 +145,39 @@ __device__ __forceinline__ RecKey record_key(const ColIn& I, const ColOpt& O, ui
                    ++ix;
                  },
                  &nex);
-      if (nex == 1) h32 = 0x8000000Fu;
+      if (nex == 1) {
+        h32 = 0x8000000Fu;
+        exact = true;
+      }
       if (nex == 2) {
         const uint32_t a = (uint32_t)(e1 - start + 1), g = (uint32_t)(s2 - e1 - 1);
-        if (a < (1u << 10) && g < (1u << 20)) h32 = 0xC0000000u | (a << 20) | g;
+        if (a < (1u << 10) && g < (1u << 20)) {
+          h32 = 0xC0000000u | (a << 20) | g;
+          exact = true;
+        }
       }
     } else {
       uint32_t b = 0, e = nc;
       if (O.strategy == TBK_STRAT_CLIP) clip_view(c, nc, &b, &e);
-      if (e - b == 1 && ((0x18Du >> cig_op(c[b])) & 1u)) h32 = 0x80000000u | cig_op(c[b]);
+      if (e - b == 1 && ((0x18Du >> cig_op(c[b])) & 1u)) {
+        h32 = 0x80000000u | cig_op(c[b]);
+        exact = true;
+      }
       if (e - b == 3 && cig_op(c[b]) == C_M && cig_op(c[b + 1]) == C_N && cig_op(c[b + 2]) == C_M && cig_len(c[b]) < (1u << 10) &&
-          cig_len(c[b + 1]) < (1u << 20))
+          cig_len(c[b + 1]) < (1u << 20)) {
         h32 = 0xC0000000u | (cig_len(c[b]) << 20) | cig_len(c[b + 1]);
+        exact = true;
+      }
     }
   }
+  if (pass && !exact) h32 = (uint32_t)(strategy_hash(I, O, i, c, nc) >> 32) & O.hash_mask & 0x7FFFFFFFu;
   int64_t span = (int64_t)end - (int64_t)start + 1;
+  RecKey K;
+  K.err = 0;
   if (pass && (span < 0 || span >= (1ll << 30) || start < 0 || tidv < -1)) {  // key fields: tid+1 and start need 31 bits
-    atomicOr(err, TBK_DERR_SPAN);
+    K.err = TBK_DERR_SPAN;
     span = 0;
   }
-  RecKey K;
   K.hi = ((uint64_t)(uint32_t)(tidv + 1) << 33) | ((uint64_t)(uint32_t)start << 2) | sc;
   K.lo = ((uint64_t)span << 32) | h32;
   K.end = end;

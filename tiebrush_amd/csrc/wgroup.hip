@@ -45,6 +45,8 @@ constexpr uint32_t WG_T = 1024;          // records between splitters: a window 
 constexpr uint32_t WG_KS = 1024;         // k * s budget
 constexpr int WG_NW = WG_NT / 64;
 constexpr int WG_R = 4;                  // records per thread and chunk in the pile-up path
+constexpr int WG_RS = 2;                 // raw form: records per thread whose loads are batched (WG_RR is a multiple)
+constexpr int WG_RR = 2;                 // raw form: records per thread and chunk
 
 // ---- partition ------------------------------------------------------------------------------------------------
 __global__ void wg_sample_k(const uint64_t* __restrict__ chi, uint32_t m, uint32_t s, uint32_t ns, uint64_t* __restrict__ shi) {
@@ -187,6 +189,88 @@ __global__ void wg_offsets_raw_k(const int32_t* __restrict__ rtid, const int32_t
     off[r * k + f] = ans;
   }
 }
+// Streaming form of the offsets matrix (replaces the per-(row, run) searches of wg_offsets_k, whose probes are scattered reads):
+// a block takes WG_OC consecutive records, keeps their partition keys in LDS, and for every run segment inside it finds by two
+// searches in W the bounds that fall between the key before the segment and its last key — each of those has its answer inside
+// the segment (one LDS bisection).  The first segment of a run takes every bound up to its first key, the last one every bound
+// beyond its keys (answer: the run's end), so each (bound, run) pair is written exactly once when the runs are sorted.  RAW: the
+// same pass checks that they are (an inversion raises TBK_DERR_RAWORDER: the caller must not run the window kernels on the
+// matrix).  Rows 0 / last and the columns of empty runs: wg_offsets_edges_k.
+constexpr uint32_t WG_OC = 2048;
+__device__ __forceinline__ uint32_t wg_upper_bound(const uint64_t* __restrict__ W, uint32_t n, uint64_t v) {  // first r with W[r] > v
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    if (W[mid] <= v)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+template <bool RAW>
+__global__ __launch_bounds__(256) void wg_offsets_stream_k(const uint64_t* __restrict__ chi, const int32_t* __restrict__ rtid,
+                                                           const int32_t* __restrict__ rpos, const uint32_t* __restrict__ run_off, uint32_t k,
+                                                           uint32_t n, const uint64_t* __restrict__ W, uint32_t nW, uint32_t* __restrict__ off,
+                                                           uint32_t* __restrict__ err) {
+  __shared__ uint64_t key[WG_OC];
+  __shared__ uint32_t s_f;
+  const uint32_t t = threadIdx.x;
+  const uint32_t i0 = blockIdx.x * WG_OC;
+  const uint32_t i1 = n - i0 < WG_OC ? n : i0 + WG_OC;
+  for (uint32_t j = t; j < i1 - i0; j += 256) key[j] = RAW ? raw_key(rtid[i0 + j], rpos[i0 + j]) : (chi[i0 + j] >> 2);
+  if (t == 0) {
+    uint32_t lo = 0, hi = k;  // last f with run_off[f] <= i0
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (run_off[mid] <= i0)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    s_f = lo;
+  }
+  __syncthreads();
+  bool bad = false;
+  for (uint32_t f = s_f; f < k; ++f) {
+    const uint32_t a = run_off[f], b = run_off[f + 1];
+    if (a >= i1) break;
+    if (b <= i0 || a == b) continue;
+    const uint32_t sa = a > i0 ? a : i0, sb = b < i1 ? b : i1;  // the run's records inside this block
+    const bool has_lo = sa > a;                                  // (then sa == i0: the record before is outside the block)
+    const uint64_t klo = has_lo ? (RAW ? raw_key(rtid[sa - 1], rpos[sa - 1]) : (chi[sa - 1] >> 2)) : 0ull;
+    const uint32_t r_lo = has_lo ? wg_upper_bound(W, nW, klo) : 0u;
+    const uint32_t r_hi = sb == b ? nW : wg_upper_bound(W, nW, key[sb - 1 - i0]);
+    for (uint32_t r = r_lo + t; r < r_hi; r += 256) {
+      const uint64_t v = W[r];
+      uint32_t lo = sa - i0, hi = sb - i0;  // first record of the segment with key >= v (none: the run ends here)
+      while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (key[mid] < v)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      off[(size_t)(r + 1) * k + f] = i0 + lo;
+    }
+    if (RAW) {
+      for (uint32_t j = sa + t; j < sb; j += 256) {
+        const uint64_t pk = j > sa ? key[j - 1 - i0] : klo;
+        bad |= pk > key[j - i0];
+      }
+    }
+  }
+  if (RAW && bad) atomicOr(err, TBK_DERR_RAWORDER);
+}
+__global__ void wg_offsets_edges_k(const uint32_t* __restrict__ run_off, uint32_t k, uint32_t nrows, uint32_t* __restrict__ off) {
+  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= k) return;
+  const uint32_t a = run_off[f], b = run_off[f + 1];
+  off[f] = a;
+  off[(size_t)(nrows - 1) * k + f] = b;
+  if (a == b)
+    for (uint32_t r = 1; r + 1 < nrows; ++r) off[(size_t)r * k + f] = a;
+}
 struct WgRaw {                 // raw mode: the window kernels read the records themselves (WgIn::chi / clo / cval / ceff are null)
   ColIn I;
   ColOpt O;
@@ -214,31 +298,57 @@ __device__ __forceinline__ uint32_t wave_seg_max(uint32_t x, uint32_t f, uint32_
   *fo = f;
   return x;
 }
-// One raw record of a window piece: fields -> key, pass, raw partition key, the value it feeds into the effective-end scan
-// (its end if it is mapped), and whether a segment of that scan starts here.  `first_of_piece`: the record opens the piece of
-// its file inside this window; `prev_rk`: the raw key of the lane to the left (valid for lanes > 0 that do not open a piece).
+// The raw fields of one record of a window piece, loaded in two batches so that the loads of several records are in flight
+// together (A: the fixed fields, the CIGAR range and — where the lane to the left is not the record before — that record's
+// position; B: the first three CIGAR words), then turned into the key, the filter verdict, the raw partition key and the value
+// the record feeds into the effective-end scan.  Records that are not there load record 0 (harmless, ignored).
+struct RawA {
+  int32_t pos, tidv, ppos, ptid;
+  uint32_t fl_mq_sc;  // flag : 16 | mapq : 8 | strand code : 2
+  int32_t nh;
+  uint32_t c0, nc;
+};
 struct RawRec {
-  uint64_t hi, lo, rk;
+  uint64_t hi, lo, rk, prk;
   uint32_t x;     // end of a mapped record, 0 otherwise
+  uint32_t err;
   bool pass;
 };
-__device__ __forceinline__ RawRec wg_raw_load(const WgRaw& R, uint32_t i, uint32_t* __restrict__ err) {
-  const ColIn& I = R.I;
-  const uint32_t fl = I.flag[i];
-  const int pos = I.pos[i], tidv = I.tid[i];
-  const int mq = (int)I.mapq[i];
-  const int32_t nhv = I.nh[i];
-  const uint32_t sc = strand_code(I.strand[i]);
-  const uint32_t c0 = I.cig_off[i], c1 = I.cig_off[i + 1];
-  const RecKey K = record_key(I, R.O, i, fl, pos, tidv, mq, nhv, sc, I.cig + c0, c1 - c0, err);
+__device__ __forceinline__ RawA wg_raw_a(const ColIn& I, uint32_t i, bool need_prev) {
+  RawA a;
+  a.pos = I.pos[i];
+  a.tidv = I.tid[i];
+  a.fl_mq_sc = (uint32_t)I.flag[i] | ((uint32_t)I.mapq[i] << 16) | (strand_code(I.strand[i]) << 24);
+  a.nh = I.nh[i];
+  a.c0 = I.cig_off[i];
+  a.nc = I.cig_off[i + 1] - a.c0;
+  const uint32_t j = need_prev && i > 0 ? i - 1 : i;
+  a.ppos = I.pos[j];
+  a.ptid = I.tid[j];
+  return a;
+}
+__device__ __forceinline__ CigView wg_raw_b(const ColIn& I, const RawA& a) {
+  CigView c;
+  const uint32_t* safe = I.cig_off;  // (always readable)
+  c.w0 = *(a.nc > 0 ? I.cig + a.c0 : safe);
+  c.w1 = *(a.nc > 1 ? I.cig + a.c0 + 1 : safe);
+  c.w2 = *(a.nc > 2 ? I.cig + a.c0 + 2 : safe);
+  c.p = I.cig + a.c0;
+  return c;
+}
+__device__ __forceinline__ RawRec wg_raw_c(const WgRaw& R, uint32_t i, const RawA& a, const CigView& c) {
+  const uint32_t fl = a.fl_mq_sc & 0xFFFFu;
+  const RecKey K = record_key(R.I, R.O, i, fl, a.pos, a.tidv, (int)((a.fl_mq_sc >> 16) & 0xFFu), a.nh, a.fl_mq_sc >> 24, c, a.nc);
   RawRec r;
   r.hi = K.hi;
   r.lo = K.lo;
   r.pass = K.pass;
-  r.rk = raw_key(tidv, pos);
+  r.err = K.err;
+  r.rk = raw_key(a.tidv, a.pos);
+  r.prk = raw_key(a.ptid, a.ppos);
   const bool mapped = !(fl & 0x4u);
   r.x = mapped && K.end > 0 ? (uint32_t)K.end : 0u;
-  if ((tidv >= 0 && pos < 0) || (mapped && tidv < 0)) atomicOr(err, TBK_DERR_RAWORDER);
+  if ((a.tidv >= 0 && a.pos < 0) || (mapped && a.tidv < 0)) r.err |= TBK_DERR_RAWORDER;
   return r;
 }
 
@@ -461,9 +571,9 @@ __global__ void wg_list_k(uint32_t nw, const uint32_t* __restrict__ wbase, uint3
 // RAW: the pieces are pieces of the input files themselves; every record's key, filter verdict and effective end (a segmented
 // prefix maximum along the piece, carried across waves, rows and chunks) are computed here, records that do not pass take no
 // part in the grouping.
-template <int SORT_E /* the ranking sorts at most SORT_E * WG_NT groups */, bool RAW>
+template <int SORT_E /* the ranking sorts at most SORT_E * WG_NT groups */, bool RAW, int NR /* records per thread and chunk */>
 __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, const WgTemp& T, uint32_t gcap, uint32_t nwords, uint64_t seed,
-                                               uint32_t w, unsigned char* lds, uint32_t* sm_u, uint32_t* s_misc, uint2* s_agg /* [WG_R * WG_NW] */,
+                                               uint32_t w, unsigned char* lds, uint32_t* sm_u, uint32_t* s_misc, uint2* s_agg /* [NR * WG_NW] */,
                                                uint32_t* __restrict__ ovf, uint32_t ovf_cap, bool final_tier, uint32_t* __restrict__ err) {
   const uint32_t t = threadIdx.x;
   const uint32_t k = In.k;
@@ -549,15 +659,15 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
   __syncthreads();
   phase(0);
   uint32_t npass_t = 0, par = 0;
-  // the window streams through in chunks of WG_NT * WG_R records: WG_R records per thread so that their loads and probes
+  // the window streams through in chunks of WG_NT * NR records: NR records per thread so that their loads and probes
   // overlap; two barriers per chunk
-  for (uint32_t c0 = 0; c0 < n_w; c0 += WG_NT * WG_R) {
-    uint32_t slot[WG_R], rec[WG_R], fil[WG_R], src[WG_R], eff[WG_R];
-    uint64_t kh[WG_R], kl[WG_R];
+  for (uint32_t c0 = 0; c0 < n_w; c0 += WG_NT * NR) {
+    uint32_t slot[NR], rec[NR], fil[NR], src[NR], eff[NR];
+    uint64_t kh[NR], kl[NR];
     uint32_t won = 0, actm = 0;
-    uint32_t xs[WG_R], fs[WG_R];  // RAW: scanned end inside the wave row, and whether a segment start shields it from the carry
+    uint32_t xs[NR], fs[NR];  // RAW: scanned end inside the wave row, and whether a segment start shields it from the carry
 #pragma unroll
-    for (int u = 0; u < WG_R; ++u) {
+    for (int u = 0; u < NR; ++u) {
       const uint32_t e = c0 + (uint32_t)u * WG_NT + t;
       slot[u] = 0xFFFFFFFFu;
       rec[u] = fil[u] = src[u] = eff[u] = 0;
@@ -573,44 +683,67 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
           rec[u] = In.cval[src[u]];
           eff[u] = In.ceff[src[u]];
         }
-      } else {
-        const bool act = e < n_w;
-        uint64_t rk = ~0ull;
-        uint32_t x = 0;
-        bool first = true;
-        if (act) {
-          fil[u] = piece_of(pre, k, e);
-          src[u] = rb[fil[u]] + e;
-          rec[u] = src[u];
-          const RawRec r = wg_raw_load(R, src[u], err);
-          kh[u] = r.hi;
-          kl[u] = r.lo;
-          rk = r.rk;
-          x = r.x;
-          if (r.pass) {
-            actm |= 1u << u;
-            ++npass_t;
-          }
-          first = e == pre[fil[u]];
-        }
-        // the record before this one in its file: the lane to the left, or — lane 0, or the first record of a piece — from memory
-        uint64_t prk = ((uint64_t)(uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(rk >> 32), 0x138, 0xf, 0xf, false) << 32) |
-                       (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)rk, 0x138, 0xf, 0xf, false);
-        if (act && (first || lane_id() == 0)) {
-          prk = src[u] > R.I.file_off[fil[u]] ? raw_key(R.I.tid[src[u] - 1], R.I.pos[src[u] - 1]) : 0ull;
-        }
-        if (act && prk > rk) atomicOr(err, TBK_DERR_RAWORDER);  // not coordinate-sorted as this path needs it
-        const uint32_t head = (!act || first || prk != rk) ? 1u : 0u;
-        xs[u] = wave_seg_max(x, head, &fs[u]);
-        if (lane_id() == 63) s_agg[u * WG_NW + (t >> 6)] = make_uint2(xs[u], fs[u]);
       }
     }
+    if constexpr (RAW) {
+      uint32_t errb = 0;
+#pragma unroll
+      for (int u0 = 0; u0 < NR; u0 += WG_RS) {  // WG_RS records per thread are decoded together
+        RawA ra[WG_RS];
+        CigView cv[WG_RS];
+        bool first[WG_RS], fromem[WG_RS];
+        uint32_t f0[WG_RS];
+#pragma unroll
+        for (int v = 0; v < WG_RS; ++v) {
+          const int u = u0 + v;
+          const uint32_t e = c0 + (uint32_t)u * WG_NT + t;
+          const bool act = e < n_w;
+          fil[u] = act ? piece_of(pre, k, e) : 0u;
+          src[u] = act ? rb[fil[u]] + e : 0u;
+          first[v] = !act || e == pre[fil[u]];
+          fromem[v] = act && (first[v] || lane_id() == 0);  // the record before it in its file is not the lane to the left
+          ra[v] = wg_raw_a(R.I, src[u], fromem[v]);
+          f0[v] = fromem[v] ? R.I.file_off[fil[u]] : 0u;
+        }
+#pragma unroll
+        for (int v = 0; v < WG_RS; ++v) cv[v] = wg_raw_b(R.I, ra[v]);
+#pragma unroll
+        for (int v = 0; v < WG_RS; ++v) {
+          const int u = u0 + v;
+          const uint32_t e = c0 + (uint32_t)u * WG_NT + t;
+          const bool act = e < n_w;
+          const RawRec r = wg_raw_c(R, src[u], ra[v], cv[v]);
+          uint64_t rk = ~0ull;
+          uint32_t x = 0;
+          if (act) {
+            rec[u] = src[u];
+            kh[u] = r.hi;
+            kl[u] = r.lo;
+            rk = r.rk;
+            x = r.x;
+            errb |= r.err;
+            if (r.pass) {
+              actm |= 1u << u;
+              ++npass_t;
+            }
+          }
+          uint64_t prk = ((uint64_t)(uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(rk >> 32), 0x138, 0xf, 0xf, false) << 32) |
+                         (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)rk, 0x138, 0xf, 0xf, false);
+          if (fromem[v]) prk = src[u] > f0[v] ? r.prk : 0ull;
+          if (act && prk > rk) errb |= TBK_DERR_RAWORDER;  // not coordinate-sorted as this path needs it
+          const uint32_t head = (first[v] || prk != rk) ? 1u : 0u;
+          xs[u] = wave_seg_max(x, head, &fs[u]);
+          if (lane_id() == 63) s_agg[u * WG_NW + (t >> 6)] = make_uint2(xs[u], fs[u]);
+        }
+      }
+      if (errb) atomicOr(err, errb);
+    }
     if (T.dbg) {
-      if (t == 0 && (kh[0] ^ kl[0] ^ rec[0] ^ eff[0] ^ kh[WG_R - 1] ^ rec[WG_R - 1]) == 0x123456789ull) T.dbg[31] = 1;  // (the loads have landed)
+      if (t == 0 && (kh[0] ^ kl[0] ^ rec[0] ^ eff[0] ^ kh[NR - 1] ^ rec[NR - 1]) == 0x123456789ull) T.dbg[31] = 1;  // (the loads have landed)
       phase(2);
     }
 #pragma unroll
-    for (int u = 0; u < WG_R; ++u) {
+    for (int u = 0; u < NR; ++u) {
       if ((actm >> u) & 1u) {
         const unsigned long long F = wg_fingerprint(kh[u], kl[u], seed);
         uint32_t hs = (uint32_t)(((F >> 32) * gcap) >> 32);
@@ -651,10 +784,10 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
     if (s_misc[1]) break;
     if constexpr (RAW) {  // effective ends: the carry that enters every (row, wave) of this chunk, folded in element order
       uint32_t c = s_misc[4 + par];
-      uint32_t snap[WG_R];
+      uint32_t snap[NR];
       const uint32_t wv = t >> 6;
 #pragma unroll
-      for (int q = 0; q < WG_R * WG_NW; ++q) {
+      for (int q = 0; q < NR * WG_NW; ++q) {
         if ((uint32_t)(q % WG_NW) == wv) snap[q / WG_NW] = c;
         const uint2 a = s_agg[q];
         c = a.y ? a.x : (a.x > c ? a.x : c);
@@ -662,10 +795,10 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
       if (t == 0) s_misc[4 + (par ^ 1u)] = c;
       par ^= 1u;
 #pragma unroll
-      for (int u = 0; u < WG_R; ++u) eff[u] = fs[u] ? xs[u] : (xs[u] > snap[u] ? xs[u] : snap[u]);
+      for (int u = 0; u < NR; ++u) eff[u] = fs[u] ? xs[u] : (xs[u] > snap[u] ? xs[u] : snap[u]);
     }
 #pragma unroll
-    for (int u = 0; u < WG_R; ++u) {
+    for (int u = 0; u < NR; ++u) {
       const bool act = (actm >> u) & 1u;
       if (act) {
         const uint32_t s = slot[u];
@@ -780,7 +913,7 @@ __global__ __launch_bounds__(WG_NT, 6) void wg_hash_k(WgIn In, WgRaw R, WgTemp T
   __shared__ uint32_t sm_u[WG_NW];
   __shared__ uint32_t s_misc[8];
   __shared__ uint2 s_agg[WG_R * WG_NW];
-  wg_hash_window<2, RAW>(In, R, T, gcap, nwords, seed, wlist[blockIdx.x], lds, sm_u, s_misc, s_agg, ovf, ovf_cap, false, err);
+  wg_hash_window<2, RAW, RAW ? WG_RR : WG_R>(In, R, T, gcap, nwords, seed, wlist[blockIdx.x], lds, sm_u, s_misc, s_agg, ovf, ovf_cap, false, err);
 }
 // second tier: the windows with more distinct groups than the first table holds (shallow data) against a table of WG_LDS_HASH2 bytes
 // (two blocks per CU); a fixed grid walks the first tier's worklist.  What overflows again goes to the sort kernel.
@@ -795,7 +928,7 @@ __global__ __launch_bounds__(WG_NT, 6) void wg_hash2_k(WgIn In, WgRaw R, WgTemp 
   const uint32_t cnt = ovf_in[0] < ovf_cap ? ovf_in[0] : ovf_cap;
   for (uint32_t wi = blockIdx.x; wi < cnt; wi += gridDim.x) {
     __syncthreads();  // (LDS of the previous window is free)
-    wg_hash_window<3, RAW>(In, R, T, gcap, nwords, seed, ovf_in[1 + wi], lds, sm_u, s_misc, s_agg, ovf, ovf_cap, true, err);
+    wg_hash_window<3, RAW, RAW ? WG_RR : WG_R>(In, R, T, gcap, nwords, seed, ovf_in[1 + wi], lds, sm_u, s_misc, s_agg, ovf, ovf_cap, true, err);
   }
 }
 
@@ -858,10 +991,17 @@ __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgRaw R, WgTemp T
         uint64_t rk = ~0ull, h = ~0ull, l = ~0ull;
         uint32_t x = 0, f = 0, srcv = 0;
         bool first = true;
+        bool fromem = false;
+        RawRec r{};
         if (act) {
           f = piece_of(pre, k, e);
           srcv = row0[f] + (e - pre[f]);
-          const RawRec r = wg_raw_load(R, srcv, err);
+          first = e == pre[f];
+          fromem = first || lane_id() == 0;
+          const RawA ra = wg_raw_a(R.I, srcv, fromem);
+          const CigView cv = wg_raw_b(R.I, ra);
+          r = wg_raw_c(R, srcv, ra, cv);
+          if (r.err) atomicOr(err, r.err);
           if (r.pass) {
             h = r.hi;
             l = r.lo;
@@ -869,11 +1009,10 @@ __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgRaw R, WgTemp T
           }
           rk = r.rk;
           x = r.x;
-          first = e == pre[f];
         }
         uint64_t prk = ((uint64_t)(uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(rk >> 32), 0x138, 0xf, 0xf, false) << 32) |
                        (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)rk, 0x138, 0xf, 0xf, false);
-        if (act && (first || lane_id() == 0)) prk = srcv > R.I.file_off[f] ? raw_key(R.I.tid[srcv - 1], R.I.pos[srcv - 1]) : 0ull;
+        if (fromem) prk = srcv > R.I.file_off[f] ? r.prk : 0ull;
         if (act && prk > rk) atomicOr(err, TBK_DERR_RAWORDER);
         const uint32_t head = (!act || first || prk != rk) ? 1u : 0u;
         uint32_t fo;
@@ -1169,12 +1308,18 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
     TBK_TRY(tbk_radix_sort_w64(ctx, &Y, &Y2, ns, ~0ull, false));
     TBK_LAUNCH(ctx, "wg_split", wg_split_k, cdiv(nsp, B), B, 0, Y, g, nsp, W);
   }
-  {
+  if (getenv("TBK_WG_OFFSETS_SEARCH")) {  // the search form (kept for comparison)
     const uint64_t nthreads = (uint64_t)cdiv(nrows, WG_OR) * k;
     if (raw)
       TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_raw_k, cdiv(nthreads, B), B, 0, I.tid, I.pos, d_run_off, k, W, nrows, off);
     else
       TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_k, cdiv(nthreads, B), B, 0, chi, d_run_off, k, W, nrows, off);
+  } else {
+    if (raw)
+      TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_stream_k<true>, cdiv(m, WG_OC), 256, 0, chi, I.tid, I.pos, d_run_off, k, m, W, nW, off, ctx->d_err);
+    else
+      TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_stream_k<false>, cdiv(m, WG_OC), 256, 0, chi, I.tid, I.pos, d_run_off, k, m, W, nW, off, ctx->d_err);
+    TBK_LAUNCH(ctx, "wg_offsets_edges", wg_offsets_edges_k, cdiv(k, B), B, 0, d_run_off, k, nrows, off);
   }
   WgTemp T;
   T.hi = scratch_hi;
@@ -1220,8 +1365,14 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   TBK_HIP(hipMemsetAsync(T.wg_cnt, 0, (size_t)nw * 4, ctx->stream));
   TBK_HIP(hipMemsetAsync(T.wp_cnt, 0, (size_t)nw * 4, ctx->stream));
   TBK_LAUNCH(ctx, "wg_list", wg_list_k, cdiv(nw, B), B, 0, nw, T.wbase, wlist, (unsigned long long*)(scw + 3));
-  TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 3, scw + 3, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-  TBK_HIP(hipStreamSynchronize(ctx->stream));
+  {
+    uint32_t eb0 = 0;
+    TBK_TRY(tbk_sync_err(ctx, &eb0));
+    if (eb0) {  // (RAW: an input this form does not take — the offsets matrix is not to be trusted; the caller decides)
+      *err_bits = eb0;
+      return 0;
+    }
+  }
   const uint32_t nw_live = (uint32_t)ctx->h_scalars[3];
   if (nw_live) {
     if (raw)
