@@ -23,6 +23,26 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
 }
 __device__ __forceinline__ uint64_t hash_step(uint64_t h, uint64_t v) { return mix64(h ^ (v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2))); }
 
+// CIGAR words of one record with the first three already in registers (loaded together with the record's other fields, ahead
+// of their use); longer CIGARs read on from memory
+struct CigView {
+  uint32_t w0, w1, w2;
+  const uint32_t* p;
+  __device__ __forceinline__ uint32_t operator[](uint32_t k) const { return k == 0 ? w0 : (k == 1 ? w1 : (k == 2 ? w2 : p[k])); }
+};
+// f(k, word) for every CIGAR word in order.  For a CigView the first three steps are straight-line code on registers.
+template <class F>
+__device__ __forceinline__ void cig_for_each(const uint32_t* c, uint32_t n, F f) {
+  for (uint32_t k = 0; k < n; ++k) f(k, c[k]);
+}
+template <class F>
+__device__ __forceinline__ void cig_for_each(const CigView& c, uint32_t n, F f) {
+  if (n > 0) f(0u, c.w0);
+  if (n > 1) f(1u, c.w1);
+  if (n > 2) f(2u, c.w2);
+  for (uint32_t k = 3; k < n; ++k) f(k, c.p[k]);
+}
+
 // Reference GSamRecord::setupCoordinates (/root/reference/src/GSam.cpp:351-417), literal:
 // calls on_exon(start1,end1) for every exon in order, returns l (reference length so that
 // end = pos + l) and the exon count through *nex.  Unmapped records are the caller's business.
@@ -32,39 +52,20 @@ __device__ __forceinline__ int walk_exons(int32_t pos, C cig, uint32_t n, F on_e
   int l = 0, cnt = 0;
   int exstart = pos;
   bool intron = false, ins = false;
-  for (uint32_t i = 0; i < n; ++i) {
-    uint32_t c = cig[i];
-    uint32_t op = cig_op(c);
-    switch (op) {
-      case C_EQ:
-      case C_X:
-      case C_M:
-      case C_D:
-        l += (int)cig_len(c);
-        intron = false;
-        ins = false;
-        break;
-      case C_N:
-        if (!ins || !intron) {
-          on_exon(exstart + 1, pos + l);
-          cnt++;
-        }
-        l += (int)cig_len(c);
-        exstart = pos + l;
-        intron = true;
-        break;
-      case C_S:
-      case C_H:
-        intron = false;
-        ins = false;
-        break;
-      case C_I:
-        ins = true;
-        break;
-      default:  // P and unknown: nothing
-        break;
+  // (the switch of the reference over the operation, as masks: M = X D add to the length and end an intron / insertion state,
+  // N closes an exon — unless an insertion directly follows an intron — and opens the next, S H only reset the state, I sets it)
+  cig_for_each(cig, n, [&](uint32_t, uint32_t c) {
+    const uint32_t op = cig_op(c);
+    const bool is_m = (0x185u >> op) & 1u, is_n = op == C_N, is_sh = (0x30u >> op) & 1u, is_i = op == C_I;
+    if (is_n && (!ins || !intron)) {
+      on_exon(exstart + 1, pos + l);
+      cnt++;
     }
-  }
+    l += (is_m || is_n) ? (int)cig_len(c) : 0;
+    exstart = is_n ? pos + l : exstart;
+    intron = is_n ? true : ((is_m || is_sh) ? false : intron);
+    ins = is_i ? true : ((is_m || is_sh) ? false : ins);
+  });
   on_exon(exstart + 1, pos + l);
   cnt++;
   *nex = cnt;
@@ -75,22 +76,10 @@ __device__ __forceinline__ int walk_exons(int32_t pos, C cig, uint32_t n, F on_e
 template <class C>
 __device__ __forceinline__ int cigar_reflen(C cig, uint32_t n) {
   int l = 0;
-  for (uint32_t i = 0; i < n; ++i) {
-    uint32_t c = cig[i];
-    uint32_t op = cig_op(c);
-    // M,=,X,D,N consume the reference: ops 0,2,3,7,8
-    if ((0x18Du >> op) & 1u) l += (int)cig_len(c);
-  }
+  // M,=,X,D,N consume the reference: ops 0,2,3,7,8
+  cig_for_each(cig, n, [&](uint32_t, uint32_t c) { l += ((0x18Du >> cig_op(c)) & 1u) ? (int)cig_len(c) : 0; });
   return l;
 }
-
-// CIGAR words of one record with the first three already in registers (loaded together with the record's other fields, ahead
-// of their use); longer CIGARs read on from memory
-struct CigView {
-  uint32_t w0, w1, w2;
-  const uint32_t* p;
-  __device__ __forceinline__ uint32_t operator[](uint32_t k) const { return k == 0 ? w0 : (k == 1 ? w1 : (k == 2 ? w2 : p[k])); }
-};
 
 // ---- wave64 scans ---------------------------------------------------------------------
 template <class T>

@@ -55,23 +55,28 @@ __device__ __forceinline__ uint32_t strand_code(uint8_t s) { return s == '+' ? 0
 // clipped CIGAR view (cmpCigarClip tiebrush.cpp:312-332)
 template <class C>
 __device__ __forceinline__ void clip_view(C c, uint32_t n, uint32_t* b, uint32_t* e) {
-  uint32_t s = 0, t = n;
-  while (s < t && cig_op(c[s]) == C_S) ++s;
-  while (t > s && cig_op(c[t - 1]) == C_S) --t;
-  *b = s;
-  *e = t;
+  uint32_t lead = 0, last = 0;  // leading S operations; index behind the last operation that is not S
+  bool leading = true;
+  cig_for_each(c, n, [&](uint32_t k, uint32_t w) {
+    const bool is_s = cig_op(w) == C_S;
+    leading = leading && is_s;
+    lead += leading ? 1u : 0u;
+    last = is_s ? last : k + 1;
+  });
+  *b = lead;
+  *e = last > lead ? last : lead;  // (all S: the empty view at n)
 }
 
 // (c, n): the record's CIGAR words, I.cig + I.cig_off[i] and their count
 template <class C>
-__device__ inline uint64_t strategy_hash(const ColIn& I, const ColOpt& O, uint32_t i, C c, uint32_t n) {
+__device__ inline uint64_t strategy_hash(const ColIn& I, const ColOpt& O, int strategy, uint32_t i, C c, uint32_t n) {
   uint64_t h = O.seed;
-  switch (O.strategy) {
+  switch (strategy) {
     case TBK_STRAT_CIGAR:
     case TBK_STRAT_FULL: {
       h = hash_step(h, n);
-      for (uint32_t k = 0; k < n; ++k) h = hash_step(h, c[k]);
-      if (O.strategy == TBK_STRAT_FULL) {
+      cig_for_each(c, n, [&](uint32_t, uint32_t w) { h = hash_step(h, w); });
+      if (strategy == TBK_STRAT_FULL) {
         uint32_t has = I.md_has[i];
         h = hash_step(h, has);
         if (has) {
@@ -86,7 +91,9 @@ __device__ inline uint64_t strategy_hash(const ColIn& I, const ColOpt& O, uint32
       uint32_t b, e;
       clip_view(c, n, &b, &e);
       h = hash_step(h, e - b);
-      for (uint32_t k = b; k < e; ++k) h = hash_step(h, c[k]);
+      cig_for_each(c, n, [&](uint32_t k, uint32_t w) {
+        if (k >= b && k < e) h = hash_step(h, w);
+      });
       break;
     }
     case TBK_STRAT_EXON: {
@@ -100,7 +107,7 @@ __device__ inline uint64_t strategy_hash(const ColIn& I, const ColOpt& O, uint32
 }
 
 __device__ inline uint64_t strategy_hash(const ColIn& I, const ColOpt& O, uint32_t i) {
-  return strategy_hash(I, O, i, I.cig + I.cig_off[i], I.cig_off[i + 1] - I.cig_off[i]);
+  return strategy_hash(I, O, O.strategy, i, I.cig + I.cig_off[i], I.cig_off[i + 1] - I.cig_off[i]);
 }
 
 // The 128-bit group key of one record from its raw fields (shared by col_keys_k and the raw window path, wgroup.hip):
@@ -117,9 +124,11 @@ struct RecKey {
   bool pass;
   uint32_t err;  // TBK_DERR_* bits met (the caller raises them)
 };
-template <class C>
+// (ST: the strategy as a compile-time constant, or -1: O.strategy)
+template <int ST = -1, class C>
 __device__ __forceinline__ RecKey record_key(const ColIn& I, const ColOpt& O, uint32_t i, uint32_t fl, int pos, int tidv, int mq, int32_t nhv,
                                              uint32_t sc, C c, uint32_t nc) {
+  const int strategy = ST >= 0 ? ST : O.strategy;
   int start = 0, end = 0;
   if (!(fl & 0x4)) {
     const int l = cigar_reflen(c, nc);
@@ -135,8 +144,8 @@ __device__ __forceinline__ RecKey record_key(const ColIn& I, const ColOpt& O, ui
   if (nh > O.max_nh) pass = false;
   uint32_t h32 = 0;
   bool exact = false;
-  if (pass && O.strategy != TBK_STRAT_FULL) {
-    if (O.strategy == TBK_STRAT_EXON) {
+  if (pass && strategy != TBK_STRAT_FULL) {
+    if (strategy == TBK_STRAT_EXON) {
       int nex = 0, e1 = 0, s2 = 0, ix = 0;
       walk_exons(pos, c, nc,
                  [&](int s, int e) {
@@ -158,7 +167,7 @@ __device__ __forceinline__ RecKey record_key(const ColIn& I, const ColOpt& O, ui
       }
     } else {
       uint32_t b = 0, e = nc;
-      if (O.strategy == TBK_STRAT_CLIP) clip_view(c, nc, &b, &e);
+      if (strategy == TBK_STRAT_CLIP) clip_view(c, nc, &b, &e);
       if (e - b == 1 && ((0x18Du >> cig_op(c[b])) & 1u)) {
         h32 = 0x80000000u | cig_op(c[b]);
         exact = true;
@@ -170,7 +179,7 @@ __device__ __forceinline__ RecKey record_key(const ColIn& I, const ColOpt& O, ui
       }
     }
   }
-  if (pass && !exact) h32 = (uint32_t)(strategy_hash(I, O, i, c, nc) >> 32) & O.hash_mask & 0x7FFFFFFFu;
+  if (pass && !exact) h32 = (uint32_t)(strategy_hash(I, O, strategy, i, c, nc) >> 32) & O.hash_mask & 0x7FFFFFFFu;
   int64_t span = (int64_t)end - (int64_t)start + 1;
   RecKey K;
   K.err = 0;

@@ -336,9 +336,10 @@ __device__ __forceinline__ CigView wg_raw_b(const ColIn& I, const RawA& a) {
   c.p = I.cig + a.c0;
   return c;
 }
+template <int ST>
 __device__ __forceinline__ RawRec wg_raw_c(const WgRaw& R, uint32_t i, const RawA& a, const CigView& c) {
   const uint32_t fl = a.fl_mq_sc & 0xFFFFu;
-  const RecKey K = record_key(R.I, R.O, i, fl, a.pos, a.tidv, (int)((a.fl_mq_sc >> 16) & 0xFFu), a.nh, a.fl_mq_sc >> 24, c, a.nc);
+  const RecKey K = record_key<ST>(R.I, R.O, i, fl, a.pos, a.tidv, (int)((a.fl_mq_sc >> 16) & 0xFFu), a.nh, a.fl_mq_sc >> 24, c, a.nc);
   RawRec r;
   r.hi = K.hi;
   r.lo = K.lo;
@@ -493,8 +494,9 @@ __device__ __forceinline__ uint16_t* wg_merge_sort(uint16_t* src, uint16_t* dst,
 }
 
 __device__ __forceinline__ unsigned long long wg_fingerprint(uint64_t hi, uint64_t lo, uint64_t seed) {
-  unsigned long long f = mix64(hi ^ seed) ^ mix64(lo + 0x9E3779B97F4A7C15ull + (seed << 1));
-  f = mix64(f);
+  // (hi, lo) -> hi * K + lo is one-to-one in lo for equal hi and, for an odd seeded K, collides for two different hi only when
+  // their difference times K equals the difference of the lo words; mix64 is a bijection
+  unsigned long long f = mix64((hi ^ seed) * ((seed << 1) | 0x9E3779B97F4A7C15ull) + lo);
   return f == ~0ull ? 0ull : f;  // ~0 marks an empty slot
 }
 
@@ -571,7 +573,7 @@ __global__ void wg_list_k(uint32_t nw, const uint32_t* __restrict__ wbase, uint3
 // RAW: the pieces are pieces of the input files themselves; every record's key, filter verdict and effective end (a segmented
 // prefix maximum along the piece, carried across waves, rows and chunks) are computed here, records that do not pass take no
 // part in the grouping.
-template <int SORT_E /* the ranking sorts at most SORT_E * WG_NT groups */, bool RAW, int NR /* records per thread and chunk */>
+template <int SORT_E /* the ranking sorts at most SORT_E * WG_NT groups */, bool RAW, int NR /* records per thread and chunk */, int ST /* RAW: strategy */>
 __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, const WgTemp& T, uint32_t gcap, uint32_t nwords, uint64_t seed,
                                                uint32_t w, unsigned char* lds, uint32_t* sm_u, uint32_t* s_misc, uint2* s_agg /* [NR * WG_NW] */,
                                                uint32_t* __restrict__ ovf, uint32_t ovf_cap, bool final_tier, uint32_t* __restrict__ err) {
@@ -712,7 +714,7 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
           const int u = u0 + v;
           const uint32_t e = c0 + (uint32_t)u * WG_NT + t;
           const bool act = e < n_w;
-          const RawRec r = wg_raw_c(R, src[u], ra[v], cv[v]);
+          const RawRec r = wg_raw_c<ST>(R, src[u], ra[v], cv[v]);
           uint64_t rk = ~0ull;
           uint32_t x = 0;
           if (act) {
@@ -905,7 +907,7 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
 }
 
 // first tier: one block per window that holds records, a table of WG_LDS_HASH bytes (four blocks per CU)
-template <bool RAW>
+template <bool RAW, int ST>
 __global__ __launch_bounds__(WG_NT, 6) void wg_hash_k(WgIn In, WgRaw R, WgTemp T, uint32_t gcap, uint32_t nwords, uint64_t seed,
                                                       const uint32_t* __restrict__ wlist, uint32_t* __restrict__ ovf /* [0] count, [1..] windows */,
                                                       uint32_t ovf_cap, uint32_t* __restrict__ err) {
@@ -913,11 +915,11 @@ __global__ __launch_bounds__(WG_NT, 6) void wg_hash_k(WgIn In, WgRaw R, WgTemp T
   __shared__ uint32_t sm_u[WG_NW];
   __shared__ uint32_t s_misc[8];
   __shared__ uint2 s_agg[WG_R * WG_NW];
-  wg_hash_window<2, RAW, RAW ? WG_RR : WG_R>(In, R, T, gcap, nwords, seed, wlist[blockIdx.x], lds, sm_u, s_misc, s_agg, ovf, ovf_cap, false, err);
+  wg_hash_window<2, RAW, RAW ? WG_RR : WG_R, ST>(In, R, T, gcap, nwords, seed, wlist[blockIdx.x], lds, sm_u, s_misc, s_agg, ovf, ovf_cap, false, err);
 }
 // second tier: the windows with more distinct groups than the first table holds (shallow data) against a table of WG_LDS_HASH2 bytes
 // (two blocks per CU); a fixed grid walks the first tier's worklist.  What overflows again goes to the sort kernel.
-template <bool RAW>
+template <bool RAW, int ST>
 __global__ __launch_bounds__(WG_NT, 6) void wg_hash2_k(WgIn In, WgRaw R, WgTemp T, uint32_t gcap, uint32_t nwords, uint64_t seed,
                                                        const uint32_t* __restrict__ ovf_in, uint32_t* __restrict__ ovf, uint32_t ovf_cap,
                                                        uint32_t* __restrict__ err) {
@@ -928,7 +930,7 @@ __global__ __launch_bounds__(WG_NT, 6) void wg_hash2_k(WgIn In, WgRaw R, WgTemp 
   const uint32_t cnt = ovf_in[0] < ovf_cap ? ovf_in[0] : ovf_cap;
   for (uint32_t wi = blockIdx.x; wi < cnt; wi += gridDim.x) {
     __syncthreads();  // (LDS of the previous window is free)
-    wg_hash_window<3, RAW, RAW ? WG_RR : WG_R>(In, R, T, gcap, nwords, seed, ovf_in[1 + wi], lds, sm_u, s_misc, s_agg, ovf, ovf_cap, true, err);
+    wg_hash_window<3, RAW, RAW ? WG_RR : WG_R, ST>(In, R, T, gcap, nwords, seed, ovf_in[1 + wi], lds, sm_u, s_misc, s_agg, ovf, ovf_cap, true, err);
   }
 }
 
@@ -936,7 +938,7 @@ __global__ __launch_bounds__(WG_NT, 6) void wg_hash2_k(WgIn In, WgRaw R, WgTemp 
 // each, sorted in LDS.  A fixed grid walks the worklist.
 // RAW: keys, filter verdicts and effective ends are computed while the window is loaded (see wg_hash_window); records that do not
 // pass sort behind every key and are left out.
-template <bool RAW>
+template <bool RAW, int ST>
 __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgRaw R, WgTemp T, ColIn I, int strategy, const uint32_t* __restrict__ ovf,
                                                       uint32_t ovf_cap, uint32_t* __restrict__ err) {
   __shared__ __align__(16) unsigned char lds[WG_LDS_MAIN];
@@ -1000,7 +1002,7 @@ __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgRaw R, WgTemp T
           fromem = first || lane_id() == 0;
           const RawA ra = wg_raw_a(R.I, srcv, fromem);
           const CigView cv = wg_raw_b(R.I, ra);
-          r = wg_raw_c(R, srcv, ra, cv);
+          r = wg_raw_c<ST>(R, srcv, ra, cv);
           if (r.err) atomicOr(err, r.err);
           if (r.pass) {
             h = r.hi;
@@ -1375,26 +1377,48 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   }
   const uint32_t nw_live = (uint32_t)ctx->h_scalars[3];
   if (nw_live) {
-    if (raw)
-      TBK_LAUNCH(ctx, "wg_hash", wg_hash_k<true>, nw_live, WG_NT, lds_hash, In, R, T, gcap, nwords, seed, wlist, ovf, ovf_cap, ctx->d_err);
-    else
-      TBK_LAUNCH(ctx, "wg_hash", wg_hash_k<false>, nw_live, WG_NT, lds_hash, In, R, T, gcap, nwords, seed, wlist, ovf, ovf_cap, ctx->d_err);
+#define WG_BY_STRATEGY(LAUNCH)          \
+  switch (strategy) {                  \
+    case TBK_STRAT_CIGAR:              \
+      LAUNCH(TBK_STRAT_CIGAR);         \
+      break;                           \
+    case TBK_STRAT_FULL:               \
+      LAUNCH(TBK_STRAT_FULL);          \
+      break;                           \
+    case TBK_STRAT_CLIP:               \
+      LAUNCH(TBK_STRAT_CLIP);          \
+      break;                           \
+    default:                           \
+      LAUNCH(TBK_STRAT_EXON);          \
+      break;                           \
+  }
+#define WG_L_HASH(S) TBK_LAUNCH(ctx, "wg_hash", (wg_hash_k<true, S>), nw_live, WG_NT, lds_hash, In, R, T, gcap, nwords, seed, wlist, ovf, ovf_cap, ctx->d_err)
+    if (raw) {
+      WG_BY_STRATEGY(WG_L_HASH)
+    } else {
+      TBK_LAUNCH(ctx, "wg_hash", (wg_hash_k<false, -1>), nw_live, WG_NT, lds_hash, In, R, T, gcap, nwords, seed, wlist, ovf, ovf_cap, ctx->d_err);
+    }
     const uint32_t gcap2 = (WG_LDS_HASH2 - (8u * k + 8u)) / (44u + 4u * nwords);
     const uint32_t lds_hash2 = gcap2 * (44u + 4u * nwords) + 8u * k + 8u;
     if (gcap2 < 65536u) {  // (slot numbers are 16-bit in the ranking)
-      if (raw)
-        TBK_LAUNCH(ctx, "wg_hash2", wg_hash2_k<true>, std::min<uint32_t>(nw_live, 512u), WG_NT, lds_hash2, In, R, T, gcap2, nwords, seed, ovf, ovf2,
-                   ovf_cap, ctx->d_err);
-      else
-        TBK_LAUNCH(ctx, "wg_hash2", wg_hash2_k<false>, std::min<uint32_t>(nw_live, 512u), WG_NT, lds_hash2, In, R, T, gcap2, nwords, seed, ovf, ovf2,
-                   ovf_cap, ctx->d_err);
+#define WG_L_HASH2(S)                                                                                                                      \
+  TBK_LAUNCH(ctx, "wg_hash2", (wg_hash2_k<true, S>), std::min<uint32_t>(nw_live, 512u), WG_NT, lds_hash2, In, R, T, gcap2, nwords, seed, ovf, ovf2, \
+             ovf_cap, ctx->d_err)
+      if (raw) {
+        WG_BY_STRATEGY(WG_L_HASH2)
+      } else {
+        TBK_LAUNCH(ctx, "wg_hash2", (wg_hash2_k<false, -1>), std::min<uint32_t>(nw_live, 512u), WG_NT, lds_hash2, In, R, T, gcap2, nwords, seed, ovf,
+                   ovf2, ovf_cap, ctx->d_err);
+      }
       ovf = ovf2;
     }
   }
-  if (raw)
-    TBK_LAUNCH(ctx, "wg_sort", wg_sort_k<true>, std::min<uint32_t>(nw, 1024u), WG_NT, 0, In, R, T, I, strategy, ovf, ovf_cap, ctx->d_err);
-  else
-    TBK_LAUNCH(ctx, "wg_sort", wg_sort_k<false>, std::min<uint32_t>(nw, 1024u), WG_NT, 0, In, R, T, I, strategy, ovf, ovf_cap, ctx->d_err);
+#define WG_L_SORT(S) TBK_LAUNCH(ctx, "wg_sort", (wg_sort_k<true, S>), std::min<uint32_t>(nw, 1024u), WG_NT, 0, In, R, T, I, strategy, ovf, ovf_cap, ctx->d_err)
+  if (raw) {
+    WG_BY_STRATEGY(WG_L_SORT)
+  } else {
+    TBK_LAUNCH(ctx, "wg_sort", (wg_sort_k<false, -1>), std::min<uint32_t>(nw, 1024u), WG_NT, 0, In, R, T, I, strategy, ovf, ovf_cap, ctx->d_err);
+  }
   uint64_t* sc = ctx->d_scalars;
   TBK_TRY(tbk_exscan_u32(ctx, T.wg_cnt, gbase, nw, sc + 1));
   TBK_TRY(tbk_exscan_u32(ctx, T.wp_cnt, pbase, nw, sc + 2));
