@@ -26,6 +26,7 @@
 #include <stdlib.h>
 
 #include "dev_common.cuh"
+#include "rx_w64.cuh"
 #include "scan_op.cuh"
 #include "strategy.cuh"
 #include "tbk_internal.h"
@@ -477,17 +478,21 @@ __global__ void yd_gexons_k(ColIn I, uint32_t ng, const uint32_t* __restrict__ g
              &nex);
 }
 
-__global__ void yd_coords_k(uint32_t nit, const uint64_t* __restrict__ v /* item words: group in the low half */, YdGroups Q, YdItems Y) {
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nit) return;
-  uint32_t o = (uint32_t)v[t];
-  const uint4 g = Q.pk[o];
-  Y.tidp1[t] = g.x;
-  Y.start[t] = (int32_t)g.y;
-  Y.end[t] = (int32_t)g.z;
-  Y.nex[t] = g.w;
-  Y.xo[t] = Q.xoff[o];
-}
+// the coordinates of an item's group, written where the list sort drops the item (the sort's last scatter pass walks the items in
+// group order, so the group table is read nearly sequentially; a pass over the sorted items would touch a line per item)
+struct YdEmit {
+  YdGroups Q;
+  YdItems Y;
+  __device__ __forceinline__ void operator()(uint32_t t, uint64_t w) const {
+    const uint32_t o = (uint32_t)w;
+    const uint4 g = Q.pk[o];
+    Y.tidp1[t] = g.x;
+    Y.start[t] = (int32_t)g.y;
+    Y.end[t] = (int32_t)g.z;
+    Y.nex[t] = g.w;
+    Y.xo[t] = Q.xoff[o];
+  }
+};
 
 struct SegMaxY {
   int32_t mx;
@@ -1088,11 +1093,6 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
         TBK_TRY(tbk_exscan_u32(ctx, ocnt, ooff, ng, nullptr));
         TBK_LAUNCH(ctx, "yd_fill", yd_fill_k, cdiv(m, B), B, 0, I, m, J.val, J.flags, J.fidx, J.sgid, J.ginv, ioff, ooff, J.G, iv);
       }
-      {  // stable split by list id (file * 2 + strand list); group order is already in place.  The id range is known:
-        uint32_t bits = 1;  // no scan for the varying bits
-        while ((1ull << bits) < 2ull * I.k) ++bits;
-        TBK_TRY(tbk_radix_sort_w64(ctx, &iv, &iv2, nit, ((1ull << bits) - 1ull) << 32, true));
-      }
       YdGroups Q;
       Q.pk = ws_alloc<uint4>(ctx, ng);
       Q.nex = ws_alloc<uint32_t>(ctx, ng);
@@ -1100,7 +1100,11 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       if (!Q.xoff) return TBK_ENOMEM;
       TBK_LAUNCH(ctx, "yd_groups", yd_groups_k, cdiv(ng, B), B, 0, I, ng, J.gperm, J.G, J.shi, J.slo, Q);
       TBK_TRY(tbk_exscan_u32(ctx, Q.nex, Q.xoff, ng, sc + 5));
-      TBK_LAUNCH(ctx, "yd_coords", yd_coords_k, cdiv(nit, B), B, 0, nit, iv, Q, Y);
+      {  // stable split by list id (file * 2 + strand list); group order is already in place.  The id range is known:
+        uint32_t bits = 1;  // no scan for the varying bits
+        while ((1ull << bits) < 2ull * I.k) ++bits;
+        TBK_TRY(tbk_radix_sort_w64_emit(ctx, &iv, &iv2, nit, ((1ull << bits) - 1ull) << 32, true, YdEmit{Q, Y}, "yd_scatter"));
+      }
       {
         YdLoad ld{iv, Y};
         YdStore st{ld};

@@ -4,6 +4,7 @@
 // All integer work, HBM-bound; no MFMA.
 #include "dev_common.cuh"
 #include "tbk_internal.h"
+#include "rx_w64.cuh"
 
 // =====================================================================================
 // exclusive scan (u32 in, u32 or u64 out) — reduce / spine / down-sweep (one block when the input is small).
@@ -180,11 +181,6 @@ int tbk_exscan_u32_u64(tbk_ctx* ctx, const uint32_t* in, uint64_t* out, uint32_t
 // 128-bit LSD radix sort, 8-bit digits, stable
 // =====================================================================================
 namespace {
-constexpr int RX_NT = 256;
-constexpr int RX_E = 8;                    // elements per lane per sub-tile
-constexpr int RX_SUB = RX_NT * RX_E;       // 2048
-constexpr int RX_MAX_ITER = 16;            // sub-tiles per tile (runtime choice: tile = RX_SUB * iter)
-
 // AND / OR of all keys: bits where and == or are constant => whole digits of them are skipped
 __global__ __launch_bounds__(256) void rx_bits_k(const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo, uint32_t n,
                                                  uint64_t* __restrict__ andor /*[4]: and_hi, or_hi, and_lo, or_lo*/) {
@@ -224,17 +220,6 @@ __global__ __launch_bounds__(256) void rx_bits_k(const uint64_t* __restrict__ hi
     atomicAnd((unsigned long long*)&andor[2], (unsigned long long)al);
     atomicOr((unsigned long long*)&andor[3], (unsigned long long)ol);
   }
-}
-
-__device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid) {
-  uint64_t peers = __ballot(valid);
-#pragma unroll
-  for (int b = 0; b < 8; ++b) {
-    bool bit = (d >> b) & 1u;
-    uint64_t bal = __ballot(valid && bit);
-    peers &= bit ? bal : ~bal;
-  }
-  return peers;
 }
 
 // per-tile digit counts -> table[digit * ntiles + tile]
@@ -374,89 +359,22 @@ __global__ __launch_bounds__(RX_NT) void rx_scatter_k(const uint64_t* __restrict
 }
 }  // namespace
 
-// ---- single 64-bit words ordered by a bit range (e.g. id : value packed into one word): the same tiled LSD pass on 8 bytes per
-// element instead of 20; the histogram pass is rx_hist_k ----------------
-namespace {
-__global__ __launch_bounds__(RX_NT) void w64_scatter_k(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint32_t shift, uint32_t n,
-                                                       uint32_t ntiles, uint32_t iter, const uint32_t* __restrict__ table,
-                                                       const uint32_t* __restrict__ totals) {
-  __shared__ uint32_t digit_base[256];
-  __shared__ uint32_t wave_cnt[4][256];
-  __shared__ uint32_t lpos[256];
-  __shared__ uint32_t sm[8];
-  __shared__ uint64_t s_w[RX_SUB];
-  const uint32_t t = threadIdx.x;
-  const uint32_t w = t >> 6;
-  {
-    uint32_t tot_d = totals[t], dummy;
-    uint32_t dbase = block_excl_sum<uint32_t, RX_NT>(tot_d, sm, &dummy);
-    digit_base[t] = dbase + table[(uint64_t)t * ntiles + blockIdx.x];
-  }
-  const uint64_t tile_base = (uint64_t)blockIdx.x * RX_SUB * iter;
-  for (uint32_t it = 0; it < iter; ++it) {
-    const uint64_t sub_base = tile_base + (uint64_t)it * RX_SUB;
-    if (sub_base >= n) break;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) wave_cnt[k][t] = 0;
-    __syncthreads();
-    uint64_t kk[RX_E];
-    uint32_t kr[RX_E];
-#pragma unroll
-    for (int e = 0; e < RX_E; ++e) {
-      uint64_t i = sub_base + (uint64_t)w * (64 * RX_E) + (uint64_t)e * 64 + lane_id();
-      kk[e] = i < n ? in[i] : ~0ull;
-    }
-#pragma unroll
-    for (int e = 0; e < RX_E; ++e) {
-      uint64_t i = sub_base + (uint64_t)w * (64 * RX_E) + (uint64_t)e * 64 + lane_id();
-      bool valid = i < n;
-      uint32_t d = (uint32_t)((kk[e] >> shift) & 0xFFu);
-      uint64_t peers = match_digit(d, valid);
-      uint32_t before = (uint32_t)__popcll(peers & lanemask_lt());
-      uint32_t base = valid ? wave_cnt[w][d] : 0u;
-      __builtin_amdgcn_wave_barrier();
-      if (valid && before == 0) wave_cnt[w][d] = base + (uint32_t)__popcll(peers);
-      __builtin_amdgcn_wave_barrier();
-      kr[e] = (base + before) | (d << 16) | (valid ? 0u : 0x80000000u);
-    }
-    __syncthreads();
-    uint32_t c0 = wave_cnt[0][t], c1 = wave_cnt[1][t], c2 = wave_cnt[2][t], c3 = wave_cnt[3][t];
-    uint32_t tot = c0 + c1 + c2 + c3, dummy;
-    uint32_t lp = block_excl_sum<uint32_t, RX_NT>(tot, sm, &dummy);
-    wave_cnt[0][t] = lp;
-    wave_cnt[1][t] = lp + c0;
-    wave_cnt[2][t] = lp + c0 + c1;
-    wave_cnt[3][t] = lp + c0 + c1 + c2;
-    lpos[t] = lp;
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < RX_E; ++e) {
-      if (!(kr[e] & 0x80000000u)) {
-        uint32_t d = (kr[e] >> 16) & 0xFFu;
-        s_w[wave_cnt[w][d] + (kr[e] & 0xFFFFu)] = kk[e];
-      }
-    }
-    __syncthreads();
-    uint32_t cnt_sub = (uint32_t)((n - sub_base) < (uint64_t)RX_SUB ? (n - sub_base) : (uint64_t)RX_SUB);
-    for (uint32_t q = t; q < cnt_sub; q += RX_NT) {
-      uint64_t kq = s_w[q];
-      uint32_t d = (uint32_t)((kq >> shift) & 0xFFu);
-      out[digit_base[d] + (q - lpos[d])] = kq;
-    }
-    __syncthreads();
-    digit_base[t] += tot;
-    __syncthreads();
-  }
-}
-}  // namespace
-
+// ---- single 64-bit words ordered by a bit range: rx_w64.cuh (the scatter pass is a template there: its last pass can hand every
+// word and its final position to a functor) ----------------
 // tile = RX_SUB * iter elements: small inputs get many small tiles (occupancy), big inputs bigger tiles
 // (the digit x tile table stays a few MB)
-static uint32_t rx_iter_for(uint32_t n) {
+uint32_t tbk_rx_iter_for(uint32_t n) {
   uint32_t it = (uint32_t)(((uint64_t)n + (uint64_t)RX_SUB * 4096 - 1) / ((uint64_t)RX_SUB * 4096));
   if (it < 1) it = 1;
   if (it > RX_MAX_ITER) it = RX_MAX_ITER;
   return it;
+}
+static uint32_t rx_iter_for(uint32_t n) { return tbk_rx_iter_for(n); }
+int tbk_rx_hist_rowscan(tbk_ctx* ctx, const uint64_t* word, uint32_t shift, uint32_t n, uint32_t ntiles, uint32_t iter, uint32_t* table,
+                        uint32_t* totals) {
+  TBK_LAUNCH(ctx, "rx_hist", rx_hist_k, ntiles, RX_NT, 0, word, shift, n, ntiles, iter, table);
+  TBK_LAUNCH(ctx, "rx_rowscan", rx_rowscan_k, 256, 256, 0, table, ntiles, totals);
+  return 0;
 }
 size_t tbk_radix_ws_bytes(uint32_t n) {
   uint32_t ntiles = cdiv(n ? n : 1, RX_SUB * rx_iter_for(n));
@@ -505,31 +423,18 @@ int tbk_radix_sort128(tbk_ctx* ctx, SortBufs* b, uint32_t n, uint64_t only_hi, u
 // reduction over the words (and one read-back) finds the bits that do, and whole constant digits are skipped.  The result is in
 // *w (swapped with *w2 as the passes go).
 int tbk_radix_sort_w64(tbk_ctx* ctx, uint64_t** w, uint64_t** w2, uint32_t n, uint64_t mask, bool mask_is_exact) {
-  if (n < 2) return 0;
-  uint64_t vary = mask;
-  if (!mask_is_exact) {
-    uint64_t* d_andor = ctx->d_scalars + 32;
-    uint64_t init[4] = {~0ull, 0ull, ~0ull, 0ull};
-    memcpy(ctx->h_scalars + 32, init, sizeof(init));
-    TBK_HIP(hipMemcpyAsync(d_andor, ctx->h_scalars + 32, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-    uint32_t g = cdiv(n, 256 * 16);
-    if (g > 512) g = 512;
-    TBK_LAUNCH(ctx, "rx_bits", rx_bits_k, g, 256, 0, *w, *w, n, d_andor);
-    TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 32, d_andor, sizeof(init), hipMemcpyDeviceToHost, ctx->stream));
-    TBK_HIP(hipStreamSynchronize(ctx->stream));
-    vary = (ctx->h_scalars[32] ^ ctx->h_scalars[33]) & mask;
-  }
-  const uint32_t iter = rx_iter_for(n);
-  uint32_t ntiles = cdiv(n, RX_SUB * iter);
-  uint32_t* table = ws_alloc<uint32_t>(ctx, (size_t)256 * ntiles);
-  uint32_t* totals = ws_alloc<uint32_t>(ctx, 256);
-  if (!table || !totals) return TBK_ENOMEM;
-  for (uint32_t shift = 0; shift < 64; shift += 8) {
-    if (((vary >> shift) & 0xFFull) == 0) continue;
-    TBK_LAUNCH(ctx, "rx_hist", rx_hist_k, ntiles, RX_NT, 0, *w, shift, n, ntiles, iter, table);
-    TBK_LAUNCH(ctx, "rx_rowscan", rx_rowscan_k, 256, 256, 0, table, ntiles, totals);
-    TBK_LAUNCH(ctx, "rx_scatter", w64_scatter_k, ntiles, RX_NT, 0, *w, *w2, shift, n, ntiles, iter, table, totals);
-    std::swap(*w, *w2);
-  }
-  return tbk_check_launch(ctx, "radix_sort_w64");
+  return tbk_radix_sort_w64_emit(ctx, w, w2, n, mask, mask_is_exact, RxNoEmit{});
+}
+int tbk_rx_vary_bits(tbk_ctx* ctx, const uint64_t* w, uint32_t n, uint64_t mask, uint64_t* vary) {
+  uint64_t* d_andor = ctx->d_scalars + 32;
+  uint64_t init[4] = {~0ull, 0ull, ~0ull, 0ull};
+  memcpy(ctx->h_scalars + 32, init, sizeof(init));
+  TBK_HIP(hipMemcpyAsync(d_andor, ctx->h_scalars + 32, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+  uint32_t g = cdiv(n, 256 * 16);
+  if (g > 512) g = 512;
+  TBK_LAUNCH(ctx, "rx_bits", rx_bits_k, g, 256, 0, w, w, n, d_andor);
+  TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 32, d_andor, sizeof(init), hipMemcpyDeviceToHost, ctx->stream));
+  TBK_HIP(hipStreamSynchronize(ctx->stream));
+  *vary = (ctx->h_scalars[32] ^ ctx->h_scalars[33]) & mask;
+  return 0;
 }
