@@ -1309,7 +1309,7 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
   }
   // Raw window path: plain tiles without an explicit merge priority go from the input records straight to the groups — the key
   // pass, the effective-end scan and the compaction are folded into the window kernels (TBK_RAW=0: test hook, keeps them apart)
-  bool use_raw = use_win && !I.prio_hi;
+  bool use_raw = use_win;
   if (const char* e = getenv("TBK_RAW")) use_raw = use_raw && strcmp(e, "0") != 0;
   WgOut win_out;
   bool win_done = false;
@@ -1371,7 +1371,8 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
       TBK_HIP(hipMemsetAsync(g_yd, 0, (size_t)ng * 4, ctx->stream));
       const uint64_t* png = sc + 1;  // (tbk_window_groups left the group count there)
       TBK_LAUNCH(ctx, "col_tie_sort", col_tie_sort_k, cdiv(ng, B), B, 0, I, O.strategy, png, wo.gmem, G, gperm, ginv);
-      // (effend == nullptr: the effective end of the representative rides in the high word of G.rep)
+      // (effend == nullptr: the effective end of the representative — or the low word of its explicit priority — rides in the
+      // high word of G.rep)
       TBK_LAUNCH(ctx, "col_write", col_write_k, cdiv(ng, B), B, 0, png, gperm, G, wo.ghi, wo.glo, out->cap_groups, out->rep, out->yc,
                  out->yx, out->g_start, out->g_end, (const int32_t*)nullptr, out->rep_effend);
       if (out->rec_group) TBK_LAUNCH(ctx, "col_recgroup", col_recgroup_w_k, cdiv(n, B), B, 0, n, wo.rec_sg, ginv, out->rec_group);

@@ -798,6 +798,11 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
       par ^= 1u;
 #pragma unroll
       for (int u = 0; u < NR; ++u) eff[u] = fs[u] ? xs[u] : (xs[u] > snap[u] ? xs[u] : snap[u]);
+      if (R.I.prio_hi) {  // cross-rank tiles: the merge order was fixed where the files live — the explicit priority replaces the scan
+#pragma unroll
+        for (int u = 0; u < NR; ++u)
+          if ((actm >> u) & 1u) eff[u] = (uint32_t)R.I.prio_hi[src[u]];
+      }
     }
 #pragma unroll
     for (int u = 0; u < NR; ++u) {
@@ -1031,7 +1036,7 @@ __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgRaw R, WgTemp T
         if (act) {
           hi[e] = h;  // (a record that does not pass: ~0, ~0 — behind every key)
           lo[e] = l;
-          val[e] = fo ? x : (x > snap ? x : snap);
+          val[e] = R.I.prio_hi ? (uint32_t)R.I.prio_hi[srcv] : (fo ? x : (x > snap ? x : snap));
           qa[e] = (uint16_t)e;
         }
         __syncthreads();
