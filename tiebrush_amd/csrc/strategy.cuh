@@ -124,17 +124,43 @@ struct RecKey {
   bool pass;
   uint32_t err;  // TBK_DERR_* bits met (the caller raises them)
 };
+// One pass over the CIGAR for the key: reference length, the clipped view [b, e) (cmpCigarClip; the whole CIGAR when `clip` is
+// false) and the first three words of that view — no indexed access afterwards.
+struct CigScan {
+  int l;
+  uint32_t b, e, v0, v1, v2;
+};
+template <class C>
+__device__ __forceinline__ CigScan cig_scan(C c, uint32_t n, bool clip) {
+  CigScan r;
+  r.l = 0;
+  r.v0 = r.v1 = r.v2 = 0;
+  uint32_t lead = 0, last = 0, nv = 0;
+  bool leading = clip;
+  cig_for_each(c, n, [&](uint32_t k, uint32_t w) {
+    const uint32_t op = cig_op(w);
+    r.l += ((0x18Du >> op) & 1u) ? (int)cig_len(w) : 0;  // M,=,X,D,N consume the reference
+    const bool is_s = clip && op == C_S;
+    leading = leading && is_s;
+    lead += leading ? 1u : 0u;
+    last = is_s ? last : k + 1;
+    if (!leading) {
+      r.v0 = nv == 0 ? w : r.v0;
+      r.v1 = nv == 1 ? w : r.v1;
+      r.v2 = nv == 2 ? w : r.v2;
+      ++nv;
+    }
+  });
+  r.b = lead;
+  r.e = clip ? (last > lead ? last : lead) : n;
+  return r;
+}
+
 // (ST: the strategy as a compile-time constant, or -1: O.strategy)
 template <int ST = -1, class C>
 __device__ __forceinline__ RecKey record_key(const ColIn& I, const ColOpt& O, uint32_t i, uint32_t fl, int pos, int tidv, int mq, int32_t nhv,
                                              uint32_t sc, C c, uint32_t nc) {
   const int strategy = ST >= 0 ? ST : O.strategy;
-  int start = 0, end = 0;
-  if (!(fl & 0x4)) {
-    const int l = cigar_reflen(c, nc);
-    start = pos + 1;
-    end = pos + l;
-  }
   bool pass = true;  // passes_options, tiebrush.cpp:532-541
   if (!O.keep_supp && (fl & 0x800)) pass = false;
   if (!O.keep_sec && (fl & 0x100)) pass = false;
@@ -142,44 +168,55 @@ __device__ __forceinline__ RecKey record_key(const ColIn& I, const ColOpt& O, ui
   if (mq < O.min_qual) pass = false;
   const int nh = nhv == TBK_NH_ABSENT ? 0 : nhv;
   if (nh > O.max_nh) pass = false;
+  const bool mapped = !(fl & 0x4);
+  int start = 0, end = 0;
   uint32_t h32 = 0;
   bool exact = false;
-  if (pass && strategy != TBK_STRAT_FULL) {
-    if (strategy == TBK_STRAT_EXON) {
-      int nex = 0, e1 = 0, s2 = 0, ix = 0;
-      walk_exons(pos, c, nc,
-                 [&](int s, int e) {
-                   if (ix == 0) e1 = e;
-                   if (ix == 1) s2 = s;
-                   ++ix;
-                 },
-                 &nex);
-      if (nex == 1) {
-        h32 = 0x8000000Fu;
+  if (strategy == TBK_STRAT_EXON) {
+    int nex = 0, e1 = 0, s2 = 0, ix = 0;
+    const int l = walk_exons(pos, c, nc,
+                             [&](int s, int e) {
+                               e1 = ix == 0 ? e : e1;
+                               s2 = ix == 1 ? s : s2;
+                               ++ix;
+                             },
+                             &nex);
+    if (mapped) {
+      start = pos + 1;
+      end = pos + l;
+    }
+    if (nex == 1) {
+      h32 = 0x8000000Fu;
+      exact = true;
+    }
+    if (nex == 2) {
+      const uint32_t a = (uint32_t)(e1 - pos), g = (uint32_t)(s2 - e1 - 1);  // first exon length, gap
+      if (a < (1u << 10) && g < (1u << 20)) {
+        h32 = 0xC0000000u | (a << 20) | g;
         exact = true;
       }
-      if (nex == 2) {
-        const uint32_t a = (uint32_t)(e1 - start + 1), g = (uint32_t)(s2 - e1 - 1);
-        if (a < (1u << 10) && g < (1u << 20)) {
-          h32 = 0xC0000000u | (a << 20) | g;
-          exact = true;
-        }
-      }
-    } else {
-      uint32_t b = 0, e = nc;
-      if (strategy == TBK_STRAT_CLIP) clip_view(c, nc, &b, &e);
-      if (e - b == 1 && ((0x18Du >> cig_op(c[b])) & 1u)) {
-        h32 = 0x80000000u | cig_op(c[b]);
+    }
+  } else {
+    const CigScan v = cig_scan(c, nc, strategy == TBK_STRAT_CLIP);
+    if (mapped) {
+      start = pos + 1;
+      end = pos + v.l;
+    }
+    if (strategy != TBK_STRAT_FULL) {
+      const uint32_t vn = v.e - v.b;
+      if (vn == 1 && ((0x18Du >> cig_op(v.v0)) & 1u)) {
+        h32 = 0x80000000u | cig_op(v.v0);
         exact = true;
       }
-      if (e - b == 3 && cig_op(c[b]) == C_M && cig_op(c[b + 1]) == C_N && cig_op(c[b + 2]) == C_M && cig_len(c[b]) < (1u << 10) &&
-          cig_len(c[b + 1]) < (1u << 20)) {
-        h32 = 0xC0000000u | (cig_len(c[b]) << 20) | cig_len(c[b + 1]);
+      if (vn == 3 && cig_op(v.v0) == C_M && cig_op(v.v1) == C_N && cig_op(v.v2) == C_M && cig_len(v.v0) < (1u << 10) &&
+          cig_len(v.v1) < (1u << 20)) {
+        h32 = 0xC0000000u | (cig_len(v.v0) << 20) | cig_len(v.v1);
         exact = true;
       }
     }
   }
   if (pass && !exact) h32 = (uint32_t)(strategy_hash(I, O, strategy, i, c, nc) >> 32) & O.hash_mask & 0x7FFFFFFFu;
+  if (!pass) h32 = 0;
   int64_t span = (int64_t)end - (int64_t)start + 1;
   RecKey K;
   K.err = 0;
