@@ -573,12 +573,16 @@ __global__ void wg_list_k(uint32_t nw, const uint32_t* __restrict__ wbase, uint3
 // RAW: the pieces are pieces of the input files themselves; every record's key, filter verdict and effective end (a segmented
 // prefix maximum along the piece, carried across waves, rows and chunks) are computed here, records that do not pass take no
 // part in the grouping.
-template <int SORT_E /* the ranking sorts at most SORT_E * WG_NT groups */, bool RAW, int NR /* records per thread and chunk */, int ST /* RAW: strategy */>
-__device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, const WgTemp& T, uint32_t gcap, uint32_t nwords, uint64_t seed,
+template <int SORT_E /* the ranking sorts at most SORT_E * WG_NT groups */, bool RAW, int NR /* records per thread and chunk */, int ST /* RAW: strategy */,
+          int GC /* > 0: at most 64 input files, a table of exactly GC slots (compile-time LDS layout); 0: sizes from the arguments */>
+__device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, const WgTemp& T, uint32_t gcap_arg, uint32_t nwords_arg, uint64_t seed,
                                                uint32_t w, unsigned char* lds, uint32_t* sm_u, uint32_t* s_misc, uint2* s_agg /* [NR * WG_NW] */,
                                                uint32_t* __restrict__ ovf, uint32_t ovf_cap, bool final_tier, uint32_t* __restrict__ err) {
   const uint32_t t = threadIdx.x;
   const uint32_t k = In.k;
+  const uint32_t gcap = GC > 0 ? (uint32_t)GC : gcap_arg;
+  const uint32_t nwords = GC > 0 ? 2u : nwords_arg;
+  const uint32_t kcap = GC > 0 ? 64u : k;  // entries of the pieces' tables
   const unsigned long long t_start = T.dbg ? __builtin_readcyclecounter() : 0ull;
   auto dbg_done = [&](int kind, uint32_t nrec) {
     if (T.dbg && threadIdx.x == 0) {
@@ -586,6 +590,17 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
       atomicAdd(&T.dbg[kind * 4 + 1], 1ull);
       atomicAdd(&T.dbg[kind * 4 + 2], (unsigned long long)nrec);
       atomicMax(&T.dbg[kind * 4 + 3], __builtin_readcyclecounter() - t_start);
+    }
+  };
+  // piece of item e (GC > 0: six steps without a branch over the table padded to 64 entries)
+  auto piece = [&](const uint32_t* pre, uint32_t e) -> uint32_t {
+    if constexpr (GC > 0) {
+      uint32_t lo = 0;
+#pragma unroll
+      for (uint32_t st = 32; st > 0; st >>= 1) lo = pre[lo + st] <= e ? lo + st : lo;
+      return lo;
+    } else {
+      return piece_of(pre, k, e);
     }
   };
   unsigned long long t_last = t_start;
@@ -612,8 +627,8 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
   uint32_t* tci = tcnt + gcap;                                                      // [gcap] claim number of the slot
   uint32_t* tbits = tci + gcap;                                                     // [gcap * nwords] samples seen
   uint32_t* pre = tbits + (size_t)gcap * nwords;                                    // [k + 1] first item of piece f
-  uint32_t* rb = pre + (k + 1);                                                     // [k] item e of piece f is compacted record rb[f] + e
-  uint16_t* pa = reinterpret_cast<uint16_t*>(rb + k);                               // [gcap] slots by claim number, then the ranking's ping
+  uint32_t* rb = pre + (kcap + 1);                                                  // [k] item e of piece f is compacted record rb[f] + e
+  uint16_t* pa = reinterpret_cast<uint16_t*>(rb + kcap);                            // [gcap] slots by claim number, then the ranking's ping
   uint16_t* pb = pa + gcap;                                                         // [gcap] ... and pong
   {
     const uint32_t* row0 = In.off + (size_t)w * k;
@@ -657,6 +672,7 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
       ex += len[u];
     }
     if (t == 0) pre[k] = n_w;
+    if (GC > 0 && t > k && t <= 64) pre[t] = n_w;  // (padding: no item reaches these)
   }
   __syncthreads();
   phase(0);
@@ -678,7 +694,7 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
       if constexpr (!RAW) {
         if (e < n_w) {
           actm |= 1u << u;
-          fil[u] = piece_of(pre, k, e);
+          fil[u] = piece(pre, e);
           src[u] = rb[fil[u]] + e;
           kh[u] = In.chi[src[u]];
           kl[u] = In.clo[src[u]];
@@ -700,7 +716,7 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
           const int u = u0 + v;
           const uint32_t e = c0 + (uint32_t)u * WG_NT + t;
           const bool act = e < n_w;
-          fil[u] = act ? piece_of(pre, k, e) : 0u;
+          fil[u] = act ? piece(pre, e) : 0u;
           src[u] = act ? rb[fil[u]] + e : 0u;
           first[v] = !act || e == pre[fil[u]];
           fromem[v] = act && (first[v] || lane_id() == 0);  // the record before it in its file is not the lane to the left
@@ -912,7 +928,8 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
 }
 
 // first tier: one block per window that holds records, a table of WG_LDS_HASH bytes (four blocks per CU)
-template <bool RAW, int ST>
+constexpr int WG_GC64 = (WG_LDS_HASH - (8 * 64 + 8)) / (44 + 4 * 2);  // table slots of the <= 64 files form of the first tier
+template <bool RAW, int ST, int GC>
 __global__ __launch_bounds__(WG_NT, 6) void wg_hash_k(WgIn In, WgRaw R, WgTemp T, uint32_t gcap, uint32_t nwords, uint64_t seed,
                                                       const uint32_t* __restrict__ wlist, uint32_t* __restrict__ ovf /* [0] count, [1..] windows */,
                                                       uint32_t ovf_cap, uint32_t* __restrict__ err) {
@@ -920,7 +937,7 @@ __global__ __launch_bounds__(WG_NT, 6) void wg_hash_k(WgIn In, WgRaw R, WgTemp T
   __shared__ uint32_t sm_u[WG_NW];
   __shared__ uint32_t s_misc[8];
   __shared__ uint2 s_agg[WG_R * WG_NW];
-  wg_hash_window<2, RAW, RAW ? WG_RR : WG_R, ST>(In, R, T, gcap, nwords, seed, wlist[blockIdx.x], lds, sm_u, s_misc, s_agg, ovf, ovf_cap, false, err);
+  wg_hash_window<2, RAW, RAW ? WG_RR : WG_R, ST, GC>(In, R, T, gcap, nwords, seed, wlist[blockIdx.x], lds, sm_u, s_misc, s_agg, ovf, ovf_cap, false, err);
 }
 // second tier: the windows with more distinct groups than the first table holds (shallow data) against a table of WG_LDS_HASH2 bytes
 // (two blocks per CU); a fixed grid walks the first tier's worklist.  What overflows again goes to the sort kernel.
@@ -935,7 +952,7 @@ __global__ __launch_bounds__(WG_NT, 6) void wg_hash2_k(WgIn In, WgRaw R, WgTemp 
   const uint32_t cnt = ovf_in[0] < ovf_cap ? ovf_in[0] : ovf_cap;
   for (uint32_t wi = blockIdx.x; wi < cnt; wi += gridDim.x) {
     __syncthreads();  // (LDS of the previous window is free)
-    wg_hash_window<3, RAW, RAW ? WG_RR : WG_R, ST>(In, R, T, gcap, nwords, seed, ovf_in[1 + wi], lds, sm_u, s_misc, s_agg, ovf, ovf_cap, true, err);
+    wg_hash_window<3, RAW, RAW ? WG_RR : WG_R, ST, 0>(In, R, T, gcap, nwords, seed, ovf_in[1 + wi], lds, sm_u, s_misc, s_agg, ovf, ovf_cap, true, err);
   }
 }
 
@@ -1397,11 +1414,16 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
       LAUNCH(TBK_STRAT_EXON);          \
       break;                           \
   }
-#define WG_L_HASH(S) TBK_LAUNCH(ctx, "wg_hash", (wg_hash_k<true, S>), nw_live, WG_NT, lds_hash, In, R, T, gcap, nwords, seed, wlist, ovf, ovf_cap, ctx->d_err)
-    if (raw) {
+#define WG_L_HASH(S) TBK_LAUNCH(ctx, "wg_hash", (wg_hash_k<true, S, 0>), nw_live, WG_NT, lds_hash, In, R, T, gcap, nwords, seed, wlist, ovf, ovf_cap, ctx->d_err)
+#define WG_L_HASH64(S)                                                                                                                       \
+  TBK_LAUNCH(ctx, "wg_hash", (wg_hash_k<true, S, WG_GC64>), nw_live, WG_NT, WG_GC64 * 52u + 8u * 64u + 8u, In, R, T, gcap, nwords, seed, wlist, ovf, \
+             ovf_cap, ctx->d_err)
+    if (raw && k <= 64) {  // compile-time table layout
+      WG_BY_STRATEGY(WG_L_HASH64)
+    } else if (raw) {
       WG_BY_STRATEGY(WG_L_HASH)
     } else {
-      TBK_LAUNCH(ctx, "wg_hash", (wg_hash_k<false, -1>), nw_live, WG_NT, lds_hash, In, R, T, gcap, nwords, seed, wlist, ovf, ovf_cap, ctx->d_err);
+      TBK_LAUNCH(ctx, "wg_hash", (wg_hash_k<false, -1, 0>), nw_live, WG_NT, lds_hash, In, R, T, gcap, nwords, seed, wlist, ovf, ovf_cap, ctx->d_err);
     }
     const uint32_t gcap2 = (WG_LDS_HASH2 - (8u * k + 8u)) / (44u + 4u * nwords);
     const uint32_t lds_hash2 = gcap2 * (44u + 4u * nwords) + 8u * k + 8u;
