@@ -430,12 +430,13 @@ __global__ void col_recgroup_w_k(uint32_t n, const uint32_t* __restrict__ rec_sg
 }
 
 struct YdItems {
-  uint32_t* tidp1;
-  int32_t* start;
-  int32_t* end;
-  uint32_t* xo;   // offset of the item's exon list in the per-group exon arrays
-  uint32_t* nex;
+  uint4* pk;      // (tid + 1, start, end, offset of the item's exon list in the per-group exon arrays): written with one store
+  uint32_t* nex;  // exon count (contiguous: the input of the node-offset scan)
   uint32_t* chead;
+  __device__ __forceinline__ uint32_t tidp1(uint32_t t) const { return reinterpret_cast<const uint32_t*>(pk)[4 * (size_t)t]; }
+  __device__ __forceinline__ int32_t start(uint32_t t) const { return (int32_t) reinterpret_cast<const uint32_t*>(pk)[4 * (size_t)t + 1]; }
+  __device__ __forceinline__ int32_t end(uint32_t t) const { return (int32_t) reinterpret_cast<const uint32_t*>(pk)[4 * (size_t)t + 2]; }
+  __device__ __forceinline__ uint32_t xo(uint32_t t) const { return reinterpret_cast<const uint32_t*>(pk)[4 * (size_t)t + 3]; }
 };
 
 // per output group (computed once, every item of the group reuses it): coordinates, exon count, exon list
@@ -486,11 +487,8 @@ struct YdEmit {
   __device__ __forceinline__ void operator()(uint32_t t, uint64_t w) const {
     const uint32_t o = (uint32_t)w;
     const uint4 g = Q.pk[o];
-    Y.tidp1[t] = g.x;
-    Y.start[t] = (int32_t)g.y;
-    Y.end[t] = (int32_t)g.z;
+    Y.pk[t] = make_uint4(g.x, g.y, g.z, Q.xoff[o]);
     Y.nex[t] = g.w;
-    Y.xo[t] = Q.xoff[o];
   }
 };
 
@@ -510,11 +508,11 @@ struct YdLoad {
   const uint64_t* list;  // item words: list id in the high half
   YdItems Y;
   __device__ __forceinline__ bool list_head(uint32_t t) const {
-    return t == 0 || (list[t] >> 32) != (list[t - 1] >> 32) || Y.tidp1[t] != Y.tidp1[t - 1];  // new list, or rspacing.reset() (:586-589)
+    return t == 0 || (list[t] >> 32) != (list[t - 1] >> 32) || Y.tidp1(t) != Y.tidp1(t - 1);  // new list, or rspacing.reset() (:586-589)
   }
   __device__ __forceinline__ SegMaxY operator()(uint32_t t) const {
     SegMaxY s;
-    s.mx = Y.end[t];
+    s.mx = Y.end(t);
     s.flag = list_head(t) ? 1u : 0u;
     return s;
   }
@@ -523,7 +521,7 @@ struct YdStore {
   YdLoad L;
   __device__ __forceinline__ void operator()(uint32_t t, const SegMaxY&, const SegMaxY& ex) const {
     // renewal: the read starts beyond every earlier end of this list => every node is cleared (processRead :230-241)
-    L.Y.chead[t] = (L.list_head(t) || L.Y.start[t] > ex.mx) ? 1u : 0u;
+    L.Y.chead[t] = (L.list_head(t) || L.Y.start(t) > ex.mx) ? 1u : 0u;
   }
 };
 
@@ -642,8 +640,9 @@ __global__ void yd_run_k(const uint32_t* __restrict__ ids, const uint32_t* __res
   int last_dist = -1;
   uint32_t alloc = noff[t0];
   for (uint32_t t = t0; t < t1; ++t) {
-    uint32_t rstart = (uint32_t)Y.start[t];
-    uint32_t xo = Y.xo[t], nex = Y.nex[t];
+    const uint4 it = Y.pk[t];
+    uint32_t rstart = it.y;
+    uint32_t xo = it.w, nex = Y.nex[t];
     int d;
     if (last_pos == rstart) {  // :225-228
       yd_merge_read(ex_s + xo, ex_e + xo, nex, N, head, alloc);
@@ -708,9 +707,10 @@ __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids
     Batch b;
     const uint32_t t = tb + (uint32_t)lane;
     const bool have = t < t1;
-    b.start = have ? (uint32_t)Y.start[t] : 0u;
+    const uint4 it = have ? Y.pk[t] : make_uint4(0u, 0u, 0u, 0u);
+    b.start = it.y;
     b.nex = have ? Y.nex[t] : 0u;
-    b.xo = have ? Y.xo[t] : 0u;
+    b.xo = it.w;
     b.o = have ? (uint32_t)v[t] : 0u;
     b.e0 = have ? ex_e[b.xo] : 0u;  // first exon end (its start is the read start)
     b.s1 = (have && b.nex > 1) ? ex_s[b.xo + 1] : 0u;
@@ -1073,10 +1073,7 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       uint64_t* iv = ws_alloc<uint64_t>(ctx, nit);
       uint64_t* iv2 = ws_alloc<uint64_t>(ctx, nit);
       YdItems Y;
-      Y.tidp1 = ws_alloc<uint32_t>(ctx, nit);
-      Y.start = ws_alloc<int32_t>(ctx, nit);
-      Y.end = ws_alloc<int32_t>(ctx, nit);
-      Y.xo = ws_alloc<uint32_t>(ctx, nit);
+      Y.pk = ws_alloc<uint4>(ctx, nit);
       Y.nex = ws_alloc<uint32_t>(ctx, nit);
       Y.chead = ws_alloc<uint32_t>(ctx, nit);
       uint32_t* cex = ws_alloc<uint32_t>(ctx, nit);

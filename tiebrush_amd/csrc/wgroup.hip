@@ -366,7 +366,7 @@ struct WgTemp {                // per window, at the window's record base
   uint64_t *hi, *lo;           // group key
   uint32_t *cnt, *ns, *poff;   // members, samples, first incidence (window-local)
   unsigned long long* rep;     // min (effend << 32 | record)
-  uint16_t *pfile, *pgl;       // incidence: sample, window-local group
+  uint32_t* pinc;              // incidence: sample | window-local group << 16
   uint32_t *wg_cnt, *wp_cnt;   // per window: groups, incidences
   uint32_t* wbase;             // [nw + 1] per window: record base (wg_rowsum_k)
   uint32_t* cslot;             // [compacted record] window base + number of the record's group inside the window ...
@@ -899,8 +899,7 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
         while (bits) {
           const uint32_t bpos = (uint32_t)__builtin_ctz(bits);
           bits &= bits - 1;
-          T.pfile[wbase + pl] = (uint16_t)(x * 32 + bpos);
-          T.pgl[wbase + pl] = (uint16_t)g;
+          T.pinc[wbase + pl] = (x * 32 + bpos) | (g << 16);
           ++pl;
           ++c;
         }
@@ -1139,8 +1138,7 @@ __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgRaw R, WgTemp T
             T.c2r[wbase + gl[u]] = wbase + gl[u];
           }
           if (fh) {
-            T.pfile[wbase + pl] = (uint16_t)fl[u];
-            T.pgl[wbase + pl] = (uint16_t)gl[u];
+            T.pinc[wbase + pl] = fl[u] | (gl[u] << 16);
             ++pl;
           }
           if (!RAW || R.all_slots || !((lo[ix[u]] >> 31) & 1ull)) T.cslot[srci[u]] = wbase + gl[u];
@@ -1243,8 +1241,9 @@ __global__ __launch_bounds__(64) void wg_compact_k(uint32_t nw, WgTemp T, const 
     if (F.slot2sg) F.slot2sg[wb + g] = sg;
   }
   for (uint32_t p = threadIdx.x; p < np; p += 64) {
-    F.pfile[pb + p] = T.pfile[wb + p];
-    F.pgrp[pb + p] = gb + T.pgl[wb + p];
+    const uint32_t pi = T.pinc[wb + p];
+    F.pfile[pb + p] = (uint16_t)pi;
+    F.pgrp[pb + p] = gb + (pi >> 16);
   }
 }
 __global__ void wg_tie_k(uint32_t ng, const uint64_t* __restrict__ ghi, const uint64_t* __restrict__ glo, uint8_t* __restrict__ tie) {
@@ -1352,8 +1351,7 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   T.ns = ws_alloc<uint32_t>(ctx, m);
   T.poff = ws_alloc<uint32_t>(ctx, m);
   T.rep = ws_alloc<unsigned long long>(ctx, m);
-  T.pfile = ws_alloc<uint16_t>(ctx, m);
-  T.pgl = ws_alloc<uint16_t>(ctx, m);
+  T.pinc = ws_alloc<uint32_t>(ctx, m);
   T.wg_cnt = ws_alloc<uint32_t>(ctx, nw);
   T.wp_cnt = ws_alloc<uint32_t>(ctx, nw);
   T.wbase = ws_alloc<uint32_t>(ctx, (size_t)nw + 1);
@@ -1366,7 +1364,7 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
     T.dbg = ws_alloc<unsigned long long>(ctx, 32);
     if (T.dbg) TBK_HIP(hipMemsetAsync(T.dbg, 0, 32 * 8, ctx->stream));
   }
-  if (!T.pgl || !pbase || !T.c2r) return TBK_ENOMEM;
+  if (!T.pinc || !pbase || !T.c2r) return TBK_ENOMEM;
   if (raw) TBK_HIP(hipMemsetAsync(T.cslot, 0xFF, (size_t)m * 4, ctx->stream));  // (only the records wg_finish_raw_k must visit get a slot)
   WgIn In{chi, clo, cval, ceff, off, W, k, nw};
   const uint32_t nwords = cdiv(k, 32);
