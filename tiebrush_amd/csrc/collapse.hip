@@ -124,7 +124,7 @@ struct EffStore {
   uint32_t* head_off;  // [file] compacted offset of the file's first record (files without records: untouched)
   uint32_t* ceff;      // optional (window path): effective end — or the explicit merge priority — in compacted order
   const uint64_t* prio;
-  __device__ __forceinline__ void operator()(uint32_t i, const EffKey& inc, const EffKey& ex) const {
+  __device__ __forceinline__ void operator()(uint32_t i, const EffKey&, const EffKey& inc, const EffKey& ex) const {
     if (kflags[i] & 2u) head_off[fidx[i]] = ex.flag_cnt & 0x7FFFFFFFu;
     if (kflags[i] & 1u) {
       uint64_t ik = ((uint64_t)inc.khi_h << 32) | inc.khi_l;
@@ -519,17 +519,38 @@ struct YdLoad {
 };
 struct YdStore {
   YdLoad L;
-  __device__ __forceinline__ void operator()(uint32_t t, const SegMaxY&, const SegMaxY& ex) const {
+  __device__ __forceinline__ void operator()(uint32_t t, const SegMaxY& v, const SegMaxY&, const SegMaxY& ex) const {
     // renewal: the read starts beyond every earlier end of this list => every node is cleared (processRead :230-241)
-    L.Y.chead[t] = (L.list_head(t) || L.Y.start(t) > ex.mx) ? 1u : 0u;
+    L.Y.chead[t] = (v.flag || L.Y.start(t) > ex.mx) ? 1u : 0u;
   }
 };
 
-__global__ void yd_chain_first_k(uint32_t nit, const uint32_t* __restrict__ chead, const uint32_t* __restrict__ cex,
-                                 uint32_t* __restrict__ chain_first) {
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < nit && chead[t]) chain_first[cex[t]] = t;
-}
+// chain heads and exon counts summed together; a head's exclusive sums are its chain's number and the first node of its arena
+struct HeadNex {
+  uint32_t h, n;
+};
+struct HeadNexOp {
+  __device__ __forceinline__ HeadNex operator()(const HeadNex& a, const HeadNex& b) const { return HeadNex{a.h + b.h, a.n + b.n}; }
+};
+struct HeadNexLoad {
+  const uint32_t *chead, *nex;
+  __device__ __forceinline__ HeadNex operator()(uint32_t t) const { return HeadNex{chead[t], nex[t]}; }
+};
+struct HeadNexStore {
+  uint32_t *chain_first, *chain_noff;
+  uint64_t* totals;  // [0] chains, [1] nodes
+  uint32_t nit;
+  __device__ __forceinline__ void operator()(uint32_t t, const HeadNex& v, const HeadNex& inc, const HeadNex& ex) const {
+    if (v.h) {
+      chain_first[ex.h] = t;
+      chain_noff[ex.h] = ex.n;
+    }
+    if (t + 1 == nit) {
+      totals[0] = inc.h;
+      totals[1] = inc.n;
+    }
+  }
+};
 
 constexpr uint32_t YD_LONG = 24;  // chains at least this long get a whole wave
 constexpr int YD_FAST_NODES = 12;   // the spliced-read fast path of yd_wave_k searches at most this many nodes per lane
@@ -638,7 +659,7 @@ __global__ void yd_run_k(const uint32_t* __restrict__ ids, const uint32_t* __res
   int32_t head = -1;
   uint32_t last_pos = 0;
   int last_dist = -1;
-  uint32_t alloc = noff[t0];
+  uint32_t alloc = noff[c];  // (per chain)
   for (uint32_t t = t0; t < t1; ++t) {
     const uint4 it = Y.pk[t];
     uint32_t rstart = it.y;
@@ -1076,7 +1097,6 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       Y.pk = ws_alloc<uint4>(ctx, nit);
       Y.nex = ws_alloc<uint32_t>(ctx, nit);
       Y.chead = ws_alloc<uint32_t>(ctx, nit);
-      uint32_t* cex = ws_alloc<uint32_t>(ctx, nit);
       uint32_t* noff = ws_alloc<uint32_t>(ctx, nit);
       uint32_t* chain_first = ws_alloc<uint32_t>(ctx, nit);
       if (!chain_first) return TBK_ENOMEM;
@@ -1108,9 +1128,11 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
         SegMaxY ident{INT32_MIN, 0u};
         TBK_TRY((scan_op_run<SegMaxY, SegMaxYOp, YdLoad, YdStore>(ctx, "yd_chain_scan", nit, ld, st, SegMaxYOp{}, ident)));
       }
-      TBK_TRY(tbk_exscan_u32(ctx, Y.chead, cex, nit, sc + 3));
-      TBK_TRY(tbk_exscan_u32(ctx, Y.nex, noff, nit, sc + 4));
-      TBK_LAUNCH(ctx, "yd_chain_first", yd_chain_first_k, cdiv(nit, B), B, 0, nit, Y.chead, cex, chain_first);
+      {  // chains numbered in item order, each with its first item and the first node of its arena
+        HeadNexLoad ld{Y.chead, Y.nex};
+        HeadNexStore st{chain_first, noff, sc + 3, nit};
+        TBK_TRY((scan_op_run<HeadNex, HeadNexOp, HeadNexLoad, HeadNexStore>(ctx, "yd_chain_number", nit, ld, st, HeadNexOp{}, HeadNex{0u, 0u})));
+      }
       TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
       TBK_HIP(hipStreamSynchronize(ctx->stream));
       const uint32_t nchains = (uint32_t)ctx->h_scalars[3];

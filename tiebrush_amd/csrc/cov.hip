@@ -149,7 +149,7 @@ struct BundleStore {
   uint32_t* bhead;
   int32_t* inclmax;
   uint32_t* err;
-  __device__ __forceinline__ void operator()(uint32_t j, const SegMax& inc, const SegMax& ex) const {
+  __device__ __forceinline__ void operator()(uint32_t j, const SegMax&, const SegMax& inc, const SegMax& ex) const {
     bool run_head = (j == 0 || tid[j] != tid[j - 1]);
     bool head = run_head || start[j] > ex.mx;  // tiecov.cpp:443
     if (!run_head && start[j] < start[j - 1]) atomicOr(err, TBK_DERR_UNSORTED);

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(SO_NT) void so_spine_k(T* __restrict__ part, uint32
   }
 }
 
-// store(i, inclusive, exclusive) with exclusive == op-prefix of everything before i (ident for i == 0)
+// store(i, element, inclusive, exclusive) with exclusive == op-prefix of everything before i (ident for i == 0)
 // INLINE: `part` holds the raw tile totals (no spine launch) and the block folds the ones before it, in order
 constexpr uint32_t SO_INLINE_NB = 2048;
 template <class T, class Op, class Load, class Store, bool INLINE>
@@ -125,11 +125,13 @@ __global__ __launch_bounds__(SO_NT) void so_down_k(uint32_t n, Load load, Store 
   __shared__ T sm[SO_NT / 64];
   __shared__ T wl[SO_NT / 64];
   const uint64_t base = (uint64_t)blockIdx.x * SO_TILE;
+  T mine[SO_E];  // the striped elements this thread loaded: kept for the store phase (the functor's loads are not repeated)
 #pragma unroll
   for (int e = 0; e < SO_E; ++e) {
     uint32_t j = (uint32_t)e * SO_NT + threadIdx.x;
     uint64_t i = base + j;
-    tile[so_pad(j)] = (i < n) ? load((uint32_t)i) : ident;
+    mine[e] = (i < n) ? load((uint32_t)i) : ident;
+    tile[so_pad(j)] = mine[e];
   }
   __syncthreads();
   T v[SO_E];
@@ -173,8 +175,7 @@ __global__ __launch_bounds__(SO_NT) void so_down_k(uint32_t n, Load load, Store 
     uint64_t i = base + j;
     if (i < n) {
       T exj = tile[so_pad(j)];
-      T vj = load((uint32_t)i);
-      store((uint32_t)i, op(exj, vj), exj);
+      store((uint32_t)i, mine[e], op(exj, mine[e]), exj);
     }
   }
 }

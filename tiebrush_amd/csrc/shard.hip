@@ -110,7 +110,7 @@ struct ShStore {
   int32_t* effend;
   int64_t* emax;
   uint32_t* err;
-  __device__ __forceinline__ void operator()(uint32_t i, const ShKey& inc, const ShKey&) const {
+  __device__ __forceinline__ void operator()(uint32_t i, const ShKey&, const ShKey& inc, const ShKey&) const {
     const uint64_t ik = ((uint64_t)inc.kh << 32) | inc.kl;
     if (ik != (uint64_t)key[i]) atomicOr(err, TBK_DERR_UNSORTED);  // an earlier record of the file has a larger (tid,start)
     effend[i] = inc.kend;
