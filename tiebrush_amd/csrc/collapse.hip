@@ -1155,6 +1155,9 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       TBK_HIP(hipStreamSynchronize(ctx->stream));
       const uint32_t* hc = (const uint32_t*)(ctx->h_scalars + 24);
       const uint32_t n_short = hc[0], n_long = hc[1];
+      if (getenv("TBK_YD_DEBUG"))
+        fprintf(stderr, "yd: %u groups, %u items, %u chains (%u short, %u long), %llu nodes\n", ng, nit, nchains, n_short, n_long,
+                (unsigned long long)nnodes);
       // short chains (a thread each) and long chains (a wave each) are independent: the short ones go to the auxiliary
       // stream and fill the CUs the few long, latency-bound waves leave idle.  (The stream was synchronised just above,
       // so the fork needs no event; the join does.)

@@ -8,8 +8,11 @@ import csv, json, re, sys, collections
 
 ALIAS = {  # kernel symbol stem -> the name bench.py reports (TBK_LAUNCH name) where the two differ
     "yd_fill_w": "yd_fill", "yd_gcount_w": "yd_gcount", "w64_scatter": "rx_scatter", "col_recgroup_w": "col_recgroup",
+    "wg_offsets_stream": "wg_offsets", "wg_offsets_edges": "wg_offsets_edges", "wg_finish_raw": "wg_finish", "wg_sample_raw": "wg_sample",
+    "w64_emit_flat": "yd_scatter",
 }
-SCAN = {"EffKey": "col_effkey_scan", "SegMaxY": "yd_chain_scan", "SegMax": "cov_bundle_scan", "ShKey": "shard_eff_scan"}
+SCAN = {"EffKey": "col_effkey_scan", "SegMaxY": "yd_chain_scan", "SegMax": "cov_bundle_scan", "ShKey": "shard_eff_scan",
+        "HeadNex": "yd_chain_number"}
 
 
 def bench_name(sym):
@@ -18,8 +21,10 @@ def bench_name(sym):
         return None
     stem = m.group(1)
     if stem in ("so_reduce", "so_spine", "so_down"):
-        t = re.search(r"::(EffKey|SegMaxY|SegMax|ShKey)\b", sym)
+        t = re.search(r"::(EffKey|SegMaxY|SegMax|ShKey|HeadNex)\b", sym)
         return SCAN.get(t.group(1)) if t else stem
+    if stem == "w64_scatter" and "YdEmit" in sym:
+        return "yd_scatter"
     return ALIAS.get(stem, stem)
 
 
