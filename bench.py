@@ -246,6 +246,7 @@ def main():
             ctx.finish_yd()
             take("collapse")               # the deferred YD stage belongs to tbk_collapse_tile
             view = ctx.groups_to_cov_in(gg)
+            take("chain")                  # tiebrush -> tiecov device chain (representatives gathered into tiecov's input view)
             cc = ctx.coverage(view, out=vbufs, raw=True)
             take("coverage")
         ctx.set_profiling(False)

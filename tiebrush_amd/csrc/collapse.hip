@@ -1633,30 +1633,33 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
 
 // ---- tiebrush -> tiecov device chain -----------------------------------------------------------------------
 namespace {
-__global__ void g2c_count_k(uint32_t ng, const uint32_t* __restrict__ rep, const uint32_t* __restrict__ cig_off, uint32_t* __restrict__ cnt) {
+__global__ void g2c_count_k(uint32_t ng, const uint32_t* __restrict__ rep, const uint32_t* __restrict__ cig_off, uint32_t* __restrict__ cnt,
+                            uint32_t* __restrict__ cfirst) {
   uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o < ng) cnt[o] = cig_off[rep[o] + 1] - cig_off[rep[o]];
+  if (o >= ng) return;
+  const uint32_t c0 = cig_off[rep[o]];
+  cnt[o] = cig_off[rep[o] + 1] - c0;
+  cfirst[o] = c0;  // (the gather pass reads the CIGAR range from here: one scattered access fewer per representative)
 }
 __global__ void g2c_gather_k(uint32_t ng, const uint32_t* __restrict__ rep, const double* __restrict__ yc, const int64_t* __restrict__ yx,
-                             const int32_t* __restrict__ tid, const int32_t* __restrict__ pos, const uint16_t* __restrict__ flag,
-                             const uint8_t* __restrict__ strand, const uint32_t* __restrict__ cig_off, const uint32_t* __restrict__ cig,
+                             const int32_t* __restrict__ tid, const int32_t* __restrict__ pos, const uint8_t* __restrict__ strand,
+                             const uint32_t* __restrict__ cfirst, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cig,
                              const uint32_t* __restrict__ ooff, uint32_t total, int32_t* __restrict__ o_tid, int32_t* __restrict__ o_pos,
-                             uint16_t* __restrict__ o_flag, uint8_t* __restrict__ o_strand, double* __restrict__ o_yc,
-                             int64_t* __restrict__ o_yx, uint32_t* __restrict__ o_cig_off, uint32_t* __restrict__ o_cig) {
+                             uint8_t* __restrict__ o_strand, double* __restrict__ o_yc, int64_t* __restrict__ o_yx,
+                             uint32_t* __restrict__ o_cig_off, uint32_t* __restrict__ o_cig) {
   uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= ng) return;
   uint32_t r = rep[o];
   o_tid[o] = tid[r];
   o_pos[o] = pos[r];
-  o_flag[o] = flag[r];
   o_strand[o] = strand[r];
   o_yc[o] = (double)(float)yc[o];  // the YC:f tag round trip (bam_aux_update_float, tiebrush.cpp:509)
   o_yx[o] = yx[o];
   uint32_t d = ooff[o];
   o_cig_off[o] = d;
   if (o + 1 == ng) o_cig_off[ng] = total;
-  uint32_t c0 = cig_off[r], c1 = cig_off[r + 1];
-  for (uint32_t k = c0; k < c1; ++k) o_cig[d + (k - c0)] = cig[k];
+  const uint32_t c0 = cfirst[o], n = cnt[o];
+  for (uint32_t k = 0; k < n; ++k) o_cig[d + k] = cig[c0 + k];
 }
 }  // namespace
 
@@ -1667,20 +1670,26 @@ extern "C" int tbk_groups_to_cov_in(tbk_ctx* ctx, const tbk_soa_in* in, const tb
   const uint32_t ng = g->n_groups;
   memset(view, 0, sizeof(*view));
   view->mem = TBK_MEM_DEVICE;
+  tbk_prof_begin_call(ctx);
+  struct ProfEnd {
+    tbk_ctx* c;
+    ~ProfEnd() { tbk_prof_end_call(c); }
+  } prof_end{ctx};
   if (ng == 0) return 0;
-  TBK_TRY(tbk_ws_reserve(ctx, (size_t)ng * 16 + ((size_t)1 << 20)));
+  TBK_TRY(tbk_ws_reserve(ctx, (size_t)ng * 24 + ((size_t)1 << 20)));
   uint32_t* cnt = ws_alloc<uint32_t>(ctx, ng);
   uint32_t* ooff = ws_alloc<uint32_t>(ctx, ng);
-  if (!ooff) return TBK_ENOMEM;
+  uint32_t* cfirst = ws_alloc<uint32_t>(ctx, ng);
+  if (!cfirst) return TBK_ENOMEM;
   const uint32_t B = 256;
-  TBK_LAUNCH(ctx, "g2c_count", g2c_count_k, cdiv(ng, B), B, 0, ng, g->rep, in->cig_off, cnt);
+  TBK_LAUNCH(ctx, "g2c_count", g2c_count_k, cdiv(ng, B), B, 0, ng, g->rep, in->cig_off, cnt, cfirst);
   TBK_TRY(tbk_exscan_u32(ctx, cnt, ooff, ng, ctx->d_scalars + 20));
   TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 20, ctx->d_scalars + 20, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   TBK_HIP(hipStreamSynchronize(ctx->stream));
   const uint64_t total = ctx->h_scalars[20];
   if (total >= (1ull << 32)) return TBK_E2BIG;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  size_t need = al((size_t)ng * 4) * 2 + al((size_t)ng * 2) + al(ng) + al((size_t)ng * 8) * 2 + al((size_t)(ng + 1) * 4) + al((size_t)total * 4 + 4);
+  size_t need = al((size_t)ng * 4) * 2 + al(ng) + al((size_t)ng * 8) * 2 + al((size_t)(ng + 1) * 4) + al((size_t)total * 4 + 4);
   if (need > ctx->d_view_cap) {
     if (ctx->d_view) (void)hipFree(ctx->d_view);
     ctx->d_view = nullptr;
@@ -1697,21 +1706,20 @@ extern "C" int tbk_groups_to_cov_in(tbk_ctx* ctx, const tbk_soa_in* in, const tb
   };
   int32_t* o_tid = (int32_t*)take((size_t)ng * 4);
   int32_t* o_pos = (int32_t*)take((size_t)ng * 4);
-  uint16_t* o_flag = (uint16_t*)take((size_t)ng * 2);
   uint8_t* o_strand = (uint8_t*)take(ng);
   double* o_yc = (double*)take((size_t)ng * 8);
   int64_t* o_yx = (int64_t*)take((size_t)ng * 8);
   uint32_t* o_cig_off = (uint32_t*)take((size_t)(ng + 1) * 4);
   uint32_t* o_cig = (uint32_t*)take((size_t)total * 4 + 4);
-  TBK_LAUNCH(ctx, "g2c_gather", g2c_gather_k, cdiv(ng, B), B, 0, ng, g->rep, g->yc, g->yx, in->tid, in->pos, in->flag, in->strand,
-             in->cig_off, in->cig, ooff, (uint32_t)total, o_tid, o_pos, o_flag, o_strand, o_yc, o_yx, o_cig_off, o_cig);
+  TBK_LAUNCH(ctx, "g2c_gather", g2c_gather_k, cdiv(ng, B), B, 0, ng, g->rep, g->yc, g->yx, in->tid, in->pos, in->strand, cfirst, cnt,
+             in->cig, ooff, (uint32_t)total, o_tid, o_pos, o_strand, o_yc, o_yx, o_cig_off, o_cig);
   TBK_HIP(hipStreamSynchronize(ctx->stream));
   TBK_TRY(tbk_check_launch(ctx, "groups_to_cov_in"));
   view->n_records = ng;
   view->n_cigar_ops = (uint32_t)total;
   view->tid = o_tid;
   view->pos = o_pos;
-  view->flag = nullptr;  // every representative counts: tbk_coverage_tile skips its validity pass (o_flag stays available below)
+  view->flag = nullptr;  // every representative counts: tbk_coverage_tile skips its validity pass
   view->cig_off = o_cig_off;
   view->cig = o_cig;
   view->yc = o_yc;
