@@ -195,3 +195,44 @@ def test_cli_streams_many_inputs_with_few_descriptors_and_small_tiles(tmp_path):
     assert np.array_equal(out.pos, tile.pos[rep]) and np.array_equal(out.tid, tile.tid[rep])
     assert np.array_equal(out.yc.astype(np.float64), flat["yc"].astype(np.float32).astype(np.float64))
     assert np.array_equal(out.yx, flat["yx"]) and np.array_equal(out.yd, flat["yd"])
+
+
+def test_tiecov_bigwig_output(tmp_path):
+    """tiecov -W (tiecov.cpp:243-275, :365-402): the coverage goes to PREFIX.bigwig; read back with the tests' own bigWig
+    parser it holds the intervals of the golden bedGraph (values as float32), junctions still go to the BED file"""
+    from bigwig_reader import BigWig
+    pre = str(tmp_path / "t1")
+    _run([os.path.join(BIN, "tiecov"), "-W", "-c", pre + ".coverage", "-j", pre + ".junctions", os.path.join(GOLDEN, "t1", "t1.bam")])
+    assert not os.path.exists(pre + ".coverage.bedgraph")
+    want = []
+    for ln in read_lines(os.path.join(GOLDEN, "t1", "t1.coverage.bedgraph"))[1:]:
+        c, a, b, v = ln.split("\t")
+        want.append((c, int(a), int(b), float(np.float32(float(v)))))
+    bw = BigWig(pre + ".coverage.bigwig")
+    assert bw.intervals() == want
+    assert bw.summary[0] == sum(b - a for _, a, b, _ in want) and bw.n_zoom >= 1
+    assert len(read_lines(pre + ".junctions.bed")) == len(read_lines(os.path.join(GOLDEN, "t1", "t1.junctions.bed")))
+
+
+def test_sam_text_inputs(tmp_path):
+    """SAM inputs (GSam.h:371-401 opens them like BAM): the ten t2 samples as SAM text give the golden t2.bam, the collapsed
+    file as SAM text gives the golden tracks; a single SAM argument is an input, not a list of paths"""
+    from samtext import bam_to_sam_text
+    sams = []
+    for i, p in enumerate(sample_paths("t2")):
+        s = tmp_path / ("t2s%d.sam" % i)
+        s.write_text(bam_to_sam_text(p)[0])
+        sams.append(str(s))
+    out = str(tmp_path / "o.bam")
+    _run([os.path.join(BIN, "tiebrush"), "-A", "-o", out] + sams)
+    _compare_bam(out, os.path.join(GOLDEN, "t2", "t2.bam"))
+    one = str(tmp_path / "one.bam")
+    _run([os.path.join(BIN, "tiebrush"), "-o", one, sams[0]])
+    from tiebrush_amd import bamio
+    assert bamio.read_bam(one).n > 0
+    csam = tmp_path / "t2.sam"
+    csam.write_text(bam_to_sam_text(os.path.join(GOLDEN, "t2", "t2.bam"))[0])
+    pre = str(tmp_path / "t2")
+    _run([os.path.join(BIN, "tiecov"), "-c", pre + ".coverage", str(csam)])
+    got = [l[:-4] if l.endswith(".000") else l for l in read_lines(pre + ".coverage.bedgraph")]
+    assert got == read_lines(os.path.join(GOLDEN, "t2", "t2.coverage.bedgraph"))

@@ -1,4 +1,5 @@
 #include "GSam.h"
+#include "sam.h"
 
 #include <stdlib.h>
 
@@ -110,7 +111,9 @@ void GSamReader::bopen(const char* filename, int32_t, const char*, int inflate_t
   fname_ = filename;
   f_ = std::make_shared<tbh::BamFile>();
   std::string err;
-  if (!tbh::bgzf_probe(fname_)) GError("Error: could not open alignment file %s (only BAM input is supported)\n", filename);
+  if (tbh::cram_probe(fname_)) GError("Error: could not open alignment file %s (CRAM input is not supported by this build)\n", filename);
+  if (!tbh::bgzf_probe(fname_) && !tbh::sam_probe(fname_))
+    GError("Error: could not open alignment file %s (neither BAM nor SAM)\n", filename);
   threads_ = inflate_threads < 1 ? 1 : inflate_threads;
   // header only: records are inflated on demand (GSamReader::next / TInputFiles::next_tile), the window slides
   if (!f_->open(fname_, err, threads_)) GError("Error: could not open alignment file %s (%s)\n", filename, err.c_str());

@@ -1,4 +1,5 @@
 #include "bam.h"
+#include "sam.h"
 
 #include <stdio.h>
 #include <string.h>
@@ -437,6 +438,14 @@ bool BamFile::fill(size_t min_records, std::string& err, int threads, size_t chu
   const size_t kFillBytes = chunk_bytes < ((size_t)128 << 10) ? ((size_t)128 << 10) : chunk_bytes;  // compressed bytes per read (>= 2 members)
   std::vector<uint8_t> raw;
   bool first = true;
+  if (file_pos_ == 0 && !eof_ && !header_done_ && !bgzf_probe(path) && sam_probe(path)) {
+    // SAM text: converted whole into the byte stream a BAM file inflates to (sam.cpp); no window — the file is in memory
+    std::vector<uint8_t> all;
+    if (!sam_to_bam(path, all, err)) return false;
+    data.insert(data.end(), all.begin(), all.end());
+    eof_ = true;
+    return index_records(err);
+  }
   while (first || (rec_off.size() < min_records && !eof_) || (!header_done_ && !eof_)) {
     first = false;
     if (eof_) break;

@@ -11,6 +11,7 @@
 
 #include "GSam.h"
 #include "tmerge.h"
+#include "bigwig.h"
 
 template <class T>
 static void dump(const std::string& dir, const char* name, const std::vector<T>& v) {
@@ -107,6 +108,39 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
-  fprintf(stderr, "usage: tbh_tool cat|mergeorder|soa|tiles|tags ...\n");
+  if (cmd == "bedgraph2bw" && argc == 5) {  // <alignment file: the chromosome list> <in.bedgraph> <out.bigwig>
+    GSamReader rd(argv[2]);
+    sam_hdr_t* hdr = rd.header();
+    std::vector<std::string> names;
+    std::vector<uint32_t> lens;
+    for (int t = 0; t < hdr->n_targets; ++t) {
+      names.push_back(hdr->target_name[t]);
+      lens.push_back(hdr->target_len[t]);
+    }
+    tbh::BigWigWriter bw;
+    std::string err;
+    if (!bw.open(argv[4], names, lens, err)) {
+      fprintf(stderr, "%s\n", err.c_str());
+      return 1;
+    }
+    FILE* f = fopen(argv[3], "r");
+    if (!f) return 1;
+    char line[4096], chrom[2048];
+    while (fgets(line, sizeof(line), f)) {
+      unsigned long a, b;
+      double v;
+      if (sscanf(line, "%2047s %lu %lu %lf", chrom, &a, &b, &v) != 4) continue;  // (track line)
+      int tid = hdr->name2tid(chrom);
+      if (tid < 0) return 1;
+      bw.add((uint32_t)tid, (uint32_t)a, (uint32_t)b, (float)v);
+    }
+    fclose(f);
+    if (!bw.close(err)) {
+      fprintf(stderr, "%s\n", err.c_str());
+      return 1;
+    }
+    return 0;
+  }
+  fprintf(stderr, "usage: tbh_tool cat|mergeorder|soa|tiles|tags|bedgraph2bw ...\n");
   return 2;
 }

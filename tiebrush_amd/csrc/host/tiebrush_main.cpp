@@ -198,7 +198,9 @@ int main(int argc, char* argv[]) {
         total += fsz[f];
       }
       const uint64_t lim = getenv("TBK_DEVICE_DECODE_MAX") ? (uint64_t)atoll(getenv("TBK_DEVICE_DECODE_MAX")) : ((uint64_t)6 << 30);
-      if (want && total > 0 && total <= lim) {
+      bool all_bam = true;  // (SAM text inputs are decoded by the host)
+      for (size_t f = 0; f < k; ++f) all_bam = all_bam && tbh::bgzf_probe(inRecords.freaders[f]->fname);
+      if (want && all_bam && total > 0 && total <= lim) {
         auto t0 = tnow();
         std::vector<std::vector<uint8_t>> comp(k);
         {

@@ -12,6 +12,7 @@
 
 #include "../../../include/tbk.h"
 #include "GSam.h"
+#include "bigwig.h"
 #include "args.h"
 
 #define VERSION "0.0.7"
@@ -27,7 +28,7 @@ static const char* USAGE =
     "  -c PREFIX    per-base coverage as bedGraph (the YC tag weighs each alignment)\n"
     "  -j PREFIX    splice junctions as BED\n"
     "  -s PREFIX    estimated number of samples per position as bedGraph (needs @CO SAMPLE: header lines)\n"
-    "  -W           BigWig output (not available in this build)\n"
+    "  -W           write the coverage (-c) as a bigWig file (PREFIX.bigwig) instead of a bedGraph\n"
     " At least one of -c / -j / -s is required.\n";
 
 static bool ends_with(const std::string& s, const char* suf) {
@@ -89,7 +90,7 @@ int main(int argc, char* argv[]) {
     GMessage("\nError: at least one of -c/-j/-s arguments required!\n");
     return 1;
   }
-  if (args.getOpt('W')) GError("Error: BigWig output (-W) is not available in this build\n");
+  const bool bigwig = args.getOpt('W') != nullptr;
   if (args.getOpt("verbose") || args.getOpt('V')) {
     fprintf(stderr, "Running TieCov " VERSION ". Command line:\n");
     args.printCmdLine(stderr);
@@ -106,9 +107,22 @@ int main(int argc, char* argv[]) {
   GSamReader samreader(infname.c_str(), SAM_QNAME | SAM_FLAG | SAM_RNAME | SAM_POS | SAM_CIGAR | SAM_AUX);
   sam_hdr_t* hdr = samreader.header();
   FILE *coutf = nullptr, *joutf = nullptr, *soutf = nullptr;
+  tbh::BigWigWriter bw;
+  bool cov_bw = false;
   if (!covfname.empty()) {
     if (covfname == "-" || covfname == "stdout") {
       coutf = stdout;
+    } else if (bigwig) {  // tiecov.cpp:365-402
+      if (!ends_with(covfname, ".bigwig")) covfname += ".bigwig";
+      std::vector<std::string> names;
+      std::vector<uint32_t> lens;
+      for (int t = 0; t < hdr->n_targets; ++t) {
+        names.push_back(hdr->target_name[t]);
+        lens.push_back(hdr->target_len[t]);
+      }
+      std::string err;
+      if (!bw.open(covfname, names, lens, err)) GError("Error creating file %s\n", covfname.c_str());
+      cov_bw = true;
     } else {
       if (!ends_with(covfname, ".bedgraph")) covfname += ".bedgraph";
       coutf = fopen(covfname.c_str(), "w");
@@ -204,8 +218,8 @@ int main(int argc, char* argv[]) {
   in.yc = yc.data();
   in.strand = strand.data();
   in.yx = yx.data();
-  if (coutf || joutf) {
-    size_t ci = coutf ? 2 * (size_t)co + 2 * n + 16 : 0, cj = joutf ? (size_t)co + 16 : 0;
+  if (coutf || cov_bw || joutf) {
+    size_t ci = (coutf || cov_bw) ? 2 * (size_t)co + 2 * n + 16 : 0, cj = joutf ? (size_t)co + 16 : 0;
     std::vector<int32_t> it(ci ? ci : 1), is(ci ? ci : 1), ie(ci ? ci : 1), jt(cj ? cj : 1), js(cj ? cj : 1), je(cj ? cj : 1);
     std::vector<double> iv(ci ? ci : 1), jv(cj ? cj : 1);
     std::vector<uint8_t> jstr(cj ? cj : 1);
@@ -230,6 +244,11 @@ int main(int argc, char* argv[]) {
       emit_lines(coutf, o.n_intervals, [&](uint32_t i, char* b, size_t cap) {
         return snprintf(b, cap, "%s\t%d\t%d\t%.3f\n", hdr->target_name[it[i]].c_str(), is[i], ie[i], iv[i]);
       });
+    if (cov_bw) {  // flushCoverage(bigWigFile_t*), tiecov.cpp:243-275: the same intervals, the value as a float
+      for (uint32_t i = 0; i < o.n_intervals; ++i) bw.add((uint32_t)it[i], (uint32_t)is[i], (uint32_t)ie[i], (float)iv[i]);
+      std::string err;
+      if (!bw.close(err)) GError("Error: writing %s failed (%s)\n", covfname.c_str(), err.c_str());
+    }
     if (joutf)  // CJunc::write, tiecov.cpp:91-95
       emit_lines(joutf, o.n_junctions, [&](uint32_t i, char* b, size_t cap) {
         return snprintf(b, cap, "%s\t%d\t%d\tJUNC%08d\t%.3f\t%c\n", hdr->target_name[jt[i]].c_str(), js[i], je[i], (int)i + 1, jv[i],

@@ -1,4 +1,5 @@
 #include "tmerge.h"
+#include "sam.h"
 
 #include <limits.h>
 #include <stdlib.h>
@@ -181,8 +182,8 @@ static void sorted_insert(std::vector<TInputRecord*>& recs, TInputRecord* r) {  
 }
 
 int TInputFiles::start() {  // tmerge.cpp:287-329
-  if (freaders.size() == 1 && !tbh::bgzf_probe(freaders[0]->fname)) {
-    // a single non-BAM argument is a list of paths
+  if (freaders.size() == 1 && !tbh::bgzf_probe(freaders[0]->fname) && !tbh::sam_probe(freaders[0]->fname)) {
+    // a single argument that is neither BAM nor SAM is a list of paths
     std::string lst = freaders[0]->fname;
     FILE* f = fopen(lst.c_str(), "r");
     if (!f) GError("Error: could not open input file %s!\n", lst.c_str());
