@@ -91,6 +91,16 @@ def test_pileup_effective_ends(ctx, window_mode):
     _cmp(ctx, tile, strategy="clip", keep_secondary=True)
 
 
+def test_nothing_passes(ctx, window_mode):
+    """every record filtered (the raw form only learns that after its window kernels have run), an empty file among the inputs"""
+    from tiebrush_amd import synth
+    tile = synth.make_tile(3, 4000, "c3", n_loci=30)
+    _cmp(ctx, tile, min_qual=200)
+    recs = [(0, 100, 0, 60, "+", 1, [(50, M)]), (0, 120, 0, 60, "+", 1, [(30, M)])]
+    _cmp(ctx, _tile([recs, [], recs]))
+    _cmp(ctx, _tile([[], recs]))
+
+
 def test_unmapped_mates_inside_a_run(ctx, window_mode):
     """an unmapped read placed at its mate's position sits inside a run of equal starts: it neither splits the run nor
     contributes an end"""

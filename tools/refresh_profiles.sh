@@ -17,3 +17,8 @@ rm -rf $O/pw
 python3 tools/build_traffic.py $O/pmc_fetch_size.csv $O/pmc_write_size.csv $O/traffic.json "c3: 64 files x 5000000 reads, --clip + tiecov"
 python3 bench.py > $O/bench_default.json 2> $O/bench.err
 tail -c 600 $O/bench_under_rocprof.json; echo; ls -la $O
+# the same kernels with the GPU to themselves (one context, the profiling steps of bench.py are serialised calls): the averages
+# of this pass are the ones bench.py's roofline objects quote from HIP events
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kss -o kss -- python3 bench.py --contexts 1 --steps 1 --warmup 0 --prof-steps 6 $COMMON > $O/bench_serial_under_rocprof.json 2> $O/kss.err
+cp $(find $O/kss -name "*kernel_stats.csv" | head -1) $O/kernel_stats_serial.csv
+rm -rf $O/kss
