@@ -50,6 +50,26 @@ static const char* USAGE =
     "  --store-frac         YC adds 1/NH per alignment (needs --keep-secondary)\n"
     "  -V,--verbose         echo the command line\n";
 
+// a buffer that is allocated, not initialised (malloc: untouched pages cost nothing)
+template <class T>
+struct RawBuf {
+  T* p = nullptr;
+  size_t cap = 0, len = 0;
+  ~RawBuf() { free(p); }
+  void resize(size_t n) {
+    if (n > cap) {
+      free(p);
+      p = (T*)malloc(n * sizeof(T));
+      if (!p) GError("Error: out of memory\n");
+      cap = n;
+    }
+    len = n;
+  }
+  T* data() { return p; }
+  size_t size() const { return len; }
+  T& operator[](size_t i) { return p[i]; }
+};
+
 int main(int argc, char* argv[]) {
   TInputFiles inRecords;
   inRecords.setup(VERSION, argc, argv);
@@ -138,10 +158,12 @@ int main(int argc, char* argv[]) {
   {
     GSamWriter outfile(outfname, inRecords.header(), GSamFile_BAM);
     TbkTile tile;
-    std::vector<uint32_t> rep;
-    std::vector<double> yc;
-    std::vector<int64_t> yx;
-    std::vector<int32_t> yd;
+    // output arrays sized by the upper bound (one group per record) but never initialised: the pages a call does not write
+    // are never touched (a value-initialising resize of 32 M entries x 24 B costs more than the collapse itself)
+    RawBuf<uint32_t> rep;
+    RawBuf<double> yc;
+    RawBuf<int64_t> yx;
+    RawBuf<int32_t> yd;
     TInputFiles::TilePlan plan;
     size_t n_tiles = 0;
     std::function<tbh::RecView(uint32_t)> get_record = [&](uint32_t g) { return inRecords.record(rep[g]); };
@@ -254,8 +276,10 @@ int main(int argc, char* argv[]) {
           auto t_col = tnow();
           if (rc == TBK_EUNSORTED) GError("Error: an input file is not coordinate-sorted!\n");
           if (rc != 0) GError("Error: GPU collapse failed: %s (%s)\n", tbk_strerror(rc), tbk_last_error(ctx));
-          std::vector<uint64_t> roff((size_t)out.n_groups + 1, 0);
-          std::vector<uint8_t> blob((size_t)out.n_groups * 96 + 4096);
+          RawBuf<uint64_t> roff;
+          roff.resize((size_t)out.n_groups + 1);
+          RawBuf<uint8_t> blob;
+          blob.resize((size_t)out.n_groups * 96 + 4096);
           rc = tbk_bam_records(ctx, rep.data(), out.n_groups, TBK_MEM_HOST, blob.data(), blob.size(), roff.data());
           if (rc == TBK_E2BIG) {
             blob.resize(roff[out.n_groups]);
