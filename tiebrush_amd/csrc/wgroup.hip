@@ -275,6 +275,7 @@ struct WgRaw {                 // raw mode: the window kernels read the records 
   ColIn I;
   ColOpt O;
   unsigned long long* n_pass;  // passing records (one atomic per block)
+  unsigned long long* n_slots; // records that left a slot in cslot (0: wg_finish_raw_k has nothing to do)
   uint32_t all_slots;          // 1: every passing record leaves its group slot in cslot (record -> group map wanted); 0: only the
                                // records whose key word is not exact (they are verified by wg_finish_raw_k)
 };
@@ -657,6 +658,7 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
       s_misc[0] = 0;  // distinct groups
       s_misc[1] = 0;  // overflow
       s_misc[2] = 0;  // RAW: passing records
+      s_misc[3] = 0;  // RAW: records that left a slot for the verification pass
       s_misc[4] = 0;  // RAW: carry of the effective-end scan into chunk 0 ...
       s_misc[5] = 0;  // ... and into chunk 1 (alternating)
     }
@@ -676,7 +678,7 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
   }
   __syncthreads();
   phase(0);
-  uint32_t npass_t = 0, par = 0;
+  uint32_t npass_t = 0, nslot_t = 0, par = 0;
   // the window streams through in chunks of WG_NT * NR records: NR records per thread so that their loads and probes
   // overlap; two barriers per chunk
   for (uint32_t c0 = 0; c0 < n_w; c0 += WG_NT * NR) {
@@ -826,7 +828,10 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
       if (act) {
         const uint32_t s = slot[u];
         if (thi[s] != kh[u] || tlo[s] != kl[u]) atomicOr(err, TBK_DERR_COLLISION);  // two keys, one fingerprint
-        if (!RAW || R.all_slots || !((kl[u] >> 31) & 1ull)) T.cslot[src[u]] = wbase + tci[s];
+        if (!RAW || R.all_slots || !((kl[u] >> 31) & 1ull)) {
+          T.cslot[src[u]] = wbase + tci[s];
+          ++nslot_t;
+        }
         const unsigned long long rr = ((unsigned long long)eff[u] << 32) | rec[u];
         if (rr < trep[s]) atomicMin(&trep[s], rr);
         const uint32_t bi = s * nwords + (fil[u] >> 5), bm = 1u << (fil[u] & 31);
@@ -882,9 +887,12 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
     if constexpr (RAW) {
       const uint32_t ws = wave_sum(npass_t);
       if (lane_id() == 0 && ws) atomicAdd(&s_misc[2], ws);
+      const uint32_t wl = wave_sum(nslot_t);
+      if (lane_id() == 0 && wl) atomicAdd(&s_misc[3], wl);
     }
     __syncthreads();
     if (RAW && t == 0 && s_misc[2]) atomicAdd(R.n_pass, (unsigned long long)s_misc[2]);
+    if (RAW && t == 0 && s_misc[3]) atomicAdd(R.n_slots, (unsigned long long)s_misc[3]);
     for (uint32_t g = t; g < d; g += WG_NT) {
       const uint32_t s = byrank[g];
       T.hi[wbase + g] = thi[s];
@@ -1141,7 +1149,10 @@ __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgRaw R, WgTemp T
             T.pinc[wbase + pl] = fl[u] | (gl[u] << 16);
             ++pl;
           }
-          if (!RAW || R.all_slots || !((lo[ix[u]] >> 31) & 1ull)) T.cslot[srci[u]] = wbase + gl[u];
+          if (!RAW || R.all_slots || !((lo[ix[u]] >> 31) & 1ull)) {
+            T.cslot[srci[u]] = wbase + gl[u];
+            if (RAW) atomicAdd(R.n_slots, 1ull);  // (the rare tier: no aggregation)
+          }
         }
       }
     }
@@ -1304,6 +1315,7 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
     R.O.seed = seed;
     R.n_pass = (unsigned long long*)(ctx->d_scalars + 0);
     R.all_slots = want_rec_sg ? 1u : 0u;
+    R.n_slots = (unsigned long long*)(ctx->d_scalars + 6);
     scratch_hi = ws_alloc<uint64_t>(ctx, m);
     scratch_lo = ws_alloc<uint64_t>(ctx, m);
     if (!scratch_lo) return TBK_ENOMEM;
@@ -1492,9 +1504,10 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
     TBK_LAUNCH(ctx, "wg_compact", wg_compact_k, nw, 64, 0, nw, T, gbase, pbase, F);
     TBK_LAUNCH(ctx, "wg_tie", wg_tie_k, cdiv(ng, B), B, 0, ng, out->ghi, out->glo, out->tie);
     if (want_rec_sg) TBK_HIP(hipMemsetAsync(out->rec_sg, 0xFF, (size_t)I.n * 4, ctx->stream));  // (records that did not pass)
-    if (raw)
-      TBK_LAUNCH(ctx, "wg_finish", wg_finish_raw_k, cdiv(m, B), B, 0, m, T.cslot, T.c2r, T.rep, slot2sg, out->rec_sg, I, strategy, ctx->d_err);
-    else
+    if (raw) {  // (nothing to verify and no record -> group map wanted: every key word was exact)
+      if (ctx->h_scalars[6] != 0)
+        TBK_LAUNCH(ctx, "wg_finish", wg_finish_raw_k, cdiv(m, B), B, 0, m, T.cslot, T.c2r, T.rep, slot2sg, out->rec_sg, I, strategy, ctx->d_err);
+    } else
       TBK_LAUNCH(ctx, "wg_finish", wg_finish_k, cdiv(m, B), B, 0, m, clo, cval, T.cslot, T.c2r, T.rep, slot2sg, out->rec_sg, I, strategy,
                  ctx->d_err);
   }

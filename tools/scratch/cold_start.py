@@ -1,5 +1,5 @@
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tiebrush_amd import api, synth_dev
 t0=time.perf_counter(); d=synth_dev.make_tile_device(32, 1000000, "c2", device="cuda:0"); torch.cuda.synchronize(); print("gen", time.perf_counter()-t0)
