@@ -1,32 +1,35 @@
-// wgroup.hip — the "window path" of the collapse stage on gfx950: from the k position-sorted runs of passing records
-// straight to the collapsed groups, without ever sorting the records themselves.
+// wgroup.hip — the "window path" of the collapse stage on gfx950: from the k position-sorted input files straight to the
+// collapsed groups, every record read once, nothing sorted.
 //
 // What it replaces (reference: /root/reference/src/tiebrush.cpp:477-499 addPData — find-or-insert of a read into the
-// sorted group list of its (tid,start) bucket — and tmerge.cpp:331-344, the k-way merge that feeds it): on the GPU the
-// sort path (collapse.hip + msort.hip) orders all m records by the 128-bit key and derives the groups from adjacent
-// records.  Deep data makes that wasteful: config 3 collapses 320 M records into 25 M groups, and a pile-up of 10^5 reads
-// on one base is sorted only to find its few dozen distinct alignments.
+// sorted group list of its (tid,start) bucket — tiebrush.cpp:532-541 passes_options, and tmerge.cpp:331-344, the k-way merge
+// that feeds them): the sort path (collapse.hip + msort.hip) computes a key per record, scans the merge priority, compacts,
+// orders all m records by the 128-bit key and derives the groups from adjacent records.  Deep data makes that wasteful: config 3
+// collapses 320 M records into 25 M groups, and a pile-up of 10^5 reads on one base is sorted only to find its few dozen
+// distinct alignments.
 //
-// Here the coordinate axis is cut into windows by splitters chosen from a sample of the runs (every s-th record; every
-// g-th sorted sample is a splitter; a splitter value that repeats — a pile-up — gets a window of its own).  Each run
-// contributes one contiguous piece to a window, found by a galloping search, so a window's records are k coalesced
-// reads.  One workgroup per window:
-//   * at most WG_CAP records (every window except pile-ups, by construction < 2T + k s): the records are staged in LDS,
-//     an index permutation is merge-sorted by (key, load order = file-major record order) with branch-free bisections,
-//     and groups, per-group counts, sample counts and the representative (arg-min of (effective end, record index)) come
-//     from wave-segmented reductions over the sorted order;
-//   * a pile-up (one (tid,start), any number of records): the records stream through once, file by file, into an LDS
-//     hash table keyed by (strand, span, key hash) — 64 bits, exact inside one bucket — with wave-aggregated counts, a
-//     per-group bitset of the samples seen and an atomic min for the representative; the few distinct groups are ranked
-//     at the end.
-// Every record is compared with the first record of its group under the exact strategy key (a hash collision raises
-// TBK_DERR_COLLISION and the host reseeds), so grouping is exact.  Windows write their groups and (group, sample)
-// incidences at their own record offset; a scan over the per-window counts and a compaction pass put them in key order.
-// What cannot be handled (more distinct groups in a pile-up than the table holds, k > 1024) raises TBK_DERR_BIGBUCKET
-// and the tile takes the sort path.
+// Here the coordinate axis is cut into windows by splitters chosen from a sample of the files' (tid, pos) keys (every s-th
+// record; every g-th sorted sample is a splitter; a splitter value that repeats — a pile-up — gets a window of its own).  Each
+// file contributes one contiguous piece to a window (wg_offsets_stream_k: one streaming pass, which also checks that the files
+// are sorted), so a window's records are k coalesced reads.  One workgroup per window (wg_hash_window): the records stream
+// through once, pieces laid end to end; per record the filter verdict and the 128-bit key come from its raw fields
+// (record_key, strategy.cuh), the merge priority — the per-file running maximum of the read ends inside a run of equal
+// starts — from a segmented prefix maximum along the piece (DPP inside a wave, LDS across waves, a carry across chunks).  The
+// passing records go into an LDS hash table keyed by a seeded 64-bit fingerprint of the key, the key stored beside it and
+// compared by every record that lands on the slot; per group: wave-aggregated count, bitset of the samples seen, atomic
+// minimum of (priority, record) for the representative.  The distinct groups are ranked by key at the end and written with
+// their (group, sample) incidences.  Windows with more distinct groups than the table holds go to a second tier with a larger
+// table, then to the LDS sort kernel (at most WG_CAP records, by construction of the splitters: index permutation
+// merge-sorted by (key, load order), groups from blocked runs).  Every record whose key word is a hash (not an exact code,
+// strategy.cuh) is compared with a member of its group under the exact strategy key (a collision raises TBK_DERR_COLLISION
+// and the host reseeds), so grouping is exact.  A scan over the per-window counts and a compaction pass put groups and
+// incidences in key order.  What cannot be handled (more distinct groups in a pile-up than the larger table holds, k > 1024)
+// raises TBK_DERR_BIGBUCKET and the tile takes the sort path; input the raw form does not take (an inversion, a mapped read
+// without a reference) raises TBK_DERR_RAWORDER and the general front end decides.  The compacted form (chi / clo / cval /
+// ceff prepared by col_keys_k + col_effkey_scan) runs through the same kernels (RAW = false).
 //
-// All integer work; bound by HBM (every record is read once, 20 B + its CIGAR words for the verification) and by LDS
-// latency in the window sort.  No MFMA.
+// All integer work.  The first-tier kernel is bound by vector-instruction issue (record decode, probing, atomics: about 450
+// VALU instructions per 64 records), not by its 13.6 GB of HBM traffic; see DESIGN.md §3.  No MFMA.
 #include <stdlib.h>
 
 #include <algorithm>
@@ -70,59 +73,6 @@ __global__ void wg_split_k(const uint64_t* __restrict__ Y, uint32_t g, uint32_t 
   W[2 * i + 1] = (first && !heavy) ? v : v + 1;
 }
 
-// off[r * k + f], r = 0 .. nrows - 1: r = 0 -> start of run f, r = nrows - 1 -> end of run f, else the first record of run
-// f with P >= W[r - 1].  A thread owns WG_OR consecutive rows of one run: one bisection, then galloping from the last answer
-// (consecutive splitters are ~T / k records apart inside a run).  Lanes run over f: a row is written coalesced.
-constexpr uint32_t WG_OR = 16;
-__global__ void wg_offsets_k(const uint64_t* __restrict__ chi, const uint32_t* __restrict__ run_off, uint32_t k, const uint64_t* __restrict__ W,
-                             uint32_t nrows, uint32_t* __restrict__ off) {
-  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t f = (uint32_t)(tid % k);
-  const uint64_t c = tid / k;
-  const uint64_t r0 = c * WG_OR;
-  if (r0 >= nrows) return;
-  const uint32_t a = run_off[f], b = run_off[f + 1];
-  uint32_t p = a;
-  bool have = false;
-  for (uint32_t u = 0; u < WG_OR; ++u) {
-    const uint64_t r = r0 + u;
-    if (r >= nrows) break;
-    uint32_t ans;
-    if (r == 0) {
-      ans = a;
-    } else if (r == nrows - 1) {
-      ans = b;
-    } else {
-      const uint64_t v = W[r - 1];
-      uint32_t lo, hi;  // answer in [lo, hi]
-      if (!have) {
-        lo = a;
-        hi = b;
-      } else {  // gallop from p (answers are non-decreasing in r)
-        lo = p;
-        uint32_t step = 1;
-        hi = p;
-        while (hi < b && (chi[hi] >> 2) < v) {
-          lo = hi + 1;
-          hi = (b - hi > step) ? hi + step : b;
-          step <<= 1;
-        }
-      }
-      while (lo < hi) {
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        if ((chi[mid] >> 2) < v)
-          lo = mid + 1;
-        else
-          hi = mid;
-      }
-      ans = lo;
-      p = ans;
-      have = true;
-    }
-    off[r * k + f] = ans;
-  }
-}
-
 // ---- raw mode: the windows are cut on the records as they come (no key pass, no compaction) -----------------------------------
 // Partition key of a raw record: (tid, pos) with every tid < 0 (unplaced reads, the tail of a sorted BAM) folded onto one value
 // beyond all references.  A file whose raw keys never decrease is coordinate-sorted in the sense of col_effkey_scan (mapped
@@ -141,55 +91,8 @@ __global__ void wg_sample_raw_k(const int32_t* __restrict__ tid, const int32_t* 
   if (d >= n) d = n - 1;
   shi[j] = raw_key(tid[d], pos[d]);
 }
-__global__ void wg_offsets_raw_k(const int32_t* __restrict__ rtid, const int32_t* __restrict__ rpos, const uint32_t* __restrict__ run_off, uint32_t k,
-                                 const uint64_t* __restrict__ W, uint32_t nrows, uint32_t* __restrict__ off) {
-  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t f = (uint32_t)(tid % k);
-  const uint64_t c = tid / k;
-  const uint64_t r0 = c * WG_OR;
-  if (r0 >= nrows) return;
-  const uint32_t a = run_off[f], b = run_off[f + 1];
-  uint32_t p = a;
-  bool have = false;
-  for (uint32_t u = 0; u < WG_OR; ++u) {
-    const uint64_t r = r0 + u;
-    if (r >= nrows) break;
-    uint32_t ans;
-    if (r == 0) {
-      ans = a;
-    } else if (r == nrows - 1) {
-      ans = b;
-    } else {
-      const uint64_t v = W[r - 1];
-      uint32_t lo, hi;  // answer in [lo, hi]
-      if (!have) {
-        lo = a;
-        hi = b;
-      } else {  // gallop from p (answers are non-decreasing in r)
-        lo = p;
-        uint32_t step = 1;
-        hi = p;
-        while (hi < b && raw_key(rtid[hi], rpos[hi]) < v) {
-          lo = hi + 1;
-          hi = (b - hi > step) ? hi + step : b;
-          step <<= 1;
-        }
-      }
-      while (lo < hi) {
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        if (raw_key(rtid[mid], rpos[mid]) < v)
-          lo = mid + 1;
-        else
-          hi = mid;
-      }
-      ans = lo;
-      p = ans;
-      have = true;
-    }
-    off[r * k + f] = ans;
-  }
-}
-// Streaming form of the offsets matrix (replaces the per-(row, run) searches of wg_offsets_k, whose probes are scattered reads):
+// The offsets matrix off[r * k + f] (r = 0: start of run f, r = nrows - 1: its end, else the first record of run f whose key is
+// >= W[r - 1]) by a streaming pass (per-(row, run) searches cost 2-4x as much in scattered probes):
 // a block takes WG_OC consecutive records, keeps their partition keys in LDS, and for every run segment inside it finds by two
 // searches in W the bounds that fall between the key before the segment and its last key — each of those has its answer inside
 // the segment (one LDS bisection).  The first segment of a run takes every bound up to its first key, the last one every bound
@@ -1343,19 +1246,11 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
     TBK_TRY(tbk_radix_sort_w64(ctx, &Y, &Y2, ns, ~0ull, false));
     TBK_LAUNCH(ctx, "wg_split", wg_split_k, cdiv(nsp, B), B, 0, Y, g, nsp, W);
   }
-  if (getenv("TBK_WG_OFFSETS_SEARCH")) {  // the search form (kept for comparison)
-    const uint64_t nthreads = (uint64_t)cdiv(nrows, WG_OR) * k;
-    if (raw)
-      TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_raw_k, cdiv(nthreads, B), B, 0, I.tid, I.pos, d_run_off, k, W, nrows, off);
-    else
-      TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_k, cdiv(nthreads, B), B, 0, chi, d_run_off, k, W, nrows, off);
-  } else {
-    if (raw)
-      TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_stream_k<true>, cdiv(m, WG_OC), 256, 0, chi, I.tid, I.pos, d_run_off, k, m, W, nW, off, ctx->d_err);
-    else
-      TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_stream_k<false>, cdiv(m, WG_OC), 256, 0, chi, I.tid, I.pos, d_run_off, k, m, W, nW, off, ctx->d_err);
-    TBK_LAUNCH(ctx, "wg_offsets_edges", wg_offsets_edges_k, cdiv(k, B), B, 0, d_run_off, k, nrows, off);
-  }
+  if (raw)
+    TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_stream_k<true>, cdiv(m, WG_OC), 256, 0, chi, I.tid, I.pos, d_run_off, k, m, W, nW, off, ctx->d_err);
+  else
+    TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_stream_k<false>, cdiv(m, WG_OC), 256, 0, chi, I.tid, I.pos, d_run_off, k, m, W, nW, off, ctx->d_err);
+  TBK_LAUNCH(ctx, "wg_offsets_edges", wg_offsets_edges_k, cdiv(k, B), B, 0, d_run_off, k, nrows, off);
   WgTemp T;
   T.hi = scratch_hi;
   T.lo = scratch_lo;
