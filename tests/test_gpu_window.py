@@ -61,6 +61,7 @@ def test_fuzz_small_tiles(ctx, window_mode, seed):
     ("c2", 2, 60000, dict()),                                     # shallow: second table / LDS sort tier
     ("c5", 40, 3000, dict(strategy="exon", max_nh=5, min_qual=1)),  # filters + spliced reads + many files
     ("c3", 70, 1500, dict(strategy="cigar")),
+    ("c2", 400, 300, dict()),                                     # several files per thread in the piece tables
 ])
 def test_many_windows(ctx, window_mode, profile, files, reads, kw):
     from tiebrush_amd import synth
