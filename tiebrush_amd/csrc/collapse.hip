@@ -1126,7 +1126,7 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
         YdLoad ld{iv, Y};
         YdStore st{ld};
         SegMaxY ident{INT32_MIN, 0u};
-        TBK_TRY((scan_op_run<SegMaxY, SegMaxYOp, YdLoad, YdStore>(ctx, "yd_chain_scan", nit, ld, st, SegMaxYOp{}, ident)));
+        TBK_TRY((scan_op_run<SegMaxY, SegMaxYOp, YdLoad, YdStore>(ctx, "yd_chain_scan", nit, ld, st, SegMaxYOp{}, ident, true)));
       }
       {  // chains numbered in item order, each with its first item and the first node of its arena
         HeadNexLoad ld{Y.chead, Y.nex};

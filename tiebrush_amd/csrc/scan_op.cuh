@@ -1,9 +1,13 @@
 // scan_op.cuh — device-wide inclusive scan with an arbitrary associative (not necessarily
 // commutative) operator over a trivially-copyable T made of 32-bit words.
-// Three launches: per-tile reduce, single-block spine, per-tile down-sweep.  Load/Store are
-// functors so the per-element work of the caller fuses into the first / last pass.
+// Two forms: three launches (per-tile reduce, single-block spine, per-tile down-sweep) or one launch with a decoupled
+// look-back (so_single_k below: scans whose elements are expensive to load gain from reading them once; cheap ones do not).
+// Load/Store are functors so the per-element work of the caller fuses into the first / last pass.
 #pragma once
 #include "dev_common.cuh"
+#include <stdlib.h>
+#include <string.h>
+
 #include "tbk_internal.h"
 
 // Word-wise shuffle of a small POD.  The words go through a by-value array copy (bit_cast), never through a pointer
@@ -180,10 +184,161 @@ __global__ __launch_bounds__(SO_NT) void so_down_k(uint32_t n, Load load, Store 
   }
 }
 
+// ---- single pass: decoupled look-back ---------------------------------------------------------------------------------
+// One launch instead of three, every element loaded once.  Tiles take a ticket (so a tile's predecessors are resident or done),
+// scan locally, publish their aggregate, look back over their predecessors' published values for their exclusive prefix and
+// publish their inclusive prefix.  The hand-off follows the "data is the flag" form of cdna_hip_programming.md Guideline 16 R2:
+// every 32-bit word of a published value travels in its own 8-byte granule {tag = 1, word}, written and polled with relaxed
+// agent-scope atomics (write-through stores, cache-bypassing loads): no fences, no L2 write-back — the fenced look-back tried in
+// round 1 was slower than three launches for exactly that cost.  The granules and the ticket are zeroed by one memset per scan.
+// Every spin is bounded: on a timeout the kernel raises TBK_DERR_INTERNAL in *err and finishes with garbage instead of hanging.
+struct SoLookback {
+  unsigned long long* agg;  // [nb * W] granules: tile aggregates
+  unsigned long long* inc;  // [nb * W] granules: inclusive prefixes
+  uint32_t* ticket;
+  uint32_t* err;
+};
+template <class T>
+__device__ __forceinline__ void so_publish(unsigned long long* g, uint32_t tile, const T& v) {
+  constexpr unsigned W = sizeof(T) / 4;
+  Words<T> a = __builtin_bit_cast(Words<T>, v);
+#pragma unroll
+  for (unsigned k = 0; k < W; ++k)
+    __hip_atomic_store(g + (size_t)tile * W + k, (1ull << 32) | a.w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class T>
+__device__ __forceinline__ bool so_peek(const unsigned long long* g, uint32_t tile, T* v) {
+  constexpr unsigned W = sizeof(T) / 4;
+  Words<T> a;
+  bool ok = true;
+#pragma unroll
+  for (unsigned k = 0; k < W; ++k) {
+    const unsigned long long x = __hip_atomic_load(g + (size_t)tile * W + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ok = ok && (x >> 32) == 1ull;
+    a.w[k] = (uint32_t)x;
+  }
+  *v = __builtin_bit_cast(T, a);
+  return ok;
+}
 template <class T, class Op, class Load, class Store>
-int scan_op_run(tbk_ctx* ctx, const char* name, uint32_t n, Load load, Store store, Op op, T ident) {
+__global__ __launch_bounds__(SO_NT) void so_single_k(uint32_t n, Load load, Store store, Op op, T ident, SoLookback S) {
+  __shared__ T tile[SO_LDS];
+  __shared__ T sm[SO_NT / 64];
+  __shared__ T wl[SO_NT / 64];
+  __shared__ T s_carry;
+  __shared__ uint32_t s_tile;
+  if (threadIdx.x == 0) s_tile = atomicAdd(S.ticket, 1u);
+  __syncthreads();
+  const uint32_t tix = s_tile;
+  const uint64_t base = (uint64_t)tix * SO_TILE;
+  T mine[SO_E];
+#pragma unroll
+  for (int e = 0; e < SO_E; ++e) {
+    uint32_t j = (uint32_t)e * SO_NT + threadIdx.x;
+    uint64_t i = base + j;
+    mine[e] = (i < n) ? load((uint32_t)i) : ident;
+    tile[so_pad(j)] = mine[e];
+  }
+  __syncthreads();
+  T v[SO_E];
+  T acc = ident;
+#pragma unroll
+  for (int e = 0; e < SO_E; ++e) {
+    v[e] = tile[so_pad(threadIdx.x * SO_E + e)];
+    acc = op(acc, v[e]);
+  }
+  T tot;
+  T inc = block_incl_scan_op(acc, op, sm, &tot);
+  T prev = shfl_up_t(inc, 1);
+  if (lane_id() == 63) wl[threadIdx.x >> 6] = inc;
+  if (threadIdx.x < 64) {  // wave 0: publish, look back, publish
+    const uint32_t lane = lane_id();
+    if (lane == 0) {
+      so_publish<T>(S.agg, tix, tot);
+      if (tix == 0) so_publish<T>(S.inc, 0u, tot);
+    }
+    T excl = ident;
+    bool failed = false;
+    int64_t j = (int64_t)tix - 1;
+    while (j >= 0 && !failed) {
+      const int64_t jj = j - (int64_t)lane;
+      const bool have = jj >= 0;
+      T val = ident;
+      bool is_inc = false, ok = !have;
+      for (uint32_t spins = 0;; ++spins) {
+        if (have && !ok) {
+          is_inc = so_peek<T>(S.inc, (uint32_t)jj, &val);
+          ok = is_inc || so_peek<T>(S.agg, (uint32_t)jj, &val);
+        }
+        if (__all(ok)) break;
+        if (spins > (1u << 22)) {  // (seconds: something is wrong — never hang)
+          failed = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (failed) break;
+      const uint64_t im = __ballot(have && is_inc);
+      const int first = im ? (int)__builtin_ctzll(im) : -1;                       // nearest tile with an inclusive prefix
+      const uint64_t hm = __ballot(have);
+      const int top = first >= 0 ? first : 63 - (int)__builtin_clzll(hm);          // farthest lane that takes part
+      T part = ident;
+      for (int l = top; l >= 0; --l) part = op(part, shfl_idx_t(val, l));           // older tiles first
+      excl = op(part, excl);
+      if (first >= 0) break;
+      j -= 64;
+    }
+    if (failed && lane == 0) atomicOr(S.err, TBK_DERR_INTERNAL);
+    if (lane == 0) {
+      if (tix > 0) so_publish<T>(S.inc, tix, op(excl, tot));
+      s_carry = excl;
+    }
+  }
+  __syncthreads();
+  const T carry = s_carry;
+  T ex;
+  if (threadIdx.x == 0)
+    ex = carry;
+  else if (lane_id() == 0)
+    ex = op(carry, wl[(threadIdx.x >> 6) - 1]);
+  else
+    ex = op(carry, prev);
+#pragma unroll
+  for (int e = 0; e < SO_E; ++e) {
+    tile[so_pad(threadIdx.x * SO_E + e)] = ex;
+    ex = op(ex, v[e]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < SO_E; ++e) {
+    uint32_t j = (uint32_t)e * SO_NT + threadIdx.x;
+    uint64_t i = base + j;
+    if (i < n) {
+      T exj = tile[so_pad(j)];
+      store((uint32_t)i, mine[e], op(exj, mine[e]), exj);
+    }
+  }
+}
+
+template <class T, class Op, class Load, class Store>
+int scan_op_run(tbk_ctx* ctx, const char* name, uint32_t n, Load load, Store store, Op op, T ident, bool single_pass = false) {
   if (n == 0) return 0;
   uint32_t nb = cdiv(n, SO_TILE);
+  static const int forced = [] {  // test hook: TBK_SCAN=lookback / 3pass forces one form for every scan
+    const char* e = getenv("TBK_SCAN");
+    return !e ? 0 : (strcmp(e, "lookback") == 0 ? 1 : (strcmp(e, "3pass") == 0 ? 2 : 0));
+  }();
+  const bool lookback = forced == 1 || (forced == 0 && single_pass);
+  if (lookback && nb > 1) {
+    constexpr size_t W = sizeof(T) / 4;
+    const size_t words = 2 * (size_t)nb * W + 2;  // granules + the ticket word (8 bytes)
+    unsigned long long* st = ws_alloc<unsigned long long>(ctx, words);
+    if (!st) return TBK_ENOMEM;
+    TBK_HIP(hipMemsetAsync(st, 0, words * 8, ctx->stream));
+    SoLookback S{st + 2, st + 2 + (size_t)nb * W, (uint32_t*)st, ctx->d_err};
+    TBK_LAUNCH(ctx, name, (so_single_k<T, Op, Load, Store>), nb, SO_NT, 0, n, load, store, op, ident, S);
+    return tbk_check_launch(ctx, name);
+  }
   T* part = ws_alloc<T>(ctx, nb);
   if (!part) return TBK_ENOMEM;
   TBK_LAUNCH(ctx, name, (so_reduce_k<T, Op, Load>), nb, SO_NT, 0, n, load, op, ident, part);
