@@ -899,7 +899,7 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
     BundleLoad ld{A.tid, A.end};
     BundleStore st{A.tid, A.start, A.bhead, A.inclmax, ctx->d_err};
     SegMax ident{INT32_MIN, 0u};
-    TBK_TRY((scan_op_run<SegMax, SegMaxOp, BundleLoad, BundleStore>(ctx, "cov_bundle_scan", m, ld, st, SegMaxOp{}, ident, true)));
+    TBK_TRY((scan_op_run<SegMax, SegMaxOp, BundleLoad, BundleStore>(ctx, "cov_bundle_scan", m, ld, st, SegMaxOp{}, ident)));
   }
   TBK_TRY(tbk_exscan_u32(ctx, A.bhead, A.bid, m, sc + 3));
   TBK_LAUNCH(ctx, "cov_bundle_fill", cov_bundle_fill_k, cdiv(m, B), B, 0, m, A);

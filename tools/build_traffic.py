@@ -20,7 +20,7 @@ def bench_name(sym):
     if not m:
         return None
     stem = m.group(1)
-    if stem in ("so_reduce", "so_spine", "so_down"):
+    if stem in ("so_reduce", "so_spine", "so_down", "so_single"):
         t = re.search(r"::(EffKey|SegMaxY|SegMax|ShKey|HeadNex)\b", sym)
         return SCAN.get(t.group(1)) if t else stem
     if stem == "w64_scatter" and "YdEmit" in sym:
