@@ -1424,7 +1424,7 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
       EffLoad ld{khi, kend, kflags};
       EffStore st{khi, klo, kflags, effend, s2.hi, s2.lo, s2.val, sc + 0, n, ctx->d_err, fidx, head_off, use_win ? ceff : nullptr, I.prio_hi};
       EffKey ident{0u, 0u, INT32_MIN, 0u};
-      TBK_TRY((scan_op_run<EffKey, EffOp, EffLoad, EffStore>(ctx, "col_effkey_scan", n, ld, st, EffOp{}, ident)));
+      TBK_TRY((scan_op_run<EffKey, EffOp, EffLoad, EffStore>(ctx, "col_effkey_scan", n, ld, st, EffOp{}, ident, true)));
     }
     if (use_runs || use_win) TBK_LAUNCH(ctx, "col_runs", col_runs_k, cdiv(I.k + 1, B), B, 0, I.k, I.file_off, head_off, sc + 0, run_off);
     uint32_t eb = 0;

@@ -331,7 +331,7 @@ extern "C" int tbk_shard_prepare(tbk_ctx* ctx, const tbk_collapse_opts* o, const
     ShLoad ld{key, kend, pass};
     ShStore st{key, effend, emax, ctx->d_err};
     ShKey ident{0u, 0u, INT32_MIN, 0u, 0u, 0u};
-    TBK_TRY((scan_op_run<ShKey, ShOp, ShLoad, ShStore>(ctx, "shard_eff_scan", n, ld, st, ShOp{}, ident)));
+    TBK_TRY((scan_op_run<ShKey, ShOp, ShLoad, ShStore>(ctx, "shard_eff_scan", n, ld, st, ShOp{}, ident, true)));
   }
   uint32_t eb = 0;
   TBK_TRY(tbk_sync_err(ctx, &eb));
