@@ -254,7 +254,7 @@ void tbk_bam_release(tbk_ctx* ctx);
  * unless stated; file_off arrays are host memory as in tbk_soa_in. */
 
 /* Per record of `in` (n_records): key = (tid+1)<<31 | start (nondecreasing inside a file, else TBK_EUNSORTED),
- * emax = per-file running max of (tid+1)<<31 | end over ALL records, effend = the effective end of the reference's
+ * emax = per-file running max of (tid+1)<<31 | (end + 1) over ALL records (a cut is valid where the next start exceeds it), effend = the effective end of the reference's
  * k-way merge (tmerge.h:28-50; it depends on filtered records too, so it is computed here and travels as the record's
  * explicit priority), pass bit 0 = passes_options (tiebrush.cpp:532-541) under `opts`. */
 int tbk_shard_prepare(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa_in* in, int64_t* key, int64_t* emax, int32_t* effend,

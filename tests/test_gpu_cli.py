@@ -236,3 +236,24 @@ def test_sam_text_inputs(tmp_path):
     _run([os.path.join(BIN, "tiecov"), "-c", pre + ".coverage", str(csam)])
     got = [l[:-4] if l.endswith(".000") else l for l in read_lines(pre + ".coverage.bedgraph")]
     assert got == read_lines(os.path.join(GOLDEN, "t2", "t2.coverage.bedgraph"))
+
+
+def test_tiles_are_not_cut_behind_an_intron_ending_cigar(tmp_path):
+    """the streaming host may cut a tile only where the next read starts beyond end + 1 of everything before it: the YD
+    lists can hold a node (end + 1, end) (a CIGAR that ends in an intron); with two-record tiles the output still equals the
+    one-tile output and the oracle"""
+    from oracle import oracle_ffi as orc
+    from test_gpu_collapse import _degenerate_exon_files
+    from test_gpu_window import _tile
+    from tiebrush_amd import bamio, synth
+    tile = _tile(_degenerate_exon_files())
+    paths = synth.write_bams(tile, str(tmp_path / "in"))
+    want = orc.collapse(tile)
+    outs = []
+    for tr in ("2", "1000000"):
+        out = str(tmp_path / ("o%s.bam" % tr))
+        _run([os.path.join(BIN, "tiebrush"), "-o", out] + paths, env=dict(os.environ, TBK_TILE_RECORDS=tr, TBK_DEVICE_DECODE="0"))
+        o = bamio.read_bam(out)
+        assert o.n == want["n_groups"]
+        assert [int(x) for x in o.yd] == [int(x) for x in want["yd"]] and [int(x) for x in o.yx] == [int(x) for x in want["yx"]]
+        outs.append(open(out, "rb").read())

@@ -345,3 +345,23 @@ def test_deferred_yd_overlaps_tiecov_chain(ctx):
     assert np.array_equal(r2["yd"], want["yd"])
     with pytest.raises(api.TbkError):
         ctx.collapse(tile, defer_yd=True)                  # host-pointer mode cannot defer
+
+
+def _degenerate_exon_files():
+    """A CIGAR that ends in an intron (… 7N 2S) leaves a last exon (end + 1, end) in the sample's segment list
+    (GSam.cpp:351-417).  The next read of that sample starts exactly at end + 1: processRead does not clear that node
+    (its start is not < the read's start), mergeRead then finds no overlap and DROPS the read's exons (tiebrush.cpp:214-216),
+    and the read after it measures its distance against what is left.  The list is only renewed by a start beyond end + 1."""
+    M, N, S = 0, 3, 4
+    f0 = [(2, 9, 0, 60, ".", 1, [(24, M), (7, N), (2, S)]),          # start 10, end 40, exons (10,33) and (41,40)
+          (2, 40, 0, 60, ".", 1, [(15, M), (40, N), (10, M)]),       # start 41 = end + 1: its exons are dropped
+          (2, 41, 0, 60, "+", 1, [(10, M), (20, N), (30, M)]),       # start 42: d = 0 (a chain cut at 41 would give 1)
+          (2, 43, 0, 60, "+", 1, [(30, M)])]
+    f1 = [(2, 41, 16, 60, "+", 1, [(10, M), (20, N), (30, M)]), (2, 200, 0, 60, "-", 1, [(30, M)])]
+    return [f0, f1]
+
+
+def test_yd_list_survives_a_start_at_end_plus_one(ctx):
+    from test_gpu_window import _tile
+    _check(ctx, _tile(_degenerate_exon_files()))
+    _check(ctx, _tile(list(reversed(_degenerate_exon_files()))))

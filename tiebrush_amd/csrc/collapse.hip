@@ -512,7 +512,9 @@ struct YdLoad {
   }
   __device__ __forceinline__ SegMaxY operator()(uint32_t t) const {
     SegMaxY s;
-    s.mx = Y.end(t);
+    // end + 1: a CIGAR that ends in an intron leaves a last exon (end + 1, end) in the list (GSam.cpp:351-417) — a node that
+    // a read starting at end + 1 does not clear; only a start beyond end + 1 renews the list
+    s.mx = Y.end(t) + 1;
     s.flag = list_head(t) ? 1u : 0u;
     return s;
   }

@@ -418,7 +418,9 @@ bool BamFile::index_records(std::string& err) {
         const uint32_t w = rd32(c + 4 * i);
         if ((0x18Du >> (w & 0xF)) & 1u) l += w >> 4;
       }
-      ke = (((int64_t)tid + 1) << 32) | (int64_t)(uint32_t)(pos + (l > 0 ? l : 1));
+      // (+ 1: the YD lists may hold a node that starts one base behind a read's end — a CIGAR ending in an intron — so a tile
+      // may only be cut where the next read starts beyond end + 1)
+      ke = (((int64_t)tid + 1) << 32) | (int64_t)(uint32_t)(pos + (l > 0 ? l : 1) + 1);
     }
     if (ke > run) run = ke;
     rec_off.push_back(off);

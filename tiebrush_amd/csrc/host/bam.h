@@ -81,7 +81,7 @@ struct BamFile {
   std::vector<uint8_t> data;      // inflated window (the first record starts at rec_off[0])
   std::vector<uint64_t> rec_off;  // offset (in data) of every indexed record's block_size field
   std::vector<int64_t> key_start; // per indexed record: sort key (tid + 1) << 32 | (pos + 1); refID -1 -> INT64_MAX
-  std::vector<int64_t> pmax_end;  // per indexed record: running max over the window of (tid + 1) << 32 | end (1-based inclusive)
+  std::vector<int64_t> pmax_end;  // per indexed record: running max over the window of (tid + 1) << 32 | end + 1 (end 1-based inclusive)
   std::string path;
   bool open(const std::string& path, std::string& err, int threads = 1);
   // inflate until the window holds at least min_records records (or the file ends); false on malformed input

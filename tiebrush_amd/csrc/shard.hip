@@ -94,7 +94,9 @@ struct ShLoad {
   const uint8_t* kfl;
   __device__ __forceinline__ ShKey operator()(uint32_t i) const {
     const uint64_t k = (uint64_t)key[i];
-    const uint64_t m = (k & ~0x7FFFFFFFull) | (uint32_t)kend[i];  // (tid + 1) : 32 | end : 31
+    // (tid + 1) : 32 | end + 1 : 31 — a cut must lie beyond end + 1: the YD lists may hold a node (end + 1, end) of a CIGAR
+    // that ends in an intron
+    const uint64_t m = (k & ~0x7FFFFFFFull) | (uint32_t)(kend[i] + 1);
     ShKey e;
     e.kh = (uint32_t)(k >> 32);
     e.kl = (uint32_t)k;

@@ -210,7 +210,7 @@ def _prepare_np(tile, max_nh=2**31 - 1, min_qual=-1, keep_supplementary=False, k
         k = key[lo:hi]
         if np.any(k[1:] < k[:-1]):
             raise ValueError("input not coordinate-sorted")
-        emax[lo:hi] = np.maximum.accumulate(((tid[lo:hi] + 1) << 31) | end[lo:hi])
+        emax[lo:hi] = np.maximum.accumulate(((tid[lo:hi] + 1) << 31) | (end[lo:hi] + 1))   # (+ 1: see shard.hip, ShLoad)
         head = np.ones(hi - lo, bool)
         head[1:] = k[1:] != k[:-1]
         run = np.cumsum(head) - 1
