@@ -253,7 +253,7 @@ void tbk_bam_release(tbk_ctx* ctx);
  * exchange itself is the caller's (torch.distributed over RCCL in tiebrush_amd/dist.py).  All arrays are device memory
  * unless stated; file_off arrays are host memory as in tbk_soa_in. */
 
-/* Per record of `in` (n_records): key = (tid+1)<<31 | start (nondecreasing inside a file, else TBK_EUNSORTED),
+/* Per record of `in` (n_records): key = (tid+1)<<31 | pos+1, 1<<62 for tid < 0 (nondecreasing inside a file, else TBK_EUNSORTED),
  * emax = per-file running max of (tid+1)<<31 | (end + 1) over ALL records (a cut is valid where the next start exceeds it), effend = the effective end of the reference's
  * k-way merge (tmerge.h:28-50; it depends on filtered records too, so it is computed here and travels as the record's
  * explicit priority), pass bit 0 = passes_options (tiebrush.cpp:532-541) under `opts`. */

@@ -57,3 +57,34 @@ def read_lines(path):
     if g and g[-1] == "":
         g = g[:-1]
     return g
+
+
+def tile_from_records(files):
+    """files: list of lists of (tid, pos, flag, mapq, strand, nh, [(len, op) ...]) in file order -> SoATile"""
+    allr = [r for f in files for r in f]
+    n, k = len(allr), len(files)
+    fo = np.zeros(k + 1, np.uint32)
+    fo[1:] = np.cumsum([len(f) for f in files])
+    cigs = [[(l << 4) | o for l, o in r[6]] for r in allr]
+    off = np.zeros(n + 1, np.uint32)
+    off[1:] = np.cumsum([len(c) for c in cigs])
+    return soa.SoATile(
+        n_files=k, file_off=fo, tbmerged=np.zeros(k, np.uint8), tid=np.array([r[0] for r in allr], np.int32),
+        pos=np.array([r[1] for r in allr], np.int32), flag=np.array([r[2] for r in allr], np.uint16),
+        mapq=np.array([r[3] for r in allr], np.uint8), strand=np.array([ord(r[4]) for r in allr], np.uint8),
+        nh=np.array([r[5] for r in allr], np.int32), cig_off=off, cig=np.array([x for c in cigs for x in c], np.uint32))
+
+
+def paired_end_like_files():
+    """What a real coordinate-sorted BAM holds besides mapped reads: unmapped mates placed at their mate's position, unplaced
+    reads (tid -1) behind everything, an input without any record — and a CIGAR that ends in an intron."""
+    M, N, S = 0, 3, 4
+    un = (-1, -1, 4, 0, ".", -(2**31), [])
+    f0 = [(0, 100, 0, 60, "+", 1, [(50, M)]), (0, 100, 4 | 8, 0, ".", 1, []), (0, 100, 0, 60, "+", 1, [(30, M)]),
+          (0, 100, 0, 60, "+", 1, [(50, M)]), (0, 120, 0, 60, "+", 1, [(30, M)]), (1, 9, 0, 60, ".", 1, [(24, M), (7, N), (2, S)]),
+          (1, 40, 0, 60, ".", 1, [(15, M), (40, N), (10, M)]), (1, 41, 0, 60, "+", 1, [(10, M), (20, N), (30, M)]), un, un]
+    f1 = []
+    f2 = [(0, 100, 0, 60, "+", 1, [(30, M)]), (0, 100, 0, 60, "+", 1, [(50, M)]), (0, 500, 4 | 8, 0, ".", 1, []),
+          (1, 41, 16, 60, "+", 1, [(10, M), (20, N), (30, M)]), (2, 5, 0, 60, "-", 1, [(40, M)]), un]
+    f3 = [(0, 90, 0, 60, "-", 1, [(30, M)]), (2, 5, 0, 60, "-", 1, [(40, M)]), (2, 7, 0, 0, "-", 1, [(40, M)])]
+    return [f0, f1, f2, f3]

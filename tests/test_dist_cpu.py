@@ -121,3 +121,18 @@ def test_gloo_world2_equals_flat(a2a_bytes, monkeypatch):
     flat = orc.collapse(tile)
     flat_cov = orc.coverage(synth.collapsed_to_cov_input(tile, flat))
     check_against_flat([got[0], got[1]], tile, flat, flat_cov)
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_loopback_real_bam_shapes(world):
+    """unmapped mates at their mate's position, unplaced reads at the end of a file, a rank whose files hold nothing, a CIGAR
+    that ends in an intron right before a cut candidate: the multi-rank path takes them as the single-GPU path does"""
+    from helpers import paired_end_like_files, tile_from_records
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import dist, synth
+    tile = tile_from_records(paired_end_like_files())
+    flat = orc.collapse(tile)
+    flat_cov = orc.coverage(synth.collapsed_to_cov_input(tile, flat))
+    tiles, first = split_tile(tile, world)
+    res = dist.run_loopback(OracleCompute(), tiles, first, want_coverage=True)
+    check_against_flat(res, tile, flat, flat_cov)

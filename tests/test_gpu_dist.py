@@ -200,3 +200,24 @@ def test_two_processes_device_path():
     flat = orc.collapse(tile, strategy=STRAT["clip"])
     flat_cov = orc.coverage(synth.collapsed_to_cov_input(tile, flat))
     check_against_flat([got[0], got[1]], tile, flat, flat_cov)
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_loopback_device_real_bam_shapes(world):
+    """as tests/test_dist_cpu.py::test_loopback_real_bam_shapes, through the tbk_shard_* kernels (the keys stay monotone over
+    unmapped and unplaced reads; an empty rank passes null arrays)"""
+    import torch
+    from helpers import paired_end_like_files, tile_from_records
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import api, dist, synth
+    tile = tile_from_records(paired_end_like_files())
+    flat = orc.collapse(tile)
+    flat_cov = orc.coverage(synth.collapsed_to_cov_input(tile, flat))
+    tiles, first = split_tile(tile, world)
+    dtiles = [api.to_device(t, "cuda:0") for t in tiles]
+    res = dist.run_loopback(DeviceCompute(), dtiles, first, want_coverage=True, device_chain=True)
+    for r in res:
+        for f in ("tid", "start", "end", "rep_fidx", "rep_idx", "yc", "yx", "yd"):
+            v = getattr(r, f)
+            setattr(r, f, v.cpu().numpy() if isinstance(v, torch.Tensor) else v)
+    check_against_flat(res, tile, flat, flat_cov)

@@ -28,21 +28,7 @@ def window_mode(request, monkeypatch):
     return request.param
 
 
-def _tile(files):
-    """files: list of lists of (tid, pos, flag, mapq, strand, nh, [(len, op) ...]) in file order"""
-    from tiebrush_amd import soa
-    allr = [r for f in files for r in f]
-    n, k = len(allr), len(files)
-    fo = np.zeros(k + 1, np.uint32)
-    fo[1:] = np.cumsum([len(f) for f in files])
-    cigs = [[(l << 4) | o for l, o in r[6]] for r in allr]
-    off = np.zeros(n + 1, np.uint32)
-    off[1:] = np.cumsum([len(c) for c in cigs])
-    return soa.SoATile(
-        n_files=k, file_off=fo, tbmerged=np.zeros(k, np.uint8), tid=np.array([r[0] for r in allr], np.int32),
-        pos=np.array([r[1] for r in allr], np.int32), flag=np.array([r[2] for r in allr], np.uint16),
-        mapq=np.array([r[3] for r in allr], np.uint8), strand=np.array([ord(r[4]) for r in allr], np.uint8),
-        nh=np.array([r[5] for r in allr], np.int32), cig_off=off, cig=np.array([x for c in cigs for x in c], np.uint32))
+from helpers import tile_from_records as _tile  # noqa: E402
 
 
 @pytest.mark.parametrize("seed", range(4))

@@ -27,7 +27,9 @@ struct ShOpt {
   uint8_t keep_supp, keep_sec;
 };
 
-// key = (tid + 1) : 32 | start : 31 (start = pos + 1, the GSamRecord 1-based start) — per file nondecreasing
+// key = (tid + 1) : 32 | pos + 1 : 31 (for a mapped read the GSamRecord 1-based start) — per file nondecreasing in a
+// coordinate-sorted BAM: unmapped reads placed at their mate's position keep that position, unplaced reads (tid < 0, the tail
+// of the file) take a key beyond every reference
 __global__ void shard_keys_k(uint32_t n, uint32_t k, const uint32_t* __restrict__ file_off, const int32_t* __restrict__ tid,
                              const int32_t* __restrict__ pos, const uint16_t* __restrict__ flag, const uint8_t* __restrict__ mapq,
                              const int32_t* __restrict__ nh, const uint32_t* __restrict__ cig_off, const uint32_t* __restrict__ cig,
@@ -59,7 +61,7 @@ __global__ void shard_keys_k(uint32_t n, uint32_t k, const uint32_t* __restrict_
     int h = nh[i] == TBK_NH_ABSENT ? 0 : nh[i];
     if (h > O.max_nh) pass = false;
     if (pass && (start < 0 || tid[i] < -1 || (int64_t)end - start + 1 >= (1ll << 30))) atomicOr(err, TBK_DERR_SPAN);
-    key[i] = ((int64_t)(uint32_t)(tid[i] + 1) << 31) | (uint32_t)start;
+    key[i] = tid[i] < 0 ? (int64_t)(1ll << 62) : (((int64_t)(uint32_t)(tid[i] + 1) << 31) | (uint32_t)(pos[i] + 1));
     kend[i] = end;
     kfl[i] = (pass ? 1u : 0u) | (i == file_off[lo] ? 2u : 0u);
     fidx[i] = (uint16_t)lo;
@@ -344,9 +346,10 @@ extern "C" int tbk_shard_prepare(tbk_ctx* ctx, const tbk_collapse_opts* o, const
 // m_out[c] (caller-initialised to -1) := max(m_out[c], farthest keyed end before cuts[c]); everything device-resident
 extern "C" int tbk_shard_probe_max(tbk_ctx* ctx, const uint32_t* file_off, uint32_t n_files, const int64_t* key, const int64_t* emax,
                                    const int64_t* cuts, uint32_t n_cuts, int64_t* m_out) {
-  if (!ctx || !file_off || !key || !emax || !cuts || !m_out || n_files == 0) return TBK_EINVAL;
+  if (!ctx || !file_off || n_files == 0) return TBK_EINVAL;
+  if (n_cuts == 0 || file_off[n_files] == 0) return 0;  // (a rank whose files hold no records contributes nothing)
+  if (!key || !emax || !cuts || !m_out) return TBK_EINVAL;
   TBK_HIP(hipSetDevice(ctx->device));
-  if (n_cuts == 0) return 0;
   TBK_TRY(tbk_ws_reserve(ctx, (size_t)1 << 20));
   uint32_t* d_fo = nullptr;
   TBK_TRY(shard_upload_file_off(ctx, file_off, n_files, &d_fo));
@@ -358,9 +361,10 @@ extern "C" int tbk_shard_probe_max(tbk_ctx* ctx, const uint32_t* file_off, uint3
 // nxt_out[c] (caller-initialised to +inf) := min(nxt_out[c], first record start beyond m[c])
 extern "C" int tbk_shard_probe_next(tbk_ctx* ctx, const uint32_t* file_off, uint32_t n_files, const int64_t* key, const int64_t* m,
                                     uint32_t n_cuts, int64_t* nxt_out) {
-  if (!ctx || !file_off || !key || !m || !nxt_out || n_files == 0) return TBK_EINVAL;
+  if (!ctx || !file_off || n_files == 0) return TBK_EINVAL;
+  if (n_cuts == 0 || file_off[n_files] == 0) return 0;
+  if (!key || !m || !nxt_out) return TBK_EINVAL;
   TBK_HIP(hipSetDevice(ctx->device));
-  if (n_cuts == 0) return 0;
   TBK_TRY(tbk_ws_reserve(ctx, (size_t)1 << 20));
   uint32_t* d_fo = nullptr;
   TBK_TRY(shard_upload_file_off(ctx, file_off, n_files, &d_fo));
@@ -374,7 +378,9 @@ extern "C" int tbk_shard_probe_next(tbk_ctx* ctx, const uint32_t* file_off, uint
 // [world][n_files][5] int64 on the DEVICE (first record, rows, words, row base, word base per (destination, file))
 extern "C" int tbk_shard_pack(tbk_ctx* ctx, const tbk_soa_in* in, const int64_t* key, const uint8_t* pass, const int32_t* effend,
                               const int64_t* cuts, uint32_t world, int32_t* rows, uint32_t* cig_out, int64_t* src_idx, int64_t* tab) {
-  if (!ctx || !in || !key || !pass || !effend || !rows || !cig_out || !src_idx || !tab || world == 0) return TBK_EINVAL;
+  if (!ctx || !in || !tab || world == 0) return TBK_EINVAL;
+  // (a rank whose files hold no records still takes part: its table of counts is all zero)
+  if (in->n_records && (!key || !pass || !effend || !rows || !cig_out || !src_idx)) return TBK_EINVAL;
   if (world > 1 && !cuts) return TBK_EINVAL;
   if (in->mem != TBK_MEM_DEVICE || in->n_files == 0 || in->n_files > 65535 || !in->file_off) return TBK_EINVAL;
   TBK_HIP(hipSetDevice(ctx->device));

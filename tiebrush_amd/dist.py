@@ -40,7 +40,7 @@ import numpy as np
 from .soa import SoATile, CovInput
 
 N_SAMPLES = 64
-KEY_INF = 1 << 62        # above every key: keys are (tid+1) << 31 | start
+KEY_INF = 1 << 62        # above every key of a placed read: keys are (tid+1) << 31 | pos+1 (unplaced reads carry exactly this value)
 
 
 # ---- numpy / torch shim (only the handful of index ops the protocol needs) -----------------------------------
@@ -192,7 +192,7 @@ def _prepare_np(tile, max_nh=2**31 - 1, min_qual=-1, keep_supplementary=False, k
     start = np.where(mapped, pos + 1, 0)
     end = np.where(mapped, pos + _reflen_np(tile), 0)
     tid = np.asarray(tile.tid).astype(np.int64)
-    key = ((tid + 1) << 31) | start
+    key = np.where(tid < 0, np.int64(1) << 62, ((tid + 1) << 31) | (pos + 1))   # (shard.hip, shard_keys_k)
     nh = np.asarray(tile.nh).astype(np.int64)
     nh = np.where(nh == -(2**31), 0, nh)
     ok = mapped & (np.asarray(tile.mapq).astype(np.int64) >= min_qual) & (nh <= max_nh)
@@ -210,7 +210,7 @@ def _prepare_np(tile, max_nh=2**31 - 1, min_qual=-1, keep_supplementary=False, k
         k = key[lo:hi]
         if np.any(k[1:] < k[:-1]):
             raise ValueError("input not coordinate-sorted")
-        emax[lo:hi] = np.maximum.accumulate(((tid[lo:hi] + 1) << 31) | (end[lo:hi] + 1))   # (+ 1: see shard.hip, ShLoad)
+        emax[lo:hi] = np.maximum.accumulate((k & ~np.int64(0x7FFFFFFF)) | (end[lo:hi] + 1))   # (+ 1: see shard.hip, ShLoad)
         head = np.ones(hi - lo, bool)
         head[1:] = k[1:] != k[:-1]
         run = np.cumsum(head) - 1
@@ -223,6 +223,8 @@ def _probe_max_np(file_off, key, emax, cuts):
     m = np.full(len(cuts), -1, np.int64)
     for f in range(len(file_off) - 1):
         lo, hi = int(file_off[f]), int(file_off[f + 1])
+        if hi == lo:
+            continue
         i = np.searchsorted(key[lo:hi], cuts, side="left")
         m = np.where(i > 0, np.maximum(m, emax[lo + np.maximum(i - 1, 0)]), m)
     return m
@@ -232,8 +234,10 @@ def _probe_next_np(file_off, key, m):
     nxt = np.full(len(m), KEY_INF, np.int64)
     for f in range(len(file_off) - 1):
         lo, hi = int(file_off[f]), int(file_off[f + 1])
+        if hi == lo:
+            continue
         i = np.searchsorted(key[lo:hi], m, side="right")
-        nxt = np.where(i < hi - lo, np.minimum(nxt, key[lo + np.minimum(i, max(hi - lo - 1, 0))] if hi > lo else nxt), nxt)
+        nxt = np.where(i < hi - lo, np.minimum(nxt, key[lo + np.minimum(i, hi - lo - 1)]), nxt)
     return nxt
 
 
