@@ -399,8 +399,12 @@ __device__ __forceinline__ uint16_t* wg_merge_sort(uint16_t* src, uint16_t* dst,
 
 __device__ __forceinline__ unsigned long long wg_fingerprint(uint64_t hi, uint64_t lo, uint64_t seed) {
   // (hi, lo) -> hi * K + lo is one-to-one in lo for equal hi and, for an odd seeded K, collides for two different hi only when
-  // their difference times K equals the difference of the lo words; mix64 is a bijection
-  unsigned long long f = mix64((hi ^ seed) * ((seed << 1) | 0x9E3779B97F4A7C15ull) + lo);
+  // their difference times K equals the difference of the lo words; the xor-shift / odd-multiply rounds behind it are bijections
+  // (two 64-bit multiplies in all: the multiplies are the quarter-rate instructions of this VALU-bound kernel)
+  unsigned long long f = (hi ^ seed) * ((seed << 1) | 0x9E3779B97F4A7C15ull) + lo;
+  f ^= f >> 29;
+  f *= 0xBF58476D1CE4E5B9ull;
+  f ^= f >> 32;
   return f == ~0ull ? 0ull : f;  // ~0 marks an empty slot
 }
 
@@ -706,16 +710,33 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
     phase(4);
     if (s_misc[1]) break;
     if constexpr (RAW) {  // effective ends: the carry that enters every (row, wave) of this chunk, folded in element order
-      uint32_t c = s_misc[4 + par];
+      // (lane q of every wave holds aggregate q; a 16-lane segmented scan gives the carry behind each of them)
+      static_assert(NR * WG_NW <= 16, "the carries are folded inside one DPP row");
+      const uint32_t c0 = s_misc[4 + par];
+      const uint32_t lq = lane_id();
+      const uint2 a = lq < (uint32_t)(NR * WG_NW) ? s_agg[lq] : make_uint2(0u, 0u);
+      uint32_t ax = a.x, af = a.y;
+#define WG_FOLD_STEP(ctrl)                                                                       \
+  {                                                                                              \
+    const uint32_t xo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ax, ctrl, 0xf, 0xf, false); \
+    const uint32_t fq = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)af, ctrl, 0xf, 0xf, false); \
+    ax = af ? ax : (xo > ax ? xo : ax);                                                          \
+    af |= fq;                                                                                    \
+  }
+      WG_FOLD_STEP(0x111)  // row_shr:1, 2, 4, 8
+      WG_FOLD_STEP(0x112)
+      WG_FOLD_STEP(0x114)
+      WG_FOLD_STEP(0x118)
+#undef WG_FOLD_STEP
+      const uint32_t cq = af ? ax : (ax > c0 ? ax : c0);  // the carry behind aggregate lq
       uint32_t snap[NR];
-      const uint32_t wv = t >> 6;
+      const int wv = __builtin_amdgcn_readfirstlane((int)(t >> 6));
 #pragma unroll
-      for (int q = 0; q < NR * WG_NW; ++q) {
-        if ((uint32_t)(q % WG_NW) == wv) snap[q / WG_NW] = c;
-        const uint2 a = s_agg[q];
-        c = a.y ? a.x : (a.x > c ? a.x : c);
+      for (int u = 0; u < NR; ++u) {
+        const int q = u * WG_NW + wv;  // uniform
+        snap[u] = q == 0 ? c0 : (uint32_t)__builtin_amdgcn_readlane((int)cq, q - 1);
       }
-      if (t == 0) s_misc[4 + (par ^ 1u)] = c;
+      if (t == 0) s_misc[4 + (par ^ 1u)] = (uint32_t)__builtin_amdgcn_readlane((int)cq, NR * WG_NW - 1);
       par ^= 1u;
 #pragma unroll
       for (int u = 0; u < NR; ++u) eff[u] = fs[u] ? xs[u] : (xs[u] > snap[u] ? xs[u] : snap[u]);
