@@ -257,3 +257,24 @@ def test_tiles_are_not_cut_behind_an_intron_ending_cigar(tmp_path):
         assert o.n == want["n_groups"]
         assert [int(x) for x in o.yd] == [int(x) for x in want["yd"]] and [int(x) for x in o.yx] == [int(x) for x in want["yx"]]
         outs.append(open(out, "rb").read())
+
+
+@pytest.mark.parametrize("env", [dict(TBK_DEVICE_DECODE="0", TBK_TILE_RECORDS="3"), dict(TBK_DEVICE_DECODE="0"), dict()],
+                         ids=["host-tiny-tiles", "host-one-tile", "device-decode"])
+def test_real_bam_shapes_through_the_command_line(tmp_path, env):
+    """unmapped mates in place, an unplaced tail, an input without records, a CIGAR ending in an intron: every decode path of
+    the command line gives the oracle's records, in its order, with its tags"""
+    from helpers import paired_end_like_files, tile_from_records
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import bamio, synth
+    tile = tile_from_records(paired_end_like_files())
+    paths = synth.write_bams(tile, str(tmp_path / "in"))
+    want = orc.collapse(tile)
+    out = str(tmp_path / "o.bam")
+    _run([os.path.join(BIN, "tiebrush"), "-o", out] + paths, env=dict(os.environ, **env))
+    o = bamio.read_bam(out)
+    fo = tile.file_of()
+    assert o.n == want["n_groups"]
+    assert [bytes(x) for x in o.qname] == [b"r%d_%d" % (int(fo[g]), int(g) - int(tile.file_off[int(fo[g])])) for g in want["rep"]]
+    assert [int(x) for x in o.yd] == [int(x) for x in want["yd"]] and [int(x) for x in o.yx] == [int(x) for x in want["yx"]]
+    assert [float(x) for x in o.yc] == [float(np.float32(x)) for x in want["yc"]]
