@@ -48,7 +48,7 @@ constexpr uint32_t WG_T = 1024;          // records between splitters: a window 
 constexpr uint32_t WG_KS = 1024;         // k * s budget
 constexpr int WG_NW = WG_NT / 64;
 constexpr int WG_R = 4;                  // records per thread and chunk in the pile-up path
-constexpr int WG_RS = 2;                 // raw form: records per thread whose loads are batched (WG_RR is a multiple)
+constexpr int WG_RS = 1;                 // raw form: records per thread decoded together (2 spills more than it hides: the kernel is VALU-bound)
 constexpr int WG_RR = 2;                 // raw form: records per thread and chunk
 
 // ---- partition ------------------------------------------------------------------------------------------------
