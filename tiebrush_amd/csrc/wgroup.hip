@@ -491,13 +491,15 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
   const uint32_t gcap = GC > 0 ? (uint32_t)GC : gcap_arg;
   const uint32_t nwords = GC > 0 ? 2u : nwords_arg;
   const uint32_t kcap = GC > 0 ? 64u : k;  // entries of the pieces' tables
-  const unsigned long long t_start = T.dbg ? __builtin_readcyclecounter() : 0ull;
+  // (the compile-time-layout form carries no instrumentation: TBK_WG_DEBUG runs take the general form)
+  unsigned long long* const dbg = GC > 0 ? nullptr : T.dbg;
+  const unsigned long long t_start = dbg ? __builtin_readcyclecounter() : 0ull;
   auto dbg_done = [&](int kind, uint32_t nrec) {
-    if (T.dbg && threadIdx.x == 0) {
-      atomicAdd(&T.dbg[kind * 4 + 0], __builtin_readcyclecounter() - t_start);
-      atomicAdd(&T.dbg[kind * 4 + 1], 1ull);
-      atomicAdd(&T.dbg[kind * 4 + 2], (unsigned long long)nrec);
-      atomicMax(&T.dbg[kind * 4 + 3], __builtin_readcyclecounter() - t_start);
+    if (dbg && threadIdx.x == 0) {
+      atomicAdd(&dbg[kind * 4 + 0], __builtin_readcyclecounter() - t_start);
+      atomicAdd(&dbg[kind * 4 + 1], 1ull);
+      atomicAdd(&dbg[kind * 4 + 2], (unsigned long long)nrec);
+      atomicMax(&dbg[kind * 4 + 3], __builtin_readcyclecounter() - t_start);
     }
   };
   // piece of item e (GC > 0: six steps without a branch over the table padded to 64 entries)
@@ -513,9 +515,9 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
   };
   unsigned long long t_last = t_start;
   auto phase = [&](int i) {  // thread 0's clock between phase marks (TBK_WG_DEBUG)
-    if (T.dbg && threadIdx.x == 0) {
+    if (dbg && threadIdx.x == 0) {
       const unsigned long long now = __builtin_readcyclecounter();
-      atomicAdd(&T.dbg[16 + i], now - t_last);
+      atomicAdd(&dbg[16 + i], now - t_last);
       t_last = now;
     }
   };
@@ -665,8 +667,8 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
       }
       if (errb) atomicOr(err, errb);
     }
-    if (T.dbg) {
-      if (t == 0 && (kh[0] ^ kl[0] ^ rec[0] ^ eff[0] ^ kh[NR - 1] ^ rec[NR - 1]) == 0x123456789ull) T.dbg[31] = 1;  // (the loads have landed)
+    if (dbg) {
+      if (t == 0 && (kh[0] ^ kl[0] ^ rec[0] ^ eff[0] ^ kh[NR - 1] ^ rec[NR - 1]) == 0x123456789ull) dbg[31] = 1;  // (the loads have landed)
       phase(2);
     }
 #pragma unroll
@@ -1344,7 +1346,7 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
 #define WG_L_HASH64(S)                                                                                                                       \
   TBK_LAUNCH(ctx, "wg_hash", (wg_hash_k<true, S, WG_GC64>), nw_live, WG_NT, WG_GC64 * 52u + 8u * 64u + 8u, In, R, T, gcap, nwords, seed, wlist, ovf, \
              ovf_cap, ctx->d_err)
-    if (raw && k <= 64) {  // compile-time table layout
+    if (raw && k <= 64 && !T.dbg) {  // compile-time table layout
       WG_BY_STRATEGY(WG_L_HASH64)
     } else if (raw) {
       WG_BY_STRATEGY(WG_L_HASH)
