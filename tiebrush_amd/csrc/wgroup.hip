@@ -874,7 +874,8 @@ __global__ __launch_bounds__(WG_NT, 6) void wg_hash_k(WgIn In, WgRaw R, WgTemp T
 }
 // second tier: the windows with more distinct groups than the first table holds (shallow data) against a table of WG_LDS_HASH2 bytes
 // (two blocks per CU); a fixed grid walks the first tier's worklist.  What overflows again goes to the sort kernel.
-template <bool RAW, int ST>
+constexpr int WG_GC64_2 = (WG_LDS_HASH2 - (8 * 64 + 8)) / (44 + 4 * 2);  // ... and of the second tier
+template <bool RAW, int ST, int GC>
 __global__ __launch_bounds__(WG_NT, 6) void wg_hash2_k(WgIn In, WgRaw R, WgTemp T, uint32_t gcap, uint32_t nwords, uint64_t seed,
                                                        const uint32_t* __restrict__ ovf_in, uint32_t* __restrict__ ovf, uint32_t ovf_cap,
                                                        uint32_t* __restrict__ err) {
@@ -885,7 +886,7 @@ __global__ __launch_bounds__(WG_NT, 6) void wg_hash2_k(WgIn In, WgRaw R, WgTemp 
   const uint32_t cnt = ovf_in[0] < ovf_cap ? ovf_in[0] : ovf_cap;
   for (uint32_t wi = blockIdx.x; wi < cnt; wi += gridDim.x) {
     __syncthreads();  // (LDS of the previous window is free)
-    wg_hash_window<3, RAW, RAW ? WG_RR : WG_R, ST, 0>(In, R, T, gcap, nwords, seed, ovf_in[1 + wi], lds, sm_u, s_misc, s_agg, ovf, ovf_cap, true, err);
+    wg_hash_window<3, RAW, RAW ? WG_RR : WG_R, ST, GC>(In, R, T, gcap, nwords, seed, ovf_in[1 + wi], lds, sm_u, s_misc, s_agg, ovf, ovf_cap, true, err);
   }
 }
 
@@ -1357,12 +1358,17 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
     const uint32_t lds_hash2 = gcap2 * (44u + 4u * nwords) + 8u * k + 8u;
     if (gcap2 < 65536u) {  // (slot numbers are 16-bit in the ranking)
 #define WG_L_HASH2(S)                                                                                                                      \
-  TBK_LAUNCH(ctx, "wg_hash2", (wg_hash2_k<true, S>), std::min<uint32_t>(nw_live, 512u), WG_NT, lds_hash2, In, R, T, gcap2, nwords, seed, ovf, ovf2, \
+  TBK_LAUNCH(ctx, "wg_hash2", (wg_hash2_k<true, S, 0>), std::min<uint32_t>(nw_live, 512u), WG_NT, lds_hash2, In, R, T, gcap2, nwords, seed, ovf, ovf2, \
              ovf_cap, ctx->d_err)
-      if (raw) {
+#define WG_L_HASH2_64(S)                                                                                                                     \
+  TBK_LAUNCH(ctx, "wg_hash2", (wg_hash2_k<true, S, WG_GC64_2>), std::min<uint32_t>(nw_live, 512u), WG_NT, WG_GC64_2 * 52u + 8u * 64u + 8u, In, R, \
+             T, gcap2, nwords, seed, ovf, ovf2, ovf_cap, ctx->d_err)
+      if (raw && k <= 64 && !T.dbg) {
+        WG_BY_STRATEGY(WG_L_HASH2_64)
+      } else if (raw) {
         WG_BY_STRATEGY(WG_L_HASH2)
       } else {
-        TBK_LAUNCH(ctx, "wg_hash2", (wg_hash2_k<false, -1>), std::min<uint32_t>(nw_live, 512u), WG_NT, lds_hash2, In, R, T, gcap2, nwords, seed, ovf,
+        TBK_LAUNCH(ctx, "wg_hash2", (wg_hash2_k<false, -1, 0>), std::min<uint32_t>(nw_live, 512u), WG_NT, lds_hash2, In, R, T, gcap2, nwords, seed, ovf,
                    ovf2, ovf_cap, ctx->d_err);
       }
       ovf = ovf2;
