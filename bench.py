@@ -11,7 +11,8 @@ Workload (BASELINE.json `configs`):
   N > 1   configs[3]'s shape: 32 files x 2M reads PER RANK (256 files over 8 GPUs), default CIGAR-only collapse; inside the
           timed step the ranks agree on bundle-aligned coordinate cuts (all-gather of sampled keys, all-reduce rounds),
           shuffle the passing records by coordinate (all-to-all over RCCL/xGMI) and each collapses + covers its own range
-          over ALL files (tiebrush_amd/dist.py).  Weak scaling: per-rank input is fixed.
+          over ALL files (tiebrush_amd/dist.py); the shuffle of step i + 1 overlaps the collapse / tiecov / YD of step i (two tail
+          contexts, every collective issued by the main thread).  Weak scaling: per-rank input is fixed.
 The tile is generated on the GPU (tiebrush_amd/synth_dev.py) before the timed region.
 
 Prints ONE JSON line (rank 0).  value = input alignment records collapsed per second, whole job, inputs resident in HBM.
@@ -89,6 +90,8 @@ def main():
     files = args.files_per_gpu or files
     reads = args.reads_per_file or reads
 
+    import threading
+
     from tiebrush_amd import api, synth, synth_dev
     tx = synth.make_transcriptome()
     t_gen = time.perf_counter()
@@ -108,17 +111,48 @@ def main():
     cbufs, vbufs = cbufs2[0], vbufs2[0]
     step_no = [0]
 
-    class StitchCompute:
-        """compute object of tiebrush_amd.dist: the same context, output buffers reused per call site"""
+    class TailCompute:
+        """what runs behind the shuffle (collapse of the owned range, device chain, tiecov, YD) on a context of its own"""
 
-        def __init__(self):
+        def __init__(self, cx):
+            self.cx = cx
             self.bufs = {}
 
         def collapse(self, tile, **kw):
-            return ctx.collapse(tile, out=self.bufs.setdefault(("c", tile.n_files, "prio" if tile.prio_hi is not None else ""), {}), **kw)
+            return self.cx.collapse(tile, out=self.bufs.setdefault(("c", tile.n_files), {}), **kw)
 
         def groups_to_cov_in(self, fin):
-            return ctx.groups_to_cov_in(fin)
+            return self.cx.groups_to_cov_in(fin)
+
+        def coverage(self, view):
+            return self.cx.coverage(view, out=self.bufs.setdefault("v", {}), raw=True)
+
+        def finish_yd(self):
+            self.cx.finish_yd()
+
+    class TailHandle:
+        def __init__(self):
+            self.res, self.err, self.th = None, None, None
+
+        def wait(self):
+            if self.th is not None:
+                self.th.join()
+                self.th = None
+            if self.err is not None:
+                raise self.err
+            return self.res
+
+    class StitchCompute:
+        """compute object of tiebrush_amd.dist.  The shuffle (merge keys, cuts, pack, unpack) runs on `ctx` in the calling
+        thread, which also issues every collective; what follows it — no collective inside — is handed over (submit_tail) to
+        one of two tail contexts with a thread each, so tile i's collapse / tiecov / YD overlap tile i + 1's shuffle and
+        exchange.  Receive buffers alternate with the tails."""
+
+        def __init__(self):
+            self.bufs = {}
+            self.tails = None                        # two contexts, created when the first tail is handed over
+            self.pending = [None, None]
+            self.turn = 0
 
         def shard_prepare(self, tile, **kw):
             return ctx.shard_prepare(tile, out=self.bufs.setdefault("sp", {}), **kw)
@@ -133,13 +167,32 @@ def main():
             return ctx.shard_pack(*a, out=self.bufs.setdefault("pk", {}))
 
         def shard_unpack(self, rows, file_off2):
-            return ctx.shard_unpack(rows, file_off2, out=self.bufs.setdefault("up", {}))
+            if self.pending[self.turn] is not None:      # the tail that still reads this set of receive buffers
+                self.pending[self.turn].wait()
+            return ctx.shard_unpack(rows, file_off2, out=self.bufs.setdefault(("up", self.turn), {}))
 
-        def finish_yd(self):
-            ctx.finish_yd()
+        def submit_tail(self, fn):
+            if self.tails is None:
+                self.tails = [TailCompute(api.Context(local_rank)) for _ in range(2)]
+            i = self.turn
+            self.turn ^= 1
+            h = TailHandle()
 
-        def coverage(self, view):
-            return ctx.coverage(view, out=self.bufs.setdefault("v", {}), raw=True)
+            def run():
+                try:
+                    h.res = fn(self.tails[i])
+                except BaseException as e:             # surfaces at wait(): a failed step fails the bench
+                    h.err = e
+
+            h.th = threading.Thread(target=run)
+            h.th.start()
+            self.pending[i] = h
+            return h
+
+        def drain(self):
+            for h in self.pending:
+                if h is not None:
+                    h.wait()
 
     from tiebrush_amd import dist as tdist
     stitch = StitchCompute()
@@ -148,8 +201,7 @@ def main():
         if use_dist:
             # bundle-aligned cuts (all-gather + all-reduce) -> all-to-all of the passing records over RCCL/xGMI -> one
             # collapse of the owned coordinate range over all files -> tiecov of it, everything resident in HBM
-            r = tdist.run_distributed(stitch, tile, rank * files, device=dev, want_coverage=True, device_chain=True, **strat)
-            return ({"n_passed": r.n_passed_local, "n_groups": r.n_groups}, r.coverage)
+            return tdist.run_distributed(stitch, tile, rank * files, device=dev, want_coverage=True, device_chain=True, **strat)
         i = step_no[0] % NCTX
         step_no[0] += 1
         cx = ctxs[i]
@@ -159,6 +211,9 @@ def main():
         return g, c
 
     def drain():
+        if use_dist:
+            stitch.drain()                                # every tail (collapse, tiecov, YD of its tile) has finished
+            return
         for cx in ctxs:
             cx.finish_yd()                                # every output of every step, YD included, is final here
 
@@ -166,7 +221,6 @@ def main():
     # caller while a stage runs and ctypes drops the GIL meanwhile): tile i + 1's collapse runs beside tile i's tiecov chain and
     # YD stage — what a streaming host with two workers does.  Launch-bound workloads (config 2) gain most; config 3 keeps the GPU
     # busy either way.
-    import threading
     last = [None] * NCTX
 
     def run_steps(k):
@@ -212,7 +266,11 @@ def main():
     dt = time.perf_counter() - t0
     free_b, total_b = torch.cuda.mem_get_info(dev)
     hbm_used_gb = round((total_b - free_b) / 1e9, 1)      # tile + every context's arena and outputs, after the timed region
-    g, c = next(x for x in last if x is not None)
+    if use_dist:
+        r = last[0].wait()
+        g, c = {"n_passed": r.n_passed_local, "n_groups": r.n_groups}, r.coverage
+    else:
+        g, c = next(x for x in last if x is not None)
     n_passed, n_groups = g["n_passed"], g["n_groups"]
     n_bases, span, n_iv, n_j = c["n_bases"], c["span_bases"], c["n_intervals"], c["n_junctions"]
     stats = torch.tensor([dt, float(n_passed), float(n_bases)], dtype=torch.float64,
