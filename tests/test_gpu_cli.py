@@ -46,6 +46,27 @@ def test_tiebrush_cli_on_samples(tmp_path, name):
     assert hdr.is_tiebrush() and len(hdr.co_samples()) == 10 and hdr.co_samples()[0].endswith(name + "s0.bam")
 
 
+@pytest.mark.parametrize("name", ["t1", "t2"])
+@pytest.mark.parametrize("flag", ["-P", "--exon"])
+def test_tiebrush_cli_clip_exon_equal_golden(tmp_path, name, flag):
+    """-P / -E on M/N-only fixtures reproduce the default-mode golden BAMs"""
+    out = str(tmp_path / "o.bam")
+    _run([os.path.join(BIN, "tiebrush"), "-A", flag, "-o", out] + sample_paths(name))
+    _compare_bam(out, os.path.join(GOLDEN, name, name + ".bam"))
+
+
+@pytest.mark.parametrize("flag", ["--clip", "-E"])
+def test_tiebrush_cli_recollapse_clip_exon(tmp_path, flag):
+    from tiebrush_amd import bamio
+    out = str(tmp_path / "t12.bam")
+    _run([os.path.join(BIN, "tiebrush"), "-A", flag, "-o", out, os.path.join(GOLDEN, "t1", "t1.bam"), os.path.join(GOLDEN, "t2", "t2.bam")])
+    o, g = bamio.read_bam(out), bamio.read_bam(os.path.join(GOLDEN, "t12.bam"))
+    assert o.n == g.n == 9491
+    for i in range(g.n):
+        assert bamio.record_identity(o, i) == bamio.record_identity(g, i)
+        assert o.yx[i] == g.yx[i] and o.yd[i] == g.yd[i]
+
+
 def test_tiebrush_cli_recollapse_and_listfile(tmp_path):
     lst = tmp_path / "inputs.txt"
     lst.write_text("# list of inputs\n%s\n%s\n" % (os.path.join(GOLDEN, "t1", "t1.bam"), os.path.join(GOLDEN, "t2", "t2.bam")))

@@ -46,6 +46,25 @@ def test_golden_samples(ctx, name, bam_loader):
     _check(ctx, tile, device=False)                         # host-pointer mode
 
 
+@pytest.mark.parametrize("name", ["t1", "t2", "t12"])
+@pytest.mark.parametrize("strategy", ["clip", "exon"])
+def test_golden_clip_exon(ctx, name, strategy, bam_loader):
+    """fixture CIGARs are M/N only, so -P and -E must give the golden BAMs too (the reference-held pin of the
+    strategy code of configs 3 and 5: cmpCigarClip tiebrush.cpp:312-332, cmpExons :334-345)"""
+    from tiebrush_amd import soa
+    if name == "t12":
+        paths = [os.path.join(GOLDEN, "t1", "t1.bam"), os.path.join(GOLDEN, "t2", "t2.bam")]
+        gold = bam_loader(os.path.join(GOLDEN, "t12.bam"))
+    else:
+        paths = sample_paths(name)
+        gold = bam_loader(os.path.join(GOLDEN, name, name + ".bam"))
+    bams = [bam_loader(p) for p in paths]
+    tile = soa.tile_from_bams(bams, with_names=True)
+    got, _ = _check(ctx, tile, collapse_same=True, strategy=strategy)
+    assert compare_groups_to_golden_bam(got, tile, bams, gold) == []
+    _check(ctx, tile, strategy=strategy)                    # HEAD default (-A off), window / sort path as the tile size picks
+
+
 def test_golden_t12_tbmerged(ctx, bam_loader):
     from tiebrush_amd import soa
     bams = [bam_loader(os.path.join(GOLDEN, "t1", "t1.bam")), bam_loader(os.path.join(GOLDEN, "t2", "t2.bam"))]

@@ -30,6 +30,29 @@ def test_collapse_samples_to_tissue(name, n_in, n_out, bam_loader):
     assert np.array_equal(head["rep"], res["rep"]) and np.array_equal(head["yd"], res["yd"])
 
 
+@pytest.mark.parametrize("name", ["t1", "t2"])
+@pytest.mark.parametrize("strategy", [2, 3])
+def test_collapse_samples_clip_exon_equal_golden(name, strategy, bam_loader):
+    """the fixture CIGARs hold only M and N, so -P (cmpCigarClip, tiebrush.cpp:312-332) and -E (cmpExons,
+    :334-345) must reproduce the golden BAMs record for record — the only reference-held evidence for the strategy code
+    of configs 3 and 5."""
+    bams = [bam_loader(p) for p in sample_paths(name)]
+    tile = soa.tile_from_bams(bams, with_names=True)
+    gold = bam_loader(os.path.join(GOLDEN, name, name + ".bam"))
+    res = orc.collapse(tile, collapse_same=True, strategy=strategy)
+    assert compare_groups_to_golden_bam(res, tile, bams, gold) == []
+
+
+@pytest.mark.parametrize("strategy", [2, 3])
+def test_recollapse_tbmerged_t12_clip_exon(strategy, bam_loader):
+    bams = [bam_loader(os.path.join(GOLDEN, "t1", "t1.bam")), bam_loader(os.path.join(GOLDEN, "t2", "t2.bam"))]
+    tile = soa.tile_from_bams(bams, with_names=True)
+    gold = bam_loader(os.path.join(GOLDEN, "t12.bam"))
+    res = orc.collapse(tile, collapse_same=True, strategy=strategy)
+    assert res["n_groups"] == 9491
+    assert compare_groups_to_golden_bam(res, tile, bams, gold) == []
+
+
 def test_recollapse_tbmerged_t12(bam_loader):
     bams = [bam_loader(os.path.join(GOLDEN, "t1", "t1.bam")), bam_loader(os.path.join(GOLDEN, "t2", "t2.bam"))]
     tile = soa.tile_from_bams(bams, with_names=True)
