@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TBK_ABI_VERSION 2
+#define TBK_ABI_VERSION 3
 
 typedef struct tbk_ctx tbk_ctx;
 
@@ -276,6 +276,36 @@ int tbk_shard_pack(tbk_ctx* ctx, const tbk_soa_in* in, const int64_t* key, const
  * n_cigar column, prio_hi = effend, prio_lo = file << 32 | index in file. */
 int tbk_shard_unpack(tbk_ctx* ctx, const int32_t* rows, uint32_t n2, const uint32_t* file_off2, uint32_t K, int32_t* tid, int32_t* pos,
                      uint16_t* flag, uint8_t* mapq, uint8_t* strand, int32_t* nh, uint32_t* cig_off, int64_t* prio_hi, int64_t* prio_lo);
+
+/* ---- Multi-GPU: collapse locally, exchange group partials (ABI version 3).  Every rank runs
+ * tbk_collapse_tile on its own files and ships ONE row per local group to the rank that owns the group's coordinate range:
+ * {key fields, local YC / YX / YD, merge priority (effective end, file, index) of the local representative} plus that
+ * representative's CIGAR.  The owner collapses the partials as TieBrush-merged records with explicit priorities — sum YC, sum
+ * YX, max YD, argmin priority: SPData::dupAdd is associative (tiebrush.cpp:408-436) and GSegList::processRead reads only the
+ * representative's start and exons, equal for every member of a group (:225-249, call site :511-524), so the YD of a
+ * sample's list is final on the rank that holds the sample.  The reference's own ancestor of this is tiewrap.py:96-126
+ * (batches re-collapsed hierarchically); unlike it, the explicit priority keeps the flat run's representative.  Exact for
+ * integral YC; carried fractional YC (inputs written with --store-frac) needs the record shuffle above. */
+
+/* Per local group o of `g` (output order; g_start / g_end required): key[o] = (tid + 1) << 31 | start and emax[o] = running
+ * maximum over the groups <= o of (tid + 1) << 31 | (end + 1) — what tbk_shard_probe_max / _next take with one "file" of
+ * n_groups entries.  *not_packable (host) = 1 when some YC is not an integer in [1, 2^31) or some YX does not fit 31 bits: the
+ * caller must then take the record shuffle. */
+int tbk_partial_keys(tbk_ctx* ctx, const tbk_soa_in* in, const tbk_groups_out* g, int64_t* key, int64_t* emax, uint32_t* not_packable);
+/* rows[n_groups][TBK_PARTIAL_ROW] (int32) = {tid, pos, strand | n_cigar << 8, effective end of the representative, its global
+ * file index (first_fidx + local file), its index inside that file, YC, YX, YD, 0} and the representatives' CIGAR words, both
+ * in group order: the groups of destination d (cuts[d - 1] <= key < cuts[d]) are contiguous.  tab[world][3] (int64, device) =
+ * {first group, rows, words} per destination.  g must carry rep_effend and a final yd (tbk_collapse_finish_yd). */
+#define TBK_PARTIAL_ROW 10
+int tbk_partial_pack(tbk_ctx* ctx, const tbk_soa_in* in, const tbk_groups_out* g, const int64_t* key, const int64_t* cuts, uint32_t world,
+                     uint32_t first_fidx, int32_t* rows, uint32_t* cig_out, int64_t* tab);
+/* Received rows (one run per source rank, each in that rank's output order) -> the SoA arrays of a tile whose "files" are the
+ * source ranks, all flagged tbmerged: flag 0, mapq 255, NH absent, cig_off (n2 + 1 entries), yc_in / yx_in / yd_in = the
+ * partial's YC / YX / YD, prio_hi = effective end, prio_lo = global file << 32 | index in file.  tbk_collapse_tile on that
+ * tile (every filter open) is the reduce-by-key of §8e. */
+int tbk_partial_unpack(tbk_ctx* ctx, const int32_t* rows, uint32_t n2, int32_t* tid, int32_t* pos, uint16_t* flag, uint8_t* mapq,
+                       uint8_t* strand, int32_t* nh, uint32_t* cig_off, double* yc_in, int64_t* yx_in, int64_t* yd_in, int64_t* prio_hi,
+                       int64_t* prio_lo);
 
 #ifdef __cplusplus
 }

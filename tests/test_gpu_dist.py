@@ -1,6 +1,7 @@
 """Multi-rank path with the real HIP compute: R virtual ranks on the one GPU of the box (loopback driver), checked
-against the flat oracle result.  Host tiles take the numpy restatement of the shuffle around the HIP collapse (explicit
-priorities); device-resident tiles take the tbk_shard_* kernels end to end."""
+against the flat oracle result, in both protocols: "partials" (local collapse -> tbk_partial_* -> the owner's collapse of the
+partials, window path in its PART form for tiles >= 64 Ki partials or under TBK_PATH=window) and "shuffle" (tbk_shard_*).  Host
+tiles take the numpy restatement of the device steps around the HIP collapse; device-resident tiles the kernels end to end."""
 import numpy as np
 import pytest
 
@@ -22,19 +23,20 @@ class GpuCompute:
         return self.api.to_numpy(self.ctx.coverage(cin))
 
 
+@pytest.mark.parametrize("mode", ["partials", "shuffle"])
 @pytest.mark.parametrize("world,profile,strategy,kw", [
     (2, "c2", "cigar", {}),
     (4, "c3", "clip", {}),
     (8, "c5", "exon", dict(max_nh=5, min_qual=1)),
 ])
-def test_loopback_gpu_equals_flat_oracle(world, profile, strategy, kw):
+def test_loopback_gpu_equals_flat_oracle(world, profile, strategy, kw, mode):
     from oracle import oracle_ffi as orc
     from tiebrush_amd import dist, synth
     tile = synth.make_tile(world * 2, 20000, profile, n_loci=800)
     flat = orc.collapse(tile, strategy=STRAT[strategy], **kw)
     flat_cov = orc.coverage(synth.collapsed_to_cov_input(tile, flat))
     tiles, first = split_tile(tile, world)
-    res = dist.run_loopback(GpuCompute(), tiles, first, strategy=strategy, want_coverage=True, **kw)
+    res = dist.run_loopback(GpuCompute(), tiles, first, strategy=strategy, want_coverage=True, mode=mode, **kw)
     check_against_flat(res, tile, flat, flat_cov)
 
 
@@ -63,8 +65,8 @@ class DeviceCompute:
     def groups_to_cov_in(self, fin):
         return self.ctx.groups_to_cov_in(fin)
 
-    def __getattr__(self, name):          # tbk_shard_prepare / _probe_* / _pack / _unpack
-        if name.startswith("shard_"):
+    def __getattr__(self, name):          # tbk_shard_* / tbk_partial_*
+        if name.startswith("shard_") or name.startswith("partial_"):
             return getattr(self.ctx, name)
         raise AttributeError(name)
 
@@ -76,16 +78,21 @@ class DeviceCompute:
         return api.to_numpy(self.ctx.coverage(view))
 
 
+@pytest.mark.parametrize("mode,path", [("partials", None), ("partials", "window"), ("shuffle", None)])
 @pytest.mark.parametrize("world,nfiles,profile,strategy,kw", [
     (4, 8, "c2", "cigar", {}),
     (3, 7, "c3", "clip", {}),
     (8, 16, "c5", "exon", dict(max_nh=5, min_qual=1)),
     (2, 2, "c2", "cigar", dict(keep_secondary=True)),
     (1, 3, "c2", "cigar", {}),
-    (8, 256, "c2", "cigar", {}),      # BASELINE.json configs[3]'s shape: 256 files, 32 per rank, 8 ranks (every rank's tile has 256 runs)
+    (8, 256, "c2", "cigar", {}),      # BASELINE.json configs[3]'s shape: 256 files, 32 per rank, 8 ranks
     (8, 1024, "c5", "exon", dict(max_nh=5, min_qual=1)),   # configs[4]'s shape: 1024 files over 8 ranks
 ])
-def test_loopback_device_resident_equals_flat_oracle(world, nfiles, profile, strategy, kw):
+def test_loopback_device_resident_equals_flat_oracle(world, nfiles, profile, strategy, kw, mode, path, monkeypatch):
+    """path = "window": TBK_PATH forces the window path wherever it applies — the owner's reduce of the partials then runs in the
+    PART form of wg_hash_k / wg_hash2_k / wg_sort_k (wgroup.hip) also on these small tiles"""
+    if path:
+        monkeypatch.setenv("TBK_PATH", path)
     import torch
     from oracle import oracle_ffi as orc
     from tiebrush_amd import api, dist, synth
@@ -96,7 +103,7 @@ def test_loopback_device_resident_equals_flat_oracle(world, nfiles, profile, str
     dtiles = [api.to_device(t, "cuda:0") for t in tiles]
     comp = DeviceCompute()
     # the device chain view lives in context memory until the next call: run coverage inside each rank's turn
-    res = dist.run_loopback(comp, dtiles, first, strategy=strategy, want_coverage=True, device_chain=True, **kw)
+    res = dist.run_loopback(comp, dtiles, first, strategy=strategy, want_coverage=True, device_chain=True, mode=mode, **kw)
     for r in res:
         for f in ("tid", "start", "end", "rep_fidx", "rep_idx", "yc", "yx", "yd"):
             v = getattr(r, f)
@@ -104,8 +111,76 @@ def test_loopback_device_resident_equals_flat_oracle(world, nfiles, profile, str
     check_against_flat(res, tile, flat, flat_cov)
 
 
+@pytest.mark.parametrize("strategy,kw", [("cigar", {}), ("exon", dict(max_nh=5, min_qual=1))])
+def test_loopback_8_ranks_32x200k_per_rank(strategy, kw):
+    """8 virtual ranks x 32 files x 200 k reads (51 M records, generated on the GPU): every local collapse takes the raw window
+    path, every owner's reduce the PART window path at ~ 0.5-1 M partials, exact against the flat oracle run"""
+    import torch
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import dist, synth, synth_dev
+    world, fpr, reads = 8, 32, 200_000
+    profile = "c2" if strategy == "cigar" else "c5"
+    tx = synth.make_transcriptome()
+    dtiles = [synth_dev.make_tile_device(fpr, reads, profile, device="cuda:0", first_file=r * fpr, tx=tx) for r in range(world)]
+    first = [r * fpr for r in range(world)]
+    comp = DeviceCompute()
+    res = dist.run_loopback(comp, dtiles, first, strategy=strategy, want_coverage=True, device_chain=True, **kw)
+    assert max(r.n_partials_received for r in res) >= 65536          # the PART window form ran
+    for r in res:
+        for f in ("tid", "start", "end", "rep_fidx", "rep_idx", "yc", "yx", "yd"):
+            v = getattr(r, f)
+            setattr(r, f, v.cpu().numpy() if isinstance(v, torch.Tensor) else v)
+    host = [synth_dev.tile_to_host(t) for t in dtiles]
+    del dtiles
+    torch.cuda.empty_cache()
+    from tiebrush_amd.soa import SoATile
+    fo = np.concatenate([[0], np.cumsum(np.concatenate([np.diff(h.file_off.astype(np.int64)) for h in host]))]).astype(np.uint32)
+    co = np.concatenate([[0], np.cumsum(np.concatenate([np.diff(h.cig_off.astype(np.int64)) for h in host]))]).astype(np.uint32)
+    cat = lambda name: np.concatenate([getattr(h, name) for h in host])
+    tile = SoATile(n_files=world * fpr, file_off=fo, tbmerged=np.zeros(world * fpr, np.uint8), tid=cat("tid"), pos=cat("pos"), flag=cat("flag"),
+                   mapq=cat("mapq"), strand=cat("strand"), nh=cat("nh"), cig_off=co, cig=cat("cig"))
+    del host
+    flat = orc.collapse(tile, strategy=STRAT[strategy], **kw)
+    flat_cov = orc.coverage(synth.collapsed_to_cov_input(tile, flat))
+    check_against_flat(res, tile, flat, flat_cov)
+
+
+def test_part_form_refuses_what_it_cannot_hold():
+    """a partial tile with a fractional carried YC under TBK_PATH=window: the PART kernels raise TBK_DERR_FRACTIONAL and the tile
+    takes the sort path's ordered sums — the result is the oracle's"""
+    import os
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import api, synth
+    tile = synth.make_tile(3, 30000, "c3", n_loci=300)
+    n = tile.n_records
+    rng = np.random.default_rng(9)
+    tile.tbmerged = np.ones(3, np.uint8)
+    tile.yc_in = (rng.integers(1, 9, n) / 4.0).astype(np.float32).astype(np.float64)
+    tile.yx_in = rng.integers(1, 4, n).astype(np.int64)
+    tile.yd_in = rng.integers(0, 50, n).astype(np.int64)
+    tile.prio_hi = rng.integers(0, 1000, n).astype(np.uint64)
+    tile.prio_lo = rng.permutation(n).astype(np.uint64)
+    from dist_helpers import OracleCompute
+    want = OracleCompute().collapse(tile, strategy="clip")
+    ctx = api.Context(0)
+    os.environ["TBK_PATH"] = "window"
+    try:
+        got = api.to_numpy(ctx.collapse(api.to_device(tile, "cuda:0"), strategy="clip"))
+        tile.yc_in = np.rint(tile.yc_in * 4.0)                     # integral: the PART form holds it
+        want2 = OracleCompute().collapse(tile, strategy="clip")
+        got2 = api.to_numpy(ctx.collapse(api.to_device(tile, "cuda:0"), strategy="clip"))
+    finally:
+        del os.environ["TBK_PATH"]
+    for g, w in ((got, want), (got2, want2)):
+        assert g["n_groups"] == w["n_groups"]
+        for k in ("rep", "yc", "yx", "yd", "g_start", "g_end"):
+            assert np.array_equal(np.asarray(g[k]), np.asarray(w[k])), k
+    ctx.close()
+
+
+@pytest.mark.parametrize("mode", ["partials", "shuffle"])
 @pytest.mark.parametrize("world", [2, 4])
-def test_loopback_device_resident_tbmerged_inputs(world, bam_loader):
+def test_loopback_device_resident_tbmerged_inputs(world, bam_loader, mode):
     """carried YC / YX / YD of TieBrush-merged inputs through the device shuffle (third all-to-all + gathered file flags)"""
     import os
     import torch
@@ -119,12 +194,39 @@ def test_loopback_device_resident_tbmerged_inputs(world, bam_loader):
     flat_cov = orc.coverage(__import__("tiebrush_amd.synth", fromlist=["x"]).collapsed_to_cov_input(tile, flat))
     tiles, first = split_tile(tile, world)
     dtiles = [api.to_device(t, "cuda:0") for t in tiles]
-    res = dist.run_loopback(DeviceCompute(), dtiles, first, want_coverage=True, device_chain=True)
+    res = dist.run_loopback(DeviceCompute(), dtiles, first, want_coverage=True, device_chain=True, mode=mode)
     for r in res:
         for f in ("tid", "start", "end", "rep_fidx", "rep_idx", "yc", "yx", "yd"):
             v = getattr(r, f)
             setattr(r, f, v.cpu().numpy() if isinstance(v, torch.Tensor) else v)
     check_against_flat(res, tile, flat, flat_cov)
+
+
+def test_partial_kernels_match_host_restatement():
+    """tbk_partial_keys / _pack / _unpack against the numpy restatement dist.py uses for host tiles"""
+    import torch
+    from tiebrush_amd import api, dist, synth
+    tile = synth.make_tile(5, 20000, "c5", n_loci=400)
+    ctx = api.Context(0)
+    dt = api.to_device(tile, "cuda:0")
+    kw = dict(strategy="exon", max_nh=5, min_qual=1)
+    fin = ctx.collapse(dt, want_coords=True, want_effend=True, **kw)
+    hfin = api.to_numpy(fin)
+    key, emax, bad = ctx.partial_keys(dt, fin)
+    hk, hm, hb = dist._partial_keys_np(tile, hfin)
+    assert bad == hb == 0 and np.array_equal(key.cpu().numpy(), hk) and np.array_equal(emax.cpu().numpy(), hm)
+    ng = fin["n_groups"]
+    cuts_h = np.array([hk[ng // 3], hk[(2 * ng) // 3] + 1, dist.KEY_INF], np.int64)
+    cuts = torch.from_numpy(cuts_h).cuda()
+    rows, cigw, tab = ctx.partial_pack(dt, fin, key, cuts, 4, 100)
+    hr, hc, ht = dist._partial_pack_np(tile, hfin, hk, cuts_h, 4, 100)
+    assert np.array_equal(tab.cpu().numpy(), ht) and np.array_equal(rows.cpu().numpy(), hr)
+    assert np.array_equal(cigw.cpu().numpy()[:len(hc)].view(np.uint32), hc)
+    A = ctx.partial_unpack(rows)
+    hA = dist._partial_unpack_np(hr)
+    for k, v in hA.items():
+        assert np.array_equal(A[k].cpu().numpy().view(v.dtype), v), k
+    ctx.close()
 
 
 def test_shard_prepare_matches_host_restatement_and_rejects_unsorted():
@@ -152,7 +254,7 @@ def test_shard_prepare_matches_host_restatement_and_rejects_unsorted():
     ctx.close()
 
 
-def _two_proc_worker(rank, world, port, q):
+def _two_proc_worker(rank, world, port, q, mode):
     import os
     import sys
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -168,7 +270,7 @@ def _two_proc_worker(rank, world, port, q):
     tile = synth.make_tile(6, 20000, "c3", n_loci=600)
     tiles, first = split_tile(tile, world)
     dt = api.to_device(tiles[rank], "cuda:0")
-    r = dist.run_distributed(DeviceCompute(), dt, first[rank], want_coverage=True, device_chain=True, strategy="clip")
+    r = dist.run_distributed(DeviceCompute(), dt, first[rank], want_coverage=True, device_chain=True, strategy="clip", mode=mode)
     for f in ("tid", "start", "end", "rep_fidx", "rep_idx", "yc", "yx", "yd"):
         v = getattr(r, f)
         setattr(r, f, v.cpu().numpy() if isinstance(v, torch.Tensor) else v)
@@ -178,7 +280,8 @@ def _two_proc_worker(rank, world, port, q):
     td.destroy_process_group()
 
 
-def test_two_processes_device_path():
+@pytest.mark.parametrize("mode", ["partials", "shuffle"])
+def test_two_processes_device_path(mode):
     """Two real processes (torch.distributed, gloo staging the device tensors through the host) sharing the one GPU of
     the box, each with its own context and the HIP shuffle kernels: the multi-process protocol end to end.  (RCCL itself
     needs one GPU per rank and runs in the driver's scaling bench.)"""
@@ -189,7 +292,7 @@ def test_two_processes_device_path():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29700 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_two_proc_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_two_proc_worker, args=(r, 2, port, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=240) for _ in range(2))
@@ -202,8 +305,9 @@ def test_two_processes_device_path():
     check_against_flat([got[0], got[1]], tile, flat, flat_cov)
 
 
+@pytest.mark.parametrize("mode", ["partials", "shuffle"])
 @pytest.mark.parametrize("world", [1, 2, 4])
-def test_loopback_device_real_bam_shapes(world):
+def test_loopback_device_real_bam_shapes(world, mode):
     """as tests/test_dist_cpu.py::test_loopback_real_bam_shapes, through the tbk_shard_* kernels (the keys stay monotone over
     unmapped and unplaced reads; an empty rank passes null arrays)"""
     import torch
@@ -215,7 +319,7 @@ def test_loopback_device_real_bam_shapes(world):
     flat_cov = orc.coverage(synth.collapsed_to_cov_input(tile, flat))
     tiles, first = split_tile(tile, world)
     dtiles = [api.to_device(t, "cuda:0") for t in tiles]
-    res = dist.run_loopback(DeviceCompute(), dtiles, first, want_coverage=True, device_chain=True)
+    res = dist.run_loopback(DeviceCompute(), dtiles, first, want_coverage=True, device_chain=True, mode=mode)
     for r in res:
         for f in ("tid", "start", "end", "rep_fidx", "rep_idx", "yc", "yx", "yd"):
             v = getattr(r, f)

@@ -110,9 +110,20 @@ def _properties(ctx, tile, **kw):
     dt = tile if api._is_torch(tile.tid) else api.to_device(tile, "cuda:0")
     res = ctx.collapse(dt, want_rec_group=True, **kw)
     g = res["n_groups"]
-    assert res["n_passed"] == n                                   # config 2/3 inputs pass every filter
+    # passes_options (tiebrush.cpp:532-541) counted on the device, independently of the kernels under test
+    fl = dt.flag.to(torch.int32) & 0xFFFF
+    ok = (fl & 0x4) == 0
+    if not kw.get("keep_supplementary"):
+        ok &= (fl & 0x800) == 0
+    if not kw.get("keep_secondary"):
+        ok &= (fl & 0x100) == 0
+    ok &= dt.mapq.to(torch.int32) >= kw.get("min_qual", -1)
+    ok &= torch.where(dt.nh == -(2**31), torch.zeros_like(dt.nh), dt.nh) <= kw.get("max_nh", 2**31 - 1)
+    n_pass = int(ok.sum())
+    del fl
+    assert res["n_passed"] == n_pass
     yc, yx, yd, rep = res["yc"], res["yx"], res["yd"], res["rep"].to(torch.int64) & 0xFFFFFFFF
-    assert float(yc.sum()) == float(n)                            # every passing record is counted exactly once
+    assert float(yc.sum()) == float(n_pass)                       # every passing record is counted exactly once
     assert int(yx.min()) >= 1 and int(yx.max()) <= tile.n_files and int(yd.min()) >= 0
     # output order: buckets by (tid,start); inside a bucket strand code then end
     tid = dt.tid[rep].to(torch.int64)
@@ -124,10 +135,10 @@ def _properties(ctx, tile, **kw):
     del key, same, code, tid
     # rec_group: every record belongs to one group, group sizes add up to YC, the representative is a member
     rg = res["rec_group"].to(torch.int64)
-    assert int(rg.min()) >= 0 and int(rg.max()) == g - 1
-    assert torch.equal(torch.bincount(rg, minlength=g).to(torch.float64), yc)
+    assert torch.equal(rg >= 0, ok) and int(rg.max()) == g - 1    # a record has a group iff it passes the filters
+    assert torch.equal(torch.bincount(rg[ok], minlength=g).to(torch.float64), yc)
     assert torch.equal(rg[rep], torch.arange(g, device=rg.device))
-    del rg
+    del rg, ok
     # tiecov checksum on the collapsed records
     view = ctx.groups_to_cov_in(res)
     cov = ctx.coverage(view)
@@ -177,6 +188,22 @@ def test_properties_config3_full_64x5M(ctx):
     from tiebrush_amd import synth_dev
     tile = synth_dev.make_tile_device(64, 5_000_000, "c3", device="cuda:0")
     g, ni = _properties(ctx, tile, strategy="clip")
+    assert 0 < g < tile.n_records
+    del tile
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("files,reads,profile,kw", [
+    (32, 2_000_000, "c2", {}),                                               # configs[3]: what one of the 8 ranks holds
+    (128, 1_000_000, "c5", dict(strategy="exon", max_nh=5, min_qual=1)),     # configs[4]: 1024 / 8 files, --exon -N 5 -Q 1
+])
+def test_properties_per_rank_shapes_config4_config5(ctx, files, reads, profile, kw):
+    """BASELINE.json configs[3] / [4] at the full size one rank sees, generated on the GPU; the filters of config 5 drop records,
+    so the expected counts come from a device-side evaluation of passes_options"""
+    import torch
+    from tiebrush_amd import synth_dev
+    tile = synth_dev.make_tile_device(files, reads, profile, device="cuda:0")
+    g, ni = _properties(ctx, tile, **kw)
     assert 0 < g < tile.n_records
     del tile
     torch.cuda.empty_cache()

@@ -123,7 +123,7 @@ class Context:
 
     def use_torch_stream(self):
         """Launch on torch's current stream so that torch ops and our kernels order correctly."""
-        s = _torch().cuda.current_stream().cuda_stream
+        s = _torch().cuda.current_stream(self.device).cuda_stream
         self._check(self.L.tbk_set_stream(self.h, C.c_void_p(s)), "tbk_set_stream")
         self._on_torch_stream = True
 
@@ -131,7 +131,7 @@ class Context:
         """Device inputs were produced on torch's stream; the context launches on its own stream unless
         use_torch_stream() was called: make the producer visible first."""
         if dev and not self._on_torch_stream:
-            _torch().cuda.current_stream().synchronize()
+            _torch().cuda.current_stream(self.device).synchronize()   # (of THIS context's device: the current device is per thread)
 
     def last_message(self) -> str:
         return (self.L.tbk_last_error(self.h) or b"").decode()
@@ -413,6 +413,58 @@ class Context:
         rows = rows.contiguous()
         self._check(self.L.tbk_shard_unpack(self.h, C.c_void_p(rows.data_ptr()) if n2 else None, n2, fo.ctypes.data, len(fo) - 1,
                                             *[C.c_void_p(bufs[name].data_ptr()) for name, _, _ in spec]), "tbk_shard_unpack")
+        return {name: bufs[name][:cnt] for name, _, cnt in spec}
+
+    # ---- multi-GPU: collapse locally, exchange group partials (device side of tiebrush_amd.dist.partials_collapse) ------
+    def partial_keys(self, tile: SoATile, fin, out=None):
+        """tbk_partial_keys: (key [ng], emax [ng], not_packable) of the local groups in `fin` (a collapse() result with
+        want_coords=True)."""
+        torch = _torch()
+        ng = int(fin["n_groups"])
+        bufs = out if out is not None else {}
+        for name in ("pkey", "pemax"):
+            if name not in bufs or bufs[name].numel() < max(ng, 1):
+                bufs[name] = torch.empty(max(ng, 1), dtype=torch.int64, device=self._dev())
+        bad = C.c_uint32(0)
+        self._order_after_torch(True)
+        self._check(self.L.tbk_partial_keys(self.h, C.byref(fin["_soa"]), C.byref(fin["_struct"]), C.c_void_p(bufs["pkey"].data_ptr()),
+                                            C.c_void_p(bufs["pemax"].data_ptr()), C.byref(bad)), "tbk_partial_keys")
+        return bufs["pkey"][:ng], bufs["pemax"][:ng], int(bad.value)
+
+    def partial_pack(self, tile: SoATile, fin, key, cuts, world, first_fidx, out=None):
+        """tbk_partial_pack: (rows [ng, 10] int32, cig words, tab [world, 3] int64) of the local groups (fin needs want_effend=True
+        and a final yd)."""
+        torch = _torch()
+        ng = int(fin["n_groups"])
+        nc = _numel(tile.cig)
+        bufs = out if out is not None else {}
+        if "prows" not in bufs or bufs["prows"].shape[0] < max(ng, 1):
+            bufs["prows"] = torch.empty((max(ng, 1), 10), dtype=torch.int32, device=self._dev())
+        if "pcig" not in bufs or bufs["pcig"].numel() < max(nc, 1):
+            bufs["pcig"] = torch.empty(max(nc, 1), dtype=torch.int32, device=self._dev())
+        tab = torch.empty((world, 3), dtype=torch.int64, device=self._dev())
+        self._order_after_torch(True)
+        self._check(self.L.tbk_partial_pack(self.h, C.byref(fin["_soa"]), C.byref(fin["_struct"]), C.c_void_p(key.data_ptr()) if ng else None,
+                                            C.c_void_p(cuts.data_ptr()) if world > 1 else None, int(world), int(first_fidx),
+                                            C.c_void_p(bufs["prows"].data_ptr()), C.c_void_p(bufs["pcig"].data_ptr()),
+                                            C.c_void_p(tab.data_ptr())), "tbk_partial_pack")
+        return bufs["prows"][:ng], bufs["pcig"], tab
+
+    def partial_unpack(self, rows, out=None):
+        """tbk_partial_unpack: the SoA arrays (torch tensors) of the received partial rows."""
+        torch = _torch()
+        n2 = int(rows.shape[0])
+        bufs = out if out is not None else {}
+        spec = (("tid", torch.int32, n2), ("pos", torch.int32, n2), ("flag", torch.int16, n2), ("mapq", torch.uint8, n2),
+                ("strand", torch.uint8, n2), ("nh", torch.int32, n2), ("cig_off", torch.int32, n2 + 1), ("yc_in", torch.float64, n2),
+                ("yx_in", torch.int64, n2), ("yd_in", torch.int64, n2), ("prio_hi", torch.int64, n2), ("prio_lo", torch.int64, n2))
+        for name, dt, cnt in spec:
+            if name not in bufs or bufs[name].numel() < max(cnt, 1):
+                bufs[name] = torch.empty(max(cnt, 1), dtype=dt, device=self._dev())
+        self._order_after_torch(True)
+        rows = rows.contiguous()
+        self._check(self.L.tbk_partial_unpack(self.h, C.c_void_p(rows.data_ptr()) if n2 else None, n2,
+                                              *[C.c_void_p(bufs[name].data_ptr()) for name, _, _ in spec]), "tbk_partial_unpack")
         return {name: bufs[name][:cnt] for name, _, cnt in spec}
 
     # ---- coverage -----------------------------------------------------------------------------

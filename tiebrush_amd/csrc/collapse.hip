@@ -272,13 +272,14 @@ __global__ void col_same_k(ColIn I, ColOpt O, const uint64_t* __restrict__ pm, c
 // counts are exact in any order; fractional terms are not, so the members of every group are re-sorted by
 // (group, effend) — stable, hence (effend, record index) = merge order — and summed by one thread per group.
 __global__ void ord_fill_k(uint32_t m, const uint32_t* __restrict__ val, const uint32_t* __restrict__ sgid,
-                           const int32_t* __restrict__ effend, const uint8_t* __restrict__ flags, uint64_t* __restrict__ hi,
-                           uint64_t* __restrict__ lo, uint32_t* __restrict__ v, uint8_t* __restrict__ fh_by_rec) {
+                           const int32_t* __restrict__ effend, const uint64_t* __restrict__ prio_hi, const uint8_t* __restrict__ flags,
+                           uint64_t* __restrict__ hi, uint64_t* __restrict__ lo, uint32_t* __restrict__ v, uint8_t* __restrict__ fh_by_rec) {
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= m) return;
   uint32_t gi = val[q];
   hi[q] = sgid[q];
-  lo[q] = (uint32_t)effend[gi];
+  // (cross-rank tiles: the merge order was fixed where the files live — the tile lacks the filtered records the scan would need)
+  lo[q] = prio_hi ? (uint32_t)prio_hi[gi] : (uint32_t)effend[gi];
   v[q] = gi;
   fh_by_rec[gi] = (flags[q] >> 2) & 1u;  // first record of its file inside the group
 }
@@ -1331,10 +1332,24 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
         return ok;
       }();
   }
+  // Group partials of other ranks (multi-GPU owner side): every "file" is the run of one source rank, all flagged
+  // TieBrush-merged, with explicit priorities — the window path in its PART form (wgroup.hip) is the reduce-by-key.  Small tiles
+  // and anything that form cannot hold (TBK_DERR_FRACTIONAL) keep the sort path, which treats them as TieBrush-merged inputs.
+  bool part = false;
+  if (in->tbmerged && in->prio_hi && in->prio_lo && in->yc_in && in->yx_in && in->yd_in && in->n_files <= 64 && !O.store_frac &&
+      !O.collapse_same && O.strategy != TBK_STRAT_FULL) {
+    part = true;
+    for (uint32_t f = 0; f < in->n_files; ++f) part = part && in->tbmerged[f] != 0;
+    const char* e = getenv("TBK_PATH");
+    if (e && strcmp(e, "sort") == 0) part = false;
+    if (part && (n >= 65536 || (e && strcmp(e, "window") == 0))) use_win = true;
+    else part = false;
+  }
   // Raw window path: plain tiles without an explicit merge priority go from the input records straight to the groups — the key
   // pass, the effective-end scan and the compaction are folded into the window kernels (TBK_RAW=0: test hook, keeps them apart)
   bool use_raw = use_win;
   if (const char* e = getenv("TBK_RAW")) use_raw = use_raw && strcmp(e, "0") != 0;
+  if (part) use_raw = true;  // (the PART form exists in raw mode only)
   WgOut win_out;
   bool win_done = false;
   uint32_t m = 0, ng = 0;
@@ -1361,11 +1376,12 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
       uint32_t eb = 0;
       WgOut wo;
       TBK_TRY(tbk_window_groups(ctx, I, O.strategy, nullptr, nullptr, nullptr, nullptr, n, I.file_off, nullptr, nullptr, out->rec_group != nullptr,
-                                O.seed, &wo, &eb, &O));
-      if (eb & (TBK_DERR_RAWORDER | TBK_DERR_BIGBUCKET)) {  // not this path's kind of input (the general front end decides what is an
-        TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));  // error), or a pile-up beyond the group table
-        use_raw = false;
-        if (eb & TBK_DERR_BIGBUCKET) use_win = false;
+                                O.seed, &wo, &eb, &O, part));
+      if (eb & (TBK_DERR_RAWORDER | TBK_DERR_BIGBUCKET | TBK_DERR_FRACTIONAL)) {  // not this path's kind of input (the general front end
+        TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));     // decides what is an error), or a pile-up beyond the
+        use_raw = false;                                                            // group table
+        if ((eb & (TBK_DERR_BIGBUCKET | TBK_DERR_FRACTIONAL)) || part) use_win = false;
+        part = false;
         continue;
       }
       if (eb & TBK_DERR_COLLISION) {  // reseed
@@ -1569,7 +1585,7 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
         ob.val2 = ws_alloc<uint32_t>(ctx, m);
         uint8_t* fh_by_rec = ws_alloc<uint8_t>(ctx, n);
         if (!ob.val2 || !fh_by_rec) return TBK_ENOMEM;
-        TBK_LAUNCH(ctx, "ord_fill", ord_fill_k, cdiv(m, B), B, 0, m, s2.val, sgid, effend, flags, ob.hi, ob.lo, ob.val, fh_by_rec);
+        TBK_LAUNCH(ctx, "ord_fill", ord_fill_k, cdiv(m, B), B, 0, m, s2.val, sgid, effend, I.prio_hi, flags, ob.hi, ob.lo, ob.val, fh_by_rec);
         TBK_TRY(tbk_radix_sort128(ctx, &ob, m));
         TBK_LAUNCH(ctx, "ord_sum", ord_sum_k, cdiv(ng, 64), 64, 0, I, O, ng, m, ob.val, fidx, fh_by_rec, G);
       }

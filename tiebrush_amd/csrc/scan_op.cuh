@@ -191,7 +191,10 @@ __global__ __launch_bounds__(SO_NT) void so_down_k(uint32_t n, Load load, Store 
 // every 32-bit word of a published value travels in its own 8-byte granule {tag = 1, word}, written and polled with relaxed
 // agent-scope atomics (write-through stores, cache-bypassing loads): no fences, no L2 write-back — the fenced look-back tried in
 // round 1 was slower than three launches for exactly that cost.  The granules and the ticket are zeroed by one memset per scan.
-// Every spin is bounded: on a timeout the kernel raises TBK_DERR_INTERNAL in *err and finishes with garbage instead of hanging.
+// Every spin is bounded by wall time (SO_SPIN_TICKS of the 100 MHz constant clock: a predecessor tile that is merely descheduled
+// or slow under a shared GPU — several contexts, side streams, RCCL — is waited for; only a tile that never comes raises
+// TBK_DERR_INTERNAL in *err, and the kernel then finishes with garbage instead of hanging).
+constexpr unsigned long long SO_SPIN_TICKS = 20ull * 100000000ull;  // 20 s
 struct SoLookback {
   unsigned long long* agg;  // [nb * W] granules: tile aggregates
   unsigned long long* inc;  // [nb * W] granules: inclusive prefixes
@@ -265,15 +268,20 @@ __global__ __launch_bounds__(SO_NT) void so_single_k(uint32_t n, Load load, Stor
       const bool have = jj >= 0;
       T val = ident;
       bool is_inc = false, ok = !have;
+      unsigned long long t_spin = 0;
       for (uint32_t spins = 0;; ++spins) {
         if (have && !ok) {
           is_inc = so_peek<T>(S.inc, (uint32_t)jj, &val);
           ok = is_inc || so_peek<T>(S.agg, (uint32_t)jj, &val);
         }
         if (__all(ok)) break;
-        if (spins > (1u << 22)) {  // (seconds: something is wrong — never hang)
-          failed = true;
-          break;
+        if ((spins & 1023u) == 1023u) {  // (the clock is read once per thousand polls)
+          const unsigned long long now = wall_clock64();
+          if (t_spin == 0) t_spin = now;
+          if (now - t_spin > SO_SPIN_TICKS) {  // something is wrong — never hang
+            failed = true;
+            break;
+          }
         }
         __builtin_amdgcn_s_sleep(1);
       }

@@ -13,6 +13,18 @@
 //   tbk_shard_pack      passing records -> 24-byte rows + CIGAR words grouped by (destination rank, file), in file order
 //   tbk_shard_unpack    received rows -> the SoA arrays of a tile whose "files" are all the input files
 //
+//
+// Group partials (the default multi-rank protocol; the record shuffle above stays as the fallback for carried
+// fractional YC): every rank collapses its own files with the ordinary single-GPU path and ships one 40-byte row per LOCAL
+// group — key fields, local YC / YX / YD, and the merge priority (effective end, file, index) of its local representative — plus
+// that representative's CIGAR to the rank that owns the group's coordinate range; the owner collapses the partials as
+// TieBrush-merged records with an explicit priority (sum YC, sum YX, max YD, argmin priority: dupAdd is associative,
+// tiebrush.cpp:408-436; processRead reads only the representative's start and exons, which every member of a group shares,
+// :225-249, so the YD of a sample is final on the rank that holds it).
+//   tbk_partial_keys    per local group: cut-search key (tid + 1, start) and running keyed maximum of end + 1
+//   tbk_partial_pack    groups -> rows + CIGAR words in group order (destinations are contiguous group ranges: no reordering)
+//   tbk_partial_unpack  received rows -> the SoA arrays of a tile of TieBrush-merged records with explicit priorities
+//
 // All integer / byte work, HBM-bound, no MFMA.  No data-path collective lives here: the exchange itself is
 // torch.distributed (RCCL over xGMI) in dist.py.
 #include "dev_common.cuh"
@@ -435,4 +447,224 @@ extern "C" int tbk_shard_unpack(tbk_ctx* ctx, const int32_t* rows, uint32_t n2, 
              cig_off, prio_hi, prio_lo);
   TBK_HIP(hipStreamSynchronize(ctx->stream));
   return tbk_check_launch(ctx, "shard_unpack");
+}
+
+// ==================================== group partials ====================================
+namespace {
+struct PmKey {  // scan element: running maximum of a 64-bit word (two 32-bit halves)
+  uint32_t h, l;
+};
+struct PmOp {
+  __device__ __forceinline__ PmKey operator()(const PmKey& a, const PmKey& b) const {
+    const uint64_t x = ((uint64_t)a.h << 32) | a.l, y = ((uint64_t)b.h << 32) | b.l;
+    return y > x ? b : a;
+  }
+};
+struct PmLoad {
+  const uint32_t* rep;
+  const int32_t* tid;
+  const int32_t* g_end;
+  __device__ __forceinline__ PmKey operator()(uint32_t o) const {
+    // (tid + 1) : 32 | end + 1 : 31 — the same keyed end as ShLoad: a cut lies beyond end + 1
+    const uint64_t m = ((uint64_t)(uint32_t)(tid[rep[o]] + 1) << 31) | (uint32_t)(g_end[o] + 1);
+    return PmKey{(uint32_t)(m >> 32), (uint32_t)m};
+  }
+};
+struct PmStore {
+  int64_t* emax;
+  __device__ __forceinline__ void operator()(uint32_t o, const PmKey&, const PmKey& inc, const PmKey&) const {
+    emax[o] = (int64_t)(((uint64_t)inc.h << 32) | inc.l);
+  }
+};
+// key of a local group for the cut search + what the 32-bit row fields cannot hold (flag word: bit 0)
+__global__ void partial_keys_k(uint32_t ng, const uint32_t* __restrict__ rep, const int32_t* __restrict__ tid, const int32_t* __restrict__ g_start,
+                               const double* __restrict__ yc, const int64_t* __restrict__ yx, int64_t* __restrict__ key, uint32_t* __restrict__ bad) {
+  const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= ng) return;
+  key[o] = (int64_t)(((uint64_t)(uint32_t)(tid[rep[o]] + 1) << 31) | (uint32_t)g_start[o]);
+  const double y = yc[o];
+  if (!(y == rint(y)) || y < 1.0 || y >= 2147483648.0 || yx[o] < 0 || yx[o] >= 2147483648ll) atomicOr(bad, 1u);
+}
+__global__ void partial_ncig_k(uint32_t ng, const uint32_t* __restrict__ rep, const uint32_t* __restrict__ cig_off, uint32_t* __restrict__ cnt,
+                               uint32_t* __restrict__ cfirst) {
+  const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= ng) return;
+  const uint32_t r = rep[o], c0 = cig_off[r];
+  cnt[o] = cig_off[r + 1] - c0;
+  cfirst[o] = c0;
+}
+// tab[d] = {first group, rows, words} of destination d: groups with cuts[d - 1] <= key < cuts[d]
+__global__ void partial_table_k(uint32_t ng, uint32_t world, const int64_t* __restrict__ key, const int64_t* __restrict__ cuts,
+                                const uint32_t* __restrict__ woff, const uint64_t* __restrict__ tot_words, long long* __restrict__ tab) {
+  const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= world) return;
+  auto lower = [&](uint32_t which) -> uint32_t {
+    if (which == 0) return 0u;
+    if (which == world) return ng;
+    const int64_t p = cuts[which - 1];
+    uint32_t lo = 0, hi = ng;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (key[mid] < p)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    return lo;
+  };
+  const uint32_t a = lower(d), b = lower(d + 1);
+  const uint64_t wa = a < ng ? woff[a] : *tot_words, wb = b < ng ? woff[b] : *tot_words;
+  tab[d * 3 + 0] = a;
+  tab[d * 3 + 1] = (long long)(b - a);
+  tab[d * 3 + 2] = (long long)(wb - wa);
+}
+// rows: TBK_PARTIAL_ROW x int32 per local group, in group (= output) order
+__global__ void partial_rows_k(uint32_t ng, uint32_t k, uint32_t first_fidx, const uint32_t* __restrict__ file_off, const uint32_t* __restrict__ rep,
+                               const double* __restrict__ yc, const int64_t* __restrict__ yx, const int32_t* __restrict__ yd,
+                               const int32_t* __restrict__ effend, const int32_t* __restrict__ tid, const int32_t* __restrict__ pos,
+                               const uint8_t* __restrict__ strand, const uint32_t* __restrict__ cfirst, const uint32_t* __restrict__ cnt,
+                               const uint32_t* __restrict__ woff, const uint32_t* __restrict__ cig, int32_t* __restrict__ rows,
+                               uint32_t* __restrict__ cig_out) {
+  const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= ng) return;
+  const uint32_t r = rep[o];
+  uint32_t lo = 0, hi = k;  // last f with file_off[f] <= r
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (file_off[mid] <= r)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  const uint32_t nc = cnt[o], c0 = cfirst[o], w = woff[o];
+  int32_t R[TBK_PARTIAL_ROW];
+  R[0] = tid[r];
+  R[1] = pos[r];
+  R[2] = (int32_t)((uint32_t)strand[r] | (nc << 8));
+  R[3] = effend[o];
+  R[4] = (int32_t)(first_fidx + lo);
+  R[5] = (int32_t)(r - file_off[lo]);
+  R[6] = (int32_t)(uint32_t)yc[o];
+  R[7] = (int32_t)yx[o];
+  R[8] = yd[o];
+  R[9] = 0;
+  static_assert(TBK_PARTIAL_ROW == 10, "row layout");
+  int2* dst = reinterpret_cast<int2*>(rows + (size_t)o * TBK_PARTIAL_ROW);  // (40-byte rows: 8-byte aligned)
+#pragma unroll
+  for (int q = 0; q < TBK_PARTIAL_ROW / 2; ++q) dst[q] = make_int2(R[2 * q], R[2 * q + 1]);
+  for (uint32_t q = 0; q < nc; ++q) cig_out[w + q] = cig[c0 + q];
+}
+__global__ void partial_ncig2_k(uint32_t n2, const int32_t* __restrict__ rows, uint32_t* __restrict__ nc) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n2) nc[j] = (uint32_t)rows[(size_t)j * TBK_PARTIAL_ROW + 2] >> 8;
+}
+__global__ void partial_unpack_k(uint32_t n2, const int32_t* __restrict__ rows, const uint64_t* __restrict__ total_words, int32_t* __restrict__ tid,
+                                 int32_t* __restrict__ pos, uint16_t* __restrict__ flag, uint8_t* __restrict__ mapq, uint8_t* __restrict__ strand,
+                                 int32_t* __restrict__ nh, uint32_t* __restrict__ cig_off, double* __restrict__ yc_in, int64_t* __restrict__ yx_in,
+                                 int64_t* __restrict__ yd_in, int64_t* __restrict__ prio_hi, int64_t* __restrict__ prio_lo) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n2) return;
+  const int2* src = reinterpret_cast<const int2*>(rows + (size_t)j * TBK_PARTIAL_ROW);
+  const int2 a = src[0], b = src[1], c = src[2], d = src[3], e = src[4];
+  tid[j] = a.x;
+  pos[j] = a.y;
+  flag[j] = 0;
+  mapq[j] = 255;
+  strand[j] = (uint8_t)((uint32_t)b.x & 0xFFu);
+  nh[j] = TBK_NH_ABSENT;
+  prio_hi[j] = (int64_t)b.y;
+  prio_lo[j] = ((int64_t)c.x << 32) | (uint32_t)c.y;
+  yc_in[j] = (double)(uint32_t)d.x;
+  yx_in[j] = (int64_t)d.y;
+  yd_in[j] = (int64_t)e.x;
+  if (j + 1 == n2) cig_off[n2] = (uint32_t)*total_words;
+}
+}  // namespace
+
+extern "C" int tbk_partial_keys(tbk_ctx* ctx, const tbk_soa_in* in, const tbk_groups_out* g, int64_t* key, int64_t* emax,
+                                uint32_t* not_packable) {
+  if (!ctx || !in || !g || !not_packable) return TBK_EINVAL;
+  *not_packable = 0;
+  if (in->mem != TBK_MEM_DEVICE || g->mem != TBK_MEM_DEVICE) return TBK_EINVAL;
+  const uint32_t ng = g->n_groups;
+  if (ng == 0) return 0;
+  if (!key || !emax || !g->rep || !g->yc || !g->yx || !g->g_start || !g->g_end || !in->tid) return TBK_EINVAL;
+  TBK_HIP(hipSetDevice(ctx->device));
+  tbk_prof_begin_call(ctx);
+  struct ProfEnd {
+    tbk_ctx* c;
+    ~ProfEnd() { tbk_prof_end_call(c); }
+  } prof_end{ctx};
+  TBK_TRY(tbk_ws_reserve(ctx, (size_t)ng * 8 + ((size_t)1 << 20)));
+  uint64_t* sc = ctx->d_scalars;
+  TBK_HIP(hipMemsetAsync(sc, 0, 16 * sizeof(uint64_t), ctx->stream));
+  TBK_LAUNCH(ctx, "partial_keys", partial_keys_k, cdiv(ng, SH_B), SH_B, 0, ng, g->rep, in->tid, g->g_start, g->yc, g->yx, key, (uint32_t*)(sc + 8));
+  {
+    PmLoad ld{g->rep, in->tid, g->g_end};
+    PmStore st{emax};
+    TBK_TRY((scan_op_run<PmKey, PmOp, PmLoad, PmStore>(ctx, "partial_emax_scan", ng, ld, st, PmOp{}, PmKey{0u, 0u})));
+  }
+  uint32_t eb = 0;
+  TBK_TRY(tbk_sync_err(ctx, &eb));
+  if (eb) return tbk_derr_to_status(ctx, eb);
+  *not_packable = (uint32_t)ctx->h_scalars[8];
+  return tbk_check_launch(ctx, "partial_keys");
+}
+
+extern "C" int tbk_partial_pack(tbk_ctx* ctx, const tbk_soa_in* in, const tbk_groups_out* g, const int64_t* key, const int64_t* cuts,
+                                uint32_t world, uint32_t first_fidx, int32_t* rows, uint32_t* cig_out, int64_t* tab) {
+  if (!ctx || !in || !g || !tab || world == 0) return TBK_EINVAL;
+  if (in->mem != TBK_MEM_DEVICE || g->mem != TBK_MEM_DEVICE || in->n_files == 0 || in->n_files > 65535 || !in->file_off) return TBK_EINVAL;
+  const uint32_t ng = g->n_groups;
+  if (ng && (!key || !rows || !cig_out || !g->rep || !g->yc || !g->yx || !g->yd || !g->rep_effend)) return TBK_EINVAL;
+  if (world > 1 && !cuts) return TBK_EINVAL;
+  TBK_HIP(hipSetDevice(ctx->device));
+  tbk_prof_begin_call(ctx);
+  struct ProfEnd {
+    tbk_ctx* c;
+    ~ProfEnd() { tbk_prof_end_call(c); }
+  } prof_end{ctx};
+  TBK_TRY(tbk_ws_reserve(ctx, (size_t)ng * 16 + ((size_t)1 << 20)));
+  uint64_t* sc = ctx->d_scalars;
+  uint32_t* cnt = ws_alloc<uint32_t>(ctx, (size_t)ng + 1);
+  uint32_t* cfirst = ws_alloc<uint32_t>(ctx, (size_t)ng + 1);
+  uint32_t* woff = ws_alloc<uint32_t>(ctx, (size_t)ng + 1);
+  if (!woff) return TBK_ENOMEM;
+  uint32_t* d_fo = nullptr;
+  TBK_TRY(shard_upload_file_off(ctx, in->file_off, in->n_files, &d_fo));
+  if (ng) TBK_LAUNCH(ctx, "partial_ncig", partial_ncig_k, cdiv(ng, SH_B), SH_B, 0, ng, g->rep, in->cig_off, cnt, cfirst);
+  TBK_TRY(tbk_exscan_u32(ctx, cnt, woff, ng, sc + 21));
+  TBK_LAUNCH(ctx, "partial_table", partial_table_k, cdiv(world, 64), 64, 0, ng, world, key, cuts, woff, sc + 21, (long long*)tab);
+  if (ng)
+    TBK_LAUNCH(ctx, "partial_rows", partial_rows_k, cdiv(ng, SH_B), SH_B, 0, ng, in->n_files, first_fidx, d_fo, g->rep, g->yc, g->yx, g->yd,
+               g->rep_effend, in->tid, in->pos, in->strand, cfirst, cnt, woff, in->cig, rows, cig_out);
+  TBK_HIP(hipStreamSynchronize(ctx->stream));
+  return tbk_check_launch(ctx, "partial_pack");
+}
+
+extern "C" int tbk_partial_unpack(tbk_ctx* ctx, const int32_t* rows, uint32_t n2, int32_t* tid, int32_t* pos, uint16_t* flag, uint8_t* mapq,
+                                  uint8_t* strand, int32_t* nh, uint32_t* cig_off, double* yc_in, int64_t* yx_in, int64_t* yd_in,
+                                  int64_t* prio_hi, int64_t* prio_lo) {
+  if (!ctx || !cig_off) return TBK_EINVAL;
+  TBK_HIP(hipSetDevice(ctx->device));
+  tbk_prof_begin_call(ctx);
+  struct ProfEnd {
+    tbk_ctx* c;
+    ~ProfEnd() { tbk_prof_end_call(c); }
+  } prof_end{ctx};
+  TBK_TRY(tbk_ws_reserve(ctx, (size_t)n2 * 8 + ((size_t)1 << 20)));
+  if (n2 == 0) {
+    TBK_HIP(hipMemsetAsync(cig_off, 0, 4, ctx->stream));
+    TBK_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+  }
+  if (!rows || !tid || !pos || !flag || !mapq || !strand || !nh || !yc_in || !yx_in || !yd_in || !prio_hi || !prio_lo) return TBK_EINVAL;
+  uint32_t* nc = ws_alloc<uint32_t>(ctx, n2);
+  if (!nc) return TBK_ENOMEM;
+  TBK_LAUNCH(ctx, "partial_ncig2", partial_ncig2_k, cdiv(n2, SH_B), SH_B, 0, n2, rows, nc);
+  TBK_TRY(tbk_exscan_u32(ctx, nc, cig_off, n2, ctx->d_scalars + 23));
+  TBK_LAUNCH(ctx, "partial_unpack", partial_unpack_k, cdiv(n2, SH_B), SH_B, 0, n2, rows, ctx->d_scalars + 23, tid, pos, flag, mapq, strand, nh,
+             cig_off, yc_in, yx_in, yd_in, prio_hi, prio_lo);
+  TBK_HIP(hipStreamSynchronize(ctx->stream));
+  return tbk_check_launch(ctx, "partial_unpack");
 }

@@ -28,9 +28,12 @@ struct WgOut {
 // the caller's next read-back must treat it as a reseed request.
 int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const uint64_t* chi, const uint64_t* clo, const uint32_t* cval,
                       const uint32_t* ceff, uint32_t m, const uint32_t* d_run_off, uint64_t* scratch_hi, uint64_t* scratch_lo,
-                      bool want_rec_sg, uint64_t seed, WgOut* out, uint32_t* err_bits, const tbkd::ColOpt* raw_opt = nullptr);
+                      bool want_rec_sg, uint64_t seed, WgOut* out, uint32_t* err_bits, const tbkd::ColOpt* raw_opt = nullptr, bool part = false);
 // raw_opt != nullptr — RAW mode: the windows are cut on the input records themselves (chi .. ceff and the scratch arrays are
 // unused and may be null, m = I.n, d_run_off = I.file_off on the device); keys, the filter and the effective ends are computed
 // inside the window kernels, the number of passing records is added to ctx->d_scalars[0] (zeroed by the caller).
 // TBK_DERR_RAWORDER in *err_bits: the input is not of the shape this mode takes — run the general path.
+// part (RAW only, k <= 64, every file TieBrush-merged, explicit priorities): the records are group partials of other ranks
+//  — WgOut::yc is the sum of the carried integral YC, yxin / ydin the sum / maximum of the carried YX / YD, no
+// incidences (np = 0); TBK_DERR_FRACTIONAL in *err_bits: a carried value this form cannot hold — run the sort path.
 bool tbk_window_supported(uint32_t k);

@@ -275,6 +275,7 @@ struct WgTemp {                // per window, at the window's record base
   uint32_t* wbase;             // [nw + 1] per window: record base (wg_rowsum_k)
   uint32_t* cslot;             // [compacted record] window base + number of the record's group inside the window ...
   uint32_t* c2r;               // ... and from that number to the group's temp slot (window base + rank by key)
+  uint32_t *yx, *yd;           // PART only: per group sum of the carried YX, maximum of the carried YD
   unsigned long long* dbg;     // optional [32]: cycles / blocks / records per block kind (TBK_WG_DEBUG)
 };
 
@@ -481,8 +482,13 @@ __global__ void wg_list_k(uint32_t nw, const uint32_t* __restrict__ wbase, uint3
 // RAW: the pieces are pieces of the input files themselves; every record's key, filter verdict and effective end (a segmented
 // prefix maximum along the piece, carried across waves, rows and chunks) are computed here, records that do not pass take no
 // part in the grouping.
+// PART (RAW only): the records are group partials of other ranks — TieBrush-merged records with an explicit priority (multi-GPU
+// owner side): a group's count is the sum of the carried integral YC, the two words that hold the bitset of the
+// samples otherwise hold the sum of the carried YX and the maximum of the carried YD, and no (group, sample) incidence is
+// emitted (tiebrush.cpp:389-395, :412-419: a TieBrush-merged record enters no sample list).
 template <int SORT_E /* the ranking sorts at most SORT_E * WG_NT groups */, bool RAW, int NR /* records per thread and chunk */, int ST /* RAW: strategy */,
-          int GC /* > 0: at most 64 input files, a table of exactly GC slots (compile-time LDS layout); 0: sizes from the arguments */>
+          int GC /* > 0: at most 64 input files, a table of exactly GC slots (compile-time LDS layout); 0: sizes from the arguments */,
+          bool PART = false>
 __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, const WgTemp& T, uint32_t gcap_arg, uint32_t nwords_arg, uint64_t seed,
                                                uint32_t w, unsigned char* lds, uint32_t* sm_u, uint32_t* s_misc, uint2* s_agg /* [NR * WG_NW] */,
                                                uint32_t* __restrict__ ovf, uint32_t ovf_cap, bool final_tier, uint32_t* __restrict__ err) {
@@ -760,11 +766,22 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
         }
         const unsigned long long rr = ((unsigned long long)eff[u] << 32) | rec[u];
         if (rr < trep[s]) atomicMin(&trep[s], rr);
-        const uint32_t bi = s * nwords + (fil[u] >> 5), bm = 1u << (fil[u] & 31);
-        if (!(tbits[bi] & bm)) atomicOr(&tbits[bi], bm);
+        if constexpr (PART) {
+          double y = R.I.yc_in[src[u]];
+          y = y == 0.0 ? 1.0 : y;  // (tiebrush.cpp:389-395: an absent / zero YC counts as one)
+          const long long yx = R.I.yx_in[src[u]], yd = R.I.yd_in[src[u]];
+          if (!(y == rint(y)) || y < 0.0 || y >= 2147483648.0 || yx < 0 || yx >= 2147483648ll || yd >= 2147483648ll)
+            atomicOr(err, TBK_DERR_FRACTIONAL);  // not this form's kind of partial: the sort path takes the tile
+          atomicAdd(&tcnt[s], (uint32_t)y);
+          atomicAdd(&tbits[s * nwords], (uint32_t)yx);
+          if (yd > 0) atomicMax(&tbits[s * nwords + 1], (uint32_t)yd);
+        } else {
+          const uint32_t bi = s * nwords + (fil[u] >> 5), bm = 1u << (fil[u] & 31);
+          if (!(tbits[bi] & bm)) atomicOr(&tbits[bi], bm);
+        }
       }
       // counts: the leader's group by one ballot (a pile-up is mostly one group), the other lanes add for themselves
-      const uint64_t am = __ballot(act);
+      const uint64_t am = PART ? 0ull : __ballot(act);
       if (am) {
         const int leader = __builtin_ctzll(am);
         const uint32_t s0 = __shfl(slot[u], leader, 64);
@@ -791,7 +808,8 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
     for (uint32_t g = t; g < d; g += WG_NT) {
       const uint32_t s = byrank[g];
       uint32_t c = 0;
-      for (uint32_t x = 0; x < nwords; ++x) c += (uint32_t)__builtin_popcount(tbits[s * nwords + x]);
+      if constexpr (!PART)
+        for (uint32_t x = 0; x < nwords; ++x) c += (uint32_t)__builtin_popcount(tbits[s * nwords + x]);
       nsr[g] = c;
     }
     __syncthreads();
@@ -828,7 +846,11 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
       uint32_t pl = nsr[g];
       T.poff[wbase + g] = pl;
       uint32_t c = 0;
-      for (uint32_t x = 0; x < nwords; ++x) {
+      if constexpr (PART) {
+        T.yx[wbase + g] = tbits[s * nwords];
+        T.yd[wbase + g] = tbits[s * nwords + 1];
+      }
+      for (uint32_t x = 0; x < (PART ? 0u : nwords); ++x) {
         uint32_t bits = tbits[s * nwords + x];
         while (bits) {
           const uint32_t bpos = (uint32_t)__builtin_ctz(bits);
@@ -862,7 +884,7 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
 
 // first tier: one block per window that holds records, a table of WG_LDS_HASH bytes (four blocks per CU)
 constexpr int WG_GC64 = (WG_LDS_HASH - (8 * 64 + 8)) / (44 + 4 * 2);  // table slots of the <= 64 files form of the first tier
-template <bool RAW, int ST, int GC>
+template <bool RAW, int ST, int GC, bool PART = false>
 __global__ __launch_bounds__(WG_NT, 6) void wg_hash_k(WgIn In, WgRaw R, WgTemp T, uint32_t gcap, uint32_t nwords, uint64_t seed,
                                                       const uint32_t* __restrict__ wlist, uint32_t* __restrict__ ovf /* [0] count, [1..] windows */,
                                                       uint32_t ovf_cap, uint32_t* __restrict__ err) {
@@ -870,12 +892,13 @@ __global__ __launch_bounds__(WG_NT, 6) void wg_hash_k(WgIn In, WgRaw R, WgTemp T
   __shared__ uint32_t sm_u[WG_NW];
   __shared__ uint32_t s_misc[8];
   __shared__ uint2 s_agg[WG_R * WG_NW];
-  wg_hash_window<2, RAW, RAW ? WG_RR : WG_R, ST, GC>(In, R, T, gcap, nwords, seed, wlist[blockIdx.x], lds, sm_u, s_misc, s_agg, ovf, ovf_cap, false, err);
+  wg_hash_window<2, RAW, RAW ? WG_RR : WG_R, ST, GC, PART>(In, R, T, gcap, nwords, seed, wlist[blockIdx.x], lds, sm_u, s_misc, s_agg, ovf, ovf_cap, false,
+                                                           err);
 }
 // second tier: the windows with more distinct groups than the first table holds (shallow data) against a table of WG_LDS_HASH2 bytes
 // (two blocks per CU); a fixed grid walks the first tier's worklist.  What overflows again goes to the sort kernel.
 constexpr int WG_GC64_2 = (WG_LDS_HASH2 - (8 * 64 + 8)) / (44 + 4 * 2);  // ... and of the second tier
-template <bool RAW, int ST, int GC>
+template <bool RAW, int ST, int GC, bool PART = false>
 __global__ __launch_bounds__(WG_NT, 6) void wg_hash2_k(WgIn In, WgRaw R, WgTemp T, uint32_t gcap, uint32_t nwords, uint64_t seed,
                                                        const uint32_t* __restrict__ ovf_in, uint32_t* __restrict__ ovf, uint32_t ovf_cap,
                                                        uint32_t* __restrict__ err) {
@@ -886,7 +909,8 @@ __global__ __launch_bounds__(WG_NT, 6) void wg_hash2_k(WgIn In, WgRaw R, WgTemp 
   const uint32_t cnt = ovf_in[0] < ovf_cap ? ovf_in[0] : ovf_cap;
   for (uint32_t wi = blockIdx.x; wi < cnt; wi += gridDim.x) {
     __syncthreads();  // (LDS of the previous window is free)
-    wg_hash_window<3, RAW, RAW ? WG_RR : WG_R, ST, GC>(In, R, T, gcap, nwords, seed, ovf_in[1 + wi], lds, sm_u, s_misc, s_agg, ovf, ovf_cap, true, err);
+    wg_hash_window<3, RAW, RAW ? WG_RR : WG_R, ST, GC, PART>(In, R, T, gcap, nwords, seed, ovf_in[1 + wi], lds, sm_u, s_misc, s_agg, ovf, ovf_cap, true,
+                                                             err);
   }
 }
 
@@ -894,7 +918,7 @@ __global__ __launch_bounds__(WG_NT, 6) void wg_hash2_k(WgIn In, WgRaw R, WgTemp 
 // each, sorted in LDS.  A fixed grid walks the worklist.
 // RAW: keys, filter verdicts and effective ends are computed while the window is loaded (see wg_hash_window); records that do not
 // pass sort behind every key and are left out.
-template <bool RAW, int ST>
+template <bool RAW, int ST, bool PART = false>
 __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgRaw R, WgTemp T, ColIn I, int strategy, const uint32_t* __restrict__ ovf,
                                                       uint32_t ovf_cap, uint32_t* __restrict__ err) {
   __shared__ __align__(16) unsigned char lds[WG_LDS_MAIN];
@@ -1051,7 +1075,7 @@ __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgRaw R, WgTemp T
       for (int u = 0; u < WG_E; ++u)
         if (((need >> u) & 1u) && !strategy_equal(I, strategy, recs[u], vb[u])) atomicOr(err, TBK_DERR_COLLISION);
     }
-    const uint32_t nh = (uint32_t)__builtin_popcount(hf & 0xFFu), nf = (uint32_t)__builtin_popcount(hf >> 8);
+    const uint32_t nh = (uint32_t)__builtin_popcount(hf & 0xFFu), nf = PART ? 0u : (uint32_t)__builtin_popcount(hf >> 8);
     uint32_t tot;
     const uint32_t ex = wg_block_excl<uint32_t>(nh | (nf << 16), sm_u, &tot);
     const uint32_t ng_w = tot & 0xFFFFu, np_w = tot >> 16;
@@ -1072,7 +1096,7 @@ __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgRaw R, WgTemp T
             T.poff[wbase + gl[u]] = pl;
             T.c2r[wbase + gl[u]] = wbase + gl[u];
           }
-          if (fh) {
+          if (!PART && fh) {
             T.pinc[wbase + pl] = fl[u] | (gl[u] << 16);
             ++pl;
           }
@@ -1088,18 +1112,36 @@ __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgRaw R, WgTemp T
     uint32_t* gcnt = reinterpret_cast<uint32_t*>(lds);
     uint32_t* gns = gcnt + WG_CAP;
     unsigned long long* grep = reinterpret_cast<unsigned long long*>(gns + WG_CAP);
+    uint32_t* gyd = reinterpret_cast<uint32_t*>(grep + WG_CAP);  // (PART; 60 of the 72 KiB)
     for (uint32_t g = t; g < ng_w; g += WG_NT) {
       gcnt[g] = 0;
       gns[g] = 0;
       grep[g] = ~0ull;
+      if (PART) gyd[g] = 0;
     }
     unsigned long long rr[WG_E];
+    uint32_t ycv[WG_E], yxv[WG_E], ydv[WG_E];  // PART: the carried YC / YX / YD of the partial
 #pragma unroll
-    for (int u = 0; u < WG_E; ++u)  // eight independent gathers in flight
+    for (int u = 0; u < WG_E; ++u) {  // eight independent gathers in flight
       rr[u] = q0 + u < n_w ? (((unsigned long long)(RAW ? val[ix[u]] : In.ceff[srci[u]]) << 32) | recs[u]) : ~0ull;
+      ycv[u] = 1u;
+      yxv[u] = ydv[u] = 0u;
+      if constexpr (PART) {
+        if (q0 + u < n_w) {
+          double y = R.I.yc_in[srci[u]];
+          y = y == 0.0 ? 1.0 : y;
+          const long long yx = R.I.yx_in[srci[u]], yd = R.I.yd_in[srci[u]];
+          if (!(y == rint(y)) || y < 0.0 || y >= 2147483648.0 || yx < 0 || yx >= 2147483648ll || yd >= 2147483648ll)
+            atomicOr(err, TBK_DERR_FRACTIONAL);
+          ycv[u] = (uint32_t)y;
+          yxv[u] = (uint32_t)yx;
+          ydv[u] = yd > 0 ? (uint32_t)yd : 0u;
+        }
+      }
+    }
     __syncthreads();
     {  // runs of one group inside the thread's positions are folded in registers; one set of LDS atomics per run
-      uint32_t cg = 0xFFFFFFFFu, c = 0, nsv = 0;
+      uint32_t cg = 0xFFFFFFFFu, c = 0, nsv = 0, ydm = 0;
       unsigned long long r = ~0ull;
 #pragma unroll
       for (int u = 0; u < WG_E; ++u) {
@@ -1108,29 +1150,37 @@ __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgRaw R, WgTemp T
             if (cg != 0xFFFFFFFFu) {
               atomicAdd(&gcnt[cg], c);
               if (nsv) atomicAdd(&gns[cg], nsv);
+              if (PART && ydm) atomicMax(&gyd[cg], ydm);
               atomicMin(&grep[cg], r);
             }
             cg = gl[u];
             c = 0;
             nsv = 0;
+            ydm = 0;
             r = ~0ull;
           }
-          ++c;
-          nsv += (hf >> (8 + u)) & 1u;
+          c += ycv[u];
+          nsv += PART ? yxv[u] : ((hf >> (8 + u)) & 1u);
+          ydm = ydv[u] > ydm ? ydv[u] : ydm;
           r = rr[u] < r ? rr[u] : r;
         }
       }
       if (cg != 0xFFFFFFFFu) {
         atomicAdd(&gcnt[cg], c);
         if (nsv) atomicAdd(&gns[cg], nsv);
+        if (PART && ydm) atomicMax(&gyd[cg], ydm);
         atomicMin(&grep[cg], r);
       }
     }
     __syncthreads();
     for (uint32_t g = t; g < ng_w; g += WG_NT) {
       T.cnt[wbase + g] = gcnt[g];
-      T.ns[wbase + g] = gns[g];
+      T.ns[wbase + g] = PART ? 0u : gns[g];
       T.rep[wbase + g] = grep[g];
+      if constexpr (PART) {
+        T.yx[wbase + g] = gns[g];
+        T.yd[wbase + g] = gyd[g];
+      }
     }
     if (t == 0) {
       T.wg_cnt[w] = ng_w;
@@ -1172,8 +1222,8 @@ __global__ __launch_bounds__(64) void wg_compact_k(uint32_t nw, WgTemp T, const 
     F.gmem[sg] = (uint32_t)(r & 0xFFFFFFFFull);
     F.yc[sg] = (double)T.cnt[wb + g];
     F.ns[sg] = T.ns[wb + g];
-    F.yxin[sg] = 0;
-    F.ydin[sg] = 0;
+    F.yxin[sg] = T.yx ? (long long)T.yx[wb + g] : 0ll;
+    F.ydin[sg] = T.yd ? (long long)T.yd[wb + g] : 0ll;
     F.first[sg] = sg;
     F.gpoff[sg] = pb + T.poff[wb + g];
     if (F.slot2sg) F.slot2sg[wb + g] = sg;
@@ -1229,12 +1279,13 @@ bool tbk_window_supported(uint32_t k) { return k >= 1 && k <= 1024; }
 
 int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const uint64_t* chi, const uint64_t* clo, const uint32_t* cval,
                       const uint32_t* ceff, uint32_t m, const uint32_t* d_run_off, uint64_t* scratch_hi, uint64_t* scratch_lo,
-                      bool want_rec_sg, uint64_t seed, WgOut* out, uint32_t* err_bits, const tbkd::ColOpt* raw_opt) {
+                      bool want_rec_sg, uint64_t seed, WgOut* out, uint32_t* err_bits, const tbkd::ColOpt* raw_opt, bool part) {
   const uint32_t k = I.k;
   const uint32_t B = 256;
   *err_bits = 0;
   const bool raw = raw_opt != nullptr;  // the records themselves are the runs: m = I.n, d_run_off = I.file_off, chi .. ceff unused
   if (!tbk_window_supported(k) || m == 0) return TBK_EINVAL;
+  if (part && (!raw || k > 64 || !I.prio_hi || !I.yc_in || !I.yx_in || !I.yd_in)) return TBK_EINVAL;
   WgRaw R{};
   if (raw) {
     R.I = I;
@@ -1291,7 +1342,13 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   uint32_t* gbase = ws_alloc<uint32_t>(ctx, nw);
   uint32_t* pbase = ws_alloc<uint32_t>(ctx, nw);
   T.dbg = nullptr;
-  if (getenv("TBK_WG_DEBUG")) {
+  T.yx = T.yd = nullptr;
+  if (part) {
+    T.yx = ws_alloc<uint32_t>(ctx, m);
+    T.yd = ws_alloc<uint32_t>(ctx, m);
+    if (!T.yd) return TBK_ENOMEM;
+  }
+  if (!part && getenv("TBK_WG_DEBUG")) {
     T.dbg = ws_alloc<unsigned long long>(ctx, 32);
     if (T.dbg) TBK_HIP(hipMemsetAsync(T.dbg, 0, 32 * 8, ctx->stream));
   }
@@ -1347,7 +1404,11 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
 #define WG_L_HASH64(S)                                                                                                                       \
   TBK_LAUNCH(ctx, "wg_hash", (wg_hash_k<true, S, WG_GC64>), nw_live, WG_NT, WG_GC64 * 52u + 8u * 64u + 8u, In, R, T, gcap, nwords, seed, wlist, ovf, \
              ovf_cap, ctx->d_err)
-    if (raw && k <= 64 && !T.dbg) {  // compile-time table layout
+    if (part) {  // group partials: one instantiation, the strategy read from the options
+      R.O.strategy = strategy;
+      TBK_LAUNCH(ctx, "wg_hash", (wg_hash_k<true, -1, WG_GC64, true>), nw_live, WG_NT, WG_GC64 * 52u + 8u * 64u + 8u, In, R, T, gcap, nwords, seed, wlist,
+                 ovf, ovf_cap, ctx->d_err);
+    } else if (raw && k <= 64 && !T.dbg) {  // compile-time table layout
       WG_BY_STRATEGY(WG_L_HASH64)
     } else if (raw) {
       WG_BY_STRATEGY(WG_L_HASH)
@@ -1363,7 +1424,10 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
 #define WG_L_HASH2_64(S)                                                                                                                     \
   TBK_LAUNCH(ctx, "wg_hash2", (wg_hash2_k<true, S, WG_GC64_2>), std::min<uint32_t>(nw_live, 512u), WG_NT, WG_GC64_2 * 52u + 8u * 64u + 8u, In, R, \
              T, gcap2, nwords, seed, ovf, ovf2, ovf_cap, ctx->d_err)
-      if (raw && k <= 64 && !T.dbg) {
+      if (part) {
+        TBK_LAUNCH(ctx, "wg_hash2", (wg_hash2_k<true, -1, WG_GC64_2, true>), std::min<uint32_t>(nw_live, 512u), WG_NT,
+                   WG_GC64_2 * 52u + 8u * 64u + 8u, In, R, T, gcap2, nwords, seed, ovf, ovf2, ovf_cap, ctx->d_err);
+      } else if (raw && k <= 64 && !T.dbg) {
         WG_BY_STRATEGY(WG_L_HASH2_64)
       } else if (raw) {
         WG_BY_STRATEGY(WG_L_HASH2)
@@ -1375,7 +1439,9 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
     }
   }
 #define WG_L_SORT(S) TBK_LAUNCH(ctx, "wg_sort", (wg_sort_k<true, S>), std::min<uint32_t>(nw, 1024u), WG_NT, 0, In, R, T, I, strategy, ovf, ovf_cap, ctx->d_err)
-  if (raw) {
+  if (part) {
+    TBK_LAUNCH(ctx, "wg_sort", (wg_sort_k<true, -1, true>), std::min<uint32_t>(nw, 1024u), WG_NT, 0, In, R, T, I, strategy, ovf, ovf_cap, ctx->d_err);
+  } else if (raw) {
     WG_BY_STRATEGY(WG_L_SORT)
   } else {
     TBK_LAUNCH(ctx, "wg_sort", (wg_sort_k<false, -1>), std::min<uint32_t>(nw, 1024u), WG_NT, 0, In, R, T, I, strategy, ovf, ovf_cap, ctx->d_err);

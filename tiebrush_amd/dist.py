@@ -1,5 +1,23 @@
-"""Multi-GPU collapse: input files shard per rank; the records are shuffled by coordinate, then collapsed once.
+"""Multi-GPU collapse: input files shard per rank; every rank collapses its own files, group partials are exchanged.
 
+Default protocol — `partials_collapse` (the reference's ancestor is tiewrap.py:96-126, batches of files collapsed
+and re-collapsed):
+  1. every rank runs the ordinary single-GPU `tbk_collapse_tile` on its own files: local groups with local YC / YX / YD and the
+     merge priority (effective end, file, index) of the local representative.  YD is final there: `GSegList::processRead` reads
+     only the representative's start and exons (tiebrush.cpp:225-249), which every member of a group shares, the call order
+     inside a sample's list is a function of the group keys (:438-457, :511-524), and a sample lives on one rank;
+  2. the ranks agree on R-1 coordinate cuts at global tiecov bundle boundaries, found on the local GROUP arrays (all-gather of 64
+     sampled group keys, all-reduce rounds as below);
+  3. one 40-byte row per local group {tid, pos, strand, n_cigar, effective end, file, index, YC, YX, YD} and the local
+     representative's CIGAR go to the owner of the group's range (one all-to-all of rows, one of CIGAR words): groups are already
+     in coordinate order, so a destination is a contiguous range — nothing is reordered;
+  4. the owner collapses what it received as TieBrush-merged records with explicit priorities (`tbk_collapse_tile`, window path in
+     its PART form): sum YC, sum YX, max YD, representative = argmin priority — `SPData::dupAdd` is associative
+     (tiebrush.cpp:408-436) — and runs tiecov on its slice.
+Unlike a tiewrap-style hierarchical run, the explicit priority keeps the flat run's representative record.  Exact for integral
+YC; inputs that carry a fractional YC (written with --store-frac) fall back, by a collective decision, to the protocol below.
+
+Fallback protocol — `shard_collapse`: the records are shuffled by coordinate, then collapsed once.
 Every rank holds some of the input files (a sample lives on one rank).  The ranks agree on R-1 coordinate cuts that no
 read of any file spans — global tiecov bundle boundaries — and every record that passes the filters moves to the rank
 that owns its coordinate range.  That rank then holds, for its range, the sorted records of ALL input files, i.e. a
@@ -463,6 +481,199 @@ def shard_collapse(compute, local_tile: SoATile, first_fidx: int, rank: int, wor
     return res
 
 
+# ---- group partials (default protocol) ------------------------------------------------------------------------------------------
+PROW = 10     # int32 words per partial row (include/tbk.h: TBK_PARTIAL_ROW)
+
+
+def _partial_keys_np(tile, fin):
+    """tbk_partial_keys on the host: (key, emax, not_packable)."""
+    ng = int(fin["n_groups"])
+    rep = np.asarray(fin["rep"]).astype(np.int64)[:ng]
+    tid = np.asarray(tile.tid).astype(np.int64)[rep]
+    gs, ge = np.asarray(fin["g_start"]).astype(np.int64)[:ng], np.asarray(fin["g_end"]).astype(np.int64)[:ng]
+    key = ((tid + 1) << 31) | gs
+    emax = np.maximum.accumulate(((tid + 1) << 31) | (ge + 1)) if ng else np.zeros(0, np.int64)
+    yc, yx = np.asarray(fin["yc"])[:ng], np.asarray(fin["yx"]).astype(np.int64)[:ng]
+    bad = bool(ng) and bool(np.any(yc != np.rint(yc)) or np.any(yc < 1) or np.any(yc >= 2**31) or np.any(yx < 0) or np.any(yx >= 2**31))
+    return key, emax, int(bad)
+
+
+def _partial_pack_np(tile, fin, key, cuts, world, first_fidx):
+    """tbk_partial_pack on the host: (rows [ng, PROW] int32, cig words, tab [world, 3])."""
+    ng = int(fin["n_groups"])
+    rep = np.asarray(fin["rep"]).astype(np.int64)[:ng]
+    fo = np.asarray(tile.file_off).astype(np.int64)
+    co = np.asarray(tile.cig_off).astype(np.int64)
+    f_of = np.searchsorted(fo, rep, side="right") - 1
+    ncig = co[rep + 1] - co[rep]
+    rows = np.zeros((ng, PROW), np.int64)
+    if ng:
+        rows[:, 0] = np.asarray(tile.tid)[rep]
+        rows[:, 1] = np.asarray(tile.pos)[rep]
+        rows[:, 2] = np.asarray(tile.strand)[rep].astype(np.int64) | (ncig << 8)
+        rows[:, 3] = np.asarray(fin["rep_effend"])[:ng]
+        rows[:, 4] = first_fidx + f_of
+        rows[:, 5] = rep - fo[f_of]
+        rows[:, 6] = np.asarray(fin["yc"])[:ng].astype(np.int64)
+        rows[:, 7] = np.asarray(fin["yx"])[:ng]
+        rows[:, 8] = np.asarray(fin["yd"])[:ng]
+    _, woff, cigw = _gather_cigars(_NP, tile.cig_off, np.asarray(tile.cig), rep)
+    b = np.concatenate([[0], np.searchsorted(key, cuts, side="left") if world > 1 else np.zeros(0, np.int64), [ng]]).astype(np.int64)
+    tab = np.stack([b[:-1], b[1:] - b[:-1], woff[b[1:]] - woff[b[:-1]]], axis=1).astype(np.int64)
+    return rows.astype(np.uint32).view(np.int32) if ng else np.zeros((0, PROW), np.int32), cigw, tab
+
+
+def _partial_unpack_np(rows):
+    r = rows.astype(np.int64)
+    n2 = r.shape[0]
+    u = r[:, 2] & 0xFFFFFFFF
+    cig_off = np.concatenate([[0], np.cumsum(u >> 8)]).astype(np.uint32)
+    return dict(tid=r[:, 0].astype(np.int32), pos=r[:, 1].astype(np.int32), flag=np.zeros(n2, np.uint16), mapq=np.full(n2, 255, np.uint8),
+                strand=(u & 0xFF).astype(np.uint8), nh=np.full(n2, -(2**31), np.int32), cig_off=cig_off,
+                yc_in=(r[:, 6] & 0xFFFFFFFF).astype(np.float64), yx_in=r[:, 7].copy(), yd_in=r[:, 8].copy(),
+                prio_hi=r[:, 3].astype(np.uint64), prio_lo=((r[:, 4] << 32) | (r[:, 5] & 0xFFFFFFFF)).astype(np.uint64))
+
+
+def partials_collapse(compute, local_tile: SoATile, first_fidx: int, rank: int, world: int, strategy="cigar", want_coverage=False,
+                      device_chain=False, local=None, stats=None, **filters):
+    """Generator like shard_collapse (same requests, same ShardResult): collapse locally, exchange group partials, reduce by key
+    on the owner.  `local`: the result of the local collapse when the driver has already run it (bench.py collapses tile i + 1
+    while tile i is exchanged) — a dict of compute.collapse(..., want_coords=True, want_effend=True) with a final `yd`.
+    `stats` (dict, optional) receives wire_rows / wire_bytes of this rank's exchange."""
+    if filters.get("store_frac") or filters.get("collapse_same"):
+        raise ValueError("--store-frac and -A need the single-tile path's ordered passes: single-GPU only (DESIGN.md §7)")
+    if strategy in ("full", 1):
+        raise ValueError("-L (CIGAR + MD) is single-GPU only: neither partials nor shuffled rows carry MD tags")
+    X = _xp(local_tile.tid)
+    mark = getattr(compute, "mark", None) or (lambda _name: None)
+    on_dev = _is_t(local_tile.tid) and hasattr(compute, "partial_keys")
+    k = local_tile.n_files
+    # ---- 1. the ordinary single-GPU collapse of this rank's files ---------------------------------------------------------
+    fin = local
+    if fin is None:
+        fin = compute.collapse(local_tile, strategy=strategy, want_coords=True, want_effend=True, **filters)
+    ng = int(fin["n_groups"])
+    n_pass = int(fin["n_passed"])
+    mark("local")
+    # ---- 2. cut keys of the local groups; one all-gather: samples + file table + "can this rank's partials be packed" -----
+    if on_dev:
+        key, emax, bad = compute.partial_keys(local_tile, fin)
+    else:
+        key, emax, bad = _partial_keys_np(_host_tile(local_tile), {kk: (X.host(v) if _is_t(v) else v) for kk, v in fin.items()
+                                                                   if kk in ("n_groups", "rep", "yc", "yx", "g_start", "g_end")})
+        if _is_t(local_tile.tid):
+            key, emax = (_torch().from_numpy(a).to(local_tile.tid.device) for a in (key, emax))
+    idx_h = (np.arange(N_SAMPLES, dtype=np.int64) * ng) // N_SAMPLES
+    tail = np.array([k, first_fidx, bad], np.int64)
+    if _is_t(key):
+        T = _torch()
+        meta = T.empty(N_SAMPLES + 3, dtype=T.int64, device=key.device)
+        if ng:
+            meta[:N_SAMPLES] = key[T.from_numpy(idx_h).to(key.device, non_blocking=True)]
+        else:
+            meta[:N_SAMPLES] = KEY_INF
+        meta[N_SAMPLES:] = T.from_numpy(tail).to(key.device, non_blocking=True)
+    else:
+        meta = np.concatenate([key[idx_h] if ng else np.full(N_SAMPLES, KEY_INF, np.int64), tail])
+    allmeta = X.host((yield ("all_gather", meta))).reshape(world, N_SAMPLES + 3)
+    ks = allmeta[:, N_SAMPLES].astype(np.int64)
+    firsts = allmeta[:, N_SAMPLES + 1].astype(np.int64)
+    if not np.array_equal(firsts, np.concatenate([[firsts[0]], firsts[0] + np.cumsum(ks)[:-1]])):
+        raise ValueError("ranks must hold consecutive blocks of the input files, in rank order")
+    if bool(allmeta[:, N_SAMPLES + 2].any()):
+        # a carried fractional YC somewhere (or a count beyond 31 bits): sums across ranks would not keep the reference's order of
+        # additions — every rank takes the record shuffle for this tile (the decision is collective: same data on all ranks)
+        res = yield from shard_collapse(compute, local_tile, first_fidx, rank, world, strategy=strategy, want_coverage=want_coverage,
+                                        device_chain=device_chain, **filters)
+        return res
+    fo1 = np.array([0, ng], np.int64)
+    p = None
+    if world > 1:
+        flat = np.sort(allmeta[:, :N_SAMPLES].reshape(-1))
+        flat = flat[flat != KEY_INF]
+        tgt = np.array([int(flat[(j * len(flat)) // world]) if len(flat) else KEY_INF for j in range(1, world)], np.int64)
+        p = _torch().from_numpy(tgt).to(key.device) if _is_t(key) else tgt
+        # ---- 3. every cut moves forward to a global bundle boundary of the GROUPS (= of the passing records) ------------
+        for _ in range(100000):
+            if on_dev:
+                m_local = compute.shard_probe_max(fo1, key, emax, p, X.full(world - 1, -1, like=key))
+            else:
+                m_local = _probe_max_np(fo1, X.host(key), X.host(emax), X.host(p))
+                m_local = _torch().from_numpy(m_local).to(key.device) if _is_t(key) else m_local
+            m = yield ("all_reduce_max", m_local)
+            ok = (m < p) | (p == KEY_INF)
+            if bool(ok.all()):
+                break
+            if on_dev:
+                nxt = compute.shard_probe_next(fo1, key, m, X.full(world - 1, KEY_INF, like=key))
+            else:
+                nxt = _probe_next_np(fo1, X.host(key), X.host(m))
+                nxt = _torch().from_numpy(nxt).to(key.device) if _is_t(key) else nxt
+            nxt = X.where(ok, p, nxt)
+            p = yield ("all_reduce_min", nxt)
+    mark("cuts")
+    # ---- 4. rows + CIGAR words in group order; exchange ----------------------------------------------------------------------
+    if on_dev:
+        rows, cigw, tab = compute.partial_pack(local_tile, fin, key, p, world, first_fidx)
+        tab_h = tab.cpu().numpy()
+    else:
+        hostify = (lambda a: X.host(a)) if _is_t(key) else (lambda a: a)
+        hfin = {kk: (X.host(v) if _is_t(v) else v) for kk, v in fin.items() if not kk.startswith("_")}
+        rows, cigw, tab_h = _partial_pack_np(_host_tile(local_tile), hfin, hostify(key), None if p is None else hostify(p), world, first_fidx)
+        if _is_t(key):
+            T = _torch()
+            rows, cigw = (T.from_numpy(np.ascontiguousarray(a)).to(key.device) for a in (rows, cigw.view(np.int32)))
+    cnt_rows = tab_h[:, 1].astype(np.int64)
+    cnt_words = tab_h[:, 2].astype(np.int64)
+    if stats is not None:
+        stats["wire_rows"] = int(cnt_rows.sum())
+        stats["wire_bytes"] = int(cnt_rows.sum()) * PROW * 4 + int(cnt_words.sum()) * 4
+        stats["wire_bytes_off_rank"] = stats["wire_bytes"] - (int(cnt_rows[rank]) * PROW * 4 + int(cnt_words[rank]) * 4)
+    mark("pack")
+    rrows, rcnt, rcig, _ = yield ("exchange_rows", (rows[:ng], cnt_rows, cigw[:int(cnt_words.sum())], cnt_words, cnt_rows.reshape(world, 1)))
+    mark("exchange")
+    # ---- 5. the partials of this rank's coordinate range: one run per source rank, TieBrush-merged, explicit priorities ----
+    n2 = int(rrows.shape[0])
+    file_off2 = np.zeros(world + 1, np.uint32)
+    file_off2[1:] = np.cumsum(np.asarray(rcnt, np.int64))
+    assert int(file_off2[-1]) == n2
+    if on_dev:
+        A = compute.partial_unpack(rrows)
+    else:
+        A = _partial_unpack_np(X.host(rrows) if _is_t(rrows) else np.asarray(rrows))
+        if _is_t(rrows):
+            T = _torch()
+            sg = {np.dtype(np.uint64): np.int64, np.dtype(np.uint32): np.int32, np.dtype(np.uint16): np.int16}
+            A = {kk: T.from_numpy(np.ascontiguousarray(v.view(sg.get(v.dtype, v.dtype)))).to(rrows.device) for kk, v in A.items()}
+    tile2 = SoATile(n_files=world, file_off=file_off2, tbmerged=np.ones(world, np.uint8), tid=A["tid"], pos=A["pos"], flag=A["flag"],
+                    mapq=A["mapq"], strand=A["strand"], nh=A["nh"], cig_off=A["cig_off"], cig=rcig, yc_in=A["yc_in"], yx_in=A["yx_in"],
+                    yd_in=A["yd_in"], prio_hi=A["prio_hi"], prio_lo=A["prio_lo"])
+    mark("unpack")
+    fin2 = compute.collapse(tile2, strategy=strategy, want_coords=True, keep_supplementary=True, keep_secondary=True)
+    g2 = int(fin2["n_groups"])
+    rep2 = X.u32_to_i64(fin2["rep"]) if _is_t(fin2["rep"]) else np.asarray(fin2["rep"]).astype(np.int64)
+    plo = X.to_i64(A["prio_lo"])[rep2] if _is_t(A["prio_lo"]) else np.asarray(A["prio_lo"]).astype(np.int64)[rep2]
+    res = ShardResult(n_groups=g2, n_passed_local=n_pass, tid=tile2.tid[rep2], start=fin2["g_start"], end=fin2["g_end"],
+                      rep_fidx=plo >> 32, rep_idx=plo & 0xFFFFFFFF, yc=fin2["yc"], yx=fin2["yx"], yd=fin2["yd"], n_partials_received=n2)
+    mark("reduce")
+    # ---- 6. tiecov on the owned slice (whole bundles by construction of the cuts) -------------------------------------------
+    if device_chain:
+        res.cov_input = compute.groups_to_cov_in(fin2)
+    else:
+        ncg, cof, cg = _gather_cigars(X, tile2.cig_off, tile2.cig, rep2)
+        ycf = fin2["yc"].to(_torch().float32).to(_torch().float64) if _is_t(fin2["yc"]) else \
+            np.asarray(fin2["yc"]).astype(np.float32).astype(np.float64)
+        res.cov_input = CovInput(tid=tile2.tid[rep2], pos=tile2.pos[rep2], flag=X.as_dtype(X.zeros(g2, like=rep2), "u16"),
+                                 cig_off=X.as_dtype(cof, "u32"), cig=cg, yc=ycf, strand=tile2.strand[rep2], yx=X.to_i64(fin2["yx"]))
+    if want_coverage:
+        cov = compute.coverage(res.cov_input)
+        nj = yield ("all_gather", X.scalar(int(cov["n_junctions"]), like=rep2))
+        res.coverage = cov
+        res.junction_offset = int(X.host(nj).reshape(-1)[:rank].sum())
+    mark("coverage")
+    return res
+
+
 def _to_like(a, like):
     return _torch().from_numpy(np.ascontiguousarray(a)).to(like.device) if _is_t(like) else a
 
@@ -479,9 +690,11 @@ def _host_tile(tile):
 
 # ---- drivers ---------------------------------------------------------------------------------------------------
 def run_loopback(compute, tiles, first_fidx, **kw):
-    """Run R virtual ranks in one process: steps the R generators in lockstep and serves their collectives."""
+    """Run R virtual ranks in one process: steps the R generators in lockstep and serves their collectives.
+    mode="partials" (default): collapse locally, exchange group partials; mode="shuffle": the record shuffle."""
     world = len(tiles)
-    gens = [shard_collapse(compute, tiles[r], first_fidx[r], r, world, **kw) for r in range(world)]
+    gen_fn = shard_collapse if kw.pop("mode", "partials") == "shuffle" else partials_collapse
+    gens = [gen_fn(compute, tiles[r], first_fidx[r], r, world, **kw) for r in range(world)]
     reqs = [next(g) for g in gens]
     results = [None] * world
     while any(r is None for r in results):
@@ -595,7 +808,8 @@ def run_distributed(compute, tile, first_fidx, device=None, group=None, **kw):
                 o += rs[s_]
         return out
 
-    gen = shard_collapse(compute, tile, first_fidx, rank, world, **kw)
+    gen_fn = shard_collapse if kw.pop("mode", "partials") == "shuffle" else partials_collapse
+    gen = gen_fn(compute, tile, first_fidx, rank, world, **kw)
     try:
         req = next(gen)
         while True:
