@@ -8,22 +8,28 @@ tbk_collapse_tile (k-way merge order, grouping, YC/YX/YD) -> device chain (tbk_g
 Workload (BASELINE.json `configs`):
   N = 1   configs[2] = the largest single-GPU configuration: 64 synthetic sorted BAMs x 5M 100-bp reads, --clip collapse,
           then tiecov -c -j of the result                                                       (--profile c3 defaults)
-  N > 1   configs[3]'s shape: 32 files x 2M reads PER RANK (256 files over 8 GPUs), default CIGAR-only collapse; inside the
-          timed step the ranks agree on bundle-aligned coordinate cuts (all-gather of sampled keys, all-reduce rounds),
-          shuffle the passing records by coordinate (all-to-all over RCCL/xGMI) and each collapses + covers its own range
-          over ALL files (tiebrush_amd/dist.py); the shuffle of step i + 1 overlaps the collapse / tiecov / YD of step i (two tail
-          contexts, every collective issued by the main thread).  Weak scaling: per-rank input is fixed.
+  N > 1   configs[3]'s shape: 32 files x 2M reads PER RANK (256 files over 8 GPUs), default CIGAR-only collapse.  Inside the
+          timed step every rank collapses its own files (the plain single-GPU path), the ranks agree on bundle-aligned
+          coordinate cuts (all-gather of sampled group keys, all-reduce rounds), exchange one 40-byte row per LOCAL GROUP plus
+          its CIGAR (all-to-all over RCCL/xGMI), and each reduces the partials of its range by key and covers it
+          (tiebrush_amd/dist.py, partials_collapse).  Tile i + 1's local collapse (a worker thread, two contexts in turn)
+          overlaps tile i's exchange / reduce / tiecov (main thread, which issues every collective).  Weak scaling: per-rank
+          input is fixed.  After the timed region every rank also times the plain single-GPU step on its own tile
+          (`plain_ms_per_step`): the same workload without the exchange.
 The tile is generated on the GPU (tiebrush_amd/synth_dev.py) before the timed region.
 
 Prints ONE JSON line (rank 0).  value = input alignment records collapsed per second, whole job, inputs resident in HBM.
-Extra objects: `roofline` (dominant kernel, HIP events on the launch stream), `roofline_coverage` (cov_tile),
-`kernel_path_host_to_host` (the same step with the SoA starting in pinned host memory and every result ending there:
-H2D + D2H inside the clock, SURVEY.md §8d — reported, never `value`), `cpu_baseline` (the CPU oracle, 1 thread, gcc -O2
-and the reference's shipped -O0, on a bounded coordinate window of the same tile).
+Extra objects, all measured in this run unless they say otherwise: `roofline` (dominant kernel, HIP events on the launch
+stream), `roofline_coverage` (cov_tile: median / min / max over >= 10 serialised launches), `kernel_path_host_to_host` (the same
+step with the SoA starting in pinned host memory and every result ending there: H2D + D2H inside the clock, SURVEY.md §8d —
+reported, never `value`), `end_to_end` (the `tiebrush` command line on 32 x 1M-read BAM files written to /tmp, run as a child
+process before this process touches the GPU: process start, BGZF both ways, tagging and PCIe inside the clock), `cpu_baseline`
+(the CPU oracle: 1 thread at gcc -O2 and at the reference's shipped -O0, and a tiewrap-style multi-process line).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -43,6 +49,88 @@ ORACLE_KW = {"c2": {}, "c3": dict(strategy=2), "c4": {}, "c5": dict(strategy=3, 
 SYNTH_PROFILE = {"c2": "c2", "c3": "c3", "c4": "c2", "c5": "c5"}
 
 
+def host_memory_budget():
+    """bytes this process may use: min(cgroup limit, MemAvailable)"""
+    lim = None
+    for p in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+        try:
+            v = open(p).read().strip()
+            if v.isdigit():
+                lim = int(v)
+                break
+        except OSError:
+            pass
+    avail = None
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    c = [x for x in (lim, avail) if x]
+    return min(c) if c else 16 << 30
+
+
+def cpu_budget():
+    """worker processes worth starting: the CPU affinity / cgroup quota, not the machine's core count"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def _cpu_batch_worker(args):
+    """tiewrap-style batch (tiewrap.py:96-126): collapse the files of one batch with the oracle, return the collapsed records as a
+    TieBrush-merged SoA (spawned process: numpy + the oracle only, never the GPU)"""
+    shm_dir, b, okw = args
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd.soa import SoATile
+    ld = lambda name: np.load(os.path.join(shm_dir, "b%d_%s.npy" % (b, name)), mmap_mode="r")
+    fo = np.asarray(ld("file_off"))
+    t = SoATile(n_files=len(fo) - 1, file_off=fo, tbmerged=np.zeros(len(fo) - 1, np.uint8), tid=ld("tid"), pos=ld("pos"), flag=ld("flag"),
+                mapq=ld("mapq"), strand=ld("strand"), nh=ld("nh"), cig_off=ld("cig_off"), cig=ld("cig"))
+    g = orc.collapse(t, **okw)
+    rep = g["rep"].astype(np.int64)
+    co = np.asarray(t.cig_off).astype(np.int64)
+    nc = co[rep + 1] - co[rep]
+    off = np.concatenate([[0], np.cumsum(nc)])
+    idx = np.repeat(co[rep] - off[:-1], nc) + np.arange(int(off[-1]))
+    out = dict(tid=np.asarray(t.tid)[rep], pos=np.asarray(t.pos)[rep], flag=np.asarray(t.flag)[rep], mapq=np.asarray(t.mapq)[rep],
+               strand=np.asarray(t.strand)[rep], nh=np.asarray(t.nh)[rep], cig_off=off.astype(np.uint32), cig=np.asarray(t.cig)[idx],
+               yc=g["yc"].astype(np.float32).astype(np.float64), yx=g["yx"], yd=g["yd"].astype(np.int64))
+    for k, v in out.items():
+        np.save(os.path.join(shm_dir, "o%d_%s.npy" % (b, k)), v)
+    return b, int(g["n_passed"]), int(g["n_groups"])
+
+
+def _cpu_warm(_):
+    import numpy  # noqa: F401
+    sys.path.insert(0, ROOT)
+    from oracle import oracle_ffi as orc
+    orc.lib("O2")
+    return os.getpid()
+
+
+def run_e2e_leg(args):
+    """the `tiebrush` command line end to end, as a child process tree that ends before this process touches the GPU"""
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "e2e_leg.py"), "--files", str(args.e2e_files), "--reads", str(args.e2e_reads),
+           "--runs", str(args.e2e_runs)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        line = [l for l in r.stdout.strip().split("\n") if l.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": "tools/e2e_leg.py failed (%d): %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}
+        return json.loads(line[-1])
+    except Exception as e:       # the leg is a report, never the headline: a failure is stated in the line, not hidden
+        return {"error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,21 +141,34 @@ def main():
     ap.add_argument("--reads-per-file", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--e2e-files", type=int, default=32)
+    ap.add_argument("--e2e-reads", type=int, default=1_000_000)
+    ap.add_argument("--e2e-runs", type=int, default=3)
     ap.add_argument("--prof-steps", type=int, default=2, help="serialised per-kernel timing steps after the timed region (>= 1)")
+    ap.add_argument("--cov-prof-reps", type=int, default=10, help="serialised coverage calls behind roofline_coverage's median")
     ap.add_argument("--contexts", type=int, default=2, help="contexts (each with its own host thread) that take the steps in turn")
-    ap.add_argument("--cpu-sample-records", type=int, default=12_000_000, help="target size of the CPU-baseline window")
-    ap.add_argument("--force-dist", action="store_true", help="run the multi-rank (shuffle-then-collapse) path even with one rank")
+    ap.add_argument("--cpu-sample-records", type=int, default=0, help="size of the CPU-baseline sample (0: the whole tile when host memory allows)")
+    ap.add_argument("--cpu-procs", type=int, default=0, help="worker processes of the tiewrap-style CPU line (0: the CPU quota, at most 16)")
+    ap.add_argument("--force-dist", action="store_true", help="run the multi-rank (group-partials) path even with one rank")
+    ap.add_argument("--dist-mode", default="partials", choices=["partials", "shuffle"])
     args = ap.parse_args()
     args.prof_steps = max(1, args.prof_steps)
-
-    import numpy as np
-    import torch
-    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or args.force_dist
+
+    # ---- end to end through the command line: a child process, finished before this process initialises the GPU ----
+    e2e = None
+    if rank == 0 and not use_dist and not args.no_e2e:
+        e2e = run_e2e_leg(args)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -85,11 +186,12 @@ def main():
     dev = "cuda:%d" % local_rank
     torch.cuda.set_device(local_rank)
 
-    profile = args.profile or ("c3" if world == 1 else "c4")
+    profile = args.profile or ("c3" if not use_dist else "c4")
     files, reads, strat, strat_name = WORKLOADS[profile]
     files = args.files_per_gpu or files
     reads = args.reads_per_file or reads
 
+    import queue
     import threading
 
     from tiebrush_amd import api, synth, synth_dev
@@ -100,145 +202,34 @@ def main():
     t_gen = time.perf_counter() - t_gen
     n_records = dtile.n_records
     n_cig_in = int(dtile.cig.numel())
-    # Two contexts take the steps in turn (software pipelining of independent tiles, as a streaming host would run them):
-    # the YD list machine of step i — deferred onto its context's side stream — overlaps the tiecov chain of step i and the
-    # collapse of step i + 1.  Every step's YD is complete before the timed region ends.
+    # Contexts take the steps in turn (software pipelining of independent tiles, as a streaming host would run them): the YD list
+    # machine of step i — deferred onto its context's side stream — overlaps the tiecov chain of step i and the collapse of step
+    # i + 1.  Every step's YD is complete before the timed region ends.
     NCTX = max(1, args.contexts)
     ctxs = [api.Context(local_rank) for _ in range(NCTX)]
     ctx = ctxs[0]
     opts_defer = ctx.make_opts(defer_yd=True, **strat)
     cbufs2, vbufs2 = [{} for _ in range(NCTX)], [{} for _ in range(NCTX)]
     cbufs, vbufs = cbufs2[0], vbufs2[0]
-    step_no = [0]
 
-    class TailCompute:
-        """what runs behind the shuffle (collapse of the owned range, device chain, tiecov, YD) on a context of its own"""
-
-        def __init__(self, cx):
-            self.cx = cx
-            self.bufs = {}
-
-        def collapse(self, tile, **kw):
-            return self.cx.collapse(tile, out=self.bufs.setdefault(("c", tile.n_files), {}), **kw)
-
-        def groups_to_cov_in(self, fin):
-            return self.cx.groups_to_cov_in(fin)
-
-        def coverage(self, view):
-            return self.cx.coverage(view, out=self.bufs.setdefault("v", {}), raw=True)
-
-        def finish_yd(self):
-            self.cx.finish_yd()
-
-    class TailHandle:
-        def __init__(self):
-            self.res, self.err, self.th = None, None, None
-
-        def wait(self):
-            if self.th is not None:
-                self.th.join()
-                self.th = None
-            if self.err is not None:
-                raise self.err
-            return self.res
-
-    class StitchCompute:
-        """compute object of tiebrush_amd.dist.  The shuffle (merge keys, cuts, pack, unpack) runs on `ctx` in the calling
-        thread, which also issues every collective; what follows it — no collective inside — is handed over (submit_tail) to
-        one of two tail contexts with a thread each, so tile i's collapse / tiecov / YD overlap tile i + 1's shuffle and
-        exchange.  Receive buffers alternate with the tails."""
-
-        def __init__(self):
-            self.bufs = {}
-            self.tails = None                        # two contexts, created when the first tail is handed over
-            self.pending = [None, None]
-            self.turn = 0
-
-        def shard_prepare(self, tile, **kw):
-            return ctx.shard_prepare(tile, out=self.bufs.setdefault("sp", {}), **kw)
-
-        def shard_probe_max(self, *a):
-            return ctx.shard_probe_max(*a)
-
-        def shard_probe_next(self, *a):
-            return ctx.shard_probe_next(*a)
-
-        def shard_pack(self, *a):
-            return ctx.shard_pack(*a, out=self.bufs.setdefault("pk", {}))
-
-        def shard_unpack(self, rows, file_off2):
-            if self.pending[self.turn] is not None:      # the tail that still reads this set of receive buffers
-                self.pending[self.turn].wait()
-            return ctx.shard_unpack(rows, file_off2, out=self.bufs.setdefault(("up", self.turn), {}))
-
-        def submit_tail(self, fn):
-            if self.tails is None:
-                self.tails = [TailCompute(api.Context(local_rank)) for _ in range(2)]
-            i = self.turn
-            self.turn ^= 1
-            h = TailHandle()
-
-            def run():
-                try:
-                    h.res = fn(self.tails[i])
-                except BaseException as e:             # surfaces at wait(): a failed step fails the bench
-                    h.err = e
-
-            h.th = threading.Thread(target=run)
-            h.th.start()
-            self.pending[i] = h
-            return h
-
-        def drain(self):
-            for h in self.pending:
-                if h is not None:
-                    h.wait()
-
-    from tiebrush_amd import dist as tdist
-    stitch = StitchCompute()
-
-    def step(tile=dtile):
-        if use_dist:
-            # bundle-aligned cuts (all-gather + all-reduce) -> all-to-all of the passing records over RCCL/xGMI -> one
-            # collapse of the owned coordinate range over all files -> tiecov of it, everything resident in HBM
-            return tdist.run_distributed(stitch, tile, rank * files, device=dev, want_coverage=True, device_chain=True, **strat)
-        i = step_no[0] % NCTX
-        step_no[0] += 1
-        cx = ctxs[i]
-        g = cx.collapse(tile, opts=opts_defer, want_coords=True, out=cbufs2[i], raw=True)   # (waits for this context's previous YD stage)
+    def plain_step(cx, tile, cb, vb):
+        g = cx.collapse(tile, opts=opts_defer, want_coords=True, out=cb, raw=True)   # (waits for this context's previous YD stage)
         view = cx.groups_to_cov_in(g)
-        c = cx.coverage(view, out=vbufs2[i], raw=True)
+        c = cx.coverage(view, out=vb, raw=True)
         return g, c
 
-    def drain():
-        if use_dist:
-            stitch.drain()                                # every tail (collapse, tiecov, YD of its tile) has finished
-            return
-        for cx in ctxs:
-            cx.finish_yd()                                # every output of every step, YD included, is final here
-
-    # K steps = K independent tiles.  Without collectives the two contexts are driven by two host threads (the C ABI blocks its
-    # caller while a stage runs and ctypes drops the GIL meanwhile): tile i + 1's collapse runs beside tile i's tiecov chain and
-    # YD stage — what a streaming host with two workers does.  Launch-bound workloads (config 2) gain most; config 3 keeps the GPU
-    # busy either way.
     last = [None] * NCTX
 
-    def run_steps(k):
-        if use_dist:
-            for _ in range(k):
-                last[0] = step()
-            return
-
+    def run_plain(k, tile=dtile):
+        """K independent tiles, contexts driven by one host thread each (the C ABI blocks its caller while a stage runs and ctypes
+        drops the GIL meanwhile): tile i + 1's collapse runs beside tile i's tiecov chain and YD stage"""
         errs = []
 
         def worker(i, cnt):
-            cx = ctxs[i]
+            torch.cuda.set_device(local_rank)             # (the current device is per thread)
             try:
                 for _ in range(cnt):
-                    gq = cx.collapse(dtile, opts=opts_defer, want_coords=True, out=cbufs2[i], raw=True)
-                    view = cx.groups_to_cov_in(gq)
-                    cq = cx.coverage(view, out=vbufs2[i], raw=True)
-                    last[i] = (gq, cq)
+                    last[i] = plain_step(ctxs[i], tile, cbufs2[i], vbufs2[i])
             except BaseException as e:                    # a failed step fails the bench, never a silent short count
                 errs.append(e)
 
@@ -249,16 +240,139 @@ def main():
             x.join()
         if errs:
             raise errs[0]
+        for cx in ctxs:
+            cx.finish_yd()                                # every output of every step, YD included, is final here
+
+    # ---- multi-rank step: local collapse (worker thread) -> partials exchange, reduce, tiecov (main thread) ----------------
+    from tiebrush_amd import dist as tdist
+    phase_ms = {}
+    wire = {"wire_bytes": 0, "wire_bytes_off_rank": 0, "wire_rows": 0, "steps": 0}
+
+    class OwnerCompute:
+        """compute object of tiebrush_amd.dist for one tile: the cut search and the pack read the local groups on the context
+        that produced them (`cl`, idle while the worker uses the other one); everything behind the exchange runs on `co`"""
+
+        def __init__(self, cl, co, bufs, done_with_local):
+            self.cl, self.co, self.bufs, self.done = cl, co, bufs, done_with_local
+            self.t = time.perf_counter()
+
+        def mark(self, name):
+            now = time.perf_counter()
+            phase_ms[name] = phase_ms.get(name, 0.0) + (now - self.t) * 1e3
+            self.t = now
+
+        def partial_keys(self, tile, fin):
+            return self.cl.partial_keys(tile, fin, out=self.bufs.setdefault("pk", {}))
+
+        def shard_probe_max(self, *a):
+            return self.cl.shard_probe_max(*a)
+
+        def shard_probe_next(self, *a):
+            return self.cl.shard_probe_next(*a)
+
+        def partial_pack(self, *a):
+            r = self.cl.partial_pack(*a, out=self.bufs.setdefault("pp", {}))
+            return r
+
+        def partial_unpack(self, rows):
+            self.done()                                   # the rows have left the local buffers: the worker may reuse the slot
+            return self.co.partial_unpack(rows, out=self.bufs.setdefault("pu", {}))
+
+        # record-shuffle fallback (carried fractional YC): same contexts
+        def shard_prepare(self, tile, **kw):
+            return self.cl.shard_prepare(tile, out=self.bufs.setdefault("sp", {}), **kw)
+
+        def shard_pack(self, *a):
+            return self.cl.shard_pack(*a, out=self.bufs.setdefault("spk", {}))
+
+        def shard_unpack(self, rows, fo2):
+            self.done()
+            return self.co.shard_unpack(rows, fo2, out=self.bufs.setdefault("sup", {}))
+
+        def collapse(self, tile, **kw):
+            return self.co.collapse(tile, out=self.bufs.setdefault(("c", tile.n_files), {}), **kw)
+
+        def groups_to_cov_in(self, fin):
+            return self.co.groups_to_cov_in(fin)
+
+        def coverage(self, view):
+            return self.co.coverage(view, out=self.bufs.setdefault("v", {}), raw=True)
+
+    dctx = {}
+
+    def run_dist(k):
+        if not dctx:
+            dctx["local"] = [api.Context(local_rank) for _ in range(2)]
+            dctx["owner"] = api.Context(local_rank)
+            dctx["lbufs"] = [{}, {}]
+            dctx["obufs"] = {}
+            dctx["opts"] = dctx["local"][0].make_opts(defer_yd=True, **strat)
+        cl, co = dctx["local"], dctx["owner"]
+        ready = queue.Queue()
+        free = [threading.Semaphore(1), threading.Semaphore(1)]
+
+        def worker():
+            torch.cuda.set_device(local_rank)
+            try:
+                fins = [None, None]
+                for i in range(k):
+                    s = i & 1
+                    free[s].acquire()                     # tile i - 2's rows have left this slot's buffers
+                    fins[s] = cl[s].collapse(dtile, opts=dctx["opts"], want_coords=True, want_effend=True, out=dctx["lbufs"][s])
+                    if i > 0:
+                        cl[s ^ 1].finish_yd()             # tile i - 1's YD ran beside tile i's window kernels
+                        ready.put((i - 1, fins[s ^ 1]))
+                cl[(k - 1) & 1].finish_yd()
+                ready.put((k - 1, fins[(k - 1) & 1]))
+            except BaseException as e:
+                ready.put((-1, e))
+
+        th = threading.Thread(target=worker)
+        th.start()
+        res = None
+        try:
+            for i in range(k):
+                j, fin = ready.get()
+                if j < 0:
+                    raise fin
+                assert j == i
+                s = i & 1
+                released = [False]
+
+                def done(s=s, released=released):
+                    if not released[0]:
+                        released[0] = True
+                        free[s].release()
+
+                comp = OwnerCompute(cl[s], co, dctx["obufs"], done)
+                st = {}
+                kw = dict(strat)
+                res = tdist.run_distributed(comp, dtile, rank * files, device=dev, want_coverage=True, device_chain=True, mode=args.dist_mode,
+                                            **(dict(local=fin, stats=st) if args.dist_mode == "partials" else {}), **kw)
+                done()
+                for kk in ("wire_bytes", "wire_bytes_off_rank", "wire_rows"):
+                    wire[kk] += st.get(kk, 0)
+                wire["steps"] += 1
+        finally:
+            th.join()
+        return res
+
+    def run_steps(k):
+        if use_dist:
+            return run_dist(k)
+        run_plain(k)
+        return None
 
     run_steps(args.warmup)
-    drain()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    phase_ms.clear()
+    for kk in wire:
+        wire[kk] = 0
     t0 = time.perf_counter()
-    run_steps(args.steps)
-    drain()
+    dres = run_steps(args.steps)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -267,8 +381,7 @@ def main():
     free_b, total_b = torch.cuda.mem_get_info(dev)
     hbm_used_gb = round((total_b - free_b) / 1e9, 1)      # tile + every context's arena and outputs, after the timed region
     if use_dist:
-        r = last[0].wait()
-        g, c = {"n_passed": r.n_passed_local, "n_groups": r.n_groups}, r.coverage
+        g, c = {"n_passed": dres.n_passed_local, "n_groups": dres.n_groups}, dres.coverage
     else:
         g, c = next(x for x in last if x is not None)
     n_passed, n_groups = g["n_passed"], g["n_groups"]
@@ -284,6 +397,37 @@ def main():
         tot_records, tot_bases = float(sm[1]), float(sm[2])
     else:
         tot_records, tot_bases = float(n_passed), float(n_bases)
+
+    # ---- multi-rank: the same per-rank workload through the plain single-GPU path, after the timed region (every rank runs it,
+    # nothing is exchanged): what the exchange costs, on the same tile, in the same run ----
+    dist_extra = {}
+    if use_dist:
+        ksteps = max(2, min(args.steps, 10))
+        run_plain(min(2, ksteps))
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        run_plain(ksteps)
+        torch.cuda.synchronize()
+        plain_dt = (time.perf_counter() - t1) / ksteps
+        dist.barrier()
+        pg, pc = next(x for x in last if x is not None)
+        nst = max(wire["steps"], 1)
+        ph = {k_: round(v / nst, 3) for k_, v in phase_ms.items()}
+        dist_extra = {
+            "plain_ms_per_step": round(plain_dt * 1e3, 4),
+            "plain_records_per_s_per_gpu": round(pg["n_passed"] / plain_dt, 1),
+            "shuffle_ms_per_step": round(sum(ph.get(k_, 0.0) for k_ in ("cuts", "pack", "exchange", "unpack", "prepare")), 3),
+            "wire_bytes_per_step": int(wire["wire_bytes"] / nst),
+            "wire_bytes_off_rank_per_step": int(wire["wire_bytes_off_rank"] / nst),
+            "partials_per_step": int(wire["wire_rows"] / nst),
+            "dist_mode": args.dist_mode,
+            "dist_phase_host_ms_per_step": ph,
+            "dist_note": "rank 0's figures.  plain_ms_per_step: the plain single-GPU step (collapse + chain + tiecov, %d contexts) on this "
+                         "rank's own tile, timed after the timed region; shuffle_ms_per_step: host wall time of the main thread between the "
+                         "local collapse and the owner's reduce (cut search, pack, exchange, unpack) — it overlaps the worker thread's next "
+                         "local collapse; wire bytes: rows x 40 B + CIGAR words, all destinations (off_rank: without the self block)" % NCTX,
+        }
 
     # ---- per-kernel durations (HIP events on the launch stream) -> roofline of the dominant kernel ----
     roof = {}
@@ -307,37 +451,62 @@ def main():
             take("chain")                  # tiebrush -> tiecov device chain (representatives gathered into tiecov's input view)
             cc = ctx.coverage(view, out=vbufs, raw=True)
             take("coverage")
+        cov_tile_us, cov_call_ms = [], []
+        for _ in range(max(0, args.cov_prof_reps)):   # further serialised coverage calls on the same view: the spread of cov_tile
+            t1 = time.perf_counter()
+            ctx.coverage(view, out=vbufs, raw=True)
+            cov_call_ms.append((time.perf_counter() - t1) * 1e3)
+            kt = ctx.kernel_times()
+            if "cov_tile" in kt:
+                cov_tile_us.append(kt["cov_tile"][0] / max(kt["cov_tile"][1], 1) * 1e3)
         ctx.set_profiling(False)
         # algorithmic bytes; the profiled steps are rank 0's local collapse + coverage
         b_collapse = gg["n_passed"] * 16 + 4 * n_cig_in
         ncig_cov = int(view.n_cigar_ops)
         b_cov = gg["n_groups"] * 12 + 4 * ncig_cov + 16 * cc["span_bases"] + 16 * cc["n_intervals"]
         traffic = {}
-        tpath = os.path.join(ROOT, "profiles", "traffic_%s_%dx%d.json" % (profile, files, reads))
-        if os.path.exists(tpath):          # PMC passes (FETCH_SIZE / WRITE_SIZE, corrected) of this same workload, per launch
-            traffic = json.load(open(tpath)).get("bytes_per_launch", {})
+        tname = "traffic_%s_%dx%d.json" % (profile, files, reads)
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if os.path.exists(tpath):          # PMC passes (FETCH_SIZE / WRITE_SIZE) of this same workload, per launch: rocprofv3 counters
+            traffic = json.load(open(tpath)).get("bytes_per_launch", {})   # cannot be read from inside the process they profile
 
-        def roofline(stage, name, alg_bytes):
+        def roofline(stage, name, alg_bytes, launch_us=None):
             ms, ln = acc[(stage, name)]
             per_launch_ms = ms / ln
             launches_per_step = ln / args.prof_steps
+            r = {"kernel": name, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+            if launch_us:                  # a list of per-launch durations: quote the median, state the spread
+                s_ = sorted(launch_us)
+                med = s_[len(s_) // 2]
+                per_launch_ms = med / 1e3
+                r.update(avg_launch_us=round(med, 2), launch_us_min=round(s_[0], 2), launch_us_max=round(s_[-1], 2), launches_measured=len(s_),
+                         statistic="median")
+            else:
+                r.update(avg_launch_us=round(per_launch_ms * 1e3, 2))
             achieved = (alg_bytes / launches_per_step) / (per_launch_ms * 1e-3) / 1e9
-            return {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic.get(name),
-                    "avg_launch_us": round(per_launch_ms * 1e3, 2), "launches_per_step": launches_per_step,
-                    "measured": "HIP events on the launch stream, profiling steps after the timed region, calls serialised (kernel alone on the GPU)",
-                    "algorithmic_bytes_per_step": int(alg_bytes)}
+            tb = traffic.get(name)
+            r.update(achieved=round(achieved, 1), frac=round(achieved / HBM_PEAK_GBS, 4), traffic=tb,
+                     frac_traffic=round(tb / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tb else None,
+                     traffic_source=("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, per launch)" % tname) if tb else None,
+                     launches_per_step=launches_per_step, algorithmic_bytes_per_step=int(alg_bytes),
+                     measured="HIP events on the launch stream, profiling steps after the timed region, calls serialised (kernel alone on the GPU)")
+            return r
 
         tot = {k: v[0] / args.prof_steps for k, v in acc.items()}
         dom = max(tot, key=tot.get)
         roof["roofline"] = roofline(dom[0], dom[1], b_collapse if dom[0] == "collapse" else b_cov)
         if ("coverage", "cov_tile") in acc:
-            roof["roofline_coverage"] = roofline("coverage", "cov_tile", b_cov)
+            roof["roofline_coverage"] = roofline("coverage", "cov_tile", b_cov, cov_tile_us or None)
+            if cov_call_ms:
+                s_ = sorted(cov_call_ms)
+                roof["roofline_coverage"]["coverage_call_ms_median"] = round(s_[len(s_) // 2], 3)
+                roof["roofline_coverage"]["frac_whole_call"] = round(b_cov / (s_[len(s_) // 2] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         cdom = max((k for k in tot if k[0] == "collapse"), key=tot.get)
         roof["roofline_collapse"] = roofline("collapse", cdom[1], b_collapse)
         roof["kernel_ms_per_step"] = {"%s/%s" % k: round(v, 4) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}
         roof["launches_per_step"] = int(sum(v[1] for v in acc.values()) / args.prof_steps)
         roof["gpu_kernel_ms_per_step_total"] = round(sum(tot.values()), 4)
+        roof["step_frac_of_hbm_peak_algorithmic"] = round((b_collapse + b_cov) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4) if not use_dist else None
 
     # ---- kernel path, pinned host -> pinned host: H2D of the SoA and D2H of every result inside the clock ----
     host_path = None
@@ -355,9 +524,8 @@ def main():
             for k in names:
                 getattr(stage, k).copy_(hin[k], non_blocking=True)
             torch.cuda.current_stream().synchronize()
-            step_no[0] = 0
-            gq, cq = step(stage)
-            drain()
+            gq, cq = plain_step(ctx, stage, cbufs, vbufs)
+            ctx.finish_yd()
             ng, ni, nj = gq["n_groups"], cq["n_intervals"], cq["n_junctions"]
             outs = [(cbufs[k], ng) for k in ("rep", "yc", "yx", "yd", "g_start", "g_end")]
             outs += [(vbufs[k], ni) for k in ("iv_tid", "iv_start", "iv_end", "iv_val")]
@@ -383,43 +551,10 @@ def main():
                      "note": "SoA in pinned host memory -> groups, intervals and junctions in pinned host memory; PCIe inside the clock"}
         del hin, stage, hout
 
-    # ---- CPU baseline: the oracle (literal single-threaded restatement of the reference) on a bounded coordinate window ----
+    # ---- CPU baseline: the oracle (literal single-threaded restatement of the reference) ----
     cpu = None
     if rank == 0 and not use_dist and not args.no_cpu_baseline:
-        from oracle import oracle_ffi as orc
-        okw = ORACLE_KW[profile]
-        # window: the first w bases of chr3 in every file, w sized so that about --cpu-sample-records records fall inside
-        frac = min(1.0, args.cpu_sample_records / max(n_records, 1))
-        if frac >= 1.0:
-            sample = synth_dev.tile_to_host(dtile)
-            wdesc = "the whole tile"
-        else:
-            n_t2 = int((dtile.tid == 2).sum())
-            w = int(synth.REF_LENS[2] * min(1.0, args.cpu_sample_records / max(n_t2, 1)))
-            sample = synth_dev.tile_to_host(dtile, window=(2, 0, w))
-            wdesc = "all %d files restricted to chr3:0-%d" % (files, w)
-
-        def cpu_leg(opt, budget_s):
-            reps = 0
-            t1 = time.perf_counter()
-            while True:
-                og = orc.collapse(sample, opt=opt, **okw)
-                oc = orc.coverage(synth.collapsed_to_cov_input(sample, og), opt=opt)
-                reps += 1
-                if time.perf_counter() - t1 > budget_s or reps >= 20:
-                    break
-            return og, oc, og["n_passed"] * reps / (time.perf_counter() - t1), reps
-
-        og, oc, v2, r2 = cpu_leg("O2", 10.0)
-        _, _, v0, r0 = cpu_leg("O0", 10.0)
-        # the GPU path on the same sample must agree with the oracle (counts here; tests/ compare every array)
-        sg = ctx.collapse(api.to_device(sample, dev), **strat)
-        assert sg["n_passed"] == og["n_passed"] and sg["n_groups"] == og["n_groups"], "GPU/oracle disagree on the bench sample"
-        cpu = {"value": round(v2, 1), "unit": "records/s", "cores": 1, "kind": "port",
-               "sample": "%s: %d records -> %d groups, collapse+coverage on SoA, gcc -O2, %d repetition(s)" %
-                         (wdesc, sample.n_records, og["n_groups"], r2),
-               "value_O0": round(v0, 1), "note_O0": "same code at -O0 -g, how the reference ships (CMakeLists.txt:49), %d repetition(s)" % r0,
-               "host_cores_available": os.cpu_count()}
+        cpu = cpu_baseline(args, profile, files, dtile, ctx, strat, n_records)
 
     if rank == 0:
         line = {
@@ -439,19 +574,16 @@ def main():
                                    % (profile, files, reads, strat_name),
                        "records_per_gpu": int(n_records), "groups_out": int(n_groups), "parallelism": "files-per-rank x%d" % world,
                        "resident": "SoA in HBM before the timed region", "generated_on_device_s": round(t_gen, 2),
-                       "contexts": NCTX, "hbm_in_use_gb": hbm_used_gb},
+                       "contexts": NCTX if not use_dist else 3, "hbm_in_use_gb": hbm_used_gb},
             "bases_per_s": round(tot_bases * args.steps / dt, 1),
             "tiecov": {"bases_covered_per_step": int(n_bases), "bundle_span_bases": int(span), "intervals": int(n_iv), "junctions": int(n_j)},
         }
+        line.update(dist_extra)
         line.update(roof)
         if host_path is not None:
             line["kernel_path_host_to_host"] = host_path
-        e2e_path = os.path.join(ROOT, "profiles", "r2_e2e_32x1M.json")
-        if os.path.exists(e2e_path):   # the command lines end to end (BAM files -> BAM file): measured by tools/e2e_bench.py, not in this run
-            e = json.load(open(e2e_path))
-            line["end_to_end"] = {"value": e["records_per_s_end_to_end"], "unit": "records/s", "workload": e["workload"],
-                                  "wall_s": e["tiebrush_wall_s"], "host_decode_wall_s": e.get("host_decode_wall_s"),
-                                  "source": "profiles/r2_e2e_32x1M.json (tools/e2e_bench.py on the same kind of box; process start, BGZF both ways, PCIe inside the clock)"}
+        if e2e is not None:
+            line["end_to_end"] = e2e
         if cpu is not None:
             line["cpu_baseline"] = cpu
     if use_dist:
@@ -464,6 +596,122 @@ def main():
         except Exception:
             pass
         print(json.dumps(line), flush=True)
+
+
+def cpu_baseline(args, profile, files, dtile, ctx, strat, n_records):
+    """1 thread at -O2 (how one would build it) and at -O0 (how the reference ships, CMakeLists.txt:49), and the reference's own
+    best-case parallel mode: tiewrap-style batches (tiewrap.py:96-126: `-t cores -b ceil(k / cores)`, every batch collapsed by its own
+    process, the batch outputs collapsed again as TieBrush-merged inputs)."""
+    import multiprocessing as mp
+    import shutil
+    import tempfile
+
+    import numpy as np
+
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import api, synth, synth_dev
+    from tiebrush_amd.soa import SoATile
+    okw = ORACLE_KW[profile]
+    import torch
+    dev = dtile.tid.device
+    tile_bytes = sum(int(getattr(dtile, k).numel()) * getattr(dtile, k).element_size() for k in ("tid", "pos", "flag", "mapq", "strand", "nh", "cig_off", "cig"))
+    budget = host_memory_budget()
+    want = args.cpu_sample_records or n_records
+    if want >= n_records and tile_bytes * 3.2 + (8 << 30) > budget:      # host copy + its /dev/shm batches + outputs
+        want = int(n_records * max(0.02, (budget - (8 << 30)) / (tile_bytes * 3.2)))
+    if want >= n_records:
+        sample = synth_dev.tile_to_host(dtile)
+        wdesc = "the whole tile"
+    else:
+        n_t2 = int((dtile.tid == 2).sum())
+        w = int(synth.REF_LENS[2] * min(1.0, want / max(n_t2, 1)))
+        sample = synth_dev.tile_to_host(dtile, window=(2, 0, w))
+        wdesc = "all %d files restricted to chr3:0-%d" % (files, w)
+
+    orc.lib("O2"), orc.lib("O0")                                          # (loading the libraries: before the clock)
+    t1 = time.perf_counter()
+    og = orc.collapse(sample, opt="O2", **okw)
+    oc = orc.coverage(synth.collapsed_to_cov_input(sample, og), opt="O2")
+    d2 = time.perf_counter() - t1
+    v2 = og["n_passed"] / d2
+    # the -O0 leg on a bounded slice of the sample (about 10 s of work): the ratio is what matters
+    n0 = min(sample.n_records, int(max(1.0, v2 / 2.0) * 10.0))
+    if n0 >= sample.n_records:
+        s0 = sample
+    else:
+        frac = n0 / sample.n_records
+        fo = sample.file_off.astype(np.int64)
+        key = (sample.tid.astype(np.int64) << 32) | sample.pos.astype(np.int64)
+        kcut = np.sort(key[::max(1, len(key) // 4096)])[int(frac * min(4096, len(key) - 1))]
+        sel = [(int(fo[f]), int(fo[f]) + int(np.searchsorted(key[fo[f]:fo[f + 1]], kcut))) for f in range(sample.n_files)]
+        co = sample.cig_off.astype(np.int64)
+        cat = lambda a: np.concatenate([a[x:y] for x, y in sel])
+        nfo = np.zeros(sample.n_files + 1, np.uint32)
+        nfo[1:] = np.cumsum([y - x for x, y in sel])
+        ncg = np.concatenate([co[x + 1:y + 1] - co[x:y] for x, y in sel])
+        s0 = SoATile(n_files=sample.n_files, file_off=nfo, tbmerged=sample.tbmerged.copy(), tid=cat(sample.tid), pos=cat(sample.pos),
+                     flag=cat(sample.flag), mapq=cat(sample.mapq), strand=cat(sample.strand), nh=cat(sample.nh),
+                     cig_off=np.concatenate([[0], np.cumsum(ncg)]).astype(np.uint32),
+                     cig=np.concatenate([sample.cig[int(co[x]):int(co[y])] for x, y in sel]))
+    t1 = time.perf_counter()
+    o0 = orc.collapse(s0, opt="O0", **okw)
+    orc.coverage(synth.collapsed_to_cov_input(s0, o0), opt="O0")
+    v0 = o0["n_passed"] / (time.perf_counter() - t1)
+    # the GPU path on the same sample must agree with the oracle (counts here; tests/ compare every array)
+    if sample.n_records <= 64_000_000:
+        sg = ctx.collapse(api.to_device(sample, str(dev)), **strat)
+        assert sg["n_passed"] == og["n_passed"] and sg["n_groups"] == og["n_groups"], "GPU/oracle disagree on the bench sample"
+    cpu = {"value": round(v2, 1), "unit": "records/s", "cores": 1, "kind": "port",
+           "sample": "%s: %d records -> %d groups, collapse + coverage on SoA, gcc -O2, 1 pass (%.1f s)" % (wdesc, sample.n_records, og["n_groups"], d2),
+           "value_O0": round(v0, 1), "note_O0": "same code at -O0 -g, how the reference ships (CMakeLists.txt:49), on the first %d records of the sample" % s0.n_records,
+           "host_cores_available": os.cpu_count(), "host_cpu_quota": cpu_budget()}
+
+    # ---- tiewrap-style parallel line ----
+    procs = args.cpu_procs or min(16, cpu_budget(), sample.n_files)
+    if procs >= 2:
+        shm = tempfile.mkdtemp(prefix="tbk_cpu_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        try:
+            k = sample.n_files
+            bsz = -(-k // procs)                           # tiewrap: -b ceil(k / cores)
+            nb = -(-k // bsz)
+            fo, co = sample.file_off.astype(np.int64), sample.cig_off.astype(np.int64)
+            for b in range(nb):                            # (input staging: outside the clock, like reading the BAMs would be)
+                f0, f1 = b * bsz, min(k, (b + 1) * bsz)
+                lo, hi = int(fo[f0]), int(fo[f1])
+                np.save(os.path.join(shm, "b%d_file_off.npy" % b), (fo[f0:f1 + 1] - fo[f0]).astype(np.uint32))
+                for nm in ("tid", "pos", "flag", "mapq", "strand", "nh"):
+                    np.save(os.path.join(shm, "b%d_%s.npy" % (b, nm)), getattr(sample, nm)[lo:hi])
+                np.save(os.path.join(shm, "b%d_cig_off.npy" % b), (co[lo:hi + 1] - co[lo]).astype(np.uint32))
+                np.save(os.path.join(shm, "b%d_cig.npy" % b), sample.cig[int(co[lo]):int(co[hi])])
+            mpx = mp.get_context("spawn")                  # (never fork a process that holds a GPU context)
+            with mpx.Pool(min(procs, nb)) as pool:
+                pool.map(_cpu_warm, range(4 * procs))          # (interpreter start and imports: before the clock)
+                t1 = time.perf_counter()
+                outs = pool.map(_cpu_batch_worker, [(shm, b, okw) for b in range(nb)])
+                t_batches = time.perf_counter() - t1
+            # second level: the batch outputs as TieBrush-merged inputs of one more run (tiewrap.py:120-126)
+            t1 = time.perf_counter()
+            ld = lambda b, nm: np.load(os.path.join(shm, "o%d_%s.npy" % (b, nm)))
+            ngs = [o[2] for o in sorted(outs)]
+            fo2 = np.concatenate([[0], np.cumsum(ngs)]).astype(np.uint32)
+            ncs = [ld(b, "cig_off") for b in range(nb)]
+            co2 = np.concatenate([[0], np.cumsum(np.concatenate([np.diff(c.astype(np.int64)) for c in ncs]))]).astype(np.uint32)
+            cat = lambda nm: np.concatenate([ld(b, nm) for b in range(nb)])
+            t2 = SoATile(n_files=nb, file_off=fo2, tbmerged=np.ones(nb, np.uint8), tid=cat("tid"), pos=cat("pos"), flag=cat("flag"),
+                         mapq=cat("mapq"), strand=cat("strand"), nh=cat("nh"), cig_off=co2, cig=cat("cig"), yc_in=cat("yc"), yx_in=cat("yx"),
+                         yd_in=cat("yd"))
+            og2 = orc.collapse(t2, opt="O2", **okw)
+            orc.coverage(synth.collapsed_to_cov_input(t2, og2), opt="O2")
+            t_final = time.perf_counter() - t1
+            assert og2["n_groups"] == og["n_groups"] and float(og2["yc"].sum()) == float(og["yc"].sum()), "hierarchical CPU run disagrees with the flat one"
+            cpu["parallel"] = {"value": round(og["n_passed"] / (t_batches + t_final), 1), "unit": "records/s", "cores": min(procs, nb),
+                               "kind": "port", "mode": "tiewrap-style: %d batches of %d files, one process each (%.1f s), then one run over the %d "
+                                                       "batch outputs as TieBrush-merged inputs + coverage (%.1f s); tiewrap.py:96-126" %
+                                                       (nb, bsz, t_batches, nb, t_final),
+                               "sample": "the same sample; batch inputs staged in /dev/shm outside the clock"}
+        finally:
+            shutil.rmtree(shm, ignore_errors=True)
+    return cpu
 
 
 if __name__ == "__main__":

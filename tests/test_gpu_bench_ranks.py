@@ -28,4 +28,26 @@ def test_bench_two_ranks_contract():
     assert d["config"]["records_per_gpu"] == 60000
     # whole-job value: both ranks' records over the slowest rank's time
     assert abs(d["value"] - 2 * 60000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.02
-    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "frac_traffic"} <= set(d["roofline"])
+    # the same per-rank workload through the plain path, the exchange's cost and its volume ride in the line
+    assert d["plain_ms_per_step"] > 0 and d["shuffle_ms_per_step"] >= 0 and d["dist_mode"] == "partials"
+    assert 0 < d["wire_bytes_per_step"] < 60000 * 24              # group partials, not records, crossed the wire
+    assert 0 < d["partials_per_step"] <= 60000
+
+
+def test_bench_default_line_contract_small():
+    """the N = 1 line on a small shape: end_to_end and cpu_baseline (1 thread + tiewrap-style processes) are measured in the run"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--profile", "c3", "--files-per-gpu", "6",
+           "--reads-per-file", "40000", "--e2e-files", "3", "--e2e-reads", "20000", "--e2e-runs", "1", "--cov-prof-reps", "10"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.strip().split("\n") if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["config"]["records_per_gpu"] == 240000
+    e = d["end_to_end"]
+    assert "error" not in e, e
+    assert e["value"] > 0 and e["runs"] == 1 and "60000 input records written as" in e["summary"]
+    c = d["cpu_baseline"]
+    assert c["cores"] == 1 and c["value"] > 0 and c["value_O0"] > 0 and c["sample"].startswith("the whole tile")
+    assert c["parallel"]["cores"] >= 2 and c["parallel"]["value"] > 0
+    rc = d["roofline_coverage"]
+    assert rc["launches_measured"] >= 10 and rc["launch_us_min"] <= rc["avg_launch_us"] <= rc["launch_us_max"]

@@ -135,3 +135,13 @@ def test_bigwig_many_chromosomes(tmp_path):
     bw = BigWig(str(out))
     assert len(bw.chroms) == n and bw.chroms[699] == ("ctg0699", 5699)
     assert bw.intervals() == want
+
+
+def test_mkbam_writes_what_the_python_writer_writes(tmp_path):
+    """tbh_tool mkbam (the fast generator of the end-to-end bench leg) == synth.write_bams, record bytes and header"""
+    from tiebrush_amd import bamio, synth
+    tile = synth.make_tile(3, 1500, "c5", n_loci=40)
+    a = synth.write_bams(tile, str(tmp_path / "py"))
+    b = synth.write_bams_fast(tile, str(tmp_path / "cc"), threads=2)
+    for pa, pb in zip(a, b):
+        assert bamio.bgzf_decompress(open(pa, "rb").read()) == bamio.bgzf_decompress(open(pb, "rb").read())

@@ -3,16 +3,44 @@
 //   mergeorder IN1.bam IN2.bam..  print "fidx idx" of every record in TInputFiles::next() order
 //   soa OUTDIR IN1.bam ...        dump the SoA tile arrays (one raw little-endian file per array)
 //   tags IN.bam OUT.bam SPEC...   apply tag edits to every record: YC=f:2.5  YX=i:255  YD=i:0  YD=del
+//   mkbam SOADIR PREFIX [LEVEL [THREADS]]   encode the raw SoA arrays of a synthetic tile (file_off, tid, pos, flag, mapq, strand,
+//                                 nh, cig_off, cig as little-endian files + header.txt) as PREFIX<f>.bam, one per input file: the
+//                                 records tiebrush_amd.synth.write_bams writes (SEQ '*', QNAME r<f>_<i>, NH:C / XS:A), files in parallel
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "GSam.h"
+#include "bgzf.h"
 #include "tmerge.h"
 #include "bigwig.h"
 
+template <class T>
+static bool slurp(const std::string& dir, const char* name, std::vector<T>& v) {
+  FILE* f = fopen((dir + "/" + name).c_str(), "rb");
+  if (!f) return false;
+  fseek(f, 0, SEEK_END);
+  const long sz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  v.resize((size_t)sz / sizeof(T));
+  const bool ok = v.empty() || fread(v.data(), sizeof(T), v.size(), f) == v.size();
+  fclose(f);
+  return ok;
+}
+// UCSC binning scheme (SAM spec 5.3), as htslib's hts_reg2bin(beg, end, 14, 5)
+static uint16_t reg2bin(int64_t beg, int64_t end) {
+  --end;
+  if (beg >> 14 == end >> 14) return (uint16_t)(((1 << 15) - 1) / 7 + (beg >> 14));
+  if (beg >> 17 == end >> 17) return (uint16_t)(((1 << 12) - 1) / 7 + (beg >> 17));
+  if (beg >> 20 == end >> 20) return (uint16_t)(((1 << 9) - 1) / 7 + (beg >> 20));
+  if (beg >> 23 == end >> 23) return (uint16_t)(((1 << 6) - 1) / 7 + (beg >> 23));
+  if (beg >> 26 == end >> 26) return (uint16_t)(((1 << 3) - 1) / 7 + (beg >> 26));
+  return 0;
+}
 template <class T>
 static void dump(const std::string& dir, const char* name, const std::vector<T>& v) {
   FILE* f = fopen((dir + "/" + name).c_str(), "wb");
@@ -71,6 +99,105 @@ int main(int argc, char** argv) {
     fputs(in.header()->text.c_str(), f);
     fclose(f);
     return 0;
+  }
+  if (cmd == "mkbam" && argc >= 4) {
+    const std::string d = argv[2], prefix = argv[3];
+    const int level = argc > 4 ? atoi(argv[4]) : 1;
+    int threads = argc > 5 ? atoi(argv[5]) : tbh::cpu_budget();
+    std::vector<uint32_t> file_off, cig_off, cig;
+    std::vector<int32_t> tid, pos, nh;
+    std::vector<uint16_t> flag;
+    std::vector<uint8_t> mapq, strand;
+    if (!slurp(d, "file_off", file_off) || !slurp(d, "tid", tid) || !slurp(d, "pos", pos) || !slurp(d, "flag", flag) || !slurp(d, "mapq", mapq) ||
+        !slurp(d, "strand", strand) || !slurp(d, "nh", nh) || !slurp(d, "cig_off", cig_off) || !slurp(d, "cig", cig) || file_off.size() < 2)
+      GError("mkbam: cannot read the SoA arrays in %s\n", d.c_str());
+    std::string text;
+    {
+      FILE* f = fopen((d + "/header.txt").c_str(), "r");
+      if (!f) GError("mkbam: no header.txt in %s\n", d.c_str());
+      char buf[4096];
+      size_t r;
+      while ((r = fread(buf, 1, sizeof(buf), f)) > 0) text.append(buf, r);
+      fclose(f);
+    }
+    tbh::BamHeader hdr;
+    hdr.text = text;
+    for (const std::string& l : hdr.lines()) {
+      if (l.compare(0, 3, "@SQ") != 0) continue;
+      const size_t a = l.find("SN:"), b = l.find("LN:");
+      if (a == std::string::npos || b == std::string::npos) continue;
+      hdr.target_name.push_back(l.substr(a + 3, l.find('\t', a) - a - 3));
+      hdr.target_len.push_back((uint32_t)atoll(l.c_str() + b + 3));
+    }
+    hdr.n_targets = (int32_t)hdr.target_name.size();
+    const uint32_t k = (uint32_t)file_off.size() - 1;
+    if (threads < 1) threads = 1;
+    if ((uint32_t)threads > k) threads = (int)k;
+    std::atomic<uint32_t> next{0};
+    std::atomic<int> failed{0};
+    auto work = [&]() {
+      std::vector<uint8_t> buf;
+      for (;;) {
+        const uint32_t f = next.fetch_add(1);
+        if (f >= k) return;
+        tbh::BgzfWriter w;
+        if (!w.open(prefix + std::to_string(f) + ".bam", level, 1)) {
+          failed = 1;
+          return;
+        }
+        buf.clear();
+        hdr.serialize(buf);
+        w.write(buf.data(), buf.size());
+        buf.clear();
+        for (uint32_t i = file_off[f]; i < file_off[f + 1]; ++i) {
+          char nm[40];
+          const int nl = snprintf(nm, sizeof(nm), "r%u_%u", f, i - file_off[f]) + 1;
+          const uint32_t c0 = cig_off[i], nc = cig_off[i + 1] - c0;
+          int64_t rl = 0;
+          for (uint32_t q = 0; q < nc; ++q) {
+            const uint32_t op = cig[c0 + q] & 0xF;
+            if ((0x18Du >> op) & 1u) rl += cig[c0 + q] >> 4;
+          }
+          const bool has_nh = nh[i] != INT32_MIN, has_xs = strand[i] == '+' || strand[i] == '-';
+          const uint32_t body = 32 + (uint32_t)nl + 4 * nc + (has_nh ? 4u : 0u) + (has_xs ? 4u : 0u);
+          const size_t o = buf.size();
+          buf.resize(o + 4 + body);
+          uint8_t* p = buf.data() + o;
+          auto w32 = [&](size_t at, uint32_t v) { memcpy(p + at, &v, 4); };
+          auto w16 = [&](size_t at, uint16_t v) { memcpy(p + at, &v, 2); };
+          w32(0, body);
+          w32(4, (uint32_t)tid[i]);
+          w32(8, (uint32_t)pos[i]);
+          p[12] = (uint8_t)nl;
+          p[13] = mapq[i];
+          w16(14, pos[i] >= 0 ? reg2bin(pos[i], pos[i] + (rl > 1 ? rl : 1)) : (uint16_t)4680);
+          w16(16, (uint16_t)nc);
+          w16(18, flag[i]);
+          w32(20, 0);                   // l_seq
+          w32(24, 0xFFFFFFFFu);         // next refID
+          w32(28, 0xFFFFFFFFu);         // next pos
+          w32(32, 0);                   // tlen
+          memcpy(p + 36, nm, (size_t)nl);
+          memcpy(p + 36 + nl, cig.data() + c0, 4 * (size_t)nc);
+          uint8_t* a = p + 36 + nl + 4 * nc;
+          if (has_nh) {
+            a[0] = 'N', a[1] = 'H', a[2] = 'C', a[3] = (uint8_t)nh[i];
+            a += 4;
+          }
+          if (has_xs) a[0] = 'X', a[1] = 'S', a[2] = 'A', a[3] = strand[i];
+          if (buf.size() >= ((size_t)4 << 20)) {
+            w.write(buf.data(), buf.size());
+            buf.clear();
+          }
+        }
+        if (!buf.empty()) w.write(buf.data(), buf.size());
+        if (!w.close()) failed = 1;
+      }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; ++t) th.emplace_back(work);
+    for (auto& t : th) t.join();
+    return failed ? 1 : 0;
   }
   if (cmd == "tiles" && argc >= 4) {  // tiles <target records> files...: one line per streamed tile = records taken from every input
     TInputFiles in;
@@ -141,6 +268,6 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
-  fprintf(stderr, "usage: tbh_tool cat|mergeorder|soa|tiles|tags|bedgraph2bw ...\n");
+  fprintf(stderr, "usage: tbh_tool cat|mergeorder|soa|mkbam|tiles|tags|bedgraph2bw ...\n");
   return 2;
 }

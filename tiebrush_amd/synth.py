@@ -227,3 +227,24 @@ def write_bams(tile: SoATile, prefix: str, level: int = 1):
         bamio.write_bam(p, header_text(), REF_NAMES, REF_LENS, b"".join(recs), level)
         paths.append(p)
     return paths
+
+
+def write_bams_fast(tile: SoATile, prefix: str, level: int = 1, threads: int = 0):
+    """The same files as write_bams, encoded by the host tool (`tbh_tool mkbam`, C++, one file per worker thread): what the
+    end-to-end leg of bench.py uses to lay down 32 x 1M-read inputs in seconds."""
+    import os
+    import shutil
+    import subprocess
+    import tempfile
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "tbh_tool")
+    d = tempfile.mkdtemp(prefix="tbk_soa_", dir=os.path.dirname(os.path.abspath(prefix)) or None)
+    try:
+        for name, dt in (("file_off", np.uint32), ("tid", np.int32), ("pos", np.int32), ("flag", np.uint16), ("mapq", np.uint8),
+                         ("strand", np.uint8), ("nh", np.int32), ("cig_off", np.uint32), ("cig", np.uint32)):
+            np.ascontiguousarray(getattr(tile, name), dtype=dt).tofile(os.path.join(d, name))
+        with open(os.path.join(d, "header.txt"), "w") as fh:
+            fh.write(header_text())
+        subprocess.run([tool, "mkbam", d, prefix, str(level)] + ([str(threads)] if threads else []), check=True)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return ["%s%d.bam" % (prefix, f) for f in range(tile.n_files)]
