@@ -31,8 +31,8 @@ def test_bench_two_ranks_contract():
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "frac_traffic"} <= set(d["roofline"])
     # the same per-rank workload through the plain path, the exchange's cost and its volume ride in the line
     assert d["plain_ms_per_step"] > 0 and d["shuffle_ms_per_step"] >= 0 and d["dist_mode"] == "partials"
-    assert 0 < d["wire_bytes_per_step"] < 60000 * 24              # group partials, not records, crossed the wire
-    assert 0 < d["partials_per_step"] <= 60000
+    assert 0 < d["partials_per_step"] <= 60000                    # one row per local group (this shallow shape has few duplicates)
+    assert d["partials_per_step"] * 44 <= d["wire_bytes_per_step"] <= d["partials_per_step"] * (40 + 4 * 8)
 
 
 def test_bench_default_line_contract_small():

@@ -159,7 +159,7 @@ def test_part_form_refuses_what_it_cannot_hold():
     tile.yx_in = rng.integers(1, 4, n).astype(np.int64)
     tile.yd_in = rng.integers(0, 50, n).astype(np.int64)
     tile.prio_hi = rng.integers(0, 1000, n).astype(np.uint64)
-    tile.prio_lo = rng.permutation(n).astype(np.uint64)
+    tile.prio_lo = np.arange(n).astype(np.uint64)       # (as in a real partial tile: the low word grows with the tile index)
     from dist_helpers import OracleCompute
     want = OracleCompute().collapse(tile, strategy="clip")
     ctx = api.Context(0)

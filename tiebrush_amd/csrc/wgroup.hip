@@ -1112,12 +1112,11 @@ __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgRaw R, WgTemp T
     uint32_t* gcnt = reinterpret_cast<uint32_t*>(lds);
     uint32_t* gns = gcnt + WG_CAP;
     unsigned long long* grep = reinterpret_cast<unsigned long long*>(gns + WG_CAP);
-    uint32_t* gyd = reinterpret_cast<uint32_t*>(grep + WG_CAP);  // (PART; 60 of the 72 KiB)
+    uint32_t* gyd = reinterpret_cast<uint32_t*>(grep + WG_CAP);  // (PART; the space of `val`: dead once the gathers below are done)
     for (uint32_t g = t; g < ng_w; g += WG_NT) {
       gcnt[g] = 0;
       gns[g] = 0;
       grep[g] = ~0ull;
-      if (PART) gyd[g] = 0;
     }
     unsigned long long rr[WG_E];
     uint32_t ycv[WG_E], yxv[WG_E], ydv[WG_E];  // PART: the carried YC / YX / YD of the partial
@@ -1140,6 +1139,10 @@ __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgRaw R, WgTemp T
       }
     }
     __syncthreads();
+    if constexpr (PART) {  // (every read of `val` is behind the barrier above)
+      for (uint32_t g = t; g < ng_w; g += WG_NT) gyd[g] = 0;
+      __syncthreads();
+    }
     {  // runs of one group inside the thread's positions are folded in registers; one set of LDS atomics per run
       uint32_t cg = 0xFFFFFFFFu, c = 0, nsv = 0, ydm = 0;
       unsigned long long r = ~0ull;
