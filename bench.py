@@ -270,9 +270,12 @@ def main():
         def shard_probe_next(self, *a):
             return self.cl.shard_probe_next(*a)
 
-        def partial_pack(self, *a):
-            r = self.cl.partial_pack(*a, out=self.bufs.setdefault("pp", {}))
-            return r
+        def partial_pack(self, *a, **kw):
+            return self.cl.partial_pack(*a, out=self.bufs.setdefault("pp", {}), **kw)
+
+        def partial_reduce(self, rows, run_off, cig, **kw):
+            self.done()                                   # the rows have left the local buffers: the worker may reuse the slot
+            return self.co.partial_reduce(rows, run_off, cig, out=self.bufs.setdefault("pr", {}), **kw)
 
         def partial_unpack(self, rows):
             self.done()                                   # the rows have left the local buffers: the worker may reuse the slot

@@ -292,13 +292,16 @@ int tbk_shard_unpack(tbk_ctx* ctx, const int32_t* rows, uint32_t n2, const uint3
  * n_groups entries.  *not_packable (host) = 1 when some YC is not an integer in [1, 2^31) or some YX does not fit 31 bits: the
  * caller must then take the record shuffle. */
 int tbk_partial_keys(tbk_ctx* ctx, const tbk_soa_in* in, const tbk_groups_out* g, int64_t* key, int64_t* emax, uint32_t* not_packable);
-/* rows[n_groups][TBK_PARTIAL_ROW] (int32) = {tid, pos, strand | n_cigar << 8, effective end of the representative, its global
- * file index (first_fidx + local file), its index inside that file, YC, YX, YD, 0} and the representatives' CIGAR words, both
- * in group order: the groups of destination d (cuts[d - 1] <= key < cuts[d]) are contiguous.  tab[world][3] (int64, device) =
- * {first group, rows, words} per destination.  g must carry rep_effend and a final yd (tbk_collapse_finish_yd). */
-#define TBK_PARTIAL_ROW 10
-int tbk_partial_pack(tbk_ctx* ctx, const tbk_soa_in* in, const tbk_groups_out* g, const int64_t* key, const int64_t* cuts, uint32_t world,
-                     uint32_t first_fidx, int32_t* rows, uint32_t* cig_out, int64_t* tab);
+/* rows[n_groups][TBK_PARTIAL_ROW] (int32, 48 bytes) = {tid, pos, strand | n_cigar << 8, effective end of the representative, its
+ * global file index (first_fidx + local file), its index inside that file, YC, YX, YD, reference span, key word, 0} and the
+ * representatives' CIGAR words, both in group order: the groups of destination d (cuts[d - 1] <= key < cuts[d]) are contiguous.
+ * Key word: what identifies the alignment among reads with equal (tid, start, strand, span) under opts->strategy — an exact code
+ * or a 31-bit hash with a fixed seed, equal on every rank (the owner verifies hashed words against the CIGARs).
+ * tab[world][3] (int64, device) = {first group, rows, words} per destination.  g must carry rep_effend and a final yd
+ * (tbk_collapse_finish_yd); opts = the options the groups were collapsed with. */
+#define TBK_PARTIAL_ROW 12
+int tbk_partial_pack(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa_in* in, const tbk_groups_out* g, const int64_t* key,
+                     const int64_t* cuts, uint32_t world, uint32_t first_fidx, int32_t* rows, uint32_t* cig_out, int64_t* tab);
 /* Received rows (one run per source rank, each in that rank's output order) -> the SoA arrays of a tile whose "files" are the
  * source ranks, all flagged tbmerged: flag 0, mapq 255, NH absent, cig_off (n2 + 1 entries), yc_in / yx_in / yd_in = the
  * partial's YC / YX / YD, prio_hi = effective end, prio_lo = global file << 32 | index in file.  tbk_collapse_tile on that
@@ -306,6 +309,16 @@ int tbk_partial_pack(tbk_ctx* ctx, const tbk_soa_in* in, const tbk_groups_out* g
 int tbk_partial_unpack(tbk_ctx* ctx, const int32_t* rows, uint32_t n2, int32_t* tid, int32_t* pos, uint16_t* flag, uint8_t* mapq,
                        uint8_t* strand, int32_t* nh, uint32_t* cig_off, double* yc_in, int64_t* yx_in, int64_t* yd_in, int64_t* prio_hi,
                        int64_t* prio_lo);
+/* The owner's step in one call, on the rows as received: rows[n2][TBK_PARTIAL_ROW] of n_runs source ranks (run_off[n_runs + 1],
+ * host; every run in its rank's output order), cig = their CIGAR words in row order.  The runs are merged in the reference's
+ * output order — (tid, start), strand, end, then the strategy compare of tiebrush.cpp:285-345 inside a tie — and partials with
+ * equal keys are reduced: out->yc = sum YC, yx = sum YX, yd = max YD, rep = ROW index of the partial with the smallest
+ * (effective end, run, row) = the flat run's representative (tmerge.h:28-50); g_start / g_end optional; n_passed = n2.  `view`
+ * (optional) receives tiecov's input of the reduced groups as tbk_groups_to_cov_in builds it (context-owned, valid until the
+ * next call).  TBK_ECOLLISION: two alignments share a hashed key word; TBK_E2BIG: more partials start on one base than a
+ * workgroup merges — in both cases tbk_partial_unpack + tbk_collapse_tile take the tile. */
+int tbk_partial_reduce(tbk_ctx* ctx, const tbk_collapse_opts* opts, const int32_t* rows, uint32_t n2, const uint32_t* run_off,
+                       uint32_t n_runs, const uint32_t* cig, tbk_groups_out* out, tbk_cov_in* view);
 
 #ifdef __cplusplus
 }

@@ -78,7 +78,7 @@ class DeviceCompute:
         return api.to_numpy(self.ctx.coverage(view))
 
 
-@pytest.mark.parametrize("mode,path", [("partials", None), ("partials", "window"), ("shuffle", None)])
+@pytest.mark.parametrize("mode,path", [("partials", None), ("partials", "general"), ("partials", "general-window"), ("shuffle", None)])
 @pytest.mark.parametrize("world,nfiles,profile,strategy,kw", [
     (4, 8, "c2", "cigar", {}),
     (3, 7, "c3", "clip", {}),
@@ -89,10 +89,13 @@ class DeviceCompute:
     (8, 1024, "c5", "exon", dict(max_nh=5, min_qual=1)),   # configs[4]'s shape: 1024 files over 8 ranks
 ])
 def test_loopback_device_resident_equals_flat_oracle(world, nfiles, profile, strategy, kw, mode, path, monkeypatch):
-    """path = "window": TBK_PATH forces the window path wherever it applies — the owner's reduce of the partials then runs in the
-    PART form of wg_hash_k / wg_hash2_k / wg_sort_k (wgroup.hip) also on these small tiles"""
+    """path None: the owner reduces with tbk_partial_reduce (merge of the runs); "general": with tbk_partial_unpack +
+    tbk_collapse_tile (TBK_PARTIAL_REDUCE=0; what a hashed-key collision or a pile-up of partials falls back to), sort path;
+    "general-window": the same under TBK_PATH=window — the PART form of wg_hash_k / wg_hash2_k / wg_sort_k (wgroup.hip)"""
     if path:
-        monkeypatch.setenv("TBK_PATH", path)
+        monkeypatch.setenv("TBK_PARTIAL_REDUCE", "0")
+        if path.endswith("window"):
+            monkeypatch.setenv("TBK_PATH", "window")
     import torch
     from oracle import oracle_ffi as orc
     from tiebrush_amd import api, dist, synth
@@ -112,9 +115,13 @@ def test_loopback_device_resident_equals_flat_oracle(world, nfiles, profile, str
 
 
 @pytest.mark.parametrize("strategy,kw", [("cigar", {}), ("exon", dict(max_nh=5, min_qual=1))])
-def test_loopback_8_ranks_32x200k_per_rank(strategy, kw):
+@pytest.mark.parametrize("general", [False, True])
+def test_loopback_8_ranks_32x200k_per_rank(strategy, kw, general, monkeypatch):
     """8 virtual ranks x 32 files x 200 k reads (51 M records, generated on the GPU): every local collapse takes the raw window
-    path, every owner's reduce the PART window path at ~ 0.5-1 M partials, exact against the flat oracle run"""
+    path, every owner reduces ~ 0.5-1 M partials — by tbk_partial_reduce, or (general) by the PART window form of
+    tbk_collapse_tile — exact against the flat oracle run"""
+    if general:
+        monkeypatch.setenv("TBK_PARTIAL_REDUCE", "0")
     import torch
     from oracle import oracle_ffi as orc
     from tiebrush_amd import dist, synth, synth_dev
@@ -125,7 +132,7 @@ def test_loopback_8_ranks_32x200k_per_rank(strategy, kw):
     first = [r * fpr for r in range(world)]
     comp = DeviceCompute()
     res = dist.run_loopback(comp, dtiles, first, strategy=strategy, want_coverage=True, device_chain=True, **kw)
-    assert max(r.n_partials_received for r in res) >= 65536          # the PART window form ran
+    assert max(r.n_partials_received for r in res) >= 65536
     for r in res:
         for f in ("tid", "start", "end", "rep_fidx", "rep_idx", "yc", "yx", "yd"):
             v = getattr(r, f)
@@ -218,14 +225,123 @@ def test_partial_kernels_match_host_restatement():
     ng = fin["n_groups"]
     cuts_h = np.array([hk[ng // 3], hk[(2 * ng) // 3] + 1, dist.KEY_INF], np.int64)
     cuts = torch.from_numpy(cuts_h).cuda()
-    rows, cigw, tab = ctx.partial_pack(dt, fin, key, cuts, 4, 100)
+    rows, cigw, tab = ctx.partial_pack(dt, fin, key, cuts, 4, 100, **kw)
     hr, hc, ht = dist._partial_pack_np(tile, hfin, hk, cuts_h, 4, 100)
-    assert np.array_equal(tab.cpu().numpy(), ht) and np.array_equal(rows.cpu().numpy(), hr)
+    gr = rows.cpu().numpy()
+    assert np.array_equal(tab.cpu().numpy(), ht) and np.array_equal(gr[:, :10], hr[:, :10]) and not gr[:, 11].any()
+    assert (gr[:, 10] != 0).all()                      # the key word: an exact code (bit 31) or a 31-bit hash, never absent
     assert np.array_equal(cigw.cpu().numpy()[:len(hc)].view(np.uint32), hc)
     A = ctx.partial_unpack(rows)
     hA = dist._partial_unpack_np(hr)
     for k, v in hA.items():
         assert np.array_equal(A[k].cpu().numpy().view(v.dtype), v), k
+    ctx.close()
+
+
+@pytest.mark.parametrize("profile,strategy,kw", [("c2", "cigar", {}), ("c3", "clip", {}), ("c5", "exon", dict(max_nh=5, min_qual=1)),
+                                                 ("c5", "cigar", dict(keep_secondary=True, keep_supplementary=True))])
+@pytest.mark.parametrize("runs", [1, 2, 5])
+def test_partial_reduce_equals_general_path(profile, strategy, kw, runs):
+    """tbk_partial_reduce against tbk_partial_unpack + tbk_collapse_tile on the same received rows: every output array, the
+    representative included"""
+    import torch
+    from tiebrush_amd import api, synth
+    from tiebrush_amd._lib import TbkError
+    from tiebrush_amd.soa import SoATile
+    tile = synth.make_tile(runs * 2, 20000, profile, n_loci=150)      # deep: many groups per position, ties on (strand, end)
+    tiles, first = split_tile(tile, runs)
+    ctx = api.Context(0)
+
+    local = []
+    for r in range(runs):
+        dt = api.to_device(tiles[r], "cuda:0")
+        fin = ctx.collapse(dt, strategy=strategy, want_coords=True, want_effend=True, **kw)
+        local.append((dt, fin, ctx.partial_keys(dt, fin)[0]))
+
+    def received():
+        rows_all, cig_all, cnt = [], [], []
+        for r, (dt, fin, key) in enumerate(local):
+            rows, cigw, tab = ctx.partial_pack(dt, fin, key, None, 1, first[r], strategy=strategy, **kw)
+            th = tab.cpu().numpy()
+            rows_all.append(rows.clone())
+            cig_all.append(cigw[:int(th[0, 2])].clone())
+            cnt.append(int(th[0, 1]))
+        return torch.cat(rows_all), torch.cat(cig_all), np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint32)
+
+    rows, cig, ro = received()
+    A = {k: v.clone() for k, v in ctx.partial_unpack(rows).items()}
+    t2 = SoATile(n_files=runs, file_off=ro, tbmerged=np.ones(runs, np.uint8), tid=A["tid"], pos=A["pos"], flag=A["flag"], mapq=A["mapq"],
+                 strand=A["strand"], nh=A["nh"], cig_off=A["cig_off"], cig=cig, yc_in=A["yc_in"], yx_in=A["yx_in"], yd_in=A["yd_in"],
+                 prio_hi=A["prio_hi"], prio_lo=A["prio_lo"])
+    want = api.to_numpy(ctx.collapse(t2, strategy=strategy, want_coords=True, keep_supplementary=True, keep_secondary=True))
+    got = ctx.partial_reduce(rows, ro, cig, strategy=strategy)
+    view = got.pop("view")
+    got = api.to_numpy(got)
+    assert got["n_groups"] == want["n_groups"] > 0
+    for k in ("rep", "yc", "yx", "yd", "g_start", "g_end"):
+        assert np.array_equal(np.asarray(got[k]).astype(np.int64), np.asarray(want[k]).astype(np.int64)), k
+    # the view is what tbk_groups_to_cov_in builds from the general path's result: same coverage
+    cov_a = api.to_numpy(ctx.coverage(view))
+    fin2 = ctx.collapse(t2, strategy=strategy, want_coords=True, keep_supplementary=True, keep_secondary=True)
+    cov_b = api.to_numpy(ctx.coverage(ctx.groups_to_cov_in(fin2)))
+    for k in ("iv_tid", "iv_start", "iv_end", "iv_val", "j_tid", "j_start", "j_end", "j_strand", "j_val"):
+        assert np.array_equal(cov_a[k], cov_b[k]), k
+    ctx.close()
+
+
+def test_partial_reduce_refuses_a_shared_hashed_key_word(monkeypatch):
+    """two different three-exon alignments with equal (tid, start, strand, span) on two ranks: distinct groups; with the hash
+    word masked away (TBK_DEBUG_HASH_MASK=0) they share a key word and tbk_partial_reduce must refuse (TBK_ECOLLISION) — never
+    merge them — and the multi-rank driver then takes the general path, which reseeds"""
+    import torch
+    from helpers import tile_from_records
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import api, dist
+    from tiebrush_amd._lib import TbkError
+    M, N = 0, 3
+    a = [(10, M), (20, N), (10, M), (30, N), (10, M)]
+    b = [(10, M), (30, N), (10, M), (20, N), (10, M)]
+    f0 = [(0, 100, 0, 60, "+", 1, a), (0, 100, 0, 60, "+", 1, a), (0, 300, 0, 60, "+", 1, [(50, M)])]
+    f1 = [(0, 100, 0, 60, "+", 1, b), (0, 300, 0, 60, "+", 1, [(50, M)])]
+    tile = tile_from_records([f0, f1])
+    flat = orc.collapse(tile)
+    assert flat["n_groups"] == 3
+    tiles, first = split_tile(tile, 2)
+    ctx = api.Context(0)
+    for mask, refuse in ((None, False), ("0", True)):
+        if mask is not None:
+            monkeypatch.setenv("TBK_DEBUG_HASH_MASK", mask)
+        rows_all, cig_all, cnt = [], [], []
+        for r in range(2):
+            dt = api.to_device(tiles[r], "cuda:0")
+            monkeypatch.delenv("TBK_DEBUG_HASH_MASK", raising=False)
+            fin = ctx.collapse(dt, want_coords=True, want_effend=True)
+            key = ctx.partial_keys(dt, fin)[0]
+            if mask is not None:
+                monkeypatch.setenv("TBK_DEBUG_HASH_MASK", mask)
+            rows, cigw, tab = ctx.partial_pack(dt, fin, key, None, 1, first[r])
+            th = tab.cpu().numpy()
+            rows_all.append(rows.clone())
+            cig_all.append(cigw[:int(th[0, 2])].clone())
+            cnt.append(int(th[0, 1]))
+        rows, cig, ro = torch.cat(rows_all), torch.cat(cig_all), np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint32)
+        if refuse:
+            with pytest.raises(TbkError) as e:
+                ctx.partial_reduce(rows, ro, cig)
+            assert e.value.status == -8                  # TBK_ECOLLISION
+        else:
+            got = ctx.partial_reduce(rows, ro, cig)
+            assert got["n_groups"] == 3 and got["yc"].cpu().numpy().tolist() == [2.0, 1.0, 2.0]
+    # the driver: packed with the masked word, refused by the merge-reduce, reduced by the general path (whose own keys the mask
+    # does not make exact either: it reseeds until the two alignments part, or gives up loudly) — here the mask is lifted for it
+    monkeypatch.delenv("TBK_DEBUG_HASH_MASK")
+    dtiles = [api.to_device(t, "cuda:0") for t in tiles]
+    res = dist.run_loopback(DeviceCompute(), dtiles, first, want_coverage=False, device_chain=True)
+    for r in res:
+        for f in ("tid", "start", "end", "rep_fidx", "rep_idx", "yc", "yx", "yd"):
+            v = getattr(r, f)
+            setattr(r, f, v.cpu().numpy() if isinstance(v, torch.Tensor) else v)
+    check_against_flat(res, tile, flat)
     ctx.close()
 
 

@@ -431,20 +431,21 @@ class Context:
                                             C.c_void_p(bufs["pemax"].data_ptr()), C.byref(bad)), "tbk_partial_keys")
         return bufs["pkey"][:ng], bufs["pemax"][:ng], int(bad.value)
 
-    def partial_pack(self, tile: SoATile, fin, key, cuts, world, first_fidx, out=None):
-        """tbk_partial_pack: (rows [ng, 10] int32, cig words, tab [world, 3] int64) of the local groups (fin needs want_effend=True
-        and a final yd)."""
+    def partial_pack(self, tile: SoATile, fin, key, cuts, world, first_fidx, out=None, opts=None, **kw):
+        """tbk_partial_pack: (rows [ng, 12] int32, cig words, tab [world, 3] int64) of the local groups (fin needs want_effend=True
+        and a final yd; opts / kw = the options the groups were collapsed with)."""
         torch = _torch()
+        o = opts if opts is not None else self.make_opts(**kw)
         ng = int(fin["n_groups"])
         nc = _numel(tile.cig)
         bufs = out if out is not None else {}
         if "prows" not in bufs or bufs["prows"].shape[0] < max(ng, 1):
-            bufs["prows"] = torch.empty((max(ng, 1), 10), dtype=torch.int32, device=self._dev())
+            bufs["prows"] = torch.empty((max(ng, 1), 12), dtype=torch.int32, device=self._dev())
         if "pcig" not in bufs or bufs["pcig"].numel() < max(nc, 1):
             bufs["pcig"] = torch.empty(max(nc, 1), dtype=torch.int32, device=self._dev())
         tab = torch.empty((world, 3), dtype=torch.int64, device=self._dev())
         self._order_after_torch(True)
-        self._check(self.L.tbk_partial_pack(self.h, C.byref(fin["_soa"]), C.byref(fin["_struct"]), C.c_void_p(key.data_ptr()) if ng else None,
+        self._check(self.L.tbk_partial_pack(self.h, C.byref(o), C.byref(fin["_soa"]), C.byref(fin["_struct"]), C.c_void_p(key.data_ptr()) if ng else None,
                                             C.c_void_p(cuts.data_ptr()) if world > 1 else None, int(world), int(first_fidx),
                                             C.c_void_p(bufs["prows"].data_ptr()), C.c_void_p(bufs["pcig"].data_ptr()),
                                             C.c_void_p(tab.data_ptr())), "tbk_partial_pack")
@@ -466,6 +467,35 @@ class Context:
         self._check(self.L.tbk_partial_unpack(self.h, C.c_void_p(rows.data_ptr()) if n2 else None, n2,
                                               *[C.c_void_p(bufs[name].data_ptr()) for name, _, _ in spec]), "tbk_partial_unpack")
         return {name: bufs[name][:cnt] for name, _, cnt in spec}
+
+    def partial_reduce(self, rows, run_off, cig, out=None, want_view=True, opts=None, **kw):
+        """tbk_partial_reduce: the owner's merge-reduce of the received partial rows (torch int32 [n2, 12]; run_off = host run
+        boundaries [R + 1]; cig = the CIGAR words as received).  Returns the usual collapse dict (rep = ROW index of the
+        representative) plus "view" (DeviceCovView of the reduced groups, valid until the next call)."""
+        torch = _torch()
+        o = opts if opts is not None else self.make_opts(**kw)
+        n2 = int(rows.shape[0])
+        ro = np.ascontiguousarray(run_off, dtype=np.uint32)
+        bufs = out if out is not None else {}
+        cap = max(n2, 1)
+        spec = (("rep", torch.int32), ("yc", torch.float64), ("yx", torch.int64), ("yd", torch.int32), ("g_start", torch.int32),
+                ("g_end", torch.int32))
+        for name, dt in spec:
+            if name not in bufs or bufs[name].numel() < cap:
+                bufs[name] = torch.empty(cap, dtype=dt, device=self._dev())
+        rows = rows.contiguous()
+        g = _lib.GroupsOut(_lib.TBK_MEM_DEVICE, cap, *[bufs[name].data_ptr() for name, _ in spec], None, None, 0, 0)
+        v = _lib.CovIn()
+        self._order_after_torch(True)
+        self._check(self.L.tbk_partial_reduce(self.h, C.byref(o), C.c_void_p(rows.data_ptr()) if n2 else None, n2, ro.ctypes.data, len(ro) - 1,
+                                              C.c_void_p(cig.data_ptr()) if cig is not None and cig.numel() else None, C.byref(g),
+                                              C.byref(v) if want_view else None), "tbk_partial_reduce")
+        m = int(g.n_groups)
+        res = dict(n_groups=m, n_passed=n2, _bufs=bufs, _struct=g, _keep=[rows, cig, ro])
+        res.update({name: bufs[name][:m] for name, _ in spec})
+        if want_view:
+            res["view"] = DeviceCovView(v, int(v.n_records), int(v.n_cigar_ops))
+        return res
 
     # ---- coverage -----------------------------------------------------------------------------
     def coverage(self, cin, want_cov=True, want_junc=True, cap_intervals=None, cap_junctions=None, out=None, raw=False):

@@ -1366,7 +1366,7 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
   // single synchronisation at the end, and the rare events that want a different path (a bucket too long for the
   // local sort, a key-hash collision) simply restart the tile.
   bool lean = use_runs && !O.store_frac && !any_tbm && n >= runs_min;
-  const uint64_t seeds[4] = {0x71EB5EEDull, 0xA5A5F00DCAFE1234ull, 0x0123456789ABCDEFull, 0xDEADBEEF0BADF00Dull};
+  const uint64_t seeds[4] = {TBK_KEY_SEED0, 0xA5A5F00DCAFE1234ull, 0x0123456789ABCDEFull, 0xDEADBEEF0BADF00Dull};
   int attempt = 0;
   for (;;) {
     if (attempt == 4) return TBK_ECOLLISION;
@@ -1695,12 +1695,22 @@ extern "C" int tbk_groups_to_cov_in(tbk_ctx* ctx, const tbk_soa_in* in, const tb
   } prof_end{ctx};
   if (ng == 0) return 0;
   TBK_TRY(tbk_ws_reserve(ctx, (size_t)ng * 24 + ((size_t)1 << 20)));
+  return tbk_cov_view_build(ctx, in->tid, in->pos, in->strand, in->cig_off, in->cig, g->rep, g->yc, g->yx, ng, view);
+}
+
+// the view of ng representatives (rep[o] indexes the given record arrays) in context-owned memory; allocates from the arena as it
+// stands (the caller has reserved it) and synchronises the stream
+int tbk_cov_view_build(tbk_ctx* ctx, const int32_t* r_tid, const int32_t* r_pos, const uint8_t* r_strand, const uint32_t* r_cig_off,
+                       const uint32_t* r_cig, const uint32_t* g_rep, const double* g_yc, const int64_t* g_yx, uint32_t ng, tbk_cov_in* view) {
+  memset(view, 0, sizeof(*view));
+  view->mem = TBK_MEM_DEVICE;
+  if (ng == 0) return 0;
   uint32_t* cnt = ws_alloc<uint32_t>(ctx, ng);
   uint32_t* ooff = ws_alloc<uint32_t>(ctx, ng);
   uint32_t* cfirst = ws_alloc<uint32_t>(ctx, ng);
   if (!cfirst) return TBK_ENOMEM;
   const uint32_t B = 256;
-  TBK_LAUNCH(ctx, "g2c_count", g2c_count_k, cdiv(ng, B), B, 0, ng, g->rep, in->cig_off, cnt, cfirst);
+  TBK_LAUNCH(ctx, "g2c_count", g2c_count_k, cdiv(ng, B), B, 0, ng, g_rep, r_cig_off, cnt, cfirst);
   TBK_TRY(tbk_exscan_u32(ctx, cnt, ooff, ng, ctx->d_scalars + 20));
   TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 20, ctx->d_scalars + 20, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   TBK_HIP(hipStreamSynchronize(ctx->stream));
@@ -1729,8 +1739,8 @@ extern "C" int tbk_groups_to_cov_in(tbk_ctx* ctx, const tbk_soa_in* in, const tb
   int64_t* o_yx = (int64_t*)take((size_t)ng * 8);
   uint32_t* o_cig_off = (uint32_t*)take((size_t)(ng + 1) * 4);
   uint32_t* o_cig = (uint32_t*)take((size_t)total * 4 + 4);
-  TBK_LAUNCH(ctx, "g2c_gather", g2c_gather_k, cdiv(ng, B), B, 0, ng, g->rep, g->yc, g->yx, in->tid, in->pos, in->strand, cfirst, cnt,
-             in->cig, ooff, (uint32_t)total, o_tid, o_pos, o_strand, o_yc, o_yx, o_cig_off, o_cig);
+  TBK_LAUNCH(ctx, "g2c_gather", g2c_gather_k, cdiv(ng, B), B, 0, ng, g_rep, g_yc, g_yx, r_tid, r_pos, r_strand, cfirst, cnt, r_cig, ooff,
+             (uint32_t)total, o_tid, o_pos, o_strand, o_yc, o_yx, o_cig_off, o_cig);
   TBK_HIP(hipStreamSynchronize(ctx->stream));
   TBK_TRY(tbk_check_launch(ctx, "groups_to_cov_in"));
   view->n_records = ng;

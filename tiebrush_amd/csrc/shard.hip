@@ -29,7 +29,9 @@
 // torch.distributed (RCCL over xGMI) in dist.py.
 #include "dev_common.cuh"
 #include "scan_op.cuh"
+#include "strategy.cuh"
 #include "tbk_internal.h"
+#include "wgroup.h"
 
 namespace {
 constexpr int SH_B = 256;
@@ -518,16 +520,22 @@ __global__ void partial_table_k(uint32_t ng, uint32_t world, const int64_t* __re
   tab[d * 3 + 1] = (long long)(b - a);
   tab[d * 3 + 2] = (long long)(wb - wa);
 }
-// rows: TBK_PARTIAL_ROW x int32 per local group, in group (= output) order
-__global__ void partial_rows_k(uint32_t ng, uint32_t k, uint32_t first_fidx, const uint32_t* __restrict__ file_off, const uint32_t* __restrict__ rep,
+// rows: TBK_PARTIAL_ROW x int32 per local group, in group (= output) order.  Words 9 / 10 are the low half of the group key
+// (strategy.cuh, record_key: reference span and the 32-bit key word — an exact code or the strategy hash under TBK_KEY_SEED0) of
+// the representative, which every member of the group shares: the owner groups partials by (tid, pos, strand, span, word)
+// without walking a CIGAR, and verifies the hashed ones.
+__global__ void partial_rows_k(uint32_t ng, uint32_t k, uint32_t first_fidx, ColIn I, ColOpt O, const uint32_t* __restrict__ rep,
                                const double* __restrict__ yc, const int64_t* __restrict__ yx, const int32_t* __restrict__ yd,
-                               const int32_t* __restrict__ effend, const int32_t* __restrict__ tid, const int32_t* __restrict__ pos,
-                               const uint8_t* __restrict__ strand, const uint32_t* __restrict__ cfirst, const uint32_t* __restrict__ cnt,
-                               const uint32_t* __restrict__ woff, const uint32_t* __restrict__ cig, int32_t* __restrict__ rows,
-                               uint32_t* __restrict__ cig_out) {
+                               const int32_t* __restrict__ effend, const uint32_t* __restrict__ cfirst, const uint32_t* __restrict__ cnt,
+                               const uint32_t* __restrict__ woff, int32_t* __restrict__ rows, uint32_t* __restrict__ cig_out,
+                               uint32_t* __restrict__ err) {
   const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= ng) return;
   const uint32_t r = rep[o];
+  const uint32_t* file_off = I.file_off;
+  const int32_t *tid = I.tid, *pos = I.pos;
+  const uint8_t* strand = I.strand;
+  const uint32_t* cig = I.cig;
   uint32_t lo = 0, hi = k;  // last f with file_off[f] <= r
   while (hi - lo > 1) {
     const uint32_t mid = (lo + hi) >> 1;
@@ -537,6 +545,8 @@ __global__ void partial_rows_k(uint32_t ng, uint32_t k, uint32_t first_fidx, con
       hi = mid;
   }
   const uint32_t nc = cnt[o], c0 = cfirst[o], w = woff[o];
+  const RecKey K = record_key(I, O, r, I.flag[r], pos[r], tid[r], (int)I.mapq[r], I.nh[r], strand_code(strand[r]), cig + c0, nc);
+  if (K.err || !K.pass) atomicOr(err, K.err | TBK_DERR_INTERNAL);  // (a representative passes the filters by construction)
   int32_t R[TBK_PARTIAL_ROW];
   R[0] = tid[r];
   R[1] = pos[r];
@@ -547,11 +557,13 @@ __global__ void partial_rows_k(uint32_t ng, uint32_t k, uint32_t first_fidx, con
   R[6] = (int32_t)(uint32_t)yc[o];
   R[7] = (int32_t)yx[o];
   R[8] = yd[o];
-  R[9] = 0;
-  static_assert(TBK_PARTIAL_ROW == 10, "row layout");
-  int2* dst = reinterpret_cast<int2*>(rows + (size_t)o * TBK_PARTIAL_ROW);  // (40-byte rows: 8-byte aligned)
+  R[9] = (int32_t)(uint32_t)(K.lo >> 32);
+  R[10] = (int32_t)(uint32_t)K.lo;
+  R[11] = 0;
+  static_assert(TBK_PARTIAL_ROW == 12, "row layout");
+  int4* dst = reinterpret_cast<int4*>(rows + (size_t)o * TBK_PARTIAL_ROW);  // (48-byte rows: 16-byte aligned)
 #pragma unroll
-  for (int q = 0; q < TBK_PARTIAL_ROW / 2; ++q) dst[q] = make_int2(R[2 * q], R[2 * q + 1]);
+  for (int q = 0; q < TBK_PARTIAL_ROW / 4; ++q) dst[q] = make_int4(R[4 * q], R[4 * q + 1], R[4 * q + 2], R[4 * q + 3]);
   for (uint32_t q = 0; q < nc; ++q) cig_out[w + q] = cig[c0 + q];
 }
 __global__ void partial_ncig2_k(uint32_t n2, const int32_t* __restrict__ rows, uint32_t* __restrict__ nc) {
@@ -564,8 +576,9 @@ __global__ void partial_unpack_k(uint32_t n2, const int32_t* __restrict__ rows, 
                                  int64_t* __restrict__ yd_in, int64_t* __restrict__ prio_hi, int64_t* __restrict__ prio_lo) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n2) return;
-  const int2* src = reinterpret_cast<const int2*>(rows + (size_t)j * TBK_PARTIAL_ROW);
-  const int2 a = src[0], b = src[1], c = src[2], d = src[3], e = src[4];
+  const int4* src = reinterpret_cast<const int4*>(rows + (size_t)j * TBK_PARTIAL_ROW);  // (48-byte rows: 16-byte aligned)
+  const int4 q0 = src[0], q1 = src[1], q2 = src[2];
+  const int2 a = make_int2(q0.x, q0.y), b = make_int2(q0.z, q0.w), c = make_int2(q1.x, q1.y), d = make_int2(q1.z, q1.w), e = make_int2(q2.x, q2.y);
   tid[j] = a.x;
   pos[j] = a.y;
   flag[j] = 0;
@@ -611,9 +624,10 @@ extern "C" int tbk_partial_keys(tbk_ctx* ctx, const tbk_soa_in* in, const tbk_gr
   return tbk_check_launch(ctx, "partial_keys");
 }
 
-extern "C" int tbk_partial_pack(tbk_ctx* ctx, const tbk_soa_in* in, const tbk_groups_out* g, const int64_t* key, const int64_t* cuts,
-                                uint32_t world, uint32_t first_fidx, int32_t* rows, uint32_t* cig_out, int64_t* tab) {
-  if (!ctx || !in || !g || !tab || world == 0) return TBK_EINVAL;
+extern "C" int tbk_partial_pack(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_in* in, const tbk_groups_out* g, const int64_t* key,
+                                const int64_t* cuts, uint32_t world, uint32_t first_fidx, int32_t* rows, uint32_t* cig_out, int64_t* tab) {
+  if (!ctx || !o || !in || !g || !tab || world == 0) return TBK_EINVAL;
+  if (o->strategy < 0 || o->strategy > 3 || o->strategy == TBK_STRAT_FULL) return TBK_EUNSUPPORTED;  // (no MD tags in a partial)
   if (in->mem != TBK_MEM_DEVICE || g->mem != TBK_MEM_DEVICE || in->n_files == 0 || in->n_files > 65535 || !in->file_off) return TBK_EINVAL;
   const uint32_t ng = g->n_groups;
   if (ng && (!key || !rows || !cig_out || !g->rep || !g->yc || !g->yx || !g->yd || !g->rep_effend)) return TBK_EINVAL;
@@ -635,9 +649,35 @@ extern "C" int tbk_partial_pack(tbk_ctx* ctx, const tbk_soa_in* in, const tbk_gr
   if (ng) TBK_LAUNCH(ctx, "partial_ncig", partial_ncig_k, cdiv(ng, SH_B), SH_B, 0, ng, g->rep, in->cig_off, cnt, cfirst);
   TBK_TRY(tbk_exscan_u32(ctx, cnt, woff, ng, sc + 21));
   TBK_LAUNCH(ctx, "partial_table", partial_table_k, cdiv(world, 64), 64, 0, ng, world, key, cuts, woff, sc + 21, (long long*)tab);
-  if (ng)
-    TBK_LAUNCH(ctx, "partial_rows", partial_rows_k, cdiv(ng, SH_B), SH_B, 0, ng, in->n_files, first_fidx, d_fo, g->rep, g->yc, g->yx, g->yd,
-               g->rep_effend, in->tid, in->pos, in->strand, cfirst, cnt, woff, in->cig, rows, cig_out);
+  if (ng) {
+    ColIn I{};
+    I.n = in->n_records;
+    I.k = in->n_files;
+    I.file_off = d_fo;
+    I.tid = in->tid;
+    I.pos = in->pos;
+    I.flag = in->flag;
+    I.mapq = in->mapq;
+    I.strand = in->strand;
+    I.nh = in->nh;
+    I.cig_off = in->cig_off;
+    I.cig = in->cig;
+    ColOpt O{};
+    O.strategy = o->strategy;
+    O.max_nh = o->max_nh;
+    O.min_qual = o->min_qual;
+    O.keep_supp = o->keep_supplementary;
+    O.keep_sec = o->keep_secondary;
+    O.seed = TBK_KEY_SEED0;
+    O.hash_mask = 0xFFFFFFFFu;
+    if (const char* e = getenv("TBK_DEBUG_HASH_MASK")) O.hash_mask = (uint32_t)strtoul(e, nullptr, 0);
+    TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
+    TBK_LAUNCH(ctx, "partial_rows", partial_rows_k, cdiv(ng, SH_B), SH_B, 0, ng, in->n_files, first_fidx, I, O, g->rep, g->yc, g->yx, g->yd,
+               g->rep_effend, cfirst, cnt, woff, rows, cig_out, ctx->d_err);
+    uint32_t eb = 0;
+    TBK_TRY(tbk_sync_err(ctx, &eb));
+    if (eb) return tbk_derr_to_status(ctx, eb);
+  }
   TBK_HIP(hipStreamSynchronize(ctx->stream));
   return tbk_check_launch(ctx, "partial_pack");
 }
@@ -667,4 +707,29 @@ extern "C" int tbk_partial_unpack(tbk_ctx* ctx, const int32_t* rows, uint32_t n2
              cig_off, yc_in, yx_in, yd_in, prio_hi, prio_lo);
   TBK_HIP(hipStreamSynchronize(ctx->stream));
   return tbk_check_launch(ctx, "partial_unpack");
+}
+
+// The owner's reduce-by-key of the partials it received (wgroup.hip, tbk_partial_reduce_device): arguments checked here.
+extern "C" int tbk_partial_reduce(tbk_ctx* ctx, const tbk_collapse_opts* o, const int32_t* rows, uint32_t n2, const uint32_t* run_off,
+                                  uint32_t n_runs, const uint32_t* cig, tbk_groups_out* out, tbk_cov_in* view) {
+  if (!ctx || !o || !out || !run_off || n_runs == 0) return TBK_EINVAL;
+  if (o->strategy < 0 || o->strategy > 3 || o->strategy == TBK_STRAT_FULL) return TBK_EUNSUPPORTED;
+  if (run_off[0] != 0 || run_off[n_runs] != n2) return TBK_EINVAL;
+  if (out->mem != TBK_MEM_DEVICE || (n2 && (!rows || !out->rep || !out->yc || !out->yx || !out->yd))) return TBK_EINVAL;
+  if (!tbk_window_supported(n_runs)) return TBK_EUNSUPPORTED;
+  TBK_HIP(hipSetDevice(ctx->device));
+  tbk_prof_begin_call(ctx);
+  struct ProfEnd {
+    tbk_ctx* c;
+    ~ProfEnd() { tbk_prof_end_call(c); }
+  } prof_end{ctx};
+  out->n_groups = 0;
+  out->n_passed = n2;
+  if (view) {
+    memset(view, 0, sizeof(*view));
+    view->mem = TBK_MEM_DEVICE;
+  }
+  if (n2 == 0) return 0;
+  TBK_TRY(tbk_ws_reserve(ctx, (size_t)n2 * 120 + ((size_t)8 << 20)));
+  return tbk_partial_reduce_device(ctx, o->strategy, rows, n2, run_off, n_runs, cig, out, view);
 }

@@ -8,6 +8,10 @@
 
 namespace tbkd {
 
+// seed of the first grouping attempt (collapse.hip reseeds on a collision) and of the key word that travels in a group partial
+// (shard.hip, tbk_partial_pack: every rank hashes with this one, so equal alignments carry equal words)
+constexpr uint64_t TBK_KEY_SEED0 = 0x71EB5EEDull;
+
 struct ColIn {
   uint32_t n, k;
   const uint32_t* file_off;  // device copy [k+1]

@@ -37,3 +37,9 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
 //  — WgOut::yc is the sum of the carried integral YC, yxin / ydin the sum / maximum of the carried YX / YD, no
 // incidences (np = 0); TBK_DERR_FRACTIONAL in *err_bits: a carried value this form cannot hold — run the sort path.
 bool tbk_window_supported(uint32_t k);
+
+// Owner side of the group-partials protocol: merge n_runs runs of partial rows (TBK_PARTIAL_ROW words each, every
+// run in its rank's output order) in output order and reduce equal keys; see tbk_partial_reduce in include/tbk.h.  The arena
+// must be reserved by the caller.
+int tbk_partial_reduce_device(tbk_ctx* ctx, int strategy, const int32_t* rows, uint32_t n2, const uint32_t* run_off_host, uint32_t n_runs,
+                              const uint32_t* cig, tbk_groups_out* out, tbk_cov_in* view);

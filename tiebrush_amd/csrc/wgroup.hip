@@ -1276,9 +1276,287 @@ __global__ void wg_finish_raw_k(uint32_t n, const uint32_t* __restrict__ cslot, 
   if (anchor != j && !strategy_equal(I, strategy, j, anchor)) atomicOr(err, TBK_DERR_COLLISION);
 }
 
+
+// ==================================== group partials: the owner's merge-reduce ====================================
+// Multi-GPU owner side: the rows a rank receives are n_runs runs, each already in the reference's output order
+// and free of duplicates — shallow data by construction (a group has at most one partial per run), the worst case of the hash
+// windows above (every window overflows both tables).  So the windows (same splitter machinery, smaller: < 3 PR_T rows) are
+// MERGED instead: a row's place is its index in its own run's piece plus, for every other piece, the number of rows that precede
+// it there (one bisection per piece, all in LDS; nothing to do for a single run).  The order is the output order itself — key
+// high word (tid, start, strand), span (= end), then, inside a tie, the strategy compare of the reference on the CIGARs
+// (tiebrush.cpp:285-345; only evaluated when two different key words meet in one tie set) — so no tie sort follows.  Equal keys
+// are adjacent after the merge: one thread per group sums YC / YX, takes the maximum YD and the representative with the smallest
+// (effective end, run), and compares every hashed key word's CIGAR with the group head's (TBK_DERR_COLLISION otherwise).
+constexpr int PR_NT = 256;
+constexpr uint32_t PR_T = 512;          // rows between splitters
+constexpr uint32_t PR_KS = 512;         // runs x sample stride
+constexpr uint32_t PR_CAP = 3 * PR_T;   // a window holds < 2 T + k s rows
+constexpr int PR_E = (int)(PR_CAP / PR_NT);
+constexpr uint32_t PR_MAXRUNS = 64;
+
+__global__ void pr_rowkeys_k(uint32_t n2, const int32_t* __restrict__ rows, uint64_t* __restrict__ chi, int32_t* __restrict__ tid,
+                             int32_t* __restrict__ pos, uint8_t* __restrict__ strand, uint32_t* __restrict__ ncig) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n2) return;
+  const int4 q = *reinterpret_cast<const int4*>(rows + (size_t)i * TBK_PARTIAL_ROW);
+  chi[i] = raw_key(q.x, q.y) << 2;
+  tid[i] = q.x;
+  pos[i] = q.y;
+  strand[i] = (uint8_t)((uint32_t)q.z & 0xFFu);
+  ncig[i] = (uint32_t)q.z >> 8;
+}
+__global__ void pr_tail_k(uint32_t n2, const uint64_t* __restrict__ total, uint32_t* __restrict__ cig_off) { cig_off[n2] = (uint32_t)*total; }
+
+struct PrTemp {      // per window, at the window's row base
+  uint32_t* rep;     // row of the representative
+  double* yc;
+  uint32_t *yx, *yd;
+  uint32_t* wg_cnt;  // [nw] groups of the window
+};
+
+__global__ __launch_bounds__(PR_NT) void pr_merge_k(const int32_t* __restrict__ rows, const uint32_t* __restrict__ off, uint32_t k, uint32_t nw,
+                                                    const uint32_t* __restrict__ wbase, ColIn I, int strategy, PrTemp T,
+                                                    uint32_t* __restrict__ err) {
+  __shared__ uint64_t khi[PR_CAP], klo[PR_CAP];
+  __shared__ uint32_t rsrc[PR_CAP];
+  __shared__ uint16_t srt[PR_CAP];
+  __shared__ uint8_t pf[PR_CAP];
+  __shared__ uint32_t pre[PR_MAXRUNS + 1], base0[PR_MAXRUNS];
+  __shared__ uint32_t sm_u[PR_NT / 64];
+  const uint32_t w = blockIdx.x, t = threadIdx.x;
+  const uint32_t wb = wbase[w];
+  const uint32_t n_w = wbase[w + 1] - wb;
+  if (n_w == 0 || n_w > PR_CAP) {
+    if (t == 0) {
+      T.wg_cnt[w] = 0;
+      if (n_w) atomicOr(err, TBK_DERR_BIGBUCKET);  // more partials on one base than a block merges: the caller takes the general path
+    }
+    return;
+  }
+  if (t < 64) {  // pieces of the window: lengths, prefix, first row (k <= 64: one wave)
+    uint32_t a = 0, len = 0;
+    if (t < k) {
+      a = off[(size_t)w * k + t];
+      const uint32_t b = off[(size_t)(w + 1) * k + t];
+      len = b > a ? b - a : 0u;
+    }
+    const uint32_t inc = wave_incl_sum(len);
+    if (t < k) {
+      pre[t] = inc - len;
+      base0[t] = a;
+    }
+    if (t == 0) pre[k] = n_w;
+  }
+  __syncthreads();
+  for (uint32_t e = t; e < n_w; e += PR_NT) {
+    const uint32_t f = piece_of(pre, k, e);
+    const uint32_t src = base0[f] + (e - pre[f]);
+    const int4* rp = reinterpret_cast<const int4*>(rows + (size_t)src * TBK_PARTIAL_ROW);
+    const int4 q0 = rp[0], q2 = rp[2];
+    khi[e] = ((uint64_t)(uint32_t)(q0.x + 1) << 33) | ((uint64_t)(uint32_t)(q0.y + 1) << 2) | strand_code((uint8_t)((uint32_t)q0.z & 0xFFu));
+    klo[e] = ((uint64_t)(uint32_t)q2.y << 32) | (uint32_t)q2.z;
+    rsrc[e] = src;
+    pf[e] = (uint8_t)f;
+  }
+  __syncthreads();
+  // three-way compare of element y with (xh, xl, xsrc) in the output order; 0 = the same group
+  auto cmp = [&](uint32_t y, uint64_t xh, uint64_t xl, uint32_t xsrc) -> int {
+    const uint64_t yh = khi[y];
+    if (yh != xh) return yh < xh ? -1 : 1;
+    const uint64_t yl = klo[y];
+    if (yl == xl) return 0;
+    if ((yl >> 32) != (xl >> 32)) return yl < xl ? -1 : 1;
+    return strategy_cmp(I, strategy, rsrc[y], xsrc);  // one tie set, two alignments: the reference's compare on the CIGARs
+  };
+  for (uint32_t e = t; e < n_w; e += PR_NT) {
+    const uint32_t r = pf[e];
+    const uint64_t xh = khi[e], xl = klo[e];
+    const uint32_t xsrc = rsrc[e];
+    uint32_t rank = e - pre[r];
+    for (uint32_t s2 = 0; s2 < k; ++s2) {
+      if (s2 == r) continue;
+      uint32_t lo = pre[s2], hi = pre[s2 + 1];
+      const uint32_t first = lo;
+      const int lim = s2 < r ? 0 : -1;  // rows of earlier runs with an equal key come first
+      while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (cmp(mid, xh, xl, xsrc) <= lim)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      rank += lo - first;
+    }
+    srt[rank] = (uint16_t)e;
+  }
+  __syncthreads();
+  // ---- heads and groups: thread t owns the eu consecutive sorted positions from t * eu ----
+  const uint32_t eu = (n_w + PR_NT - 1) / PR_NT;
+  const uint32_t q0 = t * eu;
+  uint32_t hf = 0;
+  {
+    uint64_t ph = 0, pl = 0;
+    if (q0 > 0 && q0 <= n_w) {
+      const uint32_t pe = srt[q0 - 1];
+      ph = khi[pe];
+      pl = klo[pe];
+    }
+#pragma unroll
+    for (int u = 0; u < PR_E; ++u) {
+      const uint32_t q = q0 + (uint32_t)u;
+      if ((uint32_t)u < eu && q < n_w) {
+        const uint32_t e = srt[q];
+        const uint64_t h = khi[e], l = klo[e];
+        if (q == 0 || h != ph || l != pl) hf |= 1u << u;
+        ph = h;
+        pl = l;
+      }
+    }
+  }
+  uint32_t tot;
+  uint32_t gid = block_excl_sum<uint32_t, PR_NT>((uint32_t)__builtin_popcount(hf), sm_u, &tot);
+#pragma unroll
+  for (int u = 0; u < PR_E; ++u) {
+    if (!((hf >> u) & 1u)) continue;
+    const uint32_t q = q0 + (uint32_t)u;
+    const uint32_t e0 = srt[q];
+    const uint64_t h = khi[e0], l = klo[e0];
+    const bool hashed = !((l >> 31) & 1ull);
+    double yc = 0.0;
+    uint32_t yx = 0, yd = 0, best = 0, beff = 0xFFFFFFFFu;
+    for (uint32_t m = q; m < n_w; ++m) {  // the group's members: adjacent, one per run at most, earlier runs first
+      const uint32_t e = srt[m];
+      if (m > q && (khi[e] != h || klo[e] != l)) break;
+      const uint32_t src = rsrc[e];
+      const int4* rp = reinterpret_cast<const int4*>(rows + (size_t)src * TBK_PARTIAL_ROW);
+      const int4 a = rp[0], b = rp[1], c = rp[2];
+      const uint32_t eff = (uint32_t)a.w;
+      if (m == q || eff < beff) {
+        beff = eff;
+        best = src;
+      }
+      yc += (double)(uint32_t)b.z;
+      yx += (uint32_t)b.w;
+      yd = (uint32_t)c.x > yd && c.x > 0 ? (uint32_t)c.x : yd;
+      if (hashed && m > q && !strategy_equal(I, strategy, src, rsrc[e0])) atomicOr(err, TBK_DERR_COLLISION);
+    }
+    T.rep[wb + gid] = best;
+    T.yc[wb + gid] = yc;
+    T.yx[wb + gid] = yx;
+    T.yd[wb + gid] = yd;
+    ++gid;
+  }
+  if (t == 0) T.wg_cnt[w] = tot;
+}
+
+__global__ __launch_bounds__(64) void pr_compact_k(uint32_t nw, const uint32_t* __restrict__ wbase, PrTemp T, const uint32_t* __restrict__ gbase,
+                                                   const int32_t* __restrict__ rows, uint32_t cap, uint32_t* __restrict__ o_rep,
+                                                   double* __restrict__ o_yc, int64_t* __restrict__ o_yx, int32_t* __restrict__ o_yd,
+                                                   int32_t* __restrict__ o_start, int32_t* __restrict__ o_end) {
+  const uint32_t w = blockIdx.x;
+  const uint32_t ng = T.wg_cnt[w];
+  if (!ng) return;
+  const uint32_t wb = wbase[w], gb = gbase[w];
+  for (uint32_t g = threadIdx.x; g < ng; g += 64) {
+    const uint32_t o = gb + g;
+    if (o >= cap) continue;
+    const uint32_t r = T.rep[wb + g];
+    o_rep[o] = r;
+    o_yc[o] = T.yc[wb + g];
+    o_yx[o] = (int64_t)T.yx[wb + g];
+    o_yd[o] = (int32_t)T.yd[wb + g];
+    if (o_start || o_end) {
+      const int32_t* R = rows + (size_t)r * TBK_PARTIAL_ROW;
+      if (o_start) o_start[o] = R[1] + 1;
+      if (o_end) o_end[o] = R[1] + R[9];
+    }
+  }
+}
+
 }  // namespace
 
 bool tbk_window_supported(uint32_t k) { return k >= 1 && k <= 1024; }
+
+int tbk_partial_reduce_device(tbk_ctx* ctx, int strategy, const int32_t* rows, uint32_t n2, const uint32_t* run_off_host, uint32_t k,
+                              const uint32_t* cig, tbk_groups_out* out, tbk_cov_in* view) {
+  if (k > PR_MAXRUNS) return TBK_EUNSUPPORTED;
+  const uint32_t B = 256, m = n2;
+  uint64_t* sc = ctx->d_scalars;
+  TBK_HIP(hipMemsetAsync(sc, 0, 16 * sizeof(uint64_t), ctx->stream));
+  uint32_t* d_run_off = ws_alloc<uint32_t>(ctx, (size_t)k + 1);
+  if (!d_run_off) return TBK_ENOMEM;
+  {
+    void* stage = tbk_stage_acquire(ctx);
+    memcpy(stage, run_off_host, (size_t)(k + 1) * 4);
+    TBK_HIP(hipMemcpyAsync(d_run_off, stage, (size_t)(k + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    tbk_stage_release(ctx);
+  }
+  uint64_t* chi = ws_alloc<uint64_t>(ctx, m);
+  int32_t* r_tid = ws_alloc<int32_t>(ctx, m);
+  int32_t* r_pos = ws_alloc<int32_t>(ctx, m);
+  uint8_t* r_strand = ws_alloc<uint8_t>(ctx, m);
+  uint32_t* ncig = ws_alloc<uint32_t>(ctx, m);
+  uint32_t* cig_off = ws_alloc<uint32_t>(ctx, (size_t)m + 1);
+  if (!cig_off) return TBK_ENOMEM;
+  TBK_LAUNCH(ctx, "pr_rowkeys", pr_rowkeys_k, cdiv(m, B), B, 0, m, rows, chi, r_tid, r_pos, r_strand, ncig);
+  TBK_TRY(tbk_exscan_u32(ctx, ncig, cig_off, m, sc + 23));
+  TBK_LAUNCH(ctx, "pr_tail", pr_tail_k, 1, 1, 0, m, sc + 23, cig_off);
+  // windows: sample stride s (power of two, k s <= PR_KS), g = PR_T / s samples per splitter
+  uint32_t s = 1;
+  while (s * 2 * k <= PR_KS && s * 2 <= PR_T) s *= 2;
+  const uint32_t g = PR_T / s;
+  const uint32_t ns = cdiv(m, s);
+  const uint32_t nsp = ns > 1 ? (ns - 1) / g : 0;
+  const uint32_t nW = 2 * nsp, nw = nW + 1, nrows = nw + 1;
+  uint64_t* W = ws_alloc<uint64_t>(ctx, (size_t)nW + 1);
+  uint32_t* off = ws_alloc<uint32_t>(ctx, (size_t)nrows * k);
+  uint32_t* wbase = ws_alloc<uint32_t>(ctx, (size_t)nw + 1);
+  uint32_t* gbase = ws_alloc<uint32_t>(ctx, nw);
+  PrTemp T;
+  T.rep = ws_alloc<uint32_t>(ctx, m);
+  T.yc = ws_alloc<double>(ctx, m);
+  T.yx = ws_alloc<uint32_t>(ctx, m);
+  T.yd = ws_alloc<uint32_t>(ctx, m);
+  T.wg_cnt = ws_alloc<uint32_t>(ctx, nw);
+  if (!W || !off || !wbase || !gbase || !T.wg_cnt || !T.yd) return TBK_ENOMEM;
+  if (nsp) {
+    uint64_t* Y = ws_alloc<uint64_t>(ctx, ns);
+    uint64_t* Y2 = ws_alloc<uint64_t>(ctx, ns);
+    if (!Y2) return TBK_ENOMEM;
+    TBK_LAUNCH(ctx, "wg_sample", wg_sample_k, cdiv(ns, B), B, 0, chi, m, s, ns, Y);
+    TBK_TRY(tbk_radix_sort_w64(ctx, &Y, &Y2, ns, ~0ull, false));
+    TBK_LAUNCH(ctx, "wg_split", wg_split_k, cdiv(nsp, B), B, 0, Y, g, nsp, W);
+  }
+  TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_stream_k<false>, cdiv(m, WG_OC), 256, 0, chi, (const int32_t*)nullptr, (const int32_t*)nullptr, d_run_off, k, m, W, nW,
+             off, ctx->d_err);
+  TBK_LAUNCH(ctx, "wg_offsets_edges", wg_offsets_edges_k, cdiv(k, B), B, 0, d_run_off, k, nrows, off);
+  TBK_LAUNCH(ctx, "wg_rowsum", wg_rowsum_k, cdiv(nrows, 4), 256, 0, off, k, nrows, wbase);
+  ColIn I{};
+  I.n = m;
+  I.k = k;
+  I.pos = r_pos;
+  I.cig_off = cig_off;
+  I.cig = cig;
+  TBK_LAUNCH(ctx, "pr_merge", pr_merge_k, nw, PR_NT, 0, rows, off, k, nw, wbase, I, strategy, T, ctx->d_err);
+  TBK_TRY(tbk_exscan_u32(ctx, T.wg_cnt, gbase, nw, sc + 1));
+  uint32_t eb = 0;
+  TBK_TRY(tbk_sync_err(ctx, &eb));
+  if (eb & TBK_DERR_BIGBUCKET) {
+    ctx->last_error = "more partials start on one base than a workgroup merges";
+    return TBK_E2BIG;
+  }
+  if (eb) return tbk_derr_to_status(ctx, eb);
+  const uint32_t ng = (uint32_t)ctx->h_scalars[1];
+  out->n_groups = ng;
+  if (ng > out->cap_groups) return TBK_E2BIG;
+  if (ng == 0) return 0;
+  TBK_LAUNCH(ctx, "pr_compact", pr_compact_k, nw, 64, 0, nw, wbase, T, gbase, rows, out->cap_groups, out->rep, out->yc, out->yx, out->yd,
+             out->g_start, out->g_end);
+  if (view) return tbk_cov_view_build(ctx, r_tid, r_pos, r_strand, cig_off, cig, out->rep, out->yc, out->yx, ng, view);
+  TBK_HIP(hipStreamSynchronize(ctx->stream));
+  return tbk_check_launch(ctx, "partial_reduce");
+}
+
 
 int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const uint64_t* chi, const uint64_t* clo, const uint32_t* cval,
                       const uint32_t* ceff, uint32_t m, const uint32_t* d_run_off, uint64_t* scratch_hi, uint64_t* scratch_lo,

@@ -8,12 +8,12 @@ and re-collapsed):
      inside a sample's list is a function of the group keys (:438-457, :511-524), and a sample lives on one rank;
   2. the ranks agree on R-1 coordinate cuts at global tiecov bundle boundaries, found on the local GROUP arrays (all-gather of 64
      sampled group keys, all-reduce rounds as below);
-  3. one 40-byte row per local group {tid, pos, strand, n_cigar, effective end, file, index, YC, YX, YD} and the local
+  3. one 48-byte row per local group {tid, pos, strand, n_cigar, effective end, file, index, YC, YX, YD, span, key word} and the local
      representative's CIGAR go to the owner of the group's range (one all-to-all of rows, one of CIGAR words): groups are already
      in coordinate order, so a destination is a contiguous range — nothing is reordered;
-  4. the owner collapses what it received as TieBrush-merged records with explicit priorities (`tbk_collapse_tile`, window path in
-     its PART form): sum YC, sum YX, max YD, representative = argmin priority — `SPData::dupAdd` is associative
-     (tiebrush.cpp:408-436) — and runs tiecov on its slice.
+  4. the owner merges the R runs it received in output order and reduces equal keys (`tbk_partial_reduce`; or, as the general
+     form, `tbk_partial_unpack` + `tbk_collapse_tile` on TieBrush-merged records with explicit priorities): sum YC, sum YX, max YD,
+     representative = argmin priority — `SPData::dupAdd` is associative (tiebrush.cpp:408-436) — and runs tiecov on its slice.
 Unlike a tiewrap-style hierarchical run, the explicit priority keeps the flat run's representative record.  Exact for integral
 YC; inputs that carry a fractional YC (written with --store-frac) fall back, by a collective decision, to the protocol below.
 
@@ -50,8 +50,6 @@ from __future__ import annotations
 
 import os
 
-from dataclasses import dataclass
-from typing import Any, Optional
 
 import numpy as np
 
@@ -161,23 +159,32 @@ def _xp(a):
     return _TT if _is_t(a) else _NP
 
 
-@dataclass
 class ShardResult:
-    """This rank's slice of the global result, in the reference's output order (arrays: numpy or torch)."""
-    n_groups: int
-    n_passed_local: int          # passing input records of THIS rank's files (sum over ranks = inCounter)
-    tid: Any
-    start: Any                   # 1-based
-    end: Any
-    rep_fidx: Any                # global file index of the representative record
-    rep_idx: Any                 # its index inside that file
-    yc: Any
-    yx: Any
-    yd: Any
-    cov_input: Any = None        # CovInput (host) or DeviceCovView (device): what tiecov reads back for this slice
-    coverage: Optional[dict] = None
-    junction_offset: int = 0
-    n_partials_received: int = 0
+    """This rank's slice of the global result, in the reference's output order (arrays: numpy or torch).
+
+    n_passed_local: passing input records of THIS rank's files (sum over ranks = inCounter); start / end: 1-based; rep_fidx /
+    rep_idx: global file index of the representative record and its index inside that file; cov_input: CovInput (host) or
+    DeviceCovView (device), what tiecov reads back for this slice.  After tbk_partial_reduce the representative is known as a ROW of
+    the received partials (rep_rows = (rows, row index per group)); tid / rep_fidx / rep_idx are gathered from it on first use."""
+    _LAZY = ("tid", "rep_fidx", "rep_idx")
+
+    def __init__(self, n_groups, n_passed_local, tid=None, start=None, end=None, rep_fidx=None, rep_idx=None, yc=None, yx=None, yd=None,
+                 cov_input=None, coverage=None, junction_offset=0, n_partials_received=0, rep_rows=None):
+        self.n_groups, self.n_passed_local = n_groups, n_passed_local
+        self.start, self.end, self.yc, self.yx, self.yd = start, end, yc, yx, yd
+        self.cov_input, self.coverage, self.junction_offset, self.n_partials_received = cov_input, coverage, junction_offset, n_partials_received
+        self.rep_rows = rep_rows
+        if rep_rows is None:
+            self.tid, self.rep_fidx, self.rep_idx = tid, rep_fidx, rep_idx
+
+    def __getattr__(self, name):          # (only reached while the lazy fields are not set)
+        if name in ShardResult._LAZY and self.__dict__.get("rep_rows") is not None:
+            rows, rep = self.rep_rows
+            T = _torch()
+            rr = rows[rep] if self.n_groups else rows[:0]
+            self.tid, self.rep_fidx, self.rep_idx = rr[:, 0], rr[:, 4].to(T.int64), rr[:, 5].to(T.int64) & 0xFFFFFFFF
+            return self.__dict__[name]
+        raise AttributeError(name)
 
 
 def _gather_cigars(X, cig_off, cig, rep):
@@ -482,7 +489,7 @@ def shard_collapse(compute, local_tile: SoATile, first_fidx: int, rank: int, wor
 
 
 # ---- group partials (default protocol) ------------------------------------------------------------------------------------------
-PROW = 10     # int32 words per partial row (include/tbk.h: TBK_PARTIAL_ROW)
+PROW = 12     # int32 words per partial row (include/tbk.h: TBK_PARTIAL_ROW)
 
 
 def _partial_keys_np(tile, fin):
@@ -517,6 +524,8 @@ def _partial_pack_np(tile, fin, key, cuts, world, first_fidx):
         rows[:, 6] = np.asarray(fin["yc"])[:ng].astype(np.int64)
         rows[:, 7] = np.asarray(fin["yx"])[:ng]
         rows[:, 8] = np.asarray(fin["yd"])[:ng]
+        rows[:, 9] = np.asarray(fin["g_end"])[:ng].astype(np.int64) - np.asarray(fin["g_start"])[:ng] + 1
+        # (word 10, the key word of tbk_partial_pack, is only read by tbk_partial_reduce: rows packed here are reduced by the general path)
     _, woff, cigw = _gather_cigars(_NP, tile.cig_off, np.asarray(tile.cig), rep)
     b = np.concatenate([[0], np.searchsorted(key, cuts, side="left") if world > 1 else np.zeros(0, np.int64), [ng]]).astype(np.int64)
     tab = np.stack([b[:-1], b[1:] - b[:-1], woff[b[1:]] - woff[b[:-1]]], axis=1).astype(np.int64)
@@ -614,7 +623,7 @@ def partials_collapse(compute, local_tile: SoATile, first_fidx: int, rank: int, 
     mark("cuts")
     # ---- 4. rows + CIGAR words in group order; exchange ----------------------------------------------------------------------
     if on_dev:
-        rows, cigw, tab = compute.partial_pack(local_tile, fin, key, p, world, first_fidx)
+        rows, cigw, tab = compute.partial_pack(local_tile, fin, key, p, world, first_fidx, strategy=strategy, **filters)
         tab_h = tab.cpu().numpy()
     else:
         hostify = (lambda a: X.host(a)) if _is_t(key) else (lambda a: a)
@@ -637,6 +646,38 @@ def partials_collapse(compute, local_tile: SoATile, first_fidx: int, rank: int, 
     file_off2 = np.zeros(world + 1, np.uint32)
     file_off2[1:] = np.cumsum(np.asarray(rcnt, np.int64))
     assert int(file_off2[-1]) == n2
+    fast = None
+    if on_dev and hasattr(compute, "partial_reduce") and os.environ.get("TBK_PARTIAL_REDUCE", "1") != "0":
+        from ._lib import TbkError
+        try:                                            # the owner's merge-reduce on the rows as they arrived
+            fast = compute.partial_reduce(rrows, file_off2, rcig, want_view=device_chain, strategy=strategy)
+        except TbkError as e:
+            if e.status not in (-8, -4, -5):            # a hashed key word shared by two alignments / a pile-up of partials / > 64 runs:
+                raise                                   # the general path (reseeds, block-sorts long buckets) takes the tile
+    if fast is not None:
+        T = _torch()
+        g2 = int(fast["n_groups"])
+        res = ShardResult(n_groups=g2, n_passed_local=n_pass, start=fast["g_start"], end=fast["g_end"], yc=fast["yc"], yx=fast["yx"], yd=fast["yd"],
+                          n_partials_received=n2, rep_rows=(rrows, fast["rep"]))
+        mark("reduce")
+        rep2 = fast["rep"]
+        if device_chain:
+            res.cov_input = fast["view"]
+        else:
+            rep2 = fast["rep"].to(T.int64)
+            rr = rrows[rep2] if g2 else rrows[:0]
+            A = compute.partial_unpack(rrows)
+            ncg, cof, cg = _gather_cigars(X, A["cig_off"], rcig, rep2)
+            res.cov_input = CovInput(tid=rr[:, 0].contiguous(), pos=rr[:, 1].contiguous(), flag=X.as_dtype(X.zeros(g2, like=rep2), "u16"),
+                                     cig_off=X.as_dtype(cof, "u32"), cig=cg, yc=fast["yc"].to(T.float32).to(T.float64),
+                                     strand=A["strand"][rep2], yx=fast["yx"])
+        if want_coverage:
+            cov = compute.coverage(res.cov_input)
+            nj = yield ("all_gather", X.scalar(int(cov["n_junctions"]), like=rep2))
+            res.coverage = cov
+            res.junction_offset = int(X.host(nj).reshape(-1)[:rank].sum())
+        mark("coverage")
+        return res
     if on_dev:
         A = compute.partial_unpack(rrows)
     else:
