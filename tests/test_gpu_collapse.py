@@ -65,6 +65,21 @@ def test_golden_clip_exon(ctx, name, strategy, bam_loader):
     _check(ctx, tile, strategy=strategy)                    # HEAD default (-A off), window / sort path as the tile size picks
 
 
+@pytest.mark.parametrize("machine", ["wave", "lane"])
+def test_golden_t2_yd_machines(ctx, machine, bam_loader, monkeypatch):
+    """golden t2 (its 64 tail-drop YDs among them) with every chain forced through yd_wave_k / through yd_lane_k"""
+    from tiebrush_amd import soa
+    monkeypatch.setenv("TBK_YD_WAVE_MIN", "1" if machine == "wave" else str(1 << 30))
+    bams = [bam_loader(p) for p in sample_paths("t2")]
+    tile = soa.tile_from_bams(bams, with_names=True)
+    gold = bam_loader(os.path.join(GOLDEN, "t2", "t2.bam"))
+    got, _ = _check(ctx, tile, collapse_same=True)
+    assert compare_groups_to_golden_bam(got, tile, bams, gold) == []
+    monkeypatch.setenv("TBK_PATH", "window")
+    got, _ = _check(ctx, tile)
+    assert int(np.asarray(got["yd"]).max()) > 0
+
+
 def test_golden_t12_tbmerged(ctx, bam_loader):
     from tiebrush_amd import soa
     bams = [bam_loader(os.path.join(GOLDEN, "t1", "t1.bam")), bam_loader(os.path.join(GOLDEN, "t2", "t2.bam"))]

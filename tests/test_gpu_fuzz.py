@@ -187,10 +187,14 @@ def _dense_tile(rng, n_files, per_file, span, introns):
         cig=np.array([x for c in cigs for x in c], np.uint32))
 
 
+@pytest.mark.parametrize("machine", ["default", "wave", "lane"])
 @pytest.mark.parametrize("seed", range(8))
-def test_fuzz_yd_long_chains(ctx, seed):
-    """yd_wave_k (one wave per long chain): runs of list-preserving items, spliced reads landing in / beyond existing
-    nodes, insertions, swallows and island restarts, against the literal GSegList of the oracle."""
+def test_fuzz_yd_long_chains(ctx, seed, machine, monkeypatch):
+    """yd_wave_k (one wave per long chain) and yd_lane_k (a chain per lane, the list in registers): runs of list-preserving
+    items, spliced reads landing in / beyond existing nodes, insertions, swallows and island restarts, against the literal
+    GSegList of the oracle.  TBK_YD_WAVE_MIN sends every chain to one machine or the other."""
+    if machine != "default":
+        monkeypatch.setenv("TBK_YD_WAVE_MIN", "1" if machine == "wave" else str(1 << 30))
     rng = np.random.default_rng(9000 + seed)
     span = int(rng.choice([600, 2000, 6000]))
     introns = []
@@ -276,8 +280,11 @@ def _spliced_region_tile(rng, n_files, n_regions):
         cig=np.array([x for c in cigs for x in c], np.uint32))
 
 
+@pytest.mark.parametrize("machine", ["default", "wave", "lane"])
 @pytest.mark.parametrize("seed", range(6))
-def test_fuzz_yd_spliced_regions(ctx, seed):
+def test_fuzz_yd_spliced_regions(ctx, seed, machine, monkeypatch):
+    if machine != "default":
+        monkeypatch.setenv("TBK_YD_WAVE_MIN", "1" if machine == "wave" else str(1 << 30))
     rng = np.random.default_rng(9500 + seed)
     tile = _spliced_region_tile(rng, int(rng.integers(1, 3)), 60)
     want = _cmp(ctx, tile, strategy="cigar")

@@ -690,6 +690,232 @@ __global__ void yd_run_k(const uint32_t* __restrict__ ids, const uint32_t* __res
   }
 }
 
+// ---- thread per chain, the list in registers -------------------------------------------------------------------------------------
+// Short chains (the bulk of the chains, a minority of the items) run one per lane.  What made the first thread-per-chain kernel
+// (yd_run_k) slow was the list in global memory — a pointer chase per node — and every lane streaming its own items (64 cache
+// lines per load instruction).  Here the sorted node list of a lane is YL_CAP (start, end) pairs in REGISTERS (every index is a
+// compile-time constant after unrolling; a dynamic position is a chain of selects: an LDS-resident list was measured 4x slower,
+// its shifts are chains of dependent LDS round trips), and the items reach the lanes through LDS: R consecutive lanes load R
+// consecutive items of one chain, so a load instruction brings in whole segments, and every lane then reads its own R staged
+// items.  Lanes of a wave take chains of similar length (bucketed by log2 of the length, longest first).  A list that outgrows
+// YL_CAP hands the chain to yd_run_k (ids_over: the outputs are maxima, a rerun from the chain's start is harmless).  Chains of
+// YD_WAVE_MIN_DEFAULT items and more keep a wave to themselves (yd_wave_k): a lane steps through an item in thousands of cycles
+// of shared issue time, so a long chain in a lane is a long tail — measured on config 3, lane + wave kernels: threshold 24:
+// 1.8 + 6.1 ms, 128: 4.8 + 6.1, 512: 4.4 + 3.5, 2048: 8.4 + 2.6 (before: yd_run_k 2.3 + yd_wave_k 7.7).
+constexpr int YL_CAP = 8;
+constexpr uint32_t YD_WAVE_MIN_DEFAULT = 24;
+
+constexpr int YD_NB = 32;  // length buckets (log2)
+
+__device__ __forceinline__ uint32_t yd_bucket(uint32_t len) { return 31u - (uint32_t)__builtin_clz(len | 1u); }
+
+// cnt[b] = chains of bucket b that go to the lane kernel, cnt[YD_NB] = chains that get a wave
+__global__ void yd_bucket_count_k(uint32_t nchains, uint32_t nit, uint32_t wave_min, const uint32_t* __restrict__ chain_first,
+                                  uint32_t* __restrict__ cnt) {
+  __shared__ uint32_t s_cnt[YD_NB + 1];
+  if (threadIdx.x <= YD_NB) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < nchains) {
+    const uint32_t len = ((c + 1 < nchains) ? chain_first[c + 1] : nit) - chain_first[c];
+    atomicAdd(&s_cnt[len >= wave_min ? YD_NB : yd_bucket(len)], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x <= YD_NB && s_cnt[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], s_cnt[threadIdx.x]);
+}
+// cursors: the buckets laid out longest first
+__global__ void yd_bucket_off_k(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ cur) {
+  uint32_t o = 0;
+  for (int b = YD_NB - 1; b >= 0; --b) {
+    cur[b] = o;
+    o += cnt[b];
+  }
+  cur[YD_NB] = 0;
+}
+__global__ void yd_bucket_fill_k(uint32_t nchains, uint32_t nit, uint32_t wave_min, const uint32_t* __restrict__ chain_first, uint32_t* __restrict__ cur,
+                                 uint32_t* __restrict__ ids_lane, uint32_t* __restrict__ ids_wave) {
+  __shared__ uint32_t s_cnt[YD_NB + 1], s_base[YD_NB + 1];
+  if (threadIdx.x <= YD_NB) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t b = 0, slot = 0;
+  if (c < nchains) {
+    const uint32_t len = ((c + 1 < nchains) ? chain_first[c + 1] : nit) - chain_first[c];
+    b = len >= wave_min ? (uint32_t)YD_NB : yd_bucket(len);
+    slot = atomicAdd(&s_cnt[b], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x <= YD_NB) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&cur[threadIdx.x], s_cnt[threadIdx.x]) : 0u;
+  __syncthreads();
+  if (c < nchains) (b == (uint32_t)YD_NB ? ids_wave : ids_lane)[s_base[b] + slot] = c;
+}
+
+template <int R /* items per lane and refill: the items of R consecutive lanes' worth are one coalesced segment */>
+__global__ __launch_bounds__(64) void yd_lane_k(const uint32_t* __restrict__ ids, uint32_t nids, uint32_t nchains, uint32_t nit,
+                                                const uint32_t* __restrict__ chain_first, YdItems Y, const uint64_t* __restrict__ v,
+                                                const uint32_t* __restrict__ ex_s, const uint32_t* __restrict__ ex_e,
+                                                int32_t* __restrict__ g_yd, uint32_t* __restrict__ ids_over, uint32_t* __restrict__ n_over) {
+  constexpr int RS = R + 1;  // row stride of the staged items (odd: the lanes' own reads fall on different banks)
+  __shared__ uint32_t S_start[64 * RS], S_xo[64 * RS], S_e0[64 * RS], S_s1[64 * RS], S_e1[64 * RS], S_nex[64 * RS], S_o[64 * RS];
+  const uint32_t x = blockIdx.x * 64 + threadIdx.x;
+  const uint32_t l = threadIdx.x;
+  const bool mine = x < nids;
+  const uint32_t c = mine ? ids[x] : 0u;
+  uint32_t t = mine ? chain_first[c] : 0u;
+  const uint32_t t1 = mine ? ((c + 1 < nchains) ? chain_first[c + 1] : nit) : 0u;
+  // the lane's sorted node list: YL_CAP (start, end) pairs in registers — every index below is a compile-time constant after
+  // unrolling, a dynamic position is a chain of selects (no scratch, no LDS round trip on the machine's critical path)
+  uint32_t ns[YL_CAP], ne[YL_CAP];
+#pragma unroll
+  for (int j = 0; j < YL_CAP; ++j) ns[j] = ne[j] = 0;
+  int cnt = 0;
+  uint32_t last_pos = 0;
+  int last_dist = -1;
+  bool over = false;
+#define YL_GET(dst, a, k)                                         \
+  {                                                               \
+    dst = a[0];                                                   \
+    _Pragma("unroll") for (int j_ = 1; j_ < YL_CAP; ++j_) dst = (k) == j_ ? a[j_] : dst; \
+  }
+#define YL_PUT(a, k, val)                                         \
+  {                                                               \
+    _Pragma("unroll") for (int j_ = 0; j_ < YL_CAP; ++j_) a[j_] = (k) == j_ ? (val) : a[j_]; \
+  }
+#define YL_REMOVE1(at) /* drop node `at` */                        \
+  {                                                               \
+    _Pragma("unroll") for (int j_ = 0; j_ + 1 < YL_CAP; ++j_) {   \
+      ns[j_] = j_ >= (at) ? ns[j_ + 1] : ns[j_];                  \
+      ne[j_] = j_ >= (at) ? ne[j_ + 1] : ne[j_];                  \
+    }                                                             \
+    --cnt;                                                        \
+  }
+  constexpr int LG = 64 / R;  // chains whose next R items one load instruction brings in
+  const uint32_t g = l / R, i0 = l % R;
+  while (__any(t < t1 && !over)) {
+    // ---- refill: the next R items of every lane's chain, R consecutive lanes reading R consecutive items ----
+    const uint32_t tl = (t < t1 && !over) ? t : 0xFFFFFFFFu;
+#pragma unroll
+    for (int p = 0; p < R; ++p) {
+      const uint32_t q = (uint32_t)p * LG + g;
+      const uint32_t tq = __shfl(tl, q, 64), t1q = __shfl(t1, q, 64);
+      const uint32_t idx = tq + i0;
+      if (tq != 0xFFFFFFFFu && idx < t1q) {
+        const uint4 a = Y.pk[idx];
+        const uint32_t nx = Y.nex[idx];
+        const uint32_t o = (uint32_t)v[idx];
+        const uint32_t w = q * RS + i0;
+        S_start[w] = a.y;
+        S_xo[w] = a.w;
+        S_e0[w] = ex_e[a.w];  // (the exon arrays follow the groups: items next to each other in a chain read next to each other)
+        S_s1[w] = nx > 1 ? ex_s[a.w + 1] : 0u;
+        S_e1[w] = nx > 1 ? ex_e[a.w + 1] : 0u;
+        S_nex[w] = nx;
+        S_o[w] = o;
+      }
+    }
+    __syncthreads();  // (one wave per block)
+#pragma unroll 1
+    for (int i = 0; i < R; ++i) {
+      const bool live = t < t1 && !over;
+      if (!__any(live)) break;
+      const uint32_t w = l * RS + (uint32_t)i;
+      const uint32_t rstart = S_start[w], xo = S_xo[w], nex = live ? S_nex[w] : 0u, e0 = S_e0[w], s1 = S_s1[w], e1 = S_e1[w], o = S_o[w];
+      if (live) {
+        int d;
+        if (last_pos == rstart) {  // processRead :221-228
+          d = last_dist;
+        } else {
+          d = 0;
+          int p = 0;  // leading nodes that start before the read (the list is sorted)
+#pragma unroll
+          for (int j = 0; j < YL_CAP; ++j) p += (j < cnt && ns[j] < rstart) ? 1 : 0;
+          if (p > 0) {
+            uint32_t pS, pE;
+            YL_GET(pS, ns, p - 1)
+            YL_GET(pE, ne, p - 1)
+            if (pE >= rstart) d = (int)(rstart - pS);
+            if (d == 0)
+              for (int r = 0; r < p; ++r) YL_REMOVE1(0)  // clearTo(prev)
+          }
+          last_pos = rstart;
+          last_dist = d;
+        }
+        // mergeRead :167-219
+        if (cnt == 0) {
+          if (nex > (uint32_t)YL_CAP) {
+            over = true;
+          } else {
+            ns[0] = rstart;
+            ne[0] = e0;
+            ns[1] = s1;
+            ne[1] = e1;
+            for (uint32_t k = 2; k < nex; ++k) {
+              const uint32_t xs = ex_s[xo + k], xe = ex_e[xo + k];
+              YL_PUT(ns, (int)k, xs)
+              YL_PUT(ne, (int)k, xe)
+            }
+            cnt = (int)nex;
+          }
+        } else {
+          int cur = 0;
+          for (uint32_t k = 0; k < nex && !over; ++k) {
+            const uint32_t es = k == 0 ? rstart : (k == 1 ? s1 : ex_s[xo + k]);
+            const uint32_t ee = k == 0 ? e0 : (k == 1 ? e1 : ex_e[xo + k]);
+            // the first node at or behind `cur` that the exon precedes or overlaps; none: this exon and the rest are dropped
+            uint32_t stop = 0;
+#pragma unroll
+            for (int j = 0; j < YL_CAP; ++j) stop |= (j >= cur && j < cnt && (ee < ns[j] || es <= ne[j])) ? (1u << j) : 0u;
+            if (!stop) break;
+            const int n = __builtin_ctz(stop);
+            uint32_t nS, nE;
+            YL_GET(nS, ns, n)
+            YL_GET(nE, ne, n)
+            if (ee < nS) {  // insert before n :182-191
+              if (cnt == YL_CAP) {
+                over = true;
+                break;
+              }
+#pragma unroll
+              for (int j = YL_CAP - 1; j > 0; --j) {
+                ns[j] = j > n ? ns[j - 1] : ns[j];
+                ne[j] = j > n ? ne[j - 1] : ne[j];
+              }
+              YL_PUT(ns, n, es)
+              YL_PUT(ne, n, ee)
+              ++cnt;
+              cur = n + 1;  // (the node the walk stands on moved up by one)
+            } else {  // overlap :194-212
+              const uint32_t newS = es < nS ? es : nS;
+              uint32_t newE = ee > nE ? ee : nE;
+              while (n + 1 < cnt) {  // swallow followers; stops behind the first one that extends the node
+                uint32_t xS, xE;
+                YL_GET(xS, ns, n + 1)
+                if (xS > newE) break;
+                YL_GET(xE, ne, n + 1)
+                YL_REMOVE1(n + 1)
+                if (xE > newE) {
+                  newE = xE;
+                  break;
+                }
+              }
+              YL_PUT(ns, n, newS)
+              YL_PUT(ne, n, newE)
+              cur = n;
+            }
+          }
+        }
+        if (!over && d > 0) atomicMax(&g_yd[o], d);
+        ++t;
+      }
+    }
+    __syncthreads();  // (the staged items are consumed before the next refill overwrites them)
+  }
+  if (over) ids_over[atomicAdd(n_over, 1u)] = c;
+#undef YL_GET
+#undef YL_PUT
+#undef YL_REMOVE1
+}
+
 // Wave-native GSegList: the sorted node list lives one node per lane (ns, ne in registers of lane i = node i),
 // control flow is wave-uniform, list surgery is ballots + shuffles.  One 64-thread block per long chain.
 // A list that would need more than 64 nodes hands the chain over to yd_run_k (ids_over).
@@ -1147,43 +1373,52 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       N.nx = ws_alloc<int32_t>(ctx, nnodes + 1);
       uint32_t* ex_s = ws_alloc<uint32_t>(ctx, ngex + 1);
       uint32_t* ex_e = ws_alloc<uint32_t>(ctx, ngex + 1);
-      uint32_t* ids_short = ws_alloc<uint32_t>(ctx, nchains);
+      uint32_t* ids_lane = ws_alloc<uint32_t>(ctx, nchains);
       uint32_t* ids_long = ws_alloc<uint32_t>(ctx, nchains);
       uint32_t* ids_over = ws_alloc<uint32_t>(ctx, nchains);
-      uint32_t* ccnt = (uint32_t*)(sc + 24);  // [0] short, [1] long, [2] overflow
-      if (!ids_over) return TBK_ENOMEM;
+      uint32_t* bcnt = ws_alloc<uint32_t>(ctx, 2 * (YD_NB + 1) + 2);  // bucket counts, cursors, [n_over]
+      if (!ids_over || !bcnt) return TBK_ENOMEM;
+      uint32_t* bcur = bcnt + (YD_NB + 1);
+      uint32_t* n_over = bcur + (YD_NB + 1);
+      TBK_HIP(hipMemsetAsync(bcnt, 0, (2 * (YD_NB + 1) + 2) * sizeof(uint32_t), ctx->stream));
       TBK_LAUNCH(ctx, "yd_gexons", yd_gexons_k, cdiv(ng, B), B, 0, I, ng, J.gperm, J.G, Q, ex_s, ex_e);
-      TBK_LAUNCH(ctx, "yd_classify", yd_classify_k, cdiv(nchains, B), B, 0, nchains, nit, chain_first, ids_short, ids_long, ccnt);
-      TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 24, ccnt, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+      // chains bucketed by the log2 of their length, longest first: the lanes of a wave of yd_lane_k run chains of like length
+      uint32_t wave_min = YD_WAVE_MIN_DEFAULT;  // TBK_YD_WAVE_MIN: test hook (1: every chain to yd_wave_k; huge: every chain to yd_lane_k)
+      if (const char* e = getenv("TBK_YD_WAVE_MIN")) wave_min = (uint32_t)strtoul(e, nullptr, 0);
+      TBK_LAUNCH(ctx, "yd_classify", yd_bucket_count_k, cdiv(nchains, B), B, 0, nchains, nit, wave_min, chain_first, bcnt);
+      TBK_LAUNCH(ctx, "yd_classify", yd_bucket_off_k, 1, 1, 0, bcnt, bcur);
+      TBK_LAUNCH(ctx, "yd_classify", yd_bucket_fill_k, cdiv(nchains, B), B, 0, nchains, nit, wave_min, chain_first, bcur, ids_lane, ids_long);
+      uint32_t* hc = (uint32_t*)(ctx->h_scalars + 24);
+      TBK_HIP(hipMemcpyAsync(hc, bcnt + YD_NB, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
       TBK_HIP(hipStreamSynchronize(ctx->stream));
-      const uint32_t* hc = (const uint32_t*)(ctx->h_scalars + 24);
-      const uint32_t n_short = hc[0], n_long = hc[1];
-      if (getenv("TBK_YD_DEBUG"))
-        fprintf(stderr, "yd: %u groups, %u items, %u chains (%u short, %u long), %llu nodes\n", ng, nit, nchains, n_short, n_long,
-                (unsigned long long)nnodes);
-      // short chains (a thread each) and long chains (a wave each) are independent: the short ones go to the auxiliary
-      // stream and fill the CUs the few long, latency-bound waves leave idle.  (The stream was synchronised just above,
-      // so the fork needs no event; the join does.)
-      hipStream_t aux = n_short && n_long ? tbk_aux_stream(ctx) : nullptr;
-      if (n_short && aux) {
-        hipStream_t keep = ctx->stream;
-        ctx->stream = aux;
-        TBK_LAUNCH(ctx, "yd_run", yd_run_k, cdiv(n_short, 64), 64, 0, ids_short, ccnt, nchains, nit, chain_first, Y, iv, noff, ex_s,
-                   ex_e, N, J.g_yd);
-        ctx->stream = keep;
-        TBK_HIP(hipEventRecord(ctx->aux_done, aux));
+      const uint32_t n_long = hc[0], n_lane = nchains - n_long;
+      if (getenv("TBK_YD_DEBUG")) {
+        uint32_t hb[YD_NB + 1];
+        TBK_HIP(hipMemcpy(hb, bcnt, sizeof(hb), hipMemcpyDeviceToHost));
+        fprintf(stderr, "yd: %u groups, %u items, %u chains (%u by lane, %u by wave), %llu nodes; chains by log2(length):", ng, nit, nchains, n_lane,
+                n_long, (unsigned long long)nnodes);
+        for (int b = 0; b <= YD_NB; ++b)
+          if (hb[b]) fprintf(stderr, " %d:%u", b, hb[b]);
+        fprintf(stderr, "\n");
       }
+      // lane chains and wave chains are independent: the few long, latency-bound waves go to the auxiliary stream beside the lane
+      // kernel.  (The stream was synchronised just above, so the fork needs no event; the join does.)
+      hipStream_t aux = n_lane && n_long ? tbk_aux_stream(ctx) : nullptr;
       if (n_long) {
-        TBK_LAUNCH(ctx, "yd_wave", yd_wave_k, n_long, 64, 0, ids_long, ccnt + 1, nchains, nit, chain_first, Y, iv, noff, ex_s,
-                   ex_e, J.g_yd, ids_over, ccnt + 2);
-        // chains whose list outgrew a wave (count only known on the device: launch for the upper bound)
-        TBK_LAUNCH(ctx, "yd_run_overflow", yd_run_k, cdiv(n_long, 64), 64, 0, ids_over, ccnt + 2, nchains, nit, chain_first, Y, iv,
-                   noff, ex_s, ex_e, N, J.g_yd);
+        hipStream_t keep = ctx->stream;
+        if (aux) ctx->stream = aux;
+        TBK_LAUNCH(ctx, "yd_wave", yd_wave_k, n_long, 64, 0, ids_long, bcnt + YD_NB, nchains, nit, chain_first, Y, iv, noff, ex_s, ex_e, J.g_yd,
+                   ids_over, n_over);
+        ctx->stream = keep;
+        if (aux) TBK_HIP(hipEventRecord(ctx->aux_done, aux));
       }
-      if (n_short && !aux)
-        TBK_LAUNCH(ctx, "yd_run", yd_run_k, cdiv(n_short, 64), 64, 0, ids_short, ccnt, nchains, nit, chain_first, Y, iv, noff, ex_s,
-                   ex_e, N, J.g_yd);
-      if (n_short && aux) TBK_HIP(hipStreamWaitEvent(ctx->stream, ctx->aux_done, 0));
+      if (n_lane)
+        TBK_LAUNCH(ctx, "yd_lane", yd_lane_k<8>, cdiv(n_lane, 64), 64, 0, ids_lane, n_lane, nchains, nit, chain_first, Y, iv, ex_s, ex_e, J.g_yd,
+                   ids_over, n_over);
+      if (n_long && aux) TBK_HIP(hipStreamWaitEvent(ctx->stream, ctx->aux_done, 0));
+      // chains whose list outgrew its lane's / wave's slots (count only known on the device: launch for the upper bound)
+      TBK_LAUNCH(ctx, "yd_run_overflow", yd_run_k, cdiv(nchains, 64), 64, 0, ids_over, n_over, nchains, nit, chain_first, Y, iv, noff, ex_s, ex_e,
+                 N, J.g_yd);
     }
   }
   TBK_LAUNCH(ctx, "col_write_yd", col_write_yd_k, cdiv(ng, B), B, 0, ng, J.gperm, J.G, J.g_yd, J.cap, J.out_yd);
