@@ -158,6 +158,10 @@ __global__ __launch_bounds__(INF_NT) void bgz_inflate_k(uint32_t nmem, const Bgz
         break;
       }
       for (uint32_t i = 0; i < len; ++i) out[o++] = (uint8_t)in.bits(8);
+      if (in.overrun()) {  // a stored block cut off by the end of the member (zeros flowed in)
+        bad = true;
+        break;
+      }
     } else if (type == 3) {
       bad = true;
       break;
@@ -372,6 +376,7 @@ extern "C" int tbk_bgzf_inflate(tbk_ctx* ctx, const uint8_t* comp, uint64_t comp
     int bsize = -1;
     while (p + 4 <= end) {
       const uint32_t slen = comp[p + 2] | (comp[p + 3] << 8);
+      if (p + 4 + slen > end) break;  // (a subfield that runs past XLEN is never read)
       if (comp[p] == 'B' && comp[p + 1] == 'C' && slen == 2) bsize = comp[p + 4] | (comp[p + 5] << 8);
       p += 4 + slen;
     }
@@ -822,6 +827,7 @@ extern "C" int tbk_bam_decode(tbk_ctx* ctx, uint32_t n_files, const uint8_t* con
       int bsize = -1;
       while (p + 4 <= end) {
         const uint32_t slen = c[p + 2] | (c[p + 3] << 8);
+        if (p + 4 + slen > end) break;  // (a subfield that runs past XLEN is never read)
         if (c[p] == 'B' && c[p + 1] == 'C' && slen == 2) bsize = c[p + 4] | (c[p + 5] << 8);
         p += 4 + slen;
       }

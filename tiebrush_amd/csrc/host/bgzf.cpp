@@ -1,5 +1,6 @@
 #include "bgzf.h"
 
+#include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -9,6 +10,99 @@
 #include <thread>
 
 namespace tbh {
+
+// ---- raw deflate codec ------------------------------------------------------------------------------------------------
+// BGZF members are whole, independent raw-deflate streams of <= 64 KiB: exactly what libdeflate's one-shot API is made for (it
+// is what htslib itself links when it can, 2-3x zlib's speed at the same levels).  The image ships libdeflate.so.0 without
+// headers, so the handful of entry points is resolved with dlopen and declared here; without the library (or with
+// TBK_NO_LIBDEFLATE set) everything goes through zlib.  Either way the inflated bytes are the same bytes; the deflated stream
+// of a member may differ byte for byte between the two (both are valid deflate of the same payload).
+namespace {
+struct LibDeflate {
+  void* (*alloc_dec)() = nullptr;
+  int (*dec)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
+  void (*free_dec)(void*) = nullptr;
+  void* (*alloc_comp)(int) = nullptr;
+  size_t (*comp)(void*, const void*, size_t, void*, size_t) = nullptr;
+  void (*free_comp)(void*) = nullptr;
+  uint32_t (*crc)(uint32_t, const void*, size_t) = nullptr;
+  bool ok = false;
+  LibDeflate() {
+    if (getenv("TBK_NO_LIBDEFLATE")) return;
+    void* h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return;
+    alloc_dec = (void* (*)())dlsym(h, "libdeflate_alloc_decompressor");
+    dec = (int (*)(void*, const void*, size_t, void*, size_t, size_t*))dlsym(h, "libdeflate_deflate_decompress");
+    free_dec = (void (*)(void*))dlsym(h, "libdeflate_free_decompressor");
+    alloc_comp = (void* (*)(int))dlsym(h, "libdeflate_alloc_compressor");
+    comp = (size_t (*)(void*, const void*, size_t, void*, size_t))dlsym(h, "libdeflate_deflate_compress");
+    free_comp = (void (*)(void*))dlsym(h, "libdeflate_free_compressor");
+    crc = (uint32_t (*)(uint32_t, const void*, size_t))dlsym(h, "libdeflate_crc32");
+    ok = alloc_dec && dec && free_dec && alloc_comp && comp && free_comp && crc;
+  }
+};
+const LibDeflate& ld() {
+  static const LibDeflate L;
+  return L;
+}
+struct TlsCodec {  // one decompressor and one compressor per thread (and level)
+  void* d = nullptr;
+  void* c = nullptr;
+  int c_level = -100;
+  ~TlsCodec() {
+    if (d) ld().free_dec(d);
+    if (c) ld().free_comp(c);
+  }
+};
+thread_local TlsCodec tls;
+}  // namespace
+
+uint32_t bgzf_crc32(const uint8_t* p, size_t n) {
+  if (ld().ok) return ld().crc(0, p, n);
+  return (uint32_t)crc32(crc32(0L, Z_NULL, 0), p, (uInt)n);
+}
+
+// inflate one raw deflate stream that must yield exactly out_n bytes
+static bool inflate_raw(const uint8_t* in, size_t n, uint8_t* out, size_t out_n) {
+  if (ld().ok) {
+    if (!tls.d) tls.d = ld().alloc_dec();
+    size_t got = 0;
+    return tls.d && ld().dec(tls.d, in, n, out, out_n, &got) == 0 && got == out_n;
+  }
+  z_stream zs;
+  memset(&zs, 0, sizeof(zs));
+  if (inflateInit2(&zs, -15) != Z_OK) return false;
+  zs.next_in = const_cast<uint8_t*>(in);
+  zs.avail_in = (uInt)n;
+  zs.next_out = out;
+  zs.avail_out = (uInt)out_n;
+  int rc = inflate(&zs, Z_FINISH);
+  inflateEnd(&zs);
+  return rc == Z_STREAM_END && zs.avail_out == 0;
+}
+// deflate n bytes into out[0, cap): the stream's length, 0 when it does not fit or the codec fails
+static size_t deflate_raw(const uint8_t* src, size_t n, int level, uint8_t* out, size_t cap) {
+  if (ld().ok) {
+    const int lv = level < 0 ? 6 : (level > 12 ? 12 : level);
+    if (!tls.c || tls.c_level != lv) {
+      if (tls.c) ld().free_comp(tls.c);
+      tls.c = ld().alloc_comp(lv);
+      tls.c_level = lv;
+    }
+    return tls.c ? ld().comp(tls.c, src, n, out, cap) : 0;
+  }
+  z_stream zs;
+  memset(&zs, 0, sizeof(zs));
+  if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return 0;
+  zs.next_in = const_cast<uint8_t*>(src);
+  zs.avail_in = (uInt)n;
+  zs.next_out = out;
+  zs.avail_out = (uInt)cap;
+  int rc = deflate(&zs, Z_FINISH);
+  size_t clen = zs.total_out;
+  deflateEnd(&zs);
+  return rc == Z_STREAM_END ? clen : 0;
+}
 
 static const uint8_t kEof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43,
                                  0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -70,6 +164,7 @@ bool bgzf_inflate_chunk(const uint8_t* raw, size_t n, bool at_eof, std::vector<u
     int bsize = -1;
     while (p + 4 <= end) {
       uint16_t slen = rd16(&raw[p + 2]);
+      if (p + 4 + slen > end) break;  // (a subfield that runs past XLEN: the member is rejected below unless BC was found before)
       if (raw[p] == 'B' && raw[p + 1] == 'C' && slen == 2) bsize = rd16(&raw[p + 4]);
       p += 4 + slen;
     }
@@ -103,26 +198,16 @@ bool bgzf_inflate_chunk(const uint8_t* raw, size_t n, bool at_eof, std::vector<u
   std::atomic<size_t> next{0};
   std::atomic<bool> ok{true};
   auto work = [&]() {
-    z_stream zs;
     for (;;) {
-      size_t i = next.fetch_add(1);
+      size_t i = next.fetch_add(8);  // (a few members per claim: the counter is shared by every worker)
       if (i >= mem.size() || !ok.load()) break;
-      const Member& m = mem[i];
-      if (m.isize == 0) continue;
-      memset(&zs, 0, sizeof(zs));
-      if (inflateInit2(&zs, -15) != Z_OK) {
-        ok = false;
-        break;
+      for (size_t j = i; j < i + 8 && j < mem.size(); ++j) {
+        const Member& m = mem[j];
+        if (m.isize == 0) continue;
+        if (!inflate_raw(raw + m.cdata, m.clen, out.data() + m.out_off, m.isize)) ok = false;
+        // the member's CRC32 covers the uncompressed bytes (RFC 1952); htslib rejects a mismatch, so do we
+        else if (bgzf_crc32(out.data() + m.out_off, m.isize) != m.crc) ok = false;
       }
-      zs.next_in = const_cast<uint8_t*>(raw) + m.cdata;
-      zs.avail_in = (uInt)m.clen;
-      zs.next_out = out.data() + m.out_off;
-      zs.avail_out = m.isize;
-      int rc = inflate(&zs, Z_FINISH);
-      inflateEnd(&zs);
-      if (rc != Z_STREAM_END || zs.avail_out != 0) ok = false;
-      // the member's CRC32 covers the uncompressed bytes (RFC 1952); htslib rejects a mismatch, so do we
-      else if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), out.data() + m.out_off, m.isize) != m.crc) ok = false;
     }
   };
   if (threads <= 1 || mem.size() < 8) {
@@ -186,21 +271,12 @@ bool BgzfWriter::open(const std::string& path, int level, int threads) {
 // deflate one <=0xff00-byte block into a complete BGZF member
 static bool deflate_member(const uint8_t* src, size_t n, int level, std::vector<uint8_t>& out) {
   out.resize(0x10000 + 64);
-  z_stream zs;
-  memset(&zs, 0, sizeof(zs));
-  if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
-  zs.next_in = const_cast<uint8_t*>(src);
-  zs.avail_in = (uInt)n;
-  zs.next_out = out.data() + 18;
-  zs.avail_out = (uInt)(out.size() - 18 - 8);
-  int rc = deflate(&zs, Z_FINISH);
-  size_t clen = zs.total_out;
-  deflateEnd(&zs);
-  if (rc != Z_STREAM_END) return false;
+  const size_t clen = deflate_raw(src, n, level, out.data() + 18, out.size() - 18 - 8);
+  if (clen == 0) return false;
   size_t bsize = clen + 25;  // total member length - 1
   const uint8_t hdr[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, (uint8_t)(bsize & 0xff), (uint8_t)(bsize >> 8)};
   memcpy(out.data(), hdr, 18);
-  uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), src, (uInt)n);
+  uint32_t crc = bgzf_crc32(src, n);
   uint32_t isz = (uint32_t)n;
   uint8_t* t = out.data() + 18 + clen;
   for (int k = 0; k < 4; ++k) t[k] = (uint8_t)(crc >> (8 * k));

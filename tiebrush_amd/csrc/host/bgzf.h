@@ -18,6 +18,9 @@ bool bgzf_read_file(const std::string& path, std::vector<uint8_t>& out, std::str
 bool bgzf_inflate_chunk(const uint8_t* raw, size_t n, bool at_eof, std::vector<uint8_t>& out, size_t* consumed, std::string& err,
                         int threads, const std::string& path);
 
+// CRC32 (RFC 1952) of a byte run
+uint32_t bgzf_crc32(const uint8_t* p, size_t n);
+
 // Deflate a byte run into whole BGZF members (<= 0xff00 payload bytes each), appended to `out`.
 bool bgzf_deflate_members(const uint8_t* src, size_t n, int level, std::vector<uint8_t>& out);
 
