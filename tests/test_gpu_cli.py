@@ -184,6 +184,30 @@ def test_cli_tiling_by_reference_is_exact(tmp_path):
     assert rc_[bamio.parse_header(rc_)[1]:] == rd_[bamio.parse_header(rd_)[1]:]
 
 
+def test_cli_decode_paths_give_the_same_record_stream(tmp_path):
+    """the four ways the command line can bring its inputs in — whole-input host loader (default), streaming host reader, tiny
+    streamed tiles, device decode — and the two deflate codecs write the same records byte for byte: plain inputs (tags appended
+    to fresh records) and TieBrush-merged inputs (tags updated in place, stale integer YC and all)"""
+    from tiebrush_amd import bamio
+    cases = {"plain": sample_paths("t2"), "merged": [os.path.join(GOLDEN, "t1", "t1.bam"), os.path.join(GOLDEN, "t2", "t2.bam")] + sample_paths("t1")[:2]}
+    for name, paths in cases.items():
+        streams = {}
+        for tag, env in (("whole", {}), ("stream", dict(TBK_HOST_FAST="0")), ("tiles", dict(TBK_TILE_RECORDS="5000")),
+                         ("device", dict(TBK_DEVICE_DECODE="1")), ("zlib", dict(TBK_NO_LIBDEFLATE="1"))):
+            out = str(tmp_path / ("%s_%s.bam" % (name, tag)))
+            r = subprocess.run([os.path.join(BIN, "tiebrush"), "-o", out] + paths, check=True, capture_output=True, text=True,
+                               env=dict(os.environ, TBK_TIMING="1", **env))
+            if tag == "whole":
+                assert "host path ms" in r.stderr             # the whole-input loader really ran
+            if tag == "device":
+                assert "device decode:" in r.stderr
+            raw = bamio.bgzf_decompress(open(out, "rb").read())
+            streams[tag] = raw[bamio.parse_header(raw)[1]:]
+        assert len(streams["whole"]) > 100000
+        for tag in ("stream", "tiles", "device", "zlib"):
+            assert streams[tag] == streams["whole"], (name, tag)
+
+
 def test_cli_streams_many_inputs_with_few_descriptors_and_small_tiles(tmp_path):
     """The streaming driver (TInputFiles::next_tile): 300 inputs under `ulimit -n 64` (an input's descriptor is only open
     while its window is refilled), tiles of ~2000 records cut at global bundle boundaries — the output equals the oracle's
@@ -280,8 +304,8 @@ def test_tiles_are_not_cut_behind_an_intron_ending_cigar(tmp_path):
         outs.append(open(out, "rb").read())
 
 
-@pytest.mark.parametrize("env", [dict(TBK_DEVICE_DECODE="0", TBK_TILE_RECORDS="3"), dict(TBK_DEVICE_DECODE="0"), dict()],
-                         ids=["host-tiny-tiles", "host-one-tile", "device-decode"])
+@pytest.mark.parametrize("env", [dict(TBK_TILE_RECORDS="3"), dict(TBK_HOST_FAST="0"), dict(), dict(TBK_DEVICE_DECODE="1"), dict(TBK_NO_LIBDEFLATE="1")],
+                         ids=["host-tiny-tiles", "host-streaming-one-tile", "host-whole-input", "device-decode", "whole-input-zlib"])
 def test_real_bam_shapes_through_the_command_line(tmp_path, env):
     """unmapped mates in place, an unplaced tail, an input without records, a CIGAR ending in an intron: every decode path of
     the command line gives the oracle's records, in its order, with its tags"""

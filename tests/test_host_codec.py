@@ -77,6 +77,47 @@ def test_soa_tile_matches_python_decoder(tmp_path, bam_loader):
     assert pg[-1].startswith("@PG\tID:TieBrush.1\tPN:TieBrush\tPP:TieBrush\tVN:test")
 
 
+def test_whole_input_loader_matches_python_decoder(tmp_path, bam_loader):
+    """fastload.cpp (the whole-input path of the tiebrush command line: every member inflated as its own task, records indexed,
+    SoA filled in parallel) against the Python decoder: the tile arrays, the carried tags of TieBrush-merged inputs, the raw
+    records behind tile indices; unplaced reads at the end of an input are left out"""
+    import struct
+    from tiebrush_amd import bamio, soa, synth
+    from helpers import paired_end_like_files, tile_from_records
+    extra = synth.write_bams(tile_from_records(paired_end_like_files()), str(tmp_path / "pe"))   # unmapped mates, unplaced tail, empty input
+    paths = [os.path.join(GOLDEN, "t1", "t1.bam")] + sample_paths("t2")[:2] + extra
+    bams = [bam_loader(p) for p in paths]
+    d = str(tmp_path / "fs")
+    os.makedirs(d)
+    subprocess.run([TOOL, "fastsoa", d] + paths, check=True)
+
+    def rd(name, dt):
+        return np.fromfile(os.path.join(d, name), dtype=dt)
+
+    keep = [np.nonzero(b.tid >= 0)[0] for b in bams]            # (a sorted BAM holds its refID -1 reads at the end)
+    assert all(len(k_) == 0 or k_[-1] == len(k_) - 1 for k_ in keep)
+    fo = np.concatenate([[0], np.cumsum([len(k_) for k_ in keep])]).astype(np.uint32)
+    assert np.array_equal(rd("file_off", np.uint32), fo)
+    assert rd("tbmerged", np.uint8).tolist() == [1, 0, 0] + [0] * len(extra)
+    for name, dt in (("tid", np.int32), ("pos", np.int32), ("flag", np.uint16), ("mapq", np.uint8), ("strand", np.uint8), ("nh", np.int32)):
+        assert np.array_equal(rd(name, dt), np.concatenate([getattr(b, name)[k_] for b, k_ in zip(bams, keep)])), name
+    ncig = np.concatenate([np.diff(b.cig_off.astype(np.int64))[k_] for b, k_ in zip(bams, keep)])
+    assert np.array_equal(rd("cig_off", np.uint32), np.concatenate([[0], np.cumsum(ncig)]).astype(np.uint32))
+    assert np.array_equal(rd("cig", np.uint32), np.concatenate([b.cig[:int(b.cig_off[len(k_)])] for b, k_ in zip(bams, keep)]))
+    n0 = int(fo[1])
+    assert np.array_equal(rd("yc_in", np.float64)[:n0], bams[0].yc[:n0].astype(np.float64))
+    assert np.array_equal(rd("yx_in", np.int64)[:n0], bams[0].yx[:n0]) and np.array_equal(rd("yd_in", np.int64)[:n0], bams[0].yd[:n0])
+    raw = open(os.path.join(d, "probe_records"), "rb").read()
+    p, seen = 0, 0
+    while p < len(raw):
+        g, ln = struct.unpack_from("<II", raw, p)
+        f = int(np.searchsorted(fo, g, side="right")) - 1
+        assert raw[p + 8:p + 8 + ln] == bamio.record_bytes(bams[f], g - int(fo[f]))
+        p += 8 + ln
+        seen += 1
+    assert seen >= 3 * 3
+
+
 @pytest.mark.parametrize("val,typ", [(0, "C"), (254, "C"), (255, "S"), (65534, "S"), (65535, "I"), (-1, "c"), (-129, "s"),
                                      (-40000, "i"), (70000, "I")])
 def test_int_tag_width_rules_on_append(tmp_path, val, typ):
@@ -193,11 +234,12 @@ def test_malformed_input_is_refused_not_read_past(tmp_path, what):
     open(p, "wb").write(bad)
     d = str(tmp_path / "soa")
     os.makedirs(d)
-    r = subprocess.run([TOOL, "soa", d, p], capture_output=True, text=True)
-    assert r.returncode != 0 and r.returncode > 0, (what, r.returncode, r.stderr)   # a clean error exit, not a signal
-    assert r.stderr.strip() != ""
-    ok = subprocess.run([TOOL, "soa", d, good], capture_output=True, text=True)
-    assert ok.returncode == 0
+    for cmd in ("soa", "fastsoa"):                                # the streaming reader and the whole-input loader
+        r = subprocess.run([TOOL, cmd, d, p], capture_output=True, text=True)
+        assert r.returncode != 0 and r.returncode > 0, (what, cmd, r.returncode, r.stderr)   # a clean error exit, not a signal
+        assert r.stderr.strip() != ""
+        ok = subprocess.run([TOOL, cmd, d, good], capture_output=True, text=True)
+        assert ok.returncode == 0
 
 
 def test_streamed_tiles_cut_where_no_read_crosses(tmp_path, bam_loader):

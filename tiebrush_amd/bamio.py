@@ -306,6 +306,13 @@ def record_identity(soa: BamSoA, i: int) -> bytes:
     return raw[o + 4:o + 14] + raw[o + 16:aux]
 
 
+def record_bytes(soa: BamSoA, i: int) -> bytes:
+    """The whole record i (refID .. end of aux, without its block_size field)."""
+    o = int(soa.rec_off[i])
+    bs = struct.unpack_from("<I", soa.raw, o)[0]
+    return bytes(soa.raw[o + 4:o + 4 + bs])
+
+
 def record_aux(soa: BamSoA, i: int):
     """Ordered list of (tag, type_char, python_value) of record i."""
     o = int(soa.rec_off[i])

@@ -63,6 +63,11 @@ uint32_t bgzf_crc32(const uint8_t* p, size_t n) {
 }
 
 // inflate one raw deflate stream that must yield exactly out_n bytes
+static bool inflate_raw(const uint8_t* in, size_t n, uint8_t* out, size_t out_n);
+bool bgzf_inflate_member(const uint8_t* cdata, size_t clen, uint8_t* out, uint32_t isize, uint32_t crc) {
+  if (!inflate_raw(cdata, clen, out, isize)) return false;
+  return bgzf_crc32(out, isize) == crc;  // the member's CRC32 covers the uncompressed bytes (RFC 1952); htslib rejects a mismatch
+}
 static bool inflate_raw(const uint8_t* in, size_t n, uint8_t* out, size_t out_n) {
   if (ld().ok) {
     if (!tls.d) tls.d = ld().alloc_dec();

@@ -18,6 +18,9 @@ bool bgzf_read_file(const std::string& path, std::vector<uint8_t>& out, std::str
 bool bgzf_inflate_chunk(const uint8_t* raw, size_t n, bool at_eof, std::vector<uint8_t>& out, size_t* consumed, std::string& err,
                         int threads, const std::string& path);
 
+// One member's deflate stream (cdata[0, clen)) -> exactly isize bytes at `out`, CRC32 checked against the member's trailer
+bool bgzf_inflate_member(const uint8_t* cdata, size_t clen, uint8_t* out, uint32_t isize, uint32_t crc);
+
 // CRC32 (RFC 1952) of a byte run
 uint32_t bgzf_crc32(const uint8_t* p, size_t n);
 

@@ -16,6 +16,7 @@
 
 #include "GSam.h"
 #include "bgzf.h"
+#include "fastload.h"
 #include "tmerge.h"
 #include "bigwig.h"
 
@@ -98,6 +99,55 @@ int main(int argc, char** argv) {
     FILE* f = fopen((d + "/header.txt").c_str(), "w");
     fputs(in.header()->text.c_str(), f);
     fclose(f);
+    return 0;
+  }
+  if (cmd == "fastsoa" && argc >= 4) {  // fastsoa OUTDIR IN1.bam ...: the tile of the whole-input loader (fastload.cpp), as `soa` dumps it
+    std::vector<std::string> paths;
+    std::vector<uint8_t> tb;
+    for (int i = 3; i < argc; ++i) {
+      paths.push_back(argv[i]);
+      GSamReader rd(argv[i]);
+      tb.push_back(rd.header()->is_tiebrush() ? 1 : 0);
+    }
+    tbh::FastTile t;
+    bool fits = false;
+    std::string err;
+    if (!tbh::fast_load(paths, tb, argc > 3 ? 3 : 1, (size_t)1 << 40, t, &fits, err) || !fits) {
+      fprintf(stderr, "%s\n", err.c_str());
+      return 1;
+    }
+    const std::string d = argv[2];
+    auto dumpp = [&](const char* name, const void* p, size_t bytes) {
+      FILE* f = fopen((d + "/" + name).c_str(), "wb");
+      if (!f) GError("cannot write %s/%s\n", d.c_str(), name);
+      if (bytes) fwrite(p, 1, bytes, f);
+      fclose(f);
+    };
+    dump(d, "file_off", t.file_off);
+    dump(d, "tbmerged", t.tbmerged);
+    dumpp("tid", t.tid, t.n * 4);
+    dumpp("pos", t.pos, t.n * 4);
+    dumpp("flag", t.flag, t.n * 2);
+    dumpp("mapq", t.mapq, t.n);
+    dumpp("strand", t.strand, t.n);
+    dumpp("nh", t.nh, t.n * 4);
+    dumpp("cig_off", t.cig_off, (t.n + 1) * 4);
+    dumpp("cig", t.cig, t.n_cig * 4);
+    dumpp("yc_in", t.yc_in, t.yc_in ? t.n * 8 : 0);
+    dumpp("yx_in", t.yx_in, t.yx_in ? t.n * 8 : 0);
+    dumpp("yd_in", t.yd_in, t.yd_in ? t.n * 8 : 0);
+    // the raw records behind a few tile indices: first, last, and one from the middle of every file
+    std::vector<uint8_t> recs;
+    for (size_t f = 0; f + 1 < t.file_off.size(); ++f)
+      for (uint32_t g : {t.file_off[f], (t.file_off[f] + t.file_off[f + 1]) / 2, t.file_off[f + 1] - 1}) {
+        if (t.file_off[f] == t.file_off[f + 1]) continue;
+        uint32_t len;
+        const uint8_t* p = t.record(g, &len);
+        recs.insert(recs.end(), (const uint8_t*)&g, (const uint8_t*)&g + 4);
+        recs.insert(recs.end(), (const uint8_t*)&len, (const uint8_t*)&len + 4);
+        recs.insert(recs.end(), p, p + len);
+      }
+    dump(d, "probe_records", recs);
     return 0;
   }
   if (cmd == "mkbam" && argc >= 4) {
@@ -268,6 +318,6 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
-  fprintf(stderr, "usage: tbh_tool cat|mergeorder|soa|mkbam|tiles|tags|bedgraph2bw ...\n");
+  fprintf(stderr, "usage: tbh_tool cat|mergeorder|soa|fastsoa|mkbam|tiles|tags|bedgraph2bw ...\n");
   return 2;
 }

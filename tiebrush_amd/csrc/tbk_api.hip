@@ -11,6 +11,11 @@
 // chained for that call and the arena is re-created at the combined size at the start of the next
 // call, so a steady-state loop performs no allocation at all.
 static int ws_begin_call(tbk_ctx* ctx, size_t hint) {
+  if (!ctx->registered.empty()) {  // (left behind by a call that failed half way)
+    (void)hipStreamSynchronize(ctx->stream);
+    for (void* p : ctx->registered) (void)hipHostUnregister(p);
+    ctx->registered.clear();
+  }
   size_t want = std::max(ctx->ws_cap, hint);
   if (ctx->yd_pending) {
     // a deferred YD stage still reads arrays in [0, ws_base_off): never move the arena now; this call bump-allocates
@@ -130,6 +135,11 @@ void tbk_prof_begin_call(tbk_ctx* ctx) {
   ctx->ev_used = 0;
 }
 void tbk_prof_end_call(tbk_ctx* ctx) {
+  if (!ctx->registered.empty()) {  // host ranges page-locked for this call's copies (host_register): the copies have to be done first
+    (void)hipStreamSynchronize(ctx->stream);
+    for (void* p : ctx->registered) (void)hipHostUnregister(p);
+    ctx->registered.clear();
+  }
   ctx->last_times.clear();
   if (!ctx->profiling) return;
   (void)hipStreamSynchronize(ctx->stream);
@@ -150,13 +160,30 @@ void tbk_prof_end_call(tbk_ctx* ctx) {
 }
 
 // ---- staging helpers for TBK_MEM_HOST ---------------------------------------------------------------
+// A large pageable source is registered (page-locked) for the duration of the call: the copy is then one DMA at the link's rate
+// instead of a trip through the runtime's bounce buffers, and nothing of the caller's memory stays pinned behind the call
+// (TBK_NO_REGISTER: test hook, plain copies).  tbk_host_unregister_all releases the registrations once the stream has drained.
+static void host_register(tbk_ctx* ctx, const void* p, size_t bytes) {
+  static const bool off = getenv("TBK_NO_REGISTER") != nullptr;
+  if (off || bytes < ((size_t)16 << 20)) return;
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type != hipMemoryTypeUnregistered) return;  // pinned already (tbk_host_alloc)
+  (void)hipGetLastError();
+  if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess)
+    ctx->registered.push_back(const_cast<void*>(p));
+  else
+    (void)hipGetLastError();
+}
 template <class T>
 static int h2d(tbk_ctx* ctx, const T* src, size_t n, const T** dst) {
   *dst = nullptr;
   if (!src) return 0;
   T* d = ws_alloc<T>(ctx, n ? n : 1);
   if (!d) return TBK_ENOMEM;
-  if (n) TBK_HIP(hipMemcpyAsync(d, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  if (n) {
+    host_register(ctx, src, n * sizeof(T));
+    TBK_HIP(hipMemcpyAsync(d, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  }
   *dst = d;
   return 0;
 }
@@ -172,6 +199,7 @@ static int dalloc(tbk_ctx* ctx, T* host, size_t n, T** dst) {
 template <class T>
 static int d2h(tbk_ctx* ctx, T* host, const T* dev, size_t n) {
   if (!host || !dev || !n) return 0;
+  host_register(ctx, host, n * sizeof(T));
   TBK_HIP(hipMemcpyAsync(host, dev, n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
   return 0;
 }
@@ -307,6 +335,8 @@ void tbk_destroy(tbk_ctx* ctx) {
   }
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (void* p : ctx->registered) (void)hipHostUnregister(p);
+  ctx->registered.clear();
   for (auto& c : ctx->ws_overflow) (void)hipFree(c.first);
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->ws) (void)hipFree(ctx->ws);

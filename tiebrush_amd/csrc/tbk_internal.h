@@ -119,6 +119,7 @@ struct tbk_ctx {
   tbk_ctx* side_ctx = nullptr;
   TbkWorker* side_worker = nullptr;
   bool side_times_pending = false;
+  std::vector<void*> registered; // caller's host ranges page-locked for the copies of the current call (tbk_api.hip: host_register)
   void* bam_dev = nullptr;       // device-decoded BAM input (bamdev.hip): inflated streams + record index + the SoA tile's arrays
 };
 
