@@ -709,45 +709,48 @@ constexpr int YD_NB = 32;  // length buckets (log2)
 
 __device__ __forceinline__ uint32_t yd_bucket(uint32_t len) { return 31u - (uint32_t)__builtin_clz(len | 1u); }
 
-// cnt[b] = chains of bucket b that go to the lane kernel, cnt[YD_NB] = chains that get a wave
+// cnt[b] = chains of length bucket b that go to the lane kernel, cnt[YD_NB + b] = those that get a wave
 __global__ void yd_bucket_count_k(uint32_t nchains, uint32_t nit, uint32_t wave_min, const uint32_t* __restrict__ chain_first,
                                   uint32_t* __restrict__ cnt) {
-  __shared__ uint32_t s_cnt[YD_NB + 1];
-  if (threadIdx.x <= YD_NB) s_cnt[threadIdx.x] = 0;
+  __shared__ uint32_t s_cnt[2 * YD_NB];
+  if (threadIdx.x < 2 * YD_NB) s_cnt[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < nchains) {
     const uint32_t len = ((c + 1 < nchains) ? chain_first[c + 1] : nit) - chain_first[c];
-    atomicAdd(&s_cnt[len >= wave_min ? YD_NB : yd_bucket(len)], 1u);
+    atomicAdd(&s_cnt[(len >= wave_min ? YD_NB : 0) + yd_bucket(len)], 1u);
   }
   __syncthreads();
-  if (threadIdx.x <= YD_NB && s_cnt[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], s_cnt[threadIdx.x]);
+  if (threadIdx.x < 2 * YD_NB && s_cnt[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], s_cnt[threadIdx.x]);
 }
-// cursors: the buckets laid out longest first
+// cursors: the buckets of either kind laid out longest first (a wave that starts a long chain late is the kernel's tail);
+// cur[2 * YD_NB] = the number of chains that get a wave
 __global__ void yd_bucket_off_k(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ cur) {
-  uint32_t o = 0;
-  for (int b = YD_NB - 1; b >= 0; --b) {
-    cur[b] = o;
-    o += cnt[b];
+  for (int kind = 0; kind < 2; ++kind) {
+    uint32_t o = 0;
+    for (int b = YD_NB - 1; b >= 0; --b) {
+      cur[kind * YD_NB + b] = o;
+      o += cnt[kind * YD_NB + b];
+    }
+    if (kind == 1) cur[2 * YD_NB] = o;
   }
-  cur[YD_NB] = 0;
 }
 __global__ void yd_bucket_fill_k(uint32_t nchains, uint32_t nit, uint32_t wave_min, const uint32_t* __restrict__ chain_first, uint32_t* __restrict__ cur,
                                  uint32_t* __restrict__ ids_lane, uint32_t* __restrict__ ids_wave) {
-  __shared__ uint32_t s_cnt[YD_NB + 1], s_base[YD_NB + 1];
-  if (threadIdx.x <= YD_NB) s_cnt[threadIdx.x] = 0;
+  __shared__ uint32_t s_cnt[2 * YD_NB], s_base[2 * YD_NB];
+  if (threadIdx.x < 2 * YD_NB) s_cnt[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t b = 0, slot = 0;
   if (c < nchains) {
     const uint32_t len = ((c + 1 < nchains) ? chain_first[c + 1] : nit) - chain_first[c];
-    b = len >= wave_min ? (uint32_t)YD_NB : yd_bucket(len);
+    b = (len >= wave_min ? (uint32_t)YD_NB : 0u) + yd_bucket(len);
     slot = atomicAdd(&s_cnt[b], 1u);
   }
   __syncthreads();
-  if (threadIdx.x <= YD_NB) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&cur[threadIdx.x], s_cnt[threadIdx.x]) : 0u;
+  if (threadIdx.x < 2 * YD_NB) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&cur[threadIdx.x], s_cnt[threadIdx.x]) : 0u;
   __syncthreads();
-  if (c < nchains) (b == (uint32_t)YD_NB ? ids_wave : ids_lane)[s_base[b] + slot] = c;
+  if (c < nchains) (b >= (uint32_t)YD_NB ? ids_wave : ids_lane)[s_base[b] + slot] = c;
 }
 
 template <int R /* items per lane and refill: the items of R consecutive lanes' worth are one coalesced segment */>
@@ -1376,11 +1379,12 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       uint32_t* ids_lane = ws_alloc<uint32_t>(ctx, nchains);
       uint32_t* ids_long = ws_alloc<uint32_t>(ctx, nchains);
       uint32_t* ids_over = ws_alloc<uint32_t>(ctx, nchains);
-      uint32_t* bcnt = ws_alloc<uint32_t>(ctx, 2 * (YD_NB + 1) + 2);  // bucket counts, cursors, [n_over]
+      uint32_t* bcnt = ws_alloc<uint32_t>(ctx, 4 * YD_NB + 4);  // bucket counts [2 * YD_NB], cursors [2 * YD_NB + 1], [n_over]
       if (!ids_over || !bcnt) return TBK_ENOMEM;
-      uint32_t* bcur = bcnt + (YD_NB + 1);
-      uint32_t* n_over = bcur + (YD_NB + 1);
-      TBK_HIP(hipMemsetAsync(bcnt, 0, (2 * (YD_NB + 1) + 2) * sizeof(uint32_t), ctx->stream));
+      uint32_t* bcur = bcnt + 2 * YD_NB;
+      uint32_t* n_wave = bcur + 2 * YD_NB;
+      uint32_t* n_over = n_wave + 1;
+      TBK_HIP(hipMemsetAsync(bcnt, 0, (4 * YD_NB + 4) * sizeof(uint32_t), ctx->stream));
       TBK_LAUNCH(ctx, "yd_gexons", yd_gexons_k, cdiv(ng, B), B, 0, I, ng, J.gperm, J.G, Q, ex_s, ex_e);
       // chains bucketed by the log2 of their length, longest first: the lanes of a wave of yd_lane_k run chains of like length
       uint32_t wave_min = YD_WAVE_MIN_DEFAULT;  // TBK_YD_WAVE_MIN: test hook (1: every chain to yd_wave_k; huge: every chain to yd_lane_k)
@@ -1389,16 +1393,16 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       TBK_LAUNCH(ctx, "yd_classify", yd_bucket_off_k, 1, 1, 0, bcnt, bcur);
       TBK_LAUNCH(ctx, "yd_classify", yd_bucket_fill_k, cdiv(nchains, B), B, 0, nchains, nit, wave_min, chain_first, bcur, ids_lane, ids_long);
       uint32_t* hc = (uint32_t*)(ctx->h_scalars + 24);
-      TBK_HIP(hipMemcpyAsync(hc, bcnt + YD_NB, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+      TBK_HIP(hipMemcpyAsync(hc, n_wave, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
       TBK_HIP(hipStreamSynchronize(ctx->stream));
       const uint32_t n_long = hc[0], n_lane = nchains - n_long;
       if (getenv("TBK_YD_DEBUG")) {
-        uint32_t hb[YD_NB + 1];
+        uint32_t hb[2 * YD_NB];
         TBK_HIP(hipMemcpy(hb, bcnt, sizeof(hb), hipMemcpyDeviceToHost));
         fprintf(stderr, "yd: %u groups, %u items, %u chains (%u by lane, %u by wave), %llu nodes; chains by log2(length):", ng, nit, nchains, n_lane,
                 n_long, (unsigned long long)nnodes);
-        for (int b = 0; b <= YD_NB; ++b)
-          if (hb[b]) fprintf(stderr, " %d:%u", b, hb[b]);
+        for (int b = 0; b < 2 * YD_NB; ++b)
+          if (hb[b]) fprintf(stderr, " %s%d:%u", b >= YD_NB ? "w" : "", b % YD_NB, hb[b]);
         fprintf(stderr, "\n");
       }
       // lane chains and wave chains are independent: the few long, latency-bound waves go to the auxiliary stream beside the lane
@@ -1407,7 +1411,7 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       if (n_long) {
         hipStream_t keep = ctx->stream;
         if (aux) ctx->stream = aux;
-        TBK_LAUNCH(ctx, "yd_wave", yd_wave_k, n_long, 64, 0, ids_long, bcnt + YD_NB, nchains, nit, chain_first, Y, iv, noff, ex_s, ex_e, J.g_yd,
+        TBK_LAUNCH(ctx, "yd_wave", yd_wave_k, n_long, 64, 0, ids_long, n_wave, nchains, nit, chain_first, Y, iv, noff, ex_s, ex_e, J.g_yd,
                    ids_over, n_over);
         ctx->stream = keep;
         if (aux) TBK_HIP(hipEventRecord(ctx->aux_done, aux));
