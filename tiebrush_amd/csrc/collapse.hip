@@ -433,7 +433,6 @@ __global__ void col_recgroup_w_k(uint32_t n, const uint32_t* __restrict__ rec_sg
 struct YdItems {
   uint4* pk;      // (tid + 1, start, end, offset of the item's exon list in the per-group exon arrays): written with one store
   uint32_t* nex;  // exon count (contiguous: the input of the node-offset scan)
-  uint32_t* chead;
   __device__ __forceinline__ uint32_t tidp1(uint32_t t) const { return reinterpret_cast<const uint32_t*>(pk)[4 * (size_t)t]; }
   __device__ __forceinline__ int32_t start(uint32_t t) const { return (int32_t) reinterpret_cast<const uint32_t*>(pk)[4 * (size_t)t + 1]; }
   __device__ __forceinline__ int32_t end(uint32_t t) const { return (int32_t) reinterpret_cast<const uint32_t*>(pk)[4 * (size_t)t + 2]; }
@@ -520,14 +519,6 @@ struct YdLoad {
     return s;
   }
 };
-struct YdStore {
-  YdLoad L;
-  __device__ __forceinline__ void operator()(uint32_t t, const SegMaxY& v, const SegMaxY&, const SegMaxY& ex) const {
-    // renewal: the read starts beyond every earlier end of this list => every node is cleared (processRead :230-241)
-    L.Y.chead[t] = (v.flag || L.Y.start(t) > ex.mx) ? 1u : 0u;
-  }
-};
-
 // chain heads and exon counts summed together; a head's exclusive sums are its chain's number and the first node of its arena
 struct HeadNex {
   uint32_t h, n;
@@ -535,22 +526,27 @@ struct HeadNex {
 struct HeadNexOp {
   __device__ __forceinline__ HeadNex operator()(const HeadNex& a, const HeadNex& b) const { return HeadNex{a.h + b.h, a.n + b.n}; }
 };
-struct HeadNexLoad {
-  const uint32_t *chead, *nex;
-  __device__ __forceinline__ HeadNex operator()(uint32_t t) const { return HeadNex{chead[t], nex[t]}; }
+struct YdHead {
+  YdLoad L;
+  __device__ __forceinline__ HeadNex operator()(uint32_t t, const SegMaxY& v, const SegMaxY&, const SegMaxY& ex) const {
+    // renewal: the read starts beyond every earlier end of this list => every node is cleared (processRead :230-241)
+    return HeadNex{(v.flag || L.Y.start(t) > ex.mx) ? 1u : 0u, L.Y.nex[t]};
+  }
 };
-struct HeadNexStore {
+// chains numbered in item order, each with its first item and the first node of its arena
+struct YdStore {
+  YdItems Y;
   uint32_t *chain_first, *chain_noff;
   uint64_t* totals;  // [0] chains, [1] nodes
   uint32_t nit;
-  __device__ __forceinline__ void operator()(uint32_t t, const HeadNex& v, const HeadNex& inc, const HeadNex& ex) const {
+  __device__ __forceinline__ void operator()(uint32_t t, const SegMaxY&, const SegMaxY&, const SegMaxY&, const HeadNex& v, const HeadNex& ex) const {
     if (v.h) {
       chain_first[ex.h] = t;
       chain_noff[ex.h] = ex.n;
     }
     if (t + 1 == nit) {
-      totals[0] = inc.h;
-      totals[1] = inc.n;
+      totals[0] = ex.h + v.h;
+      totals[1] = ex.n + v.n;
     }
   }
 };
@@ -1328,7 +1324,6 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       YdItems Y;
       Y.pk = ws_alloc<uint4>(ctx, nit);
       Y.nex = ws_alloc<uint32_t>(ctx, nit);
-      Y.chead = ws_alloc<uint32_t>(ctx, nit);
       uint32_t* noff = ws_alloc<uint32_t>(ctx, nit);
       uint32_t* chain_first = ws_alloc<uint32_t>(ctx, nit);
       if (!chain_first) return TBK_ENOMEM;
@@ -1355,15 +1350,12 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
         TBK_TRY(tbk_radix_sort_w64_emit(ctx, &iv, &iv2, nit, ((1ull << bits) - 1ull) << 32, true, YdEmit{Q, Y}, "yd_scatter"));
       }
       {
-        YdLoad ld{iv, Y};
-        YdStore st{ld};
+        YdLoad ld{iv, Y};  // chain heads (segmented running maximum of the ends) and their numbering, one pass
+        YdHead hd{ld};
+        YdStore st{Y, chain_first, noff, sc + 3, nit};
         SegMaxY ident{INT32_MIN, 0u};
-        TBK_TRY((scan_op_run<SegMaxY, SegMaxYOp, YdLoad, YdStore>(ctx, "yd_chain_scan", nit, ld, st, SegMaxYOp{}, ident, true)));
-      }
-      {  // chains numbered in item order, each with its first item and the first node of its arena
-        HeadNexLoad ld{Y.chead, Y.nex};
-        HeadNexStore st{chain_first, noff, sc + 3, nit};
-        TBK_TRY((scan_op_run<HeadNex, HeadNexOp, HeadNexLoad, HeadNexStore>(ctx, "yd_chain_number", nit, ld, st, HeadNexOp{}, HeadNex{0u, 0u})));
+        TBK_TRY((scan_two_run<SegMaxY, SegMaxYOp, HeadNex, HeadNexOp, YdLoad, YdHead, YdStore>(ctx, "yd_chains", nit, ld, hd, st, SegMaxYOp{}, ident,
+                                                                                              HeadNexOp{}, HeadNex{0u, 0u})));
       }
       TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
       TBK_HIP(hipStreamSynchronize(ctx->stream));

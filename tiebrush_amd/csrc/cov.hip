@@ -50,7 +50,6 @@ struct CovArrays {
   int32_t* end;      // 1-based inclusive
   int32_t* tid;
   uint32_t* bhead;   // bundle head flag
-  int32_t* inclmax;  // inclusive running max of end inside the tid run
   uint32_t* bid;     // bundle id
   uint64_t* cs;      // compacted start (0-based cpos)
   uint16_t* pk;      // tile kernel input: compacted start inside its home tile (13 bits) | bundle head << 15
@@ -143,33 +142,36 @@ struct BundleLoad {
     return s;
   }
 };
-struct BundleStore {
+struct BundleHead {
   const int32_t* tid;
   const int32_t* start;
-  uint32_t* bhead;
-  int32_t* inclmax;
+  __device__ __forceinline__ uint32_t operator()(uint32_t j, const SegMax&, const SegMax&, const SegMax& ex) const {
+    return (j == 0 || tid[j] != tid[j - 1] || start[j] > ex.mx) ? 1u : 0u;  // tiecov.cpp:443
+  }
+};
+// One pass gives every record its bundle (scan_two_run numbers the heads) and every bundle its reference sequence, start and
+// end: a record closes its bundle when the next one is a head, which its own inclusive maximum already decides.
+struct BundleStore {
+  CovArrays A;
+  uint32_t m;
+  uint64_t* nb_out;
   uint32_t* err;
-  __device__ __forceinline__ void operator()(uint32_t j, const SegMax&, const SegMax& inc, const SegMax& ex) const {
-    bool run_head = (j == 0 || tid[j] != tid[j - 1]);
-    bool head = run_head || start[j] > ex.mx;  // tiecov.cpp:443
-    if (!run_head && start[j] < start[j - 1]) atomicOr(err, TBK_DERR_UNSORTED);
-    bhead[j] = head ? 1u : 0u;
-    inclmax[j] = inc.mx;
+  __device__ __forceinline__ void operator()(uint32_t j, const SegMax&, const SegMax& inc, const SegMax&, uint32_t head, uint32_t before) const {
+    const int32_t t = A.tid[j], st = A.start[j];
+    if (j != 0 && A.tid[j - 1] == t && st < A.start[j - 1]) atomicOr(err, TBK_DERR_UNSORTED);
+    const uint32_t b = before + head - 1u;
+    A.bhead[j] = head;
+    A.bid[j] = b;
+    if (head) {
+      A.b_tid[b] = t;
+      A.b_start[b] = st;
+    }
+    const bool last = j + 1 == m;
+    if (last || A.tid[j + 1] != t || A.start[j + 1] > inc.mx) A.b_end[b] = inc.mx;
+    if (last) *nb_out = (uint64_t)b + 1u;
   }
 };
 
-__global__ void cov_bundle_fill_k(uint32_t m, CovArrays A) {
-  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= m) return;
-  // bid arrives as the EXCLUSIVE scan of the head flags: turn it into the bundle index
-  uint32_t b = A.bid[j] + A.bhead[j] - 1u;
-  A.bid[j] = b;
-  if (A.bhead[j]) {
-    A.b_tid[b] = A.tid[j];
-    A.b_start[b] = A.start[j];
-  }
-  if (j + 1 == m || A.bhead[j + 1]) A.b_end[b] = A.inclmax[j];
-}
 __global__ void cov_bundle_span_k(uint32_t nb, CovArrays A) {
   uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < nb) A.b_span[b] = (uint32_t)(A.b_end[b] - A.b_start[b] + 1);
@@ -679,6 +681,106 @@ __global__ void junc_fill_k(uint32_t m, CovArrays A, const int32_t* __restrict__
              &nex);
 }
 
+// Integral YC: the junction items of a block of consecutive records (reads of one locus repeat the same few introns) are summed
+// in an LDS table first, and only one item per distinct junction and block — with its partial sum — goes on to the sort: on
+// config 3 some 6 M items become a few hundred thousand.  The table's claim word holds the junction exactly (start relative to
+// the block's first record : 24 | length : 31 | strand code : 2 | 1); an item that does not fit that form (another reference
+// sequence than the block's first record, a start 2^24 bases on) or finds the table full travels on its own.  Sums are integers
+// (the caller has checked every YC is integral and the total below 2^52), so the order of the additions is free.
+constexpr uint32_t JA_REC = 1024;   // records per block (4 per thread)
+constexpr uint32_t JA_SLOTS = 1024;
+__global__ __launch_bounds__(256) void junc_agg_k(uint32_t m, CovArrays A, const int32_t* __restrict__ tid, const int32_t* __restrict__ pos,
+                                                  const uint32_t* __restrict__ cig_off, const uint32_t* __restrict__ cig,
+                                                  const uint8_t* __restrict__ strand, const double* __restrict__ yc, const uint32_t* __restrict__ jcnt,
+                                                  uint64_t* __restrict__ hi, uint64_t* __restrict__ lo, double* __restrict__ pv,
+                                                  unsigned long long* __restrict__ n_out) {
+  __shared__ unsigned long long claim[JA_SLOTS];
+  __shared__ unsigned long long sum[JA_SLOTS];
+  const uint32_t j0 = blockIdx.x * JA_REC;
+  for (uint32_t q = threadIdx.x; q < JA_SLOTS; q += 256) {
+    claim[q] = ~0ull;
+    sum[q] = 0;
+  }
+  const uint32_t i0 = A.ridx[j0];
+  const int32_t tid0 = tid[i0], start0 = pos[i0];
+  __syncthreads();
+  auto emit = [&](uint64_t h, uint64_t l, double v) {  // an item on its own
+    const unsigned long long at = atomicAdd(n_out, 1ull);
+    hi[at] = h;
+    lo[at] = l;
+    pv[at] = v;
+  };
+  for (uint32_t r = 0; r < JA_REC / 256; ++r) {
+    const uint32_t j = j0 + r * 256 + threadIdx.x;
+    if (j >= m) continue;
+    if (!jcnt[j]) continue;
+    const uint32_t i = A.ridx[j];
+    const uint32_t nc = cig_off[i + 1] - cig_off[i];
+    const uint64_t t = (uint64_t)(uint32_t)tid[i] << 32;
+    const uint32_t st = strand ? strand[i] : (uint32_t)'.';
+    const uint32_t sc = st == '+' ? 0u : (st == '-' ? 1u : (st == '.' ? 2u : 3u));
+    const long long y = yc ? (long long)yc[i] : 1ll;
+    const bool same_ref = tid[i] == tid0;
+    int prev_end = 0, k = 0, nex = 0;
+    walk_exons(pos[i], cig + cig_off[i], nc,
+               [&](int es, int ee) {
+                 if (k > 0) {  // CJunc(exons[i-1].end+1, exons[i].start-1, strand) tiecov.cpp:104
+                   const uint32_t js = (uint32_t)(prev_end + 1), len = (uint32_t)(es - 1 - prev_end);
+                   const uint64_t rel = (uint64_t)((int64_t)js - (int64_t)start0);
+                   bool done = false;
+                   if (same_ref && rel < (1ull << 24) && len < (1u << 31) && sc < 3u) {
+                     const unsigned long long key = (rel << 34) | ((unsigned long long)len << 3) | (sc << 1) | 1ull;
+                     uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 54);  // 10 bits
+                     for (uint32_t probe = 0; probe < 32 && !done; ++probe) {
+                       unsigned long long cur = *(volatile unsigned long long*)&claim[h];
+                       if (cur == ~0ull) {
+                         cur = atomicCAS(&claim[h], ~0ull, key);  // (the word found there if another lane was first)
+                         if (cur == ~0ull) cur = key;
+                       }
+                       if (cur == key) {
+                         atomicAdd(&sum[h], (unsigned long long)y);
+                         done = true;
+                       }
+                       h = (h + 1) & (JA_SLOTS - 1);
+                     }
+                   }
+                   if (!done) emit(t | js, ((uint64_t)len << 8) | st, (double)y);
+                 }
+                 prev_end = ee;
+                 ++k;
+               },
+               &nex);
+  }
+  __syncthreads();
+  // flush: one reservation per block
+  uint32_t mine = 0;
+  for (uint32_t q = threadIdx.x; q < JA_SLOTS; q += 256) mine += claim[q] != ~0ull ? 1u : 0u;
+  __shared__ uint32_t s_cnt[4];
+  const uint32_t inc = wave_incl_sum(mine);
+  if (lane_id() == 63) s_cnt[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  uint32_t before = inc - mine;
+  for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += s_cnt[w];
+  __shared__ unsigned long long s_at;
+  if (threadIdx.x == 255) s_at = (before + mine) ? atomicAdd(n_out, (unsigned long long)(before + mine)) : 0ull;
+  __syncthreads();
+  unsigned long long at = s_at + before;
+  for (uint32_t q = threadIdx.x; q < JA_SLOTS; q += 256) {
+    const unsigned long long key = claim[q];
+    if (key == ~0ull) continue;
+    const uint32_t js = (uint32_t)((int64_t)start0 + (int64_t)(key >> 34));
+    const uint32_t len = (uint32_t)((key >> 3) & 0x7FFFFFFFull), sc = (uint32_t)((key >> 1) & 3ull);
+    hi[at] = ((uint64_t)(uint32_t)tid0 << 32) | js;
+    lo[at] = ((uint64_t)len << 8) | (sc == 0 ? (uint32_t)'+' : (sc == 1 ? (uint32_t)'-' : (uint32_t)'.'));
+    pv[at] = (double)(long long)sum[q];
+    ++at;
+  }
+}
+__global__ void junc_iota_k(uint32_t n, uint32_t* __restrict__ v) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n) v[q] = q;
+}
+
 __global__ void junc_head_k(uint32_t nj, const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo, uint32_t* __restrict__ head) {
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nj) return;
@@ -728,6 +830,7 @@ __global__ void junc_head_write_k(uint32_t nj, const uint64_t* __restrict__ hi, 
   j_strand[o] = (uint8_t)(lo[q] & 0xFFu);
   j_val[o] = 0.0;
 }
+template <bool PARTIAL /* val indexes partial sums (junc_agg_k) instead of records */>
 __global__ void junc_sum_k(uint32_t nj, CovArrays A, const uint32_t* __restrict__ val, const uint32_t* __restrict__ head,
                            const uint32_t* __restrict__ hoff, const double* __restrict__ yc, uint32_t cap, double* __restrict__ j_val) {
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -736,7 +839,7 @@ __global__ void junc_sum_k(uint32_t nj, CovArrays A, const uint32_t* __restrict_
   double v = 0.0;
   if (act) {
     o = hoff[q] + head[q] - 1u;
-    v = yc ? yc[A.ridx[val[q]]] : 1.0;
+    v = PARTIAL ? yc[val[q]] : (yc ? yc[A.ridx[val[q]]] : 1.0);
   }
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {  // inclusive segmented sum over lanes holding the same junction
@@ -792,15 +895,32 @@ static int junc_branch(tbk_ctx* ctx, uint32_t m, const CovArrays& A, const tbk_c
   uint32_t* head = ws_alloc<uint32_t>(ctx, nj);
   uint32_t* hoff = ws_alloc<uint32_t>(ctx, nj);
   if (!hoff) return TBK_ENOMEM;
-  TBK_LAUNCH(ctx, "junc_fill", junc_fill_k, cdiv(m, B), B, 0, m, A, in->tid, in->pos, in->cig_off, in->cig, in->strand, joff, sb.hi,
-             sb.lo, sb.val);
-  TBK_TRY(tbk_radix_sort128(ctx, &sb, nj));
-  TBK_LAUNCH(ctx, "junc_head", junc_head_k, cdiv(nj, B), B, 0, nj, sb.hi, sb.lo, head);
-  TBK_TRY(tbk_exscan_u32(ctx, head, hoff, nj, sc + 9));
+  uint32_t ns = nj;   // items that reach the sort
+  double* pv = nullptr;
+  const bool agg = integral && !getenv("TBK_NO_JUNC_AGG");
+  if (agg) {  // block-level sums first: one item per distinct junction and block of records
+    pv = ws_alloc<double>(ctx, nj);
+    if (!pv) return TBK_ENOMEM;
+    TBK_HIP(hipMemsetAsync(sc + 11, 0, sizeof(uint64_t), ctx->stream));
+    TBK_LAUNCH(ctx, "junc_agg", junc_agg_k, cdiv(m, JA_REC), 256, 0, m, A, in->tid, in->pos, in->cig_off, in->cig, in->strand, in->yc, jcnt, sb.hi, sb.lo,
+               pv, (unsigned long long*)(sc + 11));
+    TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 11, sc + 11, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    TBK_HIP(hipStreamSynchronize(ctx->stream));
+    ns = (uint32_t)ctx->h_scalars[11];
+    TBK_LAUNCH(ctx, "junc_iota", junc_iota_k, cdiv(ns, B), B, 0, ns, sb.val);
+  } else {
+    TBK_LAUNCH(ctx, "junc_fill", junc_fill_k, cdiv(m, B), B, 0, m, A, in->tid, in->pos, in->cig_off, in->cig, in->strand, joff, sb.hi, sb.lo, sb.val);
+  }
+  TBK_TRY(tbk_radix_sort128(ctx, &sb, ns));
+  TBK_LAUNCH(ctx, "junc_head", junc_head_k, cdiv(ns, B), B, 0, ns, sb.hi, sb.lo, head);
+  TBK_TRY(tbk_exscan_u32(ctx, head, hoff, ns, sc + 9));
   if (integral) {
-    TBK_LAUNCH(ctx, "junc_head_write", junc_head_write_k, cdiv(nj, B), B, 0, nj, sb.hi, sb.lo, head, hoff, out->cap_junctions, out->j_tid,
+    TBK_LAUNCH(ctx, "junc_head_write", junc_head_write_k, cdiv(ns, B), B, 0, ns, sb.hi, sb.lo, head, hoff, out->cap_junctions, out->j_tid,
                out->j_start, out->j_end, out->j_strand, out->j_val);
-    TBK_LAUNCH(ctx, "junc_sum", junc_sum_k, cdiv(nj, B), B, 0, nj, A, sb.val, head, hoff, in->yc, out->cap_junctions, out->j_val);
+    if (agg)
+      TBK_LAUNCH(ctx, "junc_sum", junc_sum_k<true>, cdiv(ns, B), B, 0, ns, A, sb.val, head, hoff, pv, out->cap_junctions, out->j_val);
+    else
+      TBK_LAUNCH(ctx, "junc_sum", junc_sum_k<false>, cdiv(ns, B), B, 0, ns, A, sb.val, head, hoff, in->yc, out->cap_junctions, out->j_val);
   } else {
     TBK_LAUNCH(ctx, "junc_write", junc_write_k, cdiv(nj, B), B, 0, nj, A, sb.hi, sb.lo, sb.val, head, hoff, in->yc, out->cap_junctions,
                out->j_tid, out->j_start, out->j_end, out->j_strand, out->j_val);
@@ -844,7 +964,6 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
   A.end = ws_alloc<int32_t>(ctx, n);
   A.tid = ws_alloc<int32_t>(ctx, n);
   A.bhead = ws_alloc<uint32_t>(ctx, n);
-  A.inclmax = ws_alloc<int32_t>(ctx, n);
   A.bid = ws_alloc<uint32_t>(ctx, n);
   A.cs = ws_alloc<uint64_t>(ctx, n);
   A.pk = ws_alloc<uint16_t>(ctx, n);
@@ -866,7 +985,7 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
     TBK_LAUNCH(ctx, "cov_valid", cov_valid_k, cdiv(n, B), B, 0, in->flag, n, valid);
     TBK_TRY(tbk_exscan_u32(ctx, valid, vpos, n, sc + 2));
   }
-  TBK_LAUNCH(ctx, "cov_prep", cov_prep_k, (cdiv(n, B) < 1024u ? cdiv(n, B) : 1024u), B, 0, n, all_valid ? (const uint32_t*)nullptr : valid, vpos, in->tid, in->pos, in->cig_off, in->cig,
+  TBK_LAUNCH(ctx, "cov_prep", cov_prep_k, (cdiv(n, B) < 4096u ? cdiv(n, B) : 4096u), B, 0, n, all_valid ? (const uint32_t*)nullptr : valid, vpos, in->tid, in->pos, in->cig_off, in->cig,
              sample_mode ? (const double*)nullptr : in->yc, want_cov ? 1 : 0, A, jcnt, sc, ctx->d_err);
   uint32_t eb = 0;
   TBK_TRY(tbk_sync_err(ctx, &eb));
@@ -897,12 +1016,12 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
   // bundles
   {
     BundleLoad ld{A.tid, A.end};
-    BundleStore st{A.tid, A.start, A.bhead, A.inclmax, ctx->d_err};
+    BundleHead hd{A.tid, A.start};
+    BundleStore st{A, m, sc + 3, ctx->d_err};
     SegMax ident{INT32_MIN, 0u};
-    TBK_TRY((scan_op_run<SegMax, SegMaxOp, BundleLoad, BundleStore>(ctx, "cov_bundle_scan", m, ld, st, SegMaxOp{}, ident)));
+    TBK_TRY((scan_two_run<SegMax, SegMaxOp, uint32_t, SoPlusU32, BundleLoad, BundleHead, BundleStore>(ctx, "cov_bundles", m, ld, hd, st, SegMaxOp{}, ident,
+                                                                                                        SoPlusU32{}, 0u)));
   }
-  TBK_TRY(tbk_exscan_u32(ctx, A.bhead, A.bid, m, sc + 3));
-  TBK_LAUNCH(ctx, "cov_bundle_fill", cov_bundle_fill_k, cdiv(m, B), B, 0, m, A);
   TBK_TRY(tbk_sync_err(ctx, &eb));
   if (eb) return tbk_derr_to_status(ctx, eb);
   const uint32_t nb = (uint32_t)ctx->h_scalars[3];

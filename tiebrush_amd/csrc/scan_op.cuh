@@ -223,6 +223,55 @@ __device__ __forceinline__ bool so_peek(const unsigned long long* g, uint32_t ti
   *v = __builtin_bit_cast(T, a);
   return ok;
 }
+// Wave 0 of a tile: publish the tile's aggregate, fold the predecessors' published values (older tiles first) into the
+// exclusive prefix, publish the inclusive prefix.  Every lane returns the exclusive prefix.
+template <class T, class Op>
+__device__ __forceinline__ T so_lookback(const SoLookback& S, uint32_t tix, const T& tot, Op op, T ident) {
+  const uint32_t lane = lane_id();
+  if (lane == 0) {
+    so_publish<T>(S.agg, tix, tot);
+    if (tix == 0) so_publish<T>(S.inc, 0u, tot);
+  }
+  T excl = ident;
+  bool failed = false;
+  int64_t j = (int64_t)tix - 1;
+  while (j >= 0 && !failed) {
+    const int64_t jj = j - (int64_t)lane;
+    const bool have = jj >= 0;
+    T val = ident;
+    bool is_inc = false, ok = !have;
+    unsigned long long t_spin = 0;
+    for (uint32_t spins = 0;; ++spins) {
+      if (have && !ok) {
+        is_inc = so_peek<T>(S.inc, (uint32_t)jj, &val);
+        ok = is_inc || so_peek<T>(S.agg, (uint32_t)jj, &val);
+      }
+      if (__all(ok)) break;
+      if ((spins & 1023u) == 1023u) {  // (the clock is read once per thousand polls)
+        const unsigned long long now = wall_clock64();
+        if (t_spin == 0) t_spin = now;
+        if (now - t_spin > SO_SPIN_TICKS) {  // something is wrong — never hang
+          failed = true;
+          break;
+        }
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (failed) break;
+    const uint64_t im = __ballot(have && is_inc);
+    const int first = im ? (int)__builtin_ctzll(im) : -1;                       // nearest tile with an inclusive prefix
+    const uint64_t hm = __ballot(have);
+    const int top = first >= 0 ? first : 63 - (int)__builtin_clzll(hm);          // farthest lane that takes part
+    T part = ident;
+    for (int l = top; l >= 0; --l) part = op(part, shfl_idx_t(val, l));           // older tiles first
+    excl = op(part, excl);
+    if (first >= 0) break;
+    j -= 64;
+  }
+  if (failed && lane == 0) atomicOr(S.err, TBK_DERR_INTERNAL);
+  if (lane == 0 && tix > 0) so_publish<T>(S.inc, tix, op(excl, tot));
+  return excl;
+}
 template <class T, class Op, class Load, class Store>
 __global__ __launch_bounds__(SO_NT) void so_single_k(uint32_t n, Load load, Store store, Op op, T ident, SoLookback S) {
   __shared__ T tile[SO_LDS];
@@ -255,52 +304,8 @@ __global__ __launch_bounds__(SO_NT) void so_single_k(uint32_t n, Load load, Stor
   T prev = shfl_up_t(inc, 1);
   if (lane_id() == 63) wl[threadIdx.x >> 6] = inc;
   if (threadIdx.x < 64) {  // wave 0: publish, look back, publish
-    const uint32_t lane = lane_id();
-    if (lane == 0) {
-      so_publish<T>(S.agg, tix, tot);
-      if (tix == 0) so_publish<T>(S.inc, 0u, tot);
-    }
-    T excl = ident;
-    bool failed = false;
-    int64_t j = (int64_t)tix - 1;
-    while (j >= 0 && !failed) {
-      const int64_t jj = j - (int64_t)lane;
-      const bool have = jj >= 0;
-      T val = ident;
-      bool is_inc = false, ok = !have;
-      unsigned long long t_spin = 0;
-      for (uint32_t spins = 0;; ++spins) {
-        if (have && !ok) {
-          is_inc = so_peek<T>(S.inc, (uint32_t)jj, &val);
-          ok = is_inc || so_peek<T>(S.agg, (uint32_t)jj, &val);
-        }
-        if (__all(ok)) break;
-        if ((spins & 1023u) == 1023u) {  // (the clock is read once per thousand polls)
-          const unsigned long long now = wall_clock64();
-          if (t_spin == 0) t_spin = now;
-          if (now - t_spin > SO_SPIN_TICKS) {  // something is wrong — never hang
-            failed = true;
-            break;
-          }
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-      if (failed) break;
-      const uint64_t im = __ballot(have && is_inc);
-      const int first = im ? (int)__builtin_ctzll(im) : -1;                       // nearest tile with an inclusive prefix
-      const uint64_t hm = __ballot(have);
-      const int top = first >= 0 ? first : 63 - (int)__builtin_clzll(hm);          // farthest lane that takes part
-      T part = ident;
-      for (int l = top; l >= 0; --l) part = op(part, shfl_idx_t(val, l));           // older tiles first
-      excl = op(part, excl);
-      if (first >= 0) break;
-      j -= 64;
-    }
-    if (failed && lane == 0) atomicOr(S.err, TBK_DERR_INTERNAL);
-    if (lane == 0) {
-      if (tix > 0) so_publish<T>(S.inc, tix, op(excl, tot));
-      s_carry = excl;
-    }
+    const T excl = so_lookback<T, Op>(S, tix, tot, op, ident);
+    if (lane_id() == 0) s_carry = excl;
   }
   __syncthreads();
   const T carry = s_carry;
@@ -326,6 +331,145 @@ __global__ __launch_bounds__(SO_NT) void so_single_k(uint32_t n, Load load, Stor
       store((uint32_t)i, mine[e], op(exj, mine[e]), exj);
     }
   }
+}
+
+// ---- two scans in one pass ------------------------------------------------------------------------------------------------
+// Bundles (tiecov) and YD chains share a shape: an element is a head when it compares in some way with the exclusive prefix of
+// a first scan, and every element then needs a sum over the heads before it (their number; for YD also their exon counts).
+// Here a tile looks back twice: once for the prefix of the caller's operator, and — after second(i, element, inclusive,
+// exclusive) has produced each element's term of the second scan — once more for the second prefix of the tiles before it.
+// store(i, element, inclusive, exclusive, term, terms_before).
+struct SoPlusU32 {
+  __device__ __forceinline__ uint32_t operator()(uint32_t a, uint32_t b) const { return a + b; }
+};
+template <class T, class Op, class T2, class Op2, class Load, class Second, class Store>
+__global__ __launch_bounds__(SO_NT) void so_two_k(uint32_t n, Load load, Second second, Store store, Op op, T ident, Op2 op2, T2 ident2, SoLookback S,
+                                                  SoLookback S2) {
+  __shared__ T tile[SO_LDS];
+  __shared__ T2 tile2[SO_LDS];
+  __shared__ T sm[SO_NT / 64];
+  __shared__ T wl[SO_NT / 64];
+  __shared__ T2 sm2[SO_NT / 64];
+  __shared__ T2 wl2[SO_NT / 64];
+  __shared__ T s_carry;
+  __shared__ T2 s_carry2;
+  __shared__ uint32_t s_tile;
+  if (threadIdx.x == 0) s_tile = atomicAdd(S.ticket, 1u);
+  __syncthreads();
+  const uint32_t tix = s_tile;
+  const uint64_t base = (uint64_t)tix * SO_TILE;
+  T mine[SO_E];
+#pragma unroll
+  for (int e = 0; e < SO_E; ++e) {
+    uint32_t j = (uint32_t)e * SO_NT + threadIdx.x;
+    uint64_t i = base + j;
+    mine[e] = (i < n) ? load((uint32_t)i) : ident;
+    tile[so_pad(j)] = mine[e];
+  }
+  __syncthreads();
+  {
+    T v[SO_E];
+    T acc = ident;
+#pragma unroll
+    for (int e = 0; e < SO_E; ++e) {
+      v[e] = tile[so_pad(threadIdx.x * SO_E + e)];
+      acc = op(acc, v[e]);
+    }
+    T tot;
+    T inc = block_incl_scan_op(acc, op, sm, &tot);
+    T prev = shfl_up_t(inc, 1);
+    if (lane_id() == 63) wl[threadIdx.x >> 6] = inc;
+    if (threadIdx.x < 64) {
+      const T excl = so_lookback<T, Op>(S, tix, tot, op, ident);
+      if (lane_id() == 0) s_carry = excl;
+    }
+    __syncthreads();
+    const T carry = s_carry;
+    T ex;
+    if (threadIdx.x == 0)
+      ex = carry;
+    else if (lane_id() == 0)
+      ex = op(carry, wl[(threadIdx.x >> 6) - 1]);
+    else
+      ex = op(carry, prev);
+#pragma unroll
+    for (int e = 0; e < SO_E; ++e) {
+      tile[so_pad(threadIdx.x * SO_E + e)] = ex;
+      ex = op(ex, v[e]);
+    }
+  }
+  __syncthreads();
+  T2 mine2[SO_E];
+#pragma unroll
+  for (int e = 0; e < SO_E; ++e) {
+    uint32_t j = (uint32_t)e * SO_NT + threadIdx.x;
+    uint64_t i = base + j;
+    mine2[e] = ident2;
+    if (i < n) {
+      const T exj = tile[so_pad(j)];
+      mine2[e] = second((uint32_t)i, mine[e], op(exj, mine[e]), exj);
+    }
+    tile2[so_pad(j)] = mine2[e];
+  }
+  __syncthreads();
+  {
+    T2 c[SO_E];
+    T2 a2 = ident2;
+#pragma unroll
+    for (int e = 0; e < SO_E; ++e) {
+      c[e] = tile2[so_pad(threadIdx.x * SO_E + e)];
+      a2 = op2(a2, c[e]);
+    }
+    T2 tot2;
+    T2 inc2 = block_incl_scan_op(a2, op2, sm2, &tot2);
+    T2 prev2 = shfl_up_t(inc2, 1);
+    if (lane_id() == 63) wl2[threadIdx.x >> 6] = inc2;
+    if (threadIdx.x < 64) {
+      const T2 excl2 = so_lookback<T2, Op2>(S2, tix, tot2, op2, ident2);
+      if (lane_id() == 0) s_carry2 = excl2;
+    }
+    __syncthreads();
+    const T2 carry2 = s_carry2;
+    T2 ex2;
+    if (threadIdx.x == 0)
+      ex2 = carry2;
+    else if (lane_id() == 0)
+      ex2 = op2(carry2, wl2[(threadIdx.x >> 6) - 1]);
+    else
+      ex2 = op2(carry2, prev2);
+#pragma unroll
+    for (int e = 0; e < SO_E; ++e) {
+      tile2[so_pad(threadIdx.x * SO_E + e)] = ex2;
+      ex2 = op2(ex2, c[e]);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < SO_E; ++e) {
+    uint32_t j = (uint32_t)e * SO_NT + threadIdx.x;
+    uint64_t i = base + j;
+    if (i < n) {
+      const T exj = tile[so_pad(j)];
+      store((uint32_t)i, mine[e], op(exj, mine[e]), exj, mine2[e], tile2[so_pad(j)]);
+    }
+  }
+}
+
+template <class T, class Op, class T2, class Op2, class Load, class Second, class Store>
+int scan_two_run(tbk_ctx* ctx, const char* name, uint32_t n, Load load, Second second, Store store, Op op, T ident, Op2 op2, T2 ident2) {
+  if (n == 0) return 0;
+  const uint32_t nb = cdiv(n, SO_TILE);
+  constexpr size_t W = sizeof(T) / 4, W2 = sizeof(T2) / 4;
+  const size_t words = 2 * (size_t)nb * (W + W2) + 2;  // granules of both scans + the ticket word
+  unsigned long long* st = ws_alloc<unsigned long long>(ctx, words);
+  if (!st) return TBK_ENOMEM;
+  TBK_HIP(hipMemsetAsync(st, 0, words * 8, ctx->stream));
+  unsigned long long* g = st + 2;
+  unsigned long long* g2 = g + 2 * (size_t)nb * W;
+  SoLookback S{g, g + (size_t)nb * W, (uint32_t*)st, ctx->d_err};
+  SoLookback S2{g2, g2 + (size_t)nb * W2, (uint32_t*)st, ctx->d_err};
+  TBK_LAUNCH(ctx, name, (so_two_k<T, Op, T2, Op2, Load, Second, Store>), nb, SO_NT, 0, n, load, second, store, op, ident, op2, ident2, S, S2);
+  return tbk_check_launch(ctx, name);
 }
 
 template <class T, class Op, class Load, class Store>
