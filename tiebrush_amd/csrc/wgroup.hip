@@ -114,11 +114,47 @@ __device__ __forceinline__ uint32_t wg_upper_bound(const uint64_t* __restrict__ 
 template <bool RAW>
 __global__ __launch_bounds__(256) void wg_offsets_stream_k(const uint64_t* __restrict__ chi, const int32_t* __restrict__ rtid,
                                                            const int32_t* __restrict__ rpos, const uint32_t* __restrict__ run_off, uint32_t k,
-                                                           uint32_t n, const uint64_t* __restrict__ W, uint32_t nW, uint32_t* __restrict__ off,
-                                                           uint32_t* __restrict__ err) {
+                                                           uint32_t n, const uint64_t* __restrict__ W, uint32_t nW, uint32_t nrows,
+                                                           uint32_t* __restrict__ offT, uint32_t* __restrict__ err) {
   __shared__ uint64_t key[WG_OC];
   __shared__ uint32_t s_f;
+  __shared__ uint32_t s_cnt[2][4];  // (two parities: one barrier per round)
   const uint32_t t = threadIdx.x;
+  // Two upper bounds in W at once (first r with W[r] > v), one per half of the block: every round the 128 threads of a half probe
+  // evenly spaced bounds of the interval left — three rounds for any nW < 2^21, where a bisection by one thread waits on ~20
+  // dependent loads (that wait, not the writes, was most of this kernel).  Both halves return both answers.
+  auto upper_bounds2 = [&](uint64_t va, bool skip_a, uint64_t vb, bool skip_b, uint32_t* ra, uint32_t* rb) {
+    const uint32_t half = t >> 7, j = t & 127u;
+    uint32_t lo[2] = {0u, 0u}, hi[2] = {skip_a ? 0u : nW, skip_b ? 0u : nW};
+    uint32_t par = 0;
+    while (lo[0] < hi[0] || lo[1] < hi[1]) {  // (uniform)
+      const uint32_t l = lo[half], h = hi[half];
+      const uint32_t step = (h - l + 127u) >> 7;
+      const uint32_t p = l + j * step;
+      const bool le = step && p < h && W[p] <= (half ? vb : va);
+      const uint64_t m = __ballot(le);
+      if ((t & 63u) == 0) s_cnt[par][t >> 6] = (uint32_t)__builtin_popcountll(m);
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const uint32_t T = s_cnt[par][2 * q] + s_cnt[par][2 * q + 1];
+        const uint32_t st = (hi[q] - lo[q] + 127u) >> 7;
+        if (lo[q] < hi[q]) {
+          if (T == 0) {
+            hi[q] = lo[q];
+          } else {
+            const uint32_t pT = lo[q] + T * st;  // the first probe that was beyond, or beyond the interval
+            hi[q] = T < 128u && pT < hi[q] ? pT : hi[q];
+            lo[q] = lo[q] + (T - 1u) * st + 1u;
+            lo[q] = lo[q] > hi[q] ? hi[q] : lo[q];
+          }
+        }
+      }
+      par ^= 1u;
+    }
+    *ra = lo[0];
+    *rb = lo[1];
+  };
   const uint32_t i0 = blockIdx.x * WG_OC;
   const uint32_t i1 = n - i0 < WG_OC ? n : i0 + WG_OC;
   for (uint32_t j = t; j < i1 - i0; j += 256) key[j] = RAW ? raw_key(rtid[i0 + j], rpos[i0 + j]) : (chi[i0 + j] >> 2);
@@ -142,8 +178,9 @@ __global__ __launch_bounds__(256) void wg_offsets_stream_k(const uint64_t* __res
     const uint32_t sa = a > i0 ? a : i0, sb = b < i1 ? b : i1;  // the run's records inside this block
     const bool has_lo = sa > a;                                  // (then sa == i0: the record before is outside the block)
     const uint64_t klo = has_lo ? (RAW ? raw_key(rtid[sa - 1], rpos[sa - 1]) : (chi[sa - 1] >> 2)) : 0ull;
-    const uint32_t r_lo = has_lo ? wg_upper_bound(W, nW, klo) : 0u;
-    const uint32_t r_hi = sb == b ? nW : wg_upper_bound(W, nW, key[sb - 1 - i0]);
+    uint32_t r_lo, r_hi;
+    upper_bounds2(klo, !has_lo, key[sb - 1 - i0], sb == b, &r_lo, &r_hi);
+    r_hi = sb == b ? nW : r_hi;
     for (uint32_t r = r_lo + t; r < r_hi; r += 256) {
       const uint64_t v = W[r];
       uint32_t lo = sa - i0, hi = sb - i0;  // first record of the segment with key >= v (none: the run ends here)
@@ -154,7 +191,7 @@ __global__ __launch_bounds__(256) void wg_offsets_stream_k(const uint64_t* __res
         else
           hi = mid;
       }
-      off[(size_t)(r + 1) * k + f] = i0 + lo;
+      offT[(size_t)f * nrows + (r + 1)] = i0 + lo;  // (consecutive r: consecutive words)
     }
     if (RAW) {
       for (uint32_t j = sa + t; j < sb; j += 256) {
@@ -165,14 +202,34 @@ __global__ __launch_bounds__(256) void wg_offsets_stream_k(const uint64_t* __res
   }
   if (RAW && bad) atomicOr(err, TBK_DERR_RAWORDER);
 }
-__global__ void wg_offsets_edges_k(const uint32_t* __restrict__ run_off, uint32_t k, uint32_t nrows, uint32_t* __restrict__ off) {
-  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= k) return;
+// (one block per run)
+__global__ void wg_offsets_edges_k(const uint32_t* __restrict__ run_off, uint32_t k, uint32_t nrows, uint32_t* __restrict__ offT) {
+  const uint32_t f = blockIdx.x;
   const uint32_t a = run_off[f], b = run_off[f + 1];
-  off[f] = a;
-  off[(size_t)(nrows - 1) * k + f] = b;
+  uint32_t* col = offT + (size_t)f * nrows;
+  if (threadIdx.x == 0) {
+    col[0] = a;
+    col[nrows - 1] = b;
+  }
   if (a == b)
-    for (uint32_t r = 1; r + 1 < nrows; ++r) off[(size_t)r * k + f] = a;
+    for (uint32_t r = 1 + threadIdx.x; r + 1 < nrows; r += blockDim.x) col[r] = a;
+}
+// The stream kernel finds, for one run at a time, consecutive bounds: it writes the matrix run-major (offT[f * nrows + r], whole
+// lines — written bound-major, every word dirtied a line of its own: 1.28 GB of writes for 92 MB of matrix on config 3), and this
+// pass turns it into the bound-major form the window kernels read a row of per window, 64 x 64 words at a time through LDS.
+__global__ __launch_bounds__(256) void wg_offsets_transpose_k(const uint32_t* __restrict__ offT, uint32_t k, uint32_t nrows, uint32_t* __restrict__ off) {
+  __shared__ uint32_t tile[64][65];
+  const uint32_t r0 = blockIdx.x * 64, f0 = blockIdx.y * 64;
+  const uint32_t tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (uint32_t y = ty; y < 64; y += 4) {  // tile[y][x] = offT[f0 + y][r0 + x]
+    const uint32_t f = f0 + y, r = r0 + tx;
+    if (f < k && r < nrows) tile[y][tx] = offT[(size_t)f * nrows + r];
+  }
+  __syncthreads();
+  for (uint32_t y = ty; y < 64; y += 4) {  // off[r0 + y][f0 + x] = tile[x][y]
+    const uint32_t r = r0 + y, f = f0 + tx;
+    if (f < k && r < nrows) off[(size_t)r * k + f] = tile[tx][y];
+  }
 }
 struct WgRaw {                 // raw mode: the window kernels read the records themselves (WgIn::chi / clo / cval / ceff are null)
   ColIn I;
@@ -1477,6 +1534,20 @@ __global__ __launch_bounds__(64) void pr_compact_k(uint32_t nw, const uint32_t* 
 
 bool tbk_window_supported(uint32_t k) { return k >= 1 && k <= 1024; }
 
+// the offsets matrix of k runs against nW bounds, bound-major in `off` ([nrows * k], nrows = nW + 2)
+static int wg_offsets_build(tbk_ctx* ctx, bool raw, const uint64_t* chi, const int32_t* rtid, const int32_t* rpos, const uint32_t* d_run_off, uint32_t k,
+                            uint32_t m, const uint64_t* W, uint32_t nW, uint32_t nrows, uint32_t* off) {
+  uint32_t* offT = ws_alloc<uint32_t>(ctx, (size_t)nrows * k);
+  if (!offT) return TBK_ENOMEM;
+  if (raw)
+    TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_stream_k<true>, cdiv(m, WG_OC), 256, 0, chi, rtid, rpos, d_run_off, k, m, W, nW, nrows, offT, ctx->d_err);
+  else
+    TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_stream_k<false>, cdiv(m, WG_OC), 256, 0, chi, rtid, rpos, d_run_off, k, m, W, nW, nrows, offT, ctx->d_err);
+  TBK_LAUNCH(ctx, "wg_offsets_edges", wg_offsets_edges_k, k, 256, 0, d_run_off, k, nrows, offT);
+  TBK_LAUNCH(ctx, "wg_offsets_transpose", wg_offsets_transpose_k, dim3(cdiv(nrows, 64u), cdiv(k, 64u)), 256, 0, offT, k, nrows, off);
+  return 0;
+}
+
 int tbk_partial_reduce_device(tbk_ctx* ctx, int strategy, const int32_t* rows, uint32_t n2, const uint32_t* run_off_host, uint32_t k,
                               const uint32_t* cig, tbk_groups_out* out, tbk_cov_in* view) {
   if (k > PR_MAXRUNS) return TBK_EUNSUPPORTED;
@@ -1527,9 +1598,7 @@ int tbk_partial_reduce_device(tbk_ctx* ctx, int strategy, const int32_t* rows, u
     TBK_TRY(tbk_radix_sort_w64(ctx, &Y, &Y2, ns, ~0ull, false));
     TBK_LAUNCH(ctx, "wg_split", wg_split_k, cdiv(nsp, B), B, 0, Y, g, nsp, W);
   }
-  TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_stream_k<false>, cdiv(m, WG_OC), 256, 0, chi, (const int32_t*)nullptr, (const int32_t*)nullptr, d_run_off, k, m, W, nW,
-             off, ctx->d_err);
-  TBK_LAUNCH(ctx, "wg_offsets_edges", wg_offsets_edges_k, cdiv(k, B), B, 0, d_run_off, k, nrows, off);
+  TBK_TRY(wg_offsets_build(ctx, false, chi, nullptr, nullptr, d_run_off, k, m, W, nW, nrows, off));
   TBK_LAUNCH(ctx, "wg_rowsum", wg_rowsum_k, cdiv(nrows, 4), 256, 0, off, k, nrows, wbase);
   ColIn I{};
   I.n = m;
@@ -1602,11 +1671,7 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
     TBK_TRY(tbk_radix_sort_w64(ctx, &Y, &Y2, ns, ~0ull, false));
     TBK_LAUNCH(ctx, "wg_split", wg_split_k, cdiv(nsp, B), B, 0, Y, g, nsp, W);
   }
-  if (raw)
-    TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_stream_k<true>, cdiv(m, WG_OC), 256, 0, chi, I.tid, I.pos, d_run_off, k, m, W, nW, off, ctx->d_err);
-  else
-    TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_stream_k<false>, cdiv(m, WG_OC), 256, 0, chi, I.tid, I.pos, d_run_off, k, m, W, nW, off, ctx->d_err);
-  TBK_LAUNCH(ctx, "wg_offsets_edges", wg_offsets_edges_k, cdiv(k, B), B, 0, d_run_off, k, nrows, off);
+  TBK_TRY(wg_offsets_build(ctx, raw, chi, I.tid, I.pos, d_run_off, k, m, W, nW, nrows, off));
   WgTemp T;
   T.hi = scratch_hi;
   T.lo = scratch_lo;
