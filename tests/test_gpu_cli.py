@@ -186,14 +186,16 @@ def test_cli_tiling_by_reference_is_exact(tmp_path):
 
 def test_cli_decode_paths_give_the_same_record_stream(tmp_path):
     """the four ways the command line can bring its inputs in — whole-input host loader (default), streaming host reader, tiny
-    streamed tiles, device decode — and the two deflate codecs write the same records byte for byte: plain inputs (tags appended
-    to fresh records) and TieBrush-merged inputs (tags updated in place, stale integer YC and all)"""
+    streamed tiles, device decode — the two deflate codecs, and the fall-back from a whole-input tile the GPU refuses (out of
+    memory) to the streaming path write the same records byte for byte: plain inputs (tags appended to fresh records) and
+    TieBrush-merged inputs (tags updated in place, stale integer YC and all)"""
     from tiebrush_amd import bamio
     cases = {"plain": sample_paths("t2"), "merged": [os.path.join(GOLDEN, "t1", "t1.bam"), os.path.join(GOLDEN, "t2", "t2.bam")] + sample_paths("t1")[:2]}
     for name, paths in cases.items():
         streams = {}
         for tag, env in (("whole", {}), ("stream", dict(TBK_HOST_FAST="0")), ("tiles", dict(TBK_TILE_RECORDS="5000")),
-                         ("device", dict(TBK_DEVICE_DECODE="1")), ("zlib", dict(TBK_NO_LIBDEFLATE="1"))):
+                         ("device", dict(TBK_DEVICE_DECODE="1")), ("zlib", dict(TBK_NO_LIBDEFLATE="1")),
+                         ("whole_nomem", dict(TBK_TEST_WHOLE_ENOMEM="1")), ("device_nomem", dict(TBK_DEVICE_DECODE="1", TBK_TEST_WHOLE_ENOMEM="1"))):
             out = str(tmp_path / ("%s_%s.bam" % (name, tag)))
             r = subprocess.run([os.path.join(BIN, "tiebrush"), "-o", out] + paths, check=True, capture_output=True, text=True,
                                env=dict(os.environ, TBK_TIMING="1", **env))
@@ -201,10 +203,14 @@ def test_cli_decode_paths_give_the_same_record_stream(tmp_path):
                 assert "host path ms" in r.stderr             # the whole-input loader really ran
             if tag == "device":
                 assert "device decode:" in r.stderr
+            if tag == "whole_nomem":                          # TBK_ENOMEM / TBK_E2BIG on the one big tile: the streaming path takes over
+                assert "whole-input tile not used" in r.stderr
+            if tag == "device_nomem":
+                assert "device decode given up" in r.stderr
             raw = bamio.bgzf_decompress(open(out, "rb").read())
             streams[tag] = raw[bamio.parse_header(raw)[1]:]
         assert len(streams["whole"]) > 100000
-        for tag in ("stream", "tiles", "device", "zlib"):
+        for tag in ("stream", "tiles", "device", "zlib", "whole_nomem", "device_nomem"):
             assert streams[tag] == streams["whole"], (name, tag)
 
 

@@ -346,26 +346,32 @@ int main(int argc, char* argv[]) {
           out.yx = yx.data();
           out.yd = yd.data();
           rc = api.collapse_tile(ctx, &opt, &in, &out);
+          if (rc == 0 && getenv("TBK_TEST_WHOLE_ENOMEM")) rc = TBK_ENOMEM;  // test hook: exercise the fall-back below
           auto t2 = tnow();
           if (rc == TBK_EUNSORTED) GError("Error: an input file is not coordinate-sorted!\n");
-          if (rc != 0) GError("Error: GPU collapse failed: %s (%s)\n", api.strerror_(rc), api.last_error(ctx));
-          get_record = [&](uint32_t g) {
-            tbh::RecView v;
-            v.p = ft.record(rep[g], &v.len);
-            return v;
-          };
-          write_groups(out.n_groups);
-          auto t3 = tnow();
-          if (timing)
-            fprintf(stderr, "host path ms: read %.1f | inflate %.1f | index %.1f | SoA %.1f | wait for the device %.1f | collapse (PCIe incl.) %.1f | tag+deflate+write %.1f\n",
-                    ft.ms_read, ft.ms_inflate, ft.ms_index, ft.ms_soa, tms(t1, t_ctxw), tms(t_ctxw, t2), tms(t2, t3));
-          ms_inflate += tms(t0, t1);
-          ms_gpu += tms(t1, t2);
-          ms_tag += tms(t2, t3);
-          inCounter += out.n_passed;
-          outCounter += out.n_groups;
-          n_tiles = 1;
-          done_fast = true;
+          if (rc == TBK_ENOMEM || rc == TBK_E2BIG) {  // one tile of everything is more than the GPU takes: the streaming path bounds it
+            if (timing) fprintf(stderr, "whole-input tile not used (%s: %s): streaming host path\n", api.strerror_(rc), api.last_error(ctx));
+            tbh::big_release_all(nthreads);
+          } else {
+            if (rc != 0) GError("Error: GPU collapse failed: %s (%s)\n", api.strerror_(rc), api.last_error(ctx));
+            get_record = [&](uint32_t g) {
+              tbh::RecView v;
+              v.p = ft.record(rep[g], &v.len);
+              return v;
+            };
+            write_groups(out.n_groups);
+            auto t3 = tnow();
+            if (timing)
+              fprintf(stderr, "host path ms: read %.1f | inflate %.1f | index %.1f | SoA %.1f | wait for the device %.1f | collapse (PCIe incl.) %.1f | tag+deflate+write %.1f\n",
+                      ft.ms_read, ft.ms_inflate, ft.ms_index, ft.ms_soa, tms(t1, t_ctxw), tms(t_ctxw, t2), tms(t2, t3));
+            ms_inflate += tms(t0, t1);
+            ms_gpu += tms(t1, t2);
+            ms_tag += tms(t2, t3);
+            inCounter += out.n_passed;
+            outCounter += out.n_groups;
+            n_tiles = 1;
+            done_fast = true;
+          }
         }
       }
     }
@@ -439,41 +445,49 @@ int main(int argc, char* argv[]) {
           out.yx = yx.data();
           out.yd = yd.data();
           rc = api.collapse_tile(ctx, &opt, &in, &out);
+          if (rc == 0 && getenv("TBK_TEST_WHOLE_ENOMEM")) rc = TBK_ENOMEM;  // test hook: exercise the fall-back below
           auto t_col = tnow();
           if (rc == TBK_EUNSORTED) GError("Error: an input file is not coordinate-sorted!\n");
-          if (rc != 0) GError("Error: GPU collapse failed: %s (%s)\n", api.strerror_(rc), api.last_error(ctx));
           RawBuf<uint64_t> roff;
-          roff.resize((size_t)out.n_groups + 1);
           RawBuf<uint8_t> blob;
-          blob.resize((size_t)out.n_groups * 96 + 4096);
-          rc = api.bam_records(ctx, rep.data(), out.n_groups, TBK_MEM_HOST, blob.data(), blob.size(), roff.data());
-          if (rc == TBK_E2BIG) {
-            blob.resize(roff[out.n_groups]);
+          if (rc == 0) {
+            roff.resize((size_t)out.n_groups + 1);
+            blob.resize((size_t)out.n_groups * 96 + 4096);
             rc = api.bam_records(ctx, rep.data(), out.n_groups, TBK_MEM_HOST, blob.data(), blob.size(), roff.data());
+            if (rc == TBK_E2BIG) {
+              blob.resize(roff[out.n_groups]);
+              rc = api.bam_records(ctx, rep.data(), out.n_groups, TBK_MEM_HOST, blob.data(), blob.size(), roff.data());
+            }
           }
-          if (rc != 0) GError("Error: fetching the representative records failed: %s (%s)\n", api.strerror_(rc), api.last_error(ctx));
-          auto t_rec = tnow();
-          api.bam_release(ctx);
-          auto t2 = tnow();
-          if (timing)
-            fprintf(stderr, "device path ms: read files %.1f | wait for the HIP context %.1f | decode %.1f | collapse %.1f | fetch representatives %.1f | release %.1f\n",
-                    tms(t0, t_read), tms(t_read, t_ctxw), tms(t_ctxw, t1), tms(t1, t_col), tms(t_col, t_rec), tms(t_rec, t2));
-          get_record = [&](uint32_t g) {
-            tbh::RecView v;
-            v.p = blob.data() + roff[g] + 4;
-            v.len = (uint32_t)(roff[g + 1] - roff[g] - 4);
-            return v;
-          };
-          write_groups(out.n_groups);
-          auto t3 = tnow();
-          ms_inflate += tms(t0, t1);
-          ms_gpu += tms(t1, t2);
-          ms_tag += tms(t2, t3);
-          inCounter += out.n_passed;
-          outCounter += out.n_groups;
-          n_tiles = 1;
-          done_on_device = true;
-          if (timing) fprintf(stderr, "device decode: %zu records from %llu compressed bytes\n", n, (unsigned long long)total);
+          if (rc == TBK_ENOMEM || rc == TBK_E2BIG) {  // decoded, but the whole input as one tile is more than the GPU takes:
+            if (timing)                                // give the device copies back and let the streaming path bound the tile
+              fprintf(stderr, "device decode given up (%s: %s): streaming host path\n", api.strerror_(rc), api.last_error(ctx));
+            api.bam_release(ctx);
+          } else {
+            if (rc != 0) GError("Error: GPU collapse / fetching the representative records failed: %s (%s)\n", api.strerror_(rc), api.last_error(ctx));
+            auto t_rec = tnow();
+            api.bam_release(ctx);
+            auto t2 = tnow();
+            if (timing)
+              fprintf(stderr, "device path ms: read files %.1f | wait for the HIP context %.1f | decode %.1f | collapse %.1f | fetch representatives %.1f | release %.1f\n",
+                      tms(t0, t_read), tms(t_read, t_ctxw), tms(t_ctxw, t1), tms(t1, t_col), tms(t_col, t_rec), tms(t_rec, t2));
+            get_record = [&](uint32_t g) {
+              tbh::RecView v;
+              v.p = blob.data() + roff[g] + 4;
+              v.len = (uint32_t)(roff[g + 1] - roff[g] - 4);
+              return v;
+            };
+            write_groups(out.n_groups);
+            auto t3 = tnow();
+            ms_inflate += tms(t0, t1);
+            ms_gpu += tms(t1, t2);
+            ms_tag += tms(t2, t3);
+            inCounter += out.n_passed;
+            outCounter += out.n_groups;
+            n_tiles = 1;
+            done_on_device = true;
+            if (timing) fprintf(stderr, "device decode: %zu records from %llu compressed bytes\n", n, (unsigned long long)total);
+          }
         } else if (timing) {
           fprintf(stderr, "device decode not used (%s: %s): streaming host path\n", api.strerror_(rc), api.last_error(ctx));
         }

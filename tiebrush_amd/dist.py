@@ -438,25 +438,6 @@ def shard_collapse(compute, local_tile: SoATile, first_fidx: int, rank: int, wor
         tile2.yx_in = ext[:, 1].contiguous() if _is_t(ext) else np.ascontiguousarray(ext[:, 1])
         tile2.yd_in = ext[:, 2].contiguous() if _is_t(ext) else np.ascontiguousarray(ext[:, 2])
     mark("unpack")
-    submit = getattr(compute, "submit_tail", None)
-    if submit is not None and on_dev and device_chain:
-        # Pipelined driver (bench.py): everything behind the shuffle needs no collective once the junction numbering across
-        # ranks is left out, so it is handed over as a closure — the driver runs it on another context and thread while this
-        # rank goes on with the next tile's shuffle — and the handle the driver returns stands in for the result.
-        def tail(cx):
-            fin = cx.collapse(tile2, strategy=strategy, want_coords=True, keep_supplementary=True, keep_secondary=True, defer_yd=True)
-            g2 = int(fin["n_groups"])
-            rep2 = X.u32_to_i64(fin["rep"])
-            plo = X.to_i64(A["prio_lo"])[rep2]
-            res = ShardResult(n_groups=g2, n_passed_local=n_pass, tid=tile2.tid[rep2], start=fin["g_start"], end=fin["g_end"],
-                              rep_fidx=plo >> 32, rep_idx=plo & 0xFFFFFFFF, yc=fin["yc"], yx=fin["yx"], yd=fin["yd"],
-                              n_partials_received=n2)
-            res.cov_input = cx.groups_to_cov_in(fin)
-            if want_coverage:
-                res.coverage = cx.coverage(res.cov_input)
-            cx.finish_yd()
-            return res
-        return submit(tail)
     defer = on_dev and hasattr(compute, "finish_yd")
     fin = compute.collapse(tile2, strategy=strategy, want_coords=True, keep_supplementary=True, keep_secondary=True,
                            **(dict(defer_yd=True) if defer else {}))
