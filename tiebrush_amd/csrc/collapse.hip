@@ -526,11 +526,14 @@ struct HeadNex {
 struct HeadNexOp {
   __device__ __forceinline__ HeadNex operator()(const HeadNex& a, const HeadNex& b) const { return HeadNex{a.h + b.h, a.n + b.n}; }
 };
+struct YdAux {  // (start, exon count) of the item
+  YdItems Y;
+  __device__ __forceinline__ int2 operator()(uint32_t t) const { return make_int2(Y.start(t), (int)Y.nex[t]); }
+};
 struct YdHead {
-  YdLoad L;
-  __device__ __forceinline__ HeadNex operator()(uint32_t t, const SegMaxY& v, const SegMaxY&, const SegMaxY& ex) const {
+  __device__ __forceinline__ HeadNex operator()(uint32_t, const SegMaxY& v, const SegMaxY&, const SegMaxY& ex, const int2& a) const {
     // renewal: the read starts beyond every earlier end of this list => every node is cleared (processRead :230-241)
-    return HeadNex{(v.flag || L.Y.start(t) > ex.mx) ? 1u : 0u, L.Y.nex[t]};
+    return HeadNex{(v.flag || a.x > ex.mx) ? 1u : 0u, (uint32_t)a.y};
   }
 };
 // chains numbered in item order, each with its first item and the first node of its arena
@@ -539,7 +542,8 @@ struct YdStore {
   uint32_t *chain_first, *chain_noff;
   uint64_t* totals;  // [0] chains, [1] nodes
   uint32_t nit;
-  __device__ __forceinline__ void operator()(uint32_t t, const SegMaxY&, const SegMaxY&, const SegMaxY&, const HeadNex& v, const HeadNex& ex) const {
+  __device__ __forceinline__ void operator()(uint32_t t, const SegMaxY&, const SegMaxY&, const SegMaxY&, const HeadNex& v, const HeadNex& ex,
+                                             const int2&) const {
     if (v.h) {
       chain_first[ex.h] = t;
       chain_noff[ex.h] = ex.n;
@@ -1351,10 +1355,11 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       }
       {
         YdLoad ld{iv, Y};  // chain heads (segmented running maximum of the ends) and their numbering, one pass
-        YdHead hd{ld};
+        YdAux ax{Y};
+        YdHead hd{};
         YdStore st{Y, chain_first, noff, sc + 3, nit};
         SegMaxY ident{INT32_MIN, 0u};
-        TBK_TRY((scan_two_run<SegMaxY, SegMaxYOp, HeadNex, HeadNexOp, YdLoad, YdHead, YdStore>(ctx, "yd_chains", nit, ld, hd, st, SegMaxYOp{}, ident,
+        TBK_TRY((scan_two_run<8, SegMaxY, SegMaxYOp, HeadNex, HeadNexOp, YdLoad, YdAux, YdHead, YdStore>(ctx, "yd_chains", nit, ld, ax, hd, st, SegMaxYOp{}, ident,
                                                                                               HeadNexOp{}, HeadNex{0u, 0u})));
       }
       TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));

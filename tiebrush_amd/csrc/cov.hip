@@ -142,11 +142,14 @@ struct BundleLoad {
     return s;
   }
 };
-struct BundleHead {
+struct BundleAux {  // (start, tid) of the record
   const int32_t* tid;
   const int32_t* start;
-  __device__ __forceinline__ uint32_t operator()(uint32_t j, const SegMax&, const SegMax&, const SegMax& ex) const {
-    return (j == 0 || tid[j] != tid[j - 1] || start[j] > ex.mx) ? 1u : 0u;  // tiecov.cpp:443
+  __device__ __forceinline__ int2 operator()(uint32_t j) const { return make_int2(start[j], tid[j]); }
+};
+struct BundleHead {
+  __device__ __forceinline__ uint32_t operator()(uint32_t, const SegMax& v, const SegMax&, const SegMax& ex, const int2& a) const {
+    return (v.flag || a.x > ex.mx) ? 1u : 0u;  // tiecov.cpp:443 (flag: first record of its reference sequence)
   }
 };
 // One pass gives every record its bundle (scan_two_run numbers the heads) and every bundle its reference sequence, start and
@@ -156,9 +159,10 @@ struct BundleStore {
   uint32_t m;
   uint64_t* nb_out;
   uint32_t* err;
-  __device__ __forceinline__ void operator()(uint32_t j, const SegMax&, const SegMax& inc, const SegMax&, uint32_t head, uint32_t before) const {
-    const int32_t t = A.tid[j], st = A.start[j];
-    if (j != 0 && A.tid[j - 1] == t && st < A.start[j - 1]) atomicOr(err, TBK_DERR_UNSORTED);
+  __device__ __forceinline__ void operator()(uint32_t j, const SegMax& v, const SegMax& inc, const SegMax&, uint32_t head, uint32_t before,
+                                             const int2& a) const {
+    const int32_t t = a.y, st = a.x;
+    if (!v.flag && st < A.start[j - 1]) atomicOr(err, TBK_DERR_UNSORTED);
     const uint32_t b = before + head - 1u;
     A.bhead[j] = head;
     A.bid[j] = b;
@@ -1016,10 +1020,11 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
   // bundles
   {
     BundleLoad ld{A.tid, A.end};
-    BundleHead hd{A.tid, A.start};
+    BundleAux ax{A.tid, A.start};
+    BundleHead hd{};
     BundleStore st{A, m, sc + 3, ctx->d_err};
     SegMax ident{INT32_MIN, 0u};
-    TBK_TRY((scan_two_run<SegMax, SegMaxOp, uint32_t, SoPlusU32, BundleLoad, BundleHead, BundleStore>(ctx, "cov_bundles", m, ld, hd, st, SegMaxOp{}, ident,
+    TBK_TRY((scan_two_run<4, SegMax, SegMaxOp, uint32_t, SoPlusU32, BundleLoad, BundleAux, BundleHead, BundleStore>(ctx, "cov_bundles", m, ld, ax, hd, st, SegMaxOp{}, ident,
                                                                                                         SoPlusU32{}, 0u)));
   }
   TBK_TRY(tbk_sync_err(ctx, &eb));

@@ -12,7 +12,8 @@ ALIAS = {  # kernel symbol stem -> the name bench.py reports (TBK_LAUNCH name) w
     "w64_emit_flat": "yd_scatter",
 }
 SCAN = {"EffKey": "col_effkey_scan", "SegMaxY": "yd_chain_scan", "SegMax": "cov_bundle_scan", "ShKey": "shard_eff_scan",
-        "HeadNex": "yd_chain_number"}
+        "HeadNex": "yd_chain_number", "PmKey": "partial_emax_scan"}
+TWO = {"SegMaxY": "yd_chains", "SegMax": "cov_bundles"}   # so_two_k: the two-stage scans (heads found and numbered in one pass)
 
 
 def bench_name(sym):
@@ -20,8 +21,11 @@ def bench_name(sym):
     if not m:
         return None
     stem = m.group(1)
+    if stem == "so_two":
+        t = re.search(r"::(SegMaxY|SegMax)\b", sym)
+        return TWO.get(t.group(1)) if t else stem
     if stem in ("so_reduce", "so_spine", "so_down", "so_single"):
-        t = re.search(r"::(EffKey|SegMaxY|SegMax|ShKey|HeadNex)\b", sym)
+        t = re.search(r"::(EffKey|SegMaxY|SegMax|ShKey|HeadNex|PmKey)\b", sym)
         return SCAN.get(t.group(1)) if t else stem
     if stem == "w64_scatter" and "YdEmit" in sym:
         return "yd_scatter"

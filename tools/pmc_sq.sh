@@ -3,8 +3,8 @@
 # usage (through gpurun): bash tools/pmc_sq.sh <tag> [kernel-name-substring]
 tag=${1:-pmc}; pat=${2:-wg_hash}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/$tag; mkdir -p $O
-rocprofv3 --pmc ${PMC:-SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS} --output-format csv -d $O/p -o p -- python3 bench.py --steps 2 --warmup 1 --prof-steps 1 --no-cpu-baseline --no-host-path > $O/bench.json 2> $O/err.log
+O=${PMC_OUT:-gpurun_out}/$tag; mkdir -p $O
+rocprofv3 --pmc ${PMC:-SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS} --output-format csv -d $O/p -o p -- python3 bench.py --steps 2 --warmup 1 --prof-steps 1 --no-cpu-baseline --no-host-path --no-e2e > $O/bench.json 2> $O/err.log
 f=$(find $O/p -name "*counter_collection.csv" | head -1)
 python3 - "$f" "$pat" <<'P'
 import csv, sys, collections
