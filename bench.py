@@ -27,6 +27,7 @@ process before this process touches the GPU: process start, BGZF both ways, tagg
 (the CPU oracle: 1 thread at gcc -O2 and at the reference's shipped -O0, and a tiewrap-style multi-process line).
 """
 import argparse
+import contextlib
 import json
 import os
 import subprocess
@@ -212,8 +213,16 @@ def main():
     cbufs2, vbufs2 = [{} for _ in range(NCTX)], [{} for _ in range(NCTX)]
     cbufs, vbufs = cbufs2[0], vbufs2[0]
 
+    # One collapse at a time: the window kernels fill the GPU, the YD stage and tiecov are chains of short or latency-bound kernels
+    # that run well beside them.  Left alone, two contexts fall into step — both in their window kernels, then both in YD, the
+    # GPU a quarter of the time with nothing but a few long YD chains on it (rocprofv3 timeline, tools/scratch/timeline.py) — so a
+    # context takes the gate for its collapse and the other one's collapse always runs beside this one's YD + tiecov.
+    gate = threading.Lock() if os.environ.get("TBK_BENCH_GATE", "1") != "0" else contextlib.nullcontext()
+
     def plain_step(cx, tile, cb, vb):
-        g = cx.collapse(tile, opts=opts_defer, want_coords=True, out=cb, raw=True)   # (waits for this context's previous YD stage)
+        cx.finish_yd()                                # (this context's previous YD stage: waited for outside the gate)
+        with gate:
+            g = cx.collapse(tile, opts=opts_defer, want_coords=True, out=cb, raw=True)
         view = cx.groups_to_cov_in(g)
         c = cx.coverage(view, out=vb, raw=True)
         return g, c
