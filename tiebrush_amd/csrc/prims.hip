@@ -31,29 +31,41 @@ __global__ __launch_bounds__(SC_NT) void scan_reduce_k(const uint32_t* __restric
   if (threadIdx.x == 0) part[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
 }
 
-// single block: exclusive scan of part[0..nb) in place, total -> *total (may be null)
+// single block: exclusive scan of part[0..nb) in place, total -> *total (may be null).  A thread owns 16 consecutive partials
+// (their loads are all in flight together): 16 K partials — 33 M elements — per round of the block.
 __global__ __launch_bounds__(1024) void scan_spine_k(uint64_t* __restrict__ part, uint32_t nb, uint64_t* __restrict__ total) {
   __shared__ uint64_t sm[16];
   __shared__ uint64_t carry_s;
+  constexpr uint32_t E = 16;
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
-  for (uint32_t base = 0; base < nb; base += 1024) {
-    uint32_t i = base + threadIdx.x;
-    uint64_t v = (i < nb) ? part[i] : 0;
-    uint64_t inc = wave_incl_sum(v);
-    uint32_t w = threadIdx.x >> 6;
+  for (uint32_t base = 0; base < nb; base += 1024 * E) {
+    const uint32_t i0 = base + threadIdx.x * E;
+    uint64_t v[E];
+    uint64_t s = 0;
+#pragma unroll
+    for (uint32_t e = 0; e < E; ++e) {
+      v[e] = (i0 + e < nb) ? part[i0 + e] : 0;
+      s += v[e];
+    }
+    const uint64_t inc = wave_incl_sum(s);
+    const uint32_t w = threadIdx.x >> 6;
     if (lane_id() == 63) sm[w] = inc;
     __syncthreads();
     uint64_t wb = 0, tot = 0;
     for (int k = 0; k < 16; ++k) {
-      uint64_t x = sm[k];
+      const uint64_t x = sm[k];
       if ((uint32_t)k < w) wb += x;
       tot += x;
     }
-    uint64_t carry = carry_s;
-    if (i < nb) part[i] = carry + wb + inc - v;
+    uint64_t ex = carry_s + wb + inc - s;
+#pragma unroll
+    for (uint32_t e = 0; e < E; ++e) {
+      if (i0 + e < nb) part[i0 + e] = ex;
+      ex += v[e];
+    }
     __syncthreads();
-    if (threadIdx.x == 0) carry_s = carry + tot;
+    if (threadIdx.x == 0) carry_s += tot;
     __syncthreads();
   }
   if (threadIdx.x == 0 && total) *total = carry_s;
