@@ -56,7 +56,8 @@ def main():
         ts, r = run({}, max(1, a.runs))
         med = ts[len(ts) // 2]
         th, _ = run({"TBK_DEVICE_DECODE": "1"}, 1)
-        summary = r.stderr.strip().split("\n")[-1]
+        lines = r.stderr.strip().split("\n")
+        summary = next((l for l in reversed(lines) if "input records written as" in l), lines[-1])   # (the tool's own summary line)
         res = {"value": round(n / med, 1), "unit": "records/s", "workload": "%d files x %d reads (config-2 read model), default collapse" % (a.files, a.reads),
                "wall_s": round(med, 3), "wall_s_min": round(ts[0], 3), "wall_s_max": round(ts[-1], 3), "runs": len(ts),
                "device_decode_wall_s": round(th[0], 3), "input_bam_bytes": sum(os.path.getsize(p) for p in paths),
