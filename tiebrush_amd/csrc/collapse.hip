@@ -446,6 +446,27 @@ struct YdGroups {
   uint32_t* xoff;
 };
 
+// The exons of a group whose key word is an exact code (strategy.cuh: record_key) follow from the key alone — one
+// reference-consuming operation: one exon (start, end); M N M / two exons with first block a and gap g: (start, start + a - 1),
+// (start + a + g, end) — so the representative's CIGAR, a random access per group, is only walked for the other groups (a few
+// per cent of an RNA-seq sample).  Returns the exon count, 0 when the CIGAR has to be walked.
+__device__ __forceinline__ uint32_t yd_exons_from_key(uint64_t lo, uint32_t st, uint32_t en, uint32_t* e0, uint32_t* s1) {
+  const uint32_t h32 = (uint32_t)lo;
+  *e0 = en;
+  *s1 = 0;
+  if ((h32 >> 30) == 2u) {  // one operation / one exon
+    const uint32_t op = h32 & 0xFu;
+    return (op == C_M || op == C_D || op == 7u || op == 8u || op == 0xFu) ? 1u : 0u;  // (M D = X, or -E's one-exon code; an N alone is two exons)
+  }
+  if ((h32 >> 30) == 3u) {
+    const uint32_t a = (h32 >> 20) & 0x3FFu, g = h32 & 0xFFFFFu;
+    *e0 = st + a - 1u;
+    *s1 = st + a + g;
+    return 2u;
+  }
+  return 0u;
+}
+
 __global__ void yd_groups_k(ColIn I, uint32_t ng, const uint32_t* __restrict__ gperm, GroupAcc G, const uint64_t* __restrict__ shi,
                             const uint64_t* __restrict__ slo, YdGroups Q) {
   uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
@@ -456,19 +477,37 @@ __global__ void yd_groups_k(ColIn I, uint32_t ng, const uint32_t* __restrict__ g
   int32_t st = (int32_t)(uint32_t)((h >> 2) & 0x7FFFFFFFull);
   const uint32_t tidp1 = (uint32_t)(h >> 33);
   const uint32_t en = (uint32_t)(st + (int32_t)(uint32_t)(l >> 32) - 1);
-  uint32_t r = (uint32_t)(G.rep[sg] & 0xFFFFFFFFull);
-  int nex = 0;
-  walk_exons(I.pos[r], I.cig + I.cig_off[r], I.cig_off[r + 1] - I.cig_off[r], [](int, int) {}, &nex);
+  uint32_t e0, s1;
+  int nex = (int)yd_exons_from_key(l, (uint32_t)st, en, &e0, &s1);
+  if (nex == 0) {
+    const uint32_t r = (uint32_t)(G.rep[sg] & 0xFFFFFFFFull);
+    walk_exons(I.pos[r], I.cig + I.cig_off[r], I.cig_off[r + 1] - I.cig_off[r], [](int, int) {}, &nex);
+  }
   Q.nex[o] = (uint32_t)nex;
   Q.pk[o] = make_uint4(tidp1, (uint32_t)st, en, (uint32_t)nex);
 }
 
-__global__ void yd_gexons_k(ColIn I, uint32_t ng, const uint32_t* __restrict__ gperm, GroupAcc G, YdGroups Q, uint32_t* __restrict__ ex_s,
-                            uint32_t* __restrict__ ex_e) {
+__global__ void yd_gexons_k(ColIn I, uint32_t ng, const uint32_t* __restrict__ gperm, GroupAcc G, const uint64_t* __restrict__ slo, YdGroups Q,
+                            uint32_t* __restrict__ ex_s, uint32_t* __restrict__ ex_e) {
   uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= ng) return;
-  uint32_t r = (uint32_t)(G.rep[gperm[o]] & 0xFFFFFFFFull);
+  const uint32_t sg = gperm[o];
   uint32_t w = Q.xoff[o];
+  {
+    const uint4 pk = Q.pk[o];
+    uint32_t e0, s1;
+    const uint32_t nk = yd_exons_from_key(slo[G.first[sg]], pk.y, pk.z, &e0, &s1);
+    if (nk) {
+      ex_s[w] = pk.y;
+      ex_e[w] = e0;
+      if (nk == 2u) {
+        ex_s[w + 1] = s1;
+        ex_e[w + 1] = pk.z;
+      }
+      return;
+    }
+  }
+  uint32_t r = (uint32_t)(G.rep[sg] & 0xFFFFFFFFull);
   int nex = 0;
   walk_exons(I.pos[r], I.cig + I.cig_off[r], I.cig_off[r + 1] - I.cig_off[r],
              [&](int es, int ee) {
@@ -1382,7 +1421,7 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       uint32_t* n_wave = bcur + 2 * YD_NB;
       uint32_t* n_over = n_wave + 1;
       TBK_HIP(hipMemsetAsync(bcnt, 0, (4 * YD_NB + 4) * sizeof(uint32_t), ctx->stream));
-      TBK_LAUNCH(ctx, "yd_gexons", yd_gexons_k, cdiv(ng, B), B, 0, I, ng, J.gperm, J.G, Q, ex_s, ex_e);
+      TBK_LAUNCH(ctx, "yd_gexons", yd_gexons_k, cdiv(ng, B), B, 0, I, ng, J.gperm, J.G, J.slo, Q, ex_s, ex_e);
       // chains bucketed by the log2 of their length, longest first: the lanes of a wave of yd_lane_k run chains of like length
       uint32_t wave_min = YD_WAVE_MIN_DEFAULT;  // TBK_YD_WAVE_MIN: test hook (1: every chain to yd_wave_k; huge: every chain to yd_lane_k)
       if (const char* e = getenv("TBK_YD_WAVE_MIN")) wave_min = (uint32_t)strtoul(e, nullptr, 0);
