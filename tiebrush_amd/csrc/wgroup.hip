@@ -376,7 +376,7 @@ __device__ __forceinline__ uint32_t piece_of(const uint32_t* pre, uint32_t k, ui
 }
 
 constexpr uint32_t WG_LDS_MAIN = WG_CAP * (8 + 8 + 4 + 2 + 2);  // sort kernel: hi, lo, val, two index permutations = 72 KiB
-constexpr uint32_t WG_LDS_HASH = 34 * 1024;                    // hash kernel: the group table (four blocks per CU)
+constexpr uint32_t WG_LDS_HASH = 40448;                        // hash kernel: the group table (four blocks per CU)
 constexpr uint32_t WG_LDS_HASH2 = 64 * 1024;                   // second tier (two blocks per CU)
 
 // Stable merge sort of the index permutation `src` (n entries, ping-pong with `dst`; returns where the result lives) by
@@ -1712,6 +1712,7 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   if (!ovf || !ovf2) return TBK_ENOMEM;
   TBK_HIP(hipMemsetAsync(ovf, 0, sizeof(uint32_t), ctx->stream));
   TBK_HIP(hipMemsetAsync(ovf2, 0, sizeof(uint32_t), ctx->stream));
+  const uint32_t* ovf1_dbg = ovf;  // (TBK_WG_DEBUG: the first tier's overflow count)
   // the windows that hold records (every splitter owns two bounds, so about half of the windows are empty by construction):
   // the hash kernel's grid is exactly those — an empty block would hold a table's worth of LDS while it finds out
   uint32_t* wlist = ws_alloc<uint32_t>(ctx, nw);
@@ -1801,6 +1802,10 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   if (T.dbg) {
     unsigned long long h[32];
     TBK_HIP(hipMemcpy(h, T.dbg, sizeof(h), hipMemcpyDeviceToHost));
+    uint32_t o1 = 0, o2 = 0;
+    TBK_HIP(hipMemcpy(&o1, ovf1_dbg, 4, hipMemcpyDeviceToHost));
+    TBK_HIP(hipMemcpy(&o2, ovf, 4, hipMemcpyDeviceToHost));
+    fprintf(stderr, "wg windows: %u with records, %u overflowed the first table (%u slots), %u the second\n", nw_live, o1, gcap, o2);
     static const char* ph[11] = {"prologue+init", "-", "key loads", "probe", "barrier 1", "atomics", "barrier 2", "-",
                                  "rank sort", "emit", "-"};
     unsigned long long tot = 0;
