@@ -55,6 +55,22 @@ def test_many_windows(ctx, window_mode, profile, files, reads, kw):
     _cmp(ctx, tile, **kw)
 
 
+@pytest.mark.parametrize("split", ["by_list", "radix"])
+def test_yd_items_by_list_and_by_radix_split(ctx, window_mode, split, monkeypatch):
+    """the YD items of the window path reach their lists without a sort (<= 64 files: bit-matrix ranks, yd_lcount_k /
+    yd_lscatter_k) or through the stable radix split (more files; TBK_YD_RADIX forces it): both against the oracle — '.' strands
+    feeding two lists, 64 files (every list in use), tiles of more than one 1024-group block, empty lists"""
+    from tiebrush_amd import synth
+    if split == "radix":
+        monkeypatch.setenv("TBK_YD_RADIX", "1")
+    for files, reads, profile, kw in ((64, 1500, "c3", dict(strategy="clip")), (3, 40000, "c2", dict()), (33, 2500, "c5", dict(strategy="exon"))):
+        tile = synth.make_tile(files, reads, profile, n_loci=300)
+        tile.strand = tile.strand.copy()
+        tile.strand[::7] = ord(".")                      # unstranded reads among the stranded ones
+        want = _cmp(ctx, tile, **kw)
+        assert int(np.asarray(want["yd"]).max()) > 0
+
+
 def test_pileup_effective_ends(ctx, window_mode):
     """One base, thousands of reads per file whose ends go up and down in file order: the representative is the member with the
     smallest (running maximum of the ends before it in its file, record index) — the scan's carry crosses lanes, waves,

@@ -430,6 +430,118 @@ __global__ void col_recgroup_w_k(uint32_t n, const uint32_t* __restrict__ rec_sg
   rec_group[i] = sg == 0xFFFFFFFFu ? -1 : (int32_t)ginv[sg];
 }
 
+
+// ---- items by list without a sort (window path, <= 64 input files: <= 128 lists) ---------------------------------------------
+// An item is a (group, list) pair, a list a (file, strand list) pair, and the chain kernels want the items of a list together, in
+// group order.  Round 2 wrote one 8-byte word per item in group order and split the 178 M words of config 3 by list with a stable
+// radix pass (count 0.1 + fill 0.7 + histogram 0.7 + scatter 2.8 ms).  But a group holds at most one item per list: the lists of
+// the 64 groups of a wave form a 64 x 128 bit matrix whose column c, read off with one ballot, gives every group of the wave its
+// rank in list c.  So: one pass counts the items per (list, tile of 256 groups), a row scan turns the counts into offsets, and
+// the second pass places every item — coordinates, exon offset and item word — where its list wants it.  No item array is
+// written twice, none is sorted.
+constexpr uint32_t YS_NT = 1024;  // groups per tile (one thread each)
+constexpr uint32_t YS_NL = 128;   // lists
+struct YsIn {
+  uint32_t ng;
+  const uint32_t* gperm;  // output order -> group
+  const uint32_t* ns;     // samples of a group
+  const uint32_t* gpoff;  // first incidence of a group (its incidences are in file order)
+  const uint16_t* pfile;
+  const uint64_t* ghi;    // group key: strand code in the low two bits
+};
+// the lists of a group as a 128-bit mask, from the 64-bit set of its files and its strand code ('.' feeds both lists of a file,
+// tiebrush.cpp:515-520)
+__device__ __forceinline__ uint64_t ys_spread32(uint64_t x) {  // bit f of the low 32 -> bit 2 f
+  x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+  x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+  x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+  x = (x | (x << 2)) & 0x3333333333333333ull;
+  x = (x | (x << 1)) & 0x5555555555555555ull;
+  return x;
+}
+__device__ __forceinline__ void ys_mask_from_files(uint64_t files, uint32_t c, uint64_t* lo, uint64_t* hi) {
+  const uint64_t a = ys_spread32(files & 0xFFFFFFFFull), b = ys_spread32(files >> 32);
+  *lo = c == 0u ? a : (c == 1u ? a << 1 : (a | (a << 1)));
+  *hi = c == 0u ? b : (c == 1u ? b << 1 : (b | (b << 1)));
+}
+// 64 x 64 bit matrix, one row per lane, transposed in six exchange steps: afterwards lane c holds column c (bit r = row r's bit c)
+__device__ __forceinline__ uint64_t wave_bit_transpose(uint64_t x) {
+  const uint32_t lane = lane_id();
+#define YS_TSTEP(J, M)                                                                     \
+  {                                                                                        \
+    const uint64_t tt = ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), J, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)x, J, 64); \
+    x = (lane & J) ? (((tt >> J) & M) | (x & ~M)) : ((x & M) | ((tt & M) << J));           \
+  }
+  YS_TSTEP(32, 0x00000000FFFFFFFFull)
+  YS_TSTEP(16, 0x0000FFFF0000FFFFull)
+  YS_TSTEP(8, 0x00FF00FF00FF00FFull)
+  YS_TSTEP(4, 0x0F0F0F0F0F0F0F0Full)
+  YS_TSTEP(2, 0x3333333333333333ull)
+  YS_TSTEP(1, 0x5555555555555555ull)
+#undef YS_TSTEP
+  return x;
+}
+__global__ __launch_bounds__(YS_NT) void yd_lcount_k(YsIn S, uint32_t ntiles, uint32_t* __restrict__ table /* [YS_NL][ntiles] */,
+                                                     uint64_t* __restrict__ gfiles /* [2 ng]: the files of output group o, its strand code */) {
+  __shared__ uint32_t hist[YS_NL];
+  if (threadIdx.x < YS_NL) hist[threadIdx.x] = 0;
+  __syncthreads();
+  uint64_t lo = 0, hi = 0;
+  {
+    const uint32_t o = blockIdx.x * YS_NT + threadIdx.x;
+    if (o < S.ng) {
+      const uint32_t sg = S.gperm[o];
+      const uint32_t n = S.ns[sg], c = (uint32_t)S.ghi[sg] & 3u, p0 = S.gpoff[sg];
+      uint64_t files = 0;
+      for (uint32_t i = 0; i < n; ++i) files |= 1ull << S.pfile[p0 + i];
+      gfiles[2 * (size_t)o] = files;
+      gfiles[2 * (size_t)o + 1] = c;
+      ys_mask_from_files(files, c, &lo, &hi);
+    }
+  }
+  const uint64_t cl = wave_bit_transpose(lo), ch = wave_bit_transpose(hi);  // lane c: the groups of this wave in lists c and 64 + c
+  if (cl) atomicAdd(&hist[lane_id()], (uint32_t)__builtin_popcountll(cl));
+  if (ch) atomicAdd(&hist[64u + lane_id()], (uint32_t)__builtin_popcountll(ch));
+  __syncthreads();
+  if (threadIdx.x < YS_NL) table[(size_t)threadIdx.x * ntiles + blockIdx.x] = hist[threadIdx.x];
+}
+__global__ void yd_ltotal_k(const uint64_t* __restrict__ totals, uint64_t* __restrict__ nit) {
+  const uint64_t s = wave_sum(totals[threadIdx.x]) ;
+  __shared__ uint64_t sm[2];
+  if (lane_id() == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *nit = sm[0] + sm[1];
+}
+// block l: row l of the table -> exclusive prefix in place, row total -> totals[l]
+__global__ __launch_bounds__(1024) void yd_lscan_k(uint32_t* __restrict__ table, uint32_t ntiles, uint64_t* __restrict__ totals) {
+  __shared__ uint32_t sm[16];
+  __shared__ uint32_t carry_s;
+  uint32_t* row = table + (size_t)blockIdx.x * ntiles;
+  constexpr uint32_t E = 8;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < ntiles; base += 1024 * E) {
+    const uint32_t i0 = base + threadIdx.x * E;
+    uint32_t v[E], s = 0;
+#pragma unroll
+    for (uint32_t e = 0; e < E; ++e) {
+      v[e] = i0 + e < ntiles ? row[i0 + e] : 0u;
+      s += v[e];
+    }
+    uint32_t tot;
+    uint32_t ex = carry_s + block_excl_sum<uint32_t, 1024>(s, sm, &tot);
+#pragma unroll
+    for (uint32_t e = 0; e < E; ++e) {
+      if (i0 + e < ntiles) row[i0 + e] = ex;
+      ex += v[e];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
+}
+
 struct YdItems {
   uint4* pk;      // (tid + 1, start, end, offset of the item's exon list in the per-group exon arrays): written with one store
   uint32_t* nex;  // exon count (contiguous: the input of the node-offset scan)
@@ -530,6 +642,81 @@ struct YdEmit {
     Y.nex[t] = g.w;
   }
 };
+
+// the second pass: every item dropped at its place in its list (the same record YdEmit leaves behind the radix split).  The items of
+// the tile are walked list by list — thread k takes the k-th, k + 256-th, ... item of that order, finds its list by a bisection in
+// the tile's per-list prefix and its group by selecting the r-th set bit of the list's 256-bit column — so that consecutive
+// threads write consecutive positions of one list.
+__device__ __forceinline__ uint32_t ys_select(uint64_t v, uint32_t r) {  // position of the r-th (0-based) set bit of v
+  uint32_t pos = 0;
+#pragma unroll
+  for (uint32_t st = 32; st >= 1; st >>= 1) {
+    const uint32_t c = (uint32_t)__builtin_popcountll((v >> pos) & ((1ull << st) - 1ull));
+    if (r >= c) {
+      r -= c;
+      pos += st;
+    }
+  }
+  return pos;
+}
+__global__ __launch_bounds__(YS_NT) void yd_lscatter_k(YsIn S, uint32_t ntiles, const uint32_t* __restrict__ table, const uint64_t* __restrict__ totals,
+                                                       const uint64_t* __restrict__ gfiles, YdGroups Q, YdItems Y, uint64_t* __restrict__ item) {
+  __shared__ uint32_t base[YS_NL];            // first position of this tile's items of list c
+  __shared__ uint32_t pre[YS_NL + 1];         // the tile's items in lists before c
+  __shared__ uint64_t wb[YS_NT / 64][YS_NL];  // column c of wave w's bit matrix
+  __shared__ uint32_t lsum[YS_NL];
+  __shared__ uint4 grec[YS_NT];
+  __shared__ uint32_t gnex[YS_NT];
+  const uint32_t t = threadIdx.x, w = t >> 6;
+  if (t < YS_NL) lsum[t] = (uint32_t)totals[t];
+  const uint32_t o = blockIdx.x * YS_NT + t;
+  uint64_t lo = 0, hi = 0;
+  if (o < S.ng) ys_mask_from_files(gfiles[2 * (size_t)o], (uint32_t)gfiles[2 * (size_t)o + 1], &lo, &hi);
+  wb[w][lane_id()] = wave_bit_transpose(lo);
+  wb[w][64u + lane_id()] = wave_bit_transpose(hi);
+  if (o < S.ng) {
+    const uint4 g = Q.pk[o];
+    grec[t] = make_uint4(g.x, g.y, g.z, Q.xoff[o]);
+    gnex[t] = g.w;
+  }
+  __syncthreads();
+  if (t < YS_NL) {
+    uint32_t b = 0;  // list base: the totals of the lists before it (128 values: a serial sum per thread is cheap enough)
+    for (uint32_t c = 0; c < t; ++c) b += lsum[c];
+    base[t] = b + table[(size_t)t * ntiles + blockIdx.x];
+    uint32_t n = 0;
+    for (uint32_t x = 0; x < YS_NT / 64; ++x) n += (uint32_t)__builtin_popcountll(wb[x][t]);
+    lsum[t] = n;  // (reused: this tile's items of list t)
+  }
+  __syncthreads();
+  if (t < 64) {  // exclusive prefix of the 128 per-list counts: one wave, two lists per lane
+    const uint32_t a = lsum[2 * t], b = lsum[2 * t + 1];
+    const uint32_t inc = wave_incl_sum(a + b);
+    pre[2 * t] = inc - a - b;
+    pre[2 * t + 1] = inc - b;
+    if (t == 63) pre[YS_NL] = inc;
+  }
+  __syncthreads();
+  const uint32_t T = pre[YS_NL];
+  for (uint32_t idx = t; idx < T; idx += YS_NT) {
+    uint32_t c = 0;  // last list with pre[c] <= idx
+#pragma unroll
+    for (uint32_t st = 64; st >= 1; st >>= 1) c = pre[c + st] <= idx ? c + st : c;
+    uint32_t r = idx - pre[c];
+    const uint32_t rank = r;
+    uint32_t x = 0;
+    for (;; ++x) {  // the wave whose column holds the r-th group (exists: r < the list's count)
+      const uint32_t n = (uint32_t)__builtin_popcountll(wb[x][c]);
+      if (r < n) break;
+      r -= n;
+    }
+    const uint32_t g = x * 64u + ys_select(wb[x][c], r);
+    const uint32_t pos = base[c] + rank;
+    Y.pk[pos] = grec[g];
+    Y.nex[pos] = gnex[g];
+    item[pos] = ((uint64_t)c << 32) | (blockIdx.x * YS_NT + g);
+  }
+}
 
 struct SegMaxY {
   int32_t mx;
@@ -1342,7 +1529,21 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
   {
     uint32_t *icnt = nullptr, *ioff = nullptr, *ocnt = nullptr, *ooff = nullptr;
     uint64_t nit64;
-    if (J.win) {  // items per output group straight from the per-group sample counts
+    const bool by_list = J.win && 2u * I.k <= YS_NL && !getenv("TBK_YD_RADIX");  // (TBK_YD_RADIX: test hook, the radix split of round 2)
+    const uint32_t ys_tiles = cdiv(ng, YS_NT);
+    const YsIn S{ng, J.gperm, J.G.ns, J.gpoff, J.pfile, J.shi};
+    uint32_t* ys_table = nullptr;
+    uint64_t* ys_totals = nullptr;
+    uint64_t* ys_files = nullptr;
+    if (by_list) {  // items per (list, tile of groups); their sum is the number of items
+      ys_table = ws_alloc<uint32_t>(ctx, (size_t)YS_NL * ys_tiles);
+      ys_totals = ws_alloc<uint64_t>(ctx, YS_NL + 1);
+      ys_files = ws_alloc<uint64_t>(ctx, 2 * (size_t)ng);
+      if (!ys_table || !ys_totals || !ys_files) return TBK_ENOMEM;
+      TBK_LAUNCH(ctx, "yd_lcount", yd_lcount_k, ys_tiles, YS_NT, 0, S, ys_tiles, ys_table, ys_files);
+      TBK_LAUNCH(ctx, "yd_lscan", yd_lscan_k, YS_NL, 1024, 0, ys_table, ys_tiles, ys_totals);
+      TBK_LAUNCH(ctx, "yd_lscan", yd_ltotal_k, 1, YS_NL, 0, ys_totals, sc + 2);
+    } else if (J.win) {  // items per output group straight from the per-group sample counts
       ocnt = ws_alloc<uint32_t>(ctx, ng);
       ooff = ws_alloc<uint32_t>(ctx, ng);
       if (!ooff) return TBK_ENOMEM;
@@ -1363,14 +1564,15 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
     if (nit) {
       // items: one word each, list id (file * 2 + strand list) : 32 | group in output order : 32
       uint64_t* iv = ws_alloc<uint64_t>(ctx, nit);
-      uint64_t* iv2 = ws_alloc<uint64_t>(ctx, nit);
+      uint64_t* iv2 = by_list ? iv : ws_alloc<uint64_t>(ctx, nit);
       YdItems Y;
       Y.pk = ws_alloc<uint4>(ctx, nit);
       Y.nex = ws_alloc<uint32_t>(ctx, nit);
       uint32_t* noff = ws_alloc<uint32_t>(ctx, nit);
       uint32_t* chain_first = ws_alloc<uint32_t>(ctx, nit);
       if (!chain_first) return TBK_ENOMEM;
-      if (J.win) {
+      if (by_list) {
+      } else if (J.win) {
         TBK_LAUNCH(ctx, "yd_fill", yd_fill_w_k, cdiv(J.np, B), B, 0, J.np, J.pfile, J.pgrp, J.gpoff, J.ginv, ooff, J.shi, iv);
       } else {
         ocnt = ws_alloc<uint32_t>(ctx, ng);
@@ -1387,7 +1589,9 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       if (!Q.xoff) return TBK_ENOMEM;
       TBK_LAUNCH(ctx, "yd_groups", yd_groups_k, cdiv(ng, B), B, 0, I, ng, J.gperm, J.G, J.shi, J.slo, Q);
       TBK_TRY(tbk_exscan_u32(ctx, Q.nex, Q.xoff, ng, sc + 5));
-      {  // stable split by list id (file * 2 + strand list); group order is already in place.  The id range is known:
+      if (by_list) {
+        TBK_LAUNCH(ctx, "yd_scatter", yd_lscatter_k, ys_tiles, YS_NT, 0, S, ys_tiles, ys_table, ys_totals, ys_files, Q, Y, iv);
+      } else {  // stable split by list id (file * 2 + strand list); group order is already in place.  The id range is known:
         uint32_t bits = 1;  // no scan for the varying bits
         while ((1ull << bits) < 2ull * I.k) ++bits;
         TBK_TRY(tbk_radix_sort_w64_emit(ctx, &iv, &iv2, nit, ((1ull << bits) - 1ull) << 32, true, YdEmit{Q, Y}, "yd_scatter"));
