@@ -542,6 +542,12 @@ __global__ __launch_bounds__(1024) void yd_lscan_k(uint32_t* __restrict__ table,
   if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
 }
 
+// The item -> group word: the low half of the 64-bit item words of the radix split, or (items placed by list) an array of its own.
+struct YdWords {
+  const uint64_t* w64;
+  const uint32_t* w32;
+  __device__ __forceinline__ uint32_t group(uint32_t t) const { return w32 ? w32[t] : (uint32_t)w64[t]; }
+};
 struct YdItems {
   uint4* pk;      // (tid + 1, start, end, offset of the item's exon list in the per-group exon arrays): written with one store
   uint32_t* nex;  // exon count (contiguous: the input of the node-offset scan)
@@ -660,11 +666,12 @@ __device__ __forceinline__ uint32_t ys_select(uint64_t v, uint32_t r) {  // posi
   return pos;
 }
 __global__ __launch_bounds__(YS_NT) void yd_lscatter_k(YsIn S, uint32_t ntiles, const uint32_t* __restrict__ table, const uint64_t* __restrict__ totals,
-                                                       const uint64_t* __restrict__ gfiles, YdGroups Q, YdItems Y, uint64_t* __restrict__ item) {
+                                                       const uint64_t* __restrict__ gfiles, YdGroups Q, YdItems Y, uint32_t* __restrict__ item) {
   __shared__ uint32_t base[YS_NL];            // first position of this tile's items of list c
   __shared__ uint32_t pre[YS_NL + 1];         // the tile's items in lists before c
   __shared__ uint64_t wb[YS_NT / 64][YS_NL];  // column c of wave w's bit matrix
   __shared__ uint32_t lsum[YS_NL];
+  __shared__ uint32_t first[YS_NL];
   __shared__ uint4 grec[YS_NT];
   __shared__ uint32_t gnex[YS_NT];
   const uint32_t t = threadIdx.x, w = t >> 6;
@@ -683,7 +690,9 @@ __global__ __launch_bounds__(YS_NT) void yd_lscatter_k(YsIn S, uint32_t ntiles, 
   if (t < YS_NL) {
     uint32_t b = 0;  // list base: the totals of the lists before it (128 values: a serial sum per thread is cheap enough)
     for (uint32_t c = 0; c < t; ++c) b += lsum[c];
-    base[t] = b + table[(size_t)t * ntiles + blockIdx.x];
+    const uint32_t here = table[(size_t)t * ntiles + blockIdx.x];
+    base[t] = b + here;
+    first[t] = here == 0u ? 1u : 0u;  // the list starts in this tile: its first item here is the first of all
     uint32_t n = 0;
     for (uint32_t x = 0; x < YS_NT / 64; ++x) n += (uint32_t)__builtin_popcountll(wb[x][t]);
     lsum[t] = n;  // (reused: this tile's items of list t)
@@ -712,9 +721,11 @@ __global__ __launch_bounds__(YS_NT) void yd_lscatter_k(YsIn S, uint32_t ntiles, 
     }
     const uint32_t g = x * 64u + ys_select(wb[x][c], r);
     const uint32_t pos = base[c] + rank;
-    Y.pk[pos] = grec[g];
+    uint4 rec = grec[g];
+    if (rank == 0u && first[c]) rec.x |= 0x80000000u;  // (read by YdLoad::list_head)
+    Y.pk[pos] = rec;
     Y.nex[pos] = gnex[g];
-    item[pos] = ((uint64_t)c << 32) | (blockIdx.x * YS_NT + g);
+    item[pos] = blockIdx.x * YS_NT + g;
   }
 }
 
@@ -731,10 +742,13 @@ struct SegMaxYOp {
   }
 };
 struct YdLoad {
-  const uint64_t* list;  // item words: list id in the high half
+  const uint64_t* list;  // item words: list id in the high half; null: the first item of every list carries bit 31 of its tid + 1 word
   YdItems Y;
-  __device__ __forceinline__ bool list_head(uint32_t t) const {
-    return t == 0 || (list[t] >> 32) != (list[t - 1] >> 32) || Y.tidp1(t) != Y.tidp1(t - 1);  // new list, or rspacing.reset() (:586-589)
+  __device__ __forceinline__ bool list_head(uint32_t t) const {  // new list, or rspacing.reset() (:586-589)
+    if (t == 0) return true;
+    const uint32_t a = Y.tidp1(t), b = Y.tidp1(t - 1);
+    if (!list) return (a >> 31) || ((a ^ b) & 0x7FFFFFFFu) != 0u;
+    return (list[t] >> 32) != (list[t - 1] >> 32) || a != b;
   }
   __device__ __forceinline__ SegMaxY operator()(uint32_t t) const {
     SegMaxY s;
@@ -877,7 +891,7 @@ __device__ void yd_merge_read(const uint32_t* __restrict__ xs, const uint32_t* _
 
 // thread per chain (short chains, and long chains whose list outgrew the 64 lanes of yd_wave_k)
 __global__ void yd_run_k(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ nids, uint32_t nchains, uint32_t nit,
-                         const uint32_t* __restrict__ chain_first, YdItems Y, const uint64_t* __restrict__ v,
+                         const uint32_t* __restrict__ chain_first, YdItems Y, YdWords v,
                          const uint32_t* __restrict__ noff, const uint32_t* __restrict__ ex_s, const uint32_t* __restrict__ ex_e,
                          SegNodes N, int32_t* __restrict__ g_yd) {
   uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -912,7 +926,7 @@ __global__ void yd_run_k(const uint32_t* __restrict__ ids, const uint32_t* __res
       last_dist = d;
       yd_merge_read(ex_s + xo, ex_e + xo, nex, N, head, alloc);
     }
-    if (d > 0) atomicMax(&g_yd[(uint32_t)v[t]], d);
+    if (d > 0) atomicMax(&g_yd[v.group(t)], d);
   }
 }
 
@@ -981,7 +995,7 @@ __global__ void yd_bucket_fill_k(uint32_t nchains, uint32_t nit, uint32_t wave_m
 
 template <int R /* items per lane and refill: the items of R consecutive lanes' worth are one coalesced segment */>
 __global__ __launch_bounds__(64) void yd_lane_k(const uint32_t* __restrict__ ids, uint32_t nids, uint32_t nchains, uint32_t nit,
-                                                const uint32_t* __restrict__ chain_first, YdItems Y, const uint64_t* __restrict__ v,
+                                                const uint32_t* __restrict__ chain_first, YdItems Y, YdWords v,
                                                 const uint32_t* __restrict__ ex_s, const uint32_t* __restrict__ ex_e,
                                                 int32_t* __restrict__ g_yd, uint32_t* __restrict__ ids_over, uint32_t* __restrict__ n_over) {
   constexpr int RS = R + 1;  // row stride of the staged items (odd: the lanes' own reads fall on different banks)
@@ -1031,7 +1045,7 @@ __global__ __launch_bounds__(64) void yd_lane_k(const uint32_t* __restrict__ ids
       if (tq != 0xFFFFFFFFu && idx < t1q) {
         const uint4 a = Y.pk[idx];
         const uint32_t nx = Y.nex[idx];
-        const uint32_t o = (uint32_t)v[idx];
+        const uint32_t o = v.group(idx);
         const uint32_t w = q * RS + i0;
         S_start[w] = a.y;
         S_xo[w] = a.w;
@@ -1162,7 +1176,7 @@ __device__ __forceinline__ uint32_t rl(uint32_t v, int lane) { return (uint32_t)
 
 __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ nids, uint32_t nchains,
                                                 uint32_t nit, const uint32_t* __restrict__ chain_first, YdItems Y,
-                                                const uint64_t* __restrict__ v, const uint32_t* __restrict__ noff,
+                                                YdWords v, const uint32_t* __restrict__ noff,
                                                 const uint32_t* __restrict__ ex_s, const uint32_t* __restrict__ ex_e,
                                                 int32_t* __restrict__ g_yd, uint32_t* __restrict__ ids_over, uint32_t* __restrict__ n_over) {
   if (blockIdx.x >= *nids) return;
@@ -1190,7 +1204,7 @@ __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids
     b.start = it.y;
     b.nex = have ? Y.nex[t] : 0u;
     b.xo = it.w;
-    b.o = have ? (uint32_t)v[t] : 0u;
+    b.o = have ? v.group(t) : 0u;
     b.e0 = have ? ex_e[b.xo] : 0u;  // first exon end (its start is the read start)
     b.s1 = (have && b.nex > 1) ? ex_s[b.xo + 1] : 0u;
     b.e1 = (have && b.nex > 1) ? ex_e[b.xo + 1] : 0u;
@@ -1563,8 +1577,10 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
     const uint32_t nit = (uint32_t)nit64;
     if (nit) {
       // items: one word each, list id (file * 2 + strand list) : 32 | group in output order : 32
-      uint64_t* iv = ws_alloc<uint64_t>(ctx, nit);
-      uint64_t* iv2 = by_list ? iv : ws_alloc<uint64_t>(ctx, nit);
+      uint64_t* iv = by_list ? nullptr : ws_alloc<uint64_t>(ctx, nit);
+      uint64_t* iv2 = by_list ? nullptr : ws_alloc<uint64_t>(ctx, nit);
+      uint32_t* io = by_list ? ws_alloc<uint32_t>(ctx, nit) : nullptr;  // items placed by list: the item -> group array
+      if (by_list && !io) return TBK_ENOMEM;
       YdItems Y;
       Y.pk = ws_alloc<uint4>(ctx, nit);
       Y.nex = ws_alloc<uint32_t>(ctx, nit);
@@ -1590,7 +1606,7 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       TBK_LAUNCH(ctx, "yd_groups", yd_groups_k, cdiv(ng, B), B, 0, I, ng, J.gperm, J.G, J.shi, J.slo, Q);
       TBK_TRY(tbk_exscan_u32(ctx, Q.nex, Q.xoff, ng, sc + 5));
       if (by_list) {
-        TBK_LAUNCH(ctx, "yd_scatter", yd_lscatter_k, ys_tiles, YS_NT, 0, S, ys_tiles, ys_table, ys_totals, ys_files, Q, Y, iv);
+        TBK_LAUNCH(ctx, "yd_scatter", yd_lscatter_k, ys_tiles, YS_NT, 0, S, ys_tiles, ys_table, ys_totals, ys_files, Q, Y, io);
       } else {  // stable split by list id (file * 2 + strand list); group order is already in place.  The id range is known:
         uint32_t bits = 1;  // no scan for the varying bits
         while ((1ull << bits) < 2ull * I.k) ++bits;
@@ -1651,17 +1667,17 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       if (n_long) {
         hipStream_t keep = ctx->stream;
         if (aux) ctx->stream = aux;
-        TBK_LAUNCH(ctx, "yd_wave", yd_wave_k, n_long, 64, 0, ids_long, n_wave, nchains, nit, chain_first, Y, iv, noff, ex_s, ex_e, J.g_yd,
+        TBK_LAUNCH(ctx, "yd_wave", yd_wave_k, n_long, 64, 0, ids_long, n_wave, nchains, nit, chain_first, Y, YdWords{iv, io}, noff, ex_s, ex_e, J.g_yd,
                    ids_over, n_over);
         ctx->stream = keep;
         if (aux) TBK_HIP(hipEventRecord(ctx->aux_done, aux));
       }
       if (n_lane)
-        TBK_LAUNCH(ctx, "yd_lane", yd_lane_k<8>, cdiv(n_lane, 64), 64, 0, ids_lane, n_lane, nchains, nit, chain_first, Y, iv, ex_s, ex_e, J.g_yd,
+        TBK_LAUNCH(ctx, "yd_lane", yd_lane_k<8>, cdiv(n_lane, 64), 64, 0, ids_lane, n_lane, nchains, nit, chain_first, Y, YdWords{iv, io}, ex_s, ex_e, J.g_yd,
                    ids_over, n_over);
       if (n_long && aux) TBK_HIP(hipStreamWaitEvent(ctx->stream, ctx->aux_done, 0));
       // chains whose list outgrew its lane's / wave's slots (count only known on the device: launch for the upper bound)
-      TBK_LAUNCH(ctx, "yd_run_overflow", yd_run_k, cdiv(nchains, 64), 64, 0, ids_over, n_over, nchains, nit, chain_first, Y, iv, noff, ex_s, ex_e,
+      TBK_LAUNCH(ctx, "yd_run_overflow", yd_run_k, cdiv(nchains, 64), 64, 0, ids_over, n_over, nchains, nit, chain_first, Y, YdWords{iv, io}, noff, ex_s, ex_e,
                  N, J.g_yd);
     }
   }
