@@ -21,10 +21,14 @@ def ctx():
     c.close()
 
 
-@pytest.fixture(params=["1", "0"], ids=["raw", "compacted"])
+@pytest.fixture(params=["1", "0", "dense"], ids=["raw", "compacted", "raw-dense-verify"])
 def window_mode(request, monkeypatch):
+    """raw: the records whose key word is hashed are listed per window for the verification pass; raw-dense-verify: they are
+    marked in a per-record array instead (TBK_WG_DENSE_VERIFY, the form -L and the record -> group map always take)"""
     monkeypatch.setenv("TBK_PATH", "window")
-    monkeypatch.setenv("TBK_RAW", request.param)
+    monkeypatch.setenv("TBK_RAW", "1" if request.param == "dense" else request.param)
+    if request.param == "dense":
+        monkeypatch.setenv("TBK_WG_DENSE_VERIFY", "1")
     return request.param
 
 

@@ -238,6 +238,9 @@ struct WgRaw {                 // raw mode: the window kernels read the records 
   unsigned long long* n_slots; // records that left a slot in cslot (0: wg_finish_raw_k has nothing to do)
   uint32_t all_slots;          // 1: every passing record leaves its group slot in cslot (record -> group map wanted); 0: only the
                                // records whose key word is not exact (they are verified by wg_finish_raw_k)
+  uint32_t sparse;             // (all_slots == 0) 1: those few records are listed per window — entry e of window w is record
+                               // vsrc[wbase + e] with slot cslot[wbase + e], vcnt[w] entries — instead of marked in a cslot array that has
+                               // to be cleared and searched record by record (1.3 GB each way on config 3 for 3 % of the records)
 };
 // Inclusive prefix maximum of x inside segments (f = 1: a segment starts at this lane), wave wide, DPP only.  Returns the scanned
 // value; *fo = 1 when a segment start lies at or before this lane (the carry from earlier waves does not reach it).
@@ -330,6 +333,8 @@ struct WgTemp {                // per window, at the window's record base
   uint32_t* pinc;              // incidence: sample | window-local group << 16
   uint32_t *wg_cnt, *wp_cnt;   // per window: groups, incidences
   uint32_t* wbase;             // [nw + 1] per window: record base (wg_rowsum_k)
+  uint32_t* vsrc;              // sparse verification list (WgRaw::sparse): the records ...
+  uint32_t* vcnt;              // ... and their number per window
   uint32_t* cslot;             // [compacted record] window base + number of the record's group inside the window ...
   uint32_t* c2r;               // ... and from that number to the group's temp slot (window base + rank by key)
   uint32_t *yx, *yd;           // PART only: per group sum of the carried YX, maximum of the carried YD
@@ -818,8 +823,14 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
         const uint32_t s = slot[u];
         if (thi[s] != kh[u] || tlo[s] != kl[u]) atomicOr(err, TBK_DERR_COLLISION);  // two keys, one fingerprint
         if (!RAW || R.all_slots || !((kl[u] >> 31) & 1ull)) {
-          T.cslot[src[u]] = wbase + tci[s];
-          ++nslot_t;
+          if (RAW && R.sparse) {
+            const uint32_t e = atomicAdd(&s_misc[3], 1u);  // (< n_w: one entry per record at most)
+            T.vsrc[wbase + e] = src[u];
+            T.cslot[wbase + e] = wbase + tci[s];
+          } else {
+            T.cslot[src[u]] = wbase + tci[s];
+            ++nslot_t;
+          }
         }
         const unsigned long long rr = ((unsigned long long)eff[u] << 32) | rec[u];
         if (rr < trep[s]) atomicMin(&trep[s], rr);
@@ -894,6 +905,7 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
     __syncthreads();
     if (RAW && t == 0 && s_misc[2]) atomicAdd(R.n_pass, (unsigned long long)s_misc[2]);
     if (RAW && t == 0 && s_misc[3]) atomicAdd(R.n_slots, (unsigned long long)s_misc[3]);
+    if (RAW && t == 0 && R.sparse) T.vcnt[w] = s_misc[3];
     for (uint32_t g = t; g < d; g += WG_NT) {
       const uint32_t s = byrank[g];
       T.hi[wbase + g] = thi[s];
@@ -982,7 +994,7 @@ __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgRaw R, WgTemp T
   __shared__ uint32_t pre[1024 + 1];
   __shared__ uint32_t sm_u[WG_NW];
   __shared__ uint2 s_agg[WG_NW];
-  __shared__ uint32_t s_carry, s_np;
+  __shared__ uint32_t s_carry, s_np, s_vn;
   const uint32_t t = threadIdx.x;
   const uint32_t k = In.k;
   const uint32_t cnt = ovf[0] < ovf_cap ? ovf[0] : ovf_cap;
@@ -997,6 +1009,7 @@ __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgRaw R, WgTemp T
         atomicMax(&T.dbg[kind * 4 + 3], __builtin_readcyclecounter() - t_start);
       }
     };
+    if (t == 0) s_vn = 0;
     __syncthreads();  // (LDS of the previous window is free)
     uint32_t n_w, wbase;
     (void)wg_prologue(In, w, pre, sm_u, &n_w, &wbase);
@@ -1158,7 +1171,13 @@ __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgRaw R, WgTemp T
             ++pl;
           }
           if (!RAW || R.all_slots || !((lo[ix[u]] >> 31) & 1ull)) {
-            T.cslot[srci[u]] = wbase + gl[u];
+            if (RAW && R.sparse) {
+              const uint32_t e = atomicAdd(&s_vn, 1u);
+              T.vsrc[wbase + e] = srci[u];
+              T.cslot[wbase + e] = wbase + gl[u];
+            } else {
+              T.cslot[srci[u]] = wbase + gl[u];
+            }
             if (RAW) atomicAdd(R.n_slots, 1ull);  // (the rare tier: no aggregation)
           }
         }
@@ -1166,6 +1185,7 @@ __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgRaw R, WgTemp T
     }
     const unsigned long long t_heads = T.dbg ? __builtin_readcyclecounter() : 0ull;
     __syncthreads();  // hi / lo are dead from here: their space holds the per-group accumulators
+    if (RAW && t == 0 && R.sparse) T.vcnt[w] = s_vn;
     uint32_t* gcnt = reinterpret_cast<uint32_t*>(lds);
     uint32_t* gns = gcnt + WG_CAP;
     unsigned long long* grep = reinterpret_cast<unsigned long long*>(gns + WG_CAP);
@@ -1298,6 +1318,21 @@ __global__ void wg_tie_k(uint32_t ng, const uint64_t* __restrict__ ghi, const ui
   uint32_t sg = blockIdx.x * blockDim.x + threadIdx.x;
   if (sg >= ng) return;
   tie[sg] = (sg == 0 || ghi[sg] != ghi[sg - 1] || (glo[sg] >> 32) != (glo[sg - 1] >> 32)) ? 1 : 0;
+}
+// RAW, sparse list (WgRaw::sparse): one 64-thread block per window walks the window's entries
+__global__ __launch_bounds__(64) void wg_finish_sparse_k(uint32_t nw, const uint32_t* __restrict__ wbase, const uint32_t* __restrict__ vcnt,
+                                                         const uint32_t* __restrict__ vsrc, const uint32_t* __restrict__ cslot,
+                                                         const uint32_t* __restrict__ c2r, const unsigned long long* __restrict__ trep, ColIn I,
+                                                         int strategy, uint32_t* __restrict__ err) {
+  const uint32_t w = blockIdx.x;
+  const uint32_t n = vcnt[w];
+  if (!n) return;
+  const uint32_t wb = wbase[w];
+  for (uint32_t e = threadIdx.x; e < n; e += 64) {
+    const uint32_t j = vsrc[wb + e];
+    const uint32_t anchor = (uint32_t)(trep[c2r[cslot[wb + e]]] & 0xFFFFFFFFull);
+    if (anchor != j && !strategy_equal(I, strategy, j, anchor)) atomicOr(err, TBK_DERR_COLLISION);
+  }
 }
 // One thread per compacted record: its group's temp slot from (cslot, c2r); the strategy key of every record whose key word is
 // not exact (bit 31 of the hash word, col_keys_k) is compared with its group's representative — a member of the group — so a
@@ -1643,6 +1678,7 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
     R.O.seed = seed;
     R.n_pass = (unsigned long long*)(ctx->d_scalars + 0);
     R.all_slots = want_rec_sg ? 1u : 0u;
+    R.sparse = (!want_rec_sg && strategy != TBK_STRAT_FULL && !getenv("TBK_WG_DENSE_VERIFY")) ? 1u : 0u;  // (-L has no exact key words: every record is verified)
     R.n_slots = (unsigned long long*)(ctx->d_scalars + 6);
     scratch_hi = ws_alloc<uint64_t>(ctx, m);
     scratch_lo = ws_alloc<uint64_t>(ctx, m);
@@ -1684,6 +1720,14 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   T.wp_cnt = ws_alloc<uint32_t>(ctx, nw);
   T.wbase = ws_alloc<uint32_t>(ctx, (size_t)nw + 1);
   T.cslot = ws_alloc<uint32_t>(ctx, m);
+  T.vsrc = nullptr;
+  T.vcnt = nullptr;
+  if (raw && R.sparse) {
+    T.vsrc = ws_alloc<uint32_t>(ctx, m);
+    T.vcnt = ws_alloc<uint32_t>(ctx, nw);
+    if (!T.vsrc || !T.vcnt) return TBK_ENOMEM;
+    TBK_HIP(hipMemsetAsync(T.vcnt, 0, (size_t)nw * 4, ctx->stream));
+  }
   T.c2r = ws_alloc<uint32_t>(ctx, m);
   uint32_t* gbase = ws_alloc<uint32_t>(ctx, nw);
   uint32_t* pbase = ws_alloc<uint32_t>(ctx, nw);
@@ -1699,7 +1743,7 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
     if (T.dbg) TBK_HIP(hipMemsetAsync(T.dbg, 0, 32 * 8, ctx->stream));
   }
   if (!T.pinc || !pbase || !T.c2r) return TBK_ENOMEM;
-  if (raw) TBK_HIP(hipMemsetAsync(T.cslot, 0xFF, (size_t)m * 4, ctx->stream));  // (only the records wg_finish_raw_k must visit get a slot)
+  if (raw && !R.sparse) TBK_HIP(hipMemsetAsync(T.cslot, 0xFF, (size_t)m * 4, ctx->stream));  // (only the records wg_finish_raw_k must visit get a slot)
   WgIn In{chi, clo, cval, ceff, off, W, k, nw};
   const uint32_t nwords = cdiv(k, 32);
   // LDS of the hash kernel: the pieces' tables (8 k + 4 bytes) and the group table share WG_LDS_HASH (four blocks per CU)
@@ -1846,7 +1890,9 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
     TBK_LAUNCH(ctx, "wg_tie", wg_tie_k, cdiv(ng, B), B, 0, ng, out->ghi, out->glo, out->tie);
     if (want_rec_sg) TBK_HIP(hipMemsetAsync(out->rec_sg, 0xFF, (size_t)I.n * 4, ctx->stream));  // (records that did not pass)
     if (raw) {  // (nothing to verify and no record -> group map wanted: every key word was exact)
-      if (ctx->h_scalars[6] != 0)
+      if (ctx->h_scalars[6] != 0 && R.sparse)
+        TBK_LAUNCH(ctx, "wg_finish", wg_finish_sparse_k, nw, 64, 0, nw, T.wbase, T.vcnt, T.vsrc, T.cslot, T.c2r, T.rep, I, strategy, ctx->d_err);
+      else if (ctx->h_scalars[6] != 0)
         TBK_LAUNCH(ctx, "wg_finish", wg_finish_raw_k, cdiv(m, B), B, 0, m, T.cslot, T.c2r, T.rep, slot2sg, out->rec_sg, I, strategy, ctx->d_err);
     } else
       TBK_LAUNCH(ctx, "wg_finish", wg_finish_k, cdiv(m, B), B, 0, m, clo, cval, T.cslot, T.c2r, T.rep, slot2sg, out->rec_sg, I, strategy,
