@@ -1543,7 +1543,8 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
   {
     uint32_t *icnt = nullptr, *ioff = nullptr, *ocnt = nullptr, *ooff = nullptr;
     uint64_t nit64;
-    const bool by_list = J.win && 2u * I.k <= YS_NL && !getenv("TBK_YD_RADIX");  // (TBK_YD_RADIX: test hook, the radix split of round 2)
+    const bool by_list = J.win && (!J.pgrp || tbk_yd_by_list(I.k));  // (no per-incidence group array: the window stage has decided)
+    static_assert(YS_NL == 128, "tbk_yd_by_list (wgroup.h) knows the number of lists");
     const uint32_t ys_tiles = cdiv(ng, YS_NT);
     const YsIn S{ng, J.gperm, J.G.ns, J.gpoff, J.pfile, J.shi};
     uint32_t* ys_table = nullptr;

@@ -1,5 +1,7 @@
 // wgroup.h — host interface of the window path (wgroup.hip) used by the collapse pipeline (collapse.hip).
 #pragma once
+#include <stdlib.h>
+
 #include "strategy.cuh"
 #include "tbk_internal.h"
 
@@ -9,7 +11,7 @@ struct WgOut {
   uint32_t* gmem = nullptr;         // [ng] the representative record of the group (any member serves the comparators)
   uint32_t* gpoff = nullptr;        // [ng] first incidence of the group
   uint16_t* pfile = nullptr;        // [np] sample (input file) of the incidence; a group's incidences are in file order
-  uint32_t* pgrp = nullptr;         // [np] group of the incidence
+  uint32_t* pgrp = nullptr;         // [np] group of the incidence; null when the YD stage places its items by list (tbk_yd_by_list)
   uint32_t* rec_sg = nullptr;       // optional [n]: group (key order) of every passing record, 0xFFFFFFFF otherwise
   // per-group accumulators, as the sort path's reduction leaves them
   double* yc = nullptr;
@@ -37,6 +39,9 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
 //  — WgOut::yc is the sum of the carried integral YC, yxin / ydin the sum / maximum of the carried YX / YD, no
 // incidences (np = 0); TBK_DERR_FRACTIONAL in *err_bits: a carried value this form cannot hold — run the sort path.
 bool tbk_window_supported(uint32_t k);
+// The YD stage of a window-path tile places its items by list without a sort when the tile has at most 64 input files (collapse.hip:
+// yd_lcount_k / yd_lscatter_k) and needs no per-incidence group array then (TBK_YD_RADIX: test hook, the radix split for any tile).
+inline bool tbk_yd_by_list(uint32_t k) { return 2u * k <= 128u && !getenv("TBK_YD_RADIX"); }
 
 // Owner side of the group-partials protocol: merge n_runs runs of partial rows (TBK_PARTIAL_ROW words each, every
 // run in its rank's output order) in output order and reduce equal keys; see tbk_partial_reduce in include/tbk.h.  The arena

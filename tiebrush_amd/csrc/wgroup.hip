@@ -1311,7 +1311,7 @@ __global__ __launch_bounds__(64) void wg_compact_k(uint32_t nw, WgTemp T, const 
   for (uint32_t p = threadIdx.x; p < np; p += 64) {
     const uint32_t pi = T.pinc[wb + p];
     F.pfile[pb + p] = (uint16_t)pi;
-    F.pgrp[pb + p] = gb + (pi >> 16);
+    if (F.pgrp) F.pgrp[pb + p] = gb + (pi >> 16);
   }
 }
 __global__ void wg_tie_k(uint32_t ng, const uint64_t* __restrict__ ghi, const uint64_t* __restrict__ glo, uint8_t* __restrict__ tie) {
@@ -1872,7 +1872,7 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   out->gmem = ws_alloc<uint32_t>(ctx, ng);
   out->gpoff = ws_alloc<uint32_t>(ctx, ng);
   out->pfile = ws_alloc<uint16_t>(ctx, np);
-  out->pgrp = ws_alloc<uint32_t>(ctx, np);
+  out->pgrp = tbk_yd_by_list(k) ? nullptr : ws_alloc<uint32_t>(ctx, np);
   out->yc = ws_alloc<double>(ctx, ng);
   out->ns = ws_alloc<uint32_t>(ctx, ng);
   out->yxin = ws_alloc<long long>(ctx, ng);
