@@ -448,6 +448,7 @@ struct YsIn {
   const uint32_t* gpoff;  // first incidence of a group (its incidences are in file order)
   const uint16_t* pfile;
   const uint64_t* ghi;    // group key: strand code in the low two bits
+  const uint64_t* gfmask; // the group's files as a bit mask (WgOut::gfmask), or null: walk the incidences
 };
 // the lists of a group as a 128-bit mask, from the 64-bit set of its files and its strand code ('.' feeds both lists of a file,
 // tiebrush.cpp:515-520)
@@ -491,9 +492,13 @@ __global__ __launch_bounds__(YS_NT) void yd_lcount_k(YsIn S, uint32_t ntiles, ui
     const uint32_t o = blockIdx.x * YS_NT + threadIdx.x;
     if (o < S.ng) {
       const uint32_t sg = S.gperm[o];
-      const uint32_t n = S.ns[sg], c = (uint32_t)S.ghi[sg] & 3u, p0 = S.gpoff[sg];
+      const uint32_t c = (uint32_t)S.ghi[sg] & 3u;
+      const uint32_t n = S.gfmask ? 0u : S.ns[sg], p0 = S.gfmask ? 0u : S.gpoff[sg];
       uint64_t files = 0;
-      for (uint32_t i = 0; i < n; ++i) files |= 1ull << S.pfile[p0 + i];
+      if (S.gfmask)
+        files = S.gfmask[sg];
+      else
+        for (uint32_t i = 0; i < n; ++i) files |= 1ull << S.pfile[p0 + i];
       gfiles[2 * (size_t)o] = files;
       gfiles[2 * (size_t)o + 1] = c;
       ys_mask_from_files(files, c, &lo, &hi);
@@ -1524,6 +1529,7 @@ struct YdJob {  // everything the YD stage needs from the main stage (device poi
   uint32_t np = 0;
   const uint16_t* pfile = nullptr;
   const uint32_t *pgrp = nullptr, *gpoff = nullptr;
+  const uint64_t* gfmask = nullptr;  // (window path, <= 64 files) the groups' files as bit masks instead of incidences
 };
 
 }  // namespace
@@ -1546,7 +1552,7 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
     const bool by_list = J.win && (!J.pgrp || tbk_yd_by_list(I.k));  // (no per-incidence group array: the window stage has decided)
     static_assert(YS_NL == 128, "tbk_yd_by_list (wgroup.h) knows the number of lists");
     const uint32_t ys_tiles = cdiv(ng, YS_NT);
-    const YsIn S{ng, J.gperm, J.G.ns, J.gpoff, J.pfile, J.shi};
+    const YsIn S{ng, J.gperm, J.G.ns, J.gpoff, J.pfile, J.shi, J.gfmask};
     uint32_t* ys_table = nullptr;
     uint64_t* ys_totals = nullptr;
     uint64_t* ys_files = nullptr;
@@ -2129,6 +2135,7 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
     job->pfile = win_out.pfile;
     job->pgrp = win_out.pgrp;
     job->gpoff = win_out.gpoff;
+    job->gfmask = win_out.gfmask;
   }
   job->val = sb.val;
   job->flags = flags;

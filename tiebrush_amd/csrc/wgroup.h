@@ -12,6 +12,7 @@ struct WgOut {
   uint32_t* gpoff = nullptr;        // [ng] first incidence of the group
   uint16_t* pfile = nullptr;        // [np] sample (input file) of the incidence; a group's incidences are in file order
   uint32_t* pgrp = nullptr;         // [np] group of the incidence; null when the YD stage places its items by list (tbk_yd_by_list)
+  uint64_t* gfmask = nullptr;       // [ng] (<= 64 files and tbk_yd_by_list) the group's files as a bit mask: np = 0, no incidence arrays
   uint32_t* rec_sg = nullptr;       // optional [n]: group (key order) of every passing record, 0xFFFFFFFF otherwise
   // per-group accumulators, as the sort path's reduction leaves them
   double* yc = nullptr;

@@ -333,6 +333,8 @@ struct WgTemp {                // per window, at the window's record base
   uint32_t* pinc;              // incidence: sample | window-local group << 16
   uint32_t *wg_cnt, *wp_cnt;   // per window: groups, incidences
   uint32_t* wbase;             // [nw + 1] per window: record base (wg_rowsum_k)
+  uint64_t* fmask;             // (<= 64 files, the YD stage places its items by list: tbk_yd_by_list) the set of a group's files as a
+                               // bit mask instead of the incidence list pinc: nothing downstream walks incidences then
   uint32_t* vsrc;              // sparse verification list (WgRaw::sparse): the records ...
   uint32_t* vcnt;              // ... and their number per window
   uint32_t* cslot;             // [compacted record] window base + number of the record's group inside the window ...
@@ -872,16 +874,17 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
     phase(8);
     for (uint32_t g = t; g < d; g += WG_NT) T.c2r[wbase + tci[byrank[g]]] = wbase + g;
     __syncthreads();
+    const bool fm = !PART && T.fmask != nullptr;  // (<= 64 files) the groups' files travel as bit masks: no incidence list, no offsets
     uint32_t* nsr = tci;  // (dead from here) [d] samples per group in rank order -> offsets
-    for (uint32_t g = t; g < d; g += WG_NT) {
-      const uint32_t s = byrank[g];
-      uint32_t c = 0;
-      if constexpr (!PART)
-        for (uint32_t x = 0; x < nwords; ++x) c += (uint32_t)__builtin_popcount(tbits[s * nwords + x]);
-      nsr[g] = c;
-    }
-    __syncthreads();
-    {
+    if (!fm) {
+      for (uint32_t g = t; g < d; g += WG_NT) {
+        const uint32_t s = byrank[g];
+        uint32_t c = 0;
+        if constexpr (!PART)
+          for (uint32_t x = 0; x < nwords; ++x) c += (uint32_t)__builtin_popcount(tbits[s * nwords + x]);
+        nsr[g] = c;
+      }
+      __syncthreads();
       uint32_t carry = 0;
       for (uint32_t i0 = 0; i0 < d; i0 += WG_NT) {
         const uint32_t i = i0 + t;
@@ -891,11 +894,9 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
         if (i < d) nsr[i] = carry + ex;
         carry += tot;
       }
-      if (t == 0) {
-        T.wg_cnt[w] = d;
-        T.wp_cnt[w] = carry;
-      }
+      if (t == 0) T.wp_cnt[w] = carry;
     }
+    if (t == 0) T.wg_cnt[w] = d;  // (fm: wp_cnt[w] stays 0)
     if constexpr (RAW) {
       const uint32_t ws = wave_sum(npass_t);
       if (lane_id() == 0 && ws) atomicAdd(&s_misc[2], ws);
@@ -912,13 +913,19 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
       T.lo[wbase + g] = tlo[s];
       T.cnt[wbase + g] = tcnt[s];
       T.rep[wbase + g] = trep[s];
-      uint32_t pl = nsr[g];
-      T.poff[wbase + g] = pl;
-      uint32_t c = 0;
       if constexpr (PART) {
         T.yx[wbase + g] = tbits[s * nwords];
         T.yd[wbase + g] = tbits[s * nwords + 1];
       }
+      if (fm) {
+        const uint32_t b0 = tbits[s * nwords], b1 = nwords > 1u ? tbits[s * nwords + 1] : 0u;
+        T.fmask[wbase + g] = ((uint64_t)b1 << 32) | b0;
+        T.ns[wbase + g] = (uint32_t)(__builtin_popcount(b0) + __builtin_popcount(b1));
+        continue;
+      }
+      uint32_t pl = nsr[g];
+      T.poff[wbase + g] = pl;
+      uint32_t c = 0;
       for (uint32_t x = 0; x < (PART ? 0u : nwords); ++x) {
         uint32_t bits = tbits[s * nwords + x];
         while (bits) {
@@ -1264,7 +1271,7 @@ __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgRaw R, WgTemp T
     }
     if (t == 0) {
       T.wg_cnt[w] = ng_w;
-      T.wp_cnt[w] = np_w;
+      T.wp_cnt[w] = T.fmask ? 0u : np_w;  // (fmask mode: wg_fmask_k turns this window's incidences into masks)
     }
     dbg_done(1, n_w);
     if (T.dbg && t == 0) {
@@ -1278,7 +1285,22 @@ __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgRaw R, WgTemp T
 
 
 // ---- compaction: windows -> key order --------------------------------------------------------------------------------
+// (fmask mode) the windows the sort kernel took leave incidence lists (pinc, poff, ns): their groups' masks from those
+__global__ __launch_bounds__(64) void wg_fmask_k(const uint32_t* __restrict__ ovf, uint32_t ovf_cap, WgTemp T) {
+  const uint32_t cnt = ovf[0] < ovf_cap ? ovf[0] : ovf_cap;
+  for (uint32_t wi = blockIdx.x; wi < cnt; wi += gridDim.x) {
+    const uint32_t w = ovf[1 + wi];
+    const uint32_t ng = T.wg_cnt[w], wb = T.wbase[w];
+    for (uint32_t g = threadIdx.x; g < ng; g += 64) {
+      const uint32_t p0 = T.poff[wb + g], n = T.ns[wb + g];
+      uint64_t m = 0;
+      for (uint32_t i = 0; i < n; ++i) m |= 1ull << (T.pinc[wb + p0 + i] & 0xFFFFu);
+      T.fmask[wb + g] = m;
+    }
+  }
+}
 struct WgFinal {
+  uint64_t* fmask;
   uint64_t *ghi, *glo;
   uint32_t *gmem, *gpoff, *pgrp, *first, *ns, *slot2sg;
   uint16_t* pfile;
@@ -1305,6 +1327,7 @@ __global__ __launch_bounds__(64) void wg_compact_k(uint32_t nw, WgTemp T, const 
     F.yxin[sg] = T.yx ? (long long)T.yx[wb + g] : 0ll;
     F.ydin[sg] = T.yd ? (long long)T.yd[wb + g] : 0ll;
     F.first[sg] = sg;
+    if (F.fmask) F.fmask[sg] = T.fmask[wb + g];
     F.gpoff[sg] = pb + T.poff[wb + g];
     if (F.slot2sg) F.slot2sg[wb + g] = sg;
   }
@@ -1720,6 +1743,11 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   T.wp_cnt = ws_alloc<uint32_t>(ctx, nw);
   T.wbase = ws_alloc<uint32_t>(ctx, (size_t)nw + 1);
   T.cslot = ws_alloc<uint32_t>(ctx, m);
+  T.fmask = nullptr;
+  if (raw && !part && k <= 64 && tbk_yd_by_list(k)) {
+    T.fmask = ws_alloc<uint64_t>(ctx, m);
+    if (!T.fmask) return TBK_ENOMEM;
+  }
   T.vsrc = nullptr;
   T.vcnt = nullptr;
   if (raw && R.sparse) {
@@ -1837,6 +1865,7 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   } else {
     TBK_LAUNCH(ctx, "wg_sort", (wg_sort_k<false, -1>), std::min<uint32_t>(nw, 1024u), WG_NT, 0, In, R, T, I, strategy, ovf, ovf_cap, ctx->d_err);
   }
+  if (T.fmask) TBK_LAUNCH(ctx, "wg_fmask", wg_fmask_k, std::min<uint32_t>(nw, 1024u), 64, 0, ovf, ovf_cap, T);
   uint64_t* sc = ctx->d_scalars;
   TBK_TRY(tbk_exscan_u32(ctx, T.wg_cnt, gbase, nw, sc + 1));
   TBK_TRY(tbk_exscan_u32(ctx, T.wp_cnt, pbase, nw, sc + 2));
@@ -1871,6 +1900,8 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   out->glo = ws_alloc<uint64_t>(ctx, ng);
   out->gmem = ws_alloc<uint32_t>(ctx, ng);
   out->gpoff = ws_alloc<uint32_t>(ctx, ng);
+  out->gfmask = T.fmask ? ws_alloc<uint64_t>(ctx, ng) : nullptr;
+  if (T.fmask && !out->gfmask) return TBK_ENOMEM;
   out->pfile = ws_alloc<uint16_t>(ctx, np);
   out->pgrp = tbk_yd_by_list(k) ? nullptr : ws_alloc<uint32_t>(ctx, np);
   out->yc = ws_alloc<double>(ctx, ng);
@@ -1884,7 +1915,7 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   out->rec_sg = want_rec_sg ? ws_alloc<uint32_t>(ctx, I.n) : nullptr;
   if (!out->tie || (want_rec_sg && !out->rec_sg)) return TBK_ENOMEM;
   if (ng) {
-    WgFinal F{out->ghi, out->glo, out->gmem, out->gpoff, out->pgrp, out->first, out->ns, slot2sg, out->pfile, out->yc, out->yxin,
+    WgFinal F{out->gfmask, out->ghi, out->glo, out->gmem, out->gpoff, out->pgrp, out->first, out->ns, slot2sg, out->pfile, out->yc, out->yxin,
               out->ydin, out->rep};
     TBK_LAUNCH(ctx, "wg_compact", wg_compact_k, nw, 64, 0, nw, T, gbase, pbase, F);
     TBK_LAUNCH(ctx, "wg_tie", wg_tie_k, cdiv(ng, B), B, 0, ng, out->ghi, out->glo, out->tie);
