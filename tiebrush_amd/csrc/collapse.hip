@@ -1470,7 +1470,7 @@ __global__ void col_write_yd_k(uint32_t ng, const uint32_t* __restrict__ gperm, 
                                uint32_t cap, int32_t* __restrict__ yd) {
   uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= ng || o >= cap) return;
-  int dmax = (int)G.ydin[gperm[o]];  // int dmax=spd.maxYD (tiebrush.cpp:511)
+  int dmax = G.ydin ? (int)G.ydin[gperm[o]] : 0;  // int dmax=spd.maxYD (tiebrush.cpp:511); null: no carried YD (plain inputs, window path)
   int d2 = g_yd[o];
   if (d2 > dmax) dmax = d2;
   yd[o] = dmax > 0 ? dmax : 0;
@@ -1488,7 +1488,7 @@ __global__ void col_write_k(const uint64_t* __restrict__ png, const uint32_t* __
   rep[o] = (uint32_t)(G.rep[sg] & 0xFFFFFFFFull);
   if (rep_effend) rep_effend[o] = effend ? effend[rep[o]] : (int32_t)(uint32_t)(G.rep[sg] >> 32);
   yc[o] = G.yc[sg];
-  yx[o] = (int64_t)G.yxin[sg] + (int64_t)G.ns[sg];
+  yx[o] = (G.yxin ? (int64_t)G.yxin[sg] : 0ll) + (int64_t)G.ns[sg];
   uint32_t q = G.first[sg];
   int32_t st = (int32_t)(uint32_t)((shi[q] >> 2) & 0x7FFFFFFFull);
   if (g_start) g_start[o] = st;

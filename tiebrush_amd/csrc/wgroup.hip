@@ -1324,11 +1324,13 @@ __global__ __launch_bounds__(64) void wg_compact_k(uint32_t nw, WgTemp T, const 
     F.gmem[sg] = (uint32_t)(r & 0xFFFFFFFFull);
     F.yc[sg] = (double)T.cnt[wb + g];
     F.ns[sg] = T.ns[wb + g];
-    F.yxin[sg] = T.yx ? (long long)T.yx[wb + g] : 0ll;
-    F.ydin[sg] = T.yd ? (long long)T.yd[wb + g] : 0ll;
+    if (F.yxin) {  // (group partials only: plain inputs carry no YX / YD — the arrays are null and the writers of the results know)
+      F.yxin[sg] = (long long)T.yx[wb + g];
+      F.ydin[sg] = (long long)T.yd[wb + g];
+    }
     F.first[sg] = sg;
     if (F.fmask) F.fmask[sg] = T.fmask[wb + g];
-    F.gpoff[sg] = pb + T.poff[wb + g];
+    if (!F.fmask) F.gpoff[sg] = pb + T.poff[wb + g];  // (file masks: no incidence list to point into)
     if (F.slot2sg) F.slot2sg[wb + g] = sg;
   }
   for (uint32_t p = threadIdx.x; p < np; p += 64) {
@@ -1906,8 +1908,9 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   out->pgrp = tbk_yd_by_list(k) ? nullptr : ws_alloc<uint32_t>(ctx, np);
   out->yc = ws_alloc<double>(ctx, ng);
   out->ns = ws_alloc<uint32_t>(ctx, ng);
-  out->yxin = ws_alloc<long long>(ctx, ng);
-  out->ydin = ws_alloc<long long>(ctx, ng);
+  out->yxin = part ? ws_alloc<long long>(ctx, ng) : nullptr;
+  out->ydin = part ? ws_alloc<long long>(ctx, ng) : nullptr;
+  if (part && !out->ydin) return TBK_ENOMEM;
   out->rep = ws_alloc<unsigned long long>(ctx, ng);
   out->first = ws_alloc<uint32_t>(ctx, ng);
   out->tie = ws_alloc<uint8_t>(ctx, ng);
