@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TBK_ABI_VERSION 3
+#define TBK_ABI_VERSION 4
 
 typedef struct tbk_ctx tbk_ctx;
 
@@ -133,6 +133,11 @@ typedef struct tbk_groups_out {
   int32_t* rec_group;    /* optional [n_records]: output index of each record's group, -1 = filtered */
   int32_t* rep_effend;   /* optional: merge-order key of the representative = running max of `end` in its file
                             (tmerge.h:28-50); what a cross-rank stitch needs to pick the global representative */
+  uint64_t* g_key;       /* optional [2 * cap_groups]: where the group lies and, when it is that simple, what its alignment looks like —
+                            word 0 = tid + 1 : 31 | 1-based start : 31 | strand code : 2 ('+' 0, '-' 1, '.' 2), word 1 = span : 32 |
+                            shape : 32, shape = 0x80000000 (one M of `span` bases, soft clips aside), 0xC0000000 | a << 20 | g (a M, g N,
+                            span - a - g M), or 0 (anything else: look at the representative).  With it tbk_groups_to_cov_in builds
+                            the tiecov input of the representatives without fetching them (GSam.cpp:351-417 gives the same exons) */
   uint32_t n_groups;     /* written by the callee = outCounter (tiebrush.cpp:528)     */
   uint32_t n_passed;     /* written by the callee = inCounter  (tiebrush.cpp:573)     */
 } tbk_groups_out;

@@ -42,7 +42,7 @@ class SoaIn(C.Structure):
 
 class GroupsOut(C.Structure):
     _fields_ = [("mem", C.c_int32), ("cap_groups", C.c_uint32), ("rep", _P), ("yc", _P), ("yx", _P), ("yd", _P),
-                ("g_start", _P), ("g_end", _P), ("rec_group", _P), ("rep_effend", _P), ("n_groups", C.c_uint32),
+                ("g_start", _P), ("g_end", _P), ("rec_group", _P), ("rep_effend", _P), ("g_key", _P), ("n_groups", C.c_uint32),
                 ("n_passed", C.c_uint32)]
 
 

@@ -152,7 +152,7 @@ class Context:
         if device_mode:
             torch = _torch()
             td = {np.int32: torch.int32, np.uint32: torch.int32, np.uint8: torch.uint8, np.float64: torch.float64,
-                  np.int64: torch.int64, np.float32: torch.float32}[dtype]
+                  np.int64: torch.int64, np.uint64: torch.int64, np.float32: torch.float32}[dtype]
             return torch.empty(n, dtype=td, device="cuda:%d" % self.device)
         return np.empty(n, dtype=dtype)
 
@@ -199,9 +199,11 @@ class Context:
         return s, dev, n
 
     def collapse(self, tile: SoATile, opts=None, want_coords=True, want_rec_group=False, want_effend=False, out=None,
-                 raw=False, **kw):
-        """Collapse one tile.  Returns a dict (rep, yc, yx, yd[, g_start, g_end, rec_group], n_groups,
-        n_passed) in the reference's output order.  `out` may carry preallocated buffers to reuse."""
+                 raw=False, want_key=None, **kw):
+        """Collapse one tile.  Returns a dict (rep, yc, yx, yd[, g_start, g_end, rec_group, g_key], n_groups,
+        n_passed) in the reference's output order.  `out` may carry preallocated buffers to reuse.
+        want_key (default: device tiles): tbk_groups_out.g_key — groups_to_cov_in then builds the tiecov input of the
+        representatives from the keys instead of fetching every representative."""
         o = opts if opts is not None else self.make_opts(**kw)
         keep = []
         s, dev, n = self._soa_struct(tile, keep)
@@ -221,9 +223,12 @@ class Context:
         gs, ge = buf("g_start", cap, np.int32, want_coords), buf("g_end", cap, np.int32, want_coords)
         rg = buf("rec_group", cap, np.int32, want_rec_group)
         re_ = buf("rep_effend", cap, np.int32, want_effend)
+        want_key = bool(dev) if want_key is None else want_key
+        gk = buf("g_key", 2 * cap, np.uint64, want_key)
         g = _lib.GroupsOut(s.mem, cap, _addr(rep, np.uint32, keep), _addr(yc, np.float64, keep),
                            _addr(yx, np.int64, keep), _addr(yd, np.int32, keep), _addr(gs, np.int32, keep),
-                           _addr(ge, np.int32, keep), _addr(rg, np.int32, keep), _addr(re_, np.int32, keep), 0, 0)
+                           _addr(ge, np.int32, keep), _addr(rg, np.int32, keep), _addr(re_, np.int32, keep),
+                           _addr(gk, np.uint64, keep), 0, 0)
         self._check(self.L.tbk_collapse_tile(self.h, C.byref(o), C.byref(s), C.byref(g)), "tbk_collapse_tile")
         m = int(g.n_groups)
         res = dict(n_groups=m, n_passed=int(g.n_passed), _bufs=bufs, _struct=g, _soa=s, _keep=keep)
@@ -236,6 +241,8 @@ class Context:
             res["rec_group"] = rg[:n]
         if want_effend:
             res["rep_effend"] = re_[:m]
+        if want_key:
+            res["g_key"] = gk[:2 * m]
         return res
 
     def groups_to_cov_in(self, collapse_result) -> DeviceCovView:
@@ -333,7 +340,7 @@ class Context:
         ge = torch.empty(cap, dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
         g = _lib.GroupsOut(_lib.TBK_MEM_DEVICE, cap, rep.data_ptr(), yc.data_ptr(), yx.data_ptr(), yd.data_ptr(), gs.data_ptr(), ge.data_ptr(),
-                           None, None, 0, 0)
+                           None, None, None, 0, 0)
         self._check(self.L.tbk_collapse_tile(self.h, C.byref(o), C.byref(s), C.byref(g)), "tbk_collapse_tile")
         m = int(g.n_groups)
         return dict(n_groups=m, n_passed=int(g.n_passed), rep=rep[:m], yc=yc[:m], yx=yx[:m], yd=yd[:m], g_start=gs[:m], g_end=ge[:m])
@@ -484,7 +491,7 @@ class Context:
             if name not in bufs or bufs[name].numel() < cap:
                 bufs[name] = torch.empty(cap, dtype=dt, device=self._dev())
         rows = rows.contiguous()
-        g = _lib.GroupsOut(_lib.TBK_MEM_DEVICE, cap, *[bufs[name].data_ptr() for name, _ in spec], None, None, 0, 0)
+        g = _lib.GroupsOut(_lib.TBK_MEM_DEVICE, cap, *[bufs[name].data_ptr() for name, _ in spec], None, None, None, 0, 0)
         v = _lib.CovIn()
         self._order_after_torch(True)
         self._check(self.L.tbk_partial_reduce(self.h, C.byref(o), C.c_void_p(rows.data_ptr()) if n2 else None, n2, ro.ctypes.data, len(ro) - 1,

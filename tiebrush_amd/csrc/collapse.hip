@@ -1480,7 +1480,7 @@ __global__ void col_write_k(const uint64_t* __restrict__ png, const uint32_t* __
                             const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo, uint32_t cap,
                             uint32_t* __restrict__ rep, double* __restrict__ yc, int64_t* __restrict__ yx,
                             int32_t* __restrict__ g_start, int32_t* __restrict__ g_end, const int32_t* __restrict__ effend,
-                            int32_t* __restrict__ rep_effend) {
+                            int32_t* __restrict__ rep_effend, uint64_t* __restrict__ g_key, int strategy) {
   const uint32_t ng = (uint32_t)*png;
   uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= ng || o >= cap) return;
@@ -1493,6 +1493,17 @@ __global__ void col_write_k(const uint64_t* __restrict__ png, const uint32_t* __
   int32_t st = (int32_t)(uint32_t)((shi[q] >> 2) & 0x7FFFFFFFull);
   if (g_start) g_start[o] = st;
   if (g_end) g_end[o] = st + (int32_t)(uint32_t)(slo[q] >> 32) - 1;
+  if (g_key) {  // tbk_groups_out.g_key: the place from the group key; the shape only where the key word says what the CIGAR looks like
+    const uint64_t lo = slo[q];
+    const uint32_t h32 = (uint32_t)lo;
+    uint32_t shape = 0;
+    if (strategy == TBK_STRAT_CIGAR || strategy == TBK_STRAT_CLIP) {  // (-E codes speak of exons, which may hold I and D)
+      if (h32 == (0x80000000u | C_M)) shape = 0x80000000u;
+      if ((h32 >> 30) == 3u) shape = h32;
+    }
+    g_key[2 * (size_t)o] = shi[q];
+    g_key[2 * (size_t)o + 1] = (lo & 0xFFFFFFFF00000000ull) | shape;
+  }
 }
 __global__ void col_recgroup_k(const uint64_t* __restrict__ pm, const uint32_t* __restrict__ val, const uint32_t* __restrict__ sgid,
                                const uint32_t* __restrict__ ginv, int32_t* __restrict__ rec_group) {
@@ -1916,7 +1927,7 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
       // (effend == nullptr: the effective end of the representative — or the low word of its explicit priority — rides in the
       // high word of G.rep)
       TBK_LAUNCH(ctx, "col_write", col_write_k, cdiv(ng, B), B, 0, png, gperm, G, wo.ghi, wo.glo, out->cap_groups, out->rep, out->yc,
-                 out->yx, out->g_start, out->g_end, (const int32_t*)nullptr, out->rep_effend);
+                 out->yx, out->g_start, out->g_end, (const int32_t*)nullptr, out->rep_effend, out->g_key, O.strategy);
       if (out->rec_group) TBK_LAUNCH(ctx, "col_recgroup", col_recgroup_w_k, cdiv(n, B), B, 0, n, wo.rec_sg, ginv, out->rec_group);
       TBK_TRY(tbk_sync_err(ctx, &eb));
       if (eb & TBK_DERR_COLLISION) {  // (the verification pass, wg_finish_raw_k): reseed
@@ -1987,7 +1998,7 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
       const uint64_t* png = sc + 1;  // (tbk_window_groups left the group count there)
       TBK_LAUNCH(ctx, "col_tie_sort", col_tie_sort_k, cdiv(ng, B), B, 0, I, O.strategy, png, wo.gmem, G, gperm, ginv);
       TBK_LAUNCH(ctx, "col_write", col_write_k, cdiv(ng, B), B, 0, png, gperm, G, wo.ghi, wo.glo, out->cap_groups, out->rep, out->yc,
-                 out->yx, out->g_start, out->g_end, effend, out->rep_effend);
+                 out->yx, out->g_start, out->g_end, effend, out->rep_effend, out->g_key, O.strategy);
       if (out->rec_group) TBK_LAUNCH(ctx, "col_recgroup", col_recgroup_w_k, cdiv(n, B), B, 0, n, wo.rec_sg, ginv, out->rec_group);
       TBK_TRY(tbk_sync_err(ctx, &eb));
       if (eb & TBK_DERR_COLLISION) {  // (the verification pass of the window path, wg_finish_k): reseed
@@ -2093,7 +2104,7 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
       }
     }
     TBK_LAUNCH(ctx, "col_write", col_write_k, cdiv(ng_hi, B), B, 0, png, gperm, G, s2.hi, s2.lo, out->cap_groups, out->rep, out->yc,
-               out->yx, out->g_start, out->g_end, effend, out->rep_effend);
+               out->yx, out->g_start, out->g_end, effend, out->rep_effend, out->g_key, O.strategy);
     if (out->rec_group) TBK_LAUNCH(ctx, "col_recgroup", col_recgroup_k, cdiv(m_hi, B), B, 0, pm, s2.val, sgid, ginv, out->rec_group);
     TBK_TRY(tbk_sync_err(ctx, &eb));
     if (lean) {
@@ -2162,6 +2173,54 @@ __global__ void g2c_count_k(uint32_t ng, const uint32_t* __restrict__ rep, const
   cnt[o] = cig_off[rep[o] + 1] - c0;
   cfirst[o] = c0;  // (the gather pass reads the CIGAR range from here: one scattered access fewer per representative)
 }
+// With tbk_groups_out.g_key: place, strand and — for the two shapes the key can describe — the CIGAR itself come from the key; only
+// the other groups' representatives are fetched (a few per cent of an RNA-seq sample; every fetch is a scattered access).
+__device__ __forceinline__ uint32_t g2c_key_ops(uint64_t k1) {  // CIGAR words the shape stands for (0: fetch the representative)
+  const uint32_t shape = (uint32_t)k1;
+  return shape == 0x80000000u ? 1u : ((shape >> 30) == 3u ? 3u : 0u);
+}
+__global__ void g2c_count_key_k(uint32_t ng, const uint64_t* __restrict__ key, const uint32_t* __restrict__ rep, const uint32_t* __restrict__ cig_off,
+                                uint32_t* __restrict__ cnt, uint32_t* __restrict__ cfirst) {
+  uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= ng) return;
+  uint32_t n = g2c_key_ops(key[2 * (size_t)o + 1]);
+  if (n == 0) {
+    const uint32_t c0 = cig_off[rep[o]];
+    n = cig_off[rep[o] + 1] - c0;
+    cfirst[o] = c0;
+  }
+  cnt[o] = n;
+}
+__global__ void g2c_gather_key_k(uint32_t ng, const uint64_t* __restrict__ key, const double* __restrict__ yc, const int64_t* __restrict__ yx,
+                                 const uint32_t* __restrict__ cfirst, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cig,
+                                 const uint32_t* __restrict__ ooff, uint32_t total, int32_t* __restrict__ o_tid, int32_t* __restrict__ o_pos,
+                                 uint8_t* __restrict__ o_strand, double* __restrict__ o_yc, int64_t* __restrict__ o_yx,
+                                 uint32_t* __restrict__ o_cig_off, uint32_t* __restrict__ o_cig) {
+  uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= ng) return;
+  const uint64_t k0 = key[2 * (size_t)o], k1 = key[2 * (size_t)o + 1];
+  o_tid[o] = (int32_t)(uint32_t)(k0 >> 33) - 1;
+  o_pos[o] = (int32_t)(uint32_t)((k0 >> 2) & 0x7FFFFFFFull) - 1;
+  const uint32_t sc = (uint32_t)k0 & 3u;
+  o_strand[o] = sc == 0u ? (uint8_t)'+' : (sc == 1u ? (uint8_t)'-' : (uint8_t)'.');
+  o_yc[o] = (double)(float)yc[o];  // the YC:f tag round trip (bam_aux_update_float, tiebrush.cpp:509)
+  o_yx[o] = yx[o];
+  const uint32_t d = ooff[o];
+  o_cig_off[o] = d;
+  if (o + 1 == ng) o_cig_off[ng] = total;
+  const uint32_t shape = (uint32_t)k1, span = (uint32_t)(k1 >> 32);
+  if (shape == 0x80000000u) {
+    o_cig[d] = (span << 4) | C_M;
+  } else if ((shape >> 30) == 3u) {
+    const uint32_t a = (shape >> 20) & 0x3FFu, g = shape & 0xFFFFFu;
+    o_cig[d] = (a << 4) | C_M;
+    o_cig[d + 1] = (g << 4) | C_N;
+    o_cig[d + 2] = ((span - a - g) << 4) | C_M;
+  } else {
+    const uint32_t c0 = cfirst[o], n = cnt[o];
+    for (uint32_t k = 0; k < n; ++k) o_cig[d + k] = cig[c0 + k];
+  }
+}
 __global__ void g2c_gather_k(uint32_t ng, const uint32_t* __restrict__ rep, const double* __restrict__ yc, const int64_t* __restrict__ yx,
                              const int32_t* __restrict__ tid, const int32_t* __restrict__ pos, const uint8_t* __restrict__ strand,
                              const uint32_t* __restrict__ cfirst, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cig,
@@ -2198,13 +2257,14 @@ extern "C" int tbk_groups_to_cov_in(tbk_ctx* ctx, const tbk_soa_in* in, const tb
   } prof_end{ctx};
   if (ng == 0) return 0;
   TBK_TRY(tbk_ws_reserve(ctx, (size_t)ng * 24 + ((size_t)1 << 20)));
-  return tbk_cov_view_build(ctx, in->tid, in->pos, in->strand, in->cig_off, in->cig, g->rep, g->yc, g->yx, ng, view);
+  return tbk_cov_view_build(ctx, in->tid, in->pos, in->strand, in->cig_off, in->cig, g->rep, g->yc, g->yx, ng, view, g->g_key);
 }
 
 // the view of ng representatives (rep[o] indexes the given record arrays) in context-owned memory; allocates from the arena as it
 // stands (the caller has reserved it) and synchronises the stream
 int tbk_cov_view_build(tbk_ctx* ctx, const int32_t* r_tid, const int32_t* r_pos, const uint8_t* r_strand, const uint32_t* r_cig_off,
-                       const uint32_t* r_cig, const uint32_t* g_rep, const double* g_yc, const int64_t* g_yx, uint32_t ng, tbk_cov_in* view) {
+                       const uint32_t* r_cig, const uint32_t* g_rep, const double* g_yc, const int64_t* g_yx, uint32_t ng, tbk_cov_in* view,
+                       const uint64_t* g_key) {
   memset(view, 0, sizeof(*view));
   view->mem = TBK_MEM_DEVICE;
   if (ng == 0) return 0;
@@ -2213,7 +2273,10 @@ int tbk_cov_view_build(tbk_ctx* ctx, const int32_t* r_tid, const int32_t* r_pos,
   uint32_t* cfirst = ws_alloc<uint32_t>(ctx, ng);
   if (!cfirst) return TBK_ENOMEM;
   const uint32_t B = 256;
-  TBK_LAUNCH(ctx, "g2c_count", g2c_count_k, cdiv(ng, B), B, 0, ng, g_rep, r_cig_off, cnt, cfirst);
+  if (g_key)
+    TBK_LAUNCH(ctx, "g2c_count", g2c_count_key_k, cdiv(ng, B), B, 0, ng, g_key, g_rep, r_cig_off, cnt, cfirst);
+  else
+    TBK_LAUNCH(ctx, "g2c_count", g2c_count_k, cdiv(ng, B), B, 0, ng, g_rep, r_cig_off, cnt, cfirst);
   TBK_TRY(tbk_exscan_u32(ctx, cnt, ooff, ng, ctx->d_scalars + 20));
   TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 20, ctx->d_scalars + 20, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   TBK_HIP(hipStreamSynchronize(ctx->stream));
@@ -2242,8 +2305,12 @@ int tbk_cov_view_build(tbk_ctx* ctx, const int32_t* r_tid, const int32_t* r_pos,
   int64_t* o_yx = (int64_t*)take((size_t)ng * 8);
   uint32_t* o_cig_off = (uint32_t*)take((size_t)(ng + 1) * 4);
   uint32_t* o_cig = (uint32_t*)take((size_t)total * 4 + 4);
-  TBK_LAUNCH(ctx, "g2c_gather", g2c_gather_k, cdiv(ng, B), B, 0, ng, g_rep, g_yc, g_yx, r_tid, r_pos, r_strand, cfirst, cnt, r_cig, ooff,
-             (uint32_t)total, o_tid, o_pos, o_strand, o_yc, o_yx, o_cig_off, o_cig);
+  if (g_key)
+    TBK_LAUNCH(ctx, "g2c_gather", g2c_gather_key_k, cdiv(ng, B), B, 0, ng, g_key, g_yc, g_yx, cfirst, cnt, r_cig, ooff, (uint32_t)total, o_tid, o_pos,
+               o_strand, o_yc, o_yx, o_cig_off, o_cig);
+  else
+    TBK_LAUNCH(ctx, "g2c_gather", g2c_gather_k, cdiv(ng, B), B, 0, ng, g_rep, g_yc, g_yx, r_tid, r_pos, r_strand, cfirst, cnt, r_cig, ooff,
+               (uint32_t)total, o_tid, o_pos, o_strand, o_yc, o_yx, o_cig_off, o_cig);
   TBK_HIP(hipStreamSynchronize(ctx->stream));
   TBK_TRY(tbk_check_launch(ctx, "groups_to_cov_in"));
   view->n_records = ng;

@@ -485,6 +485,7 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
     TBK_TRY(dalloc(ctx, out->g_end, cap, &dout.g_end));
     TBK_TRY(dalloc(ctx, out->rec_group, n, &dout.rec_group));
     TBK_TRY(dalloc(ctx, out->rep_effend, cap, &dout.rep_effend));
+    TBK_TRY(dalloc(ctx, out->g_key, 2 * cap, &dout.g_key));
     rc = tbk_collapse_device(ctx, opts, in, &dout);
     if (rc == 0 && ctx->yd_job) {
       void* job = ctx->yd_job;
@@ -503,6 +504,7 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
       TBK_TRY(d2h(ctx, out->g_end, dout.g_end, g));
       TBK_TRY(d2h(ctx, out->rec_group, dout.rec_group, n));
       TBK_TRY(d2h(ctx, out->rep_effend, dout.rep_effend, g));
+      TBK_TRY(d2h(ctx, out->g_key, dout.g_key, 2 * g));
       TBK_HIP(hipStreamSynchronize(ctx->stream));
     }
   } else if (in->mem == TBK_MEM_DEVICE) {
@@ -557,6 +559,7 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
     TBK_TRY(dalloc(ctx, out->g_end, cap, &dout.g_end));
     TBK_TRY(dalloc(ctx, out->rec_group, n, &dout.rec_group));
     TBK_TRY(dalloc(ctx, out->rep_effend, cap, &dout.rep_effend));
+    TBK_TRY(dalloc(ctx, out->g_key, 2 * cap, &dout.g_key));
     rc = tbk_collapse_device(ctx, opts, &din, &dout);
     if (rc == 0 && ctx->yd_job) {
       void* job = ctx->yd_job;
@@ -575,6 +578,7 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
       TBK_TRY(d2h(ctx, out->g_end, dout.g_end, g));
       TBK_TRY(d2h(ctx, out->rec_group, dout.rec_group, n));
       TBK_TRY(d2h(ctx, out->rep_effend, dout.rep_effend, g));
+      TBK_TRY(d2h(ctx, out->g_key, dout.g_key, 2 * g));
       TBK_HIP(hipStreamSynchronize(ctx->stream));
     }
   }

@@ -220,5 +220,6 @@ int tbk_collapse_yd_run(tbk_ctx* run_on, void* job);  // consumes ctx->yd_job (p
 int tbk_coverage_device(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out);
 // tiecov's input view of ng representatives (tbk_groups_to_cov_in's body; the arena must be reserved by the caller)
 int tbk_cov_view_build(tbk_ctx* ctx, const int32_t* r_tid, const int32_t* r_pos, const uint8_t* r_strand, const uint32_t* r_cig_off,
-                       const uint32_t* r_cig, const uint32_t* g_rep, const double* g_yc, const int64_t* g_yx, uint32_t ng, tbk_cov_in* view);
+                       const uint32_t* r_cig, const uint32_t* g_rep, const double* g_yc, const int64_t* g_yx, uint32_t ng, tbk_cov_in* view,
+                       const uint64_t* g_key = nullptr);
 int tbk_sample_device(tbk_ctx* ctx, const tbk_cov_in* in, int32_t num_samples, tbk_sample_out* out);
