@@ -41,9 +41,9 @@
 
 namespace {
 
-constexpr int WG_NT = 384;               // threads per window block
+constexpr int WG_NT = 512;               // threads per window block
 constexpr int WG_E = 8;                  // records per thread in the LDS path
-constexpr int WG_CAP = WG_NT * WG_E;     // 3072 records sorted in LDS
+constexpr int WG_CAP = WG_NT * WG_E;     // 4096 records sorted in LDS
 constexpr uint32_t WG_T = 1024;          // records between splitters: a window holds < 2 T + k s <= WG_CAP records
 constexpr uint32_t WG_KS = 1024;         // k * s budget
 constexpr int WG_NW = WG_NT / 64;
@@ -51,8 +51,8 @@ constexpr int WG_R = 4;                  // records per thread and chunk in the 
 constexpr int WG_RS = 1;                 // raw form: records per thread decoded together
 constexpr int WG_RR = 1;                 // raw form: records per thread and chunk.  One, not two: the kernel waits on its dependent loads
                                          // (piece -> fields -> CIGAR words) most of the time and what hides them is resident waves — at one
-                                         // record per thread it fits 64 VGPRs, eight waves per SIMD instead of six, five blocks per CU instead
-                                         // of four (config 3: 10.2 -> 8.3 ms).  Fewer instructions (a leaner fingerprint, no strategy hash, one
+                                         // record per thread it fits 64 VGPRs: eight waves per SIMD instead of six, i.e. four blocks of 512 threads per CU
+                                         // where there were four of 384 (config 3: 10.2 -> 8.3 ms).  Fewer instructions (a leaner fingerprint, no strategy hash, one
                                          // 16-byte load for six fields) had changed nothing.
 
 // ---- partition ------------------------------------------------------------------------------------------------
@@ -387,7 +387,7 @@ __device__ __forceinline__ uint32_t piece_of(const uint32_t* pre, uint32_t k, ui
 }
 
 constexpr uint32_t WG_LDS_MAIN = WG_CAP * (8 + 8 + 4 + 2 + 2);  // sort kernel: hi, lo, val, two index permutations = 72 KiB
-constexpr uint32_t WG_LDS_HASH = 31744;                        // hash kernel: the group table (five blocks per CU)
+constexpr uint32_t WG_LDS_HASH = 40448;                        // hash kernel: the group table (four blocks of eight waves per CU)
 constexpr uint32_t WG_LDS_HASH2 = 64 * 1024;                   // second tier (two blocks per CU)
 
 // Stable merge sort of the index permutation `src` (n entries, ping-pong with `dst`; returns where the result lives) by
@@ -962,7 +962,7 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
   }
 }
 
-// first tier: one block per window that holds records, a table of WG_LDS_HASH bytes (five blocks per CU)
+// first tier: one block per window that holds records, a table of WG_LDS_HASH bytes (four blocks per CU)
 constexpr int WG_GC64 = (WG_LDS_HASH - (8 * 64 + 8)) / (44 + 4 * 2);  // table slots of the <= 64 files form of the first tier
 template <bool RAW, int ST, int GC, bool PART = false>
 __global__ __launch_bounds__(WG_NT, 8) void wg_hash_k(WgIn In, WgRaw R, WgTemp T, uint32_t gcap, uint32_t nwords, uint64_t seed,
@@ -1780,7 +1780,7 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   if (raw && !R.sparse) TBK_HIP(hipMemsetAsync(T.cslot, 0xFF, (size_t)m * 4, ctx->stream));  // (only the records wg_finish_raw_k must visit get a slot)
   WgIn In{chi, clo, cval, ceff, off, W, k, nw};
   const uint32_t nwords = cdiv(k, 32);
-  // LDS of the hash kernel: the pieces' tables (8 k + 4 bytes) and the group table share WG_LDS_HASH (five blocks per CU)
+  // LDS of the hash kernel: the pieces' tables (8 k + 4 bytes) and the group table share WG_LDS_HASH (four blocks per CU)
   const uint32_t gcap = (WG_LDS_HASH - (8u * k + 8u)) / (44u + 4u * nwords);
   const uint32_t lds_hash = gcap * (44u + 4u * nwords) + 8u * k + 8u;
   TBK_LAUNCH(ctx, "wg_rowsum", wg_rowsum_k, cdiv(nrows, 4), 256, 0, off, k, nrows, T.wbase);
