@@ -9,7 +9,8 @@ import csv, json, re, sys, collections
 ALIAS = {  # kernel symbol stem -> the name bench.py reports (TBK_LAUNCH name) where the two differ
     "yd_fill_w": "yd_fill", "yd_gcount_w": "yd_gcount", "w64_scatter": "rx_scatter", "col_recgroup_w": "col_recgroup",
     "wg_offsets_stream": "wg_offsets", "wg_offsets_edges": "wg_offsets_edges", "wg_finish_raw": "wg_finish", "wg_sample_raw": "wg_sample",
-    "w64_emit_flat": "yd_scatter",
+    "w64_emit_flat": "yd_scatter", "yd_lscatter": "yd_scatter", "yd_ltotal": "yd_lscan", "g2c_gather_key": "g2c_gather", "g2c_count_key": "g2c_count",
+    "wg_finish_sparse": "wg_finish",
 }
 SCAN = {"EffKey": "col_effkey_scan", "SegMaxY": "yd_chain_scan", "SegMax": "cov_bundle_scan", "ShKey": "shard_eff_scan",
         "HeadNex": "yd_chain_number", "PmKey": "partial_emax_scan"}
