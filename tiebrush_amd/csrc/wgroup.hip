@@ -45,7 +45,7 @@ constexpr int WG_NT = 512;               // threads per window block
 constexpr int WG_E = 8;                  // records per thread in the LDS path
 constexpr int WG_CAP = WG_NT * WG_E;     // 4096 records sorted in LDS
 constexpr uint32_t WG_T = 1024;          // records between splitters: a window holds < 2 T + k s <= WG_CAP records
-constexpr uint32_t WG_KS = 1024;         // k * s budget
+constexpr uint32_t WG_KS = 2048;         // k * s budget (2 T + k s = WG_CAP)
 constexpr int WG_NW = WG_NT / 64;
 constexpr int WG_R = 4;                  // records per thread and chunk in the pile-up path
 constexpr int WG_RS = 1;                 // raw form: records per thread decoded together
