@@ -381,6 +381,46 @@ def test_deferred_yd_overlaps_tiecov_chain(ctx):
         ctx.collapse(tile, defer_yd=True)                  # host-pointer mode cannot defer
 
 
+@pytest.mark.parametrize("profile,kw,okw", [("c2", dict(), dict()), ("c3", dict(strategy="clip"), dict(strategy=2)),
+                                            ("c5", dict(strategy="exon", max_nh=5, min_qual=1), dict(strategy=3, max_nh=5, min_qual=1))])
+def test_device_chain_view_from_keys(ctx, profile, kw, okw):
+    """tbk_groups_out.g_key (ABI 4): the tiecov input of the representatives built from the group keys — the CIGAR itself for a single
+    M or M N M under the CIGAR / clip strategies, fetched otherwise (indels, three exons, -E) — gives the intervals and
+    junctions of the view that fetches every representative, and of the oracle; the key words say what tbk.h says they say"""
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import api, synth
+    tile = synth.make_tile(5, 30000, profile, n_loci=500)
+    tile.strand = tile.strand.copy()
+    tile.strand[::5] = ord(".")
+    want = orc.collapse(tile, **okw)
+    cw = orc.coverage(synth.collapsed_to_cov_input(tile, want))
+    dt = api.to_device(tile, "cuda:0")
+    covs = {}
+    for want_key in (True, False):
+        res = ctx.collapse(dt, want_key=want_key, **kw)
+        covs[want_key] = api.to_numpy(ctx.coverage(ctx.groups_to_cov_in(res)))
+        if want_key:
+            got = api.to_numpy(res)
+            key = np.asarray(got["g_key"]).view(np.uint64).reshape(-1, 2)
+            rep = np.asarray(got["rep"]).astype(np.int64)
+            assert np.array_equal((key[:, 0] >> np.uint64(33)).astype(np.int64) - 1, tile.tid[rep])
+            assert np.array_equal(((key[:, 0] >> np.uint64(2)) & np.uint64(0x7FFFFFFF)).astype(np.int64), np.asarray(got["g_start"]))
+            assert np.array_equal((key[:, 1] >> np.uint64(32)).astype(np.int64), np.asarray(got["g_end"]) - np.asarray(got["g_start"]) + 1)
+            code = (key[:, 0] & np.uint64(3)).astype(np.int64)
+            assert np.array_equal(np.array([ord("+"), ord("-"), ord(".")])[code], tile.strand[rep])
+            shape = (key[:, 1] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+            if kw.get("strategy") == "exon":
+                assert not shape.any()                       # exon codes / hashed words say nothing about the CIGAR
+            else:
+                assert (shape != 0).mean() > 0.5              # most reads are one M or M N M
+                ncig = (tile.cig_off[rep + 1] - tile.cig_off[rep]).astype(np.int64)
+                one = shape == 0x80000000
+                assert (ncig[one] <= 3).all() and (ncig[(shape >> 30) == 3] >= 3).all()
+    for k in ("iv_tid", "iv_start", "iv_end", "iv_val", "j_tid", "j_start", "j_end", "j_strand", "j_val"):
+        assert np.array_equal(covs[True][k], covs[False][k]), k
+        assert np.array_equal(covs[True][k], cw[k]), k
+
+
 def _degenerate_exon_files():
     """A CIGAR that ends in an intron (… 7N 2S) leaves a last exon (end + 1, end) in the sample's segment list
     (GSam.cpp:351-417).  The next read of that sample starts exactly at end + 1: processRead does not clear that node
