@@ -1054,7 +1054,8 @@ __global__ __launch_bounds__(64) void yd_lane_k(const uint32_t* __restrict__ ids
         const uint32_t w = q * RS + i0;
         S_start[w] = a.y;
         S_xo[w] = a.w;
-        S_e0[w] = ex_e[a.w];  // (the exon arrays follow the groups: items next to each other in a chain read next to each other)
+        S_e0[w] = nx > 1 ? ex_e[a.w] : a.z;  // (a single exon ends where the read ends; the exon arrays follow the groups: items next to
+                                             // each other in a chain read next to each other)
         S_s1[w] = nx > 1 ? ex_s[a.w + 1] : 0u;
         S_e1[w] = nx > 1 ? ex_e[a.w + 1] : 0u;
         S_nex[w] = nx;
@@ -1210,7 +1211,8 @@ __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids
     b.nex = have ? Y.nex[t] : 0u;
     b.xo = it.w;
     b.o = have ? v.group(t) : 0u;
-    b.e0 = have ? ex_e[b.xo] : 0u;  // first exon end (its start is the read start)
+    b.e0 = have ? (b.nex > 1u ? ex_e[b.xo] : it.z) : 0u;  // first exon end (its start is the read start); a single exon ends where the
+                                                          // read ends: no gather (three items in four, a 64-byte sector each)
     b.s1 = (have && b.nex > 1) ? ex_s[b.xo + 1] : 0u;
     b.e1 = (have && b.nex > 1) ? ex_e[b.xo + 1] : 0u;
     b.s2 = (have && b.nex > 2) ? ex_s[b.xo + 2] : 0u;
