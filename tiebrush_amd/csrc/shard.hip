@@ -487,10 +487,24 @@ __global__ void partial_keys_k(uint32_t ng, const uint32_t* __restrict__ rep, co
   const double y = yc[o];
   if (!(y == rint(y)) || y < 1.0 || y >= 2147483648.0 || yx[o] < 0 || yx[o] >= 2147483648ll) atomicOr(bad, 1u);
 }
-__global__ void partial_ncig_k(uint32_t ng, const uint32_t* __restrict__ rep, const uint32_t* __restrict__ cig_off, uint32_t* __restrict__ cnt,
-                               uint32_t* __restrict__ cfirst) {
+// With tbk_groups_out.g_key a group whose alignment is a single M or M N M (the key says so) is packed from its key: place, strand,
+// key word and the CIGAR words themselves — the representative's record is fetched only for the other groups (soft clips do not
+// travel then: neither the owner's comparisons under -P nor tiecov look at them).
+__device__ __forceinline__ uint32_t partial_key_ops(const uint64_t* __restrict__ gkey, uint32_t o) {
+  if (!gkey) return 0u;
+  const uint32_t shape = (uint32_t)gkey[2 * (size_t)o + 1];
+  return shape == 0x80000000u ? 1u : ((shape >> 30) == 3u ? 3u : 0u);
+}
+__global__ void partial_ncig_k(uint32_t ng, const uint32_t* __restrict__ rep, const uint32_t* __restrict__ cig_off, const uint64_t* __restrict__ gkey,
+                               uint32_t* __restrict__ cnt, uint32_t* __restrict__ cfirst) {
   const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= ng) return;
+  const uint32_t nk = partial_key_ops(gkey, o);
+  if (nk) {
+    cnt[o] = nk;
+    cfirst[o] = 0;
+    return;
+  }
   const uint32_t r = rep[o], c0 = cig_off[r];
   cnt[o] = cig_off[r + 1] - c0;
   cfirst[o] = c0;
@@ -527,8 +541,8 @@ __global__ void partial_table_k(uint32_t ng, uint32_t world, const int64_t* __re
 __global__ void partial_rows_k(uint32_t ng, uint32_t k, uint32_t first_fidx, ColIn I, ColOpt O, const uint32_t* __restrict__ rep,
                                const double* __restrict__ yc, const int64_t* __restrict__ yx, const int32_t* __restrict__ yd,
                                const int32_t* __restrict__ effend, const uint32_t* __restrict__ cfirst, const uint32_t* __restrict__ cnt,
-                               const uint32_t* __restrict__ woff, int32_t* __restrict__ rows, uint32_t* __restrict__ cig_out,
-                               uint32_t* __restrict__ err) {
+                               const uint32_t* __restrict__ woff, const uint64_t* __restrict__ gkey, int32_t* __restrict__ rows,
+                               uint32_t* __restrict__ cig_out, uint32_t* __restrict__ err) {
   const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= ng) return;
   const uint32_t r = rep[o];
@@ -545,26 +559,46 @@ __global__ void partial_rows_k(uint32_t ng, uint32_t k, uint32_t first_fidx, Col
       hi = mid;
   }
   const uint32_t nc = cnt[o], c0 = cfirst[o], w = woff[o];
-  const RecKey K = record_key(I, O, r, I.flag[r], pos[r], tid[r], (int)I.mapq[r], I.nh[r], strand_code(strand[r]), cig + c0, nc);
-  if (K.err || !K.pass) atomicOr(err, K.err | TBK_DERR_INTERNAL);  // (a representative passes the filters by construction)
   int32_t R[TBK_PARTIAL_ROW];
-  R[0] = tid[r];
-  R[1] = pos[r];
-  R[2] = (int32_t)((uint32_t)strand[r] | (nc << 8));
+  const uint32_t nk = partial_key_ops(gkey, o);
+  uint64_t klo;
+  if (nk) {  // everything but the merge priority and the sums comes from the key
+    const uint64_t k0 = gkey[2 * (size_t)o], k1 = gkey[2 * (size_t)o + 1];
+    const uint32_t sc = (uint32_t)k0 & 3u, span = (uint32_t)(k1 >> 32), shape = (uint32_t)k1;
+    R[0] = (int32_t)(uint32_t)(k0 >> 33) - 1;
+    R[1] = (int32_t)(uint32_t)((k0 >> 2) & 0x7FFFFFFFull) - 1;
+    R[2] = (int32_t)((sc == 0u ? (uint32_t)'+' : (sc == 1u ? (uint32_t)'-' : (uint32_t)'.')) | (nk << 8));
+    klo = k1;  // (span : 32 | exact code : 32 — the code of record_key for these two shapes is the shape word)
+    if (nk == 1u) {
+      cig_out[w] = (span << 4) | C_M;
+    } else {
+      const uint32_t a = (shape >> 20) & 0x3FFu, g = shape & 0xFFFFFu;
+      cig_out[w] = (a << 4) | C_M;
+      cig_out[w + 1] = (g << 4) | C_N;
+      cig_out[w + 2] = ((span - a - g) << 4) | C_M;
+    }
+  } else {
+    const RecKey K = record_key(I, O, r, I.flag[r], pos[r], tid[r], (int)I.mapq[r], I.nh[r], strand_code(strand[r]), cig + c0, nc);
+    if (K.err || !K.pass) atomicOr(err, K.err | TBK_DERR_INTERNAL);  // (a representative passes the filters by construction)
+    R[0] = tid[r];
+    R[1] = pos[r];
+    R[2] = (int32_t)((uint32_t)strand[r] | (nc << 8));
+    klo = K.lo;
+    for (uint32_t q = 0; q < nc; ++q) cig_out[w + q] = cig[c0 + q];
+  }
   R[3] = effend[o];
   R[4] = (int32_t)(first_fidx + lo);
   R[5] = (int32_t)(r - file_off[lo]);
   R[6] = (int32_t)(uint32_t)yc[o];
   R[7] = (int32_t)yx[o];
   R[8] = yd[o];
-  R[9] = (int32_t)(uint32_t)(K.lo >> 32);
-  R[10] = (int32_t)(uint32_t)K.lo;
+  R[9] = (int32_t)(uint32_t)(klo >> 32);
+  R[10] = (int32_t)(uint32_t)klo;
   R[11] = 0;
   static_assert(TBK_PARTIAL_ROW == 12, "row layout");
   int4* dst = reinterpret_cast<int4*>(rows + (size_t)o * TBK_PARTIAL_ROW);  // (48-byte rows: 16-byte aligned)
 #pragma unroll
   for (int q = 0; q < TBK_PARTIAL_ROW / 4; ++q) dst[q] = make_int4(R[4 * q], R[4 * q + 1], R[4 * q + 2], R[4 * q + 3]);
-  for (uint32_t q = 0; q < nc; ++q) cig_out[w + q] = cig[c0 + q];
 }
 __global__ void partial_ncig2_k(uint32_t n2, const int32_t* __restrict__ rows, uint32_t* __restrict__ nc) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -646,7 +680,7 @@ extern "C" int tbk_partial_pack(tbk_ctx* ctx, const tbk_collapse_opts* o, const 
   if (!woff) return TBK_ENOMEM;
   uint32_t* d_fo = nullptr;
   TBK_TRY(shard_upload_file_off(ctx, in->file_off, in->n_files, &d_fo));
-  if (ng) TBK_LAUNCH(ctx, "partial_ncig", partial_ncig_k, cdiv(ng, SH_B), SH_B, 0, ng, g->rep, in->cig_off, cnt, cfirst);
+  if (ng) TBK_LAUNCH(ctx, "partial_ncig", partial_ncig_k, cdiv(ng, SH_B), SH_B, 0, ng, g->rep, in->cig_off, g->g_key, cnt, cfirst);
   TBK_TRY(tbk_exscan_u32(ctx, cnt, woff, ng, sc + 21));
   TBK_LAUNCH(ctx, "partial_table", partial_table_k, cdiv(world, 64), 64, 0, ng, world, key, cuts, woff, sc + 21, (long long*)tab);
   if (ng) {
@@ -673,7 +707,7 @@ extern "C" int tbk_partial_pack(tbk_ctx* ctx, const tbk_collapse_opts* o, const 
     if (const char* e = getenv("TBK_DEBUG_HASH_MASK")) O.hash_mask = (uint32_t)strtoul(e, nullptr, 0);
     TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
     TBK_LAUNCH(ctx, "partial_rows", partial_rows_k, cdiv(ng, SH_B), SH_B, 0, ng, in->n_files, first_fidx, I, O, g->rep, g->yc, g->yx, g->yd,
-               g->rep_effend, cfirst, cnt, woff, rows, cig_out, ctx->d_err);
+               g->rep_effend, cfirst, cnt, woff, g->g_key, rows, cig_out, ctx->d_err);
     uint32_t eb = 0;
     TBK_TRY(tbk_sync_err(ctx, &eb));
     if (eb) return tbk_derr_to_status(ctx, eb);
