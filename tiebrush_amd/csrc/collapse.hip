@@ -482,11 +482,63 @@ __device__ __forceinline__ uint64_t wave_bit_transpose(uint64_t x) {
 #undef YS_TSTEP
   return x;
 }
-__global__ __launch_bounds__(YS_NT) void yd_lcount_k(YsIn S, uint32_t ntiles, uint32_t* __restrict__ table /* [YS_NL][ntiles] */,
+// The chain heads come with the placement.  An item opens a chain when it is the first of its list, when its reference sequence
+// differs from the item before it in the list (rspacing.reset(), tiebrush.cpp:586-589), or when it starts beyond the running maximum
+// of end + 1 of the items before it on that reference (the list renews itself, processRead :230-241; end + 1: a CIGAR that ends in an
+// intron leaves a last exon (end + 1, end), GSam.cpp:351-417, a node a read starting at end + 1 does not clear).  What a tile of groups
+// has to know of the items before it is, per list, an aggregate of this monoid — so the first pass also folds every (list, tile)
+// cell's items into one, a scan along each list's row gives every cell the aggregate of the cells before it, and the second pass
+// walks a cell's items once more, in order, to flag its heads.  (Round 2 and the radix path find the heads afterwards, in a scan over
+// all items: 2.2 ms for 178 M items on config 3.)
+struct YsAgg {
+  uint32_t first_tid, last_tid;  // tid + 1 of the first / last item; last_tid == 0: no item
+  int32_t mx;                    // maximum of end + 1 over the trailing items that share last_tid
+  uint32_t whole;                // every item shares one tid
+};
+__device__ __forceinline__ YsAgg ys_combine(const YsAgg& a, const YsAgg& b) {
+  if (b.last_tid == 0u) return a;
+  if (a.last_tid == 0u) return b;
+  YsAgg r;
+  r.first_tid = a.first_tid;
+  r.last_tid = b.last_tid;
+  const bool joins = b.whole && b.first_tid == a.last_tid;
+  r.mx = joins ? (a.mx > b.mx ? a.mx : b.mx) : b.mx;
+  r.whole = joins ? a.whole : 0u;
+  return r;
+}
+// A tile's items of list c are the set bits of column c, wave by wave.  The walk is two-level: every (wave, list) cell — two per
+// thread — folds its few items (three or four on average), thread c chains the sixteen cells of its list (ys_chain_cells), and the
+// cells are walked once more where the heads are wanted.  Aggregates live in LDS as three words (the `whole` bit rides in bit 31
+// of first_tid: tid + 1 < 2^31).
+struct YsCells {
+  uint32_t (*a)[YS_NL];  // first_tid | whole << 31
+  uint32_t (*b)[YS_NL];  // last_tid
+  int32_t (*m)[YS_NL];   // mx
+  __device__ __forceinline__ YsAgg get(uint32_t x, uint32_t c) const { return YsAgg{a[x][c] & 0x7FFFFFFFu, b[x][c], m[x][c], a[x][c] >> 31}; }
+  __device__ __forceinline__ void put(uint32_t x, uint32_t c, const YsAgg& v) const {
+    a[x][c] = v.first_tid | (v.whole << 31);
+    b[x][c] = v.last_tid;
+    m[x][c] = v.mx;
+  }
+};
+// cells -> the aggregate of the list's items before each cell (start: before the tile); returns the aggregate behind the last cell
+__device__ __forceinline__ YsAgg ys_chain_cells(const YsCells& P, uint32_t c, YsAgg run) {
+  for (uint32_t x = 0; x < YS_NT / 64; ++x) {
+    const YsAgg mine = P.get(x, c);
+    P.put(x, c, run);
+    run = ys_combine(run, mine);
+  }
+  return run;
+}
+__global__ __launch_bounds__(YS_NT) void yd_lcount_k(YsIn S, const uint4* __restrict__ gpk /* YdGroups::pk */, uint32_t ntiles,
+                                                     uint32_t* __restrict__ table /* [YS_NL][ntiles] */, uint4* __restrict__ agg /* [YS_NL][ntiles] */,
                                                      uint64_t* __restrict__ gfiles /* [2 ng]: the files of output group o, its strand code */) {
-  __shared__ uint32_t hist[YS_NL];
-  if (threadIdx.x < YS_NL) hist[threadIdx.x] = 0;
-  __syncthreads();
+  __shared__ uint64_t wb[YS_NT / 64][YS_NL];
+  __shared__ uint32_t g_tid[YS_NT];
+  __shared__ int32_t g_e1[YS_NT];
+  __shared__ uint32_t pa[YS_NT / 64][YS_NL], pb[YS_NT / 64][YS_NL];
+  __shared__ int32_t pm[YS_NT / 64][YS_NL];
+  const YsCells P{pa, pb, pm};
   uint64_t lo = 0, hi = 0;
   {
     const uint32_t o = blockIdx.x * YS_NT + threadIdx.x;
@@ -502,13 +554,59 @@ __global__ __launch_bounds__(YS_NT) void yd_lcount_k(YsIn S, uint32_t ntiles, ui
       gfiles[2 * (size_t)o] = files;
       gfiles[2 * (size_t)o + 1] = c;
       ys_mask_from_files(files, c, &lo, &hi);
+      const uint4 g = gpk[o];
+      g_tid[threadIdx.x] = g.x;
+      g_e1[threadIdx.x] = (int32_t)g.z + 1;
     }
   }
-  const uint64_t cl = wave_bit_transpose(lo), ch = wave_bit_transpose(hi);  // lane c: the groups of this wave in lists c and 64 + c
-  if (cl) atomicAdd(&hist[lane_id()], (uint32_t)__builtin_popcountll(cl));
-  if (ch) atomicAdd(&hist[64u + lane_id()], (uint32_t)__builtin_popcountll(ch));
+  wb[threadIdx.x >> 6][lane_id()] = wave_bit_transpose(lo);  // lane c: the groups of this wave in lists c and 64 + c
+  wb[threadIdx.x >> 6][64u + lane_id()] = wave_bit_transpose(hi);
   __syncthreads();
-  if (threadIdx.x < YS_NL) table[(size_t)threadIdx.x * ntiles + blockIdx.x] = hist[threadIdx.x];
+  for (uint32_t q = threadIdx.x; q < (YS_NT / 64) * YS_NL; q += YS_NT) {
+    const uint32_t x = q / YS_NL, c = q % YS_NL;
+    YsAgg A{0u, 0u, INT32_MIN, 1u};
+    for (uint64_t m = wb[x][c]; m; m &= m - 1) {
+      const uint32_t g = x * 64u + (uint32_t)__builtin_ctzll(m);
+      A = ys_combine(A, YsAgg{g_tid[g], g_tid[g], g_e1[g], 1u});
+    }
+    P.put(x, c, A);
+  }
+  __syncthreads();
+  if (threadIdx.x < YS_NL) {
+    const uint32_t c = threadIdx.x;
+    uint32_t n = 0;
+    for (uint32_t x = 0; x < YS_NT / 64; ++x) n += (uint32_t)__builtin_popcountll(wb[x][c]);
+    const YsAgg A = ys_chain_cells(P, c, YsAgg{0u, 0u, INT32_MIN, 1u});
+    table[(size_t)c * ntiles + blockIdx.x] = n;
+    agg[(size_t)c * ntiles + blockIdx.x] = make_uint4(A.first_tid, A.last_tid, (uint32_t)A.mx, A.whole);
+  }
+}
+// block l: row l of the aggregates -> exclusive prefix in place (the aggregate of the list's items in the tiles before)
+__global__ __launch_bounds__(256) void yd_lagg_scan_k(uint4* __restrict__ agg, uint32_t ntiles) {
+  __shared__ uint4 part[256];
+  uint4* row = agg + (size_t)blockIdx.x * ntiles;
+  const uint32_t per = (ntiles + 255u) / 256u, i0 = threadIdx.x * per, i1 = i0 + per < ntiles ? i0 + per : ntiles;
+  auto un = [](const uint4& v) { return YsAgg{v.x, v.y, (int32_t)v.z, v.w}; };
+  auto pk = [](const YsAgg& a) { return make_uint4(a.first_tid, a.last_tid, (uint32_t)a.mx, a.whole); };
+  YsAgg A{0u, 0u, INT32_MIN, 1u};
+  for (uint32_t i = i0; i < i1; ++i) A = ys_combine(A, un(row[i]));
+  part[threadIdx.x] = pk(A);
+  __syncthreads();
+  if (threadIdx.x == 0) {  // 256 partial aggregates: a serial exclusive scan
+    YsAgg run{0u, 0u, INT32_MIN, 1u};
+    for (uint32_t q = 0; q < 256; ++q) {
+      const YsAgg mine = un(part[q]);
+      part[q] = pk(run);
+      run = ys_combine(run, mine);
+    }
+  }
+  __syncthreads();
+  YsAgg run = un(part[threadIdx.x]);
+  for (uint32_t i = i0; i < i1; ++i) {
+    const YsAgg mine = un(row[i]);
+    row[i] = pk(run);
+    run = ys_combine(run, mine);
+  }
 }
 __global__ void yd_ltotal_k(const uint64_t* __restrict__ totals, uint64_t* __restrict__ nit) {
   const uint64_t s = wave_sum(totals[threadIdx.x]) ;
@@ -555,7 +653,7 @@ struct YdWords {
 };
 struct YdItems {
   uint4* pk;      // (tid + 1, start, end, offset of the item's exon list in the per-group exon arrays): written with one store
-  uint32_t* nex;  // exon count (contiguous: the input of the node-offset scan)
+  uint32_t* nex;  // exon count (contiguous: the input of the node-offset scan); items placed by list: bit 31 = the item opens a chain
   __device__ __forceinline__ uint32_t tidp1(uint32_t t) const { return reinterpret_cast<const uint32_t*>(pk)[4 * (size_t)t]; }
   __device__ __forceinline__ int32_t start(uint32_t t) const { return (int32_t) reinterpret_cast<const uint32_t*>(pk)[4 * (size_t)t + 1]; }
   __device__ __forceinline__ int32_t end(uint32_t t) const { return (int32_t) reinterpret_cast<const uint32_t*>(pk)[4 * (size_t)t + 2]; }
@@ -671,16 +769,21 @@ __device__ __forceinline__ uint32_t ys_select(uint64_t v, uint32_t r) {  // posi
   return pos;
 }
 __global__ __launch_bounds__(YS_NT) void yd_lscatter_k(YsIn S, uint32_t ntiles, const uint32_t* __restrict__ table, const uint64_t* __restrict__ totals,
-                                                       const uint64_t* __restrict__ gfiles, YdGroups Q, YdItems Y, uint32_t* __restrict__ item) {
+                                                       const uint4* __restrict__ agg, const uint64_t* __restrict__ gfiles, YdGroups Q, YdItems Y,
+                                                       uint32_t* __restrict__ item) {
   __shared__ uint32_t base[YS_NL];            // first position of this tile's items of list c
   __shared__ uint32_t pre[YS_NL + 1];         // the tile's items in lists before c
   __shared__ uint64_t wb[YS_NT / 64][YS_NL];  // column c of wave w's bit matrix
-  __shared__ uint32_t lsum[YS_NL];
-  __shared__ uint32_t first[YS_NL];
+  __shared__ uint64_t hb[YS_NT / 64][YS_NL];  // ... and which of those items open a chain
+  __shared__ uint32_t ltot[YS_NL];            // items of list c in the whole call
+  __shared__ uint32_t lsum[YS_NL];            // ... and in this tile
   __shared__ uint4 grec[YS_NT];
   __shared__ uint32_t gnex[YS_NT];
+  __shared__ uint32_t pa[YS_NT / 64][YS_NL], pb[YS_NT / 64][YS_NL];
+  __shared__ int32_t pm[YS_NT / 64][YS_NL];
+  const YsCells P{pa, pb, pm};
   const uint32_t t = threadIdx.x, w = t >> 6;
-  if (t < YS_NL) lsum[t] = (uint32_t)totals[t];
+  if (t < YS_NL) ltot[t] = (uint32_t)totals[t];
   const uint32_t o = blockIdx.x * YS_NT + t;
   uint64_t lo = 0, hi = 0;
   if (o < S.ng) ys_mask_from_files(gfiles[2 * (size_t)o], (uint32_t)gfiles[2 * (size_t)o + 1], &lo, &hi);
@@ -692,15 +795,39 @@ __global__ __launch_bounds__(YS_NT) void yd_lscatter_k(YsIn S, uint32_t ntiles, 
     gnex[t] = g.w;
   }
   __syncthreads();
+  for (uint32_t q = t; q < (YS_NT / 64) * YS_NL; q += YS_NT) {  // every cell folds its items
+    const uint32_t x = q / YS_NL, c = q % YS_NL;
+    YsAgg A{0u, 0u, INT32_MIN, 1u};
+    for (uint64_t m = wb[x][c]; m; m &= m - 1) {
+      const uint4 g = grec[x * 64u + (uint32_t)__builtin_ctzll(m)];
+      A = ys_combine(A, YsAgg{g.x, g.x, (int32_t)g.z + 1, 1u});
+    }
+    P.put(x, c, A);
+  }
+  __syncthreads();
   if (t < YS_NL) {
     uint32_t b = 0;  // list base: the totals of the lists before it (128 values: a serial sum per thread is cheap enough)
-    for (uint32_t c = 0; c < t; ++c) b += lsum[c];
-    const uint32_t here = table[(size_t)t * ntiles + blockIdx.x];
-    base[t] = b + here;
-    first[t] = here == 0u ? 1u : 0u;  // the list starts in this tile: its first item here is the first of all
+    for (uint32_t c = 0; c < t; ++c) b += ltot[c];
+    base[t] = b + table[(size_t)t * ntiles + blockIdx.x];
     uint32_t n = 0;
     for (uint32_t x = 0; x < YS_NT / 64; ++x) n += (uint32_t)__builtin_popcountll(wb[x][t]);
-    lsum[t] = n;  // (reused: this tile's items of list t)
+    lsum[t] = n;
+    // every cell of the list learns the aggregate of the list's items before it, those of the tiles before included
+    const uint4 av = agg[(size_t)t * ntiles + blockIdx.x];
+    (void)ys_chain_cells(P, t, YsAgg{av.x, av.y, (int32_t)av.z, av.w});
+  }
+  __syncthreads();
+  for (uint32_t q = t; q < (YS_NT / 64) * YS_NL; q += YS_NT) {  // ... and flags its heads
+    const uint32_t x = q / YS_NL, c = q % YS_NL;
+    YsAgg A = P.get(x, c);
+    uint64_t heads = 0;
+    for (uint64_t m = wb[x][c]; m; m &= m - 1) {
+      const uint32_t bit = (uint32_t)__builtin_ctzll(m);
+      const uint4 g = grec[x * 64u + bit];
+      if (A.last_tid == 0u || g.x != A.last_tid || (int32_t)g.y > A.mx) heads |= 1ull << bit;
+      A = ys_combine(A, YsAgg{g.x, g.x, (int32_t)g.z + 1, 1u});
+    }
+    hb[x][c] = heads;
   }
   __syncthreads();
   if (t < 64) {  // exclusive prefix of the 128 per-list counts: one wave, two lists per lane
@@ -724,12 +851,11 @@ __global__ __launch_bounds__(YS_NT) void yd_lscatter_k(YsIn S, uint32_t ntiles, 
       if (r < n) break;
       r -= n;
     }
-    const uint32_t g = x * 64u + ys_select(wb[x][c], r);
+    const uint32_t bit = ys_select(wb[x][c], r);
+    const uint32_t g = x * 64u + bit;
     const uint32_t pos = base[c] + rank;
-    uint4 rec = grec[g];
-    if (rank == 0u && first[c]) rec.x |= 0x80000000u;  // (read by YdLoad::list_head)
-    Y.pk[pos] = rec;
-    Y.nex[pos] = gnex[g];
+    Y.pk[pos] = grec[g];
+    Y.nex[pos] = gnex[g] | ((uint32_t)((hb[x][c] >> bit) & 1ull) << 31);  // (bit 31: the item opens a chain — read by yd_number)
     item[pos] = blockIdx.x * YS_NT + g;
   }
 }
@@ -747,13 +873,10 @@ struct SegMaxYOp {
   }
 };
 struct YdLoad {
-  const uint64_t* list;  // item words: list id in the high half; null: the first item of every list carries bit 31 of its tid + 1 word
+  const uint64_t* list;  // item words: list id in the high half
   YdItems Y;
   __device__ __forceinline__ bool list_head(uint32_t t) const {  // new list, or rspacing.reset() (:586-589)
-    if (t == 0) return true;
-    const uint32_t a = Y.tidp1(t), b = Y.tidp1(t - 1);
-    if (!list) return (a >> 31) || ((a ^ b) & 0x7FFFFFFFu) != 0u;
-    return (list[t] >> 32) != (list[t - 1] >> 32) || a != b;
+    return t == 0 || (list[t] >> 32) != (list[t - 1] >> 32) || Y.tidp1(t) != Y.tidp1(t - 1);
   }
   __device__ __forceinline__ SegMaxY operator()(uint32_t t) const {
     SegMaxY s;
@@ -799,6 +922,93 @@ struct YdStore {
     }
   }
 };
+
+// Items placed by list carry their head flag in bit 31 of the exon-count word: numbering the chains (and summing the exon counts
+// before each head, its node-arena base) is a scan of that one array — 4 bytes per item, four items per lane and load, thread order =
+// item order: tile sums, a scan of the 43 k tile sums, and a second pass that writes at the heads (3 % of the items).
+constexpr uint32_t YN_NT = 256, YN_ROWS = 4, YN_TILE = YN_NT * 4 * YN_ROWS;  // 4096 items per block
+__device__ __forceinline__ uint4 yn_load(const uint32_t* __restrict__ w, uint64_t i, uint32_t nit) {  // items i .. i + 3 (0 beyond the end)
+  if (i + 3 < nit) return *reinterpret_cast<const uint4*>(w + i);  // (i is a multiple of 4, the array 256-byte aligned)
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (i < nit) v.x = w[i];
+  if (i + 1 < nit) v.y = w[i + 1];
+  if (i + 2 < nit) v.z = w[i + 2];
+  return v;
+}
+__global__ __launch_bounds__(YN_NT) void yn_reduce_k(const uint32_t* __restrict__ w, uint32_t nit, unsigned long long* __restrict__ part) {
+  __shared__ unsigned long long sm[YN_NT / 64];
+  unsigned long long acc = 0;  // heads : 32 | exon counts : 32 (nodes < 2^31: checked by the caller)
+#pragma unroll
+  for (uint32_t r = 0; r < YN_ROWS; ++r) {
+    const uint4 v = yn_load(w, (uint64_t)blockIdx.x * YN_TILE + ((uint64_t)r * YN_NT + threadIdx.x) * 4u, nit);
+    const uint32_t h = (v.x >> 31) + (v.y >> 31) + (v.z >> 31) + (v.w >> 31);
+    const uint32_t n = (v.x & 0x7FFFFFFFu) + (v.y & 0x7FFFFFFFu) + (v.z & 0x7FFFFFFFu) + (v.w & 0x7FFFFFFFu);
+    acc += ((unsigned long long)h << 32) + n;
+  }
+  acc = wave_sum(acc);
+  if (lane_id() == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+// single block: exclusive prefix of the tile sums in place; the grand totals -> totals[0] (chains), totals[1] (nodes)
+__global__ __launch_bounds__(1024) void yn_spine_k(unsigned long long* __restrict__ part, uint32_t nb, uint64_t* __restrict__ totals) {
+  __shared__ unsigned long long sm[16];
+  __shared__ unsigned long long carry_s, nodes_s;
+  constexpr uint32_t E = 16;
+  if (threadIdx.x == 0) carry_s = nodes_s = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < nb; base += 1024 * E) {
+    const uint32_t i0 = base + threadIdx.x * E;
+    unsigned long long v[E], s2 = 0, n2 = 0;
+#pragma unroll
+    for (uint32_t e = 0; e < E; ++e) {
+      v[e] = i0 + e < nb ? part[i0 + e] : 0ull;
+      s2 += v[e];
+      n2 += v[e] & 0xFFFFFFFFull;  // (a tile's exon counts are far below 2^32; their total need not be: counted on its own)
+    }
+    n2 = wave_sum(n2);
+    if (lane_id() == 0 && n2) atomicAdd(&nodes_s, n2);
+    unsigned long long tot;
+    unsigned long long ex = carry_s + block_excl_sum<unsigned long long, 1024>(s2, sm, &tot);
+#pragma unroll
+    for (uint32_t e = 0; e < E; ++e) {
+      if (i0 + e < nb) part[i0 + e] = ex;
+      ex += v[e];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    totals[0] = carry_s >> 32;  // (meaningless when the nodes overflow 32 bits: the caller refuses the tile on totals[1])
+    totals[1] = nodes_s;
+  }
+}
+__global__ __launch_bounds__(YN_NT) void yn_emit_k(const uint32_t* __restrict__ w, uint32_t nit, const unsigned long long* __restrict__ part,
+                                                   uint32_t* __restrict__ chain_first, uint32_t* __restrict__ chain_noff) {
+  __shared__ unsigned long long sm[YN_NT / 64 + 4];
+  unsigned long long carry = part[blockIdx.x];
+#pragma unroll
+  for (uint32_t r = 0; r < YN_ROWS; ++r) {
+    const uint64_t i = (uint64_t)blockIdx.x * YN_TILE + ((uint64_t)r * YN_NT + threadIdx.x) * 4u;
+    const uint4 v = yn_load(w, i, nit);
+    const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mine += ((unsigned long long)(wv[e] >> 31) << 32) + (wv[e] & 0x7FFFFFFFu);
+    unsigned long long tot;
+    unsigned long long ex = carry + block_excl_sum<unsigned long long, YN_NT>(mine, sm, &tot);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if ((wv[e] >> 31) && (ex >> 32) < nit) {  // chains numbered in item order, each with its first item and the first node of its arena
+        chain_first[(uint32_t)(ex >> 32)] = (uint32_t)(i + (uint64_t)e);  // (the bound only matters when the node count overflows)
+        chain_noff[(uint32_t)(ex >> 32)] = (uint32_t)ex;
+      }
+      ex += ((unsigned long long)(wv[e] >> 31) << 32) + (wv[e] & 0x7FFFFFFFu);
+    }
+    carry += tot;
+  }
+}
 
 constexpr uint32_t YD_LONG = 24;  // chains at least this long get a whole wave
 constexpr int YD_FAST_NODES = 12;   // the spliced-read fast path of yd_wave_k searches at most this many nodes per lane
@@ -911,7 +1121,7 @@ __global__ void yd_run_k(const uint32_t* __restrict__ ids, const uint32_t* __res
   for (uint32_t t = t0; t < t1; ++t) {
     const uint4 it = Y.pk[t];
     uint32_t rstart = it.y;
-    uint32_t xo = it.w, nex = Y.nex[t];
+    uint32_t xo = it.w, nex = Y.nex[t] & 0x7FFFFFFFu;  // (bit 31: head flag of items placed by list)
     int d;
     if (last_pos == rstart) {  // :225-228
       yd_merge_read(ex_s + xo, ex_e + xo, nex, N, head, alloc);
@@ -1049,7 +1259,7 @@ __global__ __launch_bounds__(64) void yd_lane_k(const uint32_t* __restrict__ ids
       const uint32_t idx = tq + i0;
       if (tq != 0xFFFFFFFFu && idx < t1q) {
         const uint4 a = Y.pk[idx];
-        const uint32_t nx = Y.nex[idx];
+        const uint32_t nx = Y.nex[idx] & 0x7FFFFFFFu;
         const uint32_t o = v.group(idx);
         const uint32_t w = q * RS + i0;
         S_start[w] = a.y;
@@ -1208,7 +1418,7 @@ __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids
     const bool have = t < t1;
     const uint4 it = have ? Y.pk[t] : make_uint4(0u, 0u, 0u, 0u);
     b.start = it.y;
-    b.nex = have ? Y.nex[t] : 0u;
+    b.nex = have ? (Y.nex[t] & 0x7FFFFFFFu) : 0u;
     b.xo = it.w;
     b.o = have ? v.group(t) : 0u;
     b.e0 = have ? (b.nex > 1u ? ex_e[b.xo] : it.z) : 0u;  // first exon end (its start is the read start); a single exon ends where the
@@ -1567,15 +1777,24 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
     const uint32_t ys_tiles = cdiv(ng, YS_NT);
     const YsIn S{ng, J.gperm, J.G.ns, J.gpoff, J.pfile, J.shi, J.gfmask};
     uint32_t* ys_table = nullptr;
+    uint4* ys_agg = nullptr;
     uint64_t* ys_totals = nullptr;
     uint64_t* ys_files = nullptr;
-    if (by_list) {  // items per (list, tile of groups); their sum is the number of items
+    YdGroups Q{};
+    if (by_list) {  // the groups' coordinates first (the first pass folds them); then items and aggregates per (list, tile of groups)
+      Q.pk = ws_alloc<uint4>(ctx, ng);
+      Q.nex = ws_alloc<uint32_t>(ctx, ng);
+      Q.xoff = ws_alloc<uint32_t>(ctx, ng);
       ys_table = ws_alloc<uint32_t>(ctx, (size_t)YS_NL * ys_tiles);
+      ys_agg = ws_alloc<uint4>(ctx, (size_t)YS_NL * ys_tiles);
       ys_totals = ws_alloc<uint64_t>(ctx, YS_NL + 1);
       ys_files = ws_alloc<uint64_t>(ctx, 2 * (size_t)ng);
-      if (!ys_table || !ys_totals || !ys_files) return TBK_ENOMEM;
-      TBK_LAUNCH(ctx, "yd_lcount", yd_lcount_k, ys_tiles, YS_NT, 0, S, ys_tiles, ys_table, ys_files);
+      if (!Q.xoff || !ys_table || !ys_agg || !ys_totals || !ys_files) return TBK_ENOMEM;
+      TBK_LAUNCH(ctx, "yd_groups", yd_groups_k, cdiv(ng, B), B, 0, I, ng, J.gperm, J.G, J.shi, J.slo, Q);
+      TBK_TRY(tbk_exscan_u32(ctx, Q.nex, Q.xoff, ng, sc + 5));
+      TBK_LAUNCH(ctx, "yd_lcount", yd_lcount_k, ys_tiles, YS_NT, 0, S, Q.pk, ys_tiles, ys_table, ys_agg, ys_files);
       TBK_LAUNCH(ctx, "yd_lscan", yd_lscan_k, YS_NL, 1024, 0, ys_table, ys_tiles, ys_totals);
+      TBK_LAUNCH(ctx, "yd_lscan", yd_lagg_scan_k, YS_NL, 256, 0, ys_agg, ys_tiles);
       TBK_LAUNCH(ctx, "yd_lscan", yd_ltotal_k, 1, YS_NL, 0, ys_totals, sc + 2);
     } else if (J.win) {  // items per output group straight from the per-group sample counts
       ocnt = ws_alloc<uint32_t>(ctx, ng);
@@ -1618,21 +1837,29 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
         TBK_TRY(tbk_exscan_u32(ctx, ocnt, ooff, ng, nullptr));
         TBK_LAUNCH(ctx, "yd_fill", yd_fill_k, cdiv(m, B), B, 0, I, m, J.val, J.flags, J.fidx, J.sgid, J.ginv, ioff, ooff, J.G, iv);
       }
-      YdGroups Q;
-      Q.pk = ws_alloc<uint4>(ctx, ng);
-      Q.nex = ws_alloc<uint32_t>(ctx, ng);
-      Q.xoff = ws_alloc<uint32_t>(ctx, ng);
-      if (!Q.xoff) return TBK_ENOMEM;
-      TBK_LAUNCH(ctx, "yd_groups", yd_groups_k, cdiv(ng, B), B, 0, I, ng, J.gperm, J.G, J.shi, J.slo, Q);
-      TBK_TRY(tbk_exscan_u32(ctx, Q.nex, Q.xoff, ng, sc + 5));
+      if (!by_list) {
+        Q.pk = ws_alloc<uint4>(ctx, ng);
+        Q.nex = ws_alloc<uint32_t>(ctx, ng);
+        Q.xoff = ws_alloc<uint32_t>(ctx, ng);
+        if (!Q.xoff) return TBK_ENOMEM;
+        TBK_LAUNCH(ctx, "yd_groups", yd_groups_k, cdiv(ng, B), B, 0, I, ng, J.gperm, J.G, J.shi, J.slo, Q);
+        TBK_TRY(tbk_exscan_u32(ctx, Q.nex, Q.xoff, ng, sc + 5));
+      }
       if (by_list) {
-        TBK_LAUNCH(ctx, "yd_scatter", yd_lscatter_k, ys_tiles, YS_NT, 0, S, ys_tiles, ys_table, ys_totals, ys_files, Q, Y, io);
+        TBK_LAUNCH(ctx, "yd_scatter", yd_lscatter_k, ys_tiles, YS_NT, 0, S, ys_tiles, ys_table, ys_totals, ys_agg, ys_files, Q, Y, io);
       } else {  // stable split by list id (file * 2 + strand list); group order is already in place.  The id range is known:
         uint32_t bits = 1;  // no scan for the varying bits
         while ((1ull << bits) < 2ull * I.k) ++bits;
         TBK_TRY(tbk_radix_sort_w64_emit(ctx, &iv, &iv2, nit, ((1ull << bits) - 1ull) << 32, true, YdEmit{Q, Y}, "yd_scatter"));
       }
-      {
+      if (by_list) {  // the heads are flagged: number them (and sum the exon counts before each) in one scan of the exon-count words
+        const uint32_t ynb = cdiv(nit, YN_TILE);
+        unsigned long long* ypart = ws_alloc<unsigned long long>(ctx, ynb);
+        if (!ypart) return TBK_ENOMEM;
+        TBK_LAUNCH(ctx, "yd_number", yn_reduce_k, ynb, YN_NT, 0, Y.nex, nit, ypart);
+        TBK_LAUNCH(ctx, "yd_number", yn_spine_k, 1, 1024, 0, ypart, ynb, sc + 3);
+        TBK_LAUNCH(ctx, "yd_number", yn_emit_k, ynb, YN_NT, 0, Y.nex, nit, ypart, chain_first, noff);
+      } else {
         YdLoad ld{iv, Y};  // chain heads (segmented running maximum of the ends) and their numbering, one pass
         YdAux ax{Y};
         YdHead hd{};
