@@ -481,16 +481,35 @@ __global__ void cov_iv_flag_k(uint32_t ncp, uint64_t S, const uint64_t* __restri
   }
 }
 
+// tile_b[t] = last bundle with b_off <= t * COV_W (t <= ntiles): an interval's bundle is then a few bisection steps inside its tile's
+// bundles instead of eighteen over all of them
+__global__ void cov_tile_bundle_k(uint32_t ntiles, uint32_t nb, const uint64_t* __restrict__ b_off, uint32_t* __restrict__ tile_b) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > ntiles) return;
+  const uint64_t p = (uint64_t)t * COV_W;
+  uint32_t lo = 0, hi = nb;
+  while (hi - lo > 1) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    if (b_off[mid] <= p)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  tile_b[t] = lo;
+}
 __global__ void cov_iv_write_k(uint32_t ncp, uint32_t nb, CovArrays A, const uint64_t* __restrict__ sp, const double* __restrict__ sv,
                                const uint32_t* __restrict__ emit, const uint32_t* __restrict__ eoff,
-                               const uint64_t* __restrict__ endpos, uint32_t cap, int32_t* __restrict__ iv_tid,
-                               int32_t* __restrict__ iv_start, int32_t* __restrict__ iv_end, double* __restrict__ iv_val) {
+                               const uint64_t* __restrict__ endpos, const uint32_t* __restrict__ tile_b, uint32_t cap,
+                               int32_t* __restrict__ iv_tid, int32_t* __restrict__ iv_start, int32_t* __restrict__ iv_end,
+                               double* __restrict__ iv_val) {
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= ncp || !emit[q]) return;
   uint32_t o = eoff[q];
   if (o >= cap) return;
   uint64_t p = sp[q] & ~(1ull << 63);
-  uint32_t lo = 0, hi = nb;  // last bundle with b_off <= p
+  const uint32_t tl = (uint32_t)(p / COV_W);
+  uint32_t lo = tile_b[tl], hi = tile_b[tl + 1] + 1u;  // last bundle with b_off <= p: between the bundles of the tile's two ends
+  if (hi > nb) hi = nb;
   while (hi - lo > 1) {
     uint32_t mid = lo + ((hi - lo) >> 1);
     if (A.b_off[mid] <= p)
@@ -1107,7 +1126,10 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
     if (ncp) {
       TBK_LAUNCH(ctx, "cov_iv_flag", cov_iv_flag_k, cdiv(ncp, B), B, 0, ncp, S, sp, sv, emit, endpos);
       TBK_TRY(tbk_exscan_u32(ctx, emit, eoff, ncp, sc + 8));
-      TBK_LAUNCH(ctx, "cov_iv_write", cov_iv_write_k, cdiv(ncp, B), B, 0, ncp, nb, A, sp, sv, emit, eoff, endpos,
+      uint32_t* tile_b = ws_alloc<uint32_t>(ctx, (size_t)ntiles + 2);
+      if (!tile_b) return TBK_ENOMEM;
+      TBK_LAUNCH(ctx, "cov_iv_write", cov_tile_bundle_k, cdiv(ntiles + 1, B), B, 0, ntiles, nb, A.b_off, tile_b);
+      TBK_LAUNCH(ctx, "cov_iv_write", cov_iv_write_k, cdiv(ncp, B), B, 0, ncp, nb, A, sp, sv, emit, eoff, endpos, tile_b,
                  out->cap_intervals, out->iv_tid, out->iv_start, out->iv_end, out->iv_val);
     }
   }
