@@ -42,10 +42,14 @@ def test_golden_tiecov(ctx, name, device, bam_loader):
     assert junction_lines(got, names) == read_lines(os.path.join(GOLDEN, name, name + ".junctions.bed"))
 
 
+@pytest.mark.parametrize("bundles", ["lean", "scan"])
 @pytest.mark.parametrize("profile,n", [("c2", 100000), ("c3", 60000), ("c5", 60000)])
-def test_synthetic_collapsed(ctx, profile, n):
+def test_synthetic_collapsed(ctx, profile, n, bundles, monkeypatch):
+    """(bundles: the three lean passes over 4096-record tiles, or — TBK_COV_BUNDLE_SCAN — the two-stage look-back scan)"""
     from oracle import oracle_ffi as orc
     from tiebrush_amd import synth
+    if bundles == "scan":
+        monkeypatch.setenv("TBK_COV_BUNDLE_SCAN", "1")
     tile = synth.make_tile(3, n, profile, n_loci=3000)
     groups = orc.collapse(tile)
     cin = synth.collapsed_to_cov_input(tile, groups)
