@@ -642,16 +642,61 @@ __device__ __forceinline__ bool cp_kept(const uint64_t* sp, const double* sv, ui
   return q > 0 && sv[q] != sv[q - 1];
 }
 
-__global__ void cov_iv_flag_k(uint32_t ncp, uint64_t S, const uint64_t* __restrict__ sp, const double* __restrict__ sv,
-                              uint32_t* __restrict__ emit, uint64_t* __restrict__ endpos) {
-  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= ncp) return;
-  bool e = cp_kept(sp, sv, q) && sv[q] != 0.0;
-  emit[q] = e ? 1u : 0u;
-  if (e) {
-    uint32_t r = q + 1;
-    while (r < ncp && !cp_kept(sp, sv, r)) ++r;
-    endpos[q] = (r < ncp) ? (sp[r] & ~(1ull << 63)) : S;
+
+// The run-length encoding in two streaming passes over tiles of IV_TILE change points (row r of a tile: 256 consecutive change
+// points, thread order = their order): how many intervals a tile emits, a scan of the tile counts, then every interval written at its
+// place — no per-change-point flag, offset and end-position arrays in between.
+constexpr uint32_t IV_NT = 256, IV_ROWS = 8, IV_TILE = IV_NT * IV_ROWS;
+__device__ __forceinline__ bool iv_emits(const uint64_t* __restrict__ sp, const double* __restrict__ sv, uint32_t q) {
+  return cp_kept(sp, sv, q) && sv[q] != 0.0;
+}
+__global__ __launch_bounds__(IV_NT) void iv_count_k(uint32_t ncp, const uint64_t* __restrict__ sp, const double* __restrict__ sv, uint32_t* __restrict__ cnt) {
+  __shared__ uint32_t sm[IV_NT / 64];
+  uint32_t n = 0;
+#pragma unroll
+  for (uint32_t r = 0; r < IV_ROWS; ++r) {
+    const uint64_t q = (uint64_t)blockIdx.x * IV_TILE + (uint64_t)r * IV_NT + threadIdx.x;
+    n += q < ncp && iv_emits(sp, sv, (uint32_t)q) ? 1u : 0u;
+  }
+  n = wave_sum(n);
+  if (lane_id() == 0) sm[threadIdx.x >> 6] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) cnt[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+__global__ __launch_bounds__(IV_NT) void iv_emit_k(uint32_t ncp, uint64_t S, uint32_t nb, CovArrays A, const uint64_t* __restrict__ sp,
+                                                   const double* __restrict__ sv, const uint32_t* __restrict__ off, const uint32_t* __restrict__ tile_b,
+                                                   uint32_t cap, int32_t* __restrict__ iv_tid, int32_t* __restrict__ iv_start, int32_t* __restrict__ iv_end,
+                                                   double* __restrict__ iv_val) {
+  __shared__ uint32_t sm[8];
+  uint32_t run = off[blockIdx.x];
+#pragma unroll 1
+  for (uint32_t r = 0; r < IV_ROWS; ++r) {
+    const uint64_t q64 = (uint64_t)blockIdx.x * IV_TILE + (uint64_t)r * IV_NT + threadIdx.x;
+    const uint32_t q = (uint32_t)q64;
+    const bool e = q64 < ncp && iv_emits(sp, sv, q);
+    uint32_t tot;
+    const uint32_t o = run + block_excl_sum<uint32_t, IV_NT>(e ? 1u : 0u, sm, &tot);
+    run += tot;
+    if (!e || o >= cap) continue;
+    uint32_t nx = q + 1;  // the next change point that is kept ends the interval
+    while (nx < ncp && !cp_kept(sp, sv, nx)) ++nx;
+    const uint64_t endp = nx < ncp ? (sp[nx] & ~(1ull << 63)) : S;
+    const uint64_t p = sp[q] & ~(1ull << 63);
+    const uint32_t tl = (uint32_t)(p / COV_W);
+    uint32_t lo = tile_b[tl], hi = tile_b[tl + 1] + 1u;  // last bundle with b_off <= p: between the bundles of the tile's two ends
+    if (hi > nb) hi = nb;
+    while (hi - lo > 1) {
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      if (A.b_off[mid] <= p)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    const int32_t s0 = A.b_start[lo] - 1 + (int32_t)(p - A.b_off[lo]);
+    iv_tid[o] = A.b_tid[lo];
+    iv_start[o] = s0;
+    iv_end[o] = s0 + (int32_t)(endp - p);
+    iv_val[o] = sv[q];
   }
 }
 
@@ -670,32 +715,6 @@ __global__ void cov_tile_bundle_k(uint32_t ntiles, uint32_t nb, const uint64_t* 
       hi = mid;
   }
   tile_b[t] = lo;
-}
-__global__ void cov_iv_write_k(uint32_t ncp, uint32_t nb, CovArrays A, const uint64_t* __restrict__ sp, const double* __restrict__ sv,
-                               const uint32_t* __restrict__ emit, const uint32_t* __restrict__ eoff,
-                               const uint64_t* __restrict__ endpos, const uint32_t* __restrict__ tile_b, uint32_t cap,
-                               int32_t* __restrict__ iv_tid, int32_t* __restrict__ iv_start, int32_t* __restrict__ iv_end,
-                               double* __restrict__ iv_val) {
-  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= ncp || !emit[q]) return;
-  uint32_t o = eoff[q];
-  if (o >= cap) return;
-  uint64_t p = sp[q] & ~(1ull << 63);
-  const uint32_t tl = (uint32_t)(p / COV_W);
-  uint32_t lo = tile_b[tl], hi = tile_b[tl + 1] + 1u;  // last bundle with b_off <= p: between the bundles of the tile's two ends
-  if (hi > nb) hi = nb;
-  while (hi - lo > 1) {
-    uint32_t mid = lo + ((hi - lo) >> 1);
-    if (A.b_off[mid] <= p)
-      lo = mid;
-    else
-      hi = mid;
-  }
-  int32_t s0 = A.b_start[lo] - 1 + (int32_t)(p - A.b_off[lo]);
-  iv_tid[o] = A.b_tid[lo];
-  iv_start[o] = s0;
-  iv_end[o] = s0 + (int32_t)(endpos[q] - p);
-  iv_val[o] = sv[q];
 }
 
 // ---- ordered double path (non-integral YC): per base, add in record order -------------------
@@ -1275,11 +1294,8 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
     uint32_t* tile_cp_base = ws_alloc<uint32_t>(ctx, ntiles);
     uint32_t* tile_cp_cnt = ws_alloc<uint32_t>(ctx, ntiles);
     uint32_t* tile_cp_off = ws_alloc<uint32_t>(ctx, ntiles);
-    uint32_t* emit = ws_alloc<uint32_t>(ctx, cp_cap);
-    uint32_t* eoff = ws_alloc<uint32_t>(ctx, cp_cap);
-    uint64_t* endpos = ws_alloc<uint64_t>(ctx, cp_cap);
     uint32_t* cp_alloc = (uint32_t*)(sc + 10);
-    if (!endpos) return TBK_ENOMEM;
+    if (!cp_pos || !cp_val || !sp || !sv || !tile_cp_off) return TBK_ENOMEM;
     if (nspill)
       TBK_LAUNCH(ctx, "cov_spill_fill", cov_spill_fill_k, cdiv(m, B), B, 0, m, A, in->cig_off, in->cig, tile_off, tile_fill,
                  sp_seg, sp_rec);
@@ -1311,13 +1327,16 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
     if (eb) return tbk_derr_to_status(ctx, eb);
     const uint32_t ncp = (uint32_t)ctx->h_scalars[6];
     if (ncp) {
-      TBK_LAUNCH(ctx, "cov_iv_flag", cov_iv_flag_k, cdiv(ncp, B), B, 0, ncp, S, sp, sv, emit, endpos);
-      TBK_TRY(tbk_exscan_u32(ctx, emit, eoff, ncp, sc + 8));
+      const uint32_t ivt = cdiv(ncp, IV_TILE);
+      uint32_t* icnt = ws_alloc<uint32_t>(ctx, ivt);
+      uint32_t* ioff = ws_alloc<uint32_t>(ctx, ivt);
       uint32_t* tile_b = ws_alloc<uint32_t>(ctx, (size_t)ntiles + 2);
-      if (!tile_b) return TBK_ENOMEM;
+      if (!icnt || !ioff || !tile_b) return TBK_ENOMEM;
       TBK_LAUNCH(ctx, "cov_iv_write", cov_tile_bundle_k, cdiv(ntiles + 1, B), B, 0, ntiles, nb, A.b_off, tile_b);
-      TBK_LAUNCH(ctx, "cov_iv_write", cov_iv_write_k, cdiv(ncp, B), B, 0, ncp, nb, A, sp, sv, emit, eoff, endpos, tile_b,
-                 out->cap_intervals, out->iv_tid, out->iv_start, out->iv_end, out->iv_val);
+      TBK_LAUNCH(ctx, "cov_iv_count", iv_count_k, ivt, IV_NT, 0, ncp, sp, sv, icnt);
+      TBK_TRY(tbk_exscan_u32(ctx, icnt, ioff, ivt, sc + 8));
+      TBK_LAUNCH(ctx, "cov_iv_write", iv_emit_k, ivt, IV_NT, 0, ncp, S, nb, A, sp, sv, ioff, tile_b, out->cap_intervals, out->iv_tid, out->iv_start,
+                 out->iv_end, out->iv_val);
     }
   }
 
