@@ -383,7 +383,7 @@ def test_deferred_yd_overlaps_tiecov_chain(ctx):
 
 @pytest.mark.parametrize("profile,kw,okw", [("c2", dict(), dict()), ("c3", dict(strategy="clip"), dict(strategy=2)),
                                             ("c5", dict(strategy="exon", max_nh=5, min_qual=1), dict(strategy=3, max_nh=5, min_qual=1))])
-def test_device_chain_view_from_keys(ctx, profile, kw, okw):
+def test_device_chain_view_from_keys(ctx, profile, kw, okw, monkeypatch):
     """tbk_groups_out.g_key (ABI 4): the tiecov input of the representatives built from the group keys — the CIGAR itself for a single
     M or M N M under the CIGAR / clip strategies, fetched otherwise (indels, three exons, -E) — gives the intervals and
     junctions of the view that fetches every representative, and of the oracle; the key words say what tbk.h says they say"""
@@ -416,9 +416,16 @@ def test_device_chain_view_from_keys(ctx, profile, kw, okw):
                 ncig = (tile.cig_off[rep + 1] - tile.cig_off[rep]).astype(np.int64)
                 one = shape == 0x80000000
                 assert (ncig[one] <= 3).all() and (ncig[(shape >> 30) == 3] >= 3).all()
+    # the view built from keys carries the results of tiecov's first pass (TBK_COV_PREP: run that pass anyway)
+    monkeypatch.setenv("TBK_COV_PREP", "1")
+    res = ctx.collapse(dt, want_key=True, **kw)
+    covs["pass"] = api.to_numpy(ctx.coverage(ctx.groups_to_cov_in(res)))
     for k in ("iv_tid", "iv_start", "iv_end", "iv_val", "j_tid", "j_start", "j_end", "j_strand", "j_val"):
         assert np.array_equal(covs[True][k], covs[False][k]), k
+        assert np.array_equal(covs[True][k], covs["pass"][k]), k
         assert np.array_equal(covs[True][k], cw[k]), k
+    for k in ("n_bases", "n_intervals", "n_junctions", "span_bases"):
+        assert covs[True][k] == covs[False][k] == covs["pass"][k] == cw[k], k
 
 
 def _degenerate_exon_files():

@@ -2420,34 +2420,96 @@ __global__ void g2c_count_key_k(uint32_t ng, const uint64_t* __restrict__ key, c
   }
   cnt[o] = n;
 }
-__global__ void g2c_gather_key_k(uint32_t ng, const uint64_t* __restrict__ key, const double* __restrict__ yc, const int64_t* __restrict__ yx,
-                                 const uint32_t* __restrict__ cfirst, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cig,
-                                 const uint32_t* __restrict__ ooff, uint32_t total, int32_t* __restrict__ o_tid, int32_t* __restrict__ o_pos,
-                                 uint8_t* __restrict__ o_strand, double* __restrict__ o_yc, int64_t* __restrict__ o_yx,
-                                 uint32_t* __restrict__ o_cig_off, uint32_t* __restrict__ o_cig) {
-  uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= ng) return;
-  const uint64_t k0 = key[2 * (size_t)o], k1 = key[2 * (size_t)o + 1];
-  o_tid[o] = (int32_t)(uint32_t)(k0 >> 33) - 1;
-  o_pos[o] = (int32_t)(uint32_t)((k0 >> 2) & 0x7FFFFFFFull) - 1;
-  const uint32_t sc = (uint32_t)k0 & 3u;
-  o_strand[o] = sc == 0u ? (uint8_t)'+' : (sc == 1u ? (uint8_t)'-' : (uint8_t)'.');
-  o_yc[o] = (double)(float)yc[o];  // the YC:f tag round trip (bam_aux_update_float, tiebrush.cpp:509)
-  o_yx[o] = yx[o];
-  const uint32_t d = ooff[o];
-  o_cig_off[o] = d;
-  if (o + 1 == ng) o_cig_off[ng] = total;
-  const uint32_t shape = (uint32_t)k1, span = (uint32_t)(k1 >> 32);
-  if (shape == 0x80000000u) {
-    o_cig[d] = (span << 4) | C_M;
-  } else if ((shape >> 30) == 3u) {
-    const uint32_t a = (shape >> 20) & 0x3FFu, g = shape & 0xFFFFFu;
-    o_cig[d] = (a << 4) | C_M;
-    o_cig[d + 1] = (g << 4) | C_N;
-    o_cig[d + 2] = ((span - a - g) << 4) | C_M;
-  } else {
-    const uint32_t c0 = cfirst[o], n = cnt[o];
-    for (uint32_t k = 0; k < n; ++k) o_cig[d + k] = cig[c0 + k];
+struct G2cPrep {  // the first pass of tbk_coverage_tile, per view record (cov.hip: cov_prep_k) — and its three scalars
+  int32_t *start, *end, *yi;
+  uint32_t *jcnt, *ridx;
+  unsigned long long* sums;  // [0] M bases, [1] sum |YC|, [2] error bits
+};
+__global__ __launch_bounds__(256) void g2c_gather_key_k(uint32_t ng, const uint64_t* __restrict__ key, const double* __restrict__ yc,
+                                                        const int64_t* __restrict__ yx, const uint32_t* __restrict__ cfirst,
+                                                        const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cig,
+                                                        const uint32_t* __restrict__ ooff, uint32_t total, int32_t* __restrict__ o_tid,
+                                                        int32_t* __restrict__ o_pos, uint8_t* __restrict__ o_strand, double* __restrict__ o_yc,
+                                                        int64_t* __restrict__ o_yx, uint32_t* __restrict__ o_cig_off, uint32_t* __restrict__ o_cig,
+                                                        G2cPrep P) {
+  unsigned long long mb = 0, ay = 0;
+  uint32_t eb = 0;
+  for (uint32_t o = blockIdx.x * blockDim.x + threadIdx.x; o < ng; o += gridDim.x * blockDim.x) {
+    const uint64_t k0 = key[2 * (size_t)o], k1 = key[2 * (size_t)o + 1];
+    const int32_t tidv = (int32_t)(uint32_t)(k0 >> 33) - 1, posv = (int32_t)(uint32_t)((k0 >> 2) & 0x7FFFFFFFull) - 1;
+    o_tid[o] = tidv;
+    o_pos[o] = posv;
+    const uint32_t sc = (uint32_t)k0 & 3u;
+    o_strand[o] = sc == 0u ? (uint8_t)'+' : (sc == 1u ? (uint8_t)'-' : (uint8_t)'.');
+    const double y0 = (double)(float)yc[o];  // the YC:f tag round trip (bam_aux_update_float, tiebrush.cpp:509)
+    o_yc[o] = y0;
+    o_yx[o] = yx[o];
+    const uint32_t d = ooff[o];
+    o_cig_off[o] = d;
+    if (o + 1 == ng) o_cig_off[ng] = total;
+    const uint32_t shape = (uint32_t)k1, span = (uint32_t)(k1 >> 32);
+    int l, nex = 0;
+    if (shape == 0x80000000u) {
+      o_cig[d] = (span << 4) | C_M;
+      l = (int)span;
+      nex = 1;
+      mb += span;
+    } else if ((shape >> 30) == 3u) {
+      const uint32_t a = (shape >> 20) & 0x3FFu, g = shape & 0xFFFFFu;
+      o_cig[d] = (a << 4) | C_M;
+      o_cig[d + 1] = (g << 4) | C_N;
+      o_cig[d + 2] = ((span - a - g) << 4) | C_M;
+      l = (int)span;
+      nex = 2;
+      mb += span - g;
+    } else {
+      const uint32_t c0 = cfirst[o], n = cnt[o];
+      l = walk_exons(posv, cig + c0, n, [](int, int) {}, &nex);
+      for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t w = cig[c0 + k];
+        o_cig[d + k] = w;
+        const uint32_t op = cig_op(w);
+        if (op == C_M)
+          mb += cig_len(w);
+        else if (op != C_I && op != C_D && op != C_N && op != C_S)
+          eb |= TBK_DERR_FATALOP;
+      }
+      if (n >= 256) eb |= TBK_DERR_NCIGAR;
+    }
+    double y = y0;
+    if (!(y == rint(y)) || !(fabs(y) < 1073741824.0)) {
+      eb |= TBK_DERR_FRACTIONAL;
+      y = 0.0;
+    } else {
+      ay += (unsigned long long)fabs(y);
+    }
+    P.ridx[o] = o;
+    P.yi[o] = (int32_t)y;
+    P.start[o] = posv + 1;
+    P.end[o] = posv + l;
+    P.jcnt[o] = (uint32_t)(nex - 1);
+  }
+  __shared__ unsigned long long red_mb[4], red_ay[4];
+  __shared__ uint32_t red_e[4];
+  mb = wave_sum(mb);
+  ay = wave_sum(ay);
+#pragma unroll
+  for (int dd = 32; dd >= 1; dd >>= 1) eb |= __shfl_xor(eb, dd, 64);
+  if (lane_id() == 0) {
+    red_mb[threadIdx.x >> 6] = mb;
+    red_ay[threadIdx.x >> 6] = ay;
+    red_e[threadIdx.x >> 6] = eb;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int q = 1; q < 4; ++q) {
+      mb += red_mb[q];
+      ay += red_ay[q];
+      eb |= red_e[q];
+    }
+    if (mb) atomicAdd(&P.sums[0], mb);
+    if (ay) atomicAdd(&P.sums[1], ay);
+    if (eb) atomicOr(&P.sums[2], (unsigned long long)eb);
   }
 }
 __global__ void g2c_gather_k(uint32_t ng, const uint32_t* __restrict__ rep, const double* __restrict__ yc, const int64_t* __restrict__ yx,
@@ -2496,6 +2558,7 @@ int tbk_cov_view_build(tbk_ctx* ctx, const int32_t* r_tid, const int32_t* r_pos,
                        const uint64_t* g_key) {
   memset(view, 0, sizeof(*view));
   view->mem = TBK_MEM_DEVICE;
+  ctx->view_prep.valid = false;  // (the context's view is about to change)
   if (ng == 0) return 0;
   uint32_t* cnt = ws_alloc<uint32_t>(ctx, ng);
   uint32_t* ooff = ws_alloc<uint32_t>(ctx, ng);
@@ -2512,7 +2575,8 @@ int tbk_cov_view_build(tbk_ctx* ctx, const int32_t* r_tid, const int32_t* r_pos,
   const uint64_t total = ctx->h_scalars[20];
   if (total >= (1ull << 32)) return TBK_E2BIG;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  size_t need = al((size_t)ng * 4) * 2 + al(ng) + al((size_t)ng * 8) * 2 + al((size_t)(ng + 1) * 4) + al((size_t)total * 4 + 4);
+  size_t need = al((size_t)ng * 4) * 2 + al(ng) + al((size_t)ng * 8) * 2 + al((size_t)(ng + 1) * 4) + al((size_t)total * 4 + 4) +
+                (g_key ? al((size_t)ng * 4) * 5 : 0);
   if (need > ctx->d_view_cap) {
     if (ctx->d_view) (void)hipFree(ctx->d_view);
     ctx->d_view = nullptr;
@@ -2534,10 +2598,19 @@ int tbk_cov_view_build(tbk_ctx* ctx, const int32_t* r_tid, const int32_t* r_pos,
   int64_t* o_yx = (int64_t*)take((size_t)ng * 8);
   uint32_t* o_cig_off = (uint32_t*)take((size_t)(ng + 1) * 4);
   uint32_t* o_cig = (uint32_t*)take((size_t)total * 4 + 4);
-  if (g_key)
-    TBK_LAUNCH(ctx, "g2c_gather", g2c_gather_key_k, cdiv(ng, B), B, 0, ng, g_key, g_yc, g_yx, cfirst, cnt, r_cig, ooff, (uint32_t)total, o_tid, o_pos,
-               o_strand, o_yc, o_yx, o_cig_off, o_cig);
-  else
+  G2cPrep P{};
+  if (g_key) {  // ... and what the first pass of tbk_coverage_tile would compute from the view (see TbkCtx::view_prep)
+    P.start = (int32_t*)take((size_t)ng * 4);
+    P.end = (int32_t*)take((size_t)ng * 4);
+    P.yi = (int32_t*)take((size_t)ng * 4);
+    P.jcnt = (uint32_t*)take((size_t)ng * 4);
+    P.ridx = (uint32_t*)take((size_t)ng * 4);
+    P.sums = (unsigned long long*)(ctx->d_scalars + 24);
+    TBK_HIP(hipMemsetAsync(P.sums, 0, 3 * sizeof(uint64_t), ctx->stream));
+    TBK_LAUNCH(ctx, "g2c_gather", g2c_gather_key_k, (cdiv(ng, B) < 4096u ? cdiv(ng, B) : 4096u), B, 0, ng, g_key, g_yc, g_yx, cfirst, cnt, r_cig, ooff,
+               (uint32_t)total, o_tid, o_pos, o_strand, o_yc, o_yx, o_cig_off, o_cig, P);
+    TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 24, ctx->d_scalars + 24, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  } else
     TBK_LAUNCH(ctx, "g2c_gather", g2c_gather_k, cdiv(ng, B), B, 0, ng, g_rep, g_yc, g_yx, r_tid, r_pos, r_strand, cfirst, cnt, r_cig, ooff,
                (uint32_t)total, o_tid, o_pos, o_strand, o_yc, o_yx, o_cig_off, o_cig);
   TBK_HIP(hipStreamSynchronize(ctx->stream));
@@ -2552,6 +2625,20 @@ int tbk_cov_view_build(tbk_ctx* ctx, const int32_t* r_tid, const int32_t* r_pos,
   view->yc = o_yc;
   view->strand = o_strand;
   view->yx = o_yx;
+  if (g_key) {
+    auto& V = ctx->view_prep;
+    V.cig = o_cig;
+    V.n = ng;
+    V.start = P.start;
+    V.end = P.end;
+    V.yi = P.yi;
+    V.jcnt = P.jcnt;
+    V.ridx = P.ridx;
+    V.n_bases = ctx->h_scalars[24];
+    V.sum_abs = ctx->h_scalars[25];
+    V.err = (uint32_t)ctx->h_scalars[26];
+    V.valid = true;
+  }
   return 0;
 }
 

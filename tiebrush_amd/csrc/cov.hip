@@ -1201,14 +1201,31 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
     TBK_LAUNCH(ctx, "cov_valid", cov_valid_k, cdiv(n, B), B, 0, in->flag, n, valid);
     TBK_TRY(tbk_exscan_u32(ctx, valid, vpos, n, sc + 2));
   }
-  TBK_LAUNCH(ctx, "cov_prep", cov_prep_k, (cdiv(n, B) < 4096u ? cdiv(n, B) : 4096u), B, 0, n, all_valid ? (const uint32_t*)nullptr : valid, vpos, in->tid, in->pos, in->cig_off, in->cig,
-             sample_mode ? (const double*)nullptr : in->yc, want_cov ? 1 : 0, A, jcnt, sc, ctx->d_err);
+  // the context's own view, built from keys, comes with this pass's results (the view builder had the CIGAR words in hand)
+  const auto& V = ctx->view_prep;
+  const bool prepared = V.valid && all_valid && !sample_mode && in->mem == TBK_MEM_DEVICE && in->cig == V.cig && n == V.n &&
+                        !getenv("TBK_COV_PREP");  // (TBK_COV_PREP: test hook, run the pass anyway)
   uint32_t eb = 0;
-  TBK_TRY(tbk_sync_err(ctx, &eb));
+  if (prepared) {
+    A.ridx = V.ridx;
+    A.start = V.start;
+    A.end = V.end;
+    A.tid = const_cast<int32_t*>(in->tid);
+    A.yi = V.yi;
+    if (want_j) jcnt = V.jcnt;
+    eb = V.err;
+    if (!want_cov) eb &= ~(uint32_t)(TBK_DERR_FATALOP | TBK_DERR_NCIGAR);
+    ctx->h_scalars[0] = V.n_bases;
+    ctx->h_scalars[1] = V.sum_abs;
+  } else {
+    TBK_LAUNCH(ctx, "cov_prep", cov_prep_k, (cdiv(n, B) < 4096u ? cdiv(n, B) : 4096u), B, 0, n, all_valid ? (const uint32_t*)nullptr : valid, vpos, in->tid, in->pos, in->cig_off, in->cig,
+               sample_mode ? (const double*)nullptr : in->yc, want_cov ? 1 : 0, A, jcnt, sc, ctx->d_err);
+    TBK_TRY(tbk_sync_err(ctx, &eb));
+  }
   const bool fractional = (eb & TBK_DERR_FRACTIONAL) != 0;
   eb &= ~TBK_DERR_FRACTIONAL;
   if (eb) return tbk_derr_to_status(ctx, eb);
-  if (fractional) TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
+  if (fractional && !prepared) TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
   const uint32_t m = all_valid ? n : (uint32_t)ctx->h_scalars[2];
   out->n_bases = ctx->h_scalars[0];
   const uint64_t sum_abs = ctx->h_scalars[1];

@@ -101,6 +101,17 @@ struct tbk_ctx {
   // view storage for tbk_groups_to_cov_in
   char* d_view = nullptr;
   size_t d_view_cap = 0;
+  // what tbk_coverage_tile's first pass (cov_prep_k) would compute from the view, left behind by the view builder that had the
+  // CIGAR words in registers anyway (valid: the view of `cig` / `n` records is the context's current one and was built from keys)
+  struct ViewPrep {
+    bool valid = false;
+    const void* cig = nullptr;
+    uint32_t n = 0;
+    int32_t *start = nullptr, *end = nullptr, *yi = nullptr;
+    uint32_t *jcnt = nullptr, *ridx = nullptr;
+    uint64_t n_bases = 0, sum_abs = 0;
+    uint32_t err = 0;  // TBK_DERR_FATALOP / _NCIGAR (raised only when intervals are wanted) / _FRACTIONAL
+  } view_prep;
   bool profiling = false;
   std::vector<KTime> ktimes;
   std::vector<hipEvent_t> ev_pool;
