@@ -1573,7 +1573,8 @@ __global__ __launch_bounds__(PR_NT) void pr_merge_k(const int32_t* __restrict__ 
 __global__ __launch_bounds__(64) void pr_compact_k(uint32_t nw, const uint32_t* __restrict__ wbase, PrTemp T, const uint32_t* __restrict__ gbase,
                                                    const int32_t* __restrict__ rows, uint32_t cap, uint32_t* __restrict__ o_rep,
                                                    double* __restrict__ o_yc, int64_t* __restrict__ o_yx, int32_t* __restrict__ o_yd,
-                                                   int32_t* __restrict__ o_start, int32_t* __restrict__ o_end) {
+                                                   int32_t* __restrict__ o_start, int32_t* __restrict__ o_end, uint64_t* __restrict__ o_key,
+                                                   int strategy) {
   const uint32_t w = blockIdx.x;
   const uint32_t ng = T.wg_cnt[w];
   if (!ng) return;
@@ -1586,10 +1587,20 @@ __global__ __launch_bounds__(64) void pr_compact_k(uint32_t nw, const uint32_t* 
     o_yc[o] = T.yc[wb + g];
     o_yx[o] = (int64_t)T.yx[wb + g];
     o_yd[o] = (int32_t)T.yd[wb + g];
-    if (o_start || o_end) {
+    if (o_start || o_end || o_key) {
       const int32_t* R = rows + (size_t)r * TBK_PARTIAL_ROW;
       if (o_start) o_start[o] = R[1] + 1;
       if (o_end) o_end[o] = R[1] + R[9];
+      if (o_key) {  // tbk_groups_out.g_key of the reduced group: the row carries place, span and key word
+        const uint32_t st = (uint32_t)R[2] & 0xFFu, word = (uint32_t)R[10];
+        uint32_t shape = 0;
+        if (strategy == TBK_STRAT_CIGAR || strategy == TBK_STRAT_CLIP) {
+          if (word == (0x80000000u | C_M)) shape = 0x80000000u;
+          if ((word >> 30) == 3u) shape = word;
+        }
+        o_key[2 * (size_t)o] = ((uint64_t)(uint32_t)(R[0] + 1) << 33) | ((uint64_t)(uint32_t)(R[1] + 1) << 2) | strand_code((uint8_t)st);
+        o_key[2 * (size_t)o + 1] = ((uint64_t)(uint32_t)R[9] << 32) | shape;
+      }
     }
   }
 }
@@ -1683,9 +1694,14 @@ int tbk_partial_reduce_device(tbk_ctx* ctx, int strategy, const int32_t* rows, u
   out->n_groups = ng;
   if (ng > out->cap_groups) return TBK_E2BIG;
   if (ng == 0) return 0;
+  uint64_t* okey = out->g_key;
+  if (view && !okey) {  // the tiecov input of the reduced groups is built from their keys (and comes with tiecov's first pass)
+    okey = ws_alloc<uint64_t>(ctx, 2 * (size_t)ng);
+    if (!okey) return TBK_ENOMEM;
+  }
   TBK_LAUNCH(ctx, "pr_compact", pr_compact_k, nw, 64, 0, nw, wbase, T, gbase, rows, out->cap_groups, out->rep, out->yc, out->yx, out->yd,
-             out->g_start, out->g_end);
-  if (view) return tbk_cov_view_build(ctx, r_tid, r_pos, r_strand, cig_off, cig, out->rep, out->yc, out->yx, ng, view);
+             out->g_start, out->g_end, okey, strategy);
+  if (view) return tbk_cov_view_build(ctx, r_tid, r_pos, r_strand, cig_off, cig, out->rep, out->yc, out->yx, ng, view, okey);
   TBK_HIP(hipStreamSynchronize(ctx->stream));
   return tbk_check_launch(ctx, "partial_reduce");
 }
