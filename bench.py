@@ -8,14 +8,14 @@ tbk_collapse_tile (k-way merge order, grouping, YC/YX/YD) -> device chain (tbk_g
 Workload (BASELINE.json `configs`):
   N = 1   configs[2] = the largest single-GPU configuration: 64 synthetic sorted BAMs x 5M 100-bp reads, --clip collapse,
           then tiecov -c -j of the result                                                       (--profile c3 defaults)
-  N > 1   configs[3]'s shape: 32 files x 2M reads PER RANK (256 files over 8 GPUs), default CIGAR-only collapse.  Inside the
-          timed step every rank collapses its own files (the plain single-GPU path), the ranks agree on bundle-aligned
-          coordinate cuts (all-gather of sampled group keys, all-reduce rounds), exchange one 40-byte row per LOCAL GROUP plus
-          its CIGAR (all-to-all over RCCL/xGMI), and each reduces the partials of its range by key and covers it
-          (tiebrush_amd/dist.py, partials_collapse).  Tile i + 1's local collapse (a worker thread, two contexts in turn)
-          overlaps tile i's exchange / reduce / tiecov (main thread, which issues every collective).  Weak scaling: per-rank
-          input is fixed.  After the timed region every rank also times the plain single-GPU step on its own tile
-          (`plain_ms_per_step`): the same workload without the exchange.
+  N > 1   the same workload PER RANK (weak scaling: per-GPU work is what it is at N = 1, so value(N) / (N x value(1)) is the scaling
+          efficiency; --profile c4 runs configs[3]'s per-rank shape, 32 files x 2M reads, instead).  Inside the timed step every
+          rank collapses its own files (the plain single-GPU path), the ranks agree on bundle-aligned coordinate cuts
+          (all-gather of sampled group keys, all-reduce rounds), exchange one 48-byte row per LOCAL GROUP plus its CIGAR
+          (all-to-all over RCCL/xGMI), and each reduces the partials of its range by key and covers it (tiebrush_amd/dist.py,
+          partials_collapse).  Tile i + 1's local collapse (a worker thread, two contexts in turn) overlaps tile i's
+          exchange / reduce / tiecov (main thread, which issues every collective).  After the timed region every rank also
+          times the plain single-GPU step on its own tile (`plain_ms_per_step`): the same workload without the exchange.
 The tile is generated on the GPU (tiebrush_amd/synth_dev.py) before the timed region.
 
 Prints ONE JSON line (rank 0).  value = input alignment records collapsed per second, whole job, inputs resident in HBM.
@@ -137,7 +137,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--profile", default=None, choices=sorted(WORKLOADS), help="default: c3 at N=1, c4 at N>1")
+    ap.add_argument("--profile", default=None, choices=sorted(WORKLOADS), help="default: c3 (per GPU, at every N)")
     ap.add_argument("--files-per-gpu", type=int, default=None)
     ap.add_argument("--reads-per-file", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -187,7 +187,7 @@ def main():
     dev = "cuda:%d" % local_rank
     torch.cuda.set_device(local_rank)
 
-    profile = args.profile or ("c3" if not use_dist else "c4")
+    profile = args.profile or "c3"   # (N > 1: the same per-GPU workload as N = 1 — weak scaling; --profile c4 is BASELINE config 4's per-rank shape)
     files, reads, strat, strat_name = WORKLOADS[profile]
     files = args.files_per_gpu or files
     reads = args.reads_per_file or reads

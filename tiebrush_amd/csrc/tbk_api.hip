@@ -135,6 +135,12 @@ void tbk_prof_begin_call(tbk_ctx* ctx) {
   ctx->ev_used = 0;
 }
 void tbk_prof_end_call(tbk_ctx* ctx) {
+  static const bool ws_dbg = getenv("TBK_WS_DEBUG") != nullptr;  // how much of its arena a call used (sizing the hints)
+  if (ws_dbg) {
+    size_t over = 0;
+    for (auto& c : ctx->ws_overflow) over += c.second;
+    fprintf(stderr, "tbk arena %p: used %.2f GB of %.2f GB (+ %.2f GB in overflow chunks)\n", (void*)ctx, ctx->ws_off / 1e9, ctx->ws_cap / 1e9, over / 1e9);
+  }
   if (!ctx->registered.empty()) {  // host ranges page-locked for this call's copies (host_register): the copies have to be done first
     (void)hipStreamSynchronize(ctx->stream);
     for (void* p : ctx->registered) (void)hipHostUnregister(p);
@@ -468,11 +474,19 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
   TBK_TRY(finish_yd(ctx));  // a still-pending YD stage of the previous tile owns part of the arena
   TBK_HIP(hipSetDevice(ctx->device));
   tbk_prof_begin_call(ctx);
-  size_t hint = (size_t)in->n_records * 160 + (size_t)in->n_cigar_ops * 8 + ((size_t)8 << 20);
+  // Arena hints.  The sort path keeps keys, sort buffers and per-record scratch (160 B per record); the window path in its raw form —
+  // large plain tiles, the predicate of tbk_collapse_device restated — works on the input where it lies and needs half of that
+  // (config 3: 26 GB for 320 M records, 9.6 GB for its YD stage).  A hint that proves too small costs one call with overflow
+  // chunks, after which the arena has learnt its size.
+  bool lean = in->mem == TBK_MEM_DEVICE && !opts->store_frac && !opts->collapse_same && !in->prio_hi && !getenv("TBK_PATH") && !getenv("TBK_RAW") &&
+              (in->n_records >= (8u << 20) || (in->n_files > 64 && in->n_records >= 65536));
+  if (lean && in->tbmerged)
+    for (uint32_t f = 0; f < in->n_files; ++f) lean = lean && in->tbmerged[f] == 0;
+  size_t hint = (size_t)in->n_records * (lean ? 92 : 160) + (size_t)in->n_cigar_ops * 8 + ((size_t)8 << 20);
   TBK_TRY(ws_begin_call(ctx, hint));
   int rc;
   ctx->yd_job = nullptr;
-  const size_t yd_hint = (size_t)in->n_records * 96 + ((size_t)8 << 20);
+  const size_t yd_hint = (size_t)in->n_records * (lean ? 40 : 96) + ((size_t)8 << 20);
   if (in->mem == TBK_MEM_DEVICE && out->mem == TBK_MEM_HOST) {
     tbk_groups_out dout = *out;
     dout.mem = TBK_MEM_DEVICE;

@@ -22,7 +22,8 @@ tail -c 600 $O/bench_under_rocprof.json; echo; ls -la $O
 fi
 if [ "$PART" != a ]; then
 # the multi-rank step at world = 1 (group partials; its plain-path reference, wire bytes and the record-shuffle fallback ride in the line)
-python3 bench.py --force-dist --no-cpu-baseline --no-host-path --no-e2e > $O/bench_force_dist.json 2> $O/bench_force_dist.err
+python3 bench.py --force-dist --profile c4 --no-cpu-baseline --no-host-path --no-e2e > $O/bench_force_dist.json 2> $O/bench_force_dist.err
+python3 bench.py --force-dist --no-cpu-baseline --no-host-path --no-e2e > $O/bench_force_dist_c3.json 2> $O/bench_force_dist_c3.err
 python3 tools/cov_prof.py c3 64 5000000 10 > $O/cov_prof_c3.txt 2> $O/cov_prof.err
 python3 tools/prof_dist.py > $O/prof_dist_c4shape.txt 2> $O/prof_dist.err
 # the same kernels with the GPU to themselves (one context, the profiling steps of bench.py are serialised calls): the averages
