@@ -209,15 +209,17 @@ def test_loopback_device_resident_tbmerged_inputs(world, bam_loader, mode):
     check_against_flat(res, tile, flat, flat_cov)
 
 
-def test_partial_kernels_match_host_restatement():
-    """tbk_partial_keys / _pack / _unpack against the numpy restatement dist.py uses for host tiles"""
+@pytest.mark.parametrize("want_key", [True, False])
+def test_partial_kernels_match_host_restatement(want_key):
+    """tbk_partial_keys / _pack / _unpack against the numpy restatement dist.py uses for host tiles (with and without
+    tbk_groups_out.g_key, which spares the kernels their gathers through the representative)"""
     import torch
     from tiebrush_amd import api, dist, synth
     tile = synth.make_tile(5, 20000, "c5", n_loci=400)
     ctx = api.Context(0)
     dt = api.to_device(tile, "cuda:0")
     kw = dict(strategy="exon", max_nh=5, min_qual=1)
-    fin = ctx.collapse(dt, want_coords=True, want_effend=True, **kw)
+    fin = ctx.collapse(dt, want_coords=True, want_effend=True, want_key=want_key, **kw)
     hfin = api.to_numpy(fin)
     key, emax, bad = ctx.partial_keys(dt, fin)
     hk, hm, hb = dist._partial_keys_np(tile, hfin)

@@ -466,9 +466,11 @@ struct PmLoad {
   const uint32_t* rep;
   const int32_t* tid;
   const int32_t* g_end;
+  const uint64_t* gkey;  // tbk_groups_out.g_key when the caller has it: the reference id without the gather through rep
   __device__ __forceinline__ PmKey operator()(uint32_t o) const {
     // (tid + 1) : 32 | end + 1 : 31 — the same keyed end as ShLoad: a cut lies beyond end + 1
-    const uint64_t m = ((uint64_t)(uint32_t)(tid[rep[o]] + 1) << 31) | (uint32_t)(g_end[o] + 1);
+    const uint32_t t1 = gkey ? (uint32_t)(gkey[2 * (size_t)o] >> 33) : (uint32_t)(tid[rep[o]] + 1);
+    const uint64_t m = ((uint64_t)t1 << 31) | (uint32_t)(g_end[o] + 1);
     return PmKey{(uint32_t)(m >> 32), (uint32_t)m};
   }
 };
@@ -480,10 +482,12 @@ struct PmStore {
 };
 // key of a local group for the cut search + what the 32-bit row fields cannot hold (flag word: bit 0)
 __global__ void partial_keys_k(uint32_t ng, const uint32_t* __restrict__ rep, const int32_t* __restrict__ tid, const int32_t* __restrict__ g_start,
-                               const double* __restrict__ yc, const int64_t* __restrict__ yx, int64_t* __restrict__ key, uint32_t* __restrict__ bad) {
+                               const double* __restrict__ yc, const int64_t* __restrict__ yx, const uint64_t* __restrict__ gkey,
+                               int64_t* __restrict__ key, uint32_t* __restrict__ bad) {
   const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= ng) return;
-  key[o] = (int64_t)(((uint64_t)(uint32_t)(tid[rep[o]] + 1) << 31) | (uint32_t)g_start[o]);
+  const uint32_t t1 = gkey ? (uint32_t)(gkey[2 * (size_t)o] >> 33) : (uint32_t)(tid[rep[o]] + 1);
+  key[o] = (int64_t)(((uint64_t)t1 << 31) | (uint32_t)g_start[o]);
   const double y = yc[o];
   if (!(y == rint(y)) || y < 1.0 || y >= 2147483648.0 || yx[o] < 0 || yx[o] >= 2147483648ll) atomicOr(bad, 1u);
 }
@@ -645,9 +649,9 @@ extern "C" int tbk_partial_keys(tbk_ctx* ctx, const tbk_soa_in* in, const tbk_gr
   TBK_TRY(tbk_ws_reserve(ctx, (size_t)ng * 8 + ((size_t)1 << 20)));
   uint64_t* sc = ctx->d_scalars;
   TBK_HIP(hipMemsetAsync(sc, 0, 16 * sizeof(uint64_t), ctx->stream));
-  TBK_LAUNCH(ctx, "partial_keys", partial_keys_k, cdiv(ng, SH_B), SH_B, 0, ng, g->rep, in->tid, g->g_start, g->yc, g->yx, key, (uint32_t*)(sc + 8));
+  TBK_LAUNCH(ctx, "partial_keys", partial_keys_k, cdiv(ng, SH_B), SH_B, 0, ng, g->rep, in->tid, g->g_start, g->yc, g->yx, g->g_key, key, (uint32_t*)(sc + 8));
   {
-    PmLoad ld{g->rep, in->tid, g->g_end};
+    PmLoad ld{g->rep, in->tid, g->g_end, g->g_key};
     PmStore st{emax};
     TBK_TRY((scan_op_run<PmKey, PmOp, PmLoad, PmStore>(ctx, "partial_emax_scan", ng, ld, st, PmOp{}, PmKey{0u, 0u})));
   }

@@ -399,64 +399,69 @@ __device__ __forceinline__ uint16_t* wg_merge_sort(uint16_t* src, uint16_t* dst,
                                                    uint32_t lim /* indices are < lim */) {
   const uint32_t t = threadIdx.x;
   const int eu = (int)((n + WG_NT - 1) / WG_NT);  // item slots in use (uniform)
+  // the rounds are branch-free, so a wave executes all of them whether or not it holds items: a wave whose items all lie
+  // beyond n (most waves of a deep window: ~ 80 groups for 512 threads) only keeps the barriers
+  const bool live = (t & ~63u) < n;
   for (uint32_t len = 1; len < n; len <<= 1) {
-    uint32_t idx[E], oa[E], osz[E], cntv[E], dbase[E];
-    uint64_t kh[E], kl[E];
-#pragma unroll
-    for (int u = 0; u < E; ++u) {
-      const uint32_t e = t + (uint32_t)u * WG_NT;
-      cntv[u] = osz[u] = oa[u] = idx[u] = dbase[u] = 0;
-      kh[u] = kl[u] = 0;
-      if (u < eu && e < n) {
-        const uint32_t base = e & ~(2 * len - 1);
-        const uint32_t mid = base + len < n ? base + len : n;
-        const uint32_t end = base + 2 * len < n ? base + 2 * len : n;
-        idx[u] = src[e];
-        kh[u] = hi[idx[u]];
-        kl[u] = lo[idx[u]];
-        if (e < mid) {  // left run: + elements of the right run below me
-          oa[u] = mid;
-          osz[u] = end - mid;
-          dbase[u] = e;
-        } else {  // right run: + elements of the left run below me
-          oa[u] = base;
-          osz[u] = mid - base;
-          dbase[u] = base + (e - mid);
-        }
-      }
-    }
-    for (uint32_t st = len; st > 0; st >>= 1) {
-      uint32_t o[E];
-      uint64_t oh[E], ol[E];
+    if (live) {
+      uint32_t idx[E], oa[E], osz[E], cntv[E], dbase[E];
+      uint64_t kh[E], kl[E];
 #pragma unroll
       for (int u = 0; u < E; ++u) {
-        if (u < eu) {
-          const uint32_t c = cntv[u] + st;
-          const uint32_t pos = oa[u] + (c <= osz[u] ? c : 1u) - 1u;
-          o[u] = src[pos < n ? pos : 0u];
+        const uint32_t e = t + (uint32_t)u * WG_NT;
+        cntv[u] = osz[u] = oa[u] = idx[u] = dbase[u] = 0;
+        kh[u] = kl[u] = 0;
+        if (u < eu && e < n) {
+          const uint32_t base = e & ~(2 * len - 1);
+          const uint32_t mid = base + len < n ? base + len : n;
+          const uint32_t end = base + 2 * len < n ? base + 2 * len : n;
+          idx[u] = src[e];
+          kh[u] = hi[idx[u]];
+          kl[u] = lo[idx[u]];
+          if (e < mid) {  // left run: + elements of the right run below me
+            oa[u] = mid;
+            osz[u] = end - mid;
+            dbase[u] = e;
+          } else {  // right run: + elements of the left run below me
+            oa[u] = base;
+            osz[u] = mid - base;
+            dbase[u] = base + (e - mid);
+          }
+        }
+      }
+      for (uint32_t st = len; st > 0; st >>= 1) {
+        uint32_t o[E];
+        uint64_t oh[E], ol[E];
+#pragma unroll
+        for (int u = 0; u < E; ++u) {
+          if (u < eu) {
+            const uint32_t c = cntv[u] + st;
+            const uint32_t pos = oa[u] + (c <= osz[u] ? c : 1u) - 1u;
+            o[u] = src[pos < n ? pos : 0u];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < E; ++u) {
+          if (u < eu) {
+            const uint32_t oo = o[u] < lim ? o[u] : 0u;
+            oh[u] = hi[oo];
+            ol[u] = lo[oo];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < E; ++u) {
+          if (u < eu) {
+            const uint32_t c = cntv[u] + st;
+            const bool less = (oh[u] < kh[u]) | ((oh[u] == kh[u]) & ((ol[u] < kl[u]) | ((ol[u] == kl[u]) & (o[u] < idx[u]))));
+            cntv[u] = (c <= osz[u] && less) ? c : cntv[u];
+          }
         }
       }
 #pragma unroll
       for (int u = 0; u < E; ++u) {
-        if (u < eu) {
-          const uint32_t oo = o[u] < lim ? o[u] : 0u;
-          oh[u] = hi[oo];
-          ol[u] = lo[oo];
-        }
+        const uint32_t e = t + (uint32_t)u * WG_NT;
+        if (u < eu && e < n) dst[dbase[u] + cntv[u]] = (uint16_t)idx[u];
       }
-#pragma unroll
-      for (int u = 0; u < E; ++u) {
-        if (u < eu) {
-          const uint32_t c = cntv[u] + st;
-          const bool less = (oh[u] < kh[u]) | ((oh[u] == kh[u]) & ((ol[u] < kl[u]) | ((ol[u] == kl[u]) & (o[u] < idx[u]))));
-          cntv[u] = (c <= osz[u] && less) ? c : cntv[u];
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < E; ++u) {
-      const uint32_t e = t + (uint32_t)u * WG_NT;
-      if (u < eu && e < n) dst[dbase[u] + cntv[u]] = (uint16_t)idx[u];
     }
     __syncthreads();
     uint16_t* tmp = src;
@@ -617,20 +622,6 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
   {
     const uint32_t* row0 = In.off + (size_t)w * k;
     const uint32_t* row1 = row0 + k;
-    // k <= 1024 < 3 * WG_NT; thread t owns the fpt files from t * fpt (blocked: prefix order = file order)
-    const uint32_t fpt = (k + WG_NT - 1) / WG_NT;
-    uint32_t a[3], len[3], sum = 0;
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const uint32_t f = t * fpt + u;
-      a[u] = len[u] = 0;
-      if ((uint32_t)u < fpt && f < k) {
-        a[u] = row0[f];
-        const uint32_t b = row1[f];
-        len[u] = b > a[u] ? b - a[u] : 0u;
-      }
-      sum += len[u];
-    }
     for (uint32_t i = t; i < gcap; i += WG_NT) {
       tc[i] = ~0ull;
       trep[i] = ~0ull;
@@ -645,16 +636,46 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
       s_misc[4] = 0;  // RAW: carry of the effective-end scan into chunk 0 ...
       s_misc[5] = 0;  // ... and into chunk 1 (alternating)
     }
-    uint32_t tot;
-    uint32_t ex = wg_block_excl<uint32_t>(sum, sm_u, &tot);
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const uint32_t f = t * fpt + u;
-      if ((uint32_t)u < fpt && f < k) {
-        pre[f] = ex;
-        rb[f] = a[u] - ex;  // (mod 2^32)
+    if constexpr (GC > 0) {  // <= 64 files: the piece lengths are one wave's scan (a block scan is ~ 100 instructions in each of the eight waves)
+      if (t < 64) {
+        uint32_t a0 = 0, len0 = 0;
+        if (t < k) {
+          a0 = row0[t];
+          const uint32_t b = row1[t];
+          len0 = b > a0 ? b - a0 : 0u;
+        }
+        const uint32_t ex0 = wave_incl_sum(len0) - len0;
+        if (t < k) {
+          pre[t] = ex0;
+          rb[t] = a0 - ex0;  // (mod 2^32)
+        }
       }
-      ex += len[u];
+    } else {
+      // k <= 1024 < 3 * WG_NT; thread t owns the fpt files from t * fpt (blocked: prefix order = file order)
+      const uint32_t fpt = (k + WG_NT - 1) / WG_NT;
+      uint32_t a[3], len[3], sum = 0;
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const uint32_t f = t * fpt + u;
+        a[u] = len[u] = 0;
+        if ((uint32_t)u < fpt && f < k) {
+          a[u] = row0[f];
+          const uint32_t b = row1[f];
+          len[u] = b > a[u] ? b - a[u] : 0u;
+        }
+        sum += len[u];
+      }
+      uint32_t tot;
+      uint32_t ex = wg_block_excl<uint32_t>(sum, sm_u, &tot);
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const uint32_t f = t * fpt + u;
+        if ((uint32_t)u < fpt && f < k) {
+          pre[f] = ex;
+          rb[f] = a[u] - ex;  // (mod 2^32)
+        }
+        ex += len[u];
+      }
     }
     if (t == 0) pre[k] = n_w;
     if (GC > 0 && t > k && t <= 64) pre[t] = n_w;  // (padding: no item reaches these)
@@ -692,6 +713,14 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
       uint32_t errb = 0;
 #pragma unroll
       for (int u0 = 0; u0 < NR; u0 += WG_RS) {  // WG_RS records per thread are decoded together
+        // (the code below is branch-free per lane: a wave whose row lies wholly beyond the window — the tail of its last chunk —
+        // would execute all of it for nothing; it leaves the aggregate an all-absent row would have left and moves on)
+        if (c0 + (uint32_t)u0 * WG_NT + (t & ~63u) >= n_w) {
+#pragma unroll
+          for (int v = 0; v < WG_RS; ++v)
+            if (lane_id() == 63) s_agg[(u0 + v) * WG_NW + (t >> 6)] = make_uint2(0u, 1u);
+          continue;
+        }
         RawA ra[WG_RS];
         CigView cv[WG_RS];
         bool first[WG_RS], fromem[WG_RS];
@@ -788,34 +817,36 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
     if constexpr (RAW) {  // effective ends: the carry that enters every (row, wave) of this chunk, folded in element order
       // (lane q of every wave holds aggregate q; a 16-lane segmented scan gives the carry behind each of them)
       static_assert(NR * WG_NW <= 16, "the carries are folded inside one DPP row");
-      const uint32_t c0 = s_misc[4 + par];
-      const uint32_t lq = lane_id();
-      const uint2 a = lq < (uint32_t)(NR * WG_NW) ? s_agg[lq] : make_uint2(0u, 0u);
-      uint32_t ax = a.x, af = a.y;
+      if (c0 + (t & ~63u) < n_w) {  // (a wave without a record in this chunk has no use for the carries; wave 0 always has one)
+        const uint32_t cin = s_misc[4 + par];
+        const uint32_t lq = lane_id();
+        const uint2 a = lq < (uint32_t)(NR * WG_NW) ? s_agg[lq] : make_uint2(0u, 0u);
+        uint32_t ax = a.x, af = a.y;
 #define WG_FOLD_STEP(ctrl)                                                                       \
-  {                                                                                              \
-    const uint32_t xo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ax, ctrl, 0xf, 0xf, false); \
-    const uint32_t fq = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)af, ctrl, 0xf, 0xf, false); \
-    ax = af ? ax : (xo > ax ? xo : ax);                                                          \
-    af |= fq;                                                                                    \
-  }
-      WG_FOLD_STEP(0x111)  // row_shr:1, 2, 4, 8
-      WG_FOLD_STEP(0x112)
-      WG_FOLD_STEP(0x114)
-      WG_FOLD_STEP(0x118)
+    {                                                                                              \
+      const uint32_t xo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ax, ctrl, 0xf, 0xf, false); \
+      const uint32_t fq = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)af, ctrl, 0xf, 0xf, false); \
+      ax = af ? ax : (xo > ax ? xo : ax);                                                          \
+      af |= fq;                                                                                    \
+    }
+        WG_FOLD_STEP(0x111)  // row_shr:1, 2, 4, 8
+        WG_FOLD_STEP(0x112)
+        WG_FOLD_STEP(0x114)
+        WG_FOLD_STEP(0x118)
 #undef WG_FOLD_STEP
-      const uint32_t cq = af ? ax : (ax > c0 ? ax : c0);  // the carry behind aggregate lq
-      uint32_t snap[NR];
-      const int wv = __builtin_amdgcn_readfirstlane((int)(t >> 6));
+        const uint32_t cq = af ? ax : (ax > cin ? ax : cin);  // the carry behind aggregate lq
+        uint32_t snap[NR];
+        const int wv = __builtin_amdgcn_readfirstlane((int)(t >> 6));
 #pragma unroll
-      for (int u = 0; u < NR; ++u) {
-        const int q = u * WG_NW + wv;  // uniform
-        snap[u] = q == 0 ? c0 : (uint32_t)__builtin_amdgcn_readlane((int)cq, q - 1);
+        for (int u = 0; u < NR; ++u) {
+          const int q = u * WG_NW + wv;  // uniform
+          snap[u] = q == 0 ? cin : (uint32_t)__builtin_amdgcn_readlane((int)cq, q - 1);
+        }
+        if (t == 0) s_misc[4 + (par ^ 1u)] = (uint32_t)__builtin_amdgcn_readlane((int)cq, NR * WG_NW - 1);
+#pragma unroll
+        for (int u = 0; u < NR; ++u) eff[u] = fs[u] ? xs[u] : (xs[u] > snap[u] ? xs[u] : snap[u]);
       }
-      if (t == 0) s_misc[4 + (par ^ 1u)] = (uint32_t)__builtin_amdgcn_readlane((int)cq, NR * WG_NW - 1);
       par ^= 1u;
-#pragma unroll
-      for (int u = 0; u < NR; ++u) eff[u] = fs[u] ? xs[u] : (xs[u] > snap[u] ? xs[u] : snap[u]);
       if (R.I.prio_hi) {  // cross-rank tiles: the merge order was fixed where the files live — the explicit priority replaces the scan
 #pragma unroll
         for (int u = 0; u < NR; ++u)
@@ -972,6 +1003,9 @@ __global__ __launch_bounds__(WG_NT, 8) void wg_hash_k(WgIn In, WgRaw R, WgTemp T
   __shared__ uint32_t sm_u[WG_NW];
   __shared__ uint32_t s_misc[8];
   __shared__ uint2 s_agg[WG_R * WG_NW];
+  // (Blocks b and b + 8 are observed to share an XCD.  Handing each XCD a contiguous eighth of the window list, so that the cache lines in
+  // which consecutive windows' pieces meet are found in one L2, was measured slower — 9.0 vs 7.5 ms on config 3: eight times as many
+  // streams into every column — so the windows in flight stay one compact range of the tile.)
   wg_hash_window<2, RAW, RAW ? WG_RR : WG_R, ST, GC, PART>(In, R, T, gcap, nwords, seed, wlist[blockIdx.x], lds, sm_u, s_misc, s_agg, ovf, ovf_cap, false,
                                                            err);
 }
@@ -1432,7 +1466,8 @@ struct PrTemp {      // per window, at the window's row base
   uint32_t* rep;     // row of the representative
   double* yc;
   uint32_t *yx, *yd;
-  uint32_t* wg_cnt;  // [nw] groups of the window
+  uint64_t *khi, *klo;  // the group's key words as the merge holds them (place + strand code; span + key word)
+  uint32_t* wg_cnt;     // [nw] groups of the window
 };
 
 __global__ __launch_bounds__(PR_NT) void pr_merge_k(const int32_t* __restrict__ rows, const uint32_t* __restrict__ off, uint32_t k, uint32_t nw,
@@ -1565,13 +1600,15 @@ __global__ __launch_bounds__(PR_NT) void pr_merge_k(const int32_t* __restrict__ 
     T.yc[wb + gid] = yc;
     T.yx[wb + gid] = yx;
     T.yd[wb + gid] = yd;
+    T.khi[wb + gid] = h;
+    T.klo[wb + gid] = l;
     ++gid;
   }
   if (t == 0) T.wg_cnt[w] = tot;
 }
 
 __global__ __launch_bounds__(64) void pr_compact_k(uint32_t nw, const uint32_t* __restrict__ wbase, PrTemp T, const uint32_t* __restrict__ gbase,
-                                                   const int32_t* __restrict__ rows, uint32_t cap, uint32_t* __restrict__ o_rep,
+                                                   uint32_t cap, uint32_t* __restrict__ o_rep,
                                                    double* __restrict__ o_yc, int64_t* __restrict__ o_yx, int32_t* __restrict__ o_yd,
                                                    int32_t* __restrict__ o_start, int32_t* __restrict__ o_end, uint64_t* __restrict__ o_key,
                                                    int strategy) {
@@ -1587,19 +1624,20 @@ __global__ __launch_bounds__(64) void pr_compact_k(uint32_t nw, const uint32_t* 
     o_yc[o] = T.yc[wb + g];
     o_yx[o] = (int64_t)T.yx[wb + g];
     o_yd[o] = (int32_t)T.yd[wb + g];
-    if (o_start || o_end || o_key) {
-      const int32_t* R = rows + (size_t)r * TBK_PARTIAL_ROW;
-      if (o_start) o_start[o] = R[1] + 1;
-      if (o_end) o_end[o] = R[1] + R[9];
-      if (o_key) {  // tbk_groups_out.g_key of the reduced group: the row carries place, span and key word
-        const uint32_t st = (uint32_t)R[2] & 0xFFu, word = (uint32_t)R[10];
+    if (o_start || o_end || o_key) {  // place, span and key word of the group ride with the merge (no gather of the representative's row)
+      const uint64_t h = T.khi[wb + g], l = T.klo[wb + g];
+      const int32_t start = (int32_t)((h >> 2) & 0x7FFFFFFFull);
+      if (o_start) o_start[o] = start;
+      if (o_end) o_end[o] = start + (int32_t)(uint32_t)(l >> 32) - 1;
+      if (o_key) {  // tbk_groups_out.g_key of the reduced group
+        const uint32_t word = (uint32_t)l;
         uint32_t shape = 0;
         if (strategy == TBK_STRAT_CIGAR || strategy == TBK_STRAT_CLIP) {
           if (word == (0x80000000u | C_M)) shape = 0x80000000u;
           if ((word >> 30) == 3u) shape = word;
         }
-        o_key[2 * (size_t)o] = ((uint64_t)(uint32_t)(R[0] + 1) << 33) | ((uint64_t)(uint32_t)(R[1] + 1) << 2) | strand_code((uint8_t)st);
-        o_key[2 * (size_t)o + 1] = ((uint64_t)(uint32_t)R[9] << 32) | shape;
+        o_key[2 * (size_t)o] = h;
+        o_key[2 * (size_t)o + 1] = (l & 0xFFFFFFFF00000000ull) | shape;
       }
     }
   }
@@ -1663,8 +1701,10 @@ int tbk_partial_reduce_device(tbk_ctx* ctx, int strategy, const int32_t* rows, u
   T.yc = ws_alloc<double>(ctx, m);
   T.yx = ws_alloc<uint32_t>(ctx, m);
   T.yd = ws_alloc<uint32_t>(ctx, m);
+  T.khi = ws_alloc<uint64_t>(ctx, m);
+  T.klo = ws_alloc<uint64_t>(ctx, m);
   T.wg_cnt = ws_alloc<uint32_t>(ctx, nw);
-  if (!W || !off || !wbase || !gbase || !T.wg_cnt || !T.yd) return TBK_ENOMEM;
+  if (!W || !off || !wbase || !gbase || !T.wg_cnt || !T.klo) return TBK_ENOMEM;
   if (nsp) {
     uint64_t* Y = ws_alloc<uint64_t>(ctx, ns);
     uint64_t* Y2 = ws_alloc<uint64_t>(ctx, ns);
@@ -1699,7 +1739,7 @@ int tbk_partial_reduce_device(tbk_ctx* ctx, int strategy, const int32_t* rows, u
     okey = ws_alloc<uint64_t>(ctx, 2 * (size_t)ng);
     if (!okey) return TBK_ENOMEM;
   }
-  TBK_LAUNCH(ctx, "pr_compact", pr_compact_k, nw, 64, 0, nw, wbase, T, gbase, rows, out->cap_groups, out->rep, out->yc, out->yx, out->yd,
+  TBK_LAUNCH(ctx, "pr_compact", pr_compact_k, nw, 64, 0, nw, wbase, T, gbase, out->cap_groups, out->rep, out->yc, out->yx, out->yd,
              out->g_start, out->g_end, okey, strategy);
   if (view) return tbk_cov_view_build(ctx, r_tid, r_pos, r_strand, cig_off, cig, out->rep, out->yc, out->yx, ng, view, okey);
   TBK_HIP(hipStreamSynchronize(ctx->stream));
