@@ -757,16 +757,20 @@ struct YdEmit {
 // the tile's per-list prefix and its group by selecting the r-th set bit of the list's 256-bit column — so that consecutive
 // threads write consecutive positions of one list.
 __device__ __forceinline__ uint32_t ys_select(uint64_t v, uint32_t r) {  // position of the r-th (0-based) set bit of v
+  // (the half first, then five 32-bit steps of bit-field extract + count: the placement loop is bound by its vector instructions)
+  const uint32_t lo = (uint32_t)v, cl = (uint32_t)__builtin_popcount(lo);
+  const bool up = r >= cl;
+  const uint32_t w = up ? (uint32_t)(v >> 32) : lo;
+  r = up ? r - cl : r;
   uint32_t pos = 0;
 #pragma unroll
-  for (uint32_t st = 32; st >= 1; st >>= 1) {
-    const uint32_t c = (uint32_t)__builtin_popcountll((v >> pos) & ((1ull << st) - 1ull));
-    if (r >= c) {
-      r -= c;
-      pos += st;
-    }
+  for (uint32_t st = 16; st >= 1; st >>= 1) {
+    const uint32_t c = (uint32_t)__builtin_popcount((w >> pos) & ((1u << st) - 1u));
+    const bool go = r >= c;
+    r = go ? r - c : r;
+    pos = go ? pos + st : pos;
   }
-  return pos;
+  return pos + (up ? 32u : 0u);
 }
 __global__ __launch_bounds__(YS_NT) void yd_lscatter_k(YsIn S, uint32_t ntiles, const uint32_t* __restrict__ table, const uint64_t* __restrict__ totals,
                                                        const uint4* __restrict__ agg, const uint64_t* __restrict__ gfiles, YdGroups Q, YdItems Y,
@@ -836,6 +840,13 @@ __global__ __launch_bounds__(YS_NT) void yd_lscatter_k(YsIn S, uint32_t ntiles, 
     pre[2 * t] = inc - a - b;
     pre[2 * t + 1] = inc - b;
     if (t == 63) pre[YS_NL] = inc;
+  } else if (t < 64 + YS_NL) {  // ... and of every list's items wave by wave (the cells' aggregates are dead: pa holds it)
+    const uint32_t c = t - 64;
+    uint32_t run = 0;
+    for (uint32_t x = 0; x < YS_NT / 64; ++x) {
+      pa[x][c] = run;
+      run += (uint32_t)__builtin_popcountll(wb[x][c]);
+    }
   }
   __syncthreads();
   const uint32_t T = pre[YS_NL];
@@ -845,12 +856,12 @@ __global__ __launch_bounds__(YS_NT) void yd_lscatter_k(YsIn S, uint32_t ntiles, 
     for (uint32_t st = 64; st >= 1; st >>= 1) c = pre[c + st] <= idx ? c + st : c;
     uint32_t r = idx - pre[c];
     const uint32_t rank = r;
+    // the wave whose column holds the r-th group: the last one with at most r of the list's items before it (it holds an item:
+    // r < the list's count).  A walk over the columns ran as long as the slowest lane of the wave: sixteen rounds, not eight.
     uint32_t x = 0;
-    for (;; ++x) {  // the wave whose column holds the r-th group (exists: r < the list's count)
-      const uint32_t n = (uint32_t)__builtin_popcountll(wb[x][c]);
-      if (r < n) break;
-      r -= n;
-    }
+#pragma unroll
+    for (uint32_t st = YS_NT / 128; st >= 1; st >>= 1) x = pa[x + st][c] <= r ? x + st : x;
+    r -= pa[x][c];
     const uint32_t bit = ys_select(wb[x][c], r);
     const uint32_t g = x * 64u + bit;
     const uint32_t pos = base[c] + rank;
