@@ -295,6 +295,20 @@ __device__ __forceinline__ RawA wg_raw_a(const ColIn& I, uint32_t i, bool need_p
   a.ptid = I.tid[j];
   return a;
 }
+// ... with the record's CIGAR range already at hand (fetched a chunk ahead, wg_hash_window)
+__device__ __forceinline__ RawA wg_raw_a(const ColIn& I, uint32_t i, bool need_prev, uint32_t c0, uint32_t c1) {
+  RawA a;
+  a.pos = I.pos[i];
+  a.tidv = I.tid[i];
+  a.fl_mq_sc = (uint32_t)I.flag[i] | ((uint32_t)I.mapq[i] << 16) | (strand_code(I.strand[i]) << 24);
+  a.nh = I.nh[i];
+  a.c0 = c0;
+  a.nc = c1 - c0;
+  const uint32_t j = need_prev && i > 0 ? i - 1 : i;
+  a.ppos = I.pos[j];
+  a.ptid = I.tid[j];
+  return a;
+}
 __device__ __forceinline__ CigView wg_raw_b(const ColIn& I, const RawA& a) {
   CigView c;
   const uint32_t* safe = I.cig_off;  // (always readable)
@@ -683,6 +697,19 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
   __syncthreads();
   phase(0);
   uint32_t npass_t = 0, nslot_t = 0, par = 0;
+  // RAW, one record per thread and chunk: the piece, the record and the CIGAR range of this thread's record of the NEXT chunk are
+  // fetched a chunk ahead (four registers), so that a chunk's CIGAR words are asked for together with its fields: one round trip to
+  // memory per chunk instead of two dependent ones
+  constexpr bool AHEAD = RAW && NR == 1 && WG_RS == 1;
+  uint32_t a_fil = 0, a_src = 0, a_c0 = 0, a_c1 = 0;
+  if constexpr (AHEAD) {
+    if (t < n_w) {
+      a_fil = piece(pre, t);
+      a_src = rb[a_fil] + t;
+      a_c0 = R.I.cig_off[a_src];
+      a_c1 = R.I.cig_off[a_src + 1];
+    }
+  }
   // the window streams through in chunks of WG_NT * NR records: NR records per thread so that their loads and probes
   // overlap; two barriers per chunk
   for (uint32_t c0 = 0; c0 < n_w; c0 += WG_NT * NR) {
@@ -730,15 +757,33 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
           const int u = u0 + v;
           const uint32_t e = c0 + (uint32_t)u * WG_NT + t;
           const bool act = e < n_w;
-          fil[u] = act ? piece(pre, e) : 0u;
-          src[u] = act ? rb[fil[u]] + e : 0u;
+          if constexpr (AHEAD) {
+            fil[u] = a_fil;  // (0, 0 and an empty CIGAR where there is no record)
+            src[u] = a_src;
+          } else {
+            fil[u] = act ? piece(pre, e) : 0u;
+            src[u] = act ? rb[fil[u]] + e : 0u;
+          }
           first[v] = !act || e == pre[fil[u]];
           fromem[v] = act && (first[v] || lane_id() == 0);  // the record before it in its file is not the lane to the left
-          ra[v] = wg_raw_a(R.I, src[u], fromem[v]);
+          if constexpr (AHEAD)
+            ra[v] = wg_raw_a(R.I, src[u], fromem[v], a_c0, a_c1);
+          else
+            ra[v] = wg_raw_a(R.I, src[u], fromem[v]);
           f0[v] = fromem[v] ? R.I.file_off[fil[u]] : 0u;
         }
 #pragma unroll
         for (int v = 0; v < WG_RS; ++v) cv[v] = wg_raw_b(R.I, ra[v]);
+        if constexpr (AHEAD) {  // behind this chunk's loads: where the next chunk's record and its CIGAR are
+          const uint32_t e2 = c0 + WG_NT + t;
+          a_fil = a_src = a_c0 = a_c1 = 0;
+          if (e2 < n_w) {
+            a_fil = piece(pre, e2);
+            a_src = rb[a_fil] + e2;
+            a_c0 = R.I.cig_off[a_src];
+            a_c1 = R.I.cig_off[a_src + 1];
+          }
+        }
 #pragma unroll
         for (int v = 0; v < WG_RS; ++v) {
           const int u = u0 + v;
