@@ -1399,21 +1399,31 @@ __global__ __launch_bounds__(64) void wg_compact_k(uint32_t nw, WgTemp T, const 
   if (!ng) return;
   const uint32_t wb = T.wbase[w], gb = gbase[w], pb = pbase[w];
   for (uint32_t g = threadIdx.x; g < ng; g += 64) {
+    // (every load before the first store: the arrays are not known to be distinct, a load behind a store would wait for its turn)
     const uint32_t sg = gb + g;
-    F.ghi[sg] = T.hi[wb + g];
-    F.glo[sg] = T.lo[wb + g];
+    const uint64_t hi = T.hi[wb + g], lo = T.lo[wb + g];
     const unsigned long long r = T.rep[wb + g];
+    const uint32_t cnt = T.cnt[wb + g], nsv = T.ns[wb + g];
+    const uint64_t fm = F.fmask ? T.fmask[wb + g] : 0ull;
+    const uint32_t po = F.fmask ? 0u : T.poff[wb + g];
+    uint32_t yx = 0, yd = 0;
+    if (F.yxin) {  // (group partials only: plain inputs carry no YX / YD — the arrays are null and the writers of the results know)
+      yx = T.yx[wb + g];
+      yd = T.yd[wb + g];
+    }
+    F.ghi[sg] = hi;
+    F.glo[sg] = lo;
     F.rep[sg] = r;
     F.gmem[sg] = (uint32_t)(r & 0xFFFFFFFFull);
-    F.yc[sg] = (double)T.cnt[wb + g];
-    F.ns[sg] = T.ns[wb + g];
-    if (F.yxin) {  // (group partials only: plain inputs carry no YX / YD — the arrays are null and the writers of the results know)
-      F.yxin[sg] = (long long)T.yx[wb + g];
-      F.ydin[sg] = (long long)T.yd[wb + g];
+    F.yc[sg] = (double)cnt;
+    F.ns[sg] = nsv;
+    if (F.yxin) {
+      F.yxin[sg] = (long long)yx;
+      F.ydin[sg] = (long long)yd;
     }
     F.first[sg] = sg;
-    if (F.fmask) F.fmask[sg] = T.fmask[wb + g];
-    if (!F.fmask) F.gpoff[sg] = pb + T.poff[wb + g];  // (file masks: no incidence list to point into)
+    if (F.fmask) F.fmask[sg] = fm;
+    if (!F.fmask) F.gpoff[sg] = pb + po;  // (file masks: no incidence list to point into)
     if (F.slot2sg) F.slot2sg[wb + g] = sg;
   }
   for (uint32_t p = threadIdx.x; p < np; p += 64) {
@@ -1664,13 +1674,15 @@ __global__ __launch_bounds__(64) void pr_compact_k(uint32_t nw, const uint32_t* 
   for (uint32_t g = threadIdx.x; g < ng; g += 64) {
     const uint32_t o = gb + g;
     if (o >= cap) continue;
-    const uint32_t r = T.rep[wb + g];
+    // (every load before the first store: the temp arrays are not known to be distinct from the outputs)
+    const uint32_t r = T.rep[wb + g], yxv = T.yx[wb + g], ydv = T.yd[wb + g];
+    const double ycv = T.yc[wb + g];
+    const uint64_t h = T.khi[wb + g], l = T.klo[wb + g];
     o_rep[o] = r;
-    o_yc[o] = T.yc[wb + g];
-    o_yx[o] = (int64_t)T.yx[wb + g];
-    o_yd[o] = (int32_t)T.yd[wb + g];
+    o_yc[o] = ycv;
+    o_yx[o] = (int64_t)yxv;
+    o_yd[o] = (int32_t)ydv;
     if (o_start || o_end || o_key) {  // place, span and key word of the group ride with the merge (no gather of the representative's row)
-      const uint64_t h = T.khi[wb + g], l = T.klo[wb + g];
       const int32_t start = (int32_t)((h >> 2) & 0x7FFFFFFFull);
       if (o_start) o_start[o] = start;
       if (o_end) o_end[o] = start + (int32_t)(uint32_t)(l >> 32) - 1;
