@@ -33,5 +33,8 @@ cp $(find $O/kss -name "*kernel_stats.csv" | head -1) $O/kernel_stats_serial.csv
 rm -rf $O/kss
 # SQ counters (one pass) of the window kernels
 PMC_OUT=$O bash tools/pmc_sq.sh prof_sq wg_ > $O/pmc_sq_wg.txt 2> $O/pmc_sq.err
+# ... and of every kernel; the multi-rank step unpipelined on config 3's shape
+PMC_OUT=$O bash tools/pmc_sq.sh prof_sq_all _k > $O/pmc_sq_all.txt 2> $O/pmc_sq_all.err
+python3 tools/prof_dist.py 64 5000000 c3 > $O/prof_dist_c3shape.txt 2> $O/prof_dist_c3.err
 fi
 echo refresh done; ls -la $O
