@@ -1176,13 +1176,15 @@ constexpr int YD_NB = 32;  // length buckets (log2)
 __device__ __forceinline__ uint32_t yd_bucket(uint32_t len) { return 31u - (uint32_t)__builtin_clz(len | 1u); }
 
 // cnt[b] = chains of length bucket b that go to the lane kernel, cnt[YD_NB + b] = those that get a wave
+// (both bucket kernels walk the chains with a fixed grid and touch the global counters once per block and bucket: returning
+// atomics on one word take ~ 12 ns each, and one per 256 chains and bucket was most of the 0.3 ms these kernels took on config 3)
+constexpr uint32_t YD_BGRID = 1024;
 __global__ void yd_bucket_count_k(uint32_t nchains, uint32_t nit, uint32_t wave_min, const uint32_t* __restrict__ chain_first,
                                   uint32_t* __restrict__ cnt) {
   __shared__ uint32_t s_cnt[2 * YD_NB];
   if (threadIdx.x < 2 * YD_NB) s_cnt[threadIdx.x] = 0;
   __syncthreads();
-  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < nchains) {
+  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nchains; c += gridDim.x * blockDim.x) {
     const uint32_t len = ((c + 1 < nchains) ? chain_first[c + 1] : nit) - chain_first[c];
     atomicAdd(&s_cnt[(len >= wave_min ? YD_NB : 0) + yd_bucket(len)], 1u);
   }
@@ -1203,20 +1205,22 @@ __global__ void yd_bucket_off_k(const uint32_t* __restrict__ cnt, uint32_t* __re
 }
 __global__ void yd_bucket_fill_k(uint32_t nchains, uint32_t nit, uint32_t wave_min, const uint32_t* __restrict__ chain_first, uint32_t* __restrict__ cur,
                                  uint32_t* __restrict__ ids_lane, uint32_t* __restrict__ ids_wave) {
-  __shared__ uint32_t s_cnt[2 * YD_NB], s_base[2 * YD_NB];
+  __shared__ uint32_t s_cnt[2 * YD_NB], s_next[2 * YD_NB];
   if (threadIdx.x < 2 * YD_NB) s_cnt[threadIdx.x] = 0;
   __syncthreads();
-  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t b = 0, slot = 0;
-  if (c < nchains) {
+  auto bucket_of = [&](uint32_t c) {
     const uint32_t len = ((c + 1 < nchains) ? chain_first[c + 1] : nit) - chain_first[c];
-    b = (len >= wave_min ? (uint32_t)YD_NB : 0u) + yd_bucket(len);
-    slot = atomicAdd(&s_cnt[b], 1u);
+    return (len >= wave_min ? (uint32_t)YD_NB : 0u) + yd_bucket(len);
+  };
+  // the block's chains per bucket, one reservation per bucket, then the same walk hands out the places
+  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nchains; c += gridDim.x * blockDim.x) atomicAdd(&s_cnt[bucket_of(c)], 1u);
+  __syncthreads();
+  if (threadIdx.x < 2 * YD_NB) s_next[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&cur[threadIdx.x], s_cnt[threadIdx.x]) : 0u;
+  __syncthreads();
+  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nchains; c += gridDim.x * blockDim.x) {
+    const uint32_t b = bucket_of(c);
+    (b >= (uint32_t)YD_NB ? ids_wave : ids_lane)[atomicAdd(&s_next[b], 1u)] = c;
   }
-  __syncthreads();
-  if (threadIdx.x < 2 * YD_NB) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&cur[threadIdx.x], s_cnt[threadIdx.x]) : 0u;
-  __syncthreads();
-  if (c < nchains) (b >= (uint32_t)YD_NB ? ids_wave : ids_lane)[s_base[b] + slot] = c;
 }
 
 template <int R /* items per lane and refill: the items of R consecutive lanes' worth are one coalesced segment */>
@@ -1903,9 +1907,9 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       // chains bucketed by the log2 of their length, longest first: the lanes of a wave of yd_lane_k run chains of like length
       uint32_t wave_min = YD_WAVE_MIN_DEFAULT;  // TBK_YD_WAVE_MIN: test hook (1: every chain to yd_wave_k; huge: every chain to yd_lane_k)
       if (const char* e = getenv("TBK_YD_WAVE_MIN")) wave_min = (uint32_t)strtoul(e, nullptr, 0);
-      TBK_LAUNCH(ctx, "yd_classify", yd_bucket_count_k, cdiv(nchains, B), B, 0, nchains, nit, wave_min, chain_first, bcnt);
+      TBK_LAUNCH(ctx, "yd_classify", yd_bucket_count_k, std::min(cdiv(nchains, B), YD_BGRID), B, 0, nchains, nit, wave_min, chain_first, bcnt);
       TBK_LAUNCH(ctx, "yd_classify", yd_bucket_off_k, 1, 1, 0, bcnt, bcur);
-      TBK_LAUNCH(ctx, "yd_classify", yd_bucket_fill_k, cdiv(nchains, B), B, 0, nchains, nit, wave_min, chain_first, bcur, ids_lane, ids_long);
+      TBK_LAUNCH(ctx, "yd_classify", yd_bucket_fill_k, std::min(cdiv(nchains, B), YD_BGRID), B, 0, nchains, nit, wave_min, chain_first, bcur, ids_lane, ids_long);
       uint32_t* hc = (uint32_t*)(ctx->h_scalars + 24);
       TBK_HIP(hipMemcpyAsync(hc, n_wave, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
       TBK_HIP(hipStreamSynchronize(ctx->stream));

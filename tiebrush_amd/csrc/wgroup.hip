@@ -246,6 +246,13 @@ struct WgRaw {                 // raw mode: the window kernels read the records 
                                // vsrc[wbase + e] with slot cslot[wbase + e], vcnt[w] entries — instead of marked in a cslot array that has
                                // to be cleared and searched record by record (1.3 GB each way on config 3 for 3 % of the records)
 };
+// The window kernels count passing records and verification entries with one atomic per block: ~ 180 K blocks on one word would
+// keep one L2 channel busy for milliseconds (a word takes ~ 88 atomics per microsecond), so the counts go to WG_NSPREAD words a cache
+// line apart and wg_spread_sum_k folds them into the two scalars afterwards.
+constexpr uint32_t WG_NSPREAD = 64, WG_SPREAD_STRIDE = 16;  // (u64 words: 128 bytes apart)
+__device__ __forceinline__ void wg_count(unsigned long long* base, unsigned long long v) {
+  atomicAdd(base + (size_t)(blockIdx.x & (WG_NSPREAD - 1u)) * WG_SPREAD_STRIDE, v);
+}
 // Inclusive prefix maximum of x inside segments (f = 1: a segment starts at this lane), wave wide, DPP only.  Returns the scanned
 // value; *fo = 1 when a segment start lies at or before this lane (the carry from earlier waves does not reach it).
 __device__ __forceinline__ uint32_t wave_seg_max(uint32_t x, uint32_t f, uint32_t* fo) {
@@ -545,15 +552,18 @@ __global__ __launch_bounds__(256) void wg_rowsum_k(const uint32_t* __restrict__ 
 }
 
 // the windows that hold records, in window order inside a wave (the order is only a scheduling matter)
-__global__ void wg_list_k(uint32_t nw, const uint32_t* __restrict__ wbase, uint32_t* __restrict__ list, unsigned long long* __restrict__ cnt) {
+__global__ __launch_bounds__(1024) void wg_list_k(uint32_t nw, const uint32_t* __restrict__ wbase, uint32_t* __restrict__ list,
+                                                   unsigned long long* __restrict__ cnt) {
+  // (one atomic per 1024 windows: returning atomics on one word take ~ 12 ns each, a wave's worth apiece was 0.1 ms on config 3)
+  __shared__ uint32_t sm[16];
+  __shared__ unsigned long long s_base;
   const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
   const bool have = w < nw && wbase[w + 1] != wbase[w];
-  const uint64_t bm = __ballot(have);
-  if (!bm) return;
-  unsigned long long base = 0;
-  if (lane_id() == (uint32_t)__builtin_ctzll(bm)) base = atomicAdd(cnt, (unsigned long long)__builtin_popcountll(bm));
-  base = __shfl(base, __builtin_ctzll(bm), 64);
-  if (have) list[base + __builtin_popcountll(bm & ((1ull << lane_id()) - 1ull))] = w;
+  uint32_t tot;
+  const uint32_t ex = block_excl_sum<uint32_t, 1024>(have ? 1u : 0u, sm, &tot);
+  if (threadIdx.x == 0) s_base = tot ? atomicAdd(cnt, (unsigned long long)tot) : 0ull;
+  __syncthreads();
+  if (have) list[s_base + ex] = w;
 }
 
 // One workgroup per window, any number of records: they stream through once, all pieces laid end to end, into an LDS table
@@ -984,8 +994,8 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
       if (lane_id() == 0 && wl) atomicAdd(&s_misc[3], wl);
     }
     __syncthreads();
-    if (RAW && t == 0 && s_misc[2]) atomicAdd(R.n_pass, (unsigned long long)s_misc[2]);
-    if (RAW && t == 0 && s_misc[3]) atomicAdd(R.n_slots, (unsigned long long)s_misc[3]);
+    if (RAW && t == 0 && s_misc[2]) wg_count(R.n_pass, (unsigned long long)s_misc[2]);
+    if (RAW && t == 0 && s_misc[3]) wg_count(R.n_slots, (unsigned long long)s_misc[3]);
     if (RAW && t == 0 && R.sparse) T.vcnt[w] = s_misc[3];
     for (uint32_t g = t; g < d; g += WG_NT) {
       const uint32_t s = byrank[g];
@@ -1182,7 +1192,7 @@ __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgRaw R, WgTemp T
         if (lane_id() == 0 && ws) atomicAdd(&s_np, ws);
       }
       __syncthreads();
-      if (t == 0 && s_np) atomicAdd(R.n_pass, (unsigned long long)s_np);
+      if (t == 0 && s_np) wg_count(R.n_pass, (unsigned long long)s_np);
     }
     uint16_t* src = wg_merge_sort<WG_E>(qa, qb, n_w, hi, lo, WG_CAP);
     if constexpr (RAW) n_w = s_np;  // the passing records are the first s_np sorted positions
@@ -1268,7 +1278,7 @@ __global__ __launch_bounds__(WG_NT, 3) void wg_sort_k(WgIn In, WgRaw R, WgTemp T
             } else {
               T.cslot[srci[u]] = wbase + gl[u];
             }
-            if (RAW) atomicAdd(R.n_slots, 1ull);  // (the rare tier: no aggregation)
+            if (RAW) wg_count(R.n_slots, 1ull);  // (the rare tier: no aggregation)
           }
         }
       }
@@ -1700,6 +1710,16 @@ __global__ __launch_bounds__(64) void pr_compact_k(uint32_t nw, const uint32_t* 
   }
 }
 
+__global__ __launch_bounds__(64) void wg_spread_sum_k(const unsigned long long* __restrict__ spread, unsigned long long* __restrict__ n_pass,
+                                                      unsigned long long* __restrict__ n_slots) {
+  const unsigned long long a = wave_sum(spread[(size_t)threadIdx.x * WG_SPREAD_STRIDE]);
+  const unsigned long long b = wave_sum(spread[(size_t)(WG_NSPREAD + threadIdx.x) * WG_SPREAD_STRIDE]);
+  if (threadIdx.x == 0) {
+    *n_pass += a;
+    *n_slots += b;
+  }
+}
+
 }  // namespace
 
 bool tbk_window_supported(uint32_t k) { return k >= 1 && k <= 1024; }
@@ -1814,14 +1834,18 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   if (!tbk_window_supported(k) || m == 0) return TBK_EINVAL;
   if (part && (!raw || k > 64 || !I.prio_hi || !I.yc_in || !I.yx_in || !I.yd_in)) return TBK_EINVAL;
   WgRaw R{};
+  unsigned long long* spread = nullptr;  // (raw) the spread counters of passing records and verification entries
   if (raw) {
     R.I = I;
     R.O = *raw_opt;
     R.O.seed = seed;
-    R.n_pass = (unsigned long long*)(ctx->d_scalars + 0);
+    spread = ws_alloc<unsigned long long>(ctx, 2 * (size_t)WG_NSPREAD * WG_SPREAD_STRIDE);
+    if (!spread) return TBK_ENOMEM;
+    TBK_HIP(hipMemsetAsync(spread, 0, 2 * (size_t)WG_NSPREAD * WG_SPREAD_STRIDE * sizeof(unsigned long long), ctx->stream));
+    R.n_pass = spread;
     R.all_slots = want_rec_sg ? 1u : 0u;
     R.sparse = (!want_rec_sg && strategy != TBK_STRAT_FULL && !getenv("TBK_WG_DENSE_VERIFY")) ? 1u : 0u;  // (-L has no exact key words: every record is verified)
-    R.n_slots = (unsigned long long*)(ctx->d_scalars + 6);
+    R.n_slots = spread + (size_t)WG_NSPREAD * WG_SPREAD_STRIDE;
     scratch_hi = ws_alloc<uint64_t>(ctx, m);
     scratch_lo = ws_alloc<uint64_t>(ctx, m);
     if (!scratch_lo) return TBK_ENOMEM;
@@ -1912,7 +1936,7 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   TBK_HIP(hipMemsetAsync(scw + 3, 0, sizeof(uint64_t), ctx->stream));
   TBK_HIP(hipMemsetAsync(T.wg_cnt, 0, (size_t)nw * 4, ctx->stream));
   TBK_HIP(hipMemsetAsync(T.wp_cnt, 0, (size_t)nw * 4, ctx->stream));
-  TBK_LAUNCH(ctx, "wg_list", wg_list_k, cdiv(nw, B), B, 0, nw, T.wbase, wlist, (unsigned long long*)(scw + 3));
+  TBK_LAUNCH(ctx, "wg_list", wg_list_k, cdiv(nw, 1024u), 1024, 0, nw, T.wbase, wlist, (unsigned long long*)(scw + 3));
   {
     uint32_t eb0 = 0;
     TBK_TRY(tbk_sync_err(ctx, &eb0));
@@ -1986,6 +2010,7 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   }
   if (T.fmask) TBK_LAUNCH(ctx, "wg_fmask", wg_fmask_k, std::min<uint32_t>(nw, 1024u), 64, 0, ovf, ovf_cap, T);
   uint64_t* sc = ctx->d_scalars;
+  if (spread) TBK_LAUNCH(ctx, "wg_spread_sum", wg_spread_sum_k, 1, 64, 0, spread, (unsigned long long*)(sc + 0), (unsigned long long*)(sc + 6));
   TBK_TRY(tbk_exscan_u32(ctx, T.wg_cnt, gbase, nw, sc + 1));
   TBK_TRY(tbk_exscan_u32(ctx, T.wp_cnt, pbase, nw, sc + 2));
   uint32_t eb = 0;
