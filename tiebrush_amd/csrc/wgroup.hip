@@ -1401,14 +1401,14 @@ struct WgFinal {
   long long *yxin, *ydin;
   unsigned long long* rep;
 };
-__global__ __launch_bounds__(64) void wg_compact_k(uint32_t nw, WgTemp T, const uint32_t* __restrict__ gbase, const uint32_t* __restrict__ pbase,
+__global__ __launch_bounds__(256) void wg_compact_k(uint32_t nw, WgTemp T, const uint32_t* __restrict__ gbase, const uint32_t* __restrict__ pbase,
                                                    WgFinal F) {
-  const uint32_t w = blockIdx.x;
+  const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;  // one wave per window (no block-wide step below)
   if (w >= nw) return;
   const uint32_t ng = T.wg_cnt[w], np = T.wp_cnt[w];
   if (!ng) return;
   const uint32_t wb = T.wbase[w], gb = gbase[w], pb = pbase[w];
-  for (uint32_t g = threadIdx.x; g < ng; g += 64) {
+  for (uint32_t g = lane; g < ng; g += 64) {
     // (every load before the first store: the arrays are not known to be distinct, a load behind a store would wait for its turn)
     const uint32_t sg = gb + g;
     const uint64_t hi = T.hi[wb + g], lo = T.lo[wb + g];
@@ -1436,7 +1436,7 @@ __global__ __launch_bounds__(64) void wg_compact_k(uint32_t nw, WgTemp T, const 
     if (!F.fmask) F.gpoff[sg] = pb + po;  // (file masks: no incidence list to point into)
     if (F.slot2sg) F.slot2sg[wb + g] = sg;
   }
-  for (uint32_t p = threadIdx.x; p < np; p += 64) {
+  for (uint32_t p = lane; p < np; p += 64) {
     const uint32_t pi = T.pinc[wb + p];
     F.pfile[pb + p] = (uint16_t)pi;
     if (F.pgrp) F.pgrp[pb + p] = gb + (pi >> 16);
@@ -1448,15 +1448,16 @@ __global__ void wg_tie_k(uint32_t ng, const uint64_t* __restrict__ ghi, const ui
   tie[sg] = (sg == 0 || ghi[sg] != ghi[sg - 1] || (glo[sg] >> 32) != (glo[sg - 1] >> 32)) ? 1 : 0;
 }
 // RAW, sparse list (WgRaw::sparse): one 64-thread block per window walks the window's entries
-__global__ __launch_bounds__(64) void wg_finish_sparse_k(uint32_t nw, const uint32_t* __restrict__ wbase, const uint32_t* __restrict__ vcnt,
+__global__ __launch_bounds__(256) void wg_finish_sparse_k(uint32_t nw, const uint32_t* __restrict__ wbase, const uint32_t* __restrict__ vcnt,
                                                          const uint32_t* __restrict__ vsrc, const uint32_t* __restrict__ cslot,
                                                          const uint32_t* __restrict__ c2r, const unsigned long long* __restrict__ trep, ColIn I,
                                                          int strategy, uint32_t* __restrict__ err) {
-  const uint32_t w = blockIdx.x;
+  const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);  // one wave per window
+  if (w >= nw) return;
   const uint32_t n = vcnt[w];
   if (!n) return;
   const uint32_t wb = wbase[w];
-  for (uint32_t e = threadIdx.x; e < n; e += 64) {
+  for (uint32_t e = threadIdx.x & 63u; e < n; e += 64) {
     const uint32_t j = vsrc[wb + e];
     const uint32_t anchor = (uint32_t)(trep[c2r[cslot[wb + e]]] & 0xFFFFFFFFull);
     if (anchor != j && !strategy_equal(I, strategy, j, anchor)) atomicOr(err, TBK_DERR_COLLISION);
@@ -1672,16 +1673,17 @@ __global__ __launch_bounds__(PR_NT) void pr_merge_k(const int32_t* __restrict__ 
   if (t == 0) T.wg_cnt[w] = tot;
 }
 
-__global__ __launch_bounds__(64) void pr_compact_k(uint32_t nw, const uint32_t* __restrict__ wbase, PrTemp T, const uint32_t* __restrict__ gbase,
+__global__ __launch_bounds__(256) void pr_compact_k(uint32_t nw, const uint32_t* __restrict__ wbase, PrTemp T, const uint32_t* __restrict__ gbase,
                                                    uint32_t cap, uint32_t* __restrict__ o_rep,
                                                    double* __restrict__ o_yc, int64_t* __restrict__ o_yx, int32_t* __restrict__ o_yd,
                                                    int32_t* __restrict__ o_start, int32_t* __restrict__ o_end, uint64_t* __restrict__ o_key,
                                                    int strategy) {
-  const uint32_t w = blockIdx.x;
+  const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);  // one wave per window
+  if (w >= nw) return;
   const uint32_t ng = T.wg_cnt[w];
   if (!ng) return;
   const uint32_t wb = wbase[w], gb = gbase[w];
-  for (uint32_t g = threadIdx.x; g < ng; g += 64) {
+  for (uint32_t g = threadIdx.x & 63u; g < ng; g += 64) {
     const uint32_t o = gb + g;
     if (o >= cap) continue;
     // (every load before the first store: the temp arrays are not known to be distinct from the outputs)
@@ -1816,7 +1818,7 @@ int tbk_partial_reduce_device(tbk_ctx* ctx, int strategy, const int32_t* rows, u
     okey = ws_alloc<uint64_t>(ctx, 2 * (size_t)ng);
     if (!okey) return TBK_ENOMEM;
   }
-  TBK_LAUNCH(ctx, "pr_compact", pr_compact_k, nw, 64, 0, nw, wbase, T, gbase, out->cap_groups, out->rep, out->yc, out->yx, out->yd,
+  TBK_LAUNCH(ctx, "pr_compact", pr_compact_k, cdiv(nw, 4u), 256, 0, nw, wbase, T, gbase, out->cap_groups, out->rep, out->yc, out->yx, out->yd,
              out->g_start, out->g_end, okey, strategy);
   if (view) return tbk_cov_view_build(ctx, r_tid, r_pos, r_strand, cig_off, cig, out->rep, out->yc, out->yx, ng, view, okey);
   TBK_HIP(hipStreamSynchronize(ctx->stream));
@@ -2062,12 +2064,12 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   if (ng) {
     WgFinal F{out->gfmask, out->ghi, out->glo, out->gmem, out->gpoff, out->pgrp, out->first, out->ns, slot2sg, out->pfile, out->yc, out->yxin,
               out->ydin, out->rep};
-    TBK_LAUNCH(ctx, "wg_compact", wg_compact_k, nw, 64, 0, nw, T, gbase, pbase, F);
+    TBK_LAUNCH(ctx, "wg_compact", wg_compact_k, cdiv(nw, 4u), 256, 0, nw, T, gbase, pbase, F);
     TBK_LAUNCH(ctx, "wg_tie", wg_tie_k, cdiv(ng, B), B, 0, ng, out->ghi, out->glo, out->tie);
     if (want_rec_sg) TBK_HIP(hipMemsetAsync(out->rec_sg, 0xFF, (size_t)I.n * 4, ctx->stream));  // (records that did not pass)
     if (raw) {  // (nothing to verify and no record -> group map wanted: every key word was exact)
       if (ctx->h_scalars[6] != 0 && R.sparse)
-        TBK_LAUNCH(ctx, "wg_finish", wg_finish_sparse_k, nw, 64, 0, nw, T.wbase, T.vcnt, T.vsrc, T.cslot, T.c2r, T.rep, I, strategy, ctx->d_err);
+        TBK_LAUNCH(ctx, "wg_finish", wg_finish_sparse_k, cdiv(nw, 4u), 256, 0, nw, T.wbase, T.vcnt, T.vsrc, T.cslot, T.c2r, T.rep, I, strategy, ctx->d_err);
       else if (ctx->h_scalars[6] != 0)
         TBK_LAUNCH(ctx, "wg_finish", wg_finish_raw_k, cdiv(m, B), B, 0, m, T.cslot, T.c2r, T.rep, slot2sg, out->rec_sg, I, strategy, ctx->d_err);
     } else
