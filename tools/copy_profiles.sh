@@ -1,0 +1,19 @@
+#!/bin/bash
+# copies what tools/refresh_profiles.sh (parts a and b) left under gpurun_out/prof/ to the names profiles/README.md lists
+set -e
+P=gpurun_out/prof; R=${1:-r3}
+cp $P/bench_default.json profiles/${R}_bench_c3.json
+cp $P/kernel_stats.csv profiles/${R}_bench_c3_kernel_stats.csv
+cp $P/pmc_fetch_size.csv profiles/${R}_bench_c3_pmc_fetch_size.csv
+cp $P/pmc_write_size.csv profiles/${R}_bench_c3_pmc_write_size.csv
+cp $P/kernel_stats_serial.csv profiles/${R}_bench_c3_serial_kernel_stats.csv
+cp $P/bench_serial_under_rocprof.json profiles/${R}_bench_c3_serial_under_rocprof.json
+cp $P/bench_under_rocprof.json profiles/${R}_bench_c3_under_rocprof.json
+cp $P/pmc_sq_wg.txt profiles/${R}_bench_c3_pmc_sq_wg.txt
+cp $P/pmc_sq_all.txt profiles/${R}_bench_c3_pmc_sq.txt
+cp $P/bench_force_dist.json profiles/${R}_bench_c4shape_force_dist.json
+cp $P/bench_force_dist_c3.json profiles/${R}_bench_c3shape_force_dist.json
+cp $P/cov_prof_c3.txt profiles/${R}_cov_prof_c3.txt
+cp $P/prof_dist_c4shape.txt profiles/${R}_prof_dist_c4shape.txt
+cp $P/prof_dist_c3shape.txt profiles/${R}_prof_dist_c3shape.txt
+cp $P/traffic.json profiles/traffic_c3_64x5000000.json
