@@ -877,13 +877,13 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
         const uint32_t lq = lane_id();
         const uint2 a = lq < (uint32_t)(NR * WG_NW) ? s_agg[lq] : make_uint2(0u, 0u);
         uint32_t ax = a.x, af = a.y;
-#define WG_FOLD_STEP(ctrl)                                                                       \
-    {                                                                                              \
-      const uint32_t xo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ax, ctrl, 0xf, 0xf, false); \
-      const uint32_t fq = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)af, ctrl, 0xf, 0xf, false); \
-      ax = af ? ax : (xo > ax ? xo : ax);                                                          \
-      af |= fq;                                                                                    \
-    }
+#define WG_FOLD_STEP(ctrl)                                                                        \
+  {                                                                                               \
+    const uint32_t xo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ax, ctrl, 0xf, 0xf, false); \
+    const uint32_t fq = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)af, ctrl, 0xf, 0xf, false); \
+    ax = af ? ax : (xo > ax ? xo : ax);                                                           \
+    af |= fq;                                                                                     \
+  }
         WG_FOLD_STEP(0x111)  // row_shr:1, 2, 4, 8
         WG_FOLD_STEP(0x112)
         WG_FOLD_STEP(0x114)
