@@ -80,6 +80,20 @@ def test_golden_t2_yd_machines(ctx, machine, bam_loader, monkeypatch):
     assert int(np.asarray(got["yd"]).max()) > 0
 
 
+@pytest.mark.parametrize("bgrid", ["1", "3"])
+def test_yd_chain_buckets_with_several_chains_per_thread(ctx, bgrid, monkeypatch):
+    """the chain buckets are filled by a fixed grid that reserves once per block and bucket: with one and three blocks for every
+    chain of the tile each thread takes many chains (at config 3's full size: 3.3 M chains for 1024 blocks); a deep synthetic
+    tile against the oracle, default path and forced window path"""
+    from tiebrush_amd import synth
+    monkeypatch.setenv("TBK_YD_BGRID", bgrid)
+    tile = synth.make_tile(12, 20000, "c3", n_loci=60)
+    got, _ = _check(ctx, tile, strategy="clip")
+    assert int(np.asarray(got["yd"]).max()) > 0
+    monkeypatch.setenv("TBK_PATH", "window")
+    _check(ctx, tile, strategy="clip")
+
+
 def test_golden_t12_tbmerged(ctx, bam_loader):
     from tiebrush_amd import soa
     bams = [bam_loader(os.path.join(GOLDEN, "t1", "t1.bam")), bam_loader(os.path.join(GOLDEN, "t2", "t2.bam"))]

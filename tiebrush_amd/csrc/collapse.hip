@@ -1907,9 +1907,11 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       // chains bucketed by the log2 of their length, longest first: the lanes of a wave of yd_lane_k run chains of like length
       uint32_t wave_min = YD_WAVE_MIN_DEFAULT;  // TBK_YD_WAVE_MIN: test hook (1: every chain to yd_wave_k; huge: every chain to yd_lane_k)
       if (const char* e = getenv("TBK_YD_WAVE_MIN")) wave_min = (uint32_t)strtoul(e, nullptr, 0);
-      TBK_LAUNCH(ctx, "yd_classify", yd_bucket_count_k, std::min(cdiv(nchains, B), YD_BGRID), B, 0, nchains, nit, wave_min, chain_first, bcnt);
+      uint32_t bgrid = std::min(cdiv(nchains, B), YD_BGRID);
+      if (const char* e = getenv("TBK_YD_BGRID")) bgrid = std::max<uint32_t>(1u, (uint32_t)strtoul(e, nullptr, 0));  // test hook: several chains per thread
+      TBK_LAUNCH(ctx, "yd_classify", yd_bucket_count_k, bgrid, B, 0, nchains, nit, wave_min, chain_first, bcnt);
       TBK_LAUNCH(ctx, "yd_classify", yd_bucket_off_k, 1, 1, 0, bcnt, bcur);
-      TBK_LAUNCH(ctx, "yd_classify", yd_bucket_fill_k, std::min(cdiv(nchains, B), YD_BGRID), B, 0, nchains, nit, wave_min, chain_first, bcur, ids_lane, ids_long);
+      TBK_LAUNCH(ctx, "yd_classify", yd_bucket_fill_k, bgrid, B, 0, nchains, nit, wave_min, chain_first, bcur, ids_lane, ids_long);
       uint32_t* hc = (uint32_t*)(ctx->h_scalars + 24);
       TBK_HIP(hipMemcpyAsync(hc, n_wave, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
       TBK_HIP(hipStreamSynchronize(ctx->stream));
