@@ -58,6 +58,20 @@ void* big_alloc(size_t bytes) {
   return p;
 }
 
+void big_free(void* q) {
+  if (!q) return;
+  {
+    std::lock_guard<std::mutex> lk(g_big_m);
+    for (size_t i = 0; i < g_big.size(); ++i)
+      if (g_big[i].first == (char*)q) {
+        g_big[i] = g_big.back();
+        g_big.pop_back();
+        break;
+      }
+  }
+  free(q);  // (both kinds of block come from the C allocator: malloc / posix_memalign)
+}
+
 void big_release_all(int threads) {
   std::vector<std::pair<char*, size_t>> work;
   {

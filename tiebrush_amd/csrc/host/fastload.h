@@ -16,6 +16,8 @@ namespace tbh {
 // huge pages when large (the inflated inputs and the tile are gigabytes: with 4 KiB pages most of a second goes into page faults
 // and, at exit, into giving the pages back one by one).  Never freed by its users.
 void* big_alloc(size_t bytes);
+// Give one block back (a buffer that grows): its pages return to the system and big_release_all forgets it.
+void big_free(void* p);
 // Give the pages of every large big_alloc block back, `threads` workers side by side (madvise DONTNEED on slices): a process
 // that is about to exit would otherwise return its gigabytes in one thread, page by page, while its caller waits.  The blocks
 // must not be read afterwards.

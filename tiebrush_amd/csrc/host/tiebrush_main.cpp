@@ -12,8 +12,11 @@
 #include <string>
 #include <unistd.h>
 
-#include <functional>
+#include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <memory>
 #include <sys/stat.h>
 #include <chrono>
@@ -56,18 +59,21 @@ static const char* USAGE =
     "  --store-frac         YC adds 1/NH per alignment (needs --keep-secondary)\n"
     "  -V,--verbose         echo the command line\n";
 
-// a buffer that is allocated, not initialised (untouched pages cost nothing), on huge pages when it is large, and never freed
-// piecewise: these buffers live as long as the process, which ends with _exit — returning gigabytes page by page first only
-// delays that
+// a buffer that is allocated, not initialised (untouched pages cost nothing), on huge pages when it is large, and not freed at
+// the end: these buffers live as long as the process, which ends with _exit — returning gigabytes page by page first only
+// delays that.  The contents do not survive a resize (every caller fills the buffer afresh), so a buffer that grows gives its
+// old block back first and grows by half at least: the streaming path resizes per tile, and tiles come in any order of size.
 template <class T>
 struct RawBuf {
   T* p = nullptr;
   size_t cap = 0, len = 0;
   void resize(size_t n) {
     if (n > cap) {
-      p = (T*)tbh::big_alloc(n * sizeof(T));  // (a buffer that grows leaves its old block behind: it happens once per run at most)
+      const size_t want = cap ? std::max(n, cap + cap / 2) : n;
+      tbh::big_free(p);
+      p = (T*)tbh::big_alloc(want * sizeof(T));
       if (!p) GError("Error: out of memory\n");
-      cap = n;
+      cap = want;
     }
     len = n;
   }
@@ -218,6 +224,11 @@ int main(int argc, char* argv[]) {
       std::unique_ptr<std::atomic<int>[]> ready(new std::atomic<int>[nsl ? nsl : 1]);
       for (uint32_t i = 0; i < nsl; ++i) ready[i].store(0);
       std::atomic<uint32_t> next_slice{0};
+      // the writer sleeps until the slice it needs is out (no spinning beside fully subscribed workers); a worker that fails
+      // says so here and the calling thread reports it once every worker has stopped
+      std::mutex ready_m;
+      std::condition_variable ready_cv;
+      std::atomic<bool> failed{false};
       const int level = outfile.level();
       auto tag_slice = [&](uint32_t sl, std::vector<uint8_t>& o, tbh::BamRec& rr) {
         const uint32_t g0 = sl * per, g1 = std::min(ng, g0 + per);
@@ -270,8 +281,12 @@ int main(int argc, char* argv[]) {
           o.insert(o.end(), rr.d.begin(), rr.d.end());
         }
         // BGZF members are independent deflate streams: the slice compresses itself, the writer only appends
-        if (!tbh::bgzf_deflate_members(o.data(), o.size(), level, runs[(size_t)sl])) GError("Error: deflate failed\n");
-        ready[sl].store(1, std::memory_order_release);
+        if (!tbh::bgzf_deflate_members(o.data(), o.size(), level, runs[(size_t)sl])) failed.store(true);
+        {
+          std::lock_guard<std::mutex> lk(ready_m);
+          ready[sl].store(1, std::memory_order_release);
+        }
+        ready_cv.notify_all();
       };
       auto worker = [&]() {
         std::vector<uint8_t> o;
@@ -280,6 +295,12 @@ int main(int argc, char* argv[]) {
         for (;;) {
           const uint32_t sl = next_slice.fetch_add(1);
           if (sl >= nsl) break;
+          if (failed.load()) {  // (stop working, but let the writer's wait for this slice end)
+            std::lock_guard<std::mutex> lk(ready_m);
+            ready[sl].store(1, std::memory_order_release);
+            ready_cv.notify_all();
+            continue;
+          }
           tag_slice(sl, o, rr);
         }
       };
@@ -289,11 +310,16 @@ int main(int argc, char* argv[]) {
       else
         worker();
       for (uint32_t sl = 0; sl < nsl; ++sl) {
-        while (!ready[sl].load(std::memory_order_acquire)) std::this_thread::yield();
+        if (!ready[sl].load(std::memory_order_acquire)) {
+          std::unique_lock<std::mutex> lk(ready_m);
+          ready_cv.wait(lk, [&] { return ready[sl].load(std::memory_order_acquire) != 0; });
+        }
+        if (failed.load()) break;
         outfile.write_members(runs[(size_t)sl].data(), runs[(size_t)sl].size());
         std::vector<uint8_t>().swap(runs[(size_t)sl]);
       }
       for (auto& x : th) x.join();
+      if (failed.load()) GError("Error: deflate failed\n");
     };
     // ---- whole-input host path: inputs that fit in memory are read, inflated and decoded into the tile in two parallel passes
     // (fastload.cpp) while the helper thread brings the device up; one collapse, one tagged output pass ----

@@ -250,8 +250,8 @@ __device__ __forceinline__ T so_lookback(const SoLookback& S, uint32_t tix, cons
       if ((spins & 1023u) == 1023u) {  // (the clock is read once per thousand polls)
         const unsigned long long now = wall_clock64();
         if (t_spin == 0) t_spin = now;
-        if (now - t_spin > SO_SPIN_TICKS) {  // something is wrong — never hang
-          failed = true;
+        if (__any(now - t_spin > SO_SPIN_TICKS)) {  // something is wrong — never hang (one decision for the whole wave: the vote
+          failed = true;                            // above must never run with some lanes gone)
           break;
         }
       }

@@ -10,12 +10,43 @@
 // One big hipMalloc'd block, bump-allocated per API call.  If a call outgrows it, overflow chunks are
 // chained for that call and the arena is re-created at the combined size at the start of the next
 // call, so a steady-state loop performs no allocation at all.
+// Host ranges page-locked for the copies of a call are shared by the contexts of the process: two contexts (or threads) copying
+// from the same pageable arrays take one registration with a count, and the range is unpinned when the last user's copies have
+// drained — a context never relies on a pin another context may drop under its copy.
+namespace {
+std::mutex g_reg_m;
+struct RegEntry {
+  void* p;
+  int users;
+};
+std::vector<RegEntry> g_reg;
+}  // namespace
+
+static void release_registered(tbk_ctx* ctx) {
+  if (ctx->registered.empty()) return;
+  (void)hipStreamSynchronize(ctx->stream);  // the copies out of / into the ranges have to be done first
+  std::lock_guard<std::mutex> lk(g_reg_m);
+  for (void* p : ctx->registered)
+    for (size_t i = 0; i < g_reg.size(); ++i)
+      if (g_reg[i].p == p) {
+        if (--g_reg[i].users == 0) {
+          (void)hipHostUnregister(p);
+          g_reg[i] = g_reg.back();
+          g_reg.pop_back();
+        }
+        break;
+      }
+  ctx->registered.clear();
+}
+// every exit path of an API call that may have registered host ranges gives them back (a call that returns early through
+// TBK_TRY must not leave the caller's memory pinned: the caller may free it before this context's next call)
+struct RegGuard {
+  tbk_ctx* ctx;
+  ~RegGuard() { release_registered(ctx); }
+};
+
 static int ws_begin_call(tbk_ctx* ctx, size_t hint) {
-  if (!ctx->registered.empty()) {  // (left behind by a call that failed half way)
-    (void)hipStreamSynchronize(ctx->stream);
-    for (void* p : ctx->registered) (void)hipHostUnregister(p);
-    ctx->registered.clear();
-  }
+  release_registered(ctx);  // (nothing to do unless a side path left something behind)
   size_t want = std::max(ctx->ws_cap, hint);
   if (ctx->yd_pending) {
     // a deferred YD stage still reads arrays in [0, ws_base_off): never move the arena now; this call bump-allocates
@@ -141,11 +172,7 @@ void tbk_prof_end_call(tbk_ctx* ctx) {
     for (auto& c : ctx->ws_overflow) over += c.second;
     fprintf(stderr, "tbk arena %p: used %.2f GB of %.2f GB (+ %.2f GB in overflow chunks)\n", (void*)ctx, ctx->ws_off / 1e9, ctx->ws_cap / 1e9, over / 1e9);
   }
-  if (!ctx->registered.empty()) {  // host ranges page-locked for this call's copies (host_register): the copies have to be done first
-    (void)hipStreamSynchronize(ctx->stream);
-    for (void* p : ctx->registered) (void)hipHostUnregister(p);
-    ctx->registered.clear();
-  }
+  release_registered(ctx);  // host ranges page-locked for this call's copies (host_register)
   ctx->last_times.clear();
   if (!ctx->profiling) return;
   (void)hipStreamSynchronize(ctx->stream);
@@ -172,13 +199,24 @@ void tbk_prof_end_call(tbk_ctx* ctx) {
 static void host_register(tbk_ctx* ctx, const void* p, size_t bytes) {
   static const bool off = getenv("TBK_NO_REGISTER") != nullptr;
   if (off || bytes < ((size_t)16 << 20)) return;
+  for (void* q : ctx->registered)
+    if (q == p) return;  // this call holds it already
+  std::lock_guard<std::mutex> lk(g_reg_m);
+  for (auto& e : g_reg)
+    if (e.p == p) {  // registered by another context of this process: share it, it stays until the last user lets go
+      ++e.users;
+      ctx->registered.push_back(const_cast<void*>(p));
+      return;
+    }
   hipPointerAttribute_t at;
-  if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type != hipMemoryTypeUnregistered) return;  // pinned already (tbk_host_alloc)
+  if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type != hipMemoryTypeUnregistered) return;  // pinned by its owner (tbk_host_alloc, the caller)
   (void)hipGetLastError();
-  if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess)
+  if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess) {
+    g_reg.push_back({const_cast<void*>(p), 1});
     ctx->registered.push_back(const_cast<void*>(p));
-  else
+  } else {
     (void)hipGetLastError();
+  }
 }
 template <class T>
 static int h2d(tbk_ctx* ctx, const T* src, size_t n, const T** dst) {
@@ -341,8 +379,7 @@ void tbk_destroy(tbk_ctx* ctx) {
   }
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  for (void* p : ctx->registered) (void)hipHostUnregister(p);
-  ctx->registered.clear();
+  release_registered(ctx);
   for (auto& c : ctx->ws_overflow) (void)hipFree(c.first);
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->ws) (void)hipFree(ctx->ws);
@@ -404,6 +441,7 @@ int tbk_coverage_tile(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out) {
   tbk_prof_begin_call(ctx);
   size_t hint = (size_t)in->n_records * 96 + (size_t)in->n_cigar_ops * 64 + ((size_t)8 << 20);
   TBK_TRY(ws_begin_call(ctx, hint));
+  RegGuard reg_guard{ctx};
   int rc;
   if (in->mem == TBK_MEM_DEVICE) {
     rc = tbk_coverage_device(ctx, in, out);
@@ -484,6 +522,7 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
     for (uint32_t f = 0; f < in->n_files; ++f) lean = lean && in->tbmerged[f] == 0;
   size_t hint = (size_t)in->n_records * (lean ? 92 : 160) + (size_t)in->n_cigar_ops * 8 + ((size_t)8 << 20);
   TBK_TRY(ws_begin_call(ctx, hint));
+  RegGuard reg_guard{ctx};
   int rc;
   ctx->yd_job = nullptr;
   const size_t yd_hint = (size_t)in->n_records * (lean ? 40 : 96) + ((size_t)8 << 20);
@@ -606,6 +645,7 @@ int tbk_sample_tile(tbk_ctx* ctx, const tbk_cov_in* in, int32_t num_samples, tbk
   TBK_HIP(hipSetDevice(ctx->device));
   tbk_prof_begin_call(ctx);
   TBK_TRY(ws_begin_call(ctx, (size_t)in->n_records * 96 + ((size_t)8 << 20)));
+  RegGuard reg_guard{ctx};
   int rc;
   if (in->mem == TBK_MEM_DEVICE) {
     rc = tbk_sample_device(ctx, in, num_samples, out);

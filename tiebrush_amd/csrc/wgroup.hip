@@ -1645,7 +1645,8 @@ __global__ __launch_bounds__(PR_NT) void pr_merge_k(const int32_t* __restrict__ 
     const uint64_t h = khi[e0], l = klo[e0];
     const bool hashed = !((l >> 31) & 1ull);
     double yc = 0.0;
-    uint32_t yx = 0, yd = 0, best = 0, beff = 0xFFFFFFFFu;
+    uint64_t yx = 0;  // (up to 64 runs of partials below 2^31 each: summed wide, refused below when the sum leaves 32 bits)
+    uint32_t yd = 0, best = 0, beff = 0xFFFFFFFFu;
     for (uint32_t m = q; m < n_w; ++m) {  // the group's members: adjacent, one per run at most, earlier runs first
       const uint32_t e = srt[m];
       if (m > q && (khi[e] != h || klo[e] != l)) break;
@@ -1664,7 +1665,8 @@ __global__ __launch_bounds__(PR_NT) void pr_merge_k(const int32_t* __restrict__ 
     }
     T.rep[wb + gid] = best;
     T.yc[wb + gid] = yc;
-    T.yx[wb + gid] = yx;
+    if (yx > 0xFFFFFFFFull) atomicOr(err, TBK_DERR_OVERFLOW);  // TBK_E2BIG: the general path (64-bit sums) takes the tile
+    T.yx[wb + gid] = (uint32_t)yx;
     T.yd[wb + gid] = yd;
     T.khi[wb + gid] = h;
     T.klo[wb + gid] = l;
