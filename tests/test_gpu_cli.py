@@ -46,6 +46,40 @@ def test_tiebrush_cli_on_samples(tmp_path, name):
     assert hdr.is_tiebrush() and len(hdr.co_samples()) == 10 and hdr.co_samples()[0].endswith(name + "s0.bam")
 
 
+def _normalise_sam_line(line):
+    """SURVEY.md §4.4 on one `samtools view` line: -> (the eleven fixed fields + every other tag as text, in order; YC; YX; YD)
+    with the absent tags at their defaults (YC 1, YX 1, YD 0) and YC compared by value (golden: YC:i, HEAD: YC:f)"""
+    f = line.rstrip("\n").split("\t")
+    vals = {"YC": 1.0, "YX": 1, "YD": 0}
+    rest = []
+    for a in f[11:]:
+        tag, ty, v = a.split(":", 2)
+        if tag in vals:
+            assert ty in ("i", "f"), a
+            vals[tag] = float(v) if tag == "YC" else int(v)
+        else:
+            rest.append(a)
+    return tuple(f[:11] + rest), vals["YC"], vals["YX"], vals["YD"]
+
+
+def test_tiebrush_cli_t2_equals_the_reference_sam_text(tmp_path):
+    """The reference keeps the text form of golden t2 (`test/t2/t2.sam`, what its run_tests.sh diffs with `samtools view`): the
+    command line's output, rendered as SAM text, equals it line for line through the §4.4 normaliser — every fixed field, every
+    carried tag with its type and text, their order, and the three counters by value."""
+    import samtext
+    out = str(tmp_path / "o.bam")
+    _run([os.path.join(BIN, "tiebrush"), "-A", "-o", out] + sample_paths("t2"))
+    txt, _ = samtext.bam_to_sam_text(out)
+    mine = [ln for ln in txt.splitlines(True) if not ln.startswith("@")]
+    gold = open(os.path.join(GOLDEN, "t2", "t2.sam")).read().splitlines(True)
+    assert len(mine) == len(gold) == 8179
+    for i, (a, b) in enumerate(zip(mine, gold)):
+        assert _normalise_sam_line(a) == _normalise_sam_line(b), i
+    # HEAD's tag text: YC:f always, YX:i always, YD:i only when positive, appended in that order behind the record's own tags
+    f = mine[1].rstrip("\n").split("\t")
+    assert [a[:5] for a in f if a[:2] in ("YC", "YX", "YD")][:2] == ["YC:f:", "YX:i:"]
+
+
 @pytest.mark.parametrize("name", ["t1", "t2"])
 @pytest.mark.parametrize("flag", ["-P", "--exon"])
 def test_tiebrush_cli_clip_exon_equal_golden(tmp_path, name, flag):

@@ -145,3 +145,15 @@ def test_mkbam_writes_what_the_python_writer_writes(tmp_path):
     b = synth.write_bams_fast(tile, str(tmp_path / "cc"), threads=2)
     for pa, pb in zip(a, b):
         assert bamio.bgzf_decompress(open(pa, "rb").read()) == bamio.bgzf_decompress(open(pb, "rb").read())
+
+
+def test_samtext_renders_golden_t2_as_the_reference_sam():
+    """`test/t2/t2.sam` is the reference's own `samtools view` text of golden t2.bam: the tests' BAM -> SAM
+    formatter reproduces it byte for byte (field text, tag types as samtools prints them, tag order), so a CLI output rendered by
+    it can be compared with that file (tests/test_gpu_cli.py)."""
+    import samtext
+    from helpers import GOLDEN
+    txt, recs = samtext.bam_to_sam_text(os.path.join(GOLDEN, "t2", "t2.bam"))
+    lines = [ln for ln in txt.splitlines(True) if not ln.startswith("@")]
+    gold = open(os.path.join(GOLDEN, "t2", "t2.sam")).read().splitlines(True)
+    assert len(recs) == 8179 and lines == gold
