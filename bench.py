@@ -8,8 +8,11 @@ tbk_collapse_tile (k-way merge order, grouping, YC/YX/YD) -> device chain (tbk_g
 Workload (BASELINE.json `configs`):
   N = 1   configs[2] = the largest single-GPU configuration: 64 synthetic sorted BAMs x 5M 100-bp reads, --clip collapse,
           then tiecov -c -j of the result                                                       (--profile c3 defaults)
-  N > 1   the same workload PER RANK (weak scaling: per-GPU work is what it is at N = 1, so value(N) / (N x value(1)) is the scaling
-          efficiency; --profile c4 runs configs[3]'s per-rank shape, 32 files x 2M reads, instead).  Inside the timed step every
+  N > 1   configs[3], BASELINE's scaling workload: ONE fixed job of 256 synthetic sorted BAMs x 2M reads, default collapse, its files
+          split over the ranks (256 / N each; N = 8: 32 per GPU as configs[3] says) — `"scaling": "strong"`.  `--scaling weak` gives
+          every rank the N = 1 workload instead (c3 per GPU; or `--profile c4 --scaling weak`: 32 files x 2M per rank), and
+          `--gpus 1 --profile c4 --scaling strong` runs the whole 256-file job on one GPU (the strong-scaling base line).  Inside
+          the timed step every
           rank collapses its own files (the plain single-GPU path), the ranks agree on bundle-aligned coordinate cuts
           (all-gather of sampled group keys, all-reduce rounds), exchange one 48-byte row per LOCAL GROUP plus its CIGAR
           (all-to-all over RCCL/xGMI), and each reduces the partials of its range by key and covers it (tiebrush_amd/dist.py,
@@ -46,6 +49,7 @@ WORKLOADS = {   # profile -> (files per GPU, reads per file, collapse options, d
     "c4": (32, 2_000_000, {}, "default CIGAR-only"),
     "c5": (128, 1_000_000, dict(strategy="exon", max_nh=5, min_qual=1), "--exon -N 5 -Q 1"),
 }
+STRONG_JOB_FILES = {"c2": 2, "c3": 64, "c4": 256, "c5": 1024}   # the whole job of --scaling strong (BASELINE.json configs)
 ORACLE_KW = {"c2": {}, "c3": dict(strategy=2), "c4": {}, "c5": dict(strategy=3, max_nh=5, min_qual=1)}
 SYNTH_PROFILE = {"c2": "c2", "c3": "c3", "c4": "c2", "c5": "c5"}
 
@@ -137,7 +141,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--profile", default=None, choices=sorted(WORKLOADS), help="default: c3 (per GPU, at every N)")
+    ap.add_argument("--profile", default=None, choices=sorted(WORKLOADS), help="default: c3 at N = 1, c4 (BASELINE's scaling workload) at N > 1")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="strong: one fixed job (c4: 256 files x 2M reads) split over the ranks; weak: the profile's per-GPU shape on every rank.  "
+                         "Default: strong with c4, weak otherwise")
     ap.add_argument("--files-per-gpu", type=int, default=None)
     ap.add_argument("--reads-per-file", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -187,9 +194,18 @@ def main():
     dev = "cuda:%d" % local_rank
     torch.cuda.set_device(local_rank)
 
-    profile = args.profile or "c3"   # (N > 1: the same per-GPU workload as N = 1 — weak scaling; --profile c4 is BASELINE config 4's per-rank shape)
+    # N = 1: config 3 (the largest single-GPU configuration).  N > 1: config 4, the fixed 256 x 2M job split over the ranks.
+    profile = args.profile or ("c3" if world == 1 else "c4")
+    scaling = args.scaling or ("strong" if profile == "c4" and world > 1 else "weak")
     files, reads, strat, strat_name = WORKLOADS[profile]
-    files = args.files_per_gpu or files
+    job_files = None
+    if scaling == "strong":
+        job_files = args.files_per_gpu * world if args.files_per_gpu else STRONG_JOB_FILES[profile]
+        if job_files % world:
+            raise SystemExit("--scaling strong: %d files do not split evenly over %d ranks" % (job_files, world))
+        files = job_files // world
+    else:
+        files = args.files_per_gpu or files
     reads = args.reads_per_file or reads
 
     import queue
@@ -400,7 +416,12 @@ def main():
     n_bases, span, n_iv, n_j = c["n_bases"], c["span_bases"], c["n_intervals"], c["n_junctions"]
     stats = torch.tensor([dt, float(n_passed), float(n_bases)], dtype=torch.float64,
                          device=dev if os.environ.get("TBK_BENCH_BACKEND", "nccl") == "nccl" else "cpu")
+    ranks_seen = 1
     if use_dist:
+        ones = torch.ones(1, dtype=torch.float64, device=stats.device)   # every rank adds one: what the collective really spanned
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ranks_seen = int(round(float(ones[0])))
+        assert ranks_seen == dist.get_world_size() == world, (ranks_seen, dist.get_world_size(), world)
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = stats.clone()
@@ -578,13 +599,16 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "int64",
             "data": "synthetic",
-            "config": {"workload": "%s: %d synthetic sorted BAMs x %d 100bp reads per GPU, %s collapse + tiecov -c -j of the result"
-                                   % (profile, files, reads, strat_name),
+            "config": {"workload": ("%s: one job of %d synthetic sorted BAMs x %d 100bp reads, %d files per GPU, %s collapse + tiecov -c -j of the result"
+                                    % (profile, job_files, reads, files, strat_name)) if scaling == "strong" else
+                                   ("%s: %d synthetic sorted BAMs x %d 100bp reads per GPU, %s collapse + tiecov -c -j of the result"
+                                    % (profile, files, reads, strat_name)),
                        "records_per_gpu": int(n_records), "groups_out": int(n_groups), "parallelism": "files-per-rank x%d" % world,
+                       "ranks_seen": ranks_seen,
                        "resident": "SoA in HBM before the timed region", "generated_on_device_s": round(t_gen, 2),
                        "contexts": NCTX if not use_dist else 3, "hbm_in_use_gb": hbm_used_gb},
             "bases_per_s": round(tot_bases * args.steps / dt, 1),

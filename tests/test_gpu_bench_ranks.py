@@ -23,7 +23,9 @@ def test_bench_two_ranks_contract():
     lines = [l for l in r.stdout.strip().split("\n") if l.startswith("{")]
     assert len(lines) == 1                                    # rank 0 prints ONE JSON line
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    # N > 1 defaults to BASELINE config 4, one fixed job split over the ranks (here 2 x 2 files of 30 k reads)
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "strong"
+    assert d["config"]["ranks_seen"] == 2 and d["config"]["workload"].startswith("c4: one job of 4 synthetic sorted BAMs")
     assert d["unit"] == "records/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["config"]["records_per_gpu"] == 60000
     # whole-job value: both ranks' records over the slowest rank's time
