@@ -42,32 +42,44 @@ def test_golden_tiecov(ctx, name, device, bam_loader):
     assert junction_lines(got, names) == read_lines(os.path.join(GOLDEN, name, name + ".junctions.bed"))
 
 
-@pytest.mark.parametrize("bundles", ["lean", "scan"])
+@pytest.mark.parametrize("bundles", ["lean", "legacy", "scan", "refused"])
 @pytest.mark.parametrize("profile,n", [("c2", 100000), ("c3", 60000), ("c5", 60000)])
 def test_synthetic_collapsed(ctx, profile, n, bundles, monkeypatch):
-    """(bundles: the three lean passes over 4096-record tiles, or — TBK_COV_BUNDLE_SCAN — the two-stage look-back scan)"""
+    """(interval chain: the lean one — one read-back, compacted starts from the head sums —, the general one behind it
+    (TBK_COV_LEGACY; with TBK_COV_BUNDLE_SCAN its bundles come from the two-stage look-back scan), and the lean one refusing an
+    input for its tile tables (TBK_COV_TILE_CAP) so that the general chain takes over)"""
     from oracle import oracle_ffi as orc
     from tiebrush_amd import synth
     if bundles == "scan":
         monkeypatch.setenv("TBK_COV_BUNDLE_SCAN", "1")
+    elif bundles == "legacy":
+        monkeypatch.setenv("TBK_COV_LEGACY", "1")
+    elif bundles == "refused":
+        monkeypatch.setenv("TBK_COV_TILE_CAP", "3")
     tile = synth.make_tile(3, n, profile, n_loci=3000)
     groups = orc.collapse(tile)
     cin = synth.collapsed_to_cov_input(tile, groups)
     _check(ctx, cin, True)
 
 
-def test_uncollapsed_deep(ctx):
+@pytest.mark.parametrize("chain", ["lean", "legacy"])
+def test_uncollapsed_deep(ctx, chain, monkeypatch):
     """raw (uncollapsed) reads: deep pile-ups, YC absent -> 1.0"""
     from tiebrush_amd import synth, soa
+    if chain == "legacy":
+        monkeypatch.setenv("TBK_COV_LEGACY", "1")
     tile = synth.make_tile(1, 200000, "c2", n_loci=50)
     cin = soa.CovInput(tid=tile.tid, pos=tile.pos, flag=tile.flag, cig_off=tile.cig_off, cig=tile.cig,
                        yc=np.ones(tile.n_records), strand=tile.strand)
     _check(ctx, cin, True)
 
 
-def test_edge_cases(ctx):
+@pytest.mark.parametrize("chain", ["lean", "legacy"])
+def test_edge_cases(ctx, chain, monkeypatch):
     from tiebrush_amd import soa
     M, I, D, N, S = 0, 1, 2, 3, 4
+    if chain == "legacy":
+        monkeypatch.setenv("TBK_COV_LEGACY", "1")
 
     def mk(recs):
         tid = np.array([r[0] for r in recs], np.int32)

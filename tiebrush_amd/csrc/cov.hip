@@ -487,6 +487,15 @@ __device__ __forceinline__ long long to_acc<long long>(double y) { return (long 
 __device__ __forceinline__ void lds_add(int32_t* p, int32_t v) { atomicAdd(p, v); }
 __device__ __forceinline__ void lds_add(long long* p, long long v) { atomicAdd((unsigned long long*)p, (unsigned long long)v); }
 
+// What the lean interval chain (cl_* below) wants from the tile kernel besides the change points: how many intervals the tile
+// emits for certain (change points with a depth other than 0, the tentative one at the tile start aside), whether its first change
+// point is tentative (bit 31 of ecnt), the depth at its first and at its last base — with these the run-length encoding needs no
+// pass over the change points to count (ecnt == nullptr: not wanted).
+struct ClTileOut {
+  uint32_t* ecnt;
+  double *fv, *lv;
+};
+
 // change point: pos = cpos | tentative<<63 ; val = depth (as double: exact for |v| < 2^53)
 // IDENT: the records are their own compaction (device chain: no validity pass), ridx[j] == j.
 // 512 threads per 8192-base tile (16 bases each in the scan phase) at <= 64 VGPRs: four blocks = 32 waves per CU, the
@@ -494,7 +503,7 @@ __device__ __forceinline__ void lds_add(long long* p, long long v) { atomicAdd((
 constexpr int COV_R = 2;  // home records a thread has in flight: their independent loads are issued together
 constexpr int COVT_NT = 512;
 constexpr int COVT_PER = COV_W / COVT_NT;
-template <class AccT, bool IDENT>
+template <class AccT, bool IDENT, bool LEAN>
 __global__ __launch_bounds__(COVT_NT, 8) void cov_tile_k(uint32_t m, uint64_t S, CovArrays A, const uint32_t* __restrict__ cig_off,
                                                      const uint32_t* __restrict__ cig, const double* __restrict__ yc,
                                                      const uint32_t* __restrict__ tile_first,
@@ -502,12 +511,12 @@ __global__ __launch_bounds__(COVT_NT, 8) void cov_tile_k(uint32_t m, uint64_t S,
                                                      const uint32_t* __restrict__ sp_rec, uint64_t* __restrict__ cp_pos,
                                                      double* __restrict__ cp_val, uint32_t* __restrict__ tile_cp_base,
                                                      uint32_t* __restrict__ tile_cp_cnt, uint32_t* __restrict__ cp_alloc,
-                                                     uint32_t cp_cap, uint32_t* __restrict__ err) {
+                                                     uint32_t cp_cap, uint32_t* __restrict__ err, ClTileOut O) {
   __shared__ AccT diff[COV_W + COV_W / 32 + 1];
   __shared__ uint32_t brk[COV_W / 32];
   __shared__ uint32_t sm_u[COVT_NT / 64];
   __shared__ AccT sm_a[COVT_NT / 64];
-  __shared__ uint32_t s_base;
+  __shared__ uint32_t s_base, s_ne;
 
   const uint32_t t = threadIdx.x;
   const uint64_t tile = blockIdx.x;
@@ -518,6 +527,7 @@ __global__ __launch_bounds__(COVT_NT, 8) void cov_tile_k(uint32_t m, uint64_t S,
 
   for (uint32_t p = t; p < COV_W + COV_W / 32 + 1; p += COVT_NT) diff[p] = 0;
   if (t < COV_W / 32) brk[t] = 0;
+  if (t == 0) s_ne = 0;
   __syncthreads();
   // home records: COV_R per thread and round, so that the (independent) loads of a round are in flight together and only
   // the CIGAR words wait for their offsets
@@ -600,6 +610,17 @@ __global__ __launch_bounds__(COVT_NT, 8) void cov_tile_k(uint32_t m, uint64_t S,
     prev = v[q];
   }
   cnt = (uint32_t)__builtin_popcount(mask);
+  if (LEAN) {
+    uint32_t ne = 0;
+#pragma unroll
+    for (int q = 0; q < COVT_PER; ++q) {
+      const bool tent = (pb + q == 0) && !((bw >> q) & 1u);
+      ne += (((mask >> q) & 1u) && !tent && v[q] != 0) ? 1u : 0u;
+      if (pb + q + 1 == wlen) O.lv[tile] = (double)v[q];
+    }
+    ne = wave_sum(ne);
+    if (lane_id() == 0 && ne) atomicAdd(&s_ne, ne);
+  }
   uint32_t btot;
   uint32_t cex = block_excl_sum<uint32_t, COVT_NT>(cnt, sm_u, &btot);
   if (t == 0) {
@@ -608,6 +629,10 @@ __global__ __launch_bounds__(COVT_NT, 8) void cov_tile_k(uint32_t m, uint64_t S,
     tile_cp_base[tile] = base;
     tile_cp_cnt[tile] = btot;
     if ((uint64_t)base + btot > cp_cap) atomicOr(err, TBK_DERR_INTERNAL);
+    if (LEAN) {
+      O.ecnt[tile] = s_ne | ((bw & 1u) ? 0u : 0x80000000u);  // (thread 0 owns base 0: tentative unless a bundle starts there)
+      O.fv[tile] = (double)v[0];
+    }
   }
   __syncthreads();
   uint32_t o = s_base + cex;
@@ -715,6 +740,411 @@ __global__ void cov_tile_bundle_k(uint32_t ntiles, uint32_t nb, const uint64_t* 
       hi = mid;
   }
   tile_b[t] = lo;
+}
+
+// ---- the lean interval chain (integral YC) --------------------------------------------------------------------------------------
+// The same intervals as the chain above with one read-back instead of four and 11 launches instead of 25.  What makes it lean:
+//  * a record's compacted start needs no bundle table and no scan over the bundles.  With C_j = the sum, over the bundle heads h <= j,
+//    of X_h = start_h - 1 - (running maximum of `end` over the records before h on the reference before h; 0 before the first
+//    record) the compacted start is cs_j = start_j - 1 - C_j: a head lands right behind the last base of the bundle before it,
+//    whether that bundle lies on the same reference or on the one before.  X rides with the head counts of the bundle passes
+//    (cl_heads_k<false>: heads and sum of X per 4096-record tile; one small scan; cl_heads_k<true>: the same walk, numbering), so
+//    the pass that numbers the bundles also writes every record's tile-kernel word, the bundle table with its offsets, the first
+//    record and the first bundle of every coverage tile, counts the pieces that leave their home tiles and lists the few
+//    records that have such pieces (cov_bundle_span + scan, cov_cs_count, cov_tile_bundle and the first half of cov_spill_fill);
+//  * the spill pieces are filled from that list (2 % of the records) instead of a second pass over all of them;
+//  * the tile kernel leaves behind how many intervals each tile emits (ClTileOut), so the run-length encoding is one small pass
+//    over the tiles and one pass over the change points where they lie — no gather into tile order, no counting pass.
+// The tile arrays are sized before the number of tiles is known; a tile beyond their capacity raises scalar 13 and the caller
+// runs the chain above instead.
+struct ClTiles {
+  uint32_t* first;  // first record whose compacted start lies in the tile or later
+  uint32_t* tb;     // bundle that holds the tile's first base
+  uint32_t* cnt;    // pieces binned into the tile from other home tiles (zeroed by the caller)
+  uint32_t cap;     // tiles the arrays hold (entries 0 .. cap - 1; entry ntiles is written too)
+};
+constexpr uint32_t CL_SC_NB = 3, CL_SC_S = 4, CL_SC_NSPILL = 5, CL_SC_NSL = 12, CL_SC_REFUSED = 13;
+
+// the spilling records of one block of cl_heads_k<true> (4096 records): a chunk of the list, the block's first home tile with it
+struct ClChunks {
+  uint32_t *base, *cnt, *tbase;  // per block
+  uint32_t* j;                   // the list: record
+  uint64_t* cs;                  //           its compacted start
+};
+template <bool EMIT>
+__global__ __launch_bounds__(CB_NT) void cl_heads_k(uint32_t m, CovArrays A, const uint4* __restrict__ part, uint32_t* __restrict__ hcnt,
+                                                    long long* __restrict__ xsum, const uint32_t* __restrict__ hbase,
+                                                    const long long* __restrict__ xbase, const uint32_t* __restrict__ cig_off,
+                                                    const uint32_t* __restrict__ cig, ClTiles T, ClChunks L, uint64_t* __restrict__ sc,
+                                                    uint32_t* __restrict__ err) {
+  __shared__ CbAgg sm[CB_NT / 64];
+  __shared__ CbAgg wl[CB_NT / 64];
+  __shared__ uint32_t smu[8];
+  __shared__ long long smx[8];
+  // EMIT: the block's spilling records and its piece counts gather in LDS and reach global memory once per block — a reservation
+  // per row on one word (24 k returning atomics on config 3) was most of this kernel's time
+  __shared__ uint32_t lcnt[EMIT ? COV_SW : 1];
+  __shared__ uint16_t l_j[EMIT ? CB_TILE : 1];
+  __shared__ uint32_t l_cs[EMIT ? CB_TILE : 1];  // (low word: the starts of a block lie within 2^32 compacted bases of its first, or the chain is refused)
+  __shared__ uint32_t s_tbase, s_nsl, s_np, s_slbase;
+  __shared__ uint64_t s_cs0, s_cs1;
+  const CbOp op{};
+  const CbAgg none{0, INT32_MIN, INT32_MIN, 1u};
+  const uint4 pv = part[blockIdx.x];
+  CbAgg run{(int32_t)pv.x, (int32_t)pv.y, (int32_t)pv.z, pv.w};  // the records before the current row
+  uint32_t heads_tile = 0, hrun = EMIT ? hbase[blockIdx.x] : 0u;
+  long long x_tile = 0, xrun = EMIT ? xbase[blockIdx.x] : 0ll;
+  bool bad = false, refused = false;
+  if (EMIT) {
+    if (threadIdx.x < COV_SW) lcnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_nsl = s_np = 0;
+  }
+#pragma unroll 1
+  for (uint32_t r = 0; r < CB_ROWS; ++r) {
+    const uint64_t i = (uint64_t)blockIdx.x * CB_TILE + ((uint64_t)r * CB_NT + threadIdx.x) * 4u;
+    int32_t t4[4], s4[4], e4[4];
+    cb_load4(A.tid, i, m, 0, t4);
+    cb_load4(A.start, i, m, 0, s4);
+    cb_load4(A.end, i, m, 0, e4);
+    CbAgg a = none;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (i + e < m) a = op(a, CbAgg{t4[e], t4[e], e4[e], 1u});
+    CbAgg tot;
+    const CbAgg inc = block_incl_scan_op(a, op, sm, &tot);
+    CbAgg ex = shfl_up_t(inc, 1);  // the aggregate of everything before this thread's first record: run (+) the threads before it in the row
+    if (lane_id() == 63) wl[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      ex = none;
+    else if (lane_id() == 0)
+      ex = wl[(threadIdx.x >> 6) - 1];
+    ex = op(run, ex);
+    uint32_t hd = 0, nh = 0;
+    long long x4[4] = {0, 0, 0, 0}, xs = 0;
+    CbAgg w = ex;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (i + e < m) {
+        const bool first = w.last_tid == INT32_MIN;
+        const bool head = first || t4[e] != w.last_tid || s4[e] > w.mx;  // tiecov.cpp:443
+        if (head) {
+          x4[e] = (long long)s4[e] - 1ll - (first ? 0ll : (long long)w.mx);
+          xs += x4[e];
+          hd |= 1u << e;
+          ++nh;
+        }
+        w = op(w, CbAgg{t4[e], t4[e], e4[e], 1u});
+      }
+    }
+    // heads and X sums before this thread in the row: one block scan of the pair
+    uint32_t rowh, before;
+    long long rowx, xbefore;
+    {
+      uint32_t hi_ = nh;
+      long long xi_ = xs;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t oh = __shfl_up(hi_, d, 64);
+        const long long ox = __shfl_up(xi_, d, 64);
+        if ((int)lane_id() >= d) {
+          hi_ += oh;
+          xi_ += ox;
+        }
+      }
+      const uint32_t wv = threadIdx.x >> 6;
+      if (lane_id() == 63) {
+        smu[wv] = hi_;
+        smx[wv] = xi_;
+      }
+      __syncthreads();
+      uint32_t bh = 0, th = 0;
+      long long bx = 0, tx = 0;
+#pragma unroll
+      for (uint32_t q = 0; q < CB_NT / 64; ++q) {
+        const uint32_t h_ = smu[q];
+        const long long x_ = smx[q];
+        if (q < wv) {
+          bh += h_;
+          bx += x_;
+        }
+        th += h_;
+        tx += x_;
+      }
+      before = bh + hi_ - nh;
+      xbefore = bx + xi_ - xs;
+      rowh = th;
+      rowx = tx;
+    }  // (smu / smx are written again only behind the row's closing barrier)
+    if (EMIT) {
+      before += hrun;
+      long long C = xrun + xbefore;  // the sum of X over the heads before this thread's records
+      const int32_t pst = i > 0 && i < m ? A.start[i - 1] : 0;  // (the record before the four: order check, its tile)
+      uint64_t prev_cs = i > 0 && i < m ? (uint64_t)((long long)pst - 1ll - C) : 0ull;
+      CbAgg v = ex;
+      uint32_t b = before;
+      uint64_t pk4 = 0;  // the four tile-kernel words of this thread's records: one store
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint64_t j = i + e;
+        if (j < m) {
+          const bool head = (hd >> e) & 1u;
+          const bool run_head = v.last_tid == INT32_MIN || t4[e] != v.last_tid;
+          const int32_t prev_start = e == 0 ? pst : s4[e - 1];
+          if (!run_head && s4[e] < prev_start) bad = true;
+          b += head ? 1u : 0u;
+          C += x4[e];
+          const uint32_t bundle = b - 1u;
+          const uint64_t cs = (uint64_t)((long long)s4[e] - 1ll - C);
+          pk4 |= (uint64_t)((uint32_t)(cs % COV_W) | (head ? 0x8000u : 0u)) << (16 * e);
+          if (head) {
+            A.b_tid[bundle] = t4[e];
+            A.b_start[bundle] = s4[e];
+            A.b_off[bundle] = cs;
+          }
+          const uint64_t tl = cs / COV_W;
+          if (r == 0 && threadIdx.x == 0 && e == 0) {  // (read behind the row's next barrier)
+            s_tbase = (uint32_t)tl;
+            s_cs0 = cs;
+          }
+          if (j + 1 == m || j + 1 == ((uint64_t)blockIdx.x + 1u) * CB_TILE) s_cs1 = cs;  // the block's last record
+          for (uint64_t tp = j ? prev_cs / COV_W + 1u : 0u; tp <= tl; ++tp) {  // the tiles whose first record this one is
+            if (tp >= T.cap) {
+              refused = true;
+              break;
+            }
+            T.first[tp] = (uint32_t)j;
+            T.tb[tp] = bundle - ((head && cs > tp * COV_W) ? 1u : 0u);
+          }
+          v = op(v, CbAgg{t4[e], t4[e], e4[e], 1u});
+          if (j + 1 == m) {
+            const uint64_t S = (uint64_t)((long long)v.mx - C);
+            const uint64_t nt = (S + COV_W - 1) / COV_W;
+            sc[CL_SC_NB] = (uint64_t)bundle + 1u;
+            sc[CL_SC_S] = S;
+            if (nt >= T.cap) {
+              refused = true;
+            } else {
+              for (uint64_t u = tl + 1; u <= nt; ++u) {
+                T.first[u] = m;
+                T.tb[u] = bundle;
+              }
+            }
+          }
+          // a read whose reference span ends inside its home tile has no piece elsewhere (96 % of the reads)
+          if ((uint32_t)(cs % COV_W) + (uint32_t)(e4[e] - s4[e] + 1) > (uint32_t)COV_W) {
+            const uint32_t k = atomicAdd(&s_nsl, 1u);
+            l_j[k] = (uint16_t)(j - (uint64_t)blockIdx.x * CB_TILE);
+            l_cs[k] = (uint32_t)cs;
+          }
+          prev_cs = cs;
+        }
+      }
+      if (i + 3 < m) {
+        *reinterpret_cast<uint64_t*>(A.pk + i) = pk4;  // (i is a multiple of 4, the array 256-byte aligned)
+      } else {
+        for (int e = 0; e < 4; ++e)
+          if (i + e < m) A.pk[i + e] = (uint16_t)(pk4 >> (16 * e));
+      }
+    }
+    heads_tile += rowh;
+    hrun += rowh;
+    x_tile += rowx;
+    xrun += rowx;
+    run = op(run, tot);
+    __syncthreads();
+  }
+  if (!EMIT && threadIdx.x == 0) {
+    hcnt[blockIdx.x] = heads_tile;
+    xsum[blockIdx.x] = x_tile;
+  }
+  if (EMIT) {
+    // the block's spilling records: count their pieces per tile (LDS window behind the block's first home tile), one reservation
+    // in the list, one chunk descriptor
+    const uint32_t nsl = s_nsl, tbase = s_tbase;
+    const uint64_t cs0 = s_cs0;
+    if (s_cs1 - cs0 >= (1ull << 32)) refused = true;
+    auto full_cs = [&](uint32_t k) { return cs0 + (uint64_t)(uint32_t)(l_cs[k] - (uint32_t)cs0); };
+    if (nsl) {  // (uniform)
+      if (threadIdx.x == 0) s_slbase = (uint32_t)atomicAdd((unsigned long long*)&sc[CL_SC_NSL], (unsigned long long)nsl);
+      uint32_t np = 0;
+      for (uint32_t k = threadIdx.x; k < nsl; k += CB_NT) {
+        const uint32_t ri = A.ridx[(uint64_t)blockIdx.x * CB_TILE + l_j[k]];
+        const uint32_t c0 = cig_off[ri];
+        for_each_spill_piece(full_cs(k), cig + c0, cig_off[ri + 1] - c0, [&](uint32_t t, uint32_t, uint32_t) {
+          ++np;
+          if (t >= T.cap)
+            refused = true;
+          else if (t - tbase < COV_SW)
+            atomicAdd(&lcnt[t - tbase], 1u);
+          else
+            atomicAdd(&T.cnt[t], 1u);
+        });
+      }
+      np = wave_sum(np);
+      if (lane_id() == 0 && np) atomicAdd(&s_np, np);
+      __syncthreads();
+      const uint32_t slb = s_slbase;
+      for (uint32_t k = threadIdx.x; k < nsl; k += CB_NT) {
+        L.j[slb + k] = (uint32_t)((uint64_t)blockIdx.x * CB_TILE + l_j[k]);
+        L.cs[slb + k] = full_cs(k);
+      }
+      if (threadIdx.x < COV_SW && lcnt[threadIdx.x] && tbase + threadIdx.x < T.cap) atomicAdd(&T.cnt[tbase + threadIdx.x], lcnt[threadIdx.x]);
+      if (threadIdx.x == 0) {
+        atomicAdd((unsigned long long*)&sc[CL_SC_NSPILL], (unsigned long long)s_np);
+        L.base[blockIdx.x] = slb;
+        L.tbase[blockIdx.x] = tbase;
+      }
+    }
+    if (threadIdx.x == 0) L.cnt[blockIdx.x] = nsl;
+    if (bad) atomicOr(err, TBK_DERR_UNSORTED);
+    if (refused) sc[CL_SC_REFUSED] = 1;
+  }
+}
+
+// one block: exclusive prefixes of the per-tile head counts and X sums
+__global__ __launch_bounds__(256) void cl_scan_k(uint32_t nt, const uint32_t* __restrict__ hcnt, const long long* __restrict__ xsum,
+                                                 uint32_t* __restrict__ hbase, long long* __restrict__ xbase) {
+  __shared__ uint32_t sh[256];
+  __shared__ long long sx[256];
+  const uint32_t per = (nt + 255u) / 256u, i0 = threadIdx.x * per, i1 = i0 + per < nt ? i0 + per : nt;
+  uint32_t h = 0;
+  long long x = 0;
+  for (uint32_t i = i0; i < i1; ++i) {
+    h += hcnt[i];
+    x += xsum[i];
+  }
+  sh[threadIdx.x] = h;
+  sx[threadIdx.x] = x;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t rh = 0;
+    long long rx = 0;
+    for (uint32_t q = 0; q < 256; ++q) {
+      const uint32_t mh = sh[q];
+      const long long mx = sx[q];
+      sh[q] = rh;
+      sx[q] = rx;
+      rh += mh;
+      rx += mx;
+    }
+  }
+  __syncthreads();
+  h = sh[threadIdx.x];
+  x = sx[threadIdx.x];
+  for (uint32_t i = i0; i < i1; ++i) {
+    hbase[i] = h;
+    xbase[i] = x;
+    h += hcnt[i];
+    x += xsum[i];
+  }
+}
+
+// the spill pieces of the listed records -> their tiles' bins: one block per chunk of the list (the spilling records of 4096
+// consecutive records: their pieces fall into a few tiles behind the chunk's first home tile), counts and ranks in an LDS window
+// of those tiles, one reservation per (chunk, tile)
+__global__ __launch_bounds__(256) void cl_spill_fill_k(ClChunks L, CovArrays A, const uint32_t* __restrict__ cig_off, const uint32_t* __restrict__ cig,
+                                                       const uint32_t* __restrict__ tile_off, uint32_t* __restrict__ tile_fill,
+                                                       uint32_t* __restrict__ sp_seg, uint32_t* __restrict__ sp_rec) {
+  __shared__ uint32_t lcnt[COV_SW], lbase[COV_SW];
+  const uint32_t n = L.cnt[blockIdx.x];
+  if (!n) return;
+  const uint32_t base = L.base[blockIdx.x], tbase = L.tbase[blockIdx.x];
+  if (threadIdx.x < COV_SW) lcnt[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < n; k += 256) {  // pass 1: how many pieces the chunk sends to each tile of its window
+    const uint32_t i = A.ridx[L.j[base + k]];
+    const uint32_t c0 = cig_off[i];
+    for_each_spill_piece(L.cs[base + k], cig + c0, cig_off[i + 1] - c0, [&](uint32_t t, uint32_t, uint32_t) {
+      if (t - tbase < COV_SW) atomicAdd(&lcnt[t - tbase], 1u);
+    });
+  }
+  __syncthreads();
+  if (threadIdx.x < COV_SW) {
+    const uint32_t c = lcnt[threadIdx.x];
+    lbase[threadIdx.x] = c ? atomicAdd(&tile_fill[tbase + threadIdx.x], c) : 0u;
+    lcnt[threadIdx.x] = 0;
+  }
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < n; k += 256) {  // pass 2: ranks inside the reservation from the LDS counters
+    const uint32_t j = L.j[base + k];
+    const uint32_t i = A.ridx[j];
+    const uint32_t c0 = cig_off[i];
+    for_each_spill_piece(L.cs[base + k], cig + c0, cig_off[i + 1] - c0, [&](uint32_t t, uint32_t off, uint32_t len) {
+      uint32_t slot;
+      if (t - tbase < COV_SW)
+        slot = tile_off[t] + lbase[t - tbase] + atomicAdd(&lcnt[t - tbase], 1u);
+      else
+        slot = tile_off[t] + atomicAdd(&tile_fill[t], 1u);
+      sp_seg[slot] = off | ((len - 1) << 16);
+      sp_rec[slot] = j;
+    });
+  }
+}
+
+// intervals per tile: the tile kernel's count, plus the tentative change point at the tile start when the depth changes there
+__device__ __forceinline__ bool cl_first_kept(const ClTileOut& O, uint32_t t) {
+  return !(O.ecnt[t] >> 31) || (t > 0 && O.fv[t] != O.lv[t - 1]);
+}
+__global__ void cl_iv_count_k(uint32_t ntiles, ClTileOut O, uint32_t* __restrict__ icnt) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntiles) return;
+  const uint32_t c = O.ecnt[t];
+  icnt[t] = (c & 0x7FFFFFFFu) + (((c >> 31) && cl_first_kept(O, t) && O.fv[t] != 0.0) ? 1u : 0u);
+}
+// one block per coverage tile: its change points, where cov_tile_k left them, become its intervals
+__global__ __launch_bounds__(256) void cl_iv_emit_k(uint32_t ntiles, uint64_t S, uint32_t nb, CovArrays A, const uint64_t* __restrict__ cp_pos,
+                                                    const double* __restrict__ cp_val, const uint32_t* __restrict__ tile_cp_base,
+                                                    const uint32_t* __restrict__ tile_cp_cnt, ClTileOut O, const uint32_t* __restrict__ ioff,
+                                                    const uint32_t* __restrict__ tile_b, uint32_t cap, int32_t* __restrict__ iv_tid,
+                                                    int32_t* __restrict__ iv_start, int32_t* __restrict__ iv_end, double* __restrict__ iv_val) {
+  __shared__ uint32_t sm[8];
+  const uint32_t t = blockIdx.x;
+  const uint32_t base = tile_cp_base[t], cnt = tile_cp_cnt[t];
+  const bool kept0 = cl_first_kept(O, t);
+  uint32_t run = ioff[t];
+  constexpr uint64_t TENT = 1ull << 63;
+  for (uint32_t k0 = 0; k0 < cnt; k0 += 256) {
+    const uint32_t k = k0 + threadIdx.x;
+    const bool have = k < cnt;
+    const uint64_t pr = have ? cp_pos[base + k] : 0ull;
+    const double val = have ? cp_val[base + k] : 0.0;
+    const bool e = have && (!(pr >> 63) || kept0) && val != 0.0;
+    uint32_t tot;
+    const uint32_t o = run + block_excl_sum<uint32_t, 256>(e ? 1u : 0u, sm, &tot);
+    run += tot;
+    if (!e || o >= cap) continue;
+    uint64_t endp = S;  // the next change point that is kept ends the interval
+    if (k + 1 < cnt) {
+      endp = cp_pos[base + k + 1] & ~TENT;  // (only a tile's first change point can be tentative)
+    } else {
+      for (uint32_t t2 = t + 1; t2 < ntiles; ++t2) {
+        if (cl_first_kept(O, t2)) {
+          endp = (uint64_t)t2 * COV_W;
+          break;
+        }
+        if (tile_cp_cnt[t2] > 1u) {
+          endp = cp_pos[tile_cp_base[t2] + 1u] & ~TENT;
+          break;
+        }
+      }
+    }
+    const uint64_t p = pr & ~TENT;
+    uint32_t lo = tile_b[t], hi = tile_b[t + 1] + 1u;  // last bundle with b_off <= p: between the bundles of the tile's two ends
+    if (hi > nb) hi = nb;
+    while (hi - lo > 1) {
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      if (A.b_off[mid] <= p)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    const int32_t s0 = A.b_start[lo] - 1 + (int32_t)(p - A.b_off[lo]);
+    iv_tid[o] = A.b_tid[lo];
+    iv_start[o] = s0;
+    iv_end[o] = s0 + (int32_t)(endp - p);
+    iv_val[o] = val;
+  }
 }
 
 // ---- ordered double path (non-integral YC): per base, add in record order -------------------
@@ -1161,6 +1591,97 @@ struct JuncSide {  // the junction branch on the side context's worker; collecte
   ~JuncSide() { (void)join(); }
 };
 
+// The lean interval chain (cl_* kernels): bundles, compacted starts, tile tables and spill counts in three passes and a small scan,
+// ONE read-back (number of bundles, span, spill pieces, spilling records), then spill fill from the list, the tile kernel, a pass
+// over the tiles and the interval writer.  Returns 1 when the tile tables proved too small (the caller then runs the general
+// chain), a negative status on errors.  The interval count is left in scalar 8 for the caller's final read-back.
+static int cov_intervals_lean(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, CovArrays A, uint32_t m, bool all_valid, uint64_t sum_abs) {
+  const uint32_t B = 256;
+  uint64_t* sc = ctx->d_scalars;
+  const uint32_t cbt = cdiv(m, CB_TILE);
+  uint4* cpart = ws_alloc<uint4>(ctx, cbt);
+  uint32_t* hcnt = ws_alloc<uint32_t>(ctx, cbt);
+  uint32_t* hbase = ws_alloc<uint32_t>(ctx, cbt);
+  long long* xsum = ws_alloc<long long>(ctx, cbt);
+  long long* xbase = ws_alloc<long long>(ctx, cbt);
+  ClChunks L;
+  L.base = ws_alloc<uint32_t>(ctx, cbt);
+  L.cnt = ws_alloc<uint32_t>(ctx, cbt);
+  L.tbase = ws_alloc<uint32_t>(ctx, cbt);
+  L.j = ws_alloc<uint32_t>(ctx, m);
+  L.cs = ws_alloc<uint64_t>(ctx, m);
+  ClTiles T;
+  // tiles: unknown until the passes have run.  m / 8 covers an average of 1024 compacted bases per record (a collapsed RNA-seq
+  // sample has a handful), 2^20 tiles any small input
+  uint64_t cap64 = (uint64_t)m / 8u > (1ull << 20) ? (uint64_t)m / 8u : (1ull << 20);
+  if (const char* e = getenv("TBK_COV_TILE_CAP")) cap64 = (uint64_t)atoll(e);  // test hook: force the refusal
+  T.cap = (uint32_t)cap64;
+  T.first = ws_alloc<uint32_t>(ctx, (size_t)T.cap + 1);
+  T.tb = ws_alloc<uint32_t>(ctx, (size_t)T.cap + 1);
+  T.cnt = ws_alloc<uint32_t>(ctx, (size_t)T.cap + 1);
+  if (!cpart || !hcnt || !hbase || !xsum || !xbase || !L.base || !L.cnt || !L.tbase || !L.j || !L.cs || !T.first || !T.tb || !T.cnt) return TBK_ENOMEM;
+  TBK_HIP(hipMemsetAsync(T.cnt, 0, ((size_t)T.cap + 1) * 4, ctx->stream));
+  TBK_LAUNCH(ctx, "cov_bundles", cb_agg_k, cbt, CB_NT, 0, m, A.tid, A.end, cpart);
+  TBK_LAUNCH(ctx, "cov_bundles", cb_spine_k, 1, 256, 0, cpart, cbt);
+  TBK_LAUNCH(ctx, "cov_bundles", cl_heads_k<false>, cbt, CB_NT, 0, m, A, cpart, hcnt, xsum, (const uint32_t*)nullptr, (const long long*)nullptr, in->cig_off,
+             in->cig, T, L, sc, ctx->d_err);
+  TBK_LAUNCH(ctx, "cov_bundles", cl_scan_k, 1, 256, 0, cbt, hcnt, xsum, hbase, xbase);
+  TBK_LAUNCH(ctx, "cov_place", cl_heads_k<true>, cbt, CB_NT, 0, m, A, cpart, hcnt, xsum, hbase, xbase, in->cig_off, in->cig, T, L, sc, ctx->d_err);
+  uint32_t eb = 0;
+  TBK_TRY(tbk_sync_err(ctx, &eb));
+  if (eb) return tbk_derr_to_status(ctx, eb);
+  if (ctx->h_scalars[CL_SC_REFUSED]) return 1;
+  const uint32_t nb = (uint32_t)ctx->h_scalars[CL_SC_NB];
+  const uint64_t S = ctx->h_scalars[CL_SC_S], nspill = ctx->h_scalars[CL_SC_NSPILL];
+  const uint32_t nsl = (uint32_t)ctx->h_scalars[CL_SC_NSL];
+  out->span_bases = S;
+  const uint32_t ntiles = (uint32_t)((S + COV_W - 1) / COV_W);  // (< T.cap)
+  if (nspill >= (1ull << 32)) return TBK_E2BIG;
+  const uint64_t cp_cap64 = 2ull * ((uint64_t)in->n_cigar_ops + nspill) + nb + ntiles + 16;  // <= 2 per M segment piece + 1 per bundle + 1 per tile
+  if (cp_cap64 >= (1ull << 32)) return TBK_E2BIG;
+  const uint32_t cp_cap = (uint32_t)cp_cap64;
+  uint32_t* tile_off = ws_alloc<uint32_t>(ctx, (size_t)ntiles + 1);
+  uint32_t* tile_fill = ws_alloc<uint32_t>(ctx, (size_t)ntiles + 1);
+  uint32_t* sp_seg = ws_alloc<uint32_t>(ctx, nspill + 1);
+  uint32_t* sp_rec = ws_alloc<uint32_t>(ctx, nspill + 1);
+  uint64_t* cp_pos = ws_alloc<uint64_t>(ctx, cp_cap);
+  double* cp_val = ws_alloc<double>(ctx, cp_cap);
+  uint32_t* tile_cp_base = ws_alloc<uint32_t>(ctx, ntiles);
+  uint32_t* tile_cp_cnt = ws_alloc<uint32_t>(ctx, ntiles);
+  uint32_t* icnt = ws_alloc<uint32_t>(ctx, ntiles);
+  uint32_t* ioff = ws_alloc<uint32_t>(ctx, ntiles);
+  ClTileOut O;
+  O.ecnt = ws_alloc<uint32_t>(ctx, ntiles);
+  O.fv = ws_alloc<double>(ctx, ntiles);
+  O.lv = ws_alloc<double>(ctx, ntiles);
+  uint32_t* cp_alloc = (uint32_t*)(sc + 10);
+  if (!tile_off || !tile_fill || !sp_seg || !sp_rec || !cp_pos || !cp_val || !tile_cp_base || !tile_cp_cnt || !icnt || !ioff || !O.ecnt || !O.fv || !O.lv)
+    return TBK_ENOMEM;
+  TBK_TRY(tbk_exscan_u32(ctx, T.cnt, tile_off, ntiles + 1, nullptr));
+  if (nsl) {
+    TBK_HIP(hipMemsetAsync(tile_fill, 0, ((size_t)ntiles + 1) * 4, ctx->stream));
+    TBK_LAUNCH(ctx, "cov_spill_fill", cl_spill_fill_k, cbt, B, 0, L, A, in->cig_off, in->cig, tile_off, tile_fill, sp_seg, sp_rec);
+  }
+#define COV_TILE_LAUNCH(ACC, ID)                                                                                                  \
+  TBK_LAUNCH(ctx, "cov_tile", (cov_tile_k<ACC, ID, true>), ntiles, COVT_NT, 0, m, S, A, in->cig_off, in->cig, in->yc, T.first, tile_off, \
+             sp_seg, sp_rec, cp_pos, cp_val, tile_cp_base, tile_cp_cnt, cp_alloc, cp_cap, ctx->d_err, O)
+  const bool small = sum_abs < (1ull << 31);  // int32 accumulators when the depth cannot overflow them
+  if (small && all_valid)
+    COV_TILE_LAUNCH(int32_t, true);
+  else if (small)
+    COV_TILE_LAUNCH(int32_t, false);
+  else if (all_valid)
+    COV_TILE_LAUNCH(long long, true);
+  else
+    COV_TILE_LAUNCH(long long, false);
+#undef COV_TILE_LAUNCH
+  TBK_LAUNCH(ctx, "cov_iv_count", cl_iv_count_k, cdiv(ntiles, B), B, 0, ntiles, O, icnt);
+  TBK_TRY(tbk_exscan_u32(ctx, icnt, ioff, ntiles, sc + 8));
+  TBK_LAUNCH(ctx, "cov_iv_write", cl_iv_emit_k, ntiles, 256, 0, ntiles, S, nb, A, cp_pos, cp_val, tile_cp_base, tile_cp_cnt, O, ioff, T.tb, out->cap_intervals,
+             out->iv_tid, out->iv_start, out->iv_end, out->iv_val);
+  return 0;
+}
+
 static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sample_mode) {
   const uint32_t n = in->n_records;
   const bool want_cov = out->cap_intervals > 0, want_j = out->cap_junctions > 0;
@@ -1246,6 +1767,19 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
     }
   }
 
+  // integral YC, intervals wanted: the lean chain (TBK_COV_LEGACY: test hook, the general chain below)
+  bool lean_done = false;
+  if (want_cov && !fractional && !sample_mode && !getenv("TBK_COV_LEGACY") && !getenv("TBK_COV_BUNDLE_SCAN")) {
+    const size_t ws_mark = ctx->ws_off;
+    const int lrc = cov_intervals_lean(ctx, in, out, A, m, all_valid, sum_abs);
+    if (lrc < 0) return lrc;
+    lean_done = lrc == 0;
+    if (!lean_done) {  // tile tables too small for this input: give the arena back and take the general chain
+      if (ctx->ws_overflow.empty()) ctx->ws_off = ws_mark;
+      TBK_HIP(hipMemsetAsync(sc + 3, 0, 11 * sizeof(uint64_t), ctx->stream));
+    }
+  }
+  if (!lean_done) {
   // bundles
   {
     if (getenv("TBK_COV_BUNDLE_SCAN")) {  // test hook: the two-stage look-back scan
@@ -1324,8 +1858,8 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
                  in->yx, tile_first, tile_off, sp_seg, sp_rec, cp_pos, cp_val, tile_cp_base, tile_cp_cnt, cp_alloc, cp_cap, ctx->d_err);
     } else {
 #define COV_TILE_LAUNCH(ACC, ID)                                                                                                   \
-  TBK_LAUNCH(ctx, "cov_tile", (cov_tile_k<ACC, ID>), ntiles, COVT_NT, 0, m, S, A, in->cig_off, in->cig, in->yc, tile_first, tile_off, \
-             sp_seg, sp_rec, cp_pos, cp_val, tile_cp_base, tile_cp_cnt, cp_alloc, cp_cap, ctx->d_err)
+  TBK_LAUNCH(ctx, "cov_tile", (cov_tile_k<ACC, ID, false>), ntiles, COVT_NT, 0, m, S, A, in->cig_off, in->cig, in->yc, tile_first, tile_off, \
+             sp_seg, sp_rec, cp_pos, cp_val, tile_cp_base, tile_cp_cnt, cp_alloc, cp_cap, ctx->d_err, ClTileOut{nullptr, nullptr, nullptr})
       const bool small = sum_abs < (1ull << 31);  // int32 accumulators when the depth cannot overflow them
       if (small && all_valid)
         COV_TILE_LAUNCH(int32_t, true);
@@ -1356,6 +1890,8 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
                  out->iv_end, out->iv_val);
     }
   }
+
+  }  // (!lean_done)
 
   if (want_j && !side.th) TBK_TRY(junc_branch(ctx, m, A, in, jcnt, out, integral, &nj, &nju));
   TBK_TRY(tbk_sync_err(ctx, &eb));

@@ -18,6 +18,9 @@ ctx = api.Context(0)
 g = ctx.collapse(dt, **kw)
 view = ctx.groups_to_cov_in(g)
 bufs = {}
+WJ = os.environ.get("TBK_PROF_NOJ") is None      # TBK_PROF_NOJ: intervals only (the main chain without the junction branch beside it)
+_cov = ctx.coverage
+ctx.coverage = lambda v, **kw: _cov(v, want_junc=WJ, **kw)
 c = ctx.coverage(view, out=bufs, raw=True)
 ctx.set_profiling(True)
 acc = {}
