@@ -42,7 +42,7 @@ def test_golden_tiecov(ctx, name, device, bam_loader):
     assert junction_lines(got, names) == read_lines(os.path.join(GOLDEN, name, name + ".junctions.bed"))
 
 
-@pytest.mark.parametrize("bundles", ["lean", "legacy", "scan", "refused"])
+@pytest.mark.parametrize("bundles", ["lean", "legacy", "scan", "refused", "junc_radix", "junc_overflow"])
 @pytest.mark.parametrize("profile,n", [("c2", 100000), ("c3", 60000), ("c5", 60000)])
 def test_synthetic_collapsed(ctx, profile, n, bundles, monkeypatch):
     """(interval chain: the lean one — one read-back, compacted starts from the head sums —, the general one behind it
@@ -56,6 +56,10 @@ def test_synthetic_collapsed(ctx, profile, n, bundles, monkeypatch):
         monkeypatch.setenv("TBK_COV_LEGACY", "1")
     elif bundles == "refused":
         monkeypatch.setenv("TBK_COV_TILE_CAP", "3")
+    elif bundles == "junc_radix":          # junctions: the global radix sort instead of the per-home LDS sorts
+        monkeypatch.setenv("TBK_JUNC_RADIX", "1")
+    elif bundles == "junc_overflow":       # ... and a home block with more items than its sort takes: the radix path takes over
+        monkeypatch.setenv("TBK_JH_CAP", "2")
     tile = synth.make_tile(3, n, profile, n_loci=3000)
     groups = orc.collapse(tile)
     cin = synth.collapsed_to_cov_input(tile, groups)

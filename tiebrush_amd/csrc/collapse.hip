@@ -2440,7 +2440,7 @@ __global__ void g2c_count_key_k(uint32_t ng, const uint64_t* __restrict__ key, c
 struct G2cPrep {  // the first pass of tbk_coverage_tile, per view record (cov.hip: cov_prep_k) — and its three scalars
   int32_t *start, *end, *yi;
   uint32_t *jcnt, *ridx;
-  unsigned long long* sums;  // [0] M bases, [1] sum |YC|, [2] error bits
+  unsigned long long* sums;  // [0] M bases, [1] sum |YC|, [2] error bits, [3] junction items (sum of jcnt)
 };
 __global__ __launch_bounds__(256) void g2c_gather_key_k(uint32_t ng, const uint64_t* __restrict__ key, const double* __restrict__ yc,
                                                         const int64_t* __restrict__ yx, const uint32_t* __restrict__ cfirst,
@@ -2449,7 +2449,7 @@ __global__ __launch_bounds__(256) void g2c_gather_key_k(uint32_t ng, const uint6
                                                         int32_t* __restrict__ o_pos, uint8_t* __restrict__ o_strand, double* __restrict__ o_yc,
                                                         int64_t* __restrict__ o_yx, uint32_t* __restrict__ o_cig_off, uint32_t* __restrict__ o_cig,
                                                         G2cPrep P) {
-  unsigned long long mb = 0, ay = 0;
+  unsigned long long mb = 0, ay = 0, nji = 0;
   uint32_t eb = 0;
   for (uint32_t o = blockIdx.x * blockDim.x + threadIdx.x; o < ng; o += gridDim.x * blockDim.x) {
     const uint64_t k0 = key[2 * (size_t)o], k1 = key[2 * (size_t)o + 1];
@@ -2505,16 +2505,19 @@ __global__ __launch_bounds__(256) void g2c_gather_key_k(uint32_t ng, const uint6
     P.start[o] = posv + 1;
     P.end[o] = posv + l;
     P.jcnt[o] = (uint32_t)(nex - 1);
+    nji += (unsigned long long)(nex - 1);
   }
-  __shared__ unsigned long long red_mb[4], red_ay[4];
+  __shared__ unsigned long long red_mb[4], red_ay[4], red_nj[4];
   __shared__ uint32_t red_e[4];
   mb = wave_sum(mb);
   ay = wave_sum(ay);
+  nji = wave_sum(nji);
 #pragma unroll
   for (int dd = 32; dd >= 1; dd >>= 1) eb |= __shfl_xor(eb, dd, 64);
   if (lane_id() == 0) {
     red_mb[threadIdx.x >> 6] = mb;
     red_ay[threadIdx.x >> 6] = ay;
+    red_nj[threadIdx.x >> 6] = nji;
     red_e[threadIdx.x >> 6] = eb;
   }
   __syncthreads();
@@ -2522,11 +2525,13 @@ __global__ __launch_bounds__(256) void g2c_gather_key_k(uint32_t ng, const uint6
     for (int q = 1; q < 4; ++q) {
       mb += red_mb[q];
       ay += red_ay[q];
+      nji += red_nj[q];
       eb |= red_e[q];
     }
     if (mb) atomicAdd(&P.sums[0], mb);
     if (ay) atomicAdd(&P.sums[1], ay);
     if (eb) atomicOr(&P.sums[2], (unsigned long long)eb);
+    if (nji) atomicAdd(&P.sums[3], nji);
   }
 }
 __global__ void g2c_gather_k(uint32_t ng, const uint32_t* __restrict__ rep, const double* __restrict__ yc, const int64_t* __restrict__ yx,
@@ -2623,10 +2628,10 @@ int tbk_cov_view_build(tbk_ctx* ctx, const int32_t* r_tid, const int32_t* r_pos,
     P.jcnt = (uint32_t*)take((size_t)ng * 4);
     P.ridx = (uint32_t*)take((size_t)ng * 4);
     P.sums = (unsigned long long*)(ctx->d_scalars + 24);
-    TBK_HIP(hipMemsetAsync(P.sums, 0, 3 * sizeof(uint64_t), ctx->stream));
+    TBK_HIP(hipMemsetAsync(P.sums, 0, 4 * sizeof(uint64_t), ctx->stream));
     TBK_LAUNCH(ctx, "g2c_gather", g2c_gather_key_k, (cdiv(ng, B) < 4096u ? cdiv(ng, B) : 4096u), B, 0, ng, g_key, g_yc, g_yx, cfirst, cnt, r_cig, ooff,
                (uint32_t)total, o_tid, o_pos, o_strand, o_yc, o_yx, o_cig_off, o_cig, P);
-    TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 24, ctx->d_scalars + 24, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 24, ctx->d_scalars + 24, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   } else
     TBK_LAUNCH(ctx, "g2c_gather", g2c_gather_k, cdiv(ng, B), B, 0, ng, g_rep, g_yc, g_yx, r_tid, r_pos, r_strand, cfirst, cnt, r_cig, ooff,
                (uint32_t)total, o_tid, o_pos, o_strand, o_yc, o_yx, o_cig_off, o_cig);
@@ -2654,6 +2659,7 @@ int tbk_cov_view_build(tbk_ctx* ctx, const int32_t* r_tid, const int32_t* r_pos,
     V.n_bases = ctx->h_scalars[24];
     V.sum_abs = ctx->h_scalars[25];
     V.err = (uint32_t)ctx->h_scalars[26];
+    V.n_junc = ctx->h_scalars[27];
     V.valid = true;
   }
   return 0;

@@ -74,7 +74,7 @@ __global__ void cov_prep_k(uint32_t n, const uint32_t* __restrict__ valid, const
                            const uint32_t* __restrict__ cig_off, const uint32_t* __restrict__ cig,
                            const double* __restrict__ yc, int check_ops, CovArrays A, uint32_t* __restrict__ jcnt,
                            uint64_t* __restrict__ scalars, uint32_t* __restrict__ err) {
-  uint64_t mb = 0, ay = 0;
+  uint64_t mb = 0, ay = 0, nji = 0;
   uint32_t e = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     if (valid && !valid[i]) continue;
@@ -102,19 +102,24 @@ __global__ void cov_prep_k(uint32_t n, const uint32_t* __restrict__ valid, const
     A.start[j] = pos[i] + 1;
     A.end[j] = pos[i] + l;
     A.tid[j] = tid[i];
-    if (jcnt) jcnt[j] = (uint32_t)(nex - 1);
+    if (jcnt) {
+      jcnt[j] = (uint32_t)(nex - 1);
+      nji += (uint64_t)(nex - 1);
+    }
   }
   // block-level reduction: the three scalars share one cache line, keep the atomics to one set per block
-  __shared__ unsigned long long red_mb[4], red_ay[4];
+  __shared__ unsigned long long red_mb[4], red_ay[4], red_nj[4];
   __shared__ uint32_t red_e[4];
   mb = wave_sum(mb);
   ay = wave_sum(ay);
+  nji = wave_sum(nji);
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) e |= __shfl_xor(e, d, 64);
   uint32_t w = threadIdx.x >> 6;
   if (lane_id() == 0) {
     red_mb[w] = mb;
     red_ay[w] = ay;
+    red_nj[w] = nji;
     red_e[w] = e;
   }
   __syncthreads();
@@ -123,10 +128,12 @@ __global__ void cov_prep_k(uint32_t n, const uint32_t* __restrict__ valid, const
     for (uint32_t k = 1; k < nw; ++k) {
       mb += red_mb[k];
       ay += red_ay[k];
+      nji += red_nj[k];
       e |= red_e[k];
     }
     if (mb) atomicAdd((unsigned long long*)&scalars[0], (unsigned long long)mb);
     if (ay) atomicAdd((unsigned long long*)&scalars[1], (unsigned long long)ay);
+    if (nji) atomicAdd((unsigned long long*)&scalars[14], (unsigned long long)nji);
     if (e) atomicOr(err, e);
   }
 }
@@ -1498,6 +1505,192 @@ __global__ void junc_sum_k(uint32_t nj, CovArrays A, const uint32_t* __restrict_
   if (act && last && o < cap) atomicAdd(&j_val[o], v);
 }
 
+
+// ---- junctions without a sort (integral YC) -------------------------------------------------------------------------------------------
+// junc_agg_k leaves one item per distinct junction and block of JA_REC records; the same junction comes from a few neighbouring
+// blocks (the reads that span it start within a read length of each other).  Every item has a HOME block: the last block whose first
+// record starts at or before the junction's first base, in (reference, start) order.  Equal junctions share their home, and homes are
+// in key order, so: count the items per home (jh_home_k), scan, scatter (jh_scatter_k), sort and sum every home's few items in LDS
+// (jh_sort_k), scan the numbers of distinct junctions, write (jh_write_k) — no global sort (8 radix passes, 24 launches, for some
+// 10^5 items) and no read-back before the end.  A home with more items than a block sorts (a raw, uncollapsed input piled a thousand
+// deep) raises scalar 12 and the radix path takes the call.
+constexpr uint32_t JH_CAP = 1024;
+__global__ void jh_blockkey_k(uint32_t nblk, CovArrays A, const int32_t* __restrict__ tid, const int32_t* __restrict__ pos, uint64_t* __restrict__ bkey) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nblk) return;
+  const uint32_t i = A.ridx[(size_t)b * JA_REC];
+  bkey[b] = ((uint64_t)(uint32_t)tid[i] << 32) | (uint32_t)(pos[i] + 1);  // (reference, 1-based start) of the block's first record
+}
+// item q (hi = reference : 32 | first base of the junction : 32, the form junc_agg_k writes) -> its home, counted
+__global__ void jh_home_k(const unsigned long long* __restrict__ n_items, uint32_t cap_items, const uint64_t* __restrict__ hi, uint32_t nblk,
+                          const uint64_t* __restrict__ bkey, uint32_t* __restrict__ home, uint32_t* __restrict__ cnt) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long n = *n_items;
+  if (q >= n || q >= cap_items) return;
+  const uint64_t k = hi[q];
+  uint32_t lo = 0, up = nblk;  // last block with bkey <= k (block 0 when none: the order check of the interval chain reports such input)
+  while (up - lo > 1) {
+    const uint32_t mid = lo + ((up - lo) >> 1);
+    if (bkey[mid] <= k)
+      lo = mid;
+    else
+      up = mid;
+  }
+  home[q] = lo;
+  atomicAdd(&cnt[lo], 1u);
+}
+__global__ void jh_scatter_k(const unsigned long long* __restrict__ n_items, uint32_t cap_items, const uint64_t* __restrict__ hi,
+                             const uint64_t* __restrict__ lo, const double* __restrict__ pv, const uint32_t* __restrict__ home,
+                             const uint32_t* __restrict__ off, uint32_t* __restrict__ fill, uint64_t* __restrict__ hi2, uint64_t* __restrict__ lo2,
+                             double* __restrict__ pv2) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long n = *n_items;
+  if (q >= n || q >= cap_items) return;
+  const uint32_t h = home[q];
+  const uint32_t at = off[h] + atomicAdd(&fill[h], 1u);
+  hi2[at] = hi[q];
+  lo2[at] = lo[q];
+  pv2[at] = pv[q];
+}
+// Homes with at most 64 items (nearly all): one wave per home, an item per lane, a bitonic network over the lanes (xor shuffles), equal
+// keys summed by a segmented scan (integers held in doubles: any order) — no LDS, no barrier.  The distinct junctions are left at the
+// front of the home's segment, their number in ucnt.  Larger homes: jh_sort_big_k.
+__global__ __launch_bounds__(256) void jh_sort_k(uint32_t nblk, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
+                                                 uint64_t* __restrict__ hi2, uint64_t* __restrict__ lo2, double* __restrict__ pv2,
+                                                 uint32_t* __restrict__ ucnt, uint32_t* __restrict__ big, uint64_t* __restrict__ nbig) {
+  const uint32_t h = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (h >= nblk) return;
+  const uint32_t n = cnt[h];
+  if (n > 64u) {  // listed for jh_sort_big_k
+    if (lane_id() == 0) big[atomicAdd((unsigned long long*)nbig, 1ull)] = h;
+    return;
+  }
+  if (n == 0) {
+    if (lane_id() == 0) ucnt[h] = 0;
+    return;
+  }
+  const uint32_t base = off[h], l = lane_id();
+  uint64_t kh = l < n ? hi2[base + l] : ~0ull, kl = l < n ? lo2[base + l] : ~0ull;
+  double kv = l < n ? pv2[base + l] : 0.0;
+#pragma unroll
+  for (uint32_t k = 2; k <= 64; k <<= 1)
+#pragma unroll
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      const uint64_t oh = __shfl_xor(kh, (int)j, 64), ol = __shfl_xor(kl, (int)j, 64);
+      const double ov = __shfl_xor(kv, (int)j, 64);
+      const bool lower = (l & j) == 0, up = (l & k) == 0;
+      const bool gt = kh > oh || (kh == oh && kl > ol);     // mine > partner's
+      const bool lt = oh > kh || (oh == kh && ol > kl);     // mine < partner's
+      // the lower lane of a pair keeps the smaller key in an ascending run, the larger one in a descending run
+      const bool take = lower ? (up ? gt : lt) : (up ? lt : gt);
+      if (take) kh = oh, kl = ol, kv = ov;
+    }
+  const uint64_t ph = __shfl_up(kh, 1, 64), pl = __shfl_up(kl, 1, 64);
+  const bool head = l < n && (l == 0 || kh != ph || kl != pl);
+  const uint64_t hm = __ballot(head);
+  // inclusive segmented sum over the lanes of one junction (the segment of lane l starts at the last head at or before it)
+  const uint64_t upto = hm & ((2ull << l) - 1ull);
+  const uint32_t seg0 = upto ? 63u - (uint32_t)__builtin_clzll(upto) : 0u;
+  double s = kv;
+#pragma unroll
+  for (uint32_t d = 1; d < 64; d <<= 1) {
+    const double o = __shfl_up(s, d, 64);
+    if (l >= d && l - d >= seg0) s += o;
+  }
+  const bool last = l < n && (l + 1 == n || ((hm >> (l + 1)) & 1ull));
+  if (last) {
+    const uint32_t r = (uint32_t)__builtin_popcountll(hm & ((2ull << l) - 1ull)) - 1u;  // rank of this junction among the home's
+    hi2[base + r] = kh;
+    lo2[base + r] = kl;
+    pv2[base + r] = s;
+  }
+  if (l == 0) ucnt[h] = (uint32_t)__builtin_popcountll(hm);
+}
+// the homes with more than 64 items (listed by jh_sort_k), a block at a time: sorted by (hi, lo) in LDS (bitonic), equal keys summed
+__global__ __launch_bounds__(256) void jh_sort_big_k(const uint32_t* __restrict__ big, const uint64_t* __restrict__ nbig, const uint32_t* __restrict__ cnt,
+                                                     const uint32_t* __restrict__ off, uint64_t* __restrict__ hi2, uint64_t* __restrict__ lo2,
+                                                     double* __restrict__ pv2, uint32_t* __restrict__ ucnt, uint64_t* __restrict__ overflow, uint32_t cap) {
+  __shared__ uint64_t kh[JH_CAP], kl[JH_CAP];
+  __shared__ double kv[JH_CAP];
+  __shared__ uint32_t sm[8];
+  const uint32_t nb_ = (uint32_t)*nbig;
+  for (uint32_t bi = blockIdx.x; bi < nb_; bi += gridDim.x) {
+  const uint32_t h = big[bi], n = cnt[h];
+  if (n > cap) {
+    if (threadIdx.x == 0) {
+      *overflow = 1;
+      ucnt[h] = 0;
+    }
+    continue;
+  }
+  const uint32_t base = off[h];
+  uint32_t np = 64;
+  while (np < n) np <<= 1;
+  for (uint32_t q = threadIdx.x; q < np; q += 256) {
+    kh[q] = q < n ? hi2[base + q] : ~0ull;
+    kl[q] = q < n ? lo2[base + q] : ~0ull;
+    kv[q] = q < n ? pv2[base + q] : 0.0;
+  }
+  __syncthreads();
+  for (uint32_t k = 2; k <= np; k <<= 1)
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t q = threadIdx.x; q < np; q += 256) {
+        const uint32_t p = q ^ j;
+        if (p > q) {
+          const bool up = (q & k) == 0;
+          const uint64_t ah = kh[q], al = kl[q], bh = kh[p], bl = kl[p];
+          const bool gt = ah > bh || (ah == bh && al > bl);
+          if (gt == up) {
+            kh[q] = bh, kl[q] = bl, kh[p] = ah, kl[p] = al;
+            const double t = kv[q];
+            kv[q] = kv[p];
+            kv[p] = t;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  // heads, their ranks, their sums
+  uint32_t run = 0;
+  for (uint32_t q0 = 0; q0 < n; q0 += 256) {
+    const uint32_t q = q0 + threadIdx.x;
+    const bool head = q < n && (q == 0 || kh[q] != kh[q - 1] || kl[q] != kl[q - 1]);
+    uint32_t tot;
+    const uint32_t r = run + block_excl_sum<uint32_t, 256>(head ? 1u : 0u, sm, &tot);
+    run += tot;
+    if (head) {
+      double s = kv[q];
+      for (uint32_t e = q + 1; e < n && kh[e] == kh[q] && kl[e] == kl[q]; ++e) s += kv[e];
+      hi2[base + r] = kh[q];  // (r <= q, and every item of the segment is in LDS: writing the front of the segment is safe)
+      lo2[base + r] = kl[q];
+      pv2[base + r] = s;
+    }
+  }
+  if (threadIdx.x == 0) ucnt[h] = run;
+  __syncthreads();  // (the LDS arrays are loaded again for the block's next home)
+  }
+}
+__global__ void jh_write_k(uint32_t nblk, const uint32_t* __restrict__ ucnt, const uint32_t* __restrict__ uoff, const uint32_t* __restrict__ off,
+                           const uint64_t* __restrict__ hi2, const uint64_t* __restrict__ lo2, const double* __restrict__ pv2, uint32_t cap,
+                           int32_t* __restrict__ j_tid, int32_t* __restrict__ j_start, int32_t* __restrict__ j_end, uint8_t* __restrict__ j_strand,
+                           double* __restrict__ j_val) {
+  // a wave per home (most homes hold a handful of junctions)
+  const uint32_t h = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (h >= nblk) return;
+  const uint32_t n = ucnt[h], o0 = uoff[h], b0 = off[h];
+  for (uint32_t u = lane_id(); u < n; u += 64) {
+    const uint32_t o = o0 + u;
+    if (o >= cap) break;
+    const uint64_t kh = hi2[b0 + u], kl = lo2[b0 + u];
+    const int32_t start = (int32_t)(uint32_t)(kh & 0xFFFFFFFFu);
+    j_tid[o] = (int32_t)(uint32_t)(kh >> 32);
+    j_start[o] = start - 1;
+    j_end[o] = start + (int32_t)(uint32_t)(kl >> 8) - 1;
+    j_strand[o] = (uint8_t)(kl & 0xFFu);
+    j_val[o] = pv2[b0 + u];
+  }
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -1519,16 +1712,24 @@ __global__ void sample_convert_k(uint32_t n, const double* __restrict__ v, float
 // arena, own host thread) while the main stream builds the intervals; `ctx` is whichever context it runs on.
 constexpr uint32_t COV_SIDE_MIN = 1u << 16;  // below this many records the fork costs more than it hides
 static int junc_branch(tbk_ctx* ctx, uint32_t m, const CovArrays& A, const tbk_cov_in* in, const uint32_t* jcnt, tbk_cov_out* out,
-                       bool integral, uint32_t* nj_out, uint32_t* nju_out) {
+                       bool integral, uint64_t nj_known, uint32_t* nj_out, uint32_t* nju_out) {
   const uint32_t B = 256;
   uint64_t* sc = ctx->d_scalars;
   *nj_out = *nju_out = 0;
-  uint32_t* joff = ws_alloc<uint32_t>(ctx, m);
-  if (!joff) return TBK_ENOMEM;
-  TBK_TRY(tbk_exscan_u32(ctx, jcnt, joff, m, sc + 7));
-  TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 7, sc + 7, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-  TBK_HIP(hipStreamSynchronize(ctx->stream));
-  const uint32_t nj = (uint32_t)ctx->h_scalars[7];
+  const bool agg = integral && !getenv("TBK_NO_JUNC_AGG");
+  uint32_t* joff = nullptr;
+  uint32_t nj;
+  if (agg && nj_known != ~0ull) {  // the block sums need no per-record offsets, and the first pass left the total behind
+    if (nj_known >= (1ull << 32)) return TBK_E2BIG;
+    nj = (uint32_t)nj_known;
+  } else {
+    joff = ws_alloc<uint32_t>(ctx, m);
+    if (!joff) return TBK_ENOMEM;
+    TBK_TRY(tbk_exscan_u32(ctx, jcnt, joff, m, sc + 7));
+    TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 7, sc + 7, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    TBK_HIP(hipStreamSynchronize(ctx->stream));
+    nj = (uint32_t)ctx->h_scalars[7];
+  }
   *nj_out = nj;
   if (!nj) return 0;
   SortBufs sb;
@@ -1543,16 +1744,49 @@ static int junc_branch(tbk_ctx* ctx, uint32_t m, const CovArrays& A, const tbk_c
   if (!hoff) return TBK_ENOMEM;
   uint32_t ns = nj;   // items that reach the sort
   double* pv = nullptr;
-  const bool agg = integral && !getenv("TBK_NO_JUNC_AGG");
   if (agg) {  // block-level sums first: one item per distinct junction and block of records
     pv = ws_alloc<double>(ctx, nj);
     if (!pv) return TBK_ENOMEM;
-    TBK_HIP(hipMemsetAsync(sc + 11, 0, sizeof(uint64_t), ctx->stream));
+    TBK_HIP(hipMemsetAsync(sc + 11, 0, 3 * sizeof(uint64_t), ctx->stream));  // [11] items, [12] a home too full, [13] homes of more than 64 items
     TBK_LAUNCH(ctx, "junc_agg", junc_agg_k, cdiv(m, JA_REC), 256, 0, m, A, in->tid, in->pos, in->cig_off, in->cig, in->strand, in->yc, jcnt, sb.hi, sb.lo,
                pv, (unsigned long long*)(sc + 11));
-    TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 11, sc + 11, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    TBK_HIP(hipStreamSynchronize(ctx->stream));
-    ns = (uint32_t)ctx->h_scalars[11];
+    if (!getenv("TBK_JUNC_RADIX")) {  // (TBK_JUNC_RADIX: test hook, the sort below)
+      // every item to its home block, the homes sorted one by one: no read-back until the junctions are written
+      const uint32_t nblk = cdiv(m, JA_REC);
+      uint64_t* bkey = ws_alloc<uint64_t>(ctx, nblk);
+      uint32_t* hcnt = ws_alloc<uint32_t>(ctx, (size_t)nblk * 2);  // counts | fill cursors
+      uint32_t* hoff2 = ws_alloc<uint32_t>(ctx, nblk);
+      uint32_t* ucnt = ws_alloc<uint32_t>(ctx, nblk);
+      uint32_t* uoff = ws_alloc<uint32_t>(ctx, nblk);
+      double* pv2 = ws_alloc<double>(ctx, nj);
+      if (!bkey || !hcnt || !hoff2 || !ucnt || !uoff || !pv2) return TBK_ENOMEM;
+      uint32_t* hfill = hcnt + nblk;
+      TBK_HIP(hipMemsetAsync(hcnt, 0, (size_t)nblk * 2 * 4, ctx->stream));
+      TBK_LAUNCH(ctx, "junc_home", jh_blockkey_k, cdiv(nblk, B), B, 0, nblk, A, in->tid, in->pos, bkey);
+      TBK_LAUNCH(ctx, "junc_home", jh_home_k, cdiv(nj, B), B, 0, (const unsigned long long*)(sc + 11), nj, sb.hi, nblk, bkey, head /* home */, hcnt);
+      TBK_TRY(tbk_exscan_u32(ctx, hcnt, hoff2, nblk, nullptr));
+      TBK_LAUNCH(ctx, "junc_home", jh_scatter_k, cdiv(nj, B), B, 0, (const unsigned long long*)(sc + 11), nj, sb.hi, sb.lo, pv, head, hoff2, hfill, sb.hi2,
+                 sb.lo2, pv2);
+      uint32_t jh_cap = JH_CAP;
+      if (const char* e = getenv("TBK_JH_CAP")) jh_cap = (uint32_t)atoi(e) < JH_CAP ? (uint32_t)atoi(e) : JH_CAP;  // test hook: force the fall-back
+      uint32_t* big = hoff;  // (nj entries, unused on this path: fewer than nj / 64 homes can hold more than 64 items)
+      TBK_LAUNCH(ctx, "junc_sort", jh_sort_k, cdiv((uint64_t)nblk * 64, B), B, 0, nblk, hcnt, hoff2, sb.hi2, sb.lo2, pv2, ucnt, big, sc + 13);
+      TBK_LAUNCH(ctx, "junc_sort", jh_sort_big_k, 512, 256, 0, big, sc + 13, hcnt, hoff2, sb.hi2, sb.lo2, pv2, ucnt, sc + 12, jh_cap);
+      TBK_TRY(tbk_exscan_u32(ctx, ucnt, uoff, nblk, sc + 9));
+      TBK_LAUNCH(ctx, "junc_write", jh_write_k, cdiv((uint64_t)nblk * 64, B), B, 0, nblk, ucnt, uoff, hoff2, sb.hi2, sb.lo2, pv2, out->cap_junctions, out->j_tid,
+                 out->j_start, out->j_end, out->j_strand, out->j_val);
+      TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 9, sc + 9, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+      TBK_HIP(hipStreamSynchronize(ctx->stream));
+      if (!ctx->h_scalars[12]) {
+        *nju_out = (uint32_t)ctx->h_scalars[9];
+        return tbk_check_launch(ctx, "junctions");
+      }
+      ns = (uint32_t)ctx->h_scalars[11];  // a home overflowed: the items are still where junc_agg_k left them
+    } else {
+      TBK_HIP(hipMemcpyAsync(ctx->h_scalars + 11, sc + 11, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+      TBK_HIP(hipStreamSynchronize(ctx->stream));
+      ns = (uint32_t)ctx->h_scalars[11];
+    }
     TBK_LAUNCH(ctx, "junc_iota", junc_iota_k, cdiv(ns, B), B, 0, ns, sb.val);
   } else {
     TBK_LAUNCH(ctx, "junc_fill", junc_fill_k, cdiv(m, B), B, 0, m, A, in->tid, in->pos, in->cig_off, in->cig, in->strand, joff, sb.hi, sb.lo, sb.val);
@@ -1751,17 +1985,18 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
   out->n_bases = ctx->h_scalars[0];
   const uint64_t sum_abs = ctx->h_scalars[1];
   const bool integral = !fractional && !sample_mode && sum_abs < (1ull << 52);  // junction sums may then be formed in any order
+  const uint64_t nj_known = prepared ? V.n_junc : (want_j ? ctx->h_scalars[14] : ~0ull);  // junction items: both first passes count them
   if (m == 0) return 0;
   if (want_j && want_cov && m >= COV_SIDE_MIN) {  // the valid records are compacted (the stream was just synchronised): fork the junction branch
     tbk_ctx* jc = tbk_side_ctx(ctx);
     if (jc) {
-      const size_t hint = (size_t)m * 8 + (size_t)in->n_cigar_ops * 56 + ((size_t)4 << 20);
+      const size_t hint = (size_t)m * 8 + (size_t)in->n_cigar_ops * 64 + ((size_t)4 << 20);
       if (!ctx->side_worker) ctx->side_worker = new TbkWorker();
       side.w = ctx->side_worker;
       side.th = true;
-      side.w->post([&side, jc, hint, m, &A, in, jcnt, out, integral, &nj, &nju]() {
+      side.w->post([&side, jc, hint, m, &A, in, jcnt, out, integral, nj_known, &nj, &nju]() {
         side.rc = tbk_side_begin(jc, hint);
-        if (side.rc == 0) side.rc = junc_branch(jc, m, A, in, jcnt, out, integral, &nj, &nju);
+        if (side.rc == 0) side.rc = junc_branch(jc, m, A, in, jcnt, out, integral, nj_known, &nj, &nju);
         tbk_side_end(jc);
       });
     }
@@ -1893,7 +2128,7 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
 
   }  // (!lean_done)
 
-  if (want_j && !side.th) TBK_TRY(junc_branch(ctx, m, A, in, jcnt, out, integral, &nj, &nju));
+  if (want_j && !side.th) TBK_TRY(junc_branch(ctx, m, A, in, jcnt, out, integral, nj_known, &nj, &nju));
   TBK_TRY(tbk_sync_err(ctx, &eb));
   if (eb) return tbk_derr_to_status(ctx, eb);
   TBK_TRY(tbk_check_launch(ctx, "coverage"));

@@ -109,7 +109,7 @@ struct tbk_ctx {
     uint32_t n = 0;
     int32_t *start = nullptr, *end = nullptr, *yi = nullptr;
     uint32_t *jcnt = nullptr, *ridx = nullptr;
-    uint64_t n_bases = 0, sum_abs = 0;
+    uint64_t n_bases = 0, sum_abs = 0, n_junc = 0;  // n_junc: junction items (sum of jcnt)
     uint32_t err = 0;  // TBK_DERR_FATALOP / _NCIGAR (raised only when intervals are wanted) / _FRACTIONAL
   } view_prep;
   bool profiling = false;
