@@ -39,3 +39,14 @@ def test_create_fails_loudly_without_gpu():
     L = _lib.load()
     h = C.c_void_p()
     assert L.tbk_create(0, C.byref(h)) == -9  # TBK_ENODEVICE, never a silent CPU path
+
+
+def test_host_library_exports_every_symbol_of_its_header():
+    txt = open(os.path.join(ROOT, "include", "tbh_host.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(tbh_[a-z0-9_]+)\s*\(", txt)))
+    assert declared == sorted(_lib.HOST_SYMBOLS)
+    H = _lib.load_host()
+    assert H.tbh_abi_version() == 1
+    for s in declared:
+        assert hasattr(H, s), s

@@ -363,3 +363,33 @@ def test_real_bam_shapes_through_the_command_line(tmp_path, env):
     assert [bytes(x) for x in o.qname] == [b"r%d_%d" % (int(fo[g]), int(g) - int(tile.file_off[int(fo[g])])) for g in want["rep"]]
     assert [int(x) for x in o.yd] == [int(x) for x in want["yd"]] and [int(x) for x in o.yx] == [int(x) for x in want["yx"]]
     assert [float(x) for x in o.yc] == [float(np.float32(x)) for x in want["yc"]]
+
+
+@pytest.mark.parametrize("name,flags", [("t1", []), ("t2", ["-P"])])
+def test_tiebrush_ranks_two_processes_end_in_one_bam(tmp_path, name, flags):
+    """`tiebrush --ranks 2`: two processes (one GPU shared through the gloo staging hook; RCCL needs a GPU per rank), five sample files
+    each — local collapse, group partials exchanged and reduced by range owner, the winners fetched back from the rank that holds
+    the file, tagged and deflated per rank, one BAM.  Its records equal the single-GPU command line's byte for byte, and the
+    golden BAM through the normaliser (HEAD without -A differs from the 0.0.6 goldens by YC + 1 at the records SURVEY.md §4.4
+    lists)."""
+    from tiebrush_amd import bamio
+    out1, out2 = str(tmp_path / "one.bam"), str(tmp_path / "two.bam")
+    ins = sample_paths(name)
+    _run([os.path.join(BIN, "tiebrush"), "-o", out1] + flags + ins)
+    env = dict(os.environ, TBK_RANKS_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([os.path.join(BIN, "tiebrush"), "--ranks", "2", "-o", out2] + flags + ins, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a, b = bamio.read_bam(out1, keep_aux=True), bamio.read_bam(out2, keep_aux=True)
+    assert a.n == b.n
+    for i in range(a.n):
+        assert bamio.record_bytes(a, i) == bamio.record_bytes(b, i), i          # every byte of every record, tags included
+    n_in = {"t1": 416922, "t2": 242910}[name]
+    assert "%d input records written as %d" % (n_in, b.n) in r.stderr
+    assert b.header.is_tiebrush() and len(b.header.co_samples()) == 10 and not os.path.exists(out2 + ".part0")
+    g = bamio.read_bam(os.path.join(GOLDEN, name, name + ".bam"))
+    deltas = {"t1": [1930, 2210], "t2": [2233, 4901, 5655, 8154]}[name]
+    assert g.n == b.n
+    for i in range(g.n):
+        assert bamio.record_identity(b, i) == bamio.record_identity(g, i), i
+        gyc = (g.yc[i] if g.has_yc[i] else 1.0) + (1.0 if i in deltas else 0.0)
+        assert b.yc[i] == gyc and b.yx[i] == g.yx[i] and b.yd[i] == g.yd[i], i

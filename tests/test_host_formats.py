@@ -157,3 +157,50 @@ def test_samtext_renders_golden_t2_as_the_reference_sam():
     lines = [ln for ln in txt.splitlines(True) if not ln.startswith("@")]
     gold = open(os.path.join(GOLDEN, "t2", "t2.sam")).read().splitlines(True)
     assert len(recs) == 8179 and lines == gold
+
+
+def test_host_write_path_of_the_ranks_tool(tmp_path):
+    """libtbh.so (include/tbh_host.h), the write-back half of `tiebrush --ranks`: raw records + YC / YX / YD in, parts of BGZF members
+    out, header + parts + EOF = a BAM whose records carry the reference's tag forms (YC:f always, YX by value width, YD only when
+    positive: tiebrush.cpp:506-525) — checked with the Python decoder on records of golden t1 (fresh records and records that
+    already carry the tags)."""
+    import ctypes as C
+    from tiebrush_amd import _lib
+    H = _lib.load_host()
+    src = [os.path.join(GOLDEN, "t1", "t1s0.bam"), os.path.join(GOLDEN, "t1", "t1.bam")]
+    assert [H.tbh_is_tiebrush(p.encode()) for p in src] == [0, 1]
+    parts = []
+    want = []
+    for pi, p in enumerate(src):
+        b = bamio.read_bam(p, keep_aux=True)
+        n = min(b.n, 3000)
+        recs = [bamio.record_bytes(b, i) for i in range(n)]           # raw records without block_size
+        blob = np.frombuffer(b"".join(recs), np.uint8).copy()
+        ln = np.array([len(r) for r in recs], np.uint32)
+        off = np.concatenate([[0], np.cumsum(ln)])[:-1].astype(np.uint64)
+        rng = np.random.default_rng(5 + pi)
+        yc = rng.integers(1, 70000, n).astype(np.float64)
+        yx = rng.choice([1, 2, 254, 255, 65534, 65535, 70000], n).astype(np.int64)
+        yd = rng.choice([0, 0, 3, 254, 255, 65535, 100000], n).astype(np.int32)
+        part = str(tmp_path / ("p%d" % pi))
+        assert H.tbh_tag_deflate_part(blob.ctypes.data, off.ctypes.data, ln.ctypes.data, n, yc.ctypes.data, yx.ctypes.data, yd.ctypes.data, 6, 3,
+                                      part.encode()) == 0, H.tbh_last_error()
+        parts.append(part)
+        for i in range(n):
+            # (an older integer-typed YC stays as it is: bam_aux_update_float refuses a non-float tag and the reference ignores
+            # the return value, GSam.h:303-305 — the golden BAMs of 0.0.6 carry YC:i)
+            old = {t: ty for t, ty, _ in bamio.record_aux(b, i)}.get("YC")
+            want.append((bamio.record_identity(b, i), float(b.yc[i]) if old not in (None, "f", "d") else float(np.float32(yc[i])), int(yx[i]), int(yd[i]),
+                         "f" if old in (None, "f", "d") else old))
+    out = str(tmp_path / "o.bam")
+    arr = lambda xs: (C.c_char_p * len(xs))(*[x.encode() for x in xs])
+    files = [os.path.join(GOLDEN, "t1", "t1s%d.bam" % i) for i in range(3)]
+    cmd = ["tiebrush", "-o", out] + files
+    assert H.tbh_write_bam_parts(out.encode(), b"0.0.7", len(cmd), arr(cmd), len(files), arr(files), len(parts), arr(parts), 1) == 0
+    assert not os.path.exists(parts[0])
+    o = bamio.read_bam(out, keep_aux=True)
+    assert o.n == len(want) and o.header.is_tiebrush() and len(o.header.co_samples()) == 3
+    for i, (ident, yc, yx, yd, yct) in enumerate(want):
+        assert bamio.record_identity(o, i) == ident and o.has_yc[i] and o.yc[i] == yc and o.yx[i] == yx and o.yd[i] == yd, i
+        types = {t: ty for t, ty, _ in bamio.record_aux(o, i)}
+        assert types["YC"] == yct and ("YD" in types) == (yd > 0)

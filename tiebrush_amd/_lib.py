@@ -128,6 +128,32 @@ def load():
     return L
 
 
+HOST_LIB_PATH = os.path.join(_HERE, "_build", "libtbh.so")
+HOST_SYMBOLS = ["tbh_abi_version", "tbh_last_error", "tbh_tag_deflate_part", "tbh_write_bam_parts", "tbh_is_tiebrush"]   # include/tbh_host.h
+_host = None
+
+
+def load_host():
+    """libtbh.so (include/tbh_host.h): the host-side write path of the multi-rank command line; no GPU code"""
+    global _host
+    if _host is not None:
+        return _host
+    if not os.path.exists(HOST_LIB_PATH):
+        raise ImportError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`" % HOST_LIB_PATH)
+    H = C.CDLL(HOST_LIB_PATH)
+    H.tbh_abi_version.restype = C.c_int
+    H.tbh_last_error.restype = C.c_char_p
+    H.tbh_tag_deflate_part.argtypes = [_P, _P, _P, C.c_uint32, _P, _P, _P, C.c_int, C.c_int, C.c_char_p]
+    H.tbh_tag_deflate_part.restype = C.c_int
+    H.tbh_write_bam_parts.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_char_p), C.c_int,
+                                      C.POINTER(C.c_char_p), C.c_int]
+    H.tbh_write_bam_parts.restype = C.c_int
+    H.tbh_is_tiebrush.argtypes = [C.c_char_p]
+    H.tbh_is_tiebrush.restype = C.c_int
+    _host = H
+    return H
+
+
 class TbkError(RuntimeError):
     def __init__(self, status, detail=""):
         self.status = status

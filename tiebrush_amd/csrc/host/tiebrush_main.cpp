@@ -4,6 +4,7 @@
 //   memory stream through TInputFiles::next_tile)  ->  tbk_collapse_tile (HIP)  ->  tag + deflate + write (host).
 // libtbk.so (and with it the HIP runtime) is bound with dlopen on a helper thread while the inputs are read (tbk_dl.h).
 // There is no CPU implementation of the collapse in this binary: without a usable GPU it exits with an error.
+#include <errno.h>
 #include <limits.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -29,6 +30,7 @@
 #include "args.h"
 #include "bgzf.h"
 #include "fastload.h"
+#include "tagwrite.h"
 #include "tbk_dl.h"
 #include "tmerge.h"
 
@@ -57,7 +59,8 @@ static const char* USAGE =
     "  -F INT               flag bits that must agree (not available in the GPU build)\n"
     "  -A,--collapse-same   do not count the same read of the same sample twice\n"
     "  --store-frac         YC adds 1/NH per alignment (needs --keep-secondary)\n"
-    "  -V,--verbose         echo the command line\n";
+    "  -V,--verbose         echo the command line\n"
+    "  --ranks N            shard the input files over N GPUs of this node (one process each), one output BAM\n";
 
 // a buffer that is allocated, not initialised (untouched pages cost nothing), on huge pages when it is large, and not freed at
 // the end: these buffers live as long as the process, which ends with _exit — returning gigabytes page by page first only
@@ -82,7 +85,38 @@ struct RawBuf {
   T& operator[](size_t i) { return p[i]; }
 };
 
+// `tiebrush --ranks N ...`: the multi-GPU form (tiebrush_amd/ranks.py: one process per GPU over torch.distributed / RCCL, the input
+// files sharded by rank, one output BAM).  This process has touched no GPU yet: it becomes the launcher, which starts the ranks.
+static void maybe_exec_ranks(int argc, char* argv[]) {
+  bool want = false;
+  for (int i = 1; i < argc; ++i) want = want || strcmp(argv[i], "--ranks") == 0 || strncmp(argv[i], "--ranks=", 8) == 0;
+  if (!want) return;
+  char exe[PATH_MAX];
+  const ssize_t n = readlink("/proc/self/exe", exe, sizeof(exe) - 1);
+  if (n <= 0) GError("Error: --ranks: cannot locate the installation\n");
+  exe[n] = 0;
+  std::string root(exe);  // <root>/tiebrush_amd/_build/tiebrush
+  for (int up = 0; up < 3; ++up) {
+    const size_t sl = root.rfind('/');
+    if (sl == std::string::npos) GError("Error: --ranks: cannot locate the installation\n");
+    root.resize(sl);
+  }
+  std::string pp = root;
+  if (const char* old = getenv("PYTHONPATH")) pp += std::string(":") + old;
+  setenv("PYTHONPATH", pp.c_str(), 1);
+  std::vector<char*> av;
+  const char* py = getenv("TBK_PYTHON") ? getenv("TBK_PYTHON") : "python3";
+  av.push_back(const_cast<char*>(py));
+  av.push_back(const_cast<char*>("-m"));
+  av.push_back(const_cast<char*>("tiebrush_amd.ranks"));
+  for (int i = 1; i < argc; ++i) av.push_back(argv[i]);
+  av.push_back(nullptr);
+  execvp(py, av.data());
+  GError("Error: --ranks: cannot start %s (%s)\n", py, strerror(errno));
+}
+
 int main(int argc, char* argv[]) {
+  maybe_exec_ranks(argc, argv);
   TInputFiles inRecords;
   inRecords.setup(VERSION, argc, argv);
   Args args(argc, argv, "help;debug;verbose;version;full;clip;exon;keep-supp;keep-secondary;keep-unmap;collapse-same;store-frac;SMLPEDVho:N:Q:F:A");
@@ -232,56 +266,8 @@ int main(int argc, char* argv[]) {
       const int level = outfile.level();
       auto tag_slice = [&](uint32_t sl, std::vector<uint8_t>& o, tbh::BamRec& rr) {
         const uint32_t g0 = sl * per, g1 = std::min(ng, g0 + per);
-        o.clear();
-        for (uint32_t g = g0; g < g1; ++g) {
-          tbh::RecView v = get_record(g);
-          // A record that carries none of the three tags yet (every record of a plain BAM input) takes them appended in the
-          // order the reference sets them — YC:f, YX by value width, YD when > 0 (bam_aux_update_* appends a missing tag;
-          // GSam.h:300-305, tiebrush.cpp:506-525): written straight into the slice.  Anything else goes through BamRec.
-          bool fresh = yx[g] >= 0 && yx[g] <= (int64_t)UINT32_MAX;
-          for (const uint8_t* a = v.aux_begin(); fresh && a + 3 <= v.aux_end();) {
-            const size_t sz = tbh::aux_field_size(a, v.aux_end());
-            if (!sz) break;
-            if (a[0] == 'Y' && (a[1] == 'C' || a[1] == 'X' || a[1] == 'D')) fresh = false;
-            a += sz;
-          }
-          if (fresh) {
-            uint8_t tg[24];
-            size_t tn = 0;
-            const float ycf = (float)yc[g];
-            tg[tn++] = 'Y', tg[tn++] = 'C', tg[tn++] = 'f';
-            memcpy(tg + tn, &ycf, 4);
-            tn += 4;
-            auto put_int = [&](char t1, uint32_t val) {  // bam_aux_update_int of a missing tag: C < 255, S < 65535, else I
-              tg[tn++] = 'Y', tg[tn++] = (uint8_t)t1;
-              const int w = val < UINT8_MAX ? 1 : (val < UINT16_MAX ? 2 : 4);
-              tg[tn++] = (uint8_t)(w == 1 ? 'C' : (w == 2 ? 'S' : 'I'));
-              for (int q = 0; q < w; ++q) tg[tn++] = (uint8_t)(val >> (8 * q));
-            };
-            put_int('X', (uint32_t)yx[g]);
-            if (yd[g] > 0) put_int('D', (uint32_t)yd[g]);
-            const uint32_t bs = v.len + (uint32_t)tn;
-            const size_t at = o.size();
-            o.resize(at + 4 + bs);
-            memcpy(o.data() + at, &bs, 4);
-            memcpy(o.data() + at + 4, v.p, v.len);
-            memcpy(o.data() + at + 4 + v.len, tg, tn);
-            continue;
-          }
-          rr.d.assign(v.p, v.p + v.len);
-          rr.update_float("YC", (float)yc[g]);
-          rr.update_int("YX", yx[g]);
-          if (yd[g] > 0)
-            rr.update_int("YD", yd[g]);
-          else
-            rr.del("YD");
-          const uint32_t bs = (uint32_t)rr.d.size();
-          const uint8_t le[4] = {(uint8_t)bs, (uint8_t)(bs >> 8), (uint8_t)(bs >> 16), (uint8_t)(bs >> 24)};
-          o.insert(o.end(), le, le + 4);
-          o.insert(o.end(), rr.d.begin(), rr.d.end());
-        }
-        // BGZF members are independent deflate streams: the slice compresses itself, the writer only appends
-        if (!tbh::bgzf_deflate_members(o.data(), o.size(), level, runs[(size_t)sl])) failed.store(true);
+        // flushPData's tags on every representative of the slice, then the slice deflates itself (tagwrite.h)
+        if (!tbh::tag_and_deflate(g0, g1, get_record, yc.data(), yx.data(), yd.data(), level, o, rr, runs[(size_t)sl])) failed.store(true);
         {
           std::lock_guard<std::mutex> lk(ready_m);
           ready[sl].store(1, std::memory_order_release);
