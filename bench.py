@@ -127,7 +127,7 @@ def run_e2e_leg(args):
     cmd = [sys.executable, os.path.join(ROOT, "tools", "e2e_leg.py"), "--files", str(args.e2e_files), "--reads", str(args.e2e_reads),
            "--runs", str(args.e2e_runs)]
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200)
         line = [l for l in r.stdout.strip().split("\n") if l.startswith("{")]
         if r.returncode != 0 or not line:
             return {"error": "tools/e2e_leg.py failed (%d): %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}
@@ -619,6 +619,9 @@ def main():
         if host_path is not None:
             line["kernel_path_host_to_host"] = host_path
         if e2e is not None:
+            for sub, name in (("seq", "end_to_end_seq"), ("c3_options", "end_to_end_c3_options")):
+                if isinstance(e2e, dict) and sub in e2e:
+                    line[name] = e2e.pop(sub)
             line["end_to_end"] = e2e
         if cpu is not None:
             line["cpu_baseline"] = cpu

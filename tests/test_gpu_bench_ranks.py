@@ -48,6 +48,9 @@ def test_bench_default_line_contract_small():
     e = d["end_to_end"]
     assert "error" not in e, e
     assert e["value"] > 0 and e["runs"] == 1 and "60000 input records written as" in e["summary"]
+    es, ec = d["end_to_end_seq"], d["end_to_end_c3_options"]          # records with SEQ / QUAL; config 3's options
+    assert es["value"] > 0 and "60000 input records written as" in es["summary"] and es["input_bytes_per_record"] > 3 * e["input_bytes_per_record"]
+    assert ec["value"] > 0 and "--clip" in ec["workload"] and "60000 input records written as" in ec["summary"]
     c = d["cpu_baseline"]
     assert c["cores"] == 1 and c["value"] > 0 and c["value_O0"] > 0 and c["sample"].startswith("the whole tile")
     assert c["parallel"]["cores"] >= 2 and c["parallel"]["value"] > 0

@@ -153,7 +153,10 @@ int main(int argc, char** argv) {
   if (cmd == "mkbam" && argc >= 4) {
     const std::string d = argv[2], prefix = argv[3];
     const int level = argc > 4 ? atoi(argv[4]) : 1;
-    int threads = argc > 5 ? atoi(argv[5]) : tbh::cpu_budget();
+    int threads = argc > 5 && atoi(argv[5]) > 0 ? atoi(argv[5]) : tbh::cpu_budget();
+    // "seq": every record carries SEQ / QUAL of its query length and the aux tags of an aligner's output, about 250 bytes per
+    // 100-bp read like the reference's fixtures (test/t1/t1s0.bam) — what BGZF inflate / deflate and the tagging really move
+    const bool with_seq = argc > 6 && strcmp(argv[6], "seq") == 0;
     std::vector<uint32_t> file_off, cig_off, cig;
     std::vector<int32_t> tid, pos, nh;
     std::vector<uint16_t> flag;
@@ -203,13 +206,19 @@ int main(int argc, char** argv) {
           char nm[40];
           const int nl = snprintf(nm, sizeof(nm), "r%u_%u", f, i - file_off[f]) + 1;
           const uint32_t c0 = cig_off[i], nc = cig_off[i + 1] - c0;
-          int64_t rl = 0;
+          int64_t rl = 0, ql = 0;
           for (uint32_t q = 0; q < nc; ++q) {
             const uint32_t op = cig[c0 + q] & 0xF;
             if ((0x18Du >> op) & 1u) rl += cig[c0 + q] >> 4;
+            if ((0x193u >> op) & 1u) ql += cig[c0 + q] >> 4;  // M I S = X consume the query
           }
           const bool has_nh = nh[i] != INT32_MIN, has_xs = strand[i] == '+' || strand[i] == '-';
-          const uint32_t body = 32 + (uint32_t)nl + 4 * nc + (has_nh ? 4u : 0u) + (has_xs ? 4u : 0u);
+          const uint32_t lseq = with_seq ? (uint32_t)ql : 0u;
+          // AS XN XM XO XG NM as C-typed zeros, MD:Z:<ql>, YT:Z:UU — the tag set of the fixtures' aligner
+          char md[16];
+          const int mdl = with_seq ? snprintf(md, sizeof(md), "%lld", (long long)ql) + 1 : 0;
+          const uint32_t extra = with_seq ? 6u * 4u + 3u + (uint32_t)mdl + 6u : 0u;
+          const uint32_t body = 32 + (uint32_t)nl + 4 * nc + (lseq + 1) / 2 + lseq + extra + (has_nh ? 4u : 0u) + (has_xs ? 4u : 0u);
           const size_t o = buf.size();
           buf.resize(o + 4 + body);
           uint8_t* p = buf.data() + o;
@@ -223,13 +232,41 @@ int main(int argc, char** argv) {
           w16(14, pos[i] >= 0 ? reg2bin(pos[i], pos[i] + (rl > 1 ? rl : 1)) : (uint16_t)4680);
           w16(16, (uint16_t)nc);
           w16(18, flag[i]);
-          w32(20, 0);                   // l_seq
+          w32(20, lseq);                // l_seq
           w32(24, 0xFFFFFFFFu);         // next refID
           w32(28, 0xFFFFFFFFu);         // next pos
           w32(32, 0);                   // tlen
           memcpy(p + 36, nm, (size_t)nl);
           memcpy(p + 36 + nl, cig.data() + c0, 4 * (size_t)nc);
           uint8_t* a = p + 36 + nl + 4 * nc;
+          if (with_seq) {
+            uint64_t x = ((uint64_t)f << 40) ^ ((uint64_t)i * 0x9E3779B97F4A7C15ull) ^ 0xD1B54A32D192ED03ull;  // (deterministic per record)
+            auto rnd = [&]() {
+              x ^= x << 13, x ^= x >> 7, x ^= x << 17;
+              return x;
+            };
+            static const uint8_t nt[4] = {1, 2, 4, 8};  // A C G T
+            for (uint32_t b = 0; b < (lseq + 1) / 2; ++b) {
+              const uint64_t r = rnd();
+              a[b] = (uint8_t)((nt[r & 3] << 4) | ((2 * b + 1 < lseq) ? nt[(r >> 2) & 3] : 0));
+            }
+            a += (lseq + 1) / 2;
+            for (uint32_t b = 0; b < lseq; ++b) {  // Phred 40 with a dip every so often (a quality string deflates well, not to nothing)
+              const uint64_t r = rnd();
+              a[b] = (r & 15) == 0 ? (uint8_t)(20 + ((r >> 4) & 15)) : (uint8_t)40;
+            }
+            a += lseq;
+            static const char* zt[6] = {"AS", "XN", "XM", "XO", "XG", "NM"};
+            for (int z = 0; z < 6; ++z) {
+              a[0] = (uint8_t)zt[z][0], a[1] = (uint8_t)zt[z][1], a[2] = 'C', a[3] = 0;
+              a += 4;
+            }
+            a[0] = 'M', a[1] = 'D', a[2] = 'Z';
+            memcpy(a + 3, md, (size_t)mdl);
+            a += 3 + mdl;
+            memcpy(a, "YTZUU", 6);
+            a += 6;
+          }
           if (has_nh) {
             a[0] = 'N', a[1] = 'H', a[2] = 'C', a[3] = (uint8_t)nh[i];
             a += 4;

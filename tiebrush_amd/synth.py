@@ -229,7 +229,7 @@ def write_bams(tile: SoATile, prefix: str, level: int = 1):
     return paths
 
 
-def write_bams_fast(tile: SoATile, prefix: str, level: int = 1, threads: int = 0):
+def write_bams_fast(tile: SoATile, prefix: str, level: int = 1, threads: int = 0, seq: bool = False):
     """The same files as write_bams, encoded by the host tool (`tbh_tool mkbam`, C++, one file per worker thread): what the
     end-to-end leg of bench.py uses to lay down 32 x 1M-read inputs in seconds."""
     import os
@@ -244,7 +244,9 @@ def write_bams_fast(tile: SoATile, prefix: str, level: int = 1, threads: int = 0
             np.ascontiguousarray(getattr(tile, name), dtype=dt).tofile(os.path.join(d, name))
         with open(os.path.join(d, "header.txt"), "w") as fh:
             fh.write(header_text())
-        subprocess.run([tool, "mkbam", d, prefix, str(level)] + ([str(threads)] if threads else []), check=True)
+        # seq: SEQ / QUAL of the query length and an aligner's tag set on every record (about 250 bytes per 100-bp read, like the
+        # reference's fixtures) instead of the bare records ('*' SEQ) that keep the files small
+        subprocess.run([tool, "mkbam", d, prefix, str(level), str(threads or 0)] + (["seq"] if seq else []), check=True)
     finally:
         shutil.rmtree(d, ignore_errors=True)
     return ["%s%d.bam" % (prefix, f) for f in range(tile.n_files)]
