@@ -149,6 +149,7 @@ def main():
     ap.add_argument("--reads-per-file", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
+    ap.add_argument("--host-subtiles", type=int, default=10, help="sub-tiles the host -> host leg cuts the tile into (bundle boundaries)")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--e2e-files", type=int, default=32)
     ap.add_argument("--e2e-reads", type=int, default=1_000_000)
@@ -235,10 +236,14 @@ def main():
     # context takes the gate for its collapse and the other one's collapse always runs beside this one's YD + tiecov.
     gate = threading.Lock() if os.environ.get("TBK_BENCH_GATE", "1") != "0" else contextlib.nullcontext()
 
+    # group arrays: a quarter of the records (a call that needs more reports it, TBK_E2BIG, and is repeated with the need: the
+    # warm-up settles the size); one group per record, the capacity that can never overflow, was 15 GB per context on config 3
+    cap_groups = max(1 << 20, n_records // 4)
+
     def plain_step(cx, tile, cb, vb):
         cx.finish_yd()                                # (this context's previous YD stage: waited for outside the gate)
         with gate:
-            g = cx.collapse(tile, opts=opts_defer, want_coords=True, out=cb, raw=True)
+            g = cx.collapse(tile, opts=opts_defer, want_coords=True, out=cb, raw=True, cap_groups=cap_groups)
         view = cx.groups_to_cov_in(g)
         c = cx.coverage(view, out=vb, raw=True)
         return g, c
@@ -346,7 +351,7 @@ def main():
                 for i in range(k):
                     s = i & 1
                     free[s].acquire()                     # tile i - 2's rows have left this slot's buffers
-                    fins[s] = cl[s].collapse(dtile, opts=dctx["opts"], want_coords=True, want_effend=True, out=dctx["lbufs"][s])
+                    fins[s] = cl[s].collapse(dtile, opts=dctx["opts"], want_coords=True, want_effend=True, out=dctx["lbufs"][s], cap_groups=cap_groups)
                     if i > 0:
                         cl[s ^ 1].finish_yd()             # tile i - 1's YD ran beside tile i's window kernels
                         ready.put((i - 1, fins[s ^ 1]))
@@ -476,7 +481,7 @@ def main():
 
         for _ in range(args.prof_steps):   # the same calls as a timed step, one after the other: every kernel is measured with
             # the GPU to itself (in the timed loop the YD stage and the next tile's collapse run beside the tiecov chain)
-            gg = ctx.collapse(dtile, opts=opts_defer, want_coords=True, out=cbufs, raw=True)
+            gg = ctx.collapse(dtile, opts=opts_defer, want_coords=True, out=cbufs, raw=True, cap_groups=cap_groups)
             take("collapse")
             ctx.finish_yd()
             take("collapse")               # the deferred YD stage belongs to tbk_collapse_tile
@@ -541,48 +546,14 @@ def main():
         roof["gpu_kernel_ms_per_step_total"] = round(sum(tot.values()), 4)
         roof["step_frac_of_hbm_peak_algorithmic"] = round((b_collapse + b_cov) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4) if not use_dist else None
 
-    # ---- kernel path, pinned host -> pinned host: H2D of the SoA and D2H of every result inside the clock ----
+    # ---- kernel path, pinned host -> pinned host: H2D of the input and D2H of every result inside the clock ----
+    # The host hands the tile over the way the streaming reader cuts it (TInputFiles::next_tile: sub-tiles bounded by global bundle
+    # boundaries, nothing the collapse or tiecov computes crosses one), every sub-tile in the packed wire form (tbk_packed_in: 9
+    # bytes per record + the CIGAR words) in pinned memory.  Two contexts, a host thread each, take the sub-tiles in turn: the
+    # link carries sub-tile i + 1 in while sub-tile i is collapsed and covered and sub-tile i - 1's results go out.
     host_path = None
     if rank == 0 and not use_dist and not args.no_host_path:
-        names = ("tid", "pos", "flag", "mapq", "strand", "nh", "cig_off", "cig")
-        hin = {k: torch.empty(getattr(dtile, k).shape, dtype=getattr(dtile, k).dtype, pin_memory=True) for k in names}
-        for k in names:
-            hin[k].copy_(getattr(dtile, k))
-        torch.cuda.synchronize()
-        from dataclasses import replace
-        stage = replace(dtile, **{k: torch.empty_like(getattr(dtile, k)) for k in names})
-        hout = {}
-
-        def host_step():
-            for k in names:
-                getattr(stage, k).copy_(hin[k], non_blocking=True)
-            torch.cuda.current_stream().synchronize()
-            gq, cq = plain_step(ctx, stage, cbufs, vbufs)
-            ctx.finish_yd()
-            ng, ni, nj = gq["n_groups"], cq["n_intervals"], cq["n_junctions"]
-            outs = [(cbufs[k], ng) for k in ("rep", "yc", "yx", "yd", "g_start", "g_end")]
-            outs += [(vbufs[k], ni) for k in ("iv_tid", "iv_start", "iv_end", "iv_val")]
-            outs += [(vbufs[k], nj) for k in ("j_tid", "j_start", "j_end", "j_strand", "j_val")]
-            nbytes = 0
-            for i, (t, cnt) in enumerate(outs):
-                if i not in hout or hout[i].numel() < cnt:
-                    hout[i] = torch.empty(max(int(cnt * 1.1), 1), dtype=t.dtype, pin_memory=True)
-                hout[i][:cnt].copy_(t[:cnt], non_blocking=True)
-                nbytes += cnt * t.element_size()
-            torch.cuda.synchronize()
-            return gq["n_passed"], nbytes
-
-        host_step()
-        reps = 3
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            npass, out_bytes = host_step()
-        hdt = (time.perf_counter() - t1) / reps
-        in_bytes = sum(hin[k].numel() * hin[k].element_size() for k in names)
-        host_path = {"value": round(npass / hdt, 1), "unit": "records/s", "ms_per_step": round(hdt * 1e3, 3),
-                     "h2d_bytes": int(in_bytes), "d2h_bytes": int(out_bytes), "reps": reps,
-                     "note": "SoA in pinned host memory -> groups, intervals and junctions in pinned host memory; PCIe inside the clock"}
-        del hin, stage, hout
+        host_path = host_to_host_leg(args, torch, np, api, dtile, ctxs, opts_defer, last, cbufs, n_records, n_cig_in)
 
     # ---- CPU baseline: the oracle (literal single-threaded restatement of the reference) ----
     cpu = None
@@ -635,6 +606,142 @@ def main():
         except Exception:
             pass
         print(json.dumps(line), flush=True)
+
+
+def host_to_host_leg(args, torch, np, api, dtile, ctxs, opts_defer, last, cbufs, n_records, n_cig_in):
+    import threading
+    from dataclasses import replace
+
+    from tiebrush_amd.soa import PackedTile
+    K = max(1, args.host_subtiles)
+    dev = dtile.tid.device
+    # -- sub-tile cuts at bundle boundaries of the collapsed groups (every record of config 3 passes the filters): from the resident
+    #    run's own output — reference id and start from g_key, ends from g_end.  Outside the clock: the reader cuts while it decodes.
+    g0 = next(x for x in last if x is not None)[0]
+    ng = g0["n_groups"]
+    bufs = g0["_bufs"]
+    k0 = bufs["g_key"][:2 * ng].view(-1, 2)[:, 0]
+    gtid = (k0 >> 33) & 0x7FFFFFFF                                  # tid + 1
+    gstart = (k0 >> 2) & 0x7FFFFFFF                                 # 1-based start
+    skey = (gtid << 32) | gstart
+    ekey = (gtid << 32) | bufs["g_end"][:ng].to(torch.int64)
+    reach = torch.cummax(ekey, 0).values
+    isb = torch.ones(ng, dtype=torch.bool, device=dev)
+    isb[1:] = skey[1:] > reach[:-1]                                 # a group that starts beyond every earlier end opens a bundle
+    bidx = torch.nonzero(isb).view(-1)
+    want = (torch.arange(1, K, device=dev, dtype=torch.int64) * ng) // K
+    pick = bidx[torch.searchsorted(bidx, want).clamp(max=bidx.numel() - 1)] if K > 1 else want
+    cut_keys = [int(x) for x in torch.unique(skey[pick]).tolist()] if K > 1 else []   # (tid + 1) << 32 | 1-based start
+    del skey, ekey, reach, isb, bidx
+    rkey = ((dtile.tid.to(torch.int64) + 1) << 32) | (dtile.pos.to(torch.int64) + 1)
+    fo = np.asarray(dtile.file_off, np.int64)
+    nf = dtile.n_files
+    ck = torch.tensor(cut_keys, dtype=torch.int64, device=dev)
+    bounds = np.zeros((nf, len(cut_keys) + 2), np.int64)            # per file: record index of every cut
+    for f in range(nf):
+        bounds[f, 0], bounds[f, -1] = fo[f], fo[f + 1]
+        if len(cut_keys):
+            bounds[f, 1:-1] = fo[f] + torch.searchsorted(rkey[int(fo[f]):int(fo[f + 1])], ck).cpu().numpy()
+    del rkey
+    co = dtile.cig_off.to(torch.int64) & 0xFFFFFFFF
+    pin = lambda t: torch.empty(t.shape, dtype=t.dtype, pin_memory=True).copy_(t)
+    subs, in_bytes = [], 0
+    for j in range(bounds.shape[1] - 1):                            # the packed form of sub-tile j, laid out on the device, then pinned
+        rng = [(int(bounds[f, j]), int(bounds[f, j + 1])) for f in range(nf)]
+        cat = lambda t: torch.cat([t[a:b] for a, b in rng])
+        sfo = np.concatenate([[0], np.cumsum([b - a for a, b in rng])]).astype(np.uint32)
+        tid = cat(dtile.tid)
+        n = int(tid.numel())
+        if n == 0:
+            continue
+        st = cat(dtile.strand).to(torch.int64)
+        sc = torch.where(st == 43, 0, torch.where(st == 45, 1, 2))
+        nh = cat(dtile.nh).to(torch.int64)
+        assert int(nh.min()) >= 0 and int(nh.max()) <= 1021         # (the synthetic profiles: every NH in range, none absent)
+        meta = ((cat(dtile.flag).to(torch.int64) & 0xFFF) | (sc << 12) | (cat(dtile.mapq).to(torch.int64) << 14) | (nh << 22)).to(torch.int32)
+        ncig = torch.cat([co[a + 1:b + 1] - co[a:b] for a, b in rng])
+        assert int(ncig.max()) < 255
+        cig = torch.cat([dtile.cig[int(co[a]):int(co[b])] for a, b in rng])
+        brk = torch.ones(n, dtype=torch.bool, device=dev)
+        brk[1:] = tid[1:] != tid[:-1]
+        brk[torch.from_numpy(sfo[:-1][sfo[:-1] < n].astype(np.int64)).to(dev)] = True
+        starts = torch.nonzero(brk).view(-1)
+        pt = PackedTile(n_files=nf, file_off=sfo, tid_run_end=torch.cat([starts[1:], torch.tensor([n], device=dev)]).cpu().numpy().astype(np.uint32),
+                        tid_run_tid=tid[starts].cpu().numpy().astype(np.int32), pos=pin(cat(dtile.pos)), meta=pin(meta), ncig=pin(ncig.to(torch.uint8)),
+                        cig=pin(cig), nh_esc_idx=np.zeros(0, np.uint32), nh_esc_val=np.zeros(0, np.int32), ncig_esc_idx=np.zeros(0, np.uint32),
+                        ncig_esc_val=np.zeros(0, np.uint32))
+        in_bytes += sum(int(t.numel()) * t.element_size() for t in (pt.pos, pt.meta, pt.ncig, pt.cig)) + pt.tid_run_end.nbytes * 2
+        subs.append(pt)
+        del tid, st, sc, nh, meta, ncig, cig, brk
+    torch.cuda.synchronize()
+    NC = len(ctxs)
+    cb2, vb2, hout = [{} for _ in range(NC)], [{} for _ in range(NC)], [dict() for _ in range(NC)]
+    capg = max(1 << 20, max(p.n_records for p in subs) // 4)
+    totals = {"passed": 0, "groups": 0, "iv": 0, "j": 0, "out_bytes": 0}
+    lock = threading.Lock()
+
+    def run_all():
+        errs = []
+        for kk in totals:
+            totals[kk] = 0
+
+        def worker(i):
+            torch.cuda.set_device(dev)
+            cx = ctxs[i]
+            try:
+                for j in range(i, len(subs), NC):
+                    t = cx.unpack_tile(subs[j])                     # H2D of the packed arrays + expansion on the device
+                    g = cx.collapse(t, opts=opts_defer, want_coords=True, out=cb2[i], raw=True, cap_groups=capg)
+                    view = cx.groups_to_cov_in(g)
+                    c = cx.coverage(view, out=vb2[i], raw=True)
+                    cx.finish_yd()
+                    ng_, ni, nj = g["n_groups"], c["n_intervals"], c["n_junctions"]
+                    outs = [(cb2[i][k_], ng_) for k_ in ("rep", "yc", "yx", "yd", "g_start", "g_end")]
+                    outs += [(vb2[i][k_], ni) for k_ in ("iv_tid", "iv_start", "iv_end", "iv_val")]
+                    outs += [(vb2[i][k_], nj) for k_ in ("j_tid", "j_start", "j_end", "j_strand", "j_val")]
+                    nb = 0
+                    for q, (tt, cnt) in enumerate(outs):
+                        if q not in hout[i] or hout[i][q].numel() < cnt:
+                            hout[i][q] = torch.empty(max(int(cnt * 1.2), 1), dtype=tt.dtype, pin_memory=True)
+                        hout[i][q][:cnt].copy_(tt[:cnt], non_blocking=True)
+                        nb += cnt * tt.element_size()
+                    torch.cuda.current_stream().synchronize()       # (this sub-tile's results are in host memory)
+                    with lock:
+                        totals["passed"] += g["n_passed"]
+                        totals["groups"] += ng_
+                        totals["iv"] += ni
+                        totals["j"] += nj
+                        totals["out_bytes"] += nb
+            except BaseException as e:
+                errs.append(e)
+
+        th = [threading.Thread(target=worker, args=(i,)) for i in range(NC)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        if errs:
+            raise errs[0]
+
+    run_all()                                                       # warm-up: arenas, unpack buffers, pinned result buffers
+    ref_g, ref_c = next(x for x in last if x is not None)
+    assert totals["passed"] == ref_g["n_passed"] and totals["groups"] == ref_g["n_groups"], "sub-tiles disagree with the one-tile run"
+    assert totals["iv"] == ref_c["n_intervals"] and totals["j"] == ref_c["n_junctions"], "sub-tiles disagree with the one-tile run (tiecov)"
+    reps = 3
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        run_all()
+    torch.cuda.synchronize()
+    hdt = (time.perf_counter() - t1) / reps
+    soa_bytes = n_records * 20 + 4 + 4 * n_cig_in
+    return {"value": round(totals["passed"] / hdt, 1), "unit": "records/s", "ms_per_step": round(hdt * 1e3, 3), "h2d_bytes": int(in_bytes),
+            "d2h_bytes": int(totals["out_bytes"]), "reps": reps, "sub_tiles": len(subs), "contexts": NC,
+            "h2d_bytes_as_soa": int(soa_bytes), "link_gb_per_s": round((in_bytes + totals["out_bytes"]) / hdt / 1e9, 1),
+            "note": "the tile as %d sub-tiles cut at bundle boundaries (what the streaming reader hands over), each in the packed wire form "
+                    "(tbk_packed_in: 9 B per record + CIGAR words) in pinned host memory -> groups, intervals and junctions of every sub-tile in "
+                    "pinned host memory; H2D, expansion, collapse, tiecov and D2H inside the clock, two contexts overlapping transfer and compute; "
+                    "totals checked against the one-tile run" % len(subs)}
 
 
 def cpu_baseline(args, profile, files, dtile, ctx, strat, n_records):

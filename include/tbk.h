@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TBK_ABI_VERSION 4
+#define TBK_ABI_VERSION 5
 
 typedef struct tbk_ctx tbk_ctx;
 
@@ -250,6 +250,35 @@ int tbk_bam_decode(tbk_ctx* ctx, uint32_t n_files, const uint8_t* const* comp, c
  * order into `out` (host); out_off[n + 1] (host) = their byte offsets.  TBK_E2BIG with out_off[n] = needed bytes. */
 int tbk_bam_records(tbk_ctx* ctx, const uint32_t* idx, uint32_t n, int idx_mem, uint8_t* out, uint64_t out_cap, uint64_t* out_off);
 void tbk_bam_release(tbk_ctx* ctx);
+
+/* ---- Packed wire form of a tile (ABI version 5) ---------------------------------------------------------------------------
+ * What a host decoder can hand over instead of tbk_soa_in when the tile has to cross PCIe: the same records in 9 bytes plus the
+ * CIGAR words instead of 20 plus the CIGAR words (the link, not the GPU, paces the host -> host path).  Every pointer is HOST
+ * memory (pinned with tbk_host_alloc for full link speed).  Plain inputs only (no TieBrush-merged file, no MD, no names). */
+typedef struct tbk_packed_in {
+  uint32_t n_files;
+  uint32_t n_records;
+  uint32_t n_cigar_ops;
+  uint32_t n_tid_runs;
+  const uint32_t* file_off;     /* [n_files + 1], as in tbk_soa_in                                                   */
+  const uint32_t* tid_run_end;  /* [n_tid_runs] ascending, last == n_records: records [tid_run_end[r - 1], tid_run_end[r])
+                                   share tid_run_tid[r] (a coordinate-sorted file changes its refID a few times)       */
+  const int32_t* tid_run_tid;   /* [n_tid_runs]                                                                      */
+  const int32_t* pos;           /* [n_records]                                                                       */
+  const uint32_t* meta;         /* [n_records] flag : 12 | strand ('+' 0, '-' 1, '.' 2) : 2 | mapq : 8 | NH code : 10
+                                   (NH 0 .. 1021 as it is, 1022 = no NH tag, 1023 = see nh_esc_*)                      */
+  const uint8_t* ncig;          /* [n_records] number of CIGAR operations, 255 = see ncig_esc_*                       */
+  const uint32_t* cig;          /* [n_cigar_ops] BAM encoding, record after record                                    */
+  uint32_t n_nh_esc, n_ncig_esc;
+  const uint32_t* nh_esc_idx;   /* records whose NH is outside 0 .. 1021                                              */
+  const int32_t* nh_esc_val;
+  const uint32_t* ncig_esc_idx; /* records with 255 CIGAR operations or more                                          */
+  const uint32_t* ncig_esc_val;
+} tbk_packed_in;
+/* Copies the packed arrays to the device and rebuilds the structure of arrays there: *tile describes a DEVICE-resident tile in
+ * context-owned memory (valid until the next tbk_unpack_tile on `ctx` or tbk_destroy; tile->file_off is in->file_off), ready for
+ * tbk_collapse_tile.  TBK_EINVAL when the counts are inconsistent. */
+int tbk_unpack_tile(tbk_ctx* ctx, const tbk_packed_in* in, tbk_soa_in* tile);
 
 /* ---- Multi-GPU: shuffle, then collapse (the reference has no counterpart — its only parallelism is
  * tiewrap.py:96-126, batches of files re-collapsed hierarchically).  Every rank holds some input files; the ranks agree

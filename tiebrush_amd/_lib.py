@@ -23,7 +23,7 @@ SYMBOLS = ["tbk_abi_version", "tbk_create", "tbk_destroy", "tbk_strerror", "tbk_
            "tbk_get_stream", "tbk_set_profiling", "tbk_kernel_times", "tbk_host_alloc", "tbk_host_free",
            "tbk_collapse_opts_default", "tbk_collapse_tile", "tbk_collapse_finish_yd", "tbk_coverage_tile", "tbk_sample_tile",
            "tbk_groups_to_cov_in", "tbk_bgzf_inflate", "tbk_bam_decode", "tbk_bam_records", "tbk_bam_release", "tbk_shard_prepare", "tbk_shard_probe_max", "tbk_shard_probe_next",
-           "tbk_shard_pack", "tbk_shard_unpack", "tbk_partial_keys", "tbk_partial_pack", "tbk_partial_unpack", "tbk_partial_reduce"]
+           "tbk_shard_pack", "tbk_shard_unpack", "tbk_partial_keys", "tbk_partial_pack", "tbk_partial_unpack", "tbk_partial_reduce", "tbk_unpack_tile"]
 
 
 class CollapseOpts(C.Structure):
@@ -38,6 +38,12 @@ class SoaIn(C.Structure):
                 ("strand", _P), ("nh", _P), ("cig_off", _P), ("cig", _P), ("yc_in", _P), ("yx_in", _P), ("yd_in", _P),
                 ("md_off", _P), ("md", _P), ("md_has", _P), ("qname_hash", _P), ("prio_hi", _P), ("prio_lo", _P),
                 ("qname_off", _P), ("qname", _P)]
+
+
+class PackedIn(C.Structure):
+    _fields_ = [("n_files", C.c_uint32), ("n_records", C.c_uint32), ("n_cigar_ops", C.c_uint32), ("n_tid_runs", C.c_uint32), ("file_off", _P),
+                ("tid_run_end", _P), ("tid_run_tid", _P), ("pos", _P), ("meta", _P), ("ncig", _P), ("cig", _P), ("n_nh_esc", C.c_uint32),
+                ("n_ncig_esc", C.c_uint32), ("nh_esc_idx", _P), ("nh_esc_val", _P), ("ncig_esc_idx", _P), ("ncig_esc_val", _P)]
 
 
 class GroupsOut(C.Structure):
@@ -124,6 +130,7 @@ def load():
     L.tbk_partial_pack.argtypes = [_P, C.POINTER(CollapseOpts), C.POINTER(SoaIn), C.POINTER(GroupsOut), _P, _P, C.c_uint32, C.c_uint32, _P, _P, _P]
     L.tbk_partial_reduce.argtypes = [_P, C.POINTER(CollapseOpts), _P, C.c_uint32, _P, C.c_uint32, _P, C.POINTER(GroupsOut), C.POINTER(CovIn)]
     L.tbk_partial_unpack.argtypes = [_P, _P, C.c_uint32] + [_P] * 12
+    L.tbk_unpack_tile.argtypes = [_P, C.POINTER(PackedIn), C.POINTER(SoaIn)]
     _lib = L
     return L
 

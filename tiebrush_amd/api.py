@@ -85,6 +85,14 @@ def _numel(a):
     return int(a.numel()) if _is_torch(a) else int(np.asarray(a).size)
 
 
+class DeviceTile:
+    """a tile living in context-owned device memory (tbk_unpack_tile): goes to collapse() like a SoATile"""
+
+    def __init__(self, struct, n_files, keep):
+        self.struct, self.n_files, self._keep = struct, n_files, keep
+        self.n_records = int(struct.n_records)
+
+
 class DeviceCovView:
     """tbk_cov_in view living in context-owned device memory (valid until the next call)."""
 
@@ -179,7 +187,33 @@ class Context:
         """Wait for a deferred YD stage (collapse(..., defer_yd=True)); the `yd` array is complete afterwards."""
         self._check(self.L.tbk_collapse_finish_yd(self.h), "tbk_collapse_finish_yd")
 
+    def unpack_tile(self, pt) -> DeviceTile:
+        """tbk_unpack_tile: a soa.PackedTile (numpy, or torch tensors in pinned host memory) -> the tile on the device"""
+        keep = []
+
+        def addr(a, dt):
+            if _is_torch(a):
+                keep.append(a)
+                return a.data_ptr() if a.numel() else None
+            b = np.ascontiguousarray(a, dtype=dt)
+            keep.append(b)
+            return b.ctypes.data if b.size else None
+
+        fo = np.ascontiguousarray(pt.file_off, dtype=np.uint32)
+        re_, rt = np.ascontiguousarray(pt.tid_run_end, np.uint32), np.ascontiguousarray(pt.tid_run_tid, np.int32)
+        keep += [fo, re_, rt]
+        p = _lib.PackedIn(pt.n_files, _numel(pt.pos), _numel(pt.cig), len(re_), fo.ctypes.data, re_.ctypes.data, rt.ctypes.data, addr(pt.pos, np.int32),
+                          addr(pt.meta, np.uint32), addr(pt.ncig, np.uint8), addr(pt.cig, np.uint32), _numel(pt.nh_esc_idx), _numel(pt.ncig_esc_idx),
+                          addr(pt.nh_esc_idx, np.uint32), addr(pt.nh_esc_val, np.int32), addr(pt.ncig_esc_idx, np.uint32),
+                          addr(pt.ncig_esc_val, np.uint32))
+        s = _lib.SoaIn()
+        self._check(self.L.tbk_unpack_tile(self.h, C.byref(p), C.byref(s)), "tbk_unpack_tile")
+        return DeviceTile(s, pt.n_files, keep)
+
     def _soa_struct(self, tile: SoATile, keep):
+        if isinstance(tile, DeviceTile):
+            keep.append(tile)
+            return tile.struct, True, tile.n_records
         dev = _is_torch(tile.tid)
         n = _numel(tile.tid)
         nc = _numel(tile.cig)
@@ -199,7 +233,7 @@ class Context:
         return s, dev, n
 
     def collapse(self, tile: SoATile, opts=None, want_coords=True, want_rec_group=False, want_effend=False, out=None,
-                 raw=False, want_key=None, **kw):
+                 raw=False, want_key=None, cap_groups=None, **kw):
         """Collapse one tile.  Returns a dict (rep, yc, yx, yd[, g_start, g_end, rec_group, g_key], n_groups,
         n_passed) in the reference's output order.  `out` may carry preallocated buffers to reuse.
         want_key (default: device tiles): tbk_groups_out.g_key — groups_to_cov_in then builds the tiecov input of the
@@ -208,8 +242,21 @@ class Context:
         keep = []
         s, dev, n = self._soa_struct(tile, keep)
         self._order_after_torch(dev)
-        cap = max(n, 1)
+        # capacity of the group arrays: one group per record can never overflow (the default); a caller that knows its data
+        # collapses (cap_groups, e.g. a quarter of the records) saves the memory, and a call that needs more says how many
+        # (TBK_E2BIG with n_groups = the need) and is repeated once with that
+        cap = max(n if cap_groups is None else min(int(cap_groups), n), 1)
         bufs = out if out is not None else {}
+        if bufs.get("_cap_groups", 0) > cap:
+            cap = bufs["_cap_groups"]
+        res = self._collapse_once(o, s, dev, n, cap, bufs, keep, want_coords, want_rec_group, want_effend, want_key, raw)
+        if isinstance(res, int):                    # TBK_E2BIG: res groups are needed
+            bufs["_cap_groups"] = cap = min(n, res + res // 16 + 1)
+            res = self._collapse_once(o, s, dev, n, cap, bufs, keep, want_coords, want_rec_group, want_effend, want_key, raw)
+            assert not isinstance(res, int)
+        return res
+
+    def _collapse_once(self, o, s, dev, n, cap, bufs, keep, want_coords, want_rec_group, want_effend, want_key, raw):
 
         def buf(name, count, dt, wanted=True):
             if not wanted:
@@ -221,7 +268,7 @@ class Context:
         rep, yc = buf("rep", cap, np.uint32), buf("yc", cap, np.float64)
         yx, yd = buf("yx", cap, np.int64), buf("yd", cap, np.int32)
         gs, ge = buf("g_start", cap, np.int32, want_coords), buf("g_end", cap, np.int32, want_coords)
-        rg = buf("rec_group", cap, np.int32, want_rec_group)
+        rg = buf("rec_group", max(n, 1), np.int32, want_rec_group)
         re_ = buf("rep_effend", cap, np.int32, want_effend)
         want_key = bool(dev) if want_key is None else want_key
         gk = buf("g_key", 2 * cap, np.uint64, want_key)
@@ -229,7 +276,10 @@ class Context:
                            _addr(yx, np.int64, keep), _addr(yd, np.int32, keep), _addr(gs, np.int32, keep),
                            _addr(ge, np.int32, keep), _addr(rg, np.int32, keep), _addr(re_, np.int32, keep),
                            _addr(gk, np.uint64, keep), 0, 0)
-        self._check(self.L.tbk_collapse_tile(self.h, C.byref(o), C.byref(s), C.byref(g)), "tbk_collapse_tile")
+        rc = self.L.tbk_collapse_tile(self.h, C.byref(o), C.byref(s), C.byref(g))
+        if rc == -4 and int(g.n_groups) > cap:      # TBK_E2BIG on the group arrays: the call reported the need
+            return int(g.n_groups)
+        self._check(rc, "tbk_collapse_tile")
         m = int(g.n_groups)
         res = dict(n_groups=m, n_passed=int(g.n_passed), _bufs=bufs, _struct=g, _soa=s, _keep=keep)
         if raw:

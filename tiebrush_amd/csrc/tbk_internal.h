@@ -131,6 +131,9 @@ struct tbk_ctx {
   TbkWorker* side_worker = nullptr;
   bool side_times_pending = false;
   std::vector<void*> registered; // caller's host ranges page-locked for the copies of the current call (tbk_api.hip: host_register)
+  char* d_unpack = nullptr;      // the tile tbk_unpack_tile rebuilt from its packed wire form (pack.hip)
+  size_t d_unpack_cap = 0;
+  std::vector<uint8_t> unpack_tbm;
   void* bam_dev = nullptr;       // device-decoded BAM input (bamdev.hip): inflated streams + record index + the SoA tile's arrays
 };
 

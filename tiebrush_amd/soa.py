@@ -138,3 +138,62 @@ def cov_input_from_bam(b) -> CovInput:
     return CovInput(tid=b.tid.astype(np.int32), pos=b.pos.astype(np.int32), flag=b.flag.astype(np.uint16),
                     cig_off=b.cig_off.astype(np.uint32), cig=b.cig.astype(np.uint32), yc=yc,
                     strand=b.strand.astype(np.uint8), yx=b.yx.astype(np.int64))
+
+
+@dataclass
+class PackedTile:
+    """mirror of tbk_packed_in (include/tbk.h): the wire form of a plain tile — 9 bytes per record + the CIGAR words"""
+    n_files: int
+    file_off: np.ndarray       # uint32 [n_files + 1]
+    tid_run_end: np.ndarray    # uint32
+    tid_run_tid: np.ndarray    # int32
+    pos: np.ndarray            # int32
+    meta: np.ndarray           # uint32: flag : 12 | strand code : 2 | mapq : 8 | NH code : 10
+    ncig: np.ndarray           # uint8
+    cig: np.ndarray            # uint32
+    nh_esc_idx: np.ndarray
+    nh_esc_val: np.ndarray
+    ncig_esc_idx: np.ndarray
+    ncig_esc_val: np.ndarray
+
+    @property
+    def n_records(self) -> int:
+        return int(self.pos.shape[0])
+
+    def nbytes(self) -> int:
+        return sum(int(a.nbytes) for a in (self.pos, self.meta, self.ncig, self.cig, self.tid_run_end, self.tid_run_tid, self.nh_esc_idx,
+                                           self.nh_esc_val, self.ncig_esc_idx, self.ncig_esc_val))
+
+
+def pack_tile(tile: SoATile) -> PackedTile:
+    """host-side packer (numpy restatement of what a decoder emits): refuses what the wire form does not carry"""
+    if np.any(tile.tbmerged) or tile.md_off is not None or tile.prio_hi is not None:
+        raise ValueError("only plain tiles have a packed form")
+    flag = np.asarray(tile.flag).astype(np.uint32)
+    if np.any(flag >> 12):
+        raise ValueError("flag bits beyond 0xFFF")
+    st = np.asarray(tile.strand)
+    sc = np.where(st == ord("+"), 0, np.where(st == ord("-"), 1, 2)).astype(np.uint32)
+    if np.any((st != ord("+")) & (st != ord("-")) & (st != ord("."))):
+        raise ValueError("strand other than + - .")
+    nh = np.asarray(tile.nh).astype(np.int64)
+    absent = nh == NH_ABSENT
+    esc = ~absent & ((nh < 0) | (nh > 1021))
+    code = np.where(absent, 1022, np.where(esc, 1023, nh)).astype(np.uint32)
+    meta = flag | (sc << 12) | (np.asarray(tile.mapq).astype(np.uint32) << 14) | (code << 22)
+    cnt = np.diff(np.asarray(tile.cig_off).astype(np.int64))
+    big = cnt >= 255
+    tid = np.asarray(tile.tid)
+    n = tile.n_records
+    # runs of equal tid; a run never spans two files
+    brk = np.ones(n, bool)
+    if n:
+        brk[1:] = tid[1:] != tid[:-1]
+        brk[np.asarray(tile.file_off[:-1])[np.asarray(tile.file_off[:-1]) < n]] = True
+    starts = np.nonzero(brk)[0]
+    run_end = np.concatenate([starts[1:], [n]]).astype(np.uint32) if n else np.array([0], np.uint32)
+    run_tid = tid[starts].astype(np.int32) if n else np.array([-1], np.int32)
+    return PackedTile(n_files=tile.n_files, file_off=np.asarray(tile.file_off, np.uint32), tid_run_end=run_end, tid_run_tid=run_tid,
+                      pos=np.ascontiguousarray(tile.pos, np.int32), meta=meta.astype(np.uint32), ncig=np.where(big, 255, cnt).astype(np.uint8),
+                      cig=np.ascontiguousarray(tile.cig, np.uint32), nh_esc_idx=np.nonzero(esc)[0].astype(np.uint32),
+                      nh_esc_val=nh[esc].astype(np.int32), ncig_esc_idx=np.nonzero(big)[0].astype(np.uint32), ncig_esc_val=cnt[big].astype(np.uint32))

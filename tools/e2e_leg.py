@@ -57,7 +57,7 @@ def leg(files, reads, profile, flags, seq, runs, device_decode, desc):
                "input_bam_bytes": in_bytes, "input_bytes_per_record": round(in_bytes / n, 1),
                "output_bam_bytes": os.path.getsize(out), "summary": summary,
                "phases": [l for l in r.stderr.split("\n") if l.startswith("host path") or l.startswith("writer closed") or l.startswith("released")
-                          or l.startswith("timing ms") or l.startswith("tiles:")][-4:],
+                          or l.startswith("timing ms") or l.startswith("tiles:")][-5:],
                "generation_s": round(t_gen, 1)}
         if device_decode:
             th, _ = run({"TBK_DEVICE_DECODE": "1"}, 1)
@@ -82,7 +82,7 @@ def main():
         # the same command line on records that carry SEQ / QUAL and an aligner's tags (about 240 inflated bytes per record, like the
         # reference's fixtures: what BGZF and the tagging really move), and with config 3's options on config 3's read model
         k2 = max(1, a.runs - 1)
-        res["seq"] = leg(a.files, a.reads, a.profile, [], True, k2, False,
+        res["seq"] = leg(a.files, a.reads, a.profile, [], True, k2, True,
                          "%d files x %d reads (config-2 read model) WITH 100-bp SEQ / QUAL and aligner tags, default collapse")
         res["c3_options"] = leg(2 * a.files, max(1, a.reads // 2), "c3", ["--clip"], False, k2, False,
                                 "%d files x %d reads (config-3 read model: 10 %% soft-clipped, records without SEQ), --clip")
