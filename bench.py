@@ -149,7 +149,8 @@ def main():
     ap.add_argument("--reads-per-file", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
-    ap.add_argument("--host-subtiles", type=int, default=10, help="sub-tiles the host -> host leg cuts the tile into (bundle boundaries)")
+    ap.add_argument("--host-subtiles", type=int, default=12, help="sub-tiles the host -> host leg cuts the tile into (bundle boundaries)")
+    ap.add_argument("--host-contexts", type=int, default=3, help="contexts (a host thread each) of the host -> host leg")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--e2e-files", type=int, default=32)
     ap.add_argument("--e2e-reads", type=int, default=1_000_000)
@@ -553,7 +554,7 @@ def main():
     # link carries sub-tile i + 1 in while sub-tile i is collapsed and covered and sub-tile i - 1's results go out.
     host_path = None
     if rank == 0 and not use_dist and not args.no_host_path:
-        host_path = host_to_host_leg(args, torch, np, api, dtile, ctxs, opts_defer, last, cbufs, n_records, n_cig_in)
+        host_path = host_to_host_leg(args, torch, np, api, dtile, strat, last, n_records, n_cig_in)
 
     # ---- CPU baseline: the oracle (literal single-threaded restatement of the reference) ----
     cpu = None
@@ -608,7 +609,7 @@ def main():
         print(json.dumps(line), flush=True)
 
 
-def host_to_host_leg(args, torch, np, api, dtile, ctxs, opts_defer, last, cbufs, n_records, n_cig_in):
+def host_to_host_leg(args, torch, np, api, dtile, strat, last, n_records, n_cig_in):
     import threading
     from dataclasses import replace
 
@@ -674,11 +675,16 @@ def host_to_host_leg(args, torch, np, api, dtile, ctxs, opts_defer, last, cbufs,
         subs.append(pt)
         del tid, st, sc, nh, meta, ncig, cig, brk
     torch.cuda.synchronize()
-    NC = len(ctxs)
+    # contexts of the leg's own (arenas sized by a sub-tile, not by the tile): one more than two keeps a sub-tile ready for the link
+    # whenever it comes free
+    NC = max(1, args.host_contexts)
+    ctxs = [api.Context(dev.index) for _ in range(NC)]
+    opts_defer = ctxs[0].make_opts(defer_yd=True, **strat)
     cb2, vb2, hout = [{} for _ in range(NC)], [{} for _ in range(NC)], [dict() for _ in range(NC)]
     capg = max(1 << 20, max(p.n_records for p in subs) // 4)
-    totals = {"passed": 0, "groups": 0, "iv": 0, "j": 0, "out_bytes": 0}
+    totals = {"passed": 0, "groups": 0, "iv": 0, "j": 0, "out_bytes": 0, "t_h2d": 0.0, "t_compute": 0.0, "t_d2h": 0.0}
     lock = threading.Lock()
+    link = threading.Lock()
 
     def run_all():
         errs = []
@@ -690,11 +696,15 @@ def host_to_host_leg(args, torch, np, api, dtile, ctxs, opts_defer, last, cbufs,
             cx = ctxs[i]
             try:
                 for j in range(i, len(subs), NC):
-                    t = cx.unpack_tile(subs[j])                     # H2D of the packed arrays + expansion on the device
+                    ta = time.perf_counter()
+                    with link:                                      # one sub-tile on the link at a time, at its full rate: the contexts fall
+                        t = cx.unpack_tile(subs[j])                 # out of step (two copies side by side finish together and leave the link
+                    tb_ = time.perf_counter()                       # idle while both compute); H2D of the packed arrays + expansion
                     g = cx.collapse(t, opts=opts_defer, want_coords=True, out=cb2[i], raw=True, cap_groups=capg)
                     view = cx.groups_to_cov_in(g)
                     c = cx.coverage(view, out=vb2[i], raw=True)
                     cx.finish_yd()
+                    tc_ = time.perf_counter()
                     ng_, ni, nj = g["n_groups"], c["n_intervals"], c["n_junctions"]
                     outs = [(cb2[i][k_], ng_) for k_ in ("rep", "yc", "yx", "yd", "g_start", "g_end")]
                     outs += [(vb2[i][k_], ni) for k_ in ("iv_tid", "iv_start", "iv_end", "iv_val")]
@@ -706,7 +716,11 @@ def host_to_host_leg(args, torch, np, api, dtile, ctxs, opts_defer, last, cbufs,
                         hout[i][q][:cnt].copy_(tt[:cnt], non_blocking=True)
                         nb += cnt * tt.element_size()
                     torch.cuda.current_stream().synchronize()       # (this sub-tile's results are in host memory)
+                    td_ = time.perf_counter()
                     with lock:
+                        totals["t_h2d"] += tb_ - ta
+                        totals["t_compute"] += tc_ - tb_
+                        totals["t_d2h"] += td_ - tc_
                         totals["passed"] += g["n_passed"]
                         totals["groups"] += ng_
                         totals["iv"] += ni
@@ -734,10 +748,15 @@ def host_to_host_leg(args, torch, np, api, dtile, ctxs, opts_defer, last, cbufs,
         run_all()
     torch.cuda.synchronize()
     hdt = (time.perf_counter() - t1) / reps
+    for cx in ctxs:
+        cx.close()
     soa_bytes = n_records * 20 + 4 + 4 * n_cig_in
     return {"value": round(totals["passed"] / hdt, 1), "unit": "records/s", "ms_per_step": round(hdt * 1e3, 3), "h2d_bytes": int(in_bytes),
             "d2h_bytes": int(totals["out_bytes"]), "reps": reps, "sub_tiles": len(subs), "contexts": NC,
             "h2d_bytes_as_soa": int(soa_bytes), "link_gb_per_s": round((in_bytes + totals["out_bytes"]) / hdt / 1e9, 1),
+            "host_wall_ms_summed_over_sub_tiles": {"unpack (H2D + expansion)": round(totals["t_h2d"] * 1e3, 1),
+                                                   "collapse + tiecov + YD": round(totals["t_compute"] * 1e3, 1),
+                                                   "results D2H": round(totals["t_d2h"] * 1e3, 1)},
             "note": "the tile as %d sub-tiles cut at bundle boundaries (what the streaming reader hands over), each in the packed wire form "
                     "(tbk_packed_in: 9 B per record + CIGAR words) in pinned host memory -> groups, intervals and junctions of every sub-tile in "
                     "pinned host memory; H2D, expansion, collapse, tiecov and D2H inside the clock, two contexts overlapping transfer and compute; "

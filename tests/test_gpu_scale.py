@@ -209,6 +209,19 @@ def test_properties_per_rank_shapes_config4_config5(ctx, files, reads, profile, 
     torch.cuda.empty_cache()
 
 
+def test_properties_config4_full_256x2M_one_gpu(ctx):
+    """BASELINE.json configs[3] as ONE job on one GPU (512 M records, 256 input files: more than 64, so the window path lists
+    (group, sample) incidences and the YD items take the radix split) — the N = 1 end of the strong-scaling workload
+    (`bench.py --gpus 1 --profile c4 --scaling strong`)."""
+    import torch
+    from tiebrush_amd import synth_dev
+    tile = synth_dev.make_tile_device(256, 2_000_000, "c2", device="cuda:0")
+    g, ni = _properties(ctx, tile)
+    assert 0 < g < tile.n_records
+    del tile
+    torch.cuda.empty_cache()
+
+
 def test_device_generator_matches_host_model(ctx):
     """synth_dev on the GPU == synth_dev on the CPU (counter-based integer stream), and the tile is oracle-exact."""
     from tiebrush_amd import synth_dev
