@@ -87,13 +87,38 @@ __global__ void wg_split_k(const uint64_t* __restrict__ Y, uint32_t g, uint32_t 
 __device__ __forceinline__ uint64_t raw_key(int tid, int pos) {
   return tid < 0 ? (1ull << 62) : (((uint64_t)(uint32_t)tid << 31) | ((uint32_t)pos & 0x7FFFFFFFu));
 }
-__global__ void wg_sample_raw_k(const int32_t* __restrict__ tid, const int32_t* __restrict__ pos, uint32_t n, uint32_t s, uint32_t ns,
-                                uint64_t* __restrict__ shi) {
+// The partition (sampling, then the offsets pass) streams the (tid, pos) pairs twice, and in a coordinate-sorted file the reference
+// id changes a handful of times: ctid[c] is the id every record of chunk c (WG_TC consecutive records) carries when the chunk lies
+// inside one file and its first and last record agree — then so does everything between them, PROVIDED the file is sorted, which the
+// window kernels check record by record against the ids as they are (wg_hash_window: a record before its predecessor raises
+// TBK_DERR_RAWORDER) — and WG_TC_MIXED otherwise (the partition then reads the ids of that chunk).  Two loads per 4096 records
+// instead of 4096: the partition reads 1.3 GB of positions twice instead of 2.6 GB of pairs (config 3).
+constexpr uint32_t WG_TC = 4096;
+constexpr int32_t WG_TC_MIXED = INT32_MIN;
+__global__ void wg_tidchunks_k(const int32_t* __restrict__ tid, uint32_t n, const uint32_t* __restrict__ run_off, uint32_t k, uint32_t nchunks,
+                               int32_t* __restrict__ ctid) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nchunks) return;
+  const uint32_t a = c * WG_TC, b = n - a < WG_TC ? n - 1 : a + WG_TC - 1;  // first and last record of the chunk
+  uint32_t lo = 0, hi = k;  // last f with run_off[f] <= a
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (run_off[mid] <= a)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  const int32_t ta = tid[a];
+  ctid[c] = (b < run_off[lo + 1] && tid[b] == ta) ? ta : WG_TC_MIXED;
+}
+__global__ void wg_sample_raw_k(const int32_t* __restrict__ tid, const int32_t* __restrict__ pos, const int32_t* __restrict__ ctid, uint32_t n,
+                                uint32_t s, uint32_t ns, uint64_t* __restrict__ shi) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= ns) return;
   uint64_t d = (uint64_t)j * s;
   if (d >= n) d = n - 1;
-  shi[j] = raw_key(tid[d], pos[d]);
+  const int32_t ct = ctid[d / WG_TC];
+  shi[j] = raw_key(ct == WG_TC_MIXED ? tid[d] : ct, pos[d]);
 }
 // The offsets matrix off[r * k + f] (r = 0: start of run f, r = nrows - 1: its end, else the first record of run f whose key is
 // >= W[r - 1]) by a streaming pass (per-(row, run) searches cost 2-4x as much in scattered probes):
@@ -117,7 +142,8 @@ __device__ __forceinline__ uint32_t wg_upper_bound(const uint64_t* __restrict__ 
 }
 template <bool RAW>
 __global__ __launch_bounds__(256) void wg_offsets_stream_k(const uint64_t* __restrict__ chi, const int32_t* __restrict__ rtid,
-                                                           const int32_t* __restrict__ rpos, const uint32_t* __restrict__ run_off, uint32_t k,
+                                                           const int32_t* __restrict__ rpos, const int32_t* __restrict__ ctid,
+                                                           const uint32_t* __restrict__ run_off, uint32_t k,
                                                            uint32_t n, const uint64_t* __restrict__ W, uint32_t nW, uint32_t nrows,
                                                            uint32_t* __restrict__ offT, uint32_t* __restrict__ err) {
   __shared__ uint64_t key[WG_OC];
@@ -161,7 +187,16 @@ __global__ __launch_bounds__(256) void wg_offsets_stream_k(const uint64_t* __res
   };
   const uint32_t i0 = blockIdx.x * WG_OC;
   const uint32_t i1 = n - i0 < WG_OC ? n : i0 + WG_OC;
-  for (uint32_t j = t; j < i1 - i0; j += 256) key[j] = RAW ? raw_key(rtid[i0 + j], rpos[i0 + j]) : (chi[i0 + j] >> 2);
+  static_assert(WG_TC % WG_OC == 0, "a block of the offsets pass lies inside one chunk of reference ids");
+  if constexpr (RAW) {
+    const int32_t ct = ctid[i0 / WG_TC];  // (uniform) the chunk's reference id, or: read them
+    if (ct != WG_TC_MIXED)
+      for (uint32_t j = t; j < i1 - i0; j += 256) key[j] = raw_key(ct, rpos[i0 + j]);
+    else
+      for (uint32_t j = t; j < i1 - i0; j += 256) key[j] = raw_key(rtid[i0 + j], rpos[i0 + j]);
+  } else {
+    for (uint32_t j = t; j < i1 - i0; j += 256) key[j] = chi[i0 + j] >> 2;
+  }
   if (t == 0) {
     uint32_t lo = 0, hi = k;  // last f with run_off[f] <= i0
     while (hi - lo > 1) {
@@ -1729,14 +1764,15 @@ __global__ __launch_bounds__(64) void wg_spread_sum_k(const unsigned long long* 
 bool tbk_window_supported(uint32_t k) { return k >= 1 && k <= 1024; }
 
 // the offsets matrix of k runs against nW bounds, bound-major in `off` ([nrows * k], nrows = nW + 2)
-static int wg_offsets_build(tbk_ctx* ctx, bool raw, const uint64_t* chi, const int32_t* rtid, const int32_t* rpos, const uint32_t* d_run_off, uint32_t k,
+static int wg_offsets_build(tbk_ctx* ctx, bool raw, const uint64_t* chi, const int32_t* rtid, const int32_t* rpos, const int32_t* ctid,
+                            const uint32_t* d_run_off, uint32_t k,
                             uint32_t m, const uint64_t* W, uint32_t nW, uint32_t nrows, uint32_t* off) {
   uint32_t* offT = ws_alloc<uint32_t>(ctx, (size_t)nrows * k);
   if (!offT) return TBK_ENOMEM;
   if (raw)
-    TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_stream_k<true>, cdiv(m, WG_OC), 256, 0, chi, rtid, rpos, d_run_off, k, m, W, nW, nrows, offT, ctx->d_err);
+    TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_stream_k<true>, cdiv(m, WG_OC), 256, 0, chi, rtid, rpos, ctid, d_run_off, k, m, W, nW, nrows, offT, ctx->d_err);
   else
-    TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_stream_k<false>, cdiv(m, WG_OC), 256, 0, chi, rtid, rpos, d_run_off, k, m, W, nW, nrows, offT, ctx->d_err);
+    TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_stream_k<false>, cdiv(m, WG_OC), 256, 0, chi, rtid, rpos, ctid, d_run_off, k, m, W, nW, nrows, offT, ctx->d_err);
   TBK_LAUNCH(ctx, "wg_offsets_edges", wg_offsets_edges_k, k, 256, 0, d_run_off, k, nrows, offT);
   TBK_LAUNCH(ctx, "wg_offsets_transpose", wg_offsets_transpose_k, dim3(cdiv(nrows, 64u), cdiv(k, 64u)), 256, 0, offT, k, nrows, off);
   return 0;
@@ -1794,7 +1830,7 @@ int tbk_partial_reduce_device(tbk_ctx* ctx, int strategy, const int32_t* rows, u
     TBK_TRY(tbk_radix_sort_w64(ctx, &Y, &Y2, ns, ~0ull, false));
     TBK_LAUNCH(ctx, "wg_split", wg_split_k, cdiv(nsp, B), B, 0, Y, g, nsp, W);
   }
-  TBK_TRY(wg_offsets_build(ctx, false, chi, nullptr, nullptr, d_run_off, k, m, W, nW, nrows, off));
+  TBK_TRY(wg_offsets_build(ctx, false, chi, nullptr, nullptr, nullptr, d_run_off, k, m, W, nW, nrows, off));
   TBK_LAUNCH(ctx, "wg_rowsum", wg_rowsum_k, cdiv(nrows, 4), 256, 0, off, k, nrows, wbase);
   ColIn I{};
   I.n = m;
@@ -1866,18 +1902,25 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   uint64_t* W = ws_alloc<uint64_t>(ctx, nW + 1);
   uint32_t* off = ws_alloc<uint32_t>(ctx, (size_t)nrows * k);
   if (!W || !off) return TBK_ENOMEM;
+  int32_t* ctid = nullptr;  // (raw) the reference id of every chunk of WG_TC records, where it has one
+  if (raw) {
+    const uint32_t nchunks = cdiv(m, WG_TC);
+    ctid = ws_alloc<int32_t>(ctx, nchunks);
+    if (!ctid) return TBK_ENOMEM;
+    TBK_LAUNCH(ctx, "wg_sample", wg_tidchunks_k, cdiv(nchunks, B), B, 0, I.tid, m, d_run_off, k, nchunks, ctid);
+  }
   if (nsp) {
     uint64_t* Y = ws_alloc<uint64_t>(ctx, ns);
     uint64_t* Y2 = ws_alloc<uint64_t>(ctx, ns);
     if (!Y2) return TBK_ENOMEM;
     if (raw)
-      TBK_LAUNCH(ctx, "wg_sample", wg_sample_raw_k, cdiv(ns, B), B, 0, I.tid, I.pos, m, s, ns, Y);
+      TBK_LAUNCH(ctx, "wg_sample", wg_sample_raw_k, cdiv(ns, B), B, 0, I.tid, I.pos, ctid, m, s, ns, Y);
     else
       TBK_LAUNCH(ctx, "wg_sample", wg_sample_k, cdiv(ns, B), B, 0, chi, m, s, ns, Y);
     TBK_TRY(tbk_radix_sort_w64(ctx, &Y, &Y2, ns, ~0ull, false));
     TBK_LAUNCH(ctx, "wg_split", wg_split_k, cdiv(nsp, B), B, 0, Y, g, nsp, W);
   }
-  TBK_TRY(wg_offsets_build(ctx, raw, chi, I.tid, I.pos, d_run_off, k, m, W, nW, nrows, off));
+  TBK_TRY(wg_offsets_build(ctx, raw, chi, I.tid, I.pos, ctid, d_run_off, k, m, W, nW, nrows, off));
   WgTemp T;
   T.hi = scratch_hi;
   T.lo = scratch_lo;
