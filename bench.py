@@ -219,6 +219,7 @@ def main():
     dtile = synth_dev.make_tile_device(files, reads, SYNTH_PROFILE[profile], device=dev, first_file=rank * files, tx=tx)
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
+    torch.cuda.empty_cache()                          # (the generator's temporaries go back to the device: only the tile stays)
     n_records = dtile.n_records
     n_cig_in = int(dtile.cig.numel())
     # Contexts take the steps in turn (software pipelining of independent tiles, as a streaming host would run them): the YD list

@@ -47,6 +47,15 @@ struct RegGuard {
 
 static int ws_begin_call(tbk_ctx* ctx, size_t hint) {
   release_registered(ctx);  // (nothing to do unless a side path left something behind)
+  ctx->ws_top = 0;
+  ctx->ws_top_mode = false;
+  if (ctx->ws_borrowed) {  // a range of another context's arena: what does not fit goes to overflow chunks, the range stays
+    for (auto& c : ctx->ws_overflow) (void)hipFree(c.first);
+    ctx->ws_overflow.clear();
+    ctx->ws_off = 0;
+    ctx->ws_over_used = 0;
+    return 0;
+  }
   size_t want = std::max(ctx->ws_cap, hint);
   if (ctx->yd_pending) {
     // a deferred YD stage still reads arrays in [0, ws_base_off): never move the arena now; this call bump-allocates
@@ -83,7 +92,12 @@ int tbk_ws_reserve(tbk_ctx* ctx, size_t bytes) { return ws_begin_call(ctx, bytes
 void* tbk_ws_alloc_raw(tbk_ctx* ctx, size_t bytes) {
   bytes = (bytes + 255) & ~(size_t)255;
   if (bytes == 0) bytes = 256;
-  if (ctx->ws_overflow.empty() && ctx->ws_off + bytes <= ctx->ws_cap) {
+  const size_t top_end = ctx->ws_cap & ~(size_t)255;  // (the arena's size is whatever a call asked for: the end that allocations count from is aligned)
+  if (ctx->ws_overflow.empty() && ctx->ws_off + ctx->ws_top + bytes <= top_end) {
+    if (ctx->ws_top_mode) {  // a temporary of the current stage: from the end of the arena
+      ctx->ws_top += bytes;
+      return ctx->ws + (top_end - ctx->ws_top);
+    }
     void* p = ctx->ws + ctx->ws_off;
     ctx->ws_off += bytes;
     return p;
@@ -382,7 +396,7 @@ void tbk_destroy(tbk_ctx* ctx) {
   release_registered(ctx);
   for (auto& c : ctx->ws_overflow) (void)hipFree(c.first);
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
-  if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->ws && !ctx->ws_borrowed) (void)hipFree(ctx->ws);
   if (ctx->d_view) (void)hipFree(ctx->d_view);
   if (ctx->d_unpack) (void)hipFree(ctx->d_unpack);
   if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
@@ -515,13 +529,14 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
   tbk_prof_begin_call(ctx);
   // Arena hints.  The sort path keeps keys, sort buffers and per-record scratch (160 B per record); the window path in its raw form —
   // large plain tiles, the predicate of tbk_collapse_device restated — works on the input where it lies and needs half of that
-  // (config 3: 26 GB for 320 M records, 9.6 GB for its YD stage).  A hint that proves too small costs one call with overflow
+  // (config 3: 25 GB for 320 M records — scratch at the far end of the arena, the group arrays at the bottom — and 9.6 GB for its
+  // YD stage, which borrows the range behind the group arrays when it is deferred).  A hint that proves too small costs one call with overflow
   // chunks, after which the arena has learnt its size.
   bool lean = in->mem == TBK_MEM_DEVICE && !opts->store_frac && !opts->collapse_same && !in->prio_hi && !getenv("TBK_PATH") && !getenv("TBK_RAW") &&
               (in->n_records >= (8u << 20) || (in->n_files > 64 && in->n_records >= 65536));
   if (lean && in->tbmerged)
     for (uint32_t f = 0; f < in->n_files; ++f) lean = lean && in->tbmerged[f] == 0;
-  size_t hint = (size_t)in->n_records * (lean ? 92 : 160) + (size_t)in->n_cigar_ops * 8 + ((size_t)8 << 20);
+  size_t hint = (size_t)in->n_records * (lean ? 84 : 160) + (size_t)in->n_cigar_ops * 8 + ((size_t)8 << 20);
   TBK_TRY(ws_begin_call(ctx, hint));
   RegGuard reg_guard{ctx};
   int rc;
@@ -573,6 +588,22 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
         ctx->ws_base_off = (ctx->ws_off + 255) & ~(size_t)255;
         ctx->yd_rc = 0;
         tbk_ctx* side = ctx->yd_ctx;
+        // The YD stage works in a range of THIS arena, right behind what it reads (the window path left its scratch at the other
+        // end, dead by now): no second arena of 40 bytes per record per context.  The calls that follow on this context start behind
+        // the range; when the arena could not hold them as well, the stage keeps an arena of its own.
+        const size_t yd_bytes = (yd_hint + 255) & ~(size_t)255;
+        const bool borrow = !getenv("TBK_YD_OWN_ARENA") && ctx->ws_base_off + yd_bytes + ctx->ws_cap / 4 <= ctx->ws_cap;
+        if (borrow) {
+          if (side->ws && !side->ws_borrowed) (void)hipFree(side->ws);
+          side->ws = ctx->ws + ctx->ws_base_off;
+          side->ws_cap = yd_bytes;
+          side->ws_borrowed = true;
+          ctx->ws_base_off += yd_bytes;
+        } else if (side->ws_borrowed) {
+          side->ws = nullptr;
+          side->ws_cap = 0;
+          side->ws_borrowed = false;
+        }
         if (!ctx->yd_worker) ctx->yd_worker = new TbkWorker();
         ctx->yd_pending = true;
         ctx->yd_worker->post([ctx, side, job, yd_hint]() { ctx->yd_rc = yd_stage_on(side, job, yd_hint); });

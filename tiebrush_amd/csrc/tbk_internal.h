@@ -91,6 +91,12 @@ struct tbk_ctx {
   // device workspace (bump allocator, reset at the start of each API call)
   char* ws = nullptr;
   size_t ws_cap = 0, ws_off = 0;
+  // two-ended: while ws_top_mode is set, allocations come from the END of the arena, downwards (ws_top bytes in use there).  A stage
+  // puts its temporaries there and what outlives it at the bottom; when its kernels are queued it sets ws_top back to 0 — the
+  // temporaries are dead in stream order — and only the bottom has to stay for a deferred YD stage (ws_base_off)
+  size_t ws_top = 0;
+  bool ws_top_mode = false;
+  bool ws_borrowed = false;      // `ws` is a range of another context's arena (deferred YD stage): never freed or regrown here
   std::vector<std::pair<char*, size_t>> ws_overflow;
   size_t ws_over_used = 0;
   // small persistent device words + pinned mirror

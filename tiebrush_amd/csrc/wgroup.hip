@@ -1873,6 +1873,17 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   const bool raw = raw_opt != nullptr;  // the records themselves are the runs: m = I.n, d_run_off = I.file_off, chi .. ceff unused
   if (!tbk_window_supported(k) || m == 0) return TBK_EINVAL;
   if (part && (!raw || k > 64 || !I.prio_hi || !I.yc_in || !I.yx_in || !I.yd_in)) return TBK_EINVAL;
+  // Everything allocated from here to the group arrays (`out`) is this stage's scratch — 80 bytes per record on the raw path — and
+  // dead once its kernels have run: it comes from the end of the arena, the group arrays (a few dozen bytes per GROUP) from the
+  // bottom, so that a deferred YD stage pins the bottom only and the calls behind the collapse find the rest of the arena free
+  struct TopMode {
+    tbk_ctx* c;
+    ~TopMode() {
+      c->ws_top_mode = false;
+      c->ws_top = 0;  // (the kernels that read the scratch are queued: dead in stream order)
+    }
+  } top_mode{ctx};
+  ctx->ws_top_mode = true;
   WgRaw R{};
   unsigned long long* spread = nullptr;  // (raw) the spread counters of passing records and verification entries
   if (raw) {
@@ -2087,6 +2098,7 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   const uint32_t ng = (uint32_t)ctx->h_scalars[1], np = (uint32_t)ctx->h_scalars[2];
   out->ng = ng;
   out->np = np;
+  ctx->ws_top_mode = false;  // the group arrays: from the bottom
   out->ghi = ws_alloc<uint64_t>(ctx, ng);
   out->glo = ws_alloc<uint64_t>(ctx, ng);
   out->gmem = ws_alloc<uint32_t>(ctx, ng);
@@ -2103,8 +2115,11 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   out->rep = ws_alloc<unsigned long long>(ctx, ng);
   out->first = ws_alloc<uint32_t>(ctx, ng);
   out->tie = ws_alloc<uint8_t>(ctx, ng);
-  uint32_t* slot2sg = want_rec_sg ? ws_alloc<uint32_t>(ctx, m) : nullptr;
   out->rec_sg = want_rec_sg ? ws_alloc<uint32_t>(ctx, I.n) : nullptr;
+  ctx->ws_top_mode = true;
+  uint32_t* slot2sg = want_rec_sg ? ws_alloc<uint32_t>(ctx, m) : nullptr;  // (scratch)
+  ctx->ws_top_mode = false;
+  if (want_rec_sg && !slot2sg) return TBK_ENOMEM;
   if (!out->tie || (want_rec_sg && !out->rec_sg)) return TBK_ENOMEM;
   if (ng) {
     WgFinal F{out->gfmask, out->ghi, out->glo, out->gmem, out->gpoff, out->pgrp, out->first, out->ns, slot2sg, out->pfile, out->yc, out->yxin,
