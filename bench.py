@@ -387,6 +387,7 @@ def main():
                 done()
                 for kk in ("wire_bytes", "wire_bytes_off_rank", "wire_rows"):
                     wire[kk] += st.get(kk, 0)
+                wire["cut_rounds_max"] = max(wire.get("cut_rounds_max", 0), st.get("cut_rounds", 0))
                 wire["steps"] += 1
         finally:
             th.join()
@@ -461,6 +462,7 @@ def main():
             "wire_bytes_per_step": int(wire["wire_bytes"] / nst),
             "wire_bytes_off_rank_per_step": int(wire["wire_bytes_off_rank"] / nst),
             "partials_per_step": int(wire["wire_rows"] / nst),
+            "cut_rounds_max": int(wire.get("cut_rounds_max", 0)),
             "dist_mode": args.dist_mode,
             "dist_phase_host_ms_per_step": ph,
             "dist_note": "rank 0's figures.  plain_ms_per_step: the plain single-GPU step (collapse + chain + tiecov, %d contexts) on this "
@@ -510,7 +512,7 @@ def main():
         if os.path.exists(tpath):          # PMC passes (FETCH_SIZE / WRITE_SIZE) of this same workload, per launch: rocprofv3 counters
             traffic = json.load(open(tpath)).get("bytes_per_launch", {})   # cannot be read from inside the process they profile
 
-        def roofline(stage, name, alg_bytes, launch_us=None):
+        def roofline(stage, name, alg_bytes, launch_us=None, owed_bytes=None, owed_note=None):
             ms, ln = acc[(stage, name)]
             per_launch_ms = ms / ln
             launches_per_step = ln / args.prof_steps
@@ -530,19 +532,30 @@ def main():
                      traffic_source=("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, per launch)" % tname) if tb else None,
                      launches_per_step=launches_per_step, algorithmic_bytes_per_step=int(alg_bytes),
                      measured="HIP events on the launch stream, profiling steps after the timed region, calls serialised (kernel alone on the GPU)")
+            if owed_bytes is not None:     # the bytes this kernel itself has to move in this run (the SURVEY §8d figure counts more)
+                r.update(frac_own_bytes=round((owed_bytes / launches_per_step) / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         own_bytes_per_step=int(owed_bytes), own_bytes_note=owed_note)
             return r
 
         tot = {k: v[0] / args.prof_steps for k, v in acc.items()}
         dom = max(tot, key=tot.get)
-        roof["roofline"] = roofline(dom[0], dom[1], b_collapse if dom[0] == "collapse" else b_cov)
+        # what the kernels owe in THIS run: the collapse writes no per-record group id (rec_group is not requested: 4 B per record of the
+        # §8d figure are never written); cov_tile_k reads the view's records and writes change points — the 16 S bytes of the reference's
+        # depth array never exist in HBM, the run-length pass and the interval writes belong to cov_iv_*
+        b_collapse_owed = gg["n_passed"] * 12 + 4 * n_cig_in
+        b_cov_own = gg["n_groups"] * 12 + 4 * ncig_cov + 16 * cc["n_intervals"]
+        note_c = "records in (12 B + CIGAR words); no group-id write: rec_group is not requested"
+        note_v = "view records in (12 B + CIGAR words) + change points out (16 B each, at least one per interval: a lower bound)"
+        roof["roofline"] = roofline(dom[0], dom[1], b_collapse if dom[0] == "collapse" else b_cov,
+                                    owed_bytes=b_collapse_owed if dom[0] == "collapse" else b_cov_own, owed_note=note_c if dom[0] == "collapse" else note_v)
         if ("coverage", "cov_tile") in acc:
-            roof["roofline_coverage"] = roofline("coverage", "cov_tile", b_cov, cov_tile_us or None)
+            roof["roofline_coverage"] = roofline("coverage", "cov_tile", b_cov, cov_tile_us or None, owed_bytes=b_cov_own, owed_note=note_v)
             if cov_call_ms:
                 s_ = sorted(cov_call_ms)
                 roof["roofline_coverage"]["coverage_call_ms_median"] = round(s_[len(s_) // 2], 3)
                 roof["roofline_coverage"]["frac_whole_call"] = round(b_cov / (s_[len(s_) // 2] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         cdom = max((k for k in tot if k[0] == "collapse"), key=tot.get)
-        roof["roofline_collapse"] = roofline("collapse", cdom[1], b_collapse)
+        roof["roofline_collapse"] = roofline("collapse", cdom[1], b_collapse, owed_bytes=b_collapse_owed, owed_note=note_c)
         roof["kernel_ms_per_step"] = {"%s/%s" % k: round(v, 4) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}
         roof["launches_per_step"] = int(sum(v[1] for v in acc.values()) / args.prof_steps)
         roof["gpu_kernel_ms_per_step_total"] = round(sum(tot.values()), 4)

@@ -56,6 +56,7 @@ import numpy as np
 from .soa import SoATile, CovInput
 
 N_SAMPLES = 64
+MAX_CUT_ROUNDS = 4096
 KEY_INF = 1 << 62        # above every key of a placed read: keys are (tid+1) << 31 | pos+1 (unplaced reads carry exactly this value)
 
 
@@ -584,7 +585,14 @@ def partials_collapse(compute, local_tile: SoATile, first_fidx: int, rank: int, 
         tgt = np.array([int(flat[(j * len(flat)) // world]) if len(flat) else KEY_INF for j in range(1, world)], np.int64)
         p = _torch().from_numpy(tgt).to(key.device) if _is_t(key) else tgt
         # ---- 3. every cut moves forward to a global bundle boundary of the GROUPS (= of the passing records) ------------
-        for _ in range(100000):
+        # (a round moves every unsettled cut to the next read start beyond what reaches across it: a cut settles as soon as it
+        # meets a gap, so the rounds are bounded by the bundles a cut has to cross — a handful on real data; MAX_CUT_ROUNDS is a
+        # guard against an input that is one bundle from end to end, which cannot be cut at all)
+        for rnd in range(MAX_CUT_ROUNDS + 1):
+            if rnd == MAX_CUT_ROUNDS:
+                raise ValueError("no bundle boundary within %d rounds of a coordinate cut: the input cannot be sharded by range" % MAX_CUT_ROUNDS)
+            if stats is not None:
+                stats["cut_rounds"] = rnd + 1
             if on_dev:
                 m_local = compute.shard_probe_max(fo1, key, emax, p, X.full(world - 1, -1, like=key))
             else:
