@@ -82,3 +82,51 @@ def test_nh_and_mapq_filters_equal_default_with_ballast(ctx, monkeypatch, path, 
     _same(a, _hip(ctx, t2, strategy=strategy))
     _same(a, orc.collapse(t2, strategy=s))
     _same(a, orc.collapse(tile, strategy=s, max_nh=5, min_qual=1))
+
+
+def _dev_strip_soft_clips(tile):
+    """strip_soft_clips on a device tile (torch)"""
+    import torch
+    from dataclasses import replace
+    cig = tile.cig.to(torch.int64) & 0xFFFFFFFF
+    keep = (cig & 0xF) != mm.S_OP
+    co = tile.cig_off.to(torch.int64) & 0xFFFFFFFF
+    ck = torch.cat([torch.zeros(1, dtype=torch.int64, device=cig.device), torch.cumsum(keep.to(torch.int64), 0)])
+    new_off = ck[co]
+    assert int((new_off[1:] - new_off[:-1]).min()) > 0
+    return replace(tile, cig=tile.cig[keep].contiguous(), cig_off=new_off.to(torch.int32))
+
+
+def _dev_same(a, b):
+    import torch
+    assert a["n_groups"] == b["n_groups"] and a["n_passed"] == b["n_passed"]
+    for k in KEYS:
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_clip_equals_default_on_the_stripped_tile_config3_shape_32M(ctx):
+    """the same identity at a tenth of config 3 (64 files x 500 k reads, generated and stripped on the device): the window path at the
+    size where it is the default, every output array"""
+    from tiebrush_amd import synth_dev
+    tile = synth_dev.make_tile_device(64, 500_000, "c3", device="cuda:0")
+    clip = {k: (v.clone() if hasattr(v, "clone") else v) for k, v in ctx.collapse(tile, strategy="clip").items() if not k.startswith("_")}
+    stripped = _dev_strip_soft_clips(tile)
+    _dev_same(clip, ctx.collapse(stripped, strategy="cigar"))
+    plain = ctx.collapse(tile, strategy="cigar")
+    assert plain["n_groups"] > clip["n_groups"]
+
+
+def test_filters_equal_default_with_ballast_config5_shape_32M(ctx):
+    """-N 5 -Q 1 --exon on config 5's per-rank shape at a quarter of its size (128 files x 250 k reads) == the default filters on the
+    tile whose dropped records became secondary alignments with passing NH / MAPQ (merge-order ballast), on the device"""
+    import torch
+    from dataclasses import replace
+    from tiebrush_amd import synth_dev
+    tile = synth_dev.make_tile_device(128, 250_000, "c5", device="cuda:0")
+    drop = (tile.nh > 5) | (tile.mapq.to(torch.int32) < 1)
+    assert int(drop.sum()) > 100000
+    t2 = replace(tile, flag=torch.where(drop, tile.flag | 0x100, tile.flag), nh=torch.where(drop, torch.ones_like(tile.nh), tile.nh),
+                 mapq=torch.where(drop, torch.full_like(tile.mapq, 60), tile.mapq))
+    a = {k: (v.clone() if hasattr(v, "clone") else v) for k, v in ctx.collapse(tile, strategy="exon", max_nh=5, min_qual=1).items()
+         if not k.startswith("_")}
+    _dev_same(a, ctx.collapse(t2, strategy="exon"))
