@@ -698,7 +698,7 @@ def host_to_host_leg(args, torch, np, api, dtile, strat, last, n_records, n_cig_
     capg = max(1 << 20, max(p.n_records for p in subs) // 4)
     totals = {"passed": 0, "groups": 0, "iv": 0, "j": 0, "out_bytes": 0, "t_h2d": 0.0, "t_compute": 0.0, "t_d2h": 0.0}
     lock = threading.Lock()
-    link = threading.Lock()
+    link = threading.Semaphore(int(os.environ.get("TBK_H2H_LINK", "1")))
 
     def run_all():
         errs = []

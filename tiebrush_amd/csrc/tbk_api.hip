@@ -454,7 +454,7 @@ int tbk_coverage_tile(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out) {
   if (in->mem != out->mem) return TBK_EINVAL;
   TBK_HIP(hipSetDevice(ctx->device));
   tbk_prof_begin_call(ctx);
-  size_t hint = (size_t)in->n_records * 96 + (size_t)in->n_cigar_ops * 64 + ((size_t)8 << 20);
+  size_t hint = (size_t)in->n_records * 96 + (size_t)in->n_cigar_ops * 64 + ((size_t)32 << 20);  // (the lean chain's tile tables: 12 MB at least)
   TBK_TRY(ws_begin_call(ctx, hint));
   RegGuard reg_guard{ctx};
   int rc;

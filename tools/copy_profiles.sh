@@ -1,7 +1,7 @@
 #!/bin/bash
 # copies what tools/refresh_profiles.sh (parts a and b) left under gpurun_out/prof/ to the names profiles/README.md lists
 set -e
-P=gpurun_out/prof; R=${1:-r3}
+P=gpurun_out/prof; R=${1:-r4}
 cp $P/bench_default.json profiles/${R}_bench_c3.json
 cp $P/kernel_stats.csv profiles/${R}_bench_c3_kernel_stats.csv
 cp $P/pmc_fetch_size.csv profiles/${R}_bench_c3_pmc_fetch_size.csv
@@ -17,3 +17,7 @@ cp $P/cov_prof_c3.txt profiles/${R}_cov_prof_c3.txt
 cp $P/prof_dist_c4shape.txt profiles/${R}_prof_dist_c4shape.txt
 cp $P/prof_dist_c3shape.txt profiles/${R}_prof_dist_c3shape.txt
 cp $P/traffic.json profiles/traffic_c3_64x5000000.json
+cp $P/bench_c4_strong_n1.json profiles/${R}_bench_c4_strong_n1.json
+cp $P/bench_c4shape.json profiles/${R}_bench_c4shape.json
+cp $P/bench_c5shape.json profiles/${R}_bench_c5shape.json
+cp $P/cov_prof_c3_intervals_only.txt profiles/${R}_cov_prof_c3_intervals_only.txt

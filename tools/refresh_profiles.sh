@@ -36,5 +36,10 @@ PMC_OUT=$O bash tools/pmc_sq.sh prof_sq wg_ > $O/pmc_sq_wg.txt 2> $O/pmc_sq.err
 # ... and of every kernel; the multi-rank step unpipelined on config 3's shape
 PMC_OUT=$O bash tools/pmc_sq.sh prof_sq_all _k > $O/pmc_sq_all.txt 2> $O/pmc_sq_all.err
 python3 tools/prof_dist.py 64 5000000 c3 > $O/prof_dist_c3shape.txt 2> $O/prof_dist_c3.err
+# BASELINE config 4 as ONE job on one GPU (the N = 1 end of the strong-scaling workload bench.py runs at N > 1), and its per-rank shape at N = 8
+python3 bench.py --profile c4 --scaling strong --no-cpu-baseline --no-host-path --no-e2e --steps 8 --warmup 2 > $O/bench_c4_strong_n1.json 2> $O/bench_c4_strong_n1.err
+python3 bench.py --profile c4 --scaling weak --no-cpu-baseline --no-host-path --no-e2e > $O/bench_c4shape.json 2> $O/bench_c4shape.err
+python3 bench.py --profile c5 --no-cpu-baseline --no-host-path --no-e2e > $O/bench_c5shape.json 2> $O/bench_c5shape.err
+TBK_PROF_NOJ=1 python3 tools/cov_prof.py c3 64 5000000 10 > $O/cov_prof_c3_intervals_only.txt 2>> $O/cov_prof.err
 fi
 echo refresh done; ls -la $O
