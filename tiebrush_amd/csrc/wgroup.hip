@@ -681,12 +681,9 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
   {
     const uint32_t* row0 = In.off + (size_t)w * k;
     const uint32_t* row1 = row0 + k;
-    for (uint32_t i = t; i < gcap; i += WG_NT) {
-      tc[i] = ~0ull;
-      trep[i] = ~0ull;
-      tcnt[i] = 0;
-    }
-    for (uint32_t i = t; i < gcap * nwords; i += WG_NT) tbits[i] = 0;
+    // only the claim words are cleared here: count, representative and sample bits of a slot are set by the thread that claims it,
+    // before the barrier that every user of the slot waits behind (37 KB of LDS stores per window became 6 KB)
+    for (uint32_t i = t; i < gcap; i += WG_NT) tc[i] = ~0ull;
     if (t == 0) {
       s_misc[0] = 0;  // distinct groups
       s_misc[1] = 0;  // overflow
@@ -694,6 +691,8 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
       s_misc[3] = 0;  // RAW: records that left a slot for the verification pass
       s_misc[4] = 0;  // RAW: carry of the effective-end scan into chunk 0 ...
       s_misc[5] = 0;  // ... and into chunk 1 (alternating)
+      s_misc[6] = 0;  // ONEBAR: overflow raised in an even chunk ...
+      s_misc[7] = 0;  // ... in an odd chunk
     }
     if constexpr (GC > 0) {  // <= 64 files: the piece lengths are one wave's scan (a block scan is ~ 100 instructions in each of the eight waves)
       if (t < 64) {
@@ -746,6 +745,14 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
   // fetched a chunk ahead (four registers), so that a chunk's CIGAR words are asked for together with its fields: one round trip to
   // memory per chunk instead of two dependent ones
   constexpr bool AHEAD = RAW && NR == 1 && WG_RS == 1;
+  // ONEBAR: one barrier per chunk instead of two.  The second one kept a fast wave out of the next chunk while a slow one still worked
+  // on this one; what they could disturb is kept apart by the chunk's parity instead — the wave aggregates of the effective-end scan
+  // (s_agg), the carry (s_misc[4 + par], as before) and the overflow flag (s_misc[6 + par]: a wave that has not yet looked at this
+  // chunk's flag must not see the next chunk's) — and everything else a chunk touches after its barrier (counts, representatives and
+  // sample bits of slots claimed BEFORE that barrier; the slots' claim numbers) is not written by the next chunk's probes, which
+  // claim and initialise NEW slots only.  Two chunks ahead is impossible: the next chunk's barrier needs every wave.
+  constexpr bool ONEBAR = RAW && NR == 1;
+  uint2* const s_agg0 = s_agg;
   uint32_t a_fil = 0, a_src = 0, a_c0 = 0, a_c1 = 0;
   if constexpr (AHEAD) {
     if (t < n_w) {
@@ -762,6 +769,8 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
     uint64_t kh[NR], kl[NR];
     uint32_t won = 0, actm = 0;
     uint32_t xs[NR], fs[NR];  // RAW: scanned end inside the wave row, and whether a segment start shields it from the carry
+    s_agg = s_agg0 + (ONEBAR ? par * (uint32_t)(NR * WG_NW) : 0u);
+    uint32_t* const ovf_flag = &s_misc[ONEBAR ? 6u + par : 1u];
 #pragma unroll
     for (int u = 0; u < NR; ++u) {
       const uint32_t e = c0 + (uint32_t)u * WG_NT + t;
@@ -892,18 +901,21 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
         if ((won >> u) & 1u) {
           thi[slot[u]] = kh[u];
           tlo[slot[u]] = kl[u];
+          trep[slot[u]] = ~0ull;
+          tcnt[slot[u]] = 0;
+          for (uint32_t x = 0; x < nwords; ++x) tbits[slot[u] * nwords + x] = 0;
           const uint32_t ci = atomicAdd(&s_misc[0], 1u);
           tci[slot[u]] = ci;
           pa[ci] = (uint16_t)slot[u];  // (a claim takes a slot: ci < gcap)
-          if (ci + 1u > (gcap >> 2) * 3u) s_misc[1] = 1;
+          if (ci + 1u > (gcap >> 2) * 3u) *ovf_flag = 1;
         }
-        if (slot[u] == 0xFFFFFFFFu) s_misc[1] = 1;
+        if (slot[u] == 0xFFFFFFFFu) *ovf_flag = 1;
       }
     }
     phase(3);
     __syncthreads();  // key and claim number of every slot claimed in this chunk are visible
     phase(4);
-    if (s_misc[1]) break;
+    if (*ovf_flag) break;
     if constexpr (RAW) {  // effective ends: the carry that enters every (row, wave) of this chunk, folded in element order
       // (lane q of every wave holds aggregate q; a 16-lane segmented scan gives the carry behind each of them)
       static_assert(NR * WG_NW <= 16, "the carries are folded inside one DPP row");
@@ -986,11 +998,11 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
       }
     }
     phase(5);
-    __syncthreads();
+    if constexpr (!ONEBAR) __syncthreads();
     phase(6);
   }
   __syncthreads();
-  const bool overflow = s_misc[1] != 0;
+  const bool overflow = ONEBAR ? (s_misc[6] | s_misc[7]) != 0 : s_misc[1] != 0;
   const uint32_t d = s_misc[0];
   if (!overflow) {
     // ---- rank the groups by key (pa holds their slots in claim order), emit groups and incidences in rank order ----
