@@ -86,9 +86,20 @@ def _launch(n, argv):
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, "-m", "tiebrush_amd.ranks"] + argv, env=env,
                                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    # a rank that fails leaves the others waiting in a collective: when one ends with an error the rest are ended too (these exact
+    # processes, by handle)
+    rc, live = 0, list(procs)
+    while live:
+        time.sleep(0.05)
+        for p in list(live):
+            r = p.poll()
+            if r is None:
+                continue
+            live.remove(p)
+            if r != 0:
+                rc = max(rc, abs(r))
+                for q in live:
+                    q.terminate()
     return rc
 
 
