@@ -601,6 +601,18 @@ def main():
             "tiecov": {"bases_covered_per_step": int(n_bases), "bundle_span_bases": int(span), "intervals": int(n_iv), "junctions": int(n_j)},
         }
         line.update(dist_extra)
+        if scaling == "strong" and world > 1:
+            # the N = 1 end of this fixed job, recorded on an MI355X (profiles/: a run of `--gpus 1 --profile c4 --scaling strong`): the
+            # default N = 1 line is config 3, another workload, so a scaling efficiency has to be read against THIS figure
+            ref = os.path.join(ROOT, "profiles", "r4_bench_%s_strong_n1.json" % profile)
+            if os.path.exists(ref) and job_files == STRONG_JOB_FILES[profile] and reads == WORKLOADS[profile][1]:
+                try:
+                    r1 = json.loads(open(ref).read().strip().splitlines()[-1])
+                    line["strong_scaling_n1_reference"] = {"value": r1["value"], "ms_per_step": r1["ms_per_step"], "workload": r1["config"]["workload"],
+                                                           "source": "profiles/r4_bench_%s_strong_n1.json (recorded, not measured in this run)" % profile,
+                                                           "speedup_vs_n1": round(line["value"] / r1["value"], 3)}
+                except Exception:
+                    pass
         line.update(roof)
         if host_path is not None:
             line["kernel_path_host_to_host"] = host_path
