@@ -11,12 +11,20 @@ from helpers import GOLDEN, sample_paths
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def ctx():
+@pytest.fixture(scope="module", params=["wave", "lane"])
+def ctx(request):
+    """every test of this file runs on both inflate kernels: a wave per member (the default) and a lane per member
+    (TBK_INFLATE_LANE, bamdev.hip: bgz_inflate_launch)"""
     from tiebrush_amd import api
+    old = os.environ.pop("TBK_INFLATE_LANE", None)
+    if request.param == "lane":
+        os.environ["TBK_INFLATE_LANE"] = "1"
     c = api.Context(0)
     yield c
     c.close()
+    os.environ.pop("TBK_INFLATE_LANE", None)
+    if old is not None:
+        os.environ["TBK_INFLATE_LANE"] = old
 
 
 def _bgzf(payload: bytes, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, block=0xff00) -> bytes:
@@ -79,6 +87,37 @@ def test_corrupt_members_are_refused(ctx):
         with pytest.raises(api.TbkError):
             ctx.bgzf_inflate(bytes(b))
     assert ctx.bgzf_inflate(good) == b"tiebrush " * 5000
+
+
+def test_mutated_streams_are_refused_or_exact(ctx):
+    """bit flips and truncations inside the deflate stream: the CRC leaves two outcomes, the payload or a refusal"""
+    from tiebrush_amd import api
+    rng = np.random.default_rng(11)
+    payload = (b"ACGTTGCA" * 7 + b"read\t%d\n") * 900 + rng.integers(0, 256, 9000, dtype=np.uint8).tobytes()
+    for level, strategy in ((6, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_FIXED), (9, zlib.Z_HUFFMAN_ONLY), (0, zlib.Z_DEFAULT_STRATEGY)):
+        good = _bgzf(payload, level, strategy)
+        bs = (good[16] | (good[17] << 8)) + 1     # first member
+        refused = 0
+        for _ in range(40):
+            b = bytearray(good)
+            at = int(rng.integers(18, bs - 8))
+            b[at] ^= 1 << int(rng.integers(0, 8))
+            try:
+                assert ctx.bgzf_inflate(bytes(b)) == payload
+            except api.TbkError:
+                refused += 1
+        assert refused >= 30, (level, refused)
+        # a member whose stream is cut short (BSIZE and the trailer moved up): refused
+        cut = bytearray(good[:bs])
+        for drop in (1, 7, 200):
+            if bs - 26 - drop < 1:
+                continue
+            c = bytearray(cut[:18]) + cut[18:bs - 8 - drop] + cut[bs - 8:bs]
+            c[16:18] = (len(c) - 1).to_bytes(2, "little")
+            try:
+                assert ctx.bgzf_inflate(bytes(c) + good[bs:]) == payload and drop < 8   # (up to 8 zero bytes may stand in for the tail)
+            except api.TbkError:
+                pass
 
 
 def test_bam_decode_matches_host_decoders(ctx, bam_loader):

@@ -358,6 +358,368 @@ __global__ __launch_bounds__(INF_NT) void bgz_inflate_k(uint32_t nmem, const Bgz
   if (bad) atomicOr(err, 1u);
 }
 
+
+// ---- RFC 1951 inflate, one WAVE per member (round 4) ----------------------------------------------------------------------------
+// The lane-per-member kernel above runs 64 different decoders in lock step: every branch of every decoder is executed by the whole
+// wave, every output byte is a store of its own, every match copy goes through memory.  Here a wave works on ONE member: the decode
+// is executed uniformly (all lanes hold the same bit buffer and take the same branches: no divergence), symbols come from multi-bit
+// tables in LDS (10 bits for literals / lengths, 9 for distances; longer codes fall back to the canonical walk), the last 32 KiB
+// of output — all a deflate distance can reach — live in an LDS ring, a match is copied by the 64 lanes together, and the output
+// leaves the ring in coalesced runs of 16 KiB.  The compressed stream is staged through LDS 2 KiB at a time.  CRC32 is checked by
+// bgz_crc_k afterwards (a lane per member is the right shape for that: 64 independent table walks per wave).
+// Same verdicts as the kernel above on malformed streams (tests/test_gpu_bgzf.py runs both).
+constexpr int IW_WIN = 32768, IW_CIN = 2048, IW_LBITS = 10, IW_DBITS = 9;
+
+struct IwBits {  // uniform across the wave
+  uint64_t buf;
+  int cnt;
+  uint32_t cpos;   // next byte of the stream to enter the buffer (multiple of 4)
+  uint32_t cbase;  // stream offset of cin[0] (multiple of 4)
+};
+
+__global__ __launch_bounds__(64) void bgz_inflate_wave_k(uint32_t nmem, const BgzMember* __restrict__ mem, const uint8_t* __restrict__ src,
+                                                         uint8_t* __restrict__ dst, uint32_t* __restrict__ err) {
+  __shared__ __align__(16) uint8_t win[IW_WIN];
+  __shared__ __align__(16) uint8_t cin[IW_CIN];
+  __shared__ uint16_t ltab[1 << IW_LBITS], dtab[1 << IW_DBITS];  // entry: symbol << 4 | code length; 0: not in the table
+  __shared__ uint16_t lcnt[16], lsym[288], dcnt[16], dsym[32];    // canonical form (puff.c): codes per length, symbols in code order
+  __shared__ uint8_t lens[32 + 320];  // [0, 19): the code-length code; [32, 32 + 316): literal / length and distance code lengths
+  __shared__ uint16_t codes[288];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t m = blockIdx.x;
+  if (m >= nmem) return;
+  const BgzMember M = mem[m];
+  const uint8_t* cs = src + M.src;
+  uint8_t* out = dst + M.dst;
+  const uint32_t clen = M.clen, cap = M.isize;
+  IwBits B{0ull, 0, 0u, 0u};
+  auto stage = [&](uint32_t base) {  // cin <- stream bytes [base, base + IW_CIN), zeros beyond the member
+    __syncthreads();
+    for (uint32_t i = lane; i < IW_CIN; i += 64) cin[i] = base + i < clen ? cs[base + i] : (uint8_t)0;
+    __syncthreads();
+    B.cbase = base;
+  };
+  auto refill = [&]() {  // at least 32 bits in the buffer afterwards
+    while (B.cnt <= 32) {
+      if (B.cpos + 4u > B.cbase + IW_CIN) stage(B.cpos);
+      const uint32_t w = *reinterpret_cast<const uint32_t*>(cin + (B.cpos - B.cbase));
+      B.buf |= (uint64_t)w << B.cnt;
+      B.cnt += 32;
+      B.cpos += 4;
+    }
+  };
+  auto bits = [&](int n) -> uint32_t {  // n <= 32
+    if (B.cnt < n) refill();
+    const uint32_t v = (uint32_t)(B.buf & ((1ull << n) - 1ull));
+    B.buf >>= n;
+    B.cnt -= n;
+    return v;
+  };
+  auto overrun = [&]() { return B.cpos - (uint32_t)(B.cnt >> 3) > clen + 8u; };  // more than 8 bytes beyond the stream consumed
+  // canonical walk over (cnt, sym): a code of any length (the slow path of the table decode and the code-length code)
+  auto walk = [&](const uint16_t* cnt, const uint16_t* sym) -> int {
+    if (B.cnt < 15) refill();
+    int code = 0, first = 0, index = 0;
+    uint32_t bb = (uint32_t)B.buf;
+    for (int len = 1; len <= 15; ++len) {
+      code |= (int)(bb & 1u);
+      bb >>= 1;
+      const int count = cnt[len];
+      if (code - count < first) {
+        B.buf >>= len;
+        B.cnt -= len;
+        return sym[index + (code - first)];
+      }
+      index += count;
+      first += count;
+      first <<= 1;
+      code <<= 1;
+    }
+    return -1;
+  };
+  // cnt / sym and the multi-bit table of a code given by lens[off .. off + n); puff.c's verdict: < 0 over-subscribed, > 0 incomplete
+  auto build = [&](uint16_t* cnt, uint16_t* sym, uint16_t* tab, int tbits, int off, int n) -> int {
+    __syncthreads();
+    if (lane < 16) cnt[lane] = 0;
+    for (uint32_t i = lane; i < (1u << tbits); i += 64) tab[i] = 0;
+    __syncthreads();
+    if (lane == 0) {
+      for (int sy = 0; sy < n; ++sy) cnt[lens[off + sy]]++;
+    }
+    __syncthreads();
+    if (cnt[0] == n) return 0;  // no codes: complete, but decoding will fail
+    int left = 1;
+    for (int l = 1; l <= 15; ++l) {
+      left <<= 1;
+      left -= cnt[l];
+      if (left < 0) return left;
+    }
+    if (lane == 0) {  // symbols in code order, and every symbol's canonical code
+      uint16_t offs[16], next[16];
+      offs[1] = 0;
+      for (int l = 1; l < 15; ++l) offs[l + 1] = offs[l] + cnt[l];
+      uint32_t c = 0;
+      for (int l = 1; l <= 15; ++l) {  // first code of every length (RFC 1951 3.2.2)
+        next[l] = (uint16_t)c;
+        c = (c + cnt[l]) << 1;
+      }
+      for (int sy = 0; sy < n; ++sy) {
+        const int l = lens[off + sy];
+        if (l != 0) {
+          sym[offs[l]++] = (uint16_t)sy;
+          codes[sy] = next[l]++;
+        }
+      }
+    }
+    __syncthreads();
+    for (int sy = (int)lane; sy < n; sy += 64) {  // the table: every index whose low l bits are the (bit-reversed) code
+      const int l = lens[off + sy];
+      if (l == 0 || l > tbits) continue;
+      const uint32_t rev = __brev((uint32_t)codes[sy]) >> (32 - l);
+      const uint16_t e = (uint16_t)((sy << 4) | l);
+      for (uint32_t k = rev; k < (1u << tbits); k += 1u << l) tab[k] = e;
+    }
+    __syncthreads();
+    return left;
+  };
+  auto decode = [&](const uint16_t* tab, int tbits, const uint16_t* cnt, const uint16_t* sym) -> int {
+    if (B.cnt < 15) refill();
+    const uint16_t e = tab[(uint32_t)B.buf & ((1u << tbits) - 1u)];
+    if (e) {
+      B.buf >>= (e & 15);
+      B.cnt -= (e & 15);
+      return e >> 4;
+    }
+    return walk(cnt, sym);
+  };
+  uint32_t o = 0, flushed = 0;
+  bool bad = false;
+  stage(0);
+  auto flush = [&](uint32_t upto) {  // ring -> memory, bytes [flushed, upto)
+    __syncthreads();
+    for (uint32_t i = flushed + lane; i < upto; i += 64) out[i] = win[i & (IW_WIN - 1)];
+    __syncthreads();
+    flushed = upto;
+  };
+  for (;;) {
+    const uint32_t last = bits(1);
+    const uint32_t type = bits(2);
+    if (type == 0) {  // stored
+      B.buf >>= (B.cnt & 7);
+      B.cnt -= (B.cnt & 7);
+      const uint32_t len = bits(16), nlen = bits(16);
+      if ((len ^ 0xFFFFu) != nlen || o + len > cap) {
+        bad = true;
+        break;
+      }
+      for (uint32_t i = 0; i < len; ++i) {
+        const uint32_t v = bits(8);
+        if (lane == 0) win[o & (IW_WIN - 1)] = (uint8_t)v;
+        ++o;
+        if (o - flushed >= 16384u) flush(o);
+      }
+      if (overrun()) {  // a stored block cut off by the end of the member (zeros flowed in)
+        bad = true;
+        break;
+      }
+    } else if (type == 3) {
+      bad = true;
+      break;
+    } else {
+      if (type == 1) {  // fixed codes
+        __syncthreads();
+        for (uint32_t sy = lane; sy < 288; sy += 64) lens[sy] = sy < 144 ? 8 : (sy < 256 ? 9 : (sy < 280 ? 7 : 8));
+        if (lane < 30) lens[288 + lane] = 5;
+        __syncthreads();
+        (void)build(lcnt, lsym, ltab, IW_LBITS, 0, 288);
+        (void)build(dcnt, dsym, dtab, IW_DBITS, 288, 30);
+      } else {  // dynamic codes
+        const int nlen = (int)bits(5) + 257, ndist = (int)bits(5) + 1, ncode = (int)bits(4) + 4;
+        if (nlen > 286 || ndist > 30) {
+          bad = true;
+          break;
+        }
+        __syncthreads();
+        if (lane < 19) lens[lane] = 0;
+        __syncthreads();
+        for (int i = 0; i < ncode; ++i) {
+          const uint32_t v = bits(3);
+          if (lane == 0) lens[kClOrder[i]] = (uint8_t)v;
+        }
+        if (build(lcnt, lsym, ltab, 7, 0, 19) != 0) {  // the code-length code must be complete (its table: the low 7 bits of ltab)
+          bad = true;
+          break;
+        }
+        // the code lengths themselves: decoded with the code-length code, written behind it (lens[32 ..]) so that the table of
+        // that code stays valid while they are read
+        int idx = 0;
+        constexpr int LO = 32;
+        while (idx < nlen + ndist) {
+          const int sy = decode(ltab, 7, lcnt, lsym);
+          if (sy < 0) {
+            bad = true;
+            break;
+          }
+          if (sy < 16) {
+            if (lane == 0) lens[LO + idx] = (uint8_t)sy;
+            ++idx;
+          } else {
+            int rep, val = 0;
+            if (sy == 16) {
+              if (idx == 0) {
+                bad = true;
+                break;
+              }
+              __syncthreads();
+              val = lens[LO + idx - 1];
+              rep = 3 + (int)bits(2);
+            } else if (sy == 17) {
+              rep = 3 + (int)bits(3);
+            } else {
+              rep = 11 + (int)bits(7);
+            }
+            if (idx + rep > nlen + ndist) {
+              bad = true;
+              break;
+            }
+            if (lane == 0)
+              for (int q = 0; q < rep; ++q) lens[LO + idx + q] = (uint8_t)val;
+            idx += rep;
+            __syncthreads();
+          }
+        }
+        if (bad) break;
+        __syncthreads();
+        if (lens[LO + 256] == 0) {  // no end-of-block code
+          bad = true;
+          break;
+        }
+        int e = build(lcnt, lsym, ltab, IW_LBITS, LO, nlen);
+        if (e < 0 || (e > 0 && nlen - (int)lcnt[0] != 1)) {  // over-subscribed, or incomplete with more than one code
+          bad = true;
+          break;
+        }
+        e = build(dcnt, dsym, dtab, IW_DBITS, LO + nlen, ndist);
+        if (e < 0 || (e > 0 && ndist - (int)dcnt[0] != 1)) {
+          bad = true;
+          break;
+        }
+      }
+      // literals and length / distance pairs
+      for (;;) {
+        int sy = decode(ltab, IW_LBITS, lcnt, lsym);
+        if (sy < 0 || overrun()) {
+          bad = true;
+          break;
+        }
+        if (sy < 256) {
+          if (o >= cap) {
+            bad = true;
+            break;
+          }
+          if (lane == 0) win[o & (IW_WIN - 1)] = (uint8_t)sy;
+          ++o;
+        } else if (sy == 256) {
+          break;
+        } else {
+          sy -= 257;
+          if (sy >= 29) {
+            bad = true;
+            break;
+          }
+          const uint32_t len = kLenBase[sy] + bits(kLenExtra[sy]);
+          const int ds = decode(dtab, IW_DBITS, dcnt, dsym);
+          if (ds < 0 || ds >= 30) {
+            bad = true;
+            break;
+          }
+          const uint32_t dist = kDistBase[ds] + bits(kDistExtra[ds]);
+          if (dist > o || o + len > cap) {
+            bad = true;
+            break;
+          }
+          // the copy: byte j of the match is byte (j mod dist) of the `dist` bytes before it — every source byte exists before the
+          // copy starts, so the lanes read first and write afterwards without stepping on each other
+          __syncthreads();
+          for (uint32_t j0 = 0; j0 < len; j0 += 64) {
+            const uint32_t j = j0 + lane;
+            uint8_t v = 0;
+            if (j < len) v = win[(o - dist + (dist >= len ? j : j % dist)) & (IW_WIN - 1)];
+            __syncthreads();
+            if (j < len) win[(o + j) & (IW_WIN - 1)] = v;
+          }
+          __syncthreads();
+          o += len;
+        }
+        if (o - flushed >= 16384u) flush(o);
+      }
+      if (bad) break;
+    }
+    if (last) break;
+    if (overrun()) {
+      bad = true;
+      break;
+    }
+  }
+  if (!bad) flush(o);
+  if (!bad && o != cap) bad = true;
+  if (bad && lane == 0) atomicOr(err, 1u);
+}
+
+// CRC32 of every member's payload against its trailer (RFC 1952): a lane per member, slicing-by-4
+__global__ __launch_bounds__(INF_NT) void bgz_crc_k(uint32_t nmem, const BgzMember* __restrict__ mem, const uint8_t* __restrict__ dst,
+                                                    uint32_t* __restrict__ err) {
+  __shared__ uint32_t crct[4][256];
+  for (uint32_t i = threadIdx.x; i < 256; i += INF_NT) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; ++k) c = (c & 1u) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
+    crct[0][i] = c;
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < 256; i += INF_NT) {
+    uint32_t c = crct[0][i];
+    for (int t = 1; t < 4; ++t) {
+      c = crct[0][c & 0xFFu] ^ (c >> 8);
+      crct[t][i] = c;
+    }
+  }
+  __syncthreads();
+  const uint32_t m = blockIdx.x * INF_NT + threadIdx.x;
+  if (m >= nmem) return;
+  const BgzMember M = mem[m];
+  const uint8_t* out = dst + M.dst;
+  const uint32_t cap = M.isize;
+  uint32_t c = 0xFFFFFFFFu;
+  uint32_t i = 0;
+  for (; i < cap && ((uintptr_t)(out + i) & 3u); ++i) c = crct[0][(c ^ out[i]) & 0xFFu] ^ (c >> 8);
+  for (; i + 16 <= cap; i += 16) {
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(out + i);
+    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+    uint32_t x = c ^ w0;
+    c = crct[3][x & 0xFFu] ^ crct[2][(x >> 8) & 0xFFu] ^ crct[1][(x >> 16) & 0xFFu] ^ crct[0][x >> 24];
+    x = c ^ w1;
+    c = crct[3][x & 0xFFu] ^ crct[2][(x >> 8) & 0xFFu] ^ crct[1][(x >> 16) & 0xFFu] ^ crct[0][x >> 24];
+    x = c ^ w2;
+    c = crct[3][x & 0xFFu] ^ crct[2][(x >> 8) & 0xFFu] ^ crct[1][(x >> 16) & 0xFFu] ^ crct[0][x >> 24];
+    x = c ^ w3;
+    c = crct[3][x & 0xFFu] ^ crct[2][(x >> 8) & 0xFFu] ^ crct[1][(x >> 16) & 0xFFu] ^ crct[0][x >> 24];
+  }
+  for (; i < cap; ++i) c = crct[0][(c ^ out[i]) & 0xFFu] ^ (c >> 8);
+  if ((c ^ 0xFFFFFFFFu) != M.crc) atomicOr(err, 1u);
+}
+
+// which inflate: the wave-per-member kernel + the CRC pass, or (TBK_INFLATE_LANE: test hook) the lane-per-member kernel
+static int bgz_inflate_launch(tbk_ctx* ctx, uint32_t nmem, const BgzMember* d_mt, const uint8_t* d_comp, uint8_t* d_out, uint32_t flags,
+                              unsigned long long* d_dbg) {
+  if (getenv("TBK_INFLATE_LANE")) {
+    TBK_LAUNCH(ctx, "bgz_inflate", bgz_inflate_k, cdiv(nmem, INF_NT), INF_NT, 0, nmem, d_mt, d_comp, d_out, flags, d_dbg, ctx->d_err);
+    return 0;
+  }
+  TBK_LAUNCH(ctx, "bgz_inflate", bgz_inflate_wave_k, nmem, 64, 0, nmem, d_mt, d_comp, d_out, ctx->d_err);
+  if (!(flags & 1u)) TBK_LAUNCH(ctx, "bgz_crc", bgz_crc_k, cdiv(nmem, INF_NT), INF_NT, 0, nmem, d_mt, d_out, ctx->d_err);
+  return 0;
+}
+
 }  // namespace
 
 // ---- C ABI ------------------------------------------------------------------------------------------------------------
@@ -407,7 +769,7 @@ extern "C" int tbk_bgzf_inflate(tbk_ctx* ctx, const uint8_t* comp, uint64_t comp
   TBK_HIP(hipMemcpyAsync(d_mt, mt.data(), mt.size() * sizeof(BgzMember), hipMemcpyHostToDevice, ctx->stream));
   unsigned long long* d_dbg = getenv("TBK_INF_DEBUG") ? ws_alloc<unsigned long long>(ctx, 8) : nullptr;
   TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
-  TBK_LAUNCH(ctx, "bgz_inflate", bgz_inflate_k, cdiv(mt.size(), INF_NT), INF_NT, 0, (uint32_t)mt.size(), d_mt, d_comp, d_out, (uint32_t)(getenv("TBK_INF_FLAGS") ? atoi(getenv("TBK_INF_FLAGS")) : 0), d_dbg, ctx->d_err);
+  TBK_TRY(bgz_inflate_launch(ctx, (uint32_t)mt.size(), d_mt, d_comp, d_out, (uint32_t)(getenv("TBK_INF_FLAGS") ? atoi(getenv("TBK_INF_FLAGS")) : 0), d_dbg));
   if (mem != TBK_MEM_DEVICE) TBK_HIP(hipMemcpyAsync(out, d_out, total, hipMemcpyDeviceToHost, ctx->stream));
   uint32_t eb = 0;
   TBK_TRY(tbk_sync_err(ctx, &eb));  // (also waits for the member table upload: `mt` dies with this frame)
@@ -878,8 +1240,7 @@ extern "C" int tbk_bam_decode(tbk_ctx* ctx, uint32_t n_files, const uint8_t* con
   if (tbmerged) memcpy(tb.data(), tbmerged, k);
   TBK_HIP(hipMemcpyAsync(d_tbm, tb.data(), k, hipMemcpyHostToDevice, ctx->stream));
   TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
-  TBK_LAUNCH(ctx, "bgz_inflate", bgz_inflate_k, cdiv(mt.size(), INF_NT), INF_NT, 0, (uint32_t)mt.size(), d_mt, d_comp, B->inf, 0u,
-             (unsigned long long*)nullptr, ctx->d_err);
+  TBK_TRY(bgz_inflate_launch(ctx, (uint32_t)mt.size(), d_mt, d_comp, B->inf, 0u, (unsigned long long*)nullptr));
   TBK_LAUNCH(ctx, "bam_header", bam_header_k, cdiv(k, 64), 64, 0, k, B->inf, d_tab, d_tab + k, d_tab + 2 * k, d_nref, ctx->d_err);
   TBK_LAUNCH(ctx, "bam_index", bam_index_k, k, IDX_NT, 0, B->inf, d_tab, d_tab + k, d_tab + 2 * k, d_tab + 3 * k, d_rec0, d_cnt, ctx->d_err);
   std::vector<uint32_t> cnt(k, 0);

@@ -21,7 +21,25 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
   x ^= x >> 31;
   return x;
 }
-__device__ __forceinline__ uint64_t hash_step(uint64_t h, uint64_t v) { return mix64(h ^ (v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2))); }
+// One step of the strategy-key hash: the state as two 32-bit halves, shifts, adds and xors only.  (It was a splitmix round: two 64-bit
+// multiplies, each three quarter-rate instructions.  The raw window kernel runs this code in nearly every wave — one record in thirty
+// needs a hash, a wave holds 64 — and is bound by its vector instructions: wg_hash_k 6.74 -> see DESIGN.md §3.)
+// For a fixed word the step is a bijection of the state, and for a fixed state it is one-to-one in the word: two keys of equal
+// length that differ in a single word never collide.  Everything else collides at the rate of a 31-bit hash, and every user of the
+// hash verifies the keys themselves behind it (wg_finish_raw_k, col_heads_k; a mismatch reseeds).
+__device__ __forceinline__ uint64_t hash_step(uint64_t h, uint64_t v) {
+  uint32_t a = (uint32_t)h, b = (uint32_t)(h >> 32);
+  a += (uint32_t)v;
+  a += a << 10;
+  a ^= a >> 6;
+  b += (uint32_t)(v >> 32);
+  b ^= a;
+  b += b << 3;
+  b ^= b >> 11;
+  b += b << 15;
+  a ^= b >> 7;
+  return ((uint64_t)b << 32) | a;
+}
 
 // CIGAR words of one record with the first three already in registers (loaded together with the record's other fields, ahead
 // of their use); longer CIGARs read on from memory

@@ -34,6 +34,12 @@
 
 #include <algorithm>
 
+// WG_EXP (build-time, 0 in every shipped build): ablation switches of wg_hash_window for timing runs under rocprofv3 — results are wrong,
+// only the kernel's duration means anything (tools/scratch/wgexp_r4.sh).  1: no table work (probes, claims, group atomics, ranking);
+// 2: no loads (every record a synthetic 100M read); 8: no ranking and no group output.  DESIGN.md §3 has the split they gave.
+#ifndef WG_EXP
+#define WG_EXP 0
+#endif
 #include "dev_common.cuh"
 #include "strategy.cuh"
 #include "tbk_internal.h"
@@ -340,6 +346,17 @@ __device__ __forceinline__ RawA wg_raw_a(const ColIn& I, uint32_t i, bool need_p
 // ... with the record's CIGAR range already at hand (fetched a chunk ahead, wg_hash_window)
 __device__ __forceinline__ RawA wg_raw_a(const ColIn& I, uint32_t i, bool need_prev, uint32_t c0, uint32_t c1) {
   RawA a;
+#if WG_EXP & 2
+  a.pos = (int)(i >> 3);
+  a.tidv = 0;
+  a.fl_mq_sc = (60u << 16);
+  a.nh = 1;
+  a.c0 = c0;
+  a.nc = 1;
+  a.ppos = (int)((need_prev && i > 0 ? i - 1 : i) >> 3);
+  a.ptid = 0;
+  return a;
+#endif
   a.pos = I.pos[i];
   a.tidv = I.tid[i];
   a.fl_mq_sc = (uint32_t)I.flag[i] | ((uint32_t)I.mapq[i] << 16) | (strand_code(I.strand[i]) << 24);
@@ -353,6 +370,12 @@ __device__ __forceinline__ RawA wg_raw_a(const ColIn& I, uint32_t i, bool need_p
 }
 __device__ __forceinline__ CigView wg_raw_b(const ColIn& I, const RawA& a) {
   CigView c;
+#if WG_EXP & 2
+  c.w0 = (100u << 4);
+  c.w1 = c.w2 = 0;
+  c.p = I.cig;
+  return c;
+#endif
   const uint32_t* safe = I.cig_off;  // (always readable)
   c.w0 = *(a.nc > 0 ? I.cig + a.c0 : safe);
   c.w1 = *(a.nc > 1 ? I.cig + a.c0 + 1 : safe);
@@ -527,6 +550,141 @@ __device__ __forceinline__ uint16_t* wg_merge_sort(uint16_t* src, uint16_t* dst,
   return src;
 }
 
+// Ranking without merge rounds.  The merge sort above pays log2(n) rounds of a barrier and a bisection of dependent LDS reads each
+// (n ~ 140 groups per window on config 3: 8 rounds, 36 bisection steps — 6.7 us of a window's 39, measured by leaving it out), for
+// keys that are nearly uniform in their leading word: (reference, start).  Here every group drops into one of 256 buckets by that
+// word — offset from the window's smallest, scaled by a shift so that the largest lands in the last bucket — with one returning LDS
+// atomic, one wave scans the bucket counts, and a group's rank is its bucket's offset plus the number of smaller keys inside its
+// bucket (a handful of compares: ~ 0.5 neighbours per bucket; a pile-up of groups on one base degenerates into counting, which is
+// still correct).  Five barriers, ~ ten LDS round trips.  Windows whose groups span more than 2^31 in (reference, start) — several
+// references in one window — keep the merge sort (uniform decision).
+// bk: 2 * 256 + 3 * WG_NW words of LDS that nobody else uses during the ranking (the table's claim words are dead by then).
+__device__ __forceinline__ int32_t wave_incl_min_i32(int32_t v) {
+#define WG_RED_STEP(ctrl, rm)                                                           \
+  {                                                                                     \
+    const int32_t o = __builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rm, 0xf, false); \
+    v = o < v ? o : v;                                                                  \
+  }
+  WG_RED_STEP(0x111, 0xf)
+  WG_RED_STEP(0x112, 0xf)
+  WG_RED_STEP(0x114, 0xf)
+  WG_RED_STEP(0x118, 0xf)
+  WG_RED_STEP(0x142, 0xa)
+  WG_RED_STEP(0x143, 0xc)
+#undef WG_RED_STEP
+  return v;  // (lane 63: the wave's minimum)
+}
+__device__ __forceinline__ uint32_t wave_incl_sum_dpp(uint32_t v) {
+#define WG_SUM_STEP(ctrl, rm) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rm, 0xf, false);
+  WG_SUM_STEP(0x111, 0xf)
+  WG_SUM_STEP(0x112, 0xf)
+  WG_SUM_STEP(0x114, 0xf)
+  WG_SUM_STEP(0x118, 0xf)
+  WG_SUM_STEP(0x142, 0xa)
+  WG_SUM_STEP(0x143, 0xc)
+#undef WG_SUM_STEP
+  return v;
+}
+constexpr uint32_t WG_RANK_NB = 256;
+template <int E>
+__device__ __forceinline__ uint16_t* wg_bucket_rank(uint16_t* src, uint16_t* dst, uint32_t n, const uint64_t* hi, const uint64_t* lo, uint32_t lim,
+                                                    uint32_t* bk) {
+  const uint32_t t = threadIdx.x;
+  uint32_t* cnt = bk;
+  uint32_t* off = bk + WG_RANK_NB;
+  int32_t* red = reinterpret_cast<int32_t*>(bk + 2 * WG_RANK_NB);  // [3][WG_NW]: minimum, - maximum, every offset fits
+  const uint64_t ref = n ? hi[src[0]] >> 2 : 0ull;
+  uint32_t idx[E], bkt[E], arr[E];
+  int32_t dl[E];
+  int32_t mn = 0x7FFFFFFF, nmx = 0x7FFFFFFF;  // (the maximum as the minimum of the negated offsets)
+  bool ok = true;
+#pragma unroll
+  for (int u = 0; u < E; ++u) {
+    const uint32_t e = t + (uint32_t)u * WG_NT;
+    idx[u] = bkt[u] = arr[u] = 0;
+    dl[u] = 0;
+    if (e < n) {
+      idx[u] = src[e];
+      const int64_t d = (int64_t)((hi[idx[u]] >> 2) - ref);
+      ok = ok && d > -(1ll << 30) && d < (1ll << 30);
+      dl[u] = (int32_t)d;
+      mn = dl[u] < mn ? dl[u] : mn;
+      nmx = -dl[u] < nmx ? -dl[u] : nmx;
+    }
+  }
+  if (t < WG_RANK_NB) cnt[t] = 0;
+  mn = wave_incl_min_i32(mn);
+  nmx = wave_incl_min_i32(nmx);
+  const bool wok = __all(ok);
+  if (lane_id() == 63) {
+    red[t >> 6] = mn;
+    red[WG_NW + (t >> 6)] = nmx;
+    red[2 * WG_NW + (t >> 6)] = wok ? 1 : 0;
+  }
+  __syncthreads();
+  int32_t gmn = 0x7FFFFFFF, gnmx = 0x7FFFFFFF, gok = 1;
+#pragma unroll
+  for (int i = 0; i < WG_NW; ++i) {
+    const int32_t a = red[i], b = red[WG_NW + i];
+    gmn = a < gmn ? a : gmn;
+    gnmx = b < gnmx ? b : gnmx;
+    gok &= red[2 * WG_NW + i];
+  }
+  if (!gok) {  // (uniform) groups of several references in one window
+    __syncthreads();
+    return wg_merge_sort<E>(src, dst, n, hi, lo, lim);
+  }
+  const uint32_t range = n ? (uint32_t)(-gnmx - gmn) : 0u;  // largest offset from the smallest key word (< 2^31)
+  const uint32_t sh = range < WG_RANK_NB ? 0u : (32u - (uint32_t)__builtin_clz(range)) - 8u;  // range >> sh < 256
+#pragma unroll
+  for (int u = 0; u < E; ++u) {
+    const uint32_t e = t + (uint32_t)u * WG_NT;
+    if (e < n) {
+      bkt[u] = (uint32_t)(dl[u] - gmn) >> sh;
+      arr[u] = atomicAdd(&cnt[bkt[u]], 1u);
+    }
+  }
+  __syncthreads();
+  if (t < 64) {  // offsets of the buckets: four counters per lane, one wave
+    const uint32_t c0 = cnt[4 * t], c1 = cnt[4 * t + 1], c2 = cnt[4 * t + 2], c3 = cnt[4 * t + 3];
+    const uint32_t sum = c0 + c1 + c2 + c3;
+    const uint32_t ex = wave_incl_sum_dpp(sum) - sum;
+    off[4 * t] = ex;
+    off[4 * t + 1] = ex + c0;
+    off[4 * t + 2] = ex + c0 + c1;
+    off[4 * t + 3] = ex + c0 + c1 + c2;
+  }
+  __syncthreads();
+  uint32_t ob[E];
+#pragma unroll
+  for (int u = 0; u < E; ++u) {
+    const uint32_t e = t + (uint32_t)u * WG_NT;
+    ob[u] = 0;
+    if (e < n) {
+      ob[u] = off[bkt[u]];
+      dst[ob[u] + arr[u]] = (uint16_t)idx[u];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < E; ++u) {
+    const uint32_t e = t + (uint32_t)u * WG_NT;
+    if (e < n) {
+      const uint32_t c = cnt[bkt[u]];
+      const uint64_t kh = hi[idx[u]], kl = lo[idx[u]];
+      uint32_t r = 0;
+      for (uint32_t j = 0; j < c; ++j) {
+        const uint32_t m = dst[ob[u] + j];
+        const uint64_t mh = hi[m], ml = lo[m];
+        r += ((mh < kh) | ((mh == kh) & ((ml < kl) | ((ml == kl) & (m < idx[u]))))) ? 1u : 0u;
+      }
+      src[ob[u] + r] = (uint16_t)idx[u];
+    }
+  }
+  __syncthreads();
+  return src;
+}
+
 __device__ __forceinline__ unsigned long long wg_fingerprint(uint64_t hi, uint64_t lo, uint64_t seed) {
   // (hi, lo) -> hi * K + lo is one-to-one in lo for equal hi and, for an odd seeded K, collides for two different hi only when
   // their difference times K equals the difference of the lo words; the xor-shift / odd-multiply rounds behind it are bijections
@@ -620,7 +778,7 @@ __global__ __launch_bounds__(1024) void wg_list_k(uint32_t nw, const uint32_t* _
 // emitted (tiebrush.cpp:389-395, :412-419: a TieBrush-merged record enters no sample list).
 template <int SORT_E /* the ranking sorts at most SORT_E * WG_NT groups */, bool RAW, int NR /* records per thread and chunk */, int ST /* RAW: strategy */,
           int GC /* > 0: at most 64 input files, a table of exactly GC slots (compile-time LDS layout); 0: sizes from the arguments */,
-          bool PART = false>
+          bool PART = false, int KA_R = -1 /* see WG_EPILOGUE_ARGS: where the caller's WgRaw ... */, int KA_T = -1 /* ... and WgTemp lie in the kernel's argument segment */>
 __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, const WgTemp& T, uint32_t gcap_arg, uint32_t nwords_arg, uint64_t seed,
                                                uint32_t w, unsigned char* lds, uint32_t* sm_u, uint32_t* s_misc, uint2* s_agg /* [NR * WG_NW] */,
                                                uint32_t* __restrict__ ovf, uint32_t ovf_cap, bool final_tier, uint32_t* __restrict__ err) {
@@ -758,8 +916,12 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
     if (t < n_w) {
       a_fil = piece(pre, t);
       a_src = rb[a_fil] + t;
+#if WG_EXP & 2
+      a_c0 = a_src; a_c1 = a_src + 1;
+#else
       a_c0 = R.I.cig_off[a_src];
       a_c1 = R.I.cig_off[a_src + 1];
+#endif
     }
   }
   // the window streams through in chunks of WG_NT * NR records: NR records per thread so that their loads and probes
@@ -834,8 +996,12 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
           if (e2 < n_w) {
             a_fil = piece(pre, e2);
             a_src = rb[a_fil] + e2;
+#if WG_EXP & 2
+            a_c0 = a_src; a_c1 = a_src + 1;
+#else
             a_c0 = R.I.cig_off[a_src];
             a_c1 = R.I.cig_off[a_src + 1];
+#endif
           }
         }
 #pragma unroll
@@ -873,6 +1039,10 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
       if (t == 0 && (kh[0] ^ kl[0] ^ rec[0] ^ eff[0] ^ kh[NR - 1] ^ rec[NR - 1]) == 0x123456789ull) dbg[31] = 1;  // (the loads have landed)
       phase(2);
     }
+#if WG_EXP & 1
+    if (kh[0] == 0x123456789ull) s_misc[0] = 1;   // (keep the keys alive)
+    actm = 0;
+#endif
 #pragma unroll
     for (int u = 0; u < NR; ++u) {
       if ((actm >> u) & 1u) {
@@ -1003,15 +1173,38 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
   }
   __syncthreads();
   const bool overflow = ONEBAR ? (s_misc[6] | s_misc[7]) != 0 : s_misc[1] != 0;
+#if WG_EXP & 8
+  const uint32_t d = s_misc[0] == 0x7FFFFFFFu ? 1u : 0u;
+#else
   const uint32_t d = s_misc[0];
+#endif
+  // What follows writes through fifteen pointers of T that the chunk loop has no use for.  As kernel arguments they are loaded at the
+  // kernel's entry and stay live across the loop — more scalar registers than the hardware has, so the compiler kept ~ 60 of the loop's
+  // own scalars in lanes of two vector registers and fetched them back with v_readlane at every use (78 of the ~ 650 vector
+  // instructions of a chunk, in a kernel that keeps the vector ALUs busy 4/5 of the time).  Here the epilogue's pointers are read
+  // from the argument segment where they are needed instead: behind an opaque move of the segment's address the loads cannot be hoisted.
+  const WgTemp* TEp = &T;
+  const WgRaw* REp = &R;
+  if constexpr (KA_T >= 0) {
+    const __attribute__((address_space(4))) unsigned char* kp =
+        (const __attribute__((address_space(4))) unsigned char*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    TEp = (const WgTemp*)(kp + KA_T);
+    REp = (const WgRaw*)(kp + KA_R);
+  }
+  const WgTemp& TE = *TEp;
+  const WgRaw& RE = *REp;
   if (!overflow) {
     // ---- rank the groups by key (pa holds their slots in claim order), emit groups and incidences in rank order ----
-    uint16_t* byrank = wg_merge_sort<SORT_E>(pa, pb, d, thi, tlo, gcap);  // d <= 3/4 gcap <= SORT_E * WG_NT
+    // (the claim words are dead: their first 2.1 KB serve the ranking's buckets; gcap >= 272 slots of 8 bytes)
+    uint16_t* byrank = gcap * 8u >= (2u * WG_RANK_NB + 3u * WG_NW) * 4u
+                           ? wg_bucket_rank<SORT_E>(pa, pb, d, thi, tlo, gcap, reinterpret_cast<uint32_t*>(tc))
+                           : wg_merge_sort<SORT_E>(pa, pb, d, thi, tlo, gcap);  // d <= 3/4 gcap <= SORT_E * WG_NT
     // (ranking by counting smaller keys — d broadcast reads per group — was measured slower than the merge rounds: 9.1 vs 8.1 ms)
     phase(8);
-    for (uint32_t g = t; g < d; g += WG_NT) T.c2r[wbase + tci[byrank[g]]] = wbase + g;
+    for (uint32_t g = t; g < d; g += WG_NT) TE.c2r[wbase + tci[byrank[g]]] = wbase + g;
     __syncthreads();
-    const bool fm = !PART && T.fmask != nullptr;  // (<= 64 files) the groups' files travel as bit masks: no incidence list, no offsets
+    const bool fm = !PART && TE.fmask != nullptr;  // (<= 64 files) the groups' files travel as bit masks: no incidence list, no offsets
     uint32_t* nsr = tci;  // (dead from here) [d] samples per group in rank order -> offsets
     if (!fm) {
       for (uint32_t g = t; g < d; g += WG_NT) {
@@ -1031,9 +1224,9 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
         if (i < d) nsr[i] = carry + ex;
         carry += tot;
       }
-      if (t == 0) T.wp_cnt[w] = carry;
+      if (t == 0) TE.wp_cnt[w] = carry;
     }
-    if (t == 0) T.wg_cnt[w] = d;  // (fm: wp_cnt[w] stays 0)
+    if (t == 0) TE.wg_cnt[w] = d;  // (fm: wp_cnt[w] stays 0)
     if constexpr (RAW) {
       const uint32_t ws = wave_sum(npass_t);
       if (lane_id() == 0 && ws) atomicAdd(&s_misc[2], ws);
@@ -1041,39 +1234,39 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
       if (lane_id() == 0 && wl) atomicAdd(&s_misc[3], wl);
     }
     __syncthreads();
-    if (RAW && t == 0 && s_misc[2]) wg_count(R.n_pass, (unsigned long long)s_misc[2]);
-    if (RAW && t == 0 && s_misc[3]) wg_count(R.n_slots, (unsigned long long)s_misc[3]);
-    if (RAW && t == 0 && R.sparse) T.vcnt[w] = s_misc[3];
+    if (RAW && t == 0 && s_misc[2]) wg_count(RE.n_pass, (unsigned long long)s_misc[2]);
+    if (RAW && t == 0 && s_misc[3]) wg_count(RE.n_slots, (unsigned long long)s_misc[3]);
+    if (RAW && t == 0 && RE.sparse) TE.vcnt[w] = s_misc[3];
     for (uint32_t g = t; g < d; g += WG_NT) {
       const uint32_t s = byrank[g];
-      T.hi[wbase + g] = thi[s];
-      T.lo[wbase + g] = tlo[s];
-      T.cnt[wbase + g] = tcnt[s];
-      T.rep[wbase + g] = trep[s];
+      TE.hi[wbase + g] = thi[s];
+      TE.lo[wbase + g] = tlo[s];
+      TE.cnt[wbase + g] = tcnt[s];
+      TE.rep[wbase + g] = trep[s];
       if constexpr (PART) {
-        T.yx[wbase + g] = tbits[s * nwords];
-        T.yd[wbase + g] = tbits[s * nwords + 1];
+        TE.yx[wbase + g] = tbits[s * nwords];
+        TE.yd[wbase + g] = tbits[s * nwords + 1];
       }
       if (fm) {
         const uint32_t b0 = tbits[s * nwords], b1 = nwords > 1u ? tbits[s * nwords + 1] : 0u;
-        T.fmask[wbase + g] = ((uint64_t)b1 << 32) | b0;
-        T.ns[wbase + g] = (uint32_t)(__builtin_popcount(b0) + __builtin_popcount(b1));
+        TE.fmask[wbase + g] = ((uint64_t)b1 << 32) | b0;
+        TE.ns[wbase + g] = (uint32_t)(__builtin_popcount(b0) + __builtin_popcount(b1));
         continue;
       }
       uint32_t pl = nsr[g];
-      T.poff[wbase + g] = pl;
+      TE.poff[wbase + g] = pl;
       uint32_t c = 0;
       for (uint32_t x = 0; x < (PART ? 0u : nwords); ++x) {
         uint32_t bits = tbits[s * nwords + x];
         while (bits) {
           const uint32_t bpos = (uint32_t)__builtin_ctz(bits);
           bits &= bits - 1;
-          T.pinc[wbase + pl] = (x * 32 + bpos) | (g << 16);
+          TE.pinc[wbase + pl] = (x * 32 + bpos) | (g << 16);
           ++pl;
           ++c;
         }
       }
-      T.ns[wbase + g] = c;
+      TE.ns[wbase + g] = c;
     }
     phase(9);
     dbg_done(2, n_w);
@@ -1082,7 +1275,7 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
   // more distinct groups than the table holds: a window of at most WG_CAP records goes to the sort kernel's worklist, a
   // pile-up sends the tile to the sort path
   if (t == 0) {
-    T.wg_cnt[w] = T.wp_cnt[w] = 0;
+    TE.wg_cnt[w] = TE.wp_cnt[w] = 0;
     if (final_tier && n_w > (uint32_t)WG_CAP) {
       atomicOr(err, TBK_DERR_BIGBUCKET);
     } else {
@@ -1097,6 +1290,12 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
 
 // first tier: one block per window that holds records, a table of WG_LDS_HASH bytes (four blocks per CU)
 constexpr int WG_GC64 = (WG_LDS_HASH - (8 * 64 + 8)) / (44 + 4 * 2);  // table slots of the <= 64 files form of the first tier
+// WG_EPILOGUE_ARGS: the leading arguments of wg_hash_k as they lie in its argument segment (every argument at its natural alignment, in order)
+struct WgHashArgs {
+  WgIn In;
+  WgRaw R;
+  WgTemp T;
+};
 template <bool RAW, int ST, int GC, bool PART = false>
 __global__ __launch_bounds__(WG_NT, 8) void wg_hash_k(WgIn In, WgRaw R, WgTemp T, uint32_t gcap, uint32_t nwords, uint64_t seed,
                                                       const uint32_t* __restrict__ wlist, uint32_t* __restrict__ ovf /* [0] count, [1..] windows */,
@@ -1108,8 +1307,8 @@ __global__ __launch_bounds__(WG_NT, 8) void wg_hash_k(WgIn In, WgRaw R, WgTemp T
   // (Blocks b and b + 8 are observed to share an XCD.  Handing each XCD a contiguous eighth of the window list, so that the cache lines in
   // which consecutive windows' pieces meet are found in one L2, was measured slower — 9.0 vs 7.5 ms on config 3: eight times as many
   // streams into every column — so the windows in flight stay one compact range of the tile.)
-  wg_hash_window<2, RAW, RAW ? WG_RR : WG_R, ST, GC, PART>(In, R, T, gcap, nwords, seed, wlist[blockIdx.x], lds, sm_u, s_misc, s_agg, ovf, ovf_cap, false,
-                                                           err);
+  wg_hash_window<2, RAW, RAW ? WG_RR : WG_R, ST, GC, PART, (int)offsetof(WgHashArgs, R), (int)offsetof(WgHashArgs, T)>(
+      In, R, T, gcap, nwords, seed, wlist[blockIdx.x], lds, sm_u, s_misc, s_agg, ovf, ovf_cap, false, err);
 }
 // second tier: the windows with more distinct groups than the first table holds (shallow data) against a table of WG_LDS_HASH2 bytes
 // (two blocks per CU); a fixed grid walks the first tier's worklist.  What overflows again goes to the sort kernel.
