@@ -708,10 +708,12 @@ __global__ __launch_bounds__(INF_NT) void bgz_crc_k(uint32_t nmem, const BgzMemb
   if ((c ^ 0xFFFFFFFFu) != M.crc) atomicOr(err, 1u);
 }
 
-// which inflate: the wave-per-member kernel + the CRC pass, or (TBK_INFLATE_LANE: test hook) the lane-per-member kernel
+// which inflate: the lane-per-member kernel, or (TBK_INFLATE_WAVE) the wave-per-member kernel + the CRC pass.  On the 32 M records
+// with SEQ / QUAL of tools/scratch/dd2_r4.sh (7.6 GB inflated) the two are level — 660 ms and 694 + 3 ms: the wave kernel's LDS
+// (39 KB: the 32 KB window) allows four waves per CU against 192 lanes, and its serial decode pays an LDS round trip per symbol.
 static int bgz_inflate_launch(tbk_ctx* ctx, uint32_t nmem, const BgzMember* d_mt, const uint8_t* d_comp, uint8_t* d_out, uint32_t flags,
                               unsigned long long* d_dbg) {
-  if (getenv("TBK_INFLATE_LANE")) {
+  if (!getenv("TBK_INFLATE_WAVE")) {
     TBK_LAUNCH(ctx, "bgz_inflate", bgz_inflate_k, cdiv(nmem, INF_NT), INF_NT, 0, nmem, d_mt, d_comp, d_out, flags, d_dbg, ctx->d_err);
     return 0;
   }
