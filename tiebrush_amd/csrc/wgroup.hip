@@ -383,6 +383,47 @@ __device__ __forceinline__ CigView wg_raw_b(const ColIn& I, const RawA& a) {
   c.p = I.cig + a.c0;
   return c;
 }
+// The same fields as they come from memory, nothing derived from a loaded value: a record's loads can be issued a chunk ahead and
+// carried across the probes and the barrier without a wait (wg_hash_window, PIPE)
+struct RawL {
+  int32_t pos, tidv, ppos, ptid, nh;
+  uint32_t c0, nc, w0, w1, w2;
+  uint16_t flag;  // (in the width they are loaded in: widening them is an instruction on the loaded value, and waits for it)
+  uint8_t mapq, strand;
+};
+__device__ __forceinline__ RawL wg_raw_l(const ColIn& I, uint32_t i, bool need_prev, uint32_t c0, uint32_t c1) {
+  RawL a;
+#if WG_EXP & 2
+  a.pos = (int)(i >> 3);
+  a.tidv = a.ptid = 0;
+  a.ppos = (int)((need_prev && i > 0 ? i - 1 : i) >> 3);
+  a.nh = 1;
+  a.flag = 0;
+  a.mapq = 60;
+  a.strand = '+';
+  a.c0 = c0;
+  a.nc = 1;
+  a.w0 = 100u << 4;
+  a.w1 = a.w2 = 0;
+  return a;
+#endif
+  a.pos = I.pos[i];
+  a.tidv = I.tid[i];
+  a.flag = I.flag[i];
+  a.mapq = I.mapq[i];
+  a.strand = I.strand[i];
+  a.nh = I.nh[i];
+  a.c0 = c0;
+  a.nc = c1 - c0;
+  const uint32_t j = need_prev && i > 0 ? i - 1 : i;
+  a.ppos = I.pos[j];
+  a.ptid = I.tid[j];
+  const uint32_t* safe = I.cig_off;  // (always readable)
+  a.w0 = *(a.nc > 0 ? I.cig + c0 : safe);
+  a.w1 = *(a.nc > 1 ? I.cig + c0 + 1 : safe);
+  a.w2 = *(a.nc > 2 ? I.cig + c0 + 2 : safe);
+  return a;
+}
 template <int ST>
 __device__ __forceinline__ RawRec wg_raw_c(const WgRaw& R, uint32_t i, const RawA& a, const CigView& c) {
   const uint32_t fl = a.fl_mq_sc & 0xFFFFu;
@@ -924,6 +965,40 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
 #endif
     }
   }
+  // PIPE (the AHEAD form): the loads of a chunk's records are issued a chunk ahead too — right behind the previous chunk's key
+  // computation, whose raw fields they replace in the registers — so that they fly while that chunk probes the table, waits at its
+  // barrier and updates its groups, instead of every wave of the block sitting out a round trip to memory at the top of each chunk
+  // (leaving the loads out altogether, WG_EXP 2, took 1.8 - 2.4 ms of the kernel's 6.7).
+  constexpr bool PIPE = AHEAD;
+  RawL n_l = {};
+  uint32_t n_fil = 0, n_src = 0, n_f0 = 0;
+  bool n_first = true, n_fromem = false;
+  auto issue = [&](uint32_t cb) {  // loads of chunk [cb, cb + WG_NT) (a_* describe it), then where the chunk behind it lies
+    if (cb + (t & ~63u) < n_w) {
+      const uint32_t e1 = cb + t;
+      const bool act1 = e1 < n_w;
+      n_fil = a_fil;
+      n_src = a_src;
+      n_first = !act1 || e1 == pre[n_fil];
+      n_fromem = act1 && (n_first || lane_id() == 0);
+      n_l = wg_raw_l(R.I, n_src, n_fromem, a_c0, a_c1);
+      n_f0 = n_fromem ? R.I.file_off[n_fil] : 0u;
+      const uint32_t e2 = cb + WG_NT + t;
+      a_fil = a_src = a_c0 = a_c1 = 0;
+      if (e2 < n_w) {
+        a_fil = piece(pre, e2);
+        a_src = rb[a_fil] + e2;
+#if WG_EXP & 2
+        a_c0 = a_src;
+        a_c1 = a_src + 1;
+#else
+        a_c0 = R.I.cig_off[a_src];
+        a_c1 = R.I.cig_off[a_src + 1];
+#endif
+      }
+    }
+  };
+  if constexpr (PIPE) issue(0u);
   // the window streams through in chunks of WG_NT * NR records: NR records per thread so that their loads and probes
   // overlap; two barriers per chunk
   for (uint32_t c0 = 0; c0 < n_w; c0 += WG_NT * NR) {
@@ -962,6 +1037,10 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
 #pragma unroll
           for (int v = 0; v < WG_RS; ++v)
             if (lane_id() == 63) s_agg[(u0 + v) * WG_NW + (t >> 6)] = make_uint2(0u, 1u);
+          // (PIPE: such a wave has asked for nothing — issue() has the same guard —, but the compiler's wait-count bookkeeping sees a path
+          // from the loads before the loop to the probes that passes through here and would make EVERY wave wait for its loads before
+          // the probes; an explicit wait on this path, free at run time, tells it that nothing is in flight)
+          if constexpr (PIPE) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), nothing else
           continue;
         }
         RawA ra[WG_RS];
@@ -973,36 +1052,36 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
           const int u = u0 + v;
           const uint32_t e = c0 + (uint32_t)u * WG_NT + t;
           const bool act = e < n_w;
-          if constexpr (AHEAD) {
-            fil[u] = a_fil;  // (0, 0 and an empty CIGAR where there is no record)
-            src[u] = a_src;
+          if constexpr (PIPE) {  // this chunk's fields were asked for a chunk ago (0, 0 and an empty CIGAR where there is no record)
+            fil[u] = n_fil;
+            src[u] = n_src;
+            first[v] = n_first;
+            fromem[v] = n_fromem;
+            f0[v] = n_f0;
+            ra[v].pos = n_l.pos;
+            ra[v].tidv = n_l.tidv;
+            ra[v].ppos = n_l.ppos;
+            ra[v].ptid = n_l.ptid;
+            ra[v].fl_mq_sc = (uint32_t)n_l.flag | ((uint32_t)n_l.mapq << 16) | (strand_code(n_l.strand) << 24);
+            ra[v].nh = n_l.nh;
+            ra[v].c0 = n_l.c0;
+            ra[v].nc = n_l.nc;
+            cv[v].w0 = n_l.w0;
+            cv[v].w1 = n_l.w1;
+            cv[v].w2 = n_l.w2;
+            cv[v].p = R.I.cig + n_l.c0;
           } else {
             fil[u] = act ? piece(pre, e) : 0u;
             src[u] = act ? rb[fil[u]] + e : 0u;
-          }
-          first[v] = !act || e == pre[fil[u]];
-          fromem[v] = act && (first[v] || lane_id() == 0);  // the record before it in its file is not the lane to the left
-          if constexpr (AHEAD)
-            ra[v] = wg_raw_a(R.I, src[u], fromem[v], a_c0, a_c1);
-          else
+            first[v] = !act || e == pre[fil[u]];
+            fromem[v] = act && (first[v] || lane_id() == 0);  // the record before it in its file is not the lane to the left
             ra[v] = wg_raw_a(R.I, src[u], fromem[v]);
-          f0[v] = fromem[v] ? R.I.file_off[fil[u]] : 0u;
-        }
-#pragma unroll
-        for (int v = 0; v < WG_RS; ++v) cv[v] = wg_raw_b(R.I, ra[v]);
-        if constexpr (AHEAD) {  // behind this chunk's loads: where the next chunk's record and its CIGAR are
-          const uint32_t e2 = c0 + WG_NT + t;
-          a_fil = a_src = a_c0 = a_c1 = 0;
-          if (e2 < n_w) {
-            a_fil = piece(pre, e2);
-            a_src = rb[a_fil] + e2;
-#if WG_EXP & 2
-            a_c0 = a_src; a_c1 = a_src + 1;
-#else
-            a_c0 = R.I.cig_off[a_src];
-            a_c1 = R.I.cig_off[a_src + 1];
-#endif
+            f0[v] = fromem[v] ? R.I.file_off[fil[u]] : 0u;
           }
+        }
+        if constexpr (!PIPE) {
+#pragma unroll
+          for (int v = 0; v < WG_RS; ++v) cv[v] = wg_raw_b(R.I, ra[v]);
         }
 #pragma unroll
         for (int v = 0; v < WG_RS; ++v) {
@@ -1034,6 +1113,7 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
         }
       }
       if (errb) atomicOr(err, errb);
+      if constexpr (PIPE) issue(c0 + WG_NT);  // the next chunk's loads, into the registers this chunk's raw fields have just left
     }
     if (dbg) {
       if (t == 0 && (kh[0] ^ kl[0] ^ rec[0] ^ eff[0] ^ kh[NR - 1] ^ rec[NR - 1]) == 0x123456789ull) dbg[31] = 1;  // (the loads have landed)
@@ -1123,6 +1203,9 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
 #pragma unroll
         for (int u = 0; u < NR; ++u)
           if ((actm >> u) & 1u) eff[u] = (uint32_t)R.I.prio_hi[src[u]];
+        // (PIPE: a load under a lane mask whose use sits under another one is "possibly in flight" at every later write of its register
+        // as far as the compiler's wait counts go — it would make every tile wait for the next chunk's loads before the next probes)
+        if constexpr (PIPE) __builtin_amdgcn_s_waitcnt(0x0F70);
       }
     }
 #pragma unroll
