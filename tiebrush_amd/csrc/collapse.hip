@@ -1420,7 +1420,15 @@ __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids
   uint32_t last_pos = 0;
   int last_dist = -1;
   bool overflow = false;
-  uint32_t S0 = 0, E0 = 0, D1 = 0xFFFFFFFFu;
+  // Scalar mirror of the ACTIVE island: node P = [SP, EP], the node behind it starts at DP (none: ~0).  P is the node the last item's
+  // processRead found as `prev` — in a pile-up the island the reads are extending.  (Round 3 mirrored node 0: but once a read
+  // starts beyond the end of node 0 without clearing it — it lies inside a later island, d > 0, and clearTo only runs when d == 0 —
+  // node 0 stays in the list, dead, and every later item of the chain failed the fast test and went through the general path
+  // one by one: 11.9 M of config 3's 13.0 M single items, two thirds of the kernel's instructions.)
+  // What the mirror says is true of the list whenever mirror_ok: any surgery at or before node P + 1 clears the flag, and the
+  // next item looks P up again.  Nodes before P are dead for every later item (sorted, disjoint: their ends lie below SP).
+  uint32_t SP = 0, EP = 0, DP = 0xFFFFFFFFu;
+  int P = -1;
   bool mirror_ok = false;
   // batch loader: lane l holds item tb+l.  The next batch is requested before the current one is processed so that
   // its global-load latency hides behind the (long, scalar-ish) item loop.
@@ -1444,6 +1452,15 @@ __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids
     b.e2 = (have && b.nex > 2) ? ex_e[b.xo + 2] : 0u;
     return b;
   };
+  auto set_mirror = [&](int p) {  // (uniform) node p becomes the active island
+    P = p;
+    if (p >= 0) {
+      SP = rl(ns, p);
+      EP = rl(ne, p);
+      DP = p + 1 < cnt ? rl(ns, p + 1) : 0xFFFFFFFFu;
+    }
+    mirror_ok = true;
+  };
   Batch nxt = load_batch(t0);
   for (uint32_t tb = t0; tb < t1 && !overflow; tb += 64) {
     const Batch cur = nxt;
@@ -1454,43 +1471,40 @@ __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids
     int it_d = 0;
     const int nb = (int)((t1 - tb) < 64u ? (t1 - tb) : 64u);
     for (int j = 0; j < nb && !overflow; ++j) {
-      // scalar mirror of the first two nodes: node 0 = [S0,E0], node 1 starts at D1 (refreshed only after list surgery)
-      if (!mirror_ok) {
-        S0 = cnt > 0 ? rl(ns, 0) : 0u;
-        E0 = cnt > 0 ? rl(ne, 0) : 0u;
-        D1 = cnt > 1 ? rl(ns, 1) : 0xFFFFFFFFu;
-        mirror_ok = true;
-      }
       const uint32_t nex = rl(it_nex, j);
-      // ---- fast path: a maximal run of items that leave the list structure alone.  Exon 0 of such an item falls inside
-      // the first island [S0,E0] and stays clear of the next node (start D1): processRead finds prev = node 0 with
-      // prev.end >= start, so d = start - S0, and mergeRead only stretches node 0's end — no clearTo, no insertion, no
-      // swallow.  Exons 1 and 2 (spliced reads) must each start inside an existing later node and end before that
-      // node's successor starts: mergeRead then only raises that node's end (max), again without surgery.  Node starts
-      // never move inside a run and every raised end stays below the following start, so testing against the list as
-      // it was when the run began is exact.  The run is found for all remaining lanes of the batch at once: a wave
-      // prefix-max of the exon-0 ends gives node 0's end before each item; the later nodes' ends are max-reduced
-      // through LDS afterwards.
+      const uint32_t hd_start = rl(it_start, j), hd_e0 = rl(it_e0, j);
+      if (!mirror_ok) {  // the island this item would extend: the last node that starts before it
+        const uint64_t lt = __ballot(lane < cnt && ns < hd_start);
+        set_mirror((lt == ~0ull ? 64 : __builtin_ctzll(~lt)) - 1);
+      }
+      // ---- fast path: a maximal run of items that leave the list structure alone.  Exon 0 of such an item starts inside the
+      // active island (SP < start <= EP) and stays clear of the next node (end < DP): processRead finds prev = node P (the node
+      // behind it starts beyond EP) with prev.end >= start, so d = start - SP, and mergeRead — whose walk passes the dead nodes
+      // before P without stopping — only stretches node P's end: no clearTo, no insertion, no swallow.  Exons 1 and 2 (spliced
+      // reads) must each start inside an existing later node and end before that node's successor starts: mergeRead then only
+      // raises that node's end (max), again without surgery.  Node starts never move inside a run and every raised end stays
+      // below the following start, so testing against the list as it was when the run began is exact.  The run is found for all
+      // remaining lanes of the batch at once: a wave prefix-max of the exon-0 ends gives node P's end before each item; the
+      // later nodes' ends are max-reduced through LDS afterwards.
       // (the head item's exon 0 is tested on the scalar side first, so an item that cannot start a run costs three
       // compares rather than the whole window analysis)
-      const uint32_t hd_start = rl(it_start, j), hd_e0 = rl(it_e0, j);
-      if (nex <= 3u && cnt >= 1 && E0 < D1 && S0 < hd_start && hd_e0 < D1 && hd_start <= E0) {
+      if (nex <= 3u && P >= 0 && SP < hd_start && hd_e0 < DP && hd_start <= EP) {
         const bool inwin = lane >= j && lane < nb;
         const uint32_t pm = wave_prefix_max(inwin ? it_e0 : 0u);
         uint32_t ex = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x138, 0xf, 0xf, false);  // wave_shr:1 -> exclusive
-        uint32_t ebefore = ex > E0 ? ex : E0;
+        uint32_t ebefore = ex > EP ? ex : EP;
         bool xok = it_nex == 1u;
         bool u1 = false, u2 = false;  // exon 1 / exon 2 raises the end of node n1 / n2
         uint32_t n1 = 0, n2 = 0;
         const uint64_t multi = __ballot(inwin && it_nex >= 2u && it_nex <= 3u);
-        if (multi != 0 && cnt <= YD_FAST_NODES) {
+        if (multi != 0 && cnt - P <= YD_FAST_NODES) {
           bool h1 = false, h2 = false;
           uint32_t UL;  // upper bound, over this window, of the end of the last node
-          if (cnt == 1) {
-            UL = ebefore;  // node 0 is the last node; its end just before this item (own exon 0 ends before exon 1 starts)
+          if (P + 1 == cnt) {
+            UL = ebefore;  // node P is the last node; its end just before this item (own exon 0 ends before exon 1 starts)
           } else {
-            uint32_t Sm = D1, Em = 0;  // D1 == start of node 1
-            for (int m = 1; m < cnt; ++m) {
+            uint32_t Sm = DP, Em = 0;  // DP == start of node P + 1
+            for (int m = P + 1; m < cnt; ++m) {
               Em = rl(ne, m);
               const uint32_t NS = (m + 1 < cnt) ? rl(ns, m + 1) : 0xFFFFFFFFu;
               if (Sm <= it_s1 && it_s1 <= Em && it_e1 < NS) {
@@ -1521,16 +1535,16 @@ __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids
             u2 = h1 && h2;
           }
         }
-        bool okl = inwin && xok && S0 < it_start && it_e0 < D1 && it_start <= ebefore;
+        bool okl = inwin && xok && SP < it_start && it_e0 < DP && it_start <= ebefore;
         uint64_t mk = __ballot(okl) >> j;
         int r = mk == ~0ull ? 64 : __builtin_ctzll(~mk);
         if (r > nb - j) r = nb - j;
         if (r > 0) {
           const bool inrun = lane >= j && lane < j + r;
-          if (inrun) it_d = (int)(it_start - S0);
+          if (inrun) it_d = (int)(it_start - SP);
           uint32_t newE = rl(pm, j + r - 1);
-          if (newE > E0) E0 = newE;
-          if (lane == 0) ne = E0;
+          if (newE > EP) EP = newE;
+          if (lane == P) ne = EP;
           if (__ballot(inrun && u1) != 0) {  // raise the ends of the nodes the later exons landed in
             __shared__ uint32_t upd[64];
             upd[lane] = 0u;
@@ -1539,11 +1553,11 @@ __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids
             if (inrun && u2) atomicMax(&upd[n2], it_e2);
             __syncthreads();
             const uint32_t u = upd[lane];
-            if (lane >= 1 && lane < cnt && u > ne) ne = u;
+            if (lane > P && lane < cnt && u > ne) ne = u;
             __syncthreads();
           }
           last_pos = rl(it_start, j + r - 1);
-          last_dist = (int)(last_pos - S0);
+          last_dist = (int)(last_pos - SP);
           j += r - 1;
           continue;
         }
@@ -1557,32 +1571,28 @@ __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids
         d = last_dist;
       } else {
         d = 0;
-        if (cnt >= 1 && D1 >= rstart) {  // at most node 0 starts before the read: all scalar
-          if (S0 < rstart) {
-            if (E0 >= rstart) {
-              d = (int)(rstart - S0);
-            } else {  // clearTo(node 0)
-              ns = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ns, 0x130, 0xf, 0xf, false);
-              ne = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ne, 0x130, 0xf, 0xf, false);
-              cnt -= 1;
-              S0 = cnt > 0 ? rl(ns, 0) : 0u;
-              E0 = cnt > 0 ? rl(ne, 0) : 0u;
-              D1 = cnt > 1 ? rl(ns, 1) : 0xFFFFFFFFu;
-            }
+        if (cnt >= 1) {
+          int np;  // leading run of nodes that start before the read (the list is sorted)
+          if (P >= 0 && SP < rstart && DP >= rstart) {
+            np = P + 1;  // still node P: all scalar
+          } else {
+            const uint64_t lt = __ballot(lane < cnt && ns < rstart);
+            np = lt == ~0ull ? 64 : __builtin_ctzll(~lt);
+            if (np > 0) set_mirror(np - 1);
           }
-        } else if (cnt >= 1) {
-          uint64_t lt = __ballot(lane < cnt && ns < rstart);
-          int np = lt == ~0ull ? 64 : __builtin_ctzll(~lt);  // leading run of nodes starting before the read
           if (np > 0) {
-            uint32_t ps = rl(ns, np - 1), pe = rl(ne, np - 1);
-            if (pe >= rstart) d = (int)(rstart - ps);
-            if (d == 0) {  // clearTo(prev): drop the first np nodes
-              ns = __shfl(ns, lane + np, 64);
-              ne = __shfl(ne, lane + np, 64);
+            if (EP >= rstart) {
+              d = (int)(rstart - SP);
+            } else {  // clearTo(prev): drop the first np nodes
+              if (np == 1) {
+                ns = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ns, 0x130, 0xf, 0xf, false);
+                ne = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ne, 0x130, 0xf, 0xf, false);
+              } else {
+                ns = __shfl(ns, lane + np, 64);
+                ne = __shfl(ne, lane + np, 64);
+              }
               cnt -= np;
-              S0 = cnt > 0 ? rl(ns, 0) : 0u;
-              E0 = cnt > 0 ? rl(ne, 0) : 0u;
-              D1 = cnt > 1 ? rl(ns, 1) : 0xFFFFFFFFu;
+              set_mirror(cnt > 0 ? 0 : -1);  // (what follows tests the read against the new first node)
             }
           }
         }
@@ -1616,17 +1626,20 @@ __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids
       } else {
         int cur = 0;
         uint32_t k = 0;
-        // exon 0 against node 0, all scalar, when it overlaps node 0 and swallows nothing
-        if (e0 >= S0 && rstart <= E0) {
-          uint32_t newE = e0 > E0 ? e0 : E0;
-          if (newE < D1) {
-            if (rstart < S0) S0 = rstart;
-            E0 = newE;
-            if (lane == 0) {
-              ns = S0;
-              ne = E0;
+        // exon 0 against the active island, all scalar, when it starts inside it and swallows nothing (the walk passes the
+        // dead nodes before P: they end below SP <= start)
+        // (a first node may also be entered from the left — the usual thing right after a clearTo —: nothing lies before it)
+        if (mirror_ok && P >= 0 && rstart <= EP && (P == 0 ? e0 >= SP : SP <= rstart)) {
+          uint32_t newE = e0 > EP ? e0 : EP;
+          if (newE < DP) {
+            if (rstart < SP) SP = rstart;
+            EP = newE;
+            if (lane == P) {
+              ns = SP;
+              ne = EP;
             }
             k = 1;
+            cur = P;
           }
         }
         if (k < nex) {
@@ -1637,7 +1650,7 @@ __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids
             uint64_t stop = __ballot(lane >= cur && lane < cnt && (ee < ns || es <= ne));
             if (stop == 0) break;  // ran off the list: this exon and the rest are dropped
             int n = __builtin_ctzll(stop);
-            if (n < 2) mirror_ok = false;
+            if (n <= P + 1) mirror_ok = false;
             uint32_t nS = rl(ns, n), nE = rl(ne, n);
             if (ee < nS) {  // insert before n
               if (cnt == 64) {
@@ -1670,7 +1683,6 @@ __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids
                   ne = de;
                 }
                 cnt--;
-                if (n + 1 < 2) mirror_ok = false;
                 if (xE > newE) {
                   newE = xE;
                   break;
