@@ -37,6 +37,11 @@ import subprocess
 import sys
 import time
 
+# Every context drives three HIP streams (main, YD, junctions) and the bench runs two or three contexts: with the runtime's default of four
+# hardware queues, streams that should overlap share a queue and run one behind the other.  Eight queues: 18.5 -> 18.3 ms per step on
+# config 3, on every run (tools/scratch/hwq_r4.sh).  Read by the HIP runtime when it starts, so it is set before anything loads it.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

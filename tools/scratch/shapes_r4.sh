@@ -1,16 +1,16 @@
 #!/bin/bash
-mkdir -p gpurun_out/shapes4
-run() { # name args...
-  n=$1; shift
-  timeout -k 10 600 python bench.py --no-cpu-baseline --no-e2e --no-host-path --prof-steps 1 --cov-prof-reps 0 "$@" > gpurun_out/shapes4/$n.json 2> gpurun_out/shapes4/$n.err || { echo "$n FAILED"; tail -5 gpurun_out/shapes4/$n.err; return; }
-  python - <<P
+# the other shapes on the current code: c4 per-rank shape (plain and as a one-rank multi-rank step), c4 as one job, c5 shape
+mkdir -p gpurun_out/shapes
+C="--no-cpu-baseline --no-host-path --no-e2e"
+timeout -k 10 300 python bench.py --profile c4 --scaling weak $C > gpurun_out/shapes/c4.json 2> gpurun_out/shapes/c4.err
+timeout -k 10 300 python bench.py --force-dist --profile c4 $C 2> gpurun_out/shapes/c4d.err | tail -n 1 > gpurun_out/shapes/c4d.json
+timeout -k 10 400 python bench.py --profile c4 --scaling strong $C > gpurun_out/shapes/c4s.json 2> gpurun_out/shapes/c4s.err
+timeout -k 10 300 python bench.py --profile c5 $C > gpurun_out/shapes/c5.json 2> gpurun_out/shapes/c5.err
+python - <<P
 import json
-d=json.load(open("gpurun_out/shapes4/$n.json"))
-print("$n", "ms", d["ms_per_step"], "value %.3g" % d["value"], "hbm", d["config"]["hbm_in_use_gb"], d["config"]["workload"][:60], "scaling", d["scaling"])
+for n in ("c4","c4d","c4s","c5"):
+    try:
+        d=json.load(open("gpurun_out/shapes/%s.json"%n))
+        print(n, "ms", d["ms_per_step"], "value %.3g"%d["value"], "plain", d.get("plain_ms_per_step"), " ".join("%s=%.2f"%(k.split("/")[-1],v) for k,v in list(d["kernel_ms_per_step"].items())[:9]))
+    except Exception as e: print(n, "failed", e)
 P
-}
-run c3 --steps 10 --warmup 3
-run c4strong1 --profile c4 --scaling strong --steps 6 --warmup 2
-run c4weak --profile c4 --steps 20 --warmup 4
-run c5 --profile c5 --steps 10 --warmup 3
-run c2 --profile c2 --steps 40 --warmup 5
