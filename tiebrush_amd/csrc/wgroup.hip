@@ -2318,8 +2318,11 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   }
 #define WG_L_HASH(S) TBK_LAUNCH(ctx, "wg_hash", (wg_hash_k<true, S, 0>), nw_live, WG_NT, lds_hash, In, R, T, gcap, nwords, seed, wlist, ovf, ovf_cap, ctx->d_err)
 #define WG_L_HASH64(S)                                                                                                                       \
-  TBK_LAUNCH(ctx, "wg_hash", (wg_hash_k<true, S, WG_GC64>), nw_live, WG_NT, WG_GC64 * 52u + 8u * 64u + 8u, In, R, T, gcap, nwords, seed, wlist, ovf, \
+  TBK_LAUNCH(ctx, "wg_hash", (wg_hash_k<true, S, WG_GC64>), nw_live, WG_NT, WG_GC64 * 52u + 8u * 64u + 8u + lds_pad, In, R, T, gcap, nwords, seed, wlist, ovf, \
              ovf_cap, ctx->d_err)
+    // TBK_WG_LDS_PAD (measurement hook): bytes of LDS the first-tier kernel asks for beyond its table — 12800 leaves room for three
+    // blocks per CU instead of four, i.e. two wave slots per SIMD for whatever another context has queued
+    const uint32_t lds_pad = getenv("TBK_WG_LDS_PAD") ? (uint32_t)atoi(getenv("TBK_WG_LDS_PAD")) : 0u;
     if (part) {  // group partials: one instantiation, the strategy read from the options
       R.O.strategy = strategy;
       TBK_LAUNCH(ctx, "wg_hash", (wg_hash_k<true, -1, WG_GC64, true>), nw_live, WG_NT, WG_GC64 * 52u + 8u * 64u + 8u, In, R, T, gcap, nwords, seed, wlist,
