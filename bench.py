@@ -162,7 +162,7 @@ def main():
     ap.add_argument("--e2e-runs", type=int, default=3)
     ap.add_argument("--prof-steps", type=int, default=2, help="serialised per-kernel timing steps after the timed region (>= 1)")
     ap.add_argument("--cov-prof-reps", type=int, default=10, help="serialised coverage calls behind roofline_coverage's median")
-    ap.add_argument("--contexts", type=int, default=2, help="contexts (each with its own host thread) that take the steps in turn")
+    ap.add_argument("--contexts", type=int, default=0, help="contexts (each with its own host thread) that take the steps in turn; 0: by the tile's size")
     ap.add_argument("--cpu-sample-records", type=int, default=0, help="size of the CPU-baseline sample (0: the whole tile when host memory allows)")
     ap.add_argument("--cpu-procs", type=int, default=0, help="worker processes of the tiewrap-style CPU line (0: the CPU quota, at most 16)")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank (group-partials) path even with one rank")
@@ -230,18 +230,21 @@ def main():
     # Contexts take the steps in turn (software pipelining of independent tiles, as a streaming host would run them): the YD list
     # machine of step i — deferred onto its context's side stream — overlaps the tiecov chain of step i and the collapse of step
     # i + 1.  Every step's YD is complete before the timed region ends.
-    NCTX = max(1, args.contexts)
+    # (0: three contexts — 17.4 ms per step on config 3 against 17.7 with two and 140 against 97 GB of HBM — while a context's arena stays
+    # below a fifth of the device: two for the 512 M-record tile of config 4 as one job)
+    NCTX = args.contexts if args.contexts > 0 else (3 if n_records <= 400_000_000 else 2)
     ctxs = [api.Context(local_rank) for _ in range(NCTX)]
     ctx = ctxs[0]
     opts_defer = ctx.make_opts(defer_yd=True, **strat)
     cbufs2, vbufs2 = [{} for _ in range(NCTX)], [{} for _ in range(NCTX)]
     cbufs, vbufs = cbufs2[0], vbufs2[0]
 
-    # One collapse at a time: the window kernels fill the GPU, the YD stage and tiecov are chains of short or latency-bound kernels
-    # that run well beside them.  Left alone, two contexts fall into step — both in their window kernels, then both in YD, the
-    # GPU a quarter of the time with nothing but a few long YD chains on it (rocprofv3 timeline, tools/scratch/timeline.py) — so a
-    # context takes the gate for its collapse and the other one's collapse always runs beside this one's YD + tiecov.
-    gate = threading.Lock() if os.environ.get("TBK_BENCH_GATE", "1") != "0" else contextlib.nullcontext()
+    # TBK_BENCH_GATE=1: one collapse at a time.  Rounds 2 and 3 needed it: left alone, two contexts fell into step — both in their
+    # window kernels, then both in YD, the GPU a quarter of the time with nothing but a few long YD chains on it (rocprofv3 timeline,
+    # tools/scratch/timeline.py).  With round 4's kernels (the window kernel a fifth shorter and bound by its vector instructions, the
+    # YD chains by their scalar ones) the contexts do better on their own: 18.3 ms per step with the gate, 17.7 without, 17.4 with
+    # three contexts (tools/scratch/ctxgate_r4.sh) — so the gate is off unless asked for.
+    gate = threading.Lock() if os.environ.get("TBK_BENCH_GATE", "0") != "0" else contextlib.nullcontext()
 
     # group arrays: a quarter of the records (a call that needs more reports it, TBK_E2BIG, and is repeated with the need: the
     # warm-up settles the size); one group per record, the capacity that can never overflow, was 15 GB per context on config 3
