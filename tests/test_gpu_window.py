@@ -59,6 +59,32 @@ def test_many_windows(ctx, window_mode, profile, files, reads, kw):
     _cmp(ctx, tile, **kw)
 
 
+@pytest.mark.parametrize("rank", ["buckets", "merge"])
+def test_ranking_by_buckets_and_by_merge_sort(ctx, window_mode, rank, monkeypatch):
+    """the groups of a window are ranked through 256 buckets of their (reference, start) word (wg_bucket_rank) or, where a window
+    spans several references or TBK_WG_RANK_MERGE asks for it, by the merge sort: both against the oracle on tiles whose windows
+    cross references (three contigs, few loci), whose groups pile up on single bases (every group of a window in one bucket) and
+    whose windows hold more than 512 groups (two groups per thread)"""
+    from tiebrush_amd import synth
+    if rank == "merge":
+        monkeypatch.setenv("TBK_WG_RANK_MERGE", "1")
+    rng = np.random.default_rng(77)
+    for files, reads, profile, kw in ((8, 20000, "c3", dict(strategy="clip")), (2, 60000, "c2", dict()), (40, 3000, "c5", dict(strategy="exon"))):
+        _cmp(ctx, synth.make_tile(files, reads, profile, n_loci=60), **kw)
+    # one base, many shapes: soft clips of every length on both sides under the default strategy -> hundreds of groups with one start
+    recs = []
+    for f in range(6):
+        rows = []
+        for i in range(700):
+            a, b = int(rng.integers(0, 30)), int(rng.integers(0, 30))
+            cig = ([(a, S)] if a else []) + [(100 - a - b, M)] + ([(b, S)] if b else [])
+            rows.append((1, 5000, 0, 60, "+", 1, cig))
+        for i in range(300):
+            rows.append((1, 5001 + i, 16, 60, "-", 1, [(100, M)]))
+        recs.append(rows)
+    _cmp(ctx, _tile(recs))
+
+
 @pytest.mark.parametrize("split", ["by_list", "radix"])
 def test_yd_items_by_list_and_by_radix_split(ctx, window_mode, split, monkeypatch):
     """the YD items of the window path reach their lists without a sort (<= 64 files: bit-matrix ranks, yd_lcount_k /

@@ -449,6 +449,7 @@ struct WgIn {
   const uint32_t* off;         // [(nw + 1) * k]
   const uint64_t* W;           // [nw - 1] bounds (window w = [W[w-1], W[w]))
   uint32_t k, nw;
+  uint32_t rank_merge;         // TBK_WG_RANK_MERGE (test hook): rank a window's groups by the merge sort instead of the buckets
 };
 struct WgTemp {                // per window, at the window's record base
   uint64_t *hi, *lo;           // group key
@@ -1282,7 +1283,7 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
   if (!overflow) {
     // ---- rank the groups by key (pa holds their slots in claim order), emit groups and incidences in rank order ----
     // (the claim words are dead: their first 2.1 KB serve the ranking's buckets; gcap >= 272 slots of 8 bytes)
-    uint16_t* byrank = gcap * 8u >= (2u * WG_RANK_NB + 3u * WG_NW) * 4u
+    uint16_t* byrank = gcap * 8u >= (2u * WG_RANK_NB + 3u * WG_NW) * 4u && !In.rank_merge
                            ? wg_bucket_rank<SORT_E>(pa, pb, d, thi, tlo, gcap, reinterpret_cast<uint32_t*>(tc))
                            : wg_merge_sort<SORT_E>(pa, pb, d, thi, tlo, gcap);  // d <= 3/4 gcap <= SORT_E * WG_NT
     // (ranking by counting smaller keys — d broadcast reads per group — was measured slower than the merge rounds: 9.1 vs 8.1 ms)
@@ -2269,7 +2270,7 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   }
   if (!T.pinc || !pbase || !T.c2r) return TBK_ENOMEM;
   if (raw && !R.sparse) TBK_HIP(hipMemsetAsync(T.cslot, 0xFF, (size_t)m * 4, ctx->stream));  // (only the records wg_finish_raw_k must visit get a slot)
-  WgIn In{chi, clo, cval, ceff, off, W, k, nw};
+  WgIn In{chi, clo, cval, ceff, off, W, k, nw, getenv("TBK_WG_RANK_MERGE") ? 1u : 0u};
   const uint32_t nwords = cdiv(k, 32);
   // LDS of the hash kernel: the pieces' tables (8 k + 4 bytes) and the group table share WG_LDS_HASH (four blocks per CU)
   const uint32_t gcap = (WG_LDS_HASH - (8u * k + 8u)) / (44u + 4u * nwords);
