@@ -232,7 +232,7 @@ def main():
     # i + 1.  Every step's YD is complete before the timed region ends.
     # (0: three contexts — 17.4 ms per step on config 3 against 17.7 with two and 140 against 97 GB of HBM — while a context's arena stays
     # below a fifth of the device: two for the 512 M-record tile of config 4 as one job)
-    NCTX = args.contexts if args.contexts > 0 else (3 if n_records <= 400_000_000 else 2)
+    NCTX = args.contexts if args.contexts > 0 else (3 if n_records <= 400_000_000 and not use_dist else 2)   # (a multi-rank run has its own three)
     ctxs = [api.Context(local_rank) for _ in range(NCTX)]
     ctx = ctxs[0]
     opts_defer = ctx.make_opts(defer_yd=True, **strat)
