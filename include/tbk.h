@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TBK_ABI_VERSION 5
+#define TBK_ABI_VERSION 6
 
 typedef struct tbk_ctx tbk_ctx;
 
@@ -250,6 +250,14 @@ int tbk_bam_decode(tbk_ctx* ctx, uint32_t n_files, const uint8_t* const* comp, c
  * order into `out` (host); out_off[n + 1] (host) = their byte offsets.  TBK_E2BIG with out_off[n] = needed bytes. */
 int tbk_bam_records(tbk_ctx* ctx, const uint32_t* idx, uint32_t n, int idx_mem, uint8_t* out, uint64_t out_cap, uint64_t* out_off);
 void tbk_bam_release(tbk_ctx* ctx);
+/* (ABI version 6) One tile out of two: the files a host decoder took (host_part: a HOST tile, plain inputs only) behind the files
+ * tbk_bam_decode took on this context (dev_part: the tile it returned) — a host and the GPU inflating their shares of the inputs
+ * side by side (the reference's a2, GSamReader::next, GSam.h:506-516, is the end-to-end limiter: SURVEY.md §8 f1).  *out is a
+ * DEVICE tile in context-owned memory (released with the decoded files), its files dev_part's then host_part's, record indices
+ * below dev_part->n_records the ones tbk_bam_records knows; file_off_out[n_files + 1] and tbmerged_out[n_files] are the caller's.
+ * TBK_EUNSUPPORTED when either part carries YC / YX / YD, MD or names. */
+int tbk_tile_join(tbk_ctx* ctx, const tbk_soa_in* dev_part, const tbk_soa_in* host_part, tbk_soa_in* out, uint32_t* file_off_out,
+                  uint8_t* tbmerged_out);
 
 /* ---- Packed wire form of a tile (ABI version 5) ---------------------------------------------------------------------------
  * What a host decoder can hand over instead of tbk_soa_in when the tile has to cross PCIe: the same records in 9 bytes plus the

@@ -153,6 +153,42 @@ def test_bam_decode_matches_host_decoders(ctx, bam_loader):
     ctx.bam_release()
 
 
+def test_record_index_by_member_and_by_chain(ctx, monkeypatch):
+    """the record index of tbk_bam_decode: a lane per BGZF member where every member begins with a record (files written through
+    htslib: the reference's fixtures), the chain of block_size fields per file otherwise (blocks cut at a fixed size: bamio's
+    writer) or when TBK_INDEX_CHAIN asks for it — the same tile every way, and the kernel that ran is the one expected"""
+    from tiebrush_amd import bamio
+    gold = [open(p, "rb").read() for p in sample_paths("t2")[:4] + [os.path.join(GOLDEN, "t12.bam")]]
+    cut = []                                              # the same records in blocks of 0x1234 payload bytes: records span blocks
+    for r in gold[:3]:
+        cut.append(_bgzf(bamio.bgzf_decompress(r), 6, zlib.Z_DEFAULT_STRATEGY, block=0x1234) + bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    fields = ("tid", "pos", "flag", "mapq", "strand", "nh", "cig_off", "cig")
+
+    def decode(files):
+        ctx.set_profiling(True)
+        s, fo = ctx.bam_decode(files)
+        kt = ctx.kernel_times()
+        got = ctx.soa_to_numpy(s, fields=fields)
+        idx = np.arange(0, s.n_records, max(1, s.n_records // 50), dtype=np.uint32)
+        blob, off = ctx.bam_records(idx)
+        ctx.bam_release()
+        ctx.set_profiling(False)
+        return fo.copy(), got, bytes(blob), kt
+
+    fo_m, got_m, blob_m, kt_m = decode(gold)
+    assert "bam_index" in kt_m and "bam_index_chain" not in kt_m         # htslib's blocks: no chain walked
+    monkeypatch.setenv("TBK_INDEX_CHAIN", "1")
+    fo_c, got_c, blob_c, kt_c = decode(gold)
+    monkeypatch.delenv("TBK_INDEX_CHAIN")
+    assert "bam_index_chain" in kt_c and np.array_equal(fo_m, fo_c) and blob_m == blob_c
+    for name in fields:
+        assert np.array_equal(got_m[name], got_c[name]), name
+    fo_x, got_x, blob_x, kt_x = decode(cut + gold[3:])                     # three files need the chain: every file takes it
+    assert "bam_index_chain" in kt_x and np.array_equal(fo_x, fo_m) and blob_x == blob_m
+    for name in fields:
+        assert np.array_equal(got_x[name], got_m[name]), name
+
+
 def test_bam_decode_then_collapse_equals_oracle(ctx, bam_loader):
     """compressed bytes -> device tile -> tbk_collapse_tile, nothing decoded on the host: the golden t2 collapse"""
     from oracle import oracle_ffi as orc

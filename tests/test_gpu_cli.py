@@ -219,8 +219,8 @@ def test_cli_tiling_by_reference_is_exact(tmp_path):
 
 
 def test_cli_decode_paths_give_the_same_record_stream(tmp_path):
-    """the four ways the command line can bring its inputs in — whole-input host loader (default), streaming host reader, tiny
-    streamed tiles, device decode — the two deflate codecs, and the fall-back from a whole-input tile the GPU refuses (out of
+    """the five ways the command line can bring its inputs in — whole-input host loader (default), streaming host reader, tiny
+    streamed tiles, device decode, hybrid (the GPU and the cores a share of the files each) — the two deflate codecs, and the fall-back from a whole-input tile the GPU refuses (out of
     memory) to the streaming path write the same records byte for byte: plain inputs (tags appended to fresh records) and
     TieBrush-merged inputs (tags updated in place, stale integer YC and all)"""
     from tiebrush_amd import bamio
@@ -229,7 +229,9 @@ def test_cli_decode_paths_give_the_same_record_stream(tmp_path):
         streams = {}
         for tag, env in (("whole", {}), ("stream", dict(TBK_HOST_FAST="0")), ("tiles", dict(TBK_TILE_RECORDS="5000")),
                          ("device", dict(TBK_DEVICE_DECODE="1")), ("zlib", dict(TBK_NO_LIBDEFLATE="1")),
-                         ("whole_nomem", dict(TBK_TEST_WHOLE_ENOMEM="1")), ("device_nomem", dict(TBK_DEVICE_DECODE="1", TBK_TEST_WHOLE_ENOMEM="1"))):
+                         ("whole_nomem", dict(TBK_TEST_WHOLE_ENOMEM="1")), ("device_nomem", dict(TBK_DEVICE_DECODE="1", TBK_TEST_WHOLE_ENOMEM="1")),
+                         ("hybrid", dict(TBK_HYBRID="1")), ("hybrid_80", dict(TBK_HYBRID="1", TBK_HYBRID_SHARE="80")),
+                         ("hybrid_nomem", dict(TBK_HYBRID="1", TBK_TEST_WHOLE_ENOMEM="1"))):
             out = str(tmp_path / ("%s_%s.bam" % (name, tag)))
             r = subprocess.run([os.path.join(BIN, "tiebrush"), "-o", out] + paths, check=True, capture_output=True, text=True,
                                env=dict(os.environ, TBK_TIMING="1", **env))
@@ -241,10 +243,14 @@ def test_cli_decode_paths_give_the_same_record_stream(tmp_path):
                 assert "whole-input tile not used" in r.stderr
             if tag == "device_nomem":
                 assert "device decode given up" in r.stderr
+            if tag.startswith("hybrid") and name == "plain":   # (the GPU decodes the first files while the cores decode the rest: tbk_tile_join)
+                assert ("hybrid decode given up" if tag == "hybrid_nomem" else "hybrid path ms: device") in r.stderr, r.stderr
+            if tag.startswith("hybrid") and name == "merged":  # (TieBrush-merged inputs carry tags the joined tile does not: the host loader takes them)
+                assert "hybrid" not in r.stderr
             raw = bamio.bgzf_decompress(open(out, "rb").read())
             streams[tag] = raw[bamio.parse_header(raw)[1]:]
         assert len(streams["whole"]) > 100000
-        for tag in ("stream", "tiles", "device", "zlib", "whole_nomem", "device_nomem"):
+        for tag in ("stream", "tiles", "device", "zlib", "whole_nomem", "device_nomem", "hybrid", "hybrid_80", "hybrid_nomem"):
             assert streams[tag] == streams["whole"], (name, tag)
 
 

@@ -896,6 +896,73 @@ __global__ __launch_bounds__(IDX_NT) void bam_index_k(const uint8_t* __restrict_
   if (threadIdx.x == 0) cnt[f] = (uint32_t)(total < 0xFFFFFFFFull ? total : 0xFFFFFFFFull);
 }
 
+// The record index without the chain.  htslib starts a new BGZF block when the next record does not fit into the current one
+// (bgzf_flush_try in bam_write1), so in a BAM file written through it every block begins with a record: a lane per member walks
+// its own 64 KiB — ~ 270 dependent loads instead of a file's million — and the walks are the file's chain IF each ends exactly where
+// its member ends.  A member whose walk does not (a writer that cuts blocks at a fixed size, a record longer than a block,
+// a corrupt length) flags its file, and flagged files take the chain kernel above, which also decides what is an error.
+//   bam_imem_count_k: records per member;  bam_imem_scan_k: per file, the members' counts -> offsets, the file's total;
+//   bam_imem_emit_k: the walks again, writing rec[cap_off[f] + offset + i]
+__device__ __forceinline__ uint32_t bam_imem_walk(const uint8_t* __restrict__ inf, const BgzMember& M, uint64_t s0, uint64_t fend, uint64_t* out, bool* aligned) {
+  const uint64_t end = M.dst + M.isize;
+  uint64_t p = M.dst > s0 ? M.dst : s0;
+  uint32_t c = 0;
+  bool ok = true;
+  if (end > s0) {
+    while (p < end) {
+      if (p + 4 > fend) {
+        ok = false;
+        break;
+      }
+      const uint32_t bs = ld32(inf + p);
+      if (bs < 32 || p + 4 + (uint64_t)bs > fend) {
+        ok = false;
+        break;
+      }
+      if (out) out[c] = p;
+      ++c;
+      p += 4 + (uint64_t)bs;
+    }
+    ok = ok && p == end;
+  }
+  *aligned = ok;
+  return c;
+}
+__global__ void bam_imem_count_k(uint32_t nmem, const BgzMember* __restrict__ mem, const uint8_t* __restrict__ inf, const uint64_t* __restrict__ fbase,
+                                 const uint64_t* __restrict__ fbytes, const uint64_t* __restrict__ first, uint32_t* __restrict__ mcnt,
+                                 uint32_t* __restrict__ fflag) {
+  const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= nmem) return;
+  const BgzMember M = mem[m];
+  bool aligned;
+  mcnt[m] = bam_imem_walk(inf, M, fbase[M.file] + first[M.file], fbase[M.file] + fbytes[M.file], nullptr, &aligned);
+  if (!aligned) fflag[M.file] = 1u;
+}
+__global__ __launch_bounds__(256) void bam_imem_scan_k(const uint32_t* __restrict__ mfirst /* [k + 1] */, uint32_t* __restrict__ mcnt /* in: counts, out: offsets */,
+                                                       uint32_t* __restrict__ cnt) {
+  __shared__ uint32_t sm[8];
+  const uint32_t f = blockIdx.x, m0 = mfirst[f], m1 = mfirst[f + 1];
+  uint32_t carry = 0;
+  for (uint32_t b = m0; b < m1; b += 256) {
+    const uint32_t i = b + threadIdx.x;
+    const uint32_t v = i < m1 ? mcnt[i] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_excl_sum<uint32_t, 256>(v, sm, &tot);
+    if (i < m1) mcnt[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) cnt[f] = carry;
+}
+__global__ void bam_imem_emit_k(uint32_t nmem, const BgzMember* __restrict__ mem, const uint8_t* __restrict__ inf, const uint64_t* __restrict__ fbase,
+                                const uint64_t* __restrict__ fbytes, const uint64_t* __restrict__ first, const uint64_t* __restrict__ cap_off,
+                                const uint32_t* __restrict__ moff, uint64_t* __restrict__ rec) {
+  const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= nmem) return;
+  const BgzMember M = mem[m];
+  bool aligned;
+  (void)bam_imem_walk(inf, M, fbase[M.file] + first[M.file], fbase[M.file] + fbytes[M.file], rec + cap_off[M.file] + moff[m], &aligned);
+}
+
 struct BamSoA {
   int32_t *tid, *pos, *nh;
   uint16_t* flag;
@@ -1244,11 +1311,35 @@ extern "C" int tbk_bam_decode(tbk_ctx* ctx, uint32_t n_files, const uint8_t* con
   TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
   TBK_TRY(bgz_inflate_launch(ctx, (uint32_t)mt.size(), d_mt, d_comp, B->inf, 0u, (unsigned long long*)nullptr));
   TBK_LAUNCH(ctx, "bam_header", bam_header_k, cdiv(k, 64), 64, 0, k, B->inf, d_tab, d_tab + k, d_tab + 2 * k, d_nref, ctx->d_err);
-  TBK_LAUNCH(ctx, "bam_index", bam_index_k, k, IDX_NT, 0, B->inf, d_tab, d_tab + k, d_tab + 2 * k, d_tab + 3 * k, d_rec0, d_cnt, ctx->d_err);
+  // the record index: a lane per member where every member begins with a record (htslib's writers), the chain per file otherwise
   std::vector<uint32_t> cnt(k, 0);
-  TBK_HIP(hipMemcpyAsync(cnt.data(), d_cnt, k * 4, hipMemcpyDeviceToHost, ctx->stream));
   uint32_t eb = 0;
-  TBK_TRY(tbk_sync_err(ctx, &eb));
+  bool chain = getenv("TBK_INDEX_CHAIN") != nullptr;  // (test hook: the chain kernel whatever the files look like)
+  if (!chain) {
+    std::vector<uint32_t> mfirst(k + 1, 0);
+    for (const BgzMember& m : mt) mfirst[m.file + 1]++;
+    for (uint32_t f = 0; f < k; ++f) mfirst[f + 1] += mfirst[f];
+    uint32_t* d_mfirst = ws_alloc<uint32_t>(ctx, k + 1);
+    uint32_t* d_mcnt = ws_alloc<uint32_t>(ctx, mt.size());
+    uint32_t* d_fflag = ws_alloc<uint32_t>(ctx, k);
+    if (!d_mfirst || !d_mcnt || !d_fflag) return TBK_ENOMEM;
+    TBK_HIP(hipMemcpyAsync(d_mfirst, mfirst.data(), (k + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    TBK_HIP(hipMemsetAsync(d_fflag, 0, k * 4, ctx->stream));
+    TBK_LAUNCH(ctx, "bam_index", bam_imem_count_k, cdiv((uint32_t)mt.size(), 64u), 64, 0, (uint32_t)mt.size(), d_mt, B->inf, d_tab, d_tab + k, d_tab + 2 * k, d_mcnt, d_fflag);
+    TBK_LAUNCH(ctx, "bam_index", bam_imem_scan_k, k, 256, 0, d_mfirst, d_mcnt, d_cnt);
+    TBK_LAUNCH(ctx, "bam_index", bam_imem_emit_k, cdiv((uint32_t)mt.size(), 64u), 64, 0, (uint32_t)mt.size(), d_mt, B->inf, d_tab, d_tab + k, d_tab + 2 * k, d_tab + 3 * k, d_mcnt,
+               d_rec0);
+    std::vector<uint32_t> fflag(k, 0);
+    TBK_HIP(hipMemcpyAsync(fflag.data(), d_fflag, k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TBK_HIP(hipMemcpyAsync(cnt.data(), d_cnt, k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TBK_TRY(tbk_sync_err(ctx, &eb));
+    for (uint32_t f = 0; f < k; ++f) chain = chain || fflag[f] != 0;  // (one file that needs the chain: every file takes it — the kernel is a block per file)
+  }
+  if (chain && !eb) {
+    TBK_LAUNCH(ctx, "bam_index_chain", bam_index_k, k, IDX_NT, 0, B->inf, d_tab, d_tab + k, d_tab + 2 * k, d_tab + 3 * k, d_rec0, d_cnt, ctx->d_err);
+    TBK_HIP(hipMemcpyAsync(cnt.data(), d_cnt, k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TBK_TRY(tbk_sync_err(ctx, &eb));
+  }
   if (eb) {
     ctx->last_error = (eb & 1u) ? "corrupt BGZF member (deflate stream, ISIZE or CRC32)" : (eb & 2u) ? "not a BAM stream / truncated header" : "corrupt BAM record chain";
     bamdev_free(ctx);
@@ -1365,6 +1456,75 @@ extern "C" int tbk_bam_decode(tbk_ctx* ctx, uint32_t n_files, const uint8_t* con
   tile->qname = qn;
   tbk_prof_end_call(ctx);
   return tbk_check_launch(ctx, "bam_decode");
+}
+
+namespace {
+__global__ void join_cig_off_k(uint32_t nb, const uint32_t* __restrict__ src /* [nb + 1], starts at 0 */, uint32_t base, uint32_t* __restrict__ dst) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= nb) dst[i] = src[i] + base;
+}
+}  // namespace
+
+// one device tile: the files decoded on this context, then the files a host decoder took (include/tbk.h)
+extern "C" int tbk_tile_join(tbk_ctx* ctx, const tbk_soa_in* a, const tbk_soa_in* b, tbk_soa_in* out, uint32_t* file_off_out, uint8_t* tbmerged_out) {
+  if (!ctx || !ctx->bam_dev || !a || !b || !out || !file_off_out || !tbmerged_out) return TBK_EINVAL;
+  if (a->mem != TBK_MEM_DEVICE || b->mem != TBK_MEM_HOST) return TBK_EINVAL;
+  if (a->yc_in || a->yx_in || a->yd_in || a->md_off || a->qname_off || a->prio_hi || b->yc_in || b->yx_in || b->yd_in || b->md_off || b->qname_off ||
+      b->prio_hi)
+    return TBK_EUNSUPPORTED;
+  BamDev* B = (BamDev*)ctx->bam_dev;
+  TBK_HIP(hipSetDevice(ctx->device));
+  const uint64_t na = a->n_records, nb = b->n_records, ca = a->n_cigar_ops, cb = b->n_cigar_ops;
+  if (na + nb >= (1ull << 32) || ca + cb >= (1ull << 32) || (uint64_t)a->n_files + b->n_files > 65535) return TBK_E2BIG;
+  const size_t n = (size_t)(na + nb);
+  int32_t* tid = bd_alloc<int32_t>(B, n);
+  int32_t* pos = bd_alloc<int32_t>(B, n);
+  int32_t* nh = bd_alloc<int32_t>(B, n);
+  uint16_t* flag = bd_alloc<uint16_t>(B, n);
+  uint8_t* mapq = bd_alloc<uint8_t>(B, n);
+  uint8_t* strand = bd_alloc<uint8_t>(B, n);
+  uint32_t* cig_off = bd_alloc<uint32_t>(B, n + 1);
+  uint32_t* cig = bd_alloc<uint32_t>(B, (size_t)(ca + cb) + 1);
+  uint32_t* tmp = bd_alloc<uint32_t>(B, (size_t)nb + 1);  // the host part's offsets as they come
+  if (!tid || !pos || !nh || !flag || !mapq || !strand || !cig_off || !cig || !tmp) return TBK_ENOMEM;
+  hipStream_t st = ctx->stream;
+#define TBK_JOIN(dst, fa, fb, T)                                                                             \
+  if (na) TBK_HIP(hipMemcpyAsync(dst, a->fa, (size_t)na * sizeof(T), hipMemcpyDeviceToDevice, st));          \
+  if (nb) TBK_HIP(hipMemcpyAsync(dst + na, b->fb, (size_t)nb * sizeof(T), hipMemcpyHostToDevice, st));
+  TBK_JOIN(tid, tid, tid, int32_t)
+  TBK_JOIN(pos, pos, pos, int32_t)
+  TBK_JOIN(nh, nh, nh, int32_t)
+  TBK_JOIN(flag, flag, flag, uint16_t)
+  TBK_JOIN(mapq, mapq, mapq, uint8_t)
+  TBK_JOIN(strand, strand, strand, uint8_t)
+#undef TBK_JOIN
+  if (ca) TBK_HIP(hipMemcpyAsync(cig, a->cig, (size_t)ca * 4, hipMemcpyDeviceToDevice, st));
+  if (cb) TBK_HIP(hipMemcpyAsync(cig + ca, b->cig, (size_t)cb * 4, hipMemcpyHostToDevice, st));
+  if (na) TBK_HIP(hipMemcpyAsync(cig_off, a->cig_off, (size_t)na * 4, hipMemcpyDeviceToDevice, st));
+  TBK_HIP(hipMemcpyAsync(tmp, b->cig_off, ((size_t)nb + 1) * 4, hipMemcpyHostToDevice, st));
+  join_cig_off_k<<<cdiv((uint32_t)nb + 1u, 256u), 256, 0, st>>>((uint32_t)nb, tmp, (uint32_t)ca, cig_off + na);
+  TBK_HIP(hipStreamSynchronize(st));  // (the host arrays may go once this returns)
+  const uint32_t ka = a->n_files, kb = b->n_files;
+  for (uint32_t f = 0; f <= ka; ++f) file_off_out[f] = a->file_off[f];
+  for (uint32_t f = 1; f <= kb; ++f) file_off_out[ka + f] = (uint32_t)na + b->file_off[f];
+  for (uint32_t f = 0; f < ka; ++f) tbmerged_out[f] = a->tbmerged ? a->tbmerged[f] : 0;
+  for (uint32_t f = 0; f < kb; ++f) tbmerged_out[ka + f] = b->tbmerged ? b->tbmerged[f] : 0;
+  memset(out, 0, sizeof(*out));
+  out->mem = TBK_MEM_DEVICE;
+  out->n_files = ka + kb;
+  out->n_records = (uint32_t)n;
+  out->n_cigar_ops = (uint32_t)(ca + cb);
+  out->file_off = file_off_out;
+  out->tbmerged = tbmerged_out;
+  out->tid = tid;
+  out->pos = pos;
+  out->flag = flag;
+  out->mapq = mapq;
+  out->strand = strand;
+  out->nh = nh;
+  out->cig_off = cig_off;
+  out->cig = cig;
+  return tbk_check_launch(ctx, "tile_join");
 }
 
 // the raw records (block_size field included, i.e. framed as in the BAM stream) behind tile indices, packed in the order given

@@ -198,10 +198,18 @@ int main(int argc, char** argv) {
           failed = 1;
           return;
         }
+        // blocks as htslib cuts them: the header in blocks of its own (bam_hdr_write ends with a flush), and a new block whenever
+        // the next record does not fit into the current one (bgzf_flush_try in bam_write1) — every block begins with a record
+        std::vector<uint8_t> z;
+        auto flush_block = [&]() {
+          if (buf.empty()) return;
+          z.clear();
+          if (!tbh::bgzf_deflate_members(buf.data(), buf.size(), level, z) || !w.write_members(z.data(), z.size())) failed = 1;
+          buf.clear();
+        };
         buf.clear();
         hdr.serialize(buf);
-        w.write(buf.data(), buf.size());
-        buf.clear();
+        flush_block();
         for (uint32_t i = file_off[f]; i < file_off[f + 1]; ++i) {
           char nm[40];
           const int nl = snprintf(nm, sizeof(nm), "r%u_%u", f, i - file_off[f]) + 1;
@@ -219,6 +227,7 @@ int main(int argc, char** argv) {
           const int mdl = with_seq ? snprintf(md, sizeof(md), "%lld", (long long)ql) + 1 : 0;
           const uint32_t extra = with_seq ? 6u * 4u + 3u + (uint32_t)mdl + 6u : 0u;
           const uint32_t body = 32 + (uint32_t)nl + 4 * nc + (lseq + 1) / 2 + lseq + extra + (has_nh ? 4u : 0u) + (has_xs ? 4u : 0u);
+          if (buf.size() + 4 + (size_t)body > 0xff00) flush_block();
           const size_t o = buf.size();
           buf.resize(o + 4 + body);
           uint8_t* p = buf.data() + o;
@@ -272,12 +281,8 @@ int main(int argc, char** argv) {
             a += 4;
           }
           if (has_xs) a[0] = 'X', a[1] = 'S', a[2] = 'A', a[3] = strand[i];
-          if (buf.size() >= ((size_t)4 << 20)) {
-            w.write(buf.data(), buf.size());
-            buf.clear();
-          }
         }
-        if (!buf.empty()) w.write(buf.data(), buf.size());
+        flush_block();
         if (!w.close()) failed = 1;
       }
     };

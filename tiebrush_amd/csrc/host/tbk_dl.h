@@ -22,6 +22,7 @@ struct TbkApi {
   decltype(&tbk_bam_decode) bam_decode = nullptr;
   decltype(&tbk_bam_records) bam_records = nullptr;
   decltype(&tbk_bam_release) bam_release = nullptr;
+  decltype(&tbk_tile_join) tile_join = nullptr;
   std::string error;
 
   bool load() {
@@ -54,6 +55,7 @@ struct TbkApi {
     TBK_BIND(bam_decode, tbk_bam_decode)
     TBK_BIND(bam_records, tbk_bam_records)
     TBK_BIND(bam_release, tbk_bam_release)
+    TBK_BIND(tile_join, tbk_tile_join)
 #undef TBK_BIND
     if (abi_version() != TBK_ABI_VERSION) {
       error = "libtbk.so has another ABI version";

@@ -307,12 +307,190 @@ int main(int argc, char* argv[]) {
       for (auto& x : th) x.join();
       if (failed.load()) GError("Error: deflate failed\n");
     };
+    bool done_fast = false;
+    bool skip_fast = false;  // (the hybrid path below loaded a part of the inputs and gave up: the streaming path takes over)
+    tbh::FastTile& ft = *new tbh::FastTile();  // (gigabytes, needed until the last record is written: left to the process exit)
+    // ---- hybrid decode: records with SEQ / QUAL are ~ 240 inflated bytes each and the run is BGZF on the host's cores (SURVEY.md
+    // §8 f1).  The GPU inflates and decodes the first files of the list (tbk_bam_decode) WHILE the cores inflate and decode the rest
+    // (fastload.cpp); tbk_tile_join makes one device tile of the two, the collapse runs on it, and a representative's raw record
+    // comes from wherever its file was decoded.  TBK_HYBRID=0 / 1 switches it off / on (default: inputs of 768 MB and more),
+    // TBK_HYBRID_SHARE = the device's share of the compressed bytes in per cent (default 40).
+    {
+      const size_t k = inRecords.freaders.size();
+      const char* hy = getenv("TBK_HYBRID");
+      bool eligible = k >= 2 && !(getenv("TBK_HOST_FAST") && atoi(getenv("TBK_HOST_FAST")) == 0) && !getenv("TBK_DEVICE_DECODE") && !getenv("TBK_TILE_RECORDS") &&
+                      opt.strategy != TBK_STRAT_FULL && !opt.collapse_same && !(hy && atoi(hy) == 0);
+      std::vector<std::string> paths(k);
+      std::vector<uint64_t> fsz(k, 0);
+      uint64_t total = 0;
+      for (size_t f = 0; f < k && eligible; ++f) {
+        paths[f] = inRecords.freaders[f]->fname;
+        struct stat st;
+        if (inRecords.freaders[f]->tbMerged || !tbh::bgzf_probe(paths[f]) || stat(paths[f].c_str(), &st) != 0) eligible = false;
+        else fsz[f] = (uint64_t)st.st_size, total += fsz[f];
+      }
+      if (eligible && !(hy && atoi(hy) != 0) && total < ((uint64_t)768 << 20)) eligible = false;
+      if (eligible) {
+        const double share = (getenv("TBK_HYBRID_SHARE") ? atof(getenv("TBK_HYBRID_SHARE")) : 40.0) / 100.0;
+        size_t kd = 0;
+        uint64_t acc = 0;
+        while (kd + 1 < k && (double)(acc + fsz[kd]) <= share * (double)total + (double)fsz[kd] / 2) acc += fsz[kd++];
+        if (kd == 0) kd = 1;
+        size_t budget = (size_t)8 << 30;
+        if (FILE* mf = fopen("/proc/meminfo", "r")) {
+          char line[256];
+          while (fgets(line, sizeof(line), mf))
+            if (strncmp(line, "MemAvailable:", 13) == 0) budget = (size_t)atoll(line + 13) * 1024 / 2;
+          fclose(mf);
+        }
+        if (FILE* cf = fopen("/sys/fs/cgroup/memory.max", "r")) {
+          char q[64];
+          if (fscanf(cf, "%63s", q) == 1 && strcmp(q, "max") != 0) budget = std::min<size_t>(budget, (size_t)atoll(q) / 2);
+          fclose(cf);
+        }
+        auto t0 = tnow();
+        // the device's share, on a thread of its own: read the files, wait for the context, decode
+        tbk_soa_in in_d;
+        memset(&in_d, 0, sizeof(in_d));
+        std::vector<uint32_t> fo_d(kd + 1, 0);
+        std::vector<uint8_t> tb_d(kd, 0);
+        int rc_d = -1;
+        bool read_ok = true;
+        double ms_dread = 0, ms_ddec = 0;
+        std::thread dth([&]() {
+          auto d0 = tnow();
+          std::vector<std::vector<uint8_t>> comp(kd);
+          std::atomic<size_t> nf{0};
+          std::atomic<bool> ok{true};
+          auto w = [&]() {
+            for (;;) {
+              size_t f = nf.fetch_add(1);
+              if (f >= kd) break;
+              comp[f].resize(fsz[f]);
+              FILE* fp = fopen(paths[f].c_str(), "rb");
+              if (!fp || fread(comp[f].data(), 1, fsz[f], fp) != fsz[f]) ok = false;
+              if (fp) fclose(fp);
+            }
+          };
+          std::vector<std::thread> th;
+          for (int t = 0; t < std::min<int>(4, (int)kd); ++t) th.emplace_back(w);
+          for (auto& x : th) x.join();
+          read_ok = ok.load();
+          auto d1 = tnow();
+          ms_dread = tms(d0, d1);
+          if (!read_ok) return;
+          need_ctx();
+          std::vector<const uint8_t*> ptr(kd);
+          for (size_t f = 0; f < kd; ++f) ptr[f] = comp[f].data();
+          rc_d = api.bam_decode(ctx, (uint32_t)kd, ptr.data(), fsz.data(), tb_d.data(), 0, 0, &in_d, fo_d.data());
+          ms_ddec = tms(d1, tnow());
+        });
+        // the cores' share
+        std::vector<std::string> ph(paths.begin() + (long)kd, paths.end());
+        std::vector<uint8_t> tbh_(k - kd, 0);
+        bool fits = false;
+        std::string err;
+        const bool okh = tbh::fast_load(ph, tbh_, nthreads, budget, ft, &fits, err);
+        auto t_host = tnow();
+        dth.join();
+        auto t1 = tnow();
+        if (!okh) GError("Error: reading the input failed (%s)\n", err.c_str());
+        if (!read_ok) GError("Error: reading the input failed\n");
+        if (rc_d != 0 && rc_d != TBK_ENOMEM && rc_d != TBK_E2BIG) GError("Error: decoding the input on the GPU failed: %s (%s)\n", api.strerror_(rc_d), api.last_error(ctx));
+        bool ok = fits && rc_d == 0;
+        tbk_soa_in in;
+        std::vector<uint32_t> fo(k + 1, 0);
+        std::vector<uint8_t> tbm(k, 0);
+        tbk_groups_out out;
+        memset(&out, 0, sizeof(out));
+        RawBuf<uint64_t> roff;
+        RawBuf<uint8_t> blob;
+        std::vector<uint32_t> dev_slot;
+        const uint32_t n_d = in_d.n_records;
+        auto t_join = t1, t_col = t1, t_rec = t1;
+        if (ok) {
+          tbk_soa_in in_h = ft.view();
+          rc = api.tile_join(ctx, &in_d, &in_h, &in, fo.data(), tbm.data());
+          t_join = tnow();
+          if (rc == 0) {
+            const size_t n = in.n_records;
+            rep.resize(n ? n : 1);
+            yc.resize(n ? n : 1);
+            yx.resize(n ? n : 1);
+            yd.resize(n ? n : 1);
+            out.mem = TBK_MEM_HOST;
+            out.cap_groups = (uint32_t)(n ? n : 1);
+            out.rep = rep.data();
+            out.yc = yc.data();
+            out.yx = yx.data();
+            out.yd = yd.data();
+            rc = api.collapse_tile(ctx, &opt, &in, &out);
+            if (rc == 0 && getenv("TBK_TEST_WHOLE_ENOMEM")) rc = TBK_ENOMEM;  // test hook: exercise the fall-back below
+            t_col = tnow();
+            if (rc == TBK_EUNSORTED) GError("Error: an input file is not coordinate-sorted!\n");
+          }
+          if (rc == 0) {  // the representatives the device decoded: their raw records come back from there
+            std::vector<uint32_t> dev_rep;
+            dev_slot.assign(out.n_groups, 0);
+            for (uint32_t g = 0; g < out.n_groups; ++g)
+              if (rep[g] < n_d) {
+                dev_slot[g] = (uint32_t)dev_rep.size();
+                dev_rep.push_back(rep[g]);
+              }
+            roff.resize(dev_rep.size() + 1);
+            blob.resize(dev_rep.size() * 260 + 4096);
+            rc = api.bam_records(ctx, dev_rep.data(), (uint32_t)dev_rep.size(), TBK_MEM_HOST, blob.data(), blob.size(), roff.data());
+            if (rc == TBK_E2BIG) {
+              blob.resize(roff[dev_rep.size()]);
+              rc = api.bam_records(ctx, dev_rep.data(), (uint32_t)dev_rep.size(), TBK_MEM_HOST, blob.data(), blob.size(), roff.data());
+            }
+            t_rec = tnow();
+          }
+          ok = rc == 0;
+          if (!ok && rc != TBK_ENOMEM && rc != TBK_E2BIG && rc != TBK_EUNSUPPORTED)
+            GError("Error: GPU collapse failed: %s (%s)\n", api.strerror_(rc), api.last_error(ctx));
+        }
+        if (ctx_ready) api.bam_release(ctx);
+        if (!ok) {
+          if (timing) fprintf(stderr, "hybrid decode given up (%s): streaming host path\n", rc_d != 0 ? api.strerror_(rc_d) : (fits ? api.strerror_(rc) : "the host's share does not fit"));
+          tbh::big_release_all(nthreads);
+          skip_fast = true;
+        } else {
+          get_record = [&](uint32_t g) {
+            tbh::RecView v;
+            if (rep[g] < n_d) {
+              const uint32_t s = dev_slot[g];
+              v.p = blob.data() + roff[s] + 4;
+              v.len = (uint32_t)(roff[s + 1] - roff[s] - 4);
+            } else {
+              v.p = ft.record(rep[g] - n_d, &v.len);
+            }
+            return v;
+          };
+          write_groups(out.n_groups);
+          auto t3 = tnow();
+          if (timing)
+            fprintf(stderr,
+                    "hybrid path ms: device %zu of %zu files (read %.1f | decode incl. context %.1f) beside host (read %.1f | inflate %.1f | index %.1f | SoA %.1f) = %.1f | "
+                    "join %.1f | collapse %.1f | fetch representatives %.1f | tag+deflate+write %.1f\n",
+                    kd, k, ms_dread, ms_ddec, ft.ms_read, ft.ms_inflate, ft.ms_index, ft.ms_soa, tms(t0, t1), tms(t1, t_join), tms(t_join, t_col), tms(t_col, t_rec),
+                    tms(t_rec, t3));
+          (void)t_host;
+          ms_inflate += tms(t0, t1);
+          ms_gpu += tms(t1, t_rec);
+          ms_tag += tms(t_rec, t3);
+          inCounter += out.n_passed;
+          outCounter += out.n_groups;
+          n_tiles = 1;
+          done_fast = true;
+        }
+      }
+    }
     // ---- whole-input host path: inputs that fit in memory are read, inflated and decoded into the tile in two parallel passes
     // (fastload.cpp) while the helper thread brings the device up; one collapse, one tagged output pass ----
-    bool done_fast = false;
-    tbh::FastTile& ft = *new tbh::FastTile();  // (gigabytes, needed until the last record is written: left to the process exit)
-    if (!(getenv("TBK_HOST_FAST") && atoi(getenv("TBK_HOST_FAST")) == 0) && !(getenv("TBK_DEVICE_DECODE") && atoi(getenv("TBK_DEVICE_DECODE")) != 0) &&
-        !getenv("TBK_TILE_RECORDS") && opt.strategy != TBK_STRAT_FULL && !opt.collapse_same) {
+    if (!done_fast && !skip_fast && !(getenv("TBK_HOST_FAST") && atoi(getenv("TBK_HOST_FAST")) == 0) &&
+        !(getenv("TBK_DEVICE_DECODE") && atoi(getenv("TBK_DEVICE_DECODE")) != 0) && !getenv("TBK_TILE_RECORDS") && opt.strategy != TBK_STRAT_FULL &&
+        !opt.collapse_same) {
       const size_t k = inRecords.freaders.size();
       bool all_bam = true;  // (SAM text inputs are converted by the streaming reader)
       std::vector<std::string> paths(k);

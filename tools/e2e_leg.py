@@ -56,7 +56,7 @@ def leg(files, reads, profile, flags, seq, runs, device_decode, desc):
                "wall_s": round(med, 3), "wall_s_min": round(ts[0], 3), "wall_s_max": round(ts[-1], 3), "runs": len(ts),
                "input_bam_bytes": in_bytes, "input_bytes_per_record": round(in_bytes / n, 1),
                "output_bam_bytes": os.path.getsize(out), "summary": summary,
-               "phases": [l for l in r.stderr.split("\n") if l.startswith("host path") or l.startswith("writer closed") or l.startswith("released")
+               "phases": [l for l in r.stderr.split("\n") if l.startswith("host path") or l.startswith("hybrid path") or l.startswith("writer closed") or l.startswith("released")
                           or l.startswith("timing ms") or l.startswith("tiles:")][-5:],
                "generation_s": round(t_gen, 1)}
         if device_decode:
