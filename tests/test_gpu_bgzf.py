@@ -11,20 +11,20 @@ from helpers import GOLDEN, sample_paths
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["lane", "wave"])
+@pytest.fixture(scope="module", params=["wave", "lane"])
 def ctx(request):
-    """every test of this file runs on both inflate kernels: a lane per member (the default) and a wave per member
-    (TBK_INFLATE_WAVE, bamdev.hip: bgz_inflate_launch)"""
+    """every test of this file runs on both inflate kernels: a wave per member (the default) and a lane per member
+    (TBK_INFLATE_LANE, bamdev.hip: bgz_inflate_launch)"""
     from tiebrush_amd import api
-    old = os.environ.pop("TBK_INFLATE_WAVE", None)
-    if request.param == "wave":
-        os.environ["TBK_INFLATE_WAVE"] = "1"
+    old = os.environ.pop("TBK_INFLATE_LANE", None)
+    if request.param == "lane":
+        os.environ["TBK_INFLATE_LANE"] = "1"
     c = api.Context(0)
     yield c
     c.close()
-    os.environ.pop("TBK_INFLATE_WAVE", None)
+    os.environ.pop("TBK_INFLATE_LANE", None)
     if old is not None:
-        os.environ["TBK_INFLATE_WAVE"] = old
+        os.environ["TBK_INFLATE_LANE"] = old
 
 
 def _bgzf(payload: bytes, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, block=0xff00) -> bytes:

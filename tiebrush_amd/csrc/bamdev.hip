@@ -617,7 +617,7 @@ __global__ __launch_bounds__(64) void bgz_inflate_wave_k(uint32_t nmem, const Bg
             bad = true;
             break;
           }
-          if (lane == 0) win[o & (IW_WIN - 1)] = (uint8_t)sy;
+          win[o & (IW_WIN - 1)] = (uint8_t)sy;  // (every lane the same byte to the same place: one LDS write)
           ++o;
         } else if (sy == 256) {
           break;
@@ -627,28 +627,52 @@ __global__ __launch_bounds__(64) void bgz_inflate_wave_k(uint32_t nmem, const Bg
             bad = true;
             break;
           }
-          const uint32_t len = kLenBase[sy] + bits(kLenExtra[sy]);
+          // base and extra bits of the length / distance codes by arithmetic (RFC 1951 3.2.5): a table in constant memory was a
+          // scalar load, two of them dependent, per match
+          const uint32_t lx = sy < 8 || sy == 28 ? 0u : ((uint32_t)sy >> 2) - 1u;
+          const uint32_t lb = sy < 8 ? (uint32_t)sy + 3u : (sy == 28 ? 258u : ((4u + ((uint32_t)sy & 3u)) << lx) + 3u);
+          const uint32_t len = lb + (lx ? bits((int)lx) : 0u);
           const int ds = decode(dtab, IW_DBITS, dcnt, dsym);
           if (ds < 0 || ds >= 30) {
             bad = true;
             break;
           }
-          const uint32_t dist = kDistBase[ds] + bits(kDistExtra[ds]);
+          const uint32_t dx = ds < 2 ? 0u : ((uint32_t)ds >> 1) - 1u;
+          const uint32_t db = ds < 2 ? (uint32_t)ds + 1u : ((2u + ((uint32_t)ds & 1u)) << dx) + 1u;
+          const uint32_t dist = db + (dx ? bits((int)dx) : 0u);
           if (dist > o || o + len > cap) {
             bad = true;
             break;
           }
-          // the copy: byte j of the match is byte (j mod dist) of the `dist` bytes before it — every source byte exists before the
-          // copy starts, so the lanes read first and write afterwards without stepping on each other
-          __syncthreads();
-          for (uint32_t j0 = 0; j0 < len; j0 += 64) {
-            const uint32_t j = j0 + lane;
-            uint8_t v = 0;
-            if (j < len) v = win[(o - dist + (dist >= len ? j : j % dist)) & (IW_WIN - 1)];
-            __syncthreads();
-            if (j < len) win[(o + j) & (IW_WIN - 1)] = v;
+          // The copy.  The block is one wave and a wave's LDS instructions execute in the order they were issued: a read sees the
+          // ring as the writes before it left it, no barrier needed.  A distance of 64 and more: no lane reads what a lane of the
+          // same instruction writes, chunks of 64 bytes in order are the byte-by-byte copy.  Shorter distances: byte j of the
+          // match is byte (j mod dist) of the `dist` bytes before it, all of which exist before the copy starts (a distance of 1
+          // — a run — is one byte for every lane).
+          if (dist >= 64u || dist >= len) {
+            for (uint32_t j0 = 0; j0 < len; j0 += 64) {
+              const uint32_t j = j0 + lane;
+              if (j < len) win[(o + j) & (IW_WIN - 1)] = win[(o - dist + j) & (IW_WIN - 1)];
+            }
+          } else if (dist == 1u) {
+            const uint8_t v = win[(o - 1u) & (IW_WIN - 1)];
+            for (uint32_t j0 = 0; j0 < len; j0 += 64) {
+              const uint32_t j = j0 + lane;
+              if (j < len) win[(o + j) & (IW_WIN - 1)] = v;
+            }
+          } else {
+            uint8_t v[5];  // len <= 258: at most five chunks, all read before the first is written
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+              const uint32_t j = (uint32_t)q * 64u + lane;
+              v[q] = j < len ? win[(o - dist + j % dist) & (IW_WIN - 1)] : (uint8_t)0;
+            }
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+              const uint32_t j = (uint32_t)q * 64u + lane;
+              if (j < len) win[(o + j) & (IW_WIN - 1)] = v[q];
+            }
           }
-          __syncthreads();
           o += len;
         }
         if (o - flushed >= 16384u) flush(o);
@@ -708,12 +732,14 @@ __global__ __launch_bounds__(INF_NT) void bgz_crc_k(uint32_t nmem, const BgzMemb
   if ((c ^ 0xFFFFFFFFu) != M.crc) atomicOr(err, 1u);
 }
 
-// which inflate: the lane-per-member kernel, or (TBK_INFLATE_WAVE) the wave-per-member kernel + the CRC pass.  On the 32 M records
-// with SEQ / QUAL of tools/scratch/dd2_r4.sh (7.6 GB inflated) the two are level — 660 ms and 694 + 3 ms: the wave kernel's LDS
-// (39 KB: the 32 KB window) allows four waves per CU against 192 lanes, and its serial decode pays an LDS round trip per symbol.
+// which inflate: the wave-per-member kernel + the CRC pass, or (TBK_INFLATE_LANE: test hook) the lane-per-member kernel.  On the 32 M
+// records with SEQ / QUAL of tools/scratch/dd2_r4.sh (7.6 GB inflated): lane per member 664 ms; wave per member 694 ms as first
+// written, 605 + 4 ms since a match is copied without barriers (one wave: its LDS instructions execute in order) and the codes'
+// base and extra bits come from arithmetic instead of tables in constant memory.  Still ~ 900 cycles a symbol: four waves per CU
+// (39 KB of LDS each) and a serial decode.
 static int bgz_inflate_launch(tbk_ctx* ctx, uint32_t nmem, const BgzMember* d_mt, const uint8_t* d_comp, uint8_t* d_out, uint32_t flags,
                               unsigned long long* d_dbg) {
-  if (!getenv("TBK_INFLATE_WAVE")) {
+  if (getenv("TBK_INFLATE_LANE")) {
     TBK_LAUNCH(ctx, "bgz_inflate", bgz_inflate_k, cdiv(nmem, INF_NT), INF_NT, 0, nmem, d_mt, d_comp, d_out, flags, d_dbg, ctx->d_err);
     return 0;
   }
