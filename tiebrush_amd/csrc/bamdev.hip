@@ -395,7 +395,14 @@ __global__ __launch_bounds__(64) void bgz_inflate_wave_k(uint32_t nmem, const Bg
   IwBits B{0ull, 0, 0u, 0u};
   auto stage = [&](uint32_t base) {  // cin <- stream bytes [base, base + IW_CIN), zeros beyond the member
     __syncthreads();
-    for (uint32_t i = lane; i < IW_CIN; i += 64) cin[i] = base + i < clen ? cs[base + i] : (uint8_t)0;
+    uint8_t t[IW_CIN / 64];  // (all the loads first: a loop of load-and-store waits for memory once per byte)
+#pragma unroll
+    for (int q = 0; q < IW_CIN / 64; ++q) {
+      const uint32_t i = (uint32_t)q * 64u + lane;
+      t[q] = base + i < clen ? cs[base + i] : (uint8_t)0;
+    }
+#pragma unroll
+    for (int q = 0; q < IW_CIN / 64; ++q) cin[(uint32_t)q * 64u + lane] = t[q];
     __syncthreads();
     B.cbase = base;
   };
