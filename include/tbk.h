@@ -258,6 +258,10 @@ void tbk_bam_release(tbk_ctx* ctx);
  * TBK_EUNSUPPORTED when either part carries YC / YX / YD, MD or names. */
 int tbk_tile_join(tbk_ctx* ctx, const tbk_soa_in* dev_part, const tbk_soa_in* host_part, tbk_soa_in* out, uint32_t* file_off_out,
                   uint8_t* tbmerged_out);
+/* (ABI version 6) Size the context's work arena now for a tbk_collapse_tile of a tile of about this shape (the window path and its
+ * deferred YD stage): growing the arena is a free and an allocation of gigabytes, ~ 0.1 s that a host can put beside its own
+ * decoding instead of inside the collapse call.  Purely an optimisation: a collapse sizes the arena itself when it has to. */
+int tbk_reserve_tile(tbk_ctx* ctx, uint64_t n_records, uint64_t n_cigar_ops);
 
 /* ---- Packed wire form of a tile (ABI version 5) ---------------------------------------------------------------------------
  * What a host decoder can hand over instead of tbk_soa_in when the tile has to cross PCIe: the same records in 9 bytes plus the

@@ -47,6 +47,9 @@ def _payloads():
         "text": text,                                                                  # long matches, overlapping copies
         "runs": b"\0" * 70_000 + b"\xff" * 70_000 + bytes(range(256)) * 300,           # distance-1 copies
         "mixed": rng.integers(0, 4, 200_000, dtype=np.uint8).tobytes() + text[:100_000],
+        # matches from 9 - 30 KB back: beyond the wave kernel's LDS ring (the bytes come back from memory), up to deflate's reach
+        "far": b"".join(blk + rng.integers(0, 256, gap, dtype=np.uint8).tobytes() + blk
+                        for blk, gap in ((rng.integers(0, 256, 700, dtype=np.uint8).tobytes(), g) for g in (8100, 8200, 9000, 15000, 31000, 20000))),
         "tiny": b"x",
         "empty_then_data": b"",
     }

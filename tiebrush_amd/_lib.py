@@ -23,7 +23,7 @@ SYMBOLS = ["tbk_abi_version", "tbk_create", "tbk_destroy", "tbk_strerror", "tbk_
            "tbk_get_stream", "tbk_set_profiling", "tbk_kernel_times", "tbk_host_alloc", "tbk_host_free",
            "tbk_collapse_opts_default", "tbk_collapse_tile", "tbk_collapse_finish_yd", "tbk_coverage_tile", "tbk_sample_tile",
            "tbk_groups_to_cov_in", "tbk_bgzf_inflate", "tbk_bam_decode", "tbk_bam_records", "tbk_bam_release", "tbk_shard_prepare", "tbk_shard_probe_max", "tbk_shard_probe_next",
-           "tbk_shard_pack", "tbk_shard_unpack", "tbk_partial_keys", "tbk_partial_pack", "tbk_partial_unpack", "tbk_partial_reduce", "tbk_unpack_tile", "tbk_tile_join"]
+           "tbk_shard_pack", "tbk_shard_unpack", "tbk_partial_keys", "tbk_partial_pack", "tbk_partial_unpack", "tbk_partial_reduce", "tbk_unpack_tile", "tbk_tile_join", "tbk_reserve_tile"]
 
 
 class CollapseOpts(C.Structure):
@@ -132,6 +132,8 @@ def load():
     L.tbk_partial_unpack.argtypes = [_P, _P, C.c_uint32] + [_P] * 12
     L.tbk_tile_join.argtypes = [_P, C.POINTER(SoaIn), C.POINTER(SoaIn), C.POINTER(SoaIn), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]
     L.tbk_tile_join.restype = C.c_int
+    L.tbk_reserve_tile.argtypes = [_P, C.c_uint64, C.c_uint64]
+    L.tbk_reserve_tile.restype = C.c_int
     L.tbk_unpack_tile.argtypes = [_P, C.POINTER(PackedIn), C.POINTER(SoaIn)]
     _lib = L
     return L

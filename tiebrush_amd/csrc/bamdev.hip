@@ -368,7 +368,13 @@ __global__ __launch_bounds__(INF_NT) void bgz_inflate_k(uint32_t nmem, const Bgz
 // leaves the ring in coalesced runs of 16 KiB.  The compressed stream is staged through LDS 2 KiB at a time.  CRC32 is checked by
 // bgz_crc_k afterwards (a lane per member is the right shape for that: 64 independent table walks per wave).
 // Same verdicts as the kernel above on malformed streams (tests/test_gpu_bgzf.py runs both).
-constexpr int IW_WIN = 32768, IW_CIN = 2048, IW_LBITS = 10, IW_DBITS = 9;
+#ifndef IW_WIN_BYTES
+#define IW_WIN_BYTES 8192
+#endif
+// IW_WIN: the LDS ring.  Not the 32 KiB a deflate distance can reach but the 8 KiB nearly every distance in a BAM stream stays within
+// (the previous records: names, tags, quality runs): four times as many waves per CU hide each other's LDS round trips, and the
+// rare match from farther back is read from the output in memory, which is flushed every IW_FLUSH bytes (before the ring is).
+constexpr int IW_WIN = IW_WIN_BYTES, IW_FLUSH = IW_WIN / 4, IW_CIN = 2048, IW_LBITS = 10, IW_DBITS = 9;
 
 struct IwBits {  // uniform across the wave
   uint64_t buf;
@@ -391,7 +397,7 @@ __global__ __launch_bounds__(64) void bgz_inflate_wave_k(uint32_t nmem, const Bg
   const BgzMember M = mem[m];
   const uint8_t* cs = src + M.src;
   uint8_t* out = dst + M.dst;
-  const uint32_t clen = M.clen, cap = M.isize;
+  const uint32_t clen = (uint32_t)__builtin_amdgcn_readfirstlane((int)M.clen), cap = (uint32_t)__builtin_amdgcn_readfirstlane((int)M.isize);
   IwBits B{0ull, 0, 0u, 0u};
   auto stage = [&](uint32_t base) {  // cin <- stream bytes [base, base + IW_CIN), zeros beyond the member
     __syncthreads();
@@ -409,7 +415,9 @@ __global__ __launch_bounds__(64) void bgz_inflate_wave_k(uint32_t nmem, const Bg
   auto refill = [&]() {  // at least 32 bits in the buffer afterwards
     while (B.cnt <= 32) {
       if (B.cpos + 4u > B.cbase + IW_CIN) stage(B.cpos);
-      const uint32_t w = *reinterpret_cast<const uint32_t*>(cin + (B.cpos - B.cbase));
+      // (what comes out of LDS is the same in every lane; saying so — readfirstlane — keeps the decoder's state in scalar registers:
+      // scalar shifts and branches instead of 64-lane ones under lane masks)
+      const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)*reinterpret_cast<const uint32_t*>(cin + (B.cpos - B.cbase)));
       B.buf |= (uint64_t)w << B.cnt;
       B.cnt += 32;
       B.cpos += 4;
@@ -431,11 +439,11 @@ __global__ __launch_bounds__(64) void bgz_inflate_wave_k(uint32_t nmem, const Bg
     for (int len = 1; len <= 15; ++len) {
       code |= (int)(bb & 1u);
       bb >>= 1;
-      const int count = cnt[len];
+      const int count = __builtin_amdgcn_readfirstlane((int)cnt[len]);
       if (code - count < first) {
         B.buf >>= len;
         B.cnt -= len;
-        return sym[index + (code - first)];
+        return __builtin_amdgcn_readfirstlane((int)sym[index + (code - first)]);
       }
       index += count;
       first += count;
@@ -454,11 +462,11 @@ __global__ __launch_bounds__(64) void bgz_inflate_wave_k(uint32_t nmem, const Bg
       for (int sy = 0; sy < n; ++sy) cnt[lens[off + sy]]++;
     }
     __syncthreads();
-    if (cnt[0] == n) return 0;  // no codes: complete, but decoding will fail
+    if (__builtin_amdgcn_readfirstlane((int)cnt[0]) == n) return 0;  // no codes: complete, but decoding will fail
     int left = 1;
     for (int l = 1; l <= 15; ++l) {
       left <<= 1;
-      left -= cnt[l];
+      left -= __builtin_amdgcn_readfirstlane((int)cnt[l]);
       if (left < 0) return left;
     }
     if (lane == 0) {  // symbols in code order, and every symbol's canonical code
@@ -491,7 +499,7 @@ __global__ __launch_bounds__(64) void bgz_inflate_wave_k(uint32_t nmem, const Bg
   };
   auto decode = [&](const uint16_t* tab, int tbits, const uint16_t* cnt, const uint16_t* sym) -> int {
     if (B.cnt < 15) refill();
-    const uint16_t e = tab[(uint32_t)B.buf & ((1u << tbits) - 1u)];
+    const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)tab[(uint32_t)B.buf & ((1u << tbits) - 1u)]);
     if (e) {
       B.buf >>= (e & 15);
       B.cnt -= (e & 15);
@@ -505,6 +513,7 @@ __global__ __launch_bounds__(64) void bgz_inflate_wave_k(uint32_t nmem, const Bg
   auto flush = [&](uint32_t upto) {  // ring -> memory, bytes [flushed, upto)
     __syncthreads();
     for (uint32_t i = flushed + lane; i < upto; i += 64) out[i] = win[i & (IW_WIN - 1)];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (a match from beyond the ring reads these bytes back from memory)
     __syncthreads();
     flushed = upto;
   };
@@ -523,7 +532,7 @@ __global__ __launch_bounds__(64) void bgz_inflate_wave_k(uint32_t nmem, const Bg
         const uint32_t v = bits(8);
         if (lane == 0) win[o & (IW_WIN - 1)] = (uint8_t)v;
         ++o;
-        if (o - flushed >= 16384u) flush(o);
+        if (o - flushed >= (uint32_t)IW_FLUSH) flush(o);
       }
       if (overrun()) {  // a stored block cut off by the end of the member (zeros flowed in)
         bad = true;
@@ -578,7 +587,7 @@ __global__ __launch_bounds__(64) void bgz_inflate_wave_k(uint32_t nmem, const Bg
                 break;
               }
               __syncthreads();
-              val = lens[LO + idx - 1];
+              val = __builtin_amdgcn_readfirstlane((int)lens[LO + idx - 1]);
               rep = 3 + (int)bits(2);
             } else if (sy == 17) {
               rep = 3 + (int)bits(3);
@@ -597,17 +606,17 @@ __global__ __launch_bounds__(64) void bgz_inflate_wave_k(uint32_t nmem, const Bg
         }
         if (bad) break;
         __syncthreads();
-        if (lens[LO + 256] == 0) {  // no end-of-block code
+        if (__builtin_amdgcn_readfirstlane((int)lens[LO + 256]) == 0) {  // no end-of-block code
           bad = true;
           break;
         }
         int e = build(lcnt, lsym, ltab, IW_LBITS, LO, nlen);
-        if (e < 0 || (e > 0 && nlen - (int)lcnt[0] != 1)) {  // over-subscribed, or incomplete with more than one code
+        if (e < 0 || (e > 0 && nlen - __builtin_amdgcn_readfirstlane((int)lcnt[0]) != 1)) {  // over-subscribed, or incomplete with more than one code
           bad = true;
           break;
         }
         e = build(dcnt, dsym, dtab, IW_DBITS, LO + nlen, ndist);
-        if (e < 0 || (e > 0 && ndist - (int)dcnt[0] != 1)) {
+        if (e < 0 || (e > 0 && ndist - __builtin_amdgcn_readfirstlane((int)dcnt[0]) != 1)) {
           bad = true;
           break;
         }
@@ -656,7 +665,13 @@ __global__ __launch_bounds__(64) void bgz_inflate_wave_k(uint32_t nmem, const Bg
           // same instruction writes, chunks of 64 bytes in order are the byte-by-byte copy.  Shorter distances: byte j of the
           // match is byte (j mod dist) of the `dist` bytes before it, all of which exist before the copy starts (a distance of 1
           // — a run — is one byte for every lane).
-          if (dist >= 64u || dist >= len) {
+          if (dist > (uint32_t)(IW_WIN - 64)) {  // from beyond the ring: those bytes are in memory (flushed: o - flushed < IW_FLUSH + 258)
+            for (uint32_t j0 = 0; j0 < len; j0 += 64) {
+              const uint32_t j = j0 + lane;
+              // (read past this CU's vector cache, which may hold the line as it was before the last flush)
+              if (j < len) win[(o + j) & (IW_WIN - 1)] = __hip_atomic_load(out + (o - dist + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          } else if (dist >= 64u || dist >= len) {
             for (uint32_t j0 = 0; j0 < len; j0 += 64) {
               const uint32_t j = j0 + lane;
               if (j < len) win[(o + j) & (IW_WIN - 1)] = win[(o - dist + j) & (IW_WIN - 1)];
@@ -682,7 +697,7 @@ __global__ __launch_bounds__(64) void bgz_inflate_wave_k(uint32_t nmem, const Bg
           }
           o += len;
         }
-        if (o - flushed >= 16384u) flush(o);
+        if (o - flushed >= (uint32_t)IW_FLUSH) flush(o);
       }
       if (bad) break;
     }
@@ -1488,6 +1503,10 @@ extern "C" int tbk_bam_decode(tbk_ctx* ctx, uint32_t n_files, const uint8_t* con
   tile->qname_off = qn_off;
   tile->qname = qn;
   tbk_prof_end_call(ctx);
+  // the arena as the collapse of this tile will want it (tbk_collapse_tile's hint for the window path and its deferred YD stage):
+  // growing it is a free and an allocation of gigabytes, ~ 0.1 s that belong here — beside the host's share of a hybrid decode,
+  // or at least not inside the collapse call — and everything this call kept in the arena is dead
+  (void)tbk_reserve_tile(ctx, n, ncig);
   return tbk_check_launch(ctx, "bam_decode");
 }
 
@@ -1497,6 +1516,14 @@ __global__ void join_cig_off_k(uint32_t nb, const uint32_t* __restrict__ src /* 
   if (i <= nb) dst[i] = src[i] + base;
 }
 }  // namespace
+
+extern "C" int tbk_reserve_tile(tbk_ctx* ctx, uint64_t n_records, uint64_t n_cigar_ops) {
+  if (!ctx) return TBK_EINVAL;
+  TBK_HIP(hipSetDevice(ctx->device));
+  // (a third more than the window path and its YD stage need: the deferred YD stage borrows its range of this arena only while a
+  // quarter of the arena stays free behind it, tbk_api.hip — otherwise it allocates an arena of its own inside the call)
+  return tbk_ws_reserve(ctx, ((size_t)n_records * (84 + 40) + (size_t)n_cigar_ops * 8) / 3 * 4 + ((size_t)16 << 20));
+}
 
 // one device tile: the files decoded on this context, then the files a host decoder took (include/tbk.h)
 extern "C" int tbk_tile_join(tbk_ctx* ctx, const tbk_soa_in* a, const tbk_soa_in* b, tbk_soa_in* out, uint32_t* file_off_out, uint8_t* tbmerged_out) {

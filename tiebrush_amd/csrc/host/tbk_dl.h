@@ -23,6 +23,7 @@ struct TbkApi {
   decltype(&tbk_bam_records) bam_records = nullptr;
   decltype(&tbk_bam_release) bam_release = nullptr;
   decltype(&tbk_tile_join) tile_join = nullptr;
+  decltype(&tbk_reserve_tile) reserve_tile = nullptr;
   std::string error;
 
   bool load() {
@@ -56,6 +57,7 @@ struct TbkApi {
     TBK_BIND(bam_records, tbk_bam_records)
     TBK_BIND(bam_release, tbk_bam_release)
     TBK_BIND(tile_join, tbk_tile_join)
+    TBK_BIND(reserve_tile, tbk_reserve_tile)
 #undef TBK_BIND
     if (abi_version() != TBK_ABI_VERSION) {
       error = "libtbk.so has another ABI version";

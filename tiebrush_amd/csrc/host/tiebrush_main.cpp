@@ -383,6 +383,11 @@ int main(int argc, char* argv[]) {
           std::vector<const uint8_t*> ptr(kd);
           for (size_t f = 0; f < kd; ++f) ptr[f] = comp[f].data();
           rc_d = api.bam_decode(ctx, (uint32_t)kd, ptr.data(), fsz.data(), tb_d.data(), 0, 0, &in_d, fo_d.data());
+          std::thread([c = std::move(comp)]() mutable { c.clear(); }).detach();  // (the compressed files: unmapped off this thread's way)
+          if (rc_d == 0 && acc > 0) {  // the arena for the joined tile, sized while the cores are still decoding their share
+            const double up = (double)total / (double)acc * 1.05;
+            (void)api.reserve_tile(ctx, (uint64_t)((double)in_d.n_records * up), (uint64_t)((double)in_d.n_cigar_ops * up));
+          }
           ms_ddec = tms(d1, tnow());
         });
         // the cores' share
@@ -619,8 +624,7 @@ int main(int argc, char* argv[]) {
         rc = api.bam_decode(ctx, (uint32_t)k, ptr.data(), fsz.data(), tb.data(), opt.strategy == TBK_STRAT_FULL, opt.collapse_same != 0, &in, fo.data());
         auto t1 = tnow();
         if (rc == 0) {
-          comp.clear();
-          comp.shrink_to_fit();
+          std::thread([c = std::move(comp)]() mutable { c.clear(); }).detach();  // (gigabytes to unmap: not on this thread's way)
           const size_t n = in.n_records;
           rep.resize(n ? n : 1);
           yc.resize(n ? n : 1);
@@ -634,7 +638,9 @@ int main(int argc, char* argv[]) {
           out.yc = yc.data();
           out.yx = yx.data();
           out.yd = yd.data();
+          auto t_pre = tnow();
           rc = api.collapse_tile(ctx, &opt, &in, &out);
+          if (timing) fprintf(stderr, "device path: output arrays %.1f ms, collapse call %.1f ms\n", tms(t1, t_pre), tms(t_pre, tnow()));
           if (rc == 0 && getenv("TBK_TEST_WHOLE_ENOMEM")) rc = TBK_ENOMEM;  // test hook: exercise the fall-back below
           auto t_col = tnow();
           if (rc == TBK_EUNSORTED) GError("Error: an input file is not coordinate-sorted!\n");

@@ -1,6 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out/hyb
-timeout -k 10 500 python -m pytest tests/test_gpu_bgzf.py tests/test_gpu_cli.py -x -q > gpurun_out/hyb/pytest.log 2>&1; rc=$?
+timeout -k 10 500 python -m pytest tests/test_gpu_cli.py -x -q -k decode_paths > gpurun_out/hyb/pytest.log 2>&1; rc=$?
 tail -n 8 gpurun_out/hyb/pytest.log
 [ $rc -ne 0 ] && exit $rc
 timeout -k 10 700 python - > gpurun_out/hyb/e2e.txt 2>&1 <<P
@@ -15,8 +15,7 @@ paths = synth.write_bams_fast(tile, os.path.join(d, "in"), seq=True)
 del tile
 print("input bytes", sum(os.path.getsize(p) for p in paths))
 exe = os.path.join("tiebrush_amd", "_build", "tiebrush")
-for tag, env in (("host", dict(TBK_HYBRID="0")), ("hybrid 42", dict(TBK_HYBRID="1")), ("hybrid 34", dict(TBK_HYBRID="1", TBK_HYBRID_SHARE="34")),
-                 ("hybrid 50", dict(TBK_HYBRID="1", TBK_HYBRID_SHARE="50")), ("host", dict(TBK_HYBRID="0")), ("hybrid 42", dict(TBK_HYBRID="1")), ("device", dict(TBK_DEVICE_DECODE="1"))):
+for tag, env in (("device", dict(TBK_DEVICE_DECODE="1")), ("host", dict(TBK_HYBRID="0")), ("hybrid 40", dict(TBK_HYBRID="1")), ("device", dict(TBK_DEVICE_DECODE="1")), ("hybrid 40", dict(TBK_HYBRID="1")), ("hybrid 45", dict(TBK_HYBRID="1", TBK_HYBRID_SHARE="45")), ("host", dict(TBK_HYBRID="0"))):
     out = os.path.join(d, "out.bam")
     t = time.time()
     r = subprocess.run([exe, "-o", out] + paths, capture_output=True, text=True, env=dict(os.environ, TBK_TIMING="1", **env))
