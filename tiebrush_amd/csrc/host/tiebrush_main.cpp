@@ -191,23 +191,28 @@ int main(int argc, char* argv[]) {
     if (api_ok && rc == 0 && !getenv("TBK_NO_WARMUP")) {
       // one tiny collapse: the first launch maps the code objects of the library onto the device and the first call sizes the
       // context's buffers — tens of milliseconds that belong beside the inflate, not behind it
-      const uint32_t fo[2] = {0, 2}, co[3] = {0, 1, 2}, cg[2] = {(50u << 4), (50u << 4)};
-      const uint8_t tb0[1] = {0}, mq[2] = {60, 60}, st[2] = {'.', '.'};
-      const int32_t ti[2] = {0, 0}, po[2] = {10, 10}, nh[2] = {1, 1};
-      const uint16_t fl[2] = {0, 0};
+      // (65 inputs of one record each: more than 64 inputs take the window path, whose kernels — the larger part of the library's
+      // device code — would otherwise be mapped by the first real collapse)
+      constexpr uint32_t WK = 65;
+      uint32_t fo[WK + 1], co[WK + 1], cg[WK];
+      uint8_t tb0[WK], mq[WK], st[WK];
+      int32_t ti[WK], po[WK], nh[WK];
+      uint16_t fl[WK];
+      for (uint32_t i = 0; i < WK; ++i) fo[i] = co[i] = i, cg[i] = 50u << 4, tb0[i] = 0, mq[i] = 60, st[i] = '.', ti[i] = 0, po[i] = 10, nh[i] = 1, fl[i] = 0;
+      fo[WK] = co[WK] = WK;
       tbk_soa_in w;
       memset(&w, 0, sizeof(w));
       w.mem = TBK_MEM_HOST;
-      w.n_files = 1, w.n_records = 2, w.n_cigar_ops = 2;
+      w.n_files = WK, w.n_records = WK, w.n_cigar_ops = WK;
       w.file_off = fo, w.tbmerged = tb0, w.tid = ti, w.pos = po, w.flag = fl, w.mapq = mq, w.strand = st, w.nh = nh, w.cig_off = co, w.cig = cg;
-      uint32_t wrep[2];
-      double wyc[2];
-      int64_t wyx[2];
-      int32_t wyd[2];
+      uint32_t wrep[WK];
+      double wyc[WK];
+      int64_t wyx[WK];
+      int32_t wyd[WK];
       tbk_groups_out wo;
       memset(&wo, 0, sizeof(wo));
       wo.mem = TBK_MEM_HOST;
-      wo.cap_groups = 2;
+      wo.cap_groups = WK;
       wo.rep = wrep, wo.yc = wyc, wo.yx = wyx, wo.yd = wyd;
       tbk_collapse_opts wopt = opt;
       (void)api.collapse_tile(ctx, &wopt, &w, &wo);
@@ -307,6 +312,22 @@ int main(int argc, char* argv[]) {
       for (auto& x : th) x.join();
       if (failed.load()) GError("Error: deflate failed\n");
     };
+    // half of what the host may still use (MemAvailable, the cgroup's limit): what the whole-input loaders may fill with inflated inputs
+    auto host_budget = []() {
+      size_t budget = (size_t)8 << 30;
+      if (FILE* mf = fopen("/proc/meminfo", "r")) {
+        char line[256];
+        while (fgets(line, sizeof(line), mf))
+          if (strncmp(line, "MemAvailable:", 13) == 0) budget = (size_t)atoll(line + 13) * 1024 / 2;
+        fclose(mf);
+      }
+      if (FILE* cf = fopen("/sys/fs/cgroup/memory.max", "r")) {
+        char q[64];
+        if (fscanf(cf, "%63s", q) == 1 && strcmp(q, "max") != 0) budget = std::min<size_t>(budget, (size_t)atoll(q) / 2);
+        fclose(cf);
+      }
+      return budget;
+    };
     bool done_fast = false;
     bool skip_fast = false;  // (the hybrid path below loaded a part of the inputs and gave up: the streaming path takes over)
     tbh::FastTile& ft = *new tbh::FastTile();  // (gigabytes, needed until the last record is written: left to the process exit)
@@ -336,18 +357,7 @@ int main(int argc, char* argv[]) {
         uint64_t acc = 0;
         while (kd + 1 < k && (double)(acc + fsz[kd]) <= share * (double)total + (double)fsz[kd] / 2) acc += fsz[kd++];
         if (kd == 0) kd = 1;
-        size_t budget = (size_t)8 << 30;
-        if (FILE* mf = fopen("/proc/meminfo", "r")) {
-          char line[256];
-          while (fgets(line, sizeof(line), mf))
-            if (strncmp(line, "MemAvailable:", 13) == 0) budget = (size_t)atoll(line + 13) * 1024 / 2;
-          fclose(mf);
-        }
-        if (FILE* cf = fopen("/sys/fs/cgroup/memory.max", "r")) {
-          char q[64];
-          if (fscanf(cf, "%63s", q) == 1 && strcmp(q, "max") != 0) budget = std::min<size_t>(budget, (size_t)atoll(q) / 2);
-          fclose(cf);
-        }
+        const size_t budget = host_budget();
         auto t0 = tnow();
         // the device's share, on a thread of its own: read the files, wait for the context, decode
         tbk_soa_in in_d;
@@ -505,18 +515,7 @@ int main(int argc, char* argv[]) {
         tb[f] = inRecords.freaders[f]->tbMerged ? 1 : 0;
         all_bam = all_bam && tbh::bgzf_probe(paths[f]);
       }
-      size_t budget = (size_t)8 << 30;
-      if (FILE* mf = fopen("/proc/meminfo", "r")) {
-        char line[256];
-        while (fgets(line, sizeof(line), mf))
-          if (strncmp(line, "MemAvailable:", 13) == 0) budget = (size_t)atoll(line + 13) * 1024 / 2;
-        fclose(mf);
-      }
-      if (FILE* cf = fopen("/sys/fs/cgroup/memory.max", "r")) {
-        char q[64];
-        if (fscanf(cf, "%63s", q) == 1 && strcmp(q, "max") != 0) budget = std::min<size_t>(budget, (size_t)atoll(q) / 2);
-        fclose(cf);
-      }
+      const size_t budget = host_budget();
       bool fits = false;
       std::string err;
       if (all_bam && k > 0) {
