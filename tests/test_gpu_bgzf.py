@@ -192,6 +192,38 @@ def test_record_index_by_member_and_by_chain(ctx, monkeypatch):
         assert np.array_equal(got_x[name], got_m[name]), name
 
 
+def test_tile_join_of_a_device_and_a_host_part(ctx, bam_loader):
+    """tbk_tile_join: the first files decoded on the GPU (tbk_bam_decode), the rest by the host — one device tile that equals the tile
+    of all the files array for array, collapses to the oracle's groups, and whose device-side records are the ones tbk_bam_records
+    hands back; parts with carried tags are refused"""
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import api, soa
+    paths = sample_paths("t2")
+    bams = [bam_loader(p) for p in paths]
+    whole = soa.tile_from_bams(bams)
+    kd = 4
+    s, fo_d = ctx.bam_decode([open(p, "rb").read() for p in paths[:kd]])
+    ctx.reserve_tile(whole.n_records, whole.cig.shape[0])
+    joined, fo = ctx.tile_join(s, soa.tile_from_bams(bams[kd:]))
+    assert np.array_equal(fo, whole.file_off) and joined.n_records == whole.n_records and joined.n_cigar_ops == whole.cig.shape[0]
+    got = ctx.soa_to_numpy(joined)
+    for name in ("tid", "pos", "flag", "mapq", "strand", "nh", "cig_off", "cig"):
+        assert np.array_equal(got[name], getattr(whole, name)), name
+    g = api.to_numpy(ctx.collapse_struct(joined, len(paths)))
+    want = orc.collapse(whole)
+    assert g["n_groups"] == want["n_groups"] and g["n_passed"] == want["n_passed"]
+    for k_ in ("rep", "yc", "yx", "yd", "g_start", "g_end"):
+        assert np.array_equal(np.asarray(g[k_]).astype(np.float64), np.asarray(want[k_]).astype(np.float64)), k_
+    n_d = int(fo_d[-1])
+    idx = np.array([0, n_d - 1, n_d // 2], np.uint32)
+    blob, off = ctx.bam_records(idx)
+    assert len(blob) == int(off[-1]) > 0
+    merged = soa.tile_from_bams([bam_loader(os.path.join(GOLDEN, "t1", "t1.bam"))])      # a TieBrush-merged part carries YC / YX / YD
+    with pytest.raises(api.TbkError):
+        ctx.tile_join(s, merged)
+    ctx.bam_release()
+
+
 def test_bam_decode_then_collapse_equals_oracle(ctx, bam_loader):
     """compressed bytes -> device tile -> tbk_collapse_tile, nothing decoded on the host: the golden t2 collapse"""
     from oracle import oracle_ffi as orc

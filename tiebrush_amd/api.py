@@ -348,6 +348,24 @@ class Context:
     def bam_release(self):
         self.L.tbk_bam_release(self.h)
 
+    def tile_join(self, dev_struct, host_tile: SoATile):
+        """tbk_tile_join: the device tile of bam_decode + a host tile (plain inputs) -> (SoaIn struct of the joined device tile, file_off);
+        its arrays live in the context until bam_release()"""
+        keep = []
+        hs, dev, _ = self._soa_struct(host_tile, keep)
+        assert not dev
+        k = int(dev_struct.n_files) + int(host_tile.n_files)
+        fo = np.zeros(k + 1, dtype=np.uint32)
+        tb = np.zeros(k, dtype=np.uint8)
+        out = _lib.SoaIn()
+        self._check(self.L.tbk_tile_join(self.h, C.byref(dev_struct), C.byref(hs), C.byref(out), fo.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                         tb.ctypes.data_as(C.POINTER(C.c_uint8))), "tbk_tile_join")
+        self._join_keep = (fo, tb)
+        return out, fo
+
+    def reserve_tile(self, n_records, n_cigar_ops):
+        self._check(self.L.tbk_reserve_tile(self.h, int(n_records), int(n_cigar_ops)), "tbk_reserve_tile")
+
     def soa_to_numpy(self, s, fields=("tid", "pos", "flag", "mapq", "strand", "nh", "cig_off", "cig")):
         """copy arrays of a device-resident SoaIn (bam_decode) to numpy (tests)"""
         import ctypes
