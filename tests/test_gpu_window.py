@@ -85,7 +85,7 @@ def test_ranking_by_buckets_and_by_merge_sort(ctx, window_mode, rank, monkeypatc
     _cmp(ctx, _tile(recs))
 
 
-@pytest.mark.parametrize("split", ["by_list", "radix"])
+@pytest.mark.parametrize("split", ["by_list", "by_list_fat_items", "radix"])
 def test_yd_items_by_list_and_by_radix_split(ctx, window_mode, split, monkeypatch):
     """the YD items of the window path reach their lists without a sort (<= 64 files: bit-matrix ranks, yd_lcount_k /
     yd_lscatter_k) or through the stable radix split (more files; TBK_YD_RADIX forces it): both against the oracle — '.' strands
@@ -93,6 +93,8 @@ def test_yd_items_by_list_and_by_radix_split(ctx, window_mode, split, monkeypatc
     from tiebrush_amd import synth
     if split == "radix":
         monkeypatch.setenv("TBK_YD_RADIX", "1")
+    if split == "by_list_fat_items":                     # (the items placed by list are 16 bytes — (start, end), exon count, group —; the hook keeps the 24)
+        monkeypatch.setenv("TBK_YD_FAT_ITEMS", "1")
     for files, reads, profile, kw in ((64, 1500, "c3", dict(strategy="clip")), (3, 40000, "c2", dict()), (33, 2500, "c5", dict(strategy="exon"))):
         tile = synth.make_tile(files, reads, profile, n_loci=300)
         tile.strand = tile.strand.copy()

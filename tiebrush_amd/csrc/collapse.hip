@@ -654,6 +654,19 @@ struct YdWords {
 struct YdItems {
   uint4* pk;      // (tid + 1, start, end, offset of the item's exon list in the per-group exon arrays): written with one store
   uint32_t* nex;  // exon count (contiguous: the input of the node-offset scan); items placed by list: bit 31 = the item opens a chain
+  // Items placed by list (<= 64 inputs) are lean: (start, end) only — 16 bytes an item with the exon count and the group word
+  // instead of 24.  The reference id is not needed behind the placement (the heads are flagged there), and the exon offset, which
+  // only the spliced items use (one in twelve on config 3), is read from the item's group.
+  uint2* se = nullptr;
+  const uint32_t* gxoff = nullptr;  // per group: offset of its exon list (YdGroups::xoff)
+  __device__ __forceinline__ uint4 rec(uint32_t t) const {
+    if (se) {
+      const uint2 a = se[t];
+      return make_uint4(0u, a.x, a.y, 0u);
+    }
+    return pk[t];
+  }
+  __device__ __forceinline__ uint32_t xo_of(const uint4& it, uint32_t group) const { return se ? gxoff[group] : it.w; }
   __device__ __forceinline__ uint32_t tidp1(uint32_t t) const { return reinterpret_cast<const uint32_t*>(pk)[4 * (size_t)t]; }
   __device__ __forceinline__ int32_t start(uint32_t t) const { return (int32_t) reinterpret_cast<const uint32_t*>(pk)[4 * (size_t)t + 1]; }
   __device__ __forceinline__ int32_t end(uint32_t t) const { return (int32_t) reinterpret_cast<const uint32_t*>(pk)[4 * (size_t)t + 2]; }
@@ -865,7 +878,10 @@ __global__ __launch_bounds__(YS_NT) void yd_lscatter_k(YsIn S, uint32_t ntiles, 
     const uint32_t bit = ys_select(wb[x][c], r);
     const uint32_t g = x * 64u + bit;
     const uint32_t pos = base[c] + rank;
-    Y.pk[pos] = grec[g];
+    if (Y.se)
+      Y.se[pos] = make_uint2(grec[g].y, grec[g].z);
+    else
+      Y.pk[pos] = grec[g];
     Y.nex[pos] = gnex[g] | ((uint32_t)((hb[x][c] >> bit) & 1ull) << 31);  // (bit 31: the item opens a chain — read by yd_number)
     item[pos] = blockIdx.x * YS_NT + g;
   }
@@ -1130,9 +1146,9 @@ __global__ void yd_run_k(const uint32_t* __restrict__ ids, const uint32_t* __res
   int last_dist = -1;
   uint32_t alloc = noff[c];  // (per chain)
   for (uint32_t t = t0; t < t1; ++t) {
-    const uint4 it = Y.pk[t];
+    const uint4 it = Y.rec(t);
     uint32_t rstart = it.y;
-    uint32_t xo = it.w, nex = Y.nex[t] & 0x7FFFFFFFu;  // (bit 31: head flag of items placed by list)
+    uint32_t xo = Y.xo_of(it, v.group(t)), nex = Y.nex[t] & 0x7FFFFFFFu;  // (bit 31: head flag of items placed by list)
     int d;
     if (last_pos == rstart) {  // :225-228
       yd_merge_read(ex_s + xo, ex_e + xo, nex, N, head, alloc);
@@ -1273,16 +1289,17 @@ __global__ __launch_bounds__(64) void yd_lane_k(const uint32_t* __restrict__ ids
       const uint32_t tq = __shfl(tl, q, 64), t1q = __shfl(t1, q, 64);
       const uint32_t idx = tq + i0;
       if (tq != 0xFFFFFFFFu && idx < t1q) {
-        const uint4 a = Y.pk[idx];
+        const uint4 a = Y.rec(idx);
         const uint32_t nx = Y.nex[idx] & 0x7FFFFFFFu;
         const uint32_t o = v.group(idx);
         const uint32_t w = q * RS + i0;
+        const uint32_t axo = nx > 1 ? Y.xo_of(a, o) : 0u;  // (only a spliced item has use for its exon list)
         S_start[w] = a.y;
-        S_xo[w] = a.w;
-        S_e0[w] = nx > 1 ? ex_e[a.w] : a.z;  // (a single exon ends where the read ends; the exon arrays follow the groups: items next to
+        S_xo[w] = axo;
+        S_e0[w] = nx > 1 ? ex_e[axo] : a.z;  // (a single exon ends where the read ends; the exon arrays follow the groups: items next to
                                              // each other in a chain read next to each other)
-        S_s1[w] = nx > 1 ? ex_s[a.w + 1] : 0u;
-        S_e1[w] = nx > 1 ? ex_e[a.w + 1] : 0u;
+        S_s1[w] = nx > 1 ? ex_s[axo + 1] : 0u;
+        S_e1[w] = nx > 1 ? ex_e[axo + 1] : 0u;
         S_nex[w] = nx;
         S_o[w] = o;
       }
@@ -1439,11 +1456,11 @@ __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids
     Batch b;
     const uint32_t t = tb + (uint32_t)lane;
     const bool have = t < t1;
-    const uint4 it = have ? Y.pk[t] : make_uint4(0u, 0u, 0u, 0u);
+    const uint4 it = have ? Y.rec(t) : make_uint4(0u, 0u, 0u, 0u);
     b.start = it.y;
     b.nex = have ? (Y.nex[t] & 0x7FFFFFFFu) : 0u;
-    b.xo = it.w;
     b.o = have ? v.group(t) : 0u;
+    b.xo = b.nex > 1u ? Y.xo_of(it, b.o) : 0u;  // (only a spliced item has use for its exon list)
     b.e0 = have ? (b.nex > 1u ? ex_e[b.xo] : it.z) : 0u;  // first exon end (its start is the read start); a single exon ends where the
                                                           // read ends: no gather (three items in four, a 64-byte sector each)
     b.s1 = (have && b.nex > 1) ? ex_s[b.xo + 1] : 0u;
@@ -1848,7 +1865,14 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       uint32_t* io = by_list ? ws_alloc<uint32_t>(ctx, nit) : nullptr;  // items placed by list: the item -> group array
       if (by_list && !io) return TBK_ENOMEM;
       YdItems Y;
-      Y.pk = ws_alloc<uint4>(ctx, nit);
+      if (by_list && !getenv("TBK_YD_FAT_ITEMS")) {  // (TBK_YD_FAT_ITEMS: test hook, the 24-byte items on this path too)
+        Y.pk = nullptr;
+        Y.se = ws_alloc<uint2>(ctx, nit);
+        Y.gxoff = Q.xoff;  // (by_list: the groups' records were made above)
+        if (!Y.se) return TBK_ENOMEM;
+      } else {
+        Y.pk = ws_alloc<uint4>(ctx, nit);
+      }
       Y.nex = ws_alloc<uint32_t>(ctx, nit);
       uint32_t* noff = ws_alloc<uint32_t>(ctx, nit);
       uint32_t* chain_first = ws_alloc<uint32_t>(ctx, nit);
