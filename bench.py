@@ -141,9 +141,60 @@ def run_e2e_leg(args):
         return {"error": repr(e)}
 
 
+def launch_ranks(n):
+    """Start one child process per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run would set them) and wait.
+    The parent initialises no GPU and imports no torch.  A rank that fails ends the others (their exact process groups, never a
+    pattern) and the parent returns non-zero; rank 0 prints the one JSON line on the inherited stdout."""
+    import signal
+    import socket
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   TBK_BENCH_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, start_new_session=True))
+
+    def stop_all(sig=signal.SIGTERM):
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, sig)
+                except (ProcessLookupError, PermissionError):
+                    pass
+
+    def on_signal(signum, _frame):
+        stop_all()
+        raise SystemExit(128 + signum)
+    signal.signal(signal.SIGTERM, on_signal)
+    signal.signal(signal.SIGINT, on_signal)
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            c = procs[r].poll()
+            if c is None:
+                continue
+            live.discard(r)
+            if c != 0 and rc == 0:
+                rc = c if c > 0 else 1
+                sys.stderr.write("bench.py: rank %d ended with status %d: stopping the other ranks\n" % (r, c))
+                stop_all()
+                t_end = time.time() + 10
+                while time.time() < t_end and any(p.poll() is None for p in procs):
+                    time.sleep(0.1)
+                stop_all(signal.SIGKILL)
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node; without WORLD_SIZE in the environment N > 1 starts the N rank processes itself (default: WORLD_SIZE, else 1)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--profile", default=None, choices=sorted(WORKLOADS), help="default: c3 at N = 1, c4 (BASELINE's scaling workload) at N > 1")
@@ -170,7 +221,15 @@ def main():
     args = ap.parse_args()
     args.prof_steps = max(1, args.prof_steps)
 
+    # `python bench.py --gpus N` with no WORLD_SIZE in the environment starts its N ranks itself (the reference's counterpart is
+    # tiewrap.py:96-126, which starts its own workers): this process never touches a GPU, it only starts and reaps the children.
+    if "WORLD_SIZE" not in os.environ and (args.gpus or 1) > 1:
+        raise SystemExit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus is None:
+        args.gpus = world
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: one rank per GPU, the two must agree" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or args.force_dist
@@ -588,7 +647,7 @@ def main():
             "metric": "input alignment records/sec collapsed (tiebrush) + bases/sec covered (tiecov)",
             "value": round(tot_records * args.steps / dt, 1),
             "unit": "records/s",
-            "n_gpus": world,
+            "n_gpus": args.gpus,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),

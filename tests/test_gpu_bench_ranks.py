@@ -56,3 +56,19 @@ def test_bench_default_line_contract_small():
     assert c["parallel"]["cores"] >= 2 and c["parallel"]["value"] > 0
     rc = d["roofline_coverage"]
     assert rc["launches_measured"] >= 10 and rc["launch_us_min"] <= rc["avg_launch_us"] <= rc["launch_us_max"]
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE (how the driver calls it) starts the two ranks itself: ONE line, n_gpus 2, ranks_seen 2"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(TBK_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--files-per-gpu", "2",
+           "--reads-per-file", "30000", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().split("\n") if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["records_per_gpu"] == 60000
+    assert abs(d["value"] - 2 * 60000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.02

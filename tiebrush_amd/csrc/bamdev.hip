@@ -1268,7 +1268,9 @@ static void bamdev_free(tbk_ctx* ctx) {
 }
 
 extern "C" void tbk_bam_release(tbk_ctx* ctx) {
-  if (ctx) bamdev_free(ctx);
+  if (!ctx) return;
+  (void)tbk_collapse_finish_yd(ctx);  // (a deferred YD stage may still read the decoded tile)
+  bamdev_free(ctx);
 }
 
 template <class T>
@@ -1283,6 +1285,7 @@ extern "C" int tbk_bam_decode(tbk_ctx* ctx, uint32_t n_files, const uint8_t* con
                               int want_md, int want_names, tbk_soa_in* tile, uint32_t* file_off_out) {
   if (!ctx || !comp || !comp_bytes || !tile || !file_off_out || n_files == 0 || n_files > 65535) return TBK_EINVAL;
   TBK_HIP(hipSetDevice(ctx->device));
+  TBK_TRY(tbk_collapse_finish_yd(ctx));  // (a deferred YD stage may still read the tile of the previous decode)
   bamdev_free(ctx);
   tbk_prof_begin_call(ctx);
   const uint32_t k = n_files;
@@ -1506,8 +1509,10 @@ extern "C" int tbk_bam_decode(tbk_ctx* ctx, uint32_t n_files, const uint8_t* con
   // the arena as the collapse of this tile will want it (tbk_collapse_tile's hint for the window path and its deferred YD stage):
   // growing it is a free and an allocation of gigabytes, ~ 0.1 s that belong here — beside the host's share of a hybrid decode,
   // or at least not inside the collapse call — and everything this call kept in the arena is dead
-  (void)tbk_reserve_tile(ctx, n, ncig);
-  return tbk_check_launch(ctx, "bam_decode");
+  // (best effort, and after the decode's own status is settled: a reserve that does not fit must not turn a good decode into an error)
+  const int rc_decode = tbk_check_launch(ctx, "bam_decode");
+  if (rc_decode == 0) (void)tbk_reserve_tile(ctx, n, ncig);
+  return rc_decode;
 }
 
 namespace {
@@ -1522,7 +1527,7 @@ extern "C" int tbk_reserve_tile(tbk_ctx* ctx, uint64_t n_records, uint64_t n_cig
   TBK_HIP(hipSetDevice(ctx->device));
   // (a third more than the window path and its YD stage need: the deferred YD stage borrows its range of this arena only while a
   // quarter of the arena stays free behind it, tbk_api.hip — otherwise it allocates an arena of its own inside the call)
-  return tbk_ws_reserve(ctx, ((size_t)n_records * (84 + 40) + (size_t)n_cigar_ops * 8) / 3 * 4 + ((size_t)16 << 20));
+  return tbk_ws_presize(ctx, ((size_t)n_records * (84 + 40) + (size_t)n_cigar_ops * 8) / 3 * 4 + ((size_t)16 << 20));
 }
 
 // one device tile: the files decoded on this context, then the files a host decoder took (include/tbk.h)
@@ -1534,6 +1539,7 @@ extern "C" int tbk_tile_join(tbk_ctx* ctx, const tbk_soa_in* a, const tbk_soa_in
     return TBK_EUNSUPPORTED;
   BamDev* B = (BamDev*)ctx->bam_dev;
   TBK_HIP(hipSetDevice(ctx->device));
+  TBK_TRY(tbk_collapse_finish_yd(ctx));
   const uint64_t na = a->n_records, nb = b->n_records, ca = a->n_cigar_ops, cb = b->n_cigar_ops;
   if (na + nb >= (1ull << 32) || ca + cb >= (1ull << 32) || (uint64_t)a->n_files + b->n_files > 65535) return TBK_E2BIG;
   const size_t n = (size_t)(na + nb);

@@ -80,18 +80,30 @@ int tbh_write_bam_parts(const char* out_path, const char* version, int cmd_argc,
   in.setup(version, cmd_argc, av.data());
   for (int i = 0; i < n_files; ++i) in.addFile(tbh_realpath(files[i]).c_str());
   in.start();
+  // written beside the target and renamed when complete: a part that cannot be read must not leave a well-formed but truncated BAM
+  const std::string tmp = std::string(out_path) + ".tmp";
+  std::string bad;
   {
-    GSamWriter out(out_path, in.header(), GSamFile_BAM);
+    GSamWriter out(tmp.c_str(), in.header(), GSamFile_BAM);
     std::vector<uint8_t> buf((size_t)8 << 20);
-    for (int p = 0; p < n_parts; ++p) {
+    for (int p = 0; p < n_parts && bad.empty(); ++p) {
       FILE* f = fopen(parts[p], "rb");
-      if (!f) return fail(std::string("tbh_write_bam_parts: cannot open ") + parts[p]);
+      if (!f) {
+        bad = std::string("tbh_write_bam_parts: cannot open ") + parts[p];
+        break;
+      }
       size_t got;
       while ((got = fread(buf.data(), 1, buf.size(), f)) > 0) out.write_members(buf.data(), got);
+      if (ferror(f)) bad = std::string("tbh_write_bam_parts: read failed on ") + parts[p];
       fclose(f);
     }
   }  // (closing the writer appends the EOF member)
   in.stop();
+  if (bad.empty() && rename(tmp.c_str(), out_path) != 0) bad = std::string("tbh_write_bam_parts: cannot rename to ") + out_path;
+  if (!bad.empty()) {
+    (void)unlink(tmp.c_str());
+    return fail(bad);
+  }
   if (remove_parts)
     for (int p = 0; p < n_parts; ++p) (void)unlink(parts[p]);
   return 0;

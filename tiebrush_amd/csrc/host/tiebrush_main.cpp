@@ -19,7 +19,10 @@
 #include <functional>
 #include <mutex>
 #include <memory>
+#include <signal.h>
+#include <spawn.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <chrono>
 #include <time.h>
 #include <thread>
@@ -33,6 +36,8 @@
 #include "tagwrite.h"
 #include "tbk_dl.h"
 #include "tmerge.h"
+
+extern char** environ;
 
 #define VERSION "0.0.7"
 
@@ -86,7 +91,11 @@ struct RawBuf {
 };
 
 // `tiebrush --ranks N ...`: the multi-GPU form (tiebrush_amd/ranks.py: one process per GPU over torch.distributed / RCCL, the input
-// files sharded by rank, one output BAM).  This process has touched no GPU yet: it becomes the launcher, which starts the ranks.
+// files sharded by rank, one output BAM).  The launcher, which starts the ranks, runs as a child of this process.
+static volatile pid_t g_ranks_child = 0;
+static void forward_to_ranks_child(int sig) {
+  if (g_ranks_child > 0) kill(g_ranks_child, sig);
+}
 static void maybe_exec_ranks(int argc, char* argv[]) {
   bool want = false;
   for (int i = 1; i < argc; ++i) want = want || strcmp(argv[i], "--ranks") == 0 || strncmp(argv[i], "--ranks=", 8) == 0;
@@ -111,8 +120,22 @@ static void maybe_exec_ranks(int argc, char* argv[]) {
   av.push_back(const_cast<char*>("tiebrush_amd.ranks"));
   for (int i = 1; i < argc; ++i) av.push_back(argv[i]);
   av.push_back(nullptr);
-  execvp(py, av.data());
-  GError("Error: --ranks: cannot start %s (%s)\n", py, strerror(errno));
+  // a CHILD, never an exec of this process: under a profiler or any launcher that preloads a GPU-initialising library this process may
+  // already hold the GPU, and replacing such a process is what takes a node down.  The launcher runs as a fresh process; this one
+  // waits, forwards the signals a caller's timeout would send and leaves with the child's status.
+  pid_t child = 0;
+  const int rc = posix_spawnp(&child, py, nullptr, nullptr, av.data(), environ);
+  if (rc != 0) GError("Error: --ranks: cannot start %s (%s)\n", py, strerror(rc));
+  g_ranks_child = child;
+  signal(SIGTERM, forward_to_ranks_child);
+  signal(SIGINT, forward_to_ranks_child);
+  signal(SIGHUP, forward_to_ranks_child);
+  int status = 0;
+  while (waitpid(child, &status, 0) < 0)
+    if (errno != EINTR) GError("Error: --ranks: waiting for the launcher failed (%s)\n", strerror(errno));
+  fflush(stdout);
+  fflush(stderr);
+  _exit(WIFEXITED(status) ? WEXITSTATUS(status) : 128 + (WIFSIGNALED(status) ? WTERMSIG(status) : 0));
 }
 
 int main(int argc, char* argv[]) {
@@ -683,8 +706,9 @@ int main(int argc, char* argv[]) {
             done_on_device = true;
             if (timing) fprintf(stderr, "device decode: %zu records from %llu compressed bytes\n", n, (unsigned long long)total);
           }
-        } else if (timing) {
-          fprintf(stderr, "device decode not used (%s: %s): streaming host path\n", api.strerror_(rc), api.last_error(ctx));
+        } else {
+          if (timing) fprintf(stderr, "device decode not used (%s: %s): streaming host path\n", api.strerror_(rc), api.last_error(ctx));
+          api.bam_release(ctx);  // (whatever the failed decode left on the device goes back before the streaming path sizes its tiles)
         }
       }
     }

@@ -54,6 +54,8 @@ extern "C" int tbk_unpack_tile(tbk_ctx* ctx, const tbk_packed_in* in, tbk_soa_in
   if ((in->n_nh_esc && (!in->nh_esc_idx || !in->nh_esc_val)) || (in->n_ncig_esc && (!in->ncig_esc_idx || !in->ncig_esc_val))) return TBK_EINVAL;
   if (n && in->tid_run_end[in->n_tid_runs - 1] != in->n_records) return TBK_EINVAL;
   TBK_HIP(hipSetDevice(ctx->device));
+  // a deferred YD stage of the previous collapse still reads the tile this call is about to overwrite (or free): wait for it first
+  TBK_TRY(tbk_collapse_finish_yd(ctx));
   memset(tile, 0, sizeof(*tile));
   tile->mem = TBK_MEM_DEVICE;
   tile->n_files = in->n_files;

@@ -89,6 +89,23 @@ static int ws_begin_call(tbk_ctx* ctx, size_t hint) {
 
 int tbk_ws_reserve(tbk_ctx* ctx, size_t bytes) { return ws_begin_call(ctx, bytes); }
 
+// tbk_ws_presize — best effort (tbk_reserve_tile is "purely an optimisation"): the larger arena is allocated FIRST and the old one freed only when that
+// worked, so a reserve that does not fit leaves the context exactly as it was — no sticky HIP error, the old arena still there — and
+// the collapse that follows sizes (or spills) by its own rules.  Nothing is resized while a deferred YD stage or a borrowed range pins
+// the arena.
+int tbk_ws_presize(tbk_ctx* ctx, size_t bytes) {
+  if (ctx->ws_borrowed || ctx->yd_pending || !ctx->ws_overflow.empty() || bytes <= ctx->ws_cap) return 0;
+  char* bigger = nullptr;
+  if (hipMalloc((void**)&bigger, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  if (ctx->ws) (void)hipFree(ctx->ws);
+  ctx->ws = bigger;
+  ctx->ws_cap = bytes;
+  return 0;
+}
+
 void* tbk_ws_alloc_raw(tbk_ctx* ctx, size_t bytes) {
   bytes = (bytes + 255) & ~(size_t)255;
   if (bytes == 0) bytes = 256;

@@ -169,6 +169,7 @@ void tbk_side_end(tbk_ctx* side);
 
 // ---- workspace ------------------------------------------------------------------
 int tbk_ws_reserve(tbk_ctx* ctx, size_t bytes);  // grow (frees + reallocates) if needed; resets the bump pointer
+int tbk_ws_presize(tbk_ctx* ctx, size_t bytes);  // best effort: a larger arena if one can be had, the old one kept otherwise; always 0
 void* tbk_ws_alloc_raw(tbk_ctx* ctx, size_t bytes);
 template <class T>
 static inline T* ws_alloc(tbk_ctx* ctx, size_t n) {

@@ -20,6 +20,7 @@ Refused, as in tiebrush_amd.dist: -A and --store-frac (order-dependent sums acro
 from __future__ import annotations
 
 import argparse
+import contextlib
 import ctypes as C
 import os
 import subprocess
@@ -274,6 +275,8 @@ def worker(a, argv):
     my_blob = np.ascontiguousarray(my_blob)
     if H.tbh_tag_deflate_part(my_blob.ctypes.data, rec_off.ctypes.data, rec_len.ctypes.data, ng, yc.ctypes.data, yx.ctypes.data, yd.ctypes.data,
                               a.level, threads, part.encode()) != 0:
+        with contextlib.suppress(OSError):
+            os.unlink(part)                        # (no half-written part is left behind)
         raise SystemExit("Error: writing %s failed: %s" % (part, H.tbh_last_error().decode()))
     t_part = time.perf_counter()
     tot = torch.tensor([float(res.n_passed_local), float(ng)], dtype=torch.float64, device=cdev)
@@ -284,6 +287,9 @@ def worker(a, argv):
         arr = lambda xs: (C.c_char_p * len(xs))(*[x.encode() for x in xs])
         parts = ["%s.part%d" % (a.out, r) for r in range(world)]
         if H.tbh_write_bam_parts(a.out.encode(), VERSION.encode(), len(cmd), arr(cmd), k, arr(files), world, arr(parts), 1) != 0:
+            for pth in parts:                      # (the output is incomplete: nothing that looks like a result stays)
+                with contextlib.suppress(OSError):
+                    os.unlink(pth)
             raise SystemExit("Error: writing %s failed: %s" % (a.out, H.tbh_last_error().decode()))
         n_in, n_out = int(tot[0]), int(tot[1])
         sys.stderr.write("%d input records written as %d (%.2f%% reduction)\n" % (n_in, n_out, 100.0 - (n_out * 100.0) / max(n_in, 1)))
