@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TBK_ABI_VERSION 6
+#define TBK_ABI_VERSION 7
 
 typedef struct tbk_ctx tbk_ctx;
 
@@ -262,6 +262,40 @@ int tbk_tile_join(tbk_ctx* ctx, const tbk_soa_in* dev_part, const tbk_soa_in* ho
  * deferred YD stage): growing the arena is a free and an allocation of gigabytes, ~ 0.1 s that a host can put beside its own
  * decoding instead of inside the collapse call.  Purely an optimisation: a collapse sizes the arena itself when it has to. */
 int tbk_reserve_tile(tbk_ctx* ctx, uint64_t n_records, uint64_t n_cigar_ops);
+
+/* ---- BGZF / BAM encode on the device (ABI version 7; SURVEY.md §8 f1, the output side) ------------------------------------------
+ * What flushPData's tagging (tiebrush.cpp:506-525: YC:f always, YX:i always, YD:i when positive and removed otherwise;
+ * bam_aux_update_float / _int / bam_aux_del of htslib 1.18 through GSam.h:300-305) and GSamWriter::write -> sam_write1 -> bgzf_write
+ * (GSam.h:648-653; zlib level 6 inside htslib) do per output record on the host. */
+
+/* Deflate a byte run into whole BGZF members (gzip members with the BC extra field, one dynamic-Huffman or stored block each, CRC32
+ * and ISIZE set) written back to back into `out` (HOST).  src lives in src_mem.  Members hold cuts[m + 1] - cuts[m] payload bytes
+ * (cuts[n_members + 1] HOST, cuts[0] = 0, cuts[n_members] = n, each piece <= 0xff00) or, with cuts == NULL, 0xff00 bytes each.
+ * *out_bytes = size of the run; TBK_E2BIG (with *out_bytes set) when out_cap is too small.  The EOF member is the caller's. */
+int tbk_bgzf_deflate(tbk_ctx* ctx, const uint8_t* src, uint64_t n, int src_mem, const uint64_t* cuts, uint32_t n_members, uint8_t* out,
+                     uint64_t out_cap, uint64_t* out_bytes);
+
+/* The output records of a collapse: group g (output order) is the raw record of its representative with the three tags set. */
+typedef struct tbk_enc_in {
+  int32_t mem;               /* tbk_mem of rep / yc / yx / yd                                                         */
+  uint32_t n;                /* output records                                                                       */
+  const uint32_t* rep;       /* [n] tile index of the representative (tbk_groups_out.rep)                             */
+  const double* yc;          /* [n] tbk_groups_out.yc / yx / yd                                                       */
+  const int64_t* yx;
+  const int32_t* yd;
+  uint32_t n_dev;            /* tile indices below n_dev are records of the tile tbk_bam_decode left on this context: their
+                                bytes are read where they lie.  0: no such tile                                       */
+  uint32_t n_host;           /* the other representatives, handed over by the caller:                                 */
+  const uint8_t* host_blob;  /* HOST: their raw records (block_size field first, as in the BAM stream), packed       */
+  const uint64_t* host_off;  /* HOST [n_host + 1]: byte offsets into host_blob                                       */
+  const uint32_t* host_slot; /* HOST [n]: for a group whose rep >= n_dev, its record's index in host_off (others ignored) */
+} tbk_enc_in;
+/* Tag, frame (block_size) and BGZF-deflate the n records on the device: `out` (HOST) receives a run of whole members — every member
+ * begins with a record, as htslib cuts them — that a BAM writer appends behind its header; the EOF member is the caller's.
+ * *out_bytes = size of the run, *payload_bytes (optional) = the tagged records' bytes before compression.  TBK_E2BIG (with
+ * *out_bytes set) when out_cap is too small; TBK_EUNSUPPORTED when a record is nearly as long as a member (the caller's host
+ * writer takes such an output); TBK_EINVAL for a malformed record. */
+int tbk_bam_encode(tbk_ctx* ctx, const tbk_enc_in* in, uint8_t* out, uint64_t out_cap, uint64_t* out_bytes, uint64_t* payload_bytes);
 
 /* ---- Packed wire form of a tile (ABI version 5) ---------------------------------------------------------------------------
  * What a host decoder can hand over instead of tbk_soa_in when the tile has to cross PCIe: the same records in 9 bytes plus the

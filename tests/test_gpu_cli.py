@@ -247,8 +247,16 @@ def test_cli_decode_paths_give_the_same_record_stream(tmp_path):
                 assert ("hybrid decode given up" if tag == "hybrid_nomem" else "hybrid path ms: device") in r.stderr, r.stderr
             if tag.startswith("hybrid") and name == "merged":  # (TieBrush-merged inputs carry tags the joined tile does not: the host loader takes them)
                 assert "hybrid" not in r.stderr
+            assert "device writer:" in r.stderr, (tag, r.stderr)   # (the default writer: tags + BGZF deflate on the GPU, devwriter.h)
             raw = bamio.bgzf_decompress(open(out, "rb").read())
             streams[tag] = raw[bamio.parse_header(raw)[1]:]
+            # the same run through the host writer (every core tags and deflates): the same records byte for byte
+            outh = str(tmp_path / ("%s_%s_hostwriter.bam" % (name, tag)))
+            rh = subprocess.run([os.path.join(BIN, "tiebrush"), "--writer", "host", "-o", outh] + paths, check=True, capture_output=True, text=True,
+                                env=dict(os.environ, TBK_TIMING="1", **env))
+            assert "device writer:" not in rh.stderr
+            rawh = bamio.bgzf_decompress(open(outh, "rb").read())
+            assert rawh[bamio.parse_header(rawh)[1]:] == streams[tag], (name, tag)   # (the headers differ in the @PG line's command line)
         assert len(streams["whole"]) > 100000
         for tag in ("stream", "tiles", "device", "zlib", "whole_nomem", "device_nomem", "hybrid", "hybrid_80", "hybrid_nomem"):
             assert streams[tag] == streams["whole"], (name, tag)
@@ -434,3 +442,66 @@ def test_tiebrush_ranks_three_ranks_uneven_files(tmp_path):
     assert a.n == b.n
     for i in range(a.n):
         assert bamio.record_bytes(a, i) == bamio.record_bytes(b, i), i
+
+
+def _records(path):
+    from tiebrush_amd import bamio
+    raw = bamio.bgzf_decompress(open(path, "rb").read())
+    return raw[bamio.parse_header(raw)[1]:]
+
+
+def _members_ok(path):
+    """every BGZF member of the file: framing, CRC32, ISIZE, zlib inflates it; the last one is the EOF member"""
+    import struct
+    import zlib
+    run = open(path, "rb").read()
+    o, sizes = 0, []
+    while o < len(run):
+        assert run[o:o + 4] == b"\x1f\x8b\x08\x04" and run[o + 12:o + 16] == b"BC\x02\x00"
+        bsize = struct.unpack_from("<H", run, o + 16)[0] + 1
+        crc, isize = struct.unpack_from("<II", run, o + bsize - 8)
+        d = zlib.decompressobj(-15)
+        got = d.decompress(run[o + 18:o + bsize - 8]) + d.flush()
+        assert d.eof and len(got) == isize and zlib.crc32(got) & 0xFFFFFFFF == crc
+        sizes.append(isize)
+        o += bsize
+    assert sizes[-1] == 0 and run[-28:] == bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    return sizes
+
+
+@pytest.mark.parametrize("case", ["t1", "t2", "t12", "t2_clip", "t2_exon"])
+def test_device_writer_equals_host_writer_on_goldens(tmp_path, case):
+    """the output side on the GPU (tbk_bam_encode) against the host writer: same record stream byte for byte, well-formed members,
+    compressed size within 10 % of the host's zlib / libdeflate level 6"""
+    paths = {"t1": sample_paths("t1"), "t2": sample_paths("t2"), "t12": [os.path.join(GOLDEN, "t1", "t1.bam"), os.path.join(GOLDEN, "t2", "t2.bam")],
+             "t2_clip": sample_paths("t2"), "t2_exon": sample_paths("t2")}[case]
+    flags = {"t2_clip": ["-P"], "t2_exon": ["-E"]}.get(case, [])
+    d, h = str(tmp_path / "dev.bam"), str(tmp_path / "host.bam")
+    rd = subprocess.run([os.path.join(BIN, "tiebrush"), "-o", d] + flags + paths, check=True, capture_output=True, text=True, env=dict(os.environ, TBK_TIMING="1"))
+    rh = subprocess.run([os.path.join(BIN, "tiebrush"), "--writer", "host", "-o", h] + flags + paths, check=True, capture_output=True, text=True,
+                        env=dict(os.environ, TBK_TIMING="1"))
+    assert "device writer:" in rd.stderr and "device writer:" not in rh.stderr
+    assert _records(d) == _records(h)
+    _members_ok(d)
+    sd, sh = os.path.getsize(d), os.path.getsize(h)
+    print("%s: %d bytes from the device writer, %d from the host writer: %.3f" % (case, sd, sh, sd / sh))
+    assert sd <= 1.10 * sh
+    # (the goldens themselves: test_tiebrush_cli_on_samples and the t12 test above run through this writer, the default)
+
+
+@pytest.mark.parametrize("profile,flags", [("c5", ["-E", "-N", "5", "-Q", "1"]), ("c3", ["--clip"]), ("c5", ["--keep-secondary", "-S", "--store-frac"]),
+                                           ("c2", []), ("c2", ["-A"]), ("c2", ["-L"])])
+def test_device_writer_equals_host_writer_on_the_option_matrix(tmp_path, profile, flags):
+    from tiebrush_amd import synth
+    tile = synth.make_tile(4, 6000, profile, n_loci=80)
+    paths = synth.write_bams(tile, str(tmp_path / "in"))
+    d, h = str(tmp_path / "dev.bam"), str(tmp_path / "host.bam")
+    _run([os.path.join(BIN, "tiebrush"), "-o", d] + flags + paths)
+    _run([os.path.join(BIN, "tiebrush"), "--writer", "host", "-o", h] + flags + paths)
+    assert _records(d) == _records(h)
+    _members_ok(d)
+
+
+def test_writer_option_is_checked():
+    r = subprocess.run([os.path.join(BIN, "tiebrush"), "--writer", "tape", "-o", "/tmp/x.bam", os.path.join(GOLDEN, "t12.bam")], capture_output=True, text=True)
+    assert r.returncode != 0 and "--writer takes host or device" in r.stderr

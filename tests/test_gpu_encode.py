@@ -1,0 +1,163 @@
+"""Device-side tagging + BGZF encode of the output records (tbk_bam_encode, bgzdef.hip) against the host writer path
+(libtbh.so: tagwrite.cpp, the code the `tiebrush` command line tags with — flushPData's rules, /root/reference/src/tiebrush.cpp:
+506-525, through htslib's bam_aux_update_* semantics): the inflated record stream must be byte-identical, every member must begin
+with a record, carry the right CRC32 / ISIZE and inflate with zlib."""
+import ctypes as C
+import gzip
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, sample_paths
+from test_gpu_deflate import check_run
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from tiebrush_amd import api
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def host_tagged_stream(records, yc, yx, yd, tmp_path):
+    """the host writer's record stream: records (bytes without block_size) tagged by tbh_tag_deflate_part, inflated again"""
+    from tiebrush_amd import _lib
+    H = _lib.load_host()
+    n = len(records)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    ln = np.array([len(r) for r in records], dtype=np.uint32)
+    off[1:] = np.cumsum(ln.astype(np.uint64))
+    blob = np.frombuffer(b"".join(records) + b"\0", dtype=np.uint8)
+    ycv = np.ascontiguousarray(yc, np.float64)
+    yxv = np.ascontiguousarray(yx, np.int64)
+    ydv = np.ascontiguousarray(yd, np.int32)
+    path = str(tmp_path / "host_part.bgzf")
+    rc = H.tbh_tag_deflate_part(blob.ctypes.data, off.ctypes.data, ln.ctypes.data, n, ycv.ctypes.data, yxv.ctypes.data, ydv.ctypes.data, 6, 2,
+                                path.encode())
+    assert rc == 0, H.tbh_last_error()
+    data = open(path, "rb").read()
+    return gzip.decompress(data) if data else b""
+
+
+def members_begin_with_records(run: bytes):
+    """every member's payload is a whole number of records (block_size chains end exactly at the member's end)"""
+    from test_gpu_deflate import members
+    import zlib
+    for z, _, isize in members(run):
+        p = zlib.decompress(z, -15)
+        o = 0
+        while o < len(p):
+            o += 4 + struct.unpack_from("<I", p, o)[0]
+        assert o == len(p) == isize
+
+
+def _golden_case(ctx, names, tbmerged, **opts):
+    files = [open(os.path.join(GOLDEN, n), "rb").read() for n in names]
+    s, fo = ctx.bam_decode(files, tbmerged=np.array(tbmerged, np.uint8))
+    g = ctx.collapse_struct(s, len(files), **opts)
+    rep = g["rep"].cpu().numpy().astype(np.uint32)
+    return s, rep, g["yc"].cpu().numpy(), g["yx"].cpu().numpy(), g["yd"].cpu().numpy()
+
+
+@pytest.mark.parametrize("case", ["t1", "t2", "t12"])
+def test_device_records_equal_the_host_writer(ctx, tmp_path, case):
+    if case == "t12":
+        names, tb = ["t1/t1.bam", "t2/t2.bam"], [1, 1]            # TieBrush-merged inputs: every record carries YC / YX (/ YD) already
+    else:
+        names, tb = [os.path.relpath(p, GOLDEN) for p in sample_paths(case)], [0] * 10
+    s, rep, yc, yx, yd = _golden_case(ctx, names, tb)
+    n_dev = int(s.n_records)
+    run, pay = ctx.bam_encode(rep, yc, yx, yd, n_dev=n_dev)
+    blob, off = ctx.bam_records(rep)
+    recs = [blob[int(off[i]) + 4:int(off[i + 1])] for i in range(len(rep))]
+    want = host_tagged_stream(recs, yc, yx, yd, tmp_path)
+    assert pay == len(want)
+    check_run(run, want)
+    members_begin_with_records(run)
+    # the same records handed over by the host instead (n_dev = 0), and half / half
+    run2, _ = ctx.bam_encode(rep, yc, yx, yd, n_dev=0, host_records={i: recs[i] for i in range(len(rep))})
+    assert gzip.decompress(run2) == want
+    half = n_dev // 2
+    run3, _ = ctx.bam_encode(rep, yc, yx, yd, n_dev=half, host_records={i: recs[i] for i in range(len(rep)) if rep[i] >= half})
+    assert gzip.decompress(run3) == want
+    ctx.bam_release()
+
+
+def test_tag_edit_rules(ctx, tmp_path):
+    """records that already carry the tags in every form bam_aux_update_* distinguishes (htslib 1.18 through GSam.h:300-305):
+    YC as f / d / a wrong type, YX in every integer width, as a string, YD present with a zero and a positive result, duplicates,
+    values at the width boundaries 254 / 255 / 65534 / 65535"""
+    from tiebrush_amd import bamio
+    auxes = [
+        b"",
+        b"NHC\x01",
+        b"YCf" + struct.pack("<f", 3.0),
+        b"YCd" + struct.pack("<d", 3.0) + b"NHC\x01",
+        b"YCi" + struct.pack("<i", 3),
+        b"XSA+" + b"YXC\x07" + b"ZZZhello\0",
+        b"YXS" + struct.pack("<H", 700) + b"YCf" + struct.pack("<f", 1.0),
+        b"YXI" + struct.pack("<I", 70000),
+        b"YXc" + struct.pack("<b", -3),
+        b"YXZabc\0",
+        b"YDC\x05",
+        b"YDI" + struct.pack("<I", 5) + b"NHC\x02",
+        b"YDZxx\0",
+        b"YXC\x01YXC\x02YDC\x09YDC\x08YCf" + struct.pack("<f", 2.0) + b"YCf" + struct.pack("<f", 9.0),
+        b"BBBC" + struct.pack("<I", 3) + b"\x01\x02\x03" + b"YDs" + struct.pack("<h", 300),
+        b"MDZ100\0YTZUU\0",
+    ]
+    vals = [(1.0, 1, 0), (2.0, 254, 0), (3.0, 255, 7), (70000.0, 65534, 254), (1e9, 65535, 255), (5.0, 70000, 65535), (2.5, 3, 65534), (7.0, 2 ** 32 + 5, 1),
+            (4.0, 4, 70000)]
+    recs, yc, yx, yd = [], [], [], []
+    for a in auxes:
+        for (c, x, d) in vals:
+            r = bamio.encode_record(0, 100 + len(recs), 0, 60, [100 << 4], b"r%d" % len(recs), aux=a, l_seq=4, seq=b"\x12\x48", qual=b"IIII")
+            recs.append(r[4:])
+            yc.append(c), yx.append(x), yd.append(d)
+    n = len(recs)
+    rep = np.arange(n, dtype=np.uint32)
+    run, pay = ctx.bam_encode(rep, yc, yx, yd, n_dev=0, host_records={i: recs[i] for i in range(n)})
+    want = host_tagged_stream(recs, yc, yx, yd, tmp_path)
+    got = gzip.decompress(run)
+    if got != want:                      # say which record differs
+        o = 0
+        for i in range(n):
+            bs = struct.unpack_from("<I", want, o)[0]
+            assert got[o:o + 4 + bs] == want[o:o + 4 + bs], (i, auxes[i // len(vals)], vals[i % len(vals)])
+            o += 4 + bs
+    assert got == want and pay == len(want)
+    members_begin_with_records(run)
+
+
+def test_many_records_many_members(ctx, tmp_path):
+    """a few hundred thousand output records: members cut at record boundaries by bisection, all of them exact"""
+    from tiebrush_amd import bamio
+    rng = np.random.default_rng(23)
+    base = [bamio.encode_record(0, 1000 + k, 16 * (k & 1), 60, [100 << 4], b"read_%d" % k, aux=b"NHC\x01" + b"ASC" + bytes([k & 63]), l_seq=100,
+                                seq=bytes(rng.integers(0, 256, 50, dtype=np.uint8)), qual=bytes(rng.integers(30, 42, 100, dtype=np.uint8)))[4:] for k in range(4000)]
+    n = 300_000
+    pick = rng.integers(0, len(base), n)
+    recs = [base[i] for i in pick]
+    yc = rng.integers(1, 400, n).astype(np.float64)
+    yx = rng.integers(1, 70, n)
+    yd = rng.integers(0, 3, n) * rng.integers(0, 70000, n)
+    rep = np.arange(n, dtype=np.uint32)
+    run, pay = ctx.bam_encode(rep, yc, yx, yd, n_dev=0, host_records={i: recs[i] for i in range(n)})
+    want = host_tagged_stream(recs, yc, yx, yd, tmp_path)
+    assert pay == len(want)
+    check_run(run, want)
+    members_begin_with_records(run)
+
+
+def test_empty_and_malformed(ctx):
+    run, pay = ctx.bam_encode(np.zeros(0, np.uint32), [], [], [])
+    assert run == b"" and pay == 0
+    from tiebrush_amd.api import TbkError
+    bad = b"\x00" * 20                                   # shorter than a BAM core
+    with pytest.raises(TbkError):
+        ctx.bam_encode(np.zeros(1, np.uint32), [1.0], [1], [0], n_dev=0, host_records={0: bad})

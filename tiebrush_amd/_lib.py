@@ -23,7 +23,7 @@ SYMBOLS = ["tbk_abi_version", "tbk_create", "tbk_destroy", "tbk_strerror", "tbk_
            "tbk_get_stream", "tbk_set_profiling", "tbk_kernel_times", "tbk_host_alloc", "tbk_host_free",
            "tbk_collapse_opts_default", "tbk_collapse_tile", "tbk_collapse_finish_yd", "tbk_coverage_tile", "tbk_sample_tile",
            "tbk_groups_to_cov_in", "tbk_bgzf_inflate", "tbk_bam_decode", "tbk_bam_records", "tbk_bam_release", "tbk_shard_prepare", "tbk_shard_probe_max", "tbk_shard_probe_next",
-           "tbk_shard_pack", "tbk_shard_unpack", "tbk_partial_keys", "tbk_partial_pack", "tbk_partial_unpack", "tbk_partial_reduce", "tbk_unpack_tile", "tbk_tile_join", "tbk_reserve_tile"]
+           "tbk_shard_pack", "tbk_shard_unpack", "tbk_partial_keys", "tbk_partial_pack", "tbk_partial_unpack", "tbk_partial_reduce", "tbk_unpack_tile", "tbk_tile_join", "tbk_reserve_tile", "tbk_bgzf_deflate", "tbk_bam_encode"]
 
 
 class CollapseOpts(C.Structure):
@@ -67,6 +67,11 @@ class CovOut(C.Structure):
 class SampleOut(C.Structure):
     _fields_ = [("mem", C.c_int32), ("cap_intervals", C.c_uint32), ("iv_tid", _P), ("iv_start", _P), ("iv_end", _P),
                 ("iv_count", _P), ("iv_heat", _P), ("n_intervals", C.c_uint32)]
+
+
+class EncIn(C.Structure):
+    _fields_ = [("mem", C.c_int32), ("n", C.c_uint32), ("rep", _P), ("yc", _P), ("yx", _P), ("yd", _P), ("n_dev", C.c_uint32), ("n_host", C.c_uint32),
+                ("host_blob", _P), ("host_off", _P), ("host_slot", _P)]
 
 
 class KernelTime(C.Structure):
@@ -135,6 +140,10 @@ def load():
     L.tbk_reserve_tile.argtypes = [_P, C.c_uint64, C.c_uint64]
     L.tbk_reserve_tile.restype = C.c_int
     L.tbk_unpack_tile.argtypes = [_P, C.POINTER(PackedIn), C.POINTER(SoaIn)]
+    L.tbk_bgzf_deflate.argtypes = [_P, _P, C.c_uint64, C.c_int, _P, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.tbk_bgzf_deflate.restype = C.c_int
+    L.tbk_bam_encode.argtypes = [_P, C.POINTER(EncIn), _P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.tbk_bam_encode.restype = C.c_int
     _lib = L
     return L
 

@@ -317,6 +317,57 @@ class Context:
         self._check(rc, "tbk_bgzf_inflate")
         return out[:int(need.value)].tobytes()
 
+    def bgzf_deflate(self, payload: bytes, cuts=None) -> bytes:
+        """tbk_bgzf_deflate: a byte run -> whole BGZF members (host bytes in, host bytes out); cuts = payload offsets of the member
+        boundaries ([0, ..., len(payload)]), default one member per 0xff00 bytes"""
+        src = np.frombuffer(payload, dtype=np.uint8)
+        need = C.c_uint64(0)
+        out = np.empty(len(src) + (len(src) // 0xff00 + 2 + (len(cuts) if cuts is not None else 0)) * 64 + 4096, dtype=np.uint8)
+        cp, nm = None, 0
+        if cuts is not None:
+            cuts = np.ascontiguousarray(cuts, dtype=np.uint64)
+            cp, nm = cuts.ctypes.data, len(cuts) - 1
+        rc = self.L.tbk_bgzf_deflate(self.h, src.ctypes.data if len(src) else None, len(src), _lib.TBK_MEM_HOST, cp, nm, out.ctypes.data, out.size,
+                                     C.byref(need))
+        if rc == -4:
+            out = np.empty(int(need.value), dtype=np.uint8)
+            rc = self.L.tbk_bgzf_deflate(self.h, src.ctypes.data, len(src), _lib.TBK_MEM_HOST, cp, nm, out.ctypes.data, out.size, C.byref(need))
+        self._check(rc, "tbk_bgzf_deflate")
+        return out[:int(need.value)].tobytes()
+
+    def bam_encode(self, rep, yc, yx, yd, n_dev=0, host_records=None):
+        """tbk_bam_encode: the output records of a collapse -> (run of BGZF members, payload bytes).  rep < n_dev: records of the tile
+        bam_decode left on this context; the others come from host_records = {group index: raw record bytes WITHOUT block_size}"""
+        rep = np.ascontiguousarray(rep, dtype=np.uint32)
+        n = len(rep)
+        yc = np.ascontiguousarray(yc, dtype=np.float64)
+        yx = np.ascontiguousarray(yx, dtype=np.int64)
+        yd = np.ascontiguousarray(yd, dtype=np.int32)
+        e = _lib.EncIn()
+        e.mem, e.n, e.rep, e.yc, e.yx, e.yd, e.n_dev = _lib.TBK_MEM_HOST, n, rep.ctypes.data, yc.ctypes.data, yx.ctypes.data, yd.ctypes.data, n_dev
+        keep = []
+        if host_records:
+            slot = np.zeros(n, dtype=np.uint32)
+            blobs, off = [], [0]
+            for k, g in enumerate(sorted(host_records)):
+                r = host_records[g]
+                slot[g] = k
+                blobs.append(len(r).to_bytes(4, "little") + r)
+                off.append(off[-1] + 4 + len(r))
+            blob = np.frombuffer(b"".join(blobs), dtype=np.uint8)
+            offa = np.asarray(off, dtype=np.uint64)
+            keep = [slot, blob, offa]
+            e.n_host, e.host_blob, e.host_off, e.host_slot = len(blobs), blob.ctypes.data, offa.ctypes.data, slot.ctypes.data
+        need, pay = C.c_uint64(0), C.c_uint64(0)
+        out = np.empty(max(1 << 16, 64 * n), dtype=np.uint8)
+        rc = self.L.tbk_bam_encode(self.h, C.byref(e), out.ctypes.data, out.size, C.byref(need), C.byref(pay))
+        if rc == -4:
+            out = np.empty(int(need.value), dtype=np.uint8)
+            rc = self.L.tbk_bam_encode(self.h, C.byref(e), out.ctypes.data, out.size, C.byref(need), C.byref(pay))
+        self._check(rc, "tbk_bam_encode")
+        del keep
+        return out[:int(need.value)].tobytes(), int(pay.value)
+
     def bam_decode(self, files, tbmerged=None, want_md=False, want_names=False):
         """tbk_bam_decode: list of whole BAM files (bytes) -> (SoaIn struct describing the device-resident tile, file_off).
         The struct can go straight to collapse_struct(); its arrays live in the context until bam_release()."""

@@ -1267,6 +1267,13 @@ static void bamdev_free(tbk_ctx* ctx) {
   ctx->bam_dev = nullptr;
 }
 
+bool tbk_bam_dev_records(tbk_ctx* ctx, const uint8_t** inf, const uint64_t** rec, uint32_t* n) {
+  BamDev* B = (BamDev*)ctx->bam_dev;
+  if (!B || !B->inf || !B->rec) return false;
+  *inf = B->inf, *rec = B->rec, *n = B->n;
+  return true;
+}
+
 extern "C" void tbk_bam_release(tbk_ctx* ctx) {
   if (!ctx) return;
   (void)tbk_collapse_finish_yd(ctx);  // (a deferred YD stage may still read the decoded tile)

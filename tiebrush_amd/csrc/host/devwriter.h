@@ -1,0 +1,218 @@
+// devwriter.h — the output side of the tiebrush command line on the device: flushPData's tagging (/root/reference/src/tiebrush.cpp:
+// 506-525) and GSamWriter::write -> sam_write1 (GSam.h:648-653) of the collapsed groups, through tbk_bam_encode (include/tbk.h).
+//
+// The groups go out in chunks through three stages that run side by side:
+//   gather   the representatives the HOST decoded are copied — by every core — into a pinned staging buffer (records the device decoded
+//            are read where they lie: nothing to gather);
+//   encode   one tbk_bam_encode per chunk: H2D of the staged records and the chunk's YC / YX / YD, tags, member cuts, deflate, D2H of the
+//            finished BGZF members into a pinned buffer (a thread of its own: the context is busy for the length of the call);
+//   write    the members appended to the output file (a thread of its own: the write of chunk k runs beside the encode of k + 1).
+// Three slots of buffers, so every stage works on a chunk of its own.  The record stream is the host writer's byte for byte
+// (tests/test_gpu_cli.py); the members differ (another deflate parse, members cut at record boundaries).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "GSam.h"
+#include "bam.h"
+#include "tbk_dl.h"
+
+class DeviceWriter {
+ public:
+  static constexpr uint32_t kChunkGroups = 256u << 10;  // ~ 64 MB of records with SEQ / QUAL per chunk
+  static constexpr int kSlots = 3;
+
+  DeviceWriter(TbkApi& api, int nthreads) : api_(api), nt_(nthreads < 1 ? 1 : nthreads) {}
+  ~DeviceWriter() {
+    for (auto& s : slot_) {
+      if (s.blob) api_.host_free(s.blob);
+      if (s.z) api_.host_free(s.z);
+    }
+  }
+  // pinned staging, sized for a chunk of typical records; grown when a chunk needs more.  Page-locking hundreds of megabytes takes tens
+  // of milliseconds: the command line calls this on its helper thread while the inputs are decoded.
+  bool reserve(size_t blob_bytes = (size_t)kChunkGroups * 272, size_t z_bytes = (size_t)kChunkGroups * 112) {
+    for (auto& s : slot_) {
+      if (!grow(s.blob, s.blob_cap, blob_bytes) || !grow(s.z, s.z_cap, z_bytes)) return false;
+    }
+    return true;
+  }
+
+  // Groups [0, ng) of a collapse (rep / yc / yx / yd: HOST arrays in output order).  Representatives with rep < n_dev are records of
+  // the tile tbk_bam_decode left on `ctx`; host_record(g) hands out the others.  Returns false — with nothing written — when the
+  // device cannot take the output (TBK_EUNSUPPORTED / TBK_ENOMEM on the first chunk: the caller's host writer takes over); any later
+  // failure is fatal (GError).  *payload / *zbytes: bytes of tagged records / of BGZF members written.
+  bool write(tbk_ctx* ctx, GSamWriter& out, uint32_t ng, const uint32_t* rep, const double* yc, const int64_t* yx, const int32_t* yd, uint32_t n_dev,
+             const std::function<tbh::RecView(uint32_t)>& host_record, uint64_t* payload, uint64_t* zbytes, std::string& why) {
+    *payload = *zbytes = 0;
+    if (ng == 0) return true;
+    if (!reserve()) {
+      why = "pinned staging memory";
+      return false;
+    }
+    const uint32_t nchunk = (ng + kChunkGroups - 1) / kChunkGroups;
+    // stage hand-offs: state[k] counts how far chunk k has come (1 gathered, 2 encoded, 3 written)
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<int> state(nchunk, 0);
+    std::atomic<int> fail{0};  // 1: first chunk refused (fall back), 2: fatal
+    std::string fail_msg;
+    auto set_state = [&](uint32_t k, int v) {
+      {
+        std::lock_guard<std::mutex> lk(m);
+        state[k] = v;
+      }
+      cv.notify_all();
+    };
+    auto wait_state = [&](uint32_t k, int v) {
+      std::unique_lock<std::mutex> lk(m);
+      cv.wait(lk, [&] { return state[k] >= v || fail.load() != 0; });
+      return fail.load() == 0;
+    };
+    std::vector<uint64_t> zsz(nchunk, 0), psz(nchunk, 0);
+    std::vector<uint32_t> nhost(nchunk, 0);
+    std::thread enc([&]() {
+      for (uint32_t k = 0; k < nchunk; ++k) {
+        if (!wait_state(k, 1)) return;
+        Slot& s = slot_[k % kSlots];
+        const uint32_t g0 = k * kChunkGroups, g1 = std::min(ng, g0 + kChunkGroups);
+        tbk_enc_in in;
+        memset(&in, 0, sizeof(in));
+        in.mem = TBK_MEM_HOST;
+        in.n = g1 - g0;
+        in.rep = rep + g0, in.yc = yc + g0, in.yx = yx + g0, in.yd = yd + g0;
+        in.n_dev = n_dev;
+        in.n_host = nhost[k];
+        in.host_blob = s.blob, in.host_off = s.off.data(), in.host_slot = s.slot.data();
+        uint64_t zb = 0, pb = 0;
+        int rc = api_.bam_encode(ctx, &in, s.z, s.z_cap, &zb, &pb);
+        if (rc == TBK_E2BIG && zb > s.z_cap) {  // (the members of this chunk need a larger buffer: the call said how large)
+          if (!grow(s.z, s.z_cap, zb + zb / 8)) rc = TBK_ENOMEM;
+          else rc = api_.bam_encode(ctx, &in, s.z, s.z_cap, &zb, &pb);
+        }
+        if (rc != 0) {
+          fail_msg = std::string(api_.strerror_(rc)) + " (" + api_.last_error(ctx) + ")";
+          fail.store(k == 0 && (rc == TBK_EUNSUPPORTED || rc == TBK_ENOMEM) ? 1 : 2);
+          cv.notify_all();
+          return;
+        }
+        zsz[k] = zb, psz[k] = pb;
+        set_state(k, 2);
+      }
+    });
+    std::thread wr([&]() {
+      for (uint32_t k = 0; k < nchunk; ++k) {
+        if (!wait_state(k, 2)) return;
+        Slot& s = slot_[k % kSlots];
+        out.write_members(s.z, (size_t)zsz[k]);
+        set_state(k, 3);
+      }
+    });
+    // the gather, on this thread and its workers
+    for (uint32_t k = 0; k < nchunk && fail.load() == 0; ++k) {
+      if (k >= (uint32_t)kSlots && !wait_state(k - kSlots, 3)) break;  // the slot's previous chunk has left the building
+      Slot& s = slot_[k % kSlots];
+      const uint32_t g0 = k * kChunkGroups, g1 = std::min(ng, g0 + kChunkGroups), nc = g1 - g0;
+      s.slot.resize(nc);
+      // pass 1: which groups bring a host record, and how long — per slice of the chunk
+      const int T = nc < 8192 ? 1 : nt_;
+      std::vector<uint64_t> sl_bytes((size_t)T + 1, 0);
+      std::vector<uint32_t> sl_cnt((size_t)T + 1, 0);
+      auto slice = [&](int t, uint32_t* a, uint32_t* b) {
+        *a = g0 + (uint32_t)((uint64_t)nc * (uint32_t)t / (uint32_t)T);
+        *b = g0 + (uint32_t)((uint64_t)nc * ((uint32_t)t + 1) / (uint32_t)T);
+      };
+      parallel(T, [&](int t) {
+        uint32_t a, b;
+        slice(t, &a, &b);
+        uint64_t by = 0;
+        uint32_t cn = 0;
+        for (uint32_t g = a; g < b; ++g)
+          if (rep[g] >= n_dev) by += 4 + (uint64_t)host_record(g).len, ++cn;
+        sl_bytes[(size_t)t + 1] = by, sl_cnt[(size_t)t + 1] = cn;
+      });
+      for (int t = 0; t < T; ++t) sl_bytes[(size_t)t + 1] += sl_bytes[(size_t)t], sl_cnt[(size_t)t + 1] += sl_cnt[(size_t)t];
+      const uint64_t total = sl_bytes[(size_t)T];
+      nhost[k] = sl_cnt[(size_t)T];
+      s.off.resize((size_t)nhost[k] + 1);
+      if (total + 16 > s.blob_cap && !grow(s.blob, s.blob_cap, total + total / 8 + 16)) {
+        fail_msg = "pinned staging memory";
+        fail.store(k == 0 ? 1 : 2);
+        cv.notify_all();
+        break;
+      }
+      // pass 2: the copies
+      parallel(T, [&](int t) {
+        uint32_t a, b;
+        slice(t, &a, &b);
+        uint64_t o = sl_bytes[(size_t)t];
+        uint32_t c = sl_cnt[(size_t)t];
+        for (uint32_t g = a; g < b; ++g) {
+          if (rep[g] < n_dev) {
+            s.slot[g - g0] = 0;
+            continue;
+          }
+          const tbh::RecView v = host_record(g);
+          s.slot[g - g0] = c;
+          s.off[c++] = o;
+          memcpy(s.blob + o, &v.len, 4);
+          memcpy(s.blob + o + 4, v.p, v.len);
+          o += 4 + (uint64_t)v.len;
+        }
+      });
+      s.off[nhost[k]] = total;
+      set_state(k, 1);
+    }
+    enc.join();
+    wr.join();
+    if (fail.load() == 1) {
+      why = fail_msg;
+      return false;
+    }
+    if (fail.load() == 2) GError("Error: encoding the output on the GPU failed: %s\n", fail_msg.c_str());
+    for (uint32_t k = 0; k < nchunk; ++k) *payload += psz[k], *zbytes += zsz[k];
+    return true;
+  }
+
+ private:
+  struct Slot {
+    uint8_t* blob = nullptr;
+    size_t blob_cap = 0;
+    uint8_t* z = nullptr;
+    size_t z_cap = 0;
+    std::vector<uint64_t> off;
+    std::vector<uint32_t> slot;
+  };
+  bool grow(uint8_t*& p, size_t& cap, size_t want) {
+    if (want <= cap) return true;
+    if (p) api_.host_free(p);
+    p = nullptr, cap = 0;
+    void* q = nullptr;
+    if (api_.host_alloc(want, &q) != 0) return false;
+    p = (uint8_t*)q, cap = want;
+    return true;
+  }
+  template <class F>
+  void parallel(int T, F f) {
+    if (T <= 1) {
+      f(0);
+      return;
+    }
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back([&f, t]() { f(t); });
+    f(0);
+    for (auto& x : th) x.join();
+  }
+  TbkApi& api_;
+  int nt_;
+  Slot slot_[kSlots];
+};

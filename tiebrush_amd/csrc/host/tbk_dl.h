@@ -24,6 +24,9 @@ struct TbkApi {
   decltype(&tbk_bam_release) bam_release = nullptr;
   decltype(&tbk_tile_join) tile_join = nullptr;
   decltype(&tbk_reserve_tile) reserve_tile = nullptr;
+  decltype(&tbk_bam_encode) bam_encode = nullptr;
+  decltype(&tbk_host_alloc) host_alloc = nullptr;
+  decltype(&tbk_host_free) host_free = nullptr;
   std::string error;
 
   bool load() {
@@ -58,6 +61,9 @@ struct TbkApi {
     TBK_BIND(bam_release, tbk_bam_release)
     TBK_BIND(tile_join, tbk_tile_join)
     TBK_BIND(reserve_tile, tbk_reserve_tile)
+    TBK_BIND(bam_encode, tbk_bam_encode)
+    TBK_BIND(host_alloc, tbk_host_alloc)
+    TBK_BIND(host_free, tbk_host_free)
 #undef TBK_BIND
     if (abi_version() != TBK_ABI_VERSION) {
       error = "libtbk.so has another ABI version";

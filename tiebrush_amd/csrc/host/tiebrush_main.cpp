@@ -32,6 +32,7 @@
 #include "GSam.h"
 #include "args.h"
 #include "bgzf.h"
+#include "devwriter.h"
 #include "fastload.h"
 #include "tagwrite.h"
 #include "tbk_dl.h"
@@ -65,7 +66,8 @@ static const char* USAGE =
     "  -A,--collapse-same   do not count the same read of the same sample twice\n"
     "  --store-frac         YC adds 1/NH per alignment (needs --keep-secondary)\n"
     "  -V,--verbose         echo the command line\n"
-    "  --ranks N            shard the input files over N GPUs of this node (one process each), one output BAM\n";
+    "  --ranks N            shard the input files over N GPUs of this node (one process each), one output BAM\n"
+    "  --writer WHICH       device (default): the output records are tagged and BGZF-compressed on the GPU; host: by the CPU cores\n";
 
 // a buffer that is allocated, not initialised (untouched pages cost nothing), on huge pages when it is large, and not freed at
 // the end: these buffers live as long as the process, which ends with _exit — returning gigabytes page by page first only
@@ -142,7 +144,7 @@ int main(int argc, char* argv[]) {
   maybe_exec_ranks(argc, argv);
   TInputFiles inRecords;
   inRecords.setup(VERSION, argc, argv);
-  Args args(argc, argv, "help;debug;verbose;version;full;clip;exon;keep-supp;keep-secondary;keep-unmap;collapse-same;store-frac;SMLPEDVho:N:Q:F:A");
+  Args args(argc, argv, "help;debug;verbose;version;full;clip;exon;keep-supp;keep-secondary;keep-unmap;collapse-same;store-frac;writer=;SMLPEDVho:N:Q:F:A");
   if (!args.error().empty()) {
     GMessage("%s\n%s\n", USAGE, args.error().c_str());
     return 1;
@@ -191,6 +193,11 @@ int main(int argc, char* argv[]) {
     fprintf(stderr, "Running TieBrush " VERSION ". Command line:\n");
     args.printCmdLine(stderr);
   }
+  bool dev_writer = true;
+  if (const char* w = args.getOpt("writer")) {
+    if (strcmp(w, "host") == 0) dev_writer = false;
+    else if (strcmp(w, "device") != 0) GError("Error: --writer takes host or device\n");
+  }
   if (opt.flags_mask != 0) GError("Error: -F is not supported by the GPU build (its reference semantics are unpinned)\n");
   if (opt.keep_unmapped) GError("Error: -M/--keep-unmap is not supported by the GPU build\n");
   while (const char* ifn = args.nextNonOpt()) inRecords.addFile(tbh_realpath(ifn).c_str());
@@ -208,9 +215,14 @@ int main(int argc, char* argv[]) {
   int dev = getenv("TBK_DEVICE") ? atoi(getenv("TBK_DEVICE")) : 0;
   int rc = 0;
   bool api_ok = false;
+  DeviceWriter* dw = nullptr;  // (pinned staging: lives until the process ends)
   std::thread ctx_thread([&]() {
     api_ok = api.load();
     if (api_ok) rc = api.create(dev, &ctx);
+    if (api_ok && rc == 0 && dev_writer) {
+      dw = new DeviceWriter(api, tbh::cpu_budget());
+      (void)dw->reserve();  // (page-locking the staging buffers: tens of milliseconds, beside the decode)
+    }
     if (api_ok && rc == 0 && !getenv("TBK_NO_WARMUP")) {
       // one tiny collapse: the first launch maps the code objects of the library onto the device and the first call sizes the
       // context's buffers — tens of milliseconds that belong beside the inflate, not behind it
@@ -251,7 +263,8 @@ int main(int argc, char* argv[]) {
   };
   inRecords.start();
   auto t_ctx = tnow();
-  double ms_load = 0, ms_gpu = 0, ms_tag = 0, ms_inflate = 0;
+  double ms_load = 0, ms_gpu = 0, ms_tag = 0, ms_inflate = 0, ms_dev_write = 0;
+  uint64_t dev_payload = 0, dev_z = 0;
 
   int nthreads = tbh::cpu_budget();
   if (nthreads < 1) nthreads = 1;
@@ -334,6 +347,20 @@ int main(int argc, char* argv[]) {
       }
       for (auto& x : th) x.join();
       if (failed.load()) GError("Error: deflate failed\n");
+    };
+    // the same on the device (devwriter.h): tags, framing and BGZF deflate as kernels, the host only gathers the records it decoded
+    // itself and appends the finished members.  false: nothing written, the host writer above takes the groups.
+    auto write_groups_device = [&](uint32_t ng, uint32_t n_dev, const std::function<tbh::RecView(uint32_t)>& host_record) {
+      if (!dev_writer || outfile.level() == 0) return false;
+      need_ctx();
+      if (!dw) return false;
+      auto a = tnow();
+      uint64_t pb = 0, zb = 0;
+      std::string why;
+      const bool ok = dw->write(ctx, outfile, ng, rep.data(), yc.data(), yx.data(), yd.data(), n_dev, host_record, &pb, &zb, why);
+      if (!ok && timing) fprintf(stderr, "device writer not used (%s): host writer\n", why.c_str());
+      if (ok) ms_dev_write += tms(a, tnow()), dev_payload += pb, dev_z += zb;
+      return ok;
     };
     // half of what the host may still use (MemAvailable, the cgroup's limit): what the whole-input loaders may fill with inflated inputs
     auto host_budget = []() {
@@ -467,7 +494,16 @@ int main(int argc, char* argv[]) {
             t_col = tnow();
             if (rc == TBK_EUNSORTED) GError("Error: an input file is not coordinate-sorted!\n");
           }
-          if (rc == 0) {  // the representatives the device decoded: their raw records come back from there
+          bool wrote_dev = false;
+          if (rc == 0) {
+            wrote_dev = write_groups_device(out.n_groups, n_d, [&](uint32_t g) {
+              tbh::RecView v;
+              v.p = ft.record(rep[g] - n_d, &v.len);
+              return v;
+            });
+            t_rec = tnow();
+          }
+          if (rc == 0 && !wrote_dev) {  // the representatives the device decoded: their raw records come back from there
             std::vector<uint32_t> dev_rep;
             dev_slot.assign(out.n_groups, 0);
             for (uint32_t g = 0; g < out.n_groups; ++g)
@@ -487,9 +523,26 @@ int main(int argc, char* argv[]) {
           ok = rc == 0;
           if (!ok && rc != TBK_ENOMEM && rc != TBK_E2BIG && rc != TBK_EUNSUPPORTED)
             GError("Error: GPU collapse failed: %s (%s)\n", api.strerror_(rc), api.last_error(ctx));
+          if (ok && wrote_dev) {
+            auto t3 = tnow();
+            if (timing)
+              fprintf(stderr,
+                      "hybrid path ms: device %zu of %zu files (read %.1f | decode incl. context %.1f) beside host (read %.1f | inflate %.1f | index %.1f | SoA %.1f) = %.1f | "
+                      "join %.1f | collapse %.1f | gather + tag + deflate (GPU) + write %.1f (%.1f MB of records -> %.1f MB)\n",
+                      kd, k, ms_dread, ms_ddec, ft.ms_read, ft.ms_inflate, ft.ms_index, ft.ms_soa, tms(t0, t1), tms(t1, t_join), tms(t_join, t_col), tms(t_col, t3),
+                      dev_payload / 1e6, dev_z / 1e6);
+            ms_inflate += tms(t0, t1);
+            ms_gpu += tms(t1, t_col);
+            ms_tag += tms(t_col, t3);
+            inCounter += out.n_passed;
+            outCounter += out.n_groups;
+            n_tiles = 1;
+            done_fast = true;
+          }
         }
         if (ctx_ready) api.bam_release(ctx);
-        if (!ok) {
+        if (done_fast) {
+        } else if (!ok) {
           if (timing) fprintf(stderr, "hybrid decode given up (%s): streaming host path\n", rc_d != 0 ? api.strerror_(rc_d) : (fits ? api.strerror_(rc) : "the host's share does not fit"));
           tbh::big_release_all(nthreads);
           skip_fast = true;
@@ -576,7 +629,7 @@ int main(int argc, char* argv[]) {
               v.p = ft.record(rep[g], &v.len);
               return v;
             };
-            write_groups(out.n_groups);
+            if (!write_groups_device(out.n_groups, 0, get_record)) write_groups(out.n_groups);
             auto t3 = tnow();
             if (timing)
               fprintf(stderr, "host path ms: read %.1f | inflate %.1f | index %.1f | SoA %.1f | wait for the device %.1f | collapse (PCIe incl.) %.1f | tag+deflate+write %.1f\n",
@@ -668,7 +721,9 @@ int main(int argc, char* argv[]) {
           if (rc == TBK_EUNSORTED) GError("Error: an input file is not coordinate-sorted!\n");
           RawBuf<uint64_t> roff;
           RawBuf<uint8_t> blob;
-          if (rc == 0) {
+          bool wrote_dev = false;
+          if (rc == 0) wrote_dev = write_groups_device(out.n_groups, (uint32_t)n, [](uint32_t) { return tbh::RecView(); });
+          if (rc == 0 && !wrote_dev) {
             roff.resize((size_t)out.n_groups + 1);
             blob.resize((size_t)out.n_groups * 96 + 4096);
             rc = api.bam_records(ctx, rep.data(), out.n_groups, TBK_MEM_HOST, blob.data(), blob.size(), roff.data());
@@ -695,7 +750,7 @@ int main(int argc, char* argv[]) {
               v.len = (uint32_t)(roff[g + 1] - roff[g] - 4);
               return v;
             };
-            write_groups(out.n_groups);
+            if (!wrote_dev) write_groups(out.n_groups);
             auto t3 = tnow();
             ms_inflate += tms(t0, t1);
             ms_gpu += tms(t1, t2);
@@ -741,7 +796,7 @@ int main(int argc, char* argv[]) {
       auto t2 = tnow();
       if (rc == TBK_EUNSORTED) GError("Error: an input file is not coordinate-sorted!\n");
       if (rc != 0) GError("Error: GPU collapse failed: %s (%s)\n", api.strerror_(rc), api.last_error(ctx));
-      write_groups(out.n_groups);
+      if (!write_groups_device(out.n_groups, 0, get_record)) write_groups(out.n_groups);
       auto t3 = tnow();
       ms_load += tms(t0, t1);
       ms_gpu += tms(t1, t2);
@@ -756,6 +811,7 @@ int main(int argc, char* argv[]) {
   if (timing) fprintf(stderr, "writer closed at %.1f ms\n", tms(t_start, t_closed));
   need_ctx();
   // (no tbk_destroy / stop: the process ends below, the OS reclaims device and host memory faster than piecewise frees)
+  if (timing && dev_z) fprintf(stderr, "device writer: %.1f MB of tagged records -> %.1f MB of BGZF members in %.1f ms\n", dev_payload / 1e6, dev_z / 1e6, ms_dev_write);
   if (timing)
     fprintf(stderr, "timing ms: open+context %.1f | inflate+index %.1f | SoA %.1f | collapse (PCIe incl.) %.1f | tag+queue %.1f | total to writer close %.1f\n",
             tms(t_start, t_ctx), ms_inflate, ms_load, ms_gpu, ms_tag, tms(t_start, t_closed));
@@ -776,6 +832,7 @@ int main(int argc, char* argv[]) {
     struct timespec ts;
     clock_gettime(CLOCK_REALTIME, &ts);
     fprintf(stderr, "exit timing: tbk_destroy %.1f ms; _exit at %.3f\n", tms(a, tnow()), (double)ts.tv_sec + ts.tv_nsec * 1e-9);
+    if (atoi(getenv("TBK_EXIT_TIMING")) > 2) return 0;  // (a plain return: what a profiler's exit handlers need to write their traces)
   }
   _exit(0);  // the output is closed and flushed: skip the runtime's teardown of a process that is done (tens of ms of hipFree / unload)
 }

@@ -141,7 +141,11 @@ struct tbk_ctx {
   size_t d_unpack_cap = 0;
   std::vector<uint8_t> unpack_tbm;
   void* bam_dev = nullptr;       // device-decoded BAM input (bamdev.hip): inflated streams + record index + the SoA tile's arrays
+  void* enc = nullptr;           // the encoder's device buffers (bgzdef.hip)
 };
+void tbk_enc_free(tbk_ctx* ctx);
+// the tile tbk_bam_decode left on the context: inflated streams, record offsets, record count (false: there is none)
+bool tbk_bam_dev_records(tbk_ctx* ctx, const uint8_t** inf, const uint64_t** rec, uint32_t* n);
 
 // side context (created on first use; nullptr if that fails -> the caller runs the branch inline), and the call
 // bracket a branch thread puts around its work on it
