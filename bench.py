@@ -684,7 +684,7 @@ def main():
         if host_path is not None:
             line["kernel_path_host_to_host"] = host_path
         if e2e is not None:
-            for sub, name in (("seq", "end_to_end_seq"), ("c3_options", "end_to_end_c3_options")):
+            for sub, name in (("seq", "end_to_end_seq"), ("seq_long", "end_to_end_seq_long"), ("c3_options", "end_to_end_c3_options")):
                 if isinstance(e2e, dict) and sub in e2e:
                     line[name] = e2e.pop(sub)
             line["end_to_end"] = e2e

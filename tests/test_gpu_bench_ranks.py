@@ -51,6 +51,9 @@ def test_bench_default_line_contract_small():
     es, ec = d["end_to_end_seq"], d["end_to_end_c3_options"]          # records with SEQ / QUAL; config 3's options
     assert es["value"] > 0 and "60000 input records written as" in es["summary"] and es["input_bytes_per_record"] > 3 * e["input_bytes_per_record"]
     assert ec["value"] > 0 and "--clip" in ec["workload"] and "60000 input records written as" in ec["summary"]
+    el = d["end_to_end_seq_long"]                                      # four times the records of the SEQ / QUAL leg
+    assert el["value"] > 0 and "240000 input records written as" in el["summary"] and el["workload"].startswith("6 files x 40000 reads")
+    assert es["host_writer_wall_s"] > 0 and es["host_writer_output_bam_bytes"] > 0   # the same leg with --writer host rides along
     c = d["cpu_baseline"]
     assert c["cores"] == 1 and c["value"] > 0 and c["value_O0"] > 0 and c["sample"].startswith("the whole tile")
     assert c["parallel"]["cores"] >= 2 and c["parallel"]["value"] > 0

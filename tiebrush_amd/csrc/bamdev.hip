@@ -17,6 +17,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "dev_common.cuh"
@@ -1267,6 +1269,96 @@ static void bamdev_free(tbk_ctx* ctx) {
   ctx->bam_dev = nullptr;
 }
 
+// ---- host -> device through a pinned ring -----------------------------------------------------------------------------------
+// The compressed files come in the caller's pageable memory (or a mapping of the page cache).  A plain hipMemcpy from there is staged by
+// the runtime on one thread (~ 10 GB/s); here a few threads copy 16 MB chunks into page-locked slots of the context and queue each
+// slot's DMA on an upload stream of its own, so the link runs near its rate and — the caller uploads group after group — the inflate
+// of one group of files runs while the next group is on its way.
+namespace {
+struct Stager {
+  static constexpr int T = 3, PER = 2;
+  static constexpr size_t S = (size_t)16 << 20;
+  uint8_t* pin[T * PER] = {};
+  hipEvent_t ev[T * PER] = {};
+  bool used[T * PER] = {};
+  hipStream_t up = nullptr;
+  hipEvent_t done = nullptr;
+};
+struct StageChunk {
+  uint8_t* dst;
+  const uint8_t* src;
+  size_t len;
+};
+}  // namespace
+
+void tbk_stager_free(tbk_ctx* ctx) {
+  Stager* S = (Stager*)ctx->stager;
+  if (!S) return;
+  for (int i = 0; i < Stager::T * Stager::PER; ++i) {
+    if (S->pin[i]) (void)hipHostFree(S->pin[i]);
+    if (S->ev[i]) (void)hipEventDestroy(S->ev[i]);
+  }
+  if (S->done) (void)hipEventDestroy(S->done);
+  if (S->up) (void)hipStreamDestroy(S->up);
+  delete S;
+  ctx->stager = nullptr;
+}
+
+static Stager* stager_get(tbk_ctx* ctx) {
+  if (ctx->stager) return (Stager*)ctx->stager;
+  Stager* S = new Stager();
+  bool ok = hipStreamCreateWithFlags(&S->up, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&S->done, hipEventDisableTiming) == hipSuccess;
+  for (int i = 0; ok && i < Stager::T * Stager::PER; ++i)
+    ok = hipHostMalloc((void**)&S->pin[i], Stager::S, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&S->ev[i], hipEventDisableTiming) == hipSuccess;
+  ctx->stager = S;
+  if (!ok) {
+    (void)hipGetLastError();
+    tbk_stager_free(ctx);
+    return nullptr;
+  }
+  return S;
+}
+
+// queues the copies of `chunks` on the upload stream and makes ctx->stream wait for them; returns when the last chunk has left the
+// caller's memory for a pinned slot (the DMA may still be running).  Without a stager (no pinned memory to be had): plain copies.
+static int staged_upload(tbk_ctx* ctx, const std::vector<StageChunk>& chunks) {
+  if (chunks.empty()) return 0;
+  Stager* S = stager_get(ctx);
+  if (!S) {
+    for (const StageChunk& c : chunks) TBK_HIP(hipMemcpyAsync(c.dst, c.src, c.len, hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+  }
+  std::atomic<size_t> next{0};
+  std::atomic<int> bad{0};
+  const int device = ctx->device;
+  auto work = [&](int t) {
+    (void)hipSetDevice(device);
+    int turn = 0;
+    for (;;) {
+      const size_t i = next.fetch_add(1);
+      if (i >= chunks.size() || bad.load()) break;
+      const int s = t * Stager::PER + (turn++ % Stager::PER);
+      if (S->used[s] && hipEventSynchronize(S->ev[s]) != hipSuccess) bad.store(1);
+      memcpy(S->pin[s], chunks[i].src, chunks[i].len);
+      if (hipMemcpyAsync(chunks[i].dst, S->pin[s], chunks[i].len, hipMemcpyHostToDevice, S->up) != hipSuccess || hipEventRecord(S->ev[s], S->up) != hipSuccess) bad.store(1);
+      S->used[s] = true;
+    }
+  };
+  const int nt = (int)std::min<size_t>(Stager::T, chunks.size());
+  std::vector<std::thread> th;
+  for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+  work(0);
+  for (auto& x : th) x.join();
+  if (bad.load()) {
+    ctx->last_error = "staged upload failed";
+    (void)hipGetLastError();
+    return TBK_EHIP;
+  }
+  TBK_HIP(hipEventRecord(S->done, S->up));
+  TBK_HIP(hipStreamWaitEvent(ctx->stream, S->done, 0));
+  return 0;
+}
+
 bool tbk_bam_dev_records(tbk_ctx* ctx, const uint8_t** inf, const uint64_t** rec, uint32_t* n) {
   BamDev* B = (BamDev*)ctx->bam_dev;
   if (!B || !B->inf || !B->rec) return false;
@@ -1296,46 +1388,79 @@ extern "C" int tbk_bam_decode(tbk_ctx* ctx, uint32_t n_files, const uint8_t* con
   bamdev_free(ctx);
   tbk_prof_begin_call(ctx);
   const uint32_t k = n_files;
-  // ---- member table of every file; inflated streams laid out file after file, 256-byte aligned ----
+  // ---- member table of every file (the files are walked side by side: a mapping of the page cache faults its pages in as the walk
+  // touches them); inflated streams laid out file after file, 256-byte aligned ----
   std::vector<BgzMember> mt;
   std::vector<uint64_t> cbase(k + 1, 0), fbase(k, 0), fbytes(k, 0);
   uint64_t ctot = 0, itot = 0;
-  for (uint32_t f = 0; f < k; ++f) {
-    cbase[f] = ctot;
-    const uint8_t* c = comp[f];
-    const uint64_t cb = comp_bytes[f];
-    if (!c) return TBK_EINVAL;
-    itot = (itot + 255) & ~(uint64_t)255;
-    fbase[f] = itot;
-    uint64_t off = 0;
-    while (off < cb) {
-      if (off + 18 > cb || c[off] != 0x1f || c[off + 1] != 0x8b || c[off + 2] != 8 || !(c[off + 3] & 4)) return TBK_EINVAL;
-      const uint32_t xlen = c[off + 10] | (c[off + 11] << 8);
-      uint64_t p = off + 12, end = p + xlen;
-      if (end > cb) return TBK_EINVAL;
-      int bsize = -1;
-      while (p + 4 <= end) {
-        const uint32_t slen = c[p + 2] | (c[p + 3] << 8);
-        if (p + 4 + slen > end) break;  // (a subfield that runs past XLEN is never read)
-        if (c[p] == 'B' && c[p + 1] == 'C' && slen == 2) bsize = c[p + 4] | (c[p + 5] << 8);
-        p += 4 + slen;
+  {
+    std::vector<std::vector<BgzMember>> fm(k);
+    std::vector<uint64_t> fi(k, 0);
+    std::atomic<uint32_t> nf{0};
+    std::atomic<int> bad{0};
+    auto walk = [&]() {
+      for (;;) {
+        const uint32_t f = nf.fetch_add(1);
+        if (f >= k || bad.load()) break;
+        const uint8_t* c = comp[f];
+        const uint64_t cb = comp_bytes[f];
+        if (!c) {
+          bad.store(1);
+          break;
+        }
+        uint64_t off = 0, isz = 0;
+        while (off < cb) {
+          if (off + 18 > cb || c[off] != 0x1f || c[off + 1] != 0x8b || c[off + 2] != 8 || !(c[off + 3] & 4)) break;
+          const uint32_t xlen = c[off + 10] | (c[off + 11] << 8);
+          uint64_t p = off + 12, end = p + xlen;
+          if (end > cb) break;
+          int bsize = -1;
+          while (p + 4 <= end) {
+            const uint32_t slen = c[p + 2] | (c[p + 3] << 8);
+            if (p + 4 + slen > end) break;  // (a subfield that runs past XLEN is never read)
+            if (c[p] == 'B' && c[p + 1] == 'C' && slen == 2) bsize = c[p + 4] | (c[p + 5] << 8);
+            p += 4 + slen;
+          }
+          if (bsize < 0 || (uint64_t)bsize + 1 < 12ull + xlen + 8 || off + (uint64_t)bsize + 1 > cb) break;
+          const uint8_t* t = c + off + bsize + 1 - 8;
+          BgzMember m;
+          m.src = off + 12 + xlen;  // (inside the file: the bases are added below)
+          m.clen = (uint32_t)((uint64_t)bsize + 1 - 8 - (12 + xlen));
+          m.crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+          m.isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+          if (m.isize > 65536) break;
+          m.dst = isz;
+          m.file = f;
+          isz += m.isize;
+          if (m.isize) fm[f].push_back(m);
+          off += (uint64_t)bsize + 1;
+        }
+        if (off != cb) bad.store(1);  // (anything htslib would reject)
+        fi[f] = isz;
       }
-      if (bsize < 0 || (uint64_t)bsize + 1 < 12ull + xlen + 8 || off + (uint64_t)bsize + 1 > cb) return TBK_EINVAL;
-      const uint8_t* t = c + off + bsize + 1 - 8;
-      BgzMember m;
-      m.src = ctot + off + 12 + xlen;
-      m.clen = (uint32_t)((uint64_t)bsize + 1 - 8 - (12 + xlen));
-      m.crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
-      m.isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
-      if (m.isize > 65536) return TBK_EINVAL;
-      m.dst = itot;
-      m.file = f;
-      itot += m.isize;
-      if (m.isize) mt.push_back(m);
-      off += (uint64_t)bsize + 1;
+    };
+    const int nw = (int)std::min<uint32_t>(k, 8);
+    std::vector<std::thread> th;
+    for (int t = 1; t < nw; ++t) th.emplace_back(walk);
+    walk();
+    for (auto& x : th) x.join();
+    if (bad.load()) return TBK_EINVAL;
+    size_t nm = 0;
+    for (uint32_t f = 0; f < k; ++f) nm += fm[f].size();
+    mt.reserve(nm);
+    for (uint32_t f = 0; f < k; ++f) {
+      cbase[f] = ctot;
+      itot = (itot + 255) & ~(uint64_t)255;
+      fbase[f] = itot;
+      for (BgzMember m : fm[f]) {
+        m.src += ctot;
+        m.dst += itot;
+        mt.push_back(m);
+      }
+      itot += fi[f];
+      fbytes[f] = fi[f];
+      ctot += comp_bytes[f];
     }
-    fbytes[f] = itot - fbase[f];
-    ctot += cb;
   }
   cbase[k] = ctot;
   if (mt.empty()) {
@@ -1358,7 +1483,6 @@ extern "C" int tbk_bam_decode(tbk_ctx* ctx, uint32_t n_files, const uint8_t* con
   uint64_t* d_rec0 = ws_alloc<uint64_t>(ctx, cap_off[k]);
   uint8_t* d_tbm = ws_alloc<uint8_t>(ctx, k);
   if (!B->inf || !d_comp || !d_mt || !d_tab || !d_rec0 || !d_tbm) return TBK_ENOMEM;
-  for (uint32_t f = 0; f < k; ++f) TBK_HIP(hipMemcpyAsync(d_comp + cbase[f], comp[f], comp_bytes[f], hipMemcpyHostToDevice, ctx->stream));
   TBK_HIP(hipMemcpyAsync(d_mt, mt.data(), mt.size() * sizeof(BgzMember), hipMemcpyHostToDevice, ctx->stream));
   TBK_HIP(hipMemcpyAsync(d_tab, fbase.data(), k * 8, hipMemcpyHostToDevice, ctx->stream));
   TBK_HIP(hipMemcpyAsync(d_tab + k, fbytes.data(), k * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -1367,7 +1491,27 @@ extern "C" int tbk_bam_decode(tbk_ctx* ctx, uint32_t n_files, const uint8_t* con
   if (tbmerged) memcpy(tb.data(), tbmerged, k);
   TBK_HIP(hipMemcpyAsync(d_tbm, tb.data(), k, hipMemcpyHostToDevice, ctx->stream));
   TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
-  TBK_TRY(bgz_inflate_launch(ctx, (uint32_t)mt.size(), d_mt, d_comp, B->inf, 0u, (unsigned long long*)nullptr));
+  // the files go up in groups of ~ 192 MB through the pinned ring, and a group is inflated while the next one is on its way
+  {
+    size_t m0 = 0;
+    for (uint32_t f0 = 0; f0 < k;) {
+      std::vector<StageChunk> chunks;
+      uint64_t gbytes = 0;
+      uint32_t f1 = f0;
+      while (f1 < k && (f1 == f0 || gbytes + comp_bytes[f1] <= ((uint64_t)192 << 20))) {
+        for (uint64_t o = 0; o < comp_bytes[f1]; o += Stager::S)
+          chunks.push_back(StageChunk{d_comp + cbase[f1] + o, comp[f1] + o, (size_t)std::min<uint64_t>(Stager::S, comp_bytes[f1] - o)});
+        gbytes += comp_bytes[f1];
+        ++f1;
+      }
+      TBK_TRY(staged_upload(ctx, chunks));
+      size_t m1 = m0;
+      while (m1 < mt.size() && mt[m1].file < f1) ++m1;
+      if (m1 > m0) TBK_TRY(bgz_inflate_launch(ctx, (uint32_t)(m1 - m0), d_mt + m0, d_comp, B->inf, 0u, (unsigned long long*)nullptr));
+      m0 = m1;
+      f0 = f1;
+    }
+  }
   TBK_LAUNCH(ctx, "bam_header", bam_header_k, cdiv(k, 64), 64, 0, k, B->inf, d_tab, d_tab + k, d_tab + 2 * k, d_nref, ctx->d_err);
   // the record index: a lane per member where every member begins with a record (htslib's writers), the chain per file otherwise
   std::vector<uint32_t> cnt(k, 0);

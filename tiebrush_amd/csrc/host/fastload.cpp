@@ -25,7 +25,13 @@ struct Member {
   size_t cdata, clen;
   uint32_t isize, crc;
   size_t out_off;
+  // the member's own record walk, made right behind its inflate (below): records kept, their CIGAR operations, where the
+  // member's offsets wait in the file's slot array, what the walk met
+  uint32_t nrec = 0, flags = 0;
+  uint64_t ncig = 0, slot0 = 0;
+  int32_t max_tid = -1;
 };
+enum : uint32_t { MW_BAD = 1u, MW_UNPLACED = 2u, MW_PLACED = 4u, MW_PLACED_AFTER_UNPLACED = 8u };
 
 template <class F>
 void parallel(int threads, F f) {
@@ -221,16 +227,73 @@ bool fast_load(const std::vector<std::string>& paths, const std::vector<uint8_t>
   t.ms_read = ms_since(t0);
   t0 = std::chrono::steady_clock::now();
   // ---- 2. inflate: every member of every input is a task of its own (any number of inputs keeps every worker busy) ----
-  std::vector<const Member*> all;
+  // The record index rides with the inflate.  htslib's writers start a new BGZF member whenever the next record does not fit
+  // (bgzf_flush_try in bam_write1) and end the header with a flush, so in nearly every file member 0 is the header and every other
+  // member is a whole number of records: the task that has just inflated a member walks its records while they are in cache — a walk over
+  // a whole file later is a chain of cache misses, one per record — and leaves their offsets in the member's own stretch of a slot
+  // array.  A file where a walk does not end exactly at its member's end (or whose header is not member 0) takes the file-wide walk below,
+  // which also decides what is an error.
+  std::vector<Member*> all;
   all.reserve(nmem);
+  std::vector<uint64_t*> slots(k, nullptr);
   for (size_t f = 0; f < k; ++f) {
     t.in[f].data = (uint8_t*)big_alloc(t.in[f].data_n);
     if (!t.in[f].data) {
       err = "out of memory";
       return false;
     }
-    for (const Member& m : mem[f]) all.push_back(&m);
+    size_t mi = 0;
+    for (Member& m : mem[f]) {
+      m.slot0 = m.out_off / 36 + mi++;  // (a record takes 36 bytes at least: the stretches cannot meet)
+      all.push_back(&m);
+    }
+    slots[f] = (uint64_t*)big_alloc((t.in[f].data_n / 36 + mem[f].size() + 1) * sizeof(uint64_t));
+    if (!slots[f]) {
+      err = "out of memory";
+      return false;
+    }
   }
+  auto walk_member = [&](Member& m) {
+    if (m.out_off == 0) return;  // (member 0: the header, looked at below)
+    const FastTile::In& I = t.in[m.f];
+    const uint8_t* d = I.data + m.out_off;
+    const size_t n = m.isize;
+    uint64_t* out = slots[m.f] + m.slot0;
+    size_t off = 0;
+    uint32_t nrec = 0, flags = 0;
+    uint64_t ncig = 0;
+    int32_t mx = -1;
+    while (off + 4 <= n) {
+      const uint32_t bs = rd32(d + off);
+      if (bs < 32 || off + 4 + (size_t)bs > n) {
+        flags |= MW_BAD;
+        break;
+      }
+      const uint8_t* r = d + off + 4;
+      const int32_t tid = (int32_t)rd32(r);
+      const uint32_t l_read_name = r[8];
+      const uint32_t n_cigar = (uint32_t)r[12] | ((uint32_t)r[13] << 8);
+      const int32_t l_seq = (int32_t)rd32(r + 16);
+      const int32_t mtid = (int32_t)rd32(r + 20);
+      const uint64_t need = 32ull + l_read_name + 4ull * n_cigar + (l_seq < 0 ? 0ull : ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq);
+      const bool name_ok = l_read_name >= 1 && 32 + l_read_name <= bs && r[32 + l_read_name - 1] == 0;
+      if (l_seq < 0 || need > bs || !name_ok || tid < -1 || mtid < -1) {
+        flags |= MW_BAD;  // (the file-wide walk names the record)
+        break;
+      }
+      mx = std::max(mx, std::max(tid, mtid));
+      if (tid < 0) {
+        flags |= MW_UNPLACED;
+      } else {
+        flags |= MW_PLACED | ((flags & MW_UNPLACED) ? MW_PLACED_AFTER_UNPLACED : 0u);
+        out[nrec++] = m.out_off + off;
+        ncig += n_cigar;
+      }
+      off += 4 + (size_t)bs;
+    }
+    if (off != n) flags |= MW_BAD;
+    m.nrec = nrec, m.ncig = ncig, m.flags = flags, m.max_tid = mx;
+  };
   {
     std::atomic<size_t> next{0};
     parallel(threads, [&]() {
@@ -238,22 +301,21 @@ bool fast_load(const std::vector<std::string>& paths, const std::vector<uint8_t>
         const size_t i = next.fetch_add(16);
         if (i >= all.size() || !ok) break;
         for (size_t j = i; j < i + 16 && j < all.size(); ++j) {
-          const Member& m = *all[j];
+          Member& m = *all[j];
           if (!m.isize) continue;
           FastTile::In& I = t.in[m.f];
           if (!bgzf_inflate_member(I.comp.data() + m.cdata, m.clen, I.data + m.out_off, m.isize, m.crc)) fail("inflate failed or CRC32 mismatch in " + I.path);
+          else walk_member(m);
         }
       }
     });
     if (!ok) return false;
   }
-  for (size_t f = 0; f < k; ++f) {
-    std::vector<uint8_t>().swap(t.in[f].comp);
-    std::vector<Member>().swap(mem[f]);
-  }
+  for (size_t f = 0; f < k; ++f) std::vector<uint8_t>().swap(t.in[f].comp);
   t.ms_inflate = ms_since(t0);
   t0 = std::chrono::steady_clock::now();
   // ---- 3. index: the records of every input (field lengths checked as bam_read1 checks them), unplaced reads dropped ----
+  std::atomic<size_t> n_fused{0};
   {
     std::atomic<size_t> nf{0};
     parallel(std::min<int>(threads, (int)k), [&]() {
@@ -287,6 +349,40 @@ bool fast_load(const std::vector<std::string>& paths, const std::vector<uint8_t>
         if (!hdr_ok) {
           fail("truncated reference list (" + I.path + ")");
           break;
+        }
+        // the members' own walks (phase 2) are the file's index when member 0 is exactly the header and every other walk ended at its
+        // member's end with well-formed records, the reference ids inside the header's table and no placed read behind an unplaced one
+        {
+          std::vector<Member>& M = mem[f];
+          bool fused = !M.empty() && M[0].out_off == 0 && (size_t)M[0].isize == p;
+          bool seen_unplaced = false;
+          uint64_t nrec = 0, ncig = 0;
+          for (size_t i = 1; fused && i < M.size(); ++i) {
+            const Member& m = M[i];
+            if ((m.flags & (MW_BAD | MW_PLACED_AFTER_UNPLACED)) || m.max_tid >= n_targets || (seen_unplaced && (m.flags & MW_PLACED))) fused = false;
+            seen_unplaced = seen_unplaced || (m.flags & MW_UNPLACED);
+            nrec += m.nrec, ncig += m.ncig;
+          }
+          if (fused) {
+            I.rec_off = (uint64_t*)big_alloc((nrec + 1) * sizeof(uint64_t));
+            if (!I.rec_off) {
+              fail("out of memory");
+              break;
+            }
+            uint64_t at = 0;
+            for (size_t i = 1; i < M.size(); ++i) {
+              memcpy(I.rec_off + at, slots[f] + M[i].slot0, (size_t)M[i].nrec * sizeof(uint64_t));
+              at += M[i].nrec;
+            }
+            I.n_rec = (size_t)nrec;
+            I.n_cig = ncig;
+            n_fused.fetch_add(1);
+            big_free(slots[f]);
+            slots[f] = nullptr;
+            continue;
+          }
+          big_free(slots[f]);
+          slots[f] = nullptr;
         }
         // (a record takes at least 36 bytes: the index can be sized before the walk)
         I.rec_off = (uint64_t*)big_alloc(((n - p) / 36 + 1) * sizeof(uint64_t));
@@ -354,6 +450,7 @@ bool fast_load(const std::vector<std::string>& paths, const std::vector<uint8_t>
   t.n = t.file_off[k];
   t.n_cig = (size_t)cig_base[k];
   t.ms_index = ms_since(t0);
+  t.n_fused = n_fused.load();
   t0 = std::chrono::steady_clock::now();
   // ---- 4. the tile: tasks of consecutive records of one input, every worker busy whatever the number of inputs ----
   const size_t n = t.n;

@@ -46,6 +46,7 @@ struct FastTile {
   int64_t *yx_in = nullptr, *yd_in = nullptr;
   size_t n = 0, n_cig = 0;
   double ms_read = 0, ms_inflate = 0, ms_index = 0, ms_soa = 0;
+  size_t n_fused = 0;  // inputs whose record index came from the members' own walks
   ~FastTile();
   tbk_soa_in view() const;
   // the raw record (without its block_size field) behind tile index g

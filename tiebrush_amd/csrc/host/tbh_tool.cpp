@@ -116,6 +116,8 @@ int main(int argc, char** argv) {
       fprintf(stderr, "%s\n", err.c_str());
       return 1;
     }
+    fprintf(stderr, "fastsoa: %zu of %zu inputs indexed by their members' own walks; ms read %.1f inflate %.1f index %.1f SoA %.1f\n", t.n_fused, t.in.size(), t.ms_read,
+            t.ms_inflate, t.ms_index, t.ms_soa);
     const std::string d = argv[2];
     auto dumpp = [&](const char* name, const void* p, size_t bytes) {
       FILE* f = fopen((d + "/" + name).c_str(), "wb");

@@ -21,6 +21,8 @@
 #include <memory>
 #include <signal.h>
 #include <spawn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <chrono>
@@ -90,6 +92,39 @@ struct RawBuf {
   T* data() { return p; }
   size_t size() const { return len; }
   T& operator[](size_t i) { return p[i]; }
+};
+
+// an input file as the page cache holds it: the device decode uploads it through its own pinned ring (tbk_bam_decode), so a private copy
+// made with read() would only be one more pass over gigabytes
+struct FileMap {
+  const uint8_t* p = nullptr;
+  size_t n = 0;
+  bool map(const std::string& path) {
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0) {
+      close(fd);
+      return false;
+    }
+    n = (size_t)st.st_size;
+    if (n) {
+      void* q = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+      if (q == MAP_FAILED) {
+        close(fd);
+        n = 0;
+        return false;
+      }
+      (void)madvise(q, n, MADV_SEQUENTIAL);
+      p = (const uint8_t*)q;
+    }
+    close(fd);
+    return true;
+  }
+  void unmap() {
+    if (p) munmap(const_cast<uint8_t*>(p), n);
+    p = nullptr, n = 0;
+  }
 };
 
 // `tiebrush --ranks N ...`: the multi-GPU form (tiebrush_amd/ranks.py: one process per GPU over torch.distributed / RCCL, the input
@@ -216,6 +251,7 @@ int main(int argc, char* argv[]) {
   int rc = 0;
   bool api_ok = false;
   DeviceWriter* dw = nullptr;  // (pinned staging: lives until the process ends)
+  double ms_ctx_ready = 0;
   std::thread ctx_thread([&]() {
     api_ok = api.load();
     if (api_ok) rc = api.create(dev, &ctx);
@@ -223,6 +259,7 @@ int main(int argc, char* argv[]) {
       dw = new DeviceWriter(api, tbh::cpu_budget());
       (void)dw->reserve();  // (page-locking the staging buffers: tens of milliseconds, beside the decode)
     }
+    ms_ctx_ready = tms(t_start, tnow());
     if (api_ok && rc == 0 && !getenv("TBK_NO_WARMUP")) {
       // one tiny collapse: the first launch maps the code objects of the library onto the device and the first call sizes the
       // context's buffers — tens of milliseconds that belong beside the inflate, not behind it
@@ -402,7 +439,20 @@ int main(int argc, char* argv[]) {
       }
       if (eligible && !(hy && atoi(hy) != 0) && total < ((uint64_t)768 << 20)) eligible = false;
       if (eligible) {
-        const double share = (getenv("TBK_HYBRID_SHARE") ? atof(getenv("TBK_HYBRID_SHARE")) : 40.0) / 100.0;
+        // The device's share of the compressed bytes: both sides should end together.  The device starts late — the HIP runtime takes
+        // ~ 0.25 s to come up, the cores work alone meanwhile — and is then several times faster: with x of T bytes on the device,
+        // t_ctx + x / R_dev = (T - x) / R_host.  Rates measured on an MI355X box with a 16-core quota (tools/scratch/e2e_long_r5.sh): the
+        // device side 4.3 GB/s of compressed BAM (upload, inflate, record index, SoA), a core 0.119 GB/s (inflate + index + SoA).
+        // 1.8 GB of input: 58 %; 7.1 GB: 70 %.  TBK_HYBRID_SHARE (per cent) overrides.
+        const int host_threads = getenv("TBK_THREADS") ? nthreads : std::max(2, nthreads - 3);
+        double share;
+        if (getenv("TBK_HYBRID_SHARE")) {
+          share = atof(getenv("TBK_HYBRID_SHARE")) / 100.0;
+        } else {
+          const double T = (double)total / 1e9, r_dev = 4.3, r_host = 0.119 * host_threads, t_ctx = 0.25;
+          const double x = (T / r_host - t_ctx) / (1.0 / r_dev + 1.0 / r_host);
+          share = std::min(0.9, std::max(0.2, x / T));
+        }
         size_t kd = 0;
         uint64_t acc = 0;
         while (kd + 1 < k && (double)(acc + fsz[kd]) <= share * (double)total + (double)fsz[kd] / 2) acc += fsz[kd++];
@@ -416,34 +466,22 @@ int main(int argc, char* argv[]) {
         std::vector<uint8_t> tb_d(kd, 0);
         int rc_d = -1;
         bool read_ok = true;
-        double ms_dread = 0, ms_ddec = 0;
+        double ms_dread = 0, ms_ddec = 0, ms_dcall = 0;
         std::thread dth([&]() {
           auto d0 = tnow();
-          std::vector<std::vector<uint8_t>> comp(kd);
-          std::atomic<size_t> nf{0};
-          std::atomic<bool> ok{true};
-          auto w = [&]() {
-            for (;;) {
-              size_t f = nf.fetch_add(1);
-              if (f >= kd) break;
-              comp[f].resize(fsz[f]);
-              FILE* fp = fopen(paths[f].c_str(), "rb");
-              if (!fp || fread(comp[f].data(), 1, fsz[f], fp) != fsz[f]) ok = false;
-              if (fp) fclose(fp);
-            }
-          };
-          std::vector<std::thread> th;
-          for (int t = 0; t < std::min<int>(4, (int)kd); ++t) th.emplace_back(w);
-          for (auto& x : th) x.join();
-          read_ok = ok.load();
+          std::vector<FileMap> comp(kd);
+          for (size_t f = 0; f < kd; ++f)
+            if (!comp[f].map(paths[f]) || comp[f].n != fsz[f]) read_ok = false;
           auto d1 = tnow();
           ms_dread = tms(d0, d1);
           if (!read_ok) return;
           need_ctx();
+          auto d2 = tnow();
           std::vector<const uint8_t*> ptr(kd);
-          for (size_t f = 0; f < kd; ++f) ptr[f] = comp[f].data();
+          for (size_t f = 0; f < kd; ++f) ptr[f] = comp[f].p;
           rc_d = api.bam_decode(ctx, (uint32_t)kd, ptr.data(), fsz.data(), tb_d.data(), 0, 0, &in_d, fo_d.data());
-          std::thread([c = std::move(comp)]() mutable { c.clear(); }).detach();  // (the compressed files: unmapped off this thread's way)
+          ms_dcall = tms(d2, tnow());
+          for (auto& c : comp) c.unmap();
           if (rc_d == 0 && acc > 0) {  // the arena for the joined tile, sized while the cores are still decoding their share
             const double up = (double)total / (double)acc * 1.05;
             (void)api.reserve_tile(ctx, (uint64_t)((double)in_d.n_records * up), (uint64_t)((double)in_d.n_cigar_ops * up));
@@ -455,7 +493,9 @@ int main(int argc, char* argv[]) {
         std::vector<uint8_t> tbh_(k - kd, 0);
         bool fits = false;
         std::string err;
-        const bool okh = tbh::fast_load(ph, tbh_, nthreads, budget, ft, &fits, err);
+        // (the device's side needs cores too while it runs — the HIP start-up, then the threads that feed the upload ring —, and a
+        // container's CPU quota stalls EVERY thread of the process once the sum goes over it: the loader leaves them room)
+        const bool okh = tbh::fast_load(ph, tbh_, host_threads, budget, ft, &fits, err);
         auto t_host = tnow();
         dth.join();
         auto t1 = tnow();
@@ -527,9 +567,9 @@ int main(int argc, char* argv[]) {
             auto t3 = tnow();
             if (timing)
               fprintf(stderr,
-                      "hybrid path ms: device %zu of %zu files (read %.1f | decode incl. context %.1f) beside host (read %.1f | inflate %.1f | index %.1f | SoA %.1f) = %.1f | "
+                      "hybrid path ms: device %zu of %zu files (context ready at %.1f | map %.1f | decode incl. context %.1f, the call %.1f) beside host (read %.1f | inflate %.1f | index %.1f | SoA %.1f) = %.1f | "
                       "join %.1f | collapse %.1f | gather + tag + deflate (GPU) + write %.1f (%.1f MB of records -> %.1f MB)\n",
-                      kd, k, ms_dread, ms_ddec, ft.ms_read, ft.ms_inflate, ft.ms_index, ft.ms_soa, tms(t0, t1), tms(t1, t_join), tms(t_join, t_col), tms(t_col, t3),
+                      kd, k, ms_ctx_ready, ms_dread, ms_ddec, ms_dcall, ft.ms_read, ft.ms_inflate, ft.ms_index, ft.ms_soa, tms(t0, t1), tms(t1, t_join), tms(t_join, t_col), tms(t_col, t3),
                       dev_payload / 1e6, dev_z / 1e6);
             ms_inflate += tms(t0, t1);
             ms_gpu += tms(t1, t_col);
@@ -666,29 +706,13 @@ int main(int argc, char* argv[]) {
       for (size_t f = 0; f < k; ++f) all_bam = all_bam && tbh::bgzf_probe(inRecords.freaders[f]->fname);
       if (want && all_bam && total > 0 && total <= lim) {
         auto t0 = tnow();
-        std::vector<std::vector<uint8_t>> comp(k);
-        {
-          std::atomic<size_t> nf{0};
-          std::atomic<bool> ok{true};
-          auto w = [&]() {
-            for (;;) {
-              size_t f = nf.fetch_add(1);
-              if (f >= k) break;
-              comp[f].resize(fsz[f]);
-              FILE* fp = fopen(inRecords.freaders[f]->fname.c_str(), "rb");
-              if (!fp || fread(comp[f].data(), 1, fsz[f], fp) != fsz[f]) ok = false;
-              if (fp) fclose(fp);
-            }
-          };
-          std::vector<std::thread> th;
-          for (int t = 0; t < std::min<int>(nthreads, (int)k); ++t) th.emplace_back(w);
-          for (auto& x : th) x.join();
-          if (!ok) GError("Error: reading the input failed\n");
-        }
+        std::vector<FileMap> comp(k);
+        for (size_t f = 0; f < k; ++f)
+          if (!comp[f].map(inRecords.freaders[f]->fname) || comp[f].n != fsz[f]) GError("Error: reading the input failed\n");
         std::vector<const uint8_t*> ptr(k);
         std::vector<uint8_t> tb(k);
         for (size_t f = 0; f < k; ++f) {
-          ptr[f] = comp[f].data();
+          ptr[f] = comp[f].p;
           tb[f] = inRecords.freaders[f]->tbMerged ? 1 : 0;
         }
         std::vector<uint32_t> fo(k + 1, 0);
@@ -698,8 +722,8 @@ int main(int argc, char* argv[]) {
         tbk_soa_in in;
         rc = api.bam_decode(ctx, (uint32_t)k, ptr.data(), fsz.data(), tb.data(), opt.strategy == TBK_STRAT_FULL, opt.collapse_same != 0, &in, fo.data());
         auto t1 = tnow();
+        for (auto& c : comp) c.unmap();
         if (rc == 0) {
-          std::thread([c = std::move(comp)]() mutable { c.clear(); }).detach();  // (gigabytes to unmap: not on this thread's way)
           const size_t n = in.n_records;
           rep.resize(n ? n : 1);
           yc.resize(n ? n : 1);

@@ -417,6 +417,7 @@ void tbk_destroy(tbk_ctx* ctx) {
   if (ctx->d_view) (void)hipFree(ctx->d_view);
   if (ctx->d_unpack) (void)hipFree(ctx->d_unpack);
   tbk_enc_free(ctx);
+  tbk_stager_free(ctx);
   if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
   if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
   if (ctx->aux_done) (void)hipEventDestroy(ctx->aux_done);

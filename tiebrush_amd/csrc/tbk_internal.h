@@ -142,7 +142,9 @@ struct tbk_ctx {
   std::vector<uint8_t> unpack_tbm;
   void* bam_dev = nullptr;       // device-decoded BAM input (bamdev.hip): inflated streams + record index + the SoA tile's arrays
   void* enc = nullptr;           // the encoder's device buffers (bgzdef.hip)
+  void* stager = nullptr;        // pinned ring + upload stream of the staged host -> device copies (bamdev.hip)
 };
+void tbk_stager_free(tbk_ctx* ctx);
 void tbk_enc_free(tbk_ctx* ctx);
 // the tile tbk_bam_decode left on the context: inflated streams, record offsets, record count (false: there is none)
 bool tbk_bam_dev_records(tbk_ctx* ctx, const uint8_t** inf, const uint64_t** rec, uint32_t* n);

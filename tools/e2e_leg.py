@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def leg(files, reads, profile, flags, seq, runs, device_decode, desc):
+def leg(files, reads, profile, flags, seq, runs, device_decode, desc, host_writer=False):
     """lay the inputs down, run the command line `runs` times, return the JSON object of the leg"""
     import torch
 
@@ -38,11 +38,11 @@ def leg(files, reads, profile, flags, seq, runs, device_decode, desc):
         binp = os.path.join(ROOT, "tiebrush_amd", "_build")
         out = os.path.join(d, "out.bam")
 
-        def run(extra_env, k):
+        def run(extra_env, k, extra_flags=()):
             ts, rr = [], None
             for _ in range(k):
                 t1 = time.time()
-                rr = subprocess.run([os.path.join(binp, "tiebrush"), "-o", out] + flags + paths, capture_output=True, text=True, check=True,
+                rr = subprocess.run([os.path.join(binp, "tiebrush"), "-o", out] + list(extra_flags) + flags + paths, capture_output=True, text=True, check=True,
                                     env=dict(os.environ, TBK_TIMING="1", **extra_env))
                 ts.append(time.time() - t1)
             return sorted(ts), rr
@@ -57,11 +57,16 @@ def leg(files, reads, profile, flags, seq, runs, device_decode, desc):
                "input_bam_bytes": in_bytes, "input_bytes_per_record": round(in_bytes / n, 1),
                "output_bam_bytes": os.path.getsize(out), "summary": summary,
                "phases": [l for l in r.stderr.split("\n") if l.startswith("host path") or l.startswith("hybrid path") or l.startswith("writer closed") or l.startswith("released")
-                          or l.startswith("timing ms") or l.startswith("tiles:")][-5:],
+                          or l.startswith("timing ms") or l.startswith("tiles:") or l.startswith("device writer")][-6:],
                "generation_s": round(t_gen, 1)}
         if device_decode:
             th, _ = run({"TBK_DEVICE_DECODE": "1"}, 1)
             res["device_decode_wall_s"] = round(th[0], 3)
+        if host_writer:     # the same run with the output tagged and deflated by the cores (--writer host): what the device writer replaces
+            th, rh = run({}, 1, ["--writer", "host"])
+            res["host_writer_wall_s"] = round(th[0], 3)
+            res["host_writer_output_bam_bytes"] = os.path.getsize(out)
+            res["host_writer_phases"] = [l for l in rh.stderr.split("\n") if l.startswith("hybrid path") or l.startswith("host path")][-1:]
         return res
     finally:
         shutil.rmtree(d, ignore_errors=True)
@@ -83,7 +88,10 @@ def main():
         # reference's fixtures: what BGZF and the tagging really move), and with config 3's options on config 3's read model
         k2 = max(1, a.runs - 1)
         res["seq"] = leg(a.files, a.reads, a.profile, [], True, k2, True,
-                         "%d files x %d reads (config-2 read model) WITH 100-bp SEQ / QUAL and aligner tags, default collapse")
+                         "%d files x %d reads (config-2 read model) WITH 100-bp SEQ / QUAL and aligner tags, default collapse", host_writer=True)
+        # ... and four times as much of it: long enough for the ~ 0.3 s the HIP runtime takes to come up to stop being a third of the run
+        res["seq_long"] = leg(2 * a.files, 2 * a.reads, a.profile, [], True, k2, False,
+                              "%d files x %d reads (config-2 read model) WITH 100-bp SEQ / QUAL and aligner tags, default collapse")
         res["c3_options"] = leg(2 * a.files, max(1, a.reads // 2), "c3", ["--clip"], False, k2, False,
                                 "%d files x %d reads (config-3 read model: 10 %% soft-clipped, records without SEQ), --clip")
     print(json.dumps(res), flush=True)

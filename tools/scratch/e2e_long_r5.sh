@@ -16,7 +16,7 @@ paths = synth.write_bams_fast(tile, "$D/in", seq=True)
 print("generated", len(paths), "files in %.1f s" % (time.time() - t0), sum(os.path.getsize(p) for p in paths))
 PY
 for share in "$@"; do
-  for i in 1 2; do
+  for i in 1 2 3; do
     S=$(date +%s.%N)
     TBK_HYBRID_SHARE=$share TBK_TIMING=1 tiebrush_amd/_build/tiebrush -o $D/out.bam $D/in*.bam 2> $D/err.txt
     E=$(date +%s.%N)
