@@ -218,6 +218,11 @@ def main():
     ap.add_argument("--cpu-procs", type=int, default=0, help="worker processes of the tiewrap-style CPU line (0: the CPU quota, at most 16)")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank (group-partials) path even with one rank")
     ap.add_argument("--dist-mode", default="partials", choices=["partials", "shuffle"])
+    ap.add_argument("--cut-search", default="lists", choices=["lists", "rounds"],
+                    help="partials protocol: cuts chosen on the device from gathered bundle lists (one read-back per step), or walked in all-reduce rounds")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="with --force-dist on one GPU: R virtual ranks in this process (loopback collectives), every one with the per-rank workload: "
+                         "what the R-way cut search, pack and reduce do, without R GPUs; reported in `emulated_world`, not in `value`")
     args = ap.parse_args()
     args.prof_steps = max(1, args.prof_steps)
 
@@ -372,6 +377,16 @@ def main():
         def partial_pack(self, *a, **kw):
             return self.cl.partial_pack(*a, out=self.bufs.setdefault("pp", {}), **kw)
 
+        # the sender's side that only queues work (tbk_partial_stage_*): no read-back before the gathered exchange table
+        def partial_stage_keys(self, tile, fin, first_fidx, carry=0):
+            return self.cl.partial_stage_keys(tile, fin, first_fidx, carry, out=self.bufs.setdefault("pk", {}))
+
+        def partial_stage_cands(self, *a):
+            return self.cl.partial_stage_cands(*a)
+
+        def partial_stage_pack(self, *a, **kw):
+            return self.cl.partial_stage_pack(*a, out=self.bufs.setdefault("pp", {}), **kw)
+
         def partial_reduce(self, rows, run_off, cig, **kw):
             self.done()                                   # the rows have left the local buffers: the worker may reuse the slot
             return self.co.partial_reduce(rows, run_off, cig, out=self.bufs.setdefault("pr", {}), **kw)
@@ -406,6 +421,8 @@ def main():
         if not dctx:
             dctx["local"] = [api.Context(local_rank) for _ in range(2)]
             dctx["owner"] = api.Context(local_rank)
+            dctx["owner"].use_torch_stream()      # the owner's kernels are ordered with the collectives by the stream, not by host waits
+            dctx["prev_nj"] = 0
             dctx["lbufs"] = [{}, {}]
             dctx["obufs"] = {}
             dctx["opts"] = dctx["local"][0].make_opts(defer_yd=True, **strat)
@@ -449,13 +466,22 @@ def main():
                 comp = OwnerCompute(cl[s], co, dctx["obufs"], done)
                 st = {}
                 kw = dict(strat)
-                res = tdist.run_distributed(comp, dtile, rank * files, device=dev, want_coverage=True, device_chain=True, mode=args.dist_mode,
-                                            **(dict(local=fin, stats=st) if args.dist_mode == "partials" else {}), **kw)
+                # (the junction counts of step i travel with step i + 1's first gather — the `carry` word —: the numbering offsets of a
+                # step's junctions are known one step later, and one gather behind the last step settles the last)
+                extra = dict(local=fin, stats=st, cut_search=args.cut_search, carry=dctx["prev_nj"], junction_gather=False) if args.dist_mode == "partials" else {}
+                res = tdist.run_distributed(comp, dtile, rank * files, device=dev, want_coverage=True, device_chain=True, mode=args.dist_mode, **extra, **kw)
                 done()
-                for kk in ("wire_bytes", "wire_bytes_off_rank", "wire_rows"):
-                    wire[kk] += st.get(kk, 0)
+                if res.coverage is not None:
+                    dctx["prev_nj"] = int(res.coverage["n_junctions"])
+                for kk in ("wire_bytes", "wire_bytes_off_rank", "wire_rows", "collectives", "host_syncs"):
+                    wire[kk] = wire.get(kk, 0) + st.get(kk, 0)
                 wire["cut_rounds_max"] = max(wire.get("cut_rounds_max", 0), st.get("cut_rounds", 0))
                 wire["steps"] += 1
+            if args.dist_mode == "partials" and res is not None and res.coverage is not None and dist.is_initialized():
+                njt = torch.tensor([int(res.coverage["n_junctions"])], dtype=torch.int64, device=dev if os.environ.get("TBK_BENCH_BACKEND", "nccl") == "nccl" else "cpu")
+                alln = [torch.zeros_like(njt) for _ in range(world)]
+                dist.all_gather(alln, njt)                 # the last step's junction counts: its numbering offsets
+                res.junction_offset = int(sum(int(x) for x in alln[:rank]))
         finally:
             th.join()
         return res
@@ -530,6 +556,12 @@ def main():
             "wire_bytes_off_rank_per_step": int(wire["wire_bytes_off_rank"] / nst),
             "partials_per_step": int(wire["wire_rows"] / nst),
             "cut_rounds_max": int(wire.get("cut_rounds_max", 0)),
+            "cut_search": args.cut_search,
+            "collectives_per_step": round(wire.get("collectives", 0) / nst, 2),
+            "host_syncs_per_step": round(wire.get("host_syncs", 0) / nst, 2),
+            "protocol_counts_note": "collectives: all-gathers of meta / bundle lists / exchange table + the two all-to-alls (rows, CIGAR words); the junction "
+                                    "counts ride in the next step's first gather.  host syncs: read-backs of the protocol itself (the gathered table; the "
+                                    "owner's group count) — tiecov's own read-back is the plain path's too",
             "dist_mode": args.dist_mode,
             "dist_phase_host_ms_per_step": ph,
             "dist_note": "rank 0's figures.  plain_ms_per_step: the plain single-GPU step (collapse + chain + tiecov, %d contexts) on this "
@@ -537,6 +569,38 @@ def main():
                          "local collapse and the owner's reduce (cut search, pack, exchange, unpack) — it overlaps the worker thread's next "
                          "local collapse; wire bytes: rows x 40 B + CIGAR words, all destinations (off_rank: without the self block)" % NCTX,
         }
+
+    # ---- R virtual ranks on this one GPU (--force-dist --emulate-world R): every virtual rank holds the per-rank workload (its own files of
+    # the synthetic job), the collectives are served in process.  Not a timing of R GPUs — the ranks run one after the other — but the
+    # R-way protocol itself: do the lists settle every cut, how many collectives and read-backs a step takes, what the stages cost.
+    if use_dist and world == 1 and args.emulate_world > 1 and args.dist_mode == "partials":
+        R = args.emulate_world
+        ectx = api.Context(local_rank)
+        ectx.use_torch_stream()
+        etiles = [dtile] + [synth_dev.make_tile_device(files, reads, SYNTH_PROFILE[profile], device=dev, first_file=r * files, tx=tx) for r in range(1, R)]
+        eopts = ectx.make_opts(**strat)
+        efins = [ectx.collapse(t_, opts=eopts, want_coords=True, want_effend=True, out={}, cap_groups=cap_groups) for t_ in etiles]
+        torch.cuda.synchronize()
+        em = {}
+        for mode_ in ("lists", "rounds"):
+            sts = [dict() for _ in range(R)]
+            for rep_ in range(3):
+                sts = [dict() for _ in range(R)]
+                torch.cuda.synchronize()
+                te = time.perf_counter()
+                eres = tdist.run_loopback(ectx, etiles, [r * files for r in range(R)], per_rank=[dict(local=efins[r], stats=sts[r]) for r in range(R)],
+                                          want_coverage=False, device_chain=True, cut_search=mode_, **strat)
+                torch.cuda.synchronize()
+                te = time.perf_counter() - te
+            yc_tot = sum(float(r_.yc.sum()) for r_ in eres)
+            em[mode_] = {"ms_per_rank_step_serialised": round(te * 1e3 / R, 3), "cut_rounds_max": max(st_.get("cut_rounds", 0) for st_ in sts),
+                         "collectives_per_step": sts[0].get("collectives"), "host_syncs_per_step": sts[0].get("host_syncs"),
+                         "groups_out": int(sum(r_.n_groups for r_ in eres)), "groups_per_rank": [int(r_.n_groups) for r_ in eres],
+                         "count_conserved": bool(abs(yc_tot - sum(int(f_["n_passed"]) for f_ in efins)) < 0.5)}
+        dist_extra["emulated_world"] = {"world": R, "records_per_rank": int(n_records), "partials_per_rank": [int(f_["n_groups"]) for f_ in efins], **em,
+                                        "note": "R virtual ranks run one after the other on one GPU with in-process collectives (tiebrush_amd.dist.run_loopback): the "
+                                                "protocol's decisions at world R, not its speed on R GPUs"}
+        del etiles, efins, eres
 
     # ---- per-kernel durations (HIP events on the launch stream) -> roofline of the dominant kernel ----
     roof = {}

@@ -203,7 +203,9 @@ const char* tbk_strerror(int status);
 const char* tbk_last_error(const tbk_ctx* ctx); /* detail of the last TBK_EHIP etc. */
 
 /* Use an external HIP stream (e.g. torch's current stream) instead of the
- * context's own; NULL restores the internal one. */
+ * context's own; NULL restores the internal one; TBK_STREAM_DEFAULT selects the
+ * device's default stream (whose handle is the null pointer). */
+#define TBK_STREAM_DEFAULT ((void*)1)
 int tbk_set_stream(tbk_ctx* ctx, void* hip_stream);
 void* tbk_get_stream(tbk_ctx* ctx);
 int tbk_set_profiling(tbk_ctx* ctx, int enabled);
@@ -382,6 +384,30 @@ int tbk_partial_keys(tbk_ctx* ctx, const tbk_soa_in* in, const tbk_groups_out* g
 #define TBK_PARTIAL_ROW 12
 int tbk_partial_pack(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa_in* in, const tbk_groups_out* g, const int64_t* key,
                      const int64_t* cuts, uint32_t world, uint32_t first_fidx, int32_t* rows, uint32_t* cig_out, int64_t* tab);
+/* (ABI version 7) The sender's side in three stages that only QUEUE device work — nothing is read back, nothing waits —, with the
+ * caller's collectives (all-gathers of the small device arrays below) in between; what the host finally reads is one gathered table.
+ * All arrays are device memory.  The reference has no counterpart (tiewrap.py:96-126 starts processes and re-collapses files).
+ *   1. tbk_partial_stage_keys: key / emax as tbk_partial_keys, and meta[TBK_PARTIAL_META] = 64 sampled keys (1 << 62 when there are
+ *      no groups), n_files, first_fidx, "not packable" (0 / 1), `carry` (a word of the caller's that travels with the gather);
+ *   2. all-gather meta -> allmeta[world][TBK_PARTIAL_META]; tbk_partial_stage_cands: targets[world - 1] = the splitter quantiles of all
+ *      samples, cands[world - 1][TBK_PARTIAL_CAND] = per cut the LOCAL bundle structure behind the target: {farthest end before the
+ *      first local bundle start at or behind the target, horizon = start of the first bundle the list does not describe (1 << 62:
+ *      none), then TBK_PARTIAL_BUNDLES pairs (bundle start, farthest end up to its last group)};
+ *   3. all-gather cands -> allcands[world][world - 1][TBK_PARTIAL_CAND]; tbk_partial_stage_pack: cuts[world - 1] = per cut the smallest
+ *      key at or behind its target that no group of ANY rank reaches across, judged from the lists (a cut no list can settle is left
+ *      at 1 << 62 with flag bit 1); rows / cig_out as tbk_partial_pack; tabx[world * 3 + 4] = tab of tbk_partial_pack, then {flags: bit
+ *      0 not packable, bit 1 a cut unsettled, bits 8.. device error bits; n_files; first_fidx; carry}.
+ * The caller all-gathers tabx, reads it (its one synchronisation), and — all flags clear — knows every rank's send and receive counts. */
+#define TBK_PARTIAL_BUNDLES 15
+#define TBK_PARTIAL_CAND (2 + 2 * TBK_PARTIAL_BUNDLES)
+#define TBK_PARTIAL_META (64 + 4)
+int tbk_partial_stage_keys(tbk_ctx* ctx, const tbk_soa_in* in, const tbk_groups_out* g, int64_t* key, int64_t* emax, uint32_t first_fidx, int64_t carry,
+                           int64_t* meta);
+int tbk_partial_stage_cands(tbk_ctx* ctx, const int64_t* key, const int64_t* emax, uint32_t n_groups, const int64_t* allmeta, uint32_t world,
+                            int64_t* targets, int64_t* cands);
+int tbk_partial_stage_pack(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa_in* in, const tbk_groups_out* g, const int64_t* key,
+                           const int64_t* mymeta, const int64_t* allcands, const int64_t* targets, uint32_t world, uint32_t first_fidx, int64_t* cuts,
+                           int32_t* rows, uint32_t* cig_out, int64_t* tabx);
 /* Received rows (one run per source rank, each in that rank's output order) -> the SoA arrays of a tile whose "files" are the
  * source ranks, all flagged tbmerged: flag 0, mapq 255, NH absent, cig_off (n2 + 1 entries), yc_in / yx_in / yd_in = the
  * partial's YC / YX / YD, prio_hi = effective end, prio_lo = global file << 32 | index in file.  tbk_collapse_tile on that

@@ -443,3 +443,58 @@ def test_loopback_device_real_bam_shapes(world, mode):
             v = getattr(r, f)
             setattr(r, f, v.cpu().numpy() if isinstance(v, torch.Tensor) else v)
     check_against_flat(res, tile, flat, flat_cov)
+
+
+def test_lists_protocol_settles_cuts_without_rounds():
+    """the cut search on gathered bundle lists (tbk_partial_stage_*): no all-reduce round, five collectives and two read-backs a step,
+    the result equal to the flat oracle — and to what the protocol's first form (cuts walked in rounds) delivers"""
+    import torch
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import api, dist, synth
+    world = 4
+    tile = synth.make_tile(8, 30000, "c3", n_loci=900)
+    flat = orc.collapse(tile, strategy=STRAT["clip"])
+    flat_cov = orc.coverage(synth.collapsed_to_cov_input(tile, flat))
+    tiles, first = split_tile(tile, world)
+    dtiles = [api.to_device(t, "cuda:0") for t in tiles]
+    for mode in ("lists", "rounds"):
+        sts = [dict() for _ in range(world)]
+        res = dist.run_loopback(DeviceCompute(), dtiles, first, strategy="clip", want_coverage=True, device_chain=True, cut_search=mode,
+                                per_rank=[dict(stats=sts[r]) for r in range(world)])
+        for r in res:
+            for f in ("tid", "start", "end", "rep_fidx", "rep_idx", "yc", "yx", "yd"):
+                v = getattr(r, f)
+                setattr(r, f, v.cpu().numpy() if isinstance(v, torch.Tensor) else v)
+        check_against_flat(res, tile, flat, flat_cov)
+        if mode == "lists":
+            assert all(st["cut_rounds"] == 0 and st["collectives"] == 6 and st["host_syncs"] == 2 for st in sts), sts   # (5 + the junction counts' gather)
+        else:
+            assert all(st["cut_rounds"] >= 1 for st in sts)
+
+
+def test_lists_hand_a_long_chain_of_bundles_to_the_rounds():
+    """two ranks whose bundles interlock like a staircase for more steps than a list describes: no candidate inside the lists' horizon
+    is a clean cut, the cut stays unsettled (flag bit 1), and the protocol's first form walks it — same result as the flat oracle"""
+    import torch
+    from helpers import tile_from_records
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import api, dist
+    M = 0
+    # rank 0: reads [100 k, 100 k + 60), rank 1: [100 k + 50, 100 k + 110): every bundle of one rank bridges two of the other, 60 links long
+    f0 = [(0, 10 + 5 * i, 0, 60, "+", 1, [(30, M)]) for i in range(40)] + [(0, 1000 + 100 * k, 0, 60, "+", 1, [(60, M)]) for k in range(60)] + \
+         [(0, 20000 + 7 * i, 0, 60, "+", 1, [(30, M)]) for i in range(40)]
+    f1 = [(0, 12 + 5 * i, 0, 60, "-", 1, [(30, M)]) for i in range(40)] + [(0, 1050 + 100 * k, 0, 60, "-", 1, [(60, M)]) for k in range(60)] + \
+         [(0, 20001 + 7 * i, 0, 60, "-", 1, [(30, M)]) for i in range(40)]
+    tile = tile_from_records([f0, f1])
+    flat = orc.collapse(tile)
+    tiles, first = split_tile(tile, 2)
+    dtiles = [api.to_device(t, "cuda:0") for t in tiles]
+    sts = [dict(), dict()]
+    res = dist.run_loopback(DeviceCompute(), dtiles, first, device_chain=True, per_rank=[dict(stats=sts[r]) for r in range(2)])
+    for r in res:
+        for f in ("tid", "start", "end", "rep_fidx", "rep_idx", "yc", "yx", "yd"):
+            v = getattr(r, f)
+            setattr(r, f, v.cpu().numpy() if isinstance(v, torch.Tensor) else v)
+    check_against_flat(res, tile, flat)
+    assert all(st["cut_rounds"] >= 1 for st in sts), sts          # the lists gave up, the rounds settled the cut
+    assert res[0].n_groups > 0 and res[1].n_groups > 0

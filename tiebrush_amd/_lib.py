@@ -14,6 +14,9 @@ LIB_PATH = os.path.join(_HERE, "_build", "libtbk.so")
 _P = C.c_void_p
 
 TBK_MEM_HOST, TBK_MEM_DEVICE = 0, 1
+PARTIAL_BUNDLES = 15
+PARTIAL_CAND = 2 + 2 * PARTIAL_BUNDLES      # include/tbk.h: TBK_PARTIAL_CAND
+PARTIAL_META = 64 + 4                         # TBK_PARTIAL_META
 STRAT = {"cigar": 0, "full": 1, "clip": 2, "exon": 3}
 STATUS = {0: "TBK_OK", -1: "TBK_EINVAL", -2: "TBK_ENOMEM", -3: "TBK_EHIP", -4: "TBK_E2BIG", -5: "TBK_EUNSUPPORTED",
           -6: "TBK_EUNSORTED", -7: "TBK_EFATALOP", -8: "TBK_ECOLLISION", -9: "TBK_ENODEVICE"}
@@ -23,7 +26,7 @@ SYMBOLS = ["tbk_abi_version", "tbk_create", "tbk_destroy", "tbk_strerror", "tbk_
            "tbk_get_stream", "tbk_set_profiling", "tbk_kernel_times", "tbk_host_alloc", "tbk_host_free",
            "tbk_collapse_opts_default", "tbk_collapse_tile", "tbk_collapse_finish_yd", "tbk_coverage_tile", "tbk_sample_tile",
            "tbk_groups_to_cov_in", "tbk_bgzf_inflate", "tbk_bam_decode", "tbk_bam_records", "tbk_bam_release", "tbk_shard_prepare", "tbk_shard_probe_max", "tbk_shard_probe_next",
-           "tbk_shard_pack", "tbk_shard_unpack", "tbk_partial_keys", "tbk_partial_pack", "tbk_partial_unpack", "tbk_partial_reduce", "tbk_unpack_tile", "tbk_tile_join", "tbk_reserve_tile", "tbk_bgzf_deflate", "tbk_bam_encode"]
+           "tbk_shard_pack", "tbk_shard_unpack", "tbk_partial_keys", "tbk_partial_pack", "tbk_partial_unpack", "tbk_partial_reduce", "tbk_unpack_tile", "tbk_tile_join", "tbk_reserve_tile", "tbk_bgzf_deflate", "tbk_bam_encode", "tbk_partial_stage_keys", "tbk_partial_stage_cands", "tbk_partial_stage_pack"]
 
 
 class CollapseOpts(C.Structure):
@@ -140,6 +143,9 @@ def load():
     L.tbk_reserve_tile.argtypes = [_P, C.c_uint64, C.c_uint64]
     L.tbk_reserve_tile.restype = C.c_int
     L.tbk_unpack_tile.argtypes = [_P, C.POINTER(PackedIn), C.POINTER(SoaIn)]
+    L.tbk_partial_stage_keys.argtypes = [_P, C.POINTER(SoaIn), C.POINTER(GroupsOut), _P, _P, C.c_uint32, C.c_int64, _P]
+    L.tbk_partial_stage_cands.argtypes = [_P, _P, _P, C.c_uint32, _P, C.c_uint32, _P, _P]
+    L.tbk_partial_stage_pack.argtypes = [_P, C.POINTER(CollapseOpts), C.POINTER(SoaIn), C.POINTER(GroupsOut), _P, _P, _P, _P, C.c_uint32, C.c_uint32, _P, _P, _P, _P]
     L.tbk_bgzf_deflate.argtypes = [_P, _P, C.c_uint64, C.c_int, _P, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64)]
     L.tbk_bgzf_deflate.restype = C.c_int
     L.tbk_bam_encode.argtypes = [_P, C.POINTER(EncIn), _P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]

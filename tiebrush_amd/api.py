@@ -8,6 +8,7 @@ place, resident in HBM).  torch is plumbing only: device memory + streams.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from dataclasses import replace
 
@@ -132,7 +133,7 @@ class Context:
     def use_torch_stream(self):
         """Launch on torch's current stream so that torch ops and our kernels order correctly."""
         s = _torch().cuda.current_stream(self.device).cuda_stream
-        self._check(self.L.tbk_set_stream(self.h, C.c_void_p(s)), "tbk_set_stream")
+        self._check(self.L.tbk_set_stream(self.h, C.c_void_p(s if s else 1)), "tbk_set_stream")   # (0 = the default stream: TBK_STREAM_DEFAULT)
         self._on_torch_stream = True
 
     def _order_after_torch(self, dev):
@@ -576,6 +577,74 @@ class Context:
                                             C.c_void_p(bufs["prows"].data_ptr()), C.c_void_p(bufs["pcig"].data_ptr()),
                                             C.c_void_p(tab.data_ptr())), "tbk_partial_pack")
         return bufs["prows"][:ng], bufs["pcig"], tab
+
+    # ---- the sender's side without a wait (tbk_partial_stage_*): every call only queues kernels, on torch's current stream, so that
+    # the collectives between the stages are ordered with them by the stream alone
+    @contextlib.contextmanager
+    def _queued_on_torch_stream(self):
+        torch = _torch()
+        was = self._on_torch_stream
+        if not was:
+            sp = torch.cuda.current_stream(self.device).cuda_stream
+            self.L.tbk_set_stream(self.h, C.c_void_p(sp if sp else 1))      # (0 = the default stream: TBK_STREAM_DEFAULT)
+            self._on_torch_stream = True
+        try:
+            yield
+        finally:
+            if not was:
+                self.L.tbk_set_stream(self.h, None)
+                self._on_torch_stream = False
+
+    def partial_stage_keys(self, tile: SoATile, fin, first_fidx, carry=0, out=None):
+        """tbk_partial_stage_keys: (key, emax, meta [PARTIAL_META] int64) — device tensors, nothing read back"""
+        torch = _torch()
+        ng = int(fin["n_groups"])
+        bufs = out if out is not None else {}
+        for name in ("pkey", "pemax"):
+            if name not in bufs or bufs[name].numel() < max(ng, 1):
+                bufs[name] = torch.empty(max(ng, 1), dtype=torch.int64, device=self._dev())
+        meta = torch.empty(_lib.PARTIAL_META, dtype=torch.int64, device=self._dev())
+        with self._queued_on_torch_stream():
+            self._check(self.L.tbk_partial_stage_keys(self.h, C.byref(fin["_soa"]), C.byref(fin["_struct"]), C.c_void_p(bufs["pkey"].data_ptr()),
+                                                      C.c_void_p(bufs["pemax"].data_ptr()), int(first_fidx), int(carry), C.c_void_p(meta.data_ptr())),
+                        "tbk_partial_stage_keys")
+        return bufs["pkey"][:ng], bufs["pemax"][:ng], meta
+
+    def partial_stage_cands(self, key, emax, allmeta, world):
+        """tbk_partial_stage_cands: (targets [world - 1], cands [world - 1, PARTIAL_CAND]) from the gathered meta rows"""
+        torch = _torch()
+        nc = max(world - 1, 1)
+        targets = torch.empty(nc, dtype=torch.int64, device=self._dev())
+        cands = torch.empty((nc, _lib.PARTIAL_CAND), dtype=torch.int64, device=self._dev())
+        ng = int(key.numel())
+        allmeta = allmeta.contiguous()
+        with self._queued_on_torch_stream():
+            self._check(self.L.tbk_partial_stage_cands(self.h, C.c_void_p(key.data_ptr()) if ng else None, C.c_void_p(emax.data_ptr()) if ng else None, ng,
+                                                       C.c_void_p(allmeta.data_ptr()), int(world), C.c_void_p(targets.data_ptr()), C.c_void_p(cands.data_ptr())),
+                        "tbk_partial_stage_cands")
+        return targets, cands
+
+    def partial_stage_pack(self, tile: SoATile, fin, key, meta, allcands, targets, world, first_fidx, out=None, opts=None, **kw):
+        """tbk_partial_stage_pack: (rows [ng, 12] int32, cig words, tabx [world * 3 + 4] int64, cuts [world - 1]) — all on the device"""
+        torch = _torch()
+        o = opts if opts is not None else self.make_opts(**kw)
+        ng = int(fin["n_groups"])
+        nc = _numel(tile.cig)
+        bufs = out if out is not None else {}
+        if "prows" not in bufs or bufs["prows"].shape[0] < max(ng, 1):
+            bufs["prows"] = torch.empty((max(ng, 1), 12), dtype=torch.int32, device=self._dev())
+        if "pcig" not in bufs or bufs["pcig"].numel() < max(nc, 1):
+            bufs["pcig"] = torch.empty(max(nc, 1), dtype=torch.int32, device=self._dev())
+        tabx = torch.empty(world * 3 + 4, dtype=torch.int64, device=self._dev())
+        cuts = torch.empty(max(world - 1, 1), dtype=torch.int64, device=self._dev())
+        allcands = allcands.contiguous() if allcands is not None else None
+        with self._queued_on_torch_stream():
+            self._check(self.L.tbk_partial_stage_pack(self.h, C.byref(o), C.byref(fin["_soa"]), C.byref(fin["_struct"]), C.c_void_p(key.data_ptr()) if ng else None,
+                                                      C.c_void_p(meta.data_ptr()), C.c_void_p(allcands.data_ptr()) if world > 1 else None,
+                                                      C.c_void_p(targets.data_ptr()) if world > 1 else None, int(world), int(first_fidx),
+                                                      C.c_void_p(cuts.data_ptr()), C.c_void_p(bufs["prows"].data_ptr()), C.c_void_p(bufs["pcig"].data_ptr()),
+                                                      C.c_void_p(tabx.data_ptr())), "tbk_partial_stage_pack")
+        return bufs["prows"][:ng], bufs["pcig"], tabx, cuts[:max(world - 1, 0)]
 
     def partial_unpack(self, rows, out=None):
         """tbk_partial_unpack: the SoA arrays (torch tensors) of the received partial rows."""

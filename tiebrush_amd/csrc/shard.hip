@@ -720,6 +720,297 @@ extern "C" int tbk_partial_pack(tbk_ctx* ctx, const tbk_collapse_opts* o, const 
   return tbk_check_launch(ctx, "partial_pack");
 }
 
+// ---- the sender's side of the group-partials protocol in three stages that never wait for the device (ABI 7) ---------------------
+// The first version of the protocol walked every cut forward in rounds — two all-reduces and a device -> host decision per round, a
+// handful of rounds per step — and read counts back between its stages.  Here the host only queues work: between the stages lie the
+// collectives (all-gathers of small device arrays), and the one thing the host ever reads is the table of the exchange, gathered from
+// every rank at once, with every verdict the stages reached riding along in its flag words.
+namespace {
+constexpr uint32_t PM_SAMPLES = 64, PM_META = TBK_PARTIAL_META, PM_B = TBK_PARTIAL_BUNDLES, PM_CAND = TBK_PARTIAL_CAND;
+constexpr int64_t PM_INF = (int64_t)1 << 62;
+static_assert(PM_CAND == 2 + 2 * PM_B && PM_META == PM_SAMPLES + 4, "include/tbk.h");
+
+__global__ void partial_meta_k(uint32_t ng, const int64_t* __restrict__ key, uint32_t n_files, uint32_t first_fidx, int64_t carry,
+                               const uint32_t* __restrict__ bad, int64_t* __restrict__ meta) {
+  const uint32_t i = threadIdx.x;
+  if (i < PM_SAMPLES) meta[i] = ng ? key[(size_t)((uint64_t)i * ng / PM_SAMPLES)] : PM_INF;
+  if (i == PM_SAMPLES) meta[i] = n_files;
+  if (i == PM_SAMPLES + 1) meta[i] = first_fidx;
+  if (i == PM_SAMPLES + 2) meta[i] = (int64_t)(*bad & 1u);
+  if (i == PM_SAMPLES + 3) meta[i] = carry;
+}
+
+// the world - 1 splitter targets: the j / world quantiles of the valid samples of every rank (one block; bitonic sort in LDS)
+__global__ __launch_bounds__(1024) void partial_targets_k(uint32_t world, const int64_t* __restrict__ allmeta, int64_t* __restrict__ tgt) {
+  __shared__ int64_t v[4096];
+  const uint32_t n = world * PM_SAMPLES;  // <= 4096
+  uint32_t m = 1;
+  while (m < n) m <<= 1;
+  for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) v[i] = i < n ? allmeta[(size_t)(i / PM_SAMPLES) * PM_META + (i % PM_SAMPLES)] : PM_INF;
+  __syncthreads();
+  for (uint32_t k = 2; k <= m; k <<= 1)
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+        const uint32_t l = i ^ j;
+        if (l > i) {
+          const int64_t a = v[i], b = v[l];
+          if (((i & k) == 0) == (a > b)) v[i] = b, v[l] = a;
+        }
+      }
+      __syncthreads();
+    }
+  __shared__ uint32_t nvalid;
+  if (threadIdx.x == 0) {
+    uint32_t lo = 0, hi = n;  // first index holding PM_INF
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (v[mid] < PM_INF) lo = mid + 1;
+      else hi = mid;
+    }
+    nvalid = lo;
+  }
+  __syncthreads();
+  for (uint32_t j = threadIdx.x + 1; j < world; j += blockDim.x) tgt[j - 1] = nvalid ? v[(size_t)((uint64_t)j * nvalid / world)] : PM_INF;
+}
+
+// One block per cut: the local bundles around the target.  A group opens a local bundle when it starts beyond the running maximum
+// of the ends before it (key[i] > emax[i - 1]).  Out: [0] the farthest end of what lies before the first bundle head at or behind the
+// target, [1] the horizon — the start of the first local bundle this list does NOT describe (PM_INF: there is none) —, then PM_B
+// pairs (start of a bundle, farthest end of everything up to its last group).
+__global__ __launch_bounds__(256) void partial_cands_k(uint32_t ng, const int64_t* __restrict__ key, const int64_t* __restrict__ emax,
+                                                       const int64_t* __restrict__ tgt, int64_t* __restrict__ cand) {
+  const uint32_t c = blockIdx.x;
+  int64_t* out = cand + (size_t)c * PM_CAND;
+  __shared__ uint32_t heads[PM_B + 1];
+  __shared__ uint32_t nheads, idx0s;
+  if (threadIdx.x == 0) {
+    const int64_t t = tgt[c];
+    uint32_t lo = 0, hi = ng;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (key[mid] < t) lo = mid + 1;
+      else hi = mid;
+    }
+    idx0s = lo;
+    nheads = 0;
+  }
+  __syncthreads();
+  const uint32_t idx0 = idx0s;
+  constexpr uint32_t LIMIT = 1u << 22;  // groups looked at before the list gives up: what lies beyond is behind the horizon
+  uint32_t base = idx0;
+  bool hit_limit = false;
+  while (base < ng) {
+    if (base - idx0 >= LIMIT) {
+      hit_limit = true;
+      break;
+    }
+    const uint32_t i = base + threadIdx.x;
+    const bool head = i < ng && (i == 0 || key[i] > emax[i - 1]);
+    // the block's heads in index order: ballots per wave, waves in turn
+    const uint64_t bal = __ballot(head);
+    __shared__ uint32_t wcnt[4];
+    if ((threadIdx.x & 63u) == 0) wcnt[threadIdx.x >> 6] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint32_t before = nheads;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += wcnt[w];
+    if (head) {
+      const uint32_t r = before + (uint32_t)__popcll(bal & ((1ull << (threadIdx.x & 63u)) - 1ull));
+      if (r <= PM_B) heads[r] = i;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) nheads += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    __syncthreads();
+    if (nheads > PM_B) break;
+    base += 256;
+  }
+  if (threadIdx.x == 0) {
+    const uint32_t nh = nheads < PM_B + 1 ? nheads : PM_B + 1;
+    const uint32_t h1 = nh ? heads[0] : ng;  // everything before the first head is one stretch with the part before the target
+    out[0] = h1 ? emax[h1 - 1] : (int64_t)-1;
+    // the horizon: the (PM_B + 1)-th head if the walk saw one, the key where the walk gave up, or nothing left at all
+    int64_t hz = PM_INF;
+    if (nh == PM_B + 1) hz = key[heads[PM_B]];
+    else if (hit_limit) hz = key[base];
+    out[1] = hz;
+    const uint32_t last_known = nh == PM_B + 1 ? heads[PM_B] : (hit_limit ? base : ng);  // one past the last group the list covers
+    for (uint32_t b = 0; b < PM_B; ++b) {
+      if (b < nh && b < PM_B) {
+        const uint32_t nexth = (b + 1 < nh) ? heads[b + 1] : last_known;
+        out[2 + 2 * b] = key[heads[b]];
+        out[3 + 2 * b] = emax[nexth - 1];
+      } else {
+        out[2 + 2 * b] = PM_INF;
+        out[3 + 2 * b] = -1;
+      }
+    }
+  }
+}
+
+// One block per cut: the smallest key that is a clean cut for EVERY rank — no group of any rank that starts before it ends at or behind
+// it — among the target and the bundle starts the ranks listed, judged from the lists alone.  A candidate beyond some rank's horizon
+// cannot be judged and is skipped; when nothing qualifies the cut stays unsettled (flag bit 1) and the caller walks it the slow way.
+__global__ __launch_bounds__(256) void partial_choose_k(uint32_t world, const int64_t* __restrict__ allcand /* [world][world - 1][PM_CAND] */,
+                                                        const int64_t* __restrict__ tgt, int64_t* __restrict__ cuts, uint32_t* __restrict__ flags) {
+  const uint32_t c = blockIdx.x, nc = world - 1;
+  const int64_t t = tgt[c];
+  __shared__ unsigned long long best;
+  if (threadIdx.x == 0) best = ~0ull;
+  __syncthreads();
+  const uint32_t ncand = 1 + world * PM_B;
+  for (uint32_t q = threadIdx.x; q < ncand; q += blockDim.x) {
+    int64_t x;
+    if (q == 0) x = t;
+    else x = allcand[((size_t)((q - 1) / PM_B) * nc + c) * PM_CAND + 2 + 2 * ((q - 1) % PM_B)];
+    if (x >= PM_INF || x < t) continue;
+    bool clean = true;
+    for (uint32_t r = 0; r < world && clean; ++r) {
+      const int64_t* L = allcand + ((size_t)r * nc + c) * PM_CAND;
+      if (x > L[1]) {  // beyond what rank r described
+        clean = false;
+        break;
+      }
+      int64_t e = L[0];  // farthest end of rank r's groups that start before x (an upper bound: running maxima)
+      for (uint32_t b = 0; b < PM_B; ++b)
+        if (L[2 + 2 * b] < x) e = L[3 + 2 * b];
+      clean = e < x;
+    }
+    if (clean) atomicMin(&best, (unsigned long long)x);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (t >= PM_INF) cuts[c] = PM_INF;  // (no samples anywhere: nothing to cut)
+    else if (best == ~0ull) {
+      cuts[c] = PM_INF;
+      atomicOr(flags, 2u);
+    } else cuts[c] = (int64_t)best;
+  }
+}
+
+// every settled cut is clean, and so is any later cut in the place of an earlier one: the cuts in ascending order (the lists of two
+// cuts may judge one candidate differently, both conservatively)
+__global__ void partial_cuts_sorted_k(uint32_t nc, int64_t* __restrict__ cuts) {
+  if (blockIdx.x || threadIdx.x) return;
+  for (uint32_t c = nc - 1; c-- > 0;)
+    if (cuts[c] > cuts[c + 1]) cuts[c] = cuts[c + 1];
+}
+
+// tabx = the table of the exchange ([world][3]) + {flags, n_files, first_fidx, carry}: flags = bit 0 the partials cannot be packed,
+// bit 1 a cut is unsettled, bits 8.. the error bits kernels raised
+__global__ void partial_tabx_k(uint32_t world, const long long* __restrict__ tab, const int64_t* __restrict__ mymeta, const uint32_t* __restrict__ flags,
+                               const uint32_t* __restrict__ derr, long long* __restrict__ tabx) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < world * 3) tabx[i] = tab[i];
+  if (i == 0) {
+    tabx[world * 3 + 0] = (long long)((*flags & 3u) | (uint32_t)(mymeta[PM_SAMPLES + 2] & 1) | (*derr << 8));
+    tabx[world * 3 + 1] = mymeta[PM_SAMPLES];
+    tabx[world * 3 + 2] = mymeta[PM_SAMPLES + 1];
+    tabx[world * 3 + 3] = mymeta[PM_SAMPLES + 3];
+  }
+}
+}  // namespace
+
+extern "C" int tbk_partial_stage_keys(tbk_ctx* ctx, const tbk_soa_in* in, const tbk_groups_out* g, int64_t* key, int64_t* emax, uint32_t first_fidx,
+                                      int64_t carry, int64_t* meta) {
+  if (!ctx || !in || !g || !meta) return TBK_EINVAL;
+  if (in->mem != TBK_MEM_DEVICE || g->mem != TBK_MEM_DEVICE) return TBK_EINVAL;
+  const uint32_t ng = g->n_groups;
+  if (ng && (!key || !emax || !g->rep || !g->yc || !g->yx || !g->g_start || !g->g_end || !in->tid)) return TBK_EINVAL;
+  TBK_HIP(hipSetDevice(ctx->device));
+  tbk_prof_begin_call(ctx);
+  struct ProfEnd {
+    tbk_ctx* c;
+    ~ProfEnd() { tbk_prof_end_call(c); }
+  } prof_end{ctx};
+  TBK_TRY(tbk_ws_reserve(ctx, (size_t)ng * 8 + ((size_t)1 << 20)));
+  uint64_t* sc = ctx->d_scalars;
+  TBK_HIP(hipMemsetAsync(sc, 0, 16 * sizeof(uint64_t), ctx->stream));
+  if (ng) {
+    TBK_LAUNCH(ctx, "partial_keys", partial_keys_k, cdiv(ng, SH_B), SH_B, 0, ng, g->rep, in->tid, g->g_start, g->yc, g->yx, g->g_key, key, (uint32_t*)(sc + 8));
+    PmLoad ld{g->rep, in->tid, g->g_end, g->g_key};
+    PmStore st{emax};
+    TBK_TRY((scan_op_run<PmKey, PmOp, PmLoad, PmStore>(ctx, "partial_emax_scan", ng, ld, st, PmOp{}, PmKey{0u, 0u})));
+  }
+  TBK_LAUNCH(ctx, "partial_meta", partial_meta_k, 1, 128, 0, ng, key, in->n_files, first_fidx, carry, (const uint32_t*)(sc + 8), meta);
+  return tbk_check_launch(ctx, "partial_stage_keys");
+}
+
+extern "C" int tbk_partial_stage_cands(tbk_ctx* ctx, const int64_t* key, const int64_t* emax, uint32_t ng, const int64_t* allmeta, uint32_t world,
+                                       int64_t* targets, int64_t* cands) {
+  if (!ctx || !allmeta || world == 0 || world > 64) return TBK_EINVAL;
+  if (world == 1) return 0;
+  if (!targets || !cands || (ng && (!key || !emax))) return TBK_EINVAL;
+  TBK_HIP(hipSetDevice(ctx->device));
+  tbk_prof_begin_call(ctx);
+  struct ProfEnd {
+    tbk_ctx* c;
+    ~ProfEnd() { tbk_prof_end_call(c); }
+  } prof_end{ctx};
+  TBK_LAUNCH(ctx, "partial_targets", partial_targets_k, 1, 1024, 0, world, allmeta, targets);
+  TBK_LAUNCH(ctx, "partial_cands", partial_cands_k, world - 1, 256, 0, ng, key, emax, targets, cands);
+  return tbk_check_launch(ctx, "partial_stage_cands");
+}
+
+extern "C" int tbk_partial_stage_pack(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_in* in, const tbk_groups_out* g, const int64_t* key,
+                                      const int64_t* mymeta, const int64_t* allcands, const int64_t* targets, uint32_t world, uint32_t first_fidx,
+                                      int64_t* cuts, int32_t* rows, uint32_t* cig_out, int64_t* tabx) {
+  if (!ctx || !o || !in || !g || !tabx || !mymeta || world == 0 || world > 64) return TBK_EINVAL;
+  if (o->strategy < 0 || o->strategy > 3 || o->strategy == TBK_STRAT_FULL) return TBK_EUNSUPPORTED;  // (no MD tags in a partial)
+  if (in->mem != TBK_MEM_DEVICE || g->mem != TBK_MEM_DEVICE || in->n_files == 0 || in->n_files > 65535 || !in->file_off) return TBK_EINVAL;
+  const uint32_t ng = g->n_groups;
+  if (ng && (!key || !rows || !cig_out || !g->rep || !g->yc || !g->yx || !g->yd || !g->rep_effend)) return TBK_EINVAL;
+  if (world > 1 && (!allcands || !targets || !cuts)) return TBK_EINVAL;
+  TBK_HIP(hipSetDevice(ctx->device));
+  tbk_prof_begin_call(ctx);
+  struct ProfEnd {
+    tbk_ctx* c;
+    ~ProfEnd() { tbk_prof_end_call(c); }
+  } prof_end{ctx};
+  TBK_TRY(tbk_ws_reserve(ctx, (size_t)ng * 16 + ((size_t)1 << 20)));
+  uint64_t* sc = ctx->d_scalars;
+  uint32_t* d_flags = (uint32_t*)(sc + 9);  // (word 8 holds stage 1's verdict, the error word is 15: neither is cleared here)
+  TBK_HIP(hipMemsetAsync(d_flags, 0, sizeof(uint64_t), ctx->stream));
+  if (world > 1) {
+    TBK_LAUNCH(ctx, "partial_choose", partial_choose_k, world - 1, 256, 0, world, allcands, targets, cuts, d_flags);
+    if (world > 2) TBK_LAUNCH(ctx, "partial_choose", partial_cuts_sorted_k, 1, 1, 0, world - 1, cuts);
+  }
+  uint32_t* cnt = ws_alloc<uint32_t>(ctx, (size_t)ng + 1);
+  uint32_t* cfirst = ws_alloc<uint32_t>(ctx, (size_t)ng + 1);
+  uint32_t* woff = ws_alloc<uint32_t>(ctx, (size_t)ng + 1);
+  long long* tab = (long long*)ws_alloc<uint64_t>(ctx, (size_t)world * 3);
+  if (!woff || !tab) return TBK_ENOMEM;
+  uint32_t* d_fo = nullptr;
+  TBK_TRY(shard_upload_file_off(ctx, in->file_off, in->n_files, &d_fo));
+  if (ng) TBK_LAUNCH(ctx, "partial_ncig", partial_ncig_k, cdiv(ng, SH_B), SH_B, 0, ng, g->rep, in->cig_off, g->g_key, cnt, cfirst);
+  TBK_TRY(tbk_exscan_u32(ctx, cnt, woff, ng, sc + 21));
+  TBK_LAUNCH(ctx, "partial_table", partial_table_k, cdiv(world, 64), 64, 0, ng, world, key, cuts, woff, sc + 21, tab);
+  if (ng) {
+    ColIn I{};
+    I.n = in->n_records;
+    I.k = in->n_files;
+    I.file_off = d_fo;
+    I.tid = in->tid;
+    I.pos = in->pos;
+    I.flag = in->flag;
+    I.mapq = in->mapq;
+    I.strand = in->strand;
+    I.nh = in->nh;
+    I.cig_off = in->cig_off;
+    I.cig = in->cig;
+    ColOpt O{};
+    O.strategy = o->strategy;
+    O.max_nh = o->max_nh;
+    O.min_qual = o->min_qual;
+    O.keep_supp = o->keep_supplementary;
+    O.keep_sec = o->keep_secondary;
+    O.seed = TBK_KEY_SEED0;
+    O.hash_mask = 0xFFFFFFFFu;
+    TBK_LAUNCH(ctx, "partial_rows", partial_rows_k, cdiv(ng, SH_B), SH_B, 0, ng, in->n_files, first_fidx, I, O, g->rep, g->yc, g->yx, g->yd,
+               g->rep_effend, cfirst, cnt, woff, g->g_key, rows, cig_out, ctx->d_err);
+  }
+  TBK_LAUNCH(ctx, "partial_tabx", partial_tabx_k, cdiv(world * 3 + 1, 64), 64, 0, world, tab, mymeta, d_flags, ctx->d_err, (long long*)tabx);
+  return tbk_check_launch(ctx, "partial_stage_pack");
+}
+
 extern "C" int tbk_partial_unpack(tbk_ctx* ctx, const int32_t* rows, uint32_t n2, int32_t* tid, int32_t* pos, uint16_t* flag, uint8_t* mapq,
                                   uint8_t* strand, int32_t* nh, uint32_t* cig_off, double* yc_in, int64_t* yx_in, int64_t* yd_in,
                                   int64_t* prio_hi, int64_t* prio_lo) {

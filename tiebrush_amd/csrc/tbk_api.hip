@@ -431,7 +431,8 @@ const char* tbk_last_error(const tbk_ctx* ctx) { return ctx ? ctx->last_error.c_
 
 int tbk_set_stream(tbk_ctx* ctx, void* s) {
   if (!ctx) return TBK_EINVAL;
-  ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+  // (TBK_STREAM_DEFAULT: the device's default stream, whose handle is the null pointer that otherwise says "the context's own")
+  ctx->stream = s == TBK_STREAM_DEFAULT ? (hipStream_t) nullptr : (s ? (hipStream_t)s : ctx->own_stream);
   return 0;
 }
 void* tbk_get_stream(tbk_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }

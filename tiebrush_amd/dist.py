@@ -525,27 +525,11 @@ def _partial_unpack_np(rows):
                 prio_hi=r[:, 3].astype(np.uint64), prio_lo=((r[:, 4] << 32) | (r[:, 5] & 0xFFFFFFFF)).astype(np.uint64))
 
 
-def partials_collapse(compute, local_tile: SoATile, first_fidx: int, rank: int, world: int, strategy="cigar", want_coverage=False,
-                      device_chain=False, local=None, stats=None, **filters):
-    """Generator like shard_collapse (same requests, same ShardResult): collapse locally, exchange group partials, reduce by key
-    on the owner.  `local`: the result of the local collapse when the driver has already run it (bench.py collapses tile i + 1
-    while tile i is exchanged) — a dict of compute.collapse(..., want_coords=True, want_effend=True) with a final `yd`.
-    `stats` (dict, optional) receives wire_rows / wire_bytes of this rank's exchange."""
-    if filters.get("store_frac") or filters.get("collapse_same"):
-        raise ValueError("--store-frac and -A need the single-tile path's ordered passes: single-GPU only (DESIGN.md §7)")
-    if strategy in ("full", 1):
-        raise ValueError("-L (CIGAR + MD) is single-GPU only: neither partials nor shuffled rows carry MD tags")
-    X = _xp(local_tile.tid)
-    mark = getattr(compute, "mark", None) or (lambda _name: None)
-    on_dev = _is_t(local_tile.tid) and hasattr(compute, "partial_keys")
+def _partials_rounds(compute, X, mark, on_dev, local_tile, fin, first_fidx, rank, world, strategy, stats, filters):
+    """steps 2 - 4 of the protocol in its first form: cuts walked forward in all-reduce rounds, counts exchanged before the rows.
+    Returns (rrows, rcnt, rcig) or "shuffle"."""
     k = local_tile.n_files
-    # ---- 1. the ordinary single-GPU collapse of this rank's files ---------------------------------------------------------
-    fin = local
-    if fin is None:
-        fin = compute.collapse(local_tile, strategy=strategy, want_coords=True, want_effend=True, **filters)
     ng = int(fin["n_groups"])
-    n_pass = int(fin["n_passed"])
-    mark("local")
     # ---- 2. cut keys of the local groups; one all-gather: samples + file table + "can this rank's partials be packed" -----
     if on_dev:
         key, emax, bad = compute.partial_keys(local_tile, fin)
@@ -574,9 +558,7 @@ def partials_collapse(compute, local_tile: SoATile, first_fidx: int, rank: int, 
     if bool(allmeta[:, N_SAMPLES + 2].any()):
         # a carried fractional YC somewhere (or a count beyond 31 bits): sums across ranks would not keep the reference's order of
         # additions — every rank takes the record shuffle for this tile (the decision is collective: same data on all ranks)
-        res = yield from shard_collapse(compute, local_tile, first_fidx, rank, world, strategy=strategy, want_coverage=want_coverage,
-                                        device_chain=device_chain, **filters)
-        return res
+        return "shuffle"
     fo1 = np.array([0, ng], np.int64)
     p = None
     if world > 1:
@@ -630,19 +612,154 @@ def partials_collapse(compute, local_tile: SoATile, first_fidx: int, rank: int, 
     mark("pack")
     rrows, rcnt, rcig, _ = yield ("exchange_rows", (rows[:ng], cnt_rows, cigw[:int(cnt_words.sum())], cnt_words, cnt_rows.reshape(world, 1)))
     mark("exchange")
+    return rrows, rcnt, rcig
+
+
+def _owner_reduce_fast(compute, X, rrows, file_off2, rcig, device_chain, strategy):
+    """tbk_partial_reduce on the rows as they arrived; None when it hands the tile to the general path (a hashed key word shared by two
+    alignments, a pile-up of partials, more runs than a window takes)"""
+    if not (hasattr(compute, "partial_reduce") and os.environ.get("TBK_PARTIAL_REDUCE", "1") != "0"):
+        return None
+    from ._lib import TbkError
+    try:
+        return compute.partial_reduce(rrows, file_off2, rcig, want_view=device_chain, strategy=strategy)
+    except TbkError as e:
+        if e.status not in (-8, -4, -5):
+            raise
+        return None
+
+
+def _partials_lists(compute, local_tile, fin, first_fidx, rank, world, strategy, want_coverage, device_chain, stats, carry, junction_gather, filters):
+    """The group-partials protocol with the cut search on lists (tbk_partial_stage_*, include/tbk.h): three all-gathers of small device
+    arrays, ONE read-back (the gathered exchange table with every verdict in its flag words), two all-to-alls whose counts every rank
+    already knows.  Returns a ShardResult, or the name of the protocol that has to take the tile instead ("rounds": a cut no list could
+    settle; "shuffle": partials that cannot be packed) — a collective decision, every rank reads the same table."""
+    X = _xp(local_tile.tid)
+    mark = getattr(compute, "mark", None) or (lambda _name: None)
+    ng = int(fin["n_groups"])
+    n_pass = int(fin["n_passed"])
+    key, emax, meta = compute.partial_stage_keys(local_tile, fin, first_fidx, carry)
+    allmeta = yield ("all_gather", meta)
+    targets = allc = None
+    if world > 1:
+        targets, cands = compute.partial_stage_cands(key, emax, allmeta, world)
+        allc = yield ("all_gather", cands)
+    rows, cigw, tabx, _cuts = compute.partial_stage_pack(local_tile, fin, key, meta, allc, targets, world, first_fidx, strategy=strategy, **filters)
+    alltab = np.asarray(X.host((yield ("all_gather", tabx)))).reshape(world, world * 3 + 4).astype(np.int64)     # the one read-back
+    if stats is not None:
+        stats["collectives"] = stats.get("collectives", 0) + (3 if world > 1 else 2)
+        stats["host_syncs"] = stats.get("host_syncs", 0) + 1
+        stats["cut_rounds"] = 0
+        stats["prev_carry"] = alltab[:, world * 3 + 3].copy()
+    flags, ks, firsts = alltab[:, world * 3], alltab[:, world * 3 + 1], alltab[:, world * 3 + 2]
+    if not np.array_equal(firsts, np.concatenate([[firsts[0]], firsts[0] + np.cumsum(ks)[:-1]])):
+        raise ValueError("ranks must hold consecutive blocks of the input files, in rank order")
+    if (flags >> 8).any():
+        raise RuntimeError("device error bits 0x%x in the partials' pack" % int((flags >> 8).max()))
+    if (flags & 1).any():
+        return "shuffle"
+    if (flags & 2).any():
+        return "rounds"
+    mark("pack")
+    tab = alltab[:, :world * 3].reshape(world, world, 3)
+    send_rows, send_words = tab[rank, :, 1].copy(), tab[rank, :, 2].copy()
+    recv_rows, recv_words = tab[:, rank, 1].copy(), tab[:, rank, 2].copy()
+    if stats is not None:
+        stats["wire_rows"] = int(send_rows.sum())
+        stats["wire_bytes"] = int(send_rows.sum()) * PROW * 4 + int(send_words.sum()) * 4
+        stats["wire_bytes_off_rank"] = stats["wire_bytes"] - (int(send_rows[rank]) * PROW * 4 + int(send_words[rank]) * 4)
+        stats["collectives"] += 2
+    big = (int(tab[:, :, 1].max()), int(tab[:, :, 2].max()))
+    rrows, rcig = yield ("exchange_known", (rows[:ng], send_rows, recv_rows, cigw[:int(send_words.sum())], send_words, recv_words, big))
+    mark("exchange")
+    n2 = int(rrows.shape[0])
+    file_off2 = np.zeros(world + 1, np.uint32)
+    file_off2[1:] = np.cumsum(recv_rows)
+    assert int(file_off2[-1]) == n2
+    fast = _owner_reduce_fast(compute, X, rrows, file_off2, rcig, device_chain, strategy)
+    if stats is not None:
+        stats["host_syncs"] += 1            # (the owner's reduce reads its group count back)
+    if fast is None:
+        return ("general", rrows, recv_rows, rcig)
+    T = _torch()
+    g2 = int(fast["n_groups"])
+    res = ShardResult(n_groups=g2, n_passed_local=n_pass, start=fast["g_start"], end=fast["g_end"], yc=fast["yc"], yx=fast["yx"], yd=fast["yd"],
+                      n_partials_received=n2, rep_rows=(rrows, fast["rep"]))
+    mark("reduce")
+    rep2 = fast["rep"]
+    if device_chain:
+        res.cov_input = fast["view"]
+    else:
+        rep2 = fast["rep"].to(T.int64)
+        rr = rrows[rep2] if g2 else rrows[:0]
+        A = compute.partial_unpack(rrows)
+        ncg, cof, cg = _gather_cigars(X, A["cig_off"], rcig, rep2)
+        res.cov_input = CovInput(tid=rr[:, 0].contiguous(), pos=rr[:, 1].contiguous(), flag=X.as_dtype(X.zeros(g2, like=rep2), "u16"),
+                                 cig_off=X.as_dtype(cof, "u32"), cig=cg, yc=fast["yc"].to(T.float32).to(T.float64),
+                                 strand=A["strand"][rep2], yx=fast["yx"])
+    if want_coverage:
+        cov = compute.coverage(res.cov_input)
+        res.coverage = cov
+        if junction_gather:
+            nj = yield ("all_gather", X.scalar(int(cov["n_junctions"]), like=rep2))
+            res.junction_offset = int(X.host(nj).reshape(-1)[:rank].sum())
+            if stats is not None:
+                stats["collectives"] += 1
+    mark("coverage")
+    return res
+
+
+def partials_collapse(compute, local_tile: SoATile, first_fidx: int, rank: int, world: int, strategy="cigar", want_coverage=False,
+                      device_chain=False, local=None, stats=None, cut_search="lists", carry=0, junction_gather=True, **filters):
+    """Generator like shard_collapse (same requests, same ShardResult): collapse locally, exchange group partials, reduce by key
+    on the owner.  `local`: the result of the local collapse when the driver has already run it (bench.py collapses tile i + 1
+    while tile i is exchanged) — a dict of compute.collapse(..., want_coords=True, want_effend=True) with a final `yd`.
+    `stats` (dict, optional) receives wire_rows / wire_bytes of this rank's exchange."""
+    if filters.get("store_frac") or filters.get("collapse_same"):
+        raise ValueError("--store-frac and -A need the single-tile path's ordered passes: single-GPU only (DESIGN.md §7)")
+    if strategy in ("full", 1):
+        raise ValueError("-L (CIGAR + MD) is single-GPU only: neither partials nor shuffled rows carry MD tags")
+    X = _xp(local_tile.tid)
+    mark = getattr(compute, "mark", None) or (lambda _name: None)
+    on_dev = _is_t(local_tile.tid) and hasattr(compute, "partial_keys")
+    k = local_tile.n_files
+    # ---- 1. the ordinary single-GPU collapse of this rank's files ---------------------------------------------------------
+    fin = local
+    if fin is None:
+        fin = compute.collapse(local_tile, strategy=strategy, want_coords=True, want_effend=True, **filters)
+    ng = int(fin["n_groups"])
+    n_pass = int(fin["n_passed"])
+    mark("local")
+    general = None
+    if on_dev and hasattr(compute, "partial_stage_keys") and cut_search == "lists":
+        got = yield from _partials_lists(compute, local_tile, fin, first_fidx, rank, world, strategy, want_coverage, device_chain, stats, carry,
+                                         junction_gather, filters)
+        if isinstance(got, ShardResult):
+            return got
+        if got == "shuffle":
+            res = yield from shard_collapse(compute, local_tile, first_fidx, rank, world, strategy=strategy, want_coverage=want_coverage,
+                                            device_chain=device_chain, **filters)
+            return res
+        if isinstance(got, tuple):          # the rows are here, the owner's merge-reduce handed them to the general path
+            general = got
+        # ("rounds": a cut no list settled — the walk below takes the tile from the start)
+    if general is None:
+        got = yield from _partials_rounds(compute, X, mark, on_dev, local_tile, fin, first_fidx, rank, world, strategy, stats, filters)
+        if got == "shuffle":
+            res = yield from shard_collapse(compute, local_tile, first_fidx, rank, world, strategy=strategy, want_coverage=want_coverage,
+                                            device_chain=device_chain, **filters)
+            return res
+        rrows, rcnt, rcig = got
+    else:
+        rrows, rcnt, rcig = general[1], general[2], general[3]
     # ---- 5. the partials of this rank's coordinate range: one run per source rank, TieBrush-merged, explicit priorities ----
     n2 = int(rrows.shape[0])
     file_off2 = np.zeros(world + 1, np.uint32)
     file_off2[1:] = np.cumsum(np.asarray(rcnt, np.int64))
     assert int(file_off2[-1]) == n2
     fast = None
-    if on_dev and hasattr(compute, "partial_reduce") and os.environ.get("TBK_PARTIAL_REDUCE", "1") != "0":
-        from ._lib import TbkError
-        try:                                            # the owner's merge-reduce on the rows as they arrived
-            fast = compute.partial_reduce(rrows, file_off2, rcig, want_view=device_chain, strategy=strategy)
-        except TbkError as e:
-            if e.status not in (-8, -4, -5):            # a hashed key word shared by two alignments / a pile-up of partials / > 64 runs:
-                raise                                   # the general path (reseeds, block-sorts long buckets) takes the tile
+    if on_dev and general is None:                      # the owner's merge-reduce on the rows as they arrived
+        fast = _owner_reduce_fast(compute, X, rrows, file_off2, rcig, device_chain, strategy)
     if fast is not None:
         T = _torch()
         g2 = int(fast["n_groups"])
@@ -719,19 +836,20 @@ def _host_tile(tile):
 
 
 # ---- drivers ---------------------------------------------------------------------------------------------------
-def run_loopback(compute, tiles, first_fidx, **kw):
+def run_loopback(compute, tiles, first_fidx, per_rank=None, **kw):
     """Run R virtual ranks in one process: steps the R generators in lockstep and serves their collectives.
-    mode="partials" (default): collapse locally, exchange group partials; mode="shuffle": the record shuffle."""
+    mode="partials" (default): collapse locally, exchange group partials; mode="shuffle": the record shuffle.
+    per_rank: optional list of R dicts of keyword arguments that differ by rank (local=..., stats=...)."""
     world = len(tiles)
     gen_fn = shard_collapse if kw.pop("mode", "partials") == "shuffle" else partials_collapse
-    gens = [gen_fn(compute, tiles[r], first_fidx[r], r, world, **kw) for r in range(world)]
+    gens = [gen_fn(compute, tiles[r], first_fidx[r], r, world, **kw, **(per_rank[r] if per_rank else {})) for r in range(world)]
     reqs = [next(g) for g in gens]
     results = [None] * world
     while any(r is None for r in results):
         assert all(res is None for res in results) and len({q[0] for q in reqs}) == 1, "ranks diverged"
         kind = reqs[0][0]
         pay = [q[1] for q in reqs]
-        X = _xp(pay[0][0] if kind in ("exchange_rows", "all_to_all") else pay[0])
+        X = _xp(pay[0][0] if kind in ("exchange_rows", "all_to_all", "exchange_known") else pay[0])
         if kind == "all_gather":
             out = [X.stack(pay)] * world
         elif kind == "all_reduce_max":
@@ -749,6 +867,17 @@ def run_loopback(compute, tiles, first_fidx, **kw):
                     parts.append(data[o:o + int(ch[d])])
                     cnts.append(int(ch[d]))
                 out.append((X.cat(parts), np.array(cnts, np.int64)))
+        elif kind == "exchange_known":       # every rank knows every count already: rows and CIGAR words move, nothing else
+            out = []
+            for d in range(world):
+                rows, words = [], []
+                for s_ in range(world):
+                    R, sr, _rr, cig, sw, _rw, _big = pay[s_]
+                    o, oc = int(np.asarray(sr)[:d].sum()), int(np.asarray(sw)[:d].sum())
+                    rows.append(R[o:o + int(sr[d])])
+                    words.append(cig[oc:oc + int(sw[d])])
+                assert [int(r.shape[0]) for r in rows] == [int(c) for c in pay[d][2]]
+                out.append((X.cat(rows), X.cat(words)))
         elif kind == "exchange_rows":
             out = []
             for d in range(world):
@@ -805,7 +934,7 @@ def run_distributed(compute, tile, first_fidx, device=None, group=None, **kw):
 
     A2A_MAX_BYTES = int(os.environ.get("TBK_A2A_MAX_BYTES", 256 << 20))   # per-peer piece of one all_to_all_single call
 
-    def a2a_rows(x, send_cnt, recv_cnt):
+    def a2a_rows(x, send_cnt, recv_cnt, big=None):
         """all_to_all of the row blocks of x (dim 0 split by send_cnt), recv_cnt rows from each source.  One rank: a
         copy.  Blocks beyond A2A_MAX_BYTES go out in several rounds: the RCCL of this image drops the tail of a
         1.5 GB self-exchange (tools/scratch/a2a_probe.py: 64 M rows x 24 B arrive as 32 M rows + zeros), and rounds of a
@@ -816,10 +945,13 @@ def run_distributed(compute, tile, first_fidx, device=None, group=None, **kw):
             return out
         row_bytes = max(1, x.element_size() * int(np.prod(x.shape[1:], dtype=np.int64)))
         chunk = max(1, A2A_MAX_BYTES // row_bytes)
-        big = max(int(max(send_cnt)), int(max(recv_cnt)))
-        rounds = torch.tensor([(big + chunk - 1) // chunk], dtype=torch.int64, device=x.device if not stage else "cpu")
-        dist.all_reduce(rounds, op=dist.ReduceOp.MAX, group=group)
-        rounds = max(1, int(rounds))
+        if big is None:        # the largest piece any rank sends: agreed on by a reduction — or known to the caller (`big`)
+            big = max(int(max(send_cnt)), int(max(recv_cnt)))
+            rounds = torch.tensor([(big + chunk - 1) // chunk], dtype=torch.int64, device=x.device if not stage else "cpu")
+            dist.all_reduce(rounds, op=dist.ReduceOp.MAX, group=group)
+            rounds = max(1, int(rounds))
+        else:
+            rounds = max(1, (int(big) + chunk - 1) // chunk)
         if rounds == 1:
             dist.all_to_all_single(out, x, output_split_sizes=[int(c) for c in recv_cnt], input_split_sizes=[int(c) for c in send_cnt],
                                    group=group)
@@ -862,6 +994,11 @@ def run_distributed(compute, tile, first_fidx, device=None, group=None, **kw):
                 rc_h = rc.cpu().numpy().astype(np.int64)
                 out = a2a_rows(t(data).contiguous(), sc_h.tolist(), rc_h.tolist())
                 res = (back(out, data), rc_h)
+            elif kind == "exchange_known":
+                R, sr, rr, cig, sw, rw, big = pay
+                outR = a2a_rows(t(R).contiguous(), [int(c) for c in sr], [int(c) for c in rr], big=big[0])
+                outC = a2a_rows(t(cig).contiguous(), [int(c) for c in sw], [int(c) for c in rw], big=big[1])
+                res = (back(outR, R), back(outC, cig))
             elif kind == "exchange_rows":
                 R, cnt, cig, ccnt, per = pay
                 # one small all-to-all tells every rank what it will receive: [rows, CIGAR words, rows per file of the sender]
