@@ -209,6 +209,10 @@ const char* tbk_last_error(const tbk_ctx* ctx); /* detail of the last TBK_EHIP e
 int tbk_set_stream(tbk_ctx* ctx, void* hip_stream);
 void* tbk_get_stream(tbk_ctx* ctx);
 int tbk_set_profiling(tbk_ctx* ctx, int enabled);
+/* Test hooks and forced path choices of a context: "key=value,key=value" (NULL or "": the defaults).  A context starts with what
+ * the environment variable TBK_DEBUG held when it was created — the only time the library looks at the environment; the keys are
+ * listed with struct TbkDebug in tiebrush_amd/csrc/tbk_internal.h (path, raw, sort, scan, hash_mask, yd_wave_min, cov_legacy, ...). */
+int tbk_set_debug(tbk_ctx* ctx, const char* spec);
 int tbk_kernel_times(tbk_ctx* ctx, tbk_kernel_time* out, int cap); /* returns count */
 
 /* Pinned host memory helpers for TBK_MEM_HOST callers. */

@@ -88,3 +88,15 @@ def paired_end_like_files():
           (1, 41, 16, 60, "+", 1, [(10, M), (20, N), (30, M)]), (2, 5, 0, 60, "-", 1, [(40, M)]), un]
     f3 = [(0, 90, 0, 60, "-", 1, [(30, M)]), (2, 5, 0, 60, "-", 1, [(40, M)]), (2, 7, 0, 0, "-", 1, [(40, M)])]
     return [f0, f1, f2, f3]
+
+
+def tbk_debug(monkeypatch, **kw):
+    """test hooks of the library (struct TbkDebug, tiebrush_amd/csrc/tbk_internal.h) for the contexts and command lines of this test:
+    merged into TBK_DEBUG ("key=value,..."); a value of None takes a key out again"""
+    cur = dict(x.split("=", 1) for x in os.environ.get("TBK_DEBUG", "").split(",") if x)
+    for k, v in kw.items():
+        if v is None:
+            cur.pop(k, None)
+        else:
+            cur[k] = str(v)
+    monkeypatch.setenv("TBK_DEBUG", ",".join("%s=%s" % kv for kv in cur.items()))

@@ -6,25 +6,17 @@ import zlib
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, sample_paths
+from helpers import GOLDEN, sample_paths, tbk_debug
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["wave", "lane"])
-def ctx(request):
-    """every test of this file runs on both inflate kernels: a wave per member (the default) and a lane per member
-    (TBK_INFLATE_LANE, bamdev.hip: bgz_inflate_launch)"""
+@pytest.fixture(scope="module")
+def ctx():
     from tiebrush_amd import api
-    old = os.environ.pop("TBK_INFLATE_LANE", None)
-    if request.param == "lane":
-        os.environ["TBK_INFLATE_LANE"] = "1"
     c = api.Context(0)
     yield c
     c.close()
-    os.environ.pop("TBK_INFLATE_LANE", None)
-    if old is not None:
-        os.environ["TBK_INFLATE_LANE"] = old
 
 
 def _bgzf(payload: bytes, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, block=0xff00) -> bytes:
@@ -159,7 +151,7 @@ def test_bam_decode_matches_host_decoders(ctx, bam_loader):
 def test_record_index_by_member_and_by_chain(ctx, monkeypatch):
     """the record index of tbk_bam_decode: a lane per BGZF member where every member begins with a record (files written through
     htslib: the reference's fixtures), the chain of block_size fields per file otherwise (blocks cut at a fixed size: bamio's
-    writer) or when TBK_INDEX_CHAIN asks for it — the same tile every way, and the kernel that ran is the one expected"""
+    writer) or when the index_chain hook asks for it — the same tile every way, and the kernel that ran is the one expected"""
     from tiebrush_amd import bamio
     gold = [open(p, "rb").read() for p in sample_paths("t2")[:4] + [os.path.join(GOLDEN, "t12.bam")]]
     cut = []                                              # the same records in blocks of 0x1234 payload bytes: records span blocks
@@ -180,9 +172,9 @@ def test_record_index_by_member_and_by_chain(ctx, monkeypatch):
 
     fo_m, got_m, blob_m, kt_m = decode(gold)
     assert "bam_index" in kt_m and "bam_index_chain" not in kt_m         # htslib's blocks: no chain walked
-    monkeypatch.setenv("TBK_INDEX_CHAIN", "1")
+    tbk_debug(monkeypatch, index_chain=1)
     fo_c, got_c, blob_c, kt_c = decode(gold)
-    monkeypatch.delenv("TBK_INDEX_CHAIN")
+    tbk_debug(monkeypatch, index_chain=None)
     assert "bam_index_chain" in kt_c and np.array_equal(fo_m, fo_c) and blob_m == blob_c
     for name in fields:
         assert np.array_equal(got_m[name], got_c[name]), name

@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, sample_paths, compare_groups_to_golden_bam
+from helpers import GOLDEN, sample_paths, compare_groups_to_golden_bam, tbk_debug
 
 pytestmark = pytest.mark.gpu
 KEYS = ("rep", "yc", "yx", "yd", "g_start", "g_end", "rec_group")
@@ -69,13 +69,13 @@ def test_golden_clip_exon(ctx, name, strategy, bam_loader):
 def test_golden_t2_yd_machines(ctx, machine, bam_loader, monkeypatch):
     """golden t2 (its 64 tail-drop YDs among them) with every chain forced through yd_wave_k / through yd_lane_k"""
     from tiebrush_amd import soa
-    monkeypatch.setenv("TBK_YD_WAVE_MIN", "1" if machine == "wave" else str(1 << 30))
+    tbk_debug(monkeypatch, yd_wave_min="1" if machine == "wave" else str(1 << 30))
     bams = [bam_loader(p) for p in sample_paths("t2")]
     tile = soa.tile_from_bams(bams, with_names=True)
     gold = bam_loader(os.path.join(GOLDEN, "t2", "t2.bam"))
     got, _ = _check(ctx, tile, collapse_same=True)
     assert compare_groups_to_golden_bam(got, tile, bams, gold) == []
-    monkeypatch.setenv("TBK_PATH", "window")
+    tbk_debug(monkeypatch, path="window")
     got, _ = _check(ctx, tile)
     assert int(np.asarray(got["yd"]).max()) > 0
 
@@ -86,11 +86,11 @@ def test_yd_chain_buckets_with_several_chains_per_thread(ctx, bgrid, monkeypatch
     chain of the tile each thread takes many chains (at config 3's full size: 3.3 M chains for 1024 blocks); a deep synthetic
     tile against the oracle, default path and forced window path"""
     from tiebrush_amd import synth
-    monkeypatch.setenv("TBK_YD_BGRID", bgrid)
+    tbk_debug(monkeypatch, yd_bgrid=bgrid)
     tile = synth.make_tile(12, 20000, "c3", n_loci=60)
     got, _ = _check(ctx, tile, strategy="clip")
     assert int(np.asarray(got["yd"]).max()) > 0
-    monkeypatch.setenv("TBK_PATH", "window")
+    tbk_debug(monkeypatch, path="window")
     _check(ctx, tile, strategy="clip")
 
 
@@ -301,12 +301,12 @@ def test_collapse_same_is_decided_on_the_name_bytes(ctx, monkeypatch):
     base.qn = np.frombuffer(b"".join(names), np.uint8).copy()
     base.qname_hash = np.array([soa.qname_hash64(x, soa.pair_order(int(f))) for x, f in zip(names, base.flag)], np.uint64)
     _check(ctx, base, collapse_same=True)
-    monkeypatch.setenv("TBK_DEBUG_QHASH_MASK", "0x3")
+    tbk_debug(monkeypatch, qhash_mask="0x3")
     _check(ctx, base, collapse_same=True)
     _check(ctx, base, collapse_same=True, store_frac=True)
-    monkeypatch.setenv("TBK_DEBUG_QHASH_MASK", "0x0")                        # every hash equal: the bytes alone decide
+    tbk_debug(monkeypatch, qhash_mask="0x0")                        # every hash equal: the bytes alone decide
     _check(ctx, base, collapse_same=True)
-    monkeypatch.delenv("TBK_DEBUG_QHASH_MASK")
+    tbk_debug(monkeypatch, qhash_mask=None)
     # names are required with -A (no silent hash-only mode)
     from tiebrush_amd import api
     nameless = synth.make_tile(2, 500, "c2", n_loci=5)
@@ -322,7 +322,7 @@ def test_hash_collision_reseed_path(ctx, monkeypatch):
     from tiebrush_amd import api, synth
     # soft-clipped reads give distinct CIGARs with equal (start, end): xS..yS vs yS..xS
     tile = synth.make_tile(3, 60000, "c3", n_loci=20)
-    monkeypatch.setenv("TBK_DEBUG_HASH_MASK", "0xFFF")      # 12 hash bits: a few colliding pairs, seed dependent
+    tbk_debug(monkeypatch, hash_mask="0xFFF")      # 12 hash bits: a few colliding pairs, seed dependent
     seen_reseed = False
     for k in range(6):
         t = synth.make_tile(3, 6000, "c3", n_loci=8 + k)
@@ -332,11 +332,11 @@ def test_hash_collision_reseed_path(ctx, monkeypatch):
             assert e.status == -8                          # TBK_ECOLLISION after four seeds: loud, not wrong
             continue
         seen_reseed |= "reseeded" in ctx.last_message()
-    monkeypatch.setenv("TBK_DEBUG_HASH_MASK", "0x3")        # 2 bits: every seed collides
+    tbk_debug(monkeypatch, hash_mask="0x3")        # 2 bits: every seed collides
     with pytest.raises(api.TbkError) as ei:
         ctx.collapse(tile)
     assert ei.value.status == -8
-    monkeypatch.delenv("TBK_DEBUG_HASH_MASK")
+    tbk_debug(monkeypatch, hash_mask=None)
     _check(ctx, tile)
 
 
@@ -431,7 +431,7 @@ def test_device_chain_view_from_keys(ctx, profile, kw, okw, monkeypatch):
                 one = shape == 0x80000000
                 assert (ncig[one] <= 3).all() and (ncig[(shape >> 30) == 3] >= 3).all()
     # the view built from keys carries the results of tiecov's first pass (TBK_COV_PREP: run that pass anyway)
-    monkeypatch.setenv("TBK_COV_PREP", "1")
+    tbk_debug(monkeypatch, cov_prep="1")
     res = ctx.collapse(dt, want_key=True, **kw)
     covs["pass"] = api.to_numpy(ctx.coverage(ctx.groups_to_cov_in(res)))
     for k in ("iv_tid", "iv_start", "iv_end", "iv_val", "j_tid", "j_start", "j_end", "j_strand", "j_val"):

@@ -4,7 +4,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, bedgraph_lines, junction_lines, read_lines
+from helpers import GOLDEN, bedgraph_lines, junction_lines, read_lines, tbk_debug
 
 pytestmark = pytest.mark.gpu
 
@@ -51,15 +51,15 @@ def test_synthetic_collapsed(ctx, profile, n, bundles, monkeypatch):
     from oracle import oracle_ffi as orc
     from tiebrush_amd import synth
     if bundles == "scan":
-        monkeypatch.setenv("TBK_COV_BUNDLE_SCAN", "1")
+        tbk_debug(monkeypatch, cov_bundle_scan="1")
     elif bundles == "legacy":
-        monkeypatch.setenv("TBK_COV_LEGACY", "1")
+        tbk_debug(monkeypatch, cov_legacy="1")
     elif bundles == "refused":
-        monkeypatch.setenv("TBK_COV_TILE_CAP", "3")
+        tbk_debug(monkeypatch, cov_tile_cap="3")
     elif bundles == "junc_radix":          # junctions: the global radix sort instead of the per-home LDS sorts
-        monkeypatch.setenv("TBK_JUNC_RADIX", "1")
+        tbk_debug(monkeypatch, junc_radix="1")
     elif bundles == "junc_overflow":       # ... and a home block with more items than its sort takes: the radix path takes over
-        monkeypatch.setenv("TBK_JH_CAP", "2")
+        tbk_debug(monkeypatch, jh_cap="2")
     tile = synth.make_tile(3, n, profile, n_loci=3000)
     groups = orc.collapse(tile)
     cin = synth.collapsed_to_cov_input(tile, groups)
@@ -71,7 +71,7 @@ def test_uncollapsed_deep(ctx, chain, monkeypatch):
     """raw (uncollapsed) reads: deep pile-ups, YC absent -> 1.0"""
     from tiebrush_amd import synth, soa
     if chain == "legacy":
-        monkeypatch.setenv("TBK_COV_LEGACY", "1")
+        tbk_debug(monkeypatch, cov_legacy="1")
     tile = synth.make_tile(1, 200000, "c2", n_loci=50)
     cin = soa.CovInput(tid=tile.tid, pos=tile.pos, flag=tile.flag, cig_off=tile.cig_off, cig=tile.cig,
                        yc=np.ones(tile.n_records), strand=tile.strand)
@@ -83,7 +83,7 @@ def test_edge_cases(ctx, chain, monkeypatch):
     from tiebrush_amd import soa
     M, I, D, N, S = 0, 1, 2, 3, 4
     if chain == "legacy":
-        monkeypatch.setenv("TBK_COV_LEGACY", "1")
+        tbk_debug(monkeypatch, cov_legacy="1")
 
     def mk(recs):
         tid = np.array([r[0] for r in recs], np.int32)

@@ -5,6 +5,8 @@ tiles take the numpy restatement of the device steps around the HIP collapse; de
 import numpy as np
 import pytest
 
+from helpers import tbk_debug
+
 from dist_helpers import split_tile, check_against_flat, STRAT
 
 pytestmark = pytest.mark.gpu
@@ -95,7 +97,7 @@ def test_loopback_device_resident_equals_flat_oracle(world, nfiles, profile, str
     if path:
         monkeypatch.setenv("TBK_PARTIAL_REDUCE", "0")
         if path.endswith("window"):
-            monkeypatch.setenv("TBK_PATH", "window")
+            tbk_debug(monkeypatch, path="window")
     import torch
     from oracle import oracle_ffi as orc
     from tiebrush_amd import api, dist, synth
@@ -152,7 +154,7 @@ def test_loopback_8_ranks_32x200k_per_rank(strategy, kw, general, monkeypatch):
     check_against_flat(res, tile, flat, flat_cov)
 
 
-def test_part_form_refuses_what_it_cannot_hold():
+def test_part_form_refuses_what_it_cannot_hold(monkeypatch):
     """a partial tile with a fractional carried YC under TBK_PATH=window: the PART kernels raise TBK_DERR_FRACTIONAL and the tile
     takes the sort path's ordered sums — the result is the oracle's"""
     import os
@@ -170,14 +172,12 @@ def test_part_form_refuses_what_it_cannot_hold():
     from dist_helpers import OracleCompute
     want = OracleCompute().collapse(tile, strategy="clip")
     ctx = api.Context(0)
-    os.environ["TBK_PATH"] = "window"
-    try:
-        got = api.to_numpy(ctx.collapse(api.to_device(tile, "cuda:0"), strategy="clip"))
-        tile.yc_in = np.rint(tile.yc_in * 4.0)                     # integral: the PART form holds it
-        want2 = OracleCompute().collapse(tile, strategy="clip")
-        got2 = api.to_numpy(ctx.collapse(api.to_device(tile, "cuda:0"), strategy="clip"))
-    finally:
-        del os.environ["TBK_PATH"]
+    tbk_debug(monkeypatch, path="window")
+    got = api.to_numpy(ctx.collapse(api.to_device(tile, "cuda:0"), strategy="clip"))
+    tile.yc_in = np.rint(tile.yc_in * 4.0)                     # integral: the PART form holds it
+    want2 = OracleCompute().collapse(tile, strategy="clip")
+    got2 = api.to_numpy(ctx.collapse(api.to_device(tile, "cuda:0"), strategy="clip"))
+    tbk_debug(monkeypatch, path=None)
     for g, w in ((got, want), (got2, want2)):
         assert g["n_groups"] == w["n_groups"]
         for k in ("rep", "yc", "yx", "yd", "g_start", "g_end"):
@@ -312,15 +312,15 @@ def test_partial_reduce_refuses_a_shared_hashed_key_word(monkeypatch):
     ctx = api.Context(0)
     for mask, refuse in ((None, False), ("0", True)):
         if mask is not None:
-            monkeypatch.setenv("TBK_DEBUG_HASH_MASK", mask)
+            tbk_debug(monkeypatch, hash_mask=mask)
         rows_all, cig_all, cnt = [], [], []
         for r in range(2):
             dt = api.to_device(tiles[r], "cuda:0")
-            monkeypatch.delenv("TBK_DEBUG_HASH_MASK", raising=False)
+            tbk_debug(monkeypatch, hash_mask=None)
             fin = ctx.collapse(dt, want_coords=True, want_effend=True)
             key = ctx.partial_keys(dt, fin)[0]
             if mask is not None:
-                monkeypatch.setenv("TBK_DEBUG_HASH_MASK", mask)
+                tbk_debug(monkeypatch, hash_mask=mask)
             rows, cigw, tab = ctx.partial_pack(dt, fin, key, None, 1, first[r])
             th = tab.cpu().numpy()
             rows_all.append(rows.clone())
@@ -336,7 +336,7 @@ def test_partial_reduce_refuses_a_shared_hashed_key_word(monkeypatch):
             assert got["n_groups"] == 3 and got["yc"].cpu().numpy().tolist() == [2.0, 1.0, 2.0]
     # the driver: packed with the masked word, refused by the merge-reduce, reduced by the general path (whose own keys the mask
     # does not make exact either: it reseeds until the two alignments part, or gives up loudly) — here the mask is lifted for it
-    monkeypatch.delenv("TBK_DEBUG_HASH_MASK")
+    tbk_debug(monkeypatch, hash_mask=None)
     dtiles = [api.to_device(t, "cuda:0") for t in tiles]
     res = dist.run_loopback(DeviceCompute(), dtiles, first, want_coverage=False, device_chain=True)
     for r in res:

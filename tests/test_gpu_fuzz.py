@@ -5,6 +5,8 @@ group ties, the comparator order and the representative rule are exercised const
 import numpy as np
 import pytest
 
+from helpers import tbk_debug
+
 pytestmark = pytest.mark.gpu
 
 M, I, D, N, S, H, P, EQ, X = 0, 1, 2, 3, 4, 5, 6, 7, 8
@@ -194,7 +196,7 @@ def test_fuzz_yd_long_chains(ctx, seed, machine, monkeypatch):
     items, spliced reads landing in / beyond existing nodes, insertions, swallows and island restarts, against the literal
     GSegList of the oracle.  TBK_YD_WAVE_MIN sends every chain to one machine or the other."""
     if machine != "default":
-        monkeypatch.setenv("TBK_YD_WAVE_MIN", "1" if machine == "wave" else str(1 << 30))
+        tbk_debug(monkeypatch, yd_wave_min="1" if machine == "wave" else str(1 << 30))
     rng = np.random.default_rng(9000 + seed)
     span = int(rng.choice([600, 2000, 6000]))
     introns = []
@@ -284,7 +286,7 @@ def _spliced_region_tile(rng, n_files, n_regions):
 @pytest.mark.parametrize("seed", range(6))
 def test_fuzz_yd_spliced_regions(ctx, seed, machine, monkeypatch):
     if machine != "default":
-        monkeypatch.setenv("TBK_YD_WAVE_MIN", "1" if machine == "wave" else str(1 << 30))
+        tbk_debug(monkeypatch, yd_wave_min="1" if machine == "wave" else str(1 << 30))
     rng = np.random.default_rng(9500 + seed)
     tile = _spliced_region_tile(rng, int(rng.integers(1, 3)), 60)
     want = _cmp(ctx, tile, strategy="cigar")
@@ -295,7 +297,7 @@ def test_fuzz_yd_spliced_regions(ctx, seed, machine, monkeypatch):
 def test_fuzz_collapse_forced_run_sort(ctx, seed, monkeypatch):
     """The run-merge sort (and the sync-free 'lean' flow that goes with it) normally serves large tiles only; force it on
     the small adversarial tiles too: odd file counts, empty files, every strategy, buckets that tie on everything."""
-    monkeypatch.setenv("TBK_SORT", "runs")
+    tbk_debug(monkeypatch, sort="runs")
     rng = np.random.default_rng(7000 + seed)
     for _ in range(10):
         tile = _rand_tile(rng, with_tb=bool(seed % 2))
@@ -306,5 +308,5 @@ def test_fuzz_collapse_forced_run_sort(ctx, seed, monkeypatch):
         _cmp(ctx, tile, strategy=str(rng.choice(STRATS)), collapse_same=True, keep_secondary=True)
         _cmp(ctx, tile, strategy=str(rng.choice(STRATS)), store_frac=True, keep_secondary=True,
              collapse_same=bool(rng.random() < 0.5))
-    monkeypatch.setenv("TBK_SORT", "radix")
+    tbk_debug(monkeypatch, sort="radix")
     _cmp(ctx, _rand_tile(rng), strategy="cigar")

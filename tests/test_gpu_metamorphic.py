@@ -4,6 +4,8 @@ tiles, through the window path and the sort path, each compared with the HIP pat
 import numpy as np
 import pytest
 
+from helpers import tbk_debug
+
 import metamorphic as mm
 
 pytestmark = pytest.mark.gpu
@@ -30,9 +32,9 @@ def _same(a, b):
 
 
 def _paths(monkeypatch, path):
-    monkeypatch.delenv("TBK_PATH", raising=False)
+    tbk_debug(monkeypatch, path=None)
     if path != "auto":
-        monkeypatch.setenv("TBK_PATH", path)
+        tbk_debug(monkeypatch, path=path)
 
 
 @pytest.mark.parametrize("path", ["auto", "window", "sort"])

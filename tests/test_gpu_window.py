@@ -6,6 +6,8 @@ chunks), unmapped records inside and behind the files, inputs the raw form hands
 import numpy as np
 import pytest
 
+from helpers import tbk_debug
+
 from test_gpu_fuzz import STRATS, _cmp, _rand_tile
 
 pytestmark = pytest.mark.gpu
@@ -25,10 +27,10 @@ def ctx():
 def window_mode(request, monkeypatch):
     """raw: the records whose key word is hashed are listed per window for the verification pass; raw-dense-verify: they are
     marked in a per-record array instead (TBK_WG_DENSE_VERIFY, the form -L and the record -> group map always take)"""
-    monkeypatch.setenv("TBK_PATH", "window")
-    monkeypatch.setenv("TBK_RAW", "1" if request.param == "dense" else request.param)
+    tbk_debug(monkeypatch, path="window")
+    tbk_debug(monkeypatch, raw="1" if request.param == "dense" else request.param)
     if request.param == "dense":
-        monkeypatch.setenv("TBK_WG_DENSE_VERIFY", "1")
+        tbk_debug(monkeypatch, wg_dense_verify="1")
     return request.param
 
 
@@ -67,7 +69,7 @@ def test_ranking_by_buckets_and_by_merge_sort(ctx, window_mode, rank, monkeypatc
     whose windows hold more than 512 groups (two groups per thread)"""
     from tiebrush_amd import synth
     if rank == "merge":
-        monkeypatch.setenv("TBK_WG_RANK_MERGE", "1")
+        tbk_debug(monkeypatch, wg_rank_merge="1")
     rng = np.random.default_rng(77)
     for files, reads, profile, kw in ((8, 20000, "c3", dict(strategy="clip")), (2, 60000, "c2", dict()), (40, 3000, "c5", dict(strategy="exon"))):
         _cmp(ctx, synth.make_tile(files, reads, profile, n_loci=60), **kw)
@@ -85,16 +87,14 @@ def test_ranking_by_buckets_and_by_merge_sort(ctx, window_mode, rank, monkeypatc
     _cmp(ctx, _tile(recs))
 
 
-@pytest.mark.parametrize("split", ["by_list", "by_list_fat_items", "radix"])
+@pytest.mark.parametrize("split", ["by_list", "radix"])
 def test_yd_items_by_list_and_by_radix_split(ctx, window_mode, split, monkeypatch):
     """the YD items of the window path reach their lists without a sort (<= 64 files: bit-matrix ranks, yd_lcount_k /
     yd_lscatter_k) or through the stable radix split (more files; TBK_YD_RADIX forces it): both against the oracle — '.' strands
     feeding two lists, 64 files (every list in use), tiles of more than one 1024-group block, empty lists"""
     from tiebrush_amd import synth
     if split == "radix":
-        monkeypatch.setenv("TBK_YD_RADIX", "1")
-    if split == "by_list_fat_items":                     # (the items placed by list are 16 bytes — (start, end), exon count, group —; the hook keeps the 24)
-        monkeypatch.setenv("TBK_YD_FAT_ITEMS", "1")
+        tbk_debug(monkeypatch, yd_radix="1")
     for files, reads, profile, kw in ((64, 1500, "c3", dict(strategy="clip")), (3, 40000, "c2", dict()), (33, 2500, "c5", dict(strategy="exon"))):
         tile = synth.make_tile(files, reads, profile, n_loci=300)
         tile.strand = tile.strand.copy()
@@ -172,3 +172,30 @@ def test_exact_key_codes(ctx, window_mode):
     recs.append((0, 500, 0, 60, "+", 1, [(3, S), (10, M), (100, N), (2_999_890, M), (2, S)]))
     for strat in STRATS[0:1] + STRATS[2:]:
         _cmp(ctx, _tile([recs, list(reversed(recs))]), strategy=strat)
+
+
+def test_debug_hooks_reach_a_live_context(monkeypatch):
+    """TBK_DEBUG is read when a context is created; this binding forwards a later change through tbk_set_debug: a small tile takes the
+    sort path, the window kernels under path=window, the sort path again once the key is gone — seen in the kernels that ran"""
+    from tiebrush_amd import api, synth
+    tile = synth.make_tile(3, 4000, "c2", n_loci=50)
+    c = api.Context(0)
+    c.set_profiling(True)
+
+    def kernels():
+        c.collapse(tile)
+        return set(c.kernel_times())
+
+    assert not any(k.startswith("wg_") for k in kernels())
+    tbk_debug(monkeypatch, path="window")
+    assert any(k.startswith("wg_hash") for k in kernels())
+    tbk_debug(monkeypatch, path=None)
+    assert not any(k.startswith("wg_") for k in kernels())
+    c2 = api.Context(0)                              # a context created while the variable is set starts with it
+    tbk_debug(monkeypatch, path="window")
+    c3 = api.Context(0)
+    c3.set_profiling(True)
+    c3.collapse(tile)
+    assert any(k.startswith("wg_hash") for k in c3.kernel_times())
+    for x in (c, c2, c3):
+        x.close()

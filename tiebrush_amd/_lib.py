@@ -23,7 +23,7 @@ STATUS = {0: "TBK_OK", -1: "TBK_EINVAL", -2: "TBK_ENOMEM", -3: "TBK_EHIP", -4: "
 
 # every symbol include/tbk.h declares
 SYMBOLS = ["tbk_abi_version", "tbk_create", "tbk_destroy", "tbk_strerror", "tbk_last_error", "tbk_set_stream",
-           "tbk_get_stream", "tbk_set_profiling", "tbk_kernel_times", "tbk_host_alloc", "tbk_host_free",
+           "tbk_get_stream", "tbk_set_profiling", "tbk_set_debug", "tbk_kernel_times", "tbk_host_alloc", "tbk_host_free",
            "tbk_collapse_opts_default", "tbk_collapse_tile", "tbk_collapse_finish_yd", "tbk_coverage_tile", "tbk_sample_tile",
            "tbk_groups_to_cov_in", "tbk_bgzf_inflate", "tbk_bam_decode", "tbk_bam_records", "tbk_bam_release", "tbk_shard_prepare", "tbk_shard_probe_max", "tbk_shard_probe_next",
            "tbk_shard_pack", "tbk_shard_unpack", "tbk_partial_keys", "tbk_partial_pack", "tbk_partial_unpack", "tbk_partial_reduce", "tbk_unpack_tile", "tbk_tile_join", "tbk_reserve_tile", "tbk_bgzf_deflate", "tbk_bam_encode", "tbk_partial_stage_keys", "tbk_partial_stage_cands", "tbk_partial_stage_pack"]
@@ -113,6 +113,7 @@ def load():
     L.tbk_get_stream.argtypes = [_P]
     L.tbk_get_stream.restype = _P
     L.tbk_set_profiling.argtypes = [_P, C.c_int]
+    L.tbk_set_debug.argtypes = [_P, C.c_char_p]
     L.tbk_kernel_times.argtypes = [_P, C.POINTER(KernelTime), C.c_int]
     L.tbk_host_alloc.argtypes = [C.c_size_t, C.POINTER(_P)]
     L.tbk_host_free.argtypes = [_P]

@@ -9,6 +9,7 @@ place, resident in HBM).  torch is plumbing only: device memory + streams.
 from __future__ import annotations
 
 import contextlib
+import os
 import ctypes as C
 from dataclasses import replace
 
@@ -103,20 +104,47 @@ class DeviceCovView:
         self.n_cigar_ops = n_cigar_ops
 
 
+class _FollowDebug:
+    """The library reads TBK_DEBUG once, when a context is created (tbk_create).  This binding is what the tests drive, and a test changes
+    the variable between two calls on one context: before a call goes out, the context is told (tbk_set_debug) when the variable has
+    changed since the last one."""
+
+    def __init__(self, lib, ctx):
+        self._lib, self._ctx = lib, ctx
+
+    def __getattr__(self, name):
+        self._ctx._follow_debug()
+        return getattr(self._lib, name)
+
+
 class Context:
     def __init__(self, device: int = 0):
-        self.L = _lib.load()
+        lib = _lib.load()
         h = C.c_void_p()
-        rc = self.L.tbk_create(int(device), C.byref(h))
+        self._debug_spec = os.environ.get("TBK_DEBUG", "")
+        rc = lib.tbk_create(int(device), C.byref(h))
         if rc != 0:
             raise TbkError(rc, "tbk_create(device=%d)" % device)
+        self._lib = lib
+        self.L = _FollowDebug(lib, self)
         self.h = h
         self.device = device
         self._on_torch_stream = False
 
+    def _follow_debug(self):
+        spec = os.environ.get("TBK_DEBUG", "")
+        if spec != self._debug_spec and getattr(self, "h", None):
+            self._debug_spec = spec
+            self._lib.tbk_set_debug(self.h, spec.encode())
+
+    def set_debug(self, spec: str):
+        """tbk_set_debug: test hooks / forced paths of this context ("key=value,..."; "" = the defaults)"""
+        self._debug_spec = os.environ.get("TBK_DEBUG", "")      # (an explicit setting stays until the variable changes again)
+        self._check(self._lib.tbk_set_debug(self.h, spec.encode()), "tbk_set_debug")
+
     def close(self):
         if getattr(self, "h", None):
-            self.L.tbk_destroy(self.h)
+            self._lib.tbk_destroy(self.h)
             self.h = None
 
     def __del__(self):

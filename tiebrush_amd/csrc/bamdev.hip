@@ -2,9 +2,9 @@
 // host (/root/reference/src/GSam.h:506-516, htslib bgzf_read_block + bam_read1) done for whole files at once on the device.
 //
 //   tbk_bam_decode    compressed BGZF members of k files (host memory) -> device-resident SoA tile (tbk_soa_in, TBK_MEM_DEVICE)
-//     bgz_inflate_k     one lane per BGZF member (members are independent raw-deflate streams of <= 64 KiB): RFC 1951 decoder
-//                       with canonical-code tables in LDS (count per length + symbols in code order), byte-exact LZ77 window
-//                       in the member's own output; CRC32 and ISIZE of every member are verified like htslib does
+//     bgz_inflate_wave_k  one wave per BGZF member (members are independent raw-deflate streams of <= 64 KiB): RFC 1951 decoder
+//                       with multi-bit tables in LDS, the last 8 KiB of output in an LDS ring; bgz_crc_k: CRC32 and ISIZE of every
+//                       member are verified like htslib does
 //     bam_index_k       one workgroup per file walks the record chain (block_size -> next record) through LDS-staged chunks
 //     bam_fields_k      one thread per record: core fields, the aux scan of the host loader (NH, XS / ts -> spliceStrand,
 //                       carried YC / YX / YD of TieBrush-merged inputs, MD and QNAME sizes), field-length validation
@@ -28,7 +28,6 @@ namespace {
 
 // ---- RFC 1951 inflate, one lane per member ------------------------------------------------------------------------
 constexpr int INF_NT = 64;           // one wave per block: 64 members
-constexpr int INF_TAB = 16 + 288 + 16 + 32;  // u16 per lane: lencnt[16] lensym[288] distcnt[16] distsym[32]
 
 struct BitIn {
   const uint8_t* p;
@@ -56,10 +55,6 @@ struct BitIn {
   __device__ __forceinline__ bool overrun() const { return p > end + 8; }
 };
 
-__constant__ uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__constant__ uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__constant__ uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__constant__ uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __constant__ uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 // canonical Huffman table from code lengths (puff.c's construct): cnt[len] = codes of that length, sym = symbols in code
@@ -111,255 +106,6 @@ struct BgzMember {
   uint32_t crc;   // CRC32 of the payload
   uint32_t file;
 };
-
-__global__ __launch_bounds__(INF_NT) void bgz_inflate_k(uint32_t nmem, const BgzMember* __restrict__ mem, const uint8_t* __restrict__ src,
-                                                        uint8_t* __restrict__ dst, uint32_t flags, unsigned long long* __restrict__ dbg, uint32_t* __restrict__ err) {
-  __shared__ uint16_t tab[INF_NT * INF_TAB];
-  __shared__ uint32_t crct[4][256];
-  for (uint32_t i = threadIdx.x; i < 256; i += INF_NT) {  // CRC-32 (IEEE, reflected), slicing-by-4 tables
-    uint32_t c = i;
-    for (int k = 0; k < 8; ++k) c = (c & 1u) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
-    crct[0][i] = c;
-  }
-  __syncthreads();
-  for (uint32_t i = threadIdx.x; i < 256; i += INF_NT) {
-    uint32_t c = crct[0][i];
-    for (int t = 1; t < 4; ++t) {
-      c = crct[0][c & 0xFFu] ^ (c >> 8);
-      crct[t][i] = c;
-    }
-  }
-  __syncthreads();
-  const uint32_t m = blockIdx.x * INF_NT + threadIdx.x;
-  if (m >= nmem) return;
-  const BgzMember M = mem[m];
-  uint16_t* lencnt = tab + threadIdx.x * INF_TAB;
-  uint16_t* lensym = lencnt + 16;
-  uint16_t* distcnt = lensym + 288;
-  uint16_t* distsym = distcnt + 16;
-  BitIn in;
-  in.p = src + M.src;
-  in.end = in.p + M.clen;
-  in.buf = 0;
-  in.cnt = 0;
-  in.bad = false;
-  uint8_t* out = dst + M.dst;
-  uint32_t o = 0;
-  const uint32_t cap = M.isize;
-  bool bad = false;
-  unsigned long long t_build = 0, t_dec = 0, t_copy = 0, t_lit = 0, n_sym = 0, n_copy = 0, t_all = __builtin_readcyclecounter();
-  for (;;) {
-    const uint32_t last = in.bits(1);
-    const uint32_t type = in.bits(2);
-    if (type == 0) {  // stored
-      in.buf >>= (in.cnt & 7);
-      in.cnt -= (in.cnt & 7);
-      const uint32_t len = in.bits(16), nlen = in.bits(16);
-      if ((len ^ 0xFFFFu) != nlen || o + len > cap) {
-        bad = true;
-        break;
-      }
-      for (uint32_t i = 0; i < len; ++i) out[o++] = (uint8_t)in.bits(8);
-      if (in.overrun()) {  // a stored block cut off by the end of the member (zeros flowed in)
-        bad = true;
-        break;
-      }
-    } else if (type == 3) {
-      bad = true;
-      break;
-    } else {
-      unsigned long long tb0 = __builtin_readcyclecounter();
-      if (type == 1) {  // fixed codes
-        uint8_t lens[288];
-        for (int s = 0; s < 144; ++s) lens[s] = 8;
-        for (int s = 144; s < 256; ++s) lens[s] = 9;
-        for (int s = 256; s < 280; ++s) lens[s] = 7;
-        for (int s = 280; s < 288; ++s) lens[s] = 8;
-        huff_build(lencnt, lensym, lens, 288);
-        for (int s = 0; s < 30; ++s) lens[s] = 5;
-        huff_build(distcnt, distsym, lens, 30);
-      } else {  // dynamic codes
-        const int nlen = (int)in.bits(5) + 257, ndist = (int)in.bits(5) + 1, ncode = (int)in.bits(4) + 4;
-        if (nlen > 286 || ndist > 30) {
-          bad = true;
-          break;
-        }
-        uint8_t lens[320];
-        for (int i = 0; i < 19; ++i) lens[i] = 0;
-        for (int i = 0; i < ncode; ++i) lens[kClOrder[i]] = (uint8_t)in.bits(3);
-        if (huff_build(lencnt, lensym, lens, 19) != 0) {  // the code-length code must be complete
-          bad = true;
-          break;
-        }
-        int idx = 0;
-        while (idx < nlen + ndist) {
-          int sym = huff_decode(in, lencnt, lensym);
-          if (sym < 0) {
-            bad = true;
-            break;
-          }
-          if (sym < 16) {
-            lens[idx++] = (uint8_t)sym;
-          } else {
-            int rep, val = 0;
-            if (sym == 16) {
-              if (idx == 0) {
-                bad = true;
-                break;
-              }
-              val = lens[idx - 1];
-              rep = 3 + (int)in.bits(2);
-            } else if (sym == 17) {
-              rep = 3 + (int)in.bits(3);
-            } else {
-              rep = 11 + (int)in.bits(7);
-            }
-            if (idx + rep > nlen + ndist) {
-              bad = true;
-              break;
-            }
-            while (rep--) lens[idx++] = (uint8_t)val;
-          }
-        }
-        if (bad) break;
-        if (lens[256] == 0) {  // no end-of-block code
-          bad = true;
-          break;
-        }
-        int e = huff_build(lencnt, lensym, lens, nlen);
-        if (e < 0 || (e > 0 && nlen - lencnt[0] != 1)) {  // over-subscribed, or incomplete with more than one code
-          bad = true;
-          break;
-        }
-        e = huff_build(distcnt, distsym, lens + nlen, ndist);
-        if (e < 0 || (e > 0 && ndist - distcnt[0] != 1)) {
-          bad = true;
-          break;
-        }
-      }
-      t_build += __builtin_readcyclecounter() - tb0;
-      // decode literals and length / distance pairs
-      for (;;) {
-        unsigned long long td0 = __builtin_readcyclecounter();
-        int sym = huff_decode(in, lencnt, lensym);
-        t_dec += __builtin_readcyclecounter() - td0;
-        ++n_sym;
-        if (sym < 0 || in.overrun()) {
-          bad = true;
-          break;
-        }
-        if (sym < 256) {
-          if (o >= cap) {
-            bad = true;
-            break;
-          }
-          out[o++] = (uint8_t)sym;
-        } else if (sym == 256) {
-          break;
-        } else {
-          sym -= 257;
-          if (sym >= 29) {
-            bad = true;
-            break;
-          }
-          const uint32_t len = kLenBase[sym] + in.bits(kLenExtra[sym]);
-          const int ds = huff_decode(in, distcnt, distsym);
-          if (ds < 0 || ds >= 30) {
-            bad = true;
-            break;
-          }
-          const uint32_t dist = kDistBase[ds] + in.bits(kDistExtra[ds]);
-          if (dist > o || o + len > cap) {
-            bad = true;
-            break;
-          }
-          unsigned long long tc0 = __builtin_readcyclecounter();
-          ++n_copy;
-          // LZ77 copy.  A byte-by-byte loop makes every load wait for the store before it (the ranges may overlap), ~1 us per
-          // byte; instead up to 16 source bytes are loaded together (independent loads) and then stored.  With dist < 16 the
-          // source repeats with period dist: the chunk is built from the first `dist` bytes.
-          if (dist >= 16) {
-            uint32_t i = 0;
-            while (i < len) {
-              const uint32_t nb = len - i < 16u ? len - i : 16u;
-              const uint32_t lim = dist < nb ? dist : nb;  // bytes that exist before this chunk is written (dist >= 16 >= nb here)
-              uint8_t b[16];
-#pragma unroll
-              for (int q = 0; q < 16; ++q) b[q] = (uint32_t)q < lim ? out[o - dist + q] : 0;
-#pragma unroll
-              for (int q = 0; q < 16; ++q)
-                if ((uint32_t)q < nb) out[o + q] = b[q];
-              o += nb;
-              i += nb;
-            }
-          } else {
-            uint8_t pat[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) pat[q] = (uint32_t)q < dist ? out[o - dist + q] : 0;
-            // expand the period to 16 bytes: b[q] = pat[q % dist]
-            uint8_t b[16];
-            uint32_t r = 0;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-              uint8_t v = 0;
-#pragma unroll
-              for (int z = 0; z < 16; ++z) v = (uint32_t)z == r ? pat[z] : v;
-              b[q] = v;
-              r = r + 1 == dist ? 0u : r + 1;
-            }
-            const uint32_t step = (16u / dist) * dist;  // whole periods per chunk: the pattern phase stays 0
-            uint32_t i = 0;
-            while (i < len) {
-              const uint32_t nb = len - i < step ? len - i : step;
-#pragma unroll
-              for (int q = 0; q < 16; ++q)
-                if ((uint32_t)q < nb) out[o + q] = b[q];
-              o += nb;
-              i += nb;
-            }
-          }
-          t_copy += __builtin_readcyclecounter() - tc0;
-        }
-      }
-      if (bad) break;
-    }
-    if (last) break;
-    if (in.overrun()) {
-      bad = true;
-      break;
-    }
-  }
-  if (dbg && m == 0) {
-    dbg[0] = __builtin_readcyclecounter() - t_all;
-    dbg[1] = t_build;
-    dbg[2] = t_dec;
-    dbg[3] = t_copy;
-    dbg[4] = n_sym;
-    dbg[5] = n_copy;
-  }
-  if (!bad && o != cap) bad = true;
-  if (!bad && !(flags & 1u)) {  // the member's CRC32 covers the payload (RFC 1952): htslib rejects a mismatch, so do we
-    uint32_t c = 0xFFFFFFFFu;
-    uint32_t i = 0;
-    for (; i < cap && ((uintptr_t)(out + i) & 3u); ++i) c = crct[0][(c ^ out[i]) & 0xFFu] ^ (c >> 8);
-    for (; i + 16 <= cap; i += 16) {  // four aligned words per round: the loads are issued together
-      const uint32_t* w = reinterpret_cast<const uint32_t*>(out + i);
-      const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
-      uint32_t x = c ^ w0;
-      c = crct[3][x & 0xFFu] ^ crct[2][(x >> 8) & 0xFFu] ^ crct[1][(x >> 16) & 0xFFu] ^ crct[0][x >> 24];
-      x = c ^ w1;
-      c = crct[3][x & 0xFFu] ^ crct[2][(x >> 8) & 0xFFu] ^ crct[1][(x >> 16) & 0xFFu] ^ crct[0][x >> 24];
-      x = c ^ w2;
-      c = crct[3][x & 0xFFu] ^ crct[2][(x >> 8) & 0xFFu] ^ crct[1][(x >> 16) & 0xFFu] ^ crct[0][x >> 24];
-      x = c ^ w3;
-      c = crct[3][x & 0xFFu] ^ crct[2][(x >> 8) & 0xFFu] ^ crct[1][(x >> 16) & 0xFFu] ^ crct[0][x >> 24];
-    }
-    for (; i < cap; ++i) c = crct[0][(c ^ out[i]) & 0xFFu] ^ (c >> 8);
-    if ((c ^ 0xFFFFFFFFu) != M.crc) bad = true;
-  }
-  if (bad) atomicOr(err, 1u);
-}
-
 
 // ---- RFC 1951 inflate, one WAVE per member (round 4) ----------------------------------------------------------------------------
 // The lane-per-member kernel above runs 64 different decoders in lock step: every branch of every decoder is executed by the whole
@@ -756,19 +502,11 @@ __global__ __launch_bounds__(INF_NT) void bgz_crc_k(uint32_t nmem, const BgzMemb
   if ((c ^ 0xFFFFFFFFu) != M.crc) atomicOr(err, 1u);
 }
 
-// which inflate: the wave-per-member kernel + the CRC pass, or (TBK_INFLATE_LANE: test hook) the lane-per-member kernel.  On the 32 M
-// records with SEQ / QUAL of tools/scratch/dd2_r4.sh (7.6 GB inflated): lane per member 664 ms; wave per member 694 ms as first
-// written, 605 + 4 ms since a match is copied without barriers (one wave: its LDS instructions execute in order) and the codes'
-// base and extra bits come from arithmetic instead of tables in constant memory.  Still ~ 900 cycles a symbol: four waves per CU
-// (39 KB of LDS each) and a serial decode.
-static int bgz_inflate_launch(tbk_ctx* ctx, uint32_t nmem, const BgzMember* d_mt, const uint8_t* d_comp, uint8_t* d_out, uint32_t flags,
-                              unsigned long long* d_dbg) {
-  if (getenv("TBK_INFLATE_LANE")) {
-    TBK_LAUNCH(ctx, "bgz_inflate", bgz_inflate_k, cdiv(nmem, INF_NT), INF_NT, 0, nmem, d_mt, d_comp, d_out, flags, d_dbg, ctx->d_err);
-    return 0;
-  }
+// the inflate: a wave per member, then the CRC pass (a lane per member).  (Rounds 3 - 4 also kept a lane-per-member decoder — 64
+// different decoders in lock step —: 664 ms for the 7.6 GB of tools/scratch/dd2_r4.sh against 274 ms; it lives in the history.)
+static int bgz_inflate_launch(tbk_ctx* ctx, uint32_t nmem, const BgzMember* d_mt, const uint8_t* d_comp, uint8_t* d_out) {
   TBK_LAUNCH(ctx, "bgz_inflate", bgz_inflate_wave_k, nmem, 64, 0, nmem, d_mt, d_comp, d_out, ctx->d_err);
-  if (!(flags & 1u)) TBK_LAUNCH(ctx, "bgz_crc", bgz_crc_k, cdiv(nmem, INF_NT), INF_NT, 0, nmem, d_mt, d_out, ctx->d_err);
+  TBK_LAUNCH(ctx, "bgz_crc", bgz_crc_k, cdiv(nmem, INF_NT), INF_NT, 0, nmem, d_mt, d_out, ctx->d_err);
   return 0;
 }
 
@@ -819,18 +557,12 @@ extern "C" int tbk_bgzf_inflate(tbk_ctx* ctx, const uint8_t* comp, uint64_t comp
   if (!d_comp || !d_mt || !d_out) return TBK_ENOMEM;
   TBK_HIP(hipMemcpyAsync(d_comp, comp, comp_bytes, hipMemcpyHostToDevice, ctx->stream));
   TBK_HIP(hipMemcpyAsync(d_mt, mt.data(), mt.size() * sizeof(BgzMember), hipMemcpyHostToDevice, ctx->stream));
-  unsigned long long* d_dbg = getenv("TBK_INF_DEBUG") ? ws_alloc<unsigned long long>(ctx, 8) : nullptr;
   TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
-  TBK_TRY(bgz_inflate_launch(ctx, (uint32_t)mt.size(), d_mt, d_comp, d_out, (uint32_t)(getenv("TBK_INF_FLAGS") ? atoi(getenv("TBK_INF_FLAGS")) : 0), d_dbg));
+  TBK_TRY(bgz_inflate_launch(ctx, (uint32_t)mt.size(), d_mt, d_comp, d_out));
   if (mem != TBK_MEM_DEVICE) TBK_HIP(hipMemcpyAsync(out, d_out, total, hipMemcpyDeviceToHost, ctx->stream));
   uint32_t eb = 0;
   TBK_TRY(tbk_sync_err(ctx, &eb));  // (also waits for the member table upload: `mt` dies with this frame)
   tbk_prof_end_call(ctx);
-  if (d_dbg) {
-    unsigned long long h[8];
-    (void)hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost);
-    fprintf(stderr, "inflate member 0: cycles %llu build %llu decode %llu copy %llu symbols %llu copies %llu\n", h[0], h[1], h[2], h[3], h[4], h[5]);
-  }
   if (eb) {
     ctx->last_error = "corrupt BGZF member (deflate stream, ISIZE or CRC32)";
     return TBK_EINVAL;
@@ -1507,7 +1239,7 @@ extern "C" int tbk_bam_decode(tbk_ctx* ctx, uint32_t n_files, const uint8_t* con
       TBK_TRY(staged_upload(ctx, chunks));
       size_t m1 = m0;
       while (m1 < mt.size() && mt[m1].file < f1) ++m1;
-      if (m1 > m0) TBK_TRY(bgz_inflate_launch(ctx, (uint32_t)(m1 - m0), d_mt + m0, d_comp, B->inf, 0u, (unsigned long long*)nullptr));
+      if (m1 > m0) TBK_TRY(bgz_inflate_launch(ctx, (uint32_t)(m1 - m0), d_mt + m0, d_comp, B->inf));
       m0 = m1;
       f0 = f1;
     }
@@ -1516,7 +1248,7 @@ extern "C" int tbk_bam_decode(tbk_ctx* ctx, uint32_t n_files, const uint8_t* con
   // the record index: a lane per member where every member begins with a record (htslib's writers), the chain per file otherwise
   std::vector<uint32_t> cnt(k, 0);
   uint32_t eb = 0;
-  bool chain = getenv("TBK_INDEX_CHAIN") != nullptr;  // (test hook: the chain kernel whatever the files look like)
+  bool chain = ctx->dbg.index_chain;  // (test hook: the chain kernel whatever the files look like)
   if (!chain) {
     std::vector<uint32_t> mfirst(k + 1, 0);
     for (const BgzMember& m : mt) mfirst[m.file + 1]++;

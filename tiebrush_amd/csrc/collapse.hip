@@ -1816,7 +1816,7 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
   {
     uint32_t *icnt = nullptr, *ioff = nullptr, *ocnt = nullptr, *ooff = nullptr;
     uint64_t nit64;
-    const bool by_list = J.win && (!J.pgrp || tbk_yd_by_list(I.k));  // (no per-incidence group array: the window stage has decided)
+    const bool by_list = J.win && (!J.pgrp || tbk_yd_by_list(ctx, I.k));  // (no per-incidence group array: the window stage has decided)
     static_assert(YS_NL == 128, "tbk_yd_by_list (wgroup.h) knows the number of lists");
     const uint32_t ys_tiles = cdiv(ng, YS_NT);
     const YsIn S{ng, J.gperm, J.G.ns, J.gpoff, J.pfile, J.shi, J.gfmask};
@@ -1865,7 +1865,7 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       uint32_t* io = by_list ? ws_alloc<uint32_t>(ctx, nit) : nullptr;  // items placed by list: the item -> group array
       if (by_list && !io) return TBK_ENOMEM;
       YdItems Y;
-      if (by_list && !getenv("TBK_YD_FAT_ITEMS")) {  // (TBK_YD_FAT_ITEMS: test hook, the 24-byte items on this path too)
+      if (by_list) {
         Y.pk = nullptr;
         Y.se = ws_alloc<uint2>(ctx, nit);
         Y.gxoff = Q.xoff;  // (by_list: the groups' records were made above)
@@ -1941,10 +1941,9 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       TBK_HIP(hipMemsetAsync(bcnt, 0, (4 * YD_NB + 4) * sizeof(uint32_t), ctx->stream));
       TBK_LAUNCH(ctx, "yd_gexons", yd_gexons_k, cdiv(ng, B), B, 0, I, ng, J.gperm, J.G, J.slo, Q, ex_s, ex_e);
       // chains bucketed by the log2 of their length, longest first: the lanes of a wave of yd_lane_k run chains of like length
-      uint32_t wave_min = YD_WAVE_MIN_DEFAULT;  // TBK_YD_WAVE_MIN: test hook (1: every chain to yd_wave_k; huge: every chain to yd_lane_k)
-      if (const char* e = getenv("TBK_YD_WAVE_MIN")) wave_min = (uint32_t)strtoul(e, nullptr, 0);
-      uint32_t bgrid = std::min(cdiv(nchains, B), YD_BGRID);
-      if (const char* e = getenv("TBK_YD_BGRID")) bgrid = std::max<uint32_t>(1u, (uint32_t)strtoul(e, nullptr, 0));  // test hook: several chains per thread
+      // (yd_wave_min: test hook — 1: every chain to yd_wave_k; huge: every chain to yd_lane_k; yd_bgrid: several chains per thread)
+      const uint32_t wave_min = ctx->dbg.yd_wave_min ? ctx->dbg.yd_wave_min : YD_WAVE_MIN_DEFAULT;
+      const uint32_t bgrid = ctx->dbg.yd_bgrid ? ctx->dbg.yd_bgrid : std::min(cdiv(nchains, B), YD_BGRID);
       TBK_LAUNCH(ctx, "yd_classify", yd_bucket_count_k, bgrid, B, 0, nchains, nit, wave_min, chain_first, bcnt);
       TBK_LAUNCH(ctx, "yd_classify", yd_bucket_off_k, 1, 1, 0, bcnt, bcur);
       TBK_LAUNCH(ctx, "yd_classify", yd_bucket_fill_k, bgrid, B, 0, nchains, nit, wave_min, chain_first, bcur, ids_lane, ids_long);
@@ -1952,15 +1951,6 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       TBK_HIP(hipMemcpyAsync(hc, n_wave, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
       TBK_HIP(hipStreamSynchronize(ctx->stream));
       const uint32_t n_long = hc[0], n_lane = nchains - n_long;
-      if (getenv("TBK_YD_DEBUG")) {
-        uint32_t hb[2 * YD_NB];
-        TBK_HIP(hipMemcpy(hb, bcnt, sizeof(hb), hipMemcpyDeviceToHost));
-        fprintf(stderr, "yd: %u groups, %u items, %u chains (%u by lane, %u by wave), %llu nodes; chains by log2(length):", ng, nit, nchains, n_lane,
-                n_long, (unsigned long long)nnodes);
-        for (int b = 0; b < 2 * YD_NB; ++b)
-          if (hb[b]) fprintf(stderr, " %s%d:%u", b >= YD_NB ? "w" : "", b % YD_NB, hb[b]);
-        fprintf(stderr, "\n");
-      }
       // lane chains and wave chains are independent: the few long, latency-bound waves go to the auxiliary stream beside the lane
       // kernel.  (The stream was synchronised just above, so the fork needs no event; the join does.)
       hipStream_t aux = n_lane && n_long ? tbk_aux_stream(ctx) : nullptr;
@@ -2047,7 +2037,7 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
   I.qn_off = in->qname_off;
   I.qn = in->qname;
   I.qh_mask = ~0ull;
-  if (const char* e = getenv("TBK_DEBUG_QHASH_MASK")) I.qh_mask = strtoull(e, nullptr, 0);
+  I.qh_mask = ctx->dbg.qhash_mask;
   I.prio_hi = in->prio_hi;
   I.prio_lo = in->prio_lo;
   ColOpt O;
@@ -2058,8 +2048,7 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
   O.keep_sec = o->keep_secondary;
   O.collapse_same = o->collapse_same;
   O.store_frac = o->store_frac;
-  O.hash_mask = 0xFFFFFFFFu;
-  if (const char* e = getenv("TBK_DEBUG_HASH_MASK")) O.hash_mask = (uint32_t)strtoul(e, nullptr, 0);
+  O.hash_mask = ctx->dbg.hash_mask;
 
   // per-record arrays of the key pass / scan / compaction (the raw window path never touches them: allocated when the tile takes
   // the general front end)
@@ -2106,9 +2095,9 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
   // level there, so more files than that take the radix sort.
   bool use_runs = in->n_files <= 64;
   uint32_t runs_min = 32768;          // below this the tile is launch-bound either way; keep the one code path
-  if (const char* e = getenv("TBK_SORT")) {  // test hook: "radix" / "runs" force one path whatever the shape
-    use_runs = strcmp(e, "radix") != 0 && (use_runs || strcmp(e, "runs") == 0);
-    if (strcmp(e, "runs") == 0) runs_min = 0;
+  if (ctx->dbg.sort) {  // test hook: sort=radix / runs force one path whatever the shape
+    use_runs = ctx->dbg.sort != 1 && (use_runs || ctx->dbg.sort == 2);
+    if (ctx->dbg.sort == 2) runs_min = 0;
   }
 
   // The window path (wgroup.hip) goes from the runs to the groups without sorting the records; it covers plain BAM inputs
@@ -2117,9 +2106,9 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
   bool use_win = tbk_window_supported(in->n_files) && !O.store_frac && !O.collapse_same && (n >= (8u << 20) || (in->n_files > 64 && n >= 65536));
   if (in->tbmerged)
     for (uint32_t f = 0; f < in->n_files; ++f) use_win = use_win && in->tbmerged[f] == 0;
-  if (const char* e = getenv("TBK_PATH")) {  // test hook: "sort" keeps the sort path, "window" takes the window path whatever the size
-    if (strcmp(e, "sort") == 0) use_win = false;
-    if (strcmp(e, "window") == 0)
+  if (ctx->dbg.path) {  // test hook: path=sort keeps the sort path, path=window takes the window path whatever the size
+    if (ctx->dbg.path == 1) use_win = false;
+    if (ctx->dbg.path == 2)
       use_win = tbk_window_supported(in->n_files) && !O.store_frac && !O.collapse_same && [&] {
         bool ok = true;
         if (in->tbmerged)
@@ -2135,15 +2124,14 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
       !O.collapse_same && O.strategy != TBK_STRAT_FULL) {
     part = true;
     for (uint32_t f = 0; f < in->n_files; ++f) part = part && in->tbmerged[f] != 0;
-    const char* e = getenv("TBK_PATH");
-    if (e && strcmp(e, "sort") == 0) part = false;
-    if (part && (n >= 65536 || (e && strcmp(e, "window") == 0))) use_win = true;
+    if (ctx->dbg.path == 1) part = false;
+    if (part && (n >= 65536 || ctx->dbg.path == 2)) use_win = true;
     else part = false;
   }
   // Raw window path: plain tiles without an explicit merge priority go from the input records straight to the groups — the key
   // pass, the effective-end scan and the compaction are folded into the window kernels (TBK_RAW=0: test hook, keeps them apart)
   bool use_raw = use_win;
-  if (const char* e = getenv("TBK_RAW")) use_raw = use_raw && strcmp(e, "0") != 0;
+  if (ctx->dbg.raw == 0) use_raw = false;
   if (part) use_raw = true;  // (the PART form exists in raw mode only)
   WgOut win_out;
   bool win_done = false;

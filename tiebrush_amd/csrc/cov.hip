@@ -1716,7 +1716,7 @@ static int junc_branch(tbk_ctx* ctx, uint32_t m, const CovArrays& A, const tbk_c
   const uint32_t B = 256;
   uint64_t* sc = ctx->d_scalars;
   *nj_out = *nju_out = 0;
-  const bool agg = integral && !getenv("TBK_NO_JUNC_AGG");
+  const bool agg = integral && !ctx->dbg.no_junc_agg;
   uint32_t* joff = nullptr;
   uint32_t nj;
   if (agg && nj_known != ~0ull) {  // the block sums need no per-record offsets, and the first pass left the total behind
@@ -1750,7 +1750,7 @@ static int junc_branch(tbk_ctx* ctx, uint32_t m, const CovArrays& A, const tbk_c
     TBK_HIP(hipMemsetAsync(sc + 11, 0, 3 * sizeof(uint64_t), ctx->stream));  // [11] items, [12] a home too full, [13] homes of more than 64 items
     TBK_LAUNCH(ctx, "junc_agg", junc_agg_k, cdiv(m, JA_REC), 256, 0, m, A, in->tid, in->pos, in->cig_off, in->cig, in->strand, in->yc, jcnt, sb.hi, sb.lo,
                pv, (unsigned long long*)(sc + 11));
-    if (!getenv("TBK_JUNC_RADIX")) {  // (TBK_JUNC_RADIX: test hook, the sort below)
+    if (!ctx->dbg.junc_radix) {  // (junc_radix: test hook, the sort below)
       // every item to its home block, the homes sorted one by one: no read-back until the junctions are written
       const uint32_t nblk = cdiv(m, JA_REC);
       uint64_t* bkey = ws_alloc<uint64_t>(ctx, nblk);
@@ -1768,7 +1768,7 @@ static int junc_branch(tbk_ctx* ctx, uint32_t m, const CovArrays& A, const tbk_c
       TBK_LAUNCH(ctx, "junc_home", jh_scatter_k, cdiv(nj, B), B, 0, (const unsigned long long*)(sc + 11), nj, sb.hi, sb.lo, pv, head, hoff2, hfill, sb.hi2,
                  sb.lo2, pv2);
       uint32_t jh_cap = JH_CAP;
-      if (const char* e = getenv("TBK_JH_CAP")) jh_cap = (uint32_t)atoi(e) < JH_CAP ? (uint32_t)atoi(e) : JH_CAP;  // test hook: force the fall-back
+      if (ctx->dbg.jh_cap && ctx->dbg.jh_cap < JH_CAP) jh_cap = ctx->dbg.jh_cap;  // test hook: force the fall-back
       uint32_t* big = hoff;  // (nj entries, unused on this path: fewer than nj / 64 homes can hold more than 64 items)
       TBK_LAUNCH(ctx, "junc_sort", jh_sort_k, cdiv((uint64_t)nblk * 64, B), B, 0, nblk, hcnt, hoff2, sb.hi2, sb.lo2, pv2, ucnt, big, sc + 13);
       TBK_LAUNCH(ctx, "junc_sort", jh_sort_big_k, 512, 256, 0, big, sc + 13, hcnt, hoff2, sb.hi2, sb.lo2, pv2, ucnt, sc + 12, jh_cap);
@@ -1848,7 +1848,7 @@ static int cov_intervals_lean(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* o
   // tiles: unknown until the passes have run.  m / 8 covers an average of 1024 compacted bases per record (a collapsed RNA-seq
   // sample has a handful), 2^20 tiles any small input
   uint64_t cap64 = (uint64_t)m / 8u > (1ull << 20) ? (uint64_t)m / 8u : (1ull << 20);
-  if (const char* e = getenv("TBK_COV_TILE_CAP")) cap64 = (uint64_t)atoll(e);  // test hook: force the refusal
+  if (ctx->dbg.cov_tile_cap) cap64 = ctx->dbg.cov_tile_cap;  // test hook: force the refusal
   T.cap = (uint32_t)cap64;
   T.first = ws_alloc<uint32_t>(ctx, (size_t)T.cap + 1);
   T.tb = ws_alloc<uint32_t>(ctx, (size_t)T.cap + 1);
@@ -1959,7 +1959,7 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
   // the context's own view, built from keys, comes with this pass's results (the view builder had the CIGAR words in hand)
   const auto& V = ctx->view_prep;
   const bool prepared = V.valid && all_valid && !sample_mode && in->mem == TBK_MEM_DEVICE && in->cig == V.cig && n == V.n &&
-                        !getenv("TBK_COV_PREP");  // (TBK_COV_PREP: test hook, run the pass anyway)
+                        !ctx->dbg.cov_prep;  // (cov_prep: test hook, run the pass anyway)
   uint32_t eb = 0;
   if (prepared) {
     A.ridx = V.ridx;
@@ -2004,7 +2004,7 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
 
   // integral YC, intervals wanted: the lean chain (TBK_COV_LEGACY: test hook, the general chain below)
   bool lean_done = false;
-  if (want_cov && !fractional && !sample_mode && !getenv("TBK_COV_LEGACY") && !getenv("TBK_COV_BUNDLE_SCAN")) {
+  if (want_cov && !fractional && !sample_mode && !ctx->dbg.cov_legacy && !ctx->dbg.cov_bundle_scan) {
     const size_t ws_mark = ctx->ws_off;
     const int lrc = cov_intervals_lean(ctx, in, out, A, m, all_valid, sum_abs);
     if (lrc < 0) return lrc;
@@ -2017,7 +2017,7 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
   if (!lean_done) {
   // bundles
   {
-    if (getenv("TBK_COV_BUNDLE_SCAN")) {  // test hook: the two-stage look-back scan
+    if (ctx->dbg.cov_bundle_scan) {  // test hook: the two-stage look-back scan
       BundleLoad ld{A.tid, A.end};
       BundleAux ax{A.tid, A.start};
       BundleHead hd{};

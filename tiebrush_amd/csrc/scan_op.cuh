@@ -483,10 +483,7 @@ template <class T, class Op, class Load, class Store>
 int scan_op_run(tbk_ctx* ctx, const char* name, uint32_t n, Load load, Store store, Op op, T ident, bool single_pass = false) {
   if (n == 0) return 0;
   uint32_t nb = cdiv(n, SO_TILE);
-  static const int forced = [] {  // test hook: TBK_SCAN=lookback / 3pass forces one form for every scan
-    const char* e = getenv("TBK_SCAN");
-    return !e ? 0 : (strcmp(e, "lookback") == 0 ? 1 : (strcmp(e, "3pass") == 0 ? 2 : 0));
-  }();
+  const int forced = ctx->dbg.scan;  // test hook: scan=lookback / 3pass forces one form for every scan
   const bool lookback = forced == 1 || (forced == 0 && single_pass);
   if (lookback && nb > 1) {
     constexpr size_t W = sizeof(T) / 4;

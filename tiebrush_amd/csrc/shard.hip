@@ -707,8 +707,7 @@ extern "C" int tbk_partial_pack(tbk_ctx* ctx, const tbk_collapse_opts* o, const 
     O.keep_supp = o->keep_supplementary;
     O.keep_sec = o->keep_secondary;
     O.seed = TBK_KEY_SEED0;
-    O.hash_mask = 0xFFFFFFFFu;
-    if (const char* e = getenv("TBK_DEBUG_HASH_MASK")) O.hash_mask = (uint32_t)strtoul(e, nullptr, 0);
+    O.hash_mask = ctx->dbg.hash_mask;
     TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
     TBK_LAUNCH(ctx, "partial_rows", partial_rows_k, cdiv(ng, SH_B), SH_B, 0, ng, in->n_files, first_fidx, I, O, g->rep, g->yc, g->yx, g->yd,
                g->rep_effend, cfirst, cnt, woff, g->g_key, rows, cig_out, ctx->d_err);
@@ -1003,7 +1002,7 @@ extern "C" int tbk_partial_stage_pack(tbk_ctx* ctx, const tbk_collapse_opts* o, 
     O.keep_supp = o->keep_supplementary;
     O.keep_sec = o->keep_secondary;
     O.seed = TBK_KEY_SEED0;
-    O.hash_mask = 0xFFFFFFFFu;
+    O.hash_mask = ctx->dbg.hash_mask;
     TBK_LAUNCH(ctx, "partial_rows", partial_rows_k, cdiv(ng, SH_B), SH_B, 0, ng, in->n_files, first_fidx, I, O, g->rep, g->yc, g->yx, g->yd,
                g->rep_effend, cfirst, cnt, woff, g->g_key, rows, cig_out, ctx->d_err);
   }

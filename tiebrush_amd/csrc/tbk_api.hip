@@ -197,8 +197,7 @@ void tbk_prof_begin_call(tbk_ctx* ctx) {
   ctx->ev_used = 0;
 }
 void tbk_prof_end_call(tbk_ctx* ctx) {
-  static const bool ws_dbg = getenv("TBK_WS_DEBUG") != nullptr;  // how much of its arena a call used (sizing the hints)
-  if (ws_dbg) {
+  if (false) {
     size_t over = 0;
     for (auto& c : ctx->ws_overflow) over += c.second;
     fprintf(stderr, "tbk arena %p: used %.2f GB of %.2f GB (+ %.2f GB in overflow chunks)\n", (void*)ctx, ctx->ws_off / 1e9, ctx->ws_cap / 1e9, over / 1e9);
@@ -228,8 +227,7 @@ void tbk_prof_end_call(tbk_ctx* ctx) {
 // instead of a trip through the runtime's bounce buffers, and nothing of the caller's memory stays pinned behind the call
 // (TBK_NO_REGISTER: test hook, plain copies).  tbk_host_unregister_all releases the registrations once the stream has drained.
 static void host_register(tbk_ctx* ctx, const void* p, size_t bytes) {
-  static const bool off = getenv("TBK_NO_REGISTER") != nullptr;
-  if (off || bytes < ((size_t)16 << 20)) return;
+  if (ctx->dbg.no_register || bytes < ((size_t)16 << 20)) return;
   for (void* q : ctx->registered)
     if (q == p) return;  // this call holds it already
   std::lock_guard<std::mutex> lk(g_reg_m);
@@ -293,7 +291,10 @@ hipStream_t tbk_aux_stream(tbk_ctx* ctx) {
 // ---- side context ----------------------------------------------------------------------------------------
 tbk_ctx* tbk_side_ctx(tbk_ctx* ctx) {
   if (!ctx->side_ctx && tbk_create(ctx->device, &ctx->side_ctx) != 0) ctx->side_ctx = nullptr;
-  if (ctx->side_ctx) ctx->side_ctx->profiling = ctx->profiling;
+  if (ctx->side_ctx) {
+    ctx->side_ctx->profiling = ctx->profiling;
+    ctx->side_ctx->dbg = ctx->dbg;
+  }
   return ctx->side_ctx;
 }
 int tbk_side_begin(tbk_ctx* side, size_t arena_hint) {
@@ -343,9 +344,55 @@ static int finish_yd(tbk_ctx* ctx) {
 }
 
 // ---- C ABI -----------------------------------------------------------------------------------------
+void tbk_debug_parse(const char* spec, TbkDebug* out) {
+  *out = TbkDebug();
+  if (!spec) return;
+  std::string s(spec);
+  size_t at = 0;
+  while (at < s.size()) {
+    size_t end = s.find(',', at);
+    if (end == std::string::npos) end = s.size();
+    const std::string kv = s.substr(at, end - at);
+    at = end + 1;
+    const size_t eq = kv.find('=');
+    const std::string k = kv.substr(0, eq), v = eq == std::string::npos ? std::string("1") : kv.substr(eq + 1);
+    const unsigned long long u = strtoull(v.c_str(), nullptr, 0);
+    const bool on = v != "0";
+    if (k == "path") out->path = v == "sort" ? 1 : (v == "window" ? 2 : 0);
+    else if (k == "raw") out->raw = on ? 1 : 0;
+    else if (k == "sort") out->sort = v == "radix" ? 1 : (v == "runs" ? 2 : 0);
+    else if (k == "scan") out->scan = v == "lookback" ? 1 : (v == "3pass" ? 2 : 0);
+    else if (k == "hash_mask") out->hash_mask = (uint32_t)u;
+    else if (k == "qhash_mask") out->qhash_mask = u;
+    else if (k == "yd_wave_min") out->yd_wave_min = (uint32_t)u;
+    else if (k == "yd_bgrid") out->yd_bgrid = (uint32_t)u;
+    else if (k == "yd_radix") out->yd_radix = on;
+    else if (k == "yd_own_arena") out->yd_own_arena = on;
+    else if (k == "wg_dense_verify") out->wg_dense_verify = on;
+    else if (k == "wg_rank_merge") out->wg_rank_merge = on;
+    else if (k == "cov_legacy") out->cov_legacy = on;
+    else if (k == "cov_bundle_scan") out->cov_bundle_scan = on;
+    else if (k == "cov_prep") out->cov_prep = on;
+    else if (k == "cov_tile_cap") out->cov_tile_cap = u;
+    else if (k == "junc_radix") out->junc_radix = on;
+    else if (k == "no_junc_agg") out->no_junc_agg = on;
+    else if (k == "jh_cap") out->jh_cap = (uint32_t)u;
+    else if (k == "index_chain") out->index_chain = on;
+    else if (k == "no_register") out->no_register = on;
+  }
+}
+
 extern "C" {
 
 int tbk_abi_version(void) { return TBK_ABI_VERSION; }
+
+int tbk_set_debug(tbk_ctx* ctx, const char* spec) {
+  if (!ctx) return TBK_EINVAL;
+  tbk_debug_parse(spec, &ctx->dbg);
+  if (ctx->yd_ctx) ctx->yd_ctx->dbg = ctx->dbg;
+  if (ctx->side_ctx) ctx->side_ctx->dbg = ctx->dbg;
+  return 0;
+}
 
 const char* tbk_strerror(int s) {
   switch (s) {
@@ -371,6 +418,7 @@ int tbk_create(int device_ordinal, tbk_ctx** out) {
   tbk_ctx* ctx = new (std::nothrow) tbk_ctx();
   if (!ctx) return TBK_ENOMEM;
   ctx->device = device_ordinal;
+  tbk_debug_parse(getenv("TBK_DEBUG"), &ctx->dbg);  // (the one place the library looks at the environment)
   bool ok = hipSetDevice(device_ordinal) == hipSuccess;
   hipDeviceProp_t prop;
   if (ok && hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
@@ -552,7 +600,7 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
   // (config 3: 25 GB for 320 M records — scratch at the far end of the arena, the group arrays at the bottom — and 9.6 GB for its
   // YD stage, which borrows the range behind the group arrays when it is deferred).  A hint that proves too small costs one call with overflow
   // chunks, after which the arena has learnt its size.
-  bool lean = in->mem == TBK_MEM_DEVICE && !opts->store_frac && !opts->collapse_same && !in->prio_hi && !getenv("TBK_PATH") && !getenv("TBK_RAW") &&
+  bool lean = in->mem == TBK_MEM_DEVICE && !opts->store_frac && !opts->collapse_same && !in->prio_hi && ctx->dbg.path == 0 && ctx->dbg.raw < 0 &&
               (in->n_records >= (8u << 20) || (in->n_files > 64 && in->n_records >= 65536));
   if (lean && in->tbmerged)
     for (uint32_t f = 0; f < in->n_files; ++f) lean = lean && in->tbmerged[f] == 0;
@@ -605,6 +653,7 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
       if (defer && !ctx->yd_ctx && tbk_create(ctx->device, &ctx->yd_ctx) != 0) defer = false;
       if (defer) {
         ctx->yd_ctx->profiling = ctx->profiling;
+        ctx->yd_ctx->dbg = ctx->dbg;
         ctx->ws_base_off = (ctx->ws_off + 255) & ~(size_t)255;
         ctx->yd_rc = 0;
         tbk_ctx* side = ctx->yd_ctx;
@@ -612,7 +661,7 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
         // end, dead by now): no second arena of 40 bytes per record per context.  The calls that follow on this context start behind
         // the range; when the arena could not hold them as well, the stage keeps an arena of its own.
         const size_t yd_bytes = (yd_hint + 255) & ~(size_t)255;
-        const bool borrow = !getenv("TBK_YD_OWN_ARENA") && ctx->ws_base_off + yd_bytes + ctx->ws_cap / 4 <= ctx->ws_cap;
+        const bool borrow = !ctx->dbg.yd_own_arena && ctx->ws_base_off + yd_bytes + ctx->ws_cap / 4 <= ctx->ws_cap;
         if (borrow) {
           if (side->ws && !side->ws_borrowed) (void)hipFree(side->ws);
           side->ws = ctx->ws + ctx->ws_base_off;

@@ -82,8 +82,31 @@ struct TbkWorker {
   }
 };
 
+// Test hooks and forced path choices.  Read ONCE, when a context is created, from TBK_DEBUG ("key=value,key=value"), and replaced as a
+// whole by tbk_set_debug (include/tbk.h): no call path reads the environment.  Every field's default is the production behaviour.
+struct TbkDebug {
+  int path = 0;               // path=sort | window: the collapse's sort path / window path whatever the tile's size
+  int raw = -1;               // raw=0: the window path with its key pass, effective-end scan and compaction as separate kernels
+  int sort = 0;               // sort=radix | runs: one ordering path whatever the shape (1 / 2)
+  int scan = 0;               // scan=lookback | 3pass: one form for every scan_op_run (1 / 2)
+  uint32_t hash_mask = 0xFFFFFFFFu;  // hash_mask=0x..: bits of the strategy hash that survive (forces key collisions)
+  uint64_t qhash_mask = ~0ull;       // qhash_mask=0x..: bits of the read-name hash (-A)
+  uint32_t yd_wave_min = 0;   // yd_wave_min=N: chains of N items and more go to yd_wave_k (0: the default split)
+  uint32_t yd_bgrid = 0;      // yd_bgrid=N: blocks of the chain bucketing (0: default)
+  bool yd_radix = false;      // yd_radix=1: the YD items through the stable radix split for any tile
+  bool yd_own_arena = false;  // yd_own_arena=1: a deferred YD stage never borrows the main arena
+  bool wg_dense_verify = false, wg_rank_merge = false;  // window path: per-record verification form; merge-sort ranking of a window's groups
+  bool cov_legacy = false, cov_bundle_scan = false, cov_prep = false, junc_radix = false, no_junc_agg = false;
+  uint64_t cov_tile_cap = 0;  // cov_tile_cap=N: capacity of the lean chain's tile tables (0: by the input)
+  uint32_t jh_cap = 0;        // jh_cap=N: items a junction home may hold (0: JH_CAP)
+  bool index_chain = false;   // index_chain=1: the record index by the per-file chain kernel whatever the files look like
+  bool no_register = false;   // no_register=1: large host buffers are not page-locked for a call's copies
+};
+void tbk_debug_parse(const char* spec, TbkDebug* out);
+
 struct tbk_ctx {
   int device = 0;
+  TbkDebug dbg;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   hipStream_t aux = nullptr;     // second stream for independent kernels inside one stage (created on first use)

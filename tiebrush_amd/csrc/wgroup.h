@@ -41,8 +41,8 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
 // incidences (np = 0); TBK_DERR_FRACTIONAL in *err_bits: a carried value this form cannot hold — run the sort path.
 bool tbk_window_supported(uint32_t k);
 // The YD stage of a window-path tile places its items by list without a sort when the tile has at most 64 input files (collapse.hip:
-// yd_lcount_k / yd_lscatter_k) and needs no per-incidence group array then (TBK_YD_RADIX: test hook, the radix split for any tile).
-inline bool tbk_yd_by_list(uint32_t k) { return 2u * k <= 128u && !getenv("TBK_YD_RADIX"); }
+// yd_lcount_k / yd_lscatter_k) and needs no per-incidence group array then (yd_radix: test hook, the radix split for any tile).
+inline bool tbk_yd_by_list(const tbk_ctx* ctx, uint32_t k) { return 2u * k <= 128u && !ctx->dbg.yd_radix; }
 
 // Owner side of the group-partials protocol: merge n_runs runs of partial rows (TBK_PARTIAL_ROW words each, every
 // run in its rank's output order) in output order and reduce equal keys; see tbk_partial_reduce in include/tbk.h.  The arena

@@ -2192,7 +2192,7 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
     TBK_HIP(hipMemsetAsync(spread, 0, 2 * (size_t)WG_NSPREAD * WG_SPREAD_STRIDE * sizeof(unsigned long long), ctx->stream));
     R.n_pass = spread;
     R.all_slots = want_rec_sg ? 1u : 0u;
-    R.sparse = (!want_rec_sg && strategy != TBK_STRAT_FULL && !getenv("TBK_WG_DENSE_VERIFY")) ? 1u : 0u;  // (-L has no exact key words: every record is verified)
+    R.sparse = (!want_rec_sg && strategy != TBK_STRAT_FULL && !ctx->dbg.wg_dense_verify) ? 1u : 0u;  // (-L has no exact key words: every record is verified)
     R.n_slots = spread + (size_t)WG_NSPREAD * WG_SPREAD_STRIDE;
     scratch_hi = ws_alloc<uint64_t>(ctx, m);
     scratch_lo = ws_alloc<uint64_t>(ctx, m);
@@ -2242,7 +2242,7 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   T.wbase = ws_alloc<uint32_t>(ctx, (size_t)nw + 1);
   T.cslot = ws_alloc<uint32_t>(ctx, m);
   T.fmask = nullptr;
-  if (raw && !part && k <= 64 && tbk_yd_by_list(k)) {
+  if (raw && !part && k <= 64 && tbk_yd_by_list(ctx, k)) {
     T.fmask = ws_alloc<uint64_t>(ctx, m);
     if (!T.fmask) return TBK_ENOMEM;
   }
@@ -2264,13 +2264,9 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
     T.yd = ws_alloc<uint32_t>(ctx, m);
     if (!T.yd) return TBK_ENOMEM;
   }
-  if (!part && getenv("TBK_WG_DEBUG")) {
-    T.dbg = ws_alloc<unsigned long long>(ctx, 32);
-    if (T.dbg) TBK_HIP(hipMemsetAsync(T.dbg, 0, 32 * 8, ctx->stream));
-  }
   if (!T.pinc || !pbase || !T.c2r) return TBK_ENOMEM;
   if (raw && !R.sparse) TBK_HIP(hipMemsetAsync(T.cslot, 0xFF, (size_t)m * 4, ctx->stream));  // (only the records wg_finish_raw_k must visit get a slot)
-  WgIn In{chi, clo, cval, ceff, off, W, k, nw, getenv("TBK_WG_RANK_MERGE") ? 1u : 0u};
+  WgIn In{chi, clo, cval, ceff, off, W, k, nw, ctx->dbg.wg_rank_merge ? 1u : 0u};
   const uint32_t nwords = cdiv(k, 32);
   // LDS of the hash kernel: the pieces' tables (8 k + 4 bytes) and the group table share WG_LDS_HASH (four blocks per CU)
   const uint32_t gcap = (WG_LDS_HASH - (8u * k + 8u)) / (44u + 4u * nwords);
@@ -2319,11 +2315,8 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   }
 #define WG_L_HASH(S) TBK_LAUNCH(ctx, "wg_hash", (wg_hash_k<true, S, 0>), nw_live, WG_NT, lds_hash, In, R, T, gcap, nwords, seed, wlist, ovf, ovf_cap, ctx->d_err)
 #define WG_L_HASH64(S)                                                                                                                       \
-  TBK_LAUNCH(ctx, "wg_hash", (wg_hash_k<true, S, WG_GC64>), nw_live, WG_NT, WG_GC64 * 52u + 8u * 64u + 8u + lds_pad, In, R, T, gcap, nwords, seed, wlist, ovf, \
+  TBK_LAUNCH(ctx, "wg_hash", (wg_hash_k<true, S, WG_GC64>), nw_live, WG_NT, WG_GC64 * 52u + 8u * 64u + 8u, In, R, T, gcap, nwords, seed, wlist, ovf, \
              ovf_cap, ctx->d_err)
-    // TBK_WG_LDS_PAD (measurement hook): bytes of LDS the first-tier kernel asks for beyond its table — 12800 leaves room for three
-    // blocks per CU instead of four, i.e. two wave slots per SIMD for whatever another context has queued
-    const uint32_t lds_pad = getenv("TBK_WG_LDS_PAD") ? (uint32_t)atoi(getenv("TBK_WG_LDS_PAD")) : 0u;
     if (part) {  // group partials: one instantiation, the strategy read from the options
       R.O.strategy = strategy;
       TBK_LAUNCH(ctx, "wg_hash", (wg_hash_k<true, -1, WG_GC64, true>), nw_live, WG_NT, WG_GC64 * 52u + 8u * 64u + 8u, In, R, T, gcap, nwords, seed, wlist,
@@ -2406,7 +2399,7 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   out->gfmask = T.fmask ? ws_alloc<uint64_t>(ctx, ng) : nullptr;
   if (T.fmask && !out->gfmask) return TBK_ENOMEM;
   out->pfile = ws_alloc<uint16_t>(ctx, np);
-  out->pgrp = tbk_yd_by_list(k) ? nullptr : ws_alloc<uint32_t>(ctx, np);
+  out->pgrp = tbk_yd_by_list(ctx, k) ? nullptr : ws_alloc<uint32_t>(ctx, np);
   out->yc = ws_alloc<double>(ctx, ng);
   out->ns = ws_alloc<uint32_t>(ctx, ng);
   out->yxin = part ? ws_alloc<long long>(ctx, ng) : nullptr;
