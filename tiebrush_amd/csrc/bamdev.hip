@@ -21,12 +21,13 @@
 #include <thread>
 #include <vector>
 
+#include "crc32_block.cuh"
 #include "dev_common.cuh"
 #include "tbk_internal.h"
 
 namespace {
 
-// ---- RFC 1951 inflate, one lane per member ------------------------------------------------------------------------
+// ---- RFC 1951 inflate ------------------------------------------------------------------------
 constexpr int INF_NT = 64;           // one wave per block: 64 members
 
 struct BitIn {
@@ -114,8 +115,7 @@ struct BgzMember {
 // tables in LDS (10 bits for literals / lengths, 9 for distances; longer codes fall back to the canonical walk), the last 32 KiB
 // of output — all a deflate distance can reach — live in an LDS ring, a match is copied by the 64 lanes together, and the output
 // leaves the ring in coalesced runs of 16 KiB.  The compressed stream is staged through LDS 2 KiB at a time.  CRC32 is checked by
-// bgz_crc_k afterwards (a lane per member is the right shape for that: 64 independent table walks per wave).
-// Same verdicts as the kernel above on malformed streams (tests/test_gpu_bgzf.py runs both).
+// bgz_crc_k afterwards (a workgroup per member).
 #ifndef IW_WIN_BYTES
 #define IW_WIN_BYTES 8192
 #endif
@@ -460,53 +460,51 @@ __global__ __launch_bounds__(64) void bgz_inflate_wave_k(uint32_t nmem, const Bg
   if (bad && lane == 0) atomicOr(err, 1u);
 }
 
-// CRC32 of every member's payload against its trailer (RFC 1952): a lane per member, slicing-by-4
-__global__ __launch_bounds__(INF_NT) void bgz_crc_k(uint32_t nmem, const BgzMember* __restrict__ mem, const uint8_t* __restrict__ dst,
-                                                    uint32_t* __restrict__ err) {
-  __shared__ uint32_t crct[4][256];
-  for (uint32_t i = threadIdx.x; i < 256; i += INF_NT) {
-    uint32_t c = i;
-    for (int k = 0; k < 8; ++k) c = (c & 1u) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
-    crct[0][i] = c;
-  }
-  __syncthreads();
-  for (uint32_t i = threadIdx.x; i < 256; i += INF_NT) {
-    uint32_t c = crct[0][i];
-    for (int t = 1; t < 4; ++t) {
-      c = crct[0][c & 0xFFu] ^ (c >> 8);
-      crct[t][i] = c;
+// CRC32 and ISIZE of every member, as htslib checks them (RFC 1952).  A workgroup per member: the payload is staged in LDS with
+// coalesced loads and its CRC computed a chunk per thread (crc32_block.cuh).  (Round 4: a lane per member walking its 64 KiB through
+// slicing tables — 64 different cache lines per load instruction: 121 ms for the 21 GB of 45 inputs, an eighth of the device decode.)
+constexpr int CRC_NT = 256;
+constexpr uint32_t CRC_LDS = 65536 + 16 + 4 * CRCB_LDS_WORDS;
+__global__ __launch_bounds__(CRC_NT) void bgz_crc_k(uint32_t nmem, const BgzMember* __restrict__ mem, const uint8_t* __restrict__ dst,
+                                                   uint32_t* __restrict__ err) {
+  extern __shared__ __align__(16) uint8_t crc_lds[];
+  uint32_t* const work = (uint32_t*)(crc_lds + 65536 + 16);
+  crcb_setup(work, threadIdx.x, CRC_NT);
+  for (uint32_t m = blockIdx.x; m < nmem; m += gridDim.x) {
+    const BgzMember M = mem[m];
+    const uint8_t* p = dst + M.dst;
+    const uint32_t n = M.isize;
+    // (a member's payload starts at any byte: bytes up to the first 16-byte boundary, then whole vectors)
+    const uint32_t head = min(n, (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u));
+    if (threadIdx.x < head) crc_lds[threadIdx.x] = p[threadIdx.x];
+    const uint32_t nv = (n - head) >> 4;
+    const uint4* pv = (const uint4*)(p + head);
+    for (uint32_t i = threadIdx.x; i < nv; i += CRC_NT) {
+      const uint4 v = pv[i];
+      uint8_t* q = crc_lds + head + 16 * i;  // (head bytes in: not 16-byte aligned in LDS — four dword stores)
+      uint32_t w[4] = {v.x, v.y, v.z, v.w};
+      __builtin_memcpy(q, w, 16);
     }
+    const uint32_t t0 = head + nv * 16;
+    if (threadIdx.x < n - t0) crc_lds[t0 + threadIdx.x] = p[t0 + threadIdx.x];
+    __syncthreads();
+    const uint32_t c = crcb_run(work, crc_lds, n, threadIdx.x, CRC_NT);
+    if (threadIdx.x == 0 && c != M.crc) atomicOr(err, 1u);
   }
-  __syncthreads();
-  const uint32_t m = blockIdx.x * INF_NT + threadIdx.x;
-  if (m >= nmem) return;
-  const BgzMember M = mem[m];
-  const uint8_t* out = dst + M.dst;
-  const uint32_t cap = M.isize;
-  uint32_t c = 0xFFFFFFFFu;
-  uint32_t i = 0;
-  for (; i < cap && ((uintptr_t)(out + i) & 3u); ++i) c = crct[0][(c ^ out[i]) & 0xFFu] ^ (c >> 8);
-  for (; i + 16 <= cap; i += 16) {
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(out + i);
-    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
-    uint32_t x = c ^ w0;
-    c = crct[3][x & 0xFFu] ^ crct[2][(x >> 8) & 0xFFu] ^ crct[1][(x >> 16) & 0xFFu] ^ crct[0][x >> 24];
-    x = c ^ w1;
-    c = crct[3][x & 0xFFu] ^ crct[2][(x >> 8) & 0xFFu] ^ crct[1][(x >> 16) & 0xFFu] ^ crct[0][x >> 24];
-    x = c ^ w2;
-    c = crct[3][x & 0xFFu] ^ crct[2][(x >> 8) & 0xFFu] ^ crct[1][(x >> 16) & 0xFFu] ^ crct[0][x >> 24];
-    x = c ^ w3;
-    c = crct[3][x & 0xFFu] ^ crct[2][(x >> 8) & 0xFFu] ^ crct[1][(x >> 16) & 0xFFu] ^ crct[0][x >> 24];
-  }
-  for (; i < cap; ++i) c = crct[0][(c ^ out[i]) & 0xFFu] ^ (c >> 8);
-  if ((c ^ 0xFFFFFFFFu) != M.crc) atomicOr(err, 1u);
 }
 
 // the inflate: a wave per member, then the CRC pass (a lane per member).  (Rounds 3 - 4 also kept a lane-per-member decoder — 64
 // different decoders in lock step —: 664 ms for the 7.6 GB of tools/scratch/dd2_r4.sh against 274 ms; it lives in the history.)
 static int bgz_inflate_launch(tbk_ctx* ctx, uint32_t nmem, const BgzMember* d_mt, const uint8_t* d_comp, uint8_t* d_out) {
   TBK_LAUNCH(ctx, "bgz_inflate", bgz_inflate_wave_k, nmem, 64, 0, nmem, d_mt, d_comp, d_out, ctx->d_err);
-  TBK_LAUNCH(ctx, "bgz_crc", bgz_crc_k, cdiv(nmem, INF_NT), INF_NT, 0, nmem, d_mt, d_out, ctx->d_err);
+  {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)bgz_crc_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CRC_LDS);
+      attr = true;
+    }
+    TBK_LAUNCH(ctx, "bgz_crc", bgz_crc_k, std::min<uint32_t>(nmem, (uint32_t)ctx->num_cu * 2u), CRC_NT, CRC_LDS, nmem, d_mt, d_out, ctx->d_err);
+  }
   return 0;
 }
 

@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <vector>
 
+#include "crc32_block.cuh"
 #include "deflate_codes.h"
 #include "dev_common.cuh"
 #include "tbk_internal.h"
@@ -67,10 +68,8 @@ constexpr uint32_t L_CODD = L_CODL + 288 * 2;
 constexpr uint32_t L_CODC = L_CODD + 32 * 2;
 constexpr uint32_t L_RLE = L_CODC + 32 * 2;               // u16[320]
 constexpr uint32_t L_BLC = L_RLE + 320 * 2;               // u32[20]
-constexpr uint32_t L_CRCT = L_BLC + 20 * 4;               // u32[256] CRC-32 table
-constexpr uint32_t L_CRCM = L_CRCT + 1024;                // u32[9][32] zero-advance matrices: 128 << k bytes
-constexpr uint32_t L_CRCV = L_CRCM + 9 * 32 * 4;          // u32[512] per-chunk registers
-constexpr uint32_t L_WSUM = L_CRCV + 512 * 4;             // u32[2][16] per-wave bit totals of the token scan
+constexpr uint32_t L_CRCT = L_BLC + 20 * 4;               // u32[CRCB_LDS_WORDS] CRC-32 work area
+constexpr uint32_t L_WSUM = L_CRCT + 4 * CRCB_LDS_WORDS;  // (crc32_block.cuh: table, zero-advance matrices, per-chunk registers); u32[2][16] per-wave bit totals of the token scan
 constexpr uint32_t L_OVER_END = L_WSUM + 2 * 16 * 4;
 static_assert(L_OVER_END <= L_CTL, "the coder's arrays must fit where the tables were");
 static_assert(L_END <= 81920, "two workgroups per CU");
@@ -93,14 +92,6 @@ __device__ __forceinline__ uint32_t match_len(const uint32_t* w, uint32_t p, uin
     l += 4;
   }
   return l < lim ? l : lim;
-}
-
-// v_j <- M * v over GF(2): M[b] = image of bit b
-__device__ __forceinline__ uint32_t gf2_matvec(const uint32_t* M, uint32_t v) {
-  uint32_t r = 0;
-#pragma unroll 1
-  for (int b = 0; b < 32; ++b) r ^= ((v >> b) & 1u) ? M[b] : 0u;
-  return r;
 }
 
 struct DfMember {
@@ -169,49 +160,12 @@ __device__ __noinline__ void df_build_code(uint32_t freq_off, int nsym, int maxb
   __syncthreads();
 }
 
-// CRC-32 of the n payload bytes in LDS -> ctl[C_CRC]: the table, the matrices that advance a register through 128 << k zero bytes, a
-// 128-byte chunk per thread (counted from the END, so that only the first chunk is short), a tree of advance-and-xor steps
+// CRC-32 of the n payload bytes in LDS -> ctl[C_CRC] (crc32_block.cuh: a chunk per thread, folded with zero-advance matrices)
 __device__ __noinline__ void df_crc32(uint32_t n) {
-  uint32_t* const crct = DF_U32(L_CRCT);
-  uint32_t* const crcm = DF_U32(L_CRCM);
-  uint32_t* const crcv = DF_U32(L_CRCV);
-  const uint8_t* const inb = DF_U8(L_IN);
-  const uint32_t tid = threadIdx.x;
-  if (tid < 256) {
-    uint32_t c = tid;
-    for (int k = 0; k < 8; ++k) c = (c & 1u) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
-    crct[tid] = c;
-  }
-  __syncthreads();
-  if (tid < 32) {
-    uint32_t s = 1u << tid;
-    for (int b = 0; b < 128; ++b) s = crct[s & 255u] ^ (s >> 8);
-    crcm[tid] = s;
-  }
-  __syncthreads();
-#pragma unroll 1
-  for (int k = 1; k < 9; ++k) {
-    if (tid < 32) crcm[k * 32 + tid] = gf2_matvec(crcm + (k - 1) * 32, crcm[(k - 1) * 32 + tid]);
-    __syncthreads();
-  }
-  const uint32_t nchunk = (n + 127u) >> 7;
-  if (tid < 512) {
-    uint32_t s = 0;
-    if (tid < nchunk) {
-      const uint32_t hi = n - 128u * tid, lo = hi >= 128u ? hi - 128u : 0u;
-      s = (tid == nchunk - 1) ? 0xFFFFFFFFu : 0u;
-      for (uint32_t b = lo; b < hi; ++b) s = crct[(s ^ inb[b]) & 255u] ^ (s >> 8);
-    }
-    crcv[tid] = s;
-  }
-  __syncthreads();
-#pragma unroll 1
-  for (int k = 0; k < 9; ++k) {
-    const uint32_t step = 1u << k;
-    if (tid < 512 && (tid & (2 * step - 1)) == 0 && tid + step < 512) crcv[tid] ^= gf2_matvec(crcm + k * 32, crcv[tid + step]);
-    __syncthreads();
-  }
-  if (tid == 0) DF_U32(L_CTL)[C_CRC] = ~crcv[0];
+  uint32_t* const work = DF_U32(L_CRCT);
+  crcb_setup(work, threadIdx.x, DF_NT);
+  const uint32_t c = crcb_run(work, DF_U8(L_IN), n, threadIdx.x, DF_NT);
+  if (threadIdx.x == 0) DF_U32(L_CTL)[C_CRC] = c;
   __syncthreads();
 }
 

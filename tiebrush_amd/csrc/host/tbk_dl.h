@@ -27,6 +27,8 @@ struct TbkApi {
   decltype(&tbk_bam_encode) bam_encode = nullptr;
   decltype(&tbk_host_alloc) host_alloc = nullptr;
   decltype(&tbk_host_free) host_free = nullptr;
+  decltype(&tbk_set_profiling) set_profiling = nullptr;
+  decltype(&tbk_kernel_times) kernel_times = nullptr;
   std::string error;
 
   bool load() {
@@ -64,6 +66,8 @@ struct TbkApi {
     TBK_BIND(bam_encode, tbk_bam_encode)
     TBK_BIND(host_alloc, tbk_host_alloc)
     TBK_BIND(host_free, tbk_host_free)
+    TBK_BIND(set_profiling, tbk_set_profiling)
+    TBK_BIND(kernel_times, tbk_kernel_times)
 #undef TBK_BIND
     if (abi_version() != TBK_ABI_VERSION) {
       error = "libtbk.so has another ABI version";

@@ -479,8 +479,23 @@ int main(int argc, char* argv[]) {
           auto d2 = tnow();
           std::vector<const uint8_t*> ptr(kd);
           for (size_t f = 0; f < kd; ++f) ptr[f] = comp[f].p;
+          if (timing) (void)api.set_profiling(ctx, 1);
           rc_d = api.bam_decode(ctx, (uint32_t)kd, ptr.data(), fsz.data(), tb_d.data(), 0, 0, &in_d, fo_d.data());
           ms_dcall = tms(d2, tnow());
+          if (timing) {  // the call's kernels (HIP events): what of its wall time the GPU was busy with
+            tbk_kernel_time kt[64];
+            const int nk = api.kernel_times(ctx, kt, 64);
+            std::string line = "device decode kernels ms:";
+            double sum = 0;
+            for (int i = 0; i < nk; ++i) {
+              char b[96];
+              snprintf(b, sizeof(b), " %s %.1f (%u)", kt[i].name, kt[i].ms, kt[i].launches);
+              line += b;
+              sum += kt[i].ms;
+            }
+            fprintf(stderr, "%s | sum %.1f of the call's %.1f\n", line.c_str(), sum, ms_dcall);
+            (void)api.set_profiling(ctx, 0);
+          }
           for (auto& c : comp) c.unmap();
           if (rc_d == 0 && acc > 0) {  // the arena for the joined tile, sized while the cores are still decoding their share
             const double up = (double)total / (double)acc * 1.05;

@@ -20,7 +20,7 @@ for share in "$@"; do
     S=$(date +%s.%N)
     TBK_HYBRID_SHARE=$share TBK_TIMING=1 tiebrush_amd/_build/tiebrush -o $D/out.bam $D/in*.bam 2> $D/err.txt
     E=$(date +%s.%N)
-    grep -E "hybrid|host path|writer closed|device writer|written as|released|tiles" $D/err.txt
+    grep -E "hybrid|host path|writer closed|device writer|written as|released|tiles|device decode kernels" $D/err.txt
     python3 -c "print('share $share: wall %.3f s' % ($E - $S))"
   done
 done
