@@ -3,7 +3,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -153,23 +156,32 @@ bool fast_load(const std::vector<std::string>& paths, const std::vector<uint8_t>
         if (f >= k || !ok) break;
         FastTile::In& I = t.in[f];
         I.path = paths[f];
-        FILE* fp = fopen(paths[f].c_str(), "rb");
-        if (!fp) {
-          fail("cannot open " + paths[f]);
-          break;
+        // mapped, not read: the inflate tasks take the compressed bytes from the page cache where they lie (a read() into a buffer of
+        // the process's own is one more pass over the file, on the loader's critical path)
+        {
+          const int fd = open(paths[f].c_str(), O_RDONLY);
+          struct stat st;
+          if (fd < 0 || fstat(fd, &st) != 0) {
+            if (fd >= 0) close(fd);
+            fail("cannot open " + paths[f]);
+            break;
+          }
+          I.comp_n = (size_t)st.st_size;
+          I.comp = nullptr;
+          if (I.comp_n) {
+            void* q = mmap(nullptr, I.comp_n, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (q == MAP_FAILED) {
+              close(fd);
+              fail("cannot map " + paths[f]);
+              break;
+            }
+            (void)madvise(q, I.comp_n, MADV_SEQUENTIAL);
+            I.comp = (const uint8_t*)q;
+          }
+          close(fd);
         }
-        fseeko(fp, 0, SEEK_END);
-        const off_t sz = ftello(fp);
-        fseeko(fp, 0, SEEK_SET);
-        I.comp.resize(sz > 0 ? (size_t)sz : 0);
-        const bool rd = I.comp.empty() || fread(I.comp.data(), 1, I.comp.size(), fp) == I.comp.size();
-        fclose(fp);
-        if (!rd) {
-          fail("short read on " + paths[f]);
-          break;
-        }
-        const uint8_t* raw = I.comp.data();
-        const size_t n = I.comp.size();
+        const uint8_t* raw = I.comp;
+        const size_t n = I.comp_n;
         size_t off = 0, total = 0;
         while (off < n) {
           if (off + 18 > n || raw[off] != 0x1f || raw[off + 1] != 0x8b || raw[off + 2] != 8 || !(raw[off + 3] & 4)) {
@@ -221,6 +233,8 @@ bool fast_load(const std::vector<std::string>& paths, const std::vector<uint8_t>
   }
   if (total + total / 2 > mem_budget) {  // the inflated streams + the tile + the output would not fit: the streaming path takes it
     *fits = false;
+    for (auto& I : t.in)
+      if (I.comp) munmap(const_cast<uint8_t*>(I.comp), I.comp_n);
     t.in.clear();
     return true;
   }
@@ -304,18 +318,22 @@ bool fast_load(const std::vector<std::string>& paths, const std::vector<uint8_t>
           Member& m = *all[j];
           if (!m.isize) continue;
           FastTile::In& I = t.in[m.f];
-          if (!bgzf_inflate_member(I.comp.data() + m.cdata, m.clen, I.data + m.out_off, m.isize, m.crc)) fail("inflate failed or CRC32 mismatch in " + I.path);
+          if (!bgzf_inflate_member(I.comp + m.cdata, m.clen, I.data + m.out_off, m.isize, m.crc)) fail("inflate failed or CRC32 mismatch in " + I.path);
           else walk_member(m);
         }
       }
     });
     if (!ok) return false;
   }
-  for (size_t f = 0; f < k; ++f) std::vector<uint8_t>().swap(t.in[f].comp);
+  for (size_t f = 0; f < k; ++f) {
+    if (t.in[f].comp) munmap(const_cast<uint8_t*>(t.in[f].comp), t.in[f].comp_n);
+    t.in[f].comp = nullptr;
+  }
   t.ms_inflate = ms_since(t0);
   t0 = std::chrono::steady_clock::now();
   // ---- 3. index: the records of every input (field lengths checked as bam_read1 checks them), unplaced reads dropped ----
   std::atomic<size_t> n_fused{0};
+  std::vector<uint8_t> fused_file(k, 0);
   {
     std::atomic<size_t> nf{0};
     parallel(std::min<int>(threads, (int)k), [&]() {
@@ -370,19 +388,16 @@ bool fast_load(const std::vector<std::string>& paths, const std::vector<uint8_t>
               break;
             }
             uint64_t at = 0;
-            for (size_t i = 1; i < M.size(); ++i) {
-              memcpy(I.rec_off + at, slots[f] + M[i].slot0, (size_t)M[i].nrec * sizeof(uint64_t));
+            for (size_t i = 1; i < M.size(); ++i) {  // (where the member's offsets go: the copies are made below, by every worker)
+              M[i].ncig = at;
               at += M[i].nrec;
             }
             I.n_rec = (size_t)nrec;
             I.n_cig = ncig;
             n_fused.fetch_add(1);
-            big_free(slots[f]);
-            slots[f] = nullptr;
+            fused_file[f] = 1;
             continue;
           }
-          big_free(slots[f]);
-          slots[f] = nullptr;
         }
         // (a record takes at least 36 bytes: the index can be sized before the walk)
         I.rec_off = (uint64_t*)big_alloc(((n - p) / 36 + 1) * sizeof(uint64_t));
@@ -432,6 +447,24 @@ bool fast_load(const std::vector<std::string>& paths, const std::vector<uint8_t>
       }
     });
     if (!ok) return false;
+  }
+  {  // the members' offsets into their files' index: tasks of 64 members, whatever the number of inputs (the slot arrays are left to
+     // the process's end like the other large blocks: returning tens of megabytes per input page by page is not worth a core's time here)
+    std::vector<std::pair<uint32_t, uint32_t>> tasks;  // (file, first member)
+    for (size_t f = 0; f < k; ++f)
+      if (fused_file[f])
+        for (size_t i = 1; i < mem[f].size(); i += 64) tasks.emplace_back((uint32_t)f, (uint32_t)i);
+    std::atomic<size_t> nt{0};
+    parallel(threads, [&]() {
+      for (;;) {
+        const size_t q = nt.fetch_add(1);
+        if (q >= tasks.size()) break;
+        const uint32_t f = tasks[q].first;
+        const std::vector<Member>& M = mem[f];
+        for (size_t i = tasks[q].second; i < M.size() && i < (size_t)tasks[q].second + 64; ++i)
+          memcpy(t.in[f].rec_off + M[i].ncig, slots[f] + M[i].slot0, (size_t)M[i].nrec * sizeof(uint64_t));
+      }
+    });
   }
   t.file_off.assign(k + 1, 0);
   std::vector<uint64_t> cig_base(k + 1, 0);

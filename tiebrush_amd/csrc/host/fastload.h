@@ -27,7 +27,8 @@ struct FastTile {
   // per input
   struct In {
     std::string path;
-    std::vector<uint8_t> comp;   // the file as it lies on disk
+    const uint8_t* comp = nullptr;  // the file as the page cache holds it (a private read-only mapping, gone once the members are inflated)
+    size_t comp_n = 0;
     uint8_t* data = nullptr;     // its inflated stream (malloc, not initialised)
     size_t data_n = 0;
     uint64_t* rec_off = nullptr;    // offset in `data` of every kept record's block_size field

@@ -442,14 +442,14 @@ int main(int argc, char* argv[]) {
         // The device's share of the compressed bytes: both sides should end together.  The device starts late — the HIP runtime takes
         // ~ 0.25 s to come up, the cores work alone meanwhile — and is then several times faster: with x of T bytes on the device,
         // t_ctx + x / R_dev = (T - x) / R_host.  Rates measured on an MI355X box with a 16-core quota (tools/scratch/e2e_long_r5.sh): the
-        // device side 4.3 GB/s of compressed BAM (upload, inflate, record index, SoA), a core 0.119 GB/s (inflate + index + SoA).
-        // 1.8 GB of input: 58 %; 7.1 GB: 70 %.  TBK_HYBRID_SHARE (per cent) overrides.
+        // device side 4.7 GB/s of compressed BAM (upload, inflate, record index, SoA), a core 0.18 GB/s (inflate with the record index
+        // riding along, SoA).  1.8 GB of input: 49 %; 7.1 GB: 62 %.  TBK_HYBRID_SHARE (per cent) overrides.
         const int host_threads = getenv("TBK_THREADS") ? nthreads : std::max(2, nthreads - 3);
         double share;
         if (getenv("TBK_HYBRID_SHARE")) {
           share = atof(getenv("TBK_HYBRID_SHARE")) / 100.0;
         } else {
-          const double T = (double)total / 1e9, r_dev = 4.3, r_host = 0.119 * host_threads, t_ctx = 0.25;
+          const double T = (double)total / 1e9, r_dev = 4.7, r_host = 0.18 * host_threads, t_ctx = 0.2;
           const double x = (T / r_host - t_ctx) / (1.0 / r_dev + 1.0 / r_host);
           share = std::min(0.9, std::max(0.2, x / T));
         }
