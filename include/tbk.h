@@ -412,6 +412,15 @@ int tbk_partial_stage_cands(tbk_ctx* ctx, const int64_t* key, const int64_t* ema
 int tbk_partial_stage_pack(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa_in* in, const tbk_groups_out* g, const int64_t* key,
                            const int64_t* mymeta, const int64_t* allcands, const int64_t* targets, uint32_t world, uint32_t first_fidx, int64_t* cuts,
                            int32_t* rows, uint32_t* cig_out, int64_t* tabx);
+/* (ABI version 7) -L across ranks: cmpFull (tiebrush.cpp:285-302) compares the MD strings behind the CIGARs, so the representatives'
+ * MD strings travel beside the rows.  tbk_partial_pack / tbk_partial_stage_pack take TBK_STRAT_FULL when `in` carries md_off / md /
+ * md_has (the key word then hashes CIGAR and MD; nothing is packed from g_key).  tbk_partial_pack_md, after either: md_out = the MD bytes
+ * of the local groups' representatives in group order, row word 11 = length | (has an MD tag) << 31, md_tab[world] = bytes per
+ * destination (tab = the [world][3] table the pack wrote: tabx starts with it).  All arrays device memory; nothing is read back. */
+int tbk_partial_pack_md(tbk_ctx* ctx, const tbk_soa_in* in, const tbk_groups_out* g, const int64_t* tab, uint32_t world, int32_t* rows, uint8_t* md_out,
+                        int64_t* md_tab);
+/* md_off[n2 + 1] / md_has[n2] of received rows (their word 11): the MD columns of the tile tbk_partial_unpack describes */
+int tbk_partial_unpack_md(tbk_ctx* ctx, const int32_t* rows, uint32_t n2, uint32_t* md_off, uint8_t* md_has);
 /* Received rows (one run per source rank, each in that rank's output order) -> the SoA arrays of a tile whose "files" are the
  * source ranks, all flagged tbmerged: flag 0, mapq 255, NH absent, cig_off (n2 + 1 entries), yc_in / yx_in / yd_in = the
  * partial's YC / YX / YD, prio_hi = effective end, prio_lo = global file << 32 | index in file.  tbk_collapse_tile on that
@@ -429,6 +438,10 @@ int tbk_partial_unpack(tbk_ctx* ctx, const int32_t* rows, uint32_t n2, int32_t* 
  * workgroup merges — in both cases tbk_partial_unpack + tbk_collapse_tile take the tile. */
 int tbk_partial_reduce(tbk_ctx* ctx, const tbk_collapse_opts* opts, const int32_t* rows, uint32_t n2, const uint32_t* run_off,
                        uint32_t n_runs, const uint32_t* cig, tbk_groups_out* out, tbk_cov_in* view);
+/* (ABI version 7) the same with the rows' MD strings (`md`: the bytes in row order, lengths in row word 11; NULL unless opts->strategy
+ * is TBK_STRAT_FULL, which tbk_partial_reduce itself refuses) */
+int tbk_partial_reduce_md(tbk_ctx* ctx, const tbk_collapse_opts* opts, const int32_t* rows, uint32_t n2, const uint32_t* run_off, uint32_t n_runs,
+                          const uint32_t* cig, const uint8_t* md, tbk_groups_out* out, tbk_cov_in* view);
 
 #ifdef __cplusplus
 }

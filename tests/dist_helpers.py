@@ -67,6 +67,9 @@ def split_tile(tile, parts):
                     cig=tile.cig[c0:c1].copy())
         if tile.yc_in is not None:
             t.yc_in, t.yx_in, t.yd_in = tile.yc_in[lo:hi].copy(), tile.yx_in[lo:hi].copy(), tile.yd_in[lo:hi].copy()
+        if tile.md_off is not None:       # -L: the MD strings of the rank's records
+            m0, m1 = int(tile.md_off[lo]), int(tile.md_off[hi])
+            t.md_off, t.md, t.md_has = (tile.md_off[lo:hi + 1] - tile.md_off[lo]).astype(np.uint32), tile.md[m0:m1].copy(), tile.md_has[lo:hi].copy()
         tiles.append(t)
         first.append(f0)
     return tiles, first

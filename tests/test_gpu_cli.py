@@ -505,3 +505,33 @@ def test_device_writer_equals_host_writer_on_the_option_matrix(tmp_path, profile
 def test_writer_option_is_checked():
     r = subprocess.run([os.path.join(BIN, "tiebrush"), "--writer", "tape", "-o", "/tmp/x.bam", os.path.join(GOLDEN, "t12.bam")], capture_output=True, text=True)
     assert r.returncode != 0 and "--writer takes host or device" in r.stderr
+
+
+def test_tiebrush_ranks_full_strategy_equals_single_gpu(tmp_path):
+    """`tiebrush --ranks 2 -L`: grouping by CIGAR and MD across ranks — the representatives' MD strings travel beside the partial rows
+    (tbk_partial_pack_md) and the owner compares them like cmpFull (tiebrush.cpp:285-302).  Four inputs whose records carry MD strings
+    that differ inside a CIGAR group (and records without the tag), two per rank: the records equal the single-GPU `tiebrush -L` byte
+    for byte, -L groups differently from the default; and the four t2 samples of the reference the same way"""
+    from tiebrush_amd import bamio
+    rng = np.random.default_rng(43)
+    variants = [b"MDZ100\0", b"MDZ50A49\0", b"MDZ10^AC90\0", b"MDZ\0", b""]
+    hdr = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chr1\tLN:100000\n"
+    ins = []
+    for f in range(4):
+        pos = np.sort(rng.integers(100, 400, 3000))
+        recs = b"".join(bamio.encode_record(0, int(p), 16 * int(rng.integers(0, 2)), 60, [100 << 4] if rng.integers(0, 4) else [40 << 4, (200 << 4) | 3, 60 << 4],
+                                            b"r%d_%d" % (f, i), aux=b"NHC\x01" + variants[int(rng.integers(0, 5))], l_seq=0) for i, p in enumerate(pos))
+        path = str(tmp_path / ("md%d.bam" % f))
+        bamio.write_bam(path, hdr, ["chr1"], [100000], recs)
+        ins.append(path)
+    env = dict(os.environ, TBK_RANKS_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for tag, inputs in (("synthetic", ins), ("t2", sample_paths("t2")[:4])):
+        one, two, dflt = str(tmp_path / (tag + "_one.bam")), str(tmp_path / (tag + "_two.bam")), str(tmp_path / (tag + "_default.bam"))
+        _run([os.path.join(BIN, "tiebrush"), "-L", "-o", one] + inputs)
+        _run([os.path.join(BIN, "tiebrush"), "-o", dflt] + inputs)
+        r = subprocess.run([os.path.join(BIN, "tiebrush"), "--ranks", "2", "-L", "-o", two] + inputs, capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        a, b, c = bamio.read_bam(one, keep_aux=True), bamio.read_bam(two, keep_aux=True), bamio.read_bam(dflt)
+        assert a.n == b.n and (a.n > c.n if tag == "synthetic" else a.n >= c.n)      # (MD splits groups the CIGAR alone joins)
+        for i in range(a.n):
+            assert bamio.record_bytes(a, i) == bamio.record_bytes(b, i), (tag, i)

@@ -498,3 +498,41 @@ def test_lists_hand_a_long_chain_of_bundles_to_the_rounds():
     check_against_flat(res, tile, flat)
     assert all(st["cut_rounds"] >= 1 for st in sts), sts          # the lists gave up, the rounds settled the cut
     assert res[0].n_groups > 0 and res[1].n_groups > 0
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("path", [None, "general"])
+def test_loopback_full_strategy_with_md(world, path, bam_loader, monkeypatch):
+    """-L across ranks: the golden t2 samples (MD tags on every record) sharded over virtual ranks, device-resident — the MD strings
+    ride beside the partial rows, the owner's merge compares CIGAR then MD — against the flat oracle run with strategy FULL; with the
+    owner's merge-reduce (tbk_partial_reduce_md) and with the general path (the PART collapse of a tile that carries the MD columns)"""
+    import torch
+    from helpers import sample_paths
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import api, dist, soa
+    if path:
+        monkeypatch.setenv("TBK_PARTIAL_REDUCE", "0")
+    bams = [bam_loader(p, keep_md=True) for p in sample_paths("t2")[:6]]
+    tile = soa.tile_from_bams(bams, with_md=True)
+    # (the fixtures' reads are error-free: one MD string per CIGAR.  Give the records MD strings that differ inside a CIGAR group —
+    # three variants and "no MD tag" —, so that the MD compare decides groups, their order inside a tie and the collisions of hashed keys)
+    rng = np.random.default_rng(41)
+    n = tile.n_records
+    variants = [b"100", b"50A49", b"10^AC90", b""]
+    pick = rng.integers(0, 5, n)
+    mds = [variants[v] if v < 4 else None for v in pick]
+    lens = np.array([0 if m is None else len(m) for m in mds], np.uint32)
+    tile.md_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+    tile.md = np.frombuffer(b"".join(m for m in mds if m), dtype=np.uint8).copy()
+    tile.md_has = np.array([0 if m is None else 1 for m in mds], np.uint8)
+    flat = orc.collapse(tile, strategy=STRAT["full"])
+    assert flat["n_groups"] > orc.collapse(tile)["n_groups"]
+    tiles, first = split_tile(tile, world)
+    dtiles = [api.to_device(t, "cuda:0") for t in tiles]
+    sts = [dict() for _ in range(world)]
+    res = dist.run_loopback(DeviceCompute(), dtiles, first, strategy="full", device_chain=True, per_rank=[dict(stats=sts[r]) for r in range(world)])
+    for r in res:
+        for f in ("tid", "start", "end", "rep_fidx", "rep_idx", "yc", "yx", "yd"):
+            v = getattr(r, f)
+            setattr(r, f, v.cpu().numpy() if isinstance(v, torch.Tensor) else v)
+    check_against_flat(res, tile, flat)

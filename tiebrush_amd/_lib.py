@@ -26,7 +26,8 @@ SYMBOLS = ["tbk_abi_version", "tbk_create", "tbk_destroy", "tbk_strerror", "tbk_
            "tbk_get_stream", "tbk_set_profiling", "tbk_set_debug", "tbk_kernel_times", "tbk_host_alloc", "tbk_host_free",
            "tbk_collapse_opts_default", "tbk_collapse_tile", "tbk_collapse_finish_yd", "tbk_coverage_tile", "tbk_sample_tile",
            "tbk_groups_to_cov_in", "tbk_bgzf_inflate", "tbk_bam_decode", "tbk_bam_records", "tbk_bam_release", "tbk_shard_prepare", "tbk_shard_probe_max", "tbk_shard_probe_next",
-           "tbk_shard_pack", "tbk_shard_unpack", "tbk_partial_keys", "tbk_partial_pack", "tbk_partial_unpack", "tbk_partial_reduce", "tbk_unpack_tile", "tbk_tile_join", "tbk_reserve_tile", "tbk_bgzf_deflate", "tbk_bam_encode", "tbk_partial_stage_keys", "tbk_partial_stage_cands", "tbk_partial_stage_pack"]
+           "tbk_shard_pack", "tbk_shard_unpack", "tbk_partial_keys", "tbk_partial_pack", "tbk_partial_unpack", "tbk_partial_reduce", "tbk_unpack_tile", "tbk_tile_join", "tbk_reserve_tile", "tbk_bgzf_deflate", "tbk_bam_encode", "tbk_partial_stage_keys", "tbk_partial_stage_cands", "tbk_partial_stage_pack",
+           "tbk_partial_pack_md", "tbk_partial_unpack_md", "tbk_partial_reduce_md"]
 
 
 class CollapseOpts(C.Structure):
@@ -147,6 +148,9 @@ def load():
     L.tbk_partial_stage_keys.argtypes = [_P, C.POINTER(SoaIn), C.POINTER(GroupsOut), _P, _P, C.c_uint32, C.c_int64, _P]
     L.tbk_partial_stage_cands.argtypes = [_P, _P, _P, C.c_uint32, _P, C.c_uint32, _P, _P]
     L.tbk_partial_stage_pack.argtypes = [_P, C.POINTER(CollapseOpts), C.POINTER(SoaIn), C.POINTER(GroupsOut), _P, _P, _P, _P, C.c_uint32, C.c_uint32, _P, _P, _P, _P]
+    L.tbk_partial_pack_md.argtypes = [_P, C.POINTER(SoaIn), C.POINTER(GroupsOut), _P, C.c_uint32, _P, _P, _P]
+    L.tbk_partial_unpack_md.argtypes = [_P, _P, C.c_uint32, _P, _P]
+    L.tbk_partial_reduce_md.argtypes = [_P, C.POINTER(CollapseOpts), _P, C.c_uint32, _P, C.c_uint32, _P, _P, C.POINTER(GroupsOut), C.POINTER(CovIn)]
     L.tbk_bgzf_deflate.argtypes = [_P, _P, C.c_uint64, C.c_int, _P, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64)]
     L.tbk_bgzf_deflate.restype = C.c_int
     L.tbk_bam_encode.argtypes = [_P, C.POINTER(EncIn), _P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]

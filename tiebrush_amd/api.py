@@ -691,7 +691,33 @@ class Context:
                                               *[C.c_void_p(bufs[name].data_ptr()) for name, _, _ in spec]), "tbk_partial_unpack")
         return {name: bufs[name][:cnt] for name, _, cnt in spec}
 
-    def partial_reduce(self, rows, run_off, cig, out=None, want_view=True, opts=None, **kw):
+    def partial_pack_md(self, tile: SoATile, fin, tab, world, rows):
+        """tbk_partial_pack_md (-L): (MD bytes of the local groups' representatives in group order [uint8], bytes per destination [world]
+        int64) — device tensors; the rows' word 11 is written.  tab: the [world, 3] table of the pack (tabx starts with it)."""
+        torch = _torch()
+        ng = int(fin["n_groups"])
+        nmd = _numel(tile.md)
+        md_out = torch.empty(max(nmd, 1), dtype=torch.uint8, device=self._dev())
+        md_tab = torch.empty(world, dtype=torch.int64, device=self._dev())
+        with self._queued_on_torch_stream():
+            self._check(self.L.tbk_partial_pack_md(self.h, C.byref(fin["_soa"]), C.byref(fin["_struct"]), C.c_void_p(tab.data_ptr()), int(world),
+                                                   C.c_void_p(rows.data_ptr()) if ng else None, C.c_void_p(md_out.data_ptr()), C.c_void_p(md_tab.data_ptr())),
+                        "tbk_partial_pack_md")
+        return md_out, md_tab
+
+    def partial_unpack_md(self, rows):
+        """tbk_partial_unpack_md: (md_off [n2 + 1] uint32 as int32 tensor, md_has [n2] uint8) of received rows"""
+        torch = _torch()
+        n2 = int(rows.shape[0])
+        md_off = torch.empty(n2 + 1, dtype=torch.int32, device=self._dev())
+        md_has = torch.empty(max(n2, 1), dtype=torch.uint8, device=self._dev())
+        self._order_after_torch(True)
+        rows = rows.contiguous()
+        self._check(self.L.tbk_partial_unpack_md(self.h, C.c_void_p(rows.data_ptr()) if n2 else None, n2, C.c_void_p(md_off.data_ptr()),
+                                                 C.c_void_p(md_has.data_ptr())), "tbk_partial_unpack_md")
+        return md_off, md_has[:n2]
+
+    def partial_reduce(self, rows, run_off, cig, out=None, want_view=True, opts=None, md=None, **kw):
         """tbk_partial_reduce: the owner's merge-reduce of the received partial rows (torch int32 [n2, 12]; run_off = host run
         boundaries [R + 1]; cig = the CIGAR words as received).  Returns the usual collapse dict (rep = ROW index of the
         representative) plus "view" (DeviceCovView of the reduced groups, valid until the next call)."""
@@ -710,11 +736,12 @@ class Context:
         g = _lib.GroupsOut(_lib.TBK_MEM_DEVICE, cap, *[bufs[name].data_ptr() for name, _ in spec], None, None, None, 0, 0)
         v = _lib.CovIn()
         self._order_after_torch(True)
-        self._check(self.L.tbk_partial_reduce(self.h, C.byref(o), C.c_void_p(rows.data_ptr()) if n2 else None, n2, ro.ctypes.data, len(ro) - 1,
-                                              C.c_void_p(cig.data_ptr()) if cig is not None and cig.numel() else None, C.byref(g),
-                                              C.byref(v) if want_view else None), "tbk_partial_reduce")
+        self._check(self.L.tbk_partial_reduce_md(self.h, C.byref(o), C.c_void_p(rows.data_ptr()) if n2 else None, n2, ro.ctypes.data, len(ro) - 1,
+                                                 C.c_void_p(cig.data_ptr()) if cig is not None and cig.numel() else None,
+                                                 C.c_void_p(md.data_ptr()) if md is not None and md.numel() else None, C.byref(g),
+                                                 C.byref(v) if want_view else None), "tbk_partial_reduce")
         m = int(g.n_groups)
-        res = dict(n_groups=m, n_passed=n2, _bufs=bufs, _struct=g, _keep=[rows, cig, ro])
+        res = dict(n_groups=m, n_passed=n2, _bufs=bufs, _struct=g, _keep=[rows, cig, ro, md])
         res.update({name: bufs[name][:m] for name, _ in spec})
         if want_view:
             res["view"] = DeviceCovView(v, int(v.n_records), int(v.n_cigar_ops))

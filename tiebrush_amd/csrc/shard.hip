@@ -665,7 +665,8 @@ extern "C" int tbk_partial_keys(tbk_ctx* ctx, const tbk_soa_in* in, const tbk_gr
 extern "C" int tbk_partial_pack(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_in* in, const tbk_groups_out* g, const int64_t* key,
                                 const int64_t* cuts, uint32_t world, uint32_t first_fidx, int32_t* rows, uint32_t* cig_out, int64_t* tab) {
   if (!ctx || !o || !in || !g || !tab || world == 0) return TBK_EINVAL;
-  if (o->strategy < 0 || o->strategy > 3 || o->strategy == TBK_STRAT_FULL) return TBK_EUNSUPPORTED;  // (no MD tags in a partial)
+  if (o->strategy < 0 || o->strategy > 3) return TBK_EUNSUPPORTED;
+  if (o->strategy == TBK_STRAT_FULL && in->n_records && (!in->md_off || !in->md_has)) return TBK_EINVAL;  // (-L: the MD strings ride along, tbk_partial_pack_md)
   if (in->mem != TBK_MEM_DEVICE || g->mem != TBK_MEM_DEVICE || in->n_files == 0 || in->n_files > 65535 || !in->file_off) return TBK_EINVAL;
   const uint32_t ng = g->n_groups;
   if (ng && (!key || !rows || !cig_out || !g->rep || !g->yc || !g->yx || !g->yd || !g->rep_effend)) return TBK_EINVAL;
@@ -684,7 +685,8 @@ extern "C" int tbk_partial_pack(tbk_ctx* ctx, const tbk_collapse_opts* o, const 
   if (!woff) return TBK_ENOMEM;
   uint32_t* d_fo = nullptr;
   TBK_TRY(shard_upload_file_off(ctx, in->file_off, in->n_files, &d_fo));
-  if (ng) TBK_LAUNCH(ctx, "partial_ncig", partial_ncig_k, cdiv(ng, SH_B), SH_B, 0, ng, g->rep, in->cig_off, g->g_key, cnt, cfirst);
+  const uint64_t* pk_key = o->strategy == TBK_STRAT_FULL ? nullptr : g->g_key;  // (-L: the key describes no alignment by itself, MD is part of it)
+  if (ng) TBK_LAUNCH(ctx, "partial_ncig", partial_ncig_k, cdiv(ng, SH_B), SH_B, 0, ng, g->rep, in->cig_off, pk_key, cnt, cfirst);
   TBK_TRY(tbk_exscan_u32(ctx, cnt, woff, ng, sc + 21));
   TBK_LAUNCH(ctx, "partial_table", partial_table_k, cdiv(world, 64), 64, 0, ng, world, key, cuts, woff, sc + 21, (long long*)tab);
   if (ng) {
@@ -700,6 +702,9 @@ extern "C" int tbk_partial_pack(tbk_ctx* ctx, const tbk_collapse_opts* o, const 
     I.nh = in->nh;
     I.cig_off = in->cig_off;
     I.cig = in->cig;
+    I.md_off = in->md_off;
+    I.md = in->md;
+    I.md_has = in->md_has;
     ColOpt O{};
     O.strategy = o->strategy;
     O.max_nh = o->max_nh;
@@ -710,7 +715,7 @@ extern "C" int tbk_partial_pack(tbk_ctx* ctx, const tbk_collapse_opts* o, const 
     O.hash_mask = ctx->dbg.hash_mask;
     TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
     TBK_LAUNCH(ctx, "partial_rows", partial_rows_k, cdiv(ng, SH_B), SH_B, 0, ng, in->n_files, first_fidx, I, O, g->rep, g->yc, g->yx, g->yd,
-               g->rep_effend, cfirst, cnt, woff, g->g_key, rows, cig_out, ctx->d_err);
+               g->rep_effend, cfirst, cnt, woff, pk_key, rows, cig_out, ctx->d_err);
     uint32_t eb = 0;
     TBK_TRY(tbk_sync_err(ctx, &eb));
     if (eb) return tbk_derr_to_status(ctx, eb);
@@ -953,7 +958,8 @@ extern "C" int tbk_partial_stage_pack(tbk_ctx* ctx, const tbk_collapse_opts* o, 
                                       const int64_t* mymeta, const int64_t* allcands, const int64_t* targets, uint32_t world, uint32_t first_fidx,
                                       int64_t* cuts, int32_t* rows, uint32_t* cig_out, int64_t* tabx) {
   if (!ctx || !o || !in || !g || !tabx || !mymeta || world == 0 || world > 64) return TBK_EINVAL;
-  if (o->strategy < 0 || o->strategy > 3 || o->strategy == TBK_STRAT_FULL) return TBK_EUNSUPPORTED;  // (no MD tags in a partial)
+  if (o->strategy < 0 || o->strategy > 3) return TBK_EUNSUPPORTED;
+  if (o->strategy == TBK_STRAT_FULL && in->n_records && (!in->md_off || !in->md_has)) return TBK_EINVAL;  // (-L: the MD strings ride along, tbk_partial_pack_md)
   if (in->mem != TBK_MEM_DEVICE || g->mem != TBK_MEM_DEVICE || in->n_files == 0 || in->n_files > 65535 || !in->file_off) return TBK_EINVAL;
   const uint32_t ng = g->n_groups;
   if (ng && (!key || !rows || !cig_out || !g->rep || !g->yc || !g->yx || !g->yd || !g->rep_effend)) return TBK_EINVAL;
@@ -979,7 +985,8 @@ extern "C" int tbk_partial_stage_pack(tbk_ctx* ctx, const tbk_collapse_opts* o, 
   if (!woff || !tab) return TBK_ENOMEM;
   uint32_t* d_fo = nullptr;
   TBK_TRY(shard_upload_file_off(ctx, in->file_off, in->n_files, &d_fo));
-  if (ng) TBK_LAUNCH(ctx, "partial_ncig", partial_ncig_k, cdiv(ng, SH_B), SH_B, 0, ng, g->rep, in->cig_off, g->g_key, cnt, cfirst);
+  const uint64_t* pk_key = o->strategy == TBK_STRAT_FULL ? nullptr : g->g_key;  // (-L: the key describes no alignment by itself, MD is part of it)
+  if (ng) TBK_LAUNCH(ctx, "partial_ncig", partial_ncig_k, cdiv(ng, SH_B), SH_B, 0, ng, g->rep, in->cig_off, pk_key, cnt, cfirst);
   TBK_TRY(tbk_exscan_u32(ctx, cnt, woff, ng, sc + 21));
   TBK_LAUNCH(ctx, "partial_table", partial_table_k, cdiv(world, 64), 64, 0, ng, world, key, cuts, woff, sc + 21, tab);
   if (ng) {
@@ -995,6 +1002,9 @@ extern "C" int tbk_partial_stage_pack(tbk_ctx* ctx, const tbk_collapse_opts* o, 
     I.nh = in->nh;
     I.cig_off = in->cig_off;
     I.cig = in->cig;
+    I.md_off = in->md_off;
+    I.md = in->md;
+    I.md_has = in->md_has;
     ColOpt O{};
     O.strategy = o->strategy;
     O.max_nh = o->max_nh;
@@ -1004,10 +1014,93 @@ extern "C" int tbk_partial_stage_pack(tbk_ctx* ctx, const tbk_collapse_opts* o, 
     O.seed = TBK_KEY_SEED0;
     O.hash_mask = ctx->dbg.hash_mask;
     TBK_LAUNCH(ctx, "partial_rows", partial_rows_k, cdiv(ng, SH_B), SH_B, 0, ng, in->n_files, first_fidx, I, O, g->rep, g->yc, g->yx, g->yd,
-               g->rep_effend, cfirst, cnt, woff, g->g_key, rows, cig_out, ctx->d_err);
+               g->rep_effend, cfirst, cnt, woff, pk_key, rows, cig_out, ctx->d_err);
   }
   TBK_LAUNCH(ctx, "partial_tabx", partial_tabx_k, cdiv(world * 3 + 1, 64), 64, 0, world, tab, mymeta, d_flags, ctx->d_err, (long long*)tabx);
   return tbk_check_launch(ctx, "partial_stage_pack");
+}
+
+// ---- -L across ranks: the MD strings of the representatives travel beside the rows (ABI 7) -------------------------------------
+namespace {
+__global__ void partial_mdlen_k(uint32_t ng, const uint32_t* __restrict__ rep, const uint32_t* __restrict__ md_off, const uint8_t* __restrict__ md_has,
+                                uint32_t* __restrict__ len) {
+  const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o > ng) return;
+  uint32_t l = 0;
+  if (o < ng) {
+    const uint32_t r = rep[o];
+    l = md_has[r] ? md_off[r + 1] - md_off[r] : 0u;
+  }
+  len[o] = l;
+}
+// the bytes in group order; row word 11 = length | "has an MD tag" << 31 (an empty MD string is not an absent one: cmpFull, tiebrush.cpp:285-302)
+__global__ void partial_mdcopy_k(uint32_t ng, const uint32_t* __restrict__ rep, const uint32_t* __restrict__ md_off, const uint8_t* __restrict__ md,
+                                 const uint8_t* __restrict__ md_has, const uint32_t* __restrict__ moff, int32_t* __restrict__ rows, uint8_t* __restrict__ out) {
+  const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= ng) return;
+  const uint32_t r = rep[o];
+  const uint32_t has = md_has[r];
+  const uint32_t m0 = md_off[r], l = has ? md_off[r + 1] - m0 : 0u;
+  rows[(size_t)o * TBK_PARTIAL_ROW + 11] = (int32_t)(l | (has ? 0x80000000u : 0u));
+  const uint32_t w = moff[o];
+  for (uint32_t q = 0; q < l; ++q) out[w + q] = md[m0 + q];
+}
+__global__ void partial_mdtab_k(uint32_t world, uint32_t ng, const long long* __restrict__ tab, const uint32_t* __restrict__ moff, const uint64_t* __restrict__ total,
+                                long long* __restrict__ md_tab) {
+  const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= world) return;
+  const uint32_t a = (uint32_t)tab[d * 3], b = a + (uint32_t)tab[d * 3 + 1];
+  const uint64_t wa = a < ng ? moff[a] : *total, wb = b < ng ? moff[b] : *total;
+  md_tab[d] = (long long)(wb - wa);
+}
+__global__ void partial_mdlen2_k(uint32_t n2, const int32_t* __restrict__ rows, uint32_t* __restrict__ len, uint8_t* __restrict__ has) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > n2) return;
+  const uint32_t w = j < n2 ? (uint32_t)rows[(size_t)j * TBK_PARTIAL_ROW + 11] : 0u;
+  len[j] = w & 0x7FFFFFFFu;
+  if (j < n2) has[j] = (uint8_t)(w >> 31);
+}
+}  // namespace
+
+extern "C" int tbk_partial_pack_md(tbk_ctx* ctx, const tbk_soa_in* in, const tbk_groups_out* g, const int64_t* tab, uint32_t world, int32_t* rows,
+                                   uint8_t* md_out, int64_t* md_tab) {
+  if (!ctx || !in || !g || !tab || !md_tab || world == 0) return TBK_EINVAL;
+  if (in->mem != TBK_MEM_DEVICE || g->mem != TBK_MEM_DEVICE) return TBK_EINVAL;
+  const uint32_t ng = g->n_groups;
+  if (ng && (!in->md_off || !in->md_has || !g->rep || !rows || !md_out)) return TBK_EINVAL;
+  TBK_HIP(hipSetDevice(ctx->device));
+  tbk_prof_begin_call(ctx);
+  struct ProfEnd {
+    tbk_ctx* c;
+    ~ProfEnd() { tbk_prof_end_call(c); }
+  } prof_end{ctx};
+  TBK_TRY(tbk_ws_reserve(ctx, (size_t)ng * 12 + ((size_t)1 << 20)));
+  uint32_t* len = ws_alloc<uint32_t>(ctx, (size_t)ng + 1);
+  uint32_t* moff = ws_alloc<uint32_t>(ctx, (size_t)ng + 1);
+  if (!len || !moff) return TBK_ENOMEM;
+  uint64_t* sc = ctx->d_scalars;
+  TBK_LAUNCH(ctx, "partial_md", partial_mdlen_k, cdiv((uint64_t)ng + 1, SH_B), SH_B, 0, ng, g->rep, in->md_off, in->md_has, len);
+  TBK_TRY(tbk_exscan_u32(ctx, len, moff, ng + 1, sc + 22));
+  if (ng) TBK_LAUNCH(ctx, "partial_md", partial_mdcopy_k, cdiv(ng, SH_B), SH_B, 0, ng, g->rep, in->md_off, in->md, in->md_has, moff, rows, md_out);
+  TBK_LAUNCH(ctx, "partial_md", partial_mdtab_k, cdiv(world, 64), 64, 0, world, ng, (const long long*)tab, moff, sc + 22, (long long*)md_tab);
+  return tbk_check_launch(ctx, "partial_pack_md");
+}
+
+extern "C" int tbk_partial_unpack_md(tbk_ctx* ctx, const int32_t* rows, uint32_t n2, uint32_t* md_off, uint8_t* md_has) {
+  if (!ctx || !md_off || (n2 && (!rows || !md_has))) return TBK_EINVAL;
+  TBK_HIP(hipSetDevice(ctx->device));
+  tbk_prof_begin_call(ctx);
+  struct ProfEnd {
+    tbk_ctx* c;
+    ~ProfEnd() { tbk_prof_end_call(c); }
+  } prof_end{ctx};
+  TBK_TRY(tbk_ws_reserve(ctx, (size_t)n2 * 8 + ((size_t)1 << 20)));
+  uint32_t* len = ws_alloc<uint32_t>(ctx, (size_t)n2 + 1);
+  if (!len) return TBK_ENOMEM;
+  TBK_LAUNCH(ctx, "partial_md", partial_mdlen2_k, cdiv((uint64_t)n2 + 1, SH_B), SH_B, 0, n2, rows, len, md_has);
+  TBK_TRY(tbk_exscan_u32(ctx, len, md_off, n2 + 1, ctx->d_scalars + 22));
+  TBK_HIP(hipStreamSynchronize(ctx->stream));
+  return tbk_check_launch(ctx, "partial_unpack_md");
 }
 
 extern "C" int tbk_partial_unpack(tbk_ctx* ctx, const int32_t* rows, uint32_t n2, int32_t* tid, int32_t* pos, uint16_t* flag, uint8_t* mapq,
@@ -1040,8 +1133,14 @@ extern "C" int tbk_partial_unpack(tbk_ctx* ctx, const int32_t* rows, uint32_t n2
 // The owner's reduce-by-key of the partials it received (wgroup.hip, tbk_partial_reduce_device): arguments checked here.
 extern "C" int tbk_partial_reduce(tbk_ctx* ctx, const tbk_collapse_opts* o, const int32_t* rows, uint32_t n2, const uint32_t* run_off,
                                   uint32_t n_runs, const uint32_t* cig, tbk_groups_out* out, tbk_cov_in* view) {
+  if (o && o->strategy == TBK_STRAT_FULL) return TBK_EUNSUPPORTED;  // (-L: tbk_partial_reduce_md, the MD strings must come along)
+  return tbk_partial_reduce_md(ctx, o, rows, n2, run_off, n_runs, cig, nullptr, out, view);
+}
+
+extern "C" int tbk_partial_reduce_md(tbk_ctx* ctx, const tbk_collapse_opts* o, const int32_t* rows, uint32_t n2, const uint32_t* run_off,
+                                     uint32_t n_runs, const uint32_t* cig, const uint8_t* md, tbk_groups_out* out, tbk_cov_in* view) {
   if (!ctx || !o || !out || !run_off || n_runs == 0) return TBK_EINVAL;
-  if (o->strategy < 0 || o->strategy > 3 || o->strategy == TBK_STRAT_FULL) return TBK_EUNSUPPORTED;
+  if (o->strategy < 0 || o->strategy > 3) return TBK_EUNSUPPORTED;
   if (run_off[0] != 0 || run_off[n_runs] != n2) return TBK_EINVAL;
   if (out->mem != TBK_MEM_DEVICE || (n2 && (!rows || !out->rep || !out->yc || !out->yx || !out->yd))) return TBK_EINVAL;
   if (!tbk_window_supported(n_runs)) return TBK_EUNSUPPORTED;
@@ -1058,6 +1157,16 @@ extern "C" int tbk_partial_reduce(tbk_ctx* ctx, const tbk_collapse_opts* o, cons
     view->mem = TBK_MEM_DEVICE;
   }
   if (n2 == 0) return 0;
-  TBK_TRY(tbk_ws_reserve(ctx, (size_t)n2 * 120 + ((size_t)8 << 20)));
-  return tbk_partial_reduce_device(ctx, o->strategy, rows, n2, run_off, n_runs, cig, out, view);
+  TBK_TRY(tbk_ws_reserve(ctx, (size_t)n2 * 128 + ((size_t)8 << 20)));
+  uint32_t* md_off = nullptr;
+  uint8_t* md_has = nullptr;
+  if (o->strategy == TBK_STRAT_FULL) {  // the rows' MD strings: lengths in word 11, bytes in row order
+    uint32_t* len = ws_alloc<uint32_t>(ctx, (size_t)n2 + 1);
+    md_off = ws_alloc<uint32_t>(ctx, (size_t)n2 + 1);
+    md_has = ws_alloc<uint8_t>(ctx, (size_t)n2 + 1);
+    if (!len || !md_off || !md_has) return TBK_ENOMEM;
+    TBK_LAUNCH(ctx, "partial_md", partial_mdlen2_k, cdiv((uint64_t)n2 + 1, SH_B), SH_B, 0, n2, rows, len, md_has);
+    TBK_TRY(tbk_exscan_u32(ctx, len, md_off, n2 + 1, ctx->d_scalars + 22));
+  }
+  return tbk_partial_reduce_device(ctx, o->strategy, rows, n2, run_off, n_runs, cig, out, view, md_off, md, md_has);
 }

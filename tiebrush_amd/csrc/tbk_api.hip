@@ -582,7 +582,7 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
       (!in->tid || !in->pos || !in->flag || !in->mapq || !in->strand || !in->nh || !in->cig_off || (in->n_cigar_ops && !in->cig)))
     return TBK_EINVAL;
   if (!out->rep || !out->yc || !out->yx || !out->yd) return TBK_EINVAL;
-  if (opts->strategy == TBK_STRAT_FULL && (!in->md_off || !in->md_has)) return TBK_EINVAL;
+  if (opts->strategy == TBK_STRAT_FULL && in->n_records && (!in->md_off || !in->md_has)) return TBK_EINVAL;
   if (opts->collapse_same && (!in->qname_hash || !in->qname_off || (in->n_records && !in->qname))) return TBK_EINVAL;  // -A compares names
   if ((in->prio_hi == nullptr) != (in->prio_lo == nullptr)) return TBK_EINVAL;
   bool any_tb = false;

@@ -48,4 +48,5 @@ inline bool tbk_yd_by_list(const tbk_ctx* ctx, uint32_t k) { return 2u * k <= 12
 // run in its rank's output order) in output order and reduce equal keys; see tbk_partial_reduce in include/tbk.h.  The arena
 // must be reserved by the caller.
 int tbk_partial_reduce_device(tbk_ctx* ctx, int strategy, const int32_t* rows, uint32_t n2, const uint32_t* run_off_host, uint32_t n_runs,
-                              const uint32_t* cig, tbk_groups_out* out, tbk_cov_in* view);
+                              const uint32_t* cig, tbk_groups_out* out, tbk_cov_in* view, const uint32_t* md_off = nullptr,
+                              const uint8_t* md = nullptr, const uint8_t* md_has = nullptr);  // (-L: the rows' MD strings as CSR)

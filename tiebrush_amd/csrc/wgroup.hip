@@ -2076,7 +2076,9 @@ static int wg_offsets_build(tbk_ctx* ctx, bool raw, const uint64_t* chi, const i
 }
 
 int tbk_partial_reduce_device(tbk_ctx* ctx, int strategy, const int32_t* rows, uint32_t n2, const uint32_t* run_off_host, uint32_t k,
-                              const uint32_t* cig, tbk_groups_out* out, tbk_cov_in* view) {
+                              const uint32_t* cig, tbk_groups_out* out, tbk_cov_in* view, const uint32_t* md_off, const uint8_t* md,
+                              const uint8_t* md_has) {
+  if (strategy == TBK_STRAT_FULL && !md_off) return TBK_EINVAL;
   if (k > PR_MAXRUNS) return TBK_EUNSUPPORTED;
   const uint32_t B = 256, m = n2;
   uint64_t* sc = ctx->d_scalars;
@@ -2135,6 +2137,9 @@ int tbk_partial_reduce_device(tbk_ctx* ctx, int strategy, const int32_t* rows, u
   I.pos = r_pos;
   I.cig_off = cig_off;
   I.cig = cig;
+  I.md_off = md_off;
+  I.md = md;
+  I.md_has = md_has;
   TBK_LAUNCH(ctx, "pr_merge", pr_merge_k, nw, PR_NT, 0, rows, off, k, nw, wbase, I, strategy, T, ctx->d_err);
   TBK_TRY(tbk_exscan_u32(ctx, T.wg_cnt, gbase, nw, sc + 1));
   uint32_t eb = 0;

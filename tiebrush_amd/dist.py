@@ -555,6 +555,8 @@ def _partials_rounds(compute, X, mark, on_dev, local_tile, fin, first_fidx, rank
     firsts = allmeta[:, N_SAMPLES + 1].astype(np.int64)
     if not np.array_equal(firsts, np.concatenate([[firsts[0]], firsts[0] + np.cumsum(ks)[:-1]])):
         raise ValueError("ranks must hold consecutive blocks of the input files, in rank order")
+    if bool(allmeta[:, N_SAMPLES + 2].any()) and strategy in ("full", 1):
+        raise ValueError("-L with carried fractional YC: the record shuffle carries no MD strings (run on one GPU)")
     if bool(allmeta[:, N_SAMPLES + 2].any()):
         # a carried fractional YC somewhere (or a count beyond 31 bits): sums across ranks would not keep the reference's order of
         # additions — every rank takes the record shuffle for this tile (the decision is collective: same data on all ranks)
@@ -610,19 +612,26 @@ def _partials_rounds(compute, X, mark, on_dev, local_tile, fin, first_fidx, rank
         stats["wire_bytes"] = int(cnt_rows.sum()) * PROW * 4 + int(cnt_words.sum()) * 4
         stats["wire_bytes_off_rank"] = stats["wire_bytes"] - (int(cnt_rows[rank]) * PROW * 4 + int(cnt_words[rank]) * 4)
     mark("pack")
+    mdb = None
+    if strategy in ("full", 1):                         # -L: the MD strings of the rows, in row order (the rows' word 11 says how long)
+        mdb, mdtab = compute.partial_pack_md(local_tile, fin, tab, world, rows)
+        mdc = mdtab.cpu().numpy().astype(np.int64)
     rrows, rcnt, rcig, _ = yield ("exchange_rows", (rows[:ng], cnt_rows, cigw[:int(cnt_words.sum())], cnt_words, cnt_rows.reshape(world, 1)))
+    rmd = None
+    if mdb is not None:
+        rmd, _ = yield ("all_to_all", (mdb[:int(mdc.sum())], mdc))
     mark("exchange")
-    return rrows, rcnt, rcig
+    return rrows, rcnt, rcig, rmd
 
 
-def _owner_reduce_fast(compute, X, rrows, file_off2, rcig, device_chain, strategy):
+def _owner_reduce_fast(compute, X, rrows, file_off2, rcig, device_chain, strategy, rmd=None):
     """tbk_partial_reduce on the rows as they arrived; None when it hands the tile to the general path (a hashed key word shared by two
     alignments, a pile-up of partials, more runs than a window takes)"""
     if not (hasattr(compute, "partial_reduce") and os.environ.get("TBK_PARTIAL_REDUCE", "1") != "0"):
         return None
     from ._lib import TbkError
     try:
-        return compute.partial_reduce(rrows, file_off2, rcig, want_view=device_chain, strategy=strategy)
+        return compute.partial_reduce(rrows, file_off2, rcig, want_view=device_chain, strategy=strategy, **(dict(md=rmd) if rmd is not None else {}))
     except TbkError as e:
         if e.status not in (-8, -4, -5):
             raise
@@ -645,7 +654,15 @@ def _partials_lists(compute, local_tile, fin, first_fidx, rank, world, strategy,
         targets, cands = compute.partial_stage_cands(key, emax, allmeta, world)
         allc = yield ("all_gather", cands)
     rows, cigw, tabx, _cuts = compute.partial_stage_pack(local_tile, fin, key, meta, allc, targets, world, first_fidx, strategy=strategy, **filters)
-    alltab = np.asarray(X.host((yield ("all_gather", tabx)))).reshape(world, world * 3 + 4).astype(np.int64)     # the one read-back
+    full = strategy in ("full", 1)
+    mdb = None
+    if full:            # -L: the representatives' MD strings ride beside the rows; their byte counts join the gathered table
+        mdb, mdtab = compute.partial_pack_md(local_tile, fin, tabx, world, rows)
+        tabx = _torch().cat([tabx, mdtab])
+    ntx = world * 3 + 4 + (world if full else 0)
+    alltab = np.asarray(X.host((yield ("all_gather", tabx)))).reshape(world, ntx).astype(np.int64)     # the one read-back
+    mdcnt = alltab[:, world * 3 + 4:] if full else None
+    alltab = alltab[:, :world * 3 + 4]
     if stats is not None:
         stats["collectives"] = stats.get("collectives", 0) + (3 if world > 1 else 2)
         stats["host_syncs"] = stats.get("host_syncs", 0) + 1
@@ -671,16 +688,24 @@ def _partials_lists(compute, local_tile, fin, first_fidx, rank, world, strategy,
         stats["collectives"] += 2
     big = (int(tab[:, :, 1].max()), int(tab[:, :, 2].max()))
     rrows, rcig = yield ("exchange_known", (rows[:ng], send_rows, recv_rows, cigw[:int(send_words.sum())], send_words, recv_words, big))
+    rmd = None
+    if full:
+        smd, rmdc = mdcnt[rank, :].copy(), mdcnt[:, rank].copy()
+        rmd, _ = yield ("exchange_known", (mdb[:int(smd.sum())], smd, rmdc, mdb[:0], np.zeros(world, np.int64), np.zeros(world, np.int64),
+                                           (int(mdcnt.max()), 0)))
+        if stats is not None:
+            stats["collectives"] += 1
+            stats["wire_bytes"] += int(smd.sum())
     mark("exchange")
     n2 = int(rrows.shape[0])
     file_off2 = np.zeros(world + 1, np.uint32)
     file_off2[1:] = np.cumsum(recv_rows)
     assert int(file_off2[-1]) == n2
-    fast = _owner_reduce_fast(compute, X, rrows, file_off2, rcig, device_chain, strategy)
+    fast = _owner_reduce_fast(compute, X, rrows, file_off2, rcig, device_chain, strategy, rmd)
     if stats is not None:
         stats["host_syncs"] += 1            # (the owner's reduce reads its group count back)
     if fast is None:
-        return ("general", rrows, recv_rows, rcig)
+        return ("general", rrows, recv_rows, rcig, rmd)
     T = _torch()
     g2 = int(fast["n_groups"])
     res = ShardResult(n_groups=g2, n_passed_local=n_pass, start=fast["g_start"], end=fast["g_end"], yc=fast["yc"], yx=fast["yx"], yd=fast["yd"],
@@ -717,11 +742,12 @@ def partials_collapse(compute, local_tile: SoATile, first_fidx: int, rank: int, 
     `stats` (dict, optional) receives wire_rows / wire_bytes of this rank's exchange."""
     if filters.get("store_frac") or filters.get("collapse_same"):
         raise ValueError("--store-frac and -A need the single-tile path's ordered passes: single-GPU only (DESIGN.md §7)")
-    if strategy in ("full", 1):
-        raise ValueError("-L (CIGAR + MD) is single-GPU only: neither partials nor shuffled rows carry MD tags")
     X = _xp(local_tile.tid)
     mark = getattr(compute, "mark", None) or (lambda _name: None)
     on_dev = _is_t(local_tile.tid) and hasattr(compute, "partial_keys")
+    full = strategy in ("full", 1)
+    if full and not (on_dev and hasattr(compute, "partial_pack_md")):
+        raise ValueError("-L (CIGAR + MD) across ranks needs device-resident tiles: the MD strings travel through tbk_partial_pack_md")
     k = local_tile.n_files
     # ---- 1. the ordinary single-GPU collapse of this rank's files ---------------------------------------------------------
     fin = local
@@ -749,9 +775,9 @@ def partials_collapse(compute, local_tile: SoATile, first_fidx: int, rank: int, 
             res = yield from shard_collapse(compute, local_tile, first_fidx, rank, world, strategy=strategy, want_coverage=want_coverage,
                                             device_chain=device_chain, **filters)
             return res
-        rrows, rcnt, rcig = got
+        rrows, rcnt, rcig, rmd = got
     else:
-        rrows, rcnt, rcig = general[1], general[2], general[3]
+        rrows, rcnt, rcig, rmd = general[1], general[2], general[3], general[4]
     # ---- 5. the partials of this rank's coordinate range: one run per source rank, TieBrush-merged, explicit priorities ----
     n2 = int(rrows.shape[0])
     file_off2 = np.zeros(world + 1, np.uint32)
@@ -759,7 +785,7 @@ def partials_collapse(compute, local_tile: SoATile, first_fidx: int, rank: int, 
     assert int(file_off2[-1]) == n2
     fast = None
     if on_dev and general is None:                      # the owner's merge-reduce on the rows as they arrived
-        fast = _owner_reduce_fast(compute, X, rrows, file_off2, rcig, device_chain, strategy)
+        fast = _owner_reduce_fast(compute, X, rrows, file_off2, rcig, device_chain, strategy, rmd)
     if fast is not None:
         T = _torch()
         g2 = int(fast["n_groups"])
@@ -795,6 +821,9 @@ def partials_collapse(compute, local_tile: SoATile, first_fidx: int, rank: int, 
     tile2 = SoATile(n_files=world, file_off=file_off2, tbmerged=np.ones(world, np.uint8), tid=A["tid"], pos=A["pos"], flag=A["flag"],
                     mapq=A["mapq"], strand=A["strand"], nh=A["nh"], cig_off=A["cig_off"], cig=rcig, yc_in=A["yc_in"], yx_in=A["yx_in"],
                     yd_in=A["yd_in"], prio_hi=A["prio_hi"], prio_lo=A["prio_lo"])
+    if full:                                            # -L: the partials' MD strings are the tile's MD columns
+        tile2.md_off, tile2.md_has = compute.partial_unpack_md(rrows)
+        tile2.md = rmd
     mark("unpack")
     fin2 = compute.collapse(tile2, strategy=strategy, want_coords=True, keep_supplementary=True, keep_secondary=True)
     g2 = int(fin2["n_groups"])
@@ -951,6 +980,8 @@ def run_distributed(compute, tile, first_fidx, device=None, group=None, **kw):
             dist.all_reduce(rounds, op=dist.ReduceOp.MAX, group=group)
             rounds = max(1, int(rounds))
         else:
+            if int(big) == 0:            # nothing moves anywhere (every rank knows): no collective
+                return out
             rounds = max(1, (int(big) + chunk - 1) // chunk)
         if rounds == 1:
             dist.all_to_all_single(out, x, output_split_sizes=[int(c) for c in recv_cnt], input_split_sizes=[int(c) for c in send_cnt],

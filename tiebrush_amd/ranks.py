@@ -15,7 +15,8 @@ range (tiebrush_amd/dist.py), and then the winners go home:
      order and the EOF member (BGZF members concatenate; GSam.h:648-653 is the reference's writer).
 The ranges are in coordinate order and whole bundles each, so the concatenation is the flat run's output record for record.
 
-Refused, as in tiebrush_amd.dist: -A and --store-frac (order-dependent sums across ranks), -L (rows carry no MD), -F, -M.
+Refused, as in tiebrush_amd.dist: -A and --store-frac (order-dependent sums across ranks), -F, -M.  -L: the representatives' MD strings
+travel beside the rows (tbk_partial_pack_md).
 """
 from __future__ import annotations
 
@@ -54,11 +55,9 @@ def _parse(argv):
     a = ap.parse_args(argv)
     if a.collapse_same or a.store_frac:
         ap.error("-A and --store-frac need the single-GPU path's ordered passes (run tiebrush without --ranks)")
-    if a.full:
-        ap.error("-L (CIGAR + MD) is single-GPU only: group partials carry no MD tags")
     if a.F or a.keep_unmap:
         ap.error("-F and -M are not supported by the GPU build")
-    if sum([a.clip, a.exon]) > 1:
+    if sum([a.clip, a.exon, a.full]) > 1:
         ap.error("only one merging strategy can be requested")
     return a
 
@@ -177,6 +176,10 @@ def _device_tile(ctx, torch, s, fo, tbmerged, dev):
                    cig_off=grab(s.cig_off, n + 1, torch.int32), cig=grab(s.cig, nc, torch.int32))
     if np.any(tile.tbmerged):
         tile.yc_in, tile.yx_in, tile.yd_in = grab(s.yc_in, n, torch.float64), grab(s.yx_in, n, torch.int64), grab(s.yd_in, n, torch.int64)
+    if s.md_off:        # -L: the MD strings as CSR (tbk_bam_decode with want_md)
+        tile.md_off, tile.md_has = grab(s.md_off, n + 1, torch.int32), grab(s.md_has, n, torch.uint8)
+        torch.cuda.synchronize()
+        tile.md = grab(s.md, int(tile.md_off[n].item()) if n else 0, torch.uint8)
     torch.cuda.synchronize()
     return tile
 
@@ -217,14 +220,14 @@ def worker(a, argv):
     tb = np.array([H.tbh_is_tiebrush(p.encode()) for p in mine], np.int32)
     if np.any(tb < 0):
         raise SystemExit("Error: cannot read the header of %s" % mine[int(np.argmin(tb))])
-    strategy = "clip" if a.clip else ("exon" if a.exon else "cigar")
+    strategy = "clip" if a.clip else ("exon" if a.exon else ("full" if a.full else "cigar"))
     filters = dict(max_nh=a.N, min_qual=a.Q, keep_supplementary=a.keep_supp, keep_secondary=a.keep_secondary)
     if a.verbose and rank == 0:
         sys.stderr.write("Running TieBrush %s on %d ranks. Command line:\ntiebrush %s\n" % (VERSION, world, " ".join(argv)))
     # ---- decode this rank's files on its GPU; the inflated records stay there for the write-back ----
     ctx = api.Context(local_rank)
     raw = [open(p, "rb").read() for p in mine]
-    s, fo = ctx.bam_decode(raw, tbmerged=tb.astype(np.uint8))
+    s, fo = ctx.bam_decode(raw, tbmerged=tb.astype(np.uint8), want_md=a.full)
     del raw
     tile = _device_tile(ctx, torch, s, fo, tb.astype(np.uint8), dev)
     t_dec = time.perf_counter()
