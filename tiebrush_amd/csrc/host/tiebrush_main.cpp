@@ -326,7 +326,7 @@ int main(int argc, char* argv[]) {
     std::function<tbh::RecView(uint32_t)> get_record = [&](uint32_t g) { return inRecords.record(rep[g]); };
     // flushPData tagging (tiebrush.cpp:506-525): the groups are independent, so slices of them are tagged, framed and
     // deflated by worker threads into per-slice runs of BGZF members, which then go to the writer in order
-    auto write_groups = [&](uint32_t ng) {
+    auto write_groups_arr = [&](uint32_t ng, const std::function<tbh::RecView(uint32_t)>& rec_of, const double* ycp, const int64_t* yxp, const int32_t* ydp) {
       const int nt = ng < 4096 ? 1 : nthreads;
       // slices of ~16 K groups, taken by the workers as they come free (a static split leaves the cores that drew sparse
       // regions idle); the calling thread appends every slice's members to the file as soon as all earlier ones are out
@@ -345,7 +345,7 @@ int main(int argc, char* argv[]) {
       auto tag_slice = [&](uint32_t sl, std::vector<uint8_t>& o, tbh::BamRec& rr) {
         const uint32_t g0 = sl * per, g1 = std::min(ng, g0 + per);
         // flushPData's tags on every representative of the slice, then the slice deflates itself (tagwrite.h)
-        if (!tbh::tag_and_deflate(g0, g1, get_record, yc.data(), yx.data(), yd.data(), level, o, rr, runs[(size_t)sl])) failed.store(true);
+        if (!tbh::tag_and_deflate(g0, g1, rec_of, ycp, yxp, ydp, level, o, rr, runs[(size_t)sl])) failed.store(true);
         {
           std::lock_guard<std::mutex> lk(ready_m);
           ready[sl].store(1, std::memory_order_release);
@@ -385,6 +385,7 @@ int main(int argc, char* argv[]) {
       for (auto& x : th) x.join();
       if (failed.load()) GError("Error: deflate failed\n");
     };
+    auto write_groups = [&](uint32_t ng) { write_groups_arr(ng, get_record, yc.data(), yx.data(), yd.data()); };
     // the same on the device (devwriter.h): tags, framing and BGZF deflate as kernels, the host only gathers the records it decoded
     // itself and appends the finished members.  false: nothing written, the host writer above takes the groups.
     auto write_groups_device = [&](uint32_t ng, uint32_t n_dev, const std::function<tbh::RecView(uint32_t)>& host_record) {
@@ -806,7 +807,67 @@ int main(int argc, char* argv[]) {
         }
       }
     }
-    if (!done_on_device) get_record = [&](uint32_t g) { return inRecords.record(rep[g]); };
+    // ---- streaming path: the inputs go through in tiles (TInputFiles::next_tile), and the OUTPUT side of tile i runs beside the
+    // input side of tile i + 1.  A tile's representatives are copied out of the input windows right behind its collapse (the windows
+    // move on with the next tile); tags, deflate and the write of the tile then belong to a writer thread with a context of its own
+    // (the device writer, or every core under --writer host), while this thread inflates, decodes and collapses the next tile.
+    // Two slots: a tile's arrays are free again once its members are in the file.
+    struct StreamSlot {
+      RawBuf<uint32_t> rep;
+      RawBuf<double> yc;
+      RawBuf<int64_t> yx;
+      RawBuf<int32_t> yd;
+      RawBuf<uint8_t> blob;   // the representatives' raw records, group after group (no block_size)
+      RawBuf<uint64_t> boff;  // [ng + 1]
+      uint32_t ng = 0;
+      bool busy = false;
+    };
+    StreamSlot slots[2];
+    std::mutex sm;
+    std::condition_variable scv;
+    std::vector<int> queue_;   // slots handed to the writer, in tile order
+    bool producer_done = false;
+    double ms_writer_busy = 0, ms_wait_slot = 0, ms_gather = 0;
+    tbk_ctx* wctx = nullptr;   // the writer's context (the collapse of the next tile keeps `ctx` busy)
+    std::thread writer_thread;
+    auto writer_main = [&]() {
+      for (;;) {
+        int si = -1;
+        {
+          std::unique_lock<std::mutex> lk(sm);
+          scv.wait(lk, [&] { return !queue_.empty() || producer_done; });
+          if (queue_.empty()) return;
+          si = queue_.front();
+          queue_.erase(queue_.begin());
+        }
+        StreamSlot& S = slots[si];
+        auto a = tnow();
+        const std::function<tbh::RecView(uint32_t)> from_blob = [&S](uint32_t g) {
+          tbh::RecView v;
+          v.p = S.blob.data() + S.boff[g];
+          v.len = (uint32_t)(S.boff[g + 1] - S.boff[g]);
+          return v;
+        };
+        bool wrote = false;
+        if (dev_writer && dw && wctx && outfile.level() != 0) {
+          uint64_t pb = 0, zb = 0;
+          std::string why;
+          wrote = dw->write(wctx, outfile, S.ng, S.rep.data(), S.yc.data(), S.yx.data(), S.yd.data(), 0, from_blob, &pb, &zb, why);
+          if (wrote) dev_payload += pb, dev_z += zb;
+          else if (timing) fprintf(stderr, "device writer not used (%s): host writer\n", why.c_str());
+        }
+        if (!wrote) write_groups_arr(S.ng, from_blob, S.yc.data(), S.yx.data(), S.yd.data());
+        const double ms = tms(a, tnow());
+        ms_writer_busy += ms;
+        if (wrote) ms_dev_write += ms;
+        {
+          std::lock_guard<std::mutex> lk(sm);
+          S.busy = false;
+        }
+        scv.notify_all();
+      }
+    };
+    int next_slot = 0;
     for (; !done_on_device;) {
       auto ti = tnow();
       const bool more = inRecords.next_tile(plan, tile_records, nthreads);
@@ -818,31 +879,102 @@ int main(int argc, char* argv[]) {
       auto t1 = tnow();
       tbk_soa_in in = tile.view();
       size_t n = tile.n();
-      rep.resize(n ? n : 1);
-      yc.resize(n ? n : 1);
-      yx.resize(n ? n : 1);
-      yd.resize(n ? n : 1);
+      StreamSlot& S = slots[next_slot];
+      {
+        auto w0 = tnow();
+        std::unique_lock<std::mutex> lk(sm);
+        scv.wait(lk, [&] { return !S.busy; });
+        ms_wait_slot += tms(w0, tnow());
+      }
+      S.rep.resize(n ? n : 1);
+      S.yc.resize(n ? n : 1);
+      S.yx.resize(n ? n : 1);
+      S.yd.resize(n ? n : 1);
       need_ctx();
+      if (!writer_thread.joinable()) {
+        if (dev_writer && api.create(dev, &wctx) != 0) wctx = nullptr;  // (no second context: the host writer takes the output)
+        writer_thread = std::thread(writer_main);
+      }
       tbk_groups_out out;
       memset(&out, 0, sizeof(out));
       out.mem = TBK_MEM_HOST;
       out.cap_groups = (uint32_t)(n ? n : 1);
-      out.rep = rep.data();
-      out.yc = yc.data();
-      out.yx = yx.data();
-      out.yd = yd.data();
+      out.rep = S.rep.data();
+      out.yc = S.yc.data();
+      out.yx = S.yx.data();
+      out.yd = S.yd.data();
       rc = api.collapse_tile(ctx, &opt, &in, &out);
       auto t2 = tnow();
       if (rc == TBK_EUNSORTED) GError("Error: an input file is not coordinate-sorted!\n");
       if (rc != 0) GError("Error: GPU collapse failed: %s (%s)\n", api.strerror_(rc), api.last_error(ctx));
-      if (!write_groups_device(out.n_groups, 0, get_record)) write_groups(out.n_groups);
+      // the representatives leave the windows: sizes per slice of groups, a prefix, the copies — every core
+      {
+        const uint32_t ng = out.n_groups;
+        S.ng = ng;
+        S.boff.resize((size_t)ng + 1);
+        const int T = ng < 8192 ? 1 : nthreads;
+        std::vector<uint64_t> part((size_t)T + 1, 0);
+        auto slice = [&](int t, uint32_t* a, uint32_t* b) {
+          *a = (uint32_t)((uint64_t)ng * (uint32_t)t / (uint32_t)T);
+          *b = (uint32_t)((uint64_t)ng * ((uint32_t)t + 1) / (uint32_t)T);
+        };
+        auto par = [&](const std::function<void(int)>& f) {
+          std::vector<std::thread> th;
+          for (int t = 1; t < T; ++t) th.emplace_back(f, t);
+          f(0);
+          for (auto& x : th) x.join();
+        };
+        par([&](int t) {
+          uint32_t a, b;
+          slice(t, &a, &b);
+          uint64_t by = 0;
+          for (uint32_t g = a; g < b; ++g) by += inRecords.record(S.rep[g]).len;
+          part[(size_t)t + 1] = by;
+        });
+        for (int t = 0; t < T; ++t) part[(size_t)t + 1] += part[(size_t)t];
+        S.blob.resize((size_t)part[(size_t)T] + 16);
+        par([&](int t) {
+          uint32_t a, b;
+          slice(t, &a, &b);
+          uint64_t o = part[(size_t)t];
+          for (uint32_t g = a; g < b; ++g) {
+            const tbh::RecView v = inRecords.record(S.rep[g]);
+            S.boff[g] = o;
+            memcpy(S.blob.data() + o, v.p, v.len);
+            o += v.len;
+          }
+        });
+        S.boff[ng] = part[(size_t)T];
+      }
       auto t3 = tnow();
-      ms_load += tms(t0, t1);
-      ms_gpu += tms(t1, t2);
-      ms_tag += tms(t2, t3);
+      ms_gather += tms(t2, t3);
       inCounter += out.n_passed;
       outCounter += out.n_groups;
       inRecords.release_tile(plan);
+      {
+        std::lock_guard<std::mutex> lk(sm);
+        S.busy = true;
+        queue_.push_back(next_slot);
+      }
+      scv.notify_all();
+      next_slot ^= 1;
+      ms_load += tms(t0, t1);
+      ms_gpu += tms(t1, t2);
+    }
+    if (writer_thread.joinable()) {
+      {
+        std::lock_guard<std::mutex> lk(sm);
+        producer_done = true;
+      }
+      scv.notify_all();
+      auto w0 = tnow();
+      writer_thread.join();
+      ms_tag += tms(w0, tnow());
+      if (wctx) api.destroy(wctx);
+      if (timing)
+        fprintf(stderr, "streamed: %zu tiles; this thread inflate+index %.1f | SoA %.1f | collapse %.1f | gather representatives %.1f | waited for a free slot %.1f | "
+                        "waited for the writer at the end %.1f; writer thread busy %.1f\n",
+                n_tiles, ms_inflate, ms_load, ms_gpu, ms_gather, ms_wait_slot, tms(w0, tnow()), ms_writer_busy);
     }
     if (timing) fprintf(stderr, "tiles: %zu\n", n_tiles);
   }
