@@ -2133,6 +2133,10 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
   bool use_raw = use_win;
   if (ctx->dbg.raw == 0) use_raw = false;
   if (part) use_raw = true;  // (the PART form exists in raw mode only)
+  if (n >= (1u << 30) || in->n_cigar_ops >= (1u << 30)) {  // the raw window kernels address a record's fields by 32-bit byte offsets
+    use_raw = false;
+    if (part) part = false, use_win = false;
+  }
   WgOut win_out;
   bool win_done = false;
   uint32_t m = 0, ng = 0;

@@ -160,6 +160,22 @@ __device__ __forceinline__ CigScan cig_scan(C c, uint32_t n, bool clip) {
   return r;
 }
 
+// The strategy hash of the CIGAR / soft-clip-stripped strategies from the scan above: the same value as strategy_hash (length of the
+// view, then its words in order), without a second pass over the CIGAR for the view's bounds — the raw window kernel runs this in
+// nearly every wave (one record in thirty needs it, a wave holds 64) and is bound by its vector instructions.
+__device__ __forceinline__ uint32_t cig_word_at(const uint32_t* c, uint32_t k) { return c[k]; }
+__device__ __forceinline__ uint32_t cig_word_at(const CigView& c, uint32_t k) { return c.p[k]; }  // (k >= 3)
+template <class C>
+__device__ __forceinline__ uint64_t view_hash(uint64_t seed, const CigScan& v, C c) {
+  const uint32_t vn = v.e - v.b;
+  uint64_t h = hash_step(seed, vn);
+  if (vn > 0) h = hash_step(h, v.v0);
+  if (vn > 1) h = hash_step(h, v.v1);
+  if (vn > 2) h = hash_step(h, v.v2);
+  for (uint32_t k = v.b + 3; k < v.e; ++k) h = hash_step(h, cig_word_at(c, k));
+  return h;
+}
+
 // (ST: the strategy as a compile-time constant, or -1: O.strategy)
 template <int ST = -1, class C>
 __device__ __forceinline__ RecKey record_key(const ColIn& I, const ColOpt& O, uint32_t i, uint32_t fl, int pos, int tidv, int mq, int32_t nhv,
@@ -175,7 +191,7 @@ __device__ __forceinline__ RecKey record_key(const ColIn& I, const ColOpt& O, ui
   const bool mapped = !(fl & 0x4);
   int start = 0, end = 0;
   uint32_t h32 = 0;
-  bool exact = false;
+  bool exact = false, hashed = false;
   if (strategy == TBK_STRAT_EXON) {
     int nex = 0, e1 = 0, s2 = 0, ix = 0;
     const int l = walk_exons(pos, c, nc,
@@ -217,9 +233,13 @@ __device__ __forceinline__ RecKey record_key(const ColIn& I, const ColOpt& O, ui
         h32 = 0xC0000000u | (cig_len(v.v0) << 20) | cig_len(v.v1);
         exact = true;
       }
+#ifndef TBK_NO_VIEW_HASH
+      if (pass && !exact) h32 = (uint32_t)(view_hash(O.seed, v, c) >> 32) & O.hash_mask & 0x7FFFFFFFu;
+      hashed = true;
+#endif
     }
   }
-  if (pass && !exact) h32 = (uint32_t)(strategy_hash(I, O, strategy, i, c, nc) >> 32) & O.hash_mask & 0x7FFFFFFFu;
+  if (pass && !exact && !hashed) h32 = (uint32_t)(strategy_hash(I, O, strategy, i, c, nc) >> 32) & O.hash_mask & 0x7FFFFFFFu;
   if (!pass) h32 = 0;
   int64_t span = (int64_t)end - (int64_t)start + 1;
   RecKey K;

@@ -40,6 +40,12 @@
 #ifndef WG_EXP
 #define WG_EXP 0
 #endif
+// WG_OPT (build-time): round-5 instruction cuts of the raw window kernel, each behind a bit so that builds with and without it can be
+// timed side by side (tools/scratch/wgopt_r5.sh).  2: the carries of the effective-end scan by two broadcast reads where the wave
+// before holds a segment start; 4: 32-bit byte offsets from the (uniform) array bases for a record's loads.
+#ifndef WG_OPT
+#define WG_OPT 6
+#endif
 #include "dev_common.cuh"
 #include "strategy.cuh"
 #include "tbk_internal.h"
@@ -391,6 +397,10 @@ struct RawL {
   uint16_t flag;  // (in the width they are loaded in: widening them is an instruction on the loaded value, and waits for it)
   uint8_t mapq, strand;
 };
+template <class T>
+__device__ __forceinline__ T wg_ld(const T* base, uint32_t byte_off) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(base) + byte_off);
+}
 __device__ __forceinline__ RawL wg_raw_l(const ColIn& I, uint32_t i, bool need_prev, uint32_t c0, uint32_t c1) {
   RawL a;
 #if WG_EXP & 2
@@ -407,6 +417,27 @@ __device__ __forceinline__ RawL wg_raw_l(const ColIn& I, uint32_t i, bool need_p
   a.w1 = a.w2 = 0;
   return a;
 #endif
+#if WG_OPT & 4
+  // byte offsets of 32 bits from the arrays' bases, which are uniform: one shift serves every 4-byte array, and the loads take the base
+  // from scalar registers (the raw form runs on tiles of < 2^30 records and CIGAR words: tbk_window_groups)
+  const uint32_t o4 = i << 2;
+  a.pos = wg_ld(I.pos, o4);
+  a.tidv = wg_ld(I.tid, o4);
+  a.flag = wg_ld(I.flag, i << 1);
+  a.mapq = wg_ld(I.mapq, i);
+  a.strand = wg_ld(I.strand, i);
+  a.nh = wg_ld(I.nh, o4);
+  a.c0 = c0;
+  a.nc = c1 - c0;
+  const uint32_t p4 = need_prev && i > 0 ? o4 - 4u : o4;
+  a.ppos = wg_ld(I.pos, p4);
+  a.ptid = wg_ld(I.tid, p4);
+  const uint32_t q4 = c0 << 2;  // (a record without the word reads word 0 of the array: always there, tbk_window_groups)
+  a.w0 = wg_ld(I.cig, a.nc > 0 ? q4 : 0u);
+  a.w1 = wg_ld(I.cig, a.nc > 1 ? q4 + 4u : 0u);
+  a.w2 = wg_ld(I.cig, a.nc > 2 ? q4 + 8u : 0u);
+  return a;
+#else
   a.pos = I.pos[i];
   a.tidv = I.tid[i];
   a.flag = I.flag[i];
@@ -423,6 +454,7 @@ __device__ __forceinline__ RawL wg_raw_l(const ColIn& I, uint32_t i, bool need_p
   a.w1 = *(a.nc > 1 ? I.cig + c0 + 1 : safe);
   a.w2 = *(a.nc > 2 ? I.cig + c0 + 2 : safe);
   return a;
+#endif
 }
 template <int ST>
 __device__ __forceinline__ RawRec wg_raw_c(const WgRaw& R, uint32_t i, const RawA& a, const CigView& c) {
@@ -962,6 +994,9 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
       a_src = rb[a_fil] + t;
 #if WG_EXP & 2
       a_c0 = a_src; a_c1 = a_src + 1;
+#elif WG_OPT & 4
+      a_c0 = wg_ld(R.I.cig_off, a_src << 2);
+      a_c1 = wg_ld(R.I.cig_off, (a_src << 2) + 4u);
 #else
       a_c0 = R.I.cig_off[a_src];
       a_c1 = R.I.cig_off[a_src + 1];
@@ -994,6 +1029,9 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
 #if WG_EXP & 2
         a_c0 = a_src;
         a_c1 = a_src + 1;
+#elif WG_OPT & 4
+        a_c0 = wg_ld(R.I.cig_off, a_src << 2);
+        a_c1 = wg_ld(R.I.cig_off, (a_src << 2) + 4u);
 #else
         a_c0 = R.I.cig_off[a_src];
         a_c1 = R.I.cig_off[a_src + 1];
@@ -1174,9 +1212,28 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
       static_assert(NR * WG_NW <= 16, "the carries are folded inside one DPP row");
       if (c0 + (t & ~63u) < n_w) {  // (a wave without a record in this chunk has no use for the carries; wave 0 always has one)
         const uint32_t cin = s_misc[4 + par];
-        const uint32_t lq = lane_id();
-        const uint2 a = lq < (uint32_t)(NR * WG_NW) ? s_agg[lq] : make_uint2(0u, 0u);
-        uint32_t ax = a.x, af = a.y;
+        const int wv = __builtin_amdgcn_readfirstlane((int)(t >> 6));
+        bool folded = false;
+#if WG_OPT & 2
+        if constexpr (NR == 1) {
+          // The carry into a wave is the aggregate of the wave before it wherever that wave holds a segment start — the first record of a
+          // piece, or a record that does not repeat its predecessor's position: nearly every wave — and the chunk's carry-out is the last
+          // wave's aggregate in the same way: two broadcast reads instead of a scan over the aggregates in every wave.
+          const uint2 pa = s_agg[wv > 0 ? wv - 1 : 0];
+          const uint2 la = s_agg[WG_NW - 1];
+          const uint32_t pf = (uint32_t)__builtin_amdgcn_readfirstlane((int)pa.y), lf = (uint32_t)__builtin_amdgcn_readfirstlane((int)la.y);
+          if (wv == 0 ? lf != 0u : pf != 0u) {  // (uniform)
+            const uint32_t snap0 = wv == 0 ? cin : pa.x;
+            if (t == 0) s_misc[4 + (par ^ 1u)] = la.x;
+            eff[0] = fs[0] ? xs[0] : (xs[0] > snap0 ? xs[0] : snap0);
+            folded = true;
+          }
+        }
+#endif
+        if (!folded) {
+          const uint32_t lq = lane_id();
+          const uint2 a = lq < (uint32_t)(NR * WG_NW) ? s_agg[lq] : make_uint2(0u, 0u);
+          uint32_t ax = a.x, af = a.y;
 #define WG_FOLD_STEP(ctrl)                                                                        \
   {                                                                                               \
     const uint32_t xo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ax, ctrl, 0xf, 0xf, false); \
@@ -1184,22 +1241,22 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
     ax = af ? ax : (xo > ax ? xo : ax);                                                           \
     af |= fq;                                                                                     \
   }
-        WG_FOLD_STEP(0x111)  // row_shr:1, 2, 4, 8
-        WG_FOLD_STEP(0x112)
-        WG_FOLD_STEP(0x114)
-        WG_FOLD_STEP(0x118)
+          WG_FOLD_STEP(0x111)  // row_shr:1, 2, 4, 8
+          WG_FOLD_STEP(0x112)
+          WG_FOLD_STEP(0x114)
+          WG_FOLD_STEP(0x118)
 #undef WG_FOLD_STEP
-        const uint32_t cq = af ? ax : (ax > cin ? ax : cin);  // the carry behind aggregate lq
-        uint32_t snap[NR];
-        const int wv = __builtin_amdgcn_readfirstlane((int)(t >> 6));
+          const uint32_t cq = af ? ax : (ax > cin ? ax : cin);  // the carry behind aggregate lq
+          uint32_t snap[NR];
 #pragma unroll
-        for (int u = 0; u < NR; ++u) {
-          const int q = u * WG_NW + wv;  // uniform
-          snap[u] = q == 0 ? cin : (uint32_t)__builtin_amdgcn_readlane((int)cq, q - 1);
+          for (int u = 0; u < NR; ++u) {
+            const int q = u * WG_NW + wv;  // uniform
+            snap[u] = q == 0 ? cin : (uint32_t)__builtin_amdgcn_readlane((int)cq, q - 1);
+          }
+          if (t == 0) s_misc[4 + (par ^ 1u)] = (uint32_t)__builtin_amdgcn_readlane((int)cq, NR * WG_NW - 1);
+#pragma unroll
+          for (int u = 0; u < NR; ++u) eff[u] = fs[u] ? xs[u] : (xs[u] > snap[u] ? xs[u] : snap[u]);
         }
-        if (t == 0) s_misc[4 + (par ^ 1u)] = (uint32_t)__builtin_amdgcn_readlane((int)cq, NR * WG_NW - 1);
-#pragma unroll
-        for (int u = 0; u < NR; ++u) eff[u] = fs[u] ? xs[u] : (xs[u] > snap[u] ? xs[u] : snap[u]);
       }
       par ^= 1u;
       if (R.I.prio_hi) {  // cross-rank tiles: the merge order was fixed where the files live — the explicit priority replaces the scan
@@ -2190,6 +2247,7 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   unsigned long long* spread = nullptr;  // (raw) the spread counters of passing records and verification entries
   if (raw) {
     R.I = I;
+    if (!R.I.cig) R.I.cig = R.I.cig_off;  // (no CIGAR word in the tile: the loads of absent words read word 0 of the array, wg_raw_l)
     R.O = *raw_opt;
     R.O.seed = seed;
     spread = ws_alloc<unsigned long long>(ctx, 2 * (size_t)WG_NSPREAD * WG_SPREAD_STRIDE);
