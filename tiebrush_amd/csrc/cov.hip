@@ -218,54 +218,109 @@ __device__ __forceinline__ void cb_load4(const int32_t* __restrict__ a, uint64_t
     for (int e = 0; e < 4; ++e) v[e] = i + e < m ? a[i + e] : fill;
   }
 }
-__global__ __launch_bounds__(CB_NT) void cb_agg_k(uint32_t m, const int32_t* __restrict__ tid, const int32_t* __restrict__ end, uint4* __restrict__ part) {
-  __shared__ CbAgg sm[CB_NT / 64];
-  const CbOp op{};
-  const CbAgg none{0, INT32_MIN, INT32_MIN, 1u};
-  CbAgg run = none;
+template <class T, class Op>
+__device__ __forceinline__ T wave_incl_scan_op(T v, Op op) {
 #pragma unroll
-  for (uint32_t r = 0; r < CB_ROWS; ++r) {
-    const uint64_t i = (uint64_t)blockIdx.x * CB_TILE + ((uint64_t)r * CB_NT + threadIdx.x) * 4u;
-    int32_t t4[4], e4[4];
-    cb_load4(tid, i, m, 0, t4);
-    cb_load4(end, i, m, 0, e4);
-    CbAgg a = none;
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (i + e < m) a = op(a, CbAgg{t4[e], t4[e], e4[e], 1u});
-    CbAgg tot;
-    (void)block_incl_scan_op(a, op, sm, &tot);
-    run = op(run, tot);
+  for (int d = 1; d < 64; d <<= 1) {
+    const T o = shfl_up_t(v, d);
+    if ((int)lane_id() >= d) v = op(o, v);
   }
-  if (threadIdx.x == 0) part[blockIdx.x] = make_uint4((uint32_t)run.first_tid, (uint32_t)run.last_tid, (uint32_t)run.mx, run.whole);
+  return v;
 }
-// one block: the tile aggregates -> for every tile the aggregate of the tiles before it
-__global__ __launch_bounds__(256) void cb_spine_k(uint4* __restrict__ part, uint32_t ntiles) {
-  __shared__ uint4 sh[256];
+// True in every thread of the block that finishes last; `done` starts at zero.  What the blocks hand to the last one travels without
+// fences: thread 0 writes its block's result with agent-scope stores (cb_put), waits for them to be acknowledged and counts the block;
+// the last block reads the results with agent-scope loads (cb_get).  (A __threadfence per block writes back and invalidates L2: with
+// 6 k blocks it made this pass — and the junction kernels beside it — five times slower.)
+__device__ __forceinline__ void cb_put(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint64_t cb_get(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint4 cb_get4(const uint4* p) {
+  const uint64_t a = cb_get(reinterpret_cast<const uint64_t*>(p)), b = cb_get(reinterpret_cast<const uint64_t*>(p) + 1);
+  return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+}
+__device__ __forceinline__ bool cb_last_block(uint32_t* __restrict__ done) {  // (called behind thread 0's cb_put's)
+  __shared__ uint32_t s_last;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (the stores above are acknowledged: a wait, no cache operation)
+    s_last = atomicAdd(done, 1u) == gridDim.x - 1u ? 1u : 0u;
+  }
+  __syncthreads();
+  return s_last != 0u;
+}
+// The tile aggregates -> for every tile the aggregate of the tiles before it, by ONE block of NT threads: a slice of the tiles per
+// thread with eight loads in flight at a time, the slices' aggregates by wave scans and one fold of the wave totals.  It runs in the
+// block of cb_agg_k that finishes last (cb_last_block): as a kernel of its own between the passes — one block — it waited for a CU
+// with room while the junction branch's grids filled the GPU (100-200 us of a 1.4 ms coverage call, whatever the streams' priorities).
+template <uint32_t NT>
+__device__ __forceinline__ void cb_spine_block(uint4* __restrict__ part, uint32_t ntiles, CbAgg* wl /* [NT / 64] */) {
   const CbOp op{};
   const CbAgg none{0, INT32_MIN, INT32_MIN, 1u};
   auto un = [](const uint4& v) { return CbAgg{(int32_t)v.x, (int32_t)v.y, (int32_t)v.z, v.w}; };
   auto pk = [](const CbAgg& a) { return make_uint4((uint32_t)a.first_tid, (uint32_t)a.last_tid, (uint32_t)a.mx, a.whole); };
-  const uint32_t per = (ntiles + 255u) / 256u, i0 = threadIdx.x * per, i1 = i0 + per < ntiles ? i0 + per : ntiles;
+  const uint4 none4 = pk(none);
+  const uint32_t per = (ntiles + NT - 1u) / NT, i0 = threadIdx.x * per, i1 = i0 + per < ntiles ? i0 + per : ntiles;
   CbAgg a = none;
-  for (uint32_t i = i0; i < i1; ++i) a = op(a, un(part[i]));
-  sh[threadIdx.x] = pk(a);
+  for (uint32_t q0 = i0; q0 < i1; q0 += 8u) {
+    uint4 v8[8];
+#pragma unroll
+    for (uint32_t u = 0; u < 8u; ++u) v8[u] = q0 + u < i1 ? cb_get4(part + q0 + u) : none4;
+#pragma unroll
+    for (uint32_t u = 0; u < 8u; ++u) a = op(a, un(v8[u]));
+  }
+  const CbAgg inc = wave_incl_scan_op(a, op);
+  if (lane_id() == 63) wl[threadIdx.x >> 6] = inc;
+  CbAgg run = shfl_up_t(inc, 1);
+  __syncthreads();  // (every slice has been read: the writes below may begin)
+  {
+    CbAgg acc = none;
+    const uint32_t wv = threadIdx.x >> 6;
+    for (uint32_t q = 0; q < wv; ++q) acc = op(acc, wl[q]);
+    run = lane_id() == 0 ? acc : op(acc, run);
+  }
+  for (uint32_t q0 = i0; q0 < i1; q0 += 8u) {
+    uint4 v8[8];
+#pragma unroll
+    for (uint32_t u = 0; u < 8u; ++u) v8[u] = q0 + u < i1 ? cb_get4(part + q0 + u) : none4;
+#pragma unroll
+    for (uint32_t u = 0; u < 8u; ++u) {
+      if (q0 + u < i1) part[q0 + u] = pk(run);
+      run = op(run, un(v8[u]));
+    }
+  }
+}
+__global__ __launch_bounds__(CB_NT) void cb_agg_k(uint32_t m, const int32_t* __restrict__ tid, const int32_t* __restrict__ end, uint4* __restrict__ part,
+                                                  uint32_t* __restrict__ done) {
+  // (the four rows' loads are issued together and their wave scans run side by side: one barrier per block, not two per row)
+  constexpr uint32_t NWV = CB_NT / 64;
+  __shared__ CbAgg wl[CB_ROWS * NWV];
+  const CbOp op{};
+  const CbAgg none{0, INT32_MIN, INT32_MIN, 1u};
+  int32_t t4[CB_ROWS][4], e4[CB_ROWS][4];
+#pragma unroll
+  for (uint32_t r = 0; r < CB_ROWS; ++r) {
+    const uint64_t i = (uint64_t)blockIdx.x * CB_TILE + ((uint64_t)r * CB_NT + threadIdx.x) * 4u;
+    cb_load4(tid, i, m, 0, t4[r]);
+    cb_load4(end, i, m, 0, e4[r]);
+  }
+#pragma unroll
+  for (uint32_t r = 0; r < CB_ROWS; ++r) {
+    const uint64_t i = (uint64_t)blockIdx.x * CB_TILE + ((uint64_t)r * CB_NT + threadIdx.x) * 4u;
+    CbAgg a = none;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (i + e < m) a = op(a, CbAgg{t4[r][e], t4[r][e], e4[r][e], 1u});
+    a = wave_incl_scan_op(a, op);
+    if (lane_id() == 63) wl[r * NWV + (threadIdx.x >> 6)] = a;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     CbAgg run = none;
-    for (uint32_t q = 0; q < 256; ++q) {
-      const CbAgg mine = un(sh[q]);
-      sh[q] = pk(run);
-      run = op(run, mine);
-    }
+#pragma unroll
+    for (uint32_t q = 0; q < CB_ROWS * NWV; ++q) run = op(run, wl[q]);
+    uint64_t* o = reinterpret_cast<uint64_t*>(part + blockIdx.x);
+    cb_put(o, (uint64_t)(uint32_t)run.first_tid | ((uint64_t)(uint32_t)run.last_tid << 32));
+    cb_put(o + 1, (uint64_t)(uint32_t)run.mx | ((uint64_t)run.whole << 32));
   }
-  __syncthreads();
-  CbAgg run = un(sh[threadIdx.x]);
-  for (uint32_t i = i0; i < i1; ++i) {
-    const CbAgg mine = un(part[i]);
-    part[i] = pk(run);
-    run = op(run, mine);
-  }
+  if (cb_last_block(done)) cb_spine_block<CB_NT>(part, gridDim.x, wl);  // (the last block: every tile's aggregate -> the aggregate before it)
 }
 // EMIT = false: heads per tile -> hcnt[tile]; EMIT = true: hbase[tile] = heads before the tile; everything is written
 template <bool EMIT>
@@ -778,16 +833,85 @@ struct ClChunks {
   uint32_t* j;                   // the list: record
   uint64_t* cs;                  //           its compacted start
 };
+// one block: exclusive prefixes of the per-tile head counts and X sums (the same shape as cb_spine_block, run by the last block of
+// cl_heads_k<false>)
+template <uint32_t NT>
+__device__ __forceinline__ void cl_scan_block(uint32_t nt, const uint32_t* __restrict__ hcnt, const long long* __restrict__ xsum,
+                                              uint32_t* __restrict__ hbase, long long* __restrict__ xbase, uint32_t* sh /* [NT / 64] */,
+                                              long long* sx /* [NT / 64] */) {
+  const uint32_t per = (nt + NT - 1u) / NT, i0 = threadIdx.x * per, i1 = i0 + per < nt ? i0 + per : nt;
+  uint32_t h = 0;
+  long long x = 0;
+  for (uint32_t q0 = i0; q0 < i1; q0 += 8u) {
+    uint32_t h8[8];
+    long long x8[8];
+#pragma unroll
+    for (uint32_t u = 0; u < 8u; ++u) {
+      h8[u] = q0 + u < i1 ? __hip_atomic_load(hcnt + q0 + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      x8[u] = q0 + u < i1 ? __hip_atomic_load(xsum + q0 + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ll;
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 8u; ++u) {
+      h += h8[u];
+      x += x8[u];
+    }
+  }
+  uint32_t hi_ = h;
+  long long xi_ = x;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t oh = __shfl_up(hi_, d, 64);
+    const long long ox = __shfl_up(xi_, d, 64);
+    if ((int)lane_id() >= d) {
+      hi_ += oh;
+      xi_ += ox;
+    }
+  }
+  if (lane_id() == 63) {
+    sh[threadIdx.x >> 6] = hi_;
+    sx[threadIdx.x >> 6] = xi_;
+  }
+  __syncthreads();
+  uint32_t rh = hi_ - h;
+  long long rx = xi_ - x;
+  for (uint32_t q = 0; q < (threadIdx.x >> 6); ++q) {
+    rh += sh[q];
+    rx += sx[q];
+  }
+  for (uint32_t q0 = i0; q0 < i1; q0 += 8u) {
+    uint32_t h8[8];
+    long long x8[8];
+#pragma unroll
+    for (uint32_t u = 0; u < 8u; ++u) {
+      h8[u] = q0 + u < i1 ? __hip_atomic_load(hcnt + q0 + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      x8[u] = q0 + u < i1 ? __hip_atomic_load(xsum + q0 + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ll;
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 8u; ++u) {
+      if (q0 + u < i1) {
+        hbase[q0 + u] = rh;
+        xbase[q0 + u] = rx;
+      }
+      rh += h8[u];
+      rx += x8[u];
+    }
+  }
+}
+
 template <bool EMIT>
-__global__ __launch_bounds__(CB_NT) void cl_heads_k(uint32_t m, CovArrays A, const uint4* __restrict__ part, uint32_t* __restrict__ hcnt,
-                                                    long long* __restrict__ xsum, const uint32_t* __restrict__ hbase,
+__global__ __launch_bounds__(CB_NT) void cl_heads_k(uint32_t m, CovArrays A, const uint4* __restrict__ part /* per tile: the aggregate of the tiles before it */,
+                                                    uint32_t* __restrict__ hcnt, long long* __restrict__ xsum, const uint32_t* __restrict__ hbase,
                                                     const long long* __restrict__ xbase, const uint32_t* __restrict__ cig_off,
                                                     const uint32_t* __restrict__ cig, ClTiles T, ClChunks L, uint64_t* __restrict__ sc,
-                                                    uint32_t* __restrict__ err) {
-  __shared__ CbAgg sm[CB_NT / 64];
-  __shared__ CbAgg wl[CB_NT / 64];
-  __shared__ uint32_t smu[8];
-  __shared__ long long smx[8];
+                                                    uint32_t* __restrict__ err, uint32_t* __restrict__ done, uint32_t* __restrict__ hbase_out,
+                                                    long long* __restrict__ xbase_out) {
+  // The four rows of a block go through the scans together: their loads are issued at once, their wave scans run side by side and the
+  // sixteen (row, wave) aggregates meet in LDS behind ONE barrier per scan (the row-by-row form had twenty barriers per block and a
+  // round trip to memory per row).
+  constexpr uint32_t NWV = CB_NT / 64;
+  __shared__ CbAgg wl[CB_ROWS * NWV];
+  __shared__ uint32_t smu[CB_ROWS * NWV];
+  __shared__ long long smx[CB_ROWS * NWV];
   // EMIT: the block's spilling records and its piece counts gather in LDS and reach global memory once per block — a reservation
   // per row on one word (24 k returning atomics on config 3) was most of this kernel's time
   __shared__ uint32_t lcnt[EMIT ? COV_SW : 1];
@@ -797,120 +921,151 @@ __global__ __launch_bounds__(CB_NT) void cl_heads_k(uint32_t m, CovArrays A, con
   __shared__ uint64_t s_cs0, s_cs1;
   const CbOp op{};
   const CbAgg none{0, INT32_MIN, INT32_MIN, 1u};
-  const uint4 pv = part[blockIdx.x];
-  CbAgg run{(int32_t)pv.x, (int32_t)pv.y, (int32_t)pv.z, pv.w};  // the records before the current row
-  uint32_t heads_tile = 0, hrun = EMIT ? hbase[blockIdx.x] : 0u;
-  long long x_tile = 0, xrun = EMIT ? xbase[blockIdx.x] : 0ll;
+  auto un = [](const uint4& v) { return CbAgg{(int32_t)v.x, (int32_t)v.y, (int32_t)v.z, v.w}; };
+  const uint32_t wv = threadIdx.x >> 6;
+  uint32_t heads_tile = 0;
+  long long x_tile = 0;
   bool bad = false, refused = false;
   if (EMIT) {
     if (threadIdx.x < COV_SW) lcnt[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_nsl = s_np = 0;
   }
-#pragma unroll 1
+  int32_t t4[CB_ROWS][4], s4[CB_ROWS][4], e4[CB_ROWS][4];
+#pragma unroll
   for (uint32_t r = 0; r < CB_ROWS; ++r) {
     const uint64_t i = (uint64_t)blockIdx.x * CB_TILE + ((uint64_t)r * CB_NT + threadIdx.x) * 4u;
-    int32_t t4[4], s4[4], e4[4];
-    cb_load4(A.tid, i, m, 0, t4);
-    cb_load4(A.start, i, m, 0, s4);
-    cb_load4(A.end, i, m, 0, e4);
+    cb_load4(A.tid, i, m, 0, t4[r]);
+    cb_load4(A.start, i, m, 0, s4[r]);
+    cb_load4(A.end, i, m, 0, e4[r]);
+  }
+  // what came before the block (cb_spine_block, cl_scan_block)
+  const CbAgg run0 = un(part[blockIdx.x]);
+  const uint32_t hrun0 = EMIT ? hbase[blockIdx.x] : 0u;
+  const long long xrun0 = EMIT ? xbase[blockIdx.x] : 0ll;
+  CbAgg ex[CB_ROWS];  // the aggregate of everything before this thread's first record of the row
+#pragma unroll
+  for (uint32_t r = 0; r < CB_ROWS; ++r) {
+    const uint64_t i = (uint64_t)blockIdx.x * CB_TILE + ((uint64_t)r * CB_NT + threadIdx.x) * 4u;
     CbAgg a = none;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      if (i + e < m) a = op(a, CbAgg{t4[e], t4[e], e4[e], 1u});
-    CbAgg tot;
-    const CbAgg inc = block_incl_scan_op(a, op, sm, &tot);
-    CbAgg ex = shfl_up_t(inc, 1);  // the aggregate of everything before this thread's first record: run (+) the threads before it in the row
-    if (lane_id() == 63) wl[threadIdx.x >> 6] = inc;
-    __syncthreads();
-    if (threadIdx.x == 0)
-      ex = none;
-    else if (lane_id() == 0)
-      ex = wl[(threadIdx.x >> 6) - 1];
-    ex = op(run, ex);
+      if (i + e < m) a = op(a, CbAgg{t4[r][e], t4[r][e], e4[r][e], 1u});
+    const CbAgg inc = wave_incl_scan_op(a, op);
+    if (lane_id() == 63) wl[r * NWV + wv] = inc;
+    ex[r] = shfl_up_t(inc, 1);  // (lane 0: replaced below)
+  }
+  __syncthreads();
+  {
+    CbAgg acc = run0;  // run0 (+) the (row, wave) aggregates before this thread's wave, rows in order
+#pragma unroll
+    for (uint32_t q = 0; q < CB_ROWS * NWV; ++q) {
+      if (q % NWV == wv) ex[q / NWV] = lane_id() == 0 ? acc : op(acc, ex[q / NWV]);
+      acc = op(acc, wl[q]);
+    }
+  }
+  uint32_t hdn[CB_ROWS];  // head flags of the four records : 4 | their number << 4
+  uint32_t hinc[CB_ROWS];
+  long long xs[CB_ROWS], xinc[CB_ROWS];
+#pragma unroll
+  for (uint32_t r = 0; r < CB_ROWS; ++r) {
+    const uint64_t i = (uint64_t)blockIdx.x * CB_TILE + ((uint64_t)r * CB_NT + threadIdx.x) * 4u;
     uint32_t hd = 0, nh = 0;
-    long long x4[4] = {0, 0, 0, 0}, xs = 0;
-    CbAgg w = ex;
+    xs[r] = 0;
+    CbAgg w = ex[r];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if (i + e < m) {
         const bool first = w.last_tid == INT32_MIN;
-        const bool head = first || t4[e] != w.last_tid || s4[e] > w.mx;  // tiecov.cpp:443
+        const bool head = first || t4[r][e] != w.last_tid || s4[r][e] > w.mx;  // tiecov.cpp:443
         if (head) {
-          x4[e] = (long long)s4[e] - 1ll - (first ? 0ll : (long long)w.mx);
-          xs += x4[e];
+          xs[r] += (long long)s4[r][e] - 1ll - (first ? 0ll : (long long)w.mx);
           hd |= 1u << e;
           ++nh;
         }
-        w = op(w, CbAgg{t4[e], t4[e], e4[e], 1u});
+        w = op(w, CbAgg{t4[r][e], t4[r][e], e4[r][e], 1u});
       }
     }
-    // heads and X sums before this thread in the row: one block scan of the pair
-    uint32_t rowh, before;
-    long long rowx, xbefore;
-    {
-      uint32_t hi_ = nh;
-      long long xi_ = xs;
+    hdn[r] = hd | (nh << 4);
+    // heads and X sums before this thread in its wave's part of the row
+    uint32_t hi_ = nh;
+    long long xi_ = xs[r];
 #pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t oh = __shfl_up(hi_, d, 64);
-        const long long ox = __shfl_up(xi_, d, 64);
-        if ((int)lane_id() >= d) {
-          hi_ += oh;
-          xi_ += ox;
-        }
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t oh = __shfl_up(hi_, d, 64);
+      const long long ox = __shfl_up(xi_, d, 64);
+      if ((int)lane_id() >= d) {
+        hi_ += oh;
+        xi_ += ox;
       }
-      const uint32_t wv = threadIdx.x >> 6;
-      if (lane_id() == 63) {
-        smu[wv] = hi_;
-        smx[wv] = xi_;
-      }
-      __syncthreads();
-      uint32_t bh = 0, th = 0;
-      long long bx = 0, tx = 0;
+    }
+    if (lane_id() == 63) {
+      smu[r * NWV + wv] = hi_;
+      smx[r * NWV + wv] = xi_;
+    }
+    hinc[r] = hi_;
+    xinc[r] = xi_;
+  }
+  __syncthreads();
+  // per row: bundles before this thread's records, the X sum before them, and the (reference, running end) the row's walk starts from
+  uint32_t bf[CB_ROWS];
+  long long cf[CB_ROWS];
+  {
+    uint32_t ah = 0;
+    long long ax = 0;
 #pragma unroll
-      for (uint32_t q = 0; q < CB_NT / 64; ++q) {
-        const uint32_t h_ = smu[q];
-        const long long x_ = smx[q];
-        if (q < wv) {
-          bh += h_;
-          bx += x_;
-        }
-        th += h_;
-        tx += x_;
+    for (uint32_t q = 0; q < CB_ROWS * NWV; ++q) {
+      if (q % NWV == wv) {
+        bf[q / NWV] = hrun0 + ah + hinc[q / NWV] - (hdn[q / NWV] >> 4);
+        cf[q / NWV] = xrun0 + ax + xinc[q / NWV] - xs[q / NWV];
       }
-      before = bh + hi_ - nh;
-      xbefore = bx + xi_ - xs;
-      rowh = th;
-      rowx = tx;
-    }  // (smu / smx are written again only behind the row's closing barrier)
-    if (EMIT) {
-      before += hrun;
-      long long C = xrun + xbefore;  // the sum of X over the heads before this thread's records
+      ah += smu[q];
+      ax += smx[q];
+    }
+    heads_tile = ah;
+    x_tile = ax;
+  }
+  if (EMIT) {
+    // the numbering walk, row by row, on what the scans left behind: five words per row, chosen by the row (the rows' records are
+    // read again, out of L2: kept in registers across an unrolled walk they cost the kernel three quarters of its resident waves)
+    const uint32_t hd_all = (hdn[0] & 15u) | ((hdn[1] & 15u) << 4) | ((hdn[2] & 15u) << 8) | ((hdn[3] & 15u) << 12);
+    static_assert(CB_ROWS == 4, "the row selects below");
+#define CL_ROW(a, r) ((r) == 0 ? a[0] : (r) == 1 ? a[1] : (r) == 2 ? a[2] : a[3])
+    const int32_t vt[CB_ROWS] = {ex[0].last_tid, ex[1].last_tid, ex[2].last_tid, ex[3].last_tid};
+    const int32_t vm[CB_ROWS] = {ex[0].mx, ex[1].mx, ex[2].mx, ex[3].mx};
+#pragma unroll 1
+    for (uint32_t r = 0; r < CB_ROWS; ++r) {
+      const uint64_t i = (uint64_t)blockIdx.x * CB_TILE + ((uint64_t)r * CB_NT + threadIdx.x) * 4u;
+      int32_t rt[4], rs[4], re[4];
+      cb_load4(A.tid, i, m, 0, rt);
+      cb_load4(A.start, i, m, 0, rs);
+      cb_load4(A.end, i, m, 0, re);
       const int32_t pst = i > 0 && i < m ? A.start[i - 1] : 0;  // (the record before the four: order check, its tile)
+      const uint32_t hd = (hd_all >> (4u * r)) & 15u;
+      long long C = CL_ROW(cf, r);  // the sum of X over the heads before this thread's records
+      uint32_t b = CL_ROW(bf, r);
+      int32_t v_tid = CL_ROW(vt, r), v_mx = CL_ROW(vm, r);  // the walk's state: last reference (INT32_MIN: none), running maximum of `end` on it
       uint64_t prev_cs = i > 0 && i < m ? (uint64_t)((long long)pst - 1ll - C) : 0ull;
-      CbAgg v = ex;
-      uint32_t b = before;
       uint64_t pk4 = 0;  // the four tile-kernel words of this thread's records: one store
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const uint64_t j = i + e;
         if (j < m) {
           const bool head = (hd >> e) & 1u;
-          const bool run_head = v.last_tid == INT32_MIN || t4[e] != v.last_tid;
-          const int32_t prev_start = e == 0 ? pst : s4[e - 1];
-          if (!run_head && s4[e] < prev_start) bad = true;
+          const bool run_head = v_tid == INT32_MIN || rt[e] != v_tid;
+          const int32_t prev_start = e == 0 ? pst : rs[e - 1];
+          if (!run_head && rs[e] < prev_start) bad = true;
           b += head ? 1u : 0u;
-          C += x4[e];
+          if (head) C += (long long)rs[e] - 1ll - (v_tid == INT32_MIN ? 0ll : (long long)v_mx);
           const uint32_t bundle = b - 1u;
-          const uint64_t cs = (uint64_t)((long long)s4[e] - 1ll - C);
+          const uint64_t cs = (uint64_t)((long long)rs[e] - 1ll - C);
           pk4 |= (uint64_t)((uint32_t)(cs % COV_W) | (head ? 0x8000u : 0u)) << (16 * e);
           if (head) {
-            A.b_tid[bundle] = t4[e];
-            A.b_start[bundle] = s4[e];
+            A.b_tid[bundle] = rt[e];
+            A.b_start[bundle] = rs[e];
             A.b_off[bundle] = cs;
           }
           const uint64_t tl = cs / COV_W;
-          if (r == 0 && threadIdx.x == 0 && e == 0) {  // (read behind the row's next barrier)
+          if (r == 0 && threadIdx.x == 0 && e == 0) {  // (read behind the barrier that closes the rows)
             s_tbase = (uint32_t)tl;
             s_cs0 = cs;
           }
@@ -923,9 +1078,10 @@ __global__ __launch_bounds__(CB_NT) void cl_heads_k(uint32_t m, CovArrays A, con
             T.first[tp] = (uint32_t)j;
             T.tb[tp] = bundle - ((head && cs > tp * COV_W) ? 1u : 0u);
           }
-          v = op(v, CbAgg{t4[e], t4[e], e4[e], 1u});
+          v_mx = (!run_head && v_mx > re[e]) ? v_mx : re[e];  // (CbOp on a single record)
+          v_tid = rt[e];
           if (j + 1 == m) {
-            const uint64_t S = (uint64_t)((long long)v.mx - C);
+            const uint64_t S = (uint64_t)((long long)v_mx - C);
             const uint64_t nt = (S + COV_W - 1) / COV_W;
             sc[CL_SC_NB] = (uint64_t)bundle + 1u;
             sc[CL_SC_S] = S;
@@ -939,7 +1095,7 @@ __global__ __launch_bounds__(CB_NT) void cl_heads_k(uint32_t m, CovArrays A, con
             }
           }
           // a read whose reference span ends inside its home tile has no piece elsewhere (96 % of the reads)
-          if ((uint32_t)(cs % COV_W) + (uint32_t)(e4[e] - s4[e] + 1) > (uint32_t)COV_W) {
+          if ((uint32_t)(cs % COV_W) + (uint32_t)(re[e] - rs[e] + 1) > (uint32_t)COV_W) {
             const uint32_t k = atomicAdd(&s_nsl, 1u);
             l_j[k] = (uint16_t)(j - (uint64_t)blockIdx.x * CB_TILE);
             l_cs[k] = (uint32_t)cs;
@@ -954,16 +1110,15 @@ __global__ __launch_bounds__(CB_NT) void cl_heads_k(uint32_t m, CovArrays A, con
           if (i + e < m) A.pk[i + e] = (uint16_t)(pk4 >> (16 * e));
       }
     }
-    heads_tile += rowh;
-    hrun += rowh;
-    x_tile += rowx;
-    xrun += rowx;
-    run = op(run, tot);
+#undef CL_ROW
     __syncthreads();
   }
-  if (!EMIT && threadIdx.x == 0) {
-    hcnt[blockIdx.x] = heads_tile;
-    xsum[blockIdx.x] = x_tile;
+  if (!EMIT) {
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(hcnt + blockIdx.x, heads_tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(xsum + blockIdx.x, x_tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (cb_last_block(done)) cl_scan_block<CB_NT>(gridDim.x, hcnt, xsum, hbase_out, xbase_out, smu, smx);  // (the last block: the prefixes the numbering pass starts from)
   }
   if (EMIT) {
     // the block's spilling records: count their pieces per tile (LDS window behind the block's first home tile), one reservation
@@ -1006,44 +1161,6 @@ __global__ __launch_bounds__(CB_NT) void cl_heads_k(uint32_t m, CovArrays A, con
     if (threadIdx.x == 0) L.cnt[blockIdx.x] = nsl;
     if (bad) atomicOr(err, TBK_DERR_UNSORTED);
     if (refused) sc[CL_SC_REFUSED] = 1;
-  }
-}
-
-// one block: exclusive prefixes of the per-tile head counts and X sums
-__global__ __launch_bounds__(256) void cl_scan_k(uint32_t nt, const uint32_t* __restrict__ hcnt, const long long* __restrict__ xsum,
-                                                 uint32_t* __restrict__ hbase, long long* __restrict__ xbase) {
-  __shared__ uint32_t sh[256];
-  __shared__ long long sx[256];
-  const uint32_t per = (nt + 255u) / 256u, i0 = threadIdx.x * per, i1 = i0 + per < nt ? i0 + per : nt;
-  uint32_t h = 0;
-  long long x = 0;
-  for (uint32_t i = i0; i < i1; ++i) {
-    h += hcnt[i];
-    x += xsum[i];
-  }
-  sh[threadIdx.x] = h;
-  sx[threadIdx.x] = x;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t rh = 0;
-    long long rx = 0;
-    for (uint32_t q = 0; q < 256; ++q) {
-      const uint32_t mh = sh[q];
-      const long long mx = sx[q];
-      sh[q] = rh;
-      sx[q] = rx;
-      rh += mh;
-      rx += mx;
-    }
-  }
-  __syncthreads();
-  h = sh[threadIdx.x];
-  x = sx[threadIdx.x];
-  for (uint32_t i = i0; i < i1; ++i) {
-    hbase[i] = h;
-    xbase[i] = x;
-    h += hcnt[i];
-    x += xsum[i];
   }
 }
 
@@ -1855,12 +1972,13 @@ static int cov_intervals_lean(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* o
   T.cnt = ws_alloc<uint32_t>(ctx, (size_t)T.cap + 1);
   if (!cpart || !hcnt || !hbase || !xsum || !xbase || !L.base || !L.cnt || !L.tbase || !L.j || !L.cs || !T.first || !T.tb || !T.cnt) return TBK_ENOMEM;
   TBK_HIP(hipMemsetAsync(T.cnt, 0, ((size_t)T.cap + 1) * 4, ctx->stream));
-  TBK_LAUNCH(ctx, "cov_bundles", cb_agg_k, cbt, CB_NT, 0, m, A.tid, A.end, cpart);
-  TBK_LAUNCH(ctx, "cov_bundles", cb_spine_k, 1, 256, 0, cpart, cbt);
+  uint32_t* done = (uint32_t*)(sc + 16);  // [0] cb_agg_k's blocks, [1] cl_heads_k<false>'s: the last one of each runs the scan over the tiles
+  TBK_HIP(hipMemsetAsync(done, 0, sizeof(uint64_t), ctx->stream));
+  TBK_LAUNCH(ctx, "cov_bundles", cb_agg_k, cbt, CB_NT, 0, m, A.tid, A.end, cpart, done);
   TBK_LAUNCH(ctx, "cov_bundles", cl_heads_k<false>, cbt, CB_NT, 0, m, A, cpart, hcnt, xsum, (const uint32_t*)nullptr, (const long long*)nullptr, in->cig_off,
-             in->cig, T, L, sc, ctx->d_err);
-  TBK_LAUNCH(ctx, "cov_bundles", cl_scan_k, 1, 256, 0, cbt, hcnt, xsum, hbase, xbase);
-  TBK_LAUNCH(ctx, "cov_place", cl_heads_k<true>, cbt, CB_NT, 0, m, A, cpart, hcnt, xsum, hbase, xbase, in->cig_off, in->cig, T, L, sc, ctx->d_err);
+             in->cig, T, L, sc, ctx->d_err, done + 1, hbase, xbase);
+  TBK_LAUNCH(ctx, "cov_place", cl_heads_k<true>, cbt, CB_NT, 0, m, A, cpart, hcnt, xsum, hbase, xbase, in->cig_off, in->cig, T, L, sc, ctx->d_err,
+             (uint32_t*)nullptr, (uint32_t*)nullptr, (long long*)nullptr);
   uint32_t eb = 0;
   TBK_TRY(tbk_sync_err(ctx, &eb));
   if (eb) return tbk_derr_to_status(ctx, eb);
@@ -2031,8 +2149,9 @@ static int cov_run(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out, bool sa
       uint32_t* hcnt = ws_alloc<uint32_t>(ctx, cbt);
       uint32_t* hbase = ws_alloc<uint32_t>(ctx, cbt);
       if (!cpart || !hcnt || !hbase) return TBK_ENOMEM;
-      TBK_LAUNCH(ctx, "cov_bundles", cb_agg_k, cbt, CB_NT, 0, m, A.tid, A.end, cpart);
-      TBK_LAUNCH(ctx, "cov_bundles", cb_spine_k, 1, 256, 0, cpart, cbt);
+      uint32_t* done = (uint32_t*)(sc + 16);  // (cb_agg_k's last block scans the tile aggregates)
+      TBK_HIP(hipMemsetAsync(done, 0, sizeof(uint64_t), ctx->stream));
+      TBK_LAUNCH(ctx, "cov_bundles", cb_agg_k, cbt, CB_NT, 0, m, A.tid, A.end, cpart, done);
       TBK_LAUNCH(ctx, "cov_bundles", cb_heads_k<false>, cbt, CB_NT, 0, m, A, cpart, hcnt, (const uint32_t*)nullptr, sc + 3, ctx->d_err);
       TBK_TRY(tbk_exscan_u32(ctx, hcnt, hbase, cbt, nullptr));
       TBK_LAUNCH(ctx, "cov_bundles", cb_heads_k<true>, cbt, CB_NT, 0, m, A, cpart, hcnt, hbase, sc + 3, ctx->d_err);
