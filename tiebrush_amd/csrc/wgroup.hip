@@ -152,6 +152,12 @@ __device__ __forceinline__ uint32_t wg_upper_bound(const uint64_t* __restrict__ 
   }
   return lo;
 }
+// A block takes WG_OG consecutive chunks.  Inside a run the bounds of consecutive chunks follow one another: the lower end of a chunk's
+// range in W is the upper end of the chunk before it, and the upper end lies a few bounds further (2.3 per chunk on config 3) — ONE
+// round of 256 probes behind the lower end finds it, where the search over all of W takes three dependent rounds; those probes and the
+// next chunk's positions are asked for while the current chunk's bisections run, so a chunk no longer waits for memory at all (one
+// chunk per block, each behind its own four round trips, was 0.83 ms for 1.3 GB of positions).
+constexpr uint32_t WG_OG = 8;
 template <bool RAW>
 __global__ __launch_bounds__(256) void wg_offsets_stream_k(const uint64_t* __restrict__ chi, const int32_t* __restrict__ rtid,
                                                            const int32_t* __restrict__ rpos, const int32_t* __restrict__ ctid,
@@ -159,9 +165,11 @@ __global__ __launch_bounds__(256) void wg_offsets_stream_k(const uint64_t* __res
                                                            uint32_t n, const uint64_t* __restrict__ W, uint32_t nW, uint32_t nrows,
                                                            uint32_t* __restrict__ offT, uint32_t* __restrict__ err) {
   __shared__ uint64_t key[WG_OC];
-  __shared__ uint32_t s_f;
   __shared__ uint32_t s_cnt[2][4];  // (two parities: one barrier per round)
+  __shared__ uint32_t s_loc[2][4];
+  __shared__ uint32_t s_run[1024 + 1];  // the runs' offsets (k <= 1024: tbk_window_supported): read once per block, not once per chunk and step
   const uint32_t t = threadIdx.x;
+  for (uint32_t f = t; f <= k; f += 256) s_run[f] = run_off[f];
   // Two upper bounds in W at once (first r with W[r] > v), one per half of the block: every round the 128 threads of a half probe
   // evenly spaced bounds of the interval left — three rounds for any nW < 2^21, where a bisection by one thread waits on ~20
   // dependent loads (that wait, not the writes, was most of this kernel).  Both halves return both answers.
@@ -197,57 +205,117 @@ __global__ __launch_bounds__(256) void wg_offsets_stream_k(const uint64_t* __res
     *ra = lo[0];
     *rb = lo[1];
   };
-  const uint32_t i0 = blockIdx.x * WG_OC;
-  const uint32_t i1 = n - i0 < WG_OC ? n : i0 + WG_OC;
-  static_assert(WG_TC % WG_OC == 0, "a block of the offsets pass lies inside one chunk of reference ids");
-  if constexpr (RAW) {
-    const int32_t ct = ctid[i0 / WG_TC];  // (uniform) the chunk's reference id, or: read them
-    if (ct != WG_TC_MIXED)
-      for (uint32_t j = t; j < i1 - i0; j += 256) key[j] = raw_key(ct, rpos[i0 + j]);
-    else
-      for (uint32_t j = t; j < i1 - i0; j += 256) key[j] = raw_key(rtid[i0 + j], rpos[i0 + j]);
-  } else {
-    for (uint32_t j = t; j < i1 - i0; j += 256) key[j] = chi[i0 + j] >> 2;
-  }
-  if (t == 0) {
-    uint32_t lo = 0, hi = k;  // last f with run_off[f] <= i0
-    while (hi - lo > 1) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (run_off[mid] <= i0)
-        lo = mid;
-      else
-        hi = mid;
-    }
-    s_f = lo;
-  }
-  __syncthreads();
+  static_assert(WG_TC % WG_OC == 0, "a chunk of the offsets pass lies inside one chunk of reference ids");
+  constexpr uint32_t KPT = WG_OC / 256;  // keys per thread
   bool bad = false;
-  for (uint32_t f = s_f; f < k; ++f) {
-    const uint32_t a = run_off[f], b = run_off[f + 1];
-    if (a >= i1) break;
-    if (b <= i0 || a == b) continue;
-    const uint32_t sa = a > i0 ? a : i0, sb = b < i1 ? b : i1;  // the run's records inside this block
-    const bool has_lo = sa > a;                                  // (then sa == i0: the record before is outside the block)
-    const uint64_t klo = has_lo ? (RAW ? raw_key(rtid[sa - 1], rpos[sa - 1]) : (chi[sa - 1] >> 2)) : 0ull;
-    uint32_t r_lo, r_hi;
-    upper_bounds2(klo, !has_lo, key[sb - 1 - i0], sb == b, &r_lo, &r_hi);
-    r_hi = sb == b ? nW : r_hi;
-    for (uint32_t r = r_lo + t; r < r_hi; r += 256) {
-      const uint64_t v = W[r];
-      uint32_t lo = sa - i0, hi = sb - i0;  // first record of the segment with key >= v (none: the run ends here)
-      while (lo < hi) {
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        if (key[mid] < v)
-          lo = mid + 1;
+  // carried from chunk to chunk: the run the last segment belonged to, where it ended (record) and its upper end in W; the probes
+  // W[c_rhi + t] asked for ahead (wprobe), and the next chunk's positions (npos)
+  uint32_t c_f = ~0u, c_end = 0, c_rhi = 0;
+  uint64_t wprobe = 0, c_klast = 0;  // (c_klast: the last key of that segment = the key before the one that continues it)
+  int32_t npos[KPT];
+  const uint32_t chunk0 = blockIdx.x * WG_OG;
+  {
+    const uint32_t i0 = chunk0 * WG_OC;
+#pragma unroll
+    for (uint32_t u = 0; u < KPT; ++u) npos[u] = (RAW && i0 + u * 256u + t < n) ? rpos[i0 + u * 256u + t] : 0;
+  }
+  for (uint32_t g = 0; g < WG_OG; ++g) {
+    const uint32_t i0 = (chunk0 + g) * WG_OC;
+    if (i0 >= n) break;  // (uniform)
+    const uint32_t i1 = n - i0 < WG_OC ? n : i0 + WG_OC;
+    if (g) __syncthreads();  // (the keys of the chunk before are no longer read)
+    if constexpr (RAW) {
+      const int32_t ct = ctid[i0 / WG_TC];  // (uniform) the chunk's reference id, or: read them
+#pragma unroll
+      for (uint32_t u = 0; u < KPT; ++u) {
+        const uint32_t j = u * 256u + t;
+        if (j < i1 - i0) key[j] = raw_key(ct != WG_TC_MIXED ? ct : rtid[i0 + j], npos[u]);
+      }
+      const uint32_t n0 = i0 + WG_OC;  // the next chunk's positions: on their way while this chunk is worked on
+      if (g + 1 < WG_OG) {
+#pragma unroll
+        for (uint32_t u = 0; u < KPT; ++u) npos[u] = n0 + u * 256u + t < n ? rpos[n0 + u * 256u + t] : 0;
+      }
+    } else {
+      for (uint32_t j = t; j < i1 - i0; j += 256) key[j] = chi[i0 + j] >> 2;
+    }
+    __syncthreads();  // (the keys; in the first chunk the runs' offsets too)
+    uint32_t f_first;  // last f with run_off[f] <= i0 (every thread for itself: the table is in LDS)
+    {
+      uint32_t lo = 0, hi = k;
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (s_run[mid] <= i0)
+          lo = mid;
         else
           hi = mid;
       }
-      offT[(size_t)f * nrows + (r + 1)] = i0 + lo;  // (consecutive r: consecutive words)
+      f_first = lo;
     }
-    if (RAW) {
-      for (uint32_t j = sa + t; j < sb; j += 256) {
-        const uint64_t pk = j > sa ? key[j - 1 - i0] : klo;
-        bad |= pk > key[j - i0];
+    uint32_t seg = 0;  // segments of this chunk so far (the parity of the probe counts' LDS words)
+    for (uint32_t f = f_first; f < k; ++f) {
+      const uint32_t a = s_run[f], b = s_run[f + 1];
+      if (a >= i1) break;
+      if (b <= i0 || a == b) continue;
+      const uint32_t sa = a > i0 ? a : i0, sb = b < i1 ? b : i1;  // the run's records inside this chunk
+      const bool has_lo = sa > a;                                  // (then sa == i0: the record before is outside the chunk)
+      const bool cont = has_lo && c_f == f && c_end == sa;         // it continues the segment the chunk before ended with
+      const uint64_t klo = !has_lo ? 0ull : cont ? c_klast : (RAW ? raw_key(rtid[sa - 1], rpos[sa - 1]) : (chi[sa - 1] >> 2));
+      const uint64_t khi = key[sb - 1 - i0];
+      uint32_t r_lo, r_hi;
+      bool found = false, have_v = false;
+      if (cont && sb == b) {  // ... and the run ends here: every bound that is left
+        r_lo = c_rhi;
+        r_hi = nW;
+        found = true;
+      } else if (cont) {
+        // the segment continues the one the chunk before ended with: its range starts where that one's ended, and ends within the
+        // 256 bounds behind it unless the chunk spans more of them (then: the search over all of W)
+        r_lo = c_rhi;
+        const bool le = r_lo + t < nW && wprobe <= khi;  // wprobe = W[r_lo + t], asked for a chunk ago
+        const uint64_t mb = __ballot(le);
+        uint32_t* sl = s_loc[(g + seg) & 1u];  // (a chunk has one such segment — its first —, consecutive chunks alternate)
+        if ((t & 63u) == 0) sl[t >> 6] = (uint32_t)__builtin_popcountll(mb);
+        __syncthreads();
+        const uint32_t c = sl[0] + sl[1] + sl[2] + sl[3];
+        if (c < 256u) {
+          r_hi = r_lo + c;
+          found = true;
+          have_v = true;  // thread t < c holds bound r_lo + t in wprobe
+        }
+      }
+      ++seg;
+      if (!found) {
+        upper_bounds2(klo, !has_lo, khi, sb == b, &r_lo, &r_hi);
+        r_hi = sb == b ? nW : r_hi;
+      }
+      const uint64_t v_mine = wprobe;
+      if (sb != b) {  // the run goes on in the next chunk: its probes
+        c_f = f;
+        c_end = sb;
+        c_rhi = r_hi;
+        c_klast = khi;
+        wprobe = r_hi + t < nW ? W[r_hi + t] : ~0ull;
+      } else {
+        c_f = ~0u;
+      }
+      for (uint32_t r = r_lo + t; r < r_hi; r += 256) {
+        const uint64_t v = have_v ? v_mine : W[r];  // (have_v: r_hi - r_lo < 256, one bound per thread at most)
+        uint32_t lo = sa - i0, hi = sb - i0;  // first record of the segment with key >= v (none: the run ends here)
+        while (lo < hi) {
+          const uint32_t mid = lo + ((hi - lo) >> 1);
+          if (key[mid] < v)
+            lo = mid + 1;
+          else
+            hi = mid;
+        }
+        offT[(size_t)f * nrows + (r + 1)] = i0 + lo;  // (consecutive r: consecutive words)
+      }
+      if (RAW) {
+        for (uint32_t j = sa + t; j < sb; j += 256) {
+          const uint64_t pk = j > sa ? key[j - 1 - i0] : klo;
+          bad |= pk > key[j - i0];
+        }
       }
     }
   }
@@ -2124,9 +2192,9 @@ static int wg_offsets_build(tbk_ctx* ctx, bool raw, const uint64_t* chi, const i
   uint32_t* offT = ws_alloc<uint32_t>(ctx, (size_t)nrows * k);
   if (!offT) return TBK_ENOMEM;
   if (raw)
-    TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_stream_k<true>, cdiv(m, WG_OC), 256, 0, chi, rtid, rpos, ctid, d_run_off, k, m, W, nW, nrows, offT, ctx->d_err);
+    TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_stream_k<true>, cdiv(m, WG_OC * WG_OG), 256, 0, chi, rtid, rpos, ctid, d_run_off, k, m, W, nW, nrows, offT, ctx->d_err);
   else
-    TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_stream_k<false>, cdiv(m, WG_OC), 256, 0, chi, rtid, rpos, ctid, d_run_off, k, m, W, nW, nrows, offT, ctx->d_err);
+    TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_stream_k<false>, cdiv(m, WG_OC * WG_OG), 256, 0, chi, rtid, rpos, ctid, d_run_off, k, m, W, nW, nrows, offT, ctx->d_err);
   TBK_LAUNCH(ctx, "wg_offsets_edges", wg_offsets_edges_k, k, 256, 0, d_run_off, k, nrows, offT);
   TBK_LAUNCH(ctx, "wg_offsets_transpose", wg_offsets_transpose_k, dim3(cdiv(nrows, 64u), cdiv(k, 64u)), 256, 0, offT, k, nrows, off);
   return 0;
