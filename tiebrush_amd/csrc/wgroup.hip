@@ -44,7 +44,7 @@
 // timed side by side (tools/scratch/wgopt_r5.sh).  2: the carries of the effective-end scan by two broadcast reads where the wave
 // before holds a segment start; 4: 32-bit byte offsets from the (uniform) array bases for a record's loads.
 #ifndef WG_OPT
-#define WG_OPT 6
+#define WG_OPT 22
 #endif
 #include "dev_common.cuh"
 #include "strategy.cuh"
@@ -469,7 +469,9 @@ template <class T>
 __device__ __forceinline__ T wg_ld(const T* base, uint32_t byte_off) {
   return *reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(base) + byte_off);
 }
-__device__ __forceinline__ RawL wg_raw_l(const ColIn& I, uint32_t i, bool need_prev, uint32_t c0, uint32_t c1) {
+// (cols: bit 0 — a filter looks at NH (-N below its maximum), bit 1 — one looks at MAPQ (-Q above zero); a column no filter refers to
+// is not read: 5 of a record's 16 bytes under the default options)
+__device__ __forceinline__ RawL wg_raw_l(const ColIn& I, uint32_t i, bool need_prev, uint32_t c0, uint32_t c1, uint32_t cols = 3u) {
   RawL a;
 #if WG_EXP & 2
   a.pos = (int)(i >> 3);
@@ -492,9 +494,17 @@ __device__ __forceinline__ RawL wg_raw_l(const ColIn& I, uint32_t i, bool need_p
   a.pos = wg_ld(I.pos, o4);
   a.tidv = wg_ld(I.tid, o4);
   a.flag = wg_ld(I.flag, i << 1);
+#if WG_OPT & 16
+  a.mapq = 255;
+  a.nh = 0;
+  if (cols & 2u) a.mapq = wg_ld(I.mapq, i);  // (uniform)
+  a.strand = wg_ld(I.strand, i);
+  if (cols & 1u) a.nh = wg_ld(I.nh, o4);
+#else
   a.mapq = wg_ld(I.mapq, i);
   a.strand = wg_ld(I.strand, i);
   a.nh = wg_ld(I.nh, o4);
+#endif
   a.c0 = c0;
   a.nc = c1 - c0;
   const uint32_t p4 = need_prev && i > 0 ? o4 - 4u : o4;
@@ -1087,7 +1097,7 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
       n_src = a_src;
       n_first = !act1 || e1 == pre[n_fil];
       n_fromem = act1 && (n_first || lane_id() == 0);
-      n_l = wg_raw_l(R.I, n_src, n_fromem, a_c0, a_c1);
+      n_l = wg_raw_l(R.I, n_src, n_fromem, a_c0, a_c1, (R.O.max_nh != INT32_MAX ? 1u : 0u) | (R.O.min_qual > 0 ? 2u : 0u));
       n_f0 = n_fromem ? R.I.file_off[n_fil] : 0u;
       const uint32_t e2 = cb + WG_NT + t;
       a_fil = a_src = a_c0 = a_c1 = 0;
