@@ -673,9 +673,13 @@ def main():
         # what the kernels owe in THIS run: the collapse writes no per-record group id (rec_group is not requested: 4 B per record of the
         # §8d figure are never written); cov_tile_k reads the view's records and writes change points — the 16 S bytes of the reference's
         # depth array never exist in HBM, the run-length pass and the interval writes belong to cov_iv_*
-        b_collapse_owed = gg["n_passed"] * 12 + 4 * n_cig_in
+        # ... and the window kernels read the NH and MAPQ columns only when -N / -Q refer to them (5 of a record's 12 input bytes)
+        opts_ = WORKLOADS[profile][2]
+        cols_skipped = 0 if ("max_nh" in opts_ or "min_qual" in opts_) else 5
+        b_collapse_owed = gg["n_passed"] * (12 - cols_skipped) + 4 * n_cig_in
         b_cov_own = gg["n_groups"] * 12 + 4 * ncig_cov + 16 * cc["n_intervals"]
-        note_c = "records in (12 B + CIGAR words); no group-id write: rec_group is not requested"
+        note_c = ("records in (%d B + CIGAR words%s); no group-id write: rec_group is not requested"
+                  % (12 - cols_skipped, "; NH and MAPQ are not read: no filter refers to them" if cols_skipped else ""))
         note_v = "view records in (12 B + CIGAR words) + change points out (16 B each, at least one per interval: a lower bound)"
         roof["roofline"] = roofline(dom[0], dom[1], b_collapse if dom[0] == "collapse" else b_cov,
                                     owed_bytes=b_collapse_owed if dom[0] == "collapse" else b_cov_own, owed_note=note_c if dom[0] == "collapse" else note_v)
