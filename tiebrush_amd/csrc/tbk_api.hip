@@ -289,25 +289,8 @@ hipStream_t tbk_aux_stream(tbk_ctx* ctx) {
 }
 
 // ---- side context ----------------------------------------------------------------------------------------
-// A side branch (the junction table beside the intervals; the YD stage beside the next tile) runs on a stream of the lowest priority:
-// the branch that the caller waits for is the other one, and its small kernels — a single block between two passes — otherwise
-// queue behind the side branch's grids for a CU with room (a 16-wave block waited 100-180 us of the 1.4 ms coverage call).
-static void side_stream_priority(tbk_ctx* side) {
-  int least = 0, greatest = 0;
-  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest) return;
-  hipStream_t s = nullptr;
-  if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least) != hipSuccess) return;
-  if (side->stream == side->own_stream) side->stream = s;
-  (void)hipStreamDestroy(side->own_stream);
-  side->own_stream = s;
-}
 tbk_ctx* tbk_side_ctx(tbk_ctx* ctx) {
-  if (!ctx->side_ctx) {
-    if (tbk_create(ctx->device, &ctx->side_ctx) != 0)
-      ctx->side_ctx = nullptr;
-    else
-      side_stream_priority(ctx->side_ctx);
-  }
+  if (!ctx->side_ctx && tbk_create(ctx->device, &ctx->side_ctx) != 0) ctx->side_ctx = nullptr;
   if (ctx->side_ctx) {
     ctx->side_ctx->profiling = ctx->profiling;
     ctx->side_ctx->dbg = ctx->dbg;
@@ -667,12 +650,7 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
       void* job = ctx->yd_job;
       ctx->yd_job = nullptr;
       bool defer = opts->defer_yd && ctx->ws_overflow.empty();  // arena must be in steady state to pin a prefix of it
-      if (defer && !ctx->yd_ctx) {
-        if (tbk_create(ctx->device, &ctx->yd_ctx) != 0)
-          defer = false;
-        else
-          side_stream_priority(ctx->yd_ctx);
-      }
+      if (defer && !ctx->yd_ctx && tbk_create(ctx->device, &ctx->yd_ctx) != 0) defer = false;
       if (defer) {
         ctx->yd_ctx->profiling = ctx->profiling;
         ctx->yd_ctx->dbg = ctx->dbg;
