@@ -545,9 +545,18 @@ int main(int argc, char* argv[]) {
             out.yc = yc.data();
             out.yx = yx.data();
             out.yd = yd.data();
+            if (timing) (void)api.set_profiling(ctx, 1);
             rc = api.collapse_tile(ctx, &opt, &in, &out);
             if (rc == 0 && getenv("TBK_TEST_WHOLE_ENOMEM")) rc = TBK_ENOMEM;  // test hook: exercise the fall-back below
             t_col = tnow();
+            if (timing) {
+              tbk_kernel_time kt[64];
+              const int nk = api.kernel_times(ctx, kt, 64);
+              double sum = 0;
+              for (int i = 0; i < nk; ++i) sum += kt[i].ms;
+              fprintf(stderr, "collapse call: %.1f ms, its kernels %.1f ms in %d kinds\n", tms(t_join, t_col), sum, nk);
+              (void)api.set_profiling(ctx, 0);
+            }
             if (rc == TBK_EUNSORTED) GError("Error: an input file is not coordinate-sorted!\n");
           }
           bool wrote_dev = false;
