@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void wg_offsets_stream_k(const uint64_t* __res
                                                            const int32_t* __restrict__ rpos, const int32_t* __restrict__ ctid,
                                                            const uint32_t* __restrict__ run_off, uint32_t k,
                                                            uint32_t n, const uint64_t* __restrict__ W, uint32_t nW, uint32_t nrows,
-                                                           uint32_t* __restrict__ offT, uint32_t* __restrict__ err) {
+                                                           uint32_t* __restrict__ offT, uint32_t* __restrict__ err, uint32_t og /* chunks per block, <= WG_OG */) {
   __shared__ uint64_t key[WG_OC];
   __shared__ uint32_t s_cnt[2][4];  // (two parities: one barrier per round)
   __shared__ uint32_t s_loc[2][4];
@@ -173,10 +173,12 @@ __global__ __launch_bounds__(256) void wg_offsets_stream_k(const uint64_t* __res
   // Two upper bounds in W at once (first r with W[r] > v), one per half of the block: every round the 128 threads of a half probe
   // evenly spaced bounds of the interval left — three rounds for any nW < 2^21, where a bisection by one thread waits on ~20
   // dependent loads (that wait, not the writes, was most of this kernel).  Both halves return both answers.
+  // (the parity of the count words goes on from call to call: a call that began at parity 0 again could overwrite the words a slower wave
+  // is still reading in the last round of the call before — two searches in a row happen wherever a chunk holds pieces of several runs)
+  uint32_t par = 0;
   auto upper_bounds2 = [&](uint64_t va, bool skip_a, uint64_t vb, bool skip_b, uint32_t* ra, uint32_t* rb) {
     const uint32_t half = t >> 7, j = t & 127u;
     uint32_t lo[2] = {0u, 0u}, hi[2] = {skip_a ? 0u : nW, skip_b ? 0u : nW};
-    uint32_t par = 0;
     while (lo[0] < hi[0] || lo[1] < hi[1]) {  // (uniform)
       const uint32_t l = lo[half], h = hi[half];
       const uint32_t step = (h - l + 127u) >> 7;
@@ -213,13 +215,13 @@ __global__ __launch_bounds__(256) void wg_offsets_stream_k(const uint64_t* __res
   uint32_t c_f = ~0u, c_end = 0, c_rhi = 0;
   uint64_t wprobe = 0, c_klast = 0;  // (c_klast: the last key of that segment = the key before the one that continues it)
   int32_t npos[KPT];
-  const uint32_t chunk0 = blockIdx.x * WG_OG;
+  const uint32_t chunk0 = blockIdx.x * og;
   {
     const uint32_t i0 = chunk0 * WG_OC;
 #pragma unroll
     for (uint32_t u = 0; u < KPT; ++u) npos[u] = (RAW && i0 + u * 256u + t < n) ? rpos[i0 + u * 256u + t] : 0;
   }
-  for (uint32_t g = 0; g < WG_OG; ++g) {
+  for (uint32_t g = 0; g < og; ++g) {
     const uint32_t i0 = (chunk0 + g) * WG_OC;
     if (i0 >= n) break;  // (uniform)
     const uint32_t i1 = n - i0 < WG_OC ? n : i0 + WG_OC;
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256) void wg_offsets_stream_k(const uint64_t* __res
         if (j < i1 - i0) key[j] = raw_key(ct != WG_TC_MIXED ? ct : rtid[i0 + j], npos[u]);
       }
       const uint32_t n0 = i0 + WG_OC;  // the next chunk's positions: on their way while this chunk is worked on
-      if (g + 1 < WG_OG) {
+      if (g + 1 < og) {
 #pragma unroll
         for (uint32_t u = 0; u < KPT; ++u) npos[u] = n0 + u * 256u + t < n ? rpos[n0 + u * 256u + t] : 0;
       }
@@ -2201,10 +2203,13 @@ static int wg_offsets_build(tbk_ctx* ctx, bool raw, const uint64_t* chi, const i
                             uint32_t m, const uint64_t* W, uint32_t nW, uint32_t nrows, uint32_t* off) {
   uint32_t* offT = ws_alloc<uint32_t>(ctx, (size_t)nrows * k);
   if (!offT) return TBK_ENOMEM;
+  // chunks per block: eight where that still leaves a few thousand blocks, fewer on small inputs (the owner's side of the multi-rank
+  // protocol: 7 M rows as 450 blocks took twice as long as 3 600 blocks of one chunk)
+  const uint32_t og = std::min<uint32_t>(WG_OG, std::max<uint32_t>(1u, m / (WG_OC * 2048u)));
   if (raw)
-    TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_stream_k<true>, cdiv(m, WG_OC * WG_OG), 256, 0, chi, rtid, rpos, ctid, d_run_off, k, m, W, nW, nrows, offT, ctx->d_err);
+    TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_stream_k<true>, cdiv(m, WG_OC * og), 256, 0, chi, rtid, rpos, ctid, d_run_off, k, m, W, nW, nrows, offT, ctx->d_err, og);
   else
-    TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_stream_k<false>, cdiv(m, WG_OC * WG_OG), 256, 0, chi, rtid, rpos, ctid, d_run_off, k, m, W, nW, nrows, offT, ctx->d_err);
+    TBK_LAUNCH(ctx, "wg_offsets", wg_offsets_stream_k<false>, cdiv(m, WG_OC * og), 256, 0, chi, rtid, rpos, ctid, d_run_off, k, m, W, nW, nrows, offT, ctx->d_err, og);
   TBK_LAUNCH(ctx, "wg_offsets_edges", wg_offsets_edges_k, k, 256, 0, d_run_off, k, nrows, offT);
   TBK_LAUNCH(ctx, "wg_offsets_transpose", wg_offsets_transpose_k, dim3(cdiv(nrows, 64u), cdiv(k, 64u)), 256, 0, offT, k, nrows, off);
   return 0;

@@ -21,3 +21,13 @@ cp $P/bench_c4_strong_n1.json profiles/${R}_bench_c4_strong_n1.json
 cp $P/bench_c4shape.json profiles/${R}_bench_c4shape.json
 cp $P/bench_c5shape.json profiles/${R}_bench_c5shape.json
 cp $P/cov_prof_c3_intervals_only.txt profiles/${R}_cov_prof_c3_intervals_only.txt
+# round 5's additions (tools/refresh_profiles_c.sh)
+if [ -f $P/deflate_bench.json ]; then
+  cp $P/deflate_bench.json profiles/${R}_deflate_bench.json
+  cp $P/deflate_kernel_stats.csv profiles/${R}_deflate_kernel_stats.csv
+  cp $P/e2e_seq_cli.txt profiles/${R}_e2e_seq_cli.txt
+  cp $P/e2e_seq_kernel_stats.csv profiles/${R}_e2e_seq_kernel_stats.csv
+  cp $P/e2e_seq_memory_copy_stats.csv profiles/${R}_e2e_seq_memory_copy_stats.csv
+  cp $P/e2e_legs.json profiles/${R}_e2e_legs.json
+  cp $P/bench_force_dist_emulate8.json profiles/${R}_bench_c4shape_force_dist_emulate8.json
+fi
