@@ -14,5 +14,5 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         T.test_fuzz_collapse_forced_run_sort(ctx, seed, MP())
     except AssertionError as e:
         bad += 1; print("FAIL seed", seed, str(e)[:200], flush=True)
-    os.environ.pop("TBK_SORT", None)
+    os.environ.pop("TBK_DEBUG", None)
 print("sort soak done, failures:", bad)

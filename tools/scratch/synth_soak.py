@@ -17,8 +17,8 @@ for it in range(int(sys.argv[1])):
     tile = synth.make_tile(files, reads, prof, n_loci=loci)
     kw = {"c2": {}, "c3": dict(strategy="clip"), "c5": dict(strategy="exon", max_nh=5, min_qual=1)}[prof]
     for path in ("window", None):
-        if path: os.environ["TBK_PATH"] = path
-        else: os.environ.pop("TBK_PATH", None)
+        if path: os.environ["TBK_DEBUG"] = "path=" + path
+        else: os.environ.pop("TBK_DEBUG", None)
         try:
             _cmp(ctx, tile, **kw); n += 1
         except AssertionError as e:

@@ -5,11 +5,10 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from test_gpu_fuzz import STRATS, _cmp, _rand_tile
 from tiebrush_amd import api, synth
-os.environ["TBK_PATH"] = "window"
 ctx = api.Context(0)
 n = 0
 for raw in ("1", "0"):
-    os.environ["TBK_RAW"] = raw
+    os.environ["TBK_DEBUG"] = "path=window,raw=" + raw   # (the binding forwards a changed TBK_DEBUG to the live context)
     for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
         rng = np.random.default_rng(31000 + seed)
         for _ in range(6):

@@ -8,7 +8,6 @@ import numpy as np
 from test_gpu_fuzz import _cmp
 from oracle import oracle_ffi as orc
 from tiebrush_amd import api, synth
-os.environ["TBK_PATH"] = "window"
 ctx = api.Context(0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 rng = np.random.default_rng(424242)
@@ -25,7 +24,7 @@ for it in range(N):
     kw, okw = KW[prof]
     if rng.random() < 0.3:
         kw, okw = (dict(), dict())          # default strategy on any profile
-    os.environ["TBK_RAW"] = "1" if rng.random() < 0.8 else "0"
+    os.environ["TBK_DEBUG"] = "path=window,raw=" + ("1" if rng.random() < 0.8 else "0")
     want = _cmp(ctx, tile, **kw)
     # device chain with the view from the keys
     dt = api.to_device(tile, "cuda:0")
