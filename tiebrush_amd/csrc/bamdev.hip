@@ -28,7 +28,6 @@
 namespace {
 
 // ---- RFC 1951 inflate ------------------------------------------------------------------------
-constexpr int INF_NT = 64;           // one wave per block: 64 members
 
 struct BitIn {
   const uint8_t* p;

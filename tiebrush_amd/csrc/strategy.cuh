@@ -233,10 +233,8 @@ __device__ __forceinline__ RecKey record_key(const ColIn& I, const ColOpt& O, ui
         h32 = 0xC0000000u | (cig_len(v.v0) << 20) | cig_len(v.v1);
         exact = true;
       }
-#ifndef TBK_NO_VIEW_HASH
       if (pass && !exact) h32 = (uint32_t)(view_hash(O.seed, v, c) >> 32) & O.hash_mask & 0x7FFFFFFFu;
       hashed = true;
-#endif
     }
   }
   if (pass && !exact && !hashed) h32 = (uint32_t)(strategy_hash(I, O, strategy, i, c, nc) >> 32) & O.hash_mask & 0x7FFFFFFFu;

@@ -40,12 +40,6 @@
 #ifndef WG_EXP
 #define WG_EXP 0
 #endif
-// WG_OPT (build-time): round-5 instruction cuts of the raw window kernel, each behind a bit so that builds with and without it can be
-// timed side by side (tools/scratch/wgopt_r5.sh).  2: the carries of the effective-end scan by two broadcast reads where the wave
-// before holds a segment start; 4: 32-bit byte offsets from the (uniform) array bases for a record's loads.
-#ifndef WG_OPT
-#define WG_OPT 22
-#endif
 #include "dev_common.cuh"
 #include "strategy.cuh"
 #include "tbk_internal.h"
@@ -489,24 +483,17 @@ __device__ __forceinline__ RawL wg_raw_l(const ColIn& I, uint32_t i, bool need_p
   a.w1 = a.w2 = 0;
   return a;
 #endif
-#if WG_OPT & 4
   // byte offsets of 32 bits from the arrays' bases, which are uniform: one shift serves every 4-byte array, and the loads take the base
   // from scalar registers (the raw form runs on tiles of < 2^30 records and CIGAR words: tbk_window_groups)
   const uint32_t o4 = i << 2;
   a.pos = wg_ld(I.pos, o4);
   a.tidv = wg_ld(I.tid, o4);
   a.flag = wg_ld(I.flag, i << 1);
-#if WG_OPT & 16
   a.mapq = 255;
   a.nh = 0;
   if (cols & 2u) a.mapq = wg_ld(I.mapq, i);  // (uniform)
   a.strand = wg_ld(I.strand, i);
   if (cols & 1u) a.nh = wg_ld(I.nh, o4);
-#else
-  a.mapq = wg_ld(I.mapq, i);
-  a.strand = wg_ld(I.strand, i);
-  a.nh = wg_ld(I.nh, o4);
-#endif
   a.c0 = c0;
   a.nc = c1 - c0;
   const uint32_t p4 = need_prev && i > 0 ? o4 - 4u : o4;
@@ -517,24 +504,6 @@ __device__ __forceinline__ RawL wg_raw_l(const ColIn& I, uint32_t i, bool need_p
   a.w1 = wg_ld(I.cig, a.nc > 1 ? q4 + 4u : 0u);
   a.w2 = wg_ld(I.cig, a.nc > 2 ? q4 + 8u : 0u);
   return a;
-#else
-  a.pos = I.pos[i];
-  a.tidv = I.tid[i];
-  a.flag = I.flag[i];
-  a.mapq = I.mapq[i];
-  a.strand = I.strand[i];
-  a.nh = I.nh[i];
-  a.c0 = c0;
-  a.nc = c1 - c0;
-  const uint32_t j = need_prev && i > 0 ? i - 1 : i;
-  a.ppos = I.pos[j];
-  a.ptid = I.tid[j];
-  const uint32_t* safe = I.cig_off;  // (always readable)
-  a.w0 = *(a.nc > 0 ? I.cig + c0 : safe);
-  a.w1 = *(a.nc > 1 ? I.cig + c0 + 1 : safe);
-  a.w2 = *(a.nc > 2 ? I.cig + c0 + 2 : safe);
-  return a;
-#endif
 }
 template <int ST>
 __device__ __forceinline__ RawRec wg_raw_c(const WgRaw& R, uint32_t i, const RawA& a, const CigView& c) {
@@ -1074,12 +1043,9 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
       a_src = rb[a_fil] + t;
 #if WG_EXP & 2
       a_c0 = a_src; a_c1 = a_src + 1;
-#elif WG_OPT & 4
+#else
       a_c0 = wg_ld(R.I.cig_off, a_src << 2);
       a_c1 = wg_ld(R.I.cig_off, (a_src << 2) + 4u);
-#else
-      a_c0 = R.I.cig_off[a_src];
-      a_c1 = R.I.cig_off[a_src + 1];
 #endif
     }
   }
@@ -1109,12 +1075,9 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
 #if WG_EXP & 2
         a_c0 = a_src;
         a_c1 = a_src + 1;
-#elif WG_OPT & 4
+#else
         a_c0 = wg_ld(R.I.cig_off, a_src << 2);
         a_c1 = wg_ld(R.I.cig_off, (a_src << 2) + 4u);
-#else
-        a_c0 = R.I.cig_off[a_src];
-        a_c1 = R.I.cig_off[a_src + 1];
 #endif
       }
     }
@@ -1294,7 +1257,6 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
         const uint32_t cin = s_misc[4 + par];
         const int wv = __builtin_amdgcn_readfirstlane((int)(t >> 6));
         bool folded = false;
-#if WG_OPT & 2
         if constexpr (NR == 1) {
           // The carry into a wave is the aggregate of the wave before it wherever that wave holds a segment start — the first record of a
           // piece, or a record that does not repeat its predecessor's position: nearly every wave — and the chunk's carry-out is the last
@@ -1309,7 +1271,6 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
             folded = true;
           }
         }
-#endif
         if (!folded) {
           const uint32_t lq = lane_id();
           const uint2 a = lq < (uint32_t)(NR * WG_NW) ? s_agg[lq] : make_uint2(0u, 0u);

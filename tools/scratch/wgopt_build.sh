@@ -1,6 +1,6 @@
 #!/bin/bash
 # builds variants of libtbk.so under gpurun_exp/<name>/ : name = flags for wgroup.hip and collapse.hip (the other objects are shared)
-# usage: wgopt_build.sh name "-DWG_OPT=0 -DTBK_NO_VIEW_HASH" ...
+# usage: wgopt_build.sh name "-DSOME_SWITCH=0" ...   (round 5 timed the window kernel's cuts this way: -DWG_OPT=<bits>, since removed)
 set -e
 cd /root/repo/tiebrush_amd/csrc
 B=../_build
