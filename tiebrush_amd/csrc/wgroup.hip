@@ -69,6 +69,39 @@ __global__ void wg_sample_k(const uint64_t* __restrict__ chi, uint32_t m, uint32
   shi[j] = chi[d < m ? d : m - 1] >> 2;
 }
 
+// The samples of k SORTED runs (sample j = key of record j * s; the runs lie end to end) need no sort to find the splitters: a sample's
+// rank among all samples is its index inside its own run plus, for every other run, the number of that run's samples before it — a
+// bisection per run over the run's samples where they lie (ties: the earlier run first, so every rank is taken once).  The samples whose
+// rank is a multiple of g are the ones wg_split_k reads: Z[q] = the sample of rank q * g.  (The owner's side of the multi-rank protocol:
+// one launch where the radix sort of the samples took ten)
+__global__ __launch_bounds__(256) void pr_sample_rank_k(const uint64_t* __restrict__ chi, uint32_t m, uint32_t s, uint32_t ns,
+                                                        const uint32_t* __restrict__ run_off, uint32_t k, uint32_t g, uint64_t* __restrict__ Z) {
+  __shared__ uint32_t j0[64 + 1];  // first sample of run r (k <= PR_MAXRUNS = 64); j0[k] = ns
+  if (threadIdx.x <= k) j0[threadIdx.x] = threadIdx.x == k ? ns : (uint32_t)(((uint64_t)run_off[threadIdx.x] + s - 1u) / s);
+  __syncthreads();
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ns) return;
+  const uint64_t K = chi[(uint64_t)j * s] >> 2;  // (j * s < m: ns = ceil(m / s))
+  uint32_t r = 0;  // the run sample j lies in: last r with j0[r] <= j (empty runs repeat a value)
+  for (uint32_t q = 1; q < k; ++q) r = j0[q] <= j ? q : r;
+  uint32_t rank = j - j0[r];
+  for (uint32_t q = 0; q < k; ++q) {
+    if (q == r) continue;
+    uint32_t lo = j0[q], hi = j0[q + 1];  // first sample of run q that is not before K (before: <, and = for the runs ahead of r)
+    const uint32_t b = lo;
+    while (lo < hi) {
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      const uint64_t v = chi[(uint64_t)mid * s] >> 2;
+      if (q < r ? v <= K : v < K)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    rank += lo - b;
+  }
+  if (rank % g == 0) Z[rank / g] = K;
+}
+
 // Y sorted samples; splitter i = Y[(i + 1) * g].  Two bounds per splitter: first of a run of equal splitters -> (v, v + 1 if
 // the run is longer than one else v); the others -> (v + 1, v + 1).  Equal consecutive bounds make empty windows.
 __global__ void wg_split_k(const uint64_t* __restrict__ Y, uint32_t g, uint32_t nsp, uint64_t* __restrict__ W) {
@@ -2222,13 +2255,11 @@ int tbk_partial_reduce_device(tbk_ctx* ctx, int strategy, const int32_t* rows, u
   T.klo = ws_alloc<uint64_t>(ctx, m);
   T.wg_cnt = ws_alloc<uint32_t>(ctx, nw);
   if (!W || !off || !wbase || !gbase || !T.wg_cnt || !T.klo) return TBK_ENOMEM;
-  if (nsp) {
-    uint64_t* Y = ws_alloc<uint64_t>(ctx, ns);
-    uint64_t* Y2 = ws_alloc<uint64_t>(ctx, ns);
-    if (!Y2) return TBK_ENOMEM;
-    TBK_LAUNCH(ctx, "wg_sample", wg_sample_k, cdiv(ns, B), B, 0, chi, m, s, ns, Y);
-    TBK_TRY(tbk_radix_sort_w64(ctx, &Y, &Y2, ns, ~0ull, false));
-    TBK_LAUNCH(ctx, "wg_split", wg_split_k, cdiv(nsp, B), B, 0, Y, g, nsp, W);
+  if (nsp) {  // the samples' ranks by bisection in the sorted runs (pr_sample_rank_k): every g-th sample in rank order, then the bounds
+    uint64_t* Z = ws_alloc<uint64_t>(ctx, (size_t)ns / g + 2);
+    if (!Z) return TBK_ENOMEM;
+    TBK_LAUNCH(ctx, "pr_sample_rank", pr_sample_rank_k, cdiv(ns, B), B, 0, chi, m, s, ns, d_run_off, k, g, Z);
+    TBK_LAUNCH(ctx, "wg_split", wg_split_k, cdiv(nsp, B), B, 0, Z, 1u, nsp, W);
   }
   TBK_TRY(wg_offsets_build(ctx, false, chi, nullptr, nullptr, nullptr, d_run_off, k, m, W, nW, nrows, off));
   TBK_LAUNCH(ctx, "wg_rowsum", wg_rowsum_k, cdiv(nrows, 4), 256, 0, off, k, nrows, wbase);
