@@ -535,3 +535,23 @@ def test_tiebrush_ranks_full_strategy_equals_single_gpu(tmp_path):
         assert a.n == b.n and (a.n > c.n if tag == "synthetic" else a.n >= c.n)      # (MD splits groups the CIGAR alone joins)
         for i in range(a.n):
             assert bamio.record_bytes(a, i) == bamio.record_bytes(b, i), (tag, i)
+
+
+def test_tiled_run_writes_behind_the_input_side(tmp_path):
+    """the bounded-memory path on records with SEQ / QUAL: several tiles, each written by the writer thread (its own context) while the
+    next one is inflated and collapsed — the same record stream as the single-tile run, with either writer, well-formed members"""
+    from tiebrush_amd import synth
+    tile = synth.make_tile(4, 40000, "c2", n_loci=300)
+    paths = synth.write_bams_fast(tile, str(tmp_path / "in"), seq=True)
+    whole = str(tmp_path / "whole.bam")
+    _run([os.path.join(BIN, "tiebrush"), "-o", whole] + paths)
+    for writer in ("device", "host"):
+        out = str(tmp_path / ("tiled_%s.bam" % writer))
+        r = subprocess.run([os.path.join(BIN, "tiebrush"), "--writer", writer, "-o", out] + paths, check=True, capture_output=True, text=True,
+                           env=dict(os.environ, TBK_TILE_RECORDS="30000", TBK_TIMING="1"))
+        assert "streamed:" in r.stderr and "writer thread busy" in r.stderr, r.stderr
+        ntiles = int(r.stderr.split("streamed:")[1].split("tiles")[0])
+        assert ntiles >= 3, r.stderr
+        assert ("device writer:" in r.stderr) == (writer == "device")
+        assert _records(out) == _records(whole), writer
+        _members_ok(out)
