@@ -675,10 +675,20 @@ struct YdItems {
 
 // per output group (computed once, every item of the group reuses it): coordinates, exon count, exon list
 struct YdGroups {
-  uint4* pk;       // (tid + 1, start, end, exon count): one 16-byte gather per item instead of four
-  uint32_t* nex;   // the exon counts again, contiguous, as the input of the offset scan
+  uint4* pk;       // (tid + 1, start, end, exon word): one 16-byte gather per item instead of four
+  uint32_t* nex;   // the exon counts, contiguous, as the input of the offset scan
   uint32_t* xoff;
 };
+// The exon word of a group / an item (YdGroups::pk.w, YdItems::nex): the exon count — or, with bit 30 set, the two exons themselves:
+// a group whose key word is the exact code of the shape M N M carries the first block a : 10 and the gap g : 20 (strategy.cuh), so
+// its exons are (start, start + a - 1), (start + a + g, end) and the chain kernels fetch nothing for such an item — neither its group
+// word nor the three sectors of the exon arrays (one item in twelve on config 3, nearly all of them of this shape; 2.6 GB of gathers
+// per launch of yd_wave_k).  Bit 31 of an item's word is the head flag of the items placed by list.
+constexpr uint32_t YD_X2 = 1u << 30;
+__device__ __forceinline__ uint32_t yd_nex_count(uint32_t w) { return (w & YD_X2) ? 2u : (w & 0x3FFFFFFFu); }
+__device__ __forceinline__ bool yd_nex_x2(uint32_t w) { return (w & YD_X2) != 0u; }
+__device__ __forceinline__ uint32_t yd_x2_a(uint32_t w) { return (w >> 20) & 0x3FFu; }
+__device__ __forceinline__ uint32_t yd_x2_g(uint32_t w) { return w & 0xFFFFFu; }
 
 // The exons of a group whose key word is an exact code (strategy.cuh: record_key) follow from the key alone — one
 // reference-consuming operation: one exon (start, end); M N M / two exons with first block a and gap g: (start, start + a - 1),
@@ -712,13 +722,19 @@ __global__ void yd_groups_k(ColIn I, uint32_t ng, const uint32_t* __restrict__ g
   const uint32_t tidp1 = (uint32_t)(h >> 33);
   const uint32_t en = (uint32_t)(st + (int32_t)(uint32_t)(l >> 32) - 1);
   uint32_t e0, s1;
-  int nex = (int)yd_exons_from_key(l, (uint32_t)st, en, &e0, &s1);
+  const uint32_t nk = yd_exons_from_key(l, (uint32_t)st, en, &e0, &s1);
+  int nex = (int)nk;
   if (nex == 0) {
     const uint32_t r = (uint32_t)(G.rep[sg] & 0xFFFFFFFFull);
     walk_exons(I.pos[r], I.cig + I.cig_off[r], I.cig_off[r + 1] - I.cig_off[r], [](int, int) {}, &nex);
   }
   Q.nex[o] = (uint32_t)nex;
-  Q.pk[o] = make_uint4(tidp1, (uint32_t)st, en, (uint32_t)nex);
+  uint32_t xw = (uint32_t)nex;
+  if (nk == 2u) {  // (from the key: the shape's two lengths, both inside their fields by the code's definition)
+    const uint32_t a = e0 - (uint32_t)st + 1u, g = s1 - e0 - 1u;
+    if (a < (1u << 10) && g < (1u << 20)) xw = YD_X2 | (a << 20) | g;
+  }
+  Q.pk[o] = make_uint4(tidp1, (uint32_t)st, en, xw);
 }
 
 __global__ void yd_gexons_k(ColIn I, uint32_t ng, const uint32_t* __restrict__ gperm, GroupAcc G, const uint64_t* __restrict__ slo, YdGroups Q,
@@ -923,7 +939,7 @@ struct HeadNexOp {
 };
 struct YdAux {  // (start, exon count) of the item
   YdItems Y;
-  __device__ __forceinline__ int2 operator()(uint32_t t) const { return make_int2(Y.start(t), (int)Y.nex[t]); }
+  __device__ __forceinline__ int2 operator()(uint32_t t) const { return make_int2(Y.start(t), (int)yd_nex_count(Y.nex[t])); }
 };
 struct YdHead {
   __device__ __forceinline__ HeadNex operator()(uint32_t, const SegMaxY& v, const SegMaxY&, const SegMaxY& ex, const int2& a) const {
@@ -969,7 +985,7 @@ __global__ __launch_bounds__(YN_NT) void yn_reduce_k(const uint32_t* __restrict_
   for (uint32_t r = 0; r < YN_ROWS; ++r) {
     const uint4 v = yn_load(w, (uint64_t)blockIdx.x * YN_TILE + ((uint64_t)r * YN_NT + threadIdx.x) * 4u, nit);
     const uint32_t h = (v.x >> 31) + (v.y >> 31) + (v.z >> 31) + (v.w >> 31);
-    const uint32_t n = (v.x & 0x7FFFFFFFu) + (v.y & 0x7FFFFFFFu) + (v.z & 0x7FFFFFFFu) + (v.w & 0x7FFFFFFFu);
+    const uint32_t n = yd_nex_count(v.x) + yd_nex_count(v.y) + yd_nex_count(v.z) + yd_nex_count(v.w);
     acc += ((unsigned long long)h << 32) + n;
   }
   acc = wave_sum(acc);
@@ -1022,7 +1038,7 @@ __global__ __launch_bounds__(YN_NT) void yn_emit_k(const uint32_t* __restrict__ 
     const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
     unsigned long long mine = 0;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) mine += ((unsigned long long)(wv[e] >> 31) << 32) + (wv[e] & 0x7FFFFFFFu);
+    for (int e = 0; e < 4; ++e) mine += ((unsigned long long)(wv[e] >> 31) << 32) + yd_nex_count(wv[e]);
     unsigned long long tot;
     unsigned long long ex = carry + block_excl_sum<unsigned long long, YN_NT>(mine, sm, &tot);
 #pragma unroll
@@ -1031,7 +1047,7 @@ __global__ __launch_bounds__(YN_NT) void yn_emit_k(const uint32_t* __restrict__ 
         chain_first[(uint32_t)(ex >> 32)] = (uint32_t)(i + (uint64_t)e);  // (the bound only matters when the node count overflows)
         chain_noff[(uint32_t)(ex >> 32)] = (uint32_t)ex;
       }
-      ex += ((unsigned long long)(wv[e] >> 31) << 32) + (wv[e] & 0x7FFFFFFFu);
+      ex += ((unsigned long long)(wv[e] >> 31) << 32) + yd_nex_count(wv[e]);
     }
     carry += tot;
   }
@@ -1135,7 +1151,7 @@ __device__ void yd_merge_read(const uint32_t* __restrict__ xs, const uint32_t* _
 __global__ void yd_run_k(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ nids, uint32_t nchains, uint32_t nit,
                          const uint32_t* __restrict__ chain_first, YdItems Y, YdWords v,
                          const uint32_t* __restrict__ noff, const uint32_t* __restrict__ ex_s, const uint32_t* __restrict__ ex_e,
-                         SegNodes N, int32_t* __restrict__ g_yd) {
+                         SegNodes N, int32_t* __restrict__ g_yd, uint32_t* __restrict__ yd_d) {
   uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x >= *nids) return;
   uint32_t c = ids[x];
@@ -1148,7 +1164,7 @@ __global__ void yd_run_k(const uint32_t* __restrict__ ids, const uint32_t* __res
   for (uint32_t t = t0; t < t1; ++t) {
     const uint4 it = Y.rec(t);
     uint32_t rstart = it.y;
-    uint32_t xo = Y.xo_of(it, v.group(t)), nex = Y.nex[t] & 0x7FFFFFFFu;  // (bit 31: head flag of items placed by list)
+    uint32_t xo = Y.xo_of(it, v.group(t)), nex = yd_nex_count(Y.nex[t]);  // (the literal version reads every exon list from the arrays)
     int d;
     if (last_pos == rstart) {  // :225-228
       yd_merge_read(ex_s + xo, ex_e + xo, nex, N, head, alloc);
@@ -1168,7 +1184,10 @@ __global__ void yd_run_k(const uint32_t* __restrict__ ids, const uint32_t* __res
       last_dist = d;
       yd_merge_read(ex_s + xo, ex_e + xo, nex, N, head, alloc);
     }
-    if (d > 0) atomicMax(&g_yd[v.group(t)], d);
+    if (yd_d)
+      yd_d[t] = d > 0 ? (uint32_t)d : 0u;
+    else if (d > 0)
+      atomicMax(&g_yd[v.group(t)], d);
   }
 }
 
@@ -1243,7 +1262,8 @@ template <int R /* items per lane and refill: the items of R consecutive lanes' 
 __global__ __launch_bounds__(64) void yd_lane_k(const uint32_t* __restrict__ ids, uint32_t nids, uint32_t nchains, uint32_t nit,
                                                 const uint32_t* __restrict__ chain_first, YdItems Y, YdWords v,
                                                 const uint32_t* __restrict__ ex_s, const uint32_t* __restrict__ ex_e,
-                                                int32_t* __restrict__ g_yd, uint32_t* __restrict__ ids_over, uint32_t* __restrict__ n_over) {
+                                                int32_t* __restrict__ g_yd, uint32_t* __restrict__ yd_d, uint32_t* __restrict__ ids_over,
+                                                uint32_t* __restrict__ n_over) {
   constexpr int RS = R + 1;  // row stride of the staged items (odd: the lanes' own reads fall on different banks)
   __shared__ uint32_t S_start[64 * RS], S_xo[64 * RS], S_e0[64 * RS], S_s1[64 * RS], S_e1[64 * RS], S_nex[64 * RS], S_o[64 * RS];
   const uint32_t x = blockIdx.x * 64 + threadIdx.x;
@@ -1290,16 +1310,20 @@ __global__ __launch_bounds__(64) void yd_lane_k(const uint32_t* __restrict__ ids
       const uint32_t idx = tq + i0;
       if (tq != 0xFFFFFFFFu && idx < t1q) {
         const uint4 a = Y.rec(idx);
-        const uint32_t nx = Y.nex[idx] & 0x7FFFFFFFu;
-        const uint32_t o = v.group(idx);
+        const uint32_t xw = Y.nex[idx];
+        const uint32_t nx = yd_nex_count(xw);
+        const bool x2 = yd_nex_x2(xw), far = nx > 1 && !x2;  // far: the exons lie in the groups' arrays (x2: they ride in the word)
+        const uint32_t o = (!yd_d || far) ? v.group(idx) : 0u;  // (yd_d: the distances go to the items' own slots — only such an item
+                                                                // looks its group up, for the exon list)
         const uint32_t w = q * RS + i0;
-        const uint32_t axo = nx > 1 ? Y.xo_of(a, o) : 0u;  // (only a spliced item has use for its exon list)
+        const uint32_t axo = far ? Y.xo_of(a, o) : 0u;
+        const uint32_t x2e0 = a.y + yd_x2_a(xw) - 1u;
         S_start[w] = a.y;
         S_xo[w] = axo;
-        S_e0[w] = nx > 1 ? ex_e[axo] : a.z;  // (a single exon ends where the read ends; the exon arrays follow the groups: items next to
-                                             // each other in a chain read next to each other)
-        S_s1[w] = nx > 1 ? ex_s[axo + 1] : 0u;
-        S_e1[w] = nx > 1 ? ex_e[axo + 1] : 0u;
+        S_e0[w] = far ? ex_e[axo] : (x2 ? x2e0 : a.z);  // (a single exon ends where the read ends; the exon arrays follow the groups:
+                                                        // items next to each other in a chain read next to each other)
+        S_s1[w] = far ? ex_s[axo + 1] : (x2 ? x2e0 + yd_x2_g(xw) + 1u : 0u);
+        S_e1[w] = far ? ex_e[axo + 1] : (x2 ? a.z : 0u);
         S_nex[w] = nx;
         S_o[w] = o;
       }
@@ -1395,7 +1419,12 @@ __global__ __launch_bounds__(64) void yd_lane_k(const uint32_t* __restrict__ ids
             }
           }
         }
-        if (!over && d > 0) atomicMax(&g_yd[o], d);
+        if (!over) {
+          if (yd_d)
+            yd_d[t] = d > 0 ? (uint32_t)d : 0u;
+          else if (d > 0)
+            atomicMax(&g_yd[o], d);
+        }
         ++t;
       }
     }
@@ -1426,7 +1455,8 @@ __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids
                                                 uint32_t nit, const uint32_t* __restrict__ chain_first, YdItems Y,
                                                 YdWords v, const uint32_t* __restrict__ noff,
                                                 const uint32_t* __restrict__ ex_s, const uint32_t* __restrict__ ex_e,
-                                                int32_t* __restrict__ g_yd, uint32_t* __restrict__ ids_over, uint32_t* __restrict__ n_over) {
+                                                int32_t* __restrict__ g_yd, uint32_t* __restrict__ yd_d, uint32_t* __restrict__ ids_over,
+                                                uint32_t* __restrict__ n_over) {
   if (blockIdx.x >= *nids) return;
   const uint32_t c = ids[blockIdx.x];
   const uint32_t t0 = chain_first[c];
@@ -1458,15 +1488,18 @@ __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids
     const bool have = t < t1;
     const uint4 it = have ? Y.rec(t) : make_uint4(0u, 0u, 0u, 0u);
     b.start = it.y;
-    b.nex = have ? (Y.nex[t] & 0x7FFFFFFFu) : 0u;
-    b.o = have ? v.group(t) : 0u;
-    b.xo = b.nex > 1u ? Y.xo_of(it, b.o) : 0u;  // (only a spliced item has use for its exon list)
-    b.e0 = have ? (b.nex > 1u ? ex_e[b.xo] : it.z) : 0u;  // first exon end (its start is the read start); a single exon ends where the
-                                                          // read ends: no gather (three items in four, a 64-byte sector each)
-    b.s1 = (have && b.nex > 1) ? ex_s[b.xo + 1] : 0u;
-    b.e1 = (have && b.nex > 1) ? ex_e[b.xo + 1] : 0u;
-    b.s2 = (have && b.nex > 2) ? ex_s[b.xo + 2] : 0u;
-    b.e2 = (have && b.nex > 2) ? ex_e[b.xo + 2] : 0u;
+    const uint32_t xw = have ? Y.nex[t] : 0u;
+    b.nex = yd_nex_count(xw);
+    const bool x2 = yd_nex_x2(xw), far = b.nex > 1u && !x2;  // far: the exons lie in the groups' arrays (x2: they ride in the word)
+    b.o = have && (!yd_d || far) ? v.group(t) : 0u;  // (yd_d: only such an item looks its group up, for the exon list)
+    b.xo = far ? Y.xo_of(it, b.o) : 0u;
+    const uint32_t x2e0 = it.y + yd_x2_a(xw) - 1u;
+    b.e0 = far ? ex_e[b.xo] : (x2 ? x2e0 : it.z);  // first exon end (its start is the read start); a single exon ends where the
+                                                   // read ends: no gather (three items in four, a 64-byte sector each)
+    b.s1 = far ? ex_s[b.xo + 1] : (x2 ? x2e0 + yd_x2_g(xw) + 1u : 0u);
+    b.e1 = far ? ex_e[b.xo + 1] : (x2 ? it.z : 0u);
+    b.s2 = (far && b.nex > 2) ? ex_s[b.xo + 2] : 0u;
+    b.e2 = (far && b.nex > 2) ? ex_e[b.xo + 2] : 0u;
     return b;
   };
   auto set_mirror = [&](int p) {  // (uniform) node p becomes the active island
@@ -1716,7 +1749,12 @@ __global__ __launch_bounds__(64) void yd_wave_k(const uint32_t* __restrict__ ids
       }
       if (lane == j) it_d = d;
     }
-    if (!overflow && have && it_d > 0) atomicMax(&g_yd[it_o], it_d);
+    if (!overflow && have) {
+      if (yd_d)
+        yd_d[tb + (uint32_t)lane] = it_d > 0 ? (uint32_t)it_d : 0u;  // (one 256-byte store per batch)
+      else if (it_d > 0)
+        atomicMax(&g_yd[it_o], it_d);
+    }
   }
   if (overflow && lane == 0) ids_over[atomicAdd(n_over, 1u)] = c;
 }
@@ -1730,6 +1768,57 @@ __global__ void col_write_yd_k(uint32_t ng, const uint32_t* __restrict__ gperm, 
   int d2 = g_yd[o];
   if (d2 > dmax) dmax = d2;
   yd[o] = dmax > 0 ? dmax : 0;
+}
+
+// Items placed by list: the chain kernels leave every item's distance in the item's own slot (yd_d, written where the item was read:
+// whole lines) instead of one device-scope atomicMax per item on the groups' array — on a chip of eight L2s such an atomic is a round
+// trip to the memory side, 22 bytes of write traffic each by the counters (3.7 GB per launch of yd_wave_k on config 3).  This pass
+// folds them per tile of YS_NT groups: the tile's items of list c are the segment [base[c], base[c] + n[c]) of that list (the
+// placement's own table), their group words say where they belong, and the maxima meet in LDS.  It writes the YD output itself
+// (col_write_yd_k's job on the other paths: int dmax = spd.maxYD, tiebrush.cpp:511-524).
+__global__ __launch_bounds__(256) void yd_lgather_k(uint32_t ng, uint32_t ntiles, const uint32_t* __restrict__ table,
+                                                    const uint64_t* __restrict__ totals, const uint32_t* __restrict__ yd_d,
+                                                    const uint32_t* __restrict__ item, const uint32_t* __restrict__ gperm, GroupAcc G,
+                                                    uint32_t cap, int32_t* __restrict__ yd) {
+  __shared__ uint32_t base[YS_NL], lsum[YS_NL], pre[YS_NL + 1];
+  __shared__ int32_t mx[YS_NT];
+  const uint32_t t = threadIdx.x, b = blockIdx.x;
+  for (uint32_t g = t; g < YS_NT; g += 256) mx[g] = 0;
+  if (t < YS_NL) {
+    uint32_t lb = 0;
+    for (uint32_t c = 0; c < t; ++c) lb += (uint32_t)totals[c];
+    const uint32_t first = table[(size_t)t * ntiles + b];
+    const uint32_t next = b + 1 < ntiles ? table[(size_t)t * ntiles + b + 1] : (uint32_t)totals[t];
+    base[t] = lb + first;
+    lsum[t] = next - first;
+  }
+  __syncthreads();
+  if (t < 64) {  // exclusive prefix of the 128 per-list counts: one wave, two lists per lane
+    const uint32_t a = lsum[2 * t], c = lsum[2 * t + 1];
+    const uint32_t inc = wave_incl_sum(a + c);
+    pre[2 * t] = inc - a - c;
+    pre[2 * t + 1] = inc - c;
+    if (t == 63) pre[YS_NL] = inc;
+  }
+  __syncthreads();
+  const uint32_t T = pre[YS_NL];
+  for (uint32_t idx = t; idx < T; idx += 256) {
+    uint32_t c = 0;  // last list with pre[c] <= idx
+#pragma unroll
+    for (uint32_t st = 64; st >= 1; st >>= 1) c = pre[c + st] <= idx ? c + st : c;
+    const uint32_t pos = base[c] + (idx - pre[c]);
+    const uint32_t d = yd_d[pos];
+    if (d) atomicMax(&mx[item[pos] - b * YS_NT], (int32_t)d);
+  }
+  __syncthreads();
+  for (uint32_t g = t; g < YS_NT; g += 256) {
+    const uint32_t o = b * YS_NT + g;
+    if (o >= ng || o >= cap) continue;
+    int dmax = G.ydin ? (int)G.ydin[gperm[o]] : 0;
+    const int d2 = mx[g];
+    if (d2 > dmax) dmax = d2;
+    yd[o] = dmax > 0 ? dmax : 0;
+  }
 }
 
 __global__ void col_write_k(const uint64_t* __restrict__ png, const uint32_t* __restrict__ gperm, GroupAcc G,
@@ -1824,6 +1913,7 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
     uint4* ys_agg = nullptr;
     uint64_t* ys_totals = nullptr;
     uint64_t* ys_files = nullptr;
+    uint32_t *yd_d = nullptr, *ys_item = nullptr;
     YdGroups Q{};
     if (by_list) {  // the groups' coordinates first (the first pass folds them); then items and aggregates per (list, tile of groups)
       Q.pk = ws_alloc<uint4>(ctx, ng);
@@ -1863,7 +1953,9 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       uint64_t* iv = by_list ? nullptr : ws_alloc<uint64_t>(ctx, nit);
       uint64_t* iv2 = by_list ? nullptr : ws_alloc<uint64_t>(ctx, nit);
       uint32_t* io = by_list ? ws_alloc<uint32_t>(ctx, nit) : nullptr;  // items placed by list: the item -> group array
-      if (by_list && !io) return TBK_ENOMEM;
+      yd_d = by_list ? ws_alloc<uint32_t>(ctx, nit) : nullptr;          // ... and every item's distance (yd_lgather_k folds them)
+      if (by_list && (!io || !yd_d)) return TBK_ENOMEM;
+      ys_item = io;
       YdItems Y;
       if (by_list) {
         Y.pk = nullptr;
@@ -1958,17 +2050,22 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
         hipStream_t keep = ctx->stream;
         if (aux) ctx->stream = aux;
         TBK_LAUNCH(ctx, "yd_wave", yd_wave_k, n_long, 64, 0, ids_long, n_wave, nchains, nit, chain_first, Y, YdWords{iv, io}, noff, ex_s, ex_e, J.g_yd,
-                   ids_over, n_over);
+                   yd_d, ids_over, n_over);
         ctx->stream = keep;
         if (aux) TBK_HIP(hipEventRecord(ctx->aux_done, aux));
       }
       if (n_lane)
         TBK_LAUNCH(ctx, "yd_lane", yd_lane_k<8>, cdiv(n_lane, 64), 64, 0, ids_lane, n_lane, nchains, nit, chain_first, Y, YdWords{iv, io}, ex_s, ex_e, J.g_yd,
-                   ids_over, n_over);
+                   yd_d, ids_over, n_over);
       if (n_long && aux) TBK_HIP(hipStreamWaitEvent(ctx->stream, ctx->aux_done, 0));
       // chains whose list outgrew its lane's / wave's slots (count only known on the device: launch for the upper bound)
       TBK_LAUNCH(ctx, "yd_run_overflow", yd_run_k, cdiv(nchains, 64), 64, 0, ids_over, n_over, nchains, nit, chain_first, Y, YdWords{iv, io}, noff, ex_s, ex_e,
-                 N, J.g_yd);
+                 N, J.g_yd, yd_d);
+    }
+    if (by_list) {  // the distances lie with the items (no item: every segment is empty): folded per tile of groups, written as YD
+      TBK_LAUNCH(ctx, "yd_gather", yd_lgather_k, ys_tiles, 256, 0, ng, ys_tiles, ys_table, ys_totals, yd_d, ys_item, J.gperm, J.G, J.cap, J.out_yd);
+      TBK_HIP(hipStreamSynchronize(ctx->stream));
+      return tbk_check_launch(ctx, "collapse_yd");
     }
   }
   TBK_LAUNCH(ctx, "col_write_yd", col_write_yd_k, cdiv(ng, B), B, 0, ng, J.gperm, J.G, J.g_yd, J.cap, J.out_yd);
@@ -2195,7 +2292,8 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
       gperm = ws_alloc<uint32_t>(ctx, ng);
       ginv = ws_alloc<uint32_t>(ctx, ng);
       if (!ginv) return TBK_ENOMEM;
-      TBK_HIP(hipMemsetAsync(g_yd, 0, (size_t)ng * 4, ctx->stream));
+      // (items placed by list leave their distances with the items, yd_lgather_k: nothing accumulates in g_yd then)
+      if (!(!wo.pgrp || tbk_yd_by_list(ctx, I.k))) TBK_HIP(hipMemsetAsync(g_yd, 0, (size_t)ng * 4, ctx->stream));
       const uint64_t* png = sc + 1;  // (tbk_window_groups left the group count there)
       TBK_LAUNCH(ctx, "col_tie_sort", col_tie_sort_k, cdiv(ng, B), B, 0, I, O.strategy, png, wo.gmem, G, gperm, ginv);
       // (effend == nullptr: the effective end of the representative — or the low word of its explicit priority — rides in the
@@ -2268,7 +2366,8 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
       gperm = ws_alloc<uint32_t>(ctx, ng);
       ginv = ws_alloc<uint32_t>(ctx, ng);
       if (!ginv) return TBK_ENOMEM;
-      TBK_HIP(hipMemsetAsync(g_yd, 0, (size_t)ng * 4, ctx->stream));
+      // (items placed by list leave their distances with the items, yd_lgather_k: nothing accumulates in g_yd then)
+      if (!(!wo.pgrp || tbk_yd_by_list(ctx, I.k))) TBK_HIP(hipMemsetAsync(g_yd, 0, (size_t)ng * 4, ctx->stream));
       const uint64_t* png = sc + 1;  // (tbk_window_groups left the group count there)
       TBK_LAUNCH(ctx, "col_tie_sort", col_tie_sort_k, cdiv(ng, B), B, 0, I, O.strategy, png, wo.gmem, G, gperm, ginv);
       TBK_LAUNCH(ctx, "col_write", col_write_k, cdiv(ng, B), B, 0, png, gperm, G, wo.ghi, wo.glo, out->cap_groups, out->rep, out->yc,
