@@ -130,7 +130,7 @@ def _cpu_warm(_):
 def run_e2e_leg(args):
     """the `tiebrush` command line end to end, as a child process tree that ends before this process touches the GPU"""
     cmd = [sys.executable, os.path.join(ROOT, "tools", "e2e_leg.py"), "--files", str(args.e2e_files), "--reads", str(args.e2e_reads),
-           "--runs", str(args.e2e_runs)]
+           "--runs", str(args.e2e_runs)] + ([] if args.no_cpu_baseline else ["--cpu-baseline"])
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200)
         line = [l for l in r.stdout.strip().split("\n") if l.startswith("{")]
@@ -749,7 +749,24 @@ def main():
                 except Exception:
                     pass
         line.update(roof)
+        # SURVEY.md §8d names two kernel-path figures; `value` is the first (the bench contract: inputs resident in HBM), the second rides
+        # beside it at the top level, with the link's own roofline
+        line["value_resident"] = line["value"]
+        line["value_definitions"] = {"value": "= value_resident: records/s with the SoA tile in HBM before the timed region (the bench contract's `value`)",
+                                     "value_host_to_host": "records/s pinned host -> pinned host: H2D of the packed tile, collapse, tiecov, D2H of every result "
+                                                           "inside the clock — the figure SURVEY.md §8(d) defines as kernel-path (SURVEY.md:429)",
+                                     "end_to_end*": "BAM files -> BAM file through the `tiebrush` command line, process start to exit"}
         if host_path is not None:
+            line["value_host_to_host"] = host_path["value"]
+            lm = host_path.get("link_measured", {})
+            moved = host_path["h2d_bytes"] + host_path["d2h_bytes"]
+            ach = moved / (host_path["ms_per_step"] * 1e-3) / 1e9
+            # what bounds this leg is the link it crosses twice: bytes on the link / time, against the link's measured two-way rate on this box
+            pk = lm.get("both_ways_gb_per_s")
+            line["roofline_link"] = {"bound": "pcie", "achieved": round(ach, 1), "peak": pk, "unit": "GB/s", "frac": round(ach / pk, 4) if pk else None,
+                                     "bytes_per_step": int(moved), "ms_per_step": host_path["ms_per_step"],
+                                     "h2d_alone_gb_per_s": lm.get("h2d_gb_per_s"), "d2h_alone_gb_per_s": lm.get("d2h_gb_per_s"),
+                                     "peak_source": "measured in this run: 1 GiB of pinned memory each way on two streams at once"}
             line["kernel_path_host_to_host"] = host_path
         if e2e is not None:
             for sub, name in (("seq", "end_to_end_seq"), ("seq_long", "end_to_end_seq_long"), ("c3_options", "end_to_end_c3_options")):
@@ -758,6 +775,10 @@ def main():
             line["end_to_end"] = e2e
         if cpu is not None:
             line["cpu_baseline"] = cpu
+        # the files -> files CPU path, timed by the end-to-end leg on that leg's own files (tools/e2e_leg.py: cpu_end_to_end)
+        ecpu = line.get("end_to_end_seq", {}).pop("cpu_baseline", None) if isinstance(line.get("end_to_end_seq"), dict) else None
+        if ecpu is not None:
+            line.setdefault("cpu_baseline", {})["end_to_end"] = dict(ecpu, beside="end_to_end_seq (the same input files, process start to output file)")
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:
@@ -912,7 +933,43 @@ def host_to_host_leg(args, torch, np, api, dtile, strat, last, n_records, n_cig_
     for cx in ctxs:
         cx.close()
     soa_bytes = n_records * 20 + 4 + 4 * n_cig_in
-    return {"value": round(totals["passed"] / hdt, 1), "unit": "records/s", "ms_per_step": round(hdt * 1e3, 3), "h2d_bytes": int(in_bytes),
+    # the link's own rate on this box, measured here: 1 GiB of pinned memory each way, alone and both ways at once (two streams)
+    link = {}
+    try:
+        nb_ = 1 << 30
+        hp_a = torch.empty(nb_, dtype=torch.uint8, pin_memory=True)
+        hp_b = torch.empty(nb_, dtype=torch.uint8, pin_memory=True)
+        dv_a = torch.empty(nb_, dtype=torch.uint8, device=dev)
+        dv_b = torch.empty(nb_, dtype=torch.uint8, device=dev)
+        s_a, s_b = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+
+        def timed(fn, reps_=3):
+            fn()
+            torch.cuda.synchronize()
+            t_ = time.perf_counter()
+            for _ in range(reps_):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t_) / reps_
+
+        def up():
+            with torch.cuda.stream(s_a):
+                dv_a.copy_(hp_a, non_blocking=True)
+
+        def down():
+            with torch.cuda.stream(s_b):
+                hp_b.copy_(dv_b, non_blocking=True)
+
+        def both():
+            up()
+            down()
+
+        link = {"h2d_gb_per_s": round(nb_ / timed(up) / 1e9, 1), "d2h_gb_per_s": round(nb_ / timed(down) / 1e9, 1),
+                "both_ways_gb_per_s": round(2 * nb_ / timed(both) / 1e9, 1)}
+        del hp_a, hp_b, dv_a, dv_b
+    except Exception as e:
+        link = {"error": repr(e)}
+    return {"value": round(totals["passed"] / hdt, 1), "link_measured": link, "unit": "records/s", "ms_per_step": round(hdt * 1e3, 3), "h2d_bytes": int(in_bytes),
             "d2h_bytes": int(totals["out_bytes"]), "reps": reps, "sub_tiles": len(subs), "contexts": NC,
             "h2d_bytes_as_soa": int(soa_bytes), "link_gb_per_s": round((in_bytes + totals["out_bytes"]) / hdt / 1e9, 1),
             "host_wall_ms_summed_over_sub_tiles": {"unpack (H2D + expansion)": round(totals["t_h2d"] * 1e3, 1),

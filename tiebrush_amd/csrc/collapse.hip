@@ -1776,42 +1776,57 @@ __global__ void col_write_yd_k(uint32_t ng, const uint32_t* __restrict__ gperm, 
 // folds them per tile of YS_NT groups: the tile's items of list c are the segment [base[c], base[c] + n[c]) of that list (the
 // placement's own table), their group words say where they belong, and the maxima meet in LDS.  It writes the YD output itself
 // (col_write_yd_k's job on the other paths: int dmax = spd.maxYD, tiebrush.cpp:511-524).
-__global__ __launch_bounds__(256) void yd_lgather_k(uint32_t ng, uint32_t ntiles, const uint32_t* __restrict__ table,
+__global__ __launch_bounds__(512) void yd_lgather_k(uint32_t ng, uint32_t ntiles, const uint32_t* __restrict__ table,
                                                     const uint64_t* __restrict__ totals, const uint32_t* __restrict__ yd_d,
                                                     const uint32_t* __restrict__ item, const uint32_t* __restrict__ gperm, GroupAcc G,
                                                     uint32_t cap, int32_t* __restrict__ yd) {
-  __shared__ uint32_t base[YS_NL], lsum[YS_NL], pre[YS_NL + 1];
+  __shared__ uint32_t base[YS_NL], lsum[YS_NL];
   __shared__ int32_t mx[YS_NT];
   const uint32_t t = threadIdx.x, b = blockIdx.x;
-  for (uint32_t g = t; g < YS_NT; g += 256) mx[g] = 0;
+  for (uint32_t g = t; g < YS_NT; g += 512) mx[g] = 0;
+  uint32_t first = 0, next = 0;
+  if (t < YS_NL) {  // (the list's total and the tile's two table entries in one round trip)
+    const uint32_t tot = (uint32_t)totals[t];
+    first = table[(size_t)t * ntiles + b];
+    next = b + 1 < ntiles ? table[(size_t)t * ntiles + b + 1] : tot;
+    lsum[t] = tot;
+  }
+  __syncthreads();
+  uint32_t lb = 0;
+  if (t < YS_NL)
+    for (uint32_t c = 0; c < t; ++c) lb += lsum[c];
+  __syncthreads();
   if (t < YS_NL) {
-    uint32_t lb = 0;
-    for (uint32_t c = 0; c < t; ++c) lb += (uint32_t)totals[c];
-    const uint32_t first = table[(size_t)t * ntiles + b];
-    const uint32_t next = b + 1 < ntiles ? table[(size_t)t * ntiles + b + 1] : (uint32_t)totals[t];
     base[t] = lb + first;
     lsum[t] = next - first;
   }
   __syncthreads();
-  if (t < 64) {  // exclusive prefix of the 128 per-list counts: one wave, two lists per lane
-    const uint32_t a = lsum[2 * t], c = lsum[2 * t + 1];
-    const uint32_t inc = wave_incl_sum(a + c);
-    pre[2 * t] = inc - a - c;
-    pre[2 * t + 1] = inc - c;
-    if (t == 63) pre[YS_NL] = inc;
-  }
-  __syncthreads();
-  const uint32_t T = pre[YS_NL];
-  for (uint32_t idx = t; idx < T; idx += 256) {
-    uint32_t c = 0;  // last list with pre[c] <= idx
+  // a wave per segment (a tile holds ~ 56 items of a list: one round of 64 lanes, whole lines, no search for the item's list)
+  // (the sixteen segments of a wave are asked for together: one round trip to memory per block instead of sixteen dependent ones —
+  // the pass is bound by that latency, not by its 1.3 GB)
+  const uint32_t wv = t >> 6, ln = t & 63u;
+  constexpr uint32_t NSEG = YS_NL / (512 / 64);
+  uint32_t dv[NSEG], gv[NSEG];
 #pragma unroll
-    for (uint32_t st = 64; st >= 1; st >>= 1) c = pre[c + st] <= idx ? c + st : c;
-    const uint32_t pos = base[c] + (idx - pre[c]);
-    const uint32_t d = yd_d[pos];
-    if (d) atomicMax(&mx[item[pos] - b * YS_NT], (int32_t)d);
+  for (uint32_t j = 0; j < NSEG; ++j) {
+    const uint32_t c = wv + j * (512 / 64);
+    const uint32_t p0 = base[c], n = lsum[c];
+    dv[j] = ln < n ? yd_d[p0 + ln] : 0u;
+    gv[j] = ln < n ? item[p0 + ln] : 0u;
+  }
+#pragma unroll
+  for (uint32_t j = 0; j < NSEG; ++j)
+    if (dv[j]) atomicMax(&mx[gv[j] - b * YS_NT], (int32_t)dv[j]);
+  for (uint32_t j = 0; j < NSEG; ++j) {  // segments of more than 64 items (a tile of 1024 groups may hold 1024 of a list)
+    const uint32_t c = wv + j * (512 / 64);
+    const uint32_t p0 = base[c], n = lsum[c];
+    for (uint32_t i = 64 + ln; i < n; i += 64) {
+      const uint32_t d = yd_d[p0 + i];
+      if (d) atomicMax(&mx[item[p0 + i] - b * YS_NT], (int32_t)d);
+    }
   }
   __syncthreads();
-  for (uint32_t g = t; g < YS_NT; g += 256) {
+  for (uint32_t g = t; g < YS_NT; g += 512) {
     const uint32_t o = b * YS_NT + g;
     if (o >= ng || o >= cap) continue;
     int dmax = G.ydin ? (int)G.ydin[gperm[o]] : 0;
@@ -2063,7 +2078,7 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
                  N, J.g_yd, yd_d);
     }
     if (by_list) {  // the distances lie with the items (no item: every segment is empty): folded per tile of groups, written as YD
-      TBK_LAUNCH(ctx, "yd_gather", yd_lgather_k, ys_tiles, 256, 0, ng, ys_tiles, ys_table, ys_totals, yd_d, ys_item, J.gperm, J.G, J.cap, J.out_yd);
+      TBK_LAUNCH(ctx, "yd_gather", yd_lgather_k, ys_tiles, 512, 0, ng, ys_tiles, ys_table, ys_totals, yd_d, ys_item, J.gperm, J.G, J.cap, J.out_yd);
       TBK_HIP(hipStreamSynchronize(ctx->stream));
       return tbk_check_launch(ctx, "collapse_yd");
     }

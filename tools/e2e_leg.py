@@ -19,7 +19,67 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def leg(files, reads, profile, flags, seq, runs, device_decode, desc, host_writer=False):
+def cpu_budget():
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_end_to_end(paths, flags, reads, d, one_thread_files=8):
+    """The CPU path beside the leg, on the SAME files: oracle/_build/tb_cpu_e2e — the repo's host codec around the oracle, the
+    reference's main loop restated (TInputFiles::next -> GSamReader::next -> addPData / flushPData -> GSamWriter::write; tiebrush.cpp:557-601) —
+    (1) on one core, as the reference runs (a bounded sample: the first `one_thread_files` inputs), and (2) the reference's best case,
+    tiewrap-style (tiewrap.py:96-126): the inputs in batches, one single-threaded process per batch side by side, then one more run over
+    the batch outputs as TieBrush-merged inputs.  Process start, BGZF both ways, parsing and tagging inside the clock, like the leg's."""
+    tool = os.path.join(ROOT, "oracle", "_build", "tb_cpu_e2e")
+    if not os.path.exists(tool):
+        return {"error": "oracle/_build/tb_cpu_e2e is not built"}
+    cpus = sorted(os.sched_getaffinity(0))
+    pin = lambda c: (lambda: os.sched_setaffinity(0, {c}))
+    res = {}
+    sub = paths[:max(1, min(one_thread_files, len(paths)))]
+    out1 = os.path.join(d, "cpu1.bam")
+    t1 = time.time()
+    r = subprocess.run([tool, "-o", out1] + flags + sub, capture_output=True, text=True, check=True, preexec_fn=pin(cpus[0]))
+    dt = time.time() - t1
+    res.update({"value": round(len(sub) * reads / dt, 1), "unit": "records/s", "cores": 1, "kind": "port",
+                "sample": "the first %d of the leg's %d input files (%d records), one process pinned to one core: %.1f s" % (len(sub), len(paths), len(sub) * reads, dt),
+                "phases": [l for l in r.stderr.split("\n") if l.startswith("tb_cpu_e2e:")][-1:]})
+    os.remove(out1)
+    procs = min(16, cpu_budget(), len(paths), len(cpus))
+    if procs >= 2:
+        bsz = -(-len(paths) // procs)                    # tiewrap: -b ceil(k / cores)
+        batches = [paths[i:i + bsz] for i in range(0, len(paths), bsz)]
+        outs = [os.path.join(d, "cpu_b%d.bam" % b) for b in range(len(batches))]
+        t1 = time.time()
+        ps = [subprocess.Popen([tool, "-o", outs[b]] + flags + batches[b], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                               preexec_fn=pin(cpus[b % len(cpus)])) for b in range(len(batches))]
+        rcs = [p.wait() for p in ps]
+        t_b = time.time() - t1
+        if any(rcs):
+            res["parallel"] = {"error": "a batch process failed: %r" % (rcs,)}
+        else:
+            outp = os.path.join(d, "cpu_par.bam")
+            t1 = time.time()
+            subprocess.run([tool, "-o", outp] + flags + outs, capture_output=True, text=True, check=True, preexec_fn=pin(cpus[0]))
+            t_f = time.time() - t1
+            res["parallel"] = {"value": round(len(paths) * reads / (t_b + t_f), 1), "unit": "records/s", "cores": len(batches), "kind": "port",
+                               "mode": "tiewrap-style: %d batches of %d files, one single-threaded process each side by side (%.1f s), then one run over "
+                                       "the %d batch outputs as TieBrush-merged inputs (%.1f s); tiewrap.py:96-126" % (len(batches), bsz, t_b, len(batches), t_f),
+                               "sample": "all %d input files of the leg (%d records)" % (len(paths), len(paths) * reads)}
+            os.remove(outp)
+        for o in outs:
+            if os.path.exists(o):
+                os.remove(o)
+    return res
+
+
+def leg(files, reads, profile, flags, seq, runs, device_decode, desc, host_writer=False, cpu_base=False):
     """lay the inputs down, run the command line `runs` times, return the JSON object of the leg"""
     import torch
 
@@ -69,6 +129,11 @@ def leg(files, reads, profile, flags, seq, runs, device_decode, desc, host_write
             res["host_writer_wall_s"] = round(th[0], 3)
             res["host_writer_output_bam_bytes"] = os.path.getsize(out)
             res["host_writer_phases"] = [l for l in rh.stderr.split("\n") if l.startswith("hybrid path") or l.startswith("host path")][-1:]
+        if cpu_base:
+            try:
+                res["cpu_baseline"] = cpu_end_to_end(paths, flags, reads, d)
+            except Exception as e:      # a report beside the leg, never the leg itself
+                res["cpu_baseline"] = {"error": repr(e)}
         return res
     finally:
         shutil.rmtree(d, ignore_errors=True)
@@ -81,6 +146,7 @@ def main():
     ap.add_argument("--runs", type=int, default=3)
     ap.add_argument("--profile", default="c2")
     ap.add_argument("--no-extra", action="store_true", help="only the first leg (bare records, default collapse)")
+    ap.add_argument("--cpu-baseline", action="store_true", help="time the CPU files -> files path (oracle/_build/tb_cpu_e2e) on the SEQ / QUAL leg's files")
     a = ap.parse_args()
     res = leg(a.files, a.reads, a.profile, [], False, a.runs, True, "%d files x %d reads (config-2 read model, records without SEQ), default collapse")
     res["measured"] = ("in this run: tools/e2e_leg.py, a child of bench.py that ended before bench.py touched the GPU; median of the runs; process "
@@ -90,7 +156,8 @@ def main():
         # reference's fixtures: what BGZF and the tagging really move), and with config 3's options on config 3's read model
         k2 = max(1, a.runs - 1)
         res["seq"] = leg(a.files, a.reads, a.profile, [], True, k2, True,
-                         "%d files x %d reads (config-2 read model) WITH 100-bp SEQ / QUAL and aligner tags, default collapse", host_writer=True)
+                         "%d files x %d reads (config-2 read model) WITH 100-bp SEQ / QUAL and aligner tags, default collapse", host_writer=True,
+                         cpu_base=a.cpu_baseline)
         # ... and four times as much of it: long enough for the ~ 0.3 s the HIP runtime takes to come up to stop being a third of the run
         res["seq_long"] = leg(2 * a.files, 2 * a.reads, a.profile, [], True, max(3, k2), False,
                               "%d files x %d reads (config-2 read model) WITH 100-bp SEQ / QUAL and aligner tags, default collapse")
