@@ -555,3 +555,42 @@ def test_tiled_run_writes_behind_the_input_side(tmp_path):
         assert ("device writer:" in r.stderr) == (writer == "device")
         assert _records(out) == _records(whole), writer
         _members_ok(out)
+
+
+def _long_record_input(tmp_path, n_before=700, n_after=150, long_len=70000):
+    """one BAM: n_before distinct 50-bp reads, then ONE read of long_len bases (a record of ~ 105 KB: longer than a BGZF member's 64 KB
+    payload, what tbk_bam_encode refuses), then n_after more — every read a group of its own, in coordinate order"""
+    from tiebrush_amd import bamio
+    recs = []
+    for i in range(n_before):
+        recs.append(bamio.encode_record(0, 100 + 10 * i, 0, 60, [(50 << 4) | 0], b"s%d" % i, aux=b"NHC\x01", l_seq=50, seq=bytes(25), qual=bytes([30]) * 50))
+    p0 = 100 + 10 * n_before
+    recs.append(bamio.encode_record(0, p0, 0, 60, [(long_len << 4) | 0], b"long", aux=b"NHC\x01", l_seq=long_len, seq=bytes((long_len + 1) // 2),
+                                    qual=bytes([30]) * long_len))
+    for i in range(n_after):
+        recs.append(bamio.encode_record(0, p0 + 10 + 10 * i, 0, 60, [(50 << 4) | 0], b"t%d" % i, aux=b"NHC\x01", l_seq=50, seq=bytes(25), qual=bytes([30]) * 50))
+    path = str(tmp_path / "long.bam")
+    bamio.write_bam(path, "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chr1\tLN:50000000\n", ["chr1"], [50000000], b"".join(recs))
+    return path, n_before + 1 + n_after
+
+
+@pytest.mark.parametrize("mode", ["long-record", "forced"])
+def test_device_writer_refusal_on_a_later_chunk_hands_over_to_the_host_writer(tmp_path, mode):
+    """A chunk the device writer cannot take (a record longer than a BGZF member — a long read — or no memory) used to end the run when it
+    was not the first one; now the chunks before it stay written and the host writer goes on from that group: the record stream equals
+    the host writer's, whatever chunk refuses.  TBK_DW_CHUNK_GROUPS makes a small input span several chunks."""
+    path, n = _long_record_input(tmp_path)
+    env = dict(os.environ, TBK_TIMING="1", TBK_DW_CHUNK_GROUPS="256")
+    if mode == "forced":
+        env["TBK_TEST_DW_REFUSE_CHUNK"] = "1"
+        path = os.path.join(GOLDEN, "t12.bam")
+    d, h = str(tmp_path / "dev.bam"), str(tmp_path / "host.bam")
+    rd = subprocess.run([os.path.join(BIN, "tiebrush"), "-o", d, path], check=True, capture_output=True, text=True, env=env)
+    subprocess.run([os.path.join(BIN, "tiebrush"), "--writer", "host", "-o", h, path], check=True, capture_output=True, text=True)
+    assert _records(d) == _records(h)
+    want_at = {"long-record": 512, "forced": 256}[mode]      # (the long read is group 700: chunk 2 of 256-group chunks)
+    assert "device writer stopped after %d of" % want_at in rd.stderr, rd.stderr[-600:]
+    _members_ok(d)
+    if mode == "long-record":
+        from tiebrush_amd import bamio
+        assert bamio.read_bam(d).n == n

@@ -536,3 +536,40 @@ def test_loopback_full_strategy_with_md(world, path, bam_loader, monkeypatch):
             v = getattr(r, f)
             setattr(r, f, v.cpu().numpy() if isinstance(v, torch.Tensor) else v)
     check_against_flat(res, tile, flat)
+
+
+def test_one_rank_on_the_general_path_posts_the_same_collectives(monkeypatch):
+    """junction_gather=False (bench.py's carry scheme): a rank whose owner reduce is refused (a per-rank event: a shared hashed key word,
+    a pile-up of partials) reduces through the general path — and must still post exactly the collectives its peers post.  Before the fix
+    that path gathered the junction counts unconditionally: one rank in an all_gather its peers never enter (the loopback driver's
+    "ranks diverged" assertion; a hang under torch.distributed)."""
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import api, dist, synth
+    from tiebrush_amd._lib import TbkError
+    tile = synth.make_tile(6, 8000, "c3", n_loci=300)
+    flat = orc.collapse(tile, strategy=STRAT["clip"])
+    tiles, first = split_tile(tile, 3)
+    dtiles = [api.to_device(t, "cuda:0") for t in tiles]
+
+    class OneRankRefused(DeviceCompute):
+        calls = 0
+
+        def __getattr__(self, name):
+            if name == "partial_reduce":
+                def refuse_second(*a, **k):
+                    type(self).calls += 1
+                    if type(self).calls == 2:       # rank 1's owner reduce
+                        raise TbkError(-8, "forced")
+                    return self.ctx.partial_reduce(*a, **k)
+                return refuse_second
+            return DeviceCompute.__getattr__(self, name)
+
+    for jg in (False, True):
+        OneRankRefused.calls = 0
+        res = dist.run_loopback(OneRankRefused(), dtiles, first, want_coverage=True, device_chain=True, strategy="clip", junction_gather=jg)
+        assert OneRankRefused.calls == 3
+        assert sum(int(r.n_groups) for r in res) == flat["n_groups"]
+        assert all(r.coverage is not None for r in res)
+        if jg:
+            nj = [int(r.coverage["n_junctions"]) for r in res]
+            assert [r.junction_offset for r in res] == [0, nj[0], nj[0] + nj[1]]

@@ -1462,7 +1462,8 @@ __global__ void junc_fill_k(uint32_t m, CovArrays A, const int32_t* __restrict__
 // the block's first record : 24 | length : 31 | strand code : 2 | 1); an item that does not fit that form (another reference
 // sequence than the block's first record, a start 2^24 bases on) or finds the table full travels on its own.  Sums are integers
 // (the caller has checked every YC is integral and the total below 2^52), so the order of the additions is free.
-constexpr uint32_t JA_REC = 1024;   // records per block (4 per thread)
+constexpr uint32_t JA_REC = 4096;   // records per block (16 per thread: a block's fixed cost — clearing and flushing its 16 KB table — is what the
+                                    // pass is made of when one record in twelve is spliced; 1024 records per block: 0.36 ms on config 3)
 constexpr uint32_t JA_SLOTS = 1024;
 __global__ __launch_bounds__(256) void junc_agg_k(uint32_t m, CovArrays A, const int32_t* __restrict__ tid, const int32_t* __restrict__ pos,
                                                   const uint32_t* __restrict__ cig_off, const uint32_t* __restrict__ cig,
@@ -1630,17 +1631,18 @@ __global__ void junc_sum_k(uint32_t nj, CovArrays A, const uint32_t* __restrict_
 
 // ---- junctions without a sort (integral YC) -------------------------------------------------------------------------------------------
 // junc_agg_k leaves one item per distinct junction and block of JA_REC records; the same junction comes from a few neighbouring
-// blocks (the reads that span it start within a read length of each other).  Every item has a HOME block: the last block whose first
+// blocks (the reads that span it start within a read length of each other).  Every item has a HOME block (of JH_REC records): the last block whose first
 // record starts at or before the junction's first base, in (reference, start) order.  Equal junctions share their home, and homes are
 // in key order, so: count the items per home (jh_home_k), scan, scatter (jh_scatter_k), sort and sum every home's few items in LDS
 // (jh_sort_k), scan the numbers of distinct junctions, write (jh_write_k) — no global sort (8 radix passes, 24 launches, for some
 // 10^5 items) and no read-back before the end.  A home with more items than a block sorts (a raw, uncollapsed input piled a thousand
 // deep) raises scalar 12 and the radix path takes the call.
 constexpr uint32_t JH_CAP = 1024;
+constexpr uint32_t JH_REC = 1024;  // records per home block (independent of junc_agg_k's blocks: an item finds its home by its key)
 __global__ void jh_blockkey_k(uint32_t nblk, CovArrays A, const int32_t* __restrict__ tid, const int32_t* __restrict__ pos, uint64_t* __restrict__ bkey) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nblk) return;
-  const uint32_t i = A.ridx[(size_t)b * JA_REC];
+  const uint32_t i = A.ridx[(size_t)b * JH_REC];
   bkey[b] = ((uint64_t)(uint32_t)tid[i] << 32) | (uint32_t)(pos[i] + 1);  // (reference, 1-based start) of the block's first record
 }
 // item q (hi = reference : 32 | first base of the junction : 32, the form junc_agg_k writes) -> its home, counted
@@ -1874,7 +1876,7 @@ static int junc_branch(tbk_ctx* ctx, uint32_t m, const CovArrays& A, const tbk_c
                pv, (unsigned long long*)(sc + 11));
     if (!ctx->dbg.junc_radix) {  // (junc_radix: test hook, the sort below)
       // every item to its home block, the homes sorted one by one: no read-back until the junctions are written
-      const uint32_t nblk = cdiv(m, JA_REC);
+      const uint32_t nblk = cdiv(m, JH_REC);
       uint64_t* bkey = ws_alloc<uint64_t>(ctx, nblk);
       uint32_t* hcnt = ws_alloc<uint32_t>(ctx, (size_t)nblk * 2);  // counts | fill cursors
       uint32_t* hoff2 = ws_alloc<uint32_t>(ctx, nblk);

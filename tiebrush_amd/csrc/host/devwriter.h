@@ -31,7 +31,12 @@ class DeviceWriter {
   static constexpr uint32_t kChunkGroups = 256u << 10;  // ~ 64 MB of records with SEQ / QUAL per chunk
   static constexpr int kSlots = 3;
 
-  DeviceWriter(TbkApi& api, int nthreads) : api_(api), nt_(nthreads < 1 ? 1 : nthreads) {}
+  DeviceWriter(TbkApi& api, int nthreads) : api_(api), nt_(nthreads < 1 ? 1 : nthreads) {
+    if (const char* e = getenv("TBK_DW_CHUNK_GROUPS")) {  // test hook: small chunks, so that a small input has a "later chunk"
+      const long v = atol(e);
+      if (v >= 64 && v <= (long)kChunkGroups) chunk_ = (uint32_t)v;
+    }
+  }
   ~DeviceWriter() {
     for (auto& s : slot_) {
       if (s.blob) api_.host_free(s.blob);
@@ -48,23 +53,30 @@ class DeviceWriter {
   }
 
   // Groups [0, ng) of a collapse (rep / yc / yx / yd: HOST arrays in output order).  Representatives with rep < n_dev are records of
-  // the tile tbk_bam_decode left on `ctx`; host_record(g) hands out the others.  Returns false — with nothing written — when the
-  // device cannot take the output (TBK_EUNSUPPORTED / TBK_ENOMEM on the first chunk: the caller's host writer takes over); any later
-  // failure is fatal (GError).  *payload / *zbytes: bytes of tagged records / of BGZF members written.
+  // the tile tbk_bam_decode left on `ctx`; host_record(g) hands out the others.  Returns false when the device cannot take the
+  // output — TBK_EUNSUPPORTED (a record too long for a BGZF member of its own: bgzdef.hip) or TBK_ENOMEM / no pinned memory, on ANY
+  // chunk: the chunks before the refused one are written in full and *groups_done says how many groups that was, so the caller's host
+  // writer takes the groups from there on (a long read far into the output does not cost the run).  Any other failure is fatal
+  // (GError).  *payload / *zbytes: bytes of tagged records / of BGZF members written.
   bool write(tbk_ctx* ctx, GSamWriter& out, uint32_t ng, const uint32_t* rep, const double* yc, const int64_t* yx, const int32_t* yd, uint32_t n_dev,
-             const std::function<tbh::RecView(uint32_t)>& host_record, uint64_t* payload, uint64_t* zbytes, std::string& why) {
+             const std::function<tbh::RecView(uint32_t)>& host_record, uint64_t* payload, uint64_t* zbytes, std::string& why, uint32_t* groups_done) {
     *payload = *zbytes = 0;
+    *groups_done = 0;
     if (ng == 0) return true;
     if (!reserve()) {
       why = "pinned staging memory";
       return false;
     }
+    const uint32_t kChunkGroups = chunk_;  // (shadows the constant: the test hook's chunk size)
     const uint32_t nchunk = (ng + kChunkGroups - 1) / kChunkGroups;
     // stage hand-offs: state[k] counts how far chunk k has come (1 gathered, 2 encoded, 3 written)
     std::mutex m;
     std::condition_variable cv;
     std::vector<int> state(nchunk, 0);
-    std::atomic<int> fail{0};  // 1: first chunk refused (fall back), 2: fatal
+    // a failure names the chunk it stopped at: every stage still finishes the chunks before it (they are written), none touches that
+    // chunk or a later one.  fail / fail_at / fail_msg change under `m` only (a waiter checks them under `m`: no lost wake-up).
+    int fail = 0;  // 1: chunk fail_at refused (the host writer takes over from there), 2: fatal
+    uint32_t fail_at = 0xFFFFFFFFu;
     std::string fail_msg;
     auto set_state = [&](uint32_t k, int v) {
       {
@@ -73,11 +85,23 @@ class DeviceWriter {
       }
       cv.notify_all();
     };
-    auto wait_state = [&](uint32_t k, int v) {
-      std::unique_lock<std::mutex> lk(m);
-      cv.wait(lk, [&] { return state[k] >= v || fail.load() != 0; });
-      return fail.load() == 0;
+    auto set_fail = [&](uint32_t k, int code, const std::string& msg) {
+      {
+        std::lock_guard<std::mutex> lk(m);
+        if (fail == 0 || k < fail_at) fail = code, fail_at = k, fail_msg = msg;
+      }
+      cv.notify_all();
     };
+    auto wait_state = [&](uint32_t k, int v) {  // false: chunk k will never get there
+      std::unique_lock<std::mutex> lk(m);
+      cv.wait(lk, [&] { return state[k] >= v || (fail != 0 && k >= fail_at); });
+      return state[k] >= v && !(fail != 0 && k >= fail_at);
+    };
+    auto failed = [&]() {
+      std::lock_guard<std::mutex> lk(m);
+      return fail != 0;
+    };
+    const char* force_refuse = getenv("TBK_TEST_DW_REFUSE_CHUNK");  // test hook: chunk k answers TBK_EUNSUPPORTED
     std::vector<uint64_t> zsz(nchunk, 0), psz(nchunk, 0);
     std::vector<uint32_t> nhost(nchunk, 0);
     std::thread enc([&]() {
@@ -94,15 +118,13 @@ class DeviceWriter {
         in.n_host = nhost[k];
         in.host_blob = s.blob, in.host_off = s.off.data(), in.host_slot = s.slot.data();
         uint64_t zb = 0, pb = 0;
-        int rc = api_.bam_encode(ctx, &in, s.z, s.z_cap, &zb, &pb);
+        int rc = (force_refuse && (uint32_t)atol(force_refuse) == k) ? TBK_EUNSUPPORTED : api_.bam_encode(ctx, &in, s.z, s.z_cap, &zb, &pb);
         if (rc == TBK_E2BIG && zb > s.z_cap) {  // (the members of this chunk need a larger buffer: the call said how large)
           if (!grow(s.z, s.z_cap, zb + zb / 8)) rc = TBK_ENOMEM;
           else rc = api_.bam_encode(ctx, &in, s.z, s.z_cap, &zb, &pb);
         }
         if (rc != 0) {
-          fail_msg = std::string(api_.strerror_(rc)) + " (" + api_.last_error(ctx) + ")";
-          fail.store(k == 0 && (rc == TBK_EUNSUPPORTED || rc == TBK_ENOMEM) ? 1 : 2);
-          cv.notify_all();
+          set_fail(k, (rc == TBK_EUNSUPPORTED || rc == TBK_ENOMEM) ? 1 : 2, std::string(api_.strerror_(rc)) + " (" + api_.last_error(ctx) + ")");
           return;
         }
         zsz[k] = zb, psz[k] = pb;
@@ -118,7 +140,7 @@ class DeviceWriter {
       }
     });
     // the gather, on this thread and its workers
-    for (uint32_t k = 0; k < nchunk && fail.load() == 0; ++k) {
+    for (uint32_t k = 0; k < nchunk && !failed(); ++k) {
       if (k >= (uint32_t)kSlots && !wait_state(k - kSlots, 3)) break;  // the slot's previous chunk has left the building
       Slot& s = slot_[k % kSlots];
       const uint32_t g0 = k * kChunkGroups, g1 = std::min(ng, g0 + kChunkGroups), nc = g1 - g0;
@@ -145,9 +167,7 @@ class DeviceWriter {
       nhost[k] = sl_cnt[(size_t)T];
       s.off.resize((size_t)nhost[k] + 1);
       if (total + 16 > s.blob_cap && !grow(s.blob, s.blob_cap, total + total / 8 + 16)) {
-        fail_msg = "pinned staging memory";
-        fail.store(k == 0 ? 1 : 2);
-        cv.notify_all();
+        set_fail(k, 1, "pinned staging memory");
         break;
       }
       // pass 2: the copies
@@ -174,12 +194,14 @@ class DeviceWriter {
     }
     enc.join();
     wr.join();
-    if (fail.load() == 1) {
+    if (fail == 2) GError("Error: encoding the output on the GPU failed: %s\n", fail_msg.c_str());
+    const uint32_t kdone = fail ? fail_at : nchunk;  // (the threads are gone: plain reads)
+    for (uint32_t k = 0; k < kdone; ++k) *payload += psz[k], *zbytes += zsz[k];
+    *groups_done = fail ? std::min<uint64_t>((uint64_t)kdone * kChunkGroups, ng) : ng;
+    if (fail == 1) {
       why = fail_msg;
       return false;
     }
-    if (fail.load() == 2) GError("Error: encoding the output on the GPU failed: %s\n", fail_msg.c_str());
-    for (uint32_t k = 0; k < nchunk; ++k) *payload += psz[k], *zbytes += zsz[k];
     return true;
   }
 
@@ -214,5 +236,6 @@ class DeviceWriter {
   }
   TbkApi& api_;
   int nt_;
+  uint32_t chunk_ = kChunkGroups;
   Slot slot_[kSlots];
 };

@@ -326,7 +326,10 @@ int main(int argc, char* argv[]) {
     std::function<tbh::RecView(uint32_t)> get_record = [&](uint32_t g) { return inRecords.record(rep[g]); };
     // flushPData tagging (tiebrush.cpp:506-525): the groups are independent, so slices of them are tagged, framed and
     // deflated by worker threads into per-slice runs of BGZF members, which then go to the writer in order
-    auto write_groups_arr = [&](uint32_t ng, const std::function<tbh::RecView(uint32_t)>& rec_of, const double* ycp, const int64_t* yxp, const int32_t* ydp) {
+    // (gfirst: the groups before it are in the file already — the device writer's chunks before the one it refused, devwriter.h)
+    auto write_groups_arr = [&](uint32_t ng_all, const std::function<tbh::RecView(uint32_t)>& rec_of, const double* ycp, const int64_t* yxp, const int32_t* ydp,
+                                uint32_t gfirst) {
+      const uint32_t ng = ng_all > gfirst ? ng_all - gfirst : 0;  // groups to write
       const int nt = ng < 4096 ? 1 : nthreads;
       // slices of ~16 K groups, taken by the workers as they come free (a static split leaves the cores that drew sparse
       // regions idle); the calling thread appends every slice's members to the file as soon as all earlier ones are out
@@ -343,7 +346,7 @@ int main(int argc, char* argv[]) {
       std::atomic<bool> failed{false};
       const int level = outfile.level();
       auto tag_slice = [&](uint32_t sl, std::vector<uint8_t>& o, tbh::BamRec& rr) {
-        const uint32_t g0 = sl * per, g1 = std::min(ng, g0 + per);
+        const uint32_t g0 = gfirst + sl * per, g1 = std::min(ng_all, g0 + per);
         // flushPData's tags on every representative of the slice, then the slice deflates itself (tagwrite.h)
         if (!tbh::tag_and_deflate(g0, g1, rec_of, ycp, yxp, ydp, level, o, rr, runs[(size_t)sl])) failed.store(true);
         {
@@ -385,9 +388,14 @@ int main(int argc, char* argv[]) {
       for (auto& x : th) x.join();
       if (failed.load()) GError("Error: deflate failed\n");
     };
-    auto write_groups = [&](uint32_t ng) { write_groups_arr(ng, get_record, yc.data(), yx.data(), yd.data()); };
+    uint32_t dev_groups_done = 0;  // groups the device writer wrote before it refused a chunk: the host writer goes on from there
+    auto write_groups = [&](uint32_t ng) {
+      const uint32_t gfirst = dev_groups_done;
+      dev_groups_done = 0;
+      write_groups_arr(ng, get_record, yc.data(), yx.data(), yd.data(), gfirst);
+    };
     // the same on the device (devwriter.h): tags, framing and BGZF deflate as kernels, the host only gathers the records it decoded
-    // itself and appends the finished members.  false: nothing written, the host writer above takes the groups.
+    // itself and appends the finished members.  false: the host writer above takes the groups from dev_groups_done on.
     auto write_groups_device = [&](uint32_t ng, uint32_t n_dev, const std::function<tbh::RecView(uint32_t)>& host_record) {
       if (!dev_writer || outfile.level() == 0) return false;
       need_ctx();
@@ -395,9 +403,11 @@ int main(int argc, char* argv[]) {
       auto a = tnow();
       uint64_t pb = 0, zb = 0;
       std::string why;
-      const bool ok = dw->write(ctx, outfile, ng, rep.data(), yc.data(), yx.data(), yd.data(), n_dev, host_record, &pb, &zb, why);
-      if (!ok && timing) fprintf(stderr, "device writer not used (%s): host writer\n", why.c_str());
-      if (ok) ms_dev_write += tms(a, tnow()), dev_payload += pb, dev_z += zb;
+      uint32_t done = 0;
+      const bool ok = dw->write(ctx, outfile, ng, rep.data(), yc.data(), yx.data(), yd.data(), n_dev, host_record, &pb, &zb, why, &done);
+      if (!ok && timing) fprintf(stderr, "device writer stopped after %u of %u groups (%s): host writer\n", done, ng, why.c_str());
+      ms_dev_write += tms(a, tnow()), dev_payload += pb, dev_z += zb;
+      dev_groups_done = ok ? 0 : done;
       return ok;
     };
     // half of what the host may still use (MemAvailable, the cgroup's limit): what the whole-input loaders may fill with inflated inputs
@@ -858,14 +868,15 @@ int main(int argc, char* argv[]) {
           return v;
         };
         bool wrote = false;
+        uint32_t wdone = 0;
         if (dev_writer && dw && wctx && outfile.level() != 0) {
           uint64_t pb = 0, zb = 0;
           std::string why;
-          wrote = dw->write(wctx, outfile, S.ng, S.rep.data(), S.yc.data(), S.yx.data(), S.yd.data(), 0, from_blob, &pb, &zb, why);
-          if (wrote) dev_payload += pb, dev_z += zb;
-          else if (timing) fprintf(stderr, "device writer not used (%s): host writer\n", why.c_str());
+          wrote = dw->write(wctx, outfile, S.ng, S.rep.data(), S.yc.data(), S.yx.data(), S.yd.data(), 0, from_blob, &pb, &zb, why, &wdone);
+          dev_payload += pb, dev_z += zb;
+          if (!wrote && timing) fprintf(stderr, "device writer stopped after %u of %u groups (%s): host writer\n", wdone, S.ng, why.c_str());
         }
-        if (!wrote) write_groups_arr(S.ng, from_blob, S.yc.data(), S.yx.data(), S.yd.data());
+        if (!wrote) write_groups_arr(S.ng, from_blob, S.yc.data(), S.yx.data(), S.yd.data(), wdone);
         const double ms = tms(a, tnow());
         ms_writer_busy += ms;
         if (wrote) ms_dev_write += ms;

@@ -307,7 +307,7 @@ def _unpack_np(rows, file_off2):
 
 
 def shard_collapse(compute, local_tile: SoATile, first_fidx: int, rank: int, world: int, strategy="cigar",
-                   want_coverage=False, device_chain=False, **filters):
+                   want_coverage=False, device_chain=False, junction_gather=True, **filters):
     """Generator: yields ("all_gather"|"all_reduce_max"|"all_reduce_min"|"exchange_rows"|"all_to_all", payload) requests
     and is sent the result; finally returns a ShardResult.  `compute` provides collapse(tile, **kw) / coverage(cin)
     [/ shard_prepare / shard_probe_* / shard_pack / shard_unpack / groups_to_cov_in / finish_yd] —
@@ -460,9 +460,10 @@ def shard_collapse(compute, local_tile: SoATile, first_fidx: int, rank: int, wor
                                  cig_off=X.as_dtype(cof, "u32"), cig=cg, yc=ycf, strand=tile2.strand[rep2], yx=X.to_i64(fin["yx"]))
     if want_coverage:
         cov = compute.coverage(res.cov_input)
-        nj = yield ("all_gather", X.scalar(int(cov["n_junctions"]), like=rep2))
         res.coverage = cov
-        res.junction_offset = int(X.host(nj).reshape(-1)[:rank].sum())
+        if junction_gather:     # (False: the caller carries the counts in its next step's first gather — on EVERY path, so that the ranks
+            nj = yield ("all_gather", X.scalar(int(cov["n_junctions"]), like=rep2))   # post the same collectives whichever path a rank took)
+            res.junction_offset = int(X.host(nj).reshape(-1)[:rank].sum())
     mark("coverage")
     if defer:
         compute.finish_yd()                                     # the YD column is final now
@@ -764,7 +765,7 @@ def partials_collapse(compute, local_tile: SoATile, first_fidx: int, rank: int, 
             return got
         if got == "shuffle":
             res = yield from shard_collapse(compute, local_tile, first_fidx, rank, world, strategy=strategy, want_coverage=want_coverage,
-                                            device_chain=device_chain, **filters)
+                                            device_chain=device_chain, junction_gather=junction_gather, **filters)
             return res
         if isinstance(got, tuple):          # the rows are here, the owner's merge-reduce handed them to the general path
             general = got
@@ -773,7 +774,7 @@ def partials_collapse(compute, local_tile: SoATile, first_fidx: int, rank: int, 
         got = yield from _partials_rounds(compute, X, mark, on_dev, local_tile, fin, first_fidx, rank, world, strategy, stats, filters)
         if got == "shuffle":
             res = yield from shard_collapse(compute, local_tile, first_fidx, rank, world, strategy=strategy, want_coverage=want_coverage,
-                                            device_chain=device_chain, **filters)
+                                            device_chain=device_chain, junction_gather=junction_gather, **filters)
             return res
         rrows, rcnt, rcig, rmd = got
     else:
@@ -805,9 +806,10 @@ def partials_collapse(compute, local_tile: SoATile, first_fidx: int, rank: int, 
                                      strand=A["strand"][rep2], yx=fast["yx"])
         if want_coverage:
             cov = compute.coverage(res.cov_input)
-            nj = yield ("all_gather", X.scalar(int(cov["n_junctions"]), like=rep2))
             res.coverage = cov
-            res.junction_offset = int(X.host(nj).reshape(-1)[:rank].sum())
+            if junction_gather:
+                nj = yield ("all_gather", X.scalar(int(cov["n_junctions"]), like=rep2))
+                res.junction_offset = int(X.host(nj).reshape(-1)[:rank].sum())
         mark("coverage")
         return res
     if on_dev:
@@ -843,9 +845,10 @@ def partials_collapse(compute, local_tile: SoATile, first_fidx: int, rank: int, 
                                  cig_off=X.as_dtype(cof, "u32"), cig=cg, yc=ycf, strand=tile2.strand[rep2], yx=X.to_i64(fin2["yx"]))
     if want_coverage:
         cov = compute.coverage(res.cov_input)
-        nj = yield ("all_gather", X.scalar(int(cov["n_junctions"]), like=rep2))
         res.coverage = cov
-        res.junction_offset = int(X.host(nj).reshape(-1)[:rank].sum())
+        if junction_gather:     # (False: the caller carries the counts in its next step's first gather — on EVERY path, so that the ranks
+            nj = yield ("all_gather", X.scalar(int(cov["n_junctions"]), like=rep2))   # post the same collectives whichever path a rank took)
+            res.junction_offset = int(X.host(nj).reshape(-1)[:rank].sum())
     mark("coverage")
     return res
 
