@@ -22,7 +22,7 @@ def build():
 def lib(opt: str = "O2"):
     if opt not in _LIBS:
         name = "libtb_oracle.so" if opt == "O2" else "libtb_oracle_O0.so"
-        path = os.path.join(_HERE, "_build", name)
+        path = os.path.join(os.environ.get("TB_ORACLE_BUILD_DIR") or os.path.join(_HERE, "_build"), name)   # (the override: tools/san_check.sh)
         if not os.path.exists(path):
             build()
         _LIBS[opt] = C.CDLL(path)

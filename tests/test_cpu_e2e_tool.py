@@ -9,7 +9,7 @@ import pytest
 from helpers import GOLDEN, sample_paths
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TOOL = os.path.join(ROOT, "oracle", "_build", "tb_cpu_e2e")
+TOOL = os.environ.get("TBK_TEST_CPU_E2E") or os.path.join(ROOT, "oracle", "_build", "tb_cpu_e2e")   # (the override: the sanitizer builds of tools/san_check.sh)
 
 
 def _run(args):

@@ -161,3 +161,34 @@ def test_empty_and_malformed(ctx):
     bad = b"\x00" * 20                                   # shorter than a BAM core
     with pytest.raises(TbkError):
         ctx.bam_encode(np.zeros(1, np.uint32), [1.0], [1], [0], n_dev=0, host_records={0: bad})
+
+
+def test_bad_split_arguments_are_refused_not_faulted(ctx):
+    """tbk_bam_encode trusts neither side of the rep / n_dev / n_host split: a representative beyond n_dev with no host record behind it
+    (no blob at all, or a slot beyond n_host) is TBK_EINVAL — it used to be a null / out-of-range dereference on the device"""
+    import ctypes as C
+
+    from tiebrush_amd import _lib
+    from tiebrush_amd.api import TbkError
+    # (a) rep >= n_dev, n_host == 0: nothing to read the record from
+    with pytest.raises(TbkError) as e:
+        ctx.bam_encode(np.array([5], np.uint32), [1.0], [1], [0], n_dev=0, host_records=None)
+    assert e.value.status == -1                              # TBK_EINVAL
+    # (b) a host slot beyond n_host
+    from tiebrush_amd import bamio
+    r0 = bamio.encode_record(0, 10, 0, 60, [(20 << 4) | 0], b"q", l_seq=0)[4:]
+    rep = np.array([0, 1], np.uint32)
+    en = _lib.EncIn()
+    yc, yx, yd = np.ones(2), np.ones(2, np.int64), np.zeros(2, np.int32)
+    slot = np.array([0, 7], np.uint32)                       # group 1 points at slot 7 of a blob that holds one record
+    blob = np.frombuffer(len(r0).to_bytes(4, "little") + r0, dtype=np.uint8)
+    off = np.array([0, 4 + len(r0)], np.uint64)
+    en.mem, en.n, en.rep, en.yc, en.yx, en.yd, en.n_dev = _lib.TBK_MEM_HOST, 2, rep.ctypes.data, yc.ctypes.data, yx.ctypes.data, yd.ctypes.data, 0
+    en.n_host, en.host_blob, en.host_off, en.host_slot = 1, blob.ctypes.data, off.ctypes.data, slot.ctypes.data
+    out = np.empty(1 << 16, np.uint8)
+    need, pay = C.c_uint64(0), C.c_uint64(0)
+    rc = ctx.L.tbk_bam_encode(ctx.h, C.byref(en), out.ctypes.data, out.size, C.byref(need), C.byref(pay))
+    assert rc == -1, rc                                       # TBK_EINVAL
+    # the context is still usable
+    run, _ = ctx.bam_encode(np.array([0], np.uint32), [1.0], [1], [0], n_dev=0, host_records={0: r0})
+    assert len(run) > 0

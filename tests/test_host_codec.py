@@ -9,7 +9,7 @@ import pytest
 from helpers import GOLDEN, sample_paths
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TOOL = os.path.join(ROOT, "tiebrush_amd", "_build", "tbh_tool")
+TOOL = os.environ.get("TBK_TEST_TBH_TOOL") or os.path.join(ROOT, "tiebrush_amd", "_build", "tbh_tool")   # (the override: the sanitizer builds of tools/san_check.sh)
 
 
 @pytest.fixture(scope="module", autouse=True)

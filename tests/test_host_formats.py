@@ -13,7 +13,7 @@ from samtext import _aux_text, bam_to_sam_text
 from tiebrush_amd import bamio
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TOOL = os.path.join(ROOT, "tiebrush_amd", "_build", "tbh_tool")
+TOOL = os.environ.get("TBK_TEST_TBH_TOOL") or os.path.join(ROOT, "tiebrush_amd", "_build", "tbh_tool")   # (the override: the sanitizer builds of tools/san_check.sh)
 
 
 def _records(path):

@@ -159,7 +159,8 @@ def load():
     return L
 
 
-HOST_LIB_PATH = os.path.join(_HERE, "_build", "libtbh.so")
+# (TBK_HOST_LIB: the sanitizer builds of tools/san_check.sh)
+HOST_LIB_PATH = os.environ.get("TBK_HOST_LIB") or os.path.join(_HERE, "_build", "libtbh.so")
 HOST_SYMBOLS = ["tbh_abi_version", "tbh_last_error", "tbh_tag_deflate_part", "tbh_write_bam_parts", "tbh_is_tiebrush"]   # include/tbh_host.h
 _host = None
 

@@ -667,6 +667,7 @@ struct EncSrc {
   const uint8_t* blob;       // raw records the host handed over (block_size first), device copy
   const uint64_t* blob_off;  // [n_blob + 1]
   const uint32_t* blob_slot; // [n] for a group whose representative is not a device record: its slot in the blob
+  uint32_t n_blob;           // records in the blob (tbk_enc_in::n_host): a slot beyond it is the caller's mistake, not a fault
 };
 
 __device__ __forceinline__ const uint8_t* enc_record(const EncSrc& S, const uint32_t* __restrict__ rep, uint32_t g, uint32_t* len) {
@@ -674,7 +675,11 @@ __device__ __forceinline__ const uint8_t* enc_record(const EncSrc& S, const uint
   const uint8_t* p;
   if (r < S.n_dev) {
     p = S.dev_inf + S.dev_rec[r];
-  } else {
+  } else {  // (enc_plan_k has checked the slot: the later passes only run when every group's record is there)
+    if (!S.blob || S.blob_slot[g] >= S.n_blob) {
+      *len = 0;
+      return nullptr;
+    }
     p = S.blob + S.blob_off[S.blob_slot[g]];
   }
   *len = rd32(p);  // block_size
@@ -700,6 +705,11 @@ __global__ __launch_bounds__(256) void enc_plan_k(uint32_t n, EncSrc S, const ui
   if (g >= n) return;
   uint32_t len;
   const uint8_t* p = enc_record(S, rep, g, &len);
+  if (!p) {  // rep[g] >= n_dev without a host record behind it (no blob, or host_slot[g] >= n_host): TBK_EINVAL, not a GPU fault
+    atomicOr(err, 4u);
+    olen[g] = 0;
+    return;
+  }
   if (len < 32) {
     atomicOr(err, 2u);
     olen[g] = 0;
@@ -1117,6 +1127,7 @@ extern "C" int tbk_bam_encode(tbk_ctx* ctx, const tbk_enc_in* in, uint8_t* out, 
     S.blob = blob;
     S.blob_off = d_boff;
     S.blob_slot = d_slot;
+    S.n_blob = in->n_host;
   }
   // ---- plan, offsets, payload ----
   TBK_HIP(hipMemsetAsync(ctx->d_scalars, 0, 16 * sizeof(uint64_t), st));
@@ -1128,7 +1139,8 @@ extern "C" int tbk_bam_encode(tbk_ctx* ctx, const tbk_enc_in* in, uint8_t* out, 
   uint32_t eb = 0;
   TBK_TRY(tbk_sync_err(ctx, &eb));
   if (eb) {
-    ctx->last_error = "bam_encode: a malformed record among the representatives";
+    ctx->last_error = (eb & 4u) ? "bam_encode: a representative beyond n_dev without a host record (host_slot >= n_host, or no host_blob)"
+                                : "bam_encode: a malformed record among the representatives";
     return TBK_EINVAL;
   }
   const uint64_t total = ctx->h_scalars[1];

@@ -244,7 +244,7 @@ __device__ __forceinline__ bool cb_last_block(uint32_t* __restrict__ done) {  //
     // the wait for their acknowledgement — stated explicitly: a workgroup-scope release fence compiles to no wait at all here (the
     // counter could pass the results, and the last block scan entries that were not there yet), an agent-scope release to an L2
     // write-back per block (buffer_wbl2: 0.37 -> 0.69 ms for the two passes, and the junction kernels beside them as much slower).
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): on gfx9 stores count there too
+    __builtin_amdgcn_s_waitcnt(TBK_WAIT_VMCNT0);  // vmcnt(0): on gfx9 stores count there too
     __asm__ volatile("" ::: "memory");
     s_last = atomicAdd(done, 1u) == gridDim.x - 1u ? 1u : 0u;
   }

@@ -5,6 +5,15 @@
 
 #define WAVE 64
 
+// The kernels are written for the gfx9 family's ISA (CDNA: gfx90a / gfx942 / gfx950; the Makefile builds gfx950): 64-wide waves, DPP row
+// operations, and s_waitcnt's gfx9 field layout — TBK_WAIT_VMCNT0 is "vmcnt(0), nothing else" THERE, where stores count in vmcnt too.
+// On gfx10 and later stores are counted by vscnt and the immediate's fields lie elsewhere: the hand-ordered hand-overs (cov.hip:
+// cb_last_block, wgroup.hip: PIPE) would compile and silently lose their ordering.  So another target does not compile at all.
+#if defined(__HIP_DEVICE_COMPILE__) && !(defined(__gfx90a__) || defined(__gfx940__) || defined(__gfx941__) || defined(__gfx942__) || defined(__gfx950__))
+#error "tiebrush_amd's kernels are written for the gfx9 / CDNA ISA (gfx950; wave64, gfx9 s_waitcnt encoding): build with ARCH=gfx950"
+#endif
+#define TBK_WAIT_VMCNT0 0x0F70
+
 enum : uint32_t { C_M = 0, C_I = 1, C_D = 2, C_N = 3, C_S = 4, C_H = 5, C_P = 6, C_EQ = 7, C_X = 8, C_B = 9 };
 __device__ __forceinline__ uint32_t cig_op(uint32_t c) { return c & 0xFu; }
 __device__ __forceinline__ uint32_t cig_len(uint32_t c) { return c >> 4; }

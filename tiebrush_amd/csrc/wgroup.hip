@@ -1157,7 +1157,7 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
           // (PIPE: such a wave has asked for nothing — issue() has the same guard —, but the compiler's wait-count bookkeeping sees a path
           // from the loads before the loop to the probes that passes through here and would make EVERY wave wait for its loads before
           // the probes; an explicit wait on this path, free at run time, tells it that nothing is in flight)
-          if constexpr (PIPE) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), nothing else
+          if constexpr (PIPE) __builtin_amdgcn_s_waitcnt(TBK_WAIT_VMCNT0);  // vmcnt(0), nothing else
           continue;
         }
         RawA ra[WG_RS];
@@ -1339,7 +1339,7 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
           if ((actm >> u) & 1u) eff[u] = (uint32_t)R.I.prio_hi[src[u]];
         // (PIPE: a load under a lane mask whose use sits under another one is "possibly in flight" at every later write of its register
         // as far as the compiler's wait counts go — it would make every tile wait for the next chunk's loads before the next probes)
-        if constexpr (PIPE) __builtin_amdgcn_s_waitcnt(0x0F70);
+        if constexpr (PIPE) __builtin_amdgcn_s_waitcnt(TBK_WAIT_VMCNT0);
       }
     }
 #pragma unroll
