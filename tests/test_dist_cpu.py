@@ -131,16 +131,22 @@ def _gloo_tile():
     return tile
 
 
-def _gloo_worker(rank, world, port, q, mode="partials"):
+def _c4_shape_tile():
+    """BASELINE.json configs[3]'s shape at a size the CPU takes: 256 files (32 per rank at world 8), a few hundred reads each"""
+    from tiebrush_amd import synth
+    return synth.make_tile(256, 300, "c2", n_loci=120)
+
+
+def _gloo_worker(rank, world, port, q, mode="partials", shape="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as td
     from dist_helpers import OracleCompute, split_tile
     from tiebrush_amd import dist
-    from test_dist_cpu import _gloo_tile
+    from test_dist_cpu import _gloo_tile, _c4_shape_tile
     td.init_process_group("gloo", rank=rank, world_size=world)
-    tile = _gloo_tile()
+    tile = _gloo_tile() if shape == "gloo" else _c4_shape_tile()
     tiles, first = split_tile(tile, world)
     r = dist.run_distributed(OracleCompute(), tiles[rank], first[rank], device="cpu", want_coverage=True, mode=mode)
     q.put((rank, r))
@@ -186,3 +192,28 @@ def test_loopback_real_bam_shapes(world, mode):
     tiles, first = split_tile(tile, world)
     res = dist.run_loopback(OracleCompute(), tiles, first, want_coverage=True, mode=mode)
     check_against_flat(res, tile, flat, flat_cov)
+
+
+def test_gloo_world8_config4_shape_equals_flat():
+    """The first real run on eight GPUs is the driver's: this is its rehearsal on the CPU — EIGHT processes, torch.distributed (gloo), the
+    partials protocol end to end on BASELINE config 4's shape (256 files, 32 per rank), every collective of the step at world 8,
+    checked against the flat oracle run (records, representatives, YC / YX / YD, coverage and the junction numbering across ranks)."""
+    import torch.multiprocessing as mp
+    from oracle import oracle_ffi as orc
+    from tiebrush_amd import synth
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, q, "partials", "c4")) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    tile = _c4_shape_tile()
+    flat = orc.collapse(tile)
+    flat_cov = orc.coverage(synth.collapsed_to_cov_input(tile, flat))
+    check_against_flat([got[r] for r in range(world)], tile, flat, flat_cov)
+    assert sum(1 for r in range(world) if got[r].n_groups > 0) >= 6          # the key range really is spread over the ranks

@@ -75,3 +75,23 @@ def test_bench_starts_its_own_ranks():
     assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["scaling"] == "strong"
     assert d["config"]["records_per_gpu"] == 60000
     assert abs(d["value"] - 2 * 60000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.02
+
+
+def test_bench_four_ranks_config4_shape():
+    """`python bench.py --gpus 4` as the driver calls it (no WORLD_SIZE: it starts its ranks), four ranks on the one GPU through the gloo hook —
+    as many processes as the box's guard allows beside the test runner (six on the card at once; the eight-rank rehearsal runs on the CPU:
+    tests/test_dist_cpu.py::test_gloo_world8_config4_shape_equals_flat) — on config 4's per-rank shape (32 files per rank): ONE line,
+    every rank seen, the whole-job value, the protocol's counts."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(TBK_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1", "--files-per-gpu", "32",
+           "--reads-per-file", "3000", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().split("\n") if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["config"]["ranks_seen"] == 4 and d["scaling"] == "strong"
+    assert d["config"]["workload"].startswith("c4: one job of 128 synthetic sorted BAMs") and d["config"]["records_per_gpu"] == 96000
+    assert abs(d["value"] - 4 * 96000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.02
+    assert d["dist_mode"] == "partials" and d["cut_rounds_max"] == 0 and d["collectives_per_step"] <= 5

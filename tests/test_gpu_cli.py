@@ -594,3 +594,19 @@ def test_device_writer_refusal_on_a_later_chunk_hands_over_to_the_host_writer(tm
     if mode == "long-record":
         from tiebrush_amd import bamio
         assert bamio.read_bam(d).n == n
+
+
+def test_tiebrush_ranks_four_ranks_equal_single_gpu(tmp_path):
+    """ten files over four ranks (3 + 3 + 2 + 2): the multi-rank command line ends in the single-GPU run's BAM, record for record (four
+    processes share the box's GPU through the gloo hook: what its process guard leaves beside the test runner)"""
+    from tiebrush_amd import bamio
+    ins = sample_paths("t1")
+    out1, out2 = str(tmp_path / "one.bam"), str(tmp_path / "four.bam")
+    _run([os.path.join(BIN, "tiebrush"), "-o", out1] + ins)
+    env = dict(os.environ, TBK_RANKS_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([os.path.join(BIN, "tiebrush"), "--ranks", "4", "-o", out2] + ins, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a, b = bamio.read_bam(out1, keep_aux=True), bamio.read_bam(out2, keep_aux=True)
+    assert a.n == b.n == 3479
+    for i in range(a.n):
+        assert bamio.record_bytes(a, i) == bamio.record_bytes(b, i), i
