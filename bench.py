@@ -39,7 +39,7 @@ import time
 
 # Every context drives three HIP streams (main, YD, junctions) and the bench runs two or three contexts: with the runtime's default of four
 # hardware queues, streams that should overlap share a queue and run one behind the other.  Eight queues: 18.5 -> 18.3 ms per step on
-# config 3, on every run (tools/scratch/hwq_r4.sh).  Read by the HIP runtime when it starts, so it is set before anything loads it.
+# config 3, on every run (round 4's measurements, DESIGN_HISTORY.md §6).  Read by the HIP runtime when it starts, so it is set before anything loads it.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -304,10 +304,10 @@ def main():
     cbufs, vbufs = cbufs2[0], vbufs2[0]
 
     # TBK_BENCH_GATE=1: one collapse at a time.  Rounds 2 and 3 needed it: left alone, two contexts fell into step — both in their
-    # window kernels, then both in YD, the GPU a quarter of the time with nothing but a few long YD chains on it (rocprofv3 timeline,
-    # tools/scratch/timeline.py).  With round 4's kernels (the window kernel a fifth shorter and bound by its vector instructions, the
+    # window kernels, then both in YD, the GPU a quarter of the time with nothing but a few long YD chains on it (a rocprofv3 timeline
+    # of round 3).  With round 4's kernels (the window kernel a fifth shorter and bound by its vector instructions, the
     # YD chains by their scalar ones) the contexts do better on their own: 18.3 ms per step with the gate, 17.7 without, 17.4 with
-    # three contexts (tools/scratch/ctxgate_r4.sh) — so the gate is off unless asked for.
+    # three contexts (round 4, DESIGN_HISTORY.md §6) — so the gate is off unless asked for.
     gate = threading.Lock() if os.environ.get("TBK_BENCH_GATE", "0") != "0" else contextlib.nullcontext()
 
     # group arrays: a quarter of the records (a call that needs more reports it, TBK_E2BIG, and is repeated with the need: the

@@ -21,8 +21,8 @@
 #include <thread>
 #include <vector>
 
-#include "crc32_block.cuh"
-#include "dev_common.cuh"
+#include "crc32_block.hpp"
+#include "dev_common.hpp"
 #include "tbk_internal.h"
 
 namespace {
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(64) void bgz_inflate_wave_k(uint32_t nmem, const Bg
 }
 
 // CRC32 and ISIZE of every member, as htslib checks them (RFC 1952).  A workgroup per member: the payload is staged in LDS with
-// coalesced loads and its CRC computed a chunk per thread (crc32_block.cuh).  (Round 4: a lane per member walking its 64 KiB through
+// coalesced loads and its CRC computed a chunk per thread (crc32_block.hpp).  (Round 4: a lane per member walking its 64 KiB through
 // slicing tables — 64 different cache lines per load instruction: 121 ms for the 21 GB of 45 inputs, an eighth of the device decode.)
 constexpr int CRC_NT = 256;
 constexpr uint32_t CRC_LDS = 65536 + 16 + 4 * CRCB_LDS_WORDS;
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(CRC_NT) void bgz_crc_k(uint32_t nmem, const BgzMemb
 }
 
 // the inflate: a wave per member, then the CRC pass (a lane per member).  (Rounds 3 - 4 also kept a lane-per-member decoder — 64
-// different decoders in lock step —: 664 ms for the 7.6 GB of tools/scratch/dd2_r4.sh against 274 ms; it lives in the history.)
+// different decoders in lock step —: 664 ms for 7.6 GB of inputs (round 4) against 274 ms; it lives in the history.)
 static int bgz_inflate_launch(tbk_ctx* ctx, uint32_t nmem, const BgzMember* d_mt, const uint8_t* d_comp, uint8_t* d_out) {
   TBK_LAUNCH(ctx, "bgz_inflate", bgz_inflate_wave_k, nmem, 64, 0, nmem, d_mt, d_comp, d_out, ctx->d_err);
   {

@@ -26,9 +26,9 @@
 #include <algorithm>
 #include <vector>
 
-#include "crc32_block.cuh"
+#include "crc32_block.hpp"
 #include "deflate_codes.h"
-#include "dev_common.cuh"
+#include "dev_common.hpp"
 #include "tbk_internal.h"
 
 namespace {
@@ -69,7 +69,7 @@ constexpr uint32_t L_CODC = L_CODD + 32 * 2;
 constexpr uint32_t L_RLE = L_CODC + 32 * 2;               // u16[320]
 constexpr uint32_t L_BLC = L_RLE + 320 * 2;               // u32[20]
 constexpr uint32_t L_CRCT = L_BLC + 20 * 4;               // u32[CRCB_LDS_WORDS] CRC-32 work area
-constexpr uint32_t L_WSUM = L_CRCT + 4 * CRCB_LDS_WORDS;  // (crc32_block.cuh: table, zero-advance matrices, per-chunk registers); u32[2][16] per-wave bit totals of the token scan
+constexpr uint32_t L_WSUM = L_CRCT + 4 * CRCB_LDS_WORDS;  // (crc32_block.hpp: table, zero-advance matrices, per-chunk registers); u32[2][16] per-wave bit totals of the token scan
 constexpr uint32_t L_OVER_END = L_WSUM + 2 * 16 * 4;
 static_assert(L_OVER_END <= L_CTL, "the coder's arrays must fit where the tables were");
 static_assert(L_END <= 81920, "two workgroups per CU");
@@ -160,7 +160,7 @@ __device__ __noinline__ void df_build_code(uint32_t freq_off, int nsym, int maxb
   __syncthreads();
 }
 
-// CRC-32 of the n payload bytes in LDS -> ctl[C_CRC] (crc32_block.cuh: a chunk per thread, folded with zero-advance matrices)
+// CRC-32 of the n payload bytes in LDS -> ctl[C_CRC] (crc32_block.hpp: a chunk per thread, folded with zero-advance matrices)
 __device__ __noinline__ void df_crc32(uint32_t n) {
   uint32_t* const work = DF_U32(L_CRCT);
   crcb_setup(work, threadIdx.x, DF_NT);

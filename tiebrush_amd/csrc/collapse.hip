@@ -25,10 +25,10 @@
 // of that list, or a chromosome change) into independent chains, one GPU thread each.
 #include <stdlib.h>
 
-#include "dev_common.cuh"
-#include "rx_w64.cuh"
-#include "scan_op.cuh"
-#include "strategy.cuh"
+#include "dev_common.hpp"
+#include "rx_w64.hpp"
+#include "scan_op.hpp"
+#include "strategy.hpp"
 #include "tbk_internal.h"
 #include "wgroup.h"
 
@@ -608,15 +608,9 @@ __global__ __launch_bounds__(256) void yd_lagg_scan_k(uint4* __restrict__ agg, u
     run = ys_combine(run, mine);
   }
 }
-__global__ void yd_ltotal_k(const uint64_t* __restrict__ totals, uint64_t* __restrict__ nit) {
-  const uint64_t s = wave_sum(totals[threadIdx.x]) ;
-  __shared__ uint64_t sm[2];
-  if (lane_id() == 0) sm[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) *nit = sm[0] + sm[1];
-}
 // block l: row l of the table -> exclusive prefix in place, row total -> totals[l]
-__global__ __launch_bounds__(1024) void yd_lscan_k(uint32_t* __restrict__ table, uint32_t ntiles, uint64_t* __restrict__ totals) {
+__global__ __launch_bounds__(1024) void yd_lscan_k(uint32_t* __restrict__ table, uint32_t ntiles, uint64_t* __restrict__ totals,
+                                                   unsigned long long* __restrict__ nit /* zeroed: the items of all lists */) {
   __shared__ uint32_t sm[16];
   __shared__ uint32_t carry_s;
   uint32_t* row = table + (size_t)blockIdx.x * ntiles;
@@ -642,7 +636,10 @@ __global__ __launch_bounds__(1024) void yd_lscan_k(uint32_t* __restrict__ table,
     if (threadIdx.x == 0) carry_s += tot;
     __syncthreads();
   }
-  if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
+  if (threadIdx.x == 0) {
+    totals[blockIdx.x] = carry_s;
+    atomicAdd(nit, (unsigned long long)carry_s);  // (128 blocks: the sum that was a launch of its own)
+  }
 }
 
 // The item -> group word: the low half of the 64-bit item words of the radix split, or (items placed by list) an array of its own.
@@ -680,7 +677,7 @@ struct YdGroups {
   uint32_t* xoff;
 };
 // The exon word of a group / an item (YdGroups::pk.w, YdItems::nex): the exon count — or, with bit 30 set, the two exons themselves:
-// a group whose key word is the exact code of the shape M N M carries the first block a : 10 and the gap g : 20 (strategy.cuh), so
+// a group whose key word is the exact code of the shape M N M carries the first block a : 10 and the gap g : 20 (strategy.hpp), so
 // its exons are (start, start + a - 1), (start + a + g, end) and the chain kernels fetch nothing for such an item — neither its group
 // word nor the three sectors of the exon arrays (one item in twelve on config 3, nearly all of them of this shape; 2.6 GB of gathers
 // per launch of yd_wave_k).  Bit 31 of an item's word is the head flag of the items placed by list.
@@ -690,7 +687,7 @@ __device__ __forceinline__ bool yd_nex_x2(uint32_t w) { return (w & YD_X2) != 0u
 __device__ __forceinline__ uint32_t yd_x2_a(uint32_t w) { return (w >> 20) & 0x3FFu; }
 __device__ __forceinline__ uint32_t yd_x2_g(uint32_t w) { return w & 0xFFFFFu; }
 
-// The exons of a group whose key word is an exact code (strategy.cuh: record_key) follow from the key alone — one
+// The exons of a group whose key word is an exact code (strategy.hpp: record_key) follow from the key alone — one
 // reference-consuming operation: one exon (start, end); M N M / two exons with first block a and gap g: (start, start + a - 1),
 // (start + a + g, end) — so the representative's CIGAR, a random access per group, is only walked for the other groups (a few
 // per cent of an RNA-seq sample).  Returns the exon count, 0 when the CIGAR has to be walked.
@@ -1942,9 +1939,8 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       TBK_LAUNCH(ctx, "yd_groups", yd_groups_k, cdiv(ng, B), B, 0, I, ng, J.gperm, J.G, J.shi, J.slo, Q);
       TBK_TRY(tbk_exscan_u32(ctx, Q.nex, Q.xoff, ng, sc + 5));
       TBK_LAUNCH(ctx, "yd_lcount", yd_lcount_k, ys_tiles, YS_NT, 0, S, Q.pk, ys_tiles, ys_table, ys_agg, ys_files);
-      TBK_LAUNCH(ctx, "yd_lscan", yd_lscan_k, YS_NL, 1024, 0, ys_table, ys_tiles, ys_totals);
+      TBK_LAUNCH(ctx, "yd_lscan", yd_lscan_k, YS_NL, 1024, 0, ys_table, ys_tiles, ys_totals, (unsigned long long*)(sc + 2));
       TBK_LAUNCH(ctx, "yd_lscan", yd_lagg_scan_k, YS_NL, 256, 0, ys_agg, ys_tiles);
-      TBK_LAUNCH(ctx, "yd_lscan", yd_ltotal_k, 1, YS_NL, 0, ys_totals, sc + 2);
     } else if (J.win) {  // items per output group straight from the per-group sample counts
       ocnt = ws_alloc<uint32_t>(ctx, ng);
       ooff = ws_alloc<uint32_t>(ctx, ng);

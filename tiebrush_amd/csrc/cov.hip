@@ -20,8 +20,8 @@
 // record order exactly as the reference does.
 #include <thread>
 
-#include "dev_common.cuh"
-#include "scan_op.cuh"
+#include "dev_common.hpp"
+#include "scan_op.hpp"
 #include "tbk_internal.h"
 
 namespace {

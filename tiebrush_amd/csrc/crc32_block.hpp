@@ -1,4 +1,4 @@
-// crc32_block.cuh — CRC-32 (RFC 1952: reflected 0xEDB88320) of a byte run that lies in LDS, by a whole workgroup.
+// crc32_block.hpp — CRC-32 (RFC 1952: reflected 0xEDB88320) of a byte run that lies in LDS, by a whole workgroup.
 // A CRC register is a linear function of (register, data) over GF(2): the run is cut into 128-byte chunks counted from its END (so that
 // only the first chunk is short), every thread runs the table-driven update over one chunk — the first with the initial 0xFFFFFFFF, the
 // others from 0 —, and the registers are folded pairwise: advancing a register through 128 << k zero bytes is a 32 x 32 bit matrix (the

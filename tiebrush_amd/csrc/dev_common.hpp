@@ -1,4 +1,4 @@
-// dev_common.cuh — device helpers: CIGAR walks, hashing, wave64 primitives.  gfx950 (wave = 64).
+// dev_common.hpp — device helpers: CIGAR walks, hashing, wave64 primitives.  gfx950 (wave = 64).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

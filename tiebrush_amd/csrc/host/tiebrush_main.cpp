@@ -452,7 +452,7 @@ int main(int argc, char* argv[]) {
       if (eligible) {
         // The device's share of the compressed bytes: both sides should end together.  The device starts late — the HIP runtime takes
         // ~ 0.25 s to come up, the cores work alone meanwhile — and is then several times faster: with x of T bytes on the device,
-        // t_ctx + x / R_dev = (T - x) / R_host.  Rates measured on an MI355X box with a 16-core quota (tools/scratch/e2e_long_r5.sh): the
+        // t_ctx + x / R_dev = (T - x) / R_host.  Rates measured on an MI355X box with a 16-core quota (round 5's end-to-end legs, tools/e2e_leg.py): the
         // device side 4.7 GB/s of compressed BAM (upload, inflate, record index, SoA), a core 0.18 GB/s (inflate with the record index
         // riding along, SoA).  1.8 GB of input: 49 %; 7.1 GB: 62 %.  TBK_HYBRID_SHARE (per cent) overrides.
         const int host_threads = getenv("TBK_THREADS") ? nthreads : std::max(2, nthreads - 3);

@@ -11,7 +11,7 @@
 //            stable LSD radix sort over its varying key bytes (msort_big_k).
 //
 // The result is the same permutation the stable 128-bit radix sort produces.  All integer work, HBM/LDS-bound; no MFMA.
-#include "dev_common.cuh"
+#include "dev_common.hpp"
 #include "tbk_internal.h"
 
 namespace {

@@ -8,7 +8,7 @@
 // structure of arrays in context-owned device memory (pos and the CIGAR words land where they stay; one kernel writes the other
 // columns, one scan the CIGAR offsets): the tile it returns goes to tbk_collapse_tile as any device-resident tile does.
 // The reference has no counterpart (its records never leave the host: GSam.h:506-516, tmerge.cpp:331-344).
-#include "dev_common.cuh"
+#include "dev_common.hpp"
 #include "tbk_internal.h"
 
 namespace {

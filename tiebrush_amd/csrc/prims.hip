@@ -2,9 +2,9 @@
 // radix sort ("wavefront radix over LDS-staged tiles": per-wave ballot matching for the
 // stable rank, the sorted sub-tile staged in LDS so that global writes are digit-contiguous).
 // All integer work, HBM-bound; no MFMA.
-#include "dev_common.cuh"
+#include "dev_common.hpp"
 #include "tbk_internal.h"
-#include "rx_w64.cuh"
+#include "rx_w64.hpp"
 
 // =====================================================================================
 // exclusive scan (u32 in, u32 or u64 out) — reduce / spine / down-sweep (one block when the input is small).
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(RX_NT) void rx_scatter_k(const uint64_t* __restrict
 }
 }  // namespace
 
-// ---- single 64-bit words ordered by a bit range: rx_w64.cuh (the scatter pass is a template there: its last pass can hand every
+// ---- single 64-bit words ordered by a bit range: rx_w64.hpp (the scatter pass is a template there: its last pass can hand every
 // word and its final position to a functor) ----------------
 // tile = RX_SUB * iter elements: small inputs get many small tiles (occupancy), big inputs bigger tiles
 // (the digit x tile table stays a few MB)

@@ -1,4 +1,4 @@
-// rx_w64.cuh — stable LSD radix sort of single 64-bit words by a bit range (e.g. id : value packed into one word), 8-bit digits,
+// rx_w64.hpp — stable LSD radix sort of single 64-bit words by a bit range (e.g. id : value packed into one word), 8-bit digits,
 // tiled: the histogram / row-scan kernels live in prims.hip, the scatter pass is a template here so that a caller can hang a
 // functor on the LAST pass — emit(final position, word) runs where the word is written, while the tile's neighbourhood of the
 // input is still cache-hot (collapse.hip: the YD items pick up their group's coordinates there instead of in a gather pass over
@@ -7,7 +7,7 @@
 #include <type_traits>
 #include <utility>
 
-#include "dev_common.cuh"
+#include "dev_common.hpp"
 #include "tbk_internal.h"
 
 constexpr int RX_NT = 256;

@@ -1,10 +1,10 @@
-// scan_op.cuh — device-wide inclusive scan with an arbitrary associative (not necessarily
+// scan_op.hpp — device-wide inclusive scan with an arbitrary associative (not necessarily
 // commutative) operator over a trivially-copyable T made of 32-bit words.
 // Two forms: three launches (per-tile reduce, single-block spine, per-tile down-sweep) or one launch with a decoupled
 // look-back (so_single_k below: scans whose elements are expensive to load gain from reading them once; cheap ones do not).
 // Load/Store are functors so the per-element work of the caller fuses into the first / last pass.
 #pragma once
-#include "dev_common.cuh"
+#include "dev_common.hpp"
 #include <stdlib.h>
 #include <string.h>
 

@@ -27,9 +27,9 @@
 //
 // All integer / byte work, HBM-bound, no MFMA.  No data-path collective lives here: the exchange itself is
 // torch.distributed (RCCL over xGMI) in dist.py.
-#include "dev_common.cuh"
-#include "scan_op.cuh"
-#include "strategy.cuh"
+#include "dev_common.hpp"
+#include "scan_op.hpp"
+#include "strategy.hpp"
 #include "tbk_internal.h"
 #include "wgroup.h"
 
@@ -539,7 +539,7 @@ __global__ void partial_table_k(uint32_t ng, uint32_t world, const int64_t* __re
   tab[d * 3 + 2] = (long long)(wb - wa);
 }
 // rows: TBK_PARTIAL_ROW x int32 per local group, in group (= output) order.  Words 9 / 10 are the low half of the group key
-// (strategy.cuh, record_key: reference span and the 32-bit key word — an exact code or the strategy hash under TBK_KEY_SEED0) of
+// (strategy.hpp, record_key: reference span and the 32-bit key word — an exact code or the strategy hash under TBK_KEY_SEED0) of
 // the representative, which every member of the group shares: the owner groups partials by (tid, pos, strand, span, word)
 // without walking a CIGAR, and verifies the hashed ones.
 __global__ void partial_rows_k(uint32_t ng, uint32_t k, uint32_t first_fidx, ColIn I, ColOpt O, const uint32_t* __restrict__ rep,

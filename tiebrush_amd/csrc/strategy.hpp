@@ -1,9 +1,9 @@
-// strategy.cuh — the record view of the collapse stage and the strategy key of a record (what "the same alignment" means
+// strategy.hpp — the record view of the collapse stage and the strategy key of a record (what "the same alignment" means
 // under the four merge strategies): seeded hash, exact equality, and the reference's three-way compare.
 // Reference: cmpCigar / cmpCigarClip / cmpExons / cmpFull, /root/reference/src/tiebrush.cpp:285-345.
 // Shared by collapse.hip (sort path) and wgroup.hip (window path).
 #pragma once
-#include "dev_common.cuh"
+#include "dev_common.hpp"
 #include "tbk_internal.h"
 
 namespace tbkd {

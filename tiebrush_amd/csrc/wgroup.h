@@ -2,7 +2,7 @@
 #pragma once
 #include <stdlib.h>
 
-#include "strategy.cuh"
+#include "strategy.hpp"
 #include "tbk_internal.h"
 
 struct WgOut {

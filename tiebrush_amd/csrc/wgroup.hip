@@ -13,7 +13,7 @@
 // file contributes one contiguous piece to a window (wg_offsets_stream_k: one streaming pass, which also checks that the files
 // are sorted), so a window's records are k coalesced reads.  One workgroup per window (wg_hash_window): the records stream
 // through once, pieces laid end to end; per record the filter verdict and the 128-bit key come from its raw fields
-// (record_key, strategy.cuh), the merge priority — the per-file running maximum of the read ends inside a run of equal
+// (record_key, strategy.hpp), the merge priority — the per-file running maximum of the read ends inside a run of equal
 // starts — from a segmented prefix maximum along the piece (DPP inside a wave, LDS across waves, a carry across chunks).  The
 // passing records go into an LDS hash table keyed by a seeded 64-bit fingerprint of the key, the key stored beside it and
 // compared by every record that lands on the slot; per group: wave-aggregated count, bitset of the samples seen, atomic
@@ -21,7 +21,7 @@
 // their (group, sample) incidences.  Windows with more distinct groups than the table holds go to a second tier with a larger
 // table, then to the LDS sort kernel (at most WG_CAP records, by construction of the splitters: index permutation
 // merge-sorted by (key, load order), groups from blocked runs).  Every record whose key word is a hash (not an exact code,
-// strategy.cuh) is compared with a member of its group under the exact strategy key (a collision raises TBK_DERR_COLLISION
+// strategy.hpp) is compared with a member of its group under the exact strategy key (a collision raises TBK_DERR_COLLISION
 // and the host reseeds), so grouping is exact.  A scan over the per-window counts and a compaction pass put groups and
 // incidences in key order.  What cannot be handled (more distinct groups in a pile-up than the larger table holds, k > 1024)
 // raises TBK_DERR_BIGBUCKET and the tile takes the sort path; input the raw form does not take (an inversion, a mapped read
@@ -34,14 +34,8 @@
 
 #include <algorithm>
 
-// WG_EXP (build-time, 0 in every shipped build): ablation switches of wg_hash_window for timing runs under rocprofv3 — results are wrong,
-// only the kernel's duration means anything (tools/scratch/wgexp_r4.sh).  1: no table work (probes, claims, group atomics, ranking);
-// 2: no loads (every record a synthetic 100M read); 8: no ranking and no group output.  DESIGN.md §3 has the split they gave.
-#ifndef WG_EXP
-#define WG_EXP 0
-#endif
-#include "dev_common.cuh"
-#include "strategy.cuh"
+#include "dev_common.hpp"
+#include "strategy.hpp"
 #include "tbk_internal.h"
 #include "wgroup.h"
 
@@ -449,17 +443,6 @@ __device__ __forceinline__ RawA wg_raw_a(const ColIn& I, uint32_t i, bool need_p
 // ... with the record's CIGAR range already at hand (fetched a chunk ahead, wg_hash_window)
 __device__ __forceinline__ RawA wg_raw_a(const ColIn& I, uint32_t i, bool need_prev, uint32_t c0, uint32_t c1) {
   RawA a;
-#if WG_EXP & 2
-  a.pos = (int)(i >> 3);
-  a.tidv = 0;
-  a.fl_mq_sc = (60u << 16);
-  a.nh = 1;
-  a.c0 = c0;
-  a.nc = 1;
-  a.ppos = (int)((need_prev && i > 0 ? i - 1 : i) >> 3);
-  a.ptid = 0;
-  return a;
-#endif
   a.pos = I.pos[i];
   a.tidv = I.tid[i];
   a.fl_mq_sc = (uint32_t)I.flag[i] | ((uint32_t)I.mapq[i] << 16) | (strand_code(I.strand[i]) << 24);
@@ -473,12 +456,6 @@ __device__ __forceinline__ RawA wg_raw_a(const ColIn& I, uint32_t i, bool need_p
 }
 __device__ __forceinline__ CigView wg_raw_b(const ColIn& I, const RawA& a) {
   CigView c;
-#if WG_EXP & 2
-  c.w0 = (100u << 4);
-  c.w1 = c.w2 = 0;
-  c.p = I.cig;
-  return c;
-#endif
   const uint32_t* safe = I.cig_off;  // (always readable)
   c.w0 = *(a.nc > 0 ? I.cig + a.c0 : safe);
   c.w1 = *(a.nc > 1 ? I.cig + a.c0 + 1 : safe);
@@ -502,20 +479,6 @@ __device__ __forceinline__ T wg_ld(const T* base, uint32_t byte_off) {
 // is not read: 5 of a record's 16 bytes under the default options)
 __device__ __forceinline__ RawL wg_raw_l(const ColIn& I, uint32_t i, bool need_prev, uint32_t c0, uint32_t c1, uint32_t cols = 3u) {
   RawL a;
-#if WG_EXP & 2
-  a.pos = (int)(i >> 3);
-  a.tidv = a.ptid = 0;
-  a.ppos = (int)((need_prev && i > 0 ? i - 1 : i) >> 3);
-  a.nh = 1;
-  a.flag = 0;
-  a.mapq = 60;
-  a.strand = '+';
-  a.c0 = c0;
-  a.nc = 1;
-  a.w0 = 100u << 4;
-  a.w1 = a.w2 = 0;
-  return a;
-#endif
   // byte offsets of 32 bits from the arrays' bases, which are uniform: one shift serves every 4-byte array, and the loads take the base
   // from scalar registers (the raw form runs on tiles of < 2^30 records and CIGAR words: tbk_window_groups)
   const uint32_t o4 = i << 2;
@@ -844,7 +807,7 @@ __device__ __forceinline__ uint16_t* wg_bucket_rank(uint16_t* src, uint16_t* dst
 __device__ __forceinline__ unsigned long long wg_fingerprint(uint64_t hi, uint64_t lo, uint64_t seed) {
   // (hi, lo) -> hi * K + lo is one-to-one in lo for equal hi and, for an odd seeded K, collides for two different hi only when
   // their difference times K equals the difference of the lo words; the xor-shift / odd-multiply rounds behind it are bijections
-  // (two 64-bit multiplies in all.  A multiply-free fingerprint — two steps of the strategy hash, dev_common.cuh — passed every
+  // (two 64-bit multiplies in all.  A multiply-free fingerprint — two steps of the strategy hash, dev_common.hpp — passed every
   // test and cost 1.2 ms: 6.59 vs 5.4 ms on config 3.  The keys of a window differ in a few low bits of `start`, and shifts and
   // adds carry those into the slot index as a near-linear sequence: the probes pile up.)
   unsigned long long f = (hi ^ seed) * ((seed << 1) | 0x9E3779B97F4A7C15ull) + lo;
@@ -1074,18 +1037,14 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
     if (t < n_w) {
       a_fil = piece(pre, t);
       a_src = rb[a_fil] + t;
-#if WG_EXP & 2
-      a_c0 = a_src; a_c1 = a_src + 1;
-#else
       a_c0 = wg_ld(R.I.cig_off, a_src << 2);
       a_c1 = wg_ld(R.I.cig_off, (a_src << 2) + 4u);
-#endif
     }
   }
   // PIPE (the AHEAD form): the loads of a chunk's records are issued a chunk ahead too — right behind the previous chunk's key
   // computation, whose raw fields they replace in the registers — so that they fly while that chunk probes the table, waits at its
   // barrier and updates its groups, instead of every wave of the block sitting out a round trip to memory at the top of each chunk
-  // (leaving the loads out altogether, WG_EXP 2, took 1.8 - 2.4 ms of the kernel's 6.7).
+  // (a build that left the loads out altogether took 1.8 - 2.4 ms off the kernel's 6.7).
   constexpr bool PIPE = AHEAD;
   RawL n_l = {};
   uint32_t n_fil = 0, n_src = 0, n_f0 = 0;
@@ -1105,13 +1064,8 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
       if (e2 < n_w) {
         a_fil = piece(pre, e2);
         a_src = rb[a_fil] + e2;
-#if WG_EXP & 2
-        a_c0 = a_src;
-        a_c1 = a_src + 1;
-#else
         a_c0 = wg_ld(R.I.cig_off, a_src << 2);
         a_c1 = wg_ld(R.I.cig_off, (a_src << 2) + 4u);
-#endif
       }
     }
   };
@@ -1236,10 +1190,6 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
       if (t == 0 && (kh[0] ^ kl[0] ^ rec[0] ^ eff[0] ^ kh[NR - 1] ^ rec[NR - 1]) == 0x123456789ull) dbg[31] = 1;  // (the loads have landed)
       phase(2);
     }
-#if WG_EXP & 1
-    if (kh[0] == 0x123456789ull) s_misc[0] = 1;   // (keep the keys alive)
-    actm = 0;
-#endif
 #pragma unroll
     for (int u = 0; u < NR; ++u) {
       if ((actm >> u) & 1u) {
@@ -1390,11 +1340,7 @@ __device__ __forceinline__ void wg_hash_window(const WgIn& In, const WgRaw& R, c
   }
   __syncthreads();
   const bool overflow = ONEBAR ? (s_misc[6] | s_misc[7]) != 0 : s_misc[1] != 0;
-#if WG_EXP & 8
-  const uint32_t d = s_misc[0] == 0x7FFFFFFFu ? 1u : 0u;
-#else
   const uint32_t d = s_misc[0];
-#endif
   // What follows writes through fifteen pointers of T that the chunk loop has no use for.  As kernel arguments they are loaded at the
   // kernel's entry and stay live across the loop — more scalar registers than the hardware has, so the compiler kept ~ 60 of the loop's
   // own scalars in lanes of two vector registers and fetched them back with v_readlane at every use (78 of the ~ 650 vector

@@ -969,7 +969,7 @@ def run_distributed(compute, tile, first_fidx, device=None, group=None, **kw):
     def a2a_rows(x, send_cnt, recv_cnt, big=None):
         """all_to_all of the row blocks of x (dim 0 split by send_cnt), recv_cnt rows from each source.  One rank: a
         copy.  Blocks beyond A2A_MAX_BYTES go out in several rounds: the RCCL of this image drops the tail of a
-        1.5 GB self-exchange (tools/scratch/a2a_probe.py: 64 M rows x 24 B arrive as 32 M rows + zeros), and rounds of a
+        1.5 GB self-exchange (a probe of round 4: 64 M rows x 24 B arrive as 32 M rows + zeros), and rounds of a
         bounded size also bound the staging memory."""
         out = torch.empty((int(sum(recv_cnt)),) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
         if world == 1:

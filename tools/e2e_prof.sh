@@ -25,4 +25,4 @@ done
 cd /tmp && TBK_EXIT_TIMING=3 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/e2e_prof" -o e2e -- "$GRAFT_REPO_ROOT/tiebrush_amd/_build/tiebrush" -o $D/out2.bam $D/in*.bam > "$GRAFT_REPO_ROOT/gpurun_out/e2e_prof/run.log" 2>&1 || true
 cd "$GRAFT_REPO_ROOT"
 find gpurun_out/e2e_prof -name "*stats*" | head
-python3 tools/scratch/copy_summary_r5.py gpurun_out/e2e_prof
+python3 tools/e2e_prof_summary.py gpurun_out/e2e_prof

@@ -11,7 +11,7 @@ cp $(find $O/dk -name "*kernel_stats.csv" | head -1) $O/deflate_kernel_stats.csv
 rm -rf $O/dk
 # the command line on 32 x 1 M reads with SEQ / QUAL: phase lines, then kernels and copies of one run under rocprofv3
 rm -rf gpurun_out/e2e_prof
-bash tools/scratch/e2e_prof_r5.sh 32 1000000 > $O/e2e_seq_cli.txt 2>&1
+bash tools/e2e_prof.sh 32 1000000 > $O/e2e_seq_cli.txt 2>&1
 cp gpurun_out/e2e_prof/e2e_kernel_stats.csv $O/e2e_seq_kernel_stats.csv
 cp gpurun_out/e2e_prof/e2e_memory_copy_stats.csv $O/e2e_seq_memory_copy_stats.csv
 rm -rf gpurun_out/e2e_prof /tmp/tbk_e2e_prof
