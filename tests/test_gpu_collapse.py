@@ -65,11 +65,16 @@ def test_golden_clip_exon(ctx, name, strategy, bam_loader):
     _check(ctx, tile, strategy=strategy)                    # HEAD default (-A off), window / sort path as the tile size picks
 
 
-@pytest.mark.parametrize("machine", ["wave", "lane"])
+@pytest.mark.parametrize("machine", ["wave", "lane", "literal"])
 def test_golden_t2_yd_machines(ctx, machine, bam_loader, monkeypatch):
-    """golden t2 (its 64 tail-drop YDs among them) with every chain forced through yd_wave_k / through yd_lane_k"""
+    """golden t2 (its 64 tail-drop YDs among them) with every chain forced through yd_wave_k / through yd_lane_k / through yd_run_k
+    (the literal list machine the other two hand their overflowing lists to: it reads single exons and the exact two-exon shape from
+    the item word, everything else from the groups' exon arrays)"""
     from tiebrush_amd import soa
-    tbk_debug(monkeypatch, yd_wave_min="1" if machine == "wave" else str(1 << 30))
+    if machine == "literal":
+        tbk_debug(monkeypatch, yd_literal="1")
+    else:
+        tbk_debug(monkeypatch, yd_wave_min="1" if machine == "wave" else str(1 << 30))
     bams = [bam_loader(p) for p in sample_paths("t2")]
     tile = soa.tile_from_bams(bams, with_names=True)
     gold = bam_loader(os.path.join(GOLDEN, "t2", "t2.bam"))
@@ -460,3 +465,16 @@ def test_yd_list_survives_a_start_at_end_plus_one(ctx):
     from test_gpu_window import _tile
     _check(ctx, _tile(_degenerate_exon_files()))
     _check(ctx, _tile(list(reversed(_degenerate_exon_files()))))
+
+
+@pytest.mark.parametrize("profile,strategy,kw", [("c3", "clip", {}), ("c5", "exon", dict(max_nh=5, min_qual=1)), ("c2", "cigar", {})])
+def test_literal_yd_machine_on_synthetic_tiles(ctx, profile, strategy, kw, monkeypatch):
+    """every chain through yd_run_k on spliced synthetic tiles (window path forced: items placed by list, their exon words; and the
+    default path), against the oracle"""
+    from tiebrush_amd import synth
+    tbk_debug(monkeypatch, yd_literal="1")
+    tile = synth.make_tile(10, 8000, profile, n_loci=60)
+    got, _ = _check(ctx, tile, strategy=strategy, **kw)
+    assert int(np.asarray(got["yd"]).max()) > 0
+    tbk_debug(monkeypatch, yd_literal="1", path="window")
+    _check(ctx, tile, strategy=strategy, **kw)

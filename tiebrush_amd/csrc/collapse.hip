@@ -686,6 +686,7 @@ __device__ __forceinline__ uint32_t yd_nex_count(uint32_t w) { return (w & YD_X2
 __device__ __forceinline__ bool yd_nex_x2(uint32_t w) { return (w & YD_X2) != 0u; }
 __device__ __forceinline__ uint32_t yd_x2_a(uint32_t w) { return (w >> 20) & 0x3FFu; }
 __device__ __forceinline__ uint32_t yd_x2_g(uint32_t w) { return w & 0xFFFFFu; }
+__device__ __forceinline__ bool yd_nex_far(uint32_t w) { return !(w & YD_X2) && (w & 0x3FFFFFFFu) > 1u; }  // its exons lie in the groups' arrays
 
 // The exons of a group whose key word is an exact code (strategy.hpp: record_key) follow from the key alone — one
 // reference-consuming operation: one exon (start, end); M N M / two exons with first block a and gap g: (start, start + a - 1),
@@ -725,12 +726,14 @@ __global__ void yd_groups_k(ColIn I, uint32_t ng, const uint32_t* __restrict__ g
     const uint32_t r = (uint32_t)(G.rep[sg] & 0xFFFFFFFFull);
     walk_exons(I.pos[r], I.cig + I.cig_off[r], I.cig_off[r + 1] - I.cig_off[r], [](int, int) {}, &nex);
   }
-  Q.nex[o] = (uint32_t)nex;
   uint32_t xw = (uint32_t)nex;
   if (nk == 2u) {  // (from the key: the shape's two lengths, both inside their fields by the code's definition)
     const uint32_t a = e0 - (uint32_t)st + 1u, g = s1 - e0 - 1u;
     if (a < (1u << 10) && g < (1u << 20)) xw = YD_X2 | (a << 20) | g;
   }
+  // the exon arrays hold the groups whose exons no item word can say: several exons, not the exact two-exon shape (a single exon is
+  // (start, end); yd_gexons_k walks only those — a few per cent of an RNA-seq sample — and the offset scan counts only them)
+  Q.nex[o] = yd_nex_far(xw) ? (uint32_t)nex : 0u;
   Q.pk[o] = make_uint4(tidp1, (uint32_t)st, en, xw);
 }
 
@@ -738,10 +741,11 @@ __global__ void yd_gexons_k(ColIn I, uint32_t ng, const uint32_t* __restrict__ g
                             uint32_t* __restrict__ ex_s, uint32_t* __restrict__ ex_e) {
   uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= ng) return;
+  const uint4 pk = Q.pk[o];
+  if (!yd_nex_far(pk.w)) return;  // (nothing reads the arrays for it: yd_groups_k counted no slot)
   const uint32_t sg = gperm[o];
   uint32_t w = Q.xoff[o];
   {
-    const uint4 pk = Q.pk[o];
     uint32_t e0, s1;
     const uint32_t nk = yd_exons_from_key(slo[G.first[sg]], pk.y, pk.z, &e0, &s1);
     if (nk) {
@@ -1161,10 +1165,20 @@ __global__ void yd_run_k(const uint32_t* __restrict__ ids, const uint32_t* __res
   for (uint32_t t = t0; t < t1; ++t) {
     const uint4 it = Y.rec(t);
     uint32_t rstart = it.y;
-    uint32_t xo = Y.xo_of(it, v.group(t)), nex = yd_nex_count(Y.nex[t]);  // (the literal version reads every exon list from the arrays)
+    const uint32_t xw = Y.nex[t], nex = yd_nex_count(xw);
+    // the item's exons: in the groups' arrays, or (one exon; the exact two-exon shape) said by the item itself
+    uint32_t ls[2] = {it.y, 0u}, le[2] = {it.z, it.z};
+    if (yd_nex_x2(xw)) {
+      le[0] = it.y + yd_x2_a(xw) - 1u;
+      ls[1] = le[0] + yd_x2_g(xw) + 1u;
+    }
+    const bool far = yd_nex_far(xw);
+    const uint32_t xo = far ? Y.xo_of(it, v.group(t)) : 0u;
+    const uint32_t* const pxs = far ? ex_s + xo : ls;
+    const uint32_t* const pxe = far ? ex_e + xo : le;
     int d;
     if (last_pos == rstart) {  // :225-228
-      yd_merge_read(ex_s + xo, ex_e + xo, nex, N, head, alloc);
+      yd_merge_read(pxs, pxe, nex, N, head, alloc);
       d = last_dist;
     } else {
       d = 0;
@@ -1179,7 +1193,7 @@ __global__ void yd_run_k(const uint32_t* __restrict__ ids, const uint32_t* __res
       }
       last_pos = rstart;
       last_dist = d;
-      yd_merge_read(ex_s + xo, ex_e + xo, nex, N, head, alloc);
+      yd_merge_read(pxs, pxe, nex, N, head, alloc);
     }
     if (yd_d)
       yd_d[t] = d > 0 ? (uint32_t)d : 0u;
@@ -1833,6 +1847,10 @@ __global__ __launch_bounds__(512) void yd_lgather_k(uint32_t ng, uint32_t ntiles
   }
 }
 
+// TIED_ONLY: the compaction pass of the window path has written every group at its key-order place (WgDirectOut), which is its output
+// place unless it belongs to a tie set of several groups (tie[] marks the set heads): only those are written here, from the
+// accumulators, through the set's permutation — one byte per group read for the rest.
+template <bool TIED_ONLY>
 __global__ void col_write_k(const uint64_t* __restrict__ png, const uint32_t* __restrict__ gperm, GroupAcc G,
                             const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo, uint32_t cap,
                             uint32_t* __restrict__ rep, double* __restrict__ yc, int64_t* __restrict__ yx,
@@ -1841,6 +1859,9 @@ __global__ void col_write_k(const uint64_t* __restrict__ png, const uint32_t* __
   const uint32_t ng = (uint32_t)*png;
   uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= ng || o >= cap) return;
+  if constexpr (TIED_ONLY) {
+    if (G.tie[o] && (o + 1 >= ng || G.tie[o + 1])) return;  // a set of one: already in place
+  }
   uint32_t sg = gperm[o];
   rep[o] = (uint32_t)(G.rep[sg] & 0xFFFFFFFFull);
   if (rep_effend) rep_effend[o] = effend ? effend[rep[o]] : (int32_t)(uint32_t)(G.rep[sg] >> 32);
@@ -2056,8 +2077,16 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       const uint32_t n_long = hc[0], n_lane = nchains - n_long;
       // lane chains and wave chains are independent: the few long, latency-bound waves go to the auxiliary stream beside the lane
       // kernel.  (The stream was synchronised just above, so the fork needs no event; the join does.)
-      hipStream_t aux = n_lane && n_long ? tbk_aux_stream(ctx) : nullptr;
-      if (n_long) {
+      const bool literal = ctx->dbg.yd_literal;  // test hook: the literal machine runs every chain
+      if (literal) {
+        if (n_long) TBK_HIP(hipMemcpyAsync(ids_over, ids_long, (size_t)n_long * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        if (n_lane) TBK_HIP(hipMemcpyAsync(ids_over + n_long, ids_lane, (size_t)n_lane * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        hc[1] = nchains;
+        TBK_HIP(hipMemcpyAsync(n_over, hc + 1, sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        TBK_HIP(hipStreamSynchronize(ctx->stream));  // (hc is reused)
+      }
+      hipStream_t aux = n_lane && n_long && !literal ? tbk_aux_stream(ctx) : nullptr;
+      if (n_long && !literal) {
         hipStream_t keep = ctx->stream;
         if (aux) ctx->stream = aux;
         TBK_LAUNCH(ctx, "yd_wave", yd_wave_k, n_long, 64, 0, ids_long, n_wave, nchains, nit, chain_first, Y, YdWords{iv, io}, noff, ex_s, ex_e, J.g_yd,
@@ -2065,7 +2094,7 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
         ctx->stream = keep;
         if (aux) TBK_HIP(hipEventRecord(ctx->aux_done, aux));
       }
-      if (n_lane)
+      if (n_lane && !literal)
         TBK_LAUNCH(ctx, "yd_lane", yd_lane_k<8>, cdiv(n_lane, 64), 64, 0, ids_lane, n_lane, nchains, nit, chain_first, Y, YdWords{iv, io}, ex_s, ex_e, J.g_yd,
                    yd_d, ids_over, n_over);
       if (n_long && aux) TBK_HIP(hipStreamWaitEvent(ctx->stream, ctx->aux_done, 0));
@@ -2270,8 +2299,16 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
     if (use_raw && use_win) {
       uint32_t eb = 0;
       WgOut wo;
+      // (the compaction pass writes the results at their key-order places; col_write_k below only rewrites the members of tie sets)
+      WgDirectOut direct;
+      direct.cap = out->cap_groups;
+      direct.rep = out->rep, direct.yc = out->yc, direct.yx = out->yx;
+      direct.g_start = out->g_start, direct.g_end = out->g_end, direct.rep_effend = out->rep_effend, direct.g_key = out->g_key;
+      direct.strategy = O.strategy;
+      const bool direct_on = out->rep && out->yc && out->yx;
+      if (!direct_on) direct.rep = nullptr;
       TBK_TRY(tbk_window_groups(ctx, I, O.strategy, nullptr, nullptr, nullptr, nullptr, n, I.file_off, nullptr, nullptr, out->rec_group != nullptr,
-                                O.seed, &wo, &eb, &O, part));
+                                O.seed, &wo, &eb, &O, part, &direct));
       if (eb & (TBK_DERR_RAWORDER | TBK_DERR_BIGBUCKET | TBK_DERR_FRACTIONAL)) {  // not this path's kind of input (the general front end
         TBK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));     // decides what is an error), or a pile-up beyond the
         use_raw = false;                                                            // group table
@@ -2309,8 +2346,12 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
       TBK_LAUNCH(ctx, "col_tie_sort", col_tie_sort_k, cdiv(ng, B), B, 0, I, O.strategy, png, wo.gmem, G, gperm, ginv);
       // (effend == nullptr: the effective end of the representative — or the low word of its explicit priority — rides in the
       // high word of G.rep)
-      TBK_LAUNCH(ctx, "col_write", col_write_k, cdiv(ng, B), B, 0, png, gperm, G, wo.ghi, wo.glo, out->cap_groups, out->rep, out->yc,
-                 out->yx, out->g_start, out->g_end, (const int32_t*)nullptr, out->rep_effend, out->g_key, O.strategy);
+      if (direct_on)
+        TBK_LAUNCH(ctx, "col_write", col_write_k<true>, cdiv(ng, B), B, 0, png, gperm, G, wo.ghi, wo.glo, out->cap_groups, out->rep, out->yc,
+                   out->yx, out->g_start, out->g_end, (const int32_t*)nullptr, out->rep_effend, out->g_key, O.strategy);
+      else
+        TBK_LAUNCH(ctx, "col_write", col_write_k<false>, cdiv(ng, B), B, 0, png, gperm, G, wo.ghi, wo.glo, out->cap_groups, out->rep, out->yc,
+                   out->yx, out->g_start, out->g_end, (const int32_t*)nullptr, out->rep_effend, out->g_key, O.strategy);
       if (out->rec_group) TBK_LAUNCH(ctx, "col_recgroup", col_recgroup_w_k, cdiv(n, B), B, 0, n, wo.rec_sg, ginv, out->rec_group);
       TBK_TRY(tbk_sync_err(ctx, &eb));
       if (eb & TBK_DERR_COLLISION) {  // (the verification pass, wg_finish_raw_k): reseed
@@ -2381,7 +2422,7 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
       if (!(!wo.pgrp || tbk_yd_by_list(ctx, I.k))) TBK_HIP(hipMemsetAsync(g_yd, 0, (size_t)ng * 4, ctx->stream));
       const uint64_t* png = sc + 1;  // (tbk_window_groups left the group count there)
       TBK_LAUNCH(ctx, "col_tie_sort", col_tie_sort_k, cdiv(ng, B), B, 0, I, O.strategy, png, wo.gmem, G, gperm, ginv);
-      TBK_LAUNCH(ctx, "col_write", col_write_k, cdiv(ng, B), B, 0, png, gperm, G, wo.ghi, wo.glo, out->cap_groups, out->rep, out->yc,
+      TBK_LAUNCH(ctx, "col_write", col_write_k<false>, cdiv(ng, B), B, 0, png, gperm, G, wo.ghi, wo.glo, out->cap_groups, out->rep, out->yc,
                  out->yx, out->g_start, out->g_end, effend, out->rep_effend, out->g_key, O.strategy);
       if (out->rec_group) TBK_LAUNCH(ctx, "col_recgroup", col_recgroup_w_k, cdiv(n, B), B, 0, n, wo.rec_sg, ginv, out->rec_group);
       TBK_TRY(tbk_sync_err(ctx, &eb));
@@ -2487,7 +2528,7 @@ int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_
         TBK_LAUNCH(ctx, "ord_sum", ord_sum_k, cdiv(ng, 64), 64, 0, I, O, ng, m, ob.val, fidx, fh_by_rec, G);
       }
     }
-    TBK_LAUNCH(ctx, "col_write", col_write_k, cdiv(ng_hi, B), B, 0, png, gperm, G, s2.hi, s2.lo, out->cap_groups, out->rep, out->yc,
+    TBK_LAUNCH(ctx, "col_write", col_write_k<false>, cdiv(ng_hi, B), B, 0, png, gperm, G, s2.hi, s2.lo, out->cap_groups, out->rep, out->yc,
                out->yx, out->g_start, out->g_end, effend, out->rep_effend, out->g_key, O.strategy);
     if (out->rec_group) TBK_LAUNCH(ctx, "col_recgroup", col_recgroup_k, cdiv(m_hi, B), B, 0, pm, s2.val, sgid, ginv, out->rec_group);
     TBK_TRY(tbk_sync_err(ctx, &eb));

@@ -367,6 +367,7 @@ void tbk_debug_parse(const char* spec, TbkDebug* out) {
     else if (k == "yd_wave_min") out->yd_wave_min = (uint32_t)u;
     else if (k == "yd_bgrid") out->yd_bgrid = (uint32_t)u;
     else if (k == "yd_radix") out->yd_radix = on;
+    else if (k == "yd_literal") out->yd_literal = on;
     else if (k == "yd_own_arena") out->yd_own_arena = on;
     else if (k == "wg_dense_verify") out->wg_dense_verify = on;
     else if (k == "wg_rank_merge") out->wg_rank_merge = on;

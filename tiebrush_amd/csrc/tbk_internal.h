@@ -94,6 +94,7 @@ struct TbkDebug {
   uint32_t yd_wave_min = 0;   // yd_wave_min=N: chains of N items and more go to yd_wave_k (0: the default split)
   uint32_t yd_bgrid = 0;      // yd_bgrid=N: blocks of the chain bucketing (0: default)
   bool yd_radix = false;      // yd_radix=1: the YD items through the stable radix split for any tile
+  bool yd_literal = false;    // yd_literal=1: every chain through yd_run_k, the literal list machine (normally the lists that outgrow the others)
   bool yd_own_arena = false;  // yd_own_arena=1: a deferred YD stage never borrows the main arena
   bool wg_dense_verify = false, wg_rank_merge = false;  // window path: per-record verification form; merge-sort ranking of a window's groups
   bool cov_legacy = false, cov_bundle_scan = false, cov_prep = false, junc_radix = false, no_junc_agg = false;

@@ -23,6 +23,19 @@ struct WgOut {
   uint8_t* tie = nullptr;
 };
 
+// The caller's result arrays (tbk_groups_out), for the compaction pass to fill in key order — which IS the output order except inside
+// a tie set (groups that share bucket, strand and end: the reference comparator orders those, col_tie_sort_k), so the collapse only
+// rewrites the members of tie sets afterwards (col_write_k<tied only>) instead of reading every group's accumulators back.
+struct WgDirectOut {
+  uint32_t cap = 0;  // entries the arrays hold (a tile with more groups is refused by the caller: nothing beyond cap is written)
+  uint32_t* rep = nullptr;
+  double* yc = nullptr;
+  int64_t* yx = nullptr;
+  int32_t *g_start = nullptr, *g_end = nullptr, *rep_effend = nullptr;
+  uint64_t* g_key = nullptr;
+  int strategy = 0;
+};
+
 // chi / clo / cval: the compacted passing records (k runs, run f = [run_off[f], run_off[f+1]), device offsets), m of them (host
 // value); ceff: the effective end of the k-way merge of every compacted record (or, for cross-rank tiles, the low word of the
 // explicit merge priority); scratch_hi / scratch_lo: two dead 8-byte-per-record arrays (>= m) to work in.
@@ -31,7 +44,8 @@ struct WgOut {
 // the caller's next read-back must treat it as a reseed request.
 int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const uint64_t* chi, const uint64_t* clo, const uint32_t* cval,
                       const uint32_t* ceff, uint32_t m, const uint32_t* d_run_off, uint64_t* scratch_hi, uint64_t* scratch_lo,
-                      bool want_rec_sg, uint64_t seed, WgOut* out, uint32_t* err_bits, const tbkd::ColOpt* raw_opt = nullptr, bool part = false);
+                      bool want_rec_sg, uint64_t seed, WgOut* out, uint32_t* err_bits, const tbkd::ColOpt* raw_opt = nullptr, bool part = false,
+                      const WgDirectOut* direct = nullptr /* RAW only */);
 // raw_opt != nullptr — RAW mode: the windows are cut on the input records themselves (chi .. ceff and the scratch arrays are
 // unused and may be null, m = I.n, d_run_off = I.file_off on the device); keys, the filter and the effective ends are computed
 // inside the window kernels, the number of passing records is added to ctx->d_scalars[0] (zeroed by the caller).

@@ -1809,6 +1809,7 @@ struct WgFinal {
   double* yc;
   long long *yxin, *ydin;
   unsigned long long* rep;
+  WgDirectOut D;  // (rep == nullptr: the caller writes its results itself)
 };
 __global__ __launch_bounds__(256) void wg_compact_k(uint32_t nw, WgTemp T, const uint32_t* __restrict__ gbase, const uint32_t* __restrict__ pbase,
                                                    WgFinal F) {
@@ -1841,6 +1842,25 @@ __global__ __launch_bounds__(256) void wg_compact_k(uint32_t nw, WgTemp T, const
       F.ydin[sg] = (long long)yd;
     }
     F.first[sg] = sg;
+    if (F.D.rep && sg < F.D.cap) {  // the caller's results in key order (col_write_k's lines; it rewrites the members of tie sets)
+      const int32_t st = (int32_t)(uint32_t)((hi >> 2) & 0x7FFFFFFFull);
+      F.D.rep[sg] = (uint32_t)(r & 0xFFFFFFFFull);
+      if (F.D.rep_effend) F.D.rep_effend[sg] = (int32_t)(uint32_t)(r >> 32);
+      F.D.yc[sg] = (double)cnt;
+      F.D.yx[sg] = (F.yxin ? (int64_t)yx : 0ll) + (int64_t)nsv;
+      if (F.D.g_start) F.D.g_start[sg] = st;
+      if (F.D.g_end) F.D.g_end[sg] = st + (int32_t)(uint32_t)(lo >> 32) - 1;
+      if (F.D.g_key) {
+        const uint32_t h32 = (uint32_t)lo;
+        uint32_t shape = 0;
+        if (F.D.strategy == TBK_STRAT_CIGAR || F.D.strategy == TBK_STRAT_CLIP) {  // (-E codes speak of exons, which may hold I and D)
+          if (h32 == (0x80000000u | C_M)) shape = 0x80000000u;
+          if ((h32 >> 30) == 3u) shape = h32;
+        }
+        F.D.g_key[2 * (size_t)sg] = hi;
+        F.D.g_key[2 * (size_t)sg + 1] = (lo & 0xFFFFFFFF00000000ull) | shape;
+      }
+    }
     if (F.fmask) F.fmask[sg] = fm;
     if (!F.fmask) F.gpoff[sg] = pb + po;  // (file masks: no incidence list to point into)
     if (F.slot2sg) F.slot2sg[wb + g] = sg;
@@ -2246,7 +2266,8 @@ int tbk_partial_reduce_device(tbk_ctx* ctx, int strategy, const int32_t* rows, u
 
 int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const uint64_t* chi, const uint64_t* clo, const uint32_t* cval,
                       const uint32_t* ceff, uint32_t m, const uint32_t* d_run_off, uint64_t* scratch_hi, uint64_t* scratch_lo,
-                      bool want_rec_sg, uint64_t seed, WgOut* out, uint32_t* err_bits, const tbkd::ColOpt* raw_opt, bool part) {
+                      bool want_rec_sg, uint64_t seed, WgOut* out, uint32_t* err_bits, const tbkd::ColOpt* raw_opt, bool part,
+                      const WgDirectOut* direct) {
   const uint32_t k = I.k;
   const uint32_t B = 256;
   *err_bits = 0;
@@ -2500,7 +2521,7 @@ int tbk_window_groups(tbk_ctx* ctx, const tbkd::ColIn& I, int strategy, const ui
   if (!out->tie || (want_rec_sg && !out->rec_sg)) return TBK_ENOMEM;
   if (ng) {
     WgFinal F{out->gfmask, out->ghi, out->glo, out->gmem, out->gpoff, out->pgrp, out->first, out->ns, slot2sg, out->pfile, out->yc, out->yxin,
-              out->ydin, out->rep};
+              out->ydin, out->rep, (raw && direct) ? *direct : WgDirectOut{}};
     TBK_LAUNCH(ctx, "wg_compact", wg_compact_k, cdiv(nw, 4u), 256, 0, nw, T, gbase, pbase, F);
     TBK_LAUNCH(ctx, "wg_tie", wg_tie_k, cdiv(ng, B), B, 0, ng, out->ghi, out->glo, out->tie);
     if (want_rec_sg) TBK_HIP(hipMemsetAsync(out->rec_sg, 0xFF, (size_t)I.n * 4, ctx->stream));  // (records that did not pass)
