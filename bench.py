@@ -739,12 +739,13 @@ def main():
         if scaling == "strong" and world > 1:
             # the N = 1 end of this fixed job, recorded on an MI355X (profiles/: a run of `--gpus 1 --profile c4 --scaling strong`): the
             # default N = 1 line is config 3, another workload, so a scaling efficiency has to be read against THIS figure
-            ref = os.path.join(ROOT, "profiles", "r4_bench_%s_strong_n1.json" % profile)
+            refs = [os.path.join(ROOT, "profiles", "r%d_bench_%s_strong_n1.json" % (r_, profile)) for r_ in (6, 5, 4)]   # (the newest recorded)
+            ref = next((r_ for r_ in refs if os.path.exists(r_)), refs[-1])
             if os.path.exists(ref) and job_files == STRONG_JOB_FILES[profile] and reads == WORKLOADS[profile][1]:
                 try:
                     r1 = json.loads(open(ref).read().strip().splitlines()[-1])
                     line["strong_scaling_n1_reference"] = {"value": r1["value"], "ms_per_step": r1["ms_per_step"], "workload": r1["config"]["workload"],
-                                                           "source": "profiles/r4_bench_%s_strong_n1.json (recorded, not measured in this run)" % profile,
+                                                           "source": "profiles/%s (recorded, not measured in this run)" % os.path.basename(ref),
                                                            "speedup_vs_n1": round(line["value"] / r1["value"], 3)}
                 except Exception:
                     pass

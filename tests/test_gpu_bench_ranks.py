@@ -59,6 +59,17 @@ def test_bench_default_line_contract_small():
     assert c["parallel"]["cores"] >= 2 and c["parallel"]["value"] > 0
     rc = d["roofline_coverage"]
     assert rc["launches_measured"] >= 10 and rc["launch_us_min"] <= rc["avg_launch_us"] <= rc["launch_us_max"]
+    # SURVEY.md §8(d)'s two kernel-path figures at the top level, the link's own roofline beside the second
+    assert d["value_resident"] == d["value"] and d["value_host_to_host"] == d["kernel_path_host_to_host"]["value"] > 0
+    rl = d["roofline_link"]
+    assert rl["bound"] == "pcie" and rl["peak"] > 0 and 0 < rl["frac"] <= 1.05 and rl["bytes_per_step"] > 0
+    assert set(d["value_definitions"]) >= {"value", "value_host_to_host"}
+    # the files -> files CPU path on the SEQ / QUAL leg's own files: one pinned core, and tiewrap-style processes
+    ce = c["end_to_end"]
+    assert "error" not in ce, ce
+    assert ce["cores"] == 1 and ce["value"] > 0 and "tb_cpu_e2e:" in ce["phases"][0] and "end_to_end_seq" in ce["beside"]
+    assert ce["parallel"]["value"] > 0 and ce["parallel"]["cores"] >= 2 and "tiewrap" in ce["parallel"]["mode"]
+    assert "cpu_baseline" not in es                                     # (moved under cpu_baseline, not left in the leg)
 
 
 def test_bench_starts_its_own_ranks():
