@@ -1024,7 +1024,7 @@ void tbk_stager_free(tbk_ctx* ctx) {
   Stager* S = (Stager*)ctx->stager;
   if (!S) return;
   for (int i = 0; i < Stager::T * Stager::PER; ++i) {
-    if (S->pin[i]) (void)hipHostFree(S->pin[i]);
+    if (S->pin[i]) tbk_host_free(S->pin[i]);
     if (S->ev[i]) (void)hipEventDestroy(S->ev[i]);
   }
   if (S->done) (void)hipEventDestroy(S->done);
@@ -1038,7 +1038,7 @@ static Stager* stager_get(tbk_ctx* ctx) {
   Stager* S = new Stager();
   bool ok = hipStreamCreateWithFlags(&S->up, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&S->done, hipEventDisableTiming) == hipSuccess;
   for (int i = 0; ok && i < Stager::T * Stager::PER; ++i)
-    ok = hipHostMalloc((void**)&S->pin[i], Stager::S, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&S->ev[i], hipEventDisableTiming) == hipSuccess;
+    ok = tbk_host_alloc(Stager::S, (void**)&S->pin[i]) == 0 && hipEventCreateWithFlags(&S->ev[i], hipEventDisableTiming) == hipSuccess;  // (huge pages + registration: tbk_api.hip)
   ctx->stager = S;
   if (!ok) {
     (void)hipGetLastError();
