@@ -39,7 +39,7 @@ def bam_loader():
 def _native_built():
     """Everything native is built in-tree (and travels with the snapshot); build it when a fresh checkout lacks it."""
     need = [os.path.join(ROOT, "tiebrush_amd", "_build", n) for n in ("libtbk.so", "tiebrush", "tiecov", "tbh_tool")]
-    need.append(os.path.join(ROOT, "oracle", "_build", "libtb_oracle.so"))
+    need += [os.path.join(ROOT, "oracle", "_build", n) for n in ("libtb_oracle.so", "tb_cpu_e2e")]
     if not all(os.path.exists(p) for p in need):
         import __graft_entry__ as g
         g.build()
