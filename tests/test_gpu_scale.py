@@ -222,6 +222,20 @@ def test_properties_config4_full_256x2M_one_gpu(ctx):
     torch.cuda.empty_cache()
 
 
+def test_properties_config5_1024_files_one_job(ctx):
+    """BASELINE.json configs[4] as ONE job on one GPU: all 1024 input files in one tile (the window path's widest form: 1024 pieces per
+    window, incidence lists, the radix-split YD items), `--exon -N 5 -Q 1`, at 1024 x 250 k = 256 M records — a quarter of the config's
+    1 M reads per file: the full 1.02 G records are inside the raw window path's 2^30-record bound but their 2.9 G CIGAR words are beyond
+    its 2^30-word bound (the eight ranks of the config hold 128 files x 1 M each: the per-rank test above)."""
+    import torch
+    from tiebrush_amd import synth_dev
+    tile = synth_dev.make_tile_device(1024, 250_000, "c5", device="cuda:0")
+    g, ni = _properties(ctx, tile, strategy="exon", max_nh=5, min_qual=1)
+    assert 0 < g < tile.n_records
+    del tile
+    torch.cuda.empty_cache()
+
+
 def test_device_generator_matches_host_model(ctx):
     """synth_dev on the GPU == synth_dev on the CPU (counter-based integer stream), and the tile is oracle-exact."""
     from tiebrush_amd import synth_dev
