@@ -17,7 +17,7 @@ print("generated", len(paths), "files in %.1f s" % (time.time() - t0), sum(os.pa
 PY
 for i in 1; do
   S=$(date +%s.%N)
-  TBK_TIMING=1 tiebrush_amd/_build/tiebrush -o $D/out.bam $D/in*.bam 2> $D/err.txt
+  TBK_TIMING=2 tiebrush_amd/_build/tiebrush -o $D/out.bam $D/in*.bam 2> $D/err.txt
   E=$(date +%s.%N)
   grep -E "hybrid path|writer closed|device writer|written as|released" $D/err.txt
   python3 -c "print('wall %.3f s' % ($E - $S))"
