@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TBK_ABI_VERSION 7
+#define TBK_ABI_VERSION 8
 
 typedef struct tbk_ctx tbk_ctx;
 
@@ -60,7 +60,11 @@ typedef enum tbk_strategy {
   TBK_STRAT_EXON = 3   /* -E: same exon coordinates                 (cmpExons     :334-345) */
 } tbk_strategy;
 
-typedef enum tbk_mem { TBK_MEM_HOST = 0, TBK_MEM_DEVICE = 1 } tbk_mem;
+typedef enum tbk_mem {
+  TBK_MEM_HOST = 0,
+  TBK_MEM_DEVICE = 1,
+  TBK_MEM_KEPT = 2 /* (ABI version 8) tbk_enc_in only: the results the context kept from its last collapse (tbk_collapse_opts.keep_results) */
+} tbk_mem;
 
 #define TBK_NH_ABSENT INT32_MIN /* record has no NH tag */
 
@@ -78,7 +82,13 @@ typedef struct tbk_collapse_opts {
   uint8_t defer_yd;           /* TBK_MEM_DEVICE only: return as soon as rep/yc/yx/coordinates are final and compute
                                  the YD column on a side stream; tbk_collapse_finish_yd() completes out->yd.  Lets
                                  the caller overlap the (YD-independent) tiecov chain with the YD list machine.   */
-  uint8_t reserved[2];
+  uint8_t keep_results;       /* (ABI version 8; was reserved, 0) the context keeps a device copy of the call's rep / yc / yx / yd until its
+                                 next tbk_collapse_tile: tbk_bam_encode reads them there (tbk_enc_in.mem = TBK_MEM_KEPT) and
+                                 tbk_kept_results hands any range of them out.  With it a TBK_MEM_HOST caller may leave out->rep / yc /
+                                 yx / yd NULL: what the output side needs on the host is `rep` (to gather the records it decoded
+                                 itself) — fetched with tbk_kept_results once n_groups says how long it is —, the tags' values never
+                                 cross the link.  Not with defer_yd.                                                            */
+  uint8_t reserved[1];
 } tbk_collapse_opts;
 
 /* One tile of decoded records, file-major: records of input file f occupy
@@ -225,6 +235,10 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
 /* Waits for a deferred YD stage (no-op when none is pending); returns its status.  The arrays of the deferred call's
  * tbk_soa_in / tbk_groups_out must stay alive until then.  Implied by the next tbk_collapse_tile and by tbk_destroy. */
 int tbk_collapse_finish_yd(tbk_ctx* ctx);
+/* (ABI version 8) Optional.  Pays what a context's first tbk_collapse_tile otherwise pays inside the call, beyond its kernels: the
+ * auxiliary stream of the YD stage (a hardware queue) and the first dispatch of its list machines.  A command line calls it on the
+ * thread that brings the device up, beside its decode; a long-lived caller never needs it. */
+int tbk_warmup(tbk_ctx* ctx);
 int tbk_coverage_tile(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out);
 int tbk_sample_tile(tbk_ctx* ctx, const tbk_cov_in* in, int32_t num_samples, tbk_sample_out* out);
 
@@ -295,6 +309,8 @@ typedef struct tbk_enc_in {
   const uint8_t* host_blob;  /* HOST: their raw records (block_size field first, as in the BAM stream), packed       */
   const uint64_t* host_off;  /* HOST [n_host + 1]: byte offsets into host_blob                                       */
   const uint32_t* host_slot; /* HOST [n]: for a group whose rep >= n_dev, its record's index in host_off (others ignored) */
+  uint32_t first;            /* (ABI version 8) mem == TBK_MEM_KEPT: the records are groups [first, first + n) of the kept results; rep /
+                                yc / yx / yd are not read (a caller that gathers host records still needs its own copy of rep)  */
 } tbk_enc_in;
 /* Tag, frame (block_size) and BGZF-deflate the n records on the device: `out` (HOST) receives a run of whole members — every member
  * begins with a record, as htslib cuts them — that a BAM writer appends behind its header; the EOF member is the caller's.
@@ -302,6 +318,10 @@ typedef struct tbk_enc_in {
  * *out_bytes set) when out_cap is too small; TBK_EUNSUPPORTED when a record is nearly as long as a member (the caller's host
  * writer takes such an output); TBK_EINVAL for a malformed record. */
 int tbk_bam_encode(tbk_ctx* ctx, const tbk_enc_in* in, uint8_t* out, uint64_t out_cap, uint64_t* out_bytes, uint64_t* payload_bytes);
+/* (ABI version 8) Groups [first, first + n) of the results kept by the last tbk_collapse_tile with keep_results, into HOST arrays (any
+ * of them may be NULL) — what a caller whose device writer refused a chunk needs for its host writer (flushPData's tag values,
+ * tiebrush.cpp:506-525).  TBK_EINVAL when nothing is kept or the range ends behind the kept groups. */
+int tbk_kept_results(tbk_ctx* ctx, uint32_t first, uint32_t n, uint32_t* rep, double* yc, int64_t* yx, int32_t* yd);
 
 /* ---- Packed wire form of a tile (ABI version 5) ---------------------------------------------------------------------------
  * What a host decoder can hand over instead of tbk_soa_in when the tile has to cross PCIe: the same records in 9 bytes plus the

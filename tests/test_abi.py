@@ -25,7 +25,7 @@ def test_library_loads_and_exports_every_symbol():
         import __graft_entry__ as g
         g.build()
     L = _lib.load()
-    assert L.tbk_abi_version() == 7
+    assert L.tbk_abi_version() == 8
     for s in _declared_symbols():
         assert hasattr(L, s), s
     assert L.tbk_strerror(-7).decode().startswith("unknown opcode")

@@ -192,3 +192,96 @@ def test_bad_split_arguments_are_refused_not_faulted(ctx):
     # the context is still usable
     run, _ = ctx.bam_encode(np.array([0], np.uint32), [1.0], [1], [0], n_dev=0, host_records={0: r0})
     assert len(run) > 0
+
+
+@pytest.mark.parametrize("case", ["t1", "t12"])
+def test_kept_results_feed_the_encoder(ctx, case):
+    """tbk_collapse_opts.keep_results (ABI 8): the context keeps the call's rep / yc / yx / yd on the device; tbk_bam_encode with
+    TBK_MEM_KEPT reads any range of them there and writes the bytes it writes from the caller's arrays; tbk_kept_results hands them out"""
+    from tiebrush_amd.api import TbkError
+    if case == "t12":
+        names, tb = ["t1/t1.bam", "t2/t2.bam"], [1, 1]
+    else:
+        names, tb = [os.path.relpath(p, GOLDEN) for p in sample_paths(case)], [0] * 10
+    s, rep, yc, yx, yd = _golden_case(ctx, names, tb, keep_results=True)
+    m, n_dev = len(rep), int(s.n_records)
+    assert m > 40
+    want, pay = ctx.bam_encode(rep, yc, yx, yd, n_dev=n_dev)
+    got, pay_k = ctx.bam_encode(rep, None, None, None, n_dev=n_dev, kept_first=0)
+    assert got == want and pay_k == pay
+    a, b = 7, m - 11                                            # a range in the middle: the writer's later chunks
+    want_mid, _ = ctx.bam_encode(rep[a:b], yc[a:b], yx[a:b], yd[a:b], n_dev=n_dev)
+    got_mid, _ = ctx.bam_encode(rep[a:b], None, None, None, n_dev=n_dev, kept_first=a)
+    assert got_mid == want_mid
+    # host records beside kept tag values (the command line's whole-input host path: rep on the host, the tags on the device)
+    blob, off = ctx.bam_records(rep)
+    recs = {i: blob[int(off[i]) + 4:int(off[i + 1])] for i in range(m)}
+    got_host, _ = ctx.bam_encode(rep, None, None, None, n_dev=0, host_records=recs, kept_first=0)
+    assert gzip.decompress(got_host) == gzip.decompress(want)
+    r2, c2, x2, d2 = ctx.kept_results(0, m)
+    assert np.array_equal(r2, rep) and np.array_equal(c2, yc) and np.array_equal(x2, yx) and np.array_equal(d2, yd)
+    r3, c3, x3, d3 = ctx.kept_results(a, b - a, tags_only=True)
+    assert r3 is None and np.array_equal(c3, yc[a:b]) and np.array_equal(x3, yx[a:b]) and np.array_equal(d3, yd[a:b])
+    with pytest.raises(TbkError):                               # a range that ends behind the kept groups
+        ctx.bam_encode(rep[:5], None, None, None, n_dev=n_dev, kept_first=m - 4)
+    with pytest.raises(TbkError):
+        ctx.kept_results(m - 1, 2)
+    # the next collapse without the option leaves nothing behind
+    g = ctx.collapse_struct(s, len(names))
+    assert g["n_groups"] == m
+    with pytest.raises(TbkError):
+        ctx.bam_encode(rep[:5], None, None, None, n_dev=n_dev, kept_first=0)
+    with pytest.raises(TbkError):
+        ctx.kept_results(0, 1)
+    with pytest.raises(TbkError):                               # the YD column of a deferred stage is not final when the call returns
+        ctx.collapse_struct(s, len(names), keep_results=True, defer_yd=True)
+    ctx.bam_release()
+
+
+def test_keep_results_lets_a_host_caller_leave_the_tag_arrays_out(ctx):
+    """with keep_results a TBK_MEM_HOST caller hands over `rep` only (what the command line's whole-input paths do): n_groups / rep as
+    ever, the values on the device equal to those of an ordinary call; without the option NULL tag arrays stay TBK_EINVAL"""
+    from tiebrush_amd import _lib, synth
+    tile = synth.make_tile(5, 30000, "c2", n_loci=300)
+    ref = ctx.collapse(tile)
+    m = ref["n_groups"]
+    keep = []
+    s, dev, n = ctx._soa_struct(tile, keep)
+    assert not dev
+    rep = np.empty(n, np.uint32)
+    want_rep = np.asarray(ref["rep"]).view(np.uint32)
+    for keep_results, with_rep, want_rc in ((1, 1, 0), (1, 0, 0), (0, 1, -1)):
+        o = ctx.make_opts(keep_results=bool(keep_results))
+        rep[:] = 0xFFFFFFFF
+        g = _lib.GroupsOut(_lib.TBK_MEM_HOST, n, rep.ctypes.data if with_rep else None, None, None, None, None, None, None, None, None, 0, 0)
+        assert ctx.L.tbk_collapse_tile(ctx.h, C.byref(o), C.byref(s), C.byref(g)) == want_rc
+        if want_rc == 0:
+            assert int(g.n_groups) == m
+            if with_rep:
+                assert np.array_equal(rep[:m], want_rep)
+            r2, c2, x2, d2 = ctx.kept_results(0, m)        # (no array at all: `rep` too comes once n_groups is known — the command line's way)
+            assert np.array_equal(r2, want_rep) and np.array_equal(c2, ref["yc"]) and np.array_equal(x2, ref["yx"]) and np.array_equal(d2, ref["yd"])
+
+
+def test_results_of_moderate_size_come_back_through_the_staging_buffer(ctx):
+    """results between 1 and 64 MB an array take the context's page-locked staging buffer and a copy by the core instead of a
+    registration of the caller's array (tbk_api.hip: d2h); TBK_DEBUG no_bounce=1 is the direct way.  Same bytes, any size around the
+    buffer's 8 MB; tbk_kept_results goes the same way; tbk_warmup (the command line's helper thread calls it) changes nothing"""
+    from tiebrush_amd import synth
+    tile = synth.make_tile(8, 400000, "c2", n_loci=200000)
+    a = ctx.collapse(tile, want_rec_group=True)
+    m = a["n_groups"]
+    assert m * 8 > (8 << 20) and m * 4 > (1 << 20)              # yc / yx need two passes of the buffer, rep / yd one
+    assert ctx.L.tbk_warmup(ctx.h) == 0
+    ctx.L.tbk_set_debug(ctx.h, b"no_bounce=1")
+    try:
+        b = ctx.collapse(tile, want_rec_group=True)
+    finally:
+        ctx.L.tbk_set_debug(ctx.h, b"")
+    for k in ("rep", "yc", "yx", "yd", "g_start", "g_end", "rec_group"):
+        assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+    c = ctx.collapse(tile, keep_results=True)
+    r, yc, yx, yd = ctx.kept_results(0, m)
+    assert np.array_equal(r, np.asarray(a["rep"]).view(np.uint32)) and np.array_equal(yc, a["yc"]) and np.array_equal(yx, a["yx"]) and np.array_equal(yd, a["yd"])
+    r, yc, yx, yd = ctx.kept_results(m // 3, m - m // 3 - 5)
+    assert np.array_equal(yx, a["yx"][m // 3:m - 5]) and np.array_equal(r, np.asarray(a["rep"]).view(np.uint32)[m // 3:m - 5])

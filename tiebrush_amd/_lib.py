@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "_build", "libtbk.so")
 
 _P = C.c_void_p
 
-TBK_MEM_HOST, TBK_MEM_DEVICE = 0, 1
+TBK_MEM_HOST, TBK_MEM_DEVICE, TBK_MEM_KEPT = 0, 1, 2
 PARTIAL_BUNDLES = 15
 PARTIAL_CAND = 2 + 2 * PARTIAL_BUNDLES      # include/tbk.h: TBK_PARTIAL_CAND
 PARTIAL_META = 64 + 4                         # TBK_PARTIAL_META
@@ -26,14 +26,14 @@ SYMBOLS = ["tbk_abi_version", "tbk_create", "tbk_destroy", "tbk_strerror", "tbk_
            "tbk_get_stream", "tbk_set_profiling", "tbk_set_debug", "tbk_kernel_times", "tbk_host_alloc", "tbk_host_free",
            "tbk_collapse_opts_default", "tbk_collapse_tile", "tbk_collapse_finish_yd", "tbk_coverage_tile", "tbk_sample_tile",
            "tbk_groups_to_cov_in", "tbk_bgzf_inflate", "tbk_bam_decode", "tbk_bam_records", "tbk_bam_release", "tbk_shard_prepare", "tbk_shard_probe_max", "tbk_shard_probe_next",
-           "tbk_shard_pack", "tbk_shard_unpack", "tbk_partial_keys", "tbk_partial_pack", "tbk_partial_unpack", "tbk_partial_reduce", "tbk_unpack_tile", "tbk_tile_join", "tbk_reserve_tile", "tbk_bgzf_deflate", "tbk_bam_encode", "tbk_partial_stage_keys", "tbk_partial_stage_cands", "tbk_partial_stage_pack",
+           "tbk_shard_pack", "tbk_shard_unpack", "tbk_partial_keys", "tbk_partial_pack", "tbk_partial_unpack", "tbk_partial_reduce", "tbk_unpack_tile", "tbk_tile_join", "tbk_reserve_tile", "tbk_bgzf_deflate", "tbk_bam_encode", "tbk_kept_results", "tbk_warmup", "tbk_partial_stage_keys", "tbk_partial_stage_cands", "tbk_partial_stage_pack",
            "tbk_partial_pack_md", "tbk_partial_unpack_md", "tbk_partial_reduce_md"]
 
 
 class CollapseOpts(C.Structure):
     _fields_ = [("strategy", C.c_int32), ("max_nh", C.c_int32), ("min_qual", C.c_int32), ("flags_mask", C.c_uint32),
                 ("keep_supplementary", C.c_uint8), ("keep_secondary", C.c_uint8), ("keep_unmapped", C.c_uint8),
-                ("collapse_same", C.c_uint8), ("store_frac", C.c_uint8), ("defer_yd", C.c_uint8), ("reserved", C.c_uint8 * 2)]
+                ("collapse_same", C.c_uint8), ("store_frac", C.c_uint8), ("defer_yd", C.c_uint8), ("keep_results", C.c_uint8), ("reserved", C.c_uint8 * 1)]
 
 
 class SoaIn(C.Structure):
@@ -75,7 +75,7 @@ class SampleOut(C.Structure):
 
 class EncIn(C.Structure):
     _fields_ = [("mem", C.c_int32), ("n", C.c_uint32), ("rep", _P), ("yc", _P), ("yx", _P), ("yd", _P), ("n_dev", C.c_uint32), ("n_host", C.c_uint32),
-                ("host_blob", _P), ("host_off", _P), ("host_slot", _P)]
+                ("host_blob", _P), ("host_off", _P), ("host_slot", _P), ("first", C.c_uint32)]
 
 
 class KernelTime(C.Structure):
@@ -155,6 +155,10 @@ def load():
     L.tbk_bgzf_deflate.restype = C.c_int
     L.tbk_bam_encode.argtypes = [_P, C.POINTER(EncIn), _P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.tbk_bam_encode.restype = C.c_int
+    L.tbk_kept_results.argtypes = [_P, C.c_uint32, C.c_uint32, _P, _P, _P, _P]
+    L.tbk_kept_results.restype = C.c_int
+    L.tbk_warmup.argtypes = [_P]
+    L.tbk_warmup.restype = C.c_int
     _lib = L
     return L
 

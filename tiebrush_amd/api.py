@@ -202,7 +202,7 @@ class Context:
     # ---- collapse -----------------------------------------------------------------------------
     def make_opts(self, strategy="cigar", max_nh=2**31 - 1, min_qual=-1, keep_supplementary=False,
                   keep_secondary=False, keep_unmapped=False, collapse_same=False, store_frac=False, flags_mask=0,
-                  defer_yd=False):
+                  defer_yd=False, keep_results=False):
         o = _lib.CollapseOpts()
         self.L.tbk_collapse_opts_default(C.byref(o))
         o.strategy = _lib.STRAT[strategy] if isinstance(strategy, str) else int(strategy)
@@ -210,6 +210,7 @@ class Context:
         o.keep_supplementary, o.keep_secondary = int(keep_supplementary), int(keep_secondary)
         o.keep_unmapped, o.collapse_same, o.store_frac = int(keep_unmapped), int(collapse_same), int(store_frac)
         o.defer_yd = int(defer_yd)
+        o.keep_results = int(keep_results)
         return o
 
     def finish_yd(self):
@@ -364,16 +365,27 @@ class Context:
         self._check(rc, "tbk_bgzf_deflate")
         return out[:int(need.value)].tobytes()
 
-    def bam_encode(self, rep, yc, yx, yd, n_dev=0, host_records=None):
+    def kept_results(self, first, n, tags_only=False):
+        """tbk_kept_results: groups [first, first + n) of the results the last collapse(..., keep_results=True) left on the context"""
+        rep, yc, yx, yd = np.empty(n, np.uint32), np.empty(n, np.float64), np.empty(n, np.int64), np.empty(n, np.int32)
+        self._check(self.L.tbk_kept_results(self.h, first, n, None if tags_only else rep.ctypes.data, yc.ctypes.data, yx.ctypes.data, yd.ctypes.data),
+                    "tbk_kept_results")
+        return (None if tags_only else rep), yc, yx, yd
+
+    def bam_encode(self, rep, yc, yx, yd, n_dev=0, host_records=None, kept_first=None):
         """tbk_bam_encode: the output records of a collapse -> (run of BGZF members, payload bytes).  rep < n_dev: records of the tile
-        bam_decode left on this context; the others come from host_records = {group index: raw record bytes WITHOUT block_size}"""
+        bam_decode left on this context; the others come from host_records = {group index: raw record bytes WITHOUT block_size}.
+        kept_first: the len(rep) groups from that index on of the results the context kept (keep_results): rep / yc / yx / yd are not handed over"""
         rep = np.ascontiguousarray(rep, dtype=np.uint32)
         n = len(rep)
-        yc = np.ascontiguousarray(yc, dtype=np.float64)
-        yx = np.ascontiguousarray(yx, dtype=np.int64)
-        yd = np.ascontiguousarray(yd, dtype=np.int32)
         e = _lib.EncIn()
-        e.mem, e.n, e.rep, e.yc, e.yx, e.yd, e.n_dev = _lib.TBK_MEM_HOST, n, rep.ctypes.data, yc.ctypes.data, yx.ctypes.data, yd.ctypes.data, n_dev
+        if kept_first is None:
+            yc = np.ascontiguousarray(yc, dtype=np.float64)
+            yx = np.ascontiguousarray(yx, dtype=np.int64)
+            yd = np.ascontiguousarray(yd, dtype=np.int32)
+            e.mem, e.n, e.rep, e.yc, e.yx, e.yd, e.n_dev = _lib.TBK_MEM_HOST, n, rep.ctypes.data, yc.ctypes.data, yx.ctypes.data, yd.ctypes.data, n_dev
+        else:
+            e.mem, e.n, e.n_dev, e.first = _lib.TBK_MEM_KEPT, n, n_dev, int(kept_first)
         keep = []
         if host_records:
             slot = np.zeros(n, dtype=np.uint32)

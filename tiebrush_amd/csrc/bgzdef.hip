@@ -1075,7 +1075,9 @@ extern "C" int tbk_bam_encode(tbk_ctx* ctx, const tbk_enc_in* in, uint8_t* out, 
   if (payload_bytes) *payload_bytes = 0;
   const uint32_t n = in->n;
   if (n == 0) return 0;
-  if (!in->rep || !in->yc || !in->yx || !in->yd) return TBK_EINVAL;
+  const bool kept = in->mem == TBK_MEM_KEPT;  // the columns of the context's last collapse (tbk_collapse_opts.keep_results), read where they lie
+  if (kept ? (!ctx->kept || (uint64_t)in->first + n > ctx->kept_n) : (!in->rep || !in->yc || !in->yx || !in->yd)) return TBK_EINVAL;
+  if (in->mem != TBK_MEM_HOST && in->mem != TBK_MEM_DEVICE && !kept) return TBK_EINVAL;
   if (in->n_host && (!in->host_blob || !in->host_off || !in->host_slot)) return TBK_EINVAL;
   TBK_HIP(hipSetDevice(ctx->device));
   EncSrc S;
@@ -1103,19 +1105,23 @@ extern "C" int tbk_bam_encode(tbk_ctx* ctx, const tbk_enc_in* in, uint8_t* out, 
     gb += al(bytes);
     return r;
   };
-  uint32_t* d_rep = (uint32_t*)take((size_t)n * 4);
-  int32_t* d_yd = (int32_t*)take((size_t)n * 4);
+  const uint32_t* d_rep = (uint32_t*)take((size_t)n * 4);
+  const int32_t* d_yd = (int32_t*)take((size_t)n * 4);
   uint32_t* d_slot = (uint32_t*)take((size_t)n * 4);
-  double* d_yc = (double*)take((size_t)n * 8);
-  int64_t* d_yx = (int64_t*)take((size_t)n * 8);
+  const double* d_yc = (double*)take((size_t)n * 8);
+  const int64_t* d_yx = (int64_t*)take((size_t)n * 8);
   uint32_t* d_olen = (uint32_t*)take(((size_t)n + 1) * 4);
   uint32_t* d_olen2 = (uint32_t*)take(((size_t)n + 1) * 4);
   uint64_t* d_ooff = (uint64_t*)take(((size_t)n + 1) * 8);
-  const hipMemcpyKind kind = in->mem == TBK_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-  TBK_HIP(hipMemcpyAsync(d_rep, in->rep, (size_t)n * 4, kind, st));
-  TBK_HIP(hipMemcpyAsync(d_yd, in->yd, (size_t)n * 4, kind, st));
-  TBK_HIP(hipMemcpyAsync(d_yc, in->yc, (size_t)n * 8, kind, st));
-  TBK_HIP(hipMemcpyAsync(d_yx, in->yx, (size_t)n * 8, kind, st));
+  if (kept) {
+    d_rep = ctx->kept_rep + in->first, d_yd = ctx->kept_yd + in->first, d_yc = ctx->kept_yc + in->first, d_yx = ctx->kept_yx + in->first;
+  } else {
+    const hipMemcpyKind kind = in->mem == TBK_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    TBK_HIP(hipMemcpyAsync((void*)d_rep, in->rep, (size_t)n * 4, kind, st));
+    TBK_HIP(hipMemcpyAsync((void*)d_yd, in->yd, (size_t)n * 4, kind, st));
+    TBK_HIP(hipMemcpyAsync((void*)d_yc, in->yc, (size_t)n * 8, kind, st));
+    TBK_HIP(hipMemcpyAsync((void*)d_yx, in->yx, (size_t)n * 8, kind, st));
+  }
   if (in->n_host) {
     const uint64_t hb = in->host_off[in->n_host];
     uint8_t* blob;

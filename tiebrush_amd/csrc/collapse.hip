@@ -25,6 +25,8 @@
 // of that list, or a chromosome change) into independent chains, one GPU thread each.
 #include <stdlib.h>
 
+#include <chrono>
+
 #include "dev_common.hpp"
 #include "rx_w64.hpp"
 #include "scan_op.hpp"
@@ -1934,6 +1936,11 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
   const ColIn& I = J.I;
   uint64_t* sc = ctx->d_scalars;
   TBK_HIP(hipSetDevice(ctx->device));
+  // (phases=1: the stage's wall time between its read-backs, to stderr)
+  const bool ph = ctx->dbg.phases;
+  const auto p0 = std::chrono::steady_clock::now();
+  auto p1 = p0, p2 = p0, p3 = p0;
+  auto since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
   TBK_HIP(hipMemsetAsync(sc, 0, 32 * sizeof(uint64_t), ctx->stream));
   {
     uint32_t *icnt = nullptr, *ioff = nullptr, *ocnt = nullptr, *ooff = nullptr;
@@ -1978,6 +1985,7 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
     TBK_HIP(hipMemcpyAsync(ctx->h_scalars, sc, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     TBK_HIP(hipStreamSynchronize(ctx->stream));
     nit64 = ctx->h_scalars[2];
+    p1 = p2 = p3 = std::chrono::steady_clock::now();
     if (nit64 >= (1ull << 32)) return TBK_E2BIG;
     const uint32_t nit = (uint32_t)nit64;
     if (nit) {
@@ -2047,6 +2055,7 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       TBK_HIP(hipStreamSynchronize(ctx->stream));
       const uint32_t nchains = (uint32_t)ctx->h_scalars[3];
       const uint64_t nnodes = ctx->h_scalars[4], ngex = ctx->h_scalars[5];
+      p2 = p3 = std::chrono::steady_clock::now();
       if (nnodes >= (1ull << 31)) return TBK_E2BIG;
       SegNodes N;
       N.s = ws_alloc<uint32_t>(ctx, nnodes + 1);
@@ -2075,6 +2084,7 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
       TBK_HIP(hipMemcpyAsync(hc, n_wave, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
       TBK_HIP(hipStreamSynchronize(ctx->stream));
       const uint32_t n_long = hc[0], n_lane = nchains - n_long;
+      p3 = std::chrono::steady_clock::now();
       // lane chains and wave chains are independent: the few long, latency-bound waves go to the auxiliary stream beside the lane
       // kernel.  (The stream was synchronised just above, so the fork needs no event; the join does.)
       const bool literal = ctx->dbg.yd_literal;  // test hook: the literal machine runs every chain
@@ -2105,12 +2115,45 @@ int tbk_collapse_yd_run(tbk_ctx* ctx, void* jobp) {
     if (by_list) {  // the distances lie with the items (no item: every segment is empty): folded per tile of groups, written as YD
       TBK_LAUNCH(ctx, "yd_gather", yd_lgather_k, ys_tiles, 512, 0, ng, ys_tiles, ys_table, ys_totals, yd_d, ys_item, J.gperm, J.G, J.cap, J.out_yd);
       TBK_HIP(hipStreamSynchronize(ctx->stream));
+      if (ph)
+        fprintf(stderr, "YD stage ms: counts %.1f | placement + numbering %.1f | buckets %.1f | list machines + gather %.1f (arena %.2f of %.2f GB, %zu overflow chunks)\n",
+                std::chrono::duration<double, std::milli>(p1 - p0).count(), std::chrono::duration<double, std::milli>(p2 - p1).count(),
+                std::chrono::duration<double, std::milli>(p3 - p2).count(), since(p3), ctx->ws_off / 1e9, ctx->ws_cap / 1e9, ctx->ws_overflow.size());
       return tbk_check_launch(ctx, "collapse_yd");
     }
   }
   TBK_LAUNCH(ctx, "col_write_yd", col_write_yd_k, cdiv(ng, B), B, 0, ng, J.gperm, J.G, J.g_yd, J.cap, J.out_yd);
   TBK_HIP(hipStreamSynchronize(ctx->stream));
   return tbk_check_launch(ctx, "collapse_yd");
+}
+
+// tbk_warmup: what a context's FIRST YD stage pays beyond its kernels — the auxiliary stream (a hardware queue: milliseconds to create)
+// and the first dispatch of each list machine on its queue — paid ahead, with launches that find no work (*nids = 0 / nids = 0).
+int tbk_collapse_warm(tbk_ctx* ctx) {
+  TBK_HIP(hipSetDevice(ctx->device));
+  uint64_t* sc = ctx->d_scalars;
+  TBK_HIP(hipMemsetAsync(sc, 0, 32 * sizeof(uint64_t), ctx->stream));
+  TBK_HIP(hipStreamSynchronize(ctx->stream));
+  uint32_t* z = (uint32_t*)sc;  // zeros: the id list, the counts, chain_first[0]
+  YdItems Y{};
+  Y.pk = (uint4*)sc, Y.nex = z;
+  const YdWords W{nullptr, z};
+  const SegNodes N{z, z, (int32_t*)z};
+  hipStream_t aux = tbk_aux_stream(ctx);
+  if (aux) {
+    hipStream_t keep = ctx->stream;
+    ctx->stream = aux;
+    TBK_LAUNCH(ctx, "yd_wave", yd_wave_k, 1, 64, 0, z, z, 0u, 0u, z, Y, W, z, z, z, (int32_t*)nullptr, z + 8, z + 16, z + 1);
+    ctx->stream = keep;
+    TBK_HIP(hipEventRecord(ctx->aux_done, aux));
+    TBK_HIP(hipStreamWaitEvent(ctx->stream, ctx->aux_done, 0));
+  } else {
+    TBK_LAUNCH(ctx, "yd_wave", yd_wave_k, 1, 64, 0, z, z, 0u, 0u, z, Y, W, z, z, z, (int32_t*)nullptr, z + 8, z + 16, z + 1);
+  }
+  TBK_LAUNCH(ctx, "yd_lane", yd_lane_k<8>, 1, 64, 0, z, 0u, 0u, 0u, z, Y, W, z, z, (int32_t*)nullptr, z + 8, z + 16, z + 1);
+  TBK_LAUNCH(ctx, "yd_run_overflow", yd_run_k, 1, 64, 0, z, z, 0u, 0u, z, Y, W, z, z, z, N, (int32_t*)nullptr, z + 8);
+  TBK_HIP(hipStreamSynchronize(ctx->stream));
+  return tbk_check_launch(ctx, "warmup");
 }
 
 // =============================================================================================================

@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -52,7 +53,8 @@ class DeviceWriter {
     return true;
   }
 
-  // Groups [0, ng) of a collapse (rep / yc / yx / yd: HOST arrays in output order).  Representatives with rep < n_dev are records of
+  // Groups [0, ng) of a collapse (rep / yc / yx / yd: HOST arrays in output order; yc == nullptr: the collapse ran with keep_results and the
+  // tags' values are read on the device, where the context kept them — `rep` is still the host's copy).  Representatives with rep < n_dev are records of
   // the tile tbk_bam_decode left on `ctx`; host_record(g) hands out the others.  Returns false when the device cannot take the
   // output — TBK_EUNSUPPORTED (a record too long for a BGZF member of its own: bgzdef.hip) or TBK_ENOMEM / no pinned memory, on ANY
   // chunk: the chunks before the refused one are written in full and *groups_done says how many groups that was, so the caller's host
@@ -104,6 +106,9 @@ class DeviceWriter {
     const char* force_refuse = getenv("TBK_TEST_DW_REFUSE_CHUNK");  // test hook: chunk k answers TBK_EUNSUPPORTED
     std::vector<uint64_t> zsz(nchunk, 0), psz(nchunk, 0);
     std::vector<uint32_t> nhost(nchunk, 0);
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    double busy_gather = 0, busy_encode = 0, busy_write = 0;  // what each stage spent working (TBK_TIMING: which one paces the pipeline)
     std::thread enc([&]() {
       for (uint32_t k = 0; k < nchunk; ++k) {
         if (!wait_state(k, 1)) return;
@@ -111,13 +116,19 @@ class DeviceWriter {
         const uint32_t g0 = k * kChunkGroups, g1 = std::min(ng, g0 + kChunkGroups);
         tbk_enc_in in;
         memset(&in, 0, sizeof(in));
-        in.mem = TBK_MEM_HOST;
         in.n = g1 - g0;
-        in.rep = rep + g0, in.yc = yc + g0, in.yx = yx + g0, in.yd = yd + g0;
+        if (yc) {
+          in.mem = TBK_MEM_HOST;
+          in.rep = rep + g0, in.yc = yc + g0, in.yx = yx + g0, in.yd = yd + g0;
+        } else {
+          in.mem = TBK_MEM_KEPT;
+          in.first = g0;
+        }
         in.n_dev = n_dev;
         in.n_host = nhost[k];
         in.host_blob = s.blob, in.host_off = s.off.data(), in.host_slot = s.slot.data();
         uint64_t zb = 0, pb = 0;
+        const auto e0 = tnow();
         int rc = (force_refuse && (uint32_t)atol(force_refuse) == k) ? TBK_EUNSUPPORTED : api_.bam_encode(ctx, &in, s.z, s.z_cap, &zb, &pb);
         if (rc == TBK_E2BIG && zb > s.z_cap) {  // (the members of this chunk need a larger buffer: the call said how large)
           if (!grow(s.z, s.z_cap, zb + zb / 8)) rc = TBK_ENOMEM;
@@ -128,6 +139,7 @@ class DeviceWriter {
           return;
         }
         zsz[k] = zb, psz[k] = pb;
+        busy_encode += tms(e0, tnow());
         set_state(k, 2);
       }
     });
@@ -135,7 +147,9 @@ class DeviceWriter {
       for (uint32_t k = 0; k < nchunk; ++k) {
         if (!wait_state(k, 2)) return;
         Slot& s = slot_[k % kSlots];
+        const auto w0 = tnow();
         out.write_members(s.z, (size_t)zsz[k]);
+        busy_write += tms(w0, tnow());
         set_state(k, 3);
       }
     });
@@ -144,6 +158,7 @@ class DeviceWriter {
       if (k >= (uint32_t)kSlots && !wait_state(k - kSlots, 3)) break;  // the slot's previous chunk has left the building
       Slot& s = slot_[k % kSlots];
       const uint32_t g0 = k * kChunkGroups, g1 = std::min(ng, g0 + kChunkGroups), nc = g1 - g0;
+      const auto g_0 = tnow();
       s.slot.resize(nc);
       // pass 1: which groups bring a host record, and how long — per slice of the chunk
       const int T = nc < 8192 ? 1 : nt_;
@@ -190,10 +205,13 @@ class DeviceWriter {
         }
       });
       s.off[nhost[k]] = total;
+      busy_gather += tms(g_0, tnow());
       set_state(k, 1);
     }
     enc.join();
     wr.join();
+    if (getenv("TBK_TIMING"))
+      fprintf(stderr, "device writer stages busy ms: gather %.1f | encode %.1f | write %.1f (%u chunks)\n", busy_gather, busy_encode, busy_write, nchunk);
     if (fail == 2) GError("Error: encoding the output on the GPU failed: %s\n", fail_msg.c_str());
     const uint32_t kdone = fail ? fail_at : nchunk;  // (the threads are gone: plain reads)
     for (uint32_t k = 0; k < kdone; ++k) *payload += psz[k], *zbytes += zsz[k];

@@ -25,6 +25,8 @@ struct TbkApi {
   decltype(&tbk_tile_join) tile_join = nullptr;
   decltype(&tbk_reserve_tile) reserve_tile = nullptr;
   decltype(&tbk_bam_encode) bam_encode = nullptr;
+  decltype(&tbk_kept_results) kept_results = nullptr;
+  decltype(&tbk_warmup) warmup = nullptr;
   decltype(&tbk_host_alloc) host_alloc = nullptr;
   decltype(&tbk_host_free) host_free = nullptr;
   decltype(&tbk_set_profiling) set_profiling = nullptr;
@@ -64,6 +66,8 @@ struct TbkApi {
     TBK_BIND(tile_join, tbk_tile_join)
     TBK_BIND(reserve_tile, tbk_reserve_tile)
     TBK_BIND(bam_encode, tbk_bam_encode)
+    TBK_BIND(kept_results, tbk_kept_results)
+    TBK_BIND(warmup, tbk_warmup)
     TBK_BIND(host_alloc, tbk_host_alloc)
     TBK_BIND(host_free, tbk_host_free)
     TBK_BIND(set_profiling, tbk_set_profiling)

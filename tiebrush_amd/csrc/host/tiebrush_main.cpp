@@ -79,7 +79,14 @@ template <class T>
 struct RawBuf {
   T* p = nullptr;
   size_t cap = 0, len = 0;
+  bool borrowed = false;
+  // another buffer's pages for a while (a dead array of the input tile: resident already, nothing to fault in)
+  void borrow(T* q, size_t n) {
+    if (!borrowed) tbh::big_free(p);
+    p = q, cap = len = n, borrowed = true;
+  }
   void resize(size_t n) {
+    if (borrowed) p = nullptr, cap = 0, borrowed = false;
     if (n > cap) {
       const size_t want = cap ? std::max(n, cap + cap / 2) : n;
       tbh::big_free(p);
@@ -255,6 +262,48 @@ int main(int argc, char* argv[]) {
   bool api_ok = false;
   DeviceWriter* dw = nullptr;  // (pinned staging: lives until the process ends)
   double ms_ctx_ready = 0;
+  // The thread brings the device up and then warms the context (below).  A caller that can use the context the moment it exists — the
+  // hybrid path's device decode — says so (ctx_urgent) and gets it unwarmed: it runs the warm-up itself when its decode is done and
+  // the cores are still busy with their share.
+  std::mutex ctx_m;
+  std::condition_variable ctx_cv;
+  bool ctx_created = false, ctx_warming = false;  // (under ctx_m)
+  std::atomic<bool> ctx_urgent{false};
+  bool ctx_warm = false;
+  auto warm_ctx = [&]() {
+    if (ctx_warm || !api_ok || rc != 0 || getenv("TBK_NO_WARMUP")) return;
+    ctx_warm = true;
+    // one tiny collapse: the first launch maps the code objects of the library onto the device and the first call sizes the
+    // context's buffers — tens of milliseconds that belong beside the inflate, not behind it
+    // (65 inputs of one record each: more than 64 inputs take the window path, whose kernels — the larger part of the library's
+    // device code — would otherwise be mapped by the first real collapse)
+    constexpr uint32_t WK = 65;
+    uint32_t fo[WK + 1], co[WK + 1], cg[WK];
+    uint8_t tb0[WK], mq[WK], st[WK];
+    int32_t ti[WK], po[WK], nh[WK];
+    uint16_t fl[WK];
+    for (uint32_t i = 0; i < WK; ++i) fo[i] = co[i] = i, cg[i] = 50u << 4, tb0[i] = 0, mq[i] = 60, st[i] = '.', ti[i] = 0, po[i] = 10, nh[i] = 1, fl[i] = 0;
+    fo[WK] = co[WK] = WK;
+    tbk_soa_in w;
+    memset(&w, 0, sizeof(w));
+    w.mem = TBK_MEM_HOST;
+    w.n_files = WK, w.n_records = WK, w.n_cigar_ops = WK;
+    w.file_off = fo, w.tbmerged = tb0, w.tid = ti, w.pos = po, w.flag = fl, w.mapq = mq, w.strand = st, w.nh = nh, w.cig_off = co, w.cig = cg;
+    uint32_t wrep[WK];
+    double wyc[WK];
+    int64_t wyx[WK];
+    int32_t wyd[WK];
+    tbk_groups_out wo;
+    memset(&wo, 0, sizeof(wo));
+    wo.mem = TBK_MEM_HOST;
+    wo.cap_groups = WK;
+    wo.rep = wrep, wo.yc = wyc, wo.yx = wyx, wo.yd = wyd;
+    tbk_collapse_opts wopt = opt;
+    (void)api.collapse_tile(ctx, &wopt, &w, &wo);
+    // the YD stage's second queue and the first dispatch of its list machines, the copy engines, the results' staging buffer: 15-40 ms
+    // of a first call otherwise
+    if (!getenv("TBK_NO_WARMUP2")) (void)api.warmup(ctx);
+  };
   std::thread ctx_thread([&]() {
     api_ok = api.load();
     if (api_ok) rc = api.create(dev, &ctx);
@@ -263,43 +312,41 @@ int main(int argc, char* argv[]) {
       (void)dw->reserve();  // (page-locking the staging buffers: tens of milliseconds, beside the decode)
     }
     ms_ctx_ready = tms(t_start, tnow());
-    if (api_ok && rc == 0 && !getenv("TBK_NO_WARMUP")) {
-      // one tiny collapse: the first launch maps the code objects of the library onto the device and the first call sizes the
-      // context's buffers — tens of milliseconds that belong beside the inflate, not behind it
-      // (65 inputs of one record each: more than 64 inputs take the window path, whose kernels — the larger part of the library's
-      // device code — would otherwise be mapped by the first real collapse)
-      constexpr uint32_t WK = 65;
-      uint32_t fo[WK + 1], co[WK + 1], cg[WK];
-      uint8_t tb0[WK], mq[WK], st[WK];
-      int32_t ti[WK], po[WK], nh[WK];
-      uint16_t fl[WK];
-      for (uint32_t i = 0; i < WK; ++i) fo[i] = co[i] = i, cg[i] = 50u << 4, tb0[i] = 0, mq[i] = 60, st[i] = '.', ti[i] = 0, po[i] = 10, nh[i] = 1, fl[i] = 0;
-      fo[WK] = co[WK] = WK;
-      tbk_soa_in w;
-      memset(&w, 0, sizeof(w));
-      w.mem = TBK_MEM_HOST;
-      w.n_files = WK, w.n_records = WK, w.n_cigar_ops = WK;
-      w.file_off = fo, w.tbmerged = tb0, w.tid = ti, w.pos = po, w.flag = fl, w.mapq = mq, w.strand = st, w.nh = nh, w.cig_off = co, w.cig = cg;
-      uint32_t wrep[WK];
-      double wyc[WK];
-      int64_t wyx[WK];
-      int32_t wyd[WK];
-      tbk_groups_out wo;
-      memset(&wo, 0, sizeof(wo));
-      wo.mem = TBK_MEM_HOST;
-      wo.cap_groups = WK;
-      wo.rep = wrep, wo.yc = wyc, wo.yx = wyx, wo.yd = wyd;
-      tbk_collapse_opts wopt = opt;
-      (void)api.collapse_tile(ctx, &wopt, &w, &wo);
+    bool warm_here;
+    {
+      std::lock_guard<std::mutex> lk(ctx_m);
+      ctx_created = true;
+      warm_here = !ctx_urgent.load();
+      ctx_warming = warm_here;
+    }
+    ctx_cv.notify_all();
+    if (warm_here) {
+      warm_ctx();
+      {
+        std::lock_guard<std::mutex> lk(ctx_m);
+        ctx_warming = false;
+      }
+      ctx_cv.notify_all();
     }
   });
   bool ctx_ready = false;
+  auto check_ctx = [&]() {
+    if (!api_ok) GError("Error: cannot load libtbk.so (%s); this build has no CPU collapse path\n", api.error.c_str());
+    if (rc != 0) GError("Error: cannot use GPU %d (%s); this build has no CPU collapse path\n", dev, api.strerror_(rc));
+  };
   auto need_ctx = [&]() {
     if (ctx_ready) return;
     ctx_thread.join();
     ctx_ready = true;
-    if (!api_ok) GError("Error: cannot load libtbk.so (%s); this build has no CPU collapse path\n", api.error.c_str());
-    if (rc != 0) GError("Error: cannot use GPU %d (%s); this build has no CPU collapse path\n", dev, api.strerror_(rc));
+    check_ctx();
+  };
+  // (the hybrid path's decode thread: the context as soon as it exists; the thread above is NOT joined here)
+  auto need_ctx_now = [&]() {
+    ctx_urgent.store(true);
+    std::unique_lock<std::mutex> lk(ctx_m);
+    ctx_cv.wait(lk, [&] { return ctx_created && !ctx_warming; });
+    lk.unlock();
+    check_ctx();
   };
   inRecords.start();
   auto t_ctx = tnow();
@@ -392,10 +439,29 @@ int main(int argc, char* argv[]) {
       if (failed.load()) GError("Error: deflate failed\n");
     };
     uint32_t dev_groups_done = 0;  // groups the device writer wrote before it refused a chunk: the host writer goes on from there
+    // the whole-input paths leave the tags' values on the device for the device writer (tbk_collapse_opts.keep_results): only `rep`
+    // comes back with the call.  When the host writer has to write after all, it fetches the values of the groups it writes.
+    bool results_kept = false;
     auto write_groups = [&](uint32_t ng) {
       const uint32_t gfirst = dev_groups_done;
       dev_groups_done = 0;
+      if (results_kept && ng > gfirst) {
+        yc.resize(ng), yx.resize(ng), yd.resize(ng);
+        const int frc = api.kept_results(ctx, gfirst, ng - gfirst, nullptr, yc.data() + gfirst, yx.data() + gfirst, yd.data() + gfirst);
+        if (frc != 0) GError("Error: fetching the collapse's results failed: %s (%s)\n", api.strerror_(frc), api.last_error(ctx));
+      }
       write_groups_arr(ng, get_record, yc.data(), yx.data(), yd.data(), gfirst);
+    };
+    const bool keep_for_writer = dev_writer && outfile.level() != 0 && !getenv("TBK_NO_KEEP_RESULTS");
+    // ... and `rep` comes back once the number of groups is known, into pages that are resident already when a dead array of the host's
+    // input tile is long enough (4 bytes per record: tid) — a fresh block of tens of megabytes is faulted in at 1-2 GB/s this late in the run
+    auto fetch_rep = [&](uint32_t ng, int32_t* dead, size_t dead_n) {
+      if (dead && ng <= dead_n) rep.borrow((uint32_t*)dead, dead_n);
+      else rep.resize(ng ? ng : 1);
+      auto f0 = tnow();
+      const int frc = api.kept_results(ctx, 0, ng, rep.data(), nullptr, nullptr, nullptr);
+      if (frc != 0) GError("Error: fetching the collapse's results failed: %s (%s)\n", api.strerror_(frc), api.last_error(ctx));
+      if (timing) fprintf(stderr, "representatives of %u groups fetched in %.1f ms (%s)\n", ng, tms(f0, tnow()), rep.borrowed ? "into the input tile's pages" : "into a new block");
     };
     // the same on the device (devwriter.h): tags, framing and BGZF deflate as kernels, the host only gathers the records it decoded
     // itself and appends the finished members.  false: the host writer above takes the groups from dev_groups_done on.
@@ -407,7 +473,7 @@ int main(int argc, char* argv[]) {
       uint64_t pb = 0, zb = 0;
       std::string why;
       uint32_t done = 0;
-      const bool ok = dw->write(ctx, outfile, ng, rep.data(), yc.data(), yx.data(), yd.data(), n_dev, host_record, &pb, &zb, why, &done);
+      const bool ok = dw->write(ctx, outfile, ng, rep.data(), results_kept ? nullptr : yc.data(), yx.data(), yd.data(), n_dev, host_record, &pb, &zb, why, &done);
       if (!ok && timing) fprintf(stderr, "device writer stopped after %u of %u groups (%s): host writer\n", done, ng, why.c_str());
       ms_dev_write += tms(a, tnow()), dev_payload += pb, dev_z += zb;
       dev_groups_done = ok ? 0 : done;
@@ -473,6 +539,7 @@ int main(int argc, char* argv[]) {
         if (kd == 0) kd = 1;
         const size_t budget = host_budget();
         auto t0 = tnow();
+        if (timing) fprintf(stderr, "hybrid decode starts at %.1f ms\n", tms(t_start, t0));
         // the device's share, on a thread of its own: read the files, wait for the context, decode
         tbk_soa_in in_d;
         memset(&in_d, 0, sizeof(in_d));
@@ -489,7 +556,7 @@ int main(int argc, char* argv[]) {
           auto d1 = tnow();
           ms_dread = tms(d0, d1);
           if (!read_ok) return;
-          need_ctx();
+          need_ctx_now();
           auto d2 = tnow();
           std::vector<const uint8_t*> ptr(kd);
           for (size_t f = 0; f < kd; ++f) ptr[f] = comp[f].p;
@@ -516,6 +583,7 @@ int main(int argc, char* argv[]) {
             (void)api.reserve_tile(ctx, (uint64_t)((double)in_d.n_records * up), (uint64_t)((double)in_d.n_cigar_ops * up));
           }
           ms_ddec = tms(d1, tnow());
+          warm_ctx();  // (the helper thread left it to this one: need_ctx_now)
         });
         // the cores' share
         std::vector<std::string> ph(paths.begin() + (long)kd, paths.end());
@@ -528,6 +596,7 @@ int main(int argc, char* argv[]) {
         auto t_host = tnow();
         dth.join();
         auto t1 = tnow();
+        need_ctx();  // (the helper thread ended long ago; this only joins it)
         if (!okh) GError("Error: reading the input failed (%s)\n", err.c_str());
         if (!read_ok) GError("Error: reading the input failed\n");
         if (rc_d != 0 && rc_d != TBK_ENOMEM && rc_d != TBK_E2BIG) GError("Error: decoding the input on the GPU failed: %s (%s)\n", api.strerror_(rc_d), api.last_error(ctx));
@@ -548,19 +617,19 @@ int main(int argc, char* argv[]) {
           t_join = tnow();
           if (rc == 0) {
             const size_t n = in.n_records;
-            rep.resize(n ? n : 1);
-            yc.resize(n ? n : 1);
-            yx.resize(n ? n : 1);
-            yd.resize(n ? n : 1);
             out.mem = TBK_MEM_HOST;
             out.cap_groups = (uint32_t)(n ? n : 1);
-            out.rep = rep.data();
-            out.yc = yc.data();
-            out.yx = yx.data();
-            out.yd = yd.data();
+            tbk_collapse_opts copt = opt;
+            copt.keep_results = keep_for_writer ? 1 : 0;
+            if (!keep_for_writer) {
+              rep.resize(n ? n : 1), yc.resize(n ? n : 1), yx.resize(n ? n : 1), yd.resize(n ? n : 1);
+              out.rep = rep.data(), out.yc = yc.data(), out.yx = yx.data(), out.yd = yd.data();
+            }
             if (ktiming) (void)api.set_profiling(ctx, 1);
-            rc = api.collapse_tile(ctx, &opt, &in, &out);
+            rc = api.collapse_tile(ctx, &copt, &in, &out);
             if (rc == 0 && getenv("TBK_TEST_WHOLE_ENOMEM")) rc = TBK_ENOMEM;  // test hook: exercise the fall-back below
+            results_kept = rc == 0 && keep_for_writer;
+            if (results_kept) fetch_rep(out.n_groups, ft.tid, ft.n);  // (the host part's SoA went to the device with tbk_tile_join)
             t_col = tnow();
             if (ktiming) {
               tbk_kernel_time kt[64];
@@ -618,7 +687,11 @@ int main(int argc, char* argv[]) {
             done_fast = true;
           }
         }
-        if (ctx_ready) api.bam_release(ctx);
+        {
+          auto r0 = tnow();
+          if (ctx_ready) api.bam_release(ctx);
+          if (timing) fprintf(stderr, "bam_release %.1f ms\n", tms(r0, tnow()));
+        }
         if (done_fast) {
         } else if (!ok) {
           if (timing) fprintf(stderr, "hybrid decode given up (%s): streaming host path\n", rc_d != 0 ? api.strerror_(rc_d) : (fits ? api.strerror_(rc) : "the host's share does not fit"));
@@ -679,22 +752,22 @@ int main(int argc, char* argv[]) {
           auto t1 = tnow();
           tbk_soa_in in = ft.view();
           const size_t n = ft.n;
-          rep.resize(n ? n : 1);
-          yc.resize(n ? n : 1);
-          yx.resize(n ? n : 1);
-          yd.resize(n ? n : 1);
           need_ctx();
           auto t_ctxw = tnow();
           tbk_groups_out out;
           memset(&out, 0, sizeof(out));
           out.mem = TBK_MEM_HOST;
           out.cap_groups = (uint32_t)(n ? n : 1);
-          out.rep = rep.data();
-          out.yc = yc.data();
-          out.yx = yx.data();
-          out.yd = yd.data();
-          rc = api.collapse_tile(ctx, &opt, &in, &out);
+          tbk_collapse_opts copt = opt;
+          copt.keep_results = keep_for_writer ? 1 : 0;
+          if (!keep_for_writer) {
+            rep.resize(n ? n : 1), yc.resize(n ? n : 1), yx.resize(n ? n : 1), yd.resize(n ? n : 1);
+            out.rep = rep.data(), out.yc = yc.data(), out.yx = yx.data(), out.yd = yd.data();
+          }
+          rc = api.collapse_tile(ctx, &copt, &in, &out);
           if (rc == 0 && getenv("TBK_TEST_WHOLE_ENOMEM")) rc = TBK_ENOMEM;  // test hook: exercise the fall-back below
+          results_kept = rc == 0 && keep_for_writer;
+          if (results_kept) fetch_rep(out.n_groups, ft.tid, ft.n);  // (the SoA went to the device with the call)
           auto t2 = tnow();
           if (rc == TBK_EUNSORTED) GError("Error: an input file is not coordinate-sorted!\n");
           if (rc == TBK_ENOMEM || rc == TBK_E2BIG) {  // one tile of everything is more than the GPU takes: the streaming path bounds it
@@ -999,7 +1072,7 @@ int main(int argc, char* argv[]) {
                         "waited for the writer at the end %.1f; writer thread busy %.1f\n",
                 n_tiles, ms_inflate, ms_load, ms_gpu, ms_gather, ms_wait_slot, tms(w0, tnow()), ms_writer_busy);
     }
-    if (timing) fprintf(stderr, "tiles: %zu\n", n_tiles);
+    if (timing) fprintf(stderr, "tiles: %zu (at %.1f ms)\n", n_tiles, tms(t_start, tnow()));
   }
   auto t_closed = tnow();
   if (timing) fprintf(stderr, "writer closed at %.1f ms\n", tms(t_start, t_closed));

@@ -4,6 +4,7 @@
 #include <sys/mman.h>
 
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <vector>
 #include <new>
@@ -29,6 +30,15 @@ std::vector<RegEntry> g_reg;
 static void release_registered(tbk_ctx* ctx) {
   if (ctx->registered.empty()) return;
   (void)hipStreamSynchronize(ctx->stream);  // the copies out of / into the ranges have to be done first
+  const auto r0 = std::chrono::steady_clock::now();
+  struct RP {
+    tbk_ctx* c;
+    std::chrono::steady_clock::time_point t;
+    size_t n;
+    ~RP() {
+      if (c->dbg.phases) fprintf(stderr, "collapse phases: %zu ranges unregistered in %.1f ms\n", n, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count());
+    }
+  } rp{ctx, r0, ctx->registered.size()};
   std::lock_guard<std::mutex> lk(g_reg_m);
   for (void* p : ctx->registered)
     for (size_t i = 0; i < g_reg.size(); ++i)
@@ -273,11 +283,118 @@ static int dalloc(tbk_ctx* ctx, T* host, size_t n, T** dst) {
   *dst = d;
   return 0;
 }
+// Results of moderate size come back through a small page-locked buffer of the context and a copy by the core.  Page-locking the
+// caller's fresh array for one copy looks cheaper (0.04 ms per MB) but is not reliably so: late in a process that holds gigabytes the
+// copy call itself was measured to block 10-20 ms for 20 MB (and 100 ms and more now and then), registered or not — the buffer's pages
+// are pinned once, when the context is young.
+constexpr size_t kBounce = (size_t)8 << 20;
+static bool bounce_ready(tbk_ctx* ctx) {
+  if (!ctx->bounce && hipHostMalloc((void**)&ctx->bounce, kBounce) != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->bounce = nullptr;
+  }
+  return ctx->bounce != nullptr;
+}
+static int d2h_bounce(tbk_ctx* ctx, char* host, const char* dev, size_t bytes) {
+  // One chunk at a time: a second copy queued while the first is in flight is given ANOTHER copy engine, whose first use in the process
+  // costs 7-8 ms (measured: HIP's log of the command line) — more than the overlap of 80 us of DMA with 150 us of memcpy can save.
+  double t_q = 0, t_c = 0;  // (phases=1: the copies, the core's part)
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  for (size_t off = 0; off < bytes; off += kBounce) {
+    const size_t len = std::min(kBounce, bytes - off);
+    const auto a = now();
+    TBK_HIP(hipMemcpyAsync(ctx->bounce, dev + off, len, hipMemcpyDeviceToHost, ctx->stream));
+    TBK_HIP(hipStreamSynchronize(ctx->stream));
+    const auto b = now();
+    memcpy(host + off, ctx->bounce, len);
+    t_q += ms(a, b), t_c += ms(b, now());
+  }
+  if (ctx->dbg.phases) fprintf(stderr, "collapse phases: %.1f MB through the staging buffer: copies %.1f | the core's part %.1f ms\n", bytes / 1e6, t_q, t_c);
+  return 0;
+}
 template <class T>
 static int d2h(tbk_ctx* ctx, T* host, const T* dev, size_t n) {
   if (!host || !dev || !n) return 0;
+  const size_t bytes = n * sizeof(T);
+  if (bytes >= ((size_t)1 << 20) && bytes <= ((size_t)64 << 20) && !ctx->dbg.no_bounce) {
+    hipPointerAttribute_t at;
+    const bool pinned = hipPointerGetAttributes(&at, host) == hipSuccess && at.type != hipMemoryTypeUnregistered;
+    (void)hipGetLastError();
+    if (!pinned && bounce_ready(ctx)) return d2h_bounce(ctx, (char*)host, (const char*)dev, bytes);
+  }
   host_register(ctx, host, n * sizeof(T));
   TBK_HIP(hipMemcpyAsync(host, dev, n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+  return 0;
+}
+
+template <class T>
+static int dalloc_if(tbk_ctx* ctx, bool want, size_t n, T** dst) {
+  *dst = nullptr;
+  if (!want) return 0;
+  T* d = ws_alloc<T>(ctx, n ? n : 1);
+  if (!d) return TBK_ENOMEM;
+  *dst = d;
+  return 0;
+}
+// the device arrays a TBK_MEM_HOST caller's results are computed into (keep: all four result columns, whatever the caller takes back)
+static int out_dalloc(tbk_ctx* ctx, const tbk_groups_out* out, size_t cap, size_t n, bool keep, tbk_groups_out* dout) {
+  dout->mem = TBK_MEM_DEVICE;
+  TBK_TRY(dalloc_if(ctx, keep || out->rep, cap, &dout->rep));
+  TBK_TRY(dalloc_if(ctx, keep || out->yc, cap, &dout->yc));
+  TBK_TRY(dalloc_if(ctx, keep || out->yx, cap, &dout->yx));
+  TBK_TRY(dalloc_if(ctx, keep || out->yd, cap, &dout->yd));
+  TBK_TRY(dalloc(ctx, out->g_start, cap, &dout->g_start));
+  TBK_TRY(dalloc(ctx, out->g_end, cap, &dout->g_end));
+  TBK_TRY(dalloc(ctx, out->rec_group, n, &dout->rec_group));
+  TBK_TRY(dalloc(ctx, out->rep_effend, cap, &dout->rep_effend));
+  TBK_TRY(dalloc(ctx, out->g_key, 2 * cap, &dout->g_key));
+  return 0;
+}
+static int out_d2h(tbk_ctx* ctx, tbk_groups_out* out, const tbk_groups_out* dout, size_t n) {
+  const size_t g = dout->n_groups;
+
+  TBK_TRY(d2h(ctx, out->rep, dout->rep, g));
+  TBK_TRY(d2h(ctx, out->yc, dout->yc, g));
+  TBK_TRY(d2h(ctx, out->yx, dout->yx, g));
+  TBK_TRY(d2h(ctx, out->yd, dout->yd, g));
+  TBK_TRY(d2h(ctx, out->g_start, dout->g_start, g));
+  TBK_TRY(d2h(ctx, out->g_end, dout->g_end, g));
+  TBK_TRY(d2h(ctx, out->rec_group, dout->rec_group, n));
+  TBK_TRY(d2h(ctx, out->rep_effend, dout->rep_effend, g));
+  TBK_TRY(d2h(ctx, out->g_key, dout->g_key, 2 * g));
+  TBK_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+// tbk_collapse_opts.keep_results: the call's rep / yc / yx / yd (device arrays, final) copied into the context's own allocation — 24 bytes
+// per group, device to device — where tbk_bam_encode and tbk_kept_results find them until the next collapse
+static int keep_results(tbk_ctx* ctx, const tbk_groups_out* d) {
+  const size_t g = d->n_groups;
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t need = 2 * al(g * 8) + 2 * al(g * 4) + 256;
+  if (need > ctx->kept_cap) {
+    if (ctx->kept) (void)hipFree(ctx->kept);
+    ctx->kept = nullptr;
+    ctx->kept_cap = 0;
+    if (hipMalloc((void**)&ctx->kept, need + need / 8) != hipSuccess) {
+      (void)hipGetLastError();
+      ctx->last_error = "keep_results: hipMalloc failed";
+      return TBK_ENOMEM;
+    }
+    ctx->kept_cap = need + need / 8;
+  }
+  char* p = ctx->kept;
+  ctx->kept_yc = (double*)p, p += al(g * 8);
+  ctx->kept_yx = (int64_t*)p, p += al(g * 8);
+  ctx->kept_rep = (uint32_t*)p, p += al(g * 4);
+  ctx->kept_yd = (int32_t*)p;
+  if (g) {
+    TBK_HIP(hipMemcpyAsync(ctx->kept_yc, d->yc, g * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    TBK_HIP(hipMemcpyAsync(ctx->kept_yx, d->yx, g * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    TBK_HIP(hipMemcpyAsync(ctx->kept_rep, d->rep, g * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    TBK_HIP(hipMemcpyAsync(ctx->kept_yd, d->yd, g * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  ctx->kept_n = (uint32_t)g;
   return 0;
 }
 
@@ -384,6 +501,8 @@ void tbk_debug_parse(const char* spec, TbkDebug* out) {
     else if (k == "jh_cap") out->jh_cap = (uint32_t)u;
     else if (k == "index_chain") out->index_chain = on;
     else if (k == "no_register") out->no_register = on;
+    else if (k == "phases") out->phases = on;
+    else if (k == "no_bounce") out->no_bounce = on;
   }
 }
 
@@ -469,6 +588,8 @@ void tbk_destroy(tbk_ctx* ctx) {
   if (ctx->ws && !ctx->ws_borrowed) (void)hipFree(ctx->ws);
   if (ctx->d_view) (void)hipFree(ctx->d_view);
   if (ctx->d_unpack) (void)hipFree(ctx->d_unpack);
+  if (ctx->kept) (void)hipFree(ctx->kept);
+  if (ctx->bounce) (void)hipHostFree(ctx->bounce);
   tbk_enc_free(ctx);
   tbk_stager_free(ctx);
   if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
@@ -635,7 +756,10 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
   if (in->n_records &&
       (!in->tid || !in->pos || !in->flag || !in->mapq || !in->strand || !in->nh || !in->cig_off || (in->n_cigar_ops && !in->cig)))
     return TBK_EINVAL;
-  if (!out->rep || !out->yc || !out->yx || !out->yd) return TBK_EINVAL;
+  // (keep_results: the results may stay on the device — a host caller takes what it needs, when it knows how many groups there are)
+  const bool host_tags_optional = opts->keep_results && out->mem == TBK_MEM_HOST;
+  if (!host_tags_optional && (!out->rep || !out->yc || !out->yx || !out->yd)) return TBK_EINVAL;
+  if (opts->keep_results && opts->defer_yd) return TBK_EINVAL;
   if (opts->strategy == TBK_STRAT_FULL && in->n_records && (!in->md_off || !in->md_has)) return TBK_EINVAL;
   if (opts->collapse_same && (!in->qname_hash || !in->qname_off || (in->n_records && !in->qname))) return TBK_EINVAL;  // -A compares names
   if ((in->prio_hi == nullptr) != (in->prio_lo == nullptr)) return TBK_EINVAL;
@@ -659,45 +783,41 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
   if (lean && in->tbmerged)
     for (uint32_t f = 0; f < in->n_files; ++f) lean = lean && in->tbmerged[f] == 0;
   size_t hint = (size_t)in->n_records * (lean ? 84 : 160) + (size_t)in->n_cigar_ops * 8 + ((size_t)8 << 20);
+  const auto pa = std::chrono::steady_clock::now();
   TBK_TRY(ws_begin_call(ctx, hint));
+  if (ctx->dbg.phases) fprintf(stderr, "collapse phases: arena ready in %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - pa).count());
   RegGuard reg_guard{ctx};
   int rc;
   ctx->yd_job = nullptr;
   const size_t yd_hint = (size_t)in->n_records * (lean ? 40 : 96) + ((size_t)8 << 20);
+  // (phases=1: where the call's wall time goes; the marks wait for the stream, so the figures are of a serialised call)
+  const bool ph = ctx->dbg.phases;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  auto mark = [&]() {
+    if (ph) (void)hipStreamSynchronize(ctx->stream);
+    return now();
+  };
+  const auto p0 = now();
+  auto p_in = p0, p_grp = p0, p_yd = p0;
+  ctx->kept_n = 0;
   if (in->mem == TBK_MEM_DEVICE && out->mem == TBK_MEM_HOST) {
     tbk_groups_out dout = *out;
-    dout.mem = TBK_MEM_DEVICE;
     const size_t cap = out->cap_groups, n = in->n_records;
-    TBK_TRY(dalloc(ctx, out->rep, cap, &dout.rep));
-    TBK_TRY(dalloc(ctx, out->yc, cap, &dout.yc));
-    TBK_TRY(dalloc(ctx, out->yx, cap, &dout.yx));
-    TBK_TRY(dalloc(ctx, out->yd, cap, &dout.yd));
-    TBK_TRY(dalloc(ctx, out->g_start, cap, &dout.g_start));
-    TBK_TRY(dalloc(ctx, out->g_end, cap, &dout.g_end));
-    TBK_TRY(dalloc(ctx, out->rec_group, n, &dout.rec_group));
-    TBK_TRY(dalloc(ctx, out->rep_effend, cap, &dout.rep_effend));
-    TBK_TRY(dalloc(ctx, out->g_key, 2 * cap, &dout.g_key));
+    TBK_TRY(out_dalloc(ctx, out, cap, n, opts->keep_results != 0, &dout));
+    p_in = mark();
     rc = tbk_collapse_device(ctx, opts, in, &dout);
+    p_grp = mark();
     if (rc == 0 && ctx->yd_job) {
       void* job = ctx->yd_job;
       ctx->yd_job = nullptr;
       rc = tbk_collapse_yd_run(ctx, job);
     }
+    p_yd = mark();
     out->n_groups = dout.n_groups;
     out->n_passed = dout.n_passed;
-    if (rc == 0) {
-      const size_t g = dout.n_groups;
-      TBK_TRY(d2h(ctx, out->rep, dout.rep, g));
-      TBK_TRY(d2h(ctx, out->yc, dout.yc, g));
-      TBK_TRY(d2h(ctx, out->yx, dout.yx, g));
-      TBK_TRY(d2h(ctx, out->yd, dout.yd, g));
-      TBK_TRY(d2h(ctx, out->g_start, dout.g_start, g));
-      TBK_TRY(d2h(ctx, out->g_end, dout.g_end, g));
-      TBK_TRY(d2h(ctx, out->rec_group, dout.rec_group, n));
-      TBK_TRY(d2h(ctx, out->rep_effend, dout.rep_effend, g));
-      TBK_TRY(d2h(ctx, out->g_key, dout.g_key, 2 * g));
-      TBK_HIP(hipStreamSynchronize(ctx->stream));
-    }
+    if (rc == 0 && opts->keep_results) rc = keep_results(ctx, &dout);
+    if (rc == 0) rc = out_d2h(ctx, out, &dout, n);
   } else if (in->mem == TBK_MEM_DEVICE) {
     rc = tbk_collapse_device(ctx, opts, in, out);
     if (rc == 0 && ctx->yd_job) {
@@ -734,6 +854,7 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
         rc = tbk_collapse_yd_run(ctx, job);
       }
     }
+    if (rc == 0 && opts->keep_results) rc = keep_results(ctx, out);
   } else {
     tbk_soa_in din = *in;
     tbk_groups_out dout = *out;
@@ -759,39 +880,64 @@ int tbk_collapse_tile(tbk_ctx* ctx, const tbk_collapse_opts* opts, const tbk_soa
     TBK_TRY(h2d(ctx, in->prio_hi, n, &din.prio_hi));
     TBK_TRY(h2d(ctx, in->prio_lo, n, &din.prio_lo));
     size_t cap = out->cap_groups;
-    TBK_TRY(dalloc(ctx, out->rep, cap, &dout.rep));
-    TBK_TRY(dalloc(ctx, out->yc, cap, &dout.yc));
-    TBK_TRY(dalloc(ctx, out->yx, cap, &dout.yx));
-    TBK_TRY(dalloc(ctx, out->yd, cap, &dout.yd));
-    TBK_TRY(dalloc(ctx, out->g_start, cap, &dout.g_start));
-    TBK_TRY(dalloc(ctx, out->g_end, cap, &dout.g_end));
-    TBK_TRY(dalloc(ctx, out->rec_group, n, &dout.rec_group));
-    TBK_TRY(dalloc(ctx, out->rep_effend, cap, &dout.rep_effend));
-    TBK_TRY(dalloc(ctx, out->g_key, 2 * cap, &dout.g_key));
+    TBK_TRY(out_dalloc(ctx, out, cap, n, opts->keep_results != 0, &dout));
+    p_in = mark();
     rc = tbk_collapse_device(ctx, opts, &din, &dout);
+    p_grp = mark();
     if (rc == 0 && ctx->yd_job) {
       void* job = ctx->yd_job;
       ctx->yd_job = nullptr;
       rc = tbk_collapse_yd_run(ctx, job);
     }
+    p_yd = mark();
     out->n_groups = dout.n_groups;
     out->n_passed = dout.n_passed;
-    if (rc == 0) {
-      size_t g = dout.n_groups;
-      TBK_TRY(d2h(ctx, out->rep, dout.rep, g));
-      TBK_TRY(d2h(ctx, out->yc, dout.yc, g));
-      TBK_TRY(d2h(ctx, out->yx, dout.yx, g));
-      TBK_TRY(d2h(ctx, out->yd, dout.yd, g));
-      TBK_TRY(d2h(ctx, out->g_start, dout.g_start, g));
-      TBK_TRY(d2h(ctx, out->g_end, dout.g_end, g));
-      TBK_TRY(d2h(ctx, out->rec_group, dout.rec_group, n));
-      TBK_TRY(d2h(ctx, out->rep_effend, dout.rep_effend, g));
-      TBK_TRY(d2h(ctx, out->g_key, dout.g_key, 2 * g));
-      TBK_HIP(hipStreamSynchronize(ctx->stream));
-    }
+    if (rc == 0 && opts->keep_results) rc = keep_results(ctx, &dout);
+    if (rc == 0) rc = out_d2h(ctx, out, &dout, n);
   }
+  if (ph && out->mem == TBK_MEM_HOST)
+    fprintf(stderr, "collapse phases ms: inputs %.1f | grouping %.1f | YD stage %.1f | results %.1f | %u groups%s\n", ms(p0, p_in), ms(p_in, p_grp), ms(p_grp, p_yd),
+            ms(p_yd, now()), out->n_groups, opts->keep_results ? " (kept on the device)" : "");
   tbk_prof_end_call(ctx);
   return rc;
+}
+
+int tbk_warmup(tbk_ctx* ctx) {
+  if (!ctx) return TBK_EINVAL;
+  TBK_TRY(finish_yd(ctx));
+  TBK_TRY(tbk_collapse_warm(ctx));
+  (void)bounce_ready(ctx);
+  // the copy engines: the process's first large copy in a direction sets that engine up inside the call (measured: 10-20 ms in the
+  // hipMemcpyAsync that brings a first tile's results back; small copies go through a kernel and do not count)
+  constexpr size_t kWarm = (size_t)4 << 20;
+  void *h = nullptr, *d = nullptr;
+  if (hipHostMalloc(&h, kWarm) == hipSuccess && hipMalloc(&d, kWarm) == hipSuccess) {
+    (void)hipMemcpyAsync(d, h, kWarm, hipMemcpyHostToDevice, ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
+    // (the way back on the OTHER stream: a stream sends a copy to the engine its last copy used, and the engine the device -> host
+    // direction gets when the runtime chooses afresh is another one)
+    hipStream_t back = tbk_aux_stream(ctx) ? tbk_aux_stream(ctx) : ctx->stream;
+    (void)hipMemcpyAsync(h, d, kWarm, hipMemcpyDeviceToHost, back);
+    (void)hipStreamSynchronize(back);
+  }
+  if (d) (void)hipFree(d);
+  if (h) (void)hipHostFree(h);
+  (void)hipGetLastError();
+  return 0;
+}
+
+int tbk_kept_results(tbk_ctx* ctx, uint32_t first, uint32_t n, uint32_t* rep, double* yc, int64_t* yx, int32_t* yd) {
+  if (!ctx) return TBK_EINVAL;
+  if (!ctx->kept || (uint64_t)first + n > ctx->kept_n) return TBK_EINVAL;
+  if (n == 0) return 0;
+  TBK_HIP(hipSetDevice(ctx->device));
+  RegGuard reg_guard{ctx};
+  TBK_TRY(d2h(ctx, rep, ctx->kept_rep + first, n));
+  TBK_TRY(d2h(ctx, yc, ctx->kept_yc + first, n));
+  TBK_TRY(d2h(ctx, yx, ctx->kept_yx + first, n));
+  TBK_TRY(d2h(ctx, yd, ctx->kept_yd + first, n));
+  TBK_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
 }
 
 int tbk_sample_tile(tbk_ctx* ctx, const tbk_cov_in* in, int32_t num_samples, tbk_sample_out* out) {

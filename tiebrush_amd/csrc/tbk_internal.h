@@ -102,6 +102,8 @@ struct TbkDebug {
   uint32_t jh_cap = 0;        // jh_cap=N: items a junction home may hold (0: JH_CAP)
   bool index_chain = false;   // index_chain=1: the record index by the per-file chain kernel whatever the files look like
   bool no_register = false;   // no_register=1: large host buffers are not page-locked for a call's copies
+  bool no_bounce = false;     // no_bounce=1: results of moderate size are copied straight into the caller's (registered) arrays
+  bool phases = false;        // phases=1: tbk_collapse_tile prints where its wall time went (copies in, grouping, YD stage, results) to stderr
 };
 void tbk_debug_parse(const char* spec, TbkDebug* out);
 
@@ -167,6 +169,15 @@ struct tbk_ctx {
   void* bam_dev = nullptr;       // device-decoded BAM input (bamdev.hip): inflated streams + record index + the SoA tile's arrays
   void* enc = nullptr;           // the encoder's device buffers (bgzdef.hip)
   void* stager = nullptr;        // pinned ring + upload stream of the staged host -> device copies (bamdev.hip)
+  char* bounce = nullptr;        // a few megabytes of page-locked memory: results of moderate size come back through it (tbk_api.hip: d2h)
+  // the last collapse's results, kept for the output side (tbk_collapse_opts.keep_results): one allocation, four columns of kept_n groups
+  char* kept = nullptr;
+  size_t kept_cap = 0;
+  uint32_t kept_n = 0;
+  uint32_t* kept_rep = nullptr;
+  double* kept_yc = nullptr;
+  int64_t* kept_yx = nullptr;
+  int32_t* kept_yd = nullptr;
 };
 void tbk_stager_free(tbk_ctx* ctx);
 void tbk_enc_free(tbk_ctx* ctx);
@@ -267,6 +278,7 @@ int tbk_sort_runs(tbk_ctx* ctx, SortBufs* b, uint32_t n_hi, const uint32_t* d_ru
 
 // ---- pipelines --------------------------------------------------------------------
 int tbk_collapse_device(tbk_ctx* ctx, const tbk_collapse_opts* o, const tbk_soa_in* in, tbk_groups_out* out);
+int tbk_collapse_warm(tbk_ctx* ctx);  // tbk_warmup: the first-use costs of the YD stage's machines
 int tbk_collapse_yd_run(tbk_ctx* run_on, void* job);  // consumes ctx->yd_job (prepared by tbk_collapse_device)
 int tbk_coverage_device(tbk_ctx* ctx, const tbk_cov_in* in, tbk_cov_out* out);
 // tiecov's input view of ng representatives (tbk_groups_to_cov_in's body; the arena must be reserved by the caller)

@@ -16,6 +16,7 @@ import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SETTLE_S = float(os.environ.get("TBK_E2E_SETTLE_S", "1.0"))   # pause before every timed run (outside the clock)
 sys.path.insert(0, ROOT)
 
 
@@ -102,9 +103,19 @@ def leg(files, reads, profile, flags, seq, runs, device_decode, desc, host_write
         def run(extra_env, k, extra_flags=()):
             ts, rr = [], None
             for _ in range(k):
+                # a NEW output file every run: over an existing one the tool pays for the old file twice — fopen("wb") drops its cached
+                # pages (20 ms per 335 MB) and the close of a file rewritten after a truncate starts the write-back at once (30 ms)
+                if os.path.exists(out):
+                    os.remove(out)
+                # ... and a run of its own: the driver takes a process's device memory down AFTER the process has gone, and a successor
+                # that starts inside that second waits for it — its context comes up 0.1-0.2 s late, its first large device allocation
+                # takes 120-290 ms instead of 0.6 (tools/stall_probe.py: with the pause none of ten runs, without it every second one)
+                time.sleep(SETTLE_S)
                 t1 = time.time()
-                rr = subprocess.run([os.path.join(binp, "tiebrush"), "-o", out] + list(extra_flags) + flags + paths, capture_output=True, text=True, check=True,
+                rr = subprocess.run([os.path.join(binp, "tiebrush"), "-o", out] + list(extra_flags) + flags + paths, capture_output=True, text=True,
                                     env=dict(os.environ, TBK_TIMING="1", **extra_env))
+                if rr.returncode != 0:
+                    raise RuntimeError("tiebrush exited with %d: %s" % (rr.returncode, rr.stderr[-2000:]))
                 ts.append(time.time() - t1)
                 os.sync()      # (the output's dirty pages leave now, not under the next run's reads)
             return sorted(ts), rr
@@ -119,7 +130,7 @@ def leg(files, reads, profile, flags, seq, runs, device_decode, desc, host_write
                "input_bam_bytes": in_bytes, "input_bytes_per_record": round(in_bytes / n, 1),
                "output_bam_bytes": os.path.getsize(out), "summary": summary,
                "phases": [l for l in r.stderr.split("\n") if l.startswith("host path") or l.startswith("hybrid path") or l.startswith("writer closed") or l.startswith("released")
-                          or l.startswith("timing ms") or l.startswith("tiles:") or l.startswith("device writer")][-6:],
+                          or l.startswith("timing ms") or l.startswith("tiles:") or l.startswith("device writer") or l.startswith("bam_release") or l.startswith("hybrid decode starts") or l.startswith("collapse phases") or l.startswith("YD stage ms") or l.startswith("representatives")][-12:],
                "generation_s": round(t_gen, 1)}
         if device_decode:
             th, _ = run({"TBK_DEVICE_DECODE": "1"}, 1)
@@ -154,7 +165,7 @@ def main():
     if not a.no_extra:
         # the same command line on records that carry SEQ / QUAL and an aligner's tags (about 240 inflated bytes per record, like the
         # reference's fixtures: what BGZF and the tagging really move), and with config 3's options on config 3's read model
-        k2 = max(1, a.runs - 1)
+        k2 = max(1, a.runs)      # (three runs a leg: the median of two is the slower one)
         res["seq"] = leg(a.files, a.reads, a.profile, [], True, k2, True,
                          "%d files x %d reads (config-2 read model) WITH 100-bp SEQ / QUAL and aligner tags, default collapse", host_writer=True,
                          cpu_base=a.cpu_baseline)
