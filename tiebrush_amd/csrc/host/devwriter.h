@@ -29,7 +29,7 @@
 
 class DeviceWriter {
  public:
-  static constexpr uint32_t kChunkGroups = 256u << 10;  // ~ 64 MB of records with SEQ / QUAL per chunk
+  static constexpr uint32_t kChunkGroups = 256u << 10;  // ~ 64 MB of records with SEQ / QUAL per chunk (512 K: the encode stage 10 % faster, the pinned staging twice as dear — no gain)
   static constexpr int kSlots = 3;
 
   DeviceWriter(TbkApi& api, int nthreads) : api_(api), nt_(nthreads < 1 ? 1 : nthreads) {
@@ -61,7 +61,8 @@ class DeviceWriter {
   // writer takes the groups from there on (a long read far into the output does not cost the run).  Any other failure is fatal
   // (GError).  *payload / *zbytes: bytes of tagged records / of BGZF members written.
   bool write(tbk_ctx* ctx, GSamWriter& out, uint32_t ng, const uint32_t* rep, const double* yc, const int64_t* yx, const int32_t* yd, uint32_t n_dev,
-             const std::function<tbh::RecView(uint32_t)>& host_record, uint64_t* payload, uint64_t* zbytes, std::string& why, uint32_t* groups_done) {
+             const std::function<tbh::RecView(uint32_t)>& host_record, uint64_t* payload, uint64_t* zbytes, std::string& why, uint32_t* groups_done,
+             const std::function<void(uint32_t, int)>& host_prefetch = nullptr) {
     *payload = *zbytes = 0;
     *groups_done = 0;
     if (ng == 0) return true;
@@ -108,7 +109,7 @@ class DeviceWriter {
     std::vector<uint32_t> nhost(nchunk, 0);
     auto tnow = [] { return std::chrono::steady_clock::now(); };
     auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    double busy_gather = 0, busy_encode = 0, busy_write = 0;  // what each stage spent working (TBK_TIMING: which one paces the pipeline)
+    double busy_gather = 0, busy_encode = 0, busy_write = 0, busy_pass1 = 0;  // what each stage spent working (TBK_TIMING: which one paces the pipeline)
     std::thread enc([&]() {
       for (uint32_t k = 0; k < nchunk; ++k) {
         if (!wait_state(k, 1)) return;
@@ -168,15 +169,29 @@ class DeviceWriter {
         *a = g0 + (uint32_t)((uint64_t)nc * (uint32_t)t / (uint32_t)T);
         *b = g0 + (uint32_t)((uint64_t)nc * ((uint32_t)t + 1) / (uint32_t)T);
       };
+      // (the records lie all over the inflated inputs: host_prefetch(g, 0 / 1) asks for g's index entry / first line a few groups ahead,
+      // and the second pass copies from what the first one found instead of looking every record up again)
+      s.view.resize(nc);
       parallel(T, [&](int t) {
         uint32_t a, b;
         slice(t, &a, &b);
         uint64_t by = 0;
         uint32_t cn = 0;
-        for (uint32_t g = a; g < b; ++g)
-          if (rep[g] >= n_dev) by += 4 + (uint64_t)host_record(g).len, ++cn;
+        constexpr uint32_t kAhead0 = 24, kAhead1 = 10;
+        for (uint32_t g = a; g < b; ++g) {
+          if (host_prefetch) {
+            if (g + kAhead0 < b && rep[g + kAhead0] >= n_dev) host_prefetch(g + kAhead0, 0);
+            if (g + kAhead1 < b && rep[g + kAhead1] >= n_dev) host_prefetch(g + kAhead1, 1);
+          }
+          if (rep[g] >= n_dev) {
+            const tbh::RecView v = host_record(g);
+            s.view[g - g0] = v;
+            by += 4 + (uint64_t)v.len, ++cn;
+          }
+        }
         sl_bytes[(size_t)t + 1] = by, sl_cnt[(size_t)t + 1] = cn;
       });
+      busy_pass1 += tms(g_0, tnow());
       for (int t = 0; t < T; ++t) sl_bytes[(size_t)t + 1] += sl_bytes[(size_t)t], sl_cnt[(size_t)t + 1] += sl_cnt[(size_t)t];
       const uint64_t total = sl_bytes[(size_t)T];
       nhost[k] = sl_cnt[(size_t)T];
@@ -196,7 +211,8 @@ class DeviceWriter {
             s.slot[g - g0] = 0;
             continue;
           }
-          const tbh::RecView v = host_record(g);
+          const tbh::RecView v = s.view[g - g0];
+          if (g + 6 < b) __builtin_prefetch(s.view[g + 6 - g0].p);
           s.slot[g - g0] = c;
           s.off[c++] = o;
           memcpy(s.blob + o, &v.len, 4);
@@ -211,7 +227,7 @@ class DeviceWriter {
     enc.join();
     wr.join();
     if (getenv("TBK_TIMING"))
-      fprintf(stderr, "device writer stages busy ms: gather %.1f | encode %.1f | write %.1f (%u chunks)\n", busy_gather, busy_encode, busy_write, nchunk);
+      fprintf(stderr, "device writer stages busy ms: gather %.1f (its first pass %.1f) | encode %.1f | write %.1f (%u chunks)\n", busy_gather, busy_pass1, busy_encode, busy_write, nchunk);
     if (fail == 2) GError("Error: encoding the output on the GPU failed: %s\n", fail_msg.c_str());
     const uint32_t kdone = fail ? fail_at : nchunk;  // (the threads are gone: plain reads)
     for (uint32_t k = 0; k < kdone; ++k) *payload += psz[k], *zbytes += zsz[k];
@@ -231,6 +247,7 @@ class DeviceWriter {
     size_t z_cap = 0;
     std::vector<uint64_t> off;
     std::vector<uint32_t> slot;
+    std::vector<tbh::RecView> view;  // the chunk's host records as the gather's first pass found them
   };
   bool grow(uint8_t*& p, size_t& cap, size_t want) {
     if (want <= cap) return true;

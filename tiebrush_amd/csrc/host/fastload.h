@@ -5,6 +5,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -52,6 +53,17 @@ struct FastTile {
   tbk_soa_in view() const;
   // the raw record (without its block_size field) behind tile index g
   const uint8_t* record(uint32_t g, uint32_t* len) const;
+  // A caller that walks many records in no memory order (the output side: representatives in coordinate order, from every input) hides
+  // the two dependent misses of record() by asking ahead: the index entry of g a few records early, then — the entry there — the record's
+  // first line.
+  void prefetch_index(uint32_t g) const {
+    const size_t f = (size_t)(std::upper_bound(file_off.begin(), file_off.end(), g) - file_off.begin()) - 1;
+    __builtin_prefetch(in[f].rec_off + (g - file_off[f]));
+  }
+  void prefetch_record(uint32_t g) const {
+    const size_t f = (size_t)(std::upper_bound(file_off.begin(), file_off.end(), g) - file_off.begin()) - 1;
+    __builtin_prefetch(in[f].data + in[f].rec_off[g - file_off[f]]);
+  }
 };
 
 // Reads paths[f] (BGZF-compressed BAM each) with `threads` workers.  false + err on malformed input; *fits = false (and true

@@ -270,11 +270,10 @@ int main(int argc, char* argv[]) {
   bool ctx_created = false, ctx_warming = false;  // (under ctx_m)
   std::atomic<bool> ctx_urgent{false};
   bool ctx_warm = false;
-  auto warm_ctx = [&]() {
-    if (ctx_warm || !api_ok || rc != 0 || getenv("TBK_NO_WARMUP")) return;
-    ctx_warm = true;
-    // one tiny collapse: the first launch maps the code objects of the library onto the device and the first call sizes the
-    // context's buffers — tens of milliseconds that belong beside the inflate, not behind it
+  // What a first call pays beyond its kernels, paid ahead: (a) for the PROCESS — the library's code objects mapped onto the device by a
+  // first launch, the copy engines' first use — with one tiny collapse and tbk_warmup on whatever context `c` is; (b) for the context
+  // that will run the real call — its second queue, its list machines' first dispatch, its staging buffer: tbk_warmup(ctx).
+  auto warm_process = [&](tbk_ctx* c) {
     // (65 inputs of one record each: more than 64 inputs take the window path, whose kernels — the larger part of the library's
     // device code — would otherwise be mapped by the first real collapse)
     constexpr uint32_t WK = 65;
@@ -299,10 +298,13 @@ int main(int argc, char* argv[]) {
     wo.cap_groups = WK;
     wo.rep = wrep, wo.yc = wyc, wo.yx = wyx, wo.yd = wyd;
     tbk_collapse_opts wopt = opt;
-    (void)api.collapse_tile(ctx, &wopt, &w, &wo);
-    // the YD stage's second queue and the first dispatch of its list machines, the copy engines, the results' staging buffer: 15-40 ms
-    // of a first call otherwise
-    if (!getenv("TBK_NO_WARMUP2")) (void)api.warmup(ctx);
+    (void)api.collapse_tile(c, &wopt, &w, &wo);
+    if (c != ctx && !getenv("TBK_NO_WARMUP2")) (void)api.warmup(c);  // (the engines; ctx gets its own call below)
+  };
+  auto warm_own = [&]() {
+    if (ctx_warm || !api_ok || rc != 0 || getenv("TBK_NO_WARMUP") || getenv("TBK_NO_WARMUP2")) return;
+    ctx_warm = true;
+    (void)api.warmup(ctx);
   };
   std::thread ctx_thread([&]() {
     api_ok = api.load();
@@ -320,13 +322,22 @@ int main(int argc, char* argv[]) {
       ctx_warming = warm_here;
     }
     ctx_cv.notify_all();
+    const bool can_warm = api_ok && rc == 0 && !getenv("TBK_NO_WARMUP");
     if (warm_here) {
-      warm_ctx();
+      if (can_warm) warm_process(ctx), warm_own();
       {
         std::lock_guard<std::mutex> lk(ctx_m);
         ctx_warming = false;
       }
       ctx_cv.notify_all();
+    } else if (can_warm) {
+      // the context is in use already (the hybrid path's device decode): the process-wide part on a context of this thread's own,
+      // beside that decode; the decode thread does the context's part when its call has returned
+      tbk_ctx* wc = nullptr;
+      if (api.create(dev, &wc) == 0) {
+        warm_process(wc);
+        api.destroy(wc);
+      }
     }
   });
   bool ctx_ready = false;
@@ -465,7 +476,8 @@ int main(int argc, char* argv[]) {
     };
     // the same on the device (devwriter.h): tags, framing and BGZF deflate as kernels, the host only gathers the records it decoded
     // itself and appends the finished members.  false: the host writer above takes the groups from dev_groups_done on.
-    auto write_groups_device = [&](uint32_t ng, uint32_t n_dev, const std::function<tbh::RecView(uint32_t)>& host_record) {
+    auto write_groups_device = [&](uint32_t ng, uint32_t n_dev, const std::function<tbh::RecView(uint32_t)>& host_record,
+                                   const std::function<void(uint32_t, int)>& host_prefetch = nullptr) {
       if (!dev_writer || outfile.level() == 0) return false;
       need_ctx();
       if (!dw) return false;
@@ -473,7 +485,7 @@ int main(int argc, char* argv[]) {
       uint64_t pb = 0, zb = 0;
       std::string why;
       uint32_t done = 0;
-      const bool ok = dw->write(ctx, outfile, ng, rep.data(), results_kept ? nullptr : yc.data(), yx.data(), yd.data(), n_dev, host_record, &pb, &zb, why, &done);
+      const bool ok = dw->write(ctx, outfile, ng, rep.data(), results_kept ? nullptr : yc.data(), yx.data(), yd.data(), n_dev, host_record, &pb, &zb, why, &done, host_prefetch);
       if (!ok && timing) fprintf(stderr, "device writer stopped after %u of %u groups (%s): host writer\n", done, ng, why.c_str());
       ms_dev_write += tms(a, tnow()), dev_payload += pb, dev_z += zb;
       dev_groups_done = ok ? 0 : done;
@@ -520,16 +532,18 @@ int main(int argc, char* argv[]) {
       if (eligible && !(hy && atoi(hy) != 0) && total < ((uint64_t)768 << 20)) eligible = false;
       if (eligible) {
         // The device's share of the compressed bytes: both sides should end together.  The device starts late — the HIP runtime takes
-        // ~ 0.25 s to come up, the cores work alone meanwhile — and is then several times faster: with x of T bytes on the device,
+        // ~ 0.1 s to come up (t_ctx = 0.15: the helper thread's warm-up beside the decode and the context's own behind it cost the
+        // device's side another 0.05), the cores work alone meanwhile — and is then several times faster: with x of T bytes on the device,
         // t_ctx + x / R_dev = (T - x) / R_host.  Rates measured on an MI355X box with a 16-core quota (round 5's end-to-end legs, tools/e2e_leg.py): the
         // device side 4.7 GB/s of compressed BAM (upload, inflate, record index, SoA), a core 0.18 GB/s (inflate with the record index
-        // riding along, SoA).  1.8 GB of input: 49 %; 7.1 GB: 62 %.  TBK_HYBRID_SHARE (per cent) overrides.
+        // riding along, SoA).  1.8 GB of input: 54 % (17 of 32 files; measured round 6, five runs a share: 16 files 407 ms for the
+        // decode, 17 files 351-361, 18 files 374-382, 19 files 377-384); 7.1 GB: 63 %.  TBK_HYBRID_SHARE (per cent) overrides.
         const int host_threads = getenv("TBK_THREADS") ? nthreads : std::max(2, nthreads - 3);
         double share;
         if (getenv("TBK_HYBRID_SHARE")) {
           share = atof(getenv("TBK_HYBRID_SHARE")) / 100.0;
         } else {
-          const double T = (double)total / 1e9, r_dev = 4.7, r_host = 0.18 * host_threads, t_ctx = 0.2;
+          const double T = (double)total / 1e9, r_dev = 4.7, r_host = 0.18 * host_threads, t_ctx = 0.15;
           const double x = (T / r_host - t_ctx) / (1.0 / r_dev + 1.0 / r_host);
           share = std::min(0.9, std::max(0.2, x / T));
         }
@@ -583,7 +597,7 @@ int main(int argc, char* argv[]) {
             (void)api.reserve_tile(ctx, (uint64_t)((double)in_d.n_records * up), (uint64_t)((double)in_d.n_cigar_ops * up));
           }
           ms_ddec = tms(d1, tnow());
-          warm_ctx();  // (the helper thread left it to this one: need_ctx_now)
+          warm_own();  // (the helper thread left the context's own part to this one: need_ctx_now)
         });
         // the cores' share
         std::vector<std::string> ph(paths.begin() + (long)kd, paths.end());
@@ -643,11 +657,14 @@ int main(int argc, char* argv[]) {
           }
           bool wrote_dev = false;
           if (rc == 0) {
-            wrote_dev = write_groups_device(out.n_groups, n_d, [&](uint32_t g) {
-              tbh::RecView v;
-              v.p = ft.record(rep[g] - n_d, &v.len);
-              return v;
-            });
+            wrote_dev = write_groups_device(
+                out.n_groups, n_d,
+                [&](uint32_t g) {
+                  tbh::RecView v;
+                  v.p = ft.record(rep[g] - n_d, &v.len);
+                  return v;
+                },
+                [&](uint32_t g, int stage) { stage == 0 ? ft.prefetch_index(rep[g] - n_d) : ft.prefetch_record(rep[g] - n_d); });
             t_rec = tnow();
           }
           if (rc == 0 && !wrote_dev) {  // the representatives the device decoded: their raw records come back from there
@@ -780,7 +797,8 @@ int main(int argc, char* argv[]) {
               v.p = ft.record(rep[g], &v.len);
               return v;
             };
-            if (!write_groups_device(out.n_groups, 0, get_record)) write_groups(out.n_groups);
+            if (!write_groups_device(out.n_groups, 0, get_record, [&](uint32_t g, int stage) { stage == 0 ? ft.prefetch_index(rep[g]) : ft.prefetch_record(rep[g]); }))
+              write_groups(out.n_groups);
             auto t3 = tnow();
             if (timing)
               fprintf(stderr, "host path ms: read %.1f | inflate %.1f | index %.1f | SoA %.1f | wait for the device %.1f | collapse (PCIe incl.) %.1f | tag+deflate+write %.1f\n",

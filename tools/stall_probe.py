@@ -30,7 +30,7 @@ def vm():
 files, reads, runs, seq = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 extra_env = dict(kv.split("=", 1) for kv in sys.argv[5:])
 d = tempfile.mkdtemp(prefix="tbk_stall_", dir="/tmp")
-tile = synth_dev.tile_to_host(synth_dev.make_tile_device(files, reads, "c2", device="cuda:0"))
+tile = synth_dev.tile_to_host(synth_dev.make_tile_device(files, reads, os.environ.get("STALL_PROFILE", "c2"), device="cuda:0"))
 paths = synth.write_bams_fast(tile, os.path.join(d, "in"), seq=bool(seq))
 del tile
 os.sync()
@@ -42,7 +42,7 @@ for r in range(runs):
     time.sleep(pause)
     a = vm()
     t = time.time()
-    p = subprocess.run([os.path.join(ROOT, "tiebrush_amd", "_build", "tiebrush"), "-o", out] + paths, capture_output=True, text=True,
+    p = subprocess.run([os.path.join(ROOT, "tiebrush_amd", "_build", "tiebrush"), "-o", out] + os.environ.get("STALL_FLAGS", "").split() + paths, capture_output=True, text=True,
                        env=dict(os.environ, TBK_TIMING="1", TBK_EXIT_TIMING="1", **extra_env))
     t_end = time.time()
     dt = t_end - t
