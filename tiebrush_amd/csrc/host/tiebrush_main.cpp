@@ -309,10 +309,7 @@ int main(int argc, char* argv[]) {
   std::thread ctx_thread([&]() {
     api_ok = api.load();
     if (api_ok) rc = api.create(dev, &ctx);
-    if (api_ok && rc == 0 && dev_writer) {
-      dw = new DeviceWriter(api, tbh::cpu_budget());
-      (void)dw->reserve();  // (page-locking the staging buffers: tens of milliseconds, beside the decode)
-    }
+    if (api_ok && rc == 0 && dev_writer) dw = new DeviceWriter(api, tbh::cpu_budget());
     ms_ctx_ready = tms(t_start, tnow());
     bool warm_here;
     {
@@ -322,6 +319,9 @@ int main(int argc, char* argv[]) {
       ctx_warming = warm_here;
     }
     ctx_cv.notify_all();
+    // (page-locking the writer's staging buffers: ~ 12 ms, beside the decode — and behind the hand-over: a decode that waits for the
+    // context does not wait for this)
+    if (dw) (void)dw->reserve();
     const bool can_warm = api_ok && rc == 0 && !getenv("TBK_NO_WARMUP");
     if (warm_here) {
       if (can_warm) warm_process(ctx), warm_own();
@@ -1108,7 +1108,7 @@ int main(int argc, char* argv[]) {
   // caller waits (measured: 0.17 s for 2.7 GB)
   {
     auto a = tnow();
-    tbh::big_release_all(nthreads);
+    if (!getenv("TBK_NO_RELEASE")) tbh::big_release_all(nthreads);  // (TBK_NO_RELEASE: diagnosis — what the exit costs without it)
     if (timing) fprintf(stderr, "released the large buffers in %.1f ms\n", tms(a, tnow()));
   }
   if (getenv("TBK_EXIT_TIMING")) {  // (diagnosis: what is left of the process exit)

@@ -43,7 +43,7 @@ for r in range(runs):
     a = vm()
     t = time.time()
     p = subprocess.run([os.path.join(ROOT, "tiebrush_amd", "_build", "tiebrush"), "-o", out] + os.environ.get("STALL_FLAGS", "").split() + paths, capture_output=True, text=True,
-                       env=dict(os.environ, TBK_TIMING="1", TBK_EXIT_TIMING="1", **extra_env))
+                       env={**os.environ, "TBK_TIMING": "1", "TBK_EXIT_TIMING": "1", **extra_env})
     t_end = time.time()
     dt = t_end - t
     ex = [l for l in p.stderr.split("\n") if l.startswith("exit timing")]
