@@ -311,6 +311,10 @@ typedef struct tbk_enc_in {
   const uint32_t* host_slot; /* HOST [n]: for a group whose rep >= n_dev, its record's index in host_off (others ignored) */
   uint32_t first;            /* (ABI version 8) mem == TBK_MEM_KEPT: the records are groups [first, first + n) of the kept results; rep /
                                 yc / yx / yd are not read (a caller that gathers host records still needs its own copy of rep)  */
+  tbk_ctx* from;             /* (ABI version 8) NULL, or ANOTHER context of the same device whose kept results (TBK_MEM_KEPT) and decoded
+                                tile (n_dev) this call reads — nothing of `from` is written, so two contexts may encode different
+                                chunks of one collapse side by side (one's copies under the other's deflate) while `from` itself
+                                encodes too; the caller keeps `from` from collapsing / decoding / releasing meanwhile             */
 } tbk_enc_in;
 /* Tag, frame (block_size) and BGZF-deflate the n records on the device: `out` (HOST) receives a run of whole members — every member
  * begins with a record, as htslib cuts them — that a BAM writer appends behind its header; the EOF member is the caller's.

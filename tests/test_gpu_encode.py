@@ -213,6 +213,18 @@ def test_kept_results_feed_the_encoder(ctx, case):
     want_mid, _ = ctx.bam_encode(rep[a:b], yc[a:b], yx[a:b], yd[a:b], n_dev=n_dev)
     got_mid, _ = ctx.bam_encode(rep[a:b], None, None, None, n_dev=n_dev, kept_first=a)
     assert got_mid == want_mid
+    # another context reads them (and the decoded tile) where they lie: tbk_enc_in.from — the command line's second encode thread
+    from tiebrush_amd import api
+    ctx2 = api.Context(0)
+    try:
+        got2, _ = ctx2.bam_encode(rep[a:b], None, None, None, n_dev=n_dev, kept_first=a, from_ctx=ctx)
+        assert got2 == want_mid
+        got3, _ = ctx2.bam_encode(rep, yc, yx, yd, n_dev=n_dev, from_ctx=ctx)        # (the caller's arrays, the other context's tile)
+        assert got3 == want
+        with pytest.raises(TbkError):                                               # ... which ctx2 itself does not have
+            ctx2.bam_encode(rep, yc, yx, yd, n_dev=n_dev)
+    finally:
+        ctx2.close()
     # host records beside kept tag values (the command line's whole-input host path: rep on the host, the tags on the device)
     blob, off = ctx.bam_records(rep)
     recs = {i: blob[int(off[i]) + 4:int(off[i + 1])] for i in range(m)}

@@ -75,7 +75,7 @@ class SampleOut(C.Structure):
 
 class EncIn(C.Structure):
     _fields_ = [("mem", C.c_int32), ("n", C.c_uint32), ("rep", _P), ("yc", _P), ("yx", _P), ("yd", _P), ("n_dev", C.c_uint32), ("n_host", C.c_uint32),
-                ("host_blob", _P), ("host_off", _P), ("host_slot", _P), ("first", C.c_uint32)]
+                ("host_blob", _P), ("host_off", _P), ("host_slot", _P), ("first", C.c_uint32), ("from_ctx", _P)]
 
 
 class KernelTime(C.Structure):

@@ -372,10 +372,11 @@ class Context:
                     "tbk_kept_results")
         return (None if tags_only else rep), yc, yx, yd
 
-    def bam_encode(self, rep, yc, yx, yd, n_dev=0, host_records=None, kept_first=None):
+    def bam_encode(self, rep, yc, yx, yd, n_dev=0, host_records=None, kept_first=None, from_ctx=None):
         """tbk_bam_encode: the output records of a collapse -> (run of BGZF members, payload bytes).  rep < n_dev: records of the tile
         bam_decode left on this context; the others come from host_records = {group index: raw record bytes WITHOUT block_size}.
-        kept_first: the len(rep) groups from that index on of the results the context kept (keep_results): rep / yc / yx / yd are not handed over"""
+        kept_first: the len(rep) groups from that index on of the results the context kept (keep_results): rep / yc / yx / yd are not handed over;
+        from_ctx: the Context that holds them (and the decoded tile), when it is not this one"""
         rep = np.ascontiguousarray(rep, dtype=np.uint32)
         n = len(rep)
         e = _lib.EncIn()
@@ -386,6 +387,8 @@ class Context:
             e.mem, e.n, e.rep, e.yc, e.yx, e.yd, e.n_dev = _lib.TBK_MEM_HOST, n, rep.ctypes.data, yc.ctypes.data, yx.ctypes.data, yd.ctypes.data, n_dev
         else:
             e.mem, e.n, e.n_dev, e.first = _lib.TBK_MEM_KEPT, n, n_dev, int(kept_first)
+        if from_ctx is not None:                  # another Context whose kept results / decoded tile this call reads (tbk_enc_in.from)
+            e.from_ctx = from_ctx.h
         keep = []
         if host_records:
             slot = np.zeros(n, dtype=np.uint32)

@@ -1386,13 +1386,9 @@ extern "C" int tbk_bam_decode(tbk_ctx* ctx, uint32_t n_files, const uint8_t* con
   tile->qname_off = qn_off;
   tile->qname = qn;
   tbk_prof_end_call(ctx);
-  // the arena as the collapse of this tile will want it (tbk_collapse_tile's hint for the window path and its deferred YD stage):
-  // growing it is a free and an allocation of gigabytes, ~ 0.1 s that belong here — beside the host's share of a hybrid decode,
-  // or at least not inside the collapse call — and everything this call kept in the arena is dead
-  // (best effort, and after the decode's own status is settled: a reserve that does not fit must not turn a good decode into an error)
-  const int rc_decode = tbk_check_launch(ctx, "bam_decode");
-  if (rc_decode == 0) (void)tbk_reserve_tile(ctx, n, ncig);
-  return rc_decode;
+  // (the arena for the collapse of this tile is the caller's to reserve — tbk_reserve_tile —: it knows whether the tile will be joined
+  // with a host part first, and an allocation of gigabytes is now and then 0.1 s of the driver's time: one, not two)
+  return tbk_check_launch(ctx, "bam_decode");
 }
 
 namespace {

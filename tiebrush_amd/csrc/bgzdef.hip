@@ -1075,8 +1075,10 @@ extern "C" int tbk_bam_encode(tbk_ctx* ctx, const tbk_enc_in* in, uint8_t* out, 
   if (payload_bytes) *payload_bytes = 0;
   const uint32_t n = in->n;
   if (n == 0) return 0;
-  const bool kept = in->mem == TBK_MEM_KEPT;  // the columns of the context's last collapse (tbk_collapse_opts.keep_results), read where they lie
-  if (kept ? (!ctx->kept || (uint64_t)in->first + n > ctx->kept_n) : (!in->rep || !in->yc || !in->yx || !in->yd)) return TBK_EINVAL;
+  const bool kept = in->mem == TBK_MEM_KEPT;  // the columns of a context's last collapse (tbk_collapse_opts.keep_results), read where they lie
+  tbk_ctx* const src = in->from ? in->from : ctx;  // whose kept results / decoded tile (read only; the same device)
+  if (src->device != ctx->device) return TBK_EINVAL;
+  if (kept ? (!src->kept || (uint64_t)in->first + n > src->kept_n) : (!in->rep || !in->yc || !in->yx || !in->yd)) return TBK_EINVAL;
   if (in->mem != TBK_MEM_HOST && in->mem != TBK_MEM_DEVICE && !kept) return TBK_EINVAL;
   if (in->n_host && (!in->host_blob || !in->host_off || !in->host_slot)) return TBK_EINVAL;
   TBK_HIP(hipSetDevice(ctx->device));
@@ -1084,7 +1086,7 @@ extern "C" int tbk_bam_encode(tbk_ctx* ctx, const tbk_enc_in* in, uint8_t* out, 
   memset(&S, 0, sizeof(S));
   S.n_dev = in->n_dev;
   if (in->n_dev) {
-    if (!tbk_bam_dev_records(ctx, &S.dev_inf, &S.dev_rec, &S.n_dev) || S.n_dev < in->n_dev) return TBK_EINVAL;
+    if (!tbk_bam_dev_records(src, &S.dev_inf, &S.dev_rec, &S.n_dev) || S.n_dev < in->n_dev) return TBK_EINVAL;
     S.n_dev = in->n_dev;
   }
   tbk_prof_begin_call(ctx);
@@ -1114,7 +1116,7 @@ extern "C" int tbk_bam_encode(tbk_ctx* ctx, const tbk_enc_in* in, uint8_t* out, 
   uint32_t* d_olen2 = (uint32_t*)take(((size_t)n + 1) * 4);
   uint64_t* d_ooff = (uint64_t*)take(((size_t)n + 1) * 8);
   if (kept) {
-    d_rep = ctx->kept_rep + in->first, d_yd = ctx->kept_yd + in->first, d_yc = ctx->kept_yc + in->first, d_yx = ctx->kept_yx + in->first;
+    d_rep = src->kept_rep + in->first, d_yd = src->kept_yd + in->first, d_yc = src->kept_yc + in->first, d_yx = src->kept_yx + in->first;
   } else {
     const hipMemcpyKind kind = in->mem == TBK_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     TBK_HIP(hipMemcpyAsync((void*)d_rep, in->rep, (size_t)n * 4, kind, st));

@@ -5,7 +5,9 @@
 //   gather   the representatives the HOST decoded are copied — by every core — into a pinned staging buffer (records the device decoded
 //            are read where they lie: nothing to gather);
 //   encode   one tbk_bam_encode per chunk: H2D of the staged records and the chunk's YC / YX / YD, tags, member cuts, deflate, D2H of the
-//            finished BGZF members into a pinned buffer (a thread of its own: the context is busy for the length of the call);
+//            finished BGZF members into a pinned buffer (a thread of its own: the context is busy for the length of the call; with a
+//            second context — set_second — two threads, the even chunks on one and the odd ones on the other: a chunk's copies run
+//            under the other chunk's deflate, tbk_enc_in.from);
 //   write    the members appended to the output file (a thread of its own: the write of chunk k runs beside the encode of k + 1).
 // Three slots of buffers, so every stage works on a chunk of its own.  The record stream is the host writer's byte for byte
 // (tests/test_gpu_cli.py); the members differ (another deflate parse, members cut at record boundaries).
@@ -30,12 +32,13 @@
 class DeviceWriter {
  public:
   static constexpr uint32_t kChunkGroups = 256u << 10;  // ~ 64 MB of records with SEQ / QUAL per chunk (512 K: the encode stage 10 % faster, the pinned staging twice as dear — no gain)
-  static constexpr int kSlots = 3;
+  static constexpr int kSlots = 3;  // (a fourth — gather, two encodes, write: a chunk each — measured no faster than three)
 
   DeviceWriter(TbkApi& api, int nthreads) : api_(api), nt_(nthreads < 1 ? 1 : nthreads) {
+    if (const char* e = getenv("TBK_DW_SLOTS")) nslots_ = std::max(2, std::min((int)kSlots, atoi(e)));
     if (const char* e = getenv("TBK_DW_CHUNK_GROUPS")) {  // test hook: small chunks, so that a small input has a "later chunk"
       const long v = atol(e);
-      if (v >= 64 && v <= (long)kChunkGroups) chunk_ = (uint32_t)v;
+      if (v >= 64 && v <= (long)kChunkGroups) chunk_ = (uint32_t)v, chunk_forced_ = true;
     }
   }
   ~DeviceWriter() {
@@ -44,10 +47,13 @@ class DeviceWriter {
       if (s.z) api_.host_free(s.z);
     }
   }
+  // a second context (same device) for a second encode thread; nullptr: one encoder
+  void set_second(tbk_ctx* c) { ctx2_ = c; }
   // pinned staging, sized for a chunk of typical records; grown when a chunk needs more.  Page-locking hundreds of megabytes takes tens
   // of milliseconds: the command line calls this on its helper thread while the inputs are decoded.
   bool reserve(size_t blob_bytes = (size_t)kChunkGroups * 272, size_t z_bytes = (size_t)kChunkGroups * 112) {
-    for (auto& s : slot_) {
+    for (int i = 0; i < nslots_; ++i) {
+      Slot& s = slot_[i];
       if (!grow(s.blob, s.blob_cap, blob_bytes) || !grow(s.z, s.z_cap, z_bytes)) return false;
     }
     return true;
@@ -70,7 +76,32 @@ class DeviceWriter {
       why = "pinned staging memory";
       return false;
     }
-    const uint32_t kChunkGroups = chunk_;  // (shadows the constant: the test hook's chunk size)
+    // The encoder deflates 512 members at a time (bgz_deflate_k: two workgroups a CU, 256 CUs, each taking the next member as it comes
+    // free): a chunk of 1047 members — 256 K records of ~ 260 bytes — runs THREE rounds for what two nearly hold (4.1 ms instead of 2.8
+    // every chunk).  The chunk is cut a little below a whole number of rounds, by the records' mean length in a sample of the groups
+    // (the host's representatives; the device's look like them); the slots' size is the cap, the test hook's size is taken as it is.
+    uint32_t kChunkGroups = chunk_;  // (shadows the constant)
+    if (!chunk_forced_ && ng > 65536) {
+      uint64_t bytes = 0, cnt = 0;
+      uint32_t longest = 0;
+      const uint32_t step = std::max<uint32_t>(1, ng / 2048);
+      for (uint32_t g = 0; g < ng; g += step)
+        if (rep[g] >= n_dev) {
+          const uint32_t l = host_record(g).len;
+          bytes += l, ++cnt, longest = std::max(longest, l);
+        }
+      if (cnt >= 64 && longest + 1024 < 0xff00u) {
+        const double tagged = (double)bytes / (double)cnt + 4 + 16;              // block_size, YC:f + YX (+ YD)
+        const double member = (double)(0xff00u - longest - 256);                 // what a member holds (bgzdef.hip: B)
+        for (int rounds = 4; rounds >= 1; --rounds) {                              // the most rounds the slots hold
+          const double groups = 0.97 * 512.0 * rounds * member / tagged;
+          if (groups <= (double)chunk_) {
+            kChunkGroups = std::max<uint32_t>(65536, (uint32_t)groups & ~1023u);
+            break;
+          }
+        }
+      }
+    }
     const uint32_t nchunk = (ng + kChunkGroups - 1) / kChunkGroups;
     // stage hand-offs: state[k] counts how far chunk k has come (1 gathered, 2 encoded, 3 written)
     std::mutex m;
@@ -110,10 +141,13 @@ class DeviceWriter {
     auto tnow = [] { return std::chrono::steady_clock::now(); };
     auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     double busy_gather = 0, busy_encode = 0, busy_write = 0, busy_pass1 = 0;  // what each stage spent working (TBK_TIMING: which one paces the pipeline)
-    std::thread enc([&]() {
-      for (uint32_t k = 0; k < nchunk; ++k) {
+    const uint32_t n_enc = ctx2_ && nchunk > 1 && !getenv("TBK_DW_ONE_ENCODER") ? 2u : 1u;
+    std::mutex busy_m;
+    auto encoder = [&](uint32_t e) {
+      tbk_ctx* const ectx = e == 0 ? ctx : ctx2_;
+      for (uint32_t k = e; k < nchunk; k += n_enc) {
         if (!wait_state(k, 1)) return;
-        Slot& s = slot_[k % kSlots];
+        Slot& s = slot_[k % (uint32_t)nslots_];
         const uint32_t g0 = k * kChunkGroups, g1 = std::min(ng, g0 + kChunkGroups);
         tbk_enc_in in;
         memset(&in, 0, sizeof(in));
@@ -125,29 +159,36 @@ class DeviceWriter {
           in.mem = TBK_MEM_KEPT;
           in.first = g0;
         }
+        if (ectx != ctx) in.from = ctx;  // (the kept results and the decoded tile live on the first context)
         in.n_dev = n_dev;
         in.n_host = nhost[k];
         in.host_blob = s.blob, in.host_off = s.off.data(), in.host_slot = s.slot.data();
         uint64_t zb = 0, pb = 0;
         const auto e0 = tnow();
-        int rc = (force_refuse && (uint32_t)atol(force_refuse) == k) ? TBK_EUNSUPPORTED : api_.bam_encode(ctx, &in, s.z, s.z_cap, &zb, &pb);
+        int rc = (force_refuse && (uint32_t)atol(force_refuse) == k) ? TBK_EUNSUPPORTED : api_.bam_encode(ectx, &in, s.z, s.z_cap, &zb, &pb);
         if (rc == TBK_E2BIG && zb > s.z_cap) {  // (the members of this chunk need a larger buffer: the call said how large)
           if (!grow(s.z, s.z_cap, zb + zb / 8)) rc = TBK_ENOMEM;
-          else rc = api_.bam_encode(ctx, &in, s.z, s.z_cap, &zb, &pb);
+          else rc = api_.bam_encode(ectx, &in, s.z, s.z_cap, &zb, &pb);
         }
         if (rc != 0) {
-          set_fail(k, (rc == TBK_EUNSUPPORTED || rc == TBK_ENOMEM) ? 1 : 2, std::string(api_.strerror_(rc)) + " (" + api_.last_error(ctx) + ")");
+          set_fail(k, (rc == TBK_EUNSUPPORTED || rc == TBK_ENOMEM) ? 1 : 2, std::string(api_.strerror_(rc)) + " (" + api_.last_error(ectx) + ")");
           return;
         }
         zsz[k] = zb, psz[k] = pb;
-        busy_encode += tms(e0, tnow());
+        {
+          std::lock_guard<std::mutex> lk(busy_m);
+          busy_encode += tms(e0, tnow());
+        }
         set_state(k, 2);
       }
-    });
+    };
+    std::thread enc([&]() { encoder(0); });
+    std::thread enc2;
+    if (n_enc > 1) enc2 = std::thread([&]() { encoder(1); });
     std::thread wr([&]() {
       for (uint32_t k = 0; k < nchunk; ++k) {
         if (!wait_state(k, 2)) return;
-        Slot& s = slot_[k % kSlots];
+        Slot& s = slot_[k % (uint32_t)nslots_];
         const auto w0 = tnow();
         out.write_members(s.z, (size_t)zsz[k]);
         busy_write += tms(w0, tnow());
@@ -156,8 +197,8 @@ class DeviceWriter {
     });
     // the gather, on this thread and its workers
     for (uint32_t k = 0; k < nchunk && !failed(); ++k) {
-      if (k >= (uint32_t)kSlots && !wait_state(k - kSlots, 3)) break;  // the slot's previous chunk has left the building
-      Slot& s = slot_[k % kSlots];
+      if (k >= (uint32_t)nslots_ && !wait_state(k - (uint32_t)nslots_, 3)) break;  // the slot's previous chunk has left the building
+      Slot& s = slot_[k % (uint32_t)nslots_];
       const uint32_t g0 = k * kChunkGroups, g1 = std::min(ng, g0 + kChunkGroups), nc = g1 - g0;
       const auto g_0 = tnow();
       s.slot.resize(nc);
@@ -225,9 +266,11 @@ class DeviceWriter {
       set_state(k, 1);
     }
     enc.join();
+    if (enc2.joinable()) enc2.join();
     wr.join();
     if (getenv("TBK_TIMING"))
-      fprintf(stderr, "device writer stages busy ms: gather %.1f (its first pass %.1f) | encode %.1f | write %.1f (%u chunks)\n", busy_gather, busy_pass1, busy_encode, busy_write, nchunk);
+      fprintf(stderr, "device writer stages busy ms: gather %.1f (its first pass %.1f) | encode %.1f on %u thread%s | write %.1f (%u chunks of %u groups)\n", busy_gather, busy_pass1,
+              busy_encode, n_enc, n_enc > 1 ? "s" : "", busy_write, nchunk, kChunkGroups);
     if (fail == 2) GError("Error: encoding the output on the GPU failed: %s\n", fail_msg.c_str());
     const uint32_t kdone = fail ? fail_at : nchunk;  // (the threads are gone: plain reads)
     for (uint32_t k = 0; k < kdone; ++k) *payload += psz[k], *zbytes += zsz[k];
@@ -270,7 +313,10 @@ class DeviceWriter {
     for (auto& x : th) x.join();
   }
   TbkApi& api_;
+  tbk_ctx* ctx2_ = nullptr;
   int nt_;
   uint32_t chunk_ = kChunkGroups;
+  bool chunk_forced_ = false;
+  int nslots_ = kSlots;
   Slot slot_[kSlots];
 };

@@ -322,6 +322,11 @@ int main(int argc, char* argv[]) {
     // (page-locking the writer's staging buffers: ~ 12 ms, beside the decode — and behind the hand-over: a decode that waits for the
     // context does not wait for this)
     if (dw) (void)dw->reserve();
+    // ... and a second context for the writer's second encode thread (its queue: ~ 10 ms to create)
+    if (dw && !getenv("TBK_DW_ONE_ENCODER")) {
+      tbk_ctx* c2 = nullptr;
+      if (api.create(dev, &c2) == 0) dw->set_second(c2);
+    }
     const bool can_warm = api_ok && rc == 0 && !getenv("TBK_NO_WARMUP");
     if (warm_here) {
       if (can_warm) warm_process(ctx), warm_own();
@@ -593,7 +598,10 @@ int main(int argc, char* argv[]) {
           }
           for (auto& c : comp) c.unmap();
           if (rc_d == 0 && acc > 0) {  // the arena for the joined tile, sized while the cores are still decoding their share
-            const double up = (double)total / (double)acc * 1.05;
+            // (tbk_reserve_tile sizes for the window path AND a deferred YD stage that borrows its range of the arena: 165 bytes a record.
+            // This call defers nothing — 84 bytes a record and the CIGAR words —: six tenths of the tile's size asks for what it takes.
+            // An allocation of gigabytes is now and then 20-25 ms per GB of the driver's time)
+            const double up = (double)total / (double)acc * 1.05 * 0.6;
             (void)api.reserve_tile(ctx, (uint64_t)((double)in_d.n_records * up), (uint64_t)((double)in_d.n_cigar_ops * up));
           }
           ms_ddec = tms(d1, tnow());

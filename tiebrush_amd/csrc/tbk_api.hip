@@ -108,9 +108,31 @@ int tbk_ws_reserve(tbk_ctx* ctx, size_t bytes) { return ws_begin_call(ctx, bytes
 // the collapse that follows sizes (or spills) by its own rules.  Nothing is resized while a deferred YD stage or a borrowed range pins
 // the arena.
 int tbk_ws_presize(tbk_ctx* ctx, size_t bytes) {
-  if (ctx->ws_borrowed || ctx->yd_pending || !ctx->ws_overflow.empty() || bytes <= ctx->ws_cap) return 0;
+  if (ctx->dbg.phases)
+    fprintf(stderr, "collapse phases: arena presize to %.2f GB asked (now %.2f GB; borrowed %d, YD pending %d, overflow chunks %zu)\n", bytes / 1e9, ctx->ws_cap / 1e9,
+            (int)ctx->ws_borrowed, (int)ctx->yd_pending, ctx->ws_overflow.size());
+  if (ctx->ws_borrowed || ctx->yd_pending) return 0;
+  // (overflow chunks are the previous call's, which has returned: they go now — ws_begin_call would free them at the next call anyway —
+  // and count towards what the arena has learnt it needs.  A call that spilled used to leave the reserve a no-op: the device decode of
+  // the hybrid path does, and the collapse behind it then sized the arena inside the call)
+  if (!ctx->ws_overflow.empty()) {
+    size_t tot = ctx->ws_cap;
+    for (auto& c : ctx->ws_overflow) {
+      tot += c.second;
+      (void)hipFree(c.first);
+    }
+    ctx->ws_overflow.clear();
+    ctx->ws_over_used = 0;
+    bytes = std::max(bytes, tot + tot / 8);
+  }
+  if (bytes <= ctx->ws_cap) return 0;
   char* bigger = nullptr;
-  if (hipMalloc((void**)&bigger, bytes) != hipSuccess) {
+  const auto a0 = std::chrono::steady_clock::now();
+  const hipError_t e = hipMalloc((void**)&bigger, bytes);
+  if (ctx->dbg.phases)
+    fprintf(stderr, "collapse phases: arena presize: hipMalloc %s in %.1f ms\n", e == hipSuccess ? "ok" : hipGetErrorString(e),
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a0).count());
+  if (e != hipSuccess) {
     (void)hipGetLastError();
     return 0;
   }

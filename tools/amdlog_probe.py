@@ -1,10 +1,11 @@
 """Diagnosis: HIP's own log (AMD_LOG_LEVEL=4) of the command line around the copy that brings the representatives back."""
-import os, subprocess, sys, tempfile
+import atexit, os, shutil, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tiebrush_amd import synth, synth_dev
 files, reads = int(sys.argv[1]), int(sys.argv[2])
 d = tempfile.mkdtemp(prefix="tbk_log_", dir="/tmp")
+atexit.register(shutil.rmtree, d, True)
 tile = synth_dev.tile_to_host(synth_dev.make_tile_device(files, reads, "c2", device="cuda:0"))
 paths = synth.write_bams_fast(tile, os.path.join(d, "in"), seq=False)
 del tile

@@ -1,6 +1,6 @@
 """Diagnosis: what the host's memory management does under a run of the command line whose library calls stall now and then
 (NUMA balancing, huge-page compaction: /proc/vmstat deltas per run beside the run's phase lines)."""
-import os, subprocess, sys, tempfile, time
+import atexit, os, shutil, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tiebrush_amd import synth, synth_dev
@@ -30,6 +30,7 @@ def vm():
 files, reads, runs, seq = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 extra_env = dict(kv.split("=", 1) for kv in sys.argv[5:])
 d = tempfile.mkdtemp(prefix="tbk_stall_", dir="/tmp")
+atexit.register(shutil.rmtree, d, True)
 tile = synth_dev.tile_to_host(synth_dev.make_tile_device(files, reads, os.environ.get("STALL_PROFILE", "c2"), device="cuda:0"))
 paths = synth.write_bams_fast(tile, os.path.join(d, "in"), seq=bool(seq))
 del tile
