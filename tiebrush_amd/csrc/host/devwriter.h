@@ -103,6 +103,15 @@ class DeviceWriter {
       }
     }
     const uint32_t nchunk = (ng + kChunkGroups - 1) / kChunkGroups;
+    Pool pool;
+    if (nt_ > 1 && ng >= 8192) {
+      pool.start(nt_ - 1);
+      pool_ = &pool;
+    }
+    struct PoolOff {
+      Pool** p;
+      ~PoolOff() { *p = nullptr; }
+    } pool_off{&pool_};
     // stage hand-offs: state[k] counts how far chunk k has come (1 gathered, 2 encoded, 3 written)
     std::mutex m;
     std::condition_variable cv;
@@ -301,16 +310,72 @@ class DeviceWriter {
     p = (uint8_t*)q, cap = want;
     return true;
   }
+  // The gather's workers live as long as the writer (two passes a chunk, tens of chunks: starting fifteen threads for each was 10-20 ms
+  // of a 50 ms stage).  parallel(T, f) runs f(0) .. f(T - 1), f(0) on the caller; T <= the pool's size + 1.
+  struct Pool {
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv_go, cv_done;
+    std::function<void(int)> job;
+    uint64_t gen = 0;
+    int want = 0, left = 0;
+    bool stop = false;
+    void start(int n) {
+      for (int i = 0; i < n; ++i)
+        th.emplace_back([this, i]() {
+          uint64_t seen = 0;
+          for (;;) {
+            std::function<void(int)> f;
+            {
+              std::unique_lock<std::mutex> lk(m);
+              cv_go.wait(lk, [&] { return stop || gen != seen; });
+              if (stop) return;
+              seen = gen;
+              if (i + 1 >= want) continue;  // (this round needs fewer workers)
+              f = job;
+            }
+            f(i + 1);
+            {
+              std::lock_guard<std::mutex> lk(m);
+              if (--left == 0) cv_done.notify_one();
+            }
+          }
+        });
+    }
+    void run(int T, const std::function<void(int)>& f) {
+      {
+        std::lock_guard<std::mutex> lk(m);
+        job = f, want = T, left = T - 1, ++gen;
+      }
+      cv_go.notify_all();
+      f(0);
+      std::unique_lock<std::mutex> lk(m);
+      cv_done.wait(lk, [&] { return left == 0; });
+    }
+    ~Pool() {
+      {
+        std::lock_guard<std::mutex> lk(m);
+        stop = true;
+      }
+      cv_go.notify_all();
+      for (auto& x : th) x.join();
+    }
+  };
+  Pool* pool_ = nullptr;
   template <class F>
   void parallel(int T, F f) {
-    if (T <= 1) {
+    if (T <= 1 || !pool_) {
+      if (T <= 1) {
+        f(0);
+        return;
+      }
+      std::vector<std::thread> th;
+      for (int t = 1; t < T; ++t) th.emplace_back([&f, t]() { f(t); });
       f(0);
+      for (auto& x : th) x.join();
       return;
     }
-    std::vector<std::thread> th;
-    for (int t = 1; t < T; ++t) th.emplace_back([&f, t]() { f(t); });
-    f(0);
-    for (auto& x : th) x.join();
+    pool_->run(T, f);
   }
   TbkApi& api_;
   tbk_ctx* ctx2_ = nullptr;
