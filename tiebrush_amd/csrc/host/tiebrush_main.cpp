@@ -1127,5 +1127,6 @@ int main(int argc, char* argv[]) {
     fprintf(stderr, "exit timing: tbk_destroy %.1f ms; _exit at %.3f\n", tms(a, tnow()), (double)ts.tv_sec + ts.tv_nsec * 1e-9);
     if (atoi(getenv("TBK_EXIT_TIMING")) > 2) return 0;  // (a plain return: what a profiler's exit handlers need to write their traces)
   }
+  if (const char* e = getenv("TBK_EXIT_SLEEP_MS")) usleep((useconds_t)atoi(e) * 1000);  // (diagnosis)
   _exit(0);  // the output is closed and flushed: skip the runtime's teardown of a process that is done (tens of ms of hipFree / unload)
 }
